@@ -1,0 +1,263 @@
+// TEST INFRASTRUCTURE -- not part of the product.
+//
+// Driver that runs the *real* reference CPU sweep (hguo/ftk headers, compiled where they
+// lie under /root/reference) and dumps what the parity suite needs:
+//   - the per-timestep input field exactly as the tracker API received it,
+//   - the quantisation factor in force at every sweep,
+//   - the discrete critical-point record stream (std::map order = sorted by element).
+//
+// It drives the tracker the way the reference's own callers do:
+//   python/pyftk.cpp:93-142 and include/ftk/filters/json_interface.hh:606-725
+//   (set_*_field_source / set_domain / initialize / push / advance_timestep / update_timestep).
+// It contains no restatement of the algorithm: everything numerical comes from
+// /root/reference/include.  Built only by oracle/Makefile into oracle/_ref/ (git-ignored).
+//
+// usage:
+//   ftk_ref_driver synthetic <name> <DW> <DH> <DD> <DT> <out.bin> [x0 x0 x0 dir dir dir] [nthreads]
+//   ftk_ref_driver file <in.bin> <out.bin> [nthreads]      (in.bin: see read_input())
+//   ftk_ref_driver time <in.bin> [nthreads]                (prints sweep seconds, no dump)
+//   ftk_ref_driver tables <out.txt>                         (dumps the unit-simplex tables)
+#include <cmath>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <string>
+#include <vector>
+#include <ftk/ndarray/synthetic.hh>
+#include <ftk/filters/critical_point_tracker_2d_regular.hh>
+#include <ftk/filters/critical_point_tracker_3d_regular.hh>
+
+struct input_t {
+  int nd = 2, nv = 1;            // nv = 1: scalar field; nv = nd: vector field
+  int D[3] = {1, 1, 1}, DT = 1;
+  std::vector<std::vector<double>> steps;  // DT arrays of nv*D0*D1*D2 doubles (component fastest)
+};
+
+template <class Base>
+struct probe : public Base {
+  probe(diy::mpi::communicator comm) : Base(comm), ftk::tracker(comm) {}
+  std::vector<uint64_t> factors;  // factor in force at each update_timestep()
+  std::vector<int> factor_steps;
+  double sweep_seconds = 0;
+  void update_timestep() override {
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    Base::update_timestep();
+    const auto t1 = std::chrono::high_resolution_clock::now();
+    sweep_seconds += std::chrono::duration<double>(t1 - t0).count();
+    factors.push_back(this->vector_field_scaling_factor);
+    factor_steps.push_back(this->current_timestep);
+  }
+};
+
+static ftk::ndarray<double> make_array(const input_t &in, int k)
+{
+  ftk::ndarray<double> a;
+  std::vector<size_t> shape;
+  if (in.nv > 1) shape.push_back(in.nv);
+  for (int i = 0; i < in.nd; i ++) shape.push_back(in.D[i]);
+  a.reshape(shape);
+  if (in.nv > 1) a.set_multicomponents();
+  std::memcpy(a.data(), in.steps[k].data(), sizeof(double) * in.steps[k].size());
+  return a;
+}
+
+static input_t synthesize(const std::string &name, int DW, int DH, int DD, int DT, const double *x0dir)
+{
+  input_t in;
+  in.DT = DT;
+  auto put = [&](const ftk::ndarray<double> &a) {
+    in.steps.emplace_back(a.data(), a.data() + a.nelem());
+  };
+  if (name == "woven") {                       // stream.hh:1468-1477
+    in.nd = 2; in.nv = 1; in.D[0] = DW; in.D[1] = DH;
+    for (int k = 0; k < DT; k ++) {
+      const double t = DT == 1 ? 0.0 : double(k) / (DT - 1);
+      put(ftk::synthetic_woven_2D<double>(DW, DH, t));
+    }
+  } else if (name == "merger_2d") {            // stream.hh:1538-1541
+    in.nd = 2; in.nv = 1; in.D[0] = DW; in.D[1] = DH;
+    for (int k = 0; k < DT; k ++) put(ftk::synthetic_merger_2D<double>(DW, DH, double(k) * 0.1));
+  } else if (name == "moving_extremum_2d") {   // stream.hh:1490-1497
+    in.nd = 2; in.nv = 1; in.D[0] = DW; in.D[1] = DH;
+    const double x0[2] = {x0dir[0], x0dir[1]}, dir[2] = {x0dir[3], x0dir[4]};
+    for (int k = 0; k < DT; k ++)
+      put(ftk::synthetic_moving_extremum<double, 2>({(size_t)DW, (size_t)DH}, x0, dir, double(k)));
+  } else if (name == "moving_extremum_3d") {   // stream.hh:1510-1517
+    in.nd = 3; in.nv = 1; in.D[0] = DW; in.D[1] = DH; in.D[2] = DD;
+    const double x0[3] = {x0dir[0], x0dir[1], x0dir[2]}, dir[3] = {x0dir[3], x0dir[4], x0dir[5]};
+    for (int k = 0; k < DT; k ++)
+      put(ftk::synthetic_moving_extremum<double, 3>({(size_t)DW, (size_t)DH, (size_t)DD}, x0, dir, double(k)));
+  } else if (name == "double_gyre") {          // stream.hh:1544-1556
+    in.nd = 2; in.nv = 2; in.D[0] = DW; in.D[1] = DH;
+    for (int k = 0; k < DT; k ++)
+      put(ftk::synthetic_double_gyre<double>(DW, DH, k * 0.1, false, 0.1, M_PI * 2, 0.25));
+  } else {
+    fprintf(stderr, "unknown synthetic case %s\n", name.c_str());
+    exit(2);
+  }
+  return in;
+}
+
+// in.bin: int32 nd, nv, D0, D1, D2, DT; then DT * nv*D0*D1*D2 doubles
+static input_t read_input(const char *fn)
+{
+  input_t in;
+  FILE *fp = fopen(fn, "rb");
+  if (!fp) { perror(fn); exit(2); }
+  int32_t h[6];
+  if (fread(h, sizeof(int32_t), 6, fp) != 6) exit(2);
+  in.nd = h[0]; in.nv = h[1]; in.D[0] = h[2]; in.D[1] = h[3]; in.D[2] = h[4]; in.DT = h[5];
+  const size_t n = (size_t)in.nv * in.D[0] * in.D[1] * in.D[2];
+  for (int k = 0; k < in.DT; k ++) {
+    std::vector<double> a(n);
+    if (fread(a.data(), sizeof(double), n, fp) != n) exit(2);
+    in.steps.push_back(std::move(a));
+  }
+  fclose(fp);
+  return in;
+}
+
+template <class Tracker>
+static void run(const input_t &in, int nthreads, const char *out, bool robust, unsigned type_filter)
+{
+  diy::mpi::communicator comm;
+  probe<Tracker> tracker(comm);
+  const size_t DW = in.D[0], DH = in.D[1], DD = in.D[2];
+  // json_interface.hh:634-656
+  if (in.nv == 1) {
+    tracker.set_scalar_field_source(ftk::SOURCE_GIVEN);
+    tracker.set_vector_field_source(ftk::SOURCE_DERIVED);
+    tracker.set_jacobian_field_source(ftk::SOURCE_DERIVED);
+    tracker.set_jacobian_symmetric(true);
+    if (in.nd == 2) tracker.set_domain(ftk::lattice({2, 2}, {DW - 3, DH - 3}));
+    else tracker.set_domain(ftk::lattice({2, 2, 2}, {DW - 3, DH - 3, DD - 3}));
+  } else {
+    tracker.set_scalar_field_source(ftk::SOURCE_NONE);
+    tracker.set_vector_field_source(ftk::SOURCE_GIVEN);
+    tracker.set_jacobian_field_source(ftk::SOURCE_DERIVED);
+    tracker.set_jacobian_symmetric(false);
+    if (in.nd == 2) tracker.set_domain(ftk::lattice({1, 1}, {DW - 2, DH - 2}));
+    else tracker.set_domain(ftk::lattice({1, 1, 1}, {DW - 2, DH - 2, DD - 2}));
+  }
+  if (in.nd == 2) tracker.set_array_domain(ftk::lattice({0, 0}, {DW, DH}));
+  else tracker.set_array_domain(ftk::lattice({0, 0, 0}, {DW, DH, DD}));
+  if (nthreads > 0) tracker.set_number_of_threads(nthreads);
+  tracker.set_enable_robust_detection(robust);
+  if (type_filter) tracker.set_type_filter(type_filter);
+  tracker.initialize();
+
+  for (int k = 0; k < in.DT; k ++) {
+    const auto a = make_array(in, k);
+    if (in.nv == 1) tracker.push_scalar_field_snapshot(a);
+    else tracker.push_vector_field_snapshot(a);
+    if (k != 0) tracker.advance_timestep();
+    if (k == in.DT - 1) tracker.update_timestep();
+  }
+
+  const auto cps = tracker.get_critical_points();
+  fprintf(stdout, "{\"sweep_seconds\": %.6f, \"records\": %zu, \"nthreads\": %d}\n",
+      tracker.sweep_seconds, cps.size(), tracker.get_number_of_threads());
+  if (!out) return;
+
+  FILE *fp = fopen(out, "wb");
+  if (!fp) { perror(out); exit(2); }
+  const char magic[8] = {'F', 'T', 'K', 'R', 'E', 'F', '1', 0};
+  fwrite(magic, 1, 8, fp);
+  const int32_t h[6] = {in.nd, in.nv, in.D[0], in.D[1], in.D[2], in.DT};
+  fwrite(h, sizeof(int32_t), 6, fp);
+  const uint64_t nf = tracker.factors.size();
+  fwrite(&nf, sizeof(uint64_t), 1, fp);
+  for (size_t i = 0; i < nf; i ++) {
+    const int64_t step = tracker.factor_steps[i];
+    fwrite(&step, sizeof(int64_t), 1, fp);
+    fwrite(&tracker.factors[i], sizeof(uint64_t), 1, fp);
+  }
+  const uint64_t nrec = cps.size();
+  fwrite(&nrec, sizeof(uint64_t), 1, fp);
+  for (const auto &cp : cps) {   // 8 + 4 + 4 + 4 + 4(pad) + 5*8 = 64 bytes
+    const uint64_t tag = cp.tag;
+    const uint32_t type = cp.type;
+    const int32_t ordinal = cp.ordinal, timestep = cp.timestep, pad = 0;
+    const double v[5] = {cp.x[0], cp.x[1], cp.x[2], cp.t, cp.scalar[0]};
+    fwrite(&tag, 8, 1, fp); fwrite(&type, 4, 1, fp); fwrite(&ordinal, 4, 1, fp);
+    fwrite(&timestep, 4, 1, fp); fwrite(&pad, 4, 1, fp); fwrite(v, 8, 5, fp);
+  }
+  for (int k = 0; k < in.DT; k ++)
+    fwrite(in.steps[k].data(), sizeof(double), in.steps[k].size(), fp);
+  fclose(fp);
+}
+
+static void dump_tables(const char *out)
+{
+  FILE *fp = fopen(out, "w");
+  for (int n = 3; n <= 4; n ++) {
+    ftk::simplicial_regular_mesh m(n);
+    const int d = n - 1;
+    fprintf(fp, "mesh %d dim %d ntypes %d ordinal %d interval %d\n", n, d,
+        m.ntypes(d), m.ntypes(d, ftk::ELEMENT_SCOPE_ORDINAL), m.ntypes(d, ftk::ELEMENT_SCOPE_INTERVAL));
+    for (int t = 0; t < m.ntypes(d); t ++) {
+      ftk::simplicial_regular_mesh_element e(std::vector<int>(n, 0), d, t);
+      fprintf(fp, "type %d ordinal %d :", t, (int)e.is_ordinal(m));
+      for (const auto &v : e.vertices(m)) {
+        fprintf(fp, " ");
+        for (int c : v) fprintf(fp, "%d", c);
+      }
+      fprintf(fp, " | side_of:");
+      for (const auto &c : e.side_of(m)) {
+        fprintf(fp, " (%d;", c.type);
+        for (int x : c.corner) fprintf(fp, " %d", x);
+        fprintf(fp, ")");
+      }
+      fprintf(fp, "\n");
+    }
+    // sides of every (d+1)-cell type
+    for (int t = 0; t < m.ntypes(d + 1); t ++) {
+      ftk::simplicial_regular_mesh_element e(std::vector<int>(n, 0), d + 1, t);
+      fprintf(fp, "cell %d sides:", t);
+      for (const auto &s : e.sides(m)) {
+        fprintf(fp, " (%d;", s.type);
+        for (int x : s.corner) fprintf(fp, " %d", x);
+        fprintf(fp, ")");
+      }
+      fprintf(fp, "\n");
+    }
+  }
+  fclose(fp);
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 2) { fprintf(stderr, "see header comment for usage\n"); return 2; }
+  const std::string mode = argv[1];
+  const bool robust = getenv("FTK_REF_NO_ROBUST") == NULL;
+  const unsigned type_filter = getenv("FTK_REF_TYPE_FILTER") ? atoi(getenv("FTK_REF_TYPE_FILTER")) : 0;
+  if (mode == "tables") { dump_tables(argv[2]); return 0; }
+
+  input_t in;
+  const char *out = NULL;
+  int nthreads = 0;
+  if (mode == "synthetic") {
+    if (argc < 8) return 2;
+    double x0dir[6] = {10, 10, 10, 0.1, 0.11, 0.1};
+    const std::string name = argv[2];
+    if (name == "moving_extremum_2d") { x0dir[3] = 0.1; x0dir[4] = 0.1; }
+    out = argv[7];
+    int a = 8;
+    if (argc >= 14) { for (int i = 0; i < 6; i ++) x0dir[i] = atof(argv[8 + i]); a = 14; }
+    if (argc > a) nthreads = atoi(argv[a]);
+    in = synthesize(name, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), x0dir);
+  } else if (mode == "file") {
+    in = read_input(argv[2]);
+    out = argv[3];
+    if (argc > 4) nthreads = atoi(argv[4]);
+  } else if (mode == "time") {
+    in = read_input(argv[2]);
+    if (argc > 3) nthreads = atoi(argv[3]);
+  } else return 2;
+
+  if (in.nd == 2) run<ftk::critical_point_tracker_2d_regular>(in, nthreads, out, robust, type_filter);
+  else run<ftk::critical_point_tracker_3d_regular>(in, nthreads, out, robust, type_filter);
+  return 0;
+}

@@ -1,0 +1,48 @@
+"""Helpers shared by the parity tests."""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def load_golden(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return dict(
+        nd=int(d["nd"]), nv=int(d["nv"]), dims=[int(x) for x in d["dims"]], DT=int(d["DT"]),
+        steps=list(d["steps"]), factors=d["factors"], records=d["records"],
+        robust=bool(int(d["robust"])) if "robust" in d else True,
+        type_filter=int(d["type_filter"]) if "type_filter" in d else None,
+        case=str(d["case"]) if "case" in d else None,
+        x0dir=d["x0dir"] if "x0dir" in d else None,
+    )
+
+
+def by_tag(recs):
+    return recs[np.argsort(recs["tag"], kind="stable")]
+
+
+def assert_records_equal(got, ref, *, coord_tol=0.0, what=""):
+    """tag / type / (ordinal, timestep when present) exact; coordinates and scalar within coord_tol
+    (0.0 = bit-identical, NaN == NaN).  `got` and `ref` are structured arrays with fields
+    tag, type, x[3], t and scalar (either [3] or scalar0)."""
+    got, ref = by_tag(got), by_tag(ref)
+    assert len(got) == len(ref), f"{what}: {len(got)} records, expected {len(ref)}"
+    assert np.array_equal(got["tag"], ref["tag"]), f"{what}: tag sets differ"
+    assert np.array_equal(got["type"], ref["type"]), \
+        f"{what}: {int((got['type'] != ref['type']).sum())} type mismatches"
+    for f in ("ordinal", "timestep"):
+        if f in got.dtype.names and f in ref.dtype.names:
+            assert np.array_equal(got[f], ref[f]), f"{what}: {f} differs"
+    gs = got["scalar"][:, 0] if got["scalar"].ndim == 2 else got["scalar"]
+    rs = ref["scalar"][:, 0] if ref["scalar"].ndim == 2 else ref["scalar"]
+    for a, b, nm in ((got["x"], ref["x"], "x"), (got["t"], ref["t"], "t"), (gs, rs, "scalar")):
+        if coord_tol == 0.0:
+            assert np.array_equal(a, b, equal_nan=True), f"{what}: {nm} not bit-identical (max diff {np.nanmax(np.abs(a - b))})"
+        else:
+            assert np.allclose(a, b, rtol=0, atol=coord_tol, equal_nan=True), f"{what}: {nm} differs by {np.nanmax(np.abs(a - b))}"
