@@ -1,0 +1,254 @@
+"""ftk_amd -- MI355X-native critical-point space-time simplex sweep behind FTK's tracker API.
+
+The product is the shared library ftk_amd/libftkx.so (HIP kernels for gfx950 + C ABI `ftkx_*`, see include/ftkx.h, and the C++
+tracker of include/ftkx_tracker.hh).  This package is the Python plumbing over that C ABI, mirroring the reference's tracker
+interface (include/ftk/filters/critical_point_tracker_{2d,3d}_regular.hh; python/pyftk.cpp:93-142)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (CP_DTYPE, SCOPE_BOTH, SCOPE_INTERVAL, SCOPE_ORDINAL, SOURCE_DERIVED, SOURCE_GIVEN, SOURCE_NONE,  # noqa: F401
+                   TAG_EXACT64, TAG_REFERENCE, TAG_WORK_INDEX, FtkxError, Options, Stats)
+
+__all__ = ["Context", "CriticalPointTracker2DRegular", "CriticalPointTracker3DRegular", "extract_cp2dt", "extract_cp3dt",
+           "scaling_factor", "CP_DTYPE", "FtkxError"]
+
+
+def _ptr(a):
+    """host numpy array / torch tensor / raw int -> (address, keepalive, on_device)"""
+    if a is None:
+        return None, None, 0
+    if isinstance(a, int):
+        return a, None, 1
+    if hasattr(a, "data_ptr"):          # torch tensor (device memory is torch's job: plumbing, not the product)
+        if a.dtype.is_floating_point and a.element_size() != 8:
+            raise TypeError("fields must be float64")
+        a = a.contiguous()
+        return a.data_ptr(), a, 1 if a.is_cuda else 0
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a.ctypes.data, a, 0
+
+
+def default_options(**kw):
+    o = Options()
+    _lib.load().ftkx_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, int(v))
+    return o
+
+
+def scaling_factor(resolution):
+    nb = C.c_int()
+    f = _lib.load().ftkx_scaling_factor(float(resolution), C.byref(nb))
+    return int(f), nb.value
+
+
+class Context:
+    """ftkx_ctx: slices resident in HBM + sweeps (include/ftkx.h)."""
+
+    def __init__(self, nd, device_id=0):
+        self._L = _lib.load()
+        self.nd = nd
+        self._h = C.c_void_p()
+        _lib.check(self._L.ftkx_create(C.byref(self._h), nd, device_id))
+        self._keep = {}
+
+    def close(self):
+        if self._h:
+            self._L.ftkx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        _lib.check(rc, self._h)
+
+    def set_stream(self, stream_ptr):
+        self._ck(self._L.ftkx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_options(self, **kw):
+        self._opt = default_options(**kw)
+        self._ck(self._L.ftkx_set_options(self._h, C.byref(self._opt)))
+
+    def set_mesh(self, domain, core, ext):
+        """each = (starts, sizes), spatial axes only (x, y[, z])"""
+        args = []
+        for st, sz in (domain, core, ext):
+            args += [_lib.ll(st), _lib.ll(sz, fill=1)]
+        self._ck(self._L.ftkx_set_mesh(self._h, *args))
+
+    def push_slice(self, t, V, J=None, S=None):
+        pv, kv, dv = _ptr(V); pj, kj, dj = _ptr(J); ps, ks, ds = _ptr(S)
+        devs = {d for p, d in ((pv, dv), (pj, dj), (ps, ds)) if p is not None}
+        if len(devs) != 1:
+            raise ValueError("V, J, S must all be host arrays or all device tensors")
+        on_dev = devs.pop()
+        self._ck(self._L.ftkx_push_slice(self._h, t, pv, pj, ps, on_dev))
+        self._keep[t] = (kv, kj, ks) if on_dev else None
+
+    def push_scalar_slice(self, t, S):
+        ps, ks, ds = _ptr(S)
+        self._ck(self._L.ftkx_push_scalar_slice(self._h, t, ps, ds))
+        self._keep[t] = ks if ds else None
+
+    def drop_slice(self, t):
+        self._ck(self._L.ftkx_drop_slice(self._h, t))
+        self._keep.pop(t, None)
+
+    def slice_resolution(self, t):
+        r, m = C.c_double(), C.c_double()
+        self._ck(self._L.ftkx_slice_resolution(self._h, t, C.byref(r), C.byref(m)))
+        return r.value, m.value
+
+    def sweep(self, t, scope, factor):
+        out, n = C.c_void_p(), C.c_size_t()
+        self._ck(self._L.ftkx_sweep(self._h, t, scope, int(factor), C.byref(out), C.byref(n)))
+        return _lib.records_from(out.value, n.value)
+
+    def sweep_enqueue(self, t, scope, factor):
+        self._ck(self._L.ftkx_sweep_enqueue(self._h, t, scope, int(factor)))
+
+    def sweep_collect(self):
+        out, n = C.c_void_p(), C.c_size_t()
+        self._ck(self._L.ftkx_sweep_collect(self._h, C.byref(out), C.byref(n)))
+        return _lib.records_from(out.value, n.value)
+
+    def stats(self):
+        s = Stats()
+        self._ck(self._L.ftkx_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    # derived fields on device tensors (ndarray/grad.hh)
+    def gradient2D(self, S_ptr, DW, DH, V_ptr): self._ck(self._L.ftkx_gradient2D(self._h, S_ptr, DW, DH, V_ptr))
+    def jacobian2D(self, V_ptr, DW, DH, symmetric, J_ptr): self._ck(self._L.ftkx_jacobian2D(self._h, V_ptr, DW, DH, int(symmetric), J_ptr))
+    def gradient3D(self, S_ptr, DW, DH, DD, V_ptr): self._ck(self._L.ftkx_gradient3D(self._h, S_ptr, DW, DH, DD, V_ptr))
+    def jacobian3D(self, V_ptr, DW, DH, DD, J_ptr): self._ck(self._L.ftkx_jacobian3D(self._h, V_ptr, DW, DH, DD, J_ptr))
+
+
+def _extract(nd, scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options, device_id):
+    L = _lib.load()
+    keep = []
+    ptrs = []
+    for a in (Vc, Vn, Jc, Jn, Sc, Sn):
+        if a is None:
+            ptrs.append(None)
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); ptrs.append(a.ctypes.data)
+    n4 = nd + 1
+    lat = [_lib.ll(domain[0], n4), _lib.ll(domain[1], n4, 1), _lib.ll(core[0], n4), _lib.ll(core[1], n4, 1), _lib.ll(ext[0], 3), _lib.ll(ext[1], 3, 1)]
+    out, n = C.c_void_p(), C.c_size_t()
+    opt = C.byref(options) if options is not None else None
+    if nd == 2:
+        rc = L.ftkx_extract_cp2dt(scope, current_timestep, *lat, *ptrs, 0, None, int(factor), opt, device_id, C.byref(out), C.byref(n))
+    else:
+        rc = L.ftkx_extract_cp3dt(scope, current_timestep, *lat, *ptrs, int(factor), opt, device_id, C.byref(out), C.byref(n))
+    _lib.check(rc)
+    recs = _lib.records_from(out.value, n.value)
+    L.ftkx_free(out)
+    return recs
+
+
+def extract_cp2dt(scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options=None, device_id=0):
+    """extract_cp2dt_cuda's argument list (critical_point_tracker_2d_regular.hh:33-63); lattices as (starts, sizes) incl. time."""
+    return _extract(2, scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options, device_id)
+
+
+def extract_cp3dt(scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options=None, device_id=0):
+    """extract_cp3dt_cuda's argument list (critical_point_tracker_3d_regular.hh:42-56)."""
+    return _extract(3, scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options, device_id)
+
+
+class _TrackerRegular:
+    """ftkx::critical_point_tracker_regular (include/ftkx_tracker.hh) through its C handle; method names are the reference's."""
+    ND = 0
+
+    def __init__(self, device_id=0):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        _lib.check(self._L.ftkx_tracker_create(C.byref(self._h), self.ND, device_id), None, True)
+        self._src = [SOURCE_NONE, SOURCE_NONE, SOURCE_NONE, 0]
+        self._flags = dict(robust=1, use_type_filter=0, type_filter=0, compute_degrees=0, exact_only=0, tag_mode=TAG_REFERENCE)
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            self._L.ftkx_tracker_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        _lib.check(rc, self._h, True)
+
+    def set_domain(self, starts, sizes): self._ck(self._L.ftkx_tracker_set_domain(self._h, _lib.ll(starts), _lib.ll(sizes, fill=1)))
+    def set_array_domain(self, starts, sizes): self._ck(self._L.ftkx_tracker_set_array_domain(self._h, _lib.ll(starts), _lib.ll(sizes, fill=1)))
+    def set_scalar_field_source(self, s): self._src[0] = s
+    def set_vector_field_source(self, s): self._src[1] = s
+    def set_jacobian_field_source(self, s): self._src[2] = s
+    def set_jacobian_symmetric(self, b): self._src[3] = int(b)
+    def set_enable_robust_detection(self, b): self._flags["robust"] = int(b)
+    def set_enable_computing_degrees(self, b): self._flags["compute_degrees"] = int(b)
+    def set_type_filter(self, f): self._flags["use_type_filter"] = 1; self._flags["type_filter"] = int(f)
+    def set_exact_only(self, b): self._flags["exact_only"] = int(b)
+    def set_tag_mode(self, m): self._flags["tag_mode"] = int(m)
+    def set_stream(self, ptr): self._ck(self._L.ftkx_tracker_set_stream(self._h, C.c_void_p(ptr)))
+
+    def initialize(self):
+        self._ck(self._L.ftkx_tracker_set_sources(self._h, *self._src))
+        f = self._flags
+        self._ck(self._L.ftkx_tracker_set_flags(self._h, f["robust"], f["use_type_filter"], f["type_filter"], f["compute_degrees"], f["exact_only"], f["tag_mode"]))
+        self._ck(self._L.ftkx_tracker_initialize(self._h))
+
+    def push_scalar_field_snapshot(self, s):
+        p, k, d = _ptr(s); self._keep.append(k)
+        self._ck(self._L.ftkx_tracker_push_scalar_field_snapshot(self._h, p, d))
+
+    def push_vector_field_snapshot(self, v):
+        p, k, d = _ptr(v); self._keep.append(k)
+        self._ck(self._L.ftkx_tracker_push_vector_field_snapshot(self._h, p, d))
+
+    def push_field_data_snapshot(self, s, v, j):
+        ps, ks, ds = _ptr(s); pv, kv, dv = _ptr(v); pj, kj, dj = _ptr(j); self._keep.append((ks, kv, kj))
+        self._ck(self._L.ftkx_tracker_push_field_data_snapshot(self._h, ps, pv, pj, dv))
+
+    def advance_timestep(self):
+        self._ck(self._L.ftkx_tracker_advance_timestep(self._h))
+        self._keep = self._keep[-2:]
+
+    def update_timestep(self): self._ck(self._L.ftkx_tracker_update_timestep(self._h))
+
+    def get_critical_points(self):
+        """(records[CP_DTYPE], ordinal[int32], timestep[int32]) in the reference's std::map order (by element tag)"""
+        n = C.c_size_t()
+        self._ck(self._L.ftkx_tracker_num_critical_points(self._h, C.byref(n)))
+        recs = np.zeros(n.value, dtype=CP_DTYPE); o = np.zeros(n.value, dtype=np.int32); ts = np.zeros(n.value, dtype=np.int32)
+        if n.value:
+            self._ck(self._L.ftkx_tracker_get_critical_points(self._h, recs.ctypes.data, o.ctypes.data, ts.ctypes.data, n.value))
+        return recs, o, ts
+
+    def get_vector_field_scaling_factor(self):
+        f, r = C.c_ulonglong(), C.c_double()
+        self._ck(self._L.ftkx_tracker_get_scaling(self._h, C.byref(f), C.byref(r)))
+        return f.value
+
+    def get_last_stats(self):
+        s = Stats()
+        self._ck(self._L.ftkx_tracker_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+
+class CriticalPointTracker2DRegular(_TrackerRegular):
+    ND = 2
+
+
+class CriticalPointTracker3DRegular(_TrackerRegular):
+    ND = 3

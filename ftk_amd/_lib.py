@@ -1,0 +1,128 @@
+"""ctypes binding of ftk_amd/libftkx.so -- plumbing only.  There is no Python or CPU implementation of the sweep behind
+these calls: if the shared library is missing the import fails, and if no GPU is visible ftkx_create() fails."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libftkx.so")
+
+# == ftkx_cp_t / ftk::feature_point_lite_t (72 bytes); `aux` sits in the C struct's padding (include/ftkx.h)
+CP_DTYPE = np.dtype([("x", "<f8", (3,)), ("t", "<f8"), ("scalar", "<f8", (3,)), ("type", "<u4"), ("aux", "<u4"), ("tag", "<u8")])
+assert CP_DTYPE.itemsize == 72
+
+OK, E_INVALID, E_DEVICE, E_NOMEM, E_NOSLICE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+SCOPE_ORDINAL, SCOPE_INTERVAL, SCOPE_BOTH = 1, 2, 3
+TAG_WORK_INDEX, TAG_REFERENCE, TAG_EXACT64 = 0, 1, 2
+SOURCE_NONE, SOURCE_GIVEN, SOURCE_DERIVED = 0, 1, 2
+
+
+class Options(C.Structure):
+    _fields_ = [("jacobian_symmetric", C.c_int), ("robust", C.c_int), ("use_type_filter", C.c_int), ("type_filter", C.c_uint),
+                ("compute_degrees", C.c_int), ("tag_mode", C.c_int), ("exact_only", C.c_int), ("derive_jacobian", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("work_items", C.c_ulonglong), ("cells", C.c_ulonglong), ("cells_survived", C.c_ulonglong),
+                ("simplices_tested", C.c_ulonglong), ("hits", C.c_ulonglong), ("cull_enabled", C.c_int)]
+
+
+class FtkxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ftkx error {code}: {msg}")
+        self.code = code
+
+
+EXPORTS = [
+    "ftkx_create", "ftkx_destroy", "ftkx_last_error", "ftkx_set_stream", "ftkx_set_options", "ftkx_default_options", "ftkx_set_mesh",
+    "ftkx_push_slice", "ftkx_push_scalar_slice", "ftkx_drop_slice", "ftkx_slice_resolution", "ftkx_scaling_factor",
+    "ftkx_sweep", "ftkx_sweep_enqueue", "ftkx_sweep_collect", "ftkx_get_stats", "ftkx_extract_cp2dt", "ftkx_extract_cp3dt", "ftkx_free",
+    "ftkx_gradient2D", "ftkx_jacobian2D", "ftkx_gradient3D", "ftkx_jacobian3D", "ftkx_version", "ftkx_device_count",
+    "ftkx_tracker_create", "ftkx_tracker_destroy", "ftkx_tracker_last_error", "ftkx_tracker_set_domain", "ftkx_tracker_set_array_domain",
+    "ftkx_tracker_set_sources", "ftkx_tracker_set_flags", "ftkx_tracker_set_stream", "ftkx_tracker_initialize",
+    "ftkx_tracker_push_scalar_field_snapshot", "ftkx_tracker_push_vector_field_snapshot", "ftkx_tracker_push_field_data_snapshot",
+    "ftkx_tracker_advance_timestep", "ftkx_tracker_update_timestep", "ftkx_tracker_num_critical_points",
+    "ftkx_tracker_get_critical_points", "ftkx_tracker_get_scaling", "ftkx_tracker_get_stats",
+]
+
+_L = None
+
+
+def load():
+    """Loads the shared library (no GPU needed for that) and declares the prototypes."""
+    global _L
+    if _L is not None:
+        return _L
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m ftk_amd.build` (hipcc --offload-arch=gfx950)")
+    L = C.CDLL(LIB_PATH)
+    vp, ll3, dbl = C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p
+    L.ftkx_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    L.ftkx_destroy.argtypes = [vp]; L.ftkx_destroy.restype = None
+    L.ftkx_last_error.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.ftkx_set_stream.argtypes = [vp, vp]
+    L.ftkx_set_options.argtypes = [vp, C.POINTER(Options)]
+    L.ftkx_default_options.argtypes = [C.POINTER(Options)]; L.ftkx_default_options.restype = None
+    L.ftkx_set_mesh.argtypes = [vp] + [ll3] * 6
+    L.ftkx_push_slice.argtypes = [vp, C.c_int, dbl, dbl, dbl, C.c_int]
+    L.ftkx_push_scalar_slice.argtypes = [vp, C.c_int, dbl, C.c_int]
+    L.ftkx_drop_slice.argtypes = [vp, C.c_int]
+    L.ftkx_slice_resolution.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ftkx_scaling_factor.argtypes = [C.c_double, C.POINTER(C.c_int)]; L.ftkx_scaling_factor.restype = C.c_ulonglong
+    L.ftkx_sweep.argtypes = [vp, C.c_int, C.c_int, C.c_ulonglong, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ftkx_sweep_enqueue.argtypes = [vp, C.c_int, C.c_int, C.c_ulonglong]
+    L.ftkx_sweep_collect.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ftkx_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.ftkx_extract_cp2dt.argtypes = [C.c_int, C.c_int] + [ll3] * 6 + [dbl] * 6 + [C.c_int, dbl, C.c_ulonglong, C.POINTER(Options), C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ftkx_extract_cp3dt.argtypes = [C.c_int, C.c_int] + [ll3] * 6 + [dbl] * 6 + [C.c_ulonglong, C.POINTER(Options), C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ftkx_free.argtypes = [vp]; L.ftkx_free.restype = None
+    L.ftkx_gradient2D.argtypes = [vp, dbl, C.c_int, C.c_int, dbl]
+    L.ftkx_jacobian2D.argtypes = [vp, dbl, C.c_int, C.c_int, C.c_int, dbl]
+    L.ftkx_gradient3D.argtypes = [vp, dbl, C.c_int, C.c_int, C.c_int, dbl]
+    L.ftkx_jacobian3D.argtypes = [vp, dbl, C.c_int, C.c_int, C.c_int, dbl]
+    L.ftkx_version.restype = C.c_char_p
+    L.ftkx_tracker_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    L.ftkx_tracker_destroy.argtypes = [vp]; L.ftkx_tracker_destroy.restype = None
+    L.ftkx_tracker_last_error.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.ftkx_tracker_set_domain.argtypes = [vp, ll3, ll3]
+    L.ftkx_tracker_set_array_domain.argtypes = [vp, ll3, ll3]
+    L.ftkx_tracker_set_sources.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ftkx_tracker_set_flags.argtypes = [vp, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int]
+    L.ftkx_tracker_set_stream.argtypes = [vp, vp]
+    L.ftkx_tracker_initialize.argtypes = [vp]
+    L.ftkx_tracker_push_scalar_field_snapshot.argtypes = [vp, dbl, C.c_int]
+    L.ftkx_tracker_push_vector_field_snapshot.argtypes = [vp, dbl, C.c_int]
+    L.ftkx_tracker_push_field_data_snapshot.argtypes = [vp, dbl, dbl, dbl, C.c_int]
+    L.ftkx_tracker_advance_timestep.argtypes = [vp]
+    L.ftkx_tracker_update_timestep.argtypes = [vp]
+    L.ftkx_tracker_num_critical_points.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.ftkx_tracker_get_critical_points.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    L.ftkx_tracker_get_scaling.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_double)]
+    L.ftkx_tracker_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    _L = L
+    return L
+
+
+def ll(values, n=3, fill=0):
+    v = [int(x) for x in values] + [fill] * (n - len(values))
+    return (C.c_longlong * n)(*v)
+
+
+def last_error(handle=None, tracker=False):
+    L = load()
+    buf = C.create_string_buffer(512)
+    (L.ftkx_tracker_last_error if tracker else L.ftkx_last_error)(handle, buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc, handle=None, tracker=False):
+    if rc != OK:
+        raise FtkxError(rc, last_error(handle, tracker))
+
+
+def records_from(ptr, n):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=CP_DTYPE)
+    buf = (C.c_char * (n * CP_DTYPE.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=CP_DTYPE).copy()

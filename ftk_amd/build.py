@@ -1,0 +1,49 @@
+"""Builds ftk_amd/libftkx.so (HIP kernels + C ABI + C++ tracker) for gfx950, in-tree.
+
+    python -m ftk_amd.build            # hipcc cross-compiles without a GPU present
+
+-ffp-contract=off is part of the contract, not a tuning flag: the FP64 hit path and the derived-field kernels must not fuse
+a*b+c (the x86-64 reference build has no FMA contraction; the one fused op, std::fma in eigen_solver2.hh:32, is explicit)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = [os.path.join(HERE, "csrc", f) for f in ("sweep_kernels.hip", "derive_kernels.hip", "ftkx_api.hip", "tracker.cpp")]
+OUT = os.path.join(HERE, "libftkx.so")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def deps():
+    d = list(SRC)
+    for root in (os.path.join(HERE, "csrc"), os.path.join(os.path.dirname(HERE), "include")):
+        d += [os.path.join(root, f) for f in os.listdir(root) if f.endswith((".hpp", ".h", ".hh"))]
+    return d
+
+
+def up_to_date():
+    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in deps())
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return OUT
+    cmd = [hipcc()] + FLAGS + ["-o", OUT] + SRC
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose="-v" in sys.argv)
+    print(OUT)

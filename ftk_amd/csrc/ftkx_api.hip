@@ -1,0 +1,524 @@
+// Host side of the C ABI declared in include/ftkx.h: context, HBM-resident slices, launch bookkeeping, hit download.
+// The reference's counterpart is the per-call host wrapper extract_cp2dt<scope> / extract_cp3dt<scope>
+// (src/filters/critical_point_tracer_2d_regular.cu:168-272, ..._3d_regular.cu:144-250), which re-allocates, re-uploads and
+// frees everything on every call and synchronises the whole device; here slices stay resident, launches go to a stream,
+// and the hit buffer is persistent (grown and the batch replayed if a launch overflows it).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "sweep_params.hpp"
+
+namespace ftkx {
+void launch_sweep(const SweepParams &p, hipStream_t stream);
+void sweep_tile_dims(int nd, int tile[3]);
+void launch_gradient2d(const double *S, int DW, int DH, double *V, hipStream_t st);
+void launch_jacobian2d(const double *V, int DW, int DH, int symmetric, double *J, hipStream_t st);
+void launch_gradient3d(const double *S, int DW, int DH, int DD, double *V, hipStream_t st);
+void launch_jacobian3d(const double *V, int DW, int DH, int DD, double *J, hipStream_t st);
+void launch_resolution(const double *p, size_t n, u64 *out2, hipStream_t st);
+}  // namespace ftkx
+
+using ftkx::SweepParams;
+using ftkx::u64;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Slice {
+  double *V = nullptr, *J = nullptr, *S = nullptr;
+  bool ownV = false, ownJ = false, ownS = false;
+  bool scalar_derived = false;      // V = gradient(S): J is derived the way jacobian2D<T, true> / jacobian3D would
+  bool have_res = false;
+  double res = 0, maxabs = 0;
+};
+
+}  // namespace
+
+struct ftkx_ctx {
+  int nd = 0, device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  ftkx_options opt;
+  long long dom_st[3] = {0, 0, 0}, dom_sz[3] = {1, 1, 1}, core_st[3] = {0, 0, 0}, core_sz[3] = {1, 1, 1}, ext_st[3] = {0, 0, 0}, ext_sz[3] = {1, 1, 1};
+  bool mesh_set = false;
+  std::map<int, Slice> slices;
+  ftkx_cp_t *d_hits = nullptr;
+  u64 capacity = 0;
+  u64 *d_counters = nullptr;        // CNT_N counters + 2 words for the resolution reduction
+  u64 *h_counters = nullptr;        // pinned
+  ftkx_cp_t *h_hits = nullptr;      // pinned
+  size_t h_cap = 0;
+  std::vector<SweepParams> pending;
+  ftkx_stats stats;
+  std::string err;
+};
+
+namespace {
+
+int fail(ftkx_ctx *c, int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  if (c) c->err = buf;
+  return code;
+}
+
+#define HIP_TRY(c, call)                                                                                   \
+  do {                                                                                                     \
+    hipError_t e_ = (call);                                                                                \
+    if (e_ != hipSuccess) return fail((c), e_ == hipErrorOutOfMemory ? FTKX_E_NOMEM : FTKX_E_DEVICE,       \
+                                      "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+size_t n_vertices(const ftkx_ctx *c)
+{
+  size_t n = 1;
+  for (int d = 0; d < c->nd; d ++) n *= (size_t)c->ext_sz[d];
+  return n;
+}
+
+void free_slice(Slice &s)
+{
+  if (s.ownV && s.V) (void)hipFree(s.V);
+  if (s.ownJ && s.J) (void)hipFree(s.J);
+  if (s.ownS && s.S) (void)hipFree(s.S);
+  s = Slice();
+}
+
+int ensure_hit_buffer(ftkx_ctx *c, u64 want)
+{
+  if (c->capacity >= want) return FTKX_OK;
+  if (c->d_hits) { HIP_TRY(c, hipFree(c->d_hits)); c->d_hits = nullptr; c->capacity = 0; }
+  HIP_TRY(c, hipMalloc((void **)&c->d_hits, want * sizeof(ftkx_cp_t)));
+  c->capacity = want;
+  return FTKX_OK;
+}
+
+int ensure_host_buffer(ftkx_ctx *c, size_t want)
+{
+  if (c->h_cap >= want) return FTKX_OK;
+  if (c->h_hits) { HIP_TRY(c, hipHostFree(c->h_hits)); c->h_hits = nullptr; c->h_cap = 0; }
+  const size_t cap = std::max<size_t>(want, 4096);
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_hits, cap * sizeof(ftkx_cp_t), hipHostMallocDefault));
+  c->h_cap = cap;
+  return FTKX_OK;
+}
+
+int slice_resolution(ftkx_ctx *c, Slice &s)
+{
+  if (s.have_res) return FTKX_OK;
+  u64 *d = c->d_counters + ftkx::CNT_N;
+  const u64 init[2] = {0x7fefffffffffffffull, 0ull};
+  HIP_TRY(c, hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  ftkx::launch_resolution(s.V, n_vertices(c) * (size_t)c->nd, d, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  u64 out[2];
+  HIP_TRY(c, hipMemcpyAsync(out, d, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  memcpy(&s.res, &out[0], 8);
+  memcpy(&s.maxabs, &out[1], 8);
+  s.have_res = true;
+  return FTKX_OK;
+}
+
+// the strict-sign cull is exact only while no determinant of the predicate can leave int64:
+// |det4| <= 24 M^3 (3D), |det3| <= 6 M^2 (2D) with M = max |quantised component|   
+bool overflow_free(int nd, double maxabs, u64 factor)
+{
+  const long double M = floorl((long double)maxabs * (long double)factor) + 1.0L;
+  const long double lim = 9223372036854775807.0L;
+  return nd == 3 ? 24.0L * M * M * M < lim : 6.0L * M * M < lim;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ftkx_version(void) { return "ftkx 0.1 (gfx950)"; }
+
+int ftkx_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void ftkx_default_options(ftkx_options *o)
+{
+  memset(o, 0, sizeof(*o));
+  o->jacobian_symmetric = 1;
+  o->robust = 1;
+  o->tag_mode = FTKX_TAG_EXACT64;
+}
+
+int ftkx_last_error(const ftkx_ctx *ctx, char *buf, size_t n)
+{
+  const std::string &e = ctx ? ctx->err : g_last_error;
+  if (buf && n) { strncpy(buf, e.c_str(), n - 1); buf[n - 1] = 0; }
+  return (int)e.size();
+}
+
+int ftkx_create(ftkx_ctx **out, int nd, int device_id)
+{
+  if (!out || (nd != 2 && nd != 3)) return fail(nullptr, FTKX_E_INVALID, "ftkx_create: nd must be 2 or 3");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) return fail(nullptr, FTKX_E_DEVICE, "ftkx_create: no HIP device (%s)", hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, FTKX_E_INVALID, "ftkx_create: device %d of %d", device_id, ndev);
+  ftkx_ctx *c = new ftkx_ctx();
+  c->nd = nd;
+  c->device = device_id;
+  ftkx_default_options(&c->opt);
+  memset(&c->stats, 0, sizeof(c->stats));
+  HIP_TRY(c, hipSetDevice(device_id));
+  HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  HIP_TRY(c, hipMalloc((void **)&c->d_counters, (ftkx::CNT_N + 2) * sizeof(u64)));
+  HIP_TRY(c, hipMemset(c->d_counters, 0, (ftkx::CNT_N + 2) * sizeof(u64)));
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_counters, ftkx::CNT_N * sizeof(u64), hipHostMallocDefault));
+  *out = c;
+  return FTKX_OK;
+}
+
+void ftkx_destroy(ftkx_ctx *c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto &kv : c->slices) free_slice(kv.second);
+  if (c->d_hits) (void)hipFree(c->d_hits);
+  if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->h_counters) (void)hipHostFree(c->h_counters);
+  if (c->h_hits) (void)hipHostFree(c->h_hits);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int ftkx_set_stream(ftkx_ctx *c, void *s)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_set_stream: sweeps pending, collect first");
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return FTKX_OK;
+}
+
+int ftkx_set_options(ftkx_ctx *c, const ftkx_options *o)
+{
+  if (!c || !o) return fail(c, FTKX_E_INVALID, "null argument");
+  if (o->tag_mode < FTKX_TAG_WORK_INDEX || o->tag_mode > FTKX_TAG_EXACT64) return fail(c, FTKX_E_INVALID, "bad tag_mode %d", o->tag_mode);
+  c->opt = *o;
+  return FTKX_OK;
+}
+
+int ftkx_set_mesh(ftkx_ctx *c, const long long dst[3], const long long dsz[3], const long long cst[3], const long long csz[3],
+                  const long long est[3], const long long esz[3])
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  if (!c->slices.empty()) return fail(c, FTKX_E_INVALID, "ftkx_set_mesh: drop all slices first");
+  for (int d = 0; d < c->nd; d ++) {
+    if (dsz[d] < 0 || csz[d] < 0 || esz[d] <= 0) return fail(c, FTKX_E_INVALID, "ftkx_set_mesh: negative size on axis %d", d);
+    if (dst[d] + dsz[d] > 2147483647LL || est[d] + esz[d] > 2147483647LL || cst[d] + csz[d] > 2147483647LL)
+      return fail(c, FTKX_E_INVALID, "ftkx_set_mesh: axis %d exceeds int range", d);
+    // every corner enumerated must be addressable: the kernel reads a vertex only when it is inside domain AND ext
+    c->dom_st[d] = dst[d]; c->dom_sz[d] = dsz[d];
+    c->core_st[d] = cst[d]; c->core_sz[d] = csz[d];
+    c->ext_st[d] = est[d]; c->ext_sz[d] = esz[d];
+  }
+  for (int d = c->nd; d < 3; d ++) { c->dom_st[d] = 0; c->dom_sz[d] = 1; c->core_st[d] = 0; c->core_sz[d] = 1; c->ext_st[d] = 0; c->ext_sz[d] = 1; }
+  c->mesh_set = true;
+  return FTKX_OK;
+}
+
+static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, const double *S, int on_device, bool scalar_only)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "push: call ftkx_set_mesh first");
+  if (t < 0) return fail(c, FTKX_E_INVALID, "push: negative timestep");
+  if (scalar_only ? !S : !V) return fail(c, FTKX_E_INVALID, "push: missing field pointer");
+  HIP_TRY(c, hipSetDevice(c->device));
+  auto it = c->slices.find(t);
+  if (it != c->slices.end()) { free_slice(it->second); c->slices.erase(it); }
+  Slice s;
+  const size_t n = n_vertices(c);
+  const int nd = c->nd;
+  auto take = [&](const double *src, size_t count, double **dst, bool *own) -> int {
+    if (!src) { *dst = nullptr; *own = false; return FTKX_OK; }
+    if (on_device) { *dst = const_cast<double *>(src); *own = false; return FTKX_OK; }
+    HIP_TRY(c, hipMalloc((void **)dst, count * sizeof(double)));
+    *own = true;
+    HIP_TRY(c, hipMemcpyAsync(*dst, src, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return FTKX_OK;
+  };
+  int rc;
+  if ((rc = take(S, n, &s.S, &s.ownS))) return rc;
+  if (scalar_only) {
+    HIP_TRY(c, hipMalloc((void **)&s.V, n * nd * sizeof(double)));
+    s.ownV = true;
+    s.scalar_derived = true;
+    if (nd == 2) ftkx::launch_gradient2d(s.S, (int)c->ext_sz[0], (int)c->ext_sz[1], s.V, c->stream);
+    else ftkx::launch_gradient3d(s.S, (int)c->ext_sz[0], (int)c->ext_sz[1], (int)c->ext_sz[2], s.V, c->stream);
+    HIP_TRY(c, hipGetLastError());
+  } else {
+    if ((rc = take(V, n * nd, &s.V, &s.ownV))) return rc;
+    if ((rc = take(J, n * nd * nd, &s.J, &s.ownJ))) return rc;
+  }
+  if (!on_device) HIP_TRY(c, hipStreamSynchronize(c->stream));   // host buffers may be reused by the caller on return
+  c->slices[t] = s;
+  return FTKX_OK;
+}
+
+int ftkx_push_slice(ftkx_ctx *c, int t, const double *V, const double *J, const double *S, int on_device)
+{ return push_common(c, t, V, J, S, on_device, false); }
+
+int ftkx_push_scalar_slice(ftkx_ctx *c, int t, const double *S, int on_device)
+{ return push_common(c, t, nullptr, nullptr, S, on_device, true); }
+
+int ftkx_drop_slice(ftkx_ctx *c, int t)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  auto it = c->slices.find(t);
+  if (it == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "ftkx_drop_slice: timestep %d not resident", t);
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_drop_slice: sweeps pending, collect first");
+  (void)hipSetDevice(c->device);
+  free_slice(it->second);
+  c->slices.erase(it);
+  return FTKX_OK;
+}
+
+int ftkx_slice_resolution(ftkx_ctx *c, int t, double *res, double *max_abs)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  auto it = c->slices.find(t);
+  if (it == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "ftkx_slice_resolution: timestep %d not resident", t);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = slice_resolution(c, it->second);
+  if (rc) return rc;
+  if (res) *res = it->second.res;
+  if (max_abs) *max_abs = it->second.maxabs;
+  return FTKX_OK;
+}
+
+unsigned long long ftkx_scaling_factor(double resolution, int *nbits_out)
+{
+  // critical_point_tracker.hh:850-864
+  int nbits = (int)std::ceil(std::log2(1.0 / resolution));
+  nbits = std::max(8, std::min(nbits, 21));
+  if (nbits_out) *nbits_out = nbits;
+  return 1ull << nbits;
+}
+
+int ftkx_sweep_enqueue(ftkx_ctx *c, int t, int scope, unsigned long long factor)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "sweep: call ftkx_set_mesh first");
+  if (scope < FTKX_SCOPE_ORDINAL || scope > FTKX_SCOPE_BOTH) return fail(c, FTKX_E_INVALID, "sweep: bad scope %d", scope);
+  if (scope == FTKX_SCOPE_BOTH && c->opt.tag_mode == FTKX_TAG_WORK_INDEX)
+    return fail(c, FTKX_E_INVALID, "sweep: FTKX_SCOPE_BOTH needs an element tag (work indices of the two scopes collide)");
+  if (factor == 0) return fail(c, FTKX_E_INVALID, "sweep: factor must be non-zero");
+  auto it0 = c->slices.find(t);
+  if (it0 == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "sweep: slice %d not resident", t);
+  Slice *s0 = &it0->second, *s1 = nullptr;
+  if (scope & FTKX_SCOPE_INTERVAL) {
+    auto it1 = c->slices.find(t + 1);
+    if (it1 == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "sweep: interval [%d, %d] needs slice %d", t, t + 1, t + 1);
+    s1 = &it1->second;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int nd = c->nd;
+  SweepParams p;
+  memset(&p, 0, sizeof(p));
+  p.nd = nd; p.scope_mask = scope; p.t = t;
+  int tile[3];
+  ftkx::sweep_tile_dims(nd, tile);
+  u64 cells = 1;
+  for (int d = 0; d < 3; d ++) {
+    p.dom_lb[d] = (int)c->dom_st[d]; p.dom_ub[d] = (int)(c->dom_st[d] + c->dom_sz[d] - 1);
+    p.core_st[d] = (int)c->core_st[d]; p.core_sz[d] = (int)c->core_sz[d];
+    p.ext_st[d] = (int)c->ext_st[d]; p.ext_sz[d] = (int)c->ext_sz[d];
+    p.ntiles[d] = d < nd ? (int)((c->core_sz[d] + tile[d] - 1) / tile[d]) : 1;
+    if (d < nd) cells *= (u64)c->core_sz[d];
+  }
+  // lattice::prod_ of the mesh lattice (lattice.hh:156-167) and simplicial_regular_mesh::dimprod_ (int; simplicial_regular_mesh.hh:930-947)
+  p.mesh_prod[0] = 1; p.dimprod[0] = 1; p.exact_prod[0] = 1;
+  for (int d = 1; d <= nd; d ++) {
+    p.mesh_prod[d] = p.mesh_prod[d - 1] * (u64)c->dom_sz[d - 1];
+    p.exact_prod[d] = p.exact_prod[d - 1] * (u64)c->dom_sz[d - 1];
+    p.dimprod[d] = (int)((u64)c->dom_sz[d - 1] * (u64)(long long)p.dimprod[d - 1]);
+  }
+  p.V[0] = s0->V; p.J[0] = s0->J; p.S[0] = s0->S;
+  if (s1) { p.V[1] = s1->V; p.J[1] = s1->J; p.S[1] = s1->S; }
+  if (s1 && ((s0->J == nullptr) != (s1->J == nullptr) || (s0->S == nullptr) != (s1->S == nullptr)))
+    return fail(c, FTKX_E_INVALID, "sweep: slices %d and %d disagree on which of J / S are given", t, t + 1);
+  p.factor = (double)factor;
+  p.jacobian_symmetric = c->opt.jacobian_symmetric; p.robust = c->opt.robust;
+  p.use_type_filter = c->opt.use_type_filter; p.type_filter = c->opt.type_filter;
+  p.compute_degrees = c->opt.compute_degrees; p.tag_mode = c->opt.tag_mode;
+  p.derive_jacobian = (s0->J == nullptr) && c->opt.derive_jacobian;
+  p.jac_symmetric_derive = s0->scalar_derived ? 1 : 0;
+
+  // cull legality
+  int cull = 0;
+  if (!c->opt.exact_only && (nd == 2 || c->opt.robust)) {
+    int rc = slice_resolution(c, *s0);
+    if (rc) return rc;
+    double mx = s0->maxabs;
+    if (s1) { if ((rc = slice_resolution(c, *s1))) return rc; mx = std::max(mx, s1->maxabs); }
+    cull = overflow_free(nd, mx, factor) ? 1 : 0;
+  }
+  p.cull = cull;
+
+  if (c->pending.empty()) {
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, ftkx::CNT_N * sizeof(u64), c->stream));
+    memset(&c->stats, 0, sizeof(c->stats));
+    int rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16));
+    if (rc) return rc;
+  }
+  p.hits = c->d_hits; p.counters = c->d_counters; p.capacity = c->capacity;
+  ftkx::launch_sweep(p, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  c->pending.push_back(p);
+
+  const u64 n_ord = nd == 2 ? 2 : 6, n_int = nd == 2 ? 10 : 54;
+  c->stats.cells += cells;
+  c->stats.work_items += cells * (((scope & 1) ? n_ord : 0) + ((scope & 2) ? n_int : 0));
+  c->stats.cull_enabled = cull;
+  return FTKX_OK;
+}
+
+int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (out) *out = nullptr;
+  if (n_out) *n_out = 0;
+  if (c->pending.empty()) return FTKX_OK;
+  for (int attempt = 0; attempt < 2; attempt ++) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, ftkx::CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const u64 hits = c->h_counters[ftkx::CNT_HITS];
+    if (hits <= c->capacity) break;
+    if (attempt == 1) { c->pending.clear(); return fail(c, FTKX_E_DEVICE, "hit buffer overflow persisted after regrow"); }
+    // the buffer was too small: grow to what this batch needs and replay it (records beyond capacity were only counted)
+    int rc = ensure_hit_buffer(c, hits + hits / 8 + 1024);
+    if (rc) { c->pending.clear(); return rc; }
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, ftkx::CNT_N * sizeof(u64), c->stream));
+    for (auto &p : c->pending) {
+      p.hits = c->d_hits; p.capacity = c->capacity;
+      ftkx::launch_sweep(p, c->stream);
+    }
+    HIP_TRY(c, hipGetLastError());
+  }
+  c->pending.clear();
+  const size_t n = (size_t)c->h_counters[ftkx::CNT_HITS];
+  c->stats.hits = n;
+  c->stats.cells_survived = c->h_counters[ftkx::CNT_CELLS_SURVIVED];
+  c->stats.simplices_tested = c->h_counters[ftkx::CNT_SIMPLICES_TESTED];
+  int rc = ensure_host_buffer(c, n);
+  if (rc) return rc;
+  if (n) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_hits, c->d_hits, n * sizeof(ftkx_cp_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // device append order is arbitrary; the reference keeps hits in a std::map ordered by element
+    std::sort(c->h_hits, c->h_hits + n, [](const ftkx_cp_t &a, const ftkx_cp_t &b) { return a.tag < b.tag; });
+  }
+  if (out) *out = c->h_hits;
+  if (n_out) *n_out = n;
+  return FTKX_OK;
+}
+
+int ftkx_sweep(ftkx_ctx *c, int t, int scope, unsigned long long factor, const ftkx_cp_t **out, size_t *n_out)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_sweep: asynchronous sweeps pending, collect first");
+  int rc = ftkx_sweep_enqueue(c, t, scope, factor);
+  if (rc) return rc;
+  return ftkx_sweep_collect(c, out, n_out);
+}
+
+int ftkx_get_stats(const ftkx_ctx *c, ftkx_stats *st)
+{
+  if (!c || !st) return fail(nullptr, FTKX_E_INVALID, "null argument");
+  *st = c->stats;
+  return FTKX_OK;
+}
+
+void ftkx_free(void *p) { free(p); }
+
+static int extract_common(int nd, int scope, int t, const long long *dst, const long long *dsz, const long long *cst, const long long *csz,
+                          const long long *est, const long long *esz, const double *Vc, const double *Vn, const double *Jc, const double *Jn,
+                          const double *Sc, const double *Sn, unsigned long long factor, const ftkx_options *opt, int device_id,
+                          ftkx_cp_t **out, size_t *n_out)
+{
+  if (!out || !n_out) return fail(nullptr, FTKX_E_INVALID, "extract: null output");
+  *out = nullptr; *n_out = 0;
+  if (scope != FTKX_SCOPE_ORDINAL && scope != FTKX_SCOPE_INTERVAL) return fail(nullptr, FTKX_E_INVALID, "extract: scope must be 1 or 2");
+  if (!Vc || (scope == FTKX_SCOPE_INTERVAL && !Vn)) return fail(nullptr, FTKX_E_INVALID, "extract: missing vector field");
+  // the time axis of core must be the single step `t` (element_for builds it that way, regular_tracker.hh:196-211)
+  if (cst[nd] != t || csz[nd] != 1) return fail(nullptr, FTKX_E_INVALID, "extract: core must cover exactly timestep %d", t);
+  if (dst[nd] != 0) return fail(nullptr, FTKX_E_UNSUPPORTED, "extract: domain must start at time 0");
+  ftkx_ctx *c = nullptr;
+  int rc = ftkx_create(&c, nd, device_id);
+  if (rc) return rc;
+  ftkx_options o;
+  if (opt) o = *opt; else { ftkx_default_options(&o); o.tag_mode = FTKX_TAG_WORK_INDEX; }
+  long long e3[3] = {est[0], est[1], nd == 3 ? est[2] : 0}, s3[3] = {esz[0], esz[1], nd == 3 ? esz[2] : 1};
+  if ((rc = ftkx_set_options(c, &o)) || (rc = ftkx_set_mesh(c, dst, dsz, cst, csz, e3, s3)) ||
+      (rc = ftkx_push_slice(c, t, Vc, Jc, Sc, 0)) ||
+      (scope == FTKX_SCOPE_INTERVAL && (rc = ftkx_push_slice(c, t + 1, Vn, Jn, Sn, 0)))) {
+    g_last_error = c->err; ftkx_destroy(c); return rc;
+  }
+  const ftkx_cp_t *recs = nullptr; size_t n = 0;
+  rc = ftkx_sweep(c, t, scope, factor, &recs, &n);
+  if (rc) { g_last_error = c->err; ftkx_destroy(c); return rc; }
+  ftkx_cp_t *copy = (ftkx_cp_t *)malloc((n ? n : 1) * sizeof(ftkx_cp_t));
+  if (!copy) { ftkx_destroy(c); return fail(nullptr, FTKX_E_NOMEM, "extract: out of host memory"); }
+  if (n) memcpy(copy, recs, n * sizeof(ftkx_cp_t));
+  ftkx_destroy(c);
+  *out = copy; *n_out = n;
+  return FTKX_OK;
+}
+
+int ftkx_extract_cp2dt(int scope, int current_timestep, const long long domain_st[3], const long long domain_sz[3],
+                       const long long core_st[3], const long long core_sz[3], const long long ext_st[2], const long long ext_sz[2],
+                       const double *Vc, const double *Vn, const double *Jc, const double *Jn, const double *Sc, const double *Sn,
+                       int use_explicit_coords, const double *coords, unsigned long long factor, const ftkx_options *opt, int device_id,
+                       ftkx_cp_t **out, size_t *n_out)
+{
+  (void)coords;
+  if (use_explicit_coords) return fail(nullptr, FTKX_E_UNSUPPORTED, "explicit coordinates are not supported (REGULAR_COORDS_SIMPLE only)");
+  return extract_common(2, scope, current_timestep, domain_st, domain_sz, core_st, core_sz, ext_st, ext_sz, Vc, Vn, Jc, Jn, Sc, Sn, factor, opt, device_id, out, n_out);
+}
+
+int ftkx_extract_cp3dt(int scope, int current_timestep, const long long domain_st[4], const long long domain_sz[4],
+                       const long long core_st[4], const long long core_sz[4], const long long ext_st[3], const long long ext_sz[3],
+                       const double *Vc, const double *Vn, const double *Jc, const double *Jn, const double *Sc, const double *Sn,
+                       unsigned long long factor, const ftkx_options *opt, int device_id, ftkx_cp_t **out, size_t *n_out)
+{
+  return extract_common(3, scope, current_timestep, domain_st, domain_sz, core_st, core_sz, ext_st, ext_sz, Vc, Vn, Jc, Jn, Sc, Sn, factor, opt, device_id, out, n_out);
+}
+
+#define DERIVE_PROLOGUE(c) do { if (!(c)) return fail(nullptr, FTKX_E_INVALID, "null context"); HIP_TRY((c), hipSetDevice((c)->device)); } while (0)
+
+int ftkx_gradient2D(ftkx_ctx *c, const double *S, int DW, int DH, double *V)
+{ DERIVE_PROLOGUE(c); ftkx::launch_gradient2d(S, DW, DH, V, c->stream); HIP_TRY(c, hipGetLastError()); HIP_TRY(c, hipStreamSynchronize(c->stream)); return FTKX_OK; }
+int ftkx_jacobian2D(ftkx_ctx *c, const double *V, int DW, int DH, int symmetric, double *J)
+{ DERIVE_PROLOGUE(c); ftkx::launch_jacobian2d(V, DW, DH, symmetric, J, c->stream); HIP_TRY(c, hipGetLastError()); HIP_TRY(c, hipStreamSynchronize(c->stream)); return FTKX_OK; }
+int ftkx_gradient3D(ftkx_ctx *c, const double *S, int DW, int DH, int DD, double *V)
+{ DERIVE_PROLOGUE(c); ftkx::launch_gradient3d(S, DW, DH, DD, V, c->stream); HIP_TRY(c, hipGetLastError()); HIP_TRY(c, hipStreamSynchronize(c->stream)); return FTKX_OK; }
+int ftkx_jacobian3D(ftkx_ctx *c, const double *V, int DW, int DH, int DD, double *J)
+{ DERIVE_PROLOGUE(c); ftkx::launch_jacobian3d(V, DW, DH, DD, J, c->stream); HIP_TRY(c, hipGetLastError()); HIP_TRY(c, hipStreamSynchronize(c->stream)); return FTKX_OK; }
+
+}  // extern "C"

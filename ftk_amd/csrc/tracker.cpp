@@ -1,0 +1,269 @@
+// Host-side tracker with the reference's operator interface (include/ftkx_tracker.hh).  Pure host logic over the C ABI:
+// snapshot window, sticky quantisation factor, ordinal + interval sweep per step, record bookkeeping.
+// Reference counterparts are cited per method.
+#include "../../include/ftkx_tracker.hh"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace ftkx {
+
+critical_point_tracker_regular::critical_point_tracker_regular(int nd_, int device_id) : nd(nd_)
+{
+  std::memset(&last_stats, 0, sizeof(last_stats));
+  int rc = ftkx_create(&ctx, nd, device_id);
+  if (rc != FTKX_OK) {
+    char buf[512];
+    ftkx_last_error(nullptr, buf, sizeof(buf));
+    throw ftkx_error(rc, buf);   // no device, no tracker: there is no CPU path behind this class
+  }
+}
+
+critical_point_tracker_regular::~critical_point_tracker_regular() { ftkx_destroy(ctx); }
+
+void critical_point_tracker_regular::check(int rc) const
+{
+  if (rc == FTKX_OK) return;
+  char buf[512];
+  ftkx_last_error(ctx, buf, sizeof(buf));
+  throw ftkx_error(rc, buf);
+}
+
+void critical_point_tracker_regular::set_stream(void *s) { check(ftkx_set_stream(ctx, s)); }
+
+// regular_tracker::initialize, regular_tracker.hh:105-149.  Single process per GPU: the partitioner returns the whole domain
+// (local_domain == domain) and, with is_input_array_partial == false, local_array_domain == array_domain.
+void critical_point_tracker_regular::initialize()
+{
+  if ((int)domain.nd() != nd || (int)array_domain.nd() != nd) throw ftkx_error(FTKX_E_INVALID, "initialize: set_domain / set_array_domain first");
+  local_domain = domain;
+  local_array_domain = array_domain;
+  long long dst[3] = {0, 0, 0}, dsz[3] = {1, 1, 1}, est[3] = {0, 0, 0}, esz[3] = {1, 1, 1};
+  for (int d = 0; d < nd; d ++) { dst[d] = domain.start(d); dsz[d] = domain.size(d); est[d] = array_domain.start(d); esz[d] = array_domain.size(d); }
+  check(ftkx_set_mesh(ctx, dst, dsz, dst, dsz, est, esz));
+  ftkx_options o;
+  ftkx_default_options(&o);
+  o.jacobian_symmetric = is_jacobian_field_symmetric;
+  o.robust = enable_robust_detection;
+  o.use_type_filter = use_type_filter;
+  o.type_filter = type_filter;
+  o.compute_degrees = enable_computing_degrees;
+  o.tag_mode = tag_mode;
+  o.exact_only = exact_only;
+  o.derive_jacobian = jacobian_field_source == SOURCE_DERIVED;
+  check(ftkx_set_options(ctx, &o));
+  initialized = true;
+}
+
+// critical_point_tracker_2d_regular::reset, 2d:227-236 (+ critical_point_tracker::reset, critical_point_tracker.hh:31-34).
+// Like the reference, the running resolution is NOT reset.
+void critical_point_tracker_regular::reset()
+{
+  current_timestep = 0;
+  while (pop_field_data_snapshot()) {}
+  next_push_timestep = 0;
+  discrete_critical_points.clear();
+}
+
+void critical_point_tracker_regular::push_scalar_field_snapshot(const double *s, bool device)
+{
+  if (!initialized) throw ftkx_error(FTKX_E_INVALID, "push: initialize() first");
+  const int t = next_push_timestep;
+  if (vector_field_source == SOURCE_DERIVED) check(ftkx_push_scalar_slice(ctx, t, s, device));   // V = gradientND(s) on the device
+  else throw ftkx_error(FTKX_E_INVALID, "push_scalar_field_snapshot: vector_field_source must be SOURCE_DERIVED");
+  field_data_snapshots.push_back(t);
+  next_push_timestep ++;
+}
+
+void critical_point_tracker_regular::push_vector_field_snapshot(const double *v, bool device)
+{
+  if (!initialized) throw ftkx_error(FTKX_E_INVALID, "push: initialize() first");
+  const int t = next_push_timestep;
+  check(ftkx_push_slice(ctx, t, v, nullptr, nullptr, device));   // J derived at hits when jacobian_field_source == SOURCE_DERIVED
+  field_data_snapshots.push_back(t);
+  next_push_timestep ++;
+}
+
+void critical_point_tracker_regular::push_field_data_snapshot(const double *s, const double *v, const double *j, bool device)
+{
+  if (!initialized) throw ftkx_error(FTKX_E_INVALID, "push: initialize() first");
+  const int t = next_push_timestep;
+  check(ftkx_push_slice(ctx, t, v, j, s, device));
+  field_data_snapshots.push_back(t);
+  next_push_timestep ++;
+}
+
+bool critical_point_tracker_regular::pop_field_data_snapshot()
+{
+  if (field_data_snapshots.empty()) return false;
+  check(ftkx_drop_slice(ctx, field_data_snapshots.front()));
+  field_data_snapshots.erase(field_data_snapshots.begin());
+  return true;
+}
+
+// critical_point_tracker::update_vector_field_scaling_factor, critical_point_tracker.hh:850-864: sticky running minimum of
+// ndarray::resolution() over every queued snapshot; the per-slice reduction runs on the device once per slice.
+void critical_point_tracker_regular::update_vector_field_scaling_factor(int minbits, int maxbits)
+{
+  for (int t : field_data_snapshots) {
+    double r = 0;
+    check(ftkx_slice_resolution(ctx, t, &r, nullptr));
+    vector_field_resolution = std::min(vector_field_resolution, r);
+  }
+  int nbits = (int)std::ceil(std::log2(1.0 / vector_field_resolution));
+  nbits = std::max(minbits, std::min(nbits, maxbits));
+  vector_field_scaling_factor = 1ull << nbits;
+}
+
+// critical_point_tracker_{2d,3d}_regular::update_timestep (2d:263-433, 3d:150-308): ordinal sweep at current_timestep and,
+// when two snapshots are queued, the interval sweep [current, current+1] -- here one launch, one download.
+void critical_point_tracker_regular::update_timestep()
+{
+  if (field_data_snapshots.empty()) return;
+  update_vector_field_scaling_factor();
+  const int scope = field_data_snapshots.size() >= 2 ? FTKX_SCOPE_BOTH : FTKX_SCOPE_ORDINAL;
+  const ftkx_cp_t *recs = nullptr;
+  size_t n = 0;
+  check(ftkx_sweep(ctx, current_timestep, scope, vector_field_scaling_factor, &recs, &n));
+  for (size_t i = 0; i < n; i ++) {
+    feature_point_t cp;
+    for (int k = 0; k < 3; k ++) { cp.x[k] = recs[i].x[k]; cp.scalar[k] = recs[i].scalar[k]; }
+    cp.t = recs[i].t;
+    cp.type = recs[i].type;
+    cp.tag = recs[i].tag;
+    cp.ordinal = ftkx_cp_ordinal(&recs[i]) != 0;
+    cp.timestep = current_timestep;
+    if (scalar_field_source == SOURCE_NONE) cp.scalar[0] = 0.0;   // 2d:642-646: scalar only when a scalar field exists
+    discrete_critical_points[cp.tag] = cp;
+  }
+  check(ftkx_get_stats(ctx, &last_stats));
+}
+
+// critical_point_tracker::advance_timestep, critical_point_tracker.hh:841-848
+bool critical_point_tracker_regular::advance_timestep()
+{
+  update_timestep();
+  pop_field_data_snapshot();
+  current_timestep ++;
+  return field_data_snapshots.size() > 0;
+}
+
+std::vector<feature_point_t> critical_point_tracker_regular::get_critical_points() const
+{
+  std::vector<feature_point_t> r;
+  r.reserve(discrete_critical_points.size());
+  for (const auto &kv : discrete_critical_points) r.push_back(kv.second);
+  return r;
+}
+
+}  // namespace ftkx
+
+// ---- C handles ---------------------------------------------------------------------------------------------------
+struct ftkx_tracker {
+  ftkx::critical_point_tracker_regular *t = nullptr;
+  int nd = 0;
+  std::string err;
+};
+
+namespace {
+thread_local std::string g_tracker_error;
+
+template <class F>
+int guarded(ftkx_tracker *h, F f)
+{
+  if (!h || !h->t) { g_tracker_error = "null tracker"; return FTKX_E_INVALID; }
+  try { f(); return FTKX_OK; }
+  catch (const ftkx::ftkx_error &e) { h->err = e.what(); g_tracker_error = e.what(); return e.code; }
+  catch (const std::exception &e) { h->err = e.what(); g_tracker_error = e.what(); return FTKX_E_INVALID; }
+}
+}  // namespace
+
+extern "C" {
+
+int ftkx_tracker_create(ftkx_tracker **out, int nd, int device_id)
+{
+  if (!out || (nd != 2 && nd != 3)) { g_tracker_error = "ftkx_tracker_create: nd must be 2 or 3"; return FTKX_E_INVALID; }
+  try {
+    ftkx_tracker *h = new ftkx_tracker();
+    h->nd = nd;
+    h->t = new ftkx::critical_point_tracker_regular(nd, device_id);
+    *out = h;
+    return FTKX_OK;
+  } catch (const ftkx::ftkx_error &e) { g_tracker_error = e.what(); return e.code; }
+}
+
+void ftkx_tracker_destroy(ftkx_tracker *h) { if (h) { delete h->t; delete h; } }
+
+int ftkx_tracker_last_error(const ftkx_tracker *h, char *buf, size_t n)
+{
+  const std::string &e = h ? h->err : g_tracker_error;
+  if (buf && n) { strncpy(buf, e.c_str(), n - 1); buf[n - 1] = 0; }
+  return (int)e.size();
+}
+
+int ftkx_tracker_set_domain(ftkx_tracker *h, const long long *st, const long long *sz)
+{ return guarded(h, [&] { h->t->set_domain(ftkx::lattice(std::vector<long long>(st, st + h->nd), std::vector<long long>(sz, sz + h->nd))); }); }
+int ftkx_tracker_set_array_domain(ftkx_tracker *h, const long long *st, const long long *sz)
+{ return guarded(h, [&] { h->t->set_array_domain(ftkx::lattice(std::vector<long long>(st, st + h->nd), std::vector<long long>(sz, sz + h->nd))); }); }
+int ftkx_tracker_set_sources(ftkx_tracker *h, int s, int v, int j, int sym)
+{ return guarded(h, [&] { h->t->set_scalar_field_source(s); h->t->set_vector_field_source(v); h->t->set_jacobian_field_source(j); h->t->set_jacobian_symmetric(sym != 0); }); }
+int ftkx_tracker_set_flags(ftkx_tracker *h, int robust, int use_tf, unsigned tf, int degrees, int exact_only, int tag_mode)
+{
+  return guarded(h, [&] {
+    h->t->set_enable_robust_detection(robust != 0);
+    if (use_tf) h->t->set_type_filter(tf);
+    h->t->set_enable_computing_degrees(degrees != 0);
+    h->t->set_exact_only(exact_only != 0);
+    h->t->set_tag_mode(tag_mode);
+  });
+}
+int ftkx_tracker_set_stream(ftkx_tracker *h, void *s) { return guarded(h, [&] { h->t->set_stream(s); }); }
+int ftkx_tracker_initialize(ftkx_tracker *h) { return guarded(h, [&] { h->t->initialize(); }); }
+int ftkx_tracker_push_scalar_field_snapshot(ftkx_tracker *h, const double *s, int dev) { return guarded(h, [&] { h->t->push_scalar_field_snapshot(s, dev != 0); }); }
+int ftkx_tracker_push_vector_field_snapshot(ftkx_tracker *h, const double *v, int dev) { return guarded(h, [&] { h->t->push_vector_field_snapshot(v, dev != 0); }); }
+int ftkx_tracker_push_field_data_snapshot(ftkx_tracker *h, const double *s, const double *v, const double *j, int dev)
+{ return guarded(h, [&] { h->t->push_field_data_snapshot(s, v, j, dev != 0); }); }
+int ftkx_tracker_advance_timestep(ftkx_tracker *h) { return guarded(h, [&] { h->t->advance_timestep(); }); }
+int ftkx_tracker_update_timestep(ftkx_tracker *h) { return guarded(h, [&] { h->t->update_timestep(); }); }
+
+int ftkx_tracker_num_critical_points(const ftkx_tracker *h, size_t *n)
+{
+  if (!h || !h->t || !n) return FTKX_E_INVALID;
+  *n = h->t->get_discrete_critical_points().size();
+  return FTKX_OK;
+}
+
+int ftkx_tracker_get_critical_points(const ftkx_tracker *h, ftkx_cp_t *out, int *ordinal, int *timestep, size_t cap)
+{
+  if (!h || !h->t || !out) return FTKX_E_INVALID;
+  size_t i = 0;
+  for (const auto &kv : h->t->get_discrete_critical_points()) {
+    if (i >= cap) break;
+    const ftkx::feature_point_t &cp = kv.second;
+    std::memset(&out[i], 0, sizeof(ftkx_cp_t));
+    for (int k = 0; k < 3; k ++) { out[i].x[k] = cp.x[k]; out[i].scalar[k] = cp.scalar[k]; }
+    out[i].t = cp.t; out[i].type = cp.type; out[i].tag = cp.tag;
+    if (ordinal) ordinal[i] = cp.ordinal;
+    if (timestep) timestep[i] = cp.timestep;
+    i ++;
+  }
+  return FTKX_OK;
+}
+
+int ftkx_tracker_get_scaling(const ftkx_tracker *h, unsigned long long *factor, double *resolution)
+{
+  if (!h || !h->t) return FTKX_E_INVALID;
+  if (factor) *factor = h->t->get_vector_field_scaling_factor();
+  if (resolution) *resolution = h->t->get_vector_field_resolution();
+  return FTKX_OK;
+}
+
+int ftkx_tracker_get_stats(const ftkx_tracker *h, ftkx_stats *st)
+{
+  if (!h || !h->t || !st) return FTKX_E_INVALID;
+  *st = h->t->get_last_stats();
+  return FTKX_OK;
+}
+
+}  // extern "C"

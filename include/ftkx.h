@@ -1,0 +1,162 @@
+/* ftkx -- C ABI of the MI355X-native critical-point space-time simplex sweep.
+ *
+ * This is the drop-in boundary for ONE hot path of hguo/ftk: the per-timestep sweep of
+ *   ftk::critical_point_tracker_2d_regular::update_timestep()   include/ftk/filters/critical_point_tracker_2d_regular.hh:263-433
+ *   ftk::critical_point_tracker_3d_regular::update_timestep()   include/ftk/filters/critical_point_tracker_3d_regular.hh:150-308
+ * i.e. what the reference hands to its accelerator back-ends through
+ *   extract_cp2dt_cuda / extract_cp2dt_sycl   critical_point_tracker_2d_regular.hh:33-63  (call sites 369-384, 399-414)
+ *   extract_cp3dt_cuda                        critical_point_tracker_3d_regular.hh:42-56  (call sites 248-260, 274-286)
+ * Results follow the reference's CPU path (check_simplex, 2d:584-685, 3d:425-514), not its CUDA/SYCL kernels
+ * (those use a different domain and quantisation).
+ *
+ * Plain C: opaque context, raw pointers and sizes, integer status codes.  No STL, no torch types.  All entry points
+ * return FTKX_OK (0) or a negative FTKX_E_* code and never call exit(); ftkx_last_error() gives the message.
+ * (The reference's own boundary returns nothing and prints CUDA errors: src/filters/utils.cuh:13-22.)
+ *
+ * Array layouts are the reference's ndarray layouts (first index fastest, include/ftk/ndarray.hh:103-117):
+ *   V[c + nd*(x + DW*(y + DH*z))]            vector field, nd components
+ *   J[k + nd*j + nd*nd*(x + DW*(y + DH*z))]  jacobian; the tracker reads Js[j][k] = J(k, j, ...)  (2d:566-582, 3d:405-422)
+ *   S[x + DW*(y + DH*z)]                     scalar
+ */
+#ifndef FTKX_H
+#define FTKX_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* == ftk::feature_point_lite_t (include/ftk/features/feature_point_lite.hh:8-15), 72 bytes */
+typedef struct ftkx_cp_t {
+  double x[3];              /* lattice coordinates (REGULAR_COORDS_SIMPLE); 2D: x[2] = 0 */
+  double t;
+  double scalar[3];         /* scalar[0] filled iff a scalar field was given (FTK_CP_MAX_NUM_VARS = 3) */
+  unsigned int type;        /* include/ftk/numeric/critical_point_type.hh:10-36 */
+  unsigned long long tag;   /* see ftkx_options.tag_mode */
+} ftkx_cp_t;
+
+/* The 4 padding bytes between `type` and `tag` (offset 60; feature_point_lite_t has the same hole) carry what the caller
+ * of the reference boundary otherwise has to remember per call (2d:387-395): bit 0 = the simplex type is ordinal,
+ * bits 1..31 = current_timestep of the sweep that emitted the record.  Consumers that ignore padding are unaffected. */
+static inline unsigned int ftkx_cp_aux(const ftkx_cp_t *cp) { return ((const unsigned int *)cp)[15]; }
+static inline int ftkx_cp_ordinal(const ftkx_cp_t *cp) { return (int)(ftkx_cp_aux(cp) & 1u); }
+static inline int ftkx_cp_timestep(const ftkx_cp_t *cp) { return (int)(ftkx_cp_aux(cp) >> 1); }
+
+typedef struct ftkx_ctx ftkx_ctx;
+
+enum {
+  FTKX_OK = 0,
+  FTKX_E_INVALID = -1,      /* bad argument / call order */
+  FTKX_E_DEVICE = -2,       /* HIP runtime error */
+  FTKX_E_NOMEM = -3,
+  FTKX_E_NOSLICE = -4,      /* sweep of a timestep whose slice is not resident */
+  FTKX_E_UNSUPPORTED = -5
+};
+
+/* ELEMENT_SCOPE_* of include/ftk/mesh/simplicial_regular_mesh.hh:39-43; BOTH = one launch doing both sweeps of a step */
+enum { FTKX_SCOPE_ORDINAL = 1, FTKX_SCOPE_INTERVAL = 2, FTKX_SCOPE_BOTH = 3 };
+
+enum {
+  FTKX_TAG_WORK_INDEX = 0,  /* index inside `core` for the given scope: what extract_cp*dt_cuda returns (src/filters/critical_point_tracer_2d_regular.cu:162-164) */
+  FTKX_TAG_REFERENCE  = 1,  /* e.to_integer(m) bit-for-bit, including its int32 products (simplicial_regular_mesh.hh:496-502) */
+  FTKX_TAG_EXACT64    = 2   /* same formula in 64-bit arithmetic: equal to REFERENCE whenever that does not overflow */
+};
+
+typedef struct ftkx_options {
+  int jacobian_symmetric;   /* is_jacobian_field_symmetric (critical_point_tracker.hh:176) */
+  int robust;               /* enable_robust_detection, 3D only (3d:439-467); 2D always runs the robust test (2d:618-622) */
+  int use_type_filter;      /* 2D only (2d:280) */
+  unsigned int type_filter;
+  int compute_degrees;      /* enable_computing_degrees, 2D only (2d:653-662) */
+  int tag_mode;             /* FTKX_TAG_* */
+  int exact_only;           /* 1: never apply the sign cull (every simplex gets the full integer test) */
+  int derive_jacobian;      /* 1: when a slice has no J, derive it at hit vertices from V exactly like ndarray/grad.hh
+                               jacobian2D/3D would (jacobian_field_source == SOURCE_DERIVED); 0: treat J as absent (zeros) */
+} ftkx_options;
+
+/* ---- context ------------------------------------------------------------------------------------------------- */
+int  ftkx_create(ftkx_ctx **ctx, int nd /*2|3*/, int device_id);
+void ftkx_destroy(ftkx_ctx *ctx);
+int  ftkx_last_error(const ftkx_ctx *ctx, char *buf, size_t n);   /* ctx may be NULL: last error of the calling thread */
+int  ftkx_set_stream(ftkx_ctx *ctx, void *hip_stream);            /* NULL = the context's own stream */
+int  ftkx_set_options(ftkx_ctx *ctx, const ftkx_options *opt);
+void ftkx_default_options(ftkx_options *opt);
+
+/* mesh: `domain` = vertex validity box == tracker `domain` (regular_tracker.hh:116-124; inclusive upper bound st+sz-1,
+ * time is [0, INT_MAX]); `core` = corners to enumerate == local_domain; `ext` = array lattice == local_array_domain. */
+int ftkx_set_mesh(ftkx_ctx *ctx, const long long domain_st[3], const long long domain_sz[3],
+                  const long long core_st[3], const long long core_sz[3],
+                  const long long ext_st[3], const long long ext_sz[3]);
+
+/* ---- slices resident in HBM (== field_data_snapshots, critical_point_tracker.hh:155-159) --------------------- */
+/* V required; J, S nullable.  on_device = 0: host pointers, copied to the device asynchronously; 1: device pointers,
+ * adopted without a copy and owned by the caller until ftkx_drop_slice(). */
+int ftkx_push_slice(ftkx_ctx *ctx, int t, const double *V, const double *J, const double *S, int on_device);
+/* scalar input (vector_field_source == SOURCE_DERIVED, 2d:238-250, 3d:125-137): uploads S and derives V = gradient2D/3D(S)
+ * on the device bit-for-bit like ndarray/grad.hh.  With options.derive_jacobian the Jacobian at hit vertices is the one
+ * jacobian2D<T, true> / jacobian3D would give for that V. */
+int ftkx_push_scalar_slice(ftkx_ctx *ctx, int t, const double *S, int on_device);
+int ftkx_drop_slice(ftkx_ctx *ctx, int t);
+/* ndarray::resolution() of the slice's V (ndarray.hh:770-778): min |v| over non-zero entries (DBL_MAX if none);
+ * max_abs (nullable) = max finite |v|, used for the no-overflow guard of the cull. */
+int ftkx_slice_resolution(ftkx_ctx *ctx, int t, double *resolution, double *max_abs);
+/* update_vector_field_scaling_factor (critical_point_tracker.hh:850-864): nbits = clamp(ceil(log2(1/res)), 8, 21) */
+unsigned long long ftkx_scaling_factor(double resolution, int *nbits);
+
+/* ---- the sweep ------------------------------------------------------------------------------------------------- */
+/* Sweeps the simplices of `scope` whose corner lies in `core` at time t (interval: [t, t+1], needs slice t+1).
+ * `factor` = vector_field_scaling_factor.  Records are returned in a context-owned pinned host buffer, sorted by tag,
+ * valid until the next call on this context.  Synchronous on the context's stream. */
+int ftkx_sweep(ftkx_ctx *ctx, int t, int scope, unsigned long long factor, const ftkx_cp_t **out, size_t *n_out);
+
+/* asynchronous form for benchmarking/pipelining: enqueue only; ftkx_sweep_collect() synchronises and returns the records
+ * of ALL sweeps enqueued since the last collect (sorted by tag). */
+int ftkx_sweep_enqueue(ftkx_ctx *ctx, int t, int scope, unsigned long long factor);
+int ftkx_sweep_collect(ftkx_ctx *ctx, const ftkx_cp_t **out, size_t *n_out);
+
+/* counters of the last collect: simplices visited (work items), cells/simplices surviving the cull, device-side hits */
+typedef struct ftkx_stats {
+  unsigned long long work_items, cells, cells_survived, simplices_tested, hits;
+  int cull_enabled;
+} ftkx_stats;
+int ftkx_get_stats(const ftkx_ctx *ctx, ftkx_stats *st);
+
+/* ---- stateless one-shot calls with the reference boundary's argument list ------------------------------------ */
+/* extract_cp2dt_{cuda,sycl}(scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, use_explicit_coords, coords)
+ * critical_point_tracker_2d_regular.hh:33-63.  Lattices are passed as (start, size) triples; host pointers; the records
+ * are malloc'd into *out (release with ftkx_free).  tag = work index inside `core` unless opt->tag_mode says otherwise. */
+int ftkx_extract_cp2dt(int scope, int current_timestep,
+                       const long long domain_st[3], const long long domain_sz[3],
+                       const long long core_st[3], const long long core_sz[3],
+                       const long long ext_st[2], const long long ext_sz[2],
+                       const double *Vc, const double *Vn, const double *Jc, const double *Jn,
+                       const double *Sc, const double *Sn, int use_explicit_coords, const double *coords,
+                       unsigned long long factor, const ftkx_options *opt, int device_id,
+                       ftkx_cp_t **out, size_t *n_out);
+/* extract_cp3dt_cuda(scope, current_timestep, domain4, core4, ext3, Vc, Vl, Jc, Jl, Sc, Sl)  critical_point_tracker_3d_regular.hh:42-56 */
+int ftkx_extract_cp3dt(int scope, int current_timestep,
+                       const long long domain_st[4], const long long domain_sz[4],
+                       const long long core_st[4], const long long core_sz[4],
+                       const long long ext_st[3], const long long ext_sz[3],
+                       const double *Vc, const double *Vn, const double *Jc, const double *Jn,
+                       const double *Sc, const double *Sn,
+                       unsigned long long factor, const ftkx_options *opt, int device_id,
+                       ftkx_cp_t **out, size_t *n_out);
+void ftkx_free(void *p);
+
+/* ---- derived fields on the device (ndarray/grad.hh), exposed for callers that keep V/J themselves ------------- */
+/* all pointers are DEVICE pointers; results are bit-identical to the reference's host loops */
+int ftkx_gradient2D(ftkx_ctx *ctx, const double *S, int DW, int DH, double *V);                    /* grad.hh:10-31   */
+int ftkx_jacobian2D(ftkx_ctx *ctx, const double *V, int DW, int DH, int symmetric, double *J);     /* grad.hh:54-86   */
+int ftkx_gradient3D(ftkx_ctx *ctx, const double *S, int DW, int DH, int DD, double *V);            /* grad.hh:130-149 */
+int ftkx_jacobian3D(ftkx_ctx *ctx, const double *V, int DW, int DH, int DD, double *J);            /* grad.hh:175-212 */
+
+/* library / device identification */
+const char *ftkx_version(void);
+int ftkx_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,160 @@
+// C++ host side above the C ABI: a tracker with the reference's operator interface for the sweep path.
+//
+// Mirrors, method for method, the part of
+//   ftk::critical_point_tracker_regular / critical_point_tracker_{2d,3d}_regular
+//   (include/ftk/filters/critical_point_tracker.hh:27-186, regular_tracker.hh:19-98,
+//    critical_point_tracker_2d_regular.hh:107-141, critical_point_tracker_3d_regular.hh:60-92)
+// that drives the simplex sweep: set_domain / set_array_domain / set_*_field_source / set_jacobian_symmetric / initialize /
+// push_{scalar,vector}_field_snapshot / advance_timestep / update_timestep / get_critical_points.
+// Same names, same argument meaning, same call order as python/pyftk.cpp:93-142 and filters/json_interface.hh:606-725 use.
+// The sweep itself runs in the HIP kernels behind include/ftkx.h; there is no CPU implementation behind this class.
+// Tracing (finalize -> trace_critical_points_offline) is outside this library: hand get_critical_points() to the reference's
+// union-find stage.
+#ifndef FTKX_TRACKER_HH
+#define FTKX_TRACKER_HH
+
+#include <cstddef>
+#include <limits>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ftkx.h"
+
+namespace ftkx {
+
+// spatial lattice: starts + sizes, like ftk::lattice (include/ftk/mesh/lattice.hh:16-69)
+struct lattice {
+  std::vector<long long> starts, sizes;
+  lattice() {}
+  lattice(const std::vector<long long> &st, const std::vector<long long> &sz) : starts(st), sizes(sz) {}
+  size_t nd() const { return sizes.size(); }
+  long long start(size_t i) const { return starts[i]; }
+  long long size(size_t i) const { return sizes[i]; }
+  long long upper_bound(size_t i) const { return starts[i] + sizes[i] - 1; }
+};
+
+enum { SOURCE_NONE = 0, SOURCE_GIVEN = 1, SOURCE_DERIVED = 2 };   // include/ftk/filters/critical_point_tracker.hh:19-24
+
+// == ftk::feature_point_t restricted to what the sweep fills (include/ftk/features/feature_point.hh:128-139)
+struct feature_point_t {
+  double x[3] = {0, 0, 0};
+  double t = 0;
+  int timestep = 0;
+  double scalar[3] = {0, 0, 0};
+  unsigned int type = 0;
+  bool ordinal = false;
+  unsigned long long tag = 0;
+};
+
+struct ftkx_error : public std::runtime_error {
+  int code;
+  ftkx_error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+class critical_point_tracker_regular {
+public:
+  critical_point_tracker_regular(int nd /*2|3*/, int device_id = 0);
+  virtual ~critical_point_tracker_regular();
+  critical_point_tracker_regular(const critical_point_tracker_regular &) = delete;
+  critical_point_tracker_regular &operator=(const critical_point_tracker_regular &) = delete;
+
+  // regular_tracker.hh:24-25
+  void set_domain(const lattice &l) { domain = l; }
+  void set_array_domain(const lattice &l) { array_domain = l; }
+  // critical_point_tracker.hh:36-48
+  void set_scalar_field_source(int s) { scalar_field_source = s; }
+  void set_vector_field_source(int s) { vector_field_source = s; }
+  void set_jacobian_field_source(int s) { jacobian_field_source = s; }
+  void set_jacobian_symmetric(bool s) { is_jacobian_field_symmetric = s; }
+  void set_enable_robust_detection(bool b) { enable_robust_detection = b; }
+  void set_enable_computing_degrees(bool b) { enable_computing_degrees = b; }
+  void set_type_filter(unsigned int f) { use_type_filter = true; type_filter = f; }
+  // tracker.hh:40-41
+  void set_current_timestep(int t) { current_timestep = t; }
+  int get_current_timestep() const { return current_timestep; }
+  // not in the reference: knobs of this implementation
+  void set_exact_only(bool b) { exact_only = b; }          // never cull (every simplex takes the integer test)
+  void set_tag_mode(int m) { tag_mode = m; }               // FTKX_TAG_REFERENCE (default) | FTKX_TAG_EXACT64
+  void set_stream(void *hip_stream);
+
+  void initialize();                                        // regular_tracker.hh:105-149 (single rank: local == global)
+  void reset();                                             // critical_point_tracker_2d_regular.hh:227-236
+
+  // host pointers, reference ndarray layout (first index fastest).  device = true: device pointers, adopted without a copy
+  // and owned by the caller until the snapshot is popped.
+  void push_scalar_field_snapshot(const double *scalar, bool device = false);               // 2d:238-250, 3d:125-137
+  void push_vector_field_snapshot(const double *vector, bool device = false);               // 2d:252-261, 3d:139-148
+  void push_field_data_snapshot(const double *scalar, const double *vector, const double *jacobian, bool device = false);  // critical_point_tracker.hh:137-140
+  bool pop_field_data_snapshot();
+
+  bool advance_timestep();                                  // critical_point_tracker.hh:841-848
+  void update_timestep();                                   // 2d:263-433, 3d:150-308 -- THE SWEEP
+
+  std::vector<feature_point_t> get_critical_points() const; // critical_point_tracker_regular.hh:32-38 (sorted by element)
+  const std::map<unsigned long long, feature_point_t> &get_discrete_critical_points() const { return discrete_critical_points; }
+
+  unsigned long long get_vector_field_scaling_factor() const { return vector_field_scaling_factor; }
+  double get_vector_field_resolution() const { return vector_field_resolution; }
+  ftkx_stats get_last_stats() const { return last_stats; }
+  ftkx_ctx *context() { return ctx; }
+
+protected:
+  void update_vector_field_scaling_factor(int minbits = 8, int maxbits = 21);   // critical_point_tracker.hh:850-864
+  void check(int rc) const;
+
+  int nd;
+  ftkx_ctx *ctx = nullptr;
+  lattice domain, array_domain, local_domain, local_array_domain;
+  int scalar_field_source = SOURCE_NONE, vector_field_source = SOURCE_NONE, jacobian_field_source = SOURCE_NONE;
+  bool is_jacobian_field_symmetric = false;
+  bool enable_robust_detection = true, enable_computing_degrees = false;
+  bool use_type_filter = false;
+  unsigned int type_filter = 0;
+  bool exact_only = false;
+  int tag_mode = FTKX_TAG_REFERENCE;
+  bool initialized = false;
+
+  int current_timestep = 0;
+  std::vector<int> field_data_snapshots;                    // timesteps resident on the device (<= 2, a deque in the reference)
+  int next_push_timestep = 0;
+  double vector_field_resolution = std::numeric_limits<double>::max();   // sticky running minimum (never reset)
+  unsigned long long vector_field_scaling_factor = 1;
+  std::map<unsigned long long, feature_point_t> discrete_critical_points;
+  ftkx_stats last_stats;
+};
+
+struct critical_point_tracker_2d_regular : public critical_point_tracker_regular {
+  explicit critical_point_tracker_2d_regular(int device_id = 0) : critical_point_tracker_regular(2, device_id) {}
+};
+struct critical_point_tracker_3d_regular : public critical_point_tracker_regular {
+  explicit critical_point_tracker_3d_regular(int device_id = 0) : critical_point_tracker_regular(3, device_id) {}
+};
+
+}  // namespace ftkx
+
+// C handles of the same class for non-C++ callers (ctypes, cgo, JNI ...).  Errors come back as FTKX_E_* codes.
+extern "C" {
+typedef struct ftkx_tracker ftkx_tracker;
+int  ftkx_tracker_create(ftkx_tracker **out, int nd, int device_id);
+void ftkx_tracker_destroy(ftkx_tracker *);
+int  ftkx_tracker_last_error(const ftkx_tracker *, char *buf, size_t n);
+int  ftkx_tracker_set_domain(ftkx_tracker *, const long long *starts, const long long *sizes);
+int  ftkx_tracker_set_array_domain(ftkx_tracker *, const long long *starts, const long long *sizes);
+int  ftkx_tracker_set_sources(ftkx_tracker *, int scalar, int vector, int jacobian, int jacobian_symmetric);
+int  ftkx_tracker_set_flags(ftkx_tracker *, int robust, int use_type_filter, unsigned type_filter, int compute_degrees, int exact_only, int tag_mode);
+int  ftkx_tracker_set_stream(ftkx_tracker *, void *hip_stream);
+int  ftkx_tracker_initialize(ftkx_tracker *);
+int  ftkx_tracker_push_scalar_field_snapshot(ftkx_tracker *, const double *s, int on_device);
+int  ftkx_tracker_push_vector_field_snapshot(ftkx_tracker *, const double *v, int on_device);
+int  ftkx_tracker_push_field_data_snapshot(ftkx_tracker *, const double *s, const double *v, const double *j, int on_device);
+int  ftkx_tracker_advance_timestep(ftkx_tracker *);
+int  ftkx_tracker_update_timestep(ftkx_tracker *);
+int  ftkx_tracker_num_critical_points(const ftkx_tracker *, size_t *n);
+/* copies up to cap records; ordinal[i], timestep[i] nullable */
+int  ftkx_tracker_get_critical_points(const ftkx_tracker *, ftkx_cp_t *out, int *ordinal, int *timestep, size_t cap);
+int  ftkx_tracker_get_scaling(const ftkx_tracker *, unsigned long long *factor, double *resolution);
+int  ftkx_tracker_get_stats(const ftkx_tracker *, ftkx_stats *st);
+}
+#endif

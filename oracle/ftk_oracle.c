@@ -991,3 +991,16 @@ size_t ftko_track(const ftko_track_args *a, ftko_rec_t **out, unsigned long long
   *out = all.p ? all.p : (ftko_rec_t *)malloc(sizeof(ftko_rec_t));
   return all.n;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * hooks for unit tests of the per-simplex arithmetic (tests/test_host_numerics.py)
+ * ---------------------------------------------------------------------------------------------- */
+int ftko_hook_cp_in_simplex2(const long long *X, const int *idx) { return robust_cp_in_simplex2((const i64 (*)[2])X, idx); }
+int ftko_hook_cp_in_simplex3(const long long *X, const int *idx) { return robust_cp_in_simplex3((const i64 (*)[3])X, idx); }
+int ftko_hook_positive2(const long long *X, const int *idx) { return positive2((const i64 (*)[2])X, idx); }
+int ftko_hook_inverse_lerp2(const double *V, double *mu) { return inverse_lerp_s2v2((const double (*)[2])V, mu); }
+int ftko_hook_inverse_lerp3(const double *V, double *mu) { return inverse_lerp_s3v3((const double (*)[3])V, mu); }
+void ftko_hook_clamp(int n, double *x) { clamp_barycentric(n, x); }
+unsigned ftko_hook_type2(const double *J, int symmetric) { return cp_type_2d((const double (*)[2])J, symmetric); }
+unsigned ftko_hook_type3(const double *J, int symmetric) { return cp_type_3d((const double (*)[3])J, symmetric); }
+long long ftko_hook_quantize(double v, unsigned long long factor) { return quantize(v, factor); }

@@ -1,0 +1,43 @@
+// TEST INFRASTRUCTURE.  Compiles the product's per-simplex arithmetic (ftk_amd/csrc/cp_device.hpp, fan_tables.hpp) for the
+// HOST with g++ so that tests/test_host_numerics.py can compare it with the oracle on millions of random and degenerate
+// inputs without a GPU.  Nothing in the product loads this library; the same headers run on the device in the HIP kernels.
+#include "../../ftk_amd/csrc/cp_device.hpp"
+#include "../../ftk_amd/csrc/fan_tables.hpp"
+
+using namespace ftkx;
+
+extern "C" {
+
+int hc_origin_in_simplex2(const long long *X, const int *ids) { return origin_in_simplex2((const u64 (*)[2])X, ids); }
+int hc_origin_in_simplex3(const long long *X, const int *ids) { return origin_in_simplex3((const u64 (*)[3])X, ids); }
+int hc_sos_origin_in_simplex2(const long long *X, const int *ids) { return sos_origin_in_simplex<2>((const u64 (*)[2])X, ids); }
+int hc_sos_origin_in_simplex3(const long long *X, const int *ids) { return sos_origin_in_simplex<3>((const u64 (*)[3])X, ids); }
+int hc_orientation2(const long long *X, const int *ids) { return orientation2((const u64 (*)[2])X, ids); }
+int hc_solve2(const double *V, double *mu) { return solve_barycentric2((const double (*)[2])V, mu); }
+int hc_solve3(const double *V, double *mu) { return solve_barycentric3((const double (*)[3])V, mu); }
+void hc_clamp3(double *x) { clamp_barycentric<3>(x); }
+void hc_clamp4(double *x) { clamp_barycentric<4>(x); }
+unsigned hc_classify2(const double *J, int symmetric) { return classify2(J[0], J[1], J[2], J[3], symmetric != 0); }
+unsigned hc_classify3(const double *J, int symmetric) { return classify3((const double (*)[3])J, symmetric != 0); }
+long long hc_quantize(double v, double factor) { return quantize(v, factor); }
+
+// batch versions (python loops are slow)
+void hc_batch_in_simplex2(int n, const long long *X, const int *ids, int *out_fast, int *out_sos)
+{ for (int i = 0; i < n; i ++) { out_fast[i] = hc_origin_in_simplex2(X + 6 * i, ids + 3 * i); out_sos[i] = hc_sos_origin_in_simplex2(X + 6 * i, ids + 3 * i); } }
+void hc_batch_in_simplex3(int n, const long long *X, const int *ids, int *out_fast, int *out_sos)
+{ for (int i = 0; i < n; i ++) { out_fast[i] = hc_origin_in_simplex3(X + 12 * i, ids + 4 * i); out_sos[i] = hc_sos_origin_in_simplex3(X + 12 * i, ids + 4 * i); } }
+
+int hc_fan(int n, int *verts /* [ntypes][n][n] */, int *ordinal, int *ord_types, int *int_types)
+{
+  if (n == 3) {
+    for (int t = 0; t < 12; t ++) { ordinal[t] = k_fan3.ordinal[t]; for (int i = 0; i < 3; i ++) for (int a = 0; a < 3; a ++) verts[(t * 3 + i) * 3 + a] = (k_fan3.vert[t][i] >> a) & 1; }
+    for (int i = 0; i < 2; i ++) ord_types[i] = k_fan3.ord_types[i];
+    for (int i = 0; i < 10; i ++) int_types[i] = k_fan3.int_types[i];
+    return 12;
+  }
+  for (int t = 0; t < 60; t ++) { ordinal[t] = k_fan4.ordinal[t]; for (int i = 0; i < 4; i ++) for (int a = 0; a < 4; a ++) verts[(t * 4 + i) * 4 + a] = (k_fan4.vert[t][i] >> a) & 1; }
+  for (int i = 0; i < 6; i ++) ord_types[i] = k_fan4.ord_types[i];
+  for (int i = 0; i < 54; i ++) int_types[i] = k_fan4.int_types[i];
+  return 60;
+}
+}

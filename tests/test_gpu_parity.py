@@ -1,0 +1,145 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against
+  (a) the golden fixtures captured from the real reference CPU path (tests/golden), and
+  (b) the oracle on the same inputs.
+Bar: record sets identical; tag / type / ordinal / timestep exact; x, t, scalar within 1e-6 (north_star) -- and we additionally
+assert they are BIT-identical, which holds because the FP64 hit path uses the same IEEE operations in the same order."""
+import numpy as np
+import pytest
+
+from common import assert_records_equal, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+COORD_TOL = 1e-6   # BASELINE.json north_star: "within 1e-6 on interpolated (x,y,z,t)"
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import ftk_amd
+    from ftk_amd import build
+    build.build()
+    return ftk_amd
+
+
+@pytest.mark.parametrize("exact_only", [False, True], ids=["cull", "exact_only"])
+@pytest.mark.parametrize("name", golden_names())
+def test_tracker_matches_reference_fixture(gpu, name, exact_only):
+    from gpu_common import run_tracker
+    g = load_golden(name)
+    recs, factors, stats = run_tracker(g["steps"], g["nd"], g["nv"], robust=g["robust"], type_filter=g["type_filter"], exact_only=exact_only)
+    assert np.array_equal(factors, g["factors"]), "per-step quantisation factor differs from the reference"
+    assert_records_equal(recs, g["records"], coord_tol=COORD_TOL, what=name)
+    assert_records_equal(recs, g["records"], coord_tol=0.0, what=name + " (bit-exact)")
+    if exact_only:
+        assert all(s["cull_enabled"] == 0 for s in stats)
+
+
+@pytest.mark.parametrize("name", ["woven_31x37x32", "moving_extremum_3d_21x21x21x32", "random_3d_scalar_13x12x11x4"])
+def test_tracker_with_device_resident_input(gpu, name):
+    from gpu_common import run_tracker
+    g = load_golden(name)
+    recs, factors, _ = run_tracker(g["steps"], g["nd"], g["nv"], device=True)
+    assert_records_equal(recs, g["records"], coord_tol=0.0, what=name)
+
+
+def test_cull_is_actually_on_where_it_is_legal(gpu):
+    from gpu_common import run_tracker
+    g = load_golden("moving_extremum_3d_32x32x32x8_dyadic")
+    _, _, stats = run_tracker(g["steps"], 3, 1)
+    assert all(s["cull_enabled"] == 1 for s in stats)
+    assert sum(s["simplices_tested"] for s in stats) < 0.05 * sum(s["work_items"] for s in stats)
+    g = load_golden("moving_extremum_3d_21x21x21x4_overflow")     # nbits 21, M = 2^25: determinants wrap -> cull must be off
+    _, _, stats = run_tracker(g["steps"], 3, 1)
+    assert all(s["cull_enabled"] == 0 for s in stats)
+
+
+@pytest.mark.parametrize("name", ["woven_31x37x32", "double_gyre_64x32x50", "adversarial_2d_vector_15x12x5",
+                                  "moving_extremum_3d_12x10x9x5_aligned", "adversarial_3d_scalar_9x9x9x4", "adversarial_3d_vector_8x8x8x3"])
+def test_boundary_call_with_given_fields(gpu, oracle, name):
+    """extract_cp{2,3}dt with the reference boundary's argument list: host V/J/S given, tag = work index inside core."""
+    g = load_golden(name)
+    nd, nv, D = g["nd"], g["nv"], g["dims"]
+    lo = 2 if nv == 1 else 1
+    dom = ([lo] * nd, [d - (3 if nv == 1 else 2) for d in D])
+    fields = []
+    for k in (0, 1):
+        a = g["steps"][k]
+        if nv == 1:
+            V = oracle.gradient2D(a) if nd == 2 else oracle.gradient3D(a)
+            J = oracle.jacobian2D(V, True) if nd == 2 else oracle.jacobian3D(V)
+            fields.append((V, J, a))
+        else:
+            J = oracle.jacobian2D(a, False) if nd == 2 else oracle.jacobian3D(a)
+            fields.append((a, J, None))
+    res = min(oracle.resolution(fields[0][0]), oracle.resolution(fields[1][0]))
+    factor, _ = oracle.scaling_factor(res)
+    opt = gpu.default_options(jacobian_symmetric=(nv == 1), tag_mode=gpu.TAG_WORK_INDEX)
+    for scope in (gpu.SCOPE_ORDINAL, gpu.SCOPE_INTERVAL):
+        ref = oracle.sweep(nd, scope, 0, dom, dom, ([0] * nd, D), (fields[0][0], fields[1][0]), (fields[0][1], fields[1][1]),
+                           (fields[0][2], fields[1][2]) if nv == 1 else None, factor, jacobian_symmetric=(nv == 1),
+                           tag_mode=oracle.TAG_WORK_INDEX)
+        f = gpu.extract_cp2dt if nd == 2 else gpu.extract_cp3dt
+        nxt = scope == gpu.SCOPE_INTERVAL
+        got = f(scope, 0, (dom[0] + [0], dom[1] + [2 ** 31 - 1]), (dom[0] + [0], dom[1] + [1]), ([0] * nd, D),
+                fields[0][0], fields[1][0] if nxt else None, fields[0][1], fields[1][1] if nxt else None,
+                fields[0][2], fields[1][2] if nxt else None, factor, opt)
+        refr = np.zeros(len(ref), dtype=got.dtype)
+        for fld in ("x", "t", "scalar", "type", "tag"):
+            refr[fld] = ref[fld]
+        assert_records_equal(got, refr, coord_tol=0.0, what=f"{name} scope {scope}")
+        assert np.array_equal(got["aux"] & 1, np.full(len(got), 1 if scope == gpu.SCOPE_ORDINAL else 0))
+
+
+def test_derived_fields_bit_identical(gpu, oracle):
+    import torch
+    rng = np.random.default_rng(5)
+    ctx = gpu.Context(2)
+    S = rng.standard_normal((37, 53)); V = rng.standard_normal((37, 53, 2))
+    dS = torch.from_numpy(S).cuda(); dV = torch.empty((37, 53, 2), dtype=torch.float64, device="cuda")
+    ctx.gradient2D(dS.data_ptr(), 53, 37, dV.data_ptr())
+    assert np.array_equal(dV.cpu().numpy(), oracle.gradient2D(S))
+    for sym in (True, False):
+        dVin = torch.from_numpy(V).cuda(); dJ = torch.zeros((37, 53, 2, 2), dtype=torch.float64, device="cuda")
+        ctx.jacobian2D(dVin.data_ptr(), 53, 37, sym, dJ.data_ptr())
+        assert np.array_equal(dJ.cpu().numpy(), oracle.jacobian2D(V, sym)), f"jacobian2D symmetric={sym}"
+    ctx.close()
+    ctx = gpu.Context(3)
+    S = rng.standard_normal((11, 13, 17)); V = rng.standard_normal((11, 13, 17, 3))
+    dS = torch.from_numpy(S).cuda(); dV = torch.empty((11, 13, 17, 3), dtype=torch.float64, device="cuda")
+    ctx.gradient3D(dS.data_ptr(), 17, 13, 11, dV.data_ptr())
+    assert np.array_equal(dV.cpu().numpy(), oracle.gradient3D(S))
+    dVin = torch.from_numpy(V).cuda(); dJ = torch.empty((11, 13, 17, 3, 3), dtype=torch.float64, device="cuda")
+    ctx.jacobian3D(dVin.data_ptr(), 17, 13, 11, dJ.data_ptr())
+    assert np.array_equal(dJ.cpu().numpy(), oracle.jacobian3D(V))
+    ctx.close()
+
+
+def test_slice_resolution_matches_ndarray_resolution(gpu, oracle):
+    rng = np.random.default_rng(9)
+    V = rng.standard_normal((19, 23, 2)) * 10
+    V[3, 4, 0] = 0.0; V[5, 6, 1] = np.nan; V[7, 8, 0] = np.inf; V[9, 9, 1] = 1e-11; V[1, 1, 0] = -4e3
+    ctx = gpu.Context(2)
+    ctx.set_mesh(([1, 1], [21, 17]), ([1, 1], [21, 17]), ([0, 0], [23, 19]))
+    ctx.push_slice(0, V)
+    res, mx = ctx.slice_resolution(0)
+    assert res == oracle.resolution(V) == 1e-11
+    assert mx == 4e3
+    ctx.close()
+
+
+def test_error_behaviour(gpu):
+    ctx = gpu.Context(2)
+    with pytest.raises(gpu.FtkxError) as e:
+        ctx.push_slice(0, np.zeros((4, 4, 2)))
+    assert e.value.code == -1                 # set_mesh first
+    ctx.set_mesh(([1, 1], [2, 2]), ([1, 1], [2, 2]), ([0, 0], [4, 4]))
+    with pytest.raises(gpu.FtkxError) as e:
+        ctx.sweep(0, gpu.SCOPE_ORDINAL, 256)
+    assert e.value.code == -4                 # slice not resident
+    ctx.push_slice(0, np.ones((4, 4, 2)))
+    with pytest.raises(gpu.FtkxError):
+        ctx.sweep(0, gpu.SCOPE_INTERVAL, 256)  # needs slice 1
+    assert len(ctx.sweep(0, gpu.SCOPE_ORDINAL, 256)) == 0
+    ctx.close()
