@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: the critical-point space-time simplex sweep (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the sweep over the whole synthetic time series: every ordinal sweep and every interval sweep of the
+configured lattice, hit records downloaded to the host.  Inputs (scalar slices and the gradient field the tracker API derives
+from them at push time) are resident in HBM when the timed region starts; the quantisation-factor pre-pass (a device
+reduction per slice + one all_gather) is timed separately and reported as `prepass_ms`.  With N > 1 the lattice is cut into
+timestep slabs (ftk_amd/tslab.py): the halo exchange of the slab-boundary slice over RCCL happens INSIDE the timed region.
+Total work is fixed as N grows ("strong" scaling): N = 8 is BASELINE.json's `moving_extremum_3d 512^3 x 32, 8xMI355X` case.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (nd, nv, case, dims, nt)
+    "c4": (3, 1, "moving_extremum_3d", (512, 512, 512), 32),   # BASELINE configs[3]: the configuration the metric is quoted on
+    "c3": (3, 1, "moving_extremum_3d", (256, 256, 256), 16),   # configs[2]
+    "c2": (2, 1, "woven", (1024, 1024), 64),                   # configs[1]
+    "c1": (2, 1, "woven", (128, 128), 10),                     # configs[0]
+    "c5": (2, 2, "double_gyre", (2048, 1024), 128),            # configs[4]
+    "small3": (3, 1, "moving_extremum_3d", (96, 96, 96), 8),
+    "small2": (2, 1, "woven", (256, 256), 8),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def me3d_params(dims):
+    from ftk_amd import synthetic
+    x0, dv = synthetic.moving_extremum_params(dims)
+    return list(x0), list(dv)
+
+
+def cpu_baseline(nd, case, want_seconds=20.0):
+    """The reference CPU sweep (oracle/_ref, the real hguo/ftk code) -- or, if that binary did not travel, the oracle port --
+    timed on this box's host cores on a bounded sub-volume of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from ftk_amd import tslab
+    ncores = os.cpu_count() or 1
+    drv = os.path.join(ROOT, "oracle", "_ref", "ftk_ref_driver")
+    if nd == 3:
+        dims, nt = (64, 64, 64), 4
+        x0, dv = me3d_params(dims)
+        sample = f"moving_extremum_3d {dims[0]}x{dims[1]}x{dims[2]}x{nt} sub-volume, same dyadic x0 offset / dir"
+        extra = [repr(v) for v in x0 + dv]
+    else:
+        dims, nt = (192, 192), 8
+        sample = f"{case} {dims[0]}x{dims[1]}x{nt} sub-volume"
+        extra = []
+    nsimp = tslab.count_simplices(nd, dims, nt, scalar_input=(case != "double_gyre"))
+    out = {}
+    if os.path.exists(drv):
+        with tempfile.TemporaryDirectory() as tmp:
+            cmd = [drv, "synthetic", case, str(dims[0]), str(dims[1]), str(dims[2] if nd == 3 else 1), str(nt), os.path.join(tmp, "o.bin")] + extra
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True)
+                j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+                out = {"value": nsimp / j["sweep_seconds"], "unit": "simplices/s", "cores": int(j["nthreads"]), "kind": "reference",
+                       "sample": sample + f" ({nsimp} simplices in {j['sweep_seconds']:.2f} s; reference default nthreads = hardware_concurrency)"}
+            except Exception as e:   # noqa: BLE001
+                out = {}
+    # the oracle port (flat arrays, pthreads) on all cores, for orientation
+    try:
+        import pyoracle
+        steps = [pyoracle.synthetic(case, list(dims), k, nt, *(me3d_params(dims) if nd == 3 else (None, None))) for k in range(nt)]
+        _, _, secs = pyoracle.track(steps, nd, 2 if case == "double_gyre" else 1, nthreads=ncores)
+        port = {"value": nsimp / secs, "unit": "simplices/s", "cores": ncores, "kind": "port", "sample": sample}
+    except Exception as e:   # noqa: BLE001
+        port = None
+    if not out and port:
+        out, port = port, None
+    return out, port
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default=os.environ.get("FTKX_BENCH_CONFIG", "c4"), choices=sorted(CONFIGS))
+    ap.add_argument("--exact-only", action="store_true", help="disable the sign cull (every simplex takes the integer test)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ftk_amd
+    from ftk_amd import synthetic, tslab
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    nd, nv, case, dims, nt = CONFIGS[args.config]
+    scalar_input = nv == 1
+    t0_own, t1_own = tslab.slab_range(nt, world, rank)
+    own = list(range(t0_own, t1_own))
+
+    # ---- setup (untimed): generate the slab, push it (upload/adopt + derive V), pre-pass ----
+    # a real (non-null) HIP stream shared by torch and the library, so that the events below time the library's kernels
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = ftk_amd.Context(nd, local_rank)
+    ctx.set_stream(stream.cuda_stream)
+    lo = 2 if scalar_input else 1
+    dom = ([lo] * nd, [d - (3 if scalar_input else 2) for d in dims])
+    ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
+    ctx.set_options(jacobian_symmetric=scalar_input, derive_jacobian=1, tag_mode=ftk_amd.TAG_EXACT64, exact_only=args.exact_only)
+    slices = {}
+    for t in own:
+        slices[t] = synthetic.generate(case, dims, t, nt, torch, dev)
+        torch.cuda.synchronize()
+        (ctx.push_scalar_slice if scalar_input else ctx.push_slice)(t, slices[t])
+    halo_buf = torch.empty_like(slices[own[0]]) if (world > 1 and own) else None
+    torch.cuda.synchronize()
+
+    tp0 = time.perf_counter()
+    local_res = {t: ctx.slice_resolution(t)[0] for t in own}
+    if world > 1:
+        factors, _ = tslab.global_factors(local_res, nt)
+    else:
+        factors = tslab.factors_from_resolutions([local_res[t] for t in range(nt)])
+    torch.cuda.synchronize()
+    prepass_ms = (time.perf_counter() - tp0) * 1e3
+
+    ev_pairs = []
+
+    def one_pass(record_events):
+        have_halo = False
+        if world > 1 and own:
+            have_halo = tslab.exchange_halo(slices[own[0]], halo_buf, nt)
+            if have_halo:
+                (ctx.push_scalar_slice if scalar_input else ctx.push_slice)(t1_own, halo_buf)
+        for t in own:
+            scope = ftk_amd.SCOPE_BOTH if (t + 1 < nt) else ftk_amd.SCOPE_ORDINAL
+            if record_events:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            ctx.sweep_enqueue(t, scope, factors[t])
+            if record_events:
+                e1.record(stream)
+                ev_pairs.append((e0, e1))
+        recs = ctx.sweep_collect()
+        st = ctx.stats()
+        if have_halo:
+            ctx.drop_slice(t1_own)
+        return recs, st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        recs, st = one_pass(False)
+    barrier()
+    tt0 = time.perf_counter()
+    for _ in range(args.steps):
+        recs, st = one_pass(True)
+    barrier()
+    elapsed = time.perf_counter() - tt0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        agg = torch.tensor([float(len(recs)), float(st["simplices_tested"]), float(st["cells_survived"])], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        n_hits, n_tested, n_cells = (int(v) for v in agg.tolist())
+    else:
+        n_hits, n_tested, n_cells = len(recs), st["simplices_tested"], st["cells_survived"]
+
+    total_simplices = tslab.count_simplices(nd, dims, nt, scalar_input)
+    kernel_ms = [a.elapsed_time(b) for a, b in ev_pairs]
+
+    # sanity of the result itself (cheap, size-independent): the single extremum must sit on x0 + dir * t
+    check = {"hits": n_hits}
+    if case == "moving_extremum_3d" and len(recs):
+        x0, dv = me3d_params(dims)
+        err = max(float(np.abs(recs["x"][:, a] - (x0[a] + dv[a] * recs["t"])).max()) for a in range(3))
+        check["max_abs_position_error_vs_analytic"] = err
+        check["types"] = sorted(set(int(v) for v in recs["type"]))
+
+    if rank == 0:
+        n_vertex = int(np.prod(dims))
+        c = 1 if scalar_input else nd
+        launches_per_pass = len(own)
+        alg_bytes_launch = 8.0 * c * n_vertex + 72.0 * (len(recs) / max(1, launches_per_pass))
+        avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        achieved = alg_bytes_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get(args.config, {}).get("hbm_bytes_per_launch")
+            except Exception:   # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "space-time simplices/sec", "value": total_simplices * args.steps / elapsed, "unit": "simplices/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"{case} {'x'.join(str(d) for d in dims)}x{nt} ({args.config}), "
+                                   f"{'scalar' if scalar_input else 'vector'} input, t-slab partition over {world} GPU(s)",
+                       "simplices_per_step": total_simplices, "exact_only": bool(args.exact_only),
+                       "nbits": int(np.log2(max(factors))), "cull": bool(st["cull_enabled"]),
+                       "input_resident": "S and V=gradient(S) per slice in HBM; J derived at hits"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "ftkx::sweep_kernel<%d>" % nd, "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms),
+                         "algorithmic_bytes_per_launch": alg_bytes_launch},
+            "prepass_ms": prepass_ms,
+            "stats": {"simplices_tested_exactly": n_tested, "cells_survived_cull": n_cells},
+            "check": check,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, port = cpu_baseline(nd, case)
+            out["cpu_baseline"] = base
+            if port:
+                out["cpu_port"] = port
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -184,7 +184,9 @@ int ftkx_create(ftkx_ctx **out, int nd, int device_id)
   ftkx_default_options(&c->opt);
   memset(&c->stats, 0, sizeof(c->stats));
   HIP_TRY(c, hipSetDevice(device_id));
-  HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  // a blocking stream: it orders itself against the legacy default stream, which is where a caller that never heard of
+  // streams (and torch's default stream) puts its copies and fills
+  HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
   c->stream = c->own_stream;
   HIP_TRY(c, hipMalloc((void **)&c->d_counters, (ftkx::CNT_N + 2) * sizeof(u64)));
   HIP_TRY(c, hipMemset(c->d_counters, 0, (ftkx::CNT_N + 2) * sizeof(u64)));

@@ -1,0 +1,88 @@
+"""Multi-GPU host logic: the space-time lattice is cut into contiguous timestep slabs, one process per GPU.
+
+The reference only decomposes SPACE over MPI ranks (include/ftk/filters/regular_tracker.hh:127-149,
+include/ftk/mesh/lattice_partitioner.hh:97-196) and leaves time "uncuttable" (include/ftk/mesh/lattice.hh:32,59).  Every
+(timestep, scope) sweep is independent given slices t, t+1 and the scalar factor(t), so here rank r owns timesteps
+[r*nt/G, (r+1)*nt/G), sweeps ordinal(t) and interval[t, t+1] for each of them, and needs two things from its neighbours:
+  * the FIRST slice of rank r+1 (one point-to-point transfer over xGMI; no ring, no all-reduce);
+  * every slice's min|V != 0| -- an all_gather of nt doubles -- because the reference's quantisation factor is a sticky running
+    minimum over all slices pushed so far (include/ftk/filters/critical_point_tracker.hh:850-864): at the sweep of
+    current = c it is min over slices 0 .. min(c+1, nt-1).
+torch.distributed is the plumbing (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests)."""
+import math
+
+import numpy as np
+
+DBL_MAX = float(np.finfo(np.float64).max)
+
+
+def slab_range(nt, world, rank):
+    """timesteps [t0, t1) owned by `rank`: contiguous, sizes differ by at most one, empty slabs allowed when world > nt"""
+    return (rank * nt) // world, ((rank + 1) * nt) // world
+
+
+def owner_of(t, nt, world):
+    for r in range(world):
+        t0, t1 = slab_range(nt, world, r)
+        if t0 <= t < t1:
+            return r
+    raise ValueError(t)
+
+
+def scaling_factor(resolution, minbits=8, maxbits=21):
+    """critical_point_tracker.hh:850-864"""
+    nbits = int(math.ceil(math.log2(1.0 / resolution)))
+    return 1 << max(minbits, min(nbits, maxbits))
+
+
+def factors_from_resolutions(res):
+    """res[t] = ndarray::resolution() of slice t for ALL nt slices -> factor used by the sweep of current_timestep == t"""
+    nt = len(res)
+    run = np.minimum.accumulate(np.minimum(np.asarray(res, dtype=np.float64), DBL_MAX))
+    return [scaling_factor(float(run[min(t + 1, nt - 1)])) for t in range(nt)]
+
+
+def global_factors(local_res, nt, group=None):
+    """local_res: {t: resolution} of the slices this rank owns.  One all_gather of nt doubles (unowned entries = DBL_MAX,
+    combined with an elementwise min)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.full((nt,), DBL_MAX, dtype=torch.float64, device=dev)
+    for t, r in local_res.items():
+        mine[t] = r
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    res = torch.stack(gathered).min(dim=0).values.cpu().numpy()
+    return factors_from_resolutions(res), res
+
+
+def exchange_halo(first_slice, recv_buffer, nt, group=None):
+    """Each rank that owns timesteps sends its FIRST slice to the owner of the preceding timestep and receives the first
+    slice of the following slab into recv_buffer.  Returns True if recv_buffer was filled (i.e. this rank's slab is not
+    the last one).  Point-to-point only: xGMI is a mesh of links, a neighbour transfer uses one of them at full rate."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    t0, t1 = slab_range(nt, world, rank)
+    ops = []
+    got = False
+    if t1 > t0:
+        if t0 > 0:
+            ops.append(dist.P2POp(dist.isend, first_slice, owner_of(t0 - 1, nt, world), group))
+        if t1 < nt:
+            ops.append(dist.P2POp(dist.irecv, recv_buffer, owner_of(t1, nt, world), group))
+            got = True
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return got
+
+
+def count_simplices(nd, dims, nt, scalar_input=True):
+    """work items of the whole job: corners x (n_ord*nt + n_int*(nt-1))   (simplicial_regular_mesh.hh:1042)"""
+    n_ord, n_int = (2, 10) if nd == 2 else (6, 54)
+    corners = 1
+    for d in dims:
+        corners *= (d - 3) if scalar_input else (d - 2)
+    return corners * (n_ord * nt + n_int * (nt - 1))

@@ -35,6 +35,7 @@ def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=Fals
         a = steps[k]
         if device:
             a = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            torch.cuda.synchronize()
         (tr.push_scalar_field_snapshot if nv == 1 else tr.push_vector_field_snapshot)(a)
         if k != 0:
             tr.advance_timestep(); factors[cur] = tr.get_vector_field_scaling_factor(); stats.append(tr.get_last_stats()); cur += 1

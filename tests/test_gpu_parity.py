@@ -102,6 +102,7 @@ def test_derived_fields_bit_identical(gpu, oracle):
     assert np.array_equal(dV.cpu().numpy(), oracle.gradient2D(S))
     for sym in (True, False):
         dVin = torch.from_numpy(V).cuda(); dJ = torch.zeros((37, 53, 2, 2), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
         ctx.jacobian2D(dVin.data_ptr(), 53, 37, sym, dJ.data_ptr())
         assert np.array_equal(dJ.cpu().numpy(), oracle.jacobian2D(V, sym)), f"jacobian2D symmetric={sym}"
     ctx.close()
@@ -143,3 +144,20 @@ def test_error_behaviour(gpu):
         ctx.sweep(0, gpu.SCOPE_INTERVAL, 256)  # needs slice 1
     assert len(ctx.sweep(0, gpu.SCOPE_ORDINAL, 256)) == 0
     ctx.close()
+
+
+def test_device_generators_match_reference_generators(gpu, oracle):
+    """bench.py generates its inputs in HBM (ftk_amd/synthetic.py); moving_extremum with the dyadic bench parameters must be
+    bit-identical to the reference generator, the transcendental cases equal to rounding."""
+    import torch
+    from ftk_amd import synthetic
+    dev = torch.device("cuda", 0)
+    dims = (40, 36, 32)
+    x0, dv = synthetic.moving_extremum_params(dims)
+    for k in (0, 3, 7):
+        a = synthetic.generate("moving_extremum_3d", dims, k, 8, torch, dev).cpu().numpy()
+        assert np.array_equal(a, oracle.synthetic("moving_extremum_3d", list(dims), k, 8, x0, dv))
+    a = synthetic.generate("woven", (50, 41), 3, 9, torch, dev).cpu().numpy()
+    assert np.allclose(a, oracle.synthetic("woven", [50, 41], 3, 9), rtol=0, atol=1e-13)
+    a = synthetic.generate("double_gyre", (48, 24), 5, 9, torch, dev).cpu().numpy()
+    assert np.allclose(a, oracle.synthetic("double_gyre", [48, 24], 5, 9), rtol=0, atol=1e-13)

@@ -1,0 +1,86 @@
+"""Host logic of the t-slab partition; the world_size-2 tests run on CPU over gloo."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ftk_amd import tslab
+
+
+def test_slab_ranges_cover_time_exactly_once():
+    for nt in (1, 2, 5, 16, 32, 33):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                t0, t1 = tslab.slab_range(nt, world, r)
+                assert 0 <= t0 <= t1 <= nt
+                seen += list(range(t0, t1))
+            assert seen == list(range(nt))
+            for t in range(nt):
+                t0, t1 = tslab.slab_range(nt, world, tslab.owner_of(t, nt, world))
+                assert t0 <= t < t1
+
+
+def test_factor_sequence_reproduces_reference(oracle):
+    """the sticky running minimum must give the reference's per-step factors (fixtures come from the real reference)"""
+    from common import load_golden
+    for name in ("woven_31x37x32", "merger_2d_32x32x100", "woven_128x128x10", "random_2d_scalar_29x24x6"):
+        g = load_golden(name)
+        res = [oracle.resolution(oracle.gradient2D(s)) for s in g["steps"]]
+        assert tslab.factors_from_resolutions(res) == [int(f) for f in g["factors"]], name
+    assert tslab.scaling_factor(0.25) == oracle.scaling_factor(0.25)[0] == 256
+
+
+def test_simplex_count_matches_baseline_table():
+    assert tslab.count_simplices(2, (128, 128), 10) == 1718750
+    assert tslab.count_simplices(2, (1024, 1024), 64) == 790170278
+    assert tslab.count_simplices(3, (256, 256, 256), 16) == 16194277 * (6 * 16 + 54 * 15)
+    assert tslab.count_simplices(2, (2048, 1024), 128, scalar_input=False) == 2091012 * (2 * 128 + 10 * 127)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, nt, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t0, t1 = tslab.slab_range(nt, world, rank)
+        # slice t is filled with the value t; resolution of slice t is 1/(t+2)
+        slices = {t: torch.full((4, 5), float(t), dtype=torch.float64) for t in range(t0, t1)}
+        buf = torch.full((4, 5), -1.0, dtype=torch.float64)
+        got = tslab.exchange_halo(slices[t0] if t1 > t0 else buf, buf, nt)
+        halo = float(buf[0, 0]) if got else None
+        factors, res = tslab.global_factors({t: 1.0 / (t + 2) for t in range(t0, t1)}, nt)
+        q.put((rank, t0, t1, halo, factors, res.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nt", [5, 8])
+def test_halo_and_factor_exchange_world2_gloo(nt):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    expect_res = [1.0 / (t + 2) for t in range(nt)]
+    expect_f = tslab.factors_from_resolutions(expect_res)
+    for rank, t0, t1, halo, factors, res in out:
+        assert res == expect_res and factors == expect_f
+        if t1 < nt:
+            assert halo == float(t1)        # first slice of the next slab
+        else:
+            assert halo is None
