@@ -123,6 +123,20 @@ class Context:
         self._ck(self._L.ftkx_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in Stats._fields_}
 
+    KERNELS = ("mask_kernel", "cull_kernel", "exact_kernel", "tile_kernel")
+
+    def invalidate_masks(self):
+        self._ck(self._L.ftkx_invalidate_masks(self._h))
+
+    def set_profiling(self, on=True):
+        self._ck(self._L.ftkx_set_profiling(self._h, int(on)))
+
+    def kernel_times(self):
+        """{kernel: (summed device ms, launches)} measured with HIP events on the context's stream"""
+        ms = (C.c_double * 4)(); n = (C.c_ulonglong * 4)()
+        self._ck(self._L.ftkx_get_kernel_times(self._h, ms, n))
+        return {k: (ms[i], n[i]) for i, k in enumerate(self.KERNELS)}
+
     # derived fields on device tensors (ndarray/grad.hh)
     def gradient2D(self, S_ptr, DW, DH, V_ptr): self._ck(self._L.ftkx_gradient2D(self._h, S_ptr, DW, DH, V_ptr))
     def jacobian2D(self, V_ptr, DW, DH, symmetric, J_ptr): self._ck(self._L.ftkx_jacobian2D(self._h, V_ptr, DW, DH, int(symmetric), J_ptr))

@@ -22,6 +22,7 @@ struct fan_table {
   unsigned char ordinal[NTYPES];
   unsigned char ord_types[NORD];    // scope-local index -> type id (unit_ordinal_simplex_types)
   unsigned char int_types[NINT];    // unit_interval_simplex_types
+  unsigned char local_index[NTYPES];// inverse of the two lists: rank of a type inside its own scope (from_work_index, :480-493)
 };
 
 namespace detail {
@@ -67,8 +68,8 @@ constexpr fan_table<N> make_fan()
     for (int i = 0; i < N; i ++)
       if (f.vert[t][i] & (1u << (N - 1))) has_time = true;
     f.ordinal[t] = has_time ? 0 : 1;
-    if (has_time) f.int_types[ni ++] = (unsigned char)t;
-    else f.ord_types[no ++] = (unsigned char)t;
+    if (has_time) { f.local_index[t] = (unsigned char)ni; f.int_types[ni ++] = (unsigned char)t; }
+    else { f.local_index[t] = (unsigned char)no; f.ord_types[no ++] = (unsigned char)t; }
   }
   return f;
 }

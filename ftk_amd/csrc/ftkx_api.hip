@@ -18,8 +18,12 @@
 #include "sweep_params.hpp"
 
 namespace ftkx {
-void launch_sweep(const SweepParams &p, hipStream_t stream);
-void sweep_tile_dims(int nd, int tile[3]);
+void launch_tile(const TileParams &p, hipStream_t stream);
+void tile_dims(int nd, int tile[3]);
+void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream);
+void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream);
+void launch_exact(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, hipStream_t stream);
+void launch_resolution_scalar(const Mesh &m, const double *S, u64 *out2, hipStream_t stream);
 void launch_gradient2d(const double *S, int DW, int DH, double *V, hipStream_t st);
 void launch_jacobian2d(const double *V, int DW, int DH, int symmetric, double *J, hipStream_t st);
 void launch_gradient3d(const double *S, int DW, int DH, int DD, double *V, hipStream_t st);
@@ -27,7 +31,10 @@ void launch_jacobian3d(const double *V, int DW, int DH, int DD, double *J, hipSt
 void launch_resolution(const double *p, size_t n, u64 *out2, hipStream_t st);
 }  // namespace ftkx
 
-using ftkx::SweepParams;
+using ftkx::Fields;
+using ftkx::MaskJob;
+using ftkx::Mesh;
+using ftkx::TileParams;
 using ftkx::u64;
 
 namespace {
@@ -36,11 +43,16 @@ thread_local std::string g_last_error;
 
 struct Slice {
   double *V = nullptr, *J = nullptr, *S = nullptr;
+  unsigned char *M = nullptr;       // vertex sign masks, built lazily for `mask_factor`
   bool ownV = false, ownJ = false, ownS = false;
-  bool scalar_derived = false;      // V = gradient(S): J is derived the way jacobian2D<T, true> / jacobian3D would
+  unsigned long long mask_factor = 0;
   bool have_res = false;
   double res = 0, maxabs = 0;
 };
+
+struct Request { int t, scope; unsigned long long factor; bool fast; };
+
+enum { K_MASK = 0, K_CULL = 1, K_EXACT = 2, K_TILE = 3, K_N = 4 };
 
 }  // namespace
 
@@ -50,15 +62,26 @@ struct ftkx_ctx {
   ftkx_options opt;
   long long dom_st[3] = {0, 0, 0}, dom_sz[3] = {1, 1, 1}, core_st[3] = {0, 0, 0}, core_sz[3] = {1, 1, 1}, ext_st[3] = {0, 0, 0}, ext_sz[3] = {1, 1, 1};
   bool mesh_set = false;
+  int scalar_mode = -1;             // -1 undecided, 0 vector slices, 1 scalar slices (V = gradient(S) evaluated in flight)
   std::map<int, Slice> slices;
   ftkx_cp_t *d_hits = nullptr;
   u64 capacity = 0;
+  u64 *d_list = nullptr;            // surviving corners of the fast path
+  u64 list_capacity = 0;
   u64 *d_counters = nullptr;        // CNT_N counters + 2 words for the resolution reduction
   u64 *h_counters = nullptr;        // pinned
   ftkx_cp_t *h_hits = nullptr;      // pinned
   size_t h_cap = 0;
-  std::vector<SweepParams> pending;
+  // per-batch descriptors: pinned staging + device copies
+  void *h_desc = nullptr, *d_desc = nullptr;
+  size_t desc_cap = 0;
+  std::vector<Request> pending;
   ftkx_stats stats;
+  // optional kernel timing (hipEvents on the context's stream)
+  int profiling = 0;
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> events;
+  double k_ms[K_N] = {0, 0, 0, 0};
+  unsigned long long k_launches[K_N] = {0, 0, 0, 0};
   std::string err;
 };
 
@@ -90,11 +113,15 @@ size_t n_vertices(const ftkx_ctx *c)
   return n;
 }
 
+int mask_pitch(const ftkx_ctx *c) { return (int)(((c->ext_sz[0] + 7) / 8) * 8 + 8); }
+size_t mask_bytes(const ftkx_ctx *c) { return (size_t)mask_pitch(c) * (size_t)c->ext_sz[1] * (size_t)(c->nd == 3 ? c->ext_sz[2] : 1); }
+
 void free_slice(Slice &s)
 {
   if (s.ownV && s.V) (void)hipFree(s.V);
   if (s.ownJ && s.J) (void)hipFree(s.J);
   if (s.ownS && s.S) (void)hipFree(s.S);
+  if (s.M) (void)hipFree(s.M);
   s = Slice();
 }
 
@@ -104,6 +131,27 @@ int ensure_hit_buffer(ftkx_ctx *c, u64 want)
   if (c->d_hits) { HIP_TRY(c, hipFree(c->d_hits)); c->d_hits = nullptr; c->capacity = 0; }
   HIP_TRY(c, hipMalloc((void **)&c->d_hits, want * sizeof(ftkx_cp_t)));
   c->capacity = want;
+  return FTKX_OK;
+}
+
+int ensure_list(ftkx_ctx *c, u64 want)
+{
+  if (c->list_capacity >= want) return FTKX_OK;
+  if (c->d_list) { HIP_TRY(c, hipFree(c->d_list)); c->d_list = nullptr; c->list_capacity = 0; }
+  HIP_TRY(c, hipMalloc((void **)&c->d_list, want * sizeof(u64)));
+  c->list_capacity = want;
+  return FTKX_OK;
+}
+
+int ensure_desc(ftkx_ctx *c, size_t bytes)
+{
+  if (c->desc_cap >= bytes) return FTKX_OK;
+  if (c->h_desc) { HIP_TRY(c, hipHostFree(c->h_desc)); c->h_desc = nullptr; }
+  if (c->d_desc) { HIP_TRY(c, hipFree(c->d_desc)); c->d_desc = nullptr; }
+  const size_t cap = std::max<size_t>(bytes, 1 << 16);
+  HIP_TRY(c, hipHostMalloc(&c->h_desc, cap, hipHostMallocDefault));
+  HIP_TRY(c, hipMalloc(&c->d_desc, cap));
+  c->desc_cap = cap;
   return FTKX_OK;
 }
 
@@ -117,13 +165,40 @@ int ensure_host_buffer(ftkx_ctx *c, size_t want)
   return FTKX_OK;
 }
 
+void fill_mesh(const ftkx_ctx *c, Mesh &m)
+{
+  memset(&m, 0, sizeof(m));
+  const int nd = c->nd;
+  m.nd = nd;
+  for (int d = 0; d < 3; d ++) {
+    m.dom_lb[d] = (int)c->dom_st[d]; m.dom_ub[d] = (int)(c->dom_st[d] + c->dom_sz[d] - 1);
+    m.core_st[d] = (int)c->core_st[d]; m.core_sz[d] = (int)c->core_sz[d];
+    m.ext_st[d] = (int)c->ext_st[d]; m.ext_sz[d] = (int)c->ext_sz[d];
+  }
+  // lattice::prod_ of the mesh lattice (lattice.hh:156-167) and simplicial_regular_mesh::dimprod_ (int; simplicial_regular_mesh.hh:930-947)
+  m.mesh_prod[0] = 1; m.dimprod[0] = 1; m.exact_prod[0] = 1;
+  for (int d = 1; d <= nd; d ++) {
+    m.mesh_prod[d] = m.mesh_prod[d - 1] * (u64)c->dom_sz[d - 1];
+    m.exact_prod[d] = m.exact_prod[d - 1] * (u64)c->dom_sz[d - 1];
+    m.dimprod[d] = (int)((u64)c->dom_sz[d - 1] * (u64)(long long)m.dimprod[d - 1]);
+  }
+  m.mask_pitch = mask_pitch(c);
+  m.jacobian_symmetric = c->opt.jacobian_symmetric; m.robust = c->opt.robust;
+  m.use_type_filter = c->opt.use_type_filter; m.type_filter = c->opt.type_filter;
+  m.compute_degrees = c->opt.compute_degrees; m.tag_mode = c->opt.tag_mode;
+  m.scalar_mode = c->scalar_mode == 1;
+  m.derive_jacobian = c->opt.derive_jacobian;
+  m.hits = c->d_hits; m.counters = c->d_counters; m.capacity = c->capacity;
+}
+
 int slice_resolution(ftkx_ctx *c, Slice &s)
 {
   if (s.have_res) return FTKX_OK;
   u64 *d = c->d_counters + ftkx::CNT_N;
   const u64 init[2] = {0x7fefffffffffffffull, 0ull};
   HIP_TRY(c, hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-  ftkx::launch_resolution(s.V, n_vertices(c) * (size_t)c->nd, d, c->stream);
+  if (c->scalar_mode == 1) { Mesh m; fill_mesh(c, m); ftkx::launch_resolution_scalar(m, s.S, d, c->stream); }
+  else ftkx::launch_resolution(s.V, n_vertices(c) * (size_t)c->nd, d, c->stream);
   HIP_TRY(c, hipGetLastError());
   u64 out[2];
   HIP_TRY(c, hipMemcpyAsync(out, d, sizeof(out), hipMemcpyDeviceToHost, c->stream));
@@ -141,6 +216,108 @@ bool overflow_free(int nd, double maxabs, u64 factor)
   const long double M = floorl((long double)maxabs * (long double)factor) + 1.0L;
   const long double lim = 9223372036854775807.0L;
   return nd == 3 ? 24.0L * M * M * M < lim : 6.0L * M * M < lim;
+}
+
+void ev_begin(ftkx_ctx *c, int kind)
+{
+  if (!c->profiling) return;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  (void)hipEventRecord(a, c->stream);
+  c->events.push_back({kind, {a, b}});
+}
+void ev_end(ftkx_ctx *c)
+{
+  if (!c->profiling || c->events.empty()) return;
+  (void)hipEventRecord(c->events.back().second.second, c->stream);
+}
+void ev_harvest(ftkx_ctx *c)   // after a stream synchronise
+{
+  for (auto &e : c->events) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e.second.first, e.second.second) == hipSuccess) { c->k_ms[e.first] += ms; c->k_launches[e.first] ++; }
+    (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second);
+  }
+  c->events.clear();
+}
+
+// launches everything the pending requests need; counters must have been zeroed.
+// Fast-path requests are grouped into sub-batches (one mask / cull / exact launch each); a new sub-batch starts whenever a
+// slice's masks would be needed under a second quantisation factor (the factor is a running minimum, so it changes a few
+// times at the start of a series and then stays put).
+int run_batch(ftkx_ctx *c)
+{
+  Mesh m;
+  fill_mesh(c, m);
+  const int nd = c->nd;
+  struct Sub { std::vector<MaskJob> jobs; std::vector<Fields> steps; };
+  std::vector<Sub> subs(1);
+  std::vector<TileParams> tiles;
+  for (const Request &r : c->pending) {
+    Slice &s0 = c->slices[r.t];
+    Slice *s1 = (r.scope & FTKX_SCOPE_INTERVAL) ? &c->slices[r.t + 1] : nullptr;
+    Fields f;
+    memset(&f, 0, sizeof(f));
+    f.S[0] = s0.S; f.V[0] = s0.V; f.J[0] = s0.J;
+    if (s1) { f.S[1] = s1->S; f.V[1] = s1->V; f.J[1] = s1->J; }
+    f.factor = (double)r.factor; f.t = r.t; f.scope_mask = r.scope;
+    if (r.fast) {
+      for (Slice *s : {&s0, s1}) {
+        if (!s) continue;
+        if (!s->M) HIP_TRY(c, hipMalloc((void **)&s->M, mask_bytes(c)));
+        if (s->mask_factor != r.factor) {
+          // masks of this slice already (re)built or used in the current sub-batch under another factor -> close it
+          bool touched = false;
+          for (const MaskJob &j : subs.back().jobs) touched = touched || j.M == s->M;
+          for (const Fields &g : subs.back().steps) touched = touched || g.M[0] == s->M || g.M[1] == s->M;
+          if (touched) subs.emplace_back();
+          subs.back().jobs.push_back(MaskJob{s->S, s->V, s->M, 1.0 / (double)r.factor});
+          s->mask_factor = r.factor;
+        }
+      }
+      f.M[0] = s0.M; f.M[1] = s1 ? s1->M : nullptr;
+      subs.back().steps.push_back(f);
+    } else {
+      TileParams p;
+      p.m = m; p.f = f; p.cull = 0;
+      int tile[3];
+      ftkx::tile_dims(nd, tile);
+      for (int d = 0; d < 3; d ++) p.ntiles[d] = d < nd ? (int)((c->core_sz[d] + tile[d] - 1) / tile[d]) : 1;
+      tiles.push_back(p);
+    }
+  }
+  // one upload for all descriptors
+  size_t total = 0;
+  std::vector<std::pair<size_t, size_t>> offs;   // (jobs offset, steps offset) per sub-batch
+  for (const Sub &sb : subs) {
+    const size_t oj = total; total += (sb.jobs.size() * sizeof(MaskJob) + 255) / 256 * 256;
+    const size_t os = total; total += (sb.steps.size() * sizeof(Fields) + 255) / 256 * 256;
+    offs.push_back({oj, os});
+  }
+  if (total) {
+    int rc = ensure_desc(c, total);
+    if (rc) return rc;
+    for (size_t i = 0; i < subs.size(); i ++) {
+      if (!subs[i].jobs.empty()) memcpy((char *)c->h_desc + offs[i].first, subs[i].jobs.data(), subs[i].jobs.size() * sizeof(MaskJob));
+      if (!subs[i].steps.empty()) memcpy((char *)c->h_desc + offs[i].second, subs[i].steps.data(), subs[i].steps.size() * sizeof(Fields));
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_desc, c->h_desc, total, hipMemcpyHostToDevice, c->stream));
+  }
+  for (size_t i = 0; i < subs.size(); i ++) {
+    const Sub &sb = subs[i];
+    if (sb.steps.empty()) continue;
+    const MaskJob *d_jobs = (const MaskJob *)((char *)c->d_desc + offs[i].first);
+    const Fields *d_steps = (const Fields *)((char *)c->d_desc + offs[i].second);
+    if (!sb.jobs.empty()) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs, (int)sb.jobs.size(), c->stream); ev_end(c); }
+    // the survivor list is shared by the sub-batches of one collect: the exact kernel of sub-batch i must not re-test the
+    // survivors of sub-batch i-1, so each sub-batch gets its own list segment by resetting the list counter in between
+    if (i > 0) HIP_TRY(c, hipMemsetAsync(c->d_counters + ftkx::CNT_SURVIVOR_LIST, 0, sizeof(u64), c->stream));
+    ev_begin(c, K_CULL); ftkx::launch_cull(m, d_steps, (int)sb.steps.size(), c->d_list, c->list_capacity, c->stream); ev_end(c);
+    ev_begin(c, K_EXACT); ftkx::launch_exact(m, d_steps, c->d_list, c->list_capacity, c->stream); ev_end(c);
+  }
+  for (const TileParams &p : tiles) { ev_begin(c, K_TILE); ftkx::launch_tile(p, c->stream); ev_end(c); }
+  HIP_TRY(c, hipGetLastError());
+  return FTKX_OK;
 }
 
 }  // namespace
@@ -202,6 +379,9 @@ void ftkx_destroy(ftkx_ctx *c)
   (void)hipStreamSynchronize(c->stream);
   for (auto &kv : c->slices) free_slice(kv.second);
   if (c->d_hits) (void)hipFree(c->d_hits);
+  if (c->d_list) (void)hipFree(c->d_list);
+  if (c->d_desc) (void)hipFree(c->d_desc);
+  if (c->h_desc) (void)hipHostFree(c->h_desc);
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   if (c->h_hits) (void)hipHostFree(c->h_hits);
@@ -241,6 +421,7 @@ int ftkx_set_mesh(ftkx_ctx *c, const long long dst[3], const long long dsz[3], c
   }
   for (int d = c->nd; d < 3; d ++) { c->dom_st[d] = 0; c->dom_sz[d] = 1; c->core_st[d] = 0; c->core_sz[d] = 1; c->ext_st[d] = 0; c->ext_sz[d] = 1; }
   c->mesh_set = true;
+  c->scalar_mode = -1;
   return FTKX_OK;
 }
 
@@ -250,6 +431,10 @@ static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, con
   if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "push: call ftkx_set_mesh first");
   if (t < 0) return fail(c, FTKX_E_INVALID, "push: negative timestep");
   if (scalar_only ? !S : !V) return fail(c, FTKX_E_INVALID, "push: missing field pointer");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "push: sweeps pending, collect first");
+  if (c->slices.empty()) c->scalar_mode = -1;
+  if (c->scalar_mode >= 0 && c->scalar_mode != (scalar_only ? 1 : 0))
+    return fail(c, FTKX_E_INVALID, "push: scalar and vector slices cannot be mixed in one context");
   HIP_TRY(c, hipSetDevice(c->device));
   auto it = c->slices.find(t);
   if (it != c->slices.end()) { free_slice(it->second); c->slices.erase(it); }
@@ -266,19 +451,15 @@ static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, con
   };
   int rc;
   if ((rc = take(S, n, &s.S, &s.ownS))) return rc;
-  if (scalar_only) {
-    HIP_TRY(c, hipMalloc((void **)&s.V, n * nd * sizeof(double)));
-    s.ownV = true;
-    s.scalar_derived = true;
-    if (nd == 2) ftkx::launch_gradient2d(s.S, (int)c->ext_sz[0], (int)c->ext_sz[1], s.V, c->stream);
-    else ftkx::launch_gradient3d(s.S, (int)c->ext_sz[0], (int)c->ext_sz[1], (int)c->ext_sz[2], s.V, c->stream);
-    HIP_TRY(c, hipGetLastError());
-  } else {
+  if (!scalar_only) {
     if ((rc = take(V, n * nd, &s.V, &s.ownV))) return rc;
     if ((rc = take(J, n * nd * nd, &s.J, &s.ownJ))) return rc;
   }
+  // scalar input: V = gradient2D/3D(S) is never materialised -- every kernel evaluates it where it needs it, with the
+  // reference's exact operations (ndarray/grad.hh), so the slice costs 8 bytes per vertex of HBM instead of 8 + 8*nd.
   if (!on_device) HIP_TRY(c, hipStreamSynchronize(c->stream));   // host buffers may be reused by the caller on return
   c->slices[t] = s;
+  c->scalar_mode = scalar_only ? 1 : 0;
   return FTKX_OK;
 }
 
@@ -338,65 +519,31 @@ int ftkx_sweep_enqueue(ftkx_ctx *c, int t, int scope, unsigned long long factor)
     if (it1 == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "sweep: interval [%d, %d] needs slice %d", t, t + 1, t + 1);
     s1 = &it1->second;
   }
-  HIP_TRY(c, hipSetDevice(c->device));
-  const int nd = c->nd;
-  SweepParams p;
-  memset(&p, 0, sizeof(p));
-  p.nd = nd; p.scope_mask = scope; p.t = t;
-  int tile[3];
-  ftkx::sweep_tile_dims(nd, tile);
-  u64 cells = 1;
-  for (int d = 0; d < 3; d ++) {
-    p.dom_lb[d] = (int)c->dom_st[d]; p.dom_ub[d] = (int)(c->dom_st[d] + c->dom_sz[d] - 1);
-    p.core_st[d] = (int)c->core_st[d]; p.core_sz[d] = (int)c->core_sz[d];
-    p.ext_st[d] = (int)c->ext_st[d]; p.ext_sz[d] = (int)c->ext_sz[d];
-    p.ntiles[d] = d < nd ? (int)((c->core_sz[d] + tile[d] - 1) / tile[d]) : 1;
-    if (d < nd) cells *= (u64)c->core_sz[d];
-  }
-  // lattice::prod_ of the mesh lattice (lattice.hh:156-167) and simplicial_regular_mesh::dimprod_ (int; simplicial_regular_mesh.hh:930-947)
-  p.mesh_prod[0] = 1; p.dimprod[0] = 1; p.exact_prod[0] = 1;
-  for (int d = 1; d <= nd; d ++) {
-    p.mesh_prod[d] = p.mesh_prod[d - 1] * (u64)c->dom_sz[d - 1];
-    p.exact_prod[d] = p.exact_prod[d - 1] * (u64)c->dom_sz[d - 1];
-    p.dimprod[d] = (int)((u64)c->dom_sz[d - 1] * (u64)(long long)p.dimprod[d - 1]);
-  }
-  p.V[0] = s0->V; p.J[0] = s0->J; p.S[0] = s0->S;
-  if (s1) { p.V[1] = s1->V; p.J[1] = s1->J; p.S[1] = s1->S; }
   if (s1 && ((s0->J == nullptr) != (s1->J == nullptr) || (s0->S == nullptr) != (s1->S == nullptr)))
     return fail(c, FTKX_E_INVALID, "sweep: slices %d and %d disagree on which of J / S are given", t, t + 1);
-  p.factor = (double)factor;
-  p.jacobian_symmetric = c->opt.jacobian_symmetric; p.robust = c->opt.robust;
-  p.use_type_filter = c->opt.use_type_filter; p.type_filter = c->opt.type_filter;
-  p.compute_degrees = c->opt.compute_degrees; p.tag_mode = c->opt.tag_mode;
-  p.derive_jacobian = (s0->J == nullptr) && c->opt.derive_jacobian;
-  p.jac_symmetric_derive = s0->scalar_derived ? 1 : 0;
+  for (int d = 0; d < c->nd; d ++)
+    if (c->core_sz[d] == 0) return FTKX_OK;    // empty core: nothing to enumerate
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int nd = c->nd;
 
-  // cull legality
-  int cull = 0;
+  // Is the strict-sign cull legal?  Only with the robust integer test and only while no determinant can leave int64.
+  bool fast = false;
   if (!c->opt.exact_only && (nd == 2 || c->opt.robust)) {
     int rc = slice_resolution(c, *s0);
     if (rc) return rc;
     double mx = s0->maxabs;
     if (s1) { if ((rc = slice_resolution(c, *s1))) return rc; mx = std::max(mx, s1->maxabs); }
-    cull = overflow_free(nd, mx, factor) ? 1 : 0;
+    fast = overflow_free(nd, mx, factor);
   }
-  p.cull = cull;
+  if (c->pending.empty()) memset(&c->stats, 0, sizeof(c->stats));
+  c->pending.push_back(Request{t, scope, factor, fast});
 
-  if (c->pending.empty()) {
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, ftkx::CNT_N * sizeof(u64), c->stream));
-    memset(&c->stats, 0, sizeof(c->stats));
-    int rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16));
-    if (rc) return rc;
-  }
-  p.hits = c->d_hits; p.counters = c->d_counters; p.capacity = c->capacity;
-  ftkx::launch_sweep(p, c->stream);
-  HIP_TRY(c, hipGetLastError());
-  c->pending.push_back(p);
-
+  u64 cells = 1;
+  for (int d = 0; d < nd; d ++) cells *= (u64)c->core_sz[d];
   const u64 n_ord = nd == 2 ? 2 : 6, n_int = nd == 2 ? 10 : 54;
   c->stats.cells += cells;
   c->stats.work_items += cells * (((scope & 1) ? n_ord : 0) + ((scope & 2) ? n_int : 0));
-  c->stats.cull_enabled = cull;
+  c->stats.cull_enabled = fast ? 1 : 0;
   return FTKX_OK;
 }
 
@@ -407,29 +554,33 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
   if (out) *out = nullptr;
   if (n_out) *n_out = 0;
   if (c->pending.empty()) return FTKX_OK;
-  for (int attempt = 0; attempt < 2; attempt ++) {
+  int rc;
+  if ((rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16)))) { c->pending.clear(); return rc; }
+  bool any_fast = false;
+  for (const Request &r : c->pending) any_fast = any_fast || r.fast;
+  if (any_fast && (rc = ensure_list(c, std::max<u64>(c->list_capacity, 1u << 20)))) { c->pending.clear(); return rc; }
+  for (int attempt = 0; ; attempt ++) {
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, ftkx::CNT_N * sizeof(u64), c->stream));
+    if ((rc = run_batch(c))) { c->pending.clear(); return rc; }
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, ftkx::CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const u64 hits = c->h_counters[ftkx::CNT_HITS];
-    if (hits <= c->capacity) break;
-    if (attempt == 1) { c->pending.clear(); return fail(c, FTKX_E_DEVICE, "hit buffer overflow persisted after regrow"); }
-    // the buffer was too small: grow to what this batch needs and replay it (records beyond capacity were only counted)
-    int rc = ensure_hit_buffer(c, hits + hits / 8 + 1024);
-    if (rc) { c->pending.clear(); return rc; }
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, ftkx::CNT_N * sizeof(u64), c->stream));
-    for (auto &p : c->pending) {
-      p.hits = c->d_hits; p.capacity = c->capacity;
-      ftkx::launch_sweep(p, c->stream);
-    }
-    HIP_TRY(c, hipGetLastError());
+    const u64 hits = c->h_counters[ftkx::CNT_HITS], listed = c->h_counters[ftkx::CNT_LIST_PEAK];
+    if (hits <= c->capacity && listed <= c->list_capacity) { ev_harvest(c); break; }
+    // a buffer was too small (records / survivors beyond capacity were only counted): grow to what this batch needs, replay it
+    for (auto &e : c->events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    c->events.clear();
+    if (attempt == 2) { c->pending.clear(); return fail(c, FTKX_E_DEVICE, "buffer overflow persisted after regrowing twice"); }
+    if (listed > c->list_capacity && (rc = ensure_list(c, listed + listed / 8 + 1024))) { c->pending.clear(); return rc; }
+    // with a truncated survivor list the hit count is a lower bound: leave generous room
+    const u64 want_hits = std::max<u64>(hits + hits / 8 + 1024, listed > c->list_capacity ? 2 * hits + 1024 : 0);
+    if (want_hits > c->capacity && (rc = ensure_hit_buffer(c, want_hits))) { c->pending.clear(); return rc; }
   }
   c->pending.clear();
   const size_t n = (size_t)c->h_counters[ftkx::CNT_HITS];
   c->stats.hits = n;
   c->stats.cells_survived = c->h_counters[ftkx::CNT_CELLS_SURVIVED];
   c->stats.simplices_tested = c->h_counters[ftkx::CNT_SIMPLICES_TESTED];
-  int rc = ensure_host_buffer(c, n);
-  if (rc) return rc;
+  if ((rc = ensure_host_buffer(c, n))) return rc;
   if (n) {
     HIP_TRY(c, hipMemcpyAsync(c->h_hits, c->d_hits, n * sizeof(ftkx_cp_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -454,6 +605,29 @@ int ftkx_get_stats(const ftkx_ctx *c, ftkx_stats *st)
 {
   if (!c || !st) return fail(nullptr, FTKX_E_INVALID, "null argument");
   *st = c->stats;
+  return FTKX_OK;
+}
+
+int ftkx_invalidate_masks(ftkx_ctx *c)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_invalidate_masks: sweeps pending, collect first");
+  for (auto &kv : c->slices) kv.second.mask_factor = 0;
+  return FTKX_OK;
+}
+
+int ftkx_set_profiling(ftkx_ctx *c, int on)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  c->profiling = on != 0;
+  for (int k = 0; k < K_N; k ++) { c->k_ms[k] = 0; c->k_launches[k] = 0; }
+  return FTKX_OK;
+}
+
+int ftkx_get_kernel_times(const ftkx_ctx *c, double ms[4], unsigned long long launches[4])
+{
+  if (!c || !ms || !launches) return fail(nullptr, FTKX_E_INVALID, "null argument");
+  for (int k = 0; k < K_N; k ++) { ms[k] = c->k_ms[k]; launches[k] = c->k_launches[k]; }
   return FTKX_OK;
 }
 

@@ -6,18 +6,22 @@
 // and what its CUDA back-end does with one thread per simplex and a global atomic per hit
 //   (src/filters/critical_point_tracer_{2d,3d}_regular.cu).
 //
-// Structure of one launch (one workgroup of 256 lanes = 4 wavefronts per tile of lattice corners):
-//   1. stage   the (TX+1)x(TY+1)x(TZ+1) vertex block of slice t (and t+1) is read from HBM once, quantised to int64
-//              and parked in LDS together with one classification byte per vertex;
-//   2. cull    each lane owns one corner: if some vector component has the same strict sign on every vertex of the
-//              corner's space-time hypercube, none of its 12/60 simplices can contain the origin (legal only while no
-//              determinant can overflow int64 -- the host decides, SweepParams::cull); surviving corners are
-//              ballot-compacted into an LDS work list;
-//   3. test    the (surviving corner x simplex type) pairs are spread over all 256 lanes; each pair reads its d+1
-//              vertices from LDS, repeats the cull per simplex, then runs the exact integer predicate (cp_device.hpp);
-//   4. emit    hits -- a fraction of a percent -- gather FP64 inputs from HBM, solve, classify, and are appended to the
-//              device hit buffer with one wave-aggregated atomic per wavefront.
-// No MFMA: this is a stencil of 64-bit integer VALU work on 8-24 bytes per vertex, bounded by HBM once the cull applies.
+// Two paths, chosen by the host per request (ftkx_api.hip):
+//
+// FAST PATH (robust test, no int64 overflow possible -> the strict-sign cull is exact):
+//   mask_kernel    streams a slice once (S, 8 B/vertex, gradient evaluated in flight -- or V for vector input) and writes one
+//                  byte per vertex: which components are strictly positive / strictly negative after quantisation;
+//   cull_kernel    streams the mask bytes of slices t and t+1 (2 B/vertex): 8 corners per lane as one 64-bit word, the AND
+//                  over the 2^(d+1) hypercube vertices done with shifts (SWAR); a corner whose AND is non-zero has a component
+//                  of uniform strict sign, none of its 12/60 simplices can contain the origin; survivors are appended to a
+//                  work list with one atomic per wavefront (prefix sum across lanes);
+//   exact_kernel   persistent workgroups pull chunks of surviving corners, stage each corner's 2^(d+1) quantised vertices in
+//                  LDS once, and spread the (corner x simplex type) pairs over all lanes: per-simplex cull, exact integer
+//                  predicate (cp_device.hpp), FP64 solve + classification for hits, ballot-compacted append.
+// TILE PATH (exact_only, non-robust 3D, or determinants that may wrap): one workgroup per tile of corners stages the tile's
+//   vertex block in LDS and tests every simplex (optionally with the same cull); used as-is when the cull is illegal.
+//
+// No MFMA: 64-bit integer VALU work on 8-24 bytes per vertex, HBM-bound once the cull applies.
 #include <hip/hip_runtime.h>
 
 #include "cp_device.hpp"
@@ -36,89 +40,175 @@ template <> struct tile_cfg<3> { static constexpr int TX = 16, TY = 4, TZ = 4; }
 constexpr int kThreads = 256;
 constexpr unsigned char kInvalid = 0x80;    // vertex outside the domain / array
 constexpr unsigned char kNonFinite = 0x40;  // NaN or Inf component: the reference rejects the simplex (2d:611, 3d:457)
+constexpr unsigned char kNeutral = 0x3f;    // cull-neutral mask byte (all six sign bits set)
 
 template <int ND> __device__ inline const fan_table<ND + 1> &dev_fan();
 template <> __device__ inline const fan_table<3> &dev_fan<2>() { return c_fan3; }
 template <> __device__ inline const fan_table<4> &dev_fan<3>() { return c_fan4; }
 
 // ---------------------------------------------------------------------------------------------------------------
-// hit path (rare): everything in FP64 from HBM
+// field access.  Array coordinates (i, j, k) are relative to ext_st.
 // ---------------------------------------------------------------------------------------------------------------
+__device__ inline int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
+
 template <int ND>
-__device__ inline size_t ext_index(const SweepParams &p, const int *vx)
+__device__ inline size_t arr_index(const Mesh &m, int i, int j, int k)
 {
-  size_t idx = (size_t)(vx[0] - p.ext_st[0]);
-  size_t stride = (size_t)p.ext_sz[0];
-  for (int d = 1; d < ND; d ++) { idx += (size_t)(vx[d] - p.ext_st[d]) * stride; stride *= (size_t)p.ext_sz[d]; }
+  size_t idx = (size_t)i + (size_t)m.ext_sz[0] * (size_t)j;
+  if (ND == 3) idx += (size_t)m.ext_sz[0] * (size_t)m.ext_sz[1] * (size_t)k;
   return idx;
 }
 
-__device__ inline int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
-
-// J at one vertex, derived from V exactly like ndarray/grad.hh (jacobian2D 54-86 incl. its operator precedence, jacobian3D
-// 175-212 incl. its interior-only support); Js[j][k] = J(k, j, vertex) as the trackers read it (2d:566-582, 3d:405-422)
+// gradient2D / gradient3D of ndarray/grad.hh at one vertex, the same FP64 operations in the same order:
+//   2D (grad.hh:17-28): indices clamped to the array, no 0.5, scaled by (D-1);  3D (grad.hh:138-146): 0.5 * central difference
+//   on interior vertices only, the array border stays 0.
 template <int ND>
-__device__ inline void derive_jacobian_at(const SweepParams &p, const double *V, const int *vx, double Js[ND][ND])
+__device__ inline void gradient_at(const Mesh &m, const double *__restrict__ S, int i, int j, int k, double g[ND])
 {
-  const int DW = p.ext_sz[0], DH = p.ext_sz[1];
-  const int i = vx[0] - p.ext_st[0], j = vx[1] - p.ext_st[1];
+  const int DW = m.ext_sz[0], DH = m.ext_sz[1];
   if constexpr (ND == 2) {
-    auto f = [&](int c, int a, int b) { return V[(size_t)c + 2 * ((size_t)clampi(a, 0, DW - 1) + (size_t)DW * (size_t)clampi(b, 0, DH - 1))]; };
-    const double H00 = f(0, i + 1, j) - f(0, i - 1, j) * (DW - 1),
-                 H01 = f(0, i, j + 1) - f(0, i, j - 1) * (DH - 1),
-                 H10 = f(1, i + 1, j) - f(1, i - 1, j) * (DW - 1),
-                 H11 = f(1, i, j + 1) - f(1, i, j - 1) * (DH - 1);
+    const int ip = clampi(i + 1, 0, DW - 1), im = clampi(i - 1, 0, DW - 1), jp = clampi(j + 1, 0, DH - 1), jm = clampi(j - 1, 0, DH - 1);
+    const int ic = clampi(i, 0, DW - 1), jc = clampi(j, 0, DH - 1);
+    g[0] = (S[(size_t)ip + (size_t)DW * jc] - S[(size_t)im + (size_t)DW * jc]) * (double)(DW - 1);
+    g[1] = (S[(size_t)ic + (size_t)DW * jp] - S[(size_t)ic + (size_t)DW * jm]) * (double)(DH - 1);
+  } else {
+    const int DD = m.ext_sz[2];
+    if (i >= 1 && i < DW - 1 && j >= 1 && j < DH - 1 && k >= 1 && k < DD - 1) {
+      const size_t sy = (size_t)DW, sz = (size_t)DW * DH, c = (size_t)i + sy * j + sz * k;
+      g[0] = 0.5 * (S[c + 1] - S[c - 1]);
+      g[1] = 0.5 * (S[c + sy] - S[c - sy]);
+      g[2] = 0.5 * (S[c + sz] - S[c - sz]);
+    } else { g[0] = 0.0; g[1] = 0.0; g[2] = 0.0; }
+  }
+}
+
+// the vector field at array coordinates: stored V, or gradient(S) when the vector field is derived
+template <int ND>
+__device__ inline void vector_at(const Mesh &m, const double *S, const double *V, int i, int j, int k, double v[ND])
+{
+  if (m.scalar_mode) gradient_at<ND>(m, S, i, j, k, v);
+  else {
+    const size_t at = arr_index<ND>(m, i, j, k) * ND;
+    for (int c = 0; c < ND; c ++) v[c] = V[at + c];
+  }
+}
+
+// J at one vertex, derived from V exactly like ndarray/grad.hh (jacobian2D 54-86 incl. its operator precedence and clamped
+// indices, jacobian3D 175-212 incl. its interior-only support); Js[j][k] = J(k, j, vertex) as the trackers read it.
+template <int ND>
+__device__ inline void derive_jacobian_at(const Mesh &m, const double *S, const double *V, int i, int j, int k, double Js[ND][ND])
+{
+  const int DW = m.ext_sz[0], DH = m.ext_sz[1];
+  if constexpr (ND == 2) {
+    double xp[2], xm[2], yp[2], ym[2];
+    const int ic = clampi(i, 0, DW - 1), jc = clampi(j, 0, DH - 1);
+    vector_at<2>(m, S, V, clampi(i + 1, 0, DW - 1), jc, 0, xp);
+    vector_at<2>(m, S, V, clampi(i - 1, 0, DW - 1), jc, 0, xm);
+    vector_at<2>(m, S, V, ic, clampi(j + 1, 0, DH - 1), 0, yp);
+    vector_at<2>(m, S, V, ic, clampi(j - 1, 0, DH - 1), 0, ym);
+    const double H00 = xp[0] - xm[0] * (double)(DW - 1), H01 = yp[0] - ym[0] * (double)(DH - 1),
+                 H10 = xp[1] - xm[1] * (double)(DW - 1), H11 = yp[1] - ym[1] * (double)(DH - 1);
     Js[0][0] = H00;
     Js[1][1] = H11;
-    // symmetric instantiation stores the mean in both off-diagonals; the other one leaves them 0 (grad.hh:79-82)
-    Js[0][1] = Js[1][0] = p.jac_symmetric_derive ? (H01 + H10) * 0.5 : 0.0;
+    // jacobian2D<T, true> (scalar input) stores the mean in both off-diagonals; <T, false> leaves them 0 (grad.hh:79-82)
+    Js[0][1] = Js[1][0] = m.scalar_mode ? (H01 + H10) * 0.5 : 0.0;
   } else {
-    const int DD = p.ext_sz[2];
-    const int k = vx[2] - p.ext_st[2];
+    const int DD = m.ext_sz[2];
     const bool interior = i >= 2 && i < DW - 2 && j >= 2 && j < DH - 2 && k >= 2 && k < DD - 2;
-    auto f = [&](int c, int a, int b, int d) { return V[(size_t)c + 3 * ((size_t)a + (size_t)DW * ((size_t)b + (size_t)DH * (size_t)d))]; };
-    for (int a = 0; a < 3; a ++) {
-      // J(a, b) = 0.5 * (V_a(x + e_b) - V_a(x - e_b));  Js[j][k] = J(k, j)
-      Js[0][a] = interior ? 0.5 * (f(a, i + 1, j, k) - f(a, i - 1, j, k)) : 0.0;
-      Js[1][a] = interior ? 0.5 * (f(a, i, j + 1, k) - f(a, i, j - 1, k)) : 0.0;
-      Js[2][a] = interior ? 0.5 * (f(a, i, j, k + 1) - f(a, i, j, k - 1)) : 0.0;
-    }
+    if (!interior) { for (int a = 0; a < 3; a ++) for (int b = 0; b < 3; b ++) Js[a][b] = 0.0; return; }
+    double p[3], q[3];
+    // J(a, b) = 0.5 * (V_a(x + e_b) - V_a(x - e_b));  Js[b][a] = J(a, b)
+    vector_at<3>(m, S, V, i + 1, j, k, p); vector_at<3>(m, S, V, i - 1, j, k, q);
+    for (int a = 0; a < 3; a ++) Js[0][a] = 0.5 * (p[a] - q[a]);
+    vector_at<3>(m, S, V, i, j + 1, k, p); vector_at<3>(m, S, V, i, j - 1, k, q);
+    for (int a = 0; a < 3; a ++) Js[1][a] = 0.5 * (p[a] - q[a]);
+    vector_at<3>(m, S, V, i, j, k + 1, p); vector_at<3>(m, S, V, i, j, k - 1, q);
+    for (int a = 0; a < 3; a ++) Js[2][a] = 0.5 * (p[a] - q[a]);
   }
+}
+
+template <int ND>
+__device__ inline bool vertex_usable(const Mesh &m, const int *vx)
+{
+  bool ok = true;
+  for (int d = 0; d < ND; d ++)
+    ok = ok && vx[d] >= m.dom_lb[d] && vx[d] <= m.dom_ub[d] && vx[d] >= m.ext_st[d] && vx[d] < m.ext_st[d] + m.ext_sz[d];
+  return ok;
+}
+
+// quantised vertex + classification byte (bits 0..2 strictly positive, 3..5 strictly negative, kNonFinite, kInvalid)
+template <int ND>
+__device__ inline unsigned char classify_vertex(const Mesh &m, const double *S, const double *V, double factor, const int *vx, i64 q[ND])
+{
+  for (int j = 0; j < ND; j ++) q[j] = 0;
+  if (!vertex_usable<ND>(m, vx)) return kInvalid;
+  double v[ND];
+  vector_at<ND>(m, S, V, vx[0] - m.ext_st[0], vx[1] - m.ext_st[1], ND == 3 ? vx[2] - m.ext_st[2] : 0, v);
+  unsigned char mk = 0;
+  for (int j = 0; j < ND; j ++) {
+    if (isnan(v[j]) || isinf(v[j])) mk |= kNonFinite;
+    q[j] = quantize(v[j], factor);
+    if (q[j] > 0) mk |= (unsigned char)(1u << j);
+    if (q[j] < 0) mk |= (unsigned char)(8u << j);
+  }
+  return mk;
 }
 
 // e.to_integer(m), mesh/simplicial_regular_mesh.hh:496-502
 template <int ND>
-__device__ inline u64 element_tag(const SweepParams &p, const int *corner /*ND spatial + time*/, int type, u64 work_index)
+__device__ inline u64 element_tag(const Mesh &m, const int *corner /*ND spatial + time*/, int type, u64 work_index)
 {
   constexpr int N = ND + 1;
   constexpr int ntypes_all = fan_table<N>::NTYPES;
-  if (p.tag_mode == FTKX_TAG_WORK_INDEX) return work_index;
+  if (m.tag_mode == FTKX_TAG_WORK_INDEX) return work_index;
   u64 ci = 0;
   for (int i = 0; i < N; i ++) {
-    const int rel = corner[i] - (i < ND ? p.dom_lb[i] : 0);
-    if (p.tag_mode == FTKX_TAG_REFERENCE) ci += (u64)(i64)(int)((unsigned)rel * (unsigned)p.dimprod[i]);   // int * int, wraps
-    else ci += (u64)(i64)rel * p.exact_prod[i];
+    const int rel = corner[i] - (i < ND ? m.dom_lb[i] : 0);
+    if (m.tag_mode == FTKX_TAG_REFERENCE) ci += (u64)(i64)(int)((unsigned)rel * (unsigned)m.dimprod[i]);   // int * int, wraps
+    else ci += (u64)(i64)rel * m.exact_prod[i];
   }
   return ci * (u64)ntypes_all + (u64)type;
 }
 
-// returns false when the 2D type filter drops the record
+// SoS vertex id: m.get_lattice().to_integer(vertex) truncated to int (regular_tracker.hh:188-194, lattice.hh:196-207)
 template <int ND>
-__device__ __noinline__ bool make_record(const SweepParams &p, const int *corner, int type, u64 work_index,
+__device__ inline int vertex_id(const Mesh &m, const int *corner, unsigned vmask)
+{
+  u64 id = (u64)(i64)(corner[0] + (int)(vmask & 1) - m.dom_lb[0]);
+  for (int d = 1; d <= ND; d ++) {
+    const int rel = corner[d] + (int)((vmask >> d) & 1) - (d < ND ? m.dom_lb[d] : 0);
+    id += (u64)(i64)rel * m.mesh_prod[d];
+  }
+  return (int)id;
+}
+
+// work index inside `core` for one scope (simplicial_regular_mesh.hh:480-493), x fastest
+template <int ND>
+__device__ inline u64 core_linear(const Mesh &m, const int *corner)
+{
+  u64 lin = (u64)(corner[0] - m.core_st[0]);
+  u64 stride = (u64)m.core_sz[0];
+  for (int d = 1; d < ND; d ++) { lin += (u64)(corner[d] - m.core_st[d]) * stride; stride *= (u64)m.core_sz[d]; }
+  return lin;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// hit path (rare): everything in FP64 from HBM.  Returns false when the 2D type filter drops the record.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ND>
+__device__ __noinline__ bool make_record(const Mesh &m, const Fields &f, const int *corner, int type,
                                          const u64 (*X)[ND], const int *ids, bool presolved, const double *mu_in, ftkx_cp_t *out)
 {
   constexpr int N = ND + 1;
   const fan_table<N> &fan = dev_fan<ND>();
-  int vx[N][N];
-  size_t at[N];
-  int slice[N];
+  int vx[N][N], ai[N][3], slice[N];
   double v[N][ND];
   for (int i = 0; i < N; i ++) {
-    const unsigned m = fan.vert[type][i];
-    for (int d = 0; d < N; d ++) vx[i][d] = corner[d] + ((m >> d) & 1u);
-    slice[i] = (m >> ND) & 1u;
-    at[i] = ext_index<ND>(p, vx[i]);
-    for (int j = 0; j < ND; j ++) v[i][j] = p.V[slice[i]][at[i] * ND + j];
+    const unsigned vm = fan.vert[type][i];
+    for (int d = 0; d < N; d ++) vx[i][d] = corner[d] + ((vm >> d) & 1u);
+    slice[i] = (vm >> ND) & 1u;
+    ai[i][0] = vx[i][0] - m.ext_st[0]; ai[i][1] = vx[i][1] - m.ext_st[1]; ai[i][2] = ND == 3 ? vx[i][2] - m.ext_st[2] : 0;
+    vector_at<ND>(m, f.S[slice[i]], f.V[slice[i]], ai[i][0], ai[i][1], ai[i][2], v[i]);
   }
   double mu[N];
   if (presolved) { for (int i = 0; i < N; i ++) mu[i] = mu_in[i]; }
@@ -140,19 +230,18 @@ __device__ __noinline__ bool make_record(const SweepParams &p, const int *corner
     }
     if constexpr (ND == 2) {
       r.x[0] = x[0]; r.x[1] = x[1];
-      // z: the reference lerps three zeros: 0*mu0 + 0*mu1 + 0*mu2 (NaN if a mu is not finite, as there)
-      r.x[2] = 0.0 * mu[0] + 0.0 * mu[1] + 0.0 * mu[2];
+      r.x[2] = 0.0 * mu[0] + 0.0 * mu[1] + 0.0 * mu[2];            // the reference lerps three zeros (2d:498-503)
       r.t = x[2];
     } else { r.x[0] = x[0]; r.x[1] = x[1]; r.x[2] = x[2]; r.t = x[3]; }
   }
-  if (p.S[0]) {
-    double acc = p.S[slice[0]][at[0]] * mu[0];
-    for (int i = 1; i < N; i ++) acc = acc + p.S[slice[i]][at[i]] * mu[i];
+  if (f.S[0]) {
+    double acc = f.S[slice[0]][arr_index<ND>(m, ai[0][0], ai[0][1], ai[0][2])] * mu[0];
+    for (int i = 1; i < N; i ++) acc = acc + f.S[slice[i]][arr_index<ND>(m, ai[i][0], ai[i][1], ai[i][2])] * mu[i];
     r.scalar[0] = acc;
   }
-  const bool have_j = p.J[0] != nullptr || p.derive_jacobian;
+  const bool have_j = f.J[0] != nullptr || m.derive_jacobian;
   if constexpr (ND == 2) {
-    if (p.compute_degrees) {                                       // 2d:653-662
+    if (m.compute_degrees) {                                       // 2d:653-662
       if (fan.ordinal[type]) {
         int deg = orientation2(X, ids);
         deg *= (type == 4) ? 1 : -1;
@@ -163,23 +252,27 @@ __device__ __noinline__ bool make_record(const SweepParams &p, const int *corner
       if (have_j) {
         double Js[3][2][2];
         for (int i = 0; i < 3; i ++) {
-          if (p.J[0]) { for (int j = 0; j < 2; j ++) for (int k = 0; k < 2; k ++) Js[i][j][k] = p.J[slice[i]][at[i] * 4 + (size_t)j * 2 + k]; }
-          else derive_jacobian_at<2>(p, p.V[slice[i]], vx[i], Js[i]);
+          if (f.J[0]) {
+            const size_t at = arr_index<2>(m, ai[i][0], ai[i][1], 0) * 4;
+            for (int j = 0; j < 2; j ++) for (int k = 0; k < 2; k ++) Js[i][j][k] = f.J[slice[i]][at + (size_t)j * 2 + k];
+          } else derive_jacobian_at<2>(m, f.S[slice[i]], f.V[slice[i]], ai[i][0], ai[i][1], 0, Js[i]);
         }
         for (int j = 0; j < 2; j ++) for (int k = 0; k < 2; k ++)
           J[j][k] = Js[0][j][k] * mu[0] + Js[1][j][k] * mu[1] + Js[2][j][k] * mu[2];
         const double s = 0.5 * (J[0][1] + J[1][0]);                // make_symmetric2x2, always (2d:669)
         J[0][1] = J[1][0] = s;
       }
-      r.type = classify2(J[0][0], J[0][1], J[1][0], J[1][1], p.jacobian_symmetric != 0);
+      r.type = classify2(J[0][0], J[0][1], J[1][0], J[1][1], m.jacobian_symmetric != 0);
     }
-    if (p.use_type_filter && !(p.type_filter & r.type)) return false;   // 2d:280
+    if (m.use_type_filter && !(m.type_filter & r.type)) return false;   // 2d:280
   } else {
     double J[3][3];
     double Js[4][3][3];
     for (int i = 0; i < 4; i ++) {
-      if (p.J[0]) { for (int j = 0; j < 3; j ++) for (int k = 0; k < 3; k ++) Js[i][j][k] = p.J[slice[i]][at[i] * 9 + (size_t)j * 3 + k]; }
-      else if (p.derive_jacobian) derive_jacobian_at<3>(p, p.V[slice[i]], vx[i], Js[i]);
+      if (f.J[0]) {
+        const size_t at = arr_index<3>(m, ai[i][0], ai[i][1], ai[i][2]) * 9;
+        for (int j = 0; j < 3; j ++) for (int k = 0; k < 3; k ++) Js[i][j][k] = f.J[slice[i]][at + (size_t)j * 3 + k];
+      } else if (m.derive_jacobian) derive_jacobian_at<3>(m, f.S[slice[i]], f.V[slice[i]], ai[i][0], ai[i][1], ai[i][2], Js[i]);
       else { for (int j = 0; j < 3; j ++) for (int k = 0; k < 3; k ++) Js[i][j][k] = 0.0; }
     }
     for (int j = 0; j < 3; j ++) for (int k = 0; k < 3; k ++) {   // lerp_s3m3x3 accumulates from 0 (linear_interpolation.hh:141-151)
@@ -187,20 +280,70 @@ __device__ __noinline__ bool make_record(const SweepParams &p, const int *corner
       for (int i = 0; i < 4; i ++) acc += Js[i][j][k] * mu[i];
       J[j][k] = acc;
     }
-    r.type = classify3(J, p.jacobian_symmetric != 0);
+    r.type = classify3(J, m.jacobian_symmetric != 0);
   }
-  r.tag = element_tag<ND>(p, corner, type, work_index);
+  const bool ordinal = fan.ordinal[type] != 0;
+  const u64 work_index = core_linear<ND>(m, corner) * (u64)(ordinal ? fan_table<N>::NORD : fan_table<N>::NINT) + fan.local_index[type];
+  r.tag = element_tag<ND>(m, corner, type, work_index);
   *out = r;
   // aux word in the struct's padding (include/ftkx.h): bit 0 = ordinal, bits 1.. = emitting timestep
-  reinterpret_cast<unsigned int *>(out)[15] = (unsigned)fan.ordinal[type] | ((unsigned)p.t << 1);
+  reinterpret_cast<unsigned int *>(out)[15] = (unsigned)ordinal | ((unsigned)f.t << 1);
   return true;
 }
 
+// one simplex: vertices already classified/quantised (flags[i], Xq[i]).  Returns hit and fills rec.
+template <int ND>
+__device__ inline bool test_simplex(const Mesh &m, const Fields &f, int cull, const int *corner, int type, unsigned tab,
+                                    const unsigned char *flags, const u64 (*X)[ND], unsigned &tested, ftkx_cp_t *rec)
+{
+  constexpr int N = ND + 1;
+  unsigned m_and = 0x3f, m_or = 0;
+  for (int i = 0; i < N; i ++) { m_and &= flags[i]; m_or |= flags[i]; }
+  if ((m_or & (kInvalid | kNonFinite)) || (cull && (m_and & 0x3f))) return false;
+  tested ++;
+  int ids[N];
+  for (int i = 0; i < N; i ++) ids[i] = vertex_id<ND>(m, corner, (tab >> (8 * i)) & 0xffu);
+  bool inside;
+  double mu[N];
+  bool presolved = false;
+  if (ND == 3 && !m.robust) {
+    // enable_robust_detection == false (3d:465-467): the FP64 solve decides
+    double v[N][ND];
+    for (int i = 0; i < N; i ++) {
+      const unsigned vm = (tab >> (8 * i)) & 0xffu;
+      const int sl = (vm >> ND) & 1;
+      vector_at<ND>(m, f.S[sl], f.V[sl], corner[0] + (int)(vm & 1) - m.ext_st[0], corner[1] + (int)((vm >> 1) & 1) - m.ext_st[1],
+                    ND == 3 ? corner[2] + (int)((vm >> 2) & 1) - m.ext_st[2] : 0, v[i]);
+    }
+    if constexpr (ND == 3) inside = solve_barycentric3(v, mu); else inside = false;
+    presolved = true;
+  } else if constexpr (ND == 2) inside = origin_in_simplex2(X, ids);
+  else inside = origin_in_simplex3(X, ids);
+  if (!inside) return false;
+  return make_record<ND>(m, f, corner, type, X, ids, presolved, mu, rec);
+}
+
+// hits of one wavefront appended with a single atomic (must be reached by all 64 lanes)
+__device__ inline void emit_hits(const Mesh &m, bool hit, const ftkx_cp_t &rec)
+{
+  const unsigned long long hb = __ballot(hit);
+  if (!hb) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)hb) - 1;
+  u64 slot0 = 0;
+  if (lane == leader) slot0 = atomicAdd(&m.counters[CNT_HITS], (u64)__popcll(hb));
+  slot0 = __shfl(slot0, leader);
+  if (hit) {
+    const u64 slot = slot0 + (u64)__popcll(hb & ((1ull << lane) - 1ull));
+    if (slot < m.capacity) m.hits[slot] = rec;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// the sweep kernel
+// TILE PATH
 // ---------------------------------------------------------------------------------------------------------------
 template <int ND>
-__global__ __launch_bounds__(kThreads) void sweep_kernel(const SweepParams p)
+__global__ __launch_bounds__(kThreads) void tile_kernel(const TileParams p)
 {
   using cfg = tile_cfg<ND>;
   constexpr int N = ND + 1;
@@ -211,12 +354,14 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const SweepParams p)
 
   __shared__ i64 s_vf[2][NH][ND];
   __shared__ unsigned char s_mask[2][NH];
-  __shared__ unsigned s_tab[fan_table<N>::NTYPES];     // four vertex masks of a type packed in one word
+  __shared__ unsigned s_tab[fan_table<N>::NTYPES];     // the vertex masks of a type packed in one word
   __shared__ unsigned short s_list[2][kThreads];       // surviving corners: [0] ordinal sweep, [1] interval sweep
   __shared__ unsigned s_cnt[2];
 
   const int tid = threadIdx.x;
   const fan_table<N> &fan = dev_fan<ND>();
+  const Mesh &m = p.m;
+  const Fields &f = p.f;
 
   // workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2): give each XCD a
   // contiguous run of tiles so that neighbouring tiles' shared halo vertices hit the same L2.
@@ -224,17 +369,11 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const SweepParams p)
   unsigned b = blockIdx.x;
   {
     const unsigned per = nblocks / 8, rem = nblocks % 8, xcd = b % 8, k = b / 8;
-    // XCD x owns per + (x < rem) tiles
-    const unsigned start = xcd * per + (xcd < rem ? xcd : rem);
-    b = start + k;
+    b = xcd * per + (xcd < rem ? xcd : rem) + k;
   }
-  int tile[3];
-  tile[0] = b % p.ntiles[0];
-  tile[1] = (b / p.ntiles[0]) % p.ntiles[1];
-  tile[2] = b / (p.ntiles[0] * p.ntiles[1]);
-  int origin[3] = {p.core_st[0] + tile[0] * cfg::TX, p.core_st[1] + tile[1] * cfg::TY, (ND == 3) ? p.core_st[2] + tile[2] * cfg::TZ : 0};
-
-  const bool need_next = (p.scope_mask & FTKX_SCOPE_INTERVAL) != 0;
+  const int tile[3] = {(int)(b % p.ntiles[0]), (int)((b / p.ntiles[0]) % p.ntiles[1]), (int)(b / (p.ntiles[0] * p.ntiles[1]))};
+  const int origin[3] = {m.core_st[0] + tile[0] * cfg::TX, m.core_st[1] + tile[1] * cfg::TY, (ND == 3) ? m.core_st[2] + tile[2] * cfg::TZ : 0};
+  const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0;
 
   if (tid < fan_table<N>::NTYPES) {
     unsigned w = 0;
@@ -243,49 +382,35 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const SweepParams p)
   }
   if (tid < 2) s_cnt[tid] = 0;
 
-  // ---- 1. stage ----
+  // ---- stage ----
   for (int h = tid; h < 2 * NH; h += kThreads) {
     const int sl = h / NH, hv = h - sl * NH;
     if (sl == 1 && !need_next) break;
-    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-    int vx[3] = {origin[0] + hx, origin[1] + hy, origin[2] + hz};
-    bool ok = true;
-    for (int d = 0; d < ND; d ++)
-      ok = ok && vx[d] >= p.dom_lb[d] && vx[d] <= p.dom_ub[d] && vx[d] >= p.ext_st[d] && vx[d] < p.ext_st[d] + p.ext_sz[d];
-    unsigned char m = 0;
+    const int vx[3] = {origin[0] + hv % HX, origin[1] + (hv / HX) % HY, origin[2] + hv / (HX * HY)};
     i64 q[ND];
-    for (int j = 0; j < ND; j ++) q[j] = 0;
-    if (ok) {
-      const size_t at = ext_index<ND>(p, vx);
-      const double *V = p.V[sl];
-      for (int j = 0; j < ND; j ++) {
-        const double v = V[at * ND + j];
-        if (isnan(v) || isinf(v)) m |= kNonFinite;
-        q[j] = quantize(v, p.factor);
-        if (q[j] > 0) m |= (unsigned char)(1u << j);
-        if (q[j] < 0) m |= (unsigned char)(8u << j);
-      }
-    } else m = kInvalid;
+    s_mask[sl][hv] = classify_vertex<ND>(m, f.S[sl], f.V[sl], f.factor, vx, q);
     for (int j = 0; j < ND; j ++) s_vf[sl][hv][j] = q[j];
-    s_mask[sl][hv] = m;
   }
   __syncthreads();
 
-  // ---- 2. cull: one corner per lane ----
+  // ---- cull: one corner per lane ----
   const int cx = tid % cfg::TX, cy = (tid / cfg::TX) % cfg::TY, cz = tid / (cfg::TX * cfg::TY);
-  const int corner_sp[3] = {origin[0] + cx, origin[1] + cy, origin[2] + cz};
   bool in_core = true;
-  for (int d = 0; d < ND; d ++) in_core = in_core && corner_sp[d] < p.core_st[d] + p.core_sz[d];
+  {
+    const int csp[3] = {origin[0] + cx, origin[1] + cy, origin[2] + cz};
+    for (int d = 0; d < ND; d ++) in_core = in_core && csp[d] < m.core_st[d] + m.core_sz[d];
+  }
   const int hbase = cx + HX * (cy + HY * cz);
   {
     unsigned and0 = 0x3f, and1 = 0x3f;
     for (int c = 0; c < (1 << ND); c ++) {
       const int off = (c & 1) + HX * (((c >> 1) & 1) + HY * ((c >> 2) & 1));
-      and0 &= s_mask[0][hbase + off];
-      if (need_next) and1 &= s_mask[1][hbase + off];
+      // vertices no simplex may use (outside the domain, non-finite) are neutral for the sign argument
+      const unsigned m0 = s_mask[0][hbase + off];
+      and0 &= (m0 & (kInvalid | kNonFinite)) ? 0x3fu : m0;
+      if (need_next) { const unsigned m1 = s_mask[1][hbase + off]; and1 &= (m1 & (kInvalid | kNonFinite)) ? 0x3fu : m1; }
     }
-    // a corner is dropped only by the strict-sign argument; invalid / non-finite vertices are handled per simplex
-    const bool keep_o = in_core && (p.scope_mask & FTKX_SCOPE_ORDINAL) && !(p.cull && (and0 & 0x3f));
+    const bool keep_o = in_core && (f.scope_mask & FTKX_SCOPE_ORDINAL) && !(p.cull && (and0 & 0x3f));
     const bool keep_i = in_core && need_next && !(p.cull && (and0 & and1 & 0x3f));
     const unsigned long long bo = __ballot(keep_o), bi = __ballot(keep_i);
     const int lane = tid & 63;
@@ -302,11 +427,11 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const SweepParams p)
   }
   __syncthreads();
 
-  // ---- 3. test: (corner, type) pairs over all lanes ----
+  // ---- test: (corner, type) pairs over all lanes ----
   const unsigned n_o = s_cnt[0], n_i = s_cnt[1];
   const unsigned items_o = n_o * NORD, total = items_o + n_i * NINT;
-  unsigned tested = 0, slow = 0;
-  for (unsigned base = 0; base < total; base += kThreads) {   // wave-uniform trip count: ballots below stay convergent
+  unsigned tested = 0;
+  for (unsigned base = 0; base < total; base += kThreads) {   // wave-uniform trip count: the ballot in emit_hits stays convergent
     const unsigned w = base + tid;
     bool hit = false;
     ftkx_cp_t rec;
@@ -320,96 +445,299 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const SweepParams p)
       const int ccx = ct % cfg::TX, ccy = (ct / cfg::TX) % cfg::TY, ccz = ct / (cfg::TX * cfg::TY);
       const int hb = ccx + HX * (ccy + HY * ccz);
       const unsigned tab = s_tab[type];
-      int hidx[N], hsl[N];
-      unsigned m_and = 0x3f, m_or = 0;
+      unsigned char flags[N];
+      u64 X[N][ND];
       for (int i = 0; i < N; i ++) {
-        const unsigned m = (tab >> (8 * i)) & 0xffu;
-        hidx[i] = hb + (m & 1) + HX * (((m >> 1) & 1) + ((ND == 3) ? HY * ((m >> 2) & 1) : 0));
-        hsl[i] = (m >> ND) & 1;
-        const unsigned mk = s_mask[hsl[i]][hidx[i]];
-        m_and &= mk; m_or |= mk;
+        const unsigned vm = (tab >> (8 * i)) & 0xffu;
+        const int hidx = hb + (vm & 1) + HX * (((vm >> 1) & 1) + ((ND == 3) ? HY * ((vm >> 2) & 1) : 0));
+        const int hsl = (vm >> ND) & 1;
+        flags[i] = s_mask[hsl][hidx];
+        for (int j = 0; j < ND; j ++) X[i][j] = (u64)s_vf[hsl][hidx][j];
       }
-      const bool skip = (m_or & (kInvalid | kNonFinite)) || (p.cull && (m_and & 0x3f));
-      if (!skip) {
-        tested ++;
-        int corner[N];
-        corner[0] = origin[0] + ccx; corner[1] = origin[1] + ccy;
-        if (ND == 3) corner[2] = origin[2] + ccz;
-        corner[ND] = p.t;
-        u64 X[N][ND];
-        int ids[N];
-        for (int i = 0; i < N; i ++) {
-          for (int j = 0; j < ND; j ++) X[i][j] = (u64)s_vf[hsl[i]][hidx[i]][j];
-          const unsigned m = (tab >> (8 * i)) & 0xffu;
-          u64 id = (u64)(i64)(corner[0] + (int)(m & 1) - p.dom_lb[0]);
-          for (int d = 1; d < N; d ++) {
-            const int rel = corner[d] + (int)((m >> d) & 1) - (d < ND ? p.dom_lb[d] : 0);
-            id += (u64)(i64)rel * p.mesh_prod[d];
-          }
-          ids[i] = (int)id;                                          // regular_tracker.hh:188-194: truncated to int
-        }
-        // work index inside `core` for this scope (simplicial_regular_mesh.hh:480-493), x fastest
-        u64 lin = (u64)(corner[0] - p.core_st[0]);
-        {
-          u64 stride = (u64)p.core_sz[0];
-          for (int d = 1; d < ND; d ++) { lin += (u64)(corner[d] - p.core_st[d]) * stride; stride *= (u64)p.core_sz[d]; }
-        }
-        const u64 work_index = lin * (u64)(ordinal ? NORD : NINT) + it;
-        bool inside;
-        double mu[N];
-        bool presolved = false;
-        if (ND == 3 && !p.robust) {
-          // enable_robust_detection == false (3d:465-467): the FP64 solve decides
-          double v[N][ND];
-          for (int i = 0; i < N; i ++) {
-            int vxx[N];
-            const unsigned m = (tab >> (8 * i)) & 0xffu;
-            for (int d = 0; d < N; d ++) vxx[d] = corner[d] + (int)((m >> d) & 1);
-            const size_t at = ext_index<ND>(p, vxx);
-            for (int j = 0; j < ND; j ++) v[i][j] = p.V[hsl[i]][at * ND + j];
-          }
-          if constexpr (ND == 3) inside = solve_barycentric3(v, mu); else inside = false;
-          presolved = true;
-        } else if constexpr (ND == 2) inside = origin_in_simplex2(X, ids);
-        else inside = origin_in_simplex3(X, ids);
-        if (inside) hit = make_record<ND>(p, corner, type, work_index, X, ids, presolved, mu, &rec);
-      }
+      int corner[N];
+      corner[0] = origin[0] + ccx; corner[1] = origin[1] + ccy;
+      if (ND == 3) corner[2] = origin[2] + ccz;
+      corner[ND] = f.t;
+      hit = test_simplex<ND>(m, f, p.cull, corner, type, tab, flags, X, tested, &rec);
     }
-    // ---- 4. emit: one atomic per wavefront ----
-    const unsigned long long hb = __ballot(hit);
-    if (hb) {
-      const int lane = tid & 63;
-      u64 slot0 = 0;
-      if (lane == __ffsll((long long)hb) - 1) slot0 = atomicAdd(&p.counters[CNT_HITS], (u64)__popcll(hb));
-      slot0 = __shfl(slot0, __ffsll((long long)hb) - 1);
-      if (hit) {
-        const u64 slot = slot0 + (u64)__popcll(hb & ((1ull << lane) - 1ull));
-        if (slot < p.capacity) p.hits[slot] = rec;
-      }
-    }
+    emit_hits(m, hit, rec);
   }
-  (void)slow;
-  // statistics: one atomic per workgroup per counter
   {
     unsigned t_sum = tested;
     for (int o = 32; o > 0; o >>= 1) t_sum += __shfl_down(t_sum, o);
-    if ((tid & 63) == 0 && t_sum) atomicAdd(&p.counters[CNT_SIMPLICES_TESTED], (u64)t_sum);
-    if (tid == 0 && (n_o + n_i)) atomicAdd(&p.counters[CNT_CELLS_SURVIVED], (u64)(n_o > n_i ? n_o : n_i));
+    if ((tid & 63) == 0 && t_sum) atomicAdd(&m.counters[CNT_SIMPLICES_TESTED], (u64)t_sum);
+    if (tid == 0 && (n_o + n_i)) atomicAdd(&m.counters[CNT_CELLS_SURVIVED], (u64)(need_next ? n_i : n_o));
   }
 }
 
-void launch_sweep(const SweepParams &p, hipStream_t stream)
+// ---------------------------------------------------------------------------------------------------------------
+// FAST PATH 1/3: vertex sign masks.  One lane per mask byte (row pitch padded to whole 8-byte words, see Mesh::mask_pitch).
+// ---------------------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ __launch_bounds__(kThreads) void mask_kernel(const Mesh m, const MaskJob *__restrict__ jobs)
+{
+  const MaskJob job = jobs[blockIdx.y];
+  const int P = m.mask_pitch, DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1;
+  const size_t n = (size_t)P * DH * DD;
+  for (size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x; idx < n; idx += (size_t)gridDim.x * kThreads) {
+    const int i = (int)(idx % P), j = (int)((idx / P) % DH), k = (int)(idx / ((size_t)P * DH));
+    unsigned char mk = kNeutral;   // padding, vertices outside the domain and non-finite vertices never block a cull
+    if (i < m.ext_sz[0]) {
+      const int vx[3] = {i + m.ext_st[0], j + m.ext_st[1], k + m.ext_st[2]};
+      bool in_dom = true;
+      for (int d = 0; d < ND; d ++) in_dom = in_dom && vx[d] >= m.dom_lb[d] && vx[d] <= m.dom_ub[d];
+      if (in_dom) {
+        double v[ND];
+        vector_at<ND>(m, job.S, job.V, i, j, k, v);
+        unsigned bits = 0;
+        bool finite = true;
+        for (int c = 0; c < ND; c ++) {
+          finite = finite && !(isnan(v[c]) || isinf(v[c]));
+          if (v[c] >= job.threshold) bits |= 1u << c;          // trunc(v * factor) >= 1
+          if (v[c] <= -job.threshold) bits |= 8u << c;         // trunc(v * factor) <= -1
+        }
+        mk = finite ? (unsigned char)bits : kNeutral;
+      }
+    }
+    job.M[idx] = mk;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// FAST PATH 2/3: corner cull on the mask bytes, 8 corners per lane (SWAR), survivors -> work list
+// ---------------------------------------------------------------------------------------------------------------
+// list entry: bits 0..39 corner index inside core (x fastest), bits 40..41 scope flags (1 ordinal, 2 interval), bits 44.. step
+__device__ inline u64 load_row_pair_and(const unsigned char *__restrict__ M, size_t row_off, int g)
+{
+  const u64 *w = reinterpret_cast<const u64 *>(M + row_off) + g;
+  const u64 w0 = w[0], w1 = w[1];                  // the pitch has 8 spare bytes: w[1] always exists
+  return w0 & ((w0 >> 8) | (w1 << 56));            // byte b = mask(x = 8g + b) & mask(x + 1)
+}
+
+template <int ND>
+__global__ __launch_bounds__(kThreads) void cull_kernel(const Mesh m, const Fields *__restrict__ steps, u64 *__restrict__ list, u64 list_capacity)
+{
+  const int DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
+  const int g = blockIdx.x * 32 + (threadIdx.x & 31);                 // 8-corner group along x
+  const int j = blockIdx.y * 8 + (threadIdx.x >> 5);
+  const int k = (ND == 3) ? (int)(blockIdx.z % DD) : 0;
+  const int step = (ND == 3) ? (int)(blockIdx.z / DD) : (int)blockIdx.z;
+  const Fields f = steps[step];
+  const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0;
+
+  u64 surv_o = 0, surv_i = 0;   // 0x80 in byte b: corner 8g + b survives
+  const int cy = j + m.ext_st[1], cz = k + m.ext_st[2];
+  bool row_ok = g * 8 < m.ext_sz[0] && j < DH && cy >= m.core_st[1] && cy < m.core_st[1] + m.core_sz[1];
+  if (ND == 3) row_ok = row_ok && cz >= m.core_st[2] && cz < m.core_st[2] + m.core_sz[2];
+  if (row_ok) {
+    u64 a0 = ~0ull, a1 = ~0ull;
+    for (int dz = 0; dz < (ND == 3 ? 2 : 1); dz ++)
+      for (int dy = 0; dy < 2; dy ++) {
+        if (j + dy >= DH || k + dz >= DD) continue;                   // row outside the array: invalid vertices, neutral
+        const size_t off = (size_t)P * ((size_t)(j + dy) + (size_t)DH * (size_t)(k + dz));
+        a0 &= load_row_pair_and(f.M[0], off, g);
+        if (need_next) a1 &= load_row_pair_and(f.M[1], off, g);
+      }
+    // bytes are <= 0x3f: adding 0x7f sets bit 7 exactly in the non-zero bytes, without carries between bytes
+    const u64 k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
+    u64 in_core = 0;
+    for (int b = 0; b < 8; b ++) {
+      const int cx = g * 8 + b + m.ext_st[0];
+      if (cx >= m.core_st[0] && cx < m.core_st[0] + m.core_sz[0]) in_core |= 0x80ull << (8 * b);
+    }
+    if (f.scope_mask & FTKX_SCOPE_ORDINAL) surv_o = ~((a0 + k7f)) & k80 & in_core;
+    if (need_next) surv_i = ~(((a0 & a1) + k7f)) & k80 & in_core;
+  }
+  const u64 any = surv_o | surv_i;
+  const unsigned cnt = (unsigned)__popcll(any);
+  // exclusive prefix sum of cnt over the wavefront, one atomic per wavefront
+  unsigned incl = cnt;
+  const int lane = threadIdx.x & 63;
+  for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+  const unsigned total = __shfl(incl, 63);
+  if (total == 0) return;
+  u64 base = 0;
+  if (lane == 63) {
+    base = atomicAdd(&m.counters[CNT_SURVIVOR_LIST], (u64)total);
+    atomicAdd(&m.counters[CNT_CELLS_SURVIVED], (u64)total);
+  }
+  base = __shfl(base, 63);
+  u64 pos = base + (incl - cnt);
+  if (cnt) {
+    const u64 row_lin = (u64)(cy - m.core_st[1]) * (u64)m.core_sz[0] + (ND == 3 ? (u64)(cz - m.core_st[2]) * (u64)m.core_sz[0] * (u64)m.core_sz[1] : 0ull);
+    for (int b = 0; b < 8; b ++) {
+      const unsigned fl = (unsigned)((surv_o >> (8 * b + 7)) & 1) | ((unsigned)((surv_i >> (8 * b + 7)) & 1) << 1);
+      if (!fl) continue;
+      const u64 lin = row_lin + (u64)(g * 8 + b + m.ext_st[0] - m.core_st[0]);
+      if (pos < list_capacity) list[pos] = lin | ((u64)fl << 40) | ((u64)step << 44);
+      pos ++;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// FAST PATH 3/3: exact test of the surviving corners
+// ---------------------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fields *__restrict__ steps, const u64 *__restrict__ list, u64 list_capacity)
+{
+  constexpr int N = ND + 1;
+  constexpr int NVC = 1 << N;                 // vertices of a corner's space-time hypercube
+  constexpr int G = kThreads / NVC;           // corners per chunk: one lane per hypercube vertex while staging
+  constexpr int NTYPES = fan_table<N>::NTYPES;
+  __shared__ i64 s_vf[G][NVC][ND];
+  __shared__ unsigned char s_flag[G][NVC];
+  __shared__ u64 s_entry[G];
+  __shared__ unsigned s_tab[NTYPES];
+
+  const int tid = threadIdx.x;
+  const fan_table<N> &fan = dev_fan<ND>();
+  if (tid < NTYPES) {
+    unsigned w = 0;
+    for (int i = 0; i < N; i ++) w |= (unsigned)fan.vert[tid][i] << (8 * i);
+    s_tab[tid] = w;
+  }
+  u64 count = m.counters[CNT_SURVIVOR_LIST];
+  if (blockIdx.x == 0 && tid == 0) atomicMax(&m.counters[CNT_LIST_PEAK], count);   // the host checks the peak against the capacity
+  if (count > list_capacity) count = list_capacity;     // overflow: the host grows the list and replays the batch
+  unsigned tested = 0;
+
+  for (u64 chunk = blockIdx.x; chunk * G < count; chunk += gridDim.x) {
+    __syncthreads();                                    // previous chunk's LDS readers are done
+    if (tid < G) s_entry[tid] = (chunk * G + tid < count) ? list[chunk * G + tid] : ~0ull;
+    __syncthreads();
+    {
+      const int gi = tid / NVC, vtx = tid % NVC;
+      const u64 e = s_entry[gi];
+      i64 q[ND];
+      unsigned char fl = kInvalid;
+      for (int c = 0; c < ND; c ++) q[c] = 0;
+      if (e != ~0ull) {
+        const Fields &f = steps[e >> 44];
+        u64 lin = e & 0xffffffffffull;
+        int vx[3] = {0, 0, 0};
+        for (int d = 0; d < ND; d ++) { vx[d] = m.core_st[d] + (int)(lin % (u64)m.core_sz[d]) + ((vtx >> d) & 1); lin /= (u64)m.core_sz[d]; }
+        const int sl = (vtx >> ND) & 1;
+        if (sl == 0 || (f.scope_mask & FTKX_SCOPE_INTERVAL)) fl = classify_vertex<ND>(m, f.S[sl], f.V[sl], f.factor, vx, q);
+      }
+      s_flag[gi][vtx] = fl;
+      for (int c = 0; c < ND; c ++) s_vf[gi][vtx][c] = q[c];
+    }
+    __syncthreads();
+    for (int base = 0; base < G * NTYPES; base += kThreads) {    // uniform trip count (emit_hits ballots)
+      const int w = base + tid;
+      bool hit = false;
+      ftkx_cp_t rec;
+      if (w < G * NTYPES) {
+        const int gi = w / NTYPES, type = w % NTYPES;
+        const u64 e = s_entry[gi];
+        const unsigned scope_flags = (e == ~0ull) ? 0u : (unsigned)((e >> 40) & 3);
+        const bool wanted = fan.ordinal[type] ? (scope_flags & 1) : (scope_flags & 2);
+        if (wanted) {
+          const Fields &f = steps[e >> 44];
+          u64 lin = e & 0xffffffffffull;
+          int corner[N];
+          for (int d = 0; d < ND; d ++) { corner[d] = m.core_st[d] + (int)(lin % (u64)m.core_sz[d]); lin /= (u64)m.core_sz[d]; }
+          corner[ND] = f.t;
+          const unsigned tab = s_tab[type];
+          unsigned char flags[N];
+          u64 X[N][ND];
+          for (int i = 0; i < N; i ++) {
+            const unsigned vm = (tab >> (8 * i)) & 0xffu;   // the axis bitmask IS the hypercube vertex index
+            flags[i] = s_flag[gi][vm];
+            for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[gi][vm][c];
+          }
+          hit = test_simplex<ND>(m, f, 1, corner, type, tab, flags, X, tested, &rec);
+        }
+      }
+      emit_hits(m, hit, rec);
+    }
+  }
+  {
+    unsigned t_sum = tested;
+    for (int o = 32; o > 0; o >>= 1) t_sum += __shfl_down(t_sum, o);
+    if ((tid & 63) == 0 && t_sum) atomicAdd(&m.counters[CNT_SIMPLICES_TESTED], (u64)t_sum);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ndarray::resolution() of V = gradient(S) without materialising V (include/ftk/ndarray.hh:770-778 over grad.hh's output):
+// min over non-zero finite |v| and max finite |v| as raw IEEE bit patterns (they order like unsigned integers for v >= 0)
+// ---------------------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ __launch_bounds__(kThreads) void resolution_scalar_kernel(const Mesh m, const double *__restrict__ S, u64 *out)
+{
+  u64 mn = 0x7fefffffffffffffull, mx = 0ull;
+  const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1;
+  const size_t n = (size_t)DW * DH * DD;
+  for (size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x; idx < n; idx += (size_t)gridDim.x * kThreads) {
+    const int i = (int)(idx % DW), j = (int)((idx / DW) % DH), k = (int)(idx / ((size_t)DW * DH));
+    double g[ND];
+    gradient_at<ND>(m, S, i, j, k, g);
+    for (int c = 0; c < ND; c ++) {
+      const double a = fabs(g[c]);
+      const u64 bits = (u64)__double_as_longlong(a);
+      if (a != 0.0 && bits < 0x7ff0000000000000ull) { mn = bits < mn ? bits : mn; mx = bits > mx ? bits : mx; }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const u64 omn = __shfl_down(mn, o), omx = __shfl_down(mx, o);
+    mn = omn < mn ? omn : mn; mx = omx > mx ? omx : mx;
+  }
+  if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], mn); atomicMax(&out[1], mx); }
+}
+
+void launch_resolution_scalar(const Mesh &m, const double *S, u64 *out2, hipStream_t stream)
+{
+  const size_t n = (size_t)m.ext_sz[0] * m.ext_sz[1] * (m.nd == 3 ? m.ext_sz[2] : 1);
+  size_t bx = (n + kThreads - 1) / kThreads;
+  if (bx > 4096) bx = 4096;
+  if (m.nd == 2) hipLaunchKernelGGL(resolution_scalar_kernel<2>, dim3((unsigned)bx), dim3(kThreads), 0, stream, m, S, out2);
+  else hipLaunchKernelGGL(resolution_scalar_kernel<3>, dim3((unsigned)bx), dim3(kThreads), 0, stream, m, S, out2);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------------
+void launch_tile(const TileParams &p, hipStream_t stream)
 {
   const unsigned nblocks = (unsigned)p.ntiles[0] * p.ntiles[1] * p.ntiles[2];
   if (nblocks == 0) return;
-  if (p.nd == 2) hipLaunchKernelGGL(sweep_kernel<2>, dim3(nblocks), dim3(kThreads), 0, stream, p);
-  else hipLaunchKernelGGL(sweep_kernel<3>, dim3(nblocks), dim3(kThreads), 0, stream, p);
+  if (p.m.nd == 2) hipLaunchKernelGGL(tile_kernel<2>, dim3(nblocks), dim3(kThreads), 0, stream, p);
+  else hipLaunchKernelGGL(tile_kernel<3>, dim3(nblocks), dim3(kThreads), 0, stream, p);
 }
 
-void sweep_tile_dims(int nd, int tile[3])
+void tile_dims(int nd, int tile[3])
 {
   if (nd == 2) { tile[0] = tile_cfg<2>::TX; tile[1] = tile_cfg<2>::TY; tile[2] = 1; }
   else { tile[0] = tile_cfg<3>::TX; tile[1] = tile_cfg<3>::TY; tile[2] = tile_cfg<3>::TZ; }
+}
+
+void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream)
+{
+  if (njobs <= 0) return;
+  const size_t n = (size_t)m.mask_pitch * m.ext_sz[1] * (m.nd == 3 ? m.ext_sz[2] : 1);
+  size_t bx = (n + kThreads - 1) / kThreads;
+  if (bx > 4096) bx = 4096;                 // grid-stride the rest
+  const dim3 grid((unsigned)bx, (unsigned)njobs);
+  if (m.nd == 2) hipLaunchKernelGGL(mask_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs);
+  else hipLaunchKernelGGL(mask_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs);
+}
+
+void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream)
+{
+  if (nsteps <= 0) return;
+  const int groups = (m.ext_sz[0] + 7) / 8;
+  const dim3 grid((unsigned)((groups + 31) / 32), (unsigned)((m.ext_sz[1] + 7) / 8), (unsigned)((m.nd == 3 ? m.ext_sz[2] : 1) * nsteps));
+  if (m.nd == 2) hipLaunchKernelGGL(cull_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, d_list, cap);
+  else hipLaunchKernelGGL(cull_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_steps, d_list, cap);
+}
+
+void launch_exact(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, hipStream_t stream)
+{
+  const dim3 grid(256 * 4);                 // persistent-style: workgroups stride over the list, every wave exits when it is drained
+  if (m.nd == 2) hipLaunchKernelGGL(exact_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, d_list, cap);
+  else hipLaunchKernelGGL(exact_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_steps, d_list, cap);
 }
 
 }  // namespace ftkx

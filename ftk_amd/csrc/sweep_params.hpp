@@ -7,32 +7,53 @@ namespace ftkx {
 typedef unsigned long long u64;
 typedef long long i64;
 
-enum { CNT_HITS = 0, CNT_CELLS_SURVIVED = 1, CNT_SIMPLICES_TESTED = 2, CNT_SLOW_PATH = 3, CNT_N = 8 };
+enum { CNT_HITS = 0, CNT_CELLS_SURVIVED = 1, CNT_SIMPLICES_TESTED = 2, CNT_SURVIVOR_LIST = 3, CNT_LIST_PEAK = 4, CNT_N = 8 };
 
-struct SweepParams {
+// everything that does not change between the sweeps of one context configuration
+struct Mesh {
   int nd;
-  int scope_mask;            // FTKX_SCOPE_*
-  int t;                     // current_timestep
-  int dom_lb[3], dom_ub[3];  // inclusive vertex validity box
+  int dom_lb[3], dom_ub[3];  // inclusive vertex validity box (mesh lb/ub, spatial part)
   int core_st[3], core_sz[3];
   int ext_st[3], ext_sz[3];
-  const double *V[2];        // device pointers: slice t, slice t+1
-  const double *J[2];
-  const double *S[2];
-  double factor;             // (double)vector_field_scaling_factor, a power of two
   u64 mesh_prod[4];          // lattice::prod_ of the mesh lattice -> SoS vertex ids (regular_tracker.hh:188-194)
   int dimprod[4];            // simplicial_regular_mesh::dimprod_ (int) -> reference tag
   u64 exact_prod[4];         // same in 64 bits
+  int mask_pitch;            // row pitch (bytes) of the vertex-mask arrays: roundup8(ext_sz[0]) + 8
   int jacobian_symmetric, robust, use_type_filter;
   unsigned type_filter;
   int compute_degrees, tag_mode;
-  int cull;                  // 1: strict-sign cull is legal (robust test, no int64 overflow possible) and enabled
-  int derive_jacobian;       // 0: J given; 1: derive from V like jacobian2D<symmetric?>/jacobian3D; see jac_symmetric_derive
-  int jac_symmetric_derive;  // jacobian2D<T, true> (scalar input) vs <T, false> (vector input)
+  int scalar_mode;           // 1: V is not stored; it is gradient2D/3D(S) evaluated where needed (vector_field_source == DERIVED)
+  int derive_jacobian;       // 1: J not stored; jacobian2D/3D of V evaluated at hit vertices (jacobian_field_source == DERIVED)
   ftkx_cp_t *hits;           // device hit buffer
   u64 *counters;             // CNT_* device counters
   u64 capacity;              // records the hit buffer can hold
+};
+
+// the fields of one (timestep, scope) request: slice t and slice t+1
+struct Fields {
+  const double *S[2];
+  const double *V[2];
+  const double *J[2];
+  const unsigned char *M[2]; // vertex sign masks (fast path only)
+  double factor;             // (double)vector_field_scaling_factor, a power of two
+  int t;                     // current_timestep
+  int scope_mask;            // FTKX_SCOPE_*
+};
+
+// tile kernel (exact_only / non-robust / overflow regime, and small jobs)
+struct TileParams {
+  Mesh m;
+  Fields f;
+  int cull;                  // 1: strict-sign cull legal and enabled
   int ntiles[3];
+};
+
+// mask kernel job: one slice
+struct MaskJob {
+  const double *S;
+  const double *V;
+  unsigned char *M;
+  double threshold;          // 1 / factor: q = trunc(v * factor) > 0  <=>  v >= 1/factor (factor is a power of two)
 };
 
 }  // namespace ftkx

@@ -110,8 +110,8 @@ unsigned long long ftkx_scaling_factor(double resolution, int *nbits);
  * valid until the next call on this context.  Synchronous on the context's stream. */
 int ftkx_sweep(ftkx_ctx *ctx, int t, int scope, unsigned long long factor, const ftkx_cp_t **out, size_t *n_out);
 
-/* asynchronous form for benchmarking/pipelining: enqueue only; ftkx_sweep_collect() synchronises and returns the records
- * of ALL sweeps enqueued since the last collect (sorted by tag). */
+/* batched form: enqueue only records the request; ftkx_sweep_collect() launches the whole batch (one mask / cull / exact
+ * launch covers every enqueued timestep), synchronises and returns the records of ALL of them (sorted by tag). */
 int ftkx_sweep_enqueue(ftkx_ctx *ctx, int t, int scope, unsigned long long factor);
 int ftkx_sweep_collect(ftkx_ctx *ctx, const ftkx_cp_t **out, size_t *n_out);
 
@@ -121,6 +121,15 @@ typedef struct ftkx_stats {
   int cull_enabled;
 } ftkx_stats;
 int ftkx_get_stats(const ftkx_ctx *ctx, ftkx_stats *st);
+
+/* The vertex sign masks a sweep builds for a slice are kept with the slice (slice t+1 of step t is slice t of step t+1).
+ * A caller that rewrites a slice's device memory in place, or a benchmark that must redo all work, drops them with this. */
+int ftkx_invalidate_masks(ftkx_ctx *ctx);
+
+/* optional kernel timing with HIP events on the context's stream (for bench.py's roofline figure).  Index: 0 mask_kernel,
+ * 1 cull_kernel, 2 exact_kernel, 3 tile_kernel; ms[] = summed device time, launches[] = launches timed since set_profiling(1). */
+int ftkx_set_profiling(ftkx_ctx *ctx, int on);
+int ftkx_get_kernel_times(const ftkx_ctx *ctx, double ms[4], unsigned long long launches[4]);
 
 /* ---- stateless one-shot calls with the reference boundary's argument list ------------------------------------ */
 /* extract_cp2dt_{cuda,sycl}(scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, use_explicit_coords, coords)
