@@ -215,147 +215,6 @@ def main():
                 traffic = json.load(open(tj)).get(args.config, {}).get("hbm_bytes_per_launch")
             except Exception:   # noqa: BLE001
                 traffic = None
-        out = {"value": nsimp / j["sweep_seconds"], "unit": "simplices/s", "cores": int(j["nthreads"]), "kind": "reference",
-                       "sample": sample + f" ({nsimp} simplices in {j['sweep_seconds']:.2f} s; reference default nthreads = hardware_concurrency)"}
-            except Exception as e:   # noqa: BLE001
-                out = {}
-    # the oracle port (flat arrays, pthreads) on all cores, for orientation
-    try:
-        import pyoracle
-        steps = [pyoracle.synthetic(case, list(dims), k, nt, *(me3d_params(dims) if nd == 3 else (None, None))) for k in range(nt)]
-        _, _, secs = pyoracle.track(steps, nd, 2 if case == "double_gyre" else 1, nthreads=ncores)
-        port = {"value": nsimp / secs, "unit": "simplices/s", "cores": ncores, "kind": "port", "sample": sample}
-    except Exception as e:   # noqa: BLE001
-        port = None
-    if not out and port:
-        out, port = port, None
-    return out, port
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default=os.environ.get("FTKX_BENCH_CONFIG", "c4"), choices=sorted(CONFIGS))
-    ap.add_argument("--exact-only", action="store_true", help="disable the sign cull (every simplex takes the integer test)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    import ftk_amd
-    from ftk_amd import synthetic, tslab
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-
-    nd, nv, case, dims, nt = CONFIGS[args.config]
-    scalar_input = nv == 1
-    t0_own, t1_own = tslab.slab_range(nt, world, rank)
-    own = list(range(t0_own, t1_own))
-
-    # ---- setup (untimed): generate the slab, push it (upload/adopt + derive V), pre-pass ----
-    # a real (non-null) HIP stream shared by torch and the library, so that the events below time the library's kernels
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    ctx = ftk_amd.Context(nd, local_rank)
-    ctx.set_stream(stream.cuda_stream)
-    lo = 2 if scalar_input else 1
-    dom = ([lo] * nd, [d - (3 if scalar_input else 2) for d in dims])
-    ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
-    ctx.set_options(jacobian_symmetric=scalar_input, derive_jacobian=1, tag_mode=ftk_amd.TAG_EXACT64, exact_only=args.exact_only)
-    slices = {}
-    for t in own:
-        slices[t] = synthetic.generate(case, dims, t, nt, torch, dev)
-        torch.cuda.synchronize()
-        (ctx.push_scalar_slice if scalar_input else ctx.push_slice)(t, slices[t])
-    halo_buf = torch.empty_like(slices[own[0]]) if (world > 1 and own) else None
-    torch.cuda.synchronize()
-
-    tp0 = time.perf_counter()
-    local_res = {t: ctx.slice_resolution(t)[0] for t in own}
-    if world > 1:
-        factors, _ = tslab.global_factors(local_res, nt)
-    else:
-        factors = tslab.factors_from_resolutions([local_res[t] for t in range(nt)])
-    torch.cuda.synchronize()
-    prepass_ms = (time.perf_counter() - tp0) * 1e3
-
-    def one_pass():
-        have_halo = False
-        ctx.invalidate_masks()      # every pass redoes ALL the work of the sweep, including the per-slice sign masks
-        if world > 1 and own:
-            have_halo = tslab.exchange_halo(slices[own[0]], halo_buf, nt)
-            if have_halo:
-                (ctx.push_scalar_slice if scalar_input else ctx.push_slice)(t1_own, halo_buf)
-        for t in own:
-            scope = ftk_amd.SCOPE_BOTH if (t + 1 < nt) else ftk_amd.SCOPE_ORDINAL
-            ctx.sweep_enqueue(t, scope, factors[t])
-        recs = ctx.sweep_collect()      # one mask / cull / exact launch for the whole slab, then the hit download
-        st = ctx.stats()
-        if have_halo:
-            ctx.drop_slice(t1_own)
-        return recs, st
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        recs, st = one_pass()
-    ctx.set_profiling(True)         # HIP events around every kernel launch, on the stream the kernels run on
-    barrier()
-    tt0 = time.perf_counter()
-    for _ in range(args.steps):
-        recs, st = one_pass()
-    barrier()
-    elapsed = time.perf_counter() - tt0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        agg = torch.tensor([float(len(recs)), float(st["simplices_tested"]), float(st["cells_survived"])], dtype=torch.float64, device=dev)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        n_hits, n_tested, n_cells = (int(v) for v in agg.tolist())
-    else:
-        n_hits, n_tested, n_cells = len(recs), st["simplices_tested"], st["cells_survived"]
-
-    total_simplices = tslab.count_simplices(nd, dims, nt, scalar_input)
-    ktimes = ctx.kernel_times()
-
-    # sanity of the result itself (cheap, size-independent): the single extremum must sit on x0 + dir * t
-    check = {"hits": n_hits}
-    if case == "moving_extremum_3d" and len(recs):
-        x0, dv = me3d_params(dims)
-        err = max(float(np.abs(recs["x"][:, a] - (x0[a] + dv[a] * recs["t"])).max()) for a in range(3))
-        check["max_abs_position_error_vs_analytic"] = err
-        check["types"] = sorted(set(int(v) for v in recs["type"]))
-
-    if rank == 0:
-        n_vertex = int(np.prod(dims))
-        c = 1 if scalar_input else nd
-        launches_per_pass = len(own)
-        alg_bytes_launch = 8.0 * c * n_vertex + 72.0 * (len(recs) / max(1, launches_per_pass))
-        avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        achieved = alg_bytes_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
-            try:
-                traffic = json.load(open(tj)).get(args.config, {}).get("hbm_bytes_per_launch")
-            except Exception:   # noqa: BLE001
-                traffic = None
         out = {
             "metric": "space-time simplices/sec", "value": total_simplices * args.steps / elapsed, "unit": "simplices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
