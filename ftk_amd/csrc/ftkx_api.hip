@@ -4,6 +4,7 @@
 // frees everything on every call and synchronises the whole device; here slices stay resident, launches go to a stream,
 // and the hit buffer is persistent (grown and the batch replayed if a launch overflows it).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -72,6 +73,12 @@ struct ftkx_ctx {
   u64 *h_counters = nullptr;        // pinned
   ftkx_cp_t *h_hits = nullptr;      // pinned
   size_t h_cap = 0;
+  // device-side ordering of the hit records by tag (radix sort of (tag, index) pairs + one gather)
+  ftkx_cp_t *d_sorted = nullptr;
+  u64 *d_keys = nullptr;            // 2 * sort_cap
+  unsigned *d_idx = nullptr;        // 2 * sort_cap
+  void *d_sort_tmp = nullptr;
+  size_t sort_cap = 0, sort_tmp_bytes = 0;
   // per-batch descriptors: pinned staging + device copies
   void *h_desc = nullptr, *d_desc = nullptr;
   size_t desc_cap = 0;
@@ -216,6 +223,47 @@ bool overflow_free(int nd, double maxabs, u64 factor)
   const long double M = floorl((long double)maxabs * (long double)factor) + 1.0L;
   const long double lim = 9223372036854775807.0L;
   return nd == 3 ? 24.0L * M * M * M < lim : 6.0L * M * M < lim;
+}
+
+__global__ void sort_keys_kernel(const ftkx_cp_t *__restrict__ hits, size_t n, u64 *__restrict__ keys, unsigned *__restrict__ idx)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { keys[i] = hits[i].tag; idx[i] = (unsigned)i; }
+}
+
+__global__ void sort_gather_kernel(const ftkx_cp_t *__restrict__ hits, const unsigned *__restrict__ idx, size_t n, ftkx_cp_t *__restrict__ out)
+{
+  // 72-byte records moved as nine 8-byte words by nine consecutive lanes: coalesced stores
+  const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n * 9) {
+    const size_t r = w / 9, k = w % 9;
+    reinterpret_cast<u64 *>(out)[w] = reinterpret_cast<const u64 *>(hits)[(size_t)idx[r] * 9 + k];
+  }
+}
+
+// the reference keeps hits in a std::map ordered by element; device append order is arbitrary
+int sort_hits_on_device(ftkx_ctx *c, size_t n)
+{
+  if (c->sort_cap < n) {
+    for (void *p : {(void *)c->d_sorted, (void *)c->d_keys, (void *)c->d_idx, c->d_sort_tmp}) if (p) (void)hipFree(p);
+    c->d_sorted = nullptr; c->d_keys = nullptr; c->d_idx = nullptr; c->d_sort_tmp = nullptr; c->sort_cap = 0;
+    const size_t cap = n + n / 4 + 1024;
+    HIP_TRY(c, hipMalloc((void **)&c->d_sorted, cap * sizeof(ftkx_cp_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_keys, 2 * cap * sizeof(u64)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_idx, 2 * cap * sizeof(unsigned)));
+    size_t tmp = 0;
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, c->d_keys, c->d_keys + cap, c->d_idx, c->d_idx + cap, (int)cap, 0, 64, c->stream));
+    HIP_TRY(c, hipMalloc(&c->d_sort_tmp, tmp));
+    c->sort_tmp_bytes = tmp;
+    c->sort_cap = cap;
+  }
+  const size_t cap = c->sort_cap;
+  hipLaunchKernelGGL(sort_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_hits, n, c->d_keys, c->d_idx);
+  size_t tmp = c->sort_tmp_bytes;
+  HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys + cap, c->d_idx, c->d_idx + cap, (int)n, 0, 64, c->stream));
+  hipLaunchKernelGGL(sort_gather_kernel, dim3((unsigned)((n * 9 + 255) / 256)), dim3(256), 0, c->stream, c->d_hits, c->d_idx + cap, n, c->d_sorted);
+  HIP_TRY(c, hipGetLastError());
+  return FTKX_OK;
 }
 
 void ev_begin(ftkx_ctx *c, int kind)
@@ -380,6 +428,10 @@ void ftkx_destroy(ftkx_ctx *c)
   for (auto &kv : c->slices) free_slice(kv.second);
   if (c->d_hits) (void)hipFree(c->d_hits);
   if (c->d_list) (void)hipFree(c->d_list);
+  if (c->d_sorted) (void)hipFree(c->d_sorted);
+  if (c->d_keys) (void)hipFree(c->d_keys);
+  if (c->d_idx) (void)hipFree(c->d_idx);
+  if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
   if (c->d_desc) (void)hipFree(c->d_desc);
   if (c->h_desc) (void)hipHostFree(c->h_desc);
   if (c->d_counters) (void)hipFree(c->d_counters);
@@ -581,10 +633,13 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
   c->stats.cells_survived = c->h_counters[ftkx::CNT_CELLS_SURVIVED];
   c->stats.simplices_tested = c->h_counters[ftkx::CNT_SIMPLICES_TESTED];
   if ((rc = ensure_host_buffer(c, n))) return rc;
-  if (n) {
+  if (n >= 4096 && n < (1ull << 31)) {
+    if ((rc = sort_hits_on_device(c, n))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_hits, c->d_sorted, n * sizeof(ftkx_cp_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  } else if (n) {
     HIP_TRY(c, hipMemcpyAsync(c->h_hits, c->d_hits, n * sizeof(ftkx_cp_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // device append order is arbitrary; the reference keeps hits in a std::map ordered by element
     std::sort(c->h_hits, c->h_hits + n, [](const ftkx_cp_t &a, const ftkx_cp_t &b) { return a.tag < b.tag; });
   }
   if (out) *out = c->h_hits;

@@ -503,6 +503,92 @@ __global__ __launch_bounds__(kThreads) void mask_kernel(const Mesh m, const Mask
   }
 }
 
+// Scalar input: the same masks, produced by a register-marching stencil so that every S value is fetched from HBM once.
+//   lane        = one x column (a wavefront is a 64-wide x row; x neighbours come from the adjacent lanes by DPP shuffles,
+//                 the two tile-edge lanes fetch their outside neighbour themselves);
+//   wavefront   = RY consecutive y rows held in registers (+1 halo row either side for d/dy);
+//   march       = along z (3D): planes z-1, z, z+1 of the wavefront's rows rotate through registers, one new plane is loaded
+//                 per step; in 2D there is nothing to march over, the RY rows give the y reuse.
+// Arithmetic per vertex is gradient2D / gradient3D of ndarray/grad.hh, operation for operation.
+template <int ND>
+__global__ __launch_bounds__(kThreads) void mask_march_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk)
+{
+  constexpr int RY = (ND == 3) ? 4 : 8;
+  const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
+  const int nzc = (ND == 3) ? (DD + zchunk - 1) / zchunk : 1;
+  const MaskJob job = jobs[blockIdx.z / nzc];
+  const int z0 = (ND == 3) ? (int)(blockIdx.z % nzc) * zchunk : 0;
+  const int z1 = (ND == 3) ? (z0 + zchunk < DD ? z0 + zchunk : DD) : 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;                       // array x of this lane (may lie in the row padding)
+  const int j0 = (blockIdx.y * 4 + wv) * RY;                  // first own row
+  if (j0 >= DH) return;                                       // whole wavefront outside (no barriers in this kernel)
+  const double *__restrict__ S = job.S;
+  const double thr = job.threshold;
+  const size_t sy = (size_t)DW, sz = (size_t)DW * DH;
+  const bool col_ok = i < DW;
+
+  // load one value with array-bounds guard (rows/planes outside the array read as 0 and are never used by a valid vertex)
+  auto ld = [&](int ii, int jj, int kk) -> double {
+    return (ii >= 0 && ii < DW && jj >= 0 && jj < DH && kk >= 0 && kk < DD) ? S[(size_t)ii + sy * jj + sz * kk] : 0.0;
+  };
+  auto ldc = [&](int ii, int jj) -> double {                 // 2D: indices clamped to the array (grad.hh:17-21)
+    return S[(size_t)clampi(ii, 0, DW - 1) + sy * clampi(jj, 0, DH - 1)];
+  };
+
+  double cur[RY + 2], prv[RY], nxt[RY];                       // cur[r+1] = own row r; cur[0], cur[RY+1] = y halo rows
+  for (int r = 0; r < RY + 2; r ++) cur[r] = (ND == 3) ? (col_ok ? ld(i, j0 + r - 1, z0) : 0.0) : ldc(i, j0 + r - 1);
+  for (int r = 0; r < RY; r ++) prv[r] = (ND == 3 && col_ok) ? ld(i, j0 + r, z0 - 1) : 0.0;
+
+  for (int k = z0; k < z1; k ++) {
+    if (ND == 3) for (int r = 0; r < RY; r ++) nxt[r] = col_ok ? ld(i, j0 + r, k + 1) : 0.0;
+    double h0 = 0.0, h1 = 0.0;
+    if (ND == 3) { h0 = col_ok ? ld(i, j0 - 1, k + 1) : 0.0; h1 = col_ok ? ld(i, j0 + RY, k + 1) : 0.0; }   // next plane's y halo
+    for (int r = 0; r < RY; r ++) {
+      const int j = j0 + r;
+      const double c = cur[r + 1];
+      // x neighbours: adjacent lanes; the tile-edge lanes read theirs from memory (two active lanes per instruction)
+      double xm = __shfl_up(c, 1), xp = __shfl_down(c, 1);
+      if (lane == 0) xm = (ND == 3) ? ld(i - 1, j, k) : ldc(i - 1, j);
+      if (lane == 63) xp = (ND == 3) ? ld(i + 1, j, k) : ldc(i + 1, j);
+      if (j >= DH) continue;
+      unsigned char mk = kNeutral;
+      if (col_ok) {
+        const int vx[3] = {i + m.ext_st[0], j + m.ext_st[1], k + m.ext_st[2]};
+        bool in_dom = true;
+        for (int d = 0; d < ND; d ++) in_dom = in_dom && vx[d] >= m.dom_lb[d] && vx[d] <= m.dom_ub[d];
+        if (in_dom) {
+          double g[ND];
+          if constexpr (ND == 3) {
+            if (i >= 1 && i < DW - 1 && j >= 1 && j < DH - 1 && k >= 1 && k < DD - 1) {
+              g[0] = 0.5 * (xp - xm); g[1] = 0.5 * (cur[r + 2] - cur[r]); g[2] = 0.5 * (nxt[r] - prv[r]);
+            } else { g[0] = 0.0; g[1] = 0.0; g[2] = 0.0; }
+          } else {
+            // clamped indices: at the array border the "neighbour" is the vertex itself
+            const double fxp = (i == DW - 1) ? c : xp, fxm = (i == 0) ? c : xm;
+            const double fyp = (j == DH - 1) ? c : cur[r + 2], fym = (j == 0) ? c : cur[r];
+            g[0] = (fxp - fxm) * (double)(DW - 1);
+            g[1] = (fyp - fym) * (double)(DH - 1);
+          }
+          unsigned bits = 0;
+          bool finite = true;
+          for (int cc = 0; cc < ND; cc ++) {
+            finite = finite && !(isnan(g[cc]) || isinf(g[cc]));
+            if (g[cc] >= thr) bits |= 1u << cc;
+            if (g[cc] <= -thr) bits |= 8u << cc;
+          }
+          mk = finite ? (unsigned char)bits : kNeutral;
+        }
+      }
+      if (i < P) job.M[(size_t)i + (size_t)P * ((size_t)j + (size_t)DH * (size_t)k)] = mk;
+    }
+    if (ND == 3) {
+      for (int r = 0; r < RY; r ++) { prv[r] = cur[r + 1]; cur[r + 1] = nxt[r]; }
+      cur[0] = h0; cur[RY + 1] = h1;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // FAST PATH 2/3: corner cull on the mask bytes, 8 corners per lane (SWAR), survivors -> work list
 // ---------------------------------------------------------------------------------------------------------------
@@ -592,14 +678,15 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
 
   const int tid = threadIdx.x;
   const fan_table<N> &fan = dev_fan<ND>();
+  u64 count = m.counters[CNT_SURVIVOR_LIST];
+  if (blockIdx.x == 0 && tid == 0) atomicMax(&m.counters[CNT_LIST_PEAK], count);   // the host checks the peak against the capacity
+  if (count > list_capacity) count = list_capacity;     // overflow: the host grows the list and replays the batch
+  if ((u64)blockIdx.x * G >= count) return;             // nothing for this workgroup: leave before touching LDS or scratch
   if (tid < NTYPES) {
     unsigned w = 0;
     for (int i = 0; i < N; i ++) w |= (unsigned)fan.vert[tid][i] << (8 * i);
     s_tab[tid] = w;
   }
-  u64 count = m.counters[CNT_SURVIVOR_LIST];
-  if (blockIdx.x == 0 && tid == 0) atomicMax(&m.counters[CNT_LIST_PEAK], count);   // the host checks the peak against the capacity
-  if (count > list_capacity) count = list_capacity;     // overflow: the host grows the list and replays the batch
   unsigned tested = 0;
 
   for (u64 chunk = blockIdx.x; chunk * G < count; chunk += gridDim.x) {
@@ -716,6 +803,18 @@ void tile_dims(int nd, int tile[3])
 void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream)
 {
   if (njobs <= 0) return;
+  if (m.scalar_mode) {
+    const int RY = (m.nd == 3) ? 4 : 8;
+    const int DD = m.nd == 3 ? m.ext_sz[2] : 1;
+    // z chunks: long enough to amortise the two start-up planes, short enough to fill 256 CUs several times over
+    int zchunk = 32;
+    if (m.nd == 3) { while (zchunk > 8 && (size_t)((m.mask_pitch + 63) / 64) * ((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)) * ((DD + zchunk - 1) / zchunk) * njobs < 4096) zchunk /= 2; }
+    const int nzc = m.nd == 3 ? (DD + zchunk - 1) / zchunk : 1;
+    const dim3 grid((unsigned)((m.mask_pitch + 63) / 64), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
+    if (m.nd == 2) hipLaunchKernelGGL(mask_march_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs, zchunk);
+    else hipLaunchKernelGGL(mask_march_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs, zchunk);
+    return;
+  }
   const size_t n = (size_t)m.mask_pitch * m.ext_sz[1] * (m.nd == 3 ? m.ext_sz[2] : 1);
   size_t bx = (n + kThreads - 1) / kThreads;
   if (bx > 4096) bx = 4096;                 // grid-stride the rest

@@ -161,3 +161,70 @@ def test_device_generators_match_reference_generators(gpu, oracle):
     assert np.allclose(a, oracle.synthetic("woven", [50, 41], 3, 9), rtol=0, atol=1e-13)
     a = synthetic.generate("double_gyre", (48, 24), 5, 9, torch, dev).cpu().numpy()
     assert np.allclose(a, oracle.synthetic("double_gyre", [48, 24], 5, 9), rtol=0, atol=1e-13)
+
+
+def _batched_context_run(gpu, steps, nd, nv, dims):
+    """all timesteps resident, every sweep enqueued, ONE collect (what bench.py does): exercises the batched launches, the
+    sub-batching on factor changes and the device-side sort of the hit buffer"""
+    from ftk_amd import tslab
+    scalar = nv == 1
+    lo = 2 if scalar else 1
+    dom = ([lo] * nd, [d - (3 if scalar else 2) for d in dims])
+    ctx = gpu.Context(nd)
+    ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
+    ctx.set_options(jacobian_symmetric=scalar, derive_jacobian=1, tag_mode=gpu.TAG_REFERENCE)
+    nt = len(steps)
+    res = []
+    for t in range(nt):
+        (ctx.push_scalar_slice if scalar else ctx.push_slice)(t, steps[t])
+        res.append(ctx.slice_resolution(t)[0])
+    factors = tslab.factors_from_resolutions(res)
+    for t in range(nt):
+        ctx.sweep_enqueue(t, gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL, factors[t])
+    recs = ctx.sweep_collect()
+    st = ctx.stats()
+    ctx.close()
+    out = np.zeros(len(recs), dtype=[("tag", "<u8"), ("type", "<u4"), ("ordinal", "<i4"), ("timestep", "<i4"),
+                                     ("x", "<f8", (3,)), ("t", "<f8"), ("scalar", "<f8", (3,))])
+    for f in ("tag", "type", "x", "t", "scalar"):
+        out[f] = recs[f]
+    out["ordinal"] = recs["aux"] & 1
+    out["timestep"] = recs["aux"] >> 1
+    return out, factors, st
+
+
+@pytest.mark.parametrize("name", ["woven_31x37x32", "merger_2d_32x32x100", "double_gyre_64x32x50", "random_2d_scalar_29x24x6",
+                                  "moving_extremum_3d_21x21x21x32", "random_3d_scalar_13x12x11x4", "moving_extremum_3d_21x21x21x4_overflow"])
+def test_batched_context_matches_reference_fixture(gpu, name):
+    g = load_golden(name)
+    recs, factors, st = _batched_context_run(gpu, g["steps"], g["nd"], g["nv"], g["dims"])
+    assert [int(f) for f in g["factors"]] == factors
+    assert_records_equal(recs, g["records"], coord_tol=0.0, what=name)
+
+
+def test_larger_2d_batch_vs_oracle(gpu, oracle):
+    """woven 256x256x8: ~15k hits in one collect (device radix sort path), factor changes inside the batch"""
+    dims, nt = (256, 256), 8
+    steps = [oracle.synthetic("woven", list(dims), k, nt) for k in range(nt)]
+    ref, rf, _ = oracle.track(steps, 2, 1, tag_mode=oracle.TAG_REFERENCE, nthreads=8)
+    recs, factors, st = _batched_context_run(gpu, steps, 2, 1, dims)
+    assert factors == [int(f) for f in rf]
+    assert len(ref) > 4096
+    assert_records_equal(recs, ref, coord_tol=0.0, what="woven 256x256x8")
+    assert st["cull_enabled"] == 1 and st["simplices_tested"] < 0.1 * st["work_items"]
+
+
+def test_larger_3d_vs_oracle_with_odd_sizes(gpu, oracle):
+    """sizes that are not multiples of the tile / word sizes, extremum near a corner of the domain"""
+    dims, nt = (45, 38, 27), 5
+    steps = [oracle.synthetic("moving_extremum_3d", list(dims), k, nt, [40.25, 3.375, 22.125], [0.5, 0.25, 0.125]) for k in range(nt)]
+    ref, rf, _ = oracle.track(steps, 3, 1, tag_mode=oracle.TAG_REFERENCE, nthreads=8)
+    recs, factors, st = _batched_context_run(gpu, steps, 3, 1, dims)
+    assert factors == [int(f) for f in rf]
+    assert_records_equal(recs, ref, coord_tol=0.0, what="moving_extremum 45x38x27x5")
+    rng = np.random.default_rng(3)
+    steps = [np.cumsum(rng.standard_normal((19, 22, 35)), axis=2) * 0.125 for _ in range(3)]
+    ref, rf, _ = oracle.track(steps, 3, 1, tag_mode=oracle.TAG_REFERENCE, nthreads=8)
+    recs, factors, st = _batched_context_run(gpu, steps, 3, 1, (35, 22, 19))
+    assert factors == [int(f) for f in rf]
+    assert_records_equal(recs, ref, coord_tol=0.0, what="random walk 35x22x19x3")
