@@ -504,12 +504,32 @@ __global__ __launch_bounds__(kThreads) void mask_kernel(const Mesh m, const Mask
 }
 
 // Scalar input: the same masks, produced by a register-marching stencil so that every S value is fetched from HBM once.
-//   lane        = one x column (a wavefront is a 64-wide x row; x neighbours come from the adjacent lanes by DPP shuffles,
-//                 the two tile-edge lanes fetch their outside neighbour themselves);
+//   lane        = one x column (a wavefront is a 64-wide x row; x neighbours come from the adjacent lanes by DPP wavefront
+//                 shifts, the two tile-edge lanes fetch their outside neighbour themselves);
 //   wavefront   = RY consecutive y rows held in registers (+1 halo row either side for d/dy);
 //   march       = along z (3D): planes z-1, z, z+1 of the wavefront's rows rotate through registers, one new plane is loaded
 //                 per step; in 2D there is nothing to march over, the RY rows give the y reuse.
-// Arithmetic per vertex is gradient2D / gradient3D of ndarray/grad.hh, operation for operation.
+// All loads are unconditional at CLAMPED array coordinates: in 2D that is literally gradient2D's index clamp (grad.hh:17-21);
+// in 3D a clamped value is only ever read for a vertex that is not interior, whose gradient is 0 by definition.
+// A NaN component compares false both ways and simply never contributes to a cull; +-Inf culls by its sign, which is safe
+// because any simplex that contains that vertex is rejected by the exact path anyway.
+__device__ inline double dpp_from_lower_lane(double v)   // lane n <- lane n-1 (lane 0 keeps its own value)
+{
+  const long long b = __double_as_longlong(v);
+  int lo = (int)b, hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ inline double dpp_from_upper_lane(double v)   // lane n <- lane n+1 (lane 63 keeps its own value)
+{
+  const long long b = __double_as_longlong(v);
+  int lo = (int)b, hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 template <int ND>
 __global__ __launch_bounds__(kThreads) void mask_march_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk)
 {
@@ -526,61 +546,57 @@ __global__ __launch_bounds__(kThreads) void mask_march_kernel(const Mesh m, cons
   const double *__restrict__ S = job.S;
   const double thr = job.threshold;
   const size_t sy = (size_t)DW, sz = (size_t)DW * DH;
-  const bool col_ok = i < DW;
 
-  // load one value with array-bounds guard (rows/planes outside the array read as 0 and are never used by a valid vertex)
-  auto ld = [&](int ii, int jj, int kk) -> double {
-    return (ii >= 0 && ii < DW && jj >= 0 && jj < DH && kk >= 0 && kk < DD) ? S[(size_t)ii + sy * jj + sz * kk] : 0.0;
-  };
-  auto ldc = [&](int ii, int jj) -> double {                 // 2D: indices clamped to the array (grad.hh:17-21)
-    return S[(size_t)clampi(ii, 0, DW - 1) + sy * clampi(jj, 0, DH - 1)];
-  };
+  // column: own (clamped) and, for the two edge lanes, the outside neighbour (clamped)
+  const int ic = i < DW ? i : DW - 1;
+  const bool edge = lane == 0 || lane == 63;
+  const int ih = lane == 0 ? (ic > 0 ? ic - 1 : 0) : (ic + 1 < DW ? ic + 1 : DW - 1);
+  const bool x_dom = i < DW && i + m.ext_st[0] >= m.dom_lb[0] && i + m.ext_st[0] <= m.dom_ub[0];
+  const bool x_int = i >= 1 && i < DW - 1;
+  // rows -1 .. RY: clamped row offsets; per-row flags as bit sets
+  size_t roff[RY + 2];
+  unsigned row_dom = 0, row_int = 0, row_ok = 0;
+  for (int r = 0; r < RY + 2; r ++) {
+    const int j = j0 + r - 1;
+    roff[r] = sy * (size_t)clampi(j, 0, DH - 1);
+    if (r >= 1 && r <= RY) {
+      if (j < DH) row_ok |= 1u << (r - 1);
+      if (j + m.ext_st[1] >= m.dom_lb[1] && j + m.ext_st[1] <= m.dom_ub[1]) row_dom |= 1u << (r - 1);
+      if (j >= 1 && j < DH - 1) row_int |= 1u << (r - 1);
+    }
+  }
+  const double *pc = S + ic, *ph = S + ih;
 
   double cur[RY + 2], prv[RY], nxt[RY];                       // cur[r+1] = own row r; cur[0], cur[RY+1] = y halo rows
-  for (int r = 0; r < RY + 2; r ++) cur[r] = (ND == 3) ? (col_ok ? ld(i, j0 + r - 1, z0) : 0.0) : ldc(i, j0 + r - 1);
-  for (int r = 0; r < RY; r ++) prv[r] = (ND == 3 && col_ok) ? ld(i, j0 + r, z0 - 1) : 0.0;
+  {
+    const size_t zo = sz * (size_t)z0, zp = sz * (size_t)(z0 > 0 ? z0 - 1 : 0);
+    for (int r = 0; r < RY + 2; r ++) cur[r] = pc[roff[r] + zo];
+    for (int r = 0; r < RY; r ++) prv[r] = (ND == 3) ? pc[roff[r + 1] + zp] : 0.0;
+  }
+  unsigned char *mrow = job.M + (size_t)i + (size_t)P * (size_t)j0;
 
   for (int k = z0; k < z1; k ++) {
-    if (ND == 3) for (int r = 0; r < RY; r ++) nxt[r] = col_ok ? ld(i, j0 + r, k + 1) : 0.0;
+    const size_t zo = sz * (size_t)k, zn = sz * (size_t)(k + 1 < DD ? k + 1 : DD - 1);
     double h0 = 0.0, h1 = 0.0;
-    if (ND == 3) { h0 = col_ok ? ld(i, j0 - 1, k + 1) : 0.0; h1 = col_ok ? ld(i, j0 + RY, k + 1) : 0.0; }   // next plane's y halo
+    if (ND == 3) {
+      for (int r = 0; r < RY; r ++) nxt[r] = pc[roff[r + 1] + zn];
+      h0 = pc[roff[0] + zn]; h1 = pc[roff[RY + 1] + zn];       // next plane's y halo rows
+    }
+    const bool z_dom = ND == 2 || (k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2]);
+    const bool z_int = ND == 2 || (k >= 1 && k < DD - 1);
     for (int r = 0; r < RY; r ++) {
-      const int j = j0 + r;
       const double c = cur[r + 1];
-      // x neighbours: adjacent lanes; the tile-edge lanes read theirs from memory (two active lanes per instruction)
-      double xm = __shfl_up(c, 1), xp = __shfl_down(c, 1);
-      if (lane == 0) xm = (ND == 3) ? ld(i - 1, j, k) : ldc(i - 1, j);
-      if (lane == 63) xp = (ND == 3) ? ld(i + 1, j, k) : ldc(i + 1, j);
-      if (j >= DH) continue;
-      unsigned char mk = kNeutral;
-      if (col_ok) {
-        const int vx[3] = {i + m.ext_st[0], j + m.ext_st[1], k + m.ext_st[2]};
-        bool in_dom = true;
-        for (int d = 0; d < ND; d ++) in_dom = in_dom && vx[d] >= m.dom_lb[d] && vx[d] <= m.dom_ub[d];
-        if (in_dom) {
-          double g[ND];
-          if constexpr (ND == 3) {
-            if (i >= 1 && i < DW - 1 && j >= 1 && j < DH - 1 && k >= 1 && k < DD - 1) {
-              g[0] = 0.5 * (xp - xm); g[1] = 0.5 * (cur[r + 2] - cur[r]); g[2] = 0.5 * (nxt[r] - prv[r]);
-            } else { g[0] = 0.0; g[1] = 0.0; g[2] = 0.0; }
-          } else {
-            // clamped indices: at the array border the "neighbour" is the vertex itself
-            const double fxp = (i == DW - 1) ? c : xp, fxm = (i == 0) ? c : xm;
-            const double fyp = (j == DH - 1) ? c : cur[r + 2], fym = (j == 0) ? c : cur[r];
-            g[0] = (fxp - fxm) * (double)(DW - 1);
-            g[1] = (fyp - fym) * (double)(DH - 1);
-          }
-          unsigned bits = 0;
-          bool finite = true;
-          for (int cc = 0; cc < ND; cc ++) {
-            finite = finite && !(isnan(g[cc]) || isinf(g[cc]));
-            if (g[cc] >= thr) bits |= 1u << cc;
-            if (g[cc] <= -thr) bits |= 8u << cc;
-          }
-          mk = finite ? (unsigned char)bits : kNeutral;
-        }
-      }
-      if (i < P) job.M[(size_t)i + (size_t)P * ((size_t)j + (size_t)DH * (size_t)k)] = mk;
+      double xm = dpp_from_lower_lane(c), xp = dpp_from_upper_lane(c);
+      if (edge) { const double h = ph[roff[r + 1] + zo]; if (lane == 0) xm = h; else xp = h; }
+      double g0, g1, g2 = 0.0;
+      if constexpr (ND == 3) { g0 = 0.5 * (xp - xm); g1 = 0.5 * (cur[r + 2] - cur[r]); g2 = 0.5 * (nxt[r] - prv[r]); }
+      else { g0 = (xp - xm) * (double)(DW - 1); g1 = (cur[r + 2] - cur[r]) * (double)(DH - 1); }
+      unsigned bits = (g0 >= thr ? 1u : 0u) | (g1 >= thr ? 2u : 0u) | (g0 <= -thr ? 8u : 0u) | (g1 <= -thr ? 16u : 0u);
+      if (ND == 3) bits |= (g2 >= thr ? 4u : 0u) | (g2 <= -thr ? 32u : 0u);
+      const bool rbit_int = (row_int >> r) & 1, rbit_dom = (row_dom >> r) & 1;
+      if (ND == 3 && !(x_int && rbit_int && z_int)) bits = 0;          // gradient3D leaves the array border at 0
+      if (!(x_dom && rbit_dom && z_dom)) bits = kNeutral;               // outside the domain (or row padding): never blocks a cull
+      if (((row_ok >> r) & 1) && i < P) mrow[(size_t)P * ((size_t)r + (size_t)DH * (size_t)k)] = (unsigned char)bits;
     }
     if (ND == 3) {
       for (int r = 0; r < RY; r ++) { prv[r] = cur[r + 1]; cur[r + 1] = nxt[r]; }
