@@ -605,6 +605,109 @@ __global__ __launch_bounds__(kThreads) void mask_march_kernel(const Mesh m, cons
   }
 }
 
+// Two x columns per lane (128-wide wavefront tiles, 16-byte loads, one plane of software prefetch).  Needs an even row
+// length (so that every lane's pair is 16-byte aligned) and slices below 4 GiB (32-bit byte offsets); the launcher falls
+// back to mask_march_kernel otherwise.  Same arithmetic, same result bytes.
+template <int ND>
+__global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk)
+{
+  constexpr int RY = (ND == 3) ? 4 : 8;
+  const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
+  const int nzc = (ND == 3) ? (DD + zchunk - 1) / zchunk : 1;
+  const MaskJob job = jobs[blockIdx.z / nzc];
+  const int z0 = (ND == 3) ? (int)(blockIdx.z % nzc) * zchunk : 0;
+  const int z1 = (ND == 3) ? (z0 + zchunk < DD ? z0 + zchunk : DD) : 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * 128 + 2 * lane;                 // columns i0, i0 + 1
+  const int j0 = (blockIdx.y * 4 + wv) * RY;
+  if (j0 >= DH) return;
+  const char *__restrict__ Sb = reinterpret_cast<const char *>(job.S);
+  const double thr = job.threshold, nthr = -job.threshold;
+  const unsigned sy = (unsigned)DW * 8u, sz = (unsigned)DW * (unsigned)DH * 8u;   // byte strides
+
+  const int ic = i0 < DW ? i0 : DW - 2;                       // clamped (even) column pair for the loads
+  const bool edge = lane == 0 || lane == 63;
+  const int ih = lane == 0 ? (ic > 0 ? ic - 1 : 0) : (ic + 2 < DW ? ic + 2 : DW - 1);
+  unsigned xkeep = 0, xneutral = 0;                           // per column: byte c of the pair
+  for (int c = 0; c < 2; c ++) {
+    const int i = i0 + c;
+    const bool x_dom = i < DW && i + m.ext_st[0] >= m.dom_lb[0] && i + m.ext_st[0] <= m.dom_ub[0];
+    const bool x_int = (ND == 2) || (i >= 1 && i < DW - 1);
+    if (x_int) xkeep |= 0x3fu << (8 * c);
+    if (!x_dom) xneutral |= 0x3fu << (8 * c);
+  }
+  unsigned roff[RY + 2];
+  unsigned row_dom = 0, row_int = 0, row_ok = 0;
+  for (int r = 0; r < RY + 2; r ++) {
+    const int j = j0 + r - 1;
+    roff[r] = sy * (unsigned)clampi(j, 0, DH - 1);
+    if (r >= 1 && r <= RY) {
+      if (j < DH) row_ok |= 1u << (r - 1);
+      if (j + m.ext_st[1] >= m.dom_lb[1] && j + m.ext_st[1] <= m.dom_ub[1]) row_dom |= 1u << (r - 1);
+      if (j >= 1 && j < DH - 1) row_int |= 1u << (r - 1);
+    }
+  }
+  const unsigned cb = (unsigned)ic * 8u, hb = (unsigned)ih * 8u;
+  auto ld2 = [&](unsigned off) -> double2 { return *reinterpret_cast<const double2 *>(Sb + off); };
+  auto ld1 = [&](unsigned off) -> double { return *reinterpret_cast<const double *>(Sb + off); };
+  auto zoff = [&](int k) -> unsigned { return sz * (unsigned)clampi(k, 0, DD - 1); };
+
+  double2 cur[RY + 2], prv[RY], nxt[RY + 2];
+  double ex[RY], exn[RY];                                     // outside-neighbour column of the two edge lanes
+  for (int r = 0; r < RY; r ++) { ex[r] = 0.0; exn[r] = 0.0; }
+  {
+    const unsigned zo = zoff(z0), zp = zoff(z0 - 1), zn = zoff(z0 + 1);
+    for (int r = 0; r < RY + 2; r ++) { cur[r] = ld2(cb + roff[r] + zo); nxt[r] = (ND == 3) ? ld2(cb + roff[r] + zn) : cur[r]; }
+    for (int r = 0; r < RY; r ++) prv[r] = (ND == 3) ? ld2(cb + roff[r + 1] + zp) : cur[r + 1];
+    if (edge) for (int r = 0; r < RY; r ++) { ex[r] = ld1(hb + roff[r + 1] + zo); exn[r] = (ND == 3) ? ld1(hb + roff[r + 1] + zn) : 0.0; }
+  }
+  unsigned char *mrow = job.M + (size_t)i0 + (size_t)P * (size_t)j0;
+  const bool last_tile_lane = (ND == 2) && (i0 + 1 == DW - 1);   // 2D clamp: the right neighbour of the last column is itself
+
+  for (int k = z0; k < z1; k ++) {
+    // prefetch plane k + 2 while plane k is being classified
+    double2 nn[RY + 2];
+    double exnn[RY];
+    if (ND == 3) {
+      const unsigned z2 = zoff(k + 2);
+      for (int r = 0; r < RY + 2; r ++) nn[r] = ld2(cb + roff[r] + z2);
+      if (edge) for (int r = 0; r < RY; r ++) exnn[r] = ld1(hb + roff[r + 1] + z2);
+    }
+    const bool z_dom = ND == 2 || (k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2]);
+    const bool z_int = ND == 2 || (k >= 1 && k < DD - 1);
+    for (int r = 0; r < RY; r ++) {
+      const double2 c = cur[r + 1];
+      double xm = dpp_from_lower_lane(c.y);                   // left neighbour of column i0
+      double xp = dpp_from_upper_lane(c.x);                   // right neighbour of column i0 + 1
+      if (lane == 0) xm = ex[r];
+      if (lane == 63) xp = ex[r];
+      if (last_tile_lane) xp = c.y;
+      double gx0, gx1, gy0, gy1, gz0 = 0.0, gz1 = 0.0;
+      if constexpr (ND == 3) {
+        gx0 = 0.5 * (c.y - xm); gx1 = 0.5 * (xp - c.x);
+        gy0 = 0.5 * (cur[r + 2].x - cur[r].x); gy1 = 0.5 * (cur[r + 2].y - cur[r].y);
+        gz0 = 0.5 * (nxt[r + 1].x - prv[r].x); gz1 = 0.5 * (nxt[r + 1].y - prv[r].y);
+      } else {
+        const double fx = (double)(DW - 1), fy = (double)(DH - 1);
+        gx0 = (c.y - xm) * fx; gx1 = (xp - c.x) * fx;
+        gy0 = (cur[r + 2].x - cur[r].x) * fy; gy1 = (cur[r + 2].y - cur[r].y) * fy;
+      }
+      unsigned bits = (gx0 >= thr ? 0x0001u : 0u) | (gy0 >= thr ? 0x0002u : 0u) | (gx0 <= nthr ? 0x0008u : 0u) | (gy0 <= nthr ? 0x0010u : 0u)
+                    | (gx1 >= thr ? 0x0100u : 0u) | (gy1 >= thr ? 0x0200u : 0u) | (gx1 <= nthr ? 0x0800u : 0u) | (gy1 <= nthr ? 0x1000u : 0u);
+      if (ND == 3) bits |= (gz0 >= thr ? 0x0004u : 0u) | (gz0 <= nthr ? 0x0020u : 0u) | (gz1 >= thr ? 0x0400u : 0u) | (gz1 <= nthr ? 0x2000u : 0u);
+      // wave-uniform row / plane conditions, per-lane column conditions
+      const bool u_int = ND == 2 || (((row_int >> r) & 1) && z_int), u_dom = ((row_dom >> r) & 1) && z_dom;
+      bits = u_int ? (bits & xkeep) : 0u;                     // gradient3D leaves the array border at 0
+      bits = u_dom ? (bits | xneutral) : 0x3f3fu;             // outside the domain / row padding: never blocks a cull
+      if (((row_ok >> r) & 1) && i0 < P) *reinterpret_cast<unsigned short *>(mrow + (size_t)P * ((size_t)r + (size_t)DH * (size_t)k)) = (unsigned short)bits;
+    }
+    if (ND == 3) {
+      for (int r = 0; r < RY; r ++) { prv[r] = cur[r + 1]; ex[r] = exn[r]; exn[r] = exnn[r]; }
+      for (int r = 0; r < RY + 2; r ++) { cur[r] = nxt[r]; nxt[r] = nn[r]; }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // FAST PATH 2/3: corner cull on the mask bytes, 8 corners per lane (SWAR), survivors -> work list
 // ---------------------------------------------------------------------------------------------------------------
@@ -826,6 +929,13 @@ void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t s
     int zchunk = 32;
     if (m.nd == 3) { while (zchunk > 8 && (size_t)((m.mask_pitch + 63) / 64) * ((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)) * ((DD + zchunk - 1) / zchunk) * njobs < 4096) zchunk /= 2; }
     const int nzc = m.nd == 3 ? (DD + zchunk - 1) / zchunk : 1;
+    const size_t slice_bytes = (size_t)m.ext_sz[0] * m.ext_sz[1] * DD * 8;
+    if ((m.ext_sz[0] % 2) == 0 && m.ext_sz[0] >= 2 && slice_bytes < (1ull << 32)) {
+      const dim3 grid2((unsigned)((m.mask_pitch + 127) / 128), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
+      if (m.nd == 2) hipLaunchKernelGGL(mask_march2_kernel<2>, grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk);
+      else hipLaunchKernelGGL(mask_march2_kernel<3>, grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk);
+      return;
+    }
     const dim3 grid((unsigned)((m.mask_pitch + 63) / 64), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
     if (m.nd == 2) hipLaunchKernelGGL(mask_march_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs, zchunk);
     else hipLaunchKernelGGL(mask_march_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs, zchunk);
