@@ -780,6 +780,118 @@ __global__ __launch_bounds__(kThreads) void cull_kernel(const Mesh m, const Fiel
   }
 }
 
+// Marching form of the cull: a lane keeps, for its 8 corners and a short run of z planes, the AND over each slice's 2^d
+// spatial cube vertices in registers and walks through the consecutive timesteps of the batch, so that every mask byte is
+// read from HBM once per batch instead of once per (step, role).  The x+1 word of a lane is its upper neighbour's word (DPP).
+__device__ inline u64 dpp_u64_from_upper_lane(u64 v)
+{
+  int lo = (int)v, hi = (int)(v >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return ((u64)(unsigned)hi << 32) | (u64)(unsigned)lo;
+}
+
+template <int ND>
+__global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, const Fields *__restrict__ steps, int nsteps,
+                                                              u64 *__restrict__ list, u64 list_capacity)
+{
+  constexpr int ZC = (ND == 3) ? 8 : 1;
+  constexpr u64 kAll = 0x3f3f3f3f3f3f3f3full, k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
+  const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int g = blockIdx.x * 64 + lane;
+  const int j = blockIdx.y * 4 + wv;
+  const int z0 = (ND == 3) ? (int)blockIdx.z * ZC : 0;
+  const int ngroups = (DW + 7) / 8;
+  const bool g_ok = g < ngroups;
+  const int gc = g_ok ? g : ngroups - 1;                       // clamped: every lane issues valid loads
+  const int cy = j + m.ext_st[1];
+  const bool row_ok = j < DH && cy >= m.core_st[1] && cy < m.core_st[1] + m.core_sz[1];   // wave-uniform
+  if (!row_ok) return;
+  u64 in_core = 0;
+  if (g_ok)
+    for (int b = 0; b < 8; b ++) {
+      const int cx = g * 8 + b + m.ext_st[0];
+      if (cx >= m.core_st[0] && cx < m.core_st[0] + m.core_sz[0]) in_core |= 0x80ull << (8 * b);
+    }
+  unsigned zmask = 0;                                          // planes of the chunk whose corners are in core
+  for (int zi = 0; zi < ZC; zi ++) {
+    const int k = z0 + zi, cz = k + m.ext_st[2];
+    if (k < DD && (ND == 2 || (cz >= m.core_st[2] && cz < m.core_st[2] + m.core_sz[2]))) zmask |= 1u << zi;
+  }
+  if (zmask == 0) return;
+  const bool have_row1 = j + 1 < DH;
+
+  // AND over (x, x+1) x (y, y+1) of one plane
+  auto plane_and = [&](const unsigned char *__restrict__ M, int k) -> u64 {
+    if (k >= DD) return kAll;
+    const size_t off0 = (size_t)P * ((size_t)j + (size_t)DH * (size_t)k);
+    u64 r = kAll;
+    for (int dy = 0; dy < 2; dy ++) {
+      if (dy == 1 && !have_row1) break;
+      const u64 *row = reinterpret_cast<const u64 *>(M + off0 + (size_t)P * dy);
+      const u64 w0 = row[gc];
+      u64 w1 = dpp_u64_from_upper_lane(w0);
+      if (lane == 63) w1 = row[gc + 1];                        // the pitch has 8 spare bytes: always addressable
+      r &= w0 & ((w0 >> 8) | (w1 << 56));
+    }
+    return r;
+  };
+  auto slice_cubes = [&](const unsigned char *__restrict__ M, u64 cube[ZC]) {
+    u64 a = plane_and(M, z0);
+    for (int zi = 0; zi < ZC; zi ++) {
+      u64 b = kAll;
+      if (ND == 3) b = plane_and(M, z0 + zi + 1);
+      cube[zi] = a & b;
+      a = b;
+    }
+  };
+
+  const u64 row_lin = (u64)(cy - m.core_st[1]) * (u64)m.core_sz[0];
+  const u64 plane_sz = (u64)m.core_sz[0] * (u64)m.core_sz[1];
+  u64 cur[ZC], nxt[ZC];
+  const unsigned char *have_cur = nullptr;
+  for (int s = 0; s < nsteps; s ++) {
+    const Fields f = steps[s];
+    const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0;
+    if (have_cur != f.M[0]) slice_cubes(f.M[0], cur);          // otherwise slice t is last step's slice t+1: already in registers
+    if (need_next) slice_cubes(f.M[1], nxt);
+    for (int zi = 0; zi < ZC; zi ++) {
+      u64 surv_o = 0, surv_i = 0;
+      if ((zmask >> zi) & 1) {
+        // bytes are <= 0x3f: adding 0x7f sets bit 7 exactly in the non-zero bytes, without carries between bytes
+        if (f.scope_mask & FTKX_SCOPE_ORDINAL) surv_o = ~(cur[zi] + k7f) & k80 & in_core;
+        if (need_next) surv_i = ~((cur[zi] & nxt[zi]) + k7f) & k80 & in_core;
+      }
+      const u64 any = surv_o | surv_i;
+      if (__ballot(any != 0) == 0) continue;                   // the common case: nothing survives in this wavefront row
+      const unsigned cnt = (unsigned)__popcll(any);
+      unsigned incl = cnt;
+      for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+      const unsigned total = __shfl(incl, 63);
+      u64 base = 0;
+      if (lane == 63) {
+        base = atomicAdd(&m.counters[CNT_SURVIVOR_LIST], (u64)total);
+        atomicAdd(&m.counters[CNT_CELLS_SURVIVED], (u64)total);
+      }
+      base = __shfl(base, 63);
+      u64 pos = base + (incl - cnt);
+      if (cnt) {
+        const u64 lin0 = row_lin + (ND == 3 ? (u64)(z0 + zi + m.ext_st[2] - m.core_st[2]) * plane_sz : 0ull);
+        for (int b = 0; b < 8; b ++) {
+          const unsigned fl = (unsigned)((surv_o >> (8 * b + 7)) & 1) | ((unsigned)((surv_i >> (8 * b + 7)) & 1) << 1);
+          if (!fl) continue;
+          const u64 lin = lin0 + (u64)(g * 8 + b + m.ext_st[0] - m.core_st[0]);
+          if (pos < list_capacity) list[pos] = lin | ((u64)fl << 40) | ((u64)s << 44);
+          pos ++;
+        }
+      }
+    }
+    if (need_next) { for (int zi = 0; zi < ZC; zi ++) cur[zi] = nxt[zi]; have_cur = f.M[1]; }
+    else have_cur = f.M[0];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // FAST PATH 3/3: exact test of the surviving corners
 // ---------------------------------------------------------------------------------------------------------------
@@ -952,6 +1064,14 @@ void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t s
 void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream)
 {
   if (nsteps <= 0) return;
+  {
+    const int ZC = m.nd == 3 ? 8 : 1;
+    const int groups = (m.ext_sz[0] + 7) / 8;
+    const dim3 grid((unsigned)((groups + 63) / 64), (unsigned)((m.ext_sz[1] + 3) / 4), (unsigned)(m.nd == 3 ? (m.ext_sz[2] + ZC - 1) / ZC : 1));
+    if (m.nd == 2) hipLaunchKernelGGL(cull_march_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, d_list, cap);
+    else hipLaunchKernelGGL(cull_march_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, d_list, cap);
+    return;
+  }
   const int groups = (m.ext_sz[0] + 7) / 8;
   const dim3 grid((unsigned)((groups + 31) / 32), (unsigned)((m.ext_sz[1] + 7) / 8), (unsigned)((m.nd == 3 ? m.ext_sz[2] : 1) * nsteps));
   if (m.nd == 2) hipLaunchKernelGGL(cull_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, d_list, cap);
