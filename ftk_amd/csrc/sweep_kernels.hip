@@ -792,24 +792,30 @@ __device__ inline u64 dpp_u64_from_upper_lane(u64 v)
 }
 
 template <int ND>
-__global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, const Fields *__restrict__ steps, int nsteps,
-                                                              u64 *__restrict__ list, u64 list_capacity)
+__global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, const Fields *__restrict__ steps, int nsteps, int step_chunk,
+                                                              int gx_log2, u64 *__restrict__ list, u64 list_capacity)
 {
-  constexpr int ZC = (ND == 3) ? 8 : 1;
+  constexpr int ZC = (ND == 3) ? 4 : 1;
   constexpr u64 kAll = 0x3f3f3f3f3f3f3f3full, k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
   const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int g = blockIdx.x * 64 + lane;
-  const int j = blockIdx.y * 4 + wv;
-  const int z0 = (ND == 3) ? (int)blockIdx.z * ZC : 0;
+  // a wavefront covers GX 8-corner groups along x times 64/GX rows (GX = 64 for rows of 512+ vertices)
+  const int GX = 1 << gx_log2, rows_per_wave = 64 >> gx_log2;
+  const int gl = lane & (GX - 1);
+  const int g = blockIdx.x * GX + gl;
+  const int j = (blockIdx.y * 4 + wv) * rows_per_wave + (lane >> gx_log2);
+  const int nzc = (ND == 3) ? (DD + ZC - 1) / ZC : 1;
+  const int z0 = (ND == 3) ? (int)(blockIdx.z % nzc) * ZC : 0;
+  const int s0 = (int)(blockIdx.z / nzc) * step_chunk;
+  const int s1 = s0 + step_chunk < nsteps ? s0 + step_chunk : nsteps;
   const int ngroups = (DW + 7) / 8;
   const bool g_ok = g < ngroups;
   const int gc = g_ok ? g : ngroups - 1;                       // clamped: every lane issues valid loads
+  const int jc = j < DH ? j : DH - 1;
   const int cy = j + m.ext_st[1];
-  const bool row_ok = j < DH && cy >= m.core_st[1] && cy < m.core_st[1] + m.core_sz[1];   // wave-uniform
-  if (!row_ok) return;
+  const bool row_ok = j < DH && cy >= m.core_st[1] && cy < m.core_st[1] + m.core_sz[1];
   u64 in_core = 0;
-  if (g_ok)
+  if (g_ok && row_ok)
     for (int b = 0; b < 8; b ++) {
       const int cx = g * 8 + b + m.ext_st[0];
       if (cx >= m.core_st[0] && cx < m.core_st[0] + m.core_sz[0]) in_core |= 0x80ull << (8 * b);
@@ -819,23 +825,20 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
     const int k = z0 + zi, cz = k + m.ext_st[2];
     if (k < DD && (ND == 2 || (cz >= m.core_st[2] && cz < m.core_st[2] + m.core_sz[2]))) zmask |= 1u << zi;
   }
-  if (zmask == 0) return;
-  const bool have_row1 = j + 1 < DH;
+  if (zmask == 0) return;                                      // wave-uniform
+  const bool have_row1 = jc + 1 < DH;
+  const bool seg_end = gl == GX - 1;                           // the x+1 word is not in the next lane
 
   // AND over (x, x+1) x (y, y+1) of one plane
   auto plane_and = [&](const unsigned char *__restrict__ M, int k) -> u64 {
     if (k >= DD) return kAll;
-    const size_t off0 = (size_t)P * ((size_t)j + (size_t)DH * (size_t)k);
-    u64 r = kAll;
-    for (int dy = 0; dy < 2; dy ++) {
-      if (dy == 1 && !have_row1) break;
-      const u64 *row = reinterpret_cast<const u64 *>(M + off0 + (size_t)P * dy);
-      const u64 w0 = row[gc];
-      u64 w1 = dpp_u64_from_upper_lane(w0);
-      if (lane == 63) w1 = row[gc + 1];                        // the pitch has 8 spare bytes: always addressable
-      r &= w0 & ((w0 >> 8) | (w1 << 56));
-    }
-    return r;
+    const size_t off0 = (size_t)P * ((size_t)jc + (size_t)DH * (size_t)k);
+    const u64 *row0 = reinterpret_cast<const u64 *>(M + off0);
+    const u64 *row1 = reinterpret_cast<const u64 *>(M + off0 + (have_row1 ? (size_t)P : 0));
+    const u64 a0 = row0[gc], b0 = row1[gc];
+    u64 a1 = dpp_u64_from_upper_lane(a0), b1 = dpp_u64_from_upper_lane(b0);
+    if (seg_end) { a1 = row0[gc + 1]; b1 = row1[gc + 1]; }    // the pitch has 8 spare bytes: always addressable
+    return (a0 & ((a0 >> 8) | (a1 << 56))) & (b0 & ((b0 >> 8) | (b1 << 56)));
   };
   auto slice_cubes = [&](const unsigned char *__restrict__ M, u64 cube[ZC]) {
     u64 a = plane_and(M, z0);
@@ -851,7 +854,8 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
   const u64 plane_sz = (u64)m.core_sz[0] * (u64)m.core_sz[1];
   u64 cur[ZC], nxt[ZC];
   const unsigned char *have_cur = nullptr;
-  for (int s = 0; s < nsteps; s ++) {
+#pragma unroll 1
+  for (int s = s0; s < s1; s ++) {
     const Fields f = steps[s];
     const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0;
     if (have_cur != f.M[0]) slice_cubes(f.M[0], cur);          // otherwise slice t is last step's slice t+1: already in registers
@@ -864,7 +868,7 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
         if (need_next) surv_i = ~((cur[zi] & nxt[zi]) + k7f) & k80 & in_core;
       }
       const u64 any = surv_o | surv_i;
-      if (__ballot(any != 0) == 0) continue;                   // the common case: nothing survives in this wavefront row
+      if (__ballot(any != 0) == 0) continue;                   // the common case: nothing survives in this wavefront
       const unsigned cnt = (unsigned)__popcll(any);
       unsigned incl = cnt;
       for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
@@ -1065,11 +1069,18 @@ void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, 
 {
   if (nsteps <= 0) return;
   {
-    const int ZC = m.nd == 3 ? 8 : 1;
+    const int ZC = m.nd == 3 ? 4 : 1;
     const int groups = (m.ext_sz[0] + 7) / 8;
-    const dim3 grid((unsigned)((groups + 63) / 64), (unsigned)((m.ext_sz[1] + 3) / 4), (unsigned)(m.nd == 3 ? (m.ext_sz[2] + ZC - 1) / ZC : 1));
-    if (m.nd == 2) hipLaunchKernelGGL(cull_march_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, d_list, cap);
-    else hipLaunchKernelGGL(cull_march_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, d_list, cap);
+    int gx_log2 = 3;
+    while (gx_log2 < 6 && (1 << gx_log2) < groups) gx_log2 ++;
+    const int GX = 1 << gx_log2, rows_per_block = 4 * (64 >> gx_log2);
+    const int nzc = m.nd == 3 ? (m.ext_sz[2] + ZC - 1) / ZC : 1;
+    // steps per lane: consecutive steps reuse the shared slice from registers; more chunks = more parallelism
+    int step_chunk = 4;
+    const int nsc = (nsteps + step_chunk - 1) / step_chunk;
+    const dim3 grid((unsigned)((groups + GX - 1) / GX), (unsigned)((m.ext_sz[1] + rows_per_block - 1) / rows_per_block), (unsigned)(nzc * nsc));
+    if (m.nd == 2) hipLaunchKernelGGL(cull_march_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, step_chunk, gx_log2, d_list, cap);
+    else hipLaunchKernelGGL(cull_march_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, step_chunk, gx_log2, d_list, cap);
     return;
   }
   const int groups = (m.ext_sz[0] + 7) / 8;
