@@ -291,21 +291,19 @@ __device__ __noinline__ bool make_record(const Mesh &m, const Fields &f, const i
   return true;
 }
 
-// one simplex: vertices already classified/quantised (flags[i], Xq[i]).  Returns hit and fills rec.
+// one simplex: vertices already classified/quantised (flags[i], X[i]).  Returns whether the origin is inside (robust integer
+// test; or the FP64 solve when enable_robust_detection is off, in which case mu is filled and *presolved set).
 template <int ND>
-__device__ inline bool test_simplex(const Mesh &m, const Fields &f, int cull, const int *corner, int type, unsigned tab,
-                                    const unsigned char *flags, const u64 (*X)[ND], unsigned &tested, ftkx_cp_t *rec)
+__device__ inline bool simplex_inside(const Mesh &m, const Fields &f, int cull, const int *corner, unsigned tab,
+                                      const unsigned char *flags, const u64 (*X)[ND], unsigned &tested, int *ids, double *mu, bool *presolved)
 {
   constexpr int N = ND + 1;
   unsigned m_and = 0x3f, m_or = 0;
   for (int i = 0; i < N; i ++) { m_and &= flags[i]; m_or |= flags[i]; }
+  *presolved = false;
   if ((m_or & (kInvalid | kNonFinite)) || (cull && (m_and & 0x3f))) return false;
   tested ++;
-  int ids[N];
   for (int i = 0; i < N; i ++) ids[i] = vertex_id<ND>(m, corner, (tab >> (8 * i)) & 0xffu);
-  bool inside;
-  double mu[N];
-  bool presolved = false;
   if (ND == 3 && !m.robust) {
     // enable_robust_detection == false (3d:465-467): the FP64 solve decides
     double v[N][ND];
@@ -315,11 +313,22 @@ __device__ inline bool test_simplex(const Mesh &m, const Fields &f, int cull, co
       vector_at<ND>(m, f.S[sl], f.V[sl], corner[0] + (int)(vm & 1) - m.ext_st[0], corner[1] + (int)((vm >> 1) & 1) - m.ext_st[1],
                     ND == 3 ? corner[2] + (int)((vm >> 2) & 1) - m.ext_st[2] : 0, v[i]);
     }
-    if constexpr (ND == 3) inside = solve_barycentric3(v, mu); else inside = false;
-    presolved = true;
-  } else if constexpr (ND == 2) inside = origin_in_simplex2(X, ids);
-  else inside = origin_in_simplex3(X, ids);
-  if (!inside) return false;
+    *presolved = true;
+    if constexpr (ND == 3) return solve_barycentric3(v, mu); else return false;
+  }
+  if constexpr (ND == 2) return origin_in_simplex2(X, ids);
+  else return origin_in_simplex3(X, ids);
+}
+
+template <int ND>
+__device__ inline bool test_simplex(const Mesh &m, const Fields &f, int cull, const int *corner, int type, unsigned tab,
+                                    const unsigned char *flags, const u64 (*X)[ND], unsigned &tested, ftkx_cp_t *rec)
+{
+  constexpr int N = ND + 1;
+  int ids[N];
+  double mu[N];
+  bool presolved;
+  if (!simplex_inside<ND>(m, f, cull, corner, tab, flags, X, tested, ids, mu, &presolved)) return false;
   return make_record<ND>(m, f, corner, type, X, ids, presolved, mu, rec);
 }
 
@@ -910,6 +919,8 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
   __shared__ unsigned char s_flag[G][NVC];
   __shared__ u64 s_entry[G];
   __shared__ unsigned s_tab[NTYPES];
+  __shared__ unsigned short s_pass[G * NTYPES];   // (corner, type) pairs that passed the predicate
+  __shared__ unsigned s_npass;
 
   const int tid = threadIdx.x;
   const fan_table<N> &fan = dev_fan<ND>();
@@ -927,6 +938,7 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
   for (u64 chunk = blockIdx.x; chunk * G < count; chunk += gridDim.x) {
     __syncthreads();                                    // previous chunk's LDS readers are done
     if (tid < G) s_entry[tid] = (chunk * G + tid < count) ? list[chunk * G + tid] : ~0ull;
+    if (tid == 0) s_npass = 0;
     __syncthreads();
     {
       const int gi = tid / NVC, vtx = tid % NVC;
@@ -946,10 +958,10 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
       for (int c = 0; c < ND; c ++) s_vf[gi][vtx][c] = q[c];
     }
     __syncthreads();
-    for (int base = 0; base < G * NTYPES; base += kThreads) {    // uniform trip count (emit_hits ballots)
+    // (corner, type) pairs over all lanes; the few that pass are parked in LDS so that the expensive FP64 record
+    // construction below runs on densely packed lanes instead of one or two lanes per wavefront
+    for (int base = 0; base < G * NTYPES; base += kThreads) {
       const int w = base + tid;
-      bool hit = false;
-      ftkx_cp_t rec;
       if (w < G * NTYPES) {
         const int gi = w / NTYPES, type = w % NTYPES;
         const u64 e = s_entry[gi];
@@ -969,8 +981,36 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
             flags[i] = s_flag[gi][vm];
             for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[gi][vm][c];
           }
-          hit = test_simplex<ND>(m, f, 1, corner, type, tab, flags, X, tested, &rec);
+          int ids[N]; double mu[N]; bool presolved;
+          if (simplex_inside<ND>(m, f, 1, corner, tab, flags, X, tested, ids, mu, &presolved))
+            s_pass[atomicAdd(&s_npass, 1u)] = (unsigned short)w;
         }
+      }
+    }
+    __syncthreads();
+    const unsigned npass = s_npass;
+    for (unsigned base = 0; base < npass; base += kThreads) {   // uniform trip count (emit_hits ballots)
+      const unsigned h = base + tid;
+      bool hit = false;
+      ftkx_cp_t rec;
+      if (h < npass) {
+        const int w = s_pass[h];
+        const int gi = w / NTYPES, type = w % NTYPES;
+        const u64 e = s_entry[gi];
+        const Fields &f = steps[e >> 44];
+        u64 lin = e & 0xffffffffffull;
+        int corner[N];
+        for (int d = 0; d < ND; d ++) { corner[d] = m.core_st[d] + (int)(lin % (u64)m.core_sz[d]); lin /= (u64)m.core_sz[d]; }
+        corner[ND] = f.t;
+        const unsigned tab = s_tab[type];
+        u64 X[N][ND];
+        int ids[N];
+        for (int i = 0; i < N; i ++) {
+          const unsigned vm = (tab >> (8 * i)) & 0xffu;
+          for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[gi][vm][c];
+          ids[i] = vertex_id<ND>(m, corner, vm);
+        }
+        hit = make_record<ND>(m, f, corner, type, X, ids, false, nullptr, &rec);
       }
       emit_hits(m, hit, rec);
     }
@@ -1076,7 +1116,7 @@ void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, 
     const int GX = 1 << gx_log2, rows_per_block = 4 * (64 >> gx_log2);
     const int nzc = m.nd == 3 ? (m.ext_sz[2] + ZC - 1) / ZC : 1;
     // steps per lane: consecutive steps reuse the shared slice from registers; more chunks = more parallelism
-    int step_chunk = 4;
+    const int step_chunk = m.nd == 3 ? 4 : 1;   // 2D slices are small and survivors common: prefer parallelism
     const int nsc = (nsteps + step_chunk - 1) / step_chunk;
     const dim3 grid((unsigned)((groups + GX - 1) / GX), (unsigned)((m.ext_sz[1] + rows_per_block - 1) / rows_per_block), (unsigned)(nzc * nsc));
     if (m.nd == 2) hipLaunchKernelGGL(cull_march_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, step_chunk, gx_log2, d_list, cap);
