@@ -844,9 +844,12 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
     const size_t off0 = (size_t)P * ((size_t)jc + (size_t)DH * (size_t)k);
     const u64 *row0 = reinterpret_cast<const u64 *>(M + off0);
     const u64 *row1 = reinterpret_cast<const u64 *>(M + off0 + (have_row1 ? (size_t)P : 0));
-    const u64 a0 = row0[gc], b0 = row1[gc];
-    u64 a1 = dpp_u64_from_upper_lane(a0), b1 = dpp_u64_from_upper_lane(b0);
-    if (seg_end) { a1 = row0[gc + 1]; b1 = row1[gc + 1]; }    // the pitch has 8 spare bytes: always addressable
+    // the lane at the end of an x segment reads its x+1 word from memory (the pitch has 8 spare bytes: always addressable);
+    // issued unconditionally next to the main loads -- the other lanes just re-read their own word from L1 -- so that no
+    // second memory round trip hides behind a branch
+    const int gn = seg_end ? gc + 1 : gc;
+    const u64 a0 = row0[gc], b0 = row1[gc], an = row0[gn], bn = row1[gn];
+    const u64 a1 = seg_end ? an : dpp_u64_from_upper_lane(a0), b1 = seg_end ? bn : dpp_u64_from_upper_lane(b0);
     return (a0 & ((a0 >> 8) | (a1 << 56))) & (b0 & ((b0 >> 8) | (b1 << 56)));
   };
   auto slice_cubes = [&](const unsigned char *__restrict__ M, u64 cube[ZC]) {
