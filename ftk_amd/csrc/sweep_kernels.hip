@@ -23,6 +23,7 @@
 //
 // No MFMA: 64-bit integer VALU work on 8-24 bytes per vertex, HBM-bound once the cull applies.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "cp_device.hpp"
 #include "fan_tables.hpp"
@@ -618,17 +619,28 @@ __global__ __launch_bounds__(kThreads) void mask_march_kernel(const Mesh m, cons
 // length (so that every lane's pair is 16-byte aligned) and slices below 4 GiB (32-bit byte offsets); the launcher falls
 // back to mask_march_kernel otherwise.  Same arithmetic, same result bytes.
 template <int ND>
-__global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk)
+__global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
 {
   constexpr int RY = (ND == 3) ? 4 : 8;
   const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
   const int nzc = (ND == 3) ? (DD + zchunk - 1) / zchunk : 1;
-  const MaskJob job = jobs[blockIdx.z / nzc];
-  const int z0 = (ND == 3) ? (int)(blockIdx.z % nzc) * zchunk : 0;
+  // Workgroups are dealt round-robin over the 8 XCDs (linear ids b and b+8 share an L2).  Give every XCD a contiguous run of
+  // (x, y, z-chunk) tiles so that the y-halo rows and the chunk-boundary planes two neighbouring tiles both read are served by
+  // one L2 instead of being fetched from HBM once per XCD.  Placement only changes speed, never the result.
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (swizzle) {
+    const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
+    unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned per = nb / 8, rem = nb % 8, xcd = b % 8, k = b / 8;
+    b = xcd * per + (xcd < rem ? xcd : rem) + k;
+    bx = b % gridDim.x; by = (b / gridDim.x) % gridDim.y; bz = b / (gridDim.x * gridDim.y);
+  }
+  const MaskJob job = jobs[bz / nzc];
+  const int z0 = (ND == 3) ? (int)(bz % nzc) * zchunk : 0;
   const int z1 = (ND == 3) ? (z0 + zchunk < DD ? z0 + zchunk : DD) : 1;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i0 = blockIdx.x * 128 + 2 * lane;                 // columns i0, i0 + 1
-  const int j0 = (blockIdx.y * 4 + wv) * RY;
+  const int i0 = bx * 128 + 2 * lane;                         // columns i0, i0 + 1
+  const int j0 = (by * 4 + wv) * RY;
   if (j0 >= DH) return;
   const char *__restrict__ Sb = reinterpret_cast<const char *>(job.S);
   const double thr = job.threshold, nthr = -job.threshold;
@@ -800,11 +812,10 @@ __device__ inline u64 dpp_u64_from_upper_lane(u64 v)
   return ((u64)(unsigned)hi << 32) | (u64)(unsigned)lo;
 }
 
-template <int ND>
+template <int ND, int ZC>
 __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, const Fields *__restrict__ steps, int nsteps, int step_chunk,
                                                               int gx_log2, u64 *__restrict__ list, u64 list_capacity)
 {
-  constexpr int ZC = (ND == 3) ? 4 : 1;
   constexpr u64 kAll = 0x3f3f3f3f3f3f3f3full, k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
   const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -849,7 +860,9 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
     // second memory round trip hides behind a branch
     const int gn = seg_end ? gc + 1 : gc;
     const u64 a0 = row0[gc], b0 = row1[gc], an = row0[gn], bn = row1[gn];
-    const u64 a1 = seg_end ? an : dpp_u64_from_upper_lane(a0), b1 = seg_end ? bn : dpp_u64_from_upper_lane(b0);
+    // DPP reads need every source lane active: shift first, under the full exec mask, select afterwards
+    const u64 da = dpp_u64_from_upper_lane(a0), db = dpp_u64_from_upper_lane(b0);
+    const u64 a1 = seg_end ? an : da, b1 = seg_end ? bn : db;
     return (a0 & ((a0 >> 8) | (a1 << 56))) & (b0 & ((b0 >> 8) | (b1 << 56)));
   };
   auto slice_cubes = [&](const unsigned char *__restrict__ M, u64 cube[ZC]) {
@@ -1085,14 +1098,17 @@ void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t s
     const int RY = (m.nd == 3) ? 4 : 8;
     const int DD = m.nd == 3 ? m.ext_sz[2] : 1;
     // z chunks: long enough to amortise the two start-up planes, short enough to fill 256 CUs several times over
-    int zchunk = 32;
-    if (m.nd == 3) { while (zchunk > 8 && (size_t)((m.mask_pitch + 63) / 64) * ((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)) * ((DD + zchunk - 1) / zchunk) * njobs < 4096) zchunk /= 2; }
+    int zchunk = 64;
+    if (const char *e = getenv("FTKX_MASK_ZCHUNK")) zchunk = atoi(e) > 0 ? atoi(e) : zchunk;
+    if (m.nd == 3) { while (zchunk > 8 && (size_t)((m.mask_pitch + 127) / 128) * ((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)) * ((DD + zchunk - 1) / zchunk) * njobs < 8192) zchunk /= 2; }
+    int swizzle = 1;
+    if (const char *e = getenv("FTKX_MASK_SWIZZLE")) swizzle = atoi(e);
     const int nzc = m.nd == 3 ? (DD + zchunk - 1) / zchunk : 1;
     const size_t slice_bytes = (size_t)m.ext_sz[0] * m.ext_sz[1] * DD * 8;
     if ((m.ext_sz[0] % 2) == 0 && m.ext_sz[0] >= 2 && slice_bytes < (1ull << 32)) {
       const dim3 grid2((unsigned)((m.mask_pitch + 127) / 128), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
-      if (m.nd == 2) hipLaunchKernelGGL(mask_march2_kernel<2>, grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk);
-      else hipLaunchKernelGGL(mask_march2_kernel<3>, grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk);
+      if (m.nd == 2) hipLaunchKernelGGL(mask_march2_kernel<2>, grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle);
+      else hipLaunchKernelGGL(mask_march2_kernel<3>, grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle);
       return;
     }
     const dim3 grid((unsigned)((m.mask_pitch + 63) / 64), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
@@ -1112,18 +1128,24 @@ void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, 
 {
   if (nsteps <= 0) return;
   {
-    const int ZC = m.nd == 3 ? 4 : 1;
+    int ZC = m.nd == 3 ? 4 : 1;
+    if (const char *e = getenv("FTKX_CULL_ZC")) { const int v = atoi(e); if (m.nd == 3 && (v == 2 || v == 4 || v == 8)) ZC = v; }
     const int groups = (m.ext_sz[0] + 7) / 8;
     int gx_log2 = 3;
     while (gx_log2 < 6 && (1 << gx_log2) < groups) gx_log2 ++;
     const int GX = 1 << gx_log2, rows_per_block = 4 * (64 >> gx_log2);
     const int nzc = m.nd == 3 ? (m.ext_sz[2] + ZC - 1) / ZC : 1;
     // steps per lane: consecutive steps reuse the shared slice from registers; more chunks = more parallelism
-    const int step_chunk = m.nd == 3 ? 4 : 1;   // 2D slices are small and survivors common: prefer parallelism
+    int step_chunk = m.nd == 3 ? 4 : 1;   // 2D slices are small and survivors common: prefer parallelism
+    if (const char *e = getenv("FTKX_CULL_STEP_CHUNK")) step_chunk = atoi(e) > 0 ? atoi(e) : step_chunk;
     const int nsc = (nsteps + step_chunk - 1) / step_chunk;
     const dim3 grid((unsigned)((groups + GX - 1) / GX), (unsigned)((m.ext_sz[1] + rows_per_block - 1) / rows_per_block), (unsigned)(nzc * nsc));
-    if (m.nd == 2) hipLaunchKernelGGL(cull_march_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, step_chunk, gx_log2, d_list, cap);
-    else hipLaunchKernelGGL(cull_march_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, step_chunk, gx_log2, d_list, cap);
+#define FTKX_CULL_LAUNCH(ND_, ZC_) hipLaunchKernelGGL((cull_march_kernel<ND_, ZC_>), grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, step_chunk, gx_log2, d_list, cap)
+    if (m.nd == 2) FTKX_CULL_LAUNCH(2, 1);
+    else if (ZC == 2) FTKX_CULL_LAUNCH(3, 2);
+    else if (ZC == 8) FTKX_CULL_LAUNCH(3, 8);
+    else FTKX_CULL_LAUNCH(3, 4);
+#undef FTKX_CULL_LAUNCH
     return;
   }
   const int groups = (m.ext_sz[0] + 7) / 8;
