@@ -615,18 +615,20 @@ __global__ __launch_bounds__(kThreads) void mask_march_kernel(const Mesh m, cons
   }
 }
 
-// Two x columns per lane (128-wide wavefront tiles, 16-byte loads, one plane of software prefetch).  Needs an even row
-// length (so that every lane's pair is 16-byte aligned) and slices below 4 GiB (32-bit byte offsets); the launcher falls
-// back to mask_march_kernel otherwise.  Same arithmetic, same result bytes.
+// Two x columns per lane, 16-byte loads, one plane of software prefetch.  A wavefront covers 128 columns of which the outer
+// lane on either side is a pure halo (it only supplies the x neighbour of the adjacent lane): tiles advance by 124 columns and
+// start at an even column, so every lane's pair stays 16-byte aligned and no lane ever needs a second, divergent load.
+// Needs an even row length and slices below 4 GiB (32-bit byte offsets); the launcher falls back to mask_march_kernel
+// otherwise.  Same arithmetic, same result bytes.
+constexpr int kMarch2Cols = 124;
+
 template <int ND>
 __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
 {
   constexpr int RY = (ND == 3) ? 4 : 8;
   const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
   const int nzc = (ND == 3) ? (DD + zchunk - 1) / zchunk : 1;
-  // Workgroups are dealt round-robin over the 8 XCDs (linear ids b and b+8 share an L2).  Give every XCD a contiguous run of
-  // (x, y, z-chunk) tiles so that the y-halo rows and the chunk-boundary planes two neighbouring tiles both read are served by
-  // one L2 instead of being fetched from HBM once per XCD.  Placement only changes speed, never the result.
+  // optional XCD-aware remap (workgroups b and b+8 share an L2): contiguous runs of tiles per XCD.  Speed only.
   unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (swizzle) {
     const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
@@ -639,20 +641,20 @@ __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, con
   const int z0 = (ND == 3) ? (int)(bz % nzc) * zchunk : 0;
   const int z1 = (ND == 3) ? (z0 + zchunk < DD ? z0 + zchunk : DD) : 1;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i0 = bx * 128 + 2 * lane;                         // columns i0, i0 + 1
+  const int i0 = (int)bx * kMarch2Cols - 2 + 2 * lane;        // columns i0, i0 + 1 (lane 0 / lane 63: halo pairs)
   const int j0 = (by * 4 + wv) * RY;
   if (j0 >= DH) return;
   const char *__restrict__ Sb = reinterpret_cast<const char *>(job.S);
   const double thr = job.threshold, nthr = -job.threshold;
   const unsigned sy = (unsigned)DW * 8u, sz = (unsigned)DW * (unsigned)DH * 8u;   // byte strides
 
-  const int ic = i0 < DW ? i0 : DW - 2;                       // clamped (even) column pair for the loads
-  const bool edge = lane == 0 || lane == 63;
-  const int ih = lane == 0 ? (ic > 0 ? ic - 1 : 0) : (ic + 2 < DW ? ic + 2 : DW - 1);
+  const int ic = i0 < 0 ? 0 : (i0 < DW ? i0 : DW - 2);        // clamped (even) column pair for the loads
+  const bool dup_lo = i0 < 0, dup_hi = i0 >= DW;              // 2D index clamp: columns left / right of the array repeat the border
+  const bool owner = lane >= 1 && lane <= 62;                 // this lane writes its two mask bytes
   unsigned xkeep = 0, xneutral = 0;                           // per column: byte c of the pair
   for (int c = 0; c < 2; c ++) {
     const int i = i0 + c;
-    const bool x_dom = i < DW && i + m.ext_st[0] >= m.dom_lb[0] && i + m.ext_st[0] <= m.dom_ub[0];
+    const bool x_dom = i >= 0 && i < DW && i + m.ext_st[0] >= m.dom_lb[0] && i + m.ext_st[0] <= m.dom_ub[0];
     const bool x_int = (ND == 2) || (i >= 1 && i < DW - 1);
     if (x_int) xkeep |= 0x3fu << (8 * c);
     if (!x_dom) xneutral |= 0x3fu << (8 * c);
@@ -668,41 +670,38 @@ __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, con
       if (j >= 1 && j < DH - 1) row_int |= 1u << (r - 1);
     }
   }
-  const unsigned cb = (unsigned)ic * 8u, hb = (unsigned)ih * 8u;
-  auto ld2 = [&](unsigned off) -> double2 { return *reinterpret_cast<const double2 *>(Sb + off); };
-  auto ld1 = [&](unsigned off) -> double { return *reinterpret_cast<const double *>(Sb + off); };
+  const unsigned cb = (unsigned)ic * 8u;
+  auto ld2 = [&](unsigned off) -> double2 {
+    double2 v = *reinterpret_cast<const double2 *>(Sb + off);
+    if (ND == 2) { if (dup_lo) v.y = v.x; if (dup_hi) v.x = v.y; }
+    return v;
+  };
   auto zoff = [&](int k) -> unsigned { return sz * (unsigned)clampi(k, 0, DD - 1); };
 
   double2 cur[RY + 2], prv[RY], nxt[RY + 2];
-  double ex[RY], exn[RY];                                     // outside-neighbour column of the two edge lanes
-  for (int r = 0; r < RY; r ++) { ex[r] = 0.0; exn[r] = 0.0; }
   {
     const unsigned zo = zoff(z0), zp = zoff(z0 - 1), zn = zoff(z0 + 1);
     for (int r = 0; r < RY + 2; r ++) { cur[r] = ld2(cb + roff[r] + zo); nxt[r] = (ND == 3) ? ld2(cb + roff[r] + zn) : cur[r]; }
     for (int r = 0; r < RY; r ++) prv[r] = (ND == 3) ? ld2(cb + roff[r + 1] + zp) : cur[r + 1];
-    if (edge) for (int r = 0; r < RY; r ++) { ex[r] = ld1(hb + roff[r + 1] + zo); exn[r] = (ND == 3) ? ld1(hb + roff[r + 1] + zn) : 0.0; }
   }
-  unsigned char *mrow = job.M + (size_t)i0 + (size_t)P * (size_t)j0;
-  const bool last_tile_lane = (ND == 2) && (i0 + 1 == DW - 1);   // 2D clamp: the right neighbour of the last column is itself
+  // the row padding [DW, P) must read as neutral for the cull: the owner lanes that fall into it write it (x_dom is false there);
+  // columns in [P, ...) are not stored
+  const bool store_ok = owner && i0 >= 0 && i0 < P;
+  unsigned char *mrow = job.M + (size_t)(i0 < 0 ? 0 : i0) + (size_t)P * (size_t)j0;
 
   for (int k = z0; k < z1; k ++) {
     // prefetch plane k + 2 while plane k is being classified
     double2 nn[RY + 2];
-    double exnn[RY];
     if (ND == 3) {
       const unsigned z2 = zoff(k + 2);
       for (int r = 0; r < RY + 2; r ++) nn[r] = ld2(cb + roff[r] + z2);
-      if (edge) for (int r = 0; r < RY; r ++) exnn[r] = ld1(hb + roff[r + 1] + z2);
     }
     const bool z_dom = ND == 2 || (k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2]);
     const bool z_int = ND == 2 || (k >= 1 && k < DD - 1);
     for (int r = 0; r < RY; r ++) {
       const double2 c = cur[r + 1];
-      double xm = dpp_from_lower_lane(c.y);                   // left neighbour of column i0
-      double xp = dpp_from_upper_lane(c.x);                   // right neighbour of column i0 + 1
-      if (lane == 0) xm = ex[r];
-      if (lane == 63) xp = ex[r];
-      if (last_tile_lane) xp = c.y;
+      const double xm = dpp_from_lower_lane(c.y);             // left neighbour of column i0   (halo lane 0 serves lane 1)
+      const double xp = dpp_from_upper_lane(c.x);             // right neighbour of column i0+1 (halo lane 63 serves lane 62)
       double gx0, gx1, gy0, gy1, gz0 = 0.0, gz1 = 0.0;
       if constexpr (ND == 3) {
         gx0 = 0.5 * (c.y - xm); gx1 = 0.5 * (xp - c.x);
@@ -720,10 +719,10 @@ __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, con
       const bool u_int = ND == 2 || (((row_int >> r) & 1) && z_int), u_dom = ((row_dom >> r) & 1) && z_dom;
       bits = u_int ? (bits & xkeep) : 0u;                     // gradient3D leaves the array border at 0
       bits = u_dom ? (bits | xneutral) : 0x3f3fu;             // outside the domain / row padding: never blocks a cull
-      if (((row_ok >> r) & 1) && i0 < P) *reinterpret_cast<unsigned short *>(mrow + (size_t)P * ((size_t)r + (size_t)DH * (size_t)k)) = (unsigned short)bits;
+      if (((row_ok >> r) & 1) && store_ok) *reinterpret_cast<unsigned short *>(mrow + (size_t)P * ((size_t)r + (size_t)DH * (size_t)k)) = (unsigned short)bits;
     }
     if (ND == 3) {
-      for (int r = 0; r < RY; r ++) { prv[r] = cur[r + 1]; ex[r] = exn[r]; exn[r] = exnn[r]; }
+      for (int r = 0; r < RY; r ++) prv[r] = cur[r + 1];
       for (int r = 0; r < RY + 2; r ++) { cur[r] = nxt[r]; nxt[r] = nn[r]; }
     }
   }
@@ -849,42 +848,56 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
   const bool have_row1 = jc + 1 < DH;
   const bool seg_end = gl == GX - 1;                           // the x+1 word is not in the next lane
 
-  // AND over (x, x+1) x (y, y+1) of one plane
-  auto plane_and = [&](const unsigned char *__restrict__ M, int k) -> u64 {
-    if (k >= DD) return kAll;
-    const size_t off0 = (size_t)P * ((size_t)jc + (size_t)DH * (size_t)k);
-    const u64 *row0 = reinterpret_cast<const u64 *>(M + off0);
-    const u64 *row1 = reinterpret_cast<const u64 *>(M + off0 + (have_row1 ? (size_t)P : 0));
-    // the lane at the end of an x segment reads its x+1 word from memory (the pitch has 8 spare bytes: always addressable);
-    // issued unconditionally next to the main loads -- the other lanes just re-read their own word from L1 -- so that no
-    // second memory round trip hides behind a branch
-    const int gn = seg_end ? gc + 1 : gc;
-    const u64 a0 = row0[gc], b0 = row1[gc], an = row0[gn], bn = row1[gn];
-    // DPP reads need every source lane active: shift first, under the full exec mask, select afterwards
-    const u64 da = dpp_u64_from_upper_lane(a0), db = dpp_u64_from_upper_lane(b0);
-    const u64 a1 = seg_end ? an : da, b1 = seg_end ? bn : db;
-    return (a0 & ((a0 >> 8) | (a1 << 56))) & (b0 & ((b0 >> 8) | (b1 << 56)));
-  };
-  auto slice_cubes = [&](const unsigned char *__restrict__ M, u64 cube[ZC]) {
-    u64 a = plane_and(M, z0);
-    for (int zi = 0; zi < ZC; zi ++) {
-      u64 b = kAll;
-      if (ND == 3) b = plane_and(M, z0 + zi + 1);
-      cube[zi] = a & b;
-      a = b;
+  // raw words of one slice for this lane: planes z0 .. z0+ZC (ND == 3) x rows (y, y+1) x (own word, x+1 word).
+  // The lane at the end of an x segment reads its x+1 word from memory (the pitch has 8 spare bytes: always addressable);
+  // the other lanes take it from the next lane by DPP, their second load just re-reads their own word from L1.
+  constexpr int NP = (ND == 3) ? ZC + 1 : 1;
+  struct Raw { u64 a0[NP], b0[NP], an[NP], bn[NP]; };
+  const int gn = seg_end ? gc + 1 : gc;
+  auto load_raw = [&](const unsigned char *__restrict__ M, Raw &r) {
+    for (int p = 0; p < NP; p ++) {
+      const int k = z0 + p < DD ? z0 + p : DD - 1;             // clamped: a plane beyond the array is replaced by neutral below
+      const size_t off0 = (size_t)P * ((size_t)jc + (size_t)DH * (size_t)k);
+      const u64 *row0 = reinterpret_cast<const u64 *>(M + off0);
+      const u64 *row1 = reinterpret_cast<const u64 *>(M + off0 + (have_row1 ? (size_t)P : 0));
+      r.a0[p] = row0[gc]; r.b0[p] = row1[gc]; r.an[p] = row0[gn]; r.bn[p] = row1[gn];
     }
+  };
+  // AND over the 2^d spatial cube vertices, per plane pair
+  auto combine = [&](const Raw &r, u64 cube[ZC]) {
+    u64 pl[NP];
+    for (int p = 0; p < NP; p ++) {
+      // DPP reads need every source lane active: shift first, under the full exec mask, select afterwards
+      const u64 da = dpp_u64_from_upper_lane(r.a0[p]), db = dpp_u64_from_upper_lane(r.b0[p]);
+      const u64 a1 = seg_end ? r.an[p] : da, b1 = seg_end ? r.bn[p] : db;
+      const u64 v = (r.a0[p] & ((r.a0[p] >> 8) | (a1 << 56))) & (r.b0[p] & ((r.b0[p] >> 8) | (b1 << 56)));
+      pl[p] = (z0 + p < DD) ? v : kAll;
+    }
+    for (int zi = 0; zi < ZC; zi ++) cube[zi] = (ND == 3) ? (pl[zi] & pl[zi + 1]) : pl[0];
   };
 
   const u64 row_lin = (u64)(cy - m.core_st[1]) * (u64)m.core_sz[0];
   const u64 plane_sz = (u64)m.core_sz[0] * (u64)m.core_sz[1];
   u64 cur[ZC], nxt[ZC];
-  const unsigned char *have_cur = nullptr;
+  const unsigned char *have_cur = nullptr, *pending_ptr = nullptr;
+  Raw pending;                                                 // software prefetch: the slice the NEXT step will need first
+  auto fetch = [&](const unsigned char *ptr, u64 cube[ZC]) {
+    if (ptr == pending_ptr) combine(pending, cube);
+    else { Raw r; load_raw(ptr, r); combine(r, cube); }
+  };
 #pragma unroll 1
   for (int s = s0; s < s1; s ++) {
     const Fields f = steps[s];
     const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0;
-    if (have_cur != f.M[0]) slice_cubes(f.M[0], cur);          // otherwise slice t is last step's slice t+1: already in registers
-    if (need_next) slice_cubes(f.M[1], nxt);
+    if (have_cur != f.M[0]) fetch(f.M[0], cur);                // otherwise slice t is last step's slice t+1: already in registers
+    if (need_next) fetch(f.M[1], nxt);
+    have_cur = need_next ? f.M[1] : f.M[0];
+    pending_ptr = nullptr;
+    if (s + 1 < s1) {                                          // issue the next step's loads now; they land while this step is scanned
+      const Fields g = steps[s + 1];
+      const unsigned char *want = (g.M[0] != have_cur) ? g.M[0] : ((g.scope_mask & FTKX_SCOPE_INTERVAL) ? g.M[1] : nullptr);
+      if (want) { load_raw(want, pending); pending_ptr = want; }
+    }
     for (int zi = 0; zi < ZC; zi ++) {
       u64 surv_o = 0, surv_i = 0;
       if ((zmask >> zi) & 1) {
@@ -916,8 +929,7 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
         }
       }
     }
-    if (need_next) { for (int zi = 0; zi < ZC; zi ++) cur[zi] = nxt[zi]; have_cur = f.M[1]; }
-    else have_cur = f.M[0];
+    if (need_next) for (int zi = 0; zi < ZC; zi ++) cur[zi] = nxt[zi];
   }
 }
 
@@ -1100,13 +1112,13 @@ void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t s
     // z chunks: long enough to amortise the two start-up planes, short enough to fill 256 CUs several times over
     int zchunk = 64;
     if (const char *e = getenv("FTKX_MASK_ZCHUNK")) zchunk = atoi(e) > 0 ? atoi(e) : zchunk;
-    if (m.nd == 3) { while (zchunk > 8 && (size_t)((m.mask_pitch + 127) / 128) * ((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)) * ((DD + zchunk - 1) / zchunk) * njobs < 8192) zchunk /= 2; }
-    int swizzle = 1;
+    if (m.nd == 3) { while (zchunk > 8 && (size_t)((m.mask_pitch + kMarch2Cols - 1) / kMarch2Cols) * ((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)) * ((DD + zchunk - 1) / zchunk) * njobs < 8192) zchunk /= 2; }
+    int swizzle = 0;
     if (const char *e = getenv("FTKX_MASK_SWIZZLE")) swizzle = atoi(e);
     const int nzc = m.nd == 3 ? (DD + zchunk - 1) / zchunk : 1;
     const size_t slice_bytes = (size_t)m.ext_sz[0] * m.ext_sz[1] * DD * 8;
     if ((m.ext_sz[0] % 2) == 0 && m.ext_sz[0] >= 2 && slice_bytes < (1ull << 32)) {
-      const dim3 grid2((unsigned)((m.mask_pitch + 127) / 128), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
+      const dim3 grid2((unsigned)((m.mask_pitch + kMarch2Cols - 1) / kMarch2Cols), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
       if (m.nd == 2) hipLaunchKernelGGL(mask_march2_kernel<2>, grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle);
       else hipLaunchKernelGGL(mask_march2_kernel<3>, grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle);
       return;
@@ -1136,7 +1148,7 @@ void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, 
     const int GX = 1 << gx_log2, rows_per_block = 4 * (64 >> gx_log2);
     const int nzc = m.nd == 3 ? (m.ext_sz[2] + ZC - 1) / ZC : 1;
     // steps per lane: consecutive steps reuse the shared slice from registers; more chunks = more parallelism
-    int step_chunk = m.nd == 3 ? 4 : 1;   // 2D slices are small and survivors common: prefer parallelism
+    int step_chunk = m.nd == 3 ? 8 : 1;   // 2D slices are small and survivors common: prefer parallelism
     if (const char *e = getenv("FTKX_CULL_STEP_CHUNK")) step_chunk = atoi(e) > 0 ? atoi(e) : step_chunk;
     const int nsc = (nsteps + step_chunk - 1) / step_chunk;
     const dim3 grid((unsigned)((groups + GX - 1) / GX), (unsigned)((m.ext_sz[1] + rows_per_block - 1) / rows_per_block), (unsigned)(nzc * nsc));
