@@ -30,6 +30,7 @@ void launch_jacobian2d(const double *V, int DW, int DH, int symmetric, double *J
 void launch_gradient3d(const double *S, int DW, int DH, int DD, double *V, hipStream_t st);
 void launch_jacobian3d(const double *V, int DW, int DH, int DD, double *J, hipStream_t st);
 void launch_resolution(const double *p, size_t n, u64 *out2, hipStream_t st);
+void launch_calib_read(const void *p, size_t bytes, double *scratch, hipStream_t stream);
 }  // namespace ftkx
 
 using ftkx::Fields;
@@ -668,6 +669,16 @@ int ftkx_invalidate_masks(ftkx_ctx *c)
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_invalidate_masks: sweeps pending, collect first");
   for (auto &kv : c->slices) kv.second.mask_factor = 0;
+  return FTKX_OK;
+}
+
+int ftkx_debug_stream_read(ftkx_ctx *c, const void *device_ptr, size_t bytes)
+{
+  if (!c || !device_ptr) return fail(c, FTKX_E_INVALID, "null argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  ftkx::launch_calib_read(device_ptr, bytes, (double *)(c->d_counters + ftkx::CNT_N), c->stream);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return FTKX_OK;
 }
 

@@ -161,6 +161,10 @@ int ftkx_jacobian2D(ftkx_ctx *ctx, const double *V, int DW, int DH, int symmetri
 int ftkx_gradient3D(ftkx_ctx *ctx, const double *S, int DW, int DH, int DD, double *V);            /* grad.hh:130-149 */
 int ftkx_jacobian3D(ftkx_ctx *ctx, const double *V, int DW, int DH, int DD, double *J);            /* grad.hh:175-212 */
 
+/* profiling aid: streams `bytes` of device memory with the mask kernel's load shape (16 B per lane) and nothing else, so that
+ * rocprofv3's FETCH_SIZE can be calibrated on a known byte count (tools/calibrate_fetch.py) */
+int ftkx_debug_stream_read(ftkx_ctx *ctx, const void *device_ptr, size_t bytes);
+
 /* library / device identification */
 const char *ftkx_version(void);
 int ftkx_device_count(void);
