@@ -313,7 +313,11 @@ int run_batch(ftkx_ctx *c)
     if (r.fast) {
       for (Slice *s : {&s0, s1}) {
         if (!s) continue;
-        if (!s->M) HIP_TRY(c, hipMalloc((void **)&s->M, mask_bytes(c)));
+        if (!s->M) {
+          HIP_TRY(c, hipMalloc((void **)&s->M, mask_bytes(c)));
+          // row padding and anything a kernel does not write is cull-neutral
+          HIP_TRY(c, hipMemsetAsync(s->M, 0x3f, mask_bytes(c), c->stream));
+        }
         if (s->mask_factor != r.factor) {
           // masks of this slice already (re)built or used in the current sub-batch under another factor -> close it
           bool touched = false;

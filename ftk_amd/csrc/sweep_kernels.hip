@@ -621,27 +621,32 @@ __global__ __launch_bounds__(kThreads) void mask_march_kernel(const Mesh m, cons
 // Needs an even row length and slices below 4 GiB (32-bit byte offsets); the launcher falls back to mask_march_kernel
 // otherwise.  Same arithmetic, same result bytes.
 constexpr int kMarch2Cols = 124;
+__device__ inline bool bits_dummy_guard(double thr) { return thr < 1e300; }   // always true for real thresholds; opaque to the optimiser
 
-template <int ND>
+// EDGE = true: 128 owner columns per wavefront, every lane owns its pair, the two outside neighbours are fetched by lanes 0 and
+// 63 into a spare register set (better when the row length is a multiple of 128, e.g. 512: 4 tiles instead of 5).
+template <int ND, bool EDGE>
 __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
 {
   constexpr int RY = (ND == 3) ? 4 : 8;
+  constexpr int TILE = EDGE ? 128 : kMarch2Cols;
   const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
   const int nzc = (ND == 3) ? (DD + zchunk - 1) / zchunk : 1;
   // optional XCD-aware remap (workgroups b and b+8 share an L2): contiguous runs of tiles per XCD.  Speed only.
   unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (swizzle) {
+  if (swizzle & 1) {
     const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
     unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     const unsigned per = nb / 8, rem = nb % 8, xcd = b % 8, k = b / 8;
     b = xcd * per + (xcd < rem ? xcd : rem) + k;
     bx = b % gridDim.x; by = (b / gridDim.x) % gridDim.y; bz = b / (gridDim.x * gridDim.y);
   }
+  const bool debug_no_store = (swizzle & 2) != 0;   // profiling experiment only (FTKX_MASK_SWIZZLE=3): results are then garbage
   const MaskJob job = jobs[bz / nzc];
   const int z0 = (ND == 3) ? (int)(bz % nzc) * zchunk : 0;
   const int z1 = (ND == 3) ? (z0 + zchunk < DD ? z0 + zchunk : DD) : 1;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i0 = (int)bx * kMarch2Cols - 2 + 2 * lane;        // columns i0, i0 + 1 (lane 0 / lane 63: halo pairs)
+  const int i0 = (int)bx * TILE + (EDGE ? 0 : -2) + 2 * lane;  // columns i0, i0 + 1 (halo variant: lane 0 / lane 63 are halo pairs)
   const int j0 = (by * 4 + wv) * RY;
   if (j0 >= DH) return;
   const char *__restrict__ Sb = reinterpret_cast<const char *>(job.S);
@@ -650,7 +655,10 @@ __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, con
 
   const int ic = i0 < 0 ? 0 : (i0 < DW ? i0 : DW - 2);        // clamped (even) column pair for the loads
   const bool dup_lo = i0 < 0, dup_hi = i0 >= DW;              // 2D index clamp: columns left / right of the array repeat the border
-  const bool owner = lane >= 1 && lane <= 62;                 // this lane writes its two mask bytes
+  const bool owner = EDGE || (lane >= 1 && lane <= 62);       // this lane writes its two mask bytes
+  const bool edge = EDGE && (lane == 0 || lane == 63);
+  const int ih = lane == 0 ? (ic > 0 ? ic - 1 : 0) : (ic + 2 < DW ? ic + 2 : DW - 1);   // EDGE: outside neighbour column (clamped)
+  const unsigned hb = (unsigned)ih * 8u;
   unsigned xkeep = 0, xneutral = 0;                           // per column: byte c of the pair
   for (int c = 0; c < 2; c ++) {
     const int i = i0 + c;
@@ -678,30 +686,40 @@ __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, con
   };
   auto zoff = [&](int k) -> unsigned { return sz * (unsigned)clampi(k, 0, DD - 1); };
 
+  auto ld1 = [&](unsigned off) -> double { return *reinterpret_cast<const double *>(Sb + off); };
   double2 cur[RY + 2], prv[RY], nxt[RY + 2];
+  double ex[EDGE ? RY : 1], exn[EDGE ? RY : 1];               // EDGE: outside-neighbour column of lanes 0 / 63, planes k and k+1
+  for (int r = 0; r < (EDGE ? RY : 1); r ++) { ex[r] = 0.0; exn[r] = 0.0; }
   {
     const unsigned zo = zoff(z0), zp = zoff(z0 - 1), zn = zoff(z0 + 1);
     for (int r = 0; r < RY + 2; r ++) { cur[r] = ld2(cb + roff[r] + zo); nxt[r] = (ND == 3) ? ld2(cb + roff[r] + zn) : cur[r]; }
     for (int r = 0; r < RY; r ++) prv[r] = (ND == 3) ? ld2(cb + roff[r + 1] + zp) : cur[r + 1];
+    if (edge) for (int r = 0; r < RY; r ++) { ex[r] = ld1(hb + roff[r + 1] + zo); exn[r] = (ND == 3) ? ld1(hb + roff[r + 1] + zn) : 0.0; }
   }
-  // the row padding [DW, P) must read as neutral for the cull: the owner lanes that fall into it write it (x_dom is false there);
-  // columns in [P, ...) are not stored
-  const bool store_ok = owner && i0 >= 0 && i0 < P;
+  // the row padding [DW, P) is neutral for the cull: it is filled once when the mask array is allocated and never written here
+  const bool store_ok = owner && i0 >= 0 && i0 < DW && !(debug_no_store && bits_dummy_guard(thr));
   unsigned char *mrow = job.M + (size_t)(i0 < 0 ? 0 : i0) + (size_t)P * (size_t)j0;
 
   for (int k = z0; k < z1; k ++) {
     // prefetch plane k + 2 while plane k is being classified
     double2 nn[RY + 2];
+    double exnn[EDGE ? RY : 1];
     if (ND == 3) {
       const unsigned z2 = zoff(k + 2);
       for (int r = 0; r < RY + 2; r ++) nn[r] = ld2(cb + roff[r] + z2);
+      if (edge) for (int r = 0; r < RY; r ++) exnn[r] = ld1(hb + roff[r + 1] + z2);
     }
     const bool z_dom = ND == 2 || (k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2]);
     const bool z_int = ND == 2 || (k >= 1 && k < DD - 1);
     for (int r = 0; r < RY; r ++) {
       const double2 c = cur[r + 1];
-      const double xm = dpp_from_lower_lane(c.y);             // left neighbour of column i0   (halo lane 0 serves lane 1)
-      const double xp = dpp_from_upper_lane(c.x);             // right neighbour of column i0+1 (halo lane 63 serves lane 62)
+      double xm = dpp_from_lower_lane(c.y);                   // left neighbour of column i0   (halo lane 0 serves lane 1)
+      double xp = dpp_from_upper_lane(c.x);                   // right neighbour of column i0+1 (halo lane 63 serves lane 62)
+      if constexpr (EDGE) {
+        if (lane == 0) xm = ex[r];
+        if (lane == 63) xp = ex[r];
+        if (ND == 2 && i0 + 1 == DW - 1) xp = c.y;            // 2D clamp: the right neighbour of the last column is itself
+      }
       double gx0, gx1, gy0, gy1, gz0 = 0.0, gz1 = 0.0;
       if constexpr (ND == 3) {
         gx0 = 0.5 * (c.y - xm); gx1 = 0.5 * (xp - c.x);
@@ -724,6 +742,7 @@ __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, con
     if (ND == 3) {
       for (int r = 0; r < RY; r ++) prv[r] = cur[r + 1];
       for (int r = 0; r < RY + 2; r ++) { cur[r] = nxt[r]; nxt[r] = nn[r]; }
+      if constexpr (EDGE) for (int r = 0; r < RY; r ++) { ex[r] = exn[r]; exn[r] = exnn[r]; }
     }
   }
 }
@@ -1132,9 +1151,16 @@ void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t s
     const int nzc = m.nd == 3 ? (DD + zchunk - 1) / zchunk : 1;
     const size_t slice_bytes = (size_t)m.ext_sz[0] * m.ext_sz[1] * DD * 8;
     if ((m.ext_sz[0] % 2) == 0 && m.ext_sz[0] >= 2 && slice_bytes < (1ull << 32)) {
-      const dim3 grid2((unsigned)((m.mask_pitch + kMarch2Cols - 1) / kMarch2Cols), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
-      if (m.nd == 2) hipLaunchKernelGGL(mask_march2_kernel<2>, grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle);
-      else hipLaunchKernelGGL(mask_march2_kernel<3>, grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle);
+      // tile variant with the fewer wavefront columns wasted: 124-column tiles with halo lanes, or 128-column tiles with edge loads
+      const int DW = m.ext_sz[0];
+      const int tiles_halo = (DW + kMarch2Cols - 1) / kMarch2Cols, tiles_edge = (DW + 127) / 128;
+      bool use_edge = tiles_edge < tiles_halo;
+      if (const char *e = getenv("FTKX_MASK_EDGE")) use_edge = atoi(e) != 0;
+      const dim3 grid2((unsigned)(use_edge ? tiles_edge : tiles_halo), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
+      if (m.nd == 2) { if (use_edge) hipLaunchKernelGGL((mask_march2_kernel<2, true>), grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle);
+                       else hipLaunchKernelGGL((mask_march2_kernel<2, false>), grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle); }
+      else { if (use_edge) hipLaunchKernelGGL((mask_march2_kernel<3, true>), grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle);
+             else hipLaunchKernelGGL((mask_march2_kernel<3, false>), grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle); }
       return;
     }
     const dim3 grid((unsigned)((m.mask_pitch + 63) / 64), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
