@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--config", default=os.environ.get("FTKX_BENCH_CONFIG", "c4"), choices=sorted(CONFIGS))
     ap.add_argument("--exact-only", action="store_true", help="disable the sign cull (every simplex takes the integer test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: dry run of the N>1 path (host-staged halo)")
+    ap.add_argument("--single-device", action="store_true", help="all ranks on cuda:0 (dry run of the N>1 logic on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -107,11 +109,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # backend "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     nd, nv, case, dims, nt = CONFIGS[args.config]
     scalar_input = nv == 1
@@ -137,28 +144,32 @@ def main():
     torch.cuda.synchronize()
 
     tp0 = time.perf_counter()
-    local_res = {t: ctx.slice_resolution(t)[0] for t in own}
+    local_rm = {t: ctx.slice_resolution(t) for t in own}
+    local_res = {t: v[0] for t, v in local_rm.items()}
     if world > 1:
-        factors, _ = tslab.global_factors(local_res, nt)
+        factors, all_res, all_max = tslab.global_factors(local_res, nt, local_max={t: v[1] for t, v in local_rm.items()})
     else:
         factors = tslab.factors_from_resolutions([local_res[t] for t in range(nt)])
     torch.cuda.synchronize()
     prepass_ms = (time.perf_counter() - tp0) * 1e3
 
+    halo_pushed = [False]
+
     def one_pass():
         have_halo = False
         ctx.invalidate_masks()      # every pass redoes ALL the work of the sweep, including the per-slice sign masks
         if world > 1 and own:
+            # the slab-boundary slice travels every pass (RCCL send/recv over xGMI), into the same device buffer
             have_halo = tslab.exchange_halo(slices[own[0]], halo_buf, nt)
-            if have_halo:
+            if have_halo and not halo_pushed[0]:
                 (ctx.push_scalar_slice if scalar_input else ctx.push_slice)(t1_own, halo_buf)
+                ctx.set_slice_resolution(t1_own, all_res[t1_own], all_max[t1_own])   # its owner's reduction, from the all_gather
+                halo_pushed[0] = True
         for t in own:
             scope = ftk_amd.SCOPE_BOTH if (t + 1 < nt) else ftk_amd.SCOPE_ORDINAL
             ctx.sweep_enqueue(t, scope, factors[t])
         recs = ctx.sweep_collect()      # one mask / cull / exact launch for the whole slab, then the hit download
         st = ctx.stats()
-        if have_halo:
-            ctx.drop_slice(t1_own)
         return recs, st
 
     def barrier():
@@ -176,10 +187,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - tt0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = dev if args.backend == "nccl" else "cpu"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        agg = torch.tensor([float(len(recs)), float(st["simplices_tested"]), float(st["cells_survived"])], dtype=torch.float64, device=dev)
+        agg = torch.tensor([float(len(recs)), float(st["simplices_tested"]), float(st["cells_survived"])], dtype=torch.float64, device=cdev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         n_hits, n_tested, n_cells = (int(v) for v in agg.tolist())
     else:

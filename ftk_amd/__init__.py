@@ -105,6 +105,9 @@ class Context:
         self._ck(self._L.ftkx_slice_resolution(self._h, t, C.byref(r), C.byref(m)))
         return r.value, m.value
 
+    def set_slice_resolution(self, t, resolution, max_abs):
+        self._ck(self._L.ftkx_set_slice_resolution(self._h, t, float(resolution), float(max_abs)))
+
     def sweep(self, t, scope, factor):
         out, n = C.c_void_p(), C.c_size_t()
         self._ck(self._L.ftkx_sweep(self._h, t, scope, int(factor), C.byref(out), C.byref(n)))

@@ -36,7 +36,7 @@ class FtkxError(RuntimeError):
 
 EXPORTS = [
     "ftkx_create", "ftkx_destroy", "ftkx_last_error", "ftkx_set_stream", "ftkx_set_options", "ftkx_default_options", "ftkx_set_mesh",
-    "ftkx_push_slice", "ftkx_push_scalar_slice", "ftkx_drop_slice", "ftkx_slice_resolution", "ftkx_scaling_factor",
+    "ftkx_push_slice", "ftkx_push_scalar_slice", "ftkx_drop_slice", "ftkx_slice_resolution", "ftkx_set_slice_resolution", "ftkx_scaling_factor",
     "ftkx_sweep", "ftkx_sweep_enqueue", "ftkx_sweep_collect", "ftkx_get_stats", "ftkx_invalidate_masks", "ftkx_debug_stream_read", "ftkx_set_profiling", "ftkx_get_kernel_times", "ftkx_extract_cp2dt", "ftkx_extract_cp3dt", "ftkx_free",
     "ftkx_gradient2D", "ftkx_jacobian2D", "ftkx_gradient3D", "ftkx_jacobian3D", "ftkx_version", "ftkx_device_count",
     "ftkx_tracker_create", "ftkx_tracker_destroy", "ftkx_tracker_last_error", "ftkx_tracker_set_domain", "ftkx_tracker_set_array_domain",
@@ -69,6 +69,7 @@ def load():
     L.ftkx_push_scalar_slice.argtypes = [vp, C.c_int, dbl, C.c_int]
     L.ftkx_drop_slice.argtypes = [vp, C.c_int]
     L.ftkx_slice_resolution.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ftkx_set_slice_resolution.argtypes = [vp, C.c_int, C.c_double, C.c_double]
     L.ftkx_scaling_factor.argtypes = [C.c_double, C.POINTER(C.c_int)]; L.ftkx_scaling_factor.restype = C.c_ulonglong
     L.ftkx_sweep.argtypes = [vp, C.c_int, C.c_int, C.c_ulonglong, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ftkx_sweep_enqueue.argtypes = [vp, C.c_int, C.c_int, C.c_ulonglong]

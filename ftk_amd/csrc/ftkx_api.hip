@@ -551,6 +551,16 @@ int ftkx_slice_resolution(ftkx_ctx *c, int t, double *res, double *max_abs)
   return FTKX_OK;
 }
 
+int ftkx_set_slice_resolution(ftkx_ctx *c, int t, double resolution, double max_abs)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  auto it = c->slices.find(t);
+  if (it == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "ftkx_set_slice_resolution: timestep %d not resident", t);
+  if (!(resolution > 0) || !(max_abs >= 0)) return fail(c, FTKX_E_INVALID, "ftkx_set_slice_resolution: bad values");
+  it->second.res = resolution; it->second.maxabs = max_abs; it->second.have_res = true;
+  return FTKX_OK;
+}
+
 unsigned long long ftkx_scaling_factor(double resolution, int *nbits_out)
 {
   // critical_point_tracker.hh:850-864

@@ -42,40 +42,55 @@ def factors_from_resolutions(res):
     return [scaling_factor(float(run[min(t + 1, nt - 1)])) for t in range(nt)]
 
 
-def global_factors(local_res, nt, group=None):
-    """local_res: {t: resolution} of the slices this rank owns.  One all_gather of nt doubles (unowned entries = DBL_MAX,
-    combined with an elementwise min)."""
+def global_factors(local_res, nt, group=None, local_max=None):
+    """local_res: {t: resolution} of the slices this rank owns (local_max: {t: max finite |V|}, optional).  One all_gather of
+    2*nt doubles; unowned entries are DBL_MAX / 0 and the ranks' vectors are combined with an elementwise min / max.
+    Returns (factors[nt], res[nt]) or, with local_max, (factors, res, maxabs[nt])."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-    mine = torch.full((nt,), DBL_MAX, dtype=torch.float64, device=dev)
+    mine = torch.zeros((2 * nt,), dtype=torch.float64, device=dev)
+    mine[:nt] = DBL_MAX
     for t, r in local_res.items():
         mine[t] = r
+    for t, v in (local_max or {}).items():
+        mine[nt + t] = v
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine, group=group)
-    res = torch.stack(gathered).min(dim=0).values.cpu().numpy()
-    return factors_from_resolutions(res), res
+    allv = torch.stack(gathered)
+    res = allv[:, :nt].min(dim=0).values.cpu().numpy()
+    mx = allv[:, nt:].max(dim=0).values.cpu().numpy()
+    if local_max is None:
+        return factors_from_resolutions(res), res
+    return factors_from_resolutions(res), res, mx
 
 
 def exchange_halo(first_slice, recv_buffer, nt, group=None):
     """Each rank that owns timesteps sends its FIRST slice to the owner of the preceding timestep and receives the first
     slice of the following slab into recv_buffer.  Returns True if recv_buffer was filled (i.e. this rank's slab is not
     the last one).  Point-to-point only: xGMI is a mesh of links, a neighbour transfer uses one of them at full rate."""
+    import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     t0, t1 = slab_range(nt, world, rank)
+    # gloo (CPU tests, or the single-GPU dry run of bench.py) cannot move device tensors: stage through host memory
+    staged = dist.get_backend(group) != "nccl" and (first_slice.is_cuda or recv_buffer.is_cuda)
+    send_t = first_slice.cpu() if staged else first_slice
+    recv_t = torch.empty(recv_buffer.shape, dtype=recv_buffer.dtype) if staged else recv_buffer
     ops = []
     got = False
     if t1 > t0:
         if t0 > 0:
-            ops.append(dist.P2POp(dist.isend, first_slice, owner_of(t0 - 1, nt, world), group))
+            ops.append(dist.P2POp(dist.isend, send_t, owner_of(t0 - 1, nt, world), group))
         if t1 < nt:
-            ops.append(dist.P2POp(dist.irecv, recv_buffer, owner_of(t1, nt, world), group))
+            ops.append(dist.P2POp(dist.irecv, recv_t, owner_of(t1, nt, world), group))
             got = True
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    if staged and got:
+        recv_buffer.copy_(recv_t)
     return got
 
 

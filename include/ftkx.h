@@ -101,6 +101,9 @@ int ftkx_drop_slice(ftkx_ctx *ctx, int t);
 /* ndarray::resolution() of the slice's V (ndarray.hh:770-778): min |v| over non-zero entries (DBL_MAX if none);
  * max_abs (nullable) = max finite |v|, used for the no-overflow guard of the cull. */
 int ftkx_slice_resolution(ftkx_ctx *ctx, int t, double *resolution, double *max_abs);
+/* A slice received from another GPU (t-slab halo) comes with the reduction its owner already did: hand it over instead of
+ * reducing the slice again. */
+int ftkx_set_slice_resolution(ftkx_ctx *ctx, int t, double resolution, double max_abs);
 /* update_vector_field_scaling_factor (critical_point_tracker.hh:850-864): nbits = clamp(ceil(log2(1/res)), 8, 21) */
 unsigned long long ftkx_scaling_factor(double resolution, int *nbits);
 

@@ -57,7 +57,8 @@ def _worker(rank, world, port, nt, q):
         buf = torch.full((4, 5), -1.0, dtype=torch.float64)
         got = tslab.exchange_halo(slices[t0] if t1 > t0 else buf, buf, nt)
         halo = float(buf[0, 0]) if got else None
-        factors, res = tslab.global_factors({t: 1.0 / (t + 2) for t in range(t0, t1)}, nt)
+        factors, res, mx = tslab.global_factors({t: 1.0 / (t + 2) for t in range(t0, t1)}, nt, local_max={t: 10.0 + t for t in range(t0, t1)})
+        assert mx.tolist() == [10.0 + t for t in range(nt)]
         q.put((rank, t0, t1, halo, factors, res.tolist()))
     finally:
         dist.destroy_process_group()
