@@ -1,0 +1,128 @@
+"""Size-independent properties at (or towards) BASELINE.json's full sizes, where the CPU oracle is too slow to be the checker:
+analytic positions, cull == exact_only, partition of `core` == whole, idempotence, sortedness/uniqueness of tags."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available()
+    import ftk_amd
+    from ftk_amd import build
+    build.build()
+    return ftk_amd
+
+
+def _run(gpu, case, dims, nt, *, exact_only=False, core=None, steps=None, nv=1, tag_mode=None):
+    import torch
+    from ftk_amd import synthetic, tslab
+    nd = len(dims)
+    scalar = nv == 1
+    dev = torch.device("cuda", 0)
+    lo = 2 if scalar else 1
+    dom = ([lo] * nd, [d - (3 if scalar else 2) for d in dims])
+    ctx = gpu.Context(nd)
+    ctx.set_mesh(dom, core or dom, ([0] * nd, list(dims)))
+    ctx.set_options(jacobian_symmetric=scalar, derive_jacobian=1, tag_mode=tag_mode or gpu.TAG_EXACT64, exact_only=exact_only)
+    keep, res = [], []
+    for t in range(nt):
+        a = synthetic.generate(case, dims, t, nt, torch, dev) if steps is None else torch.from_numpy(np.ascontiguousarray(steps[t])).to(dev)
+        torch.cuda.synchronize()
+        keep.append(a)
+        (ctx.push_scalar_slice if scalar else ctx.push_slice)(t, a)
+        res.append(ctx.slice_resolution(t)[0])
+    factors = tslab.factors_from_resolutions(res)
+    for t in range(nt):
+        ctx.sweep_enqueue(t, gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL, factors[t])
+    recs = ctx.sweep_collect()
+    st = ctx.stats()
+    ctx.close()
+    return recs, st, factors
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for f in ("tag", "type", "aux"):
+        assert np.array_equal(a[f], b[f]), f
+    for f in ("x", "t", "scalar"):
+        assert np.array_equal(a[f], b[f], equal_nan=True), f
+
+
+def test_c3_moving_extremum_256cubed_analytic(gpu):
+    """BASELINE configs[2]: 256^3 x 16, 1.47e10 simplices.  One extremum on x0 + dir*t, every record a minimum."""
+    from ftk_amd import synthetic, tslab
+    dims, nt = (256, 256, 256), 16
+    recs, st, factors = _run(gpu, "moving_extremum_3d", dims, nt)
+    assert st["work_items"] == tslab.count_simplices(3, dims, nt) and st["cull_enabled"] == 1
+    assert set(factors) == {256}
+    x0, dv = synthetic.moving_extremum_params(dims)
+    assert len(recs) > 0 and set(recs["type"].tolist()) == {2}
+    for a in range(3):
+        assert np.abs(recs["x"][:, a] - (x0[a] + dv[a] * recs["t"])).max() < 1e-6      # north_star tolerance (observed ~1e-14)
+    assert np.all(np.diff(recs["tag"].astype(np.uint64)) > 0)                         # sorted, unique
+    ordinal = recs[(recs["aux"] & 1) == 1]
+    assert np.array_equal(ordinal["t"], (ordinal["aux"] >> 1).astype(float))           # ordinal points sit exactly on their timestep
+    assert len(np.unique(ordinal["aux"] >> 1)) == nt                                   # the trajectory crosses every slice
+    assert recs["scalar"][:, 0].min() >= 0 and recs["scalar"][:, 0].max() < 1.0        # S = |x - xc|^2 near the extremum
+
+
+def test_cull_equals_exact_only_128cubed(gpu):
+    recs_c, st_c, _ = _run(gpu, "moving_extremum_3d", (128, 128, 128), 4)
+    recs_e, st_e, _ = _run(gpu, "moving_extremum_3d", (128, 128, 128), 4, exact_only=True)
+    assert st_c["cull_enabled"] == 1 and st_e["cull_enabled"] == 0
+    assert st_e["simplices_tested"] > 100 * max(1, st_c["simplices_tested"])
+    _same(recs_c, recs_e)
+
+
+def test_cull_equals_exact_only_woven_1024(gpu):
+    """BASELINE configs[1] geometry (1024 x 1024), 6 timesteps: ~5e4 records"""
+    recs_c, st_c, f = _run(gpu, "woven", (1024, 1024), 6)
+    recs_e, st_e, _ = _run(gpu, "woven", (1024, 1024), 6, exact_only=True)
+    assert len(recs_c) > 3000 and st_c["cull_enabled"] == 1
+    _same(recs_c, recs_e)
+    assert set(recs_c["type"].tolist()) <= {1, 2, 4, 8}
+
+
+def test_double_gyre_vector_path_cull_equals_exact(gpu):
+    """BASELINE configs[4] kind (vector input, non-symmetric Jacobian, nbits 21) at 512 x 256 x 6"""
+    recs_c, st_c, f = _run(gpu, "double_gyre", (512, 256), 6, nv=2)
+    recs_e, st_e, _ = _run(gpu, "double_gyre", (512, 256), 6, nv=2, exact_only=True)
+    assert set(f) == {1 << 21}
+    _same(recs_c, recs_e)
+    assert len(recs_c) > 0 and set(recs_c["type"].tolist()) == {4}      # the derived off-diagonals are 0 -> saddles
+
+
+def test_partition_of_core_equals_whole(gpu):
+    """sweeping two halves of `core` (what a spatially partitioned caller would do) and merging == sweeping the whole domain"""
+    dims, nt = (96, 80, 64), 4
+    whole, _, _ = _run(gpu, "moving_extremum_3d", dims, nt)
+    lo, sz = [2, 2, 2], [d - 3 for d in dims]
+    h = sz[0] // 2
+    left, _, _ = _run(gpu, "moving_extremum_3d", dims, nt, core=(lo, [h, sz[1], sz[2]]))
+    right, _, _ = _run(gpu, "moving_extremum_3d", dims, nt, core=([lo[0] + h, 2, 2], [sz[0] - h, sz[1], sz[2]]))
+    merged = np.concatenate([left, right])
+    merged = merged[np.argsort(merged["tag"], kind="stable")]
+    _same(whole, merged)
+    rng = np.random.default_rng(1)
+    steps = [np.cumsum(rng.standard_normal((40, 56)), axis=1) * 0.25 for _ in range(3)]
+    whole, _, _ = _run(gpu, None, (56, 40), 3, steps=steps)
+    a, _, _ = _run(gpu, None, (56, 40), 3, steps=steps, core=([2, 2], [53, 17]))
+    b, _, _ = _run(gpu, None, (56, 40), 3, steps=steps, core=([2, 19], [53, 20]))
+    merged = np.concatenate([a, b]); merged = merged[np.argsort(merged["tag"], kind="stable")]
+    assert len(whole) > 50
+    _same(whole, merged)
+
+
+def test_idempotent_and_deterministic(gpu):
+    a, _, _ = _run(gpu, "woven", (300, 260), 5)
+    b, _, _ = _run(gpu, "woven", (300, 260), 5)
+    _same(a, b)
+
+
+def test_reference_and_exact_tags_agree_without_overflow(gpu):
+    a, _, _ = _run(gpu, "moving_extremum_3d", (64, 64, 64), 4, tag_mode=gpu.TAG_REFERENCE)
+    b, _, _ = _run(gpu, "moving_extremum_3d", (64, 64, 64), 4, tag_mode=gpu.TAG_EXACT64)
+    assert np.array_equal(a["tag"], b["tag"])
