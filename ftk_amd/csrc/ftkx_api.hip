@@ -24,6 +24,8 @@ void tile_dims(int nd, int tile[3]);
 void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream);
 void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream);
 void launch_exact(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, hipStream_t stream);
+bool masks_have_summary(const Mesh &m);
+void launch_cull_two_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream);
 void launch_resolution_scalar(const Mesh &m, const double *S, u64 *out2, hipStream_t stream);
 void launch_gradient2d(const double *S, int DW, int DH, double *V, hipStream_t st);
 void launch_jacobian2d(const double *V, int DW, int DH, int symmetric, double *J, hipStream_t st);
@@ -46,6 +48,7 @@ thread_local std::string g_last_error;
 struct Slice {
   double *V = nullptr, *J = nullptr, *S = nullptr;
   unsigned char *M = nullptr;       // vertex sign masks, built lazily for `mask_factor`
+  unsigned char *U = nullptr;       // per-8-vertex summaries of M (two-level cull)
   bool ownV = false, ownJ = false, ownS = false;
   unsigned long long mask_factor = 0;
   bool have_res = false;
@@ -70,6 +73,8 @@ struct ftkx_ctx {
   u64 capacity = 0;
   u64 *d_list = nullptr;            // surviving corners of the fast path
   u64 list_capacity = 0;
+  u64 *d_refine = nullptr;          // words the summary level could not rule out (two-level cull)
+  u64 refine_capacity = 0;
   u64 *d_counters = nullptr;        // CNT_N counters + 2 words for the resolution reduction
   u64 *h_counters = nullptr;        // pinned
   ftkx_cp_t *h_hits = nullptr;      // pinned
@@ -122,6 +127,8 @@ size_t n_vertices(const ftkx_ctx *c)
 }
 
 int mask_pitch(const ftkx_ctx *c) { return (int)(((c->ext_sz[0] + 7) / 8) * 8 + 8); }
+int u_pitch(const ftkx_ctx *c) { return (int)((((c->ext_sz[0] + 7) / 8 + 7) / 8) * 8 + 8); }
+size_t u_bytes(const ftkx_ctx *c) { return (size_t)u_pitch(c) * (size_t)c->ext_sz[1] * (size_t)(c->nd == 3 ? c->ext_sz[2] : 1); }
 size_t mask_bytes(const ftkx_ctx *c) { return (size_t)mask_pitch(c) * (size_t)c->ext_sz[1] * (size_t)(c->nd == 3 ? c->ext_sz[2] : 1); }
 
 void free_slice(Slice &s)
@@ -130,6 +137,7 @@ void free_slice(Slice &s)
   if (s.ownJ && s.J) (void)hipFree(s.J);
   if (s.ownS && s.S) (void)hipFree(s.S);
   if (s.M) (void)hipFree(s.M);
+  if (s.U) (void)hipFree(s.U);
   s = Slice();
 }
 
@@ -148,6 +156,15 @@ int ensure_list(ftkx_ctx *c, u64 want)
   if (c->d_list) { HIP_TRY(c, hipFree(c->d_list)); c->d_list = nullptr; c->list_capacity = 0; }
   HIP_TRY(c, hipMalloc((void **)&c->d_list, want * sizeof(u64)));
   c->list_capacity = want;
+  return FTKX_OK;
+}
+
+int ensure_refine(ftkx_ctx *c, u64 want)
+{
+  if (c->refine_capacity >= want) return FTKX_OK;
+  if (c->d_refine) { HIP_TRY(c, hipFree(c->d_refine)); c->d_refine = nullptr; c->refine_capacity = 0; }
+  HIP_TRY(c, hipMalloc((void **)&c->d_refine, want * sizeof(u64)));
+  c->refine_capacity = want;
   return FTKX_OK;
 }
 
@@ -191,6 +208,7 @@ void fill_mesh(const ftkx_ctx *c, Mesh &m)
     m.dimprod[d] = (int)((u64)c->dom_sz[d - 1] * (u64)(long long)m.dimprod[d - 1]);
   }
   m.mask_pitch = mask_pitch(c);
+  m.u_pitch = u_pitch(c);
   m.jacobian_symmetric = c->opt.jacobian_symmetric; m.robust = c->opt.robust;
   m.use_type_filter = c->opt.use_type_filter; m.type_filter = c->opt.type_filter;
   m.compute_degrees = c->opt.compute_degrees; m.tag_mode = c->opt.tag_mode;
@@ -301,6 +319,7 @@ int run_batch(ftkx_ctx *c)
   const int nd = c->nd;
   struct Sub { std::vector<MaskJob> jobs; std::vector<Fields> steps; };
   std::vector<Sub> subs(1);
+  const bool two_level = ftkx::masks_have_summary(m);
   std::vector<TileParams> tiles;
   for (const Request &r : c->pending) {
     Slice &s0 = c->slices[r.t];
@@ -318,17 +337,23 @@ int run_batch(ftkx_ctx *c)
           // row padding and anything a kernel does not write is cull-neutral
           HIP_TRY(c, hipMemsetAsync(s->M, 0x3f, mask_bytes(c), c->stream));
         }
+        if (two_level && !s->U) {
+          HIP_TRY(c, hipMalloc((void **)&s->U, u_bytes(c)));
+          HIP_TRY(c, hipMemsetAsync(s->U, 0x3f, u_bytes(c), c->stream));
+          s->mask_factor = 0;      // summaries must be produced together with the masks
+        }
         if (s->mask_factor != r.factor) {
           // masks of this slice already (re)built or used in the current sub-batch under another factor -> close it
           bool touched = false;
           for (const MaskJob &j : subs.back().jobs) touched = touched || j.M == s->M;
           for (const Fields &g : subs.back().steps) touched = touched || g.M[0] == s->M || g.M[1] == s->M;
           if (touched) subs.emplace_back();
-          subs.back().jobs.push_back(MaskJob{s->S, s->V, s->M, 1.0 / (double)r.factor});
+          subs.back().jobs.push_back(MaskJob{s->S, s->V, s->M, two_level ? s->U : nullptr, 1.0 / (double)r.factor});
           s->mask_factor = r.factor;
         }
       }
       f.M[0] = s0.M; f.M[1] = s1 ? s1->M : nullptr;
+      f.U[0] = two_level ? s0.U : nullptr; f.U[1] = (two_level && s1) ? s1->U : nullptr;
       subs.back().steps.push_back(f);
     } else {
       TileParams p;
@@ -364,8 +389,14 @@ int run_batch(ftkx_ctx *c)
     if (!sb.jobs.empty()) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs, (int)sb.jobs.size(), c->stream); ev_end(c); }
     // the survivor list is shared by the sub-batches of one collect: the exact kernel of sub-batch i must not re-test the
     // survivors of sub-batch i-1, so each sub-batch gets its own list segment by resetting the list counter in between
-    if (i > 0) HIP_TRY(c, hipMemsetAsync(c->d_counters + ftkx::CNT_SURVIVOR_LIST, 0, sizeof(u64), c->stream));
-    ev_begin(c, K_CULL); ftkx::launch_cull(m, d_steps, (int)sb.steps.size(), c->d_list, c->list_capacity, c->stream); ev_end(c);
+    if (i > 0) {
+      HIP_TRY(c, hipMemsetAsync(c->d_counters + ftkx::CNT_SURVIVOR_LIST, 0, sizeof(u64), c->stream));
+      HIP_TRY(c, hipMemsetAsync(c->d_counters + ftkx::CNT_REFINE_LIST, 0, sizeof(u64), c->stream));
+    }
+    ev_begin(c, K_CULL);
+    if (two_level) ftkx::launch_cull_two_level(m, d_steps, (int)sb.steps.size(), c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
+    else ftkx::launch_cull(m, d_steps, (int)sb.steps.size(), c->d_list, c->list_capacity, c->stream);
+    ev_end(c);
     ev_begin(c, K_EXACT); ftkx::launch_exact(m, d_steps, c->d_list, c->list_capacity, c->stream); ev_end(c);
   }
   for (const TileParams &p : tiles) { ev_begin(c, K_TILE); ftkx::launch_tile(p, c->stream); ev_end(c); }
@@ -433,6 +464,7 @@ void ftkx_destroy(ftkx_ctx *c)
   for (auto &kv : c->slices) free_slice(kv.second);
   if (c->d_hits) (void)hipFree(c->d_hits);
   if (c->d_list) (void)hipFree(c->d_list);
+  if (c->d_refine) (void)hipFree(c->d_refine);
   if (c->d_sorted) (void)hipFree(c->d_sorted);
   if (c->d_keys) (void)hipFree(c->d_keys);
   if (c->d_idx) (void)hipFree(c->d_idx);
@@ -626,20 +658,22 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
   bool any_fast = false;
   for (const Request &r : c->pending) any_fast = any_fast || r.fast;
   if (any_fast && (rc = ensure_list(c, std::max<u64>(c->list_capacity, 1u << 20)))) { c->pending.clear(); return rc; }
+  if (any_fast && (rc = ensure_refine(c, std::max<u64>(c->refine_capacity, 1u << 20)))) { c->pending.clear(); return rc; }
   for (int attempt = 0; ; attempt ++) {
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, ftkx::CNT_N * sizeof(u64), c->stream));
     if ((rc = run_batch(c))) { c->pending.clear(); return rc; }
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, ftkx::CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const u64 hits = c->h_counters[ftkx::CNT_HITS], listed = c->h_counters[ftkx::CNT_LIST_PEAK];
-    if (hits <= c->capacity && listed <= c->list_capacity) { ev_harvest(c); break; }
+    const u64 hits = c->h_counters[ftkx::CNT_HITS], listed = c->h_counters[ftkx::CNT_LIST_PEAK], refined = c->h_counters[ftkx::CNT_REFINE_PEAK];
+    if (hits <= c->capacity && listed <= c->list_capacity && refined <= c->refine_capacity) { ev_harvest(c); break; }
     // a buffer was too small (records / survivors beyond capacity were only counted): grow to what this batch needs, replay it
     for (auto &e : c->events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
     c->events.clear();
-    if (attempt == 2) { c->pending.clear(); return fail(c, FTKX_E_DEVICE, "buffer overflow persisted after regrowing twice"); }
+    if (attempt == 3) { c->pending.clear(); return fail(c, FTKX_E_DEVICE, "buffer overflow persisted after regrowing three times"); }
+    if (refined > c->refine_capacity && (rc = ensure_refine(c, refined + refined / 8 + 1024))) { c->pending.clear(); return rc; }
     if (listed > c->list_capacity && (rc = ensure_list(c, listed + listed / 8 + 1024))) { c->pending.clear(); return rc; }
     // with a truncated survivor list the hit count is a lower bound: leave generous room
-    const u64 want_hits = std::max<u64>(hits + hits / 8 + 1024, listed > c->list_capacity ? 2 * hits + 1024 : 0);
+    const u64 want_hits = std::max<u64>(hits + hits / 8 + 1024, (listed > c->list_capacity || refined > c->refine_capacity) ? 2 * hits + 1024 : 0);
     if (want_hits > c->capacity && (rc = ensure_hit_buffer(c, want_hits))) { c->pending.clear(); return rc; }
   }
   c->pending.clear();

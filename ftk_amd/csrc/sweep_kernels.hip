@@ -738,6 +738,17 @@ __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, con
       bits = u_int ? (bits & xkeep) : 0u;                     // gradient3D leaves the array border at 0
       bits = u_dom ? (bits | xneutral) : 0x3f3fu;             // outside the domain / row padding: never blocks a cull
       if (((row_ok >> r) & 1) && store_ok) *reinterpret_cast<unsigned short *>(mrow + (size_t)P * ((size_t)r + (size_t)DH * (size_t)k)) = (unsigned short)bits;
+      if constexpr (EDGE) {
+        // summary byte of the aligned 8-vertex word this quad of lanes covers: the sign bits ALL eight vertices share.
+        // (lanes beyond the row contribute neutral bytes, so a partial last word summarises its real vertices only)
+        if (job.U) {
+          int q = (int)((bits & (bits >> 8)) & 0x3fu);
+          q &= __builtin_amdgcn_update_dpp(q, q, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+          q &= __builtin_amdgcn_update_dpp(q, q, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
+          if (((row_ok >> r) & 1) && (lane & 3) == 0 && i0 < DW)
+            job.U[(size_t)(i0 >> 3) + (size_t)m.u_pitch * ((size_t)(j0 + r) + (size_t)DH * (size_t)k)] = (unsigned char)q;
+        }
+      }
     }
     if (ND == 3) {
       for (int r = 0; r < RY; r ++) prv[r] = cur[r + 1];
@@ -758,67 +769,6 @@ __device__ inline u64 load_row_pair_and(const unsigned char *__restrict__ M, siz
   return w0 & ((w0 >> 8) | (w1 << 56));            // byte b = mask(x = 8g + b) & mask(x + 1)
 }
 
-template <int ND>
-__global__ __launch_bounds__(kThreads) void cull_kernel(const Mesh m, const Fields *__restrict__ steps, u64 *__restrict__ list, u64 list_capacity)
-{
-  const int DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
-  const int g = blockIdx.x * 32 + (threadIdx.x & 31);                 // 8-corner group along x
-  const int j = blockIdx.y * 8 + (threadIdx.x >> 5);
-  const int k = (ND == 3) ? (int)(blockIdx.z % DD) : 0;
-  const int step = (ND == 3) ? (int)(blockIdx.z / DD) : (int)blockIdx.z;
-  const Fields f = steps[step];
-  const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0;
-
-  u64 surv_o = 0, surv_i = 0;   // 0x80 in byte b: corner 8g + b survives
-  const int cy = j + m.ext_st[1], cz = k + m.ext_st[2];
-  bool row_ok = g * 8 < m.ext_sz[0] && j < DH && cy >= m.core_st[1] && cy < m.core_st[1] + m.core_sz[1];
-  if (ND == 3) row_ok = row_ok && cz >= m.core_st[2] && cz < m.core_st[2] + m.core_sz[2];
-  if (row_ok) {
-    u64 a0 = ~0ull, a1 = ~0ull;
-    for (int dz = 0; dz < (ND == 3 ? 2 : 1); dz ++)
-      for (int dy = 0; dy < 2; dy ++) {
-        if (j + dy >= DH || k + dz >= DD) continue;                   // row outside the array: invalid vertices, neutral
-        const size_t off = (size_t)P * ((size_t)(j + dy) + (size_t)DH * (size_t)(k + dz));
-        a0 &= load_row_pair_and(f.M[0], off, g);
-        if (need_next) a1 &= load_row_pair_and(f.M[1], off, g);
-      }
-    // bytes are <= 0x3f: adding 0x7f sets bit 7 exactly in the non-zero bytes, without carries between bytes
-    const u64 k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
-    u64 in_core = 0;
-    for (int b = 0; b < 8; b ++) {
-      const int cx = g * 8 + b + m.ext_st[0];
-      if (cx >= m.core_st[0] && cx < m.core_st[0] + m.core_sz[0]) in_core |= 0x80ull << (8 * b);
-    }
-    if (f.scope_mask & FTKX_SCOPE_ORDINAL) surv_o = ~((a0 + k7f)) & k80 & in_core;
-    if (need_next) surv_i = ~(((a0 & a1) + k7f)) & k80 & in_core;
-  }
-  const u64 any = surv_o | surv_i;
-  const unsigned cnt = (unsigned)__popcll(any);
-  // exclusive prefix sum of cnt over the wavefront, one atomic per wavefront
-  unsigned incl = cnt;
-  const int lane = threadIdx.x & 63;
-  for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-  const unsigned total = __shfl(incl, 63);
-  if (total == 0) return;
-  u64 base = 0;
-  if (lane == 63) {
-    base = atomicAdd(&m.counters[CNT_SURVIVOR_LIST], (u64)total);
-    atomicAdd(&m.counters[CNT_CELLS_SURVIVED], (u64)total);
-  }
-  base = __shfl(base, 63);
-  u64 pos = base + (incl - cnt);
-  if (cnt) {
-    const u64 row_lin = (u64)(cy - m.core_st[1]) * (u64)m.core_sz[0] + (ND == 3 ? (u64)(cz - m.core_st[2]) * (u64)m.core_sz[0] * (u64)m.core_sz[1] : 0ull);
-    for (int b = 0; b < 8; b ++) {
-      const unsigned fl = (unsigned)((surv_o >> (8 * b + 7)) & 1) | ((unsigned)((surv_i >> (8 * b + 7)) & 1) << 1);
-      if (!fl) continue;
-      const u64 lin = row_lin + (u64)(g * 8 + b + m.ext_st[0] - m.core_st[0]);
-      if (pos < list_capacity) list[pos] = lin | ((u64)fl << 40) | ((u64)step << 44);
-      pos ++;
-    }
-  }
-}
-
 // Marching form of the cull: a lane keeps, for its 8 corners and a short run of z planes, the AND over each slice's 2^d
 // spatial cube vertices in registers and walks through the consecutive timesteps of the batch, so that every mask byte is
 // read from HBM once per batch instead of once per (step, role).  The x+1 word of a lane is its upper neighbour's word (DPP).
@@ -830,10 +780,14 @@ __device__ inline u64 dpp_u64_from_upper_lane(u64 v)
   return ((u64)(unsigned)hi << 32) | (u64)(unsigned)lo;
 }
 
-template <int ND, int ZC>
+// COARSE = true runs the very same cull one level up: the "mask array" is the per-word summary U (one byte = 8 vertices), a
+// "corner" is an aligned group of 8 corners, and what survives is appended to the refine list instead of the final list.
+template <int ND, int ZC, bool COARSE>
 __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, const Fields *__restrict__ steps, int nsteps, int step_chunk,
                                                               int gx_log2, u64 *__restrict__ list, u64 list_capacity)
 {
+  constexpr int kListCounter = COARSE ? CNT_REFINE_LIST : CNT_SURVIVOR_LIST;
+  constexpr int kStatCounter = COARSE ? CNT_WORDS_REFINED : CNT_CELLS_SURVIVED;
   constexpr u64 kAll = 0x3f3f3f3f3f3f3f3full, k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
   const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -908,13 +862,15 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
   for (int s = s0; s < s1; s ++) {
     const Fields f = steps[s];
     const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0;
-    if (have_cur != f.M[0]) fetch(f.M[0], cur);                // otherwise slice t is last step's slice t+1: already in registers
-    if (need_next) fetch(f.M[1], nxt);
-    have_cur = need_next ? f.M[1] : f.M[0];
+    const unsigned char *fm0 = COARSE ? f.U[0] : f.M[0], *fm1 = COARSE ? f.U[1] : f.M[1];
+    if (have_cur != fm0) fetch(fm0, cur);                      // otherwise slice t is last step's slice t+1: already in registers
+    if (need_next) fetch(fm1, nxt);
+    have_cur = need_next ? fm1 : fm0;
     pending_ptr = nullptr;
     if (s + 1 < s1) {                                          // issue the next step's loads now; they land while this step is scanned
       const Fields g = steps[s + 1];
-      const unsigned char *want = (g.M[0] != have_cur) ? g.M[0] : ((g.scope_mask & FTKX_SCOPE_INTERVAL) ? g.M[1] : nullptr);
+      const unsigned char *gm0 = COARSE ? g.U[0] : g.M[0], *gm1 = COARSE ? g.U[1] : g.M[1];
+      const unsigned char *want = (gm0 != have_cur) ? gm0 : ((g.scope_mask & FTKX_SCOPE_INTERVAL) ? gm1 : nullptr);
       if (want) { load_raw(want, pending); pending_ptr = want; }
     }
     for (int zi = 0; zi < ZC; zi ++) {
@@ -932,8 +888,8 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
       const unsigned total = __shfl(incl, 63);
       u64 base = 0;
       if (lane == 63) {
-        base = atomicAdd(&m.counters[CNT_SURVIVOR_LIST], (u64)total);
-        atomicAdd(&m.counters[CNT_CELLS_SURVIVED], (u64)total);
+        base = atomicAdd(&m.counters[kListCounter], (u64)total);
+        atomicAdd(&m.counters[kStatCounter], (u64)total);
       }
       base = __shfl(base, 63);
       u64 pos = base + (incl - cnt);
@@ -949,6 +905,75 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
       }
     }
     if (need_next) for (int zi = 0; zi < ZC; zi ++) cur[zi] = nxt[zi];
+  }
+}
+
+// Second level of the two-level cull: one lane per refine-list entry (an aligned word of 8 corners whose summaries could not
+// rule it out) repeats the test on the vertex mask bytes and appends the corners that still survive to the work list.
+// `mc` is the coarse view the first level ran on (its core / ext describe words), `m` the real mesh.
+template <int ND>
+__global__ __launch_bounds__(kThreads) void refine_kernel(const Mesh m, const Mesh mc, const Fields *__restrict__ steps,
+                                                          const u64 *__restrict__ refine, u64 refine_capacity,
+                                                          u64 *__restrict__ list, u64 list_capacity)
+{
+  const int DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
+  const int lane = threadIdx.x & 63;
+  u64 count = m.counters[CNT_REFINE_LIST];
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&m.counters[CNT_REFINE_PEAK], count);
+  if (count > refine_capacity) count = refine_capacity;
+  const u64 k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
+  for (u64 base = (u64)blockIdx.x * kThreads; base < count; base += (u64)gridDim.x * kThreads) {   // block-uniform trip count
+    const u64 idx = base + threadIdx.x;
+    u64 surv_o = 0, surv_i = 0, row_lin = 0;
+    int g = 0, step = 0;
+    if (idx < count) {
+      const u64 e = refine[idx];
+      step = (int)(e >> 44);
+      const unsigned want = (unsigned)((e >> 40) & 3);
+      u64 lin = e & 0xffffffffffull;
+      g = mc.core_st[0] + (int)(lin % (u64)mc.core_sz[0]); lin /= (u64)mc.core_sz[0];
+      const int cy = mc.core_st[1] + (int)(lin % (u64)mc.core_sz[1]); lin /= (u64)mc.core_sz[1];
+      const int cz = (ND == 3) ? mc.core_st[2] + (int)lin : 0;
+      const int j = cy - m.ext_st[1], k = cz - m.ext_st[2];
+      const Fields f = steps[step];
+      const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0 && (want & 2);
+      u64 a0 = ~0ull, a1 = ~0ull;
+      for (int dz = 0; dz < (ND == 3 ? 2 : 1); dz ++)
+        for (int dy = 0; dy < 2; dy ++) {
+          if (j + dy >= DH || k + dz >= DD) continue;                   // row outside the array: invalid vertices, neutral
+          const size_t off = (size_t)P * ((size_t)(j + dy) + (size_t)DH * (size_t)(k + dz));
+          a0 &= load_row_pair_and(f.M[0], off, g);
+          if (need_next) a1 &= load_row_pair_and(f.M[1], off, g);
+        }
+      u64 in_core = 0;
+      for (int b = 0; b < 8; b ++) {
+        const int cx = g * 8 + b + m.ext_st[0];
+        if (cx >= m.core_st[0] && cx < m.core_st[0] + m.core_sz[0]) in_core |= 0x80ull << (8 * b);
+      }
+      if ((f.scope_mask & FTKX_SCOPE_ORDINAL) && (want & 1)) surv_o = ~(a0 + k7f) & k80 & in_core;
+      if (need_next) surv_i = ~((a0 & a1) + k7f) & k80 & in_core;
+      row_lin = (u64)(cy - m.core_st[1]) * (u64)m.core_sz[0] + (ND == 3 ? (u64)(cz - m.core_st[2]) * (u64)m.core_sz[0] * (u64)m.core_sz[1] : 0ull);
+    }
+    const u64 any = surv_o | surv_i;
+    if (__ballot(any != 0) == 0) continue;
+    const unsigned cnt = (unsigned)__popcll(any);
+    unsigned incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+    const unsigned total = __shfl(incl, 63);
+    u64 pbase = 0;
+    if (lane == 63) {
+      pbase = atomicAdd(&m.counters[CNT_SURVIVOR_LIST], (u64)total);
+      atomicAdd(&m.counters[CNT_CELLS_SURVIVED], (u64)total);
+    }
+    pbase = __shfl(pbase, 63);
+    u64 pos = pbase + (incl - cnt);
+    for (int b = 0; b < 8 && cnt; b ++) {
+      const unsigned fl = (unsigned)((surv_o >> (8 * b + 7)) & 1) | ((unsigned)((surv_i >> (8 * b + 7)) & 1) << 1);
+      if (!fl) continue;
+      const u64 lin = row_lin + (u64)(g * 8 + b + m.ext_st[0] - m.core_st[0]);
+      if (pos < list_capacity) list[pos] = lin | ((u64)fl << 40) | ((u64)step << 44);
+      pos ++;
+    }
   }
 }
 
@@ -1176,34 +1201,62 @@ void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t s
   else hipLaunchKernelGGL(mask_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs);
 }
 
+// does launch_masks produce the per-word summaries for this mesh?  (only the 128-column edge variant of the marching kernel does)
+bool masks_have_summary(const Mesh &m)
+{
+  if (!m.scalar_mode) return false;
+  const int DD = m.nd == 3 ? m.ext_sz[2] : 1;
+  const size_t slice_bytes = (size_t)m.ext_sz[0] * m.ext_sz[1] * DD * 8;
+  if ((m.ext_sz[0] % 8) != 0 || slice_bytes >= (1ull << 32)) return false;
+  if (const char *e = getenv("FTKX_TWO_LEVEL")) if (atoi(e) == 0) return false;
+  const int DW = m.ext_sz[0];
+  bool use_edge = (DW + 127) / 128 < (DW + kMarch2Cols - 1) / kMarch2Cols;
+  if (const char *e = getenv("FTKX_MASK_EDGE")) use_edge = atoi(e) != 0;
+  return use_edge;
+}
+
+template <bool COARSE>
+static void launch_cull_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream)
+{
+  int ZC = m.nd == 3 ? 4 : 1;
+  if (const char *e = getenv("FTKX_CULL_ZC")) { const int v = atoi(e); if (m.nd == 3 && (v == 2 || v == 4 || v == 8)) ZC = v; }
+  const int groups = (m.ext_sz[0] + 7) / 8;
+  int gx_log2 = 3;
+  while (gx_log2 < 6 && (1 << gx_log2) < groups) gx_log2 ++;
+  const int GX = 1 << gx_log2, rows_per_block = 4 * (64 >> gx_log2);
+  const int nzc = m.nd == 3 ? (m.ext_sz[2] + ZC - 1) / ZC : 1;
+  // steps per lane: consecutive steps reuse the shared slice from registers; more chunks = more parallelism
+  int step_chunk = m.nd == 3 ? 16 : 1;   // 2D slices are small and survivors common: prefer parallelism
+  if (const char *e = getenv("FTKX_CULL_STEP_CHUNK")) step_chunk = atoi(e) > 0 ? atoi(e) : step_chunk;
+  const int nsc = (nsteps + step_chunk - 1) / step_chunk;
+  const dim3 grid((unsigned)((groups + GX - 1) / GX), (unsigned)((m.ext_sz[1] + rows_per_block - 1) / rows_per_block), (unsigned)(nzc * nsc));
+#define FTKX_CULL_LAUNCH(ND_, ZC_) hipLaunchKernelGGL((cull_march_kernel<ND_, ZC_, COARSE>), grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, step_chunk, gx_log2, d_list, cap)
+  if (m.nd == 2) FTKX_CULL_LAUNCH(2, 1);
+  else if (ZC == 2) FTKX_CULL_LAUNCH(3, 2);
+  else if (ZC == 8) FTKX_CULL_LAUNCH(3, 8);
+  else FTKX_CULL_LAUNCH(3, 4);
+#undef FTKX_CULL_LAUNCH
+}
+
 void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream)
 {
   if (nsteps <= 0) return;
-  {
-    int ZC = m.nd == 3 ? 4 : 1;
-    if (const char *e = getenv("FTKX_CULL_ZC")) { const int v = atoi(e); if (m.nd == 3 && (v == 2 || v == 4 || v == 8)) ZC = v; }
-    const int groups = (m.ext_sz[0] + 7) / 8;
-    int gx_log2 = 3;
-    while (gx_log2 < 6 && (1 << gx_log2) < groups) gx_log2 ++;
-    const int GX = 1 << gx_log2, rows_per_block = 4 * (64 >> gx_log2);
-    const int nzc = m.nd == 3 ? (m.ext_sz[2] + ZC - 1) / ZC : 1;
-    // steps per lane: consecutive steps reuse the shared slice from registers; more chunks = more parallelism
-    int step_chunk = m.nd == 3 ? 16 : 1;   // 2D slices are small and survivors common: prefer parallelism
-    if (const char *e = getenv("FTKX_CULL_STEP_CHUNK")) step_chunk = atoi(e) > 0 ? atoi(e) : step_chunk;
-    const int nsc = (nsteps + step_chunk - 1) / step_chunk;
-    const dim3 grid((unsigned)((groups + GX - 1) / GX), (unsigned)((m.ext_sz[1] + rows_per_block - 1) / rows_per_block), (unsigned)(nzc * nsc));
-#define FTKX_CULL_LAUNCH(ND_, ZC_) hipLaunchKernelGGL((cull_march_kernel<ND_, ZC_>), grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, step_chunk, gx_log2, d_list, cap)
-    if (m.nd == 2) FTKX_CULL_LAUNCH(2, 1);
-    else if (ZC == 2) FTKX_CULL_LAUNCH(3, 2);
-    else if (ZC == 8) FTKX_CULL_LAUNCH(3, 8);
-    else FTKX_CULL_LAUNCH(3, 4);
-#undef FTKX_CULL_LAUNCH
-    return;
-  }
-  const int groups = (m.ext_sz[0] + 7) / 8;
-  const dim3 grid((unsigned)((groups + 31) / 32), (unsigned)((m.ext_sz[1] + 7) / 8), (unsigned)((m.nd == 3 ? m.ext_sz[2] : 1) * nsteps));
-  if (m.nd == 2) hipLaunchKernelGGL(cull_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, d_list, cap);
-  else hipLaunchKernelGGL(cull_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_steps, d_list, cap);
+  launch_cull_level<false>(m, d_steps, nsteps, d_list, cap, stream);
+}
+
+// two-level form: summaries first (1/8 of the bytes), vertex masks only for the words the summaries could not rule out
+void launch_cull_two_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream)
+{
+  if (nsteps <= 0) return;
+  Mesh mc = m;                                   // the coarse view: one "vertex" per aligned word of 8
+  const int w0 = (m.core_st[0] - m.ext_st[0]) / 8, w1 = (m.core_st[0] + m.core_sz[0] - 1 - m.ext_st[0]) / 8;
+  mc.ext_st[0] = 0; mc.ext_sz[0] = (m.ext_sz[0] + 7) / 8;
+  mc.core_st[0] = w0; mc.core_sz[0] = w1 - w0 + 1;
+  mc.mask_pitch = m.u_pitch;
+  launch_cull_level<true>(mc, d_steps, nsteps, d_refine, refine_cap, stream);
+  const dim3 grid(256 * 4);
+  if (m.nd == 2) hipLaunchKernelGGL(refine_kernel<2>, grid, dim3(kThreads), 0, stream, m, mc, d_steps, d_refine, refine_cap, d_list, cap);
+  else hipLaunchKernelGGL(refine_kernel<3>, grid, dim3(kThreads), 0, stream, m, mc, d_steps, d_refine, refine_cap, d_list, cap);
 }
 
 void launch_exact(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, hipStream_t stream)

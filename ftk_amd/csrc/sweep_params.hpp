@@ -7,7 +7,8 @@ namespace ftkx {
 typedef unsigned long long u64;
 typedef long long i64;
 
-enum { CNT_HITS = 0, CNT_CELLS_SURVIVED = 1, CNT_SIMPLICES_TESTED = 2, CNT_SURVIVOR_LIST = 3, CNT_LIST_PEAK = 4, CNT_N = 8 };
+enum { CNT_HITS = 0, CNT_CELLS_SURVIVED = 1, CNT_SIMPLICES_TESTED = 2, CNT_SURVIVOR_LIST = 3, CNT_LIST_PEAK = 4,
+       CNT_REFINE_LIST = 5, CNT_REFINE_PEAK = 6, CNT_WORDS_REFINED = 7, CNT_N = 8 };
 
 // everything that does not change between the sweeps of one context configuration
 struct Mesh {
@@ -19,6 +20,7 @@ struct Mesh {
   int dimprod[4];            // simplicial_regular_mesh::dimprod_ (int) -> reference tag
   u64 exact_prod[4];         // same in 64 bits
   int mask_pitch;            // row pitch (bytes) of the vertex-mask arrays: roundup8(ext_sz[0]) + 8
+  int u_pitch;               // row pitch of the per-8-vertex summary arrays: roundup8(ceil(ext_sz[0] / 8)) + 8
   int jacobian_symmetric, robust, use_type_filter;
   unsigned type_filter;
   int compute_degrees, tag_mode;
@@ -35,6 +37,7 @@ struct Fields {
   const double *V[2];
   const double *J[2];
   const unsigned char *M[2]; // vertex sign masks (fast path only)
+  const unsigned char *U[2]; // their per-word summaries (two-level cull), or nullptr
   double factor;             // (double)vector_field_scaling_factor, a power of two
   int t;                     // current_timestep
   int scope_mask;            // FTKX_SCOPE_*
@@ -53,6 +56,7 @@ struct MaskJob {
   const double *S;
   const double *V;
   unsigned char *M;
+  unsigned char *U;          // summary: AND of the 8 mask bytes of each aligned x word (nullptr: not produced)
   double threshold;          // 1 / factor: q = trunc(v * factor) > 0  <=>  v >= 1/factor (factor is a power of two)
 };
 
