@@ -737,7 +737,7 @@ __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, con
       const bool u_int = ND == 2 || (((row_int >> r) & 1) && z_int), u_dom = ((row_dom >> r) & 1) && z_dom;
       bits = u_int ? (bits & xkeep) : 0u;                     // gradient3D leaves the array border at 0
       bits = u_dom ? (bits | xneutral) : 0x3f3fu;             // outside the domain / row padding: never blocks a cull
-      if (((row_ok >> r) & 1) && store_ok) *reinterpret_cast<unsigned short *>(mrow + (size_t)P * ((size_t)r + (size_t)DH * (size_t)k)) = (unsigned short)bits;
+      bool word_uniform = false;
       if constexpr (EDGE) {
         // summary byte of the aligned 8-vertex word this quad of lanes covers: the sign bits ALL eight vertices share.
         // (lanes beyond the row contribute neutral bytes, so a partial last word summarises its real vertices only)
@@ -747,8 +747,14 @@ __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, con
           q &= __builtin_amdgcn_update_dpp(q, q, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
           if (((row_ok >> r) & 1) && (lane & 3) == 0 && i0 < DW)
             job.U[(size_t)(i0 >> 3) + (size_t)m.u_pitch * ((size_t)(j0 + r) + (size_t)DH * (size_t)k)] = (unsigned char)q;
+          // A word whose eight vertices share a strict sign is fully described by its summary: the refine kernel substitutes
+          // the summary for it (conservative: it may only cull less), so its eight mask bytes are not written at all --
+          // on smooth fields that is almost every word, and the mask array costs 1/8 byte per vertex of HBM writes instead of 1.
+          word_uniform = q != 0;
         }
       }
+      if (((row_ok >> r) & 1) && store_ok && !word_uniform)
+        *reinterpret_cast<unsigned short *>(mrow + (size_t)P * ((size_t)r + (size_t)DH * (size_t)k)) = (unsigned short)bits;
     }
     if (ND == 3) {
       for (int r = 0; r < RY; r ++) prv[r] = cur[r + 1];
@@ -938,12 +944,21 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(const Mesh m, const Me
       const Fields f = steps[step];
       const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0 && (want & 2);
       u64 a0 = ~0ull, a1 = ~0ull;
+      // words whose summary is non-zero were not written to M (mask_march2_kernel): their summary, replicated, stands in
+      auto row_pair_and = [&](const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ Up, size_t row) -> u64 {
+        const unsigned char *u = Up + (size_t)m.u_pitch * row + g;
+        const u64 *w = reinterpret_cast<const u64 *>(Mp + (size_t)P * row) + g;
+        const unsigned u0 = u[0], u1 = u[1];                       // the summary pitch has spare bytes too
+        const u64 w0 = u0 ? (u64)u0 * 0x0101010101010101ull : w[0];
+        const u64 w1 = u1 ? (u64)u1 * 0x0101010101010101ull : w[1];
+        return w0 & ((w0 >> 8) | (w1 << 56));
+      };
       for (int dz = 0; dz < (ND == 3 ? 2 : 1); dz ++)
         for (int dy = 0; dy < 2; dy ++) {
           if (j + dy >= DH || k + dz >= DD) continue;                   // row outside the array: invalid vertices, neutral
-          const size_t off = (size_t)P * ((size_t)(j + dy) + (size_t)DH * (size_t)(k + dz));
-          a0 &= load_row_pair_and(f.M[0], off, g);
-          if (need_next) a1 &= load_row_pair_and(f.M[1], off, g);
+          const size_t row = (size_t)(j + dy) + (size_t)DH * (size_t)(k + dz);
+          a0 &= row_pair_and(f.M[0], f.U[0], row);
+          if (need_next) a1 &= row_pair_and(f.M[1], f.U[1], row);
         }
       u64 in_core = 0;
       for (int b = 0; b < 8; b ++) {
