@@ -679,8 +679,11 @@ __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, con
     }
   }
   const unsigned cb = (unsigned)ic * 8u;
+  const bool use_nt = (swizzle & 4) != 0;
   auto ld2 = [&](unsigned off) -> double2 {
-    double2 v = *reinterpret_cast<const double2 *>(Sb + off);
+    const double2 *q = reinterpret_cast<const double2 *>(Sb + off);
+    double2 v;
+    if (use_nt) { v.x = __builtin_nontemporal_load(&q->x); v.y = __builtin_nontemporal_load(&q->y); } else v = *q;
     if (ND == 2) { if (dup_lo) v.y = v.x; if (dup_hi) v.x = v.y; }
     return v;
   };
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, con
     // prefetch plane k + 2 while plane k is being classified
     double2 nn[RY + 2];
     double exnn[EDGE ? RY : 1];
-    if (ND == 3) {
+    if (ND == 3 && k + 2 <= z1) {                             // plane z1 is still needed (d/dz of the chunk's last plane), z1 + 1 is not
       const unsigned z2 = zoff(k + 2);
       for (int r = 0; r < RY + 2; r ++) nn[r] = ld2(cb + roff[r] + z2);
       if (edge) for (int r = 0; r < RY; r ++) exnn[r] = ld1(hb + roff[r + 1] + z2);
