@@ -626,7 +626,7 @@ __device__ inline bool bits_dummy_guard(double thr) { return thr < 1e300; }   //
 // EDGE = true: 128 owner columns per wavefront, every lane owns its pair, the two outside neighbours are fetched by lanes 0 and
 // 63 into a spare register set (better when the row length is a multiple of 128, e.g. 512: 4 tiles instead of 5).
 template <int ND, bool EDGE>
-__global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
+__global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
 {
   constexpr int RY = (ND == 3) ? 4 : 8;
   constexpr int TILE = EDGE ? 128 : kMarch2Cols;
@@ -647,7 +647,8 @@ __global__ __launch_bounds__(kThreads) void mask_march2_kernel(const Mesh m, con
   const int z1 = (ND == 3) ? (z0 + zchunk < DD ? z0 + zchunk : DD) : 1;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i0 = (int)bx * TILE + (EDGE ? 0 : -2) + 2 * lane;  // columns i0, i0 + 1 (halo variant: lane 0 / lane 63 are halo pairs)
-  const int j0 = (by * 4 + wv) * RY;
+  const int wpb = blockDim.x >> 6;                             // wavefronts per workgroup = consecutive row groups sharing halo rows in L1/L2
+  const int j0 = (by * wpb + wv) * RY;
   if (j0 >= DH) return;
   const char *__restrict__ Sb = reinterpret_cast<const char *>(job.S);
   const double thr = job.threshold, nthr = -job.threshold;
@@ -1186,7 +1187,7 @@ void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t s
     const int RY = (m.nd == 3) ? 4 : 8;
     const int DD = m.nd == 3 ? m.ext_sz[2] : 1;
     // z chunks: long enough to amortise the two start-up planes, short enough to fill 256 CUs several times over
-    int zchunk = 64;
+    int zchunk = 32;
     if (const char *e = getenv("FTKX_MASK_ZCHUNK")) zchunk = atoi(e) > 0 ? atoi(e) : zchunk;
     if (m.nd == 3) { while (zchunk > 8 && (size_t)((m.mask_pitch + kMarch2Cols - 1) / kMarch2Cols) * ((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)) * ((DD + zchunk - 1) / zchunk) * njobs < 8192) zchunk /= 2; }
     int swizzle = 1;   // measured on 512^3 x 32: 8.7 ms with the XCD-contiguous mapping vs 11.8 ms without
@@ -1199,11 +1200,14 @@ void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t s
       const int tiles_halo = (DW + kMarch2Cols - 1) / kMarch2Cols, tiles_edge = (DW + 127) / 128;
       bool use_edge = tiles_edge < tiles_halo;
       if (const char *e = getenv("FTKX_MASK_EDGE")) use_edge = atoi(e) != 0;
-      const dim3 grid2((unsigned)(use_edge ? tiles_edge : tiles_halo), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
-      if (m.nd == 2) { if (use_edge) hipLaunchKernelGGL((mask_march2_kernel<2, true>), grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle);
-                       else hipLaunchKernelGGL((mask_march2_kernel<2, false>), grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle); }
-      else { if (use_edge) hipLaunchKernelGGL((mask_march2_kernel<3, true>), grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle);
-             else hipLaunchKernelGGL((mask_march2_kernel<3, false>), grid2, dim3(kThreads), 0, stream, m, d_jobs, zchunk, swizzle); }
+      int wpb = 4;
+      if (const char *e = getenv("FTKX_MASK_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 12) wpb = v; }
+      const dim3 grid2((unsigned)(use_edge ? tiles_edge : tiles_halo), (unsigned)((m.ext_sz[1] + wpb * RY - 1) / (wpb * RY)), (unsigned)(nzc * njobs));
+      const dim3 blk((unsigned)(64 * wpb));
+      if (m.nd == 2) { if (use_edge) hipLaunchKernelGGL((mask_march2_kernel<2, true>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle);
+                       else hipLaunchKernelGGL((mask_march2_kernel<2, false>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle); }
+      else { if (use_edge) hipLaunchKernelGGL((mask_march2_kernel<3, true>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle);
+             else hipLaunchKernelGGL((mask_march2_kernel<3, false>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle); }
       return;
     }
     const dim3 grid((unsigned)((m.mask_pitch + 63) / 64), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
