@@ -25,6 +25,7 @@ void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t s
 void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream);
 void launch_exact(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, hipStream_t stream);
 bool masks_have_summary(const Mesh &m);
+bool march2_supported(const Mesh &m);
 void launch_cull_two_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream);
 void launch_resolution_scalar(const Mesh &m, const double *S, u64 *out2, hipStream_t stream);
 void launch_gradient2d(const double *S, int DW, int DH, double *V, hipStream_t st);
@@ -223,7 +224,17 @@ int slice_resolution(ftkx_ctx *c, Slice &s)
   u64 *d = c->d_counters + ftkx::CNT_N;
   const u64 init[2] = {0x7fefffffffffffffull, 0ull};
   HIP_TRY(c, hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-  if (c->scalar_mode == 1) { Mesh m; fill_mesh(c, m); ftkx::launch_resolution_scalar(m, s.S, d, c->stream); }
+  if (c->scalar_mode == 1) {
+    Mesh m; fill_mesh(c, m);
+    if (ftkx::march2_supported(m)) {
+      // the marching stencil kernel in reduce-only mode: same single pass over S as the mask kernel, nothing stored
+      int rc = ensure_desc(c, sizeof(MaskJob));
+      if (rc) return rc;
+      const MaskJob job{s.S, nullptr, nullptr, nullptr, d, 1.0};
+      HIP_TRY(c, hipMemcpyAsync(c->d_desc, &job, sizeof(job), hipMemcpyHostToDevice, c->stream));
+      ftkx::launch_masks(m, (const MaskJob *)c->d_desc, 1, c->stream);
+    } else ftkx::launch_resolution_scalar(m, s.S, d, c->stream);
+  }
   else ftkx::launch_resolution(s.V, n_vertices(c) * (size_t)c->nd, d, c->stream);
   HIP_TRY(c, hipGetLastError());
   u64 out[2];
@@ -348,7 +359,7 @@ int run_batch(ftkx_ctx *c)
           for (const MaskJob &j : subs.back().jobs) touched = touched || j.M == s->M;
           for (const Fields &g : subs.back().steps) touched = touched || g.M[0] == s->M || g.M[1] == s->M;
           if (touched) subs.emplace_back();
-          subs.back().jobs.push_back(MaskJob{s->S, s->V, s->M, two_level ? s->U : nullptr, 1.0 / (double)r.factor});
+          subs.back().jobs.push_back(MaskJob{s->S, s->V, s->M, two_level ? s->U : nullptr, nullptr, 1.0 / (double)r.factor});
           s->mask_factor = r.factor;
         }
       }

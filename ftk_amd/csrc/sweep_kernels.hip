@@ -702,6 +702,14 @@ __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const Ma
   }
   // the row padding [DW, P) is neutral for the cull: it is filled once when the mask array is allocated and never written here
   const bool store_ok = owner && i0 >= 0 && i0 < DW && !(debug_no_store && bits_dummy_guard(thr));
+  const bool want_mask = job.M != nullptr;
+  // pre-pass mode: ndarray::resolution() of V = gradient(S) over the WHOLE array (ndarray.hh:770-778), fused into the same walk
+  u64 red_mn = 0x7fefffffffffffffull, red_mx = 0ull;
+  auto red_take = [&](double g) {
+    const double a = fabs(g);
+    const u64 b = (u64)__double_as_longlong(a);
+    if (a != 0.0 && b < 0x7ff0000000000000ull) { red_mn = b < red_mn ? b : red_mn; red_mx = b > red_mx ? b : red_mx; }
+  };
   unsigned char *mrow = job.M + (size_t)(i0 < 0 ? 0 : i0) + (size_t)P * (size_t)j0;
 
   for (int k = z0; k < z1; k ++) {
@@ -739,6 +747,10 @@ __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const Ma
       if (ND == 3) bits |= (gz0 >= thr ? 0x0004u : 0u) | (gz0 <= nthr ? 0x0020u : 0u) | (gz1 >= thr ? 0x0400u : 0u) | (gz1 <= nthr ? 0x2000u : 0u);
       // wave-uniform row / plane conditions, per-lane column conditions
       const bool u_int = ND == 2 || (((row_int >> r) & 1) && z_int), u_dom = ((row_dom >> r) & 1) && z_dom;
+      if (job.red && u_int && ((row_ok >> r) & 1) && store_ok) {
+        if (xkeep & 0x3fu) { red_take(gx0); red_take(gy0); if (ND == 3) red_take(gz0); }
+        if (xkeep & 0x3f00u) { red_take(gx1); red_take(gy1); if (ND == 3) red_take(gz1); }
+      }
       bits = u_int ? (bits & xkeep) : 0u;                     // gradient3D leaves the array border at 0
       bits = u_dom ? (bits | xneutral) : 0x3f3fu;             // outside the domain / row padding: never blocks a cull
       bool word_uniform = false;
@@ -757,7 +769,7 @@ __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const Ma
           word_uniform = q != 0;
         }
       }
-      if (((row_ok >> r) & 1) && store_ok && !word_uniform)
+      if (((row_ok >> r) & 1) && store_ok && want_mask && !word_uniform)
         *reinterpret_cast<unsigned short *>(mrow + (size_t)P * ((size_t)r + (size_t)DH * (size_t)k)) = (unsigned short)bits;
     }
     if (ND == 3) {
@@ -765,6 +777,13 @@ __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const Ma
       for (int r = 0; r < RY + 2; r ++) { cur[r] = nxt[r]; nxt[r] = nn[r]; }
       if constexpr (EDGE) for (int r = 0; r < RY; r ++) { ex[r] = exn[r]; exn[r] = exnn[r]; }
     }
+  }
+  if (job.red) {
+    for (int o = 32; o > 0; o >>= 1) {
+      const u64 omn = __shfl_down(red_mn, o), omx = __shfl_down(red_mx, o);
+      red_mn = omn < red_mn ? omn : red_mn; red_mx = omx > red_mx ? omx : red_mx;
+    }
+    if (lane == 0) { atomicMin(&job.red[0], red_mn); atomicMax(&job.red[1], red_mx); }
   }
 }
 
@@ -1138,6 +1157,16 @@ __global__ __launch_bounds__(kThreads) void resolution_scalar_kernel(const Mesh 
     mn = omn < mn ? omn : mn; mx = omx > mx ? omx : mx;
   }
   if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], mn); atomicMax(&out[1], mx); }
+}
+
+void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream);
+
+// can the marching kernel (which carries the fused reduction) walk this mesh?
+bool march2_supported(const Mesh &m)
+{
+  const int DD = m.nd == 3 ? m.ext_sz[2] : 1;
+  const size_t slice_bytes = (size_t)m.ext_sz[0] * m.ext_sz[1] * DD * 8;
+  return m.scalar_mode && (m.ext_sz[0] % 2) == 0 && m.ext_sz[0] >= 2 && slice_bytes < (1ull << 32);
 }
 
 void launch_resolution_scalar(const Mesh &m, const double *S, u64 *out2, hipStream_t stream)
