@@ -26,6 +26,7 @@ void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, 
 void launch_exact(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, hipStream_t stream);
 bool masks_have_summary(const Mesh &m);
 bool march2_supported(const Mesh &m);
+void launch_reduce_march(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream);
 void launch_cull_two_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream);
 void launch_resolution_scalar(const Mesh &m, const double *S, u64 *out2, hipStream_t stream);
 void launch_gradient2d(const double *S, int DW, int DH, double *V, hipStream_t st);
@@ -232,7 +233,7 @@ int slice_resolution(ftkx_ctx *c, Slice &s)
       if (rc) return rc;
       const MaskJob job{s.S, nullptr, nullptr, nullptr, d, 1.0};
       HIP_TRY(c, hipMemcpyAsync(c->d_desc, &job, sizeof(job), hipMemcpyHostToDevice, c->stream));
-      ftkx::launch_masks(m, (const MaskJob *)c->d_desc, 1, c->stream);
+      ftkx::launch_reduce_march(m, (const MaskJob *)c->d_desc, 1, c->stream);
     } else ftkx::launch_resolution_scalar(m, s.S, d, c->stream);
   }
   else ftkx::launch_resolution(s.V, n_vertices(c) * (size_t)c->nd, d, c->stream);

@@ -625,7 +625,7 @@ __device__ inline bool bits_dummy_guard(double thr) { return thr < 1e300; }   //
 
 // EDGE = true: 128 owner columns per wavefront, every lane owns its pair, the two outside neighbours are fetched by lanes 0 and
 // 63 into a spare register set (better when the row length is a multiple of 128, e.g. 512: 4 tiles instead of 5).
-template <int ND, bool EDGE>
+template <int ND, bool EDGE, bool REDUCE>
 __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
 {
   constexpr int RY = (ND == 3) ? 4 : 8;
@@ -702,13 +702,14 @@ __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const Ma
   }
   // the row padding [DW, P) is neutral for the cull: it is filled once when the mask array is allocated and never written here
   const bool store_ok = owner && i0 >= 0 && i0 < DW && !(debug_no_store && bits_dummy_guard(thr));
-  const bool want_mask = job.M != nullptr;
-  // pre-pass mode: ndarray::resolution() of V = gradient(S) over the WHOLE array (ndarray.hh:770-778), fused into the same walk
-  u64 red_mn = 0x7fefffffffffffffull, red_mx = 0ull;
+  const bool want_mask = !REDUCE;
+  // REDUCE = pre-pass instantiation: ndarray::resolution() of V = gradient(S) over the WHOLE array (ndarray.hh:770-778) with the
+  // same single walk over S; nothing is stored.  min over non-zero |v| (NaN and Inf never win), max over finite |v|.
+  double red_mn = DBL_MAX, red_mx = 0.0;
   auto red_take = [&](double g) {
     const double a = fabs(g);
-    const u64 b = (u64)__double_as_longlong(a);
-    if (a != 0.0 && b < 0x7ff0000000000000ull) { red_mn = b < red_mn ? b : red_mn; red_mx = b > red_mx ? b : red_mx; }
+    red_mn = fmin(red_mn, a == 0.0 ? DBL_MAX : a);
+    red_mx = fmax(red_mx, a < HUGE_VAL ? a : 0.0);
   };
   unsigned char *mrow = job.M + (size_t)(i0 < 0 ? 0 : i0) + (size_t)P * (size_t)j0;
 
@@ -747,9 +748,12 @@ __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const Ma
       if (ND == 3) bits |= (gz0 >= thr ? 0x0004u : 0u) | (gz0 <= nthr ? 0x0020u : 0u) | (gz1 >= thr ? 0x0400u : 0u) | (gz1 <= nthr ? 0x2000u : 0u);
       // wave-uniform row / plane conditions, per-lane column conditions
       const bool u_int = ND == 2 || (((row_int >> r) & 1) && z_int), u_dom = ((row_dom >> r) & 1) && z_dom;
-      if (job.red && u_int && ((row_ok >> r) & 1) && store_ok) {
-        if (xkeep & 0x3fu) { red_take(gx0); red_take(gy0); if (ND == 3) red_take(gz0); }
-        if (xkeep & 0x3f00u) { red_take(gx1); red_take(gy1); if (ND == 3) red_take(gz1); }
+      if constexpr (REDUCE) {
+        if (u_int && ((row_ok >> r) & 1) && store_ok) {
+          if (xkeep & 0x3fu) { red_take(gx0); red_take(gy0); if (ND == 3) red_take(gz0); }
+          if (xkeep & 0x3f00u) { red_take(gx1); red_take(gy1); if (ND == 3) red_take(gz1); }
+        }
+        continue;
       }
       bits = u_int ? (bits & xkeep) : 0u;                     // gradient3D leaves the array border at 0
       bits = u_dom ? (bits | xneutral) : 0x3f3fu;             // outside the domain / row padding: never blocks a cull
@@ -778,12 +782,10 @@ __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const Ma
       if constexpr (EDGE) for (int r = 0; r < RY; r ++) { ex[r] = exn[r]; exn[r] = exnn[r]; }
     }
   }
-  if (job.red) {
-    for (int o = 32; o > 0; o >>= 1) {
-      const u64 omn = __shfl_down(red_mn, o), omx = __shfl_down(red_mx, o);
-      red_mn = omn < red_mn ? omn : red_mn; red_mx = omx > red_mx ? omx : red_mx;
-    }
-    if (lane == 0) { atomicMin(&job.red[0], red_mn); atomicMax(&job.red[1], red_mx); }
+  if constexpr (REDUCE) {
+    for (int o = 32; o > 0; o >>= 1) { red_mn = fmin(red_mn, __shfl_down(red_mn, o)); red_mx = fmax(red_mx, __shfl_down(red_mx, o)); }
+    // non-negative doubles order like their bit patterns
+    if (lane == 0) { atomicMin(&job.red[0], (u64)__double_as_longlong(red_mn)); atomicMax(&job.red[1], (u64)__double_as_longlong(red_mx)); }
   }
 }
 
@@ -1159,7 +1161,7 @@ __global__ __launch_bounds__(kThreads) void resolution_scalar_kernel(const Mesh 
   if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], mn); atomicMax(&out[1], mx); }
 }
 
-void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream);
+void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool reduce, hipStream_t stream);
 
 // can the marching kernel (which carries the fused reduction) walk this mesh?
 bool march2_supported(const Mesh &m)
@@ -1209,7 +1211,7 @@ void tile_dims(int nd, int tile[3])
   else { tile[0] = tile_cfg<3>::TX; tile[1] = tile_cfg<3>::TY; tile[2] = tile_cfg<3>::TZ; }
 }
 
-void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream)
+void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool reduce, hipStream_t stream)
 {
   if (njobs <= 0) return;
   if (m.scalar_mode) {
@@ -1233,10 +1235,12 @@ void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t s
       if (const char *e = getenv("FTKX_MASK_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 12) wpb = v; }
       const dim3 grid2((unsigned)(use_edge ? tiles_edge : tiles_halo), (unsigned)((m.ext_sz[1] + wpb * RY - 1) / (wpb * RY)), (unsigned)(nzc * njobs));
       const dim3 blk((unsigned)(64 * wpb));
-      if (m.nd == 2) { if (use_edge) hipLaunchKernelGGL((mask_march2_kernel<2, true>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle);
-                       else hipLaunchKernelGGL((mask_march2_kernel<2, false>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle); }
-      else { if (use_edge) hipLaunchKernelGGL((mask_march2_kernel<3, true>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle);
-             else hipLaunchKernelGGL((mask_march2_kernel<3, false>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle); }
+#define FTKX_M2(ND_, E_, R_) hipLaunchKernelGGL((mask_march2_kernel<ND_, E_, R_>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle)
+      if (reduce) { if (m.nd == 2) { if (use_edge) FTKX_M2(2, true, true); else FTKX_M2(2, false, true); }
+                    else { if (use_edge) FTKX_M2(3, true, true); else FTKX_M2(3, false, true); } }
+      else { if (m.nd == 2) { if (use_edge) FTKX_M2(2, true, false); else FTKX_M2(2, false, false); }
+             else { if (use_edge) FTKX_M2(3, true, false); else FTKX_M2(3, false, false); } }
+#undef FTKX_M2
       return;
     }
     const dim3 grid((unsigned)((m.mask_pitch + 63) / 64), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
@@ -1288,6 +1292,10 @@ static void launch_cull_level(const Mesh &m, const Fields *d_steps, int nsteps, 
   else FTKX_CULL_LAUNCH(3, 4);
 #undef FTKX_CULL_LAUNCH
 }
+
+void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream) { launch_masks_impl(m, d_jobs, njobs, false, stream); }
+// pre-pass: only valid when march2_supported(m)
+void launch_reduce_march(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream) { launch_masks_impl(m, d_jobs, njobs, true, stream); }
 
 void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream)
 {
