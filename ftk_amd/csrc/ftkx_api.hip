@@ -77,7 +77,7 @@ struct ftkx_ctx {
   u64 list_capacity = 0;
   u64 *d_refine = nullptr;          // words the summary level could not rule out (two-level cull)
   u64 refine_capacity = 0;
-  u64 *d_counters = nullptr;        // CNT_N counters + 2 words for the resolution reduction
+  u64 *d_counters = nullptr;        // CNT_N counters + 128 words (64 {min, max} slots) for the resolution reduction
   u64 *h_counters = nullptr;        // pinned
   ftkx_cp_t *h_hits = nullptr;      // pinned
   size_t h_cap = 0;
@@ -223,7 +223,8 @@ int slice_resolution(ftkx_ctx *c, Slice &s)
 {
   if (s.have_res) return FTKX_OK;
   u64 *d = c->d_counters + ftkx::CNT_N;
-  const u64 init[2] = {0x7fefffffffffffffull, 0ull};
+  u64 init[128];
+  for (int i = 0; i < 64; i ++) { init[2 * i] = 0x7fefffffffffffffull; init[2 * i + 1] = 0ull; }
   HIP_TRY(c, hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   if (c->scalar_mode == 1) {
     Mesh m; fill_mesh(c, m);
@@ -238,11 +239,13 @@ int slice_resolution(ftkx_ctx *c, Slice &s)
   }
   else ftkx::launch_resolution(s.V, n_vertices(c) * (size_t)c->nd, d, c->stream);
   HIP_TRY(c, hipGetLastError());
-  u64 out[2];
+  u64 out[128];
   HIP_TRY(c, hipMemcpyAsync(out, d, sizeof(out), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  memcpy(&s.res, &out[0], 8);
-  memcpy(&s.maxabs, &out[1], 8);
+  u64 mn = out[0], mx = out[1];
+  for (int i = 1; i < 64; i ++) { mn = std::min(mn, out[2 * i]); mx = std::max(mx, out[2 * i + 1]); }
+  memcpy(&s.res, &mn, 8);
+  memcpy(&s.maxabs, &mx, 8);
   s.have_res = true;
   return FTKX_OK;
 }
@@ -461,8 +464,8 @@ int ftkx_create(ftkx_ctx **out, int nd, int device_id)
   // streams (and torch's default stream) puts its copies and fills
   HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
   c->stream = c->own_stream;
-  HIP_TRY(c, hipMalloc((void **)&c->d_counters, (ftkx::CNT_N + 2) * sizeof(u64)));
-  HIP_TRY(c, hipMemset(c->d_counters, 0, (ftkx::CNT_N + 2) * sizeof(u64)));
+  HIP_TRY(c, hipMalloc((void **)&c->d_counters, (ftkx::CNT_N + 128) * sizeof(u64)));
+  HIP_TRY(c, hipMemset(c->d_counters, 0, (ftkx::CNT_N + 128) * sizeof(u64)));
   HIP_TRY(c, hipHostMalloc((void **)&c->h_counters, ftkx::CNT_N * sizeof(u64), hipHostMallocDefault));
   *out = c;
   return FTKX_OK;

@@ -785,7 +785,9 @@ __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const Ma
   if constexpr (REDUCE) {
     for (int o = 32; o > 0; o >>= 1) { red_mn = fmin(red_mn, __shfl_down(red_mn, o)); red_mx = fmax(red_mx, __shfl_down(red_mx, o)); }
     // non-negative doubles order like their bit patterns
-    if (lane == 0) { atomicMin(&job.red[0], (u64)__double_as_longlong(red_mn)); atomicMax(&job.red[1], (u64)__double_as_longlong(red_mx)); }
+    // 64 result slots (the host folds them): all wavefronts hammering one address would serialise at the memory side
+    const unsigned slot = (blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + wv) & 63u;
+    if (lane == 0) { atomicMin(&job.red[2 * slot], (u64)__double_as_longlong(red_mn)); atomicMax(&job.red[2 * slot + 1], (u64)__double_as_longlong(red_mx)); }
   }
 }
 

@@ -57,7 +57,7 @@ struct MaskJob {
   const double *V;
   unsigned char *M;
   unsigned char *U;          // summary: AND of the 8 mask bytes of each aligned x word (nullptr: not produced)
-  u64 *red;                  // optional reduction output: [0] min non-zero finite |v| bits, [1] max finite |v| bits (pre-pass)
+  u64 *red;                  // pre-pass reduction output: 64 slots of {min non-zero finite |v| bits, max finite |v| bits}
   double threshold;          // 1 / factor: q = trunc(v * factor) > 0  <=>  v >= 1/factor (factor is a power of two)
 };
 
