@@ -20,9 +20,10 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(src, pattern))
+    # gpurun MERGES into gpurun_out/: an earlier call's files may still be there -- take the newest match
+    g = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
     assert g, pattern
-    return g[0]
+    return g[-1]
 
 
 shutil.copy(one("trace/*/*kernel_stats.csv"), os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"))
@@ -54,7 +55,9 @@ for name in sorted(set(fetch) | set(write)):
 json.dump(summary, open(os.path.join(dst, f"{tag}_{cfg}_pmc_summary.json"), "w"), indent=1)
 bench = json.loads(open(one("bench_plain.json")).read().strip().splitlines()[-1])
 dom = bench["roofline"]["kernel"].replace("ftkx::", "").split("<")[0]
-cand = [v for n, v in summary["kernels"].items() if dom.replace("mask_kernel", "mask_") in n or dom in n]
+# bench.py labels kernel families; the marching mask kernel's pre-pass instantiation (<.., true>) is not the timed one
+key = {"mask_kernel": "mask_", "cull_kernel": "cull_", "exact_kernel": "exact_", "tile_kernel": "tile_"}.get(dom, dom)
+cand = [v for n, v in summary["kernels"].items() if key in n and not n.rstrip().endswith(", true>")]
 tj = os.path.join(dst, "traffic.json")
 traffic = json.load(open(tj)) if os.path.exists(tj) else {}
 if cand:
