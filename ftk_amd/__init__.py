@@ -34,7 +34,12 @@ def default_options(**kw):
     o = Options()
     _lib.load().ftkx_default_options(C.byref(o))
     for k, v in kw.items():
-        setattr(o, k, int(v))
+        if k == "coords_bounds":
+            o.coords_mode = 1
+            for i, b in enumerate(v):
+                o.coords_bounds[i] = float(b)
+        else:
+            setattr(o, k, int(v))
     return o
 
 
@@ -218,6 +223,7 @@ class _TrackerRegular:
     def set_exact_only(self, b): self._flags["exact_only"] = int(b)
     def set_tag_mode(self, m): self._flags["tag_mode"] = int(m)
     def set_stream(self, ptr): self._ck(self._L.ftkx_tracker_set_stream(self._h, C.c_void_p(ptr)))
+    def set_coords_bounds(self, b): self._ck(self._L.ftkx_tracker_set_coords_bounds(self._h, (C.c_double * len(b))(*[float(x) for x in b])))
 
     def initialize(self):
         self._ck(self._L.ftkx_tracker_set_sources(self._h, *self._src))

@@ -20,7 +20,8 @@ SOURCE_NONE, SOURCE_GIVEN, SOURCE_DERIVED = 0, 1, 2
 
 class Options(C.Structure):
     _fields_ = [("jacobian_symmetric", C.c_int), ("robust", C.c_int), ("use_type_filter", C.c_int), ("type_filter", C.c_uint),
-                ("compute_degrees", C.c_int), ("tag_mode", C.c_int), ("exact_only", C.c_int), ("derive_jacobian", C.c_int)]
+                ("compute_degrees", C.c_int), ("tag_mode", C.c_int), ("exact_only", C.c_int), ("derive_jacobian", C.c_int),
+                ("coords_mode", C.c_int), ("coords_bounds", C.c_double * 6)]
 
 
 class Stats(C.Structure):
@@ -40,7 +41,7 @@ EXPORTS = [
     "ftkx_sweep", "ftkx_sweep_enqueue", "ftkx_sweep_collect", "ftkx_get_stats", "ftkx_invalidate_masks", "ftkx_debug_stream_read", "ftkx_set_profiling", "ftkx_get_kernel_times", "ftkx_extract_cp2dt", "ftkx_extract_cp3dt", "ftkx_free",
     "ftkx_gradient2D", "ftkx_jacobian2D", "ftkx_gradient3D", "ftkx_jacobian3D", "ftkx_version", "ftkx_device_count",
     "ftkx_tracker_create", "ftkx_tracker_destroy", "ftkx_tracker_last_error", "ftkx_tracker_set_domain", "ftkx_tracker_set_array_domain",
-    "ftkx_tracker_set_sources", "ftkx_tracker_set_flags", "ftkx_tracker_set_stream", "ftkx_tracker_initialize",
+    "ftkx_tracker_set_sources", "ftkx_tracker_set_flags", "ftkx_tracker_set_stream", "ftkx_tracker_set_coords_bounds", "ftkx_tracker_initialize",
     "ftkx_tracker_push_scalar_field_snapshot", "ftkx_tracker_push_vector_field_snapshot", "ftkx_tracker_push_field_data_snapshot",
     "ftkx_tracker_advance_timestep", "ftkx_tracker_update_timestep", "ftkx_tracker_num_critical_points",
     "ftkx_tracker_get_critical_points", "ftkx_tracker_get_scaling", "ftkx_tracker_get_stats",
@@ -95,6 +96,7 @@ def load():
     L.ftkx_tracker_set_sources.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.ftkx_tracker_set_flags.argtypes = [vp, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int]
     L.ftkx_tracker_set_stream.argtypes = [vp, vp]
+    L.ftkx_tracker_set_coords_bounds.argtypes = [vp, C.POINTER(C.c_double)]
     L.ftkx_tracker_initialize.argtypes = [vp]
     L.ftkx_tracker_push_scalar_field_snapshot.argtypes = [vp, dbl, C.c_int]
     L.ftkx_tracker_push_vector_field_snapshot.argtypes = [vp, dbl, C.c_int]

@@ -216,6 +216,8 @@ void fill_mesh(const ftkx_ctx *c, Mesh &m)
   m.compute_degrees = c->opt.compute_degrees; m.tag_mode = c->opt.tag_mode;
   m.scalar_mode = c->scalar_mode == 1;
   m.derive_jacobian = c->opt.derive_jacobian;
+  m.coords_mode = c->opt.coords_mode;
+  for (int i = 0; i < 6; i ++) m.coords_bounds[i] = c->opt.coords_bounds[i];
   m.hits = c->d_hits; m.counters = c->d_counters; m.capacity = c->capacity;
 }
 
@@ -505,6 +507,7 @@ int ftkx_set_options(ftkx_ctx *c, const ftkx_options *o)
 {
   if (!c || !o) return fail(c, FTKX_E_INVALID, "null argument");
   if (o->tag_mode < FTKX_TAG_WORK_INDEX || o->tag_mode > FTKX_TAG_EXACT64) return fail(c, FTKX_E_INVALID, "bad tag_mode %d", o->tag_mode);
+  if (o->coords_mode != 0 && o->coords_mode != 1) return fail(c, FTKX_E_UNSUPPORTED, "coords_mode %d: only REGULAR_COORDS_SIMPLE (0) and _BOUNDS (1) are implemented", o->coords_mode);
   c->opt = *o;
   return FTKX_OK;
 }

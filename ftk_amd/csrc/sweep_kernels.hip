@@ -223,10 +223,16 @@ __device__ __noinline__ bool make_record(const Mesh &m, const Fields &f, const i
   r.scalar[0] = r.scalar[1] = r.scalar[2] = 0.0;
   {
     // lerp of the lattice coordinates, left to right (linear_interpolation.hh:83-101, 129-139)
+    // simplex_coordinates: lattice integers, or image bounds ((v - array_lb) / double(array_size - 1)) * (b1 - b0) + b0
+    auto phys = [&](int d, int v) -> double {
+      if (d < ND && m.coords_mode == 1)
+        return ((double)(unsigned long long)(v - m.ext_st[d]) / (double)(m.ext_sz[d] - 1)) * (m.coords_bounds[2 * d + 1] - m.coords_bounds[2 * d]) + m.coords_bounds[2 * d];
+      return (double)v;
+    };
     double x[4] = {0, 0, 0, 0};
     for (int d = 0; d < N; d ++) {
-      double acc = (double)vx[0][d] * mu[0];
-      for (int i = 1; i < N; i ++) acc = acc + (double)vx[i][d] * mu[i];
+      double acc = phys(d, vx[0][d]) * mu[0];
+      for (int i = 1; i < N; i ++) acc = acc + phys(d, vx[i][d]) * mu[i];
       x[d] = acc;
     }
     if constexpr (ND == 2) {

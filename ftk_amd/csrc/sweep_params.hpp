@@ -26,6 +26,8 @@ struct Mesh {
   int compute_degrees, tag_mode;
   int scalar_mode;           // 1: V is not stored; it is gradient2D/3D(S) evaluated where needed (vector_field_source == DERIVED)
   int derive_jacobian;       // 1: J not stored; jacobian2D/3D of V evaluated at hit vertices (jacobian_field_source == DERIVED)
+  int coords_mode;           // 0 lattice integers, 1 image bounds
+  double coords_bounds[6];
   ftkx_cp_t *hits;           // device hit buffer
   u64 *counters;             // CNT_* device counters
   u64 capacity;              // records the hit buffer can hold

@@ -52,6 +52,8 @@ void critical_point_tracker_regular::initialize()
   o.tag_mode = tag_mode;
   o.exact_only = exact_only;
   o.derive_jacobian = jacobian_field_source == SOURCE_DERIVED;
+  o.coords_mode = mode_phys_coords;
+  for (size_t i = 0; i < 6 && i < bounds_coords.size(); i ++) o.coords_bounds[i] = bounds_coords[i];
   check(ftkx_set_options(ctx, &o));
   initialized = true;
 }
@@ -219,6 +221,7 @@ int ftkx_tracker_set_flags(ftkx_tracker *h, int robust, int use_tf, unsigned tf,
   });
 }
 int ftkx_tracker_set_stream(ftkx_tracker *h, void *s) { return guarded(h, [&] { h->t->set_stream(s); }); }
+int ftkx_tracker_set_coords_bounds(ftkx_tracker *h, const double *b) { return guarded(h, [&] { h->t->set_coords_bounds(std::vector<double>(b, b + 2 * h->nd)); }); }
 int ftkx_tracker_initialize(ftkx_tracker *h) { return guarded(h, [&] { h->t->initialize(); }); }
 int ftkx_tracker_push_scalar_field_snapshot(ftkx_tracker *h, const double *s, int dev) { return guarded(h, [&] { h->t->push_scalar_field_snapshot(s, dev != 0); }); }
 int ftkx_tracker_push_vector_field_snapshot(ftkx_tracker *h, const double *v, int dev) { return guarded(h, [&] { h->t->push_vector_field_snapshot(v, dev != 0); }); }

@@ -73,6 +73,9 @@ typedef struct ftkx_options {
   int exact_only;           /* 1: never apply the sign cull (every simplex gets the full integer test) */
   int derive_jacobian;      /* 1: when a slice has no J, derive it at hit vertices from V exactly like ndarray/grad.hh
                                jacobian2D/3D would (jacobian_field_source == SOURCE_DERIVED); 0: treat J as absent (zeros) */
+  int coords_mode;          /* 0 REGULAR_COORDS_SIMPLE (lattice integers), 1 REGULAR_COORDS_BOUNDS (set_coords_bounds,
+                               regular_tracker.hh:38; 2d:504-510, 3d:358-365); RECTILINEAR / EXPLICIT are not supported */
+  double coords_bounds[6];  /* x0,x1,y0,y1[,z0,z1] */
 } ftkx_options;
 
 /* ---- context ------------------------------------------------------------------------------------------------- */

@@ -71,6 +71,8 @@ public:
   void set_enable_robust_detection(bool b) { enable_robust_detection = b; }
   void set_enable_computing_degrees(bool b) { enable_computing_degrees = b; }
   void set_type_filter(unsigned int f) { use_type_filter = true; type_filter = f; }
+  // regular_tracker.hh:38 -- REGULAR_COORDS_BOUNDS: x0,x1,y0,y1[,z0,z1]
+  void set_coords_bounds(const std::vector<double> &b) { bounds_coords = b; mode_phys_coords = 1; }
   // tracker.hh:40-41
   void set_current_timestep(int t) { current_timestep = t; }
   int get_current_timestep() const { return current_timestep; }
@@ -114,6 +116,8 @@ protected:
   unsigned int type_filter = 0;
   bool exact_only = false;
   int tag_mode = FTKX_TAG_REFERENCE;
+  int mode_phys_coords = 0;
+  std::vector<double> bounds_coords;
   bool initialized = false;
 
   int current_timestep = 0;
@@ -145,6 +149,7 @@ int  ftkx_tracker_set_array_domain(ftkx_tracker *, const long long *starts, cons
 int  ftkx_tracker_set_sources(ftkx_tracker *, int scalar, int vector, int jacobian, int jacobian_symmetric);
 int  ftkx_tracker_set_flags(ftkx_tracker *, int robust, int use_type_filter, unsigned type_filter, int compute_degrees, int exact_only, int tag_mode);
 int  ftkx_tracker_set_stream(ftkx_tracker *, void *hip_stream);
+int  ftkx_tracker_set_coords_bounds(ftkx_tracker *, const double *bounds /* 2*nd values */);
 int  ftkx_tracker_initialize(ftkx_tracker *);
 int  ftkx_tracker_push_scalar_field_snapshot(ftkx_tracker *, const double *s, int on_device);
 int  ftkx_tracker_push_vector_field_snapshot(ftkx_tracker *, const double *v, int on_device);

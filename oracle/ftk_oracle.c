@@ -529,6 +529,15 @@ static u64 element_tag(const sweep_ctx *c, const int *corner, int type, int mode
   return ci * (u64)c->ntypes_all + (u64)type;
 }
 
+/* simplex_coordinates: REGULAR_COORDS_SIMPLE -> the lattice integer; REGULAR_COORDS_BOUNDS ->
+ * ((v - array_lb) / double(array_size - 1)) * (b1 - b0) + b0   (2d:504-510, 3d:358-365; array_domain == ext) */
+static inline double phys_coord(const ftko_sweep_args *a, int d, int v)
+{
+  if (a->coords_mode == 1)
+    return ((double)(unsigned long long)(v - a->ext_st[d]) / (double)(a->ext_sz[d] - 1)) * (a->bounds[2 * d + 1] - a->bounds[2 * d]) + a->bounds[2 * d];
+  return (double)v;
+}
+
 static int check_simplex(const sweep_ctx *c, u64 work_index, ftko_rec_t *rec)
 {
   const ftko_sweep_args *a = c->a;
@@ -587,7 +596,7 @@ static int check_simplex(const sweep_ctx *c, u64 work_index, ftko_rec_t *rec)
     memset(rec, 0, sizeof(*rec));
     /* simplex_coordinates (REGULAR_COORDS_SIMPLE) + lerp_s2v4, linear_interpolation.hh:83-101 */
     double X[3][4];
-    for (int i = 0; i < 3; i ++) { X[i][0] = vx[i][0]; X[i][1] = vx[i][1]; X[i][2] = 0.0; X[i][3] = vx[i][2]; }
+    for (int i = 0; i < 3; i ++) { X[i][0] = phys_coord(a, 0, vx[i][0]); X[i][1] = phys_coord(a, 1, vx[i][1]); X[i][2] = 0.0; X[i][3] = vx[i][2]; }
     rec->cp.x[0] = X[0][0] * mu[0] + X[1][0] * mu[1] + X[2][0] * mu[2];
     rec->cp.x[1] = X[0][1] * mu[0] + X[1][1] * mu[1] + X[2][1] * mu[2];
     rec->cp.x[2] = X[0][2] * mu[0] + X[1][2] * mu[1] + X[2][2] * mu[2];
@@ -636,7 +645,7 @@ static int check_simplex(const sweep_ctx *c, u64 work_index, ftko_rec_t *rec)
 
     memset(rec, 0, sizeof(*rec));
     double X[4][4];
-    for (int i = 0; i < 4; i ++) for (int d = 0; d < 4; d ++) X[i][d] = vx[i][d];
+    for (int i = 0; i < 4; i ++) { for (int d = 0; d < 3; d ++) X[i][d] = phys_coord(a, d, vx[i][d]); X[i][3] = vx[i][3]; }
     double x[4];
     for (int d = 0; d < 4; d ++) x[d] = X[0][d] * mu[0] + X[1][d] * mu[1] + X[2][d] * mu[2] + X[3][d] * mu[3]; /* lerp_s3v4 :129-139 */
     rec->cp.x[0] = x[0]; rec->cp.x[1] = x[1]; rec->cp.x[2] = x[2]; rec->cp.t = x[3];
@@ -936,6 +945,7 @@ size_t ftko_track(const ftko_track_args *a, ftko_rec_t **out, unsigned long long
   sa.jacobian_symmetric = scalar_in;
   sa.robust = a->robust; sa.use_type_filter = a->use_type_filter; sa.type_filter = a->type_filter;
   sa.compute_degrees = a->compute_degrees; sa.tag_mode = a->tag_mode; sa.nthreads = a->nthreads;
+  sa.coords_mode = a->coords_mode; for (int i = 0; i < 6; i ++) sa.bounds[i] = a->bounds[i];
   int degenerate = 0;
   for (int d = 0; d < nd; d ++) if (sa.domain_sz[d] <= 0) degenerate = 1;
 

@@ -66,6 +66,8 @@ typedef struct {
   int compute_degrees;                    /* enable_computing_degrees (2D only)                                     */
   int tag_mode;                           /* FTKO_TAG_*                                                             */
   int nthreads;                           /* <=1: serial                                                            */
+  int coords_mode;                        /* 0 REGULAR_COORDS_SIMPLE, 1 REGULAR_COORDS_BOUNDS (regular_tracker.hh:38, 2d:504-510, 3d:358-365) */
+  double bounds[6];                       /* x0,x1,y0,y1[,z0,z1]                                                    */
 } ftko_sweep_args;
 
 /* returns the number of records, writes a malloc'd array sorted by (corner t,z,y,x, type) to *out (free with ftko_free) */
@@ -113,6 +115,8 @@ typedef struct {
   int compute_degrees;
   int tag_mode;
   int nthreads;
+  int coords_mode;
+  double bounds[6];
 } ftko_track_args;
 
 /* returns #records; *out sorted by (t,z,y,x,type); factors[k] (k < DT) = factor in force at the sweep of

@@ -27,6 +27,7 @@ class SweepArgs(C.Structure):
         ("factor", C.c_ulonglong),
         ("jacobian_symmetric", C.c_int), ("robust", C.c_int), ("use_type_filter", C.c_int),
         ("type_filter", C.c_uint), ("compute_degrees", C.c_int), ("tag_mode", C.c_int), ("nthreads", C.c_int),
+        ("coords_mode", C.c_int), ("bounds", C.c_double * 6),
     ]
 
 
@@ -36,6 +37,7 @@ class TrackArgs(C.Structure):
         ("steps", C.POINTER(C.c_void_p)),
         ("robust", C.c_int), ("use_type_filter", C.c_int), ("type_filter", C.c_uint),
         ("compute_degrees", C.c_int), ("tag_mode", C.c_int), ("nthreads", C.c_int),
+        ("coords_mode", C.c_int), ("bounds", C.c_double * 6),
     ]
 
 
@@ -200,7 +202,7 @@ def sweep(nd, scope, t, domain, core, ext, V, J, S, factor, jacobian_symmetric=T
     return _take(out, n)
 
 
-def track(steps, nd, nv, robust=True, type_filter=None, compute_degrees=False, tag_mode=TAG_REFERENCE, nthreads=1):
+def track(steps, nd, nv, robust=True, type_filter=None, compute_degrees=False, tag_mode=TAG_REFERENCE, nthreads=1, bounds=None):
     """steps: list of DT numpy arrays (scalar: shape reversed dims; vector: (..., nd)).
     Returns (records, factors[DT], sweep_seconds)."""
     steps = [_f64(s) for s in steps]
@@ -215,6 +217,10 @@ def track(steps, nd, nv, robust=True, type_filter=None, compute_degrees=False, t
     a.steps = C.cast(ptrs, C.POINTER(C.c_void_p))
     a.robust, a.use_type_filter, a.type_filter = int(robust), int(type_filter is not None), int(type_filter or 0)
     a.compute_degrees, a.tag_mode, a.nthreads = int(compute_degrees), tag_mode, nthreads
+    if bounds is not None:
+        a.coords_mode = 1
+        for i, b in enumerate(bounds):
+            a.bounds[i] = float(b)
     factors = np.zeros(DT, dtype=np.uint64)
     secs = C.c_double()
     out = C.c_void_p()

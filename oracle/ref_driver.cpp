@@ -120,7 +120,7 @@ static input_t read_input(const char *fn)
 }
 
 template <class Tracker>
-static void run(const input_t &in, int nthreads, const char *out, bool robust, unsigned type_filter)
+static void run(const input_t &in, int nthreads, const char *out, bool robust, unsigned type_filter, bool degrees, const std::vector<double> &bounds)
 {
   diy::mpi::communicator comm;
   probe<Tracker> tracker(comm);
@@ -146,6 +146,8 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
   if (nthreads > 0) tracker.set_number_of_threads(nthreads);
   tracker.set_enable_robust_detection(robust);
   if (type_filter) tracker.set_type_filter(type_filter);
+  if (degrees) tracker.set_enable_computing_degrees(true);
+  if (!bounds.empty()) tracker.set_coords_bounds(bounds);   // REGULAR_COORDS_BOUNDS, regular_tracker.hh:38
   tracker.initialize();
 
   for (int k = 0; k < in.DT; k ++) {
@@ -233,6 +235,12 @@ int main(int argc, char **argv)
   const std::string mode = argv[1];
   const bool robust = getenv("FTK_REF_NO_ROBUST") == NULL;
   const unsigned type_filter = getenv("FTK_REF_TYPE_FILTER") ? atoi(getenv("FTK_REF_TYPE_FILTER")) : 0;
+  const bool degrees = getenv("FTK_REF_DEGREES") != NULL;
+  std::vector<double> bounds;
+  if (const char *b = getenv("FTK_REF_BOUNDS")) {   // "x0,x1,y0,y1[,z0,z1]"
+    std::string sb(b); size_t pos = 0;
+    while (pos < sb.size()) { size_t q = sb.find(',', pos); if (q == std::string::npos) q = sb.size(); bounds.push_back(atof(sb.substr(pos, q - pos).c_str())); pos = q + 1; }
+  }
   if (mode == "tables") { dump_tables(argv[2]); return 0; }
 
   input_t in;
@@ -257,7 +265,7 @@ int main(int argc, char **argv)
     if (argc > 3) nthreads = atoi(argv[3]);
   } else return 2;
 
-  if (in.nd == 2) run<ftk::critical_point_tracker_2d_regular>(in, nthreads, out, robust, type_filter);
-  else run<ftk::critical_point_tracker_3d_regular>(in, nthreads, out, robust, type_filter);
+  if (in.nd == 2) run<ftk::critical_point_tracker_2d_regular>(in, nthreads, out, robust, type_filter, degrees, bounds);
+  else run<ftk::critical_point_tracker_3d_regular>(in, nthreads, out, robust, type_filter, degrees, bounds);
   return 0;
 }

@@ -19,6 +19,8 @@ def load_golden(name):
         robust=bool(int(d["robust"])) if "robust" in d else True,
         type_filter=int(d["type_filter"]) if "type_filter" in d else None,
         case=str(d["case"]) if "case" in d else None,
+        degrees=bool(int(d["degrees"])) if "degrees" in d else False,
+        bounds=[float(v) for v in d["bounds"]] if "bounds" in d else None,
         x0dir=d["x0dir"] if "x0dir" in d else None,
     )
 

@@ -39,11 +39,13 @@ SYNTHETIC = [
 ]
 
 
-def run_synthetic(out, case, DW, DH, DD, DT, x0dir):
+def run_synthetic(out, case, DW, DH, DD, DT, x0dir, env=None):
     cmd = [DRIVER, "synthetic", case, str(DW), str(DH), str(DD), str(DT), out]
     if x0dir is not None:
         cmd += [repr(float(v)) for v in x0dir]
-    r = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=e)
     return r.stdout.decode()
 
 
@@ -125,6 +127,15 @@ def main():
         a3 = adversarial_3d(rng, 9, 3, 1)
         run_file(out, a3, 3, 1, env={"FTK_REF_NO_ROBUST": "1"}); save("adversarial_3d_scalar_9x9x9x3_norobust", read_dump(out), dict(robust=0))
         run_file(out, a3, 3, 1); save("adversarial_3d_scalar_9x9x9x3_b", read_dump(out))
+
+        # enable_computing_degrees (2d:653-662) and REGULAR_COORDS_BOUNDS (2d:504-510, 3d:358-365)
+        run_synthetic(out, "woven", 31, 37, 1, 6, None, env={"FTK_REF_DEGREES": "1"})
+        save("woven_31x37x6_degrees", read_dump(out), dict(case="woven", degrees=1))
+        run_synthetic(out, "woven", 40, 33, 1, 5, None, env={"FTK_REF_BOUNDS": "-1.5,2.25,10,11.5"})
+        save("woven_40x33x5_bounds", read_dump(out), dict(case="woven", bounds=np.array([-1.5, 2.25, 10, 11.5])))
+        run_synthetic(out, "moving_extremum_3d", 14, 13, 12, 4, [6.25, 6.375, 5.125, 0.5, 0.25, 0.125], env={"FTK_REF_BOUNDS": "0,1,-2,2,100,130"})
+        save("moving_extremum_3d_14x13x12x4_bounds", read_dump(out), dict(case="moving_extremum_3d", bounds=np.array([0, 1, -2, 2, 100, 130.0]),
+                                                                          x0dir=np.array([6.25, 6.375, 5.125, 0.5, 0.25, 0.125])))
 
         subprocess.run([DRIVER, "tables", os.path.join(HERE, "unit_simplex_tables.txt")], check=True, stderr=subprocess.DEVNULL)
 

@@ -5,7 +5,8 @@ import numpy as np
 import ftk_amd
 
 
-def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=False, tag_mode=ftk_amd.TAG_REFERENCE, device=False):
+def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=False, tag_mode=ftk_amd.TAG_REFERENCE, device=False,
+                compute_degrees=False, bounds=None):
     """returns (records, ordinal, timestep, factors[DT], stats_list)"""
     import torch
     T = ftk_amd.CriticalPointTracker2DRegular if nd == 2 else ftk_amd.CriticalPointTracker3DRegular
@@ -25,6 +26,9 @@ def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=Fals
     if type_filter is not None:
         tr.set_type_filter(type_filter)
     tr.set_exact_only(exact_only)
+    tr.set_enable_computing_degrees(compute_degrees)
+    if bounds is not None:
+        tr.set_coords_bounds(bounds)
     tr.set_tag_mode(tag_mode)
     tr.initialize()
     DT = len(steps)

@@ -28,7 +28,8 @@ def gpu():
 def test_tracker_matches_reference_fixture(gpu, name, exact_only):
     from gpu_common import run_tracker
     g = load_golden(name)
-    recs, factors, stats = run_tracker(g["steps"], g["nd"], g["nv"], robust=g["robust"], type_filter=g["type_filter"], exact_only=exact_only)
+    recs, factors, stats = run_tracker(g["steps"], g["nd"], g["nv"], robust=g["robust"], type_filter=g["type_filter"], exact_only=exact_only,
+                                       compute_degrees=g["degrees"], bounds=g["bounds"])
     assert np.array_equal(factors, g["factors"]), "per-step quantisation factor differs from the reference"
     assert_records_equal(recs, g["records"], coord_tol=COORD_TOL, what=name)
     assert_records_equal(recs, g["records"], coord_tol=0.0, what=name + " (bit-exact)")
