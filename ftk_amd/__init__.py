@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import (CP_DTYPE, SCOPE_BOTH, SCOPE_INTERVAL, SCOPE_ORDINAL, SOURCE_DERIVED, SOURCE_GIVEN, SOURCE_NONE,  # noqa: F401
                    TAG_EXACT64, TAG_REFERENCE, TAG_WORK_INDEX, FtkxError, Options, Stats)
 
-__all__ = ["Context", "CriticalPointTracker2DRegular", "CriticalPointTracker3DRegular", "extract_cp2dt", "extract_cp3dt",
+__all__ = ["trace_curves", "Context", "CriticalPointTracker2DRegular", "CriticalPointTracker3DRegular", "extract_cp2dt", "extract_cp3dt",
            "scaling_factor", "CP_DTYPE", "FtkxError"]
 
 
@@ -183,6 +183,20 @@ def extract_cp2dt(scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc
 def extract_cp3dt(scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options=None, device_id=0):
     """extract_cp3dt_cuda's argument list (critical_point_tracker_3d_regular.hh:42-56)."""
     return _extract(3, scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options, device_id)
+
+
+def trace_curves(nd, domain, records):
+    """Pass 2 (ftkx_trace_curves): records (CP_DTYPE, element tags) -> (list of index arrays into `records`, loop flags, n_special)."""
+    L = _lib.load()
+    recs = np.ascontiguousarray(records, dtype=CP_DTYPE)
+    out = _lib.Curves()
+    _lib.check(L.ftkx_trace_curves(nd, _lib.ll(domain[0]), _lib.ll(domain[1], fill=1), recs.ctypes.data, len(recs), C.byref(out)))
+    offs = np.ctypeslib.as_array(out.offsets, shape=(out.n_curves + 1,)).copy()
+    idx = np.ctypeslib.as_array(out.indices, shape=(max(1, out.n_points),))[:out.n_points].copy()
+    loop = np.ctypeslib.as_array(out.loop, shape=(max(1, out.n_curves),))[:out.n_curves].copy()
+    nspecial = out.n_special
+    L.ftkx_free_curves(C.byref(out))
+    return [idx[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)], loop, nspecial
 
 
 class _TrackerRegular:

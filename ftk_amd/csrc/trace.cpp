@@ -1,0 +1,281 @@
+// Pass 2 on the hit set: from the discrete critical-point records of the sweep to traced curves.
+// Host-side, like the reference's own pass 2 -- it touches only the hits (<= ~0.5 % of the simplices).
+//
+// Reference semantics reproduced (include/ftk/...):
+//   neighbourhood      two d-simplices are neighbours iff they share a (d+1)-cell: f.side_of(m) -> c.sides(m)
+//                      (filters/critical_point_tracker_2d_regular.hh:189-197; mesh/simplicial_regular_mesh.hh:571-601, 717-797)
+//   components         union-find over the hits (filters/critical_point_tracker.hh:688-703, basic/duf.hh)
+//   curves             geometry/cc2curves.hh:10-111: nodes with more than two neighbours in the hit set are "special" and
+//                      dropped; every connected component of the remaining ("ordinary") nodes is one curve, ordered by walking
+//                      from its smallest element, first towards its smallest neighbour, then the other way
+//   loop flag          geometry/cc2curves.hh:113-122
+// "smallest" is the order of simplicial_regular_mesh_element::operator< (mesh/simplicial_regular_mesh.hh:327-337): corners compared
+// as vectors with x FIRST, then the type.  The traversal below follows the same order so that each curve's point sequence equals
+// the reference's (tests/test_trace.py compares against curves dumped from the real reference).
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ftkx.h"
+#include "fan_tables.hpp"
+
+namespace {
+
+typedef unsigned long long u64;
+
+struct Elem {
+  int c[4];   // corner x, y, (z,) t ; unused axes 0
+  int type;
+};
+
+inline bool elem_less(const Elem &a, const Elem &b, int n)
+{
+  for (int d = 0; d < n; d ++) if (a.c[d] != b.c[d]) return a.c[d] < b.c[d];
+  return a.type < b.type;
+}
+
+// adjacency of the simplex fan, generated from the same chain rule as fan_tables.hpp
+template <int N>
+struct Adjacency {
+  static constexpr int NF = ftkx::fan_table<N>::NTYPES;          // (N-1)-simplex types
+  static constexpr int NC = (N == 3) ? 6 : 24;                   // N-cell types (N! Kuhn simplices)
+  struct Ref { int type; int off[N]; };
+  std::array<std::array<Ref, N + 1>, NC> sides;                  // faces of a cell
+  std::array<std::vector<Ref>, NF> side_of;                      // cells containing a face (always 2)
+
+  Adjacency()
+  {
+    const ftkx::fan_table<N> &fan = ftkx::fan_of<N>::get();
+    // cells: chains 0 < k1 < ... < kN = full, in lexicographic order of the vertex list (x most significant):
+    // enumerate keys (MSB = x) in increasing order at every level
+    std::vector<std::array<unsigned, N + 1>> cells;   // vertex axis masks (bit a = axis a)
+    std::array<unsigned, N + 1> chain{};
+    enumerate(1, 0u, chain, cells);
+    for (int ct = 0; ct < NC; ct ++) {
+      for (int drop = 0; drop <= N; drop ++) {
+        unsigned v[N]; int m = 0;
+        for (int i = 0; i <= N; i ++) if (i != drop) v[m ++] = cells[ct][i];
+        unsigned common = ~0u;
+        for (int i = 0; i < N; i ++) common &= v[i];             // axes set in every remaining vertex -> corner offset
+        for (int i = 0; i < N; i ++) v[i] &= ~common;
+        int ft = -1;
+        for (int t = 0; t < NF && ft < 0; t ++) {
+          bool same = true;
+          for (int i = 0; i < N; i ++) same = same && fan.vert[t][i] == v[i];
+          if (same) ft = t;
+        }
+        Ref r; r.type = ft;
+        for (int a = 0; a < N; a ++) r.off[a] = (common >> a) & 1;
+        sides[ct][drop] = r;
+        Ref back; back.type = ct;
+        for (int a = 0; a < N; a ++) back.off[a] = -r.off[a];
+        side_of[ft].push_back(back);
+      }
+    }
+  }
+
+private:
+  static unsigned key_to_mask(unsigned key) { unsigned m = 0; for (int a = 0; a < N; a ++) if ((key >> (N - 1 - a)) & 1u) m |= 1u << a; return m; }
+  void enumerate(int depth, unsigned prev_key, std::array<unsigned, N + 1> &chain, std::vector<std::array<unsigned, N + 1>> &out)
+  {
+    if (depth == N + 1) { out.push_back(chain); return; }
+    for (unsigned key = 0; key < (1u << N); key ++)
+      if (key != prev_key && (key & prev_key) == prev_key) {
+        // a maximal chain adds exactly one axis per level
+        if (__builtin_popcount(key) != depth) continue;
+        chain[depth] = key_to_mask(key);
+        enumerate(depth + 1, key, chain, out);
+      }
+  }
+};
+
+template <int N>
+struct Tracer {
+  static constexpr int ND = N - 1;
+  static constexpr int NTYPES = ftkx::fan_table<N>::NTYPES;
+  const Adjacency<N> &adj;
+  long long lb[3], sz[3];
+  u64 prod[4];
+  std::vector<std::pair<u64, int>> index;   // (tag, record) sorted by tag
+
+  Tracer(const Adjacency<N> &a, const long long *dst, const long long *dsz) : adj(a)
+  {
+    prod[0] = 1;
+    for (int d = 0; d < ND; d ++) { lb[d] = dst[d]; sz[d] = dsz[d]; prod[d + 1] = prod[d] * (u64)dsz[d]; }
+  }
+
+  // e.to_integer(m) in 64-bit arithmetic (mesh/simplicial_regular_mesh.hh:496-502); false if the corner is outside the mesh box
+  bool encode(const Elem &e, u64 *tag) const
+  {
+    u64 ci = 0;
+    for (int d = 0; d < ND; d ++) {
+      const long long rel = e.c[d] - lb[d];
+      if (rel < 0 || rel >= sz[d]) return false;
+      ci += (u64)rel * prod[d];
+    }
+    if (e.c[ND] < 0) return false;
+    ci += (u64)e.c[ND] * prod[ND];
+    *tag = ci * (u64)NTYPES + (u64)e.type;
+    return true;
+  }
+  Elem decode(u64 tag) const
+  {
+    Elem e; e.c[0] = e.c[1] = e.c[2] = e.c[3] = 0;
+    e.type = (int)(tag % (u64)NTYPES);
+    u64 ci = tag / (u64)NTYPES;
+    for (int d = 0; d < ND; d ++) { e.c[d] = (int)(lb[d] + (long long)(ci % (u64)sz[d])); ci /= (u64)sz[d]; }
+    e.c[ND] = (int)ci;
+    return e;
+  }
+  int find(const Elem &e) const
+  {
+    u64 tag;
+    if (!encode(e, &tag)) return -1;
+    auto it = std::lower_bound(index.begin(), index.end(), std::make_pair(tag, -1));
+    return (it != index.end() && it->first == tag) ? it->second : -1;
+  }
+  // records that share a (d+1)-cell with e, in the element order of the reference's std::set, e itself excluded
+  void neighbours(const Elem &e, std::vector<std::pair<Elem, int>> &out) const
+  {
+    out.clear();
+    for (const auto &cell : adj.side_of[e.type]) {
+      int cc[N];
+      for (int a = 0; a < N; a ++) cc[a] = e.c[a] + cell.off[a];
+      for (const auto &face : adj.sides[cell.type]) {
+        Elem f; f.c[0] = f.c[1] = f.c[2] = f.c[3] = 0;
+        for (int a = 0; a < N; a ++) f.c[a] = cc[a] + face.off[a];
+        f.type = face.type;
+        bool self = f.type == e.type;
+        for (int a = 0; a < N && self; a ++) self = f.c[a] == e.c[a];
+        if (self) continue;
+        const int r = find(f);
+        if (r >= 0) out.push_back({f, r});
+      }
+    }
+    std::sort(out.begin(), out.end(), [](const std::pair<Elem, int> &a, const std::pair<Elem, int> &b) { return elem_less(a.first, b.first, N); });
+    out.erase(std::unique(out.begin(), out.end(), [](const std::pair<Elem, int> &a, const std::pair<Elem, int> &b) { return a.second == b.second; }), out.end());
+  }
+};
+
+struct UnionFind {
+  std::vector<int> p;
+  explicit UnionFind(size_t n) : p(n) { for (size_t i = 0; i < n; i ++) p[i] = (int)i; }
+  int find(int x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
+  void unite(int a, int b) { a = find(a); b = find(b); if (a != b) p[b] = a; }
+};
+
+template <int N>
+int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs, size_t n, ftkx_curves *out)
+{
+  static const Adjacency<N> adj;
+  Tracer<N> tr(adj, dst, dsz);
+  tr.index.resize(n);
+  for (size_t i = 0; i < n; i ++) tr.index[i] = {recs[i].tag, (int)i};
+  std::sort(tr.index.begin(), tr.index.end());
+  for (size_t i = 1; i < n; i ++) if (tr.index[i].first == tr.index[i - 1].first) return FTKX_E_INVALID;   // duplicate tags
+
+  std::vector<Elem> elem(n);
+  for (size_t i = 0; i < n; i ++) elem[i] = tr.decode(recs[i].tag);
+  // adjacency lists inside the hit set (sorted in element order), degrees
+  std::vector<std::vector<int>> nb(n);
+  std::vector<std::pair<Elem, int>> tmp;
+  for (size_t i = 0; i < n; i ++) {
+    tr.neighbours(elem[i], tmp);
+    nb[i].reserve(tmp.size());
+    for (const auto &t : tmp) nb[i].push_back(t.second);
+  }
+  std::vector<char> ordinary(n);
+  for (size_t i = 0; i < n; i ++) ordinary[i] = nb[i].size() <= 2;
+
+  // curves = connected components of the ordinary nodes
+  UnionFind uf(n);
+  for (size_t i = 0; i < n; i ++)
+    if (ordinary[i]) for (int j : nb[i]) if (ordinary[j]) uf.unite((int)i, j);
+  // seeds: the smallest element of every component, components enumerated in element order of their seed
+  std::vector<int> order(n);
+  for (size_t i = 0; i < n; i ++) order[i] = (int)i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return elem_less(elem[a], elem[b], N); });
+  std::vector<int> comp_size(n, 0);
+  for (size_t i = 0; i < n; i ++) if (ordinary[i]) comp_size[uf.find((int)i)] ++;
+
+  std::vector<int> seq; seq.reserve(n);
+  std::vector<long long> offsets(1, 0);
+  std::vector<int> loops;
+  std::vector<char> visited(n, 0), seeded(n, 0);
+  std::vector<int> front, back;
+  for (int s : order) {
+    if (!ordinary[s]) continue;
+    const int root = uf.find(s);
+    if (seeded[root]) continue;
+    seeded[root] = 1;
+    // cc2curves.hh:48-105
+    front.clear(); back.clear();
+    visited[s] = 1;
+    std::vector<int> seed_nb;
+    for (int j : nb[s]) if (ordinary[j]) seed_nb.push_back(j);
+    for (int dir = 0; dir < 2; dir ++) {
+      if (seed_nb.empty()) break;
+      int cur = dir == 0 ? seed_nb.front() : seed_nb.back();
+      while (true) {
+        if (!visited[cur]) { (dir == 0 ? back : front).push_back(cur); visited[cur] = 1; }
+        int next = -1;
+        for (int j : nb[cur]) if (ordinary[j] && !visited[j]) { next = j; break; }   // same component by construction
+        if (next < 0) break;
+        cur = next;
+      }
+      if (seed_nb.size() == 1) break;
+    }
+    const size_t begin = seq.size();
+    for (size_t i = front.size(); i > 0; i --) seq.push_back(front[i - 1]);
+    seq.push_back(s);
+    for (int v : back) seq.push_back(v);
+    offsets.push_back((long long)seq.size());
+    // is_loop, cc2curves.hh:113-122
+    int loop = 0;
+    if (seq.size() - begin >= 2) {
+      const int f = seq[begin], b = seq.back();
+      for (int j : nb[f]) if (j == b) loop = 1;
+    }
+    loops.push_back(loop);
+    (void)comp_size;
+  }
+
+  out->n_curves = loops.size();
+  out->n_points = seq.size();
+  out->offsets = (long long *)malloc(offsets.size() * sizeof(long long));
+  out->indices = (long long *)malloc((seq.size() ? seq.size() : 1) * sizeof(long long));
+  out->loop = (int *)malloc((loops.size() ? loops.size() : 1) * sizeof(int));
+  if (!out->offsets || !out->indices || !out->loop) return FTKX_E_NOMEM;
+  memcpy(out->offsets, offsets.data(), offsets.size() * sizeof(long long));
+  for (size_t i = 0; i < seq.size(); i ++) out->indices[i] = seq[i];
+  for (size_t i = 0; i < loops.size(); i ++) out->loop[i] = loops[i];
+  size_t nspecial = 0;
+  for (size_t i = 0; i < n; i ++) nspecial += !ordinary[i];
+  out->n_special = nspecial;
+  return FTKX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ftkx_trace_curves(int nd, const long long domain_st[3], const long long domain_sz[3], const ftkx_cp_t *recs, size_t n, ftkx_curves *out)
+{
+  if (!out || (n && !recs) || (nd != 2 && nd != 3)) return FTKX_E_INVALID;
+  memset(out, 0, sizeof(*out));
+  for (int d = 0; d < nd; d ++) if (domain_sz[d] <= 0) return FTKX_E_INVALID;
+  return nd == 2 ? trace_impl<3>(domain_st, domain_sz, recs, n, out) : trace_impl<4>(domain_st, domain_sz, recs, n, out);
+}
+
+void ftkx_free_curves(ftkx_curves *c)
+{
+  if (!c) return;
+  free(c->offsets); free(c->indices); free(c->loop);
+  memset(c, 0, sizeof(*c));
+}
+
+}  // extern "C"

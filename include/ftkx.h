@@ -160,6 +160,21 @@ int ftkx_extract_cp3dt(int scope, int current_timestep,
                        ftkx_cp_t **out, size_t *n_out);
 void ftkx_free(void *p);
 
+/* ---- pass 2 on the hit set: records -> traced curves (host side, like the reference's) --------------------------------
+ * Replaces critical_point_tracker::trace_critical_points_offline (include/ftk/filters/critical_point_tracker.hh:668-817) with
+ * the neighbourhood of critical_point_tracker_2d_regular.hh:189-197 and geometry/cc2curves.hh:10-122: two hits are neighbours
+ * iff their simplices share a (d+1)-cell; hits with more than two neighbours are dropped; every connected component of the rest
+ * is one curve whose points come in the reference's order.  `recs[i].tag` must be element tags (FTKX_TAG_EXACT64, or
+ * FTKX_TAG_REFERENCE where that did not overflow) of the mesh whose spatial box is (domain_st, domain_sz). */
+typedef struct ftkx_curves {
+  size_t n_curves, n_points, n_special;   /* n_special: hits dropped for having more than two neighbours */
+  long long *offsets;                     /* n_curves + 1 */
+  long long *indices;                     /* n_points indices into recs[], curve after curve */
+  int *loop;                              /* n_curves: first and last point are neighbours */
+} ftkx_curves;
+int  ftkx_trace_curves(int nd, const long long domain_st[3], const long long domain_sz[3], const ftkx_cp_t *recs, size_t n, ftkx_curves *out);
+void ftkx_free_curves(ftkx_curves *c);
+
 /* ---- derived fields on the device (ndarray/grad.hh), exposed for callers that keep V/J themselves ------------- */
 /* all pointers are DEVICE pointers; results are bit-identical to the reference's host loops */
 int ftkx_gradient2D(ftkx_ctx *ctx, const double *S, int DW, int DH, double *V);                    /* grad.hh:10-31   */

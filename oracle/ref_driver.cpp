@@ -188,6 +188,19 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
   }
   for (int k = 0; k < in.DT; k ++)
     fwrite(in.steps[k].data(), sizeof(double), in.steps[k].size(), fp);
+  // pass 2 of the reference (finalize -> trace_critical_points_offline, filters/critical_point_tracker.hh:668-817):
+  // the traced curves, each as the ordered list of its points' element tags
+  tracker.finalize();
+  const auto &curves = tracker.get_traced_critical_points();
+  const char cmagic[4] = {'C', 'U', 'R', 'V'};
+  fwrite(cmagic, 1, 4, fp);
+  const uint64_t ncurves = curves.size();
+  fwrite(&ncurves, 8, 1, fp);
+  for (const auto &kv : curves) {
+    const int32_t loop = kv.second.loop, n = (int32_t)kv.second.size();
+    fwrite(&loop, 4, 1, fp); fwrite(&n, 4, 1, fp);
+    for (const auto &cp : kv.second) { const uint64_t tag = cp.tag; fwrite(&tag, 8, 1, fp); }
+  }
   fclose(fp);
 }
 

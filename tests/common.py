@@ -12,7 +12,8 @@ def golden_names():
 
 
 def load_golden(name):
-    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d = {k: z[k] for k in z.files}      # NpzFile re-reads (and inflates) an array on every access
     return dict(
         nd=int(d["nd"]), nv=int(d["nv"]), dims=[int(x) for x in d["dims"]], DT=int(d["DT"]),
         steps=list(d["steps"]), factors=d["factors"], records=d["records"],
@@ -21,6 +22,8 @@ def load_golden(name):
         case=str(d["case"]) if "case" in d else None,
         degrees=bool(int(d["degrees"])) if "degrees" in d else False,
         bounds=[float(v) for v in d["bounds"]] if "bounds" in d else None,
+        curves=([(int(d["curve_loop"][i]), d["curve_tags"][d["curve_offsets"][i]:d["curve_offsets"][i + 1]]) for i in range(len(d["curve_loop"]))]
+                if "curve_loop" in d else None),
         x0dir=d["x0dir"] if "x0dir" in d else None,
     )
 

@@ -62,10 +62,16 @@ def run_file(out, steps, nd, nv, env=None):
 def save(name, d, extra=None):
     meta = dict(nd=d["nd"], nv=d["nv"], dims=np.array(d["dims"]), DT=d["DT"])
     meta.update(extra or {})
+    if d.get("curves") is not None:
+        # traced curves of the reference's pass 2: concatenated tag lists + offsets + loop flags
+        meta["curve_tags"] = np.concatenate([c[1] for c in d["curves"]]) if d["curves"] else np.zeros(0, dtype=np.uint64)
+        meta["curve_offsets"] = np.cumsum([0] + [len(c[1]) for c in d["curves"]]).astype(np.int64)
+        meta["curve_loop"] = np.array([c[0] for c in d["curves"]], dtype=np.int32)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), steps=d["steps"], factors=d["factors"], records=d["records"], **meta)
     types, counts = np.unique(d["records"]["type"], return_counts=True)
     print(f"{name}: {len(d['records'])} records ({int(d['records']['ordinal'].sum())} ordinal) types "
-          f"{dict(zip(types.tolist(), counts.tolist()))} factors {sorted(set(d['factors'].tolist()))}")
+          f"{dict(zip(types.tolist(), counts.tolist()))} factors {sorted(set(d['factors'].tolist()))} "
+          f"curves {len(d['curves']) if d.get('curves') is not None else None}")
 
 
 def adversarial_2d(rng, DW, DH, DT, nv):

@@ -23,7 +23,17 @@ def read_dump(path):
     dims = [int(D0), int(D1)] + ([int(D2)] if nd == 3 else [])
     shape = tuple(reversed(dims)) + ((int(nv),) if nv > 1 else ())
     steps = steps.reshape((int(DT),) + shape)
-    return dict(nd=int(nd), nv=int(nv), dims=dims, DT=int(DT), factors=factors, records=recs, steps=steps)
+    off += 8 * n * int(DT)
+    curves = None
+    if raw[off:off + 4] == b"CURV":
+        off += 4
+        nc = int(np.frombuffer(raw, "<u8", 1, off)[0]); off += 8
+        curves = []
+        for _ in range(nc):
+            loop, npts = np.frombuffer(raw, "<i4", 2, off); off += 8
+            tags = np.frombuffer(raw, "<u8", int(npts), off).copy(); off += 8 * int(npts)
+            curves.append((int(loop), tags))
+    return dict(nd=int(nd), nv=int(nv), dims=dims, DT=int(DT), factors=factors, records=recs, steps=steps, curves=curves)
 
 
 def write_input(path, steps, nd, nv):

@@ -1,0 +1,51 @@
+"""Pass 2: ftkx_trace_curves on the reference's own discrete records must give the reference's traced curves
+(dumped after finalize() by oracle/_ref/ftk_ref_driver): same number of curves, same point sequence per curve, same loop flag.
+Host-side code: runs without a GPU."""
+import numpy as np
+import pytest
+
+from common import golden_names, load_golden
+
+KNOWN_CURVES = {  # BASELINE.md section 3, column "curves at finalize()"
+    "woven_31x37x32": 56, "woven_128x128x10": 66, "moving_extremum_3d_32x32x32x8_dyadic": 1, "double_gyre_64x32x50": 2,
+    "moving_extremum_2d_21x21x32": 1, "moving_extremum_3d_21x21x21x32": 1, "merger_2d_32x32x100": 5,
+    "moving_extremum_3d_21x21x21x4_overflow": 23208, "moving_extremum_2d_21x21x9_aligned": 1,
+}
+
+
+def _trace(g):
+    import ftk_amd
+    from ftk_amd import build
+    build.build()
+    ref = g["records"]
+    recs = np.zeros(len(ref), dtype=ftk_amd.CP_DTYPE)
+    recs["tag"] = ref["tag"]; recs["type"] = ref["type"]; recs["x"] = ref["x"]; recs["t"] = ref["t"]
+    scalar = g["nv"] == 1
+    lo = 2 if scalar else 1
+    dom = ([lo] * g["nd"], [d - (3 if scalar else 2) for d in g["dims"]])
+    curves, loop, nspecial = ftk_amd.trace_curves(g["nd"], dom, recs)
+    return recs, curves, loop, nspecial
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_curves_equal_reference(name):
+    g = load_golden(name)
+    recs, curves, loop, nspecial = _trace(g)
+    ref = g["curves"]
+    assert len(curves) == len(ref)
+    if name in KNOWN_CURVES:
+        assert len(curves) == KNOWN_CURVES[name]
+    got = sorted((tuple(recs["tag"][c].tolist()), int(l)) for c, l in zip(curves, loop))
+    exp = sorted((tuple(t.tolist()), int(l)) for l, t in ref)
+    # same curves as point sequences; a curve may legitimately be reported in either direction only if the reference's
+    # std::set iteration were unspecified -- it is not, so demand identity
+    assert got == exp
+    # every hit is on exactly one curve or was dropped as a branching ("special") node
+    assert sum(len(c) for c in curves) + nspecial == len(recs)
+
+
+def test_duplicate_tags_are_rejected():
+    import ftk_amd
+    recs = np.zeros(2, dtype=ftk_amd.CP_DTYPE)
+    with pytest.raises(ftk_amd.FtkxError):
+        ftk_amd.trace_curves(2, ([2, 2], [10, 10]), recs)
