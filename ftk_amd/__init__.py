@@ -272,6 +272,16 @@ class _TrackerRegular:
             self._ck(self._L.ftkx_tracker_get_critical_points(self._h, recs.ctypes.data, o.ctypes.data, ts.ctypes.data, n.value))
         return recs, o, ts
 
+    def finalize(self): self._ck(self._L.ftkx_tracker_finalize(self._h))
+
+    def get_traced_critical_points(self):
+        """after finalize(): (list of tag arrays, one per curve, in curve order; loop flags)"""
+        nc, npts = C.c_size_t(), C.c_size_t()
+        self._ck(self._L.ftkx_tracker_num_curves(self._h, C.byref(nc), C.byref(npts)))
+        offs = np.zeros(nc.value + 1, dtype=np.int64); tags = np.zeros(max(1, npts.value), dtype=np.uint64); loop = np.zeros(max(1, nc.value), dtype=np.int32)
+        self._ck(self._L.ftkx_tracker_get_curves(self._h, offs.ctypes.data, tags.ctypes.data, loop.ctypes.data))
+        return [tags[offs[i]:offs[i + 1]] for i in range(nc.value)], loop[:nc.value]
+
     def get_vector_field_scaling_factor(self):
         f, r = C.c_ulonglong(), C.c_double()
         self._ck(self._L.ftkx_tracker_get_scaling(self._h, C.byref(f), C.byref(r)))

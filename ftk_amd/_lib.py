@@ -50,6 +50,7 @@ EXPORTS = [
     "ftkx_tracker_push_scalar_field_snapshot", "ftkx_tracker_push_vector_field_snapshot", "ftkx_tracker_push_field_data_snapshot",
     "ftkx_tracker_advance_timestep", "ftkx_tracker_update_timestep", "ftkx_tracker_num_critical_points",
     "ftkx_tracker_get_critical_points", "ftkx_tracker_get_scaling", "ftkx_tracker_get_stats",
+    "ftkx_tracker_finalize", "ftkx_tracker_num_curves", "ftkx_tracker_get_curves",
 ]
 
 _L = None
@@ -114,6 +115,9 @@ def load():
     L.ftkx_tracker_get_critical_points.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.ftkx_tracker_get_scaling.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_double)]
     L.ftkx_tracker_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.ftkx_tracker_finalize.argtypes = [vp]
+    L.ftkx_tracker_num_curves.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.ftkx_tracker_get_curves.argtypes = [vp, vp, vp, vp]
     _L = L
     return L
 

@@ -151,6 +151,35 @@ bool critical_point_tracker_regular::advance_timestep()
   return field_data_snapshots.size() > 0;
 }
 
+// critical_point_tracker_{2d,3d}_regular::finalize (2d:143-225, 3d:86-117) without streaming trajectories:
+// traced_critical_points = trace_critical_points_offline(discrete_critical_points, neighbours-sharing-a-cell)
+void critical_point_tracker_regular::finalize()
+{
+  std::vector<ftkx_cp_t> recs;
+  std::vector<const feature_point_t *> pts;
+  recs.reserve(discrete_critical_points.size());
+  for (const auto &kv : discrete_critical_points) {
+    ftkx_cp_t r;
+    std::memset(&r, 0, sizeof(r));
+    r.tag = kv.first;
+    recs.push_back(r);
+    pts.push_back(&kv.second);
+  }
+  long long dst[3] = {0, 0, 0}, dsz[3] = {1, 1, 1};
+  for (int d = 0; d < nd; d ++) { dst[d] = domain.start(d); dsz[d] = domain.size(d); }
+  ftkx_curves c;
+  const int rc = ftkx_trace_curves(nd, dst, dsz, recs.data(), recs.size(), &c);
+  if (rc != FTKX_OK) { ftkx_free_curves(&c); throw ftkx_error(rc, "finalize: ftkx_trace_curves failed (tags must not have overflowed int32: use FTKX_TAG_EXACT64 on very large meshes)"); }
+  traced_critical_points.clear(); traced_loop.clear();
+  for (size_t i = 0; i < c.n_curves; i ++) {
+    std::vector<feature_point_t> curve;
+    for (long long k = c.offsets[i]; k < c.offsets[i + 1]; k ++) curve.push_back(*pts[c.indices[k]]);
+    traced_critical_points.push_back(std::move(curve));
+    traced_loop.push_back(c.loop[i]);
+  }
+  ftkx_free_curves(&c);
+}
+
 std::vector<feature_point_t> critical_point_tracker_regular::get_critical_points() const
 {
   std::vector<feature_point_t> r;
@@ -259,6 +288,31 @@ int ftkx_tracker_get_scaling(const ftkx_tracker *h, unsigned long long *factor, 
   if (!h || !h->t) return FTKX_E_INVALID;
   if (factor) *factor = h->t->get_vector_field_scaling_factor();
   if (resolution) *resolution = h->t->get_vector_field_resolution();
+  return FTKX_OK;
+}
+
+int ftkx_tracker_finalize(ftkx_tracker *h) { return guarded(h, [&] { h->t->finalize(); }); }
+
+int ftkx_tracker_num_curves(const ftkx_tracker *h, size_t *n_curves, size_t *n_points)
+{
+  if (!h || !h->t || !n_curves || !n_points) return FTKX_E_INVALID;
+  *n_curves = h->t->get_traced_critical_points().size();
+  size_t np = 0;
+  for (const auto &c : h->t->get_traced_critical_points()) np += c.size();
+  *n_points = np;
+  return FTKX_OK;
+}
+
+int ftkx_tracker_get_curves(const ftkx_tracker *h, long long *offsets, unsigned long long *tags, int *loop)
+{
+  if (!h || !h->t || !offsets || !tags || !loop) return FTKX_E_INVALID;
+  size_t k = 0, i = 0;
+  offsets[0] = 0;
+  for (const auto &c : h->t->get_traced_critical_points()) {
+    for (const auto &p : c) tags[k ++] = p.tag;
+    loop[i] = h->t->get_traced_loop_flags()[i];
+    offsets[++ i] = (long long)k;
+  }
   return FTKX_OK;
 }
 

@@ -8,8 +8,8 @@
 // push_{scalar,vector}_field_snapshot / advance_timestep / update_timestep / get_critical_points.
 // Same names, same argument meaning, same call order as python/pyftk.cpp:93-142 and filters/json_interface.hh:606-725 use.
 // The sweep itself runs in the HIP kernels behind include/ftkx.h; there is no CPU implementation behind this class.
-// Tracing (finalize -> trace_critical_points_offline) is outside this library: hand get_critical_points() to the reference's
-// union-find stage.
+// finalize() runs pass 2 (trace_critical_points_offline + cc2curves) on the host through ftkx_trace_curves; the trajectory
+// post-processing of json_interface::post_process (split by type, smoothing, ...) is outside this library.
 #ifndef FTKX_TRACKER_HH
 #define FTKX_TRACKER_HH
 
@@ -94,6 +94,11 @@ public:
   bool advance_timestep();                                  // critical_point_tracker.hh:841-848
   void update_timestep();                                   // 2d:263-433, 3d:150-308 -- THE SWEEP
 
+  void finalize();                                          // 2d:143-225, 3d:86-117 -> trace_critical_points_offline
+  // traced curves after finalize(): each an ordered list of points (feature_curve_t), loop flag alongside
+  const std::vector<std::vector<feature_point_t>> &get_traced_critical_points() const { return traced_critical_points; }
+  const std::vector<int> &get_traced_loop_flags() const { return traced_loop; }
+
   std::vector<feature_point_t> get_critical_points() const; // critical_point_tracker_regular.hh:32-38 (sorted by element)
   const std::map<unsigned long long, feature_point_t> &get_discrete_critical_points() const { return discrete_critical_points; }
 
@@ -126,6 +131,8 @@ protected:
   double vector_field_resolution = std::numeric_limits<double>::max();   // sticky running minimum (never reset)
   unsigned long long vector_field_scaling_factor = 1;
   std::map<unsigned long long, feature_point_t> discrete_critical_points;
+  std::vector<std::vector<feature_point_t>> traced_critical_points;
+  std::vector<int> traced_loop;
   ftkx_stats last_stats;
 };
 
@@ -161,5 +168,9 @@ int  ftkx_tracker_num_critical_points(const ftkx_tracker *, size_t *n);
 int  ftkx_tracker_get_critical_points(const ftkx_tracker *, ftkx_cp_t *out, int *ordinal, int *timestep, size_t cap);
 int  ftkx_tracker_get_scaling(const ftkx_tracker *, unsigned long long *factor, double *resolution);
 int  ftkx_tracker_get_stats(const ftkx_tracker *, ftkx_stats *st);
+int  ftkx_tracker_finalize(ftkx_tracker *);
+/* after finalize: number of curves / total points; then offsets[n_curves+1], tags[n_points] (element tags in curve order), loop[n_curves] */
+int  ftkx_tracker_num_curves(const ftkx_tracker *, size_t *n_curves, size_t *n_points);
+int  ftkx_tracker_get_curves(const ftkx_tracker *, long long *offsets, unsigned long long *tags, int *loop);
 }
 #endif

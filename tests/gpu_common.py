@@ -6,7 +6,7 @@ import ftk_amd
 
 
 def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=False, tag_mode=ftk_amd.TAG_REFERENCE, device=False,
-                compute_degrees=False, bounds=None):
+                compute_degrees=False, bounds=None, want_curves=False):
     """returns (records, ordinal, timestep, factors[DT], stats_list)"""
     import torch
     T = ftk_amd.CriticalPointTracker2DRegular if nd == 2 else ftk_amd.CriticalPointTracker3DRegular
@@ -46,10 +46,15 @@ def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=Fals
         if k == DT - 1:
             tr.update_timestep(); factors[cur] = tr.get_vector_field_scaling_factor(); stats.append(tr.get_last_stats())
     recs, o, ts = tr.get_critical_points()
+    if want_curves:
+        tr.finalize()
+        curves = tr.get_traced_critical_points()
     tr.close()
     out = np.zeros(len(recs), dtype=[("tag", "<u8"), ("type", "<u4"), ("ordinal", "<i4"), ("timestep", "<i4"),
                                      ("x", "<f8", (3,)), ("t", "<f8"), ("scalar", "<f8", (3,))])
     for f in ("tag", "type", "x", "t", "scalar"):
         out[f] = recs[f]
     out["ordinal"] = o; out["timestep"] = ts
+    if want_curves:
+        return out, factors, stats, curves
     return out, factors, stats

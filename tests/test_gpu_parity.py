@@ -229,3 +229,17 @@ def test_larger_3d_vs_oracle_with_odd_sizes(gpu, oracle):
     recs, factors, st = _batched_context_run(gpu, steps, 3, 1, (35, 22, 19))
     assert factors == [int(f) for f in rf]
     assert_records_equal(recs, ref, coord_tol=0.0, what="random walk 35x22x19x3")
+
+
+@pytest.mark.parametrize("name", ["woven_31x37x32", "merger_2d_32x32x100", "double_gyre_64x32x50", "moving_extremum_3d_21x21x21x32",
+                                  "random_3d_scalar_13x12x11x4"])
+def test_tracker_end_to_end_curves(gpu, name):
+    """sweep on the GPU + finalize(): the traced curves are the reference's (56 for the woven test of the reference itself)"""
+    from gpu_common import run_tracker
+    g = load_golden(name)
+    recs, factors, stats, (curves, loop) = run_tracker(g["steps"], g["nd"], g["nv"], want_curves=True)
+    got = sorted((tuple(c.tolist()), int(l)) for c, l in zip(curves, loop))
+    exp = sorted((tuple(t.tolist()), int(l)) for l, t in g["curves"])
+    assert got == exp
+    if name == "woven_31x37x32":
+        assert len(curves) == 56      # tests/test_critical_point_tracking_woven.cpp:32-37
