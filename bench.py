@@ -154,6 +154,7 @@ def main():
     prepass_ms = (time.perf_counter() - tp0) * 1e3
 
     halo_pushed = [False]
+    host_ms = [0.0, 0.0]
 
     def one_pass():
         have_halo = False
@@ -165,10 +166,13 @@ def main():
                 (ctx.push_scalar_slice if scalar_input else ctx.push_slice)(t1_own, halo_buf)
                 ctx.set_slice_resolution(t1_own, all_res[t1_own], all_max[t1_own])   # its owner's reduction, from the all_gather
                 halo_pushed[0] = True
+        te0 = time.perf_counter()
         for t in own:
             scope = ftk_amd.SCOPE_BOTH if (t + 1 < nt) else ftk_amd.SCOPE_ORDINAL
             ctx.sweep_enqueue(t, scope, factors[t])
+        te1 = time.perf_counter()
         recs = ctx.sweep_collect()      # one mask / cull / exact launch for the whole slab, then the hit download
+        host_ms[0] += (te1 - te0) * 1e3; host_ms[1] += (time.perf_counter() - te1) * 1e3
         st = ctx.stats()
         return recs, st
 
@@ -180,6 +184,7 @@ def main():
     for _ in range(args.warmup):
         recs, st = one_pass()
     ctx.set_profiling(True)         # HIP events around every kernel launch, on the stream the kernels run on
+    host_ms[0] = host_ms[1] = 0.0
     barrier()
     tt0 = time.perf_counter()
     for _ in range(args.steps):
@@ -242,6 +247,7 @@ def main():
                          "all_kernels_ms_per_pass": all_ms, "achieved_all_kernels": alg_bytes_pass / (all_ms * 1e-3) / 1e9,
                          "kernel_ms_per_pass": {k: v[0] / args.steps for k, v in ktimes.items()}},
             "prepass_ms": prepass_ms,
+            "wall_breakdown_ms_per_pass": {"enqueue_calls": host_ms[0] / args.steps, "collect_launch_sync_sort_download": host_ms[1] / args.steps},
             "stats": {"simplices_tested_exactly": n_tested, "cells_survived_cull": n_cells},
             "check": check,
         }

@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import (CP_DTYPE, SCOPE_BOTH, SCOPE_INTERVAL, SCOPE_ORDINAL, SOURCE_DERIVED, SOURCE_GIVEN, SOURCE_NONE,  # noqa: F401
                    TAG_EXACT64, TAG_REFERENCE, TAG_WORK_INDEX, FtkxError, Options, Stats)
 
-__all__ = ["trace_curves", "Context", "CriticalPointTracker2DRegular", "CriticalPointTracker3DRegular", "extract_cp2dt", "extract_cp3dt",
+__all__ = ["trace_curves", "trace_and_post_process", "Context", "CriticalPointTracker2DRegular", "CriticalPointTracker3DRegular", "extract_cp2dt", "extract_cp3dt",
            "scaling_factor", "CP_DTYPE", "FtkxError"]
 
 
@@ -197,6 +197,25 @@ def trace_curves(nd, domain, records):
     nspecial = out.n_special
     L.ftkx_free_curves(C.byref(out))
     return [idx[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)], loop, nspecial
+
+
+def trace_and_post_process(nd, domain, records):
+    """ftkx_trace_curves followed by ftkx_post_process_curves (json_interface::post_process defaults).
+    records: CP_DTYPE with element tags and the aux word.  Returns a list of (indices, types, t, loop) per trajectory."""
+    L = _lib.load()
+    recs = np.ascontiguousarray(records, dtype=CP_DTYPE)
+    cur = _lib.Curves()
+    _lib.check(L.ftkx_trace_curves(nd, _lib.ll(domain[0]), _lib.ll(domain[1], fill=1), recs.ctypes.data, len(recs), C.byref(cur)))
+    out = _lib.Trajectories()
+    rc = L.ftkx_post_process_curves(recs.ctypes.data, len(recs), C.byref(cur), C.byref(out))
+    L.ftkx_free_curves(C.byref(cur))
+    _lib.check(rc)
+    n, npts = out.n_curves, max(1, out.n_points)
+    offs = np.ctypeslib.as_array(out.offsets, shape=(n + 1,)).copy()
+    idx = np.ctypeslib.as_array(out.indices, shape=(npts,)).copy(); ty = np.ctypeslib.as_array(out.type, shape=(npts,)).copy()
+    tt = np.ctypeslib.as_array(out.t, shape=(npts,)).copy(); loop = np.ctypeslib.as_array(out.loop, shape=(max(1, n),)).copy()
+    L.ftkx_free_trajectories(C.byref(out))
+    return [(idx[offs[i]:offs[i + 1]], ty[offs[i]:offs[i + 1]], tt[offs[i]:offs[i + 1]], int(loop[i])) for i in range(n)]
 
 
 class _TrackerRegular:

@@ -34,6 +34,11 @@ class Curves(C.Structure):
                 ("offsets", C.POINTER(C.c_longlong)), ("indices", C.POINTER(C.c_longlong)), ("loop", C.POINTER(C.c_int))]
 
 
+class Trajectories(C.Structure):
+    _fields_ = [("n_curves", C.c_size_t), ("n_points", C.c_size_t), ("offsets", C.POINTER(C.c_longlong)), ("indices", C.POINTER(C.c_longlong)),
+                ("loop", C.POINTER(C.c_int)), ("type", C.POINTER(C.c_uint)), ("t", C.POINTER(C.c_double))]
+
+
 class FtkxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"ftkx error {code}: {msg}")
@@ -44,7 +49,7 @@ EXPORTS = [
     "ftkx_create", "ftkx_destroy", "ftkx_last_error", "ftkx_set_stream", "ftkx_set_options", "ftkx_default_options", "ftkx_set_mesh",
     "ftkx_push_slice", "ftkx_push_scalar_slice", "ftkx_drop_slice", "ftkx_slice_resolution", "ftkx_set_slice_resolution", "ftkx_scaling_factor",
     "ftkx_sweep", "ftkx_sweep_enqueue", "ftkx_sweep_collect", "ftkx_get_stats", "ftkx_invalidate_masks", "ftkx_debug_stream_read", "ftkx_set_profiling", "ftkx_get_kernel_times", "ftkx_extract_cp2dt", "ftkx_extract_cp3dt", "ftkx_free",
-    "ftkx_trace_curves", "ftkx_free_curves", "ftkx_gradient2D", "ftkx_jacobian2D", "ftkx_gradient3D", "ftkx_jacobian3D", "ftkx_version", "ftkx_device_count",
+    "ftkx_trace_curves", "ftkx_free_curves", "ftkx_post_process_curves", "ftkx_free_trajectories", "ftkx_gradient2D", "ftkx_jacobian2D", "ftkx_gradient3D", "ftkx_jacobian3D", "ftkx_version", "ftkx_device_count",
     "ftkx_tracker_create", "ftkx_tracker_destroy", "ftkx_tracker_last_error", "ftkx_tracker_set_domain", "ftkx_tracker_set_array_domain",
     "ftkx_tracker_set_sources", "ftkx_tracker_set_flags", "ftkx_tracker_set_stream", "ftkx_tracker_set_coords_bounds", "ftkx_tracker_initialize",
     "ftkx_tracker_push_scalar_field_snapshot", "ftkx_tracker_push_vector_field_snapshot", "ftkx_tracker_push_field_data_snapshot",
@@ -91,6 +96,8 @@ def load():
     L.ftkx_free.argtypes = [vp]; L.ftkx_free.restype = None
     L.ftkx_trace_curves.argtypes = [C.c_int, ll3, ll3, vp, C.c_size_t, C.POINTER(Curves)]
     L.ftkx_free_curves.argtypes = [C.POINTER(Curves)]; L.ftkx_free_curves.restype = None
+    L.ftkx_post_process_curves.argtypes = [vp, C.c_size_t, C.POINTER(Curves), C.POINTER(Trajectories)]
+    L.ftkx_free_trajectories.argtypes = [C.POINTER(Trajectories)]; L.ftkx_free_trajectories.restype = None
     L.ftkx_gradient2D.argtypes = [vp, dbl, C.c_int, C.c_int, dbl]
     L.ftkx_jacobian2D.argtypes = [vp, dbl, C.c_int, C.c_int, C.c_int, dbl]
     L.ftkx_gradient3D.argtypes = [vp, dbl, C.c_int, C.c_int, C.c_int, dbl]

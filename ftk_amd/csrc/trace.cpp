@@ -278,4 +278,126 @@ void ftkx_free_curves(ftkx_curves *c)
   memset(c, 0, sizeof(*c));
 }
 
+// Trajectory post-processing with the defaults of json_interface::post_process (include/ftk/filters/json_interface.hh:758-800):
+//   per curve   smooth_ordinal_types(2), smooth_interval_types(), rotate()          features/feature_curve.hh:295-348, 254-266
+//   set         split_all(): curves of mixed type are cut into runs of one type      features/feature_curve_set.hh:514-532, feature_curve.hh:220-243
+//   per curve   reorder() (ascending time), adjust_time() (monotone t)               features/feature_curve.hh:268-293
+// Quirks kept: split() drops the first point of every new run (the point at which the type changes), split pieces are never
+// loops, and a curve whose single type is 0 (UNKNOWN) counts as "inconsistent" and goes through split() too.
+int ftkx_post_process_curves(const ftkx_cp_t *recs, size_t n, const ftkx_curves *in, ftkx_trajectories *out)
+{
+  if (!out || !in || (n && !recs)) return FTKX_E_INVALID;
+  memset(out, 0, sizeof(*out));
+  struct Pt { long long idx; unsigned type; double t; int ordinal, timestep; };
+  struct Curve { std::vector<Pt> p; int loop; };
+  std::vector<Curve> curves(in->n_curves);
+  for (size_t c = 0; c < in->n_curves; c ++) {
+    curves[c].loop = in->loop[c];
+    for (long long k = in->offsets[c]; k < in->offsets[c + 1]; k ++) {
+      const long long i = in->indices[k];
+      if (i < 0 || (size_t)i >= n) return FTKX_E_INVALID;
+      curves[c].p.push_back(Pt{i, recs[i].type, recs[i].t, ftkx_cp_ordinal(&recs[i]), ftkx_cp_timestep(&recs[i])});
+    }
+  }
+  auto ordinals_of = [](const std::vector<Pt> &p) { std::vector<int> o; for (size_t i = 0; i < p.size(); i ++) if (p[i].ordinal) o.push_back((int)i); return o; };
+  for (Curve &cv : curves) {
+    std::vector<Pt> &p = cv.p;
+    {   // smooth_ordinal_types(half_window_size = 2)
+      const int h = 2;
+      const std::vector<int> o = ordinals_of(p);
+      if ((int)o.size() >= 2 * h + 1) {
+        std::vector<std::pair<int, unsigned>> pending;
+        for (int i = h; i < (int)o.size() - h; i ++) {
+          unsigned consistent = p[o[i - h]].type;
+          for (int j = i - h; j <= i + h; j ++) {
+            if (j == i) continue;
+            if (consistent != p[o[j]].type) { consistent = 0; break; }
+          }
+          if (consistent != 0 && p[o[i]].type != consistent) pending.push_back({o[i], consistent});
+        }
+        for (const auto &kv : pending) p[kv.first].type = kv.second;
+      }
+    }
+    {   // smooth_interval_types
+      const std::vector<int> o = ordinals_of(p);
+      if (!o.empty()) {
+        const unsigned ft = p[o.front()].type;
+        for (int i = 0; i < o.front(); i ++) p[i].type = ft;
+        const unsigned bt = p[o.back()].type;
+        for (int i = o.back(); i < (int)p.size(); i ++) p[i].type = bt;
+        for (size_t i = 0; i + 1 < o.size(); i ++) {
+          if (p[o[i]].type == p[o[i + 1]].type) {
+            const unsigned it = p[o[i]].type;
+            for (int j = o[i]; j < o[i + 1]; j ++) p[j].type = it;
+          } else {
+            const unsigned lt = p[o[i]].type, rt = p[o[i + 1]].type;
+            int j;
+            for (j = o[i]; j < o[i + 1]; j ++) if (p[j].type != lt) break;
+            for (; j < o[i + 1]; j ++) p[j].type = rt;
+          }
+        }
+      }
+    }
+    // rotate
+    if (cv.loop && !p.empty() && p.front().type == p.back().type) {
+      size_t i = 0;
+      for (; i < p.size(); i ++) if (p.front().type != p[i].type) break;
+      if (i < p.size()) std::rotate(p.begin(), p.begin() + i, p.end());
+    }
+  }
+  // split_all
+  std::vector<Curve> result;
+  for (Curve &cv : curves) {
+    if (cv.p.empty()) { result.push_back(cv); continue; }
+    unsigned consistent = cv.p[0].type;
+    for (const Pt &q : cv.p) if (q.type != consistent) { consistent = 0; break; }
+    if (consistent != 0) { result.push_back(cv); continue; }
+    Curve sub; sub.loop = 0;
+    unsigned current = 0;
+    for (size_t i = 0; i < cv.p.size(); i ++) {
+      if (sub.p.empty()) current = cv.p[i].type;
+      if (cv.p[i].type == current) sub.p.push_back(cv.p[i]);
+      if (cv.p[i].type != current || i == cv.p.size() - 1) {
+        if (!sub.p.empty()) { result.push_back(sub); sub.p.clear(); }
+      }
+    }
+  }
+  for (Curve &cv : result) {
+    std::vector<Pt> &p = cv.p;
+    if (!p.empty() && !cv.loop) {   // reorder
+      bool reverse = false;
+      if (p.front().timestep == p.back().timestep) { if (p.front().t > p.back().t) reverse = true; }
+      else if (p.front().timestep > p.back().timestep) reverse = true;
+      if (reverse) std::reverse(p.begin(), p.end());
+    }
+    // adjust_time
+    for (size_t i = 0; i < p.size(); i ++) { if (i == 0 || p[i].ordinal) continue; p[i].t = std::max(p[i - 1].t, p[i].t); }
+    for (size_t i = p.size(); i -- > 0; ) { if (i == p.size() - 1 || p[i].ordinal) continue; p[i].t = std::min(p[i + 1].t, p[i].t); }
+  }
+  size_t np = 0;
+  for (const Curve &cv : result) np += cv.p.size();
+  out->n_curves = result.size(); out->n_points = np;
+  out->offsets = (long long *)malloc((result.size() + 1) * sizeof(long long));
+  out->indices = (long long *)malloc((np ? np : 1) * sizeof(long long));
+  out->loop = (int *)malloc((result.size() ? result.size() : 1) * sizeof(int));
+  out->type = (unsigned *)malloc((np ? np : 1) * sizeof(unsigned));
+  out->t = (double *)malloc((np ? np : 1) * sizeof(double));
+  if (!out->offsets || !out->indices || !out->loop || !out->type || !out->t) return FTKX_E_NOMEM;
+  size_t k = 0;
+  out->offsets[0] = 0;
+  for (size_t c = 0; c < result.size(); c ++) {
+    for (const Pt &q : result[c].p) { out->indices[k] = q.idx; out->type[k] = q.type; out->t[k] = q.t; k ++; }
+    out->offsets[c + 1] = (long long)k;
+    out->loop[c] = result[c].loop;
+  }
+  return FTKX_OK;
+}
+
+void ftkx_free_trajectories(ftkx_trajectories *c)
+{
+  if (!c) return;
+  free(c->offsets); free(c->indices); free(c->loop); free(c->type); free(c->t);
+  memset(c, 0, sizeof(*c));
+}
+
 }  // extern "C"

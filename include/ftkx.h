@@ -175,6 +175,21 @@ typedef struct ftkx_curves {
 int  ftkx_trace_curves(int nd, const long long domain_st[3], const long long domain_sz[3], const ftkx_cp_t *recs, size_t n, ftkx_curves *out);
 void ftkx_free_curves(ftkx_curves *c);
 
+/* Trajectory post-processing with the defaults of json_interface::post_process (include/ftk/filters/json_interface.hh:758-800):
+ * smooth_ordinal_types / smooth_interval_types / rotate, split_all, reorder / adjust_time (features/feature_curve.hh:220-348,
+ * features/feature_curve_set.hh:514-532).  recs[] must carry the aux word (ordinal, timestep) the sweep writes.  Per point the
+ * smoothed type and adjusted time come back next to the index into recs[]. */
+typedef struct ftkx_trajectories {
+  size_t n_curves, n_points;
+  long long *offsets;
+  long long *indices;
+  int *loop;
+  unsigned int *type;
+  double *t;
+} ftkx_trajectories;
+int  ftkx_post_process_curves(const ftkx_cp_t *recs, size_t n, const ftkx_curves *in, ftkx_trajectories *out);
+void ftkx_free_trajectories(ftkx_trajectories *c);
+
 /* ---- derived fields on the device (ndarray/grad.hh), exposed for callers that keep V/J themselves ------------- */
 /* all pointers are DEVICE pointers; results are bit-identical to the reference's host loops */
 int ftkx_gradient2D(ftkx_ctx *ctx, const double *S, int DW, int DH, double *V);                    /* grad.hh:10-31   */

@@ -201,6 +201,26 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
     fwrite(&loop, 4, 1, fp); fwrite(&n, 4, 1, fp);
     for (const auto &cp : kv.second) { const uint64_t tag = cp.tag; fwrite(&tag, 8, 1, fp); }
   }
+  // the reference's trajectory post-processing, called exactly as json_interface::post_process does with its default options
+  // (filters/json_interface.hh:758-800: no duration pruning, interval points kept, no velocities)
+  {
+    auto &trajs = tracker.get_traced_critical_points();
+    trajs.foreach([](ftk::feature_curve_t &t) { t.smooth_ordinal_types(); t.smooth_interval_types(); t.rotate(); t.update_statistics(); });
+    trajs.split_all();
+    trajs.foreach([](ftk::feature_curve_t &t) { t.reorder(); t.adjust_time(); t.update_statistics(); });
+    const char pmagic[4] = {'P', 'P', 'C', 'V'};
+    fwrite(pmagic, 1, 4, fp);
+    const uint64_t np = trajs.size();
+    fwrite(&np, 8, 1, fp);
+    for (const auto &kv : trajs) {
+      const int32_t loop = kv.second.loop, n = (int32_t)kv.second.size();
+      fwrite(&loop, 4, 1, fp); fwrite(&n, 4, 1, fp);
+      for (const auto &cp : kv.second) {
+        const uint64_t tag = cp.tag; const uint32_t type = cp.type, pad = 0; const double t = cp.t;
+        fwrite(&tag, 8, 1, fp); fwrite(&type, 4, 1, fp); fwrite(&pad, 4, 1, fp); fwrite(&t, 8, 1, fp);
+      }
+    }
+  }
   fclose(fp);
 }
 

@@ -24,6 +24,8 @@ def load_golden(name):
         bounds=[float(v) for v in d["bounds"]] if "bounds" in d else None,
         curves=([(int(d["curve_loop"][i]), d["curve_tags"][d["curve_offsets"][i]:d["curve_offsets"][i + 1]]) for i in range(len(d["curve_loop"]))]
                 if "curve_loop" in d else None),
+        pp=([(int(d["pp_loop"][i]), d["pp_tags"][d["pp_offsets"][i]:d["pp_offsets"][i + 1]], d["pp_types"][d["pp_offsets"][i]:d["pp_offsets"][i + 1]],
+              d["pp_t"][d["pp_offsets"][i]:d["pp_offsets"][i + 1]]) for i in range(len(d["pp_loop"]))] if "pp_loop" in d else None),
         x0dir=d["x0dir"] if "x0dir" in d else None,
     )
 

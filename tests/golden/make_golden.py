@@ -67,11 +67,17 @@ def save(name, d, extra=None):
         meta["curve_tags"] = np.concatenate([c[1] for c in d["curves"]]) if d["curves"] else np.zeros(0, dtype=np.uint64)
         meta["curve_offsets"] = np.cumsum([0] + [len(c[1]) for c in d["curves"]]).astype(np.int64)
         meta["curve_loop"] = np.array([c[0] for c in d["curves"]], dtype=np.int32)
+    if d.get("pp") is not None:
+        # post-processed trajectories (json_interface::post_process defaults): per point tag, type, t
+        meta["pp_offsets"] = np.cumsum([0] + [len(c[1]) for c in d["pp"]]).astype(np.int64)
+        allp = np.concatenate([c[1] for c in d["pp"]]) if d["pp"] else np.zeros(0, dtype=[("tag", "<u8"), ("type", "<u4"), ("_pad", "<u4"), ("t", "<f8")])
+        meta["pp_tags"] = allp["tag"]; meta["pp_types"] = allp["type"]; meta["pp_t"] = allp["t"]
+        meta["pp_loop"] = np.array([c[0] for c in d["pp"]], dtype=np.int32)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), steps=d["steps"], factors=d["factors"], records=d["records"], **meta)
     types, counts = np.unique(d["records"]["type"], return_counts=True)
     print(f"{name}: {len(d['records'])} records ({int(d['records']['ordinal'].sum())} ordinal) types "
           f"{dict(zip(types.tolist(), counts.tolist()))} factors {sorted(set(d['factors'].tolist()))} "
-          f"curves {len(d['curves']) if d.get('curves') is not None else None}")
+          f"curves {len(d['curves']) if d.get('curves') is not None else None} post-processed {len(d['pp']) if d.get('pp') is not None else None}")
 
 
 def adversarial_2d(rng, DW, DH, DT, nv):

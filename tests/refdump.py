@@ -33,7 +33,17 @@ def read_dump(path):
             loop, npts = np.frombuffer(raw, "<i4", 2, off); off += 8
             tags = np.frombuffer(raw, "<u8", int(npts), off).copy(); off += 8 * int(npts)
             curves.append((int(loop), tags))
-    return dict(nd=int(nd), nv=int(nv), dims=dims, DT=int(DT), factors=factors, records=recs, steps=steps, curves=curves)
+    pp = None
+    if raw[off:off + 4] == b"PPCV":
+        off += 4
+        nc = int(np.frombuffer(raw, "<u8", 1, off)[0]); off += 8
+        pp = []
+        PT = np.dtype([("tag", "<u8"), ("type", "<u4"), ("_pad", "<u4"), ("t", "<f8")])
+        for _ in range(nc):
+            loop, npts = np.frombuffer(raw, "<i4", 2, off); off += 8
+            pts = np.frombuffer(raw, PT, int(npts), off).copy(); off += PT.itemsize * int(npts)
+            pp.append((int(loop), pts))
+    return dict(nd=int(nd), nv=int(nv), dims=dims, DT=int(DT), factors=factors, records=recs, steps=steps, curves=curves, pp=pp)
 
 
 def write_input(path, steps, nd, nv):

@@ -44,6 +44,36 @@ def test_curves_equal_reference(name):
     assert sum(len(c) for c in curves) + nspecial == len(recs)
 
 
+KNOWN_TRAJECTORIES = {  # the reference's own test assertions (tests/test_critical_point_tracking_*.cpp)
+    "woven_31x37x32": 56, "double_gyre_64x32x50": 2, "merger_2d_32x32x100": 9,
+    "moving_extremum_2d_21x21x32": 1, "moving_extremum_3d_21x21x21x32": 1,
+}
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_post_processed_trajectories_equal_reference(name):
+    """trace + post-process == the reference's finalize() + json_interface::post_process() (default options)"""
+    import ftk_amd
+    from ftk_amd import build
+    build.build()
+    g = load_golden(name)
+    ref = g["records"]
+    recs = np.zeros(len(ref), dtype=ftk_amd.CP_DTYPE)
+    for f in ("tag", "type", "x", "t"):
+        recs[f] = ref[f]
+    recs["aux"] = (ref["ordinal"].astype(np.uint32) & 1) | (ref["timestep"].astype(np.uint32) << 1)
+    scalar = g["nv"] == 1
+    lo = 2 if scalar else 1
+    dom = ([lo] * g["nd"], [d - (3 if scalar else 2) for d in g["dims"]])
+    trajs = ftk_amd.trace_and_post_process(g["nd"], dom, recs)
+    assert len(trajs) == len(g["pp"])
+    if name in KNOWN_TRAJECTORIES:
+        assert len(trajs) == KNOWN_TRAJECTORIES[name]
+    got = sorted((tuple(recs["tag"][i].tolist()), tuple(ty.tolist()), tuple(tt.tolist()), lp) for i, ty, tt, lp in trajs)
+    exp = sorted((tuple(tg.tolist()), tuple(ty.tolist()), tuple(tt.tolist()), lp) for lp, tg, ty, tt in g["pp"])
+    assert got == exp
+
+
 def test_duplicate_tags_are_rejected():
     import ftk_amd
     recs = np.zeros(2, dtype=ftk_amd.CP_DTYPE)
