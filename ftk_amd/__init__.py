@@ -8,10 +8,11 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (CP_DTYPE, SCOPE_BOTH, SCOPE_INTERVAL, SCOPE_ORDINAL, SOURCE_DERIVED, SOURCE_GIVEN, SOURCE_NONE,  # noqa: F401
+from ._lib import (CP_DTYPE, FORMAT_BINARY, FORMAT_JSON, FORMAT_TEXT, SCOPE_BOTH, SCOPE_INTERVAL, SCOPE_ORDINAL, SOURCE_DERIVED, SOURCE_GIVEN, SOURCE_NONE,  # noqa: F401
                    TAG_EXACT64, TAG_REFERENCE, TAG_WORK_INDEX, FtkxError, Options, Stats)
 
-__all__ = ["trace_curves", "trace_and_post_process", "Context", "CriticalPointTracker2DRegular", "CriticalPointTracker3DRegular", "extract_cp2dt", "extract_cp3dt",
+__all__ = ["trace_curves", "trace_and_post_process", "post_process", "TrajectorySet", "write_critical_points", "read_critical_points",
+           "write_traced_critical_points", "read_traced_critical_points", "Context", "CriticalPointTracker2DRegular", "CriticalPointTracker3DRegular", "extract_cp2dt", "extract_cp3dt",
            "scaling_factor", "CP_DTYPE", "FtkxError"]
 
 
@@ -199,9 +200,43 @@ def trace_curves(nd, domain, records):
     return [idx[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)], loop, nspecial
 
 
-def trace_and_post_process(nd, domain, records):
-    """ftkx_trace_curves followed by ftkx_post_process_curves (json_interface::post_process defaults).
-    records: CP_DTYPE with element tags and the aux word.  Returns a list of (indices, types, t, loop) per trajectory."""
+class TrajectorySet:
+    """ftkx_trajectories as numpy arrays: curve c owns points offsets[c]:offsets[c+1]; per point the index into the record
+    array, the (smoothed) type and the (adjusted) time; per curve the loop flag and its label in the reference's multimap."""
+
+    def __init__(self, offsets, indices, type, t, loop, id):
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.indices = np.ascontiguousarray(indices, dtype=np.int64)
+        self.type = np.ascontiguousarray(type, dtype=np.uint32)
+        self.t = np.ascontiguousarray(t, dtype=np.float64)
+        self.loop = np.ascontiguousarray(loop, dtype=np.int32)
+        self.id = np.ascontiguousarray(id, dtype=np.int32)
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def curve(self, c):
+        a, b = self.offsets[c], self.offsets[c + 1]
+        return self.indices[a:b], self.type[a:b], self.t[a:b], int(self.loop[c])
+
+    @classmethod
+    def _from_c(cls, out):
+        n, npts = out.n_curves, out.n_points
+        grab = lambda p, k: np.ctypeslib.as_array(p, shape=(max(1, k),))[:k].copy()  # noqa: E731
+        return cls(np.ctypeslib.as_array(out.offsets, shape=(n + 1,)).copy(), grab(out.indices, npts), grab(out.type, npts), grab(out.t, npts),
+                   grab(out.loop, n), grab(out.id, n))
+
+    def _to_c(self):
+        out = _lib.Trajectories()
+        out.n_curves, out.n_points = len(self), len(self.indices)
+        out.offsets = self.offsets.ctypes.data_as(C.POINTER(C.c_longlong)); out.indices = self.indices.ctypes.data_as(C.POINTER(C.c_longlong))
+        out.loop = self.loop.ctypes.data_as(C.POINTER(C.c_int)); out.type = self.type.ctypes.data_as(C.POINTER(C.c_uint))
+        out.t = self.t.ctypes.data_as(C.POINTER(C.c_double)); out.id = self.id.ctypes.data_as(C.POINTER(C.c_int))
+        return out
+
+
+def post_process(nd, domain, records):
+    """ftkx_trace_curves followed by ftkx_post_process_curves (json_interface::post_process defaults) -> TrajectorySet."""
     L = _lib.load()
     recs = np.ascontiguousarray(records, dtype=CP_DTYPE)
     cur = _lib.Curves()
@@ -210,12 +245,71 @@ def trace_and_post_process(nd, domain, records):
     rc = L.ftkx_post_process_curves(recs.ctypes.data, len(recs), C.byref(cur), C.byref(out))
     L.ftkx_free_curves(C.byref(cur))
     _lib.check(rc)
-    n, npts = out.n_curves, max(1, out.n_points)
-    offs = np.ctypeslib.as_array(out.offsets, shape=(n + 1,)).copy()
-    idx = np.ctypeslib.as_array(out.indices, shape=(npts,)).copy(); ty = np.ctypeslib.as_array(out.type, shape=(npts,)).copy()
-    tt = np.ctypeslib.as_array(out.t, shape=(npts,)).copy(); loop = np.ctypeslib.as_array(out.loop, shape=(max(1, n),)).copy()
+    ts = TrajectorySet._from_c(out)
     L.ftkx_free_trajectories(C.byref(out))
-    return [(idx[offs[i]:offs[i + 1]], ty[offs[i]:offs[i + 1]], tt[offs[i]:offs[i + 1]], int(loop[i])) for i in range(n)]
+    return ts
+
+
+def trace_and_post_process(nd, domain, records):
+    """post_process() as a list of (indices, types, t, loop) per trajectory."""
+    ts = post_process(nd, domain, records)
+    return [ts.curve(c) for c in range(len(ts))]
+
+
+def _format(path, format):
+    if format is None:
+        return _lib.load().ftkx_format_from_path(str(path).encode())
+    return {"binary": FORMAT_BINARY, "json": FORMAT_JSON, "text": FORMAT_TEXT}.get(format, format)
+
+
+def _names(scalar_names):
+    if scalar_names is None:
+        return None, -1
+    arr = (C.c_char_p * max(1, len(scalar_names)))(*[s.encode() for s in scalar_names])
+    return arr, len(scalar_names)
+
+
+def write_critical_points(path, records, format=None, v=None, id=None, scalar_names=None):
+    """critical_point_tracker::write_critical_points_{json,binary,text}; format None = by file name (txt / json / else binary)."""
+    recs = np.ascontiguousarray(records, dtype=CP_DTYPE)
+    vv = None if v is None else np.ascontiguousarray(v, dtype=np.float64).reshape(len(recs), 3)
+    ii = None if id is None else np.ascontiguousarray(id, dtype=np.uint64)
+    names, nn = _names(scalar_names)
+    _lib.check(_lib.load().ftkx_write_critical_points(str(path).encode(), _format(path, format), recs.ctypes.data, len(recs),
+                                                      None if vv is None else vv.ctypes.data, None if ii is None else ii.ctypes.data, names, nn))
+
+
+def read_critical_points(path, format=None):
+    """read_critical_points_{json,binary} -> (records[CP_DTYPE] with the aux word, v[n,3], id[n])"""
+    L = _lib.load()
+    r, v, i, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_size_t()
+    _lib.check(L.ftkx_read_critical_points(str(path).encode(), _format(path, format), C.byref(r), C.byref(n), C.byref(v), C.byref(i)))
+    k = n.value
+    recs = np.frombuffer(C.string_at(r.value, k * CP_DTYPE.itemsize), dtype=CP_DTYPE).copy()
+    vv = np.frombuffer(C.string_at(v.value, k * 24), dtype=np.float64).reshape(k, 3).copy()
+    ii = np.frombuffer(C.string_at(i.value, k * 8), dtype=np.uint64).copy()
+    for p in (r, v, i):
+        L.ftkx_free(p)
+    return recs, vv, ii
+
+
+def write_traced_critical_points(path, records, trajectories, format=None, scalar_names=None):
+    """write_traced_critical_points_{json,binary,text} of a TrajectorySet over `records`."""
+    recs = np.ascontiguousarray(records, dtype=CP_DTYPE)
+    tr = trajectories._to_c()
+    names, nn = _names(scalar_names)
+    _lib.check(_lib.load().ftkx_write_traced_critical_points(str(path).encode(), _format(path, format), recs.ctypes.data, len(recs), C.byref(tr), names, nn))
+
+
+def read_traced_critical_points(path, format=None):
+    """read_traced_critical_points_{json,binary} -> (records in file order, TrajectorySet indexing them)"""
+    L = _lib.load()
+    r, n, out = C.c_void_p(), C.c_size_t(), _lib.Trajectories()
+    _lib.check(L.ftkx_read_traced_critical_points(str(path).encode(), _format(path, format), C.byref(r), C.byref(n), C.byref(out)))
+    recs = np.frombuffer(C.string_at(r.value, n.value * CP_DTYPE.itemsize), dtype=CP_DTYPE).copy()
+    ts = TrajectorySet._from_c(out)
+    L.ftkx_free(r); L.ftkx_free_trajectories(C.byref(out))
+    return recs, ts
 
 
 class _TrackerRegular:
@@ -300,6 +394,31 @@ class _TrackerRegular:
         offs = np.zeros(nc.value + 1, dtype=np.int64); tags = np.zeros(max(1, npts.value), dtype=np.uint64); loop = np.zeros(max(1, nc.value), dtype=np.int32)
         self._ck(self._L.ftkx_tracker_get_curves(self._h, offs.ctypes.data, tags.ctypes.data, loop.ctypes.data))
         return [tags[offs[i]:offs[i + 1]] for i in range(nc.value)], loop[:nc.value]
+
+    def post_process(self):
+        """json_interface::post_process with its default options, on the traced curves"""
+        self._ck(self._L.ftkx_tracker_post_process(self._h))
+
+    def get_traced_trajectories(self):
+        """after finalize() [+ post_process()]: list of (tags, types, t, loop, label) per curve"""
+        curves, loop = self.get_traced_critical_points()
+        npts = sum(len(c) for c in curves)
+        ty = np.zeros(max(1, npts), dtype=np.uint32); tt = np.zeros(max(1, npts), dtype=np.float64); ids = np.zeros(max(1, len(curves)), dtype=np.int32)
+        self._ck(self._L.ftkx_tracker_get_curve_points(self._h, ty.ctypes.data, tt.ctypes.data, ids.ctypes.data))
+        out, k = [], 0
+        for i, c in enumerate(curves):
+            out.append((c, ty[k:k + len(c)], tt[k:k + len(c)], int(loop[i]), int(ids[i]))); k += len(c)
+        return out
+
+    def _write(self, path, fmt, traced): self._ck(self._L.ftkx_tracker_write(self._h, str(path).encode(), fmt, traced))
+    def write_critical_points_json(self, path): self._write(path, FORMAT_JSON, 0)
+    def write_critical_points_binary(self, path): self._write(path, FORMAT_BINARY, 0)
+    def write_critical_points_text(self, path): self._write(path, FORMAT_TEXT, 0)
+    def write_traced_critical_points_json(self, path): self._write(path, FORMAT_JSON, 1)
+    def write_traced_critical_points_binary(self, path): self._write(path, FORMAT_BINARY, 1)
+    def write_traced_critical_points_text(self, path): self._write(path, FORMAT_TEXT, 1)
+    def read_critical_points_json(self, path): self._ck(self._L.ftkx_tracker_read_critical_points(self._h, str(path).encode(), FORMAT_JSON))
+    def read_critical_points_binary(self, path): self._ck(self._L.ftkx_tracker_read_critical_points(self._h, str(path).encode(), FORMAT_BINARY))
 
     def get_vector_field_scaling_factor(self):
         f, r = C.c_ulonglong(), C.c_double()

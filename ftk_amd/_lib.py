@@ -15,6 +15,7 @@ assert CP_DTYPE.itemsize == 72
 OK, E_INVALID, E_DEVICE, E_NOMEM, E_NOSLICE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 SCOPE_ORDINAL, SCOPE_INTERVAL, SCOPE_BOTH = 1, 2, 3
 TAG_WORK_INDEX, TAG_REFERENCE, TAG_EXACT64 = 0, 1, 2
+FORMAT_BINARY, FORMAT_JSON, FORMAT_TEXT = 0, 1, 2
 SOURCE_NONE, SOURCE_GIVEN, SOURCE_DERIVED = 0, 1, 2
 
 
@@ -36,7 +37,7 @@ class Curves(C.Structure):
 
 class Trajectories(C.Structure):
     _fields_ = [("n_curves", C.c_size_t), ("n_points", C.c_size_t), ("offsets", C.POINTER(C.c_longlong)), ("indices", C.POINTER(C.c_longlong)),
-                ("loop", C.POINTER(C.c_int)), ("type", C.POINTER(C.c_uint)), ("t", C.POINTER(C.c_double))]
+                ("loop", C.POINTER(C.c_int)), ("type", C.POINTER(C.c_uint)), ("t", C.POINTER(C.c_double)), ("id", C.POINTER(C.c_int))]
 
 
 class FtkxError(RuntimeError):
@@ -49,7 +50,8 @@ EXPORTS = [
     "ftkx_create", "ftkx_destroy", "ftkx_last_error", "ftkx_set_stream", "ftkx_set_options", "ftkx_default_options", "ftkx_set_mesh",
     "ftkx_push_slice", "ftkx_push_scalar_slice", "ftkx_drop_slice", "ftkx_slice_resolution", "ftkx_set_slice_resolution", "ftkx_scaling_factor",
     "ftkx_sweep", "ftkx_sweep_enqueue", "ftkx_sweep_collect", "ftkx_get_stats", "ftkx_invalidate_masks", "ftkx_debug_stream_read", "ftkx_set_profiling", "ftkx_get_kernel_times", "ftkx_extract_cp2dt", "ftkx_extract_cp3dt", "ftkx_free",
-    "ftkx_trace_curves", "ftkx_free_curves", "ftkx_post_process_curves", "ftkx_free_trajectories", "ftkx_gradient2D", "ftkx_jacobian2D", "ftkx_gradient3D", "ftkx_jacobian3D", "ftkx_version", "ftkx_device_count",
+    "ftkx_trace_curves", "ftkx_free_curves", "ftkx_post_process_curves", "ftkx_free_trajectories", "ftkx_format_from_path", "ftkx_write_critical_points", "ftkx_read_critical_points", "ftkx_write_traced_critical_points", "ftkx_read_traced_critical_points", "ftkx_gradient2D", "ftkx_jacobian2D", "ftkx_gradient3D", "ftkx_jacobian3D", "ftkx_version", "ftkx_device_count",
+    "ftkx_tracker_post_process", "ftkx_tracker_get_curve_points", "ftkx_tracker_write", "ftkx_tracker_read_critical_points",
     "ftkx_tracker_create", "ftkx_tracker_destroy", "ftkx_tracker_last_error", "ftkx_tracker_set_domain", "ftkx_tracker_set_array_domain",
     "ftkx_tracker_set_sources", "ftkx_tracker_set_flags", "ftkx_tracker_set_stream", "ftkx_tracker_set_coords_bounds", "ftkx_tracker_initialize",
     "ftkx_tracker_push_scalar_field_snapshot", "ftkx_tracker_push_vector_field_snapshot", "ftkx_tracker_push_field_data_snapshot",
@@ -98,6 +100,11 @@ def load():
     L.ftkx_free_curves.argtypes = [C.POINTER(Curves)]; L.ftkx_free_curves.restype = None
     L.ftkx_post_process_curves.argtypes = [vp, C.c_size_t, C.POINTER(Curves), C.POINTER(Trajectories)]
     L.ftkx_free_trajectories.argtypes = [C.POINTER(Trajectories)]; L.ftkx_free_trajectories.restype = None
+    L.ftkx_format_from_path.argtypes = [C.c_char_p]
+    L.ftkx_write_critical_points.argtypes = [C.c_char_p, C.c_int, vp, C.c_size_t, vp, vp, C.POINTER(C.c_char_p), C.c_int]
+    L.ftkx_read_critical_points.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(vp)]
+    L.ftkx_write_traced_critical_points.argtypes = [C.c_char_p, C.c_int, vp, C.c_size_t, C.POINTER(Trajectories), C.POINTER(C.c_char_p), C.c_int]
+    L.ftkx_read_traced_critical_points.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(Trajectories)]
     L.ftkx_gradient2D.argtypes = [vp, dbl, C.c_int, C.c_int, dbl]
     L.ftkx_jacobian2D.argtypes = [vp, dbl, C.c_int, C.c_int, C.c_int, dbl]
     L.ftkx_gradient3D.argtypes = [vp, dbl, C.c_int, C.c_int, C.c_int, dbl]
@@ -125,6 +132,10 @@ def load():
     L.ftkx_tracker_finalize.argtypes = [vp]
     L.ftkx_tracker_num_curves.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.ftkx_tracker_get_curves.argtypes = [vp, vp, vp, vp]
+    L.ftkx_tracker_post_process.argtypes = [vp]
+    L.ftkx_tracker_get_curve_points.argtypes = [vp, vp, vp, vp]
+    L.ftkx_tracker_write.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    L.ftkx_tracker_read_critical_points.argtypes = [vp, C.c_char_p, C.c_int]
     _L = L
     return L
 

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "sweep_params.hpp"
+#include "internal.hpp"
 
 namespace ftkx {
 void launch_tile(const TileParams &p, hipStream_t stream);
@@ -99,6 +100,8 @@ struct ftkx_ctx {
   unsigned long long k_launches[K_N] = {0, 0, 0, 0};
   std::string err;
 };
+
+namespace ftkx { void set_global_error(const char *msg) { g_last_error = msg ? msg : ""; } }
 
 namespace {
 

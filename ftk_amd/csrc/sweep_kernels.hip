@@ -647,6 +647,19 @@ __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const Ma
     b = xcd * per + (xcd < rem ? xcd : rem) + k;
     bx = b % gridDim.x; by = (b / gridDim.x) % gridDim.y; bz = b / (gridDim.x * gridDim.y);
   }
+  if (swizzle & 8) {
+    // grouped placement: the hardware deals workgroups round-robin to the 8 XCDs, so workgroup ids b, b+8, b+16, ... share an
+    // L2.  Give each XCD, at any moment, one group of G = gridDim.x * YG neighbouring tiles (all x tiles of YG row groups): the x
+    // edge columns and y halo rows a tile needs from its neighbours are then L2 hits, while the 8 XCDs still work side by side
+    // in memory.  Groups are contiguous in the linear tile order, so the tail that does not fill 8 groups keeps the identity.
+    const unsigned YG = ((unsigned)swizzle >> 8) & 0xffu;
+    const unsigned nb = gridDim.x * gridDim.y * gridDim.z, G = gridDim.x * YG;
+    const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (b < (nb / (8u * G)) * (8u * G)) {
+      const unsigned q = b % 8u, r = b / 8u, grp = (r / G) * 8u + q, in = r % G, ngy = gridDim.y / YG;
+      bx = in % gridDim.x; by = (grp % ngy) * YG + in / gridDim.x; bz = grp / ngy;
+    }
+  }
   const bool debug_no_store = (swizzle & 2) != 0;   // profiling experiment only (FTKX_MASK_SWIZZLE=3): results are then garbage
   const MaskJob job = jobs[bz / nzc];
   const int z0 = (ND == 3) ? (int)(bz % nzc) * zchunk : 0;
@@ -686,14 +699,18 @@ __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const Ma
     }
   }
   const unsigned cb = (unsigned)ic * 8u;
-  const bool use_nt = (swizzle & 4) != 0;
-  auto ld2 = [&](unsigned off) -> double2 {
+  // swizzle bit 4: every load nontemporal; bit 16: only the rows no other wavefront reads (r = 2 .. RY-1 of 0 .. RY+1; rows 0, 1,
+  // RY, RY+1 are halo rows here or in the neighbouring wavefront and should stay cached for it)
+  const bool nt_all = (swizzle & 4) != 0, nt_private = (swizzle & 16) != 0;
+  auto ld2r = [&](unsigned off, bool nt) -> double2 {
     const double2 *q = reinterpret_cast<const double2 *>(Sb + off);
     double2 v;
-    if (use_nt) { v.x = __builtin_nontemporal_load(&q->x); v.y = __builtin_nontemporal_load(&q->y); } else v = *q;
+    if (nt) { v.x = __builtin_nontemporal_load(&q->x); v.y = __builtin_nontemporal_load(&q->y); } else v = *q;
     if (ND == 2) { if (dup_lo) v.y = v.x; if (dup_hi) v.x = v.y; }
     return v;
   };
+  auto ld2 = [&](unsigned off) -> double2 { return ld2r(off, nt_all); };
+  auto row_nt = [&](int r) -> bool { return nt_all || (nt_private && r >= 2 && r <= RY - 1); };
   auto zoff = [&](int k) -> unsigned { return sz * (unsigned)clampi(k, 0, DD - 1); };
 
   auto ld1 = [&](unsigned off) -> double { return *reinterpret_cast<const double *>(Sb + off); };
@@ -702,7 +719,7 @@ __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const Ma
   for (int r = 0; r < (EDGE ? RY : 1); r ++) { ex[r] = 0.0; exn[r] = 0.0; }
   {
     const unsigned zo = zoff(z0), zp = zoff(z0 - 1), zn = zoff(z0 + 1);
-    for (int r = 0; r < RY + 2; r ++) { cur[r] = ld2(cb + roff[r] + zo); nxt[r] = (ND == 3) ? ld2(cb + roff[r] + zn) : cur[r]; }
+    for (int r = 0; r < RY + 2; r ++) { cur[r] = ld2r(cb + roff[r] + zo, row_nt(r)); nxt[r] = (ND == 3) ? ld2r(cb + roff[r] + zn, row_nt(r)) : cur[r]; }
     for (int r = 0; r < RY; r ++) prv[r] = (ND == 3) ? ld2(cb + roff[r + 1] + zp) : cur[r + 1];
     if (edge) for (int r = 0; r < RY; r ++) { ex[r] = ld1(hb + roff[r + 1] + zo); exn[r] = (ND == 3) ? ld1(hb + roff[r + 1] + zn) : 0.0; }
   }
@@ -725,7 +742,7 @@ __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const Ma
     double exnn[EDGE ? RY : 1];
     if (ND == 3 && k + 2 <= z1) {                             // plane z1 is still needed (d/dz of the chunk's last plane), z1 + 1 is not
       const unsigned z2 = zoff(k + 2);
-      for (int r = 0; r < RY + 2; r ++) nn[r] = ld2(cb + roff[r] + z2);
+      for (int r = 0; r < RY + 2; r ++) nn[r] = ld2r(cb + roff[r] + z2, row_nt(r));
       if (edge) for (int r = 0; r < RY; r ++) exnn[r] = ld1(hb + roff[r + 1] + z2);
     }
     const bool z_dom = ND == 2 || (k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2]);
@@ -793,6 +810,246 @@ __global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const Ma
     // non-negative doubles order like their bit patterns
     // 64 result slots (the host folds them): all wavefronts hammering one address would serialise at the memory side
     const unsigned slot = (blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + wv) & 63u;
+    if (lane == 0) { atomicMin(&job.red[2 * slot], (u64)__double_as_longlong(red_mn)); atomicMax(&job.red[2 * slot + 1], (u64)__double_as_longlong(red_mx)); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same walk as mask_march2_kernel<ND, EDGE = true, REDUCE> on a VALU diet.  rocprofv3 showed the kernel above issue-bound
+// (VALUBusy 72 %, 2.96e9 VALU instructions per 512^3 x 32 launch) rather than HBM-bound, so this version removes instructions
+// that do no arithmetic for the result:
+//   * the four plane buffers rotate by NAME (the z loop is unrolled four times) instead of being copied every plane;
+//   * row addresses are wave-uniform (SGPR base, readfirstlane'd wavefront id) + one constant per-lane byte offset, loaded
+//     and stored through global (not flat) address space: no 64-bit VALU address arithmetic;
+//   * 3D: 0.5 * (a - b) >= thr is tested as (a - b) >= 2 thr -- exact, scaling by a power of two -- so the multiply goes;
+//   * lanes 0 / 63 take the outside neighbour through the DPP shift's `old` operand (an invalid source lane keeps `old`)
+//     instead of two selects per value;
+//   * the 6 sign bits of a vertex are shifted into an accumulator by add-with-carry straight from the compare masks.
+// Same mask / summary bytes as the kernel above (tests/test_gpu_properties.py compares the two).
+// ---------------------------------------------------------------------------------------------------------------
+typedef double v2d __attribute__((ext_vector_type(2)));
+#define FTKX_GLOBAL __attribute__((address_space(1)))
+
+__device__ inline double dpp_lower_or(double v, double edge)   // lane n <- lane n-1; lane 0 <- its own `edge`
+{
+  const long long b = __double_as_longlong(v), e = __double_as_longlong(edge);
+  const int lo = __builtin_amdgcn_update_dpp((int)e, (int)b, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(e >> 32), (int)(b >> 32), 0x138, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ inline double dpp_upper_or(double v, double edge)   // lane n <- lane n+1; lane 63 <- its own `edge`
+{
+  const long long b = __double_as_longlong(v), e = __double_as_longlong(edge);
+  const int lo = __builtin_amdgcn_update_dpp((int)e, (int)b, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(e >> 32), (int)(b >> 32), 0x130, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__device__ inline void remap_block(int swizzle, unsigned &bx, unsigned &by, unsigned &bz)
+{
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+  if (swizzle & 1) {
+    const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
+    unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned per = nb / 8, rem = nb % 8, xcd = b % 8, k = b / 8;
+    b = xcd * per + (xcd < rem ? xcd : rem) + k;
+    bx = b % gridDim.x; by = (b / gridDim.x) % gridDim.y; bz = b / (gridDim.x * gridDim.y);
+  }
+  if (swizzle & 8) {   // grouped placement, see mask_march2_kernel
+    const unsigned YG = ((unsigned)swizzle >> 8) & 0xffu;
+    const unsigned nb = gridDim.x * gridDim.y * gridDim.z, G = gridDim.x * YG;
+    const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (b < (nb / (8u * G)) * (8u * G)) {
+      const unsigned q = b % 8u, r = b / 8u, grp = (r / G) * 8u + q, in = r % G, ngy = gridDim.y / YG;
+      bx = in % gridDim.x; by = (grp % ngy) * YG + in / gridDim.x; bz = grp / ngy;
+    }
+  }
+}
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+// Shifts the sign bits of one row's vertex pair into two accumulators, most significant first:
+//   a = [neg_z neg_y neg_x pos_z pos_y pos_x]   (2D: [neg_y neg_x pos_y pos_x], spread by the caller)
+// one compare + one add-with-carry (a = a + a + carry) per bit.  gfx950 needs two wait states between a VALU writing an
+// SGPR and a VALU reading it; the compares run three ahead of the adds, so no s_nop is needed.
+template <int ND>
+__device__ inline void shift_in_signs(unsigned &a0, unsigned &a1, double dx0, double dx1, double dy0, double dy1, double dz0, double dz1, double tn, double tp)
+{
+  unsigned long long m0, m1, m2;
+  if constexpr (ND == 3)
+    asm("v_cmp_le_f64_e64 %[m0], %[dz0], %[tn]\n\tv_cmp_le_f64_e64 %[m1], %[dz1], %[tn]\n\tv_cmp_le_f64_e64 %[m2], %[dy0], %[tn]\n\t"
+        "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m0]\n\tv_cmp_le_f64_e64 %[m0], %[dy1], %[tn]\n\t"
+        "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m1]\n\tv_cmp_le_f64_e64 %[m1], %[dx0], %[tn]\n\t"
+        "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m2]\n\tv_cmp_le_f64_e64 %[m2], %[dx1], %[tn]\n\t"
+        "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m0]\n\tv_cmp_ge_f64_e64 %[m0], %[dz0], %[tp]\n\t"
+        "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m1]\n\tv_cmp_ge_f64_e64 %[m1], %[dz1], %[tp]\n\t"
+        "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m2]\n\tv_cmp_ge_f64_e64 %[m2], %[dy0], %[tp]\n\t"
+        "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m0]\n\tv_cmp_ge_f64_e64 %[m0], %[dy1], %[tp]\n\t"
+        "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m1]\n\tv_cmp_ge_f64_e64 %[m1], %[dx0], %[tp]\n\t"
+        "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m2]\n\tv_cmp_ge_f64_e64 %[m2], %[dx1], %[tp]\n\t"
+        "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m0]\n\tv_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m1]\n\t"
+        "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m2]"
+        : [a0] "+v"(a0), [a1] "+v"(a1), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2)
+        : [dx0] "v"(dx0), [dx1] "v"(dx1), [dy0] "v"(dy0), [dy1] "v"(dy1), [dz0] "v"(dz0), [dz1] "v"(dz1), [tn] "s"(tn), [tp] "s"(tp)
+        : "vcc");
+  else
+    asm("v_cmp_le_f64_e64 %[m0], %[dy0], %[tn]\n\tv_cmp_le_f64_e64 %[m1], %[dy1], %[tn]\n\tv_cmp_le_f64_e64 %[m2], %[dx0], %[tn]\n\t"
+        "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m0]\n\tv_cmp_le_f64_e64 %[m0], %[dx1], %[tn]\n\t"
+        "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m1]\n\tv_cmp_ge_f64_e64 %[m1], %[dy0], %[tp]\n\t"
+        "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m2]\n\tv_cmp_ge_f64_e64 %[m2], %[dy1], %[tp]\n\t"
+        "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m0]\n\tv_cmp_ge_f64_e64 %[m0], %[dx0], %[tp]\n\t"
+        "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m1]\n\tv_cmp_ge_f64_e64 %[m1], %[dx1], %[tp]\n\t"
+        "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m2]\n\tv_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m0]\n\t"
+        "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m1]"
+        : [a0] "+v"(a0), [a1] "+v"(a1), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2)
+        : [dx0] "v"(dx0), [dx1] "v"(dx1), [dy0] "v"(dy0), [dy1] "v"(dy1), [tn] "s"(tn), [tp] "s"(tp)
+        : "vcc");
+}
+
+// PD = prefetch distance: at the step for plane k the loads of plane k + 1 + PD are issued (PD = 1: three planes of registers
+// plus one in flight; every further plane costs (RY + 2) * 4 + RY * 2 VGPRs and one wavefront of occupancy at PD = 2)
+template <int ND, bool REDUCE, int PD>
+__global__ __launch_bounds__(PD == 1 ? 768 : 512) void mask_march4_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
+{
+  constexpr int RY = (ND == 3) ? 4 : 8;
+  constexpr int NB = 3 + PD;                                   // plane buffers: k-1, k, k+1, and PD planes on their way
+  const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
+  const int nzc = (ND == 3) ? (DD + zchunk - 1) / zchunk : 1;
+  unsigned bx, by, bz;
+  remap_block(swizzle, bx, by, bz);
+  const MaskJob job = jobs[bz / nzc];
+  const int z0 = (ND == 3) ? (int)(bz % nzc) * zchunk : 0;
+  const int z1 = (ND == 3) ? (z0 + zchunk < DD ? z0 + zchunk : DD) : 1;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform by construction; tell the compiler
+  const int wpb = blockDim.x >> 6;
+  const int i0 = (int)bx * 128 + 2 * lane;                     // this lane's columns i0, i0 + 1
+  const int j0 = ((int)by * wpb + wv) * RY;
+  if (j0 >= DH) return;
+  // Buffer resources: address = wave-uniform SGPR offset + one constant per-lane VGPR offset, no VALU address arithmetic.
+  // (march2_supported guarantees slices below 4 GiB; the mask and summary arrays are smaller still.)
+  const unsigned sy = (unsigned)DW * 8u, sz = (unsigned)DW * (unsigned)DH * 8u;   // byte strides
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void *)job.S, 0, (int)(sz * (unsigned)DD), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)job.M, 0, (int)((unsigned)P * (unsigned)DH * (unsigned)DD), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)job.U, 0, (int)((unsigned)m.u_pitch * (unsigned)DH * (unsigned)DD), 0x00020000);
+  const bool have_u = job.U != nullptr;
+  const double thr = job.threshold;
+  // what the raw central difference (a - b) is compared with: 3D g = 0.5 (a - b); 2D g = (a - b) (D - 1) keeps its multiply
+  const double tpos = (ND == 3) ? 2.0 * thr : thr, tneg = -tpos;
+
+  const int ic = i0 < DW ? i0 : DW - 2;                        // clamped (even) column pair: lanes beyond the row load valid memory
+  const bool edge = lane == 0 || lane == 63;
+  const int ih = lane == 0 ? (ic > 0 ? ic - 1 : 0) : (ic + 2 < DW ? ic + 2 : DW - 1);   // outside neighbour column (clamped)
+  const unsigned cb = (unsigned)ic * 8u, hb = (unsigned)ih * 8u;   // the only per-lane parts of a load address
+  unsigned xkeep = 0, xneutral = 0;                            // per column: byte c of the pair
+  for (int c = 0; c < 2; c ++) {
+    const int i = i0 + c;
+    const bool x_dom = i < DW && i + m.ext_st[0] >= m.dom_lb[0] && i + m.ext_st[0] <= m.dom_ub[0];
+    const bool x_int = (ND == 2) || (i >= 1 && i < DW - 1);
+    if (x_int) xkeep |= 0x3fu << (8 * c);
+    if (!x_dom) xneutral |= 0x3fu << (8 * c);
+  }
+  unsigned roff[RY + 2];                                       // wave-uniform row offsets, rows -1 .. RY (clamped)
+  unsigned row_dom = 0, row_int = 0, row_ok = 0;
+  for (int r = 0; r < RY + 2; r ++) {
+    const int j = j0 + r - 1;
+    roff[r] = sy * (unsigned)clampi(j, 0, DH - 1);
+    if (r >= 1 && r <= RY) {
+      if (j < DH) row_ok |= 1u << (r - 1);
+      if (j + m.ext_st[1] >= m.dom_lb[1] && j + m.ext_st[1] <= m.dom_ub[1]) row_dom |= 1u << (r - 1);
+      if (j >= 1 && j < DH - 1) row_int |= 1u << (r - 1);
+    }
+  }
+  const int nt_mode = (swizzle & 4) ? 1 : ((swizzle & 16) ? 2 : 0);   // 1: all loads nontemporal, 2: only rows no other wavefront reads
+  auto load_plane = [&](v2d (&B)[RY + 2], double (&X)[RY], int k) {
+    const unsigned zo = sz * (unsigned)clampi(k, 0, DD - 1);
+    for (int r = 0; r < RY + 2; r ++) {
+      const bool nt = nt_mode == 1 || (nt_mode == 2 && r >= 2 && r <= RY - 1);
+      const v4u raw = nt ? __builtin_amdgcn_raw_buffer_load_b128(rS, cb, zo + roff[r], 2) : __builtin_amdgcn_raw_buffer_load_b128(rS, cb, zo + roff[r], 0);
+      B[r] = __builtin_bit_cast(v2d, raw);
+    }
+    if (edge) for (int r = 0; r < RY; r ++) X[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rS, hb, zo + roff[r + 1], 0));
+  };
+
+  const bool in_row = i0 < DW;
+  const bool debug_no_store = (swizzle & 2) != 0 && bits_dummy_guard(thr);   // profiling experiment only: results are then garbage
+  const bool store_ok = in_row && !debug_no_store;
+  const unsigned mcol = (unsigned)i0, ucol = (unsigned)(i0 >> 3);
+  const bool u_lane = (lane & 3) == 0 && in_row;
+  double red_mn = DBL_MAX, red_mx = 0.0;
+  auto red_take = [&](double g) {
+    const double a = fabs(g);
+    red_mn = fmin(red_mn, a == 0.0 ? DBL_MAX : a);
+    red_mx = fmax(red_mx, a < HUGE_VAL ? a : 0.0);
+  };
+
+  // one plane: prefetch plane k + 1 + PD into NN / XNN, classify plane k from (PR = k-1, CU = k, NX = k+1) and CU's edge values XC
+  auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], const v2d (&NX)[RY + 2], v2d (&NN)[RY + 2],
+                  const double (&XC)[RY], double (&XNN)[RY], int k) {
+    if (ND == 3 && k + 1 + PD <= z1) load_plane(NN, XNN, k + 1 + PD);   // plane z1 is still needed (d/dz of the chunk's last plane), z1 + 1 is not
+    const bool z_dom = ND == 2 || (k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2]);
+    const bool z_int = ND == 2 || (k >= 1 && k < DD - 1);
+    const unsigned mplane = (unsigned)P * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
+    const unsigned uplane = (unsigned)m.u_pitch * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
+    for (int r = 0; r < RY; r ++) {
+      const v2d c = CU[r + 1];
+      double xm = dpp_lower_or(c.y, XC[r]);                    // left neighbour of column i0
+      double xp = dpp_upper_or(c.x, XC[r]);                    // right neighbour of column i0 + 1
+      if (ND == 2 && i0 + 1 == DW - 1) xp = c.y;              // 2D clamp: the right neighbour of the last column is itself
+      double dx0 = c.y - xm, dx1 = xp - c.x;
+      double dy0 = CU[r + 2].x - CU[r].x, dy1 = CU[r + 2].y - CU[r].y;
+      double dz0 = 0.0, dz1 = 0.0;
+      if constexpr (ND == 3) { dz0 = NX[r + 1].x - PR[r + 1].x; dz1 = NX[r + 1].y - PR[r + 1].y; }
+      else { const double fx = (double)(DW - 1), fy = (double)(DH - 1); dx0 *= fx; dx1 *= fx; dy0 *= fy; dy1 *= fy; }
+      const bool u_int = ND == 2 || (((row_int >> r) & 1) && z_int), u_dom = ((row_dom >> r) & 1) && z_dom;
+      if constexpr (REDUCE) {
+        if (u_int && ((row_ok >> r) & 1) && store_ok) {
+          const double h = (ND == 3) ? 0.5 : 1.0;
+          if (xkeep & 0x3fu) { red_take(h * dx0); red_take(h * dy0); if (ND == 3) red_take(h * dz0); }
+          if (xkeep & 0x3f00u) { red_take(h * dx1); red_take(h * dy1); if (ND == 3) red_take(h * dz1); }
+        }
+        continue;
+      }
+      unsigned a0 = 0, a1 = 0;
+      shift_in_signs<ND>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, tneg, tpos);
+      if (ND == 2) { a0 = ((a0 & 0xcu) << 1) | (a0 & 3u); a1 = ((a1 & 0xcu) << 1) | (a1 & 3u); }   // leave the two z bits empty
+      unsigned bits = a0 | (a1 << 8);
+      // wave-uniform row / plane conditions, per-lane column conditions
+      const unsigned keep = u_int ? xkeep : 0u;                // gradient3D leaves the array border at 0
+      const unsigned neut = u_dom ? xneutral : 0x3f3fu;        // outside the domain / row padding: never blocks a cull
+      bits = (bits & keep) | neut;
+      bool word_uniform = false;
+      const bool rok = (row_ok >> r) & 1;
+      // summary byte of the aligned 8-vertex word this quad of lanes covers: the sign bits ALL eight vertices share
+      if (have_u) {
+        int q = (int)((bits & (bits >> 8)) & 0x3fu);
+        q &= __builtin_amdgcn_update_dpp(q, q, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+        q &= __builtin_amdgcn_update_dpp(q, q, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
+        if (rok && u_lane) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)q, rU, ucol, uplane + (unsigned)m.u_pitch * (unsigned)r, 0);
+        word_uniform = q != 0;                                 // then the refine kernel substitutes the summary: mask bytes not needed
+      }
+      if (rok && store_ok && !word_uniform)
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rM, mcol, mplane + (unsigned)P * (unsigned)r, 0);
+    }
+  };
+
+  // the plane buffers rotate by NAME: the z loop is unrolled NB times, every index below is a compile-time constant
+  v2d B[NB][RY + 2];
+  double X[NB][RY];
+  for (int b = 0; b < NB; b ++) for (int r = 0; r < RY; r ++) X[b][r] = 0.0;
+  load_plane(B[0], X[0], z0 - 1);
+  load_plane(B[1], X[1], z0);
+  if (ND == 3) { for (int b = 2; b < 2 + PD; b ++) if (z0 + b - 1 <= z1) load_plane(B[b], X[b], z0 + b - 1); }
+  else for (int b = 2; b < NB; b ++) for (int r = 0; r < RY + 2; r ++) B[b][r] = B[1][r];
+  for (int k = z0; k < z1; k += NB) {
+#pragma unroll
+    for (int i = 0; i < NB; i ++)
+      if (k + i < z1) step(B[i], B[(i + 1) % NB], B[(i + 2) % NB], B[(i + 2 + PD) % NB], X[(i + 1) % NB], X[(i + 2 + PD) % NB], k + i);
+  }
+  if constexpr (REDUCE) {
+    for (int o = 32; o > 0; o >>= 1) { red_mn = fmin(red_mn, __shfl_down(red_mn, o)); red_mx = fmax(red_mx, __shfl_down(red_mx, o)); }
+    const unsigned slot = (blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + (unsigned)wv) & 63u;
     if (lane == 0) { atomicMin(&job.red[2 * slot], (u64)__double_as_longlong(red_mn)); atomicMax(&job.red[2 * slot + 1], (u64)__double_as_longlong(red_mx)); }
   }
 }
@@ -1245,7 +1502,27 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       int wpb = 4;
       if (const char *e = getenv("FTKX_MASK_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 12) wpb = v; }
       const dim3 grid2((unsigned)(use_edge ? tiles_edge : tiles_halo), (unsigned)((m.ext_sz[1] + wpb * RY - 1) / (wpb * RY)), (unsigned)(nzc * njobs));
+      if (swizzle & 8) {   // grouped placement: YG row groups per group (must divide the grid's y extent)
+        int yg = 1;
+        if (const char *e = getenv("FTKX_MASK_YG")) yg = atoi(e) > 0 ? atoi(e) : 1;
+        while (yg > 1 && grid2.y % (unsigned)yg) yg --;
+        swizzle = (swizzle & 0xff) | (yg << 8);
+      }
       const dim3 blk((unsigned)(64 * wpb));
+      bool diet = use_edge;                                   // the VALU-diet kernel implements the 128-column layout only
+      if (const char *e = getenv("FTKX_MASK_V")) diet = diet && atoi(e) != 2;
+      if (diet) {
+        int pd = 1;
+        if (const char *e = getenv("FTKX_MASK_PD")) pd = atoi(e);
+#define FTKX_M4(ND_, R_, PD_) hipLaunchKernelGGL((mask_march4_kernel<ND_, R_, PD_>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle)
+        if (reduce) { if (m.nd == 2) FTKX_M4(2, true, 1); else FTKX_M4(3, true, 1); }
+        else if (m.nd == 2) FTKX_M4(2, false, 1);
+        else if (pd == 2) FTKX_M4(3, false, 2);
+        else if (pd == 3) FTKX_M4(3, false, 3);
+        else FTKX_M4(3, false, 1);
+#undef FTKX_M4
+        return;
+      }
 #define FTKX_M2(ND_, E_, R_) hipLaunchKernelGGL((mask_march2_kernel<ND_, E_, R_>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle)
       if (reduce) { if (m.nd == 2) { if (use_edge) FTKX_M2(2, true, true); else FTKX_M2(2, false, true); }
                     else { if (use_edge) FTKX_M2(3, true, true); else FTKX_M2(3, false, true); } }

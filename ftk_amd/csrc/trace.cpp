@@ -289,10 +289,11 @@ int ftkx_post_process_curves(const ftkx_cp_t *recs, size_t n, const ftkx_curves 
   if (!out || !in || (n && !recs)) return FTKX_E_INVALID;
   memset(out, 0, sizeof(*out));
   struct Pt { long long idx; unsigned type; double t; int ordinal, timestep; };
-  struct Curve { std::vector<Pt> p; int loop; };
+  struct Curve { std::vector<Pt> p; int loop; int id; };
   std::vector<Curve> curves(in->n_curves);
   for (size_t c = 0; c < in->n_curves; c ++) {
     curves[c].loop = in->loop[c];
+    curves[c].id = (int)c;                       // feature_curve_set_t::add numbers traced curves 0, 1, 2, ... (feature_curve_set.hh:458-465)
     for (long long k = in->offsets[c]; k < in->offsets[c + 1]; k ++) {
       const long long i = in->indices[k];
       if (i < 0 || (size_t)i >= n) return FTKX_E_INVALID;
@@ -352,7 +353,7 @@ int ftkx_post_process_curves(const ftkx_cp_t *recs, size_t n, const ftkx_curves 
     unsigned consistent = cv.p[0].type;
     for (const Pt &q : cv.p) if (q.type != consistent) { consistent = 0; break; }
     if (consistent != 0) { result.push_back(cv); continue; }
-    Curve sub; sub.loop = 0;
+    Curve sub; sub.loop = 0; sub.id = cv.id;   // split_all re-adds the pieces under their parent's label (feature_curve_set.hh:530-531)
     unsigned current = 0;
     for (size_t i = 0; i < cv.p.size(); i ++) {
       if (sub.p.empty()) current = cv.p[i].type;
@@ -382,13 +383,15 @@ int ftkx_post_process_curves(const ftkx_cp_t *recs, size_t n, const ftkx_curves 
   out->loop = (int *)malloc((result.size() ? result.size() : 1) * sizeof(int));
   out->type = (unsigned *)malloc((np ? np : 1) * sizeof(unsigned));
   out->t = (double *)malloc((np ? np : 1) * sizeof(double));
-  if (!out->offsets || !out->indices || !out->loop || !out->type || !out->t) return FTKX_E_NOMEM;
+  out->id = (int *)malloc((result.size() ? result.size() : 1) * sizeof(int));
+  if (!out->offsets || !out->indices || !out->loop || !out->type || !out->t || !out->id) return FTKX_E_NOMEM;
   size_t k = 0;
   out->offsets[0] = 0;
   for (size_t c = 0; c < result.size(); c ++) {
     for (const Pt &q : result[c].p) { out->indices[k] = q.idx; out->type[k] = q.type; out->t[k] = q.t; k ++; }
     out->offsets[c + 1] = (long long)k;
     out->loop[c] = result[c].loop;
+    out->id[c] = result[c].id;
   }
   return FTKX_OK;
 }
@@ -396,7 +399,7 @@ int ftkx_post_process_curves(const ftkx_cp_t *recs, size_t n, const ftkx_curves 
 void ftkx_free_trajectories(ftkx_trajectories *c)
 {
   if (!c) return;
-  free(c->offsets); free(c->indices); free(c->loop); free(c->type); free(c->t);
+  free(c->offsets); free(c->indices); free(c->loop); free(c->type); free(c->t); free(c->id);
   memset(c, 0, sizeof(*c));
 }
 

@@ -55,6 +55,13 @@ void critical_point_tracker_regular::initialize()
   o.coords_mode = mode_phys_coords;
   for (size_t i = 0; i < 6 && i < bounds_coords.size(); i ++) o.coords_bounds[i] = bounds_coords[i];
   check(ftkx_set_options(ctx, &o));
+  // the discrete points are kept in the reference's element order, which needs the mesh sizes
+  element_order ord;
+  ord.nd = nd;
+  for (int d = 0; d < nd; d ++) ord.n[d] = domain.size(d);
+  discrete_map_t ordered(ord);
+  for (const auto &kv : discrete_critical_points) ordered.insert(kv);
+  discrete_critical_points.swap(ordered);
   initialized = true;
 }
 
@@ -170,15 +177,133 @@ void critical_point_tracker_regular::finalize()
   ftkx_curves c;
   const int rc = ftkx_trace_curves(nd, dst, dsz, recs.data(), recs.size(), &c);
   if (rc != FTKX_OK) { ftkx_free_curves(&c); throw ftkx_error(rc, "finalize: ftkx_trace_curves failed (tags must not have overflowed int32: use FTKX_TAG_EXACT64 on very large meshes)"); }
-  traced_critical_points.clear(); traced_loop.clear();
+  traced_critical_points.clear(); traced_loop.clear(); traced_id.clear();
   for (size_t i = 0; i < c.n_curves; i ++) {
     std::vector<feature_point_t> curve;
     for (long long k = c.offsets[i]; k < c.offsets[i + 1]; k ++) curve.push_back(*pts[c.indices[k]]);
     traced_critical_points.push_back(std::move(curve));
     traced_loop.push_back(c.loop[i]);
+    traced_id.push_back((int)i);
   }
   ftkx_free_curves(&c);
 }
+
+namespace {
+ftkx_cp_t record_of(const feature_point_t &cp)
+{
+  ftkx_cp_t r;
+  std::memset(&r, 0, sizeof(r));
+  for (int k = 0; k < 3; k ++) { r.x[k] = cp.x[k]; r.scalar[k] = cp.scalar[k]; }
+  r.t = cp.t; r.type = cp.type; r.tag = cp.tag;
+  reinterpret_cast<unsigned int *>(&r)[15] = ((unsigned)cp.timestep << 1) | (cp.ordinal ? 1u : 0u);
+  return r;
+}
+feature_point_t point_of(const ftkx_cp_t &r)
+{
+  feature_point_t cp;
+  for (int k = 0; k < 3; k ++) { cp.x[k] = r.x[k]; cp.scalar[k] = r.scalar[k]; }
+  cp.t = r.t; cp.type = r.type; cp.tag = r.tag;
+  cp.ordinal = ftkx_cp_ordinal(&r) != 0; cp.timestep = ftkx_cp_timestep(&r);
+  return cp;
+}
+struct flat_curves {   // traced curves as one record array + offsets (points in curve order)
+  std::vector<ftkx_cp_t> recs;
+  std::vector<long long> offsets, indices;
+  flat_curves(const std::vector<std::vector<feature_point_t>> &curves)
+  {
+    offsets.push_back(0);
+    for (const auto &c : curves) {
+      for (const auto &p : c) { indices.push_back((long long)recs.size()); recs.push_back(record_of(p)); }
+      offsets.push_back((long long)recs.size());
+    }
+  }
+};
+std::string io_error()
+{
+  char msg[512] = {0};
+  ftkx_last_error(nullptr, msg, sizeof msg);
+  return msg;
+}
+}  // namespace
+
+// json_interface::post_process (filters/json_interface.hh:758-800) with the options it defaults to
+void critical_point_tracker_regular::post_process()
+{
+  flat_curves f(traced_critical_points);
+  ftkx_curves in;
+  std::memset(&in, 0, sizeof(in));
+  in.n_curves = traced_critical_points.size(); in.n_points = f.recs.size();
+  in.offsets = f.offsets.data(); in.indices = f.indices.data(); in.loop = traced_loop.data();
+  ftkx_trajectories out;
+  const int rc = ftkx_post_process_curves(f.recs.data(), f.recs.size(), &in, &out);
+  if (rc != FTKX_OK) { ftkx_free_trajectories(&out); throw ftkx_error(rc, "post_process failed"); }
+  std::vector<std::vector<feature_point_t>> curves(out.n_curves);
+  std::vector<int> loop(out.n_curves), ids(out.n_curves);
+  for (size_t c = 0; c < out.n_curves; c ++) {
+    // a split piece keeps its parent's label; labels of traced curves are their own (possibly already post-processed) ids
+    loop[c] = out.loop[c]; ids[c] = traced_id[out.id[c]];
+    for (long long k = out.offsets[c]; k < out.offsets[c + 1]; k ++) {
+      feature_point_t p = point_of(f.recs[out.indices[k]]);
+      p.type = out.type[k]; p.t = out.t[k];
+      curves[c].push_back(p);
+    }
+  }
+  ftkx_free_trajectories(&out);
+  traced_critical_points.swap(curves); traced_loop.swap(loop); traced_id.swap(ids);
+}
+
+void critical_point_tracker_regular::write_discrete(const std::string &filename, int format) const
+{
+  std::vector<ftkx_cp_t> recs;
+  recs.reserve(discrete_critical_points.size());
+  for (const auto &kv : discrete_critical_points) recs.push_back(record_of(kv.second));
+  // text labels: the reference's scalar_components default to {"scalar"} whether or not a scalar field exists
+  const int rc = ftkx_write_critical_points(filename.c_str(), format, recs.data(), recs.size(), nullptr, nullptr, nullptr, -1);
+  if (rc != FTKX_OK) throw ftkx_error(rc, io_error());
+}
+void critical_point_tracker_regular::write_critical_points_json(const std::string &f) const { write_discrete(f, FTKX_FORMAT_JSON); }
+void critical_point_tracker_regular::write_critical_points_binary(const std::string &f) const { write_discrete(f, FTKX_FORMAT_BINARY); }
+void critical_point_tracker_regular::write_critical_points_text(const std::string &f) const { write_discrete(f, FTKX_FORMAT_TEXT); }
+
+// critical_point_tracker_regular::put_critical_points (critical_point_tracker_regular.hh:40-46): tags are trusted as keys
+void critical_point_tracker_regular::put_critical_points(const std::vector<feature_point_t> &cps)
+{
+  for (const auto &cp : cps) discrete_critical_points[cp.tag] = cp;
+}
+
+void critical_point_tracker_regular::read_discrete(const std::string &filename, int format)
+{
+  ftkx_cp_t *recs = nullptr;
+  size_t n = 0;
+  const int rc = ftkx_read_critical_points(filename.c_str(), format, &recs, &n, nullptr, nullptr);
+  if (rc != FTKX_OK) throw ftkx_error(rc, io_error());
+  std::vector<feature_point_t> cps;
+  cps.reserve(n);
+  for (size_t i = 0; i < n; i ++) cps.push_back(point_of(recs[i]));
+  ftkx_free(recs);
+  put_critical_points(cps);
+}
+void critical_point_tracker_regular::read_critical_points_json(const std::string &f) { read_discrete(f, FTKX_FORMAT_JSON); }
+void critical_point_tracker_regular::read_critical_points_binary(const std::string &f) { read_discrete(f, FTKX_FORMAT_BINARY); }
+
+void critical_point_tracker_regular::write_traced(const std::string &filename, int format) const
+{
+  flat_curves f(traced_critical_points);
+  std::vector<unsigned> type(f.recs.size() ? f.recs.size() : 1);
+  std::vector<double> t(f.recs.size() ? f.recs.size() : 1);
+  for (size_t i = 0; i < f.recs.size(); i ++) { type[i] = f.recs[i].type; t[i] = f.recs[i].t; }
+  std::vector<int> loop(traced_loop), ids(traced_id);
+  loop.resize(traced_critical_points.size() + 1); ids.resize(traced_critical_points.size() + 1);
+  ftkx_trajectories tr;
+  std::memset(&tr, 0, sizeof(tr));
+  tr.n_curves = traced_critical_points.size(); tr.n_points = f.recs.size();
+  tr.offsets = f.offsets.data(); tr.indices = f.indices.data(); tr.loop = loop.data(); tr.type = type.data(); tr.t = t.data(); tr.id = ids.data();
+  const int rc = ftkx_write_traced_critical_points(filename.c_str(), format, f.recs.data(), f.recs.size(), &tr, nullptr, -1);
+  if (rc != FTKX_OK) throw ftkx_error(rc, io_error());
+}
+void critical_point_tracker_regular::write_traced_critical_points_json(const std::string &f) const { write_traced(f, FTKX_FORMAT_JSON); }
+void critical_point_tracker_regular::write_traced_critical_points_binary(const std::string &f) const { write_traced(f, FTKX_FORMAT_BINARY); }
+void critical_point_tracker_regular::write_traced_critical_points_text(const std::string &f) const { write_traced(f, FTKX_FORMAT_TEXT); }
 
 std::vector<feature_point_t> critical_point_tracker_regular::get_critical_points() const
 {
@@ -314,6 +439,43 @@ int ftkx_tracker_get_curves(const ftkx_tracker *h, long long *offsets, unsigned 
     offsets[++ i] = (long long)k;
   }
   return FTKX_OK;
+}
+
+int ftkx_tracker_post_process(ftkx_tracker *h) { return guarded(h, [&] { h->t->post_process(); }); }
+
+int ftkx_tracker_get_curve_points(const ftkx_tracker *h, unsigned int *type, double *t, int *ids)
+{
+  if (!h || !h->t) return FTKX_E_INVALID;
+  size_t k = 0, i = 0;
+  for (const auto &c : h->t->get_traced_critical_points()) {
+    for (const auto &p : c) { if (type) type[k] = p.type; if (t) t[k] = p.t; k ++; }
+    if (ids) ids[i] = h->t->get_traced_ids()[i];
+    i ++;
+  }
+  return FTKX_OK;
+}
+
+int ftkx_tracker_write(const ftkx_tracker *h, const char *path, int format, int traced)
+{
+  if (!path) return FTKX_E_INVALID;
+  return guarded(const_cast<ftkx_tracker *>(h), [&] {
+    const std::string f(path);
+    const ftkx::critical_point_tracker_regular &t = *h->t;
+    if (format == FTKX_FORMAT_JSON) { if (traced) t.write_traced_critical_points_json(f); else t.write_critical_points_json(f); }
+    else if (format == FTKX_FORMAT_TEXT) { if (traced) t.write_traced_critical_points_text(f); else t.write_critical_points_text(f); }
+    else if (format == FTKX_FORMAT_BINARY) { if (traced) t.write_traced_critical_points_binary(f); else t.write_critical_points_binary(f); }
+    else throw ftkx::ftkx_error(FTKX_E_INVALID, "ftkx_tracker_write: unknown format");
+  });
+}
+
+int ftkx_tracker_read_critical_points(ftkx_tracker *h, const char *path, int format)
+{
+  if (!path) return FTKX_E_INVALID;
+  return guarded(h, [&] {
+    if (format == FTKX_FORMAT_JSON) h->t->read_critical_points_json(path);
+    else if (format == FTKX_FORMAT_BINARY) h->t->read_critical_points_binary(path);
+    else throw ftkx::ftkx_error(FTKX_E_UNSUPPORTED, "ftkx_tracker_read_critical_points: json or binary");
+  });
 }
 
 int ftkx_tracker_get_stats(const ftkx_tracker *h, ftkx_stats *st)

@@ -186,9 +186,34 @@ typedef struct ftkx_trajectories {
   int *loop;
   unsigned int *type;
   double *t;
+  int *id;                                /* n_curves: label of the curve in the reference's multimap = index of the traced curve
+                                             it came from (split pieces share their parent's label, feature_curve_set.hh:530-531) */
 } ftkx_trajectories;
 int  ftkx_post_process_curves(const ftkx_cp_t *recs, size_t n, const ftkx_curves *in, ftkx_trajectories *out);
 void ftkx_free_trajectories(ftkx_trajectories *c);
+
+/* ---- record-stream formats: what `ftk --output-type discrete|traced` writes and reads -------- */
+/* binary = diy::serializeToFile, byte-identical to the reference's files; json = nlohmann's compact dump (parses to the
+ * same values); text = the ostream print-outs.  Host only.  Errors: ftkx_last_error(NULL, ...). */
+enum { FTKX_FORMAT_BINARY = 0, FTKX_FORMAT_JSON = 1, FTKX_FORMAT_TEXT = 2 };
+int ftkx_format_from_path(const char *path);     /* "...txt" text, "...json" json, else binary (filters/json_interface.hh:225-231) */
+/* critical_point_tracker::write_critical_points_{json,binary,text} (filters/critical_point_tracker.hh:106-108, 339-343,
+ * 392-396; point members features/feature_point.hh:143-205).  recs[] carry ordinal/timestep in their aux word.  v (3 per
+ * point) and id are nullable: the sweep does not produce them and the reference writes zeros for discrete points.
+ * scalar_names: labels of the text format; n_scalar_names < 0 = the tracker's default {"scalar"}. */
+int ftkx_write_critical_points(const char *path, int format, const ftkx_cp_t *recs, size_t n, const double *v, const unsigned long long *id,
+                               const char *const *scalar_names, int n_scalar_names);
+/* read_critical_points_{json,binary} (critical_point_tracker.hh:345-352, 498-508).  *recs (and *v, *id when asked for) are
+ * malloc'ed: release with ftkx_free.  There is no text reader (the reference has none): FTKX_E_UNSUPPORTED. */
+int ftkx_read_critical_points(const char *path, int format, ftkx_cp_t **recs, size_t *n, double **v, unsigned long long **id);
+/* write_traced_critical_points_{json,binary,text} (critical_point_tracker.hh:354-373, 475-484; features/feature_curve.hh:436-510,
+ * features/feature_curve_set.hh:75-118, 180-228) of trajectories as ftkx_post_process_curves returns them (or of raw traced
+ * curves: fill type/t with NULL to take them from recs).  Per-curve statistics = feature_curve_t::update_statistics. */
+int ftkx_write_traced_critical_points(const char *path, int format, const ftkx_cp_t *recs, size_t n, const ftkx_trajectories *trajs,
+                                      const char *const *scalar_names, int n_scalar_names);
+/* read_traced_critical_points_{json,binary}: points come back as records in file order (indices = 0..n-1), curve labels as
+ * the reference assigns them on load.  Release with ftkx_free(*recs) and ftkx_free_trajectories. */
+int ftkx_read_traced_critical_points(const char *path, int format, ftkx_cp_t **recs, size_t *n, ftkx_trajectories *trajs);
 
 /* ---- derived fields on the device (ndarray/grad.hh), exposed for callers that keep V/J themselves ------------- */
 /* all pointers are DEVICE pointers; results are bit-identical to the reference's host loops */

@@ -8,8 +8,9 @@
 // push_{scalar,vector}_field_snapshot / advance_timestep / update_timestep / get_critical_points.
 // Same names, same argument meaning, same call order as python/pyftk.cpp:93-142 and filters/json_interface.hh:606-725 use.
 // The sweep itself runs in the HIP kernels behind include/ftkx.h; there is no CPU implementation behind this class.
-// finalize() runs pass 2 (trace_critical_points_offline + cc2curves) on the host through ftkx_trace_curves; the trajectory
-// post-processing of json_interface::post_process (split by type, smoothing, ...) is outside this library.
+// finalize() runs pass 2 (trace_critical_points_offline + cc2curves) on the host through ftkx_trace_curves; post_process() is
+// json_interface::post_process with its default options (ftkx_post_process_curves); the write_/read_ members are the
+// reference's record-stream formats (ftkx_write_critical_points & co.).
 #ifndef FTKX_TRACKER_HH
 #define FTKX_TRACKER_HH
 
@@ -47,6 +48,30 @@ struct feature_point_t {
   bool ordinal = false;
   unsigned long long tag = 0;
 };
+
+// Order of the reference's std::map<element_t, feature_point_t>: simplicial_regular_mesh_element::operator<
+// (mesh/simplicial_regular_mesh.hh:327-337) = corner as a vector (x first, ..., time last), then the type -- expressed on
+// element tags (tag = linear corner index * ntypes + type, simplicial_regular_mesh.hh:496-502).  Tags that wrapped in
+// FTKX_TAG_REFERENCE mode on very large meshes still get a strict weak order, but not the reference's.
+struct element_order {
+  long long n[3] = {1, 1, 1};   // spatial sizes of the mesh (= domain sizes)
+  int nd = 2;
+  bool operator()(unsigned long long a, unsigned long long b) const
+  {
+    if (a == b) return false;
+    const unsigned long long ntypes = nd == 2 ? 12 : 60;
+    unsigned long long ia = a / ntypes, ib = b / ntypes;
+    for (int d = 0; d < nd; d ++) {
+      const unsigned long long m = (unsigned long long)(n[d] > 0 ? n[d] : 1);
+      const unsigned long long ca = ia % m, cb = ib % m;
+      if (ca != cb) return ca < cb;
+      ia /= m; ib /= m;
+    }
+    if (ia != ib) return ia < ib;                  // time
+    return a % ntypes < b % ntypes;
+  }
+};
+typedef std::map<unsigned long long, feature_point_t, element_order> discrete_map_t;
 
 struct ftkx_error : public std::runtime_error {
   int code;
@@ -98,9 +123,24 @@ public:
   // traced curves after finalize(): each an ordered list of points (feature_curve_t), loop flag alongside
   const std::vector<std::vector<feature_point_t>> &get_traced_critical_points() const { return traced_critical_points; }
   const std::vector<int> &get_traced_loop_flags() const { return traced_loop; }
+  const std::vector<int> &get_traced_ids() const { return traced_id; }   // label of each curve in the reference's multimap
+  // json_interface::post_process, default options (filters/json_interface.hh:758-800): smooth types, rotate, split_all,
+  // reorder, adjust_time.  Rewrites the traced curves in place.
+  void post_process();
+
+  // i/o of discrete points (critical_point_tracker.hh:104-116) and of traced curves (:118-131), the reference's formats
+  void write_critical_points_json(const std::string &filename) const;
+  void write_critical_points_binary(const std::string &filename) const;
+  void write_critical_points_text(const std::string &filename) const;
+  void read_critical_points_json(const std::string &filename);       // -> put_critical_points
+  void read_critical_points_binary(const std::string &filename);
+  void put_critical_points(const std::vector<feature_point_t> &);     // critical_point_tracker_regular.hh:40-46
+  void write_traced_critical_points_json(const std::string &filename) const;
+  void write_traced_critical_points_binary(const std::string &filename) const;
+  void write_traced_critical_points_text(const std::string &filename) const;
 
   std::vector<feature_point_t> get_critical_points() const; // critical_point_tracker_regular.hh:32-38 (sorted by element)
-  const std::map<unsigned long long, feature_point_t> &get_discrete_critical_points() const { return discrete_critical_points; }
+  const discrete_map_t &get_discrete_critical_points() const { return discrete_critical_points; }
 
   unsigned long long get_vector_field_scaling_factor() const { return vector_field_scaling_factor; }
   double get_vector_field_resolution() const { return vector_field_resolution; }
@@ -130,10 +170,14 @@ protected:
   int next_push_timestep = 0;
   double vector_field_resolution = std::numeric_limits<double>::max();   // sticky running minimum (never reset)
   unsigned long long vector_field_scaling_factor = 1;
-  std::map<unsigned long long, feature_point_t> discrete_critical_points;
+  discrete_map_t discrete_critical_points;                    // keyed by element tag, iterated in the reference's element order
   std::vector<std::vector<feature_point_t>> traced_critical_points;
-  std::vector<int> traced_loop;
+  std::vector<int> traced_loop, traced_id;
   ftkx_stats last_stats;
+
+  void write_discrete(const std::string &filename, int format) const;
+  void read_discrete(const std::string &filename, int format);
+  void write_traced(const std::string &filename, int format) const;
 };
 
 struct critical_point_tracker_2d_regular : public critical_point_tracker_regular {
@@ -172,5 +216,12 @@ int  ftkx_tracker_finalize(ftkx_tracker *);
 /* after finalize: number of curves / total points; then offsets[n_curves+1], tags[n_points] (element tags in curve order), loop[n_curves] */
 int  ftkx_tracker_num_curves(const ftkx_tracker *, size_t *n_curves, size_t *n_points);
 int  ftkx_tracker_get_curves(const ftkx_tracker *, long long *offsets, unsigned long long *tags, int *loop);
+/* json_interface::post_process defaults on the traced curves; afterwards get_curves returns the trajectories, and
+ * ftkx_tracker_get_curve_points the per-point (smoothed) type and (adjusted) time, ids[n_curves] the multimap labels */
+int  ftkx_tracker_post_process(ftkx_tracker *);
+int  ftkx_tracker_get_curve_points(const ftkx_tracker *, unsigned int *type, double *t, int *ids);
+/* format = FTKX_FORMAT_*; traced = 0 discrete points (write_critical_points_*), 1 traced curves (write_traced_critical_points_*) */
+int  ftkx_tracker_write(const ftkx_tracker *, const char *path, int format, int traced);
+int  ftkx_tracker_read_critical_points(ftkx_tracker *, const char *path, int format);
 }
 #endif

@@ -188,6 +188,14 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
   }
   for (int k = 0; k < in.DT; k ++)
     fwrite(in.steps[k].data(), sizeof(double), in.steps[k].size(), fp);
+  // the reference's own record-stream writers (filters/critical_point_tracker.hh:108, 339-343, 416-420; json_interface.hh:822-828)
+  const char *wprefix = getenv("FTK_REF_WRITE_PREFIX");
+  if (wprefix) {
+    const std::string p(wprefix);
+    tracker.write_critical_points_json(p + ".discrete.json");
+    tracker.write_critical_points_binary(p + ".discrete.bin");
+    tracker.write_critical_points_text(p + ".discrete.txt");
+  }
   // pass 2 of the reference (finalize -> trace_critical_points_offline, filters/critical_point_tracker.hh:668-817):
   // the traced curves, each as the ordered list of its points' element tags
   tracker.finalize();
@@ -208,6 +216,12 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
     trajs.foreach([](ftk::feature_curve_t &t) { t.smooth_ordinal_types(); t.smooth_interval_types(); t.rotate(); t.update_statistics(); });
     trajs.split_all();
     trajs.foreach([](ftk::feature_curve_t &t) { t.reorder(); t.adjust_time(); t.update_statistics(); });
+    if (wprefix) {
+      const std::string p(wprefix);
+      tracker.write_traced_critical_points_json(p + ".traced.json");
+      tracker.write_traced_critical_points_binary(p + ".traced.bin");
+      tracker.write_traced_critical_points_text(p + ".traced.txt");
+    }
     const char pmagic[4] = {'P', 'P', 'C', 'V'};
     fwrite(pmagic, 1, 4, fp);
     const uint64_t np = trajs.size();

@@ -8,7 +8,17 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))) if not n.startswith("io_"))
+
+
+def io_golden_names():
+    return sorted(os.path.basename(p)[3:-4] for p in glob.glob(os.path.join(GOLDEN, "io_*.npz")))
+
+
+def load_io_golden(name):
+    """the six files the reference wrote for one run (tests/golden/make_golden_io.py), as bytes"""
+    z = np.load(os.path.join(GOLDEN, "io_" + name + ".npz"))
+    return {k: z[k].tobytes() for k in z.files if k != "records_fixture"}, str(z["records_fixture"])
 
 
 def load_golden(name):

@@ -6,7 +6,7 @@ import ftk_amd
 
 
 def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=False, tag_mode=ftk_amd.TAG_REFERENCE, device=False,
-                compute_degrees=False, bounds=None, want_curves=False):
+                compute_degrees=False, bounds=None, want_curves=False, after=None):
     """returns (records, ordinal, timestep, factors[DT], stats_list)"""
     import torch
     T = ftk_amd.CriticalPointTracker2DRegular if nd == 2 else ftk_amd.CriticalPointTracker3DRegular
@@ -49,6 +49,8 @@ def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=Fals
     if want_curves:
         tr.finalize()
         curves = tr.get_traced_critical_points()
+    if after is not None:
+        after(tr)      # e.g. finalize / post_process / write_* on the live tracker
     tr.close()
     out = np.zeros(len(recs), dtype=[("tag", "<u8"), ("type", "<u4"), ("ordinal", "<i4"), ("timestep", "<i4"),
                                      ("x", "<f8", (3,)), ("t", "<f8"), ("scalar", "<f8", (3,))])

@@ -1,0 +1,123 @@
+// Stand-alone probe: what read bandwidth can a pure streaming kernel reach on this GPU, as a function of load shape?
+// hipcc -O3 --offload-arch=gfx950 -o bw_probe bw_probe.hip && ./bw_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// block-contiguous segments: one segment = blockDim * U * 16 bytes, loads of a thread are blockDim*16 apart (each wave
+// instruction reads 1 KiB contiguous); segments dealt round-robin to blocks
+template <int U, bool NT>
+__global__ __launch_bounds__(1024) void seg_read(const double2 *__restrict__ p, size_t nseg, double *out)
+{
+  double acc = 0.0;
+  const size_t seg16 = (size_t)blockDim.x * U;
+  for (size_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+    const double2 *q = p + s * seg16 + threadIdx.x;
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u ++) {
+      if (NT) { v[u].x = __builtin_nontemporal_load(&q[(size_t)u * blockDim.x].x); v[u].y = __builtin_nontemporal_load(&q[(size_t)u * blockDim.x].y); }
+      else v[u] = q[(size_t)u * blockDim.x];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u ++) acc += v[u].x + v[u].y;
+  }
+  if (acc == 1.2345e300) out[0] = acc;
+}
+
+// software-pipelined variant: keep the next segment's loads in flight while summing the current one
+template <int U>
+__global__ __launch_bounds__(1024) void seg_read_pipe(const double2 *__restrict__ p, size_t nseg, double *out)
+{
+  double acc = 0.0;
+  const size_t seg16 = (size_t)blockDim.x * U;
+  size_t s = blockIdx.x;
+  double2 cur[U], nxt[U];
+  if (s < nseg) { const double2 *q = p + s * seg16 + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; u ++) cur[u] = q[(size_t)u * blockDim.x]; }
+  for (; s < nseg; s += gridDim.x) {
+    const size_t sn = s + gridDim.x;
+    if (sn < nseg) { const double2 *q = p + sn * seg16 + threadIdx.x;
+#pragma unroll
+      for (int u = 0; u < U; u ++) nxt[u] = q[(size_t)u * blockDim.x]; }
+#pragma unroll
+    for (int u = 0; u < U; u ++) { acc += cur[u].x + cur[u].y; cur[u] = nxt[u]; }
+  }
+  if (acc == 1.2345e300) out[0] = acc;
+}
+
+// the mask kernel's walk without its arithmetic: wave = 128 columns x R rows (+2 halo rows), marching along z
+// NTMODE: 0 plain loads, 1 all nontemporal, 2 nontemporal for the rows no other wavefront reads (r = 2 .. R-1)
+// XW: wavefronts of a workgroup side by side along x (1: all stacked in y, as the mask kernel does; 4: a whole 512-column row)
+template <int R, int NTMODE = 0, int XW = 1>
+__global__ __launch_bounds__(1024) void march_read(const char *__restrict__ S, int DW, int DH, int DD, int zchunk, double *out)
+{
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nzc = (DD + zchunk - 1) / zchunk;
+  const unsigned slice = blockIdx.z / nzc;
+  const int z0 = (blockIdx.z % nzc) * zchunk, z1 = min(z0 + zchunk, DD);
+  const int wpb = blockDim.x >> 6;
+  const int j0 = (blockIdx.y * (wpb / XW) + wv / XW) * R;
+  const unsigned sy = DW * 8u, sz = (unsigned)DW * DH * 8u;
+  const char *base = S + (size_t)slice * sz * DD + (size_t)((blockIdx.x * XW + wv % XW) * 128 + 2 * lane) * 8;
+  double acc = 0.0;
+  double2 nn[R + 2];
+  for (int k = z0 - 1; k <= z1; k ++) {
+    const int kc = k < 0 ? 0 : (k >= DD ? DD - 1 : k);
+#pragma unroll
+    for (int r = 0; r < R + 2; r ++) {
+      int j = j0 + r - 1; j = j < 0 ? 0 : (j >= DH ? DH - 1 : j);
+      const double2 *q = reinterpret_cast<const double2 *>(base + (size_t)sz * kc + (size_t)sy * j);
+      if (NTMODE == 1 || (NTMODE == 2 && r >= 2 && r <= R - 1)) { nn[r].x = __builtin_nontemporal_load(&q->x); nn[r].y = __builtin_nontemporal_load(&q->y); }
+      else nn[r] = *q;
+    }
+#pragma unroll
+    for (int r = 0; r < R + 2; r ++) acc += nn[r].x + nn[r].y;
+  }
+  if (acc == 1.2345e300) out[0] = acc;
+}
+
+template <class F> float time_it(F f, int reps = 5)
+{
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  f(); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a));
+  for (int i = 0; i < reps; i ++) f();
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps;
+}
+
+int main()
+{
+  const size_t bytes = 8ull << 30;
+  double2 *p; double *out;
+  CK(hipMalloc(&p, bytes)); CK(hipMalloc(&out, 8));
+  CK(hipMemset(p, 0, bytes));
+  printf("%-44s %8s %8s\n", "variant", "ms", "TB/s");
+  auto rep = [&](const char *name, float ms, double b) { printf("%-44s %8.3f %8.2f\n", name, ms, b / ms / 1e9); fflush(stdout); };
+#define SEG(U, NT, BD, GRID) { const size_t nseg = bytes / ((size_t)BD * U * 16); char nm[96]; snprintf(nm, 96, "seg U=%d nt=%d block=%d grid=%d", U, NT, BD, GRID); \
+    rep(nm, time_it([&] { hipLaunchKernelGGL((seg_read<U, NT>), dim3(GRID), dim3(BD), 0, 0, p, nseg, out); }), (double)bytes); }
+  SEG(1, false, 256, 4096) SEG(2, false, 256, 4096) SEG(4, false, 256, 4096) SEG(8, false, 256, 4096)
+  SEG(4, false, 256, 2048) SEG(4, false, 256, 8192) SEG(4, false, 256, 16384) SEG(4, false, 256, 65536)
+  SEG(4, false, 512, 2048) SEG(4, false, 1024, 1024) SEG(8, false, 512, 2048) SEG(4, false, 64, 16384) SEG(8, false, 64, 16384)
+  SEG(4, true, 256, 4096) SEG(8, true, 256, 4096) SEG(4, true, 256, 16384)
+#define PIPE(U, BD, GRID) { const size_t nseg = bytes / ((size_t)BD * U * 16); char nm[96]; snprintf(nm, 96, "pipe U=%d block=%d grid=%d", U, BD, GRID); \
+    rep(nm, time_it([&] { hipLaunchKernelGGL((seg_read_pipe<U>), dim3(GRID), dim3(BD), 0, 0, p, nseg, out); }), (double)bytes); }
+  PIPE(2, 256, 4096) PIPE(4, 256, 4096) PIPE(4, 256, 2048) PIPE(8, 256, 2048) PIPE(4, 256, 1024) PIPE(6, 256, 3072) PIPE(6, 256, 768)
+  // marching walk over 8 slices of 512^3 (8 GiB)
+  const int DW = 512, DH = 512, DD = 512, NS = 8;
+#define MARCH(R, NTM, XW, WPB, ZC) { const int nzc = DD / ZC; char nm[96]; snprintf(nm, 96, "march R=%d nt=%d xw=%d wpb=%d zchunk=%d", R, NTM, XW, WPB, ZC); \
+    rep(nm, time_it([&] { hipLaunchKernelGGL((march_read<R, NTM, XW>), dim3(DW / (128 * XW), DH / (R * (WPB / XW)), nzc * NS), dim3(64 * WPB), 0, 0, (const char *)p, DW, DH, DD, ZC, out); }), (double)bytes); }
+  MARCH(4, 0, 1, 4, 32) MARCH(4, 1, 1, 4, 32) MARCH(4, 2, 1, 4, 32)
+  MARCH(8, 0, 1, 4, 32) MARCH(8, 1, 1, 4, 32) MARCH(8, 2, 1, 4, 32)
+  MARCH(4, 0, 4, 4, 32) MARCH(4, 1, 4, 4, 32)
+  MARCH(4, 0, 4, 8, 32) MARCH(4, 1, 4, 8, 32) MARCH(4, 0, 4, 16, 32) MARCH(4, 1, 4, 16, 32) MARCH(4, 2, 4, 16, 32)
+  MARCH(8, 0, 4, 8, 32) MARCH(8, 1, 4, 8, 32) MARCH(8, 2, 4, 8, 32)
+  MARCH(4, 1, 1, 4, 128) MARCH(4, 1, 1, 8, 32) MARCH(4, 1, 1, 2, 32) MARCH(4, 1, 1, 1, 32) MARCH(2, 1, 1, 4, 32) MARCH(2, 0, 1, 4, 32) MARCH(1, 1, 1, 4, 32)
+  return 0;
+}
