@@ -126,3 +126,40 @@ def test_reference_and_exact_tags_agree_without_overflow(gpu):
     a, _, _ = _run(gpu, "moving_extremum_3d", (64, 64, 64), 4, tag_mode=gpu.TAG_REFERENCE)
     b, _, _ = _run(gpu, "moving_extremum_3d", (64, 64, 64), 4, tag_mode=gpu.TAG_EXACT64)
     assert np.array_equal(a["tag"], b["tag"])
+
+
+@pytest.mark.parametrize("case,dims,nt,rough", [("moving_extremum_3d", (256, 128, 72), 4, False), ("moving_extremum_3d", (130, 70, 40), 3, True),
+                                                ("woven", (1024, 512), 5, False), ("woven", (258, 100), 4, True)])
+def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
+    """The marching mask kernel exists in two generations with the same 128-column layout (mask_march2_kernel<.., EDGE> and the
+    leaner mask_march4_kernel, prefetch distances 1..3) and several workgroup placements.  Same results AND the same cull
+    statistics (cells that survive, words refined) = the same mask / summary bytes where it matters."""
+    import os
+    steps = None
+    if rough:   # a field with plateaus, ties and noise: many non-uniform words, masks actually written and refined
+        rng = np.random.default_rng(7)
+        shape = tuple(reversed(dims))
+        # (values on a 1/64 grid: the resolution stays at 2^-7, so the determinants cannot overflow and the cull stays legal)
+        steps = [np.round(rng.standard_normal(shape) * 2) * 0.25 + rng.integers(-2, 3, size=shape) / 64.0 for _ in range(nt)]
+    variants = [{}, {"FTKX_MASK_V": "2"}, {"FTKX_MASK_PD": "2"}, {"FTKX_MASK_PD": "3"}, {"FTKX_MASK_SWIZZLE": "0"}, {"FTKX_MASK_SWIZZLE": "1"},
+                {"FTKX_MASK_SWIZZLE": "24", "FTKX_MASK_YG": "4"}, {"FTKX_MASK_V": "2", "FTKX_MASK_SWIZZLE": "0"}, {"FTKX_MASK_EDGE": "0"}]
+    base = None
+    for env in variants:
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            recs, st, _ = _run(gpu, case, dims, nt, steps=steps)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        key = (st["cells_survived"], st["simplices_tested"])
+        if base is None:
+            base = (recs, key)
+            assert st["cull_enabled"] == 1
+        else:
+            _same(recs, base[0])
+            if env.get("FTKX_MASK_EDGE") != "0":        # the 124-column layout has no summaries: different (coarser) cull path
+                assert key == base[1], (env, key, base[1])

@@ -53,17 +53,28 @@ __global__ __launch_bounds__(1024) void seg_read_pipe(const double2 *__restrict_
 // the mask kernel's walk without its arithmetic: wave = 128 columns x R rows (+2 halo rows), marching along z
 // NTMODE: 0 plain loads, 1 all nontemporal, 2 nontemporal for the rows no other wavefront reads (r = 2 .. R-1)
 // XW: wavefronts of a workgroup side by side along x (1: all stacked in y, as the mask kernel does; 4: a whole 512-column row)
-template <int R, int NTMODE = 0, int XW = 1>
-__global__ __launch_bounds__(1024) void march_read(const char *__restrict__ S, int DW, int DH, int DD, int zchunk, double *out)
+// EDGELD: lanes 0 / 63 also fetch one 8-byte neighbour per own row (the mask kernel's x edges); USTORE: one byte per 4 lanes per
+// own row is written (the mask kernel's summary stream, 1/8 byte per vertex)
+template <int R, int NTMODE = 0, int XW = 1, bool EDGELD = false, int USTORE = 0, int YG = 0>
+__global__ __launch_bounds__(1024) void march_read(const char *__restrict__ S, int DW, int DH, int DD, int zchunk, double *out, unsigned char *U = nullptr)
 {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nzc = (DD + zchunk - 1) / zchunk;
-  const unsigned slice = blockIdx.z / nzc;
-  const int z0 = (blockIdx.z % nzc) * zchunk, z1 = min(z0 + zchunk, DD);
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (YG > 0) {
+    const unsigned nb = gridDim.x * gridDim.y * gridDim.z, G = gridDim.x * YG;
+    const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (b < (nb / (8u * G)) * (8u * G)) {
+      const unsigned q = b % 8u, r = b / 8u, grp = (r / G) * 8u + q, in = r % G, ngy = gridDim.y / YG;
+      bx = in % gridDim.x; by = (grp % ngy) * YG + in / gridDim.x; bz = grp / ngy;
+    }
+  }
+  const unsigned slice = bz / nzc;
+  const int z0 = (bz % nzc) * zchunk, z1 = min(z0 + zchunk, DD);
   const int wpb = blockDim.x >> 6;
-  const int j0 = (blockIdx.y * (wpb / XW) + wv / XW) * R;
+  const int j0 = (by * (wpb / XW) + wv / XW) * R;
   const unsigned sy = DW * 8u, sz = (unsigned)DW * DH * 8u;
-  const char *base = S + (size_t)slice * sz * DD + (size_t)((blockIdx.x * XW + wv % XW) * 128 + 2 * lane) * 8;
+  const char *base = S + (size_t)slice * sz * DD + (size_t)((bx * XW + wv % XW) * 128 + 2 * lane) * 8;
   double acc = 0.0;
   double2 nn[R + 2];
   for (int k = z0 - 1; k <= z1; k ++) {
@@ -77,6 +88,39 @@ __global__ __launch_bounds__(1024) void march_read(const char *__restrict__ S, i
     }
 #pragma unroll
     for (int r = 0; r < R + 2; r ++) acc += nn[r].x + nn[r].y;
+    if (EDGELD && (lane == 0 || lane == 63)) {
+      const int ic = bx * 128 + 2 * lane, ih = lane == 0 ? (ic > 0 ? ic - 1 : 0) : (ic + 2 < DW ? ic + 2 : DW - 1);
+#pragma unroll
+      for (int r = 1; r <= R; r ++) {
+        int j = j0 + r - 1; j = j >= DH ? DH - 1 : j;
+        acc += *reinterpret_cast<const double *>(S + (size_t)slice * sz * DD + (size_t)sz * kc + (size_t)sy * j + (size_t)ih * 8);
+      }
+    }
+    if (USTORE == 1 && k >= z0 && k < z1 && (lane & 3) == 0) {
+#pragma unroll
+      for (int r = 0; r < R; r ++)
+        U[(size_t)slice * (DW / 8) * DH * DD + (size_t)(DW / 8) * ((size_t)(j0 + r) + (size_t)DH * k) + ((bx * 128 + 2 * lane) >> 3)] = (unsigned char)(acc > 0.5);
+    }
+    if (USTORE == 2 && k >= z0 && k < z1 && lane < 4) {       // same bytes, 4 lanes x 4 B per row
+#pragma unroll
+      for (int r = 0; r < R; r ++)
+        *reinterpret_cast<unsigned *>(U + (size_t)slice * (DW / 8) * DH * DD + (size_t)(DW / 8) * ((size_t)(j0 + r) + (size_t)DH * k) + bx * 16 + lane * 4) = (unsigned)(acc > 0.5);
+    }
+    if (USTORE >= 4 && k >= z0 && k < z1 && lane < R) {
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      unsigned char *q = U + (size_t)slice * (DW / 8) * DH * DD + (((size_t)bx * DD + k) * DH + j0 + lane) * 16;
+      if (USTORE == 4) { u4 v = {(unsigned)k, 1u, 2u, 3u}; *reinterpret_cast<u4 *>(q) = v; }                       // value independent of the loads
+      if (USTORE == 5 && ((k - z0) & 3) == 3) { u4 v = {(unsigned)(acc > 0.5), 1u, 2u, 3u};                         // every 4th plane, 4x the bytes
+        for (int t = 0; t < 4; t ++) *reinterpret_cast<u4 *>(q - (size_t)t * DH * 16) = v; }
+      if (USTORE == 6) { u4 v = {(unsigned)(acc > 0.5), 1u, 2u, 3u}; __builtin_nontemporal_store(v, reinterpret_cast<u4 *>(q)); }
+      if (USTORE == 7 && ((k - z0) & 7) == 7) { u4 v = {(unsigned)(acc > 0.5), 1u, 2u, 3u};
+        for (int t = 0; t < 8; t ++) *reinterpret_cast<u4 *>(q - (size_t)t * DH * 16) = v; }
+    }
+    if (USTORE == 3 && k >= z0 && k < z1 && lane < R) {       // tiled layout: a wavefront's R rows x 16 B are contiguous, lane r stores row r
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      u4 v = {(unsigned)(acc > 0.5), 1u, 2u, 3u};
+      *reinterpret_cast<u4 *>(U + (size_t)slice * (DW / 8) * DH * DD + (((size_t)bx * DD + k) * DH + j0 + lane) * 16) = v;
+    }
   }
   if (acc == 1.2345e300) out[0] = acc;
 }
@@ -113,11 +157,10 @@ int main()
   const int DW = 512, DH = 512, DD = 512, NS = 8;
 #define MARCH(R, NTM, XW, WPB, ZC) { const int nzc = DD / ZC; char nm[96]; snprintf(nm, 96, "march R=%d nt=%d xw=%d wpb=%d zchunk=%d", R, NTM, XW, WPB, ZC); \
     rep(nm, time_it([&] { hipLaunchKernelGGL((march_read<R, NTM, XW>), dim3(DW / (128 * XW), DH / (R * (WPB / XW)), nzc * NS), dim3(64 * WPB), 0, 0, (const char *)p, DW, DH, DD, ZC, out); }), (double)bytes); }
-  MARCH(4, 0, 1, 4, 32) MARCH(4, 1, 1, 4, 32) MARCH(4, 2, 1, 4, 32)
-  MARCH(8, 0, 1, 4, 32) MARCH(8, 1, 1, 4, 32) MARCH(8, 2, 1, 4, 32)
-  MARCH(4, 0, 4, 4, 32) MARCH(4, 1, 4, 4, 32)
-  MARCH(4, 0, 4, 8, 32) MARCH(4, 1, 4, 8, 32) MARCH(4, 0, 4, 16, 32) MARCH(4, 1, 4, 16, 32) MARCH(4, 2, 4, 16, 32)
-  MARCH(8, 0, 4, 8, 32) MARCH(8, 1, 4, 8, 32) MARCH(8, 2, 4, 8, 32)
-  MARCH(4, 1, 1, 4, 128) MARCH(4, 1, 1, 8, 32) MARCH(4, 1, 1, 2, 32) MARCH(4, 1, 1, 1, 32) MARCH(2, 1, 1, 4, 32) MARCH(2, 0, 1, 4, 32) MARCH(1, 1, 1, 4, 32)
+  unsigned char *U; CK(hipMalloc(&U, bytes / 64));
+#define MARCHG(R, NTM, E, US, WPB, ZC, YG) { const int nzc = DD / ZC; char nm[96]; snprintf(nm, 96, "march R=%d nt=%d edge=%d ust=%d wpb=%d zc=%d yg=%d", R, NTM, E, US, WPB, ZC, YG); \
+    rep(nm, time_it([&] { hipLaunchKernelGGL((march_read<R, NTM, 1, E, US, YG>), dim3(DW / 128, DH / (R * WPB), nzc * NS), dim3(64 * WPB), 0, 0, (const char *)p, DW, DH, DD, ZC, out, U); }), (double)bytes); }
+  MARCHG(8, 2, true, 0, 4, 32, 2) MARCHG(8, 2, true, 3, 4, 32, 2) MARCHG(8, 2, true, 4, 4, 32, 2) MARCHG(8, 2, true, 5, 4, 32, 2) MARCHG(8, 2, true, 6, 4, 32, 2) MARCHG(8, 2, true, 7, 4, 32, 2)
+  MARCHG(4, 0, true, 0, 4, 32, 4) MARCHG(4, 0, true, 3, 4, 32, 4) MARCHG(4, 0, true, 4, 4, 32, 4) MARCHG(4, 0, true, 5, 4, 32, 4) MARCHG(4, 0, true, 6, 4, 32, 4) MARCHG(4, 0, true, 7, 4, 32, 4)
   return 0;
 }

@@ -9,6 +9,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -57,7 +58,11 @@ bench = json.loads(open(one("bench_plain.json")).read().strip().splitlines()[-1]
 dom = bench["roofline"]["kernel"].replace("ftkx::", "").split("<")[0]
 # bench.py labels kernel families; the marching mask kernel's pre-pass instantiation (<.., true>) is not the timed one
 key = {"mask_kernel": "mask_", "cull_kernel": "cull_", "exact_kernel": "exact_", "tile_kernel": "tile_"}.get(dom, dom)
-cand = [v for n, v in summary["kernels"].items() if key in n and not n.rstrip().endswith(", true>")]
+def is_prepass(n):   # REDUCE instantiations: mask_march2_kernel<ND, EDGE, true>, mask_march4_kernel<ND, true, PD>
+    return n.rstrip().endswith(", true>") or re.search(r"mask_march4_kernel<\d, true", n) is not None
+
+
+cand = [v for n, v in summary["kernels"].items() if key in n and not is_prepass(n)]
 tj = os.path.join(dst, "traffic.json")
 traffic = json.load(open(tj)) if os.path.exists(tj) else {}
 if cand:
