@@ -192,7 +192,8 @@ def main():
             scope = ftk_amd.SCOPE_BOTH if (t + 1 < nt) else ftk_amd.SCOPE_ORDINAL
             ctx.sweep_enqueue(t, scope, factors[t])
         te1 = time.perf_counter()
-        recs = ctx.sweep_collect()      # one mask / cull / exact launch for the whole slab, then the hit download
+        # one mask / cull / exact launch for the whole slab, then the hit download into the library's pinned host buffer
+        recs = ctx.sweep_collect(copy=False)
         host_ms[0] += (te1 - te0) * 1e3; host_ms[1] += (time.perf_counter() - te1) * 1e3
         st = ctx.stats()
         return recs, st

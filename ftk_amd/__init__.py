@@ -122,10 +122,11 @@ class Context:
     def sweep_enqueue(self, t, scope, factor):
         self._ck(self._L.ftkx_sweep_enqueue(self._h, t, scope, int(factor)))
 
-    def sweep_collect(self):
+    def sweep_collect(self, copy=True):
+        """copy=False: a view of the library's pinned host buffer, valid until the next sweep / collect on this context"""
         out, n = C.c_void_p(), C.c_size_t()
         self._ck(self._L.ftkx_sweep_collect(self._h, C.byref(out), C.byref(n)))
-        return _lib.records_from(out.value, n.value)
+        return _lib.records_from(out.value, n.value, copy)
 
     def stats(self):
         s = Stats()

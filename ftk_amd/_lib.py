@@ -157,8 +157,9 @@ def check(rc, handle=None, tracker=False):
         raise FtkxError(rc, last_error(handle, tracker))
 
 
-def records_from(ptr, n):
+def records_from(ptr, n, copy=True):
     if n == 0 or not ptr:
         return np.zeros(0, dtype=CP_DTYPE)
     buf = (C.c_char * (n * CP_DTYPE.itemsize)).from_address(ptr)
-    return np.frombuffer(buf, dtype=CP_DTYPE).copy()
+    a = np.frombuffer(buf, dtype=CP_DTYPE)
+    return a.copy() if copy else a

@@ -190,7 +190,9 @@ int ensure_host_buffer(ftkx_ctx *c, size_t want)
   if (c->h_cap >= want) return FTKX_OK;
   if (c->h_hits) { HIP_TRY(c, hipHostFree(c->h_hits)); c->h_hits = nullptr; c->h_cap = 0; }
   const size_t cap = std::max<size_t>(want, 4096);
-  HIP_TRY(c, hipHostMalloc((void **)&c->h_hits, cap * sizeof(ftkx_cp_t), hipHostMallocDefault));
+  // non-coherent = ordinary cached host memory for the CPU (it only reads the records after a stream synchronise);
+  // the default coherent mapping is uncached on this platform and made every consumer crawl (5 GB/s)
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_hits, cap * sizeof(ftkx_cp_t), hipHostMallocNonCoherent));
   c->h_cap = cap;
   return FTKX_OK;
 }
@@ -281,7 +283,7 @@ __global__ void sort_gather_kernel(const ftkx_cp_t *__restrict__ hits, const uns
 }
 
 // the reference keeps hits in a std::map ordered by element; device append order is arbitrary
-int sort_hits_on_device(ftkx_ctx *c, size_t n)
+int sort_hits_on_device(ftkx_ctx *c, size_t n, int key_bits)
 {
   if (c->sort_cap < n) {
     for (void *p : {(void *)c->d_sorted, (void *)c->d_keys, (void *)c->d_idx, c->d_sort_tmp}) if (p) (void)hipFree(p);
@@ -299,7 +301,8 @@ int sort_hits_on_device(ftkx_ctx *c, size_t n)
   const size_t cap = c->sort_cap;
   hipLaunchKernelGGL(sort_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_hits, n, c->d_keys, c->d_idx);
   size_t tmp = c->sort_tmp_bytes;
-  HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys + cap, c->d_idx, c->d_idx + cap, (int)n, 0, 64, c->stream));
+  // only the bits a tag of this batch can have take part: an 8-bit digit pass less per byte saved
+  HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys + cap, c->d_idx, c->d_idx + cap, (int)n, 0, key_bits, c->stream));
   hipLaunchKernelGGL(sort_gather_kernel, dim3((unsigned)((n * 9 + 255) / 256)), dim3(256), 0, c->stream, c->d_hits, c->d_idx + cap, n, c->d_sorted);
   HIP_TRY(c, hipGetLastError());
   return FTKX_OK;
@@ -680,6 +683,19 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
   for (const Request &r : c->pending) any_fast = any_fast || r.fast;
   if (any_fast && (rc = ensure_list(c, std::max<u64>(c->list_capacity, 1u << 20)))) { c->pending.clear(); return rc; }
   if (any_fast && (rc = ensure_refine(c, std::max<u64>(c->refine_capacity, 1u << 20)))) { c->pending.clear(); return rc; }
+  // upper bound of the tags this batch can emit -> number of key bits for the device sort
+  int key_bits = 64;
+  if (c->opt.tag_mode != FTKX_TAG_REFERENCE) {            // REFERENCE tags go through int32 products and may wrap to anything
+    int t_max = 0;
+    for (const Request &r : c->pending) t_max = std::max(t_max, r.t);
+    long double bound = c->nd == 2 ? 12.0L : 60.0L;
+    const bool work_index = c->opt.tag_mode == FTKX_TAG_WORK_INDEX;
+    for (int d = 0; d < c->nd; d ++) bound *= (long double)(work_index ? c->core_sz[d] : c->dom_sz[d]);
+    if (!work_index) bound *= (long double)(t_max + 2);
+    int b = 1;
+    while (b < 64 && ldexpl(1.0L, b) <= bound) b ++;
+    key_bits = b;
+  }
   for (int attempt = 0; ; attempt ++) {
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, ftkx::CNT_N * sizeof(u64), c->stream));
     if ((rc = run_batch(c))) { c->pending.clear(); return rc; }
@@ -704,7 +720,7 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
   c->stats.simplices_tested = c->h_counters[ftkx::CNT_SIMPLICES_TESTED];
   if ((rc = ensure_host_buffer(c, n))) return rc;
   if (n >= 4096 && n < (1ull << 31)) {
-    if ((rc = sort_hits_on_device(c, n))) return rc;
+    if ((rc = sort_hits_on_device(c, n, key_bits))) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->h_hits, c->d_sorted, n * sizeof(ftkx_cp_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   } else if (n) {
