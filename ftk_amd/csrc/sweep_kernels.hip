@@ -942,6 +942,7 @@ __global__ __launch_bounds__(PD == 1 ? 768 : 512) void mask_march4_kernel(const 
   const bool edge = lane == 0 || lane == 63;
   const int ih = lane == 0 ? (ic > 0 ? ic - 1 : 0) : (ic + 2 < DW ? ic + 2 : DW - 1);   // outside neighbour column (clamped)
   const unsigned cb = (unsigned)ic * 8u, hb = (unsigned)ih * 8u;   // the only per-lane parts of a load address
+  const unsigned hb_or_oob = edge ? hb : 0xfffffff0u;              // beyond num_records: the buffer unit drops the access
   unsigned xkeep = 0, xneutral = 0;                            // per column: byte c of the pair
   for (int c = 0; c < 2; c ++) {
     const int i = i0 + c;
@@ -969,7 +970,10 @@ __global__ __launch_bounds__(PD == 1 ? 768 : 512) void mask_march4_kernel(const 
       const v4u raw = nt ? __builtin_amdgcn_raw_buffer_load_b128(rS, cb, zo + roff[r], 2) : __builtin_amdgcn_raw_buffer_load_b128(rS, cb, zo + roff[r], 0);
       B[r] = __builtin_bit_cast(v2d, raw);
     }
-    if (edge) for (int r = 0; r < RY; r ++) X[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rS, hb, zo + roff[r + 1], 0));
+    // every lane executes the edge loads (no branch around them: a path without them would make the compiler's s_waitcnt
+    // bookkeeping assume the fewest loads in flight and wait for the prefetch itself); the 62 lanes that are not at a tile edge
+    // carry an out-of-range offset, which a buffer load answers with 0 without touching memory
+    for (int r = 0; r < RY; r ++) X[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rS, hb_or_oob, zo + roff[r + 1], 0));
   };
 
   const bool in_row = i0 < DW;
@@ -987,7 +991,9 @@ __global__ __launch_bounds__(PD == 1 ? 768 : 512) void mask_march4_kernel(const 
   // one plane: prefetch plane k + 1 + PD into NN / XNN, classify plane k from (PR = k-1, CU = k, NX = k+1) and CU's edge values XC
   auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], const v2d (&NX)[RY + 2], v2d (&NN)[RY + 2],
                   const double (&XC)[RY], double (&XNN)[RY], int k) {
-    if (ND == 3 && k + 1 + PD <= z1) load_plane(NN, XNN, k + 1 + PD);   // plane z1 is still needed (d/dz of the chunk's last plane), z1 + 1 is not
+    // Unconditional (the last steps of a chunk re-request plane z1, an L2 hit): with a branch around the prefetch the compiler
+    // has to wait for the fewest loads any path leaves in flight, i.e. for the prefetch itself (s_waitcnt vmcnt(0) per plane).
+    if (ND == 3) load_plane(NN, XNN, k + 1 + PD < z1 ? k + 1 + PD : z1);
     const bool z_dom = ND == 2 || (k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2]);
     const bool z_int = ND == 2 || (k >= 1 && k < DD - 1);
     const unsigned mplane = (unsigned)P * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
@@ -1004,7 +1010,7 @@ __global__ __launch_bounds__(PD == 1 ? 768 : 512) void mask_march4_kernel(const 
       else { const double fx = (double)(DW - 1), fy = (double)(DH - 1); dx0 *= fx; dx1 *= fx; dy0 *= fy; dy1 *= fy; }
       const bool u_int = ND == 2 || (((row_int >> r) & 1) && z_int), u_dom = ((row_dom >> r) & 1) && z_dom;
       if constexpr (REDUCE) {
-        if (u_int && ((row_ok >> r) & 1) && store_ok) {
+        if (u_int && ((row_ok >> r) & 1) && store_ok && k < z1) {
           const double h = (ND == 3) ? 0.5 : 1.0;
           if (xkeep & 0x3fu) { red_take(h * dx0); red_take(h * dy0); if (ND == 3) red_take(h * dz0); }
           if (xkeep & 0x3f00u) { red_take(h * dx1); red_take(h * dy1); if (ND == 3) red_take(h * dz1); }
@@ -1020,7 +1026,7 @@ __global__ __launch_bounds__(PD == 1 ? 768 : 512) void mask_march4_kernel(const 
       const unsigned neut = u_dom ? xneutral : 0x3f3fu;        // outside the domain / row padding: never blocks a cull
       bits = (bits & keep) | neut;
       bool word_uniform = false;
-      const bool rok = (row_ok >> r) & 1;
+      const bool rok = ((row_ok >> r) & 1) && k < z1;
       // summary byte of the aligned 8-vertex word this quad of lanes covers: the sign bits ALL eight vertices share
       if (have_u) {
         int q = (int)((bits & (bits >> 8)) & 0x3fu);
@@ -1040,12 +1046,12 @@ __global__ __launch_bounds__(PD == 1 ? 768 : 512) void mask_march4_kernel(const 
   for (int b = 0; b < NB; b ++) for (int r = 0; r < RY; r ++) X[b][r] = 0.0;
   load_plane(B[0], X[0], z0 - 1);
   load_plane(B[1], X[1], z0);
-  if (ND == 3) { for (int b = 2; b < 2 + PD; b ++) if (z0 + b - 1 <= z1) load_plane(B[b], X[b], z0 + b - 1); }
+  if (ND == 3) { for (int b = 2; b < 2 + PD; b ++) load_plane(B[b], X[b], z0 + b - 1 < z1 ? z0 + b - 1 : z1); }
   else for (int b = 2; b < NB; b ++) for (int r = 0; r < RY + 2; r ++) B[b][r] = B[1][r];
   for (int k = z0; k < z1; k += NB) {
 #pragma unroll
-    for (int i = 0; i < NB; i ++)
-      if (k + i < z1) step(B[i], B[(i + 1) % NB], B[(i + 2) % NB], B[(i + 2 + PD) % NB], X[(i + 1) % NB], X[(i + 2 + PD) % NB], k + i);
+    for (int i = 0; i < NB; i ++)   // no `if (k + i < z1)` around a step (see load_plane): planes past the chunk are walked without stores
+      step(B[i], B[(i + 1) % NB], B[(i + 2) % NB], B[(i + 2 + PD) % NB], X[(i + 1) % NB], X[(i + 2 + PD) % NB], k + i);
   }
   if constexpr (REDUCE) {
     for (int o = 32; o > 0; o >>= 1) { red_mn = fmin(red_mn, __shfl_down(red_mn, o)); red_mx = fmax(red_mx, __shfl_down(red_mx, o)); }

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(1024) void seg_read_pipe(const double2 *__restrict_
 // XW: wavefronts of a workgroup side by side along x (1: all stacked in y, as the mask kernel does; 4: a whole 512-column row)
 // EDGELD: lanes 0 / 63 also fetch one 8-byte neighbour per own row (the mask kernel's x edges); USTORE: one byte per 4 lanes per
 // own row is written (the mask kernel's summary stream, 1/8 byte per vertex)
-template <int R, int NTMODE = 0, int XW = 1, bool EDGELD = false, int USTORE = 0, int YG = 0>
+template <int R, int NTMODE = 0, int XW = 1, int EDGELD = 0, int USTORE = 0, int YG = 0>
 __global__ __launch_bounds__(1024) void march_read(const char *__restrict__ S, int DW, int DH, int DD, int zchunk, double *out, unsigned char *U = nullptr)
 {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -88,7 +88,13 @@ __global__ __launch_bounds__(1024) void march_read(const char *__restrict__ S, i
     }
 #pragma unroll
     for (int r = 0; r < R + 2; r ++) acc += nn[r].x + nn[r].y;
-    if (EDGELD && (lane == 0 || lane == 63)) {
+    if (EDGELD == 2 && (lane < R || lane >= 64 - R)) {
+      const int rr = lane < R ? lane : lane - (64 - R);
+      const int ic = bx * 128, ih = lane < R ? (ic > 0 ? ic - 1 : 0) : (ic + 128 < DW ? ic + 128 : DW - 1);
+      int j = j0 + rr; j = j >= DH ? DH - 1 : j;
+      acc += *reinterpret_cast<const double *>(S + (size_t)slice * sz * DD + (size_t)sz * kc + (size_t)sy * j + (size_t)ih * 8);
+    }
+    if (EDGELD == 1 && (lane == 0 || lane == 63)) {
       const int ic = bx * 128 + 2 * lane, ih = lane == 0 ? (ic > 0 ? ic - 1 : 0) : (ic + 2 < DW ? ic + 2 : DW - 1);
 #pragma unroll
       for (int r = 1; r <= R; r ++) {
@@ -136,8 +142,9 @@ template <class F> float time_it(F f, int reps = 5)
   return ms / reps;
 }
 
-int main()
+int main(int argc, char **)
 {
+  const bool only_march = argc > 1;
   const size_t bytes = 8ull << 30;
   double2 *p; double *out;
   CK(hipMalloc(&p, bytes)); CK(hipMalloc(&out, 8));
@@ -146,6 +153,7 @@ int main()
   auto rep = [&](const char *name, float ms, double b) { printf("%-44s %8.3f %8.2f\n", name, ms, b / ms / 1e9); fflush(stdout); };
 #define SEG(U, NT, BD, GRID) { const size_t nseg = bytes / ((size_t)BD * U * 16); char nm[96]; snprintf(nm, 96, "seg U=%d nt=%d block=%d grid=%d", U, NT, BD, GRID); \
     rep(nm, time_it([&] { hipLaunchKernelGGL((seg_read<U, NT>), dim3(GRID), dim3(BD), 0, 0, p, nseg, out); }), (double)bytes); }
+  if (!only_march) {
   SEG(1, false, 256, 4096) SEG(2, false, 256, 4096) SEG(4, false, 256, 4096) SEG(8, false, 256, 4096)
   SEG(4, false, 256, 2048) SEG(4, false, 256, 8192) SEG(4, false, 256, 16384) SEG(4, false, 256, 65536)
   SEG(4, false, 512, 2048) SEG(4, false, 1024, 1024) SEG(8, false, 512, 2048) SEG(4, false, 64, 16384) SEG(8, false, 64, 16384)
@@ -153,6 +161,7 @@ int main()
 #define PIPE(U, BD, GRID) { const size_t nseg = bytes / ((size_t)BD * U * 16); char nm[96]; snprintf(nm, 96, "pipe U=%d block=%d grid=%d", U, BD, GRID); \
     rep(nm, time_it([&] { hipLaunchKernelGGL((seg_read_pipe<U>), dim3(GRID), dim3(BD), 0, 0, p, nseg, out); }), (double)bytes); }
   PIPE(2, 256, 4096) PIPE(4, 256, 4096) PIPE(4, 256, 2048) PIPE(8, 256, 2048) PIPE(4, 256, 1024) PIPE(6, 256, 3072) PIPE(6, 256, 768)
+  }
   // marching walk over 8 slices of 512^3 (8 GiB)
   const int DW = 512, DH = 512, DD = 512, NS = 8;
 #define MARCH(R, NTM, XW, WPB, ZC) { const int nzc = DD / ZC; char nm[96]; snprintf(nm, 96, "march R=%d nt=%d xw=%d wpb=%d zchunk=%d", R, NTM, XW, WPB, ZC); \
@@ -160,7 +169,7 @@ int main()
   unsigned char *U; CK(hipMalloc(&U, bytes / 64));
 #define MARCHG(R, NTM, E, US, WPB, ZC, YG) { const int nzc = DD / ZC; char nm[96]; snprintf(nm, 96, "march R=%d nt=%d edge=%d ust=%d wpb=%d zc=%d yg=%d", R, NTM, E, US, WPB, ZC, YG); \
     rep(nm, time_it([&] { hipLaunchKernelGGL((march_read<R, NTM, 1, E, US, YG>), dim3(DW / 128, DH / (R * WPB), nzc * NS), dim3(64 * WPB), 0, 0, (const char *)p, DW, DH, DD, ZC, out, U); }), (double)bytes); }
-  MARCHG(8, 2, true, 0, 4, 32, 2) MARCHG(8, 2, true, 3, 4, 32, 2) MARCHG(8, 2, true, 4, 4, 32, 2) MARCHG(8, 2, true, 5, 4, 32, 2) MARCHG(8, 2, true, 6, 4, 32, 2) MARCHG(8, 2, true, 7, 4, 32, 2)
-  MARCHG(4, 0, true, 0, 4, 32, 4) MARCHG(4, 0, true, 3, 4, 32, 4) MARCHG(4, 0, true, 4, 4, 32, 4) MARCHG(4, 0, true, 5, 4, 32, 4) MARCHG(4, 0, true, 6, 4, 32, 4) MARCHG(4, 0, true, 7, 4, 32, 4)
+  MARCHG(8, 2, 0, 0, 4, 32, 2) MARCHG(8, 2, 1, 0, 4, 32, 2) MARCHG(8, 2, 2, 0, 4, 32, 2) MARCHG(8, 2, 0, 1, 4, 32, 2) MARCHG(8, 2, 0, 3, 4, 32, 2) MARCHG(8, 2, 2, 3, 4, 32, 2)
+  MARCHG(4, 0, 0, 0, 4, 32, 4) MARCHG(4, 0, 1, 0, 4, 32, 4) MARCHG(4, 0, 2, 0, 4, 32, 4) MARCHG(4, 0, 0, 1, 4, 32, 4) MARCHG(4, 0, 0, 3, 4, 32, 4) MARCHG(4, 0, 2, 3, 4, 32, 4)
   return 0;
 }
