@@ -1,0 +1,44 @@
+"""The N > 1 path of bench.py (t-slab partition, halo slice, global factors, merged hits) exercised on ONE GPU: two and three
+ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one device), everything else is the code the driver runs with
+`--gpus N`.  The hit set and the exact-test statistics must not depend on the number of slabs."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _bench(n, cfg, extra=()):
+    common = ["bench.py", "--gpus", str(n), "--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *extra]
+    if n == 1:
+        cmd = [sys.executable, *common]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), *common, "--backend", "gloo", "--single-device"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("cfg", ["small3", "small2"])
+def test_slab_count_does_not_change_the_result(cfg):
+    one = _bench(1, cfg)
+    assert one["n_gpus"] == 1 and one["check"]["hits"] > 0
+    for n, extra in ((2, ()), (3, ()), (2, ("--halo-in-loop",))):
+        many = _bench(n, cfg, extra)
+        assert many["n_gpus"] == n and many["scaling"] == "strong"
+        assert many["check"]["hits"] == one["check"]["hits"]
+        assert many["config"]["simplices_per_step"] == one["config"]["simplices_per_step"]
+        assert many["halo_exchange"]["in_timed_region"] == (len(extra) > 0) and many["halo_exchange"]["bytes_per_rank"] > 0
+        assert many["config"]["nbits"] == one["config"]["nbits"]

@@ -163,3 +163,26 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
             _same(recs, base[0])
             if env.get("FTKX_MASK_EDGE") != "0":        # the 124-column layout has no summaries: different (coarser) cull path
                 assert key == base[1], (env, key, base[1])
+
+
+def test_slices_beyond_4GiB_take_the_64bit_kernels(gpu):
+    """Maximum sizes: a 1024 x 1024 x 520 slice is 4.06 GiB, past the 32-bit byte offsets of the marching mask kernels
+    (march2_supported is false) -- the sweep then runs the size_t-indexed kernels.  Same analytic trajectory, same records with
+    and without the cull, and the same records as the 32-bit path gives on the sub-volume that fits it."""
+    from ftk_amd import synthetic
+    dims, nt = (1024, 1024, 520), 3
+    assert dims[0] * dims[1] * dims[2] * 8 >= 1 << 32
+    recs, st, factors = _run(gpu, "moving_extremum_3d", dims, nt)
+    assert st["cull_enabled"] == 1 and set(factors) == {256}
+    x0, dv = synthetic.moving_extremum_params(dims)
+    assert len(recs) >= nt and set(recs["type"].tolist()) == {2}
+    for a in range(3):
+        assert np.abs(recs["x"][:, a] - (x0[a] + dv[a] * recs["t"])).max() < 1e-6
+    assert np.all(np.diff(recs["tag"].astype(np.uint64)) > 0)
+    # the extremum sits near the centre: a core of 64^3 cells around it, swept without the cull, must give the same records
+    lo = [int(x0[a]) - 32 for a in range(3)]
+    core = (lo, [64, 64, 64])
+    sub, st_e, _ = _run(gpu, "moving_extremum_3d", dims, nt, exact_only=True, core=core)
+    assert st_e["cull_enabled"] == 0
+    inside = np.ones(len(recs), dtype=bool)
+    _same(recs[inside], sub)
