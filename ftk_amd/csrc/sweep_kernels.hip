@@ -23,6 +23,8 @@
 //
 // No MFMA: 64-bit integer VALU work on 8-24 bytes per vertex, HBM-bound once the cull applies.
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
 #include <cstdlib>
 
 #include "cp_device.hpp"
@@ -907,12 +909,39 @@ __device__ inline void shift_in_signs(unsigned &a0, unsigned &a1, double dx0, do
         : "vcc");
 }
 
-// PD = prefetch distance: at the step for plane k the loads of plane k + 1 + PD are issued (PD = 1: three planes of registers
-// plus one in flight; every further plane costs (RY + 2) * 4 + RY * 2 VGPRs and one wavefront of occupancy at PD = 2)
-template <int ND, bool REDUCE, int PD>
-__global__ __launch_bounds__(PD == 1 ? 768 : 512) void mask_march4_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
+// compile-time loop: DPP controls must be integer constant expressions, so the row index has to be one
+template <class F, int... I> __device__ inline void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ inline void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// The outside-neighbour values of a plane live in ONE register: lane r holds the left neighbour of row r's first column, lane
+// 64 - RY + r the right neighbour of its last column (r = 0 .. RY-1; one buffer load per plane, 2 RY lanes active).  Row r's
+// pair is moved to lanes 0 and 63 -- where the wavefront shifts below pick it up as their `old` operand -- by two row shifts
+// (row_shl:r restricted to lanes 0-15, row_shr:(RY-1-r) restricted to lanes 48-63).
+template <int R_, int RY_>
+__device__ inline double edge_for_row(double xe)
 {
-  constexpr int RY = (ND == 3) ? 4 : 8;
+  const long long b = __double_as_longlong(xe);
+  const int lo0 = (int)b, hi0 = (int)(b >> 32);
+  int lo = lo0, hi = hi0;
+  if constexpr (R_ > 0) {
+    lo = __builtin_amdgcn_update_dpp(lo0, lo0, 0x100 + R_ /* row_shl:R_ */, 0x1, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi0, hi0, 0x100 + R_, 0x1, 0xf, false);
+  }
+  constexpr int S_ = RY_ - 1 - R_;
+  if constexpr (S_ > 0) {
+    lo = __builtin_amdgcn_update_dpp(lo, lo0, 0x110 + S_ /* row_shr:S_ */, 0x8, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi0, 0x110 + S_, 0x8, 0xf, false);
+  }
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// PD = prefetch distance: at the step for plane k the loads of plane k + 1 + PD are issued (PD = 1: three planes of registers
+// plus one in flight).  RY = rows per wavefront: a plane costs (RY + 2) * 4 + 2 VGPRs; 3D runs RY = 4 at three wavefronts per
+// SIMD or RY = 8 at two (fewer halo rows per useful row, and 6 of 10 row loads are private to the wavefront).
+template <int ND, bool REDUCE, int PD, int RY>
+__global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void mask_march4_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
+{
+  static_assert(RY >= 2 && RY <= 8, "row flags are 8-bit sets; the edge register holds 2 RY <= 16 values");
   constexpr int NB = 3 + PD;                                   // plane buffers: k-1, k, k+1, and PD planes on their way
   const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
   const int nzc = (ND == 3) ? (DD + zchunk - 1) / zchunk : 1;
@@ -939,10 +968,18 @@ __global__ __launch_bounds__(PD == 1 ? 768 : 512) void mask_march4_kernel(const 
   const double tpos = (ND == 3) ? 2.0 * thr : thr, tneg = -tpos;
 
   const int ic = i0 < DW ? i0 : DW - 2;                        // clamped (even) column pair: lanes beyond the row load valid memory
-  const bool edge = lane == 0 || lane == 63;
-  const int ih = lane == 0 ? (ic > 0 ? ic - 1 : 0) : (ic + 2 < DW ? ic + 2 : DW - 1);   // outside neighbour column (clamped)
-  const unsigned cb = (unsigned)ic * 8u, hb = (unsigned)ih * 8u;   // the only per-lane parts of a load address
-  const unsigned hb_or_oob = edge ? hb : 0xfffffff0u;              // beyond num_records: the buffer unit drops the access
+  const unsigned cb = (unsigned)ic * 8u;                       // the only per-lane part of a row load's address
+  // edge register: which (row, side) this lane fetches, as a byte offset inside a plane; every other lane carries an offset
+  // beyond num_records, which a buffer load answers with 0 without touching memory (no branch around the load: see step)
+  unsigned xoff = 0xfffffff0u;
+  {
+    const int t0c = (int)bx * 128;                             // the tile's first column
+    const int xr = lane < RY ? lane : (lane >= 64 - RY ? lane - (64 - RY) : -1);
+    if (xr >= 0 && !(swizzle & 32)) {                          // (swizzle bit 32: profiling experiment, no edge fetches, wrong results at tile edges)
+      const int col = lane < RY ? (t0c > 0 ? t0c - 1 : 0) : (t0c + 128 < DW ? t0c + 128 : DW - 1);
+      xoff = sy * (unsigned)clampi(j0 + xr, 0, DH - 1) + (unsigned)col * 8u;
+    }
+  }
   unsigned xkeep = 0, xneutral = 0;                            // per column: byte c of the pair
   for (int c = 0; c < 2; c ++) {
     const int i = i0 + c;
@@ -963,17 +1000,14 @@ __global__ __launch_bounds__(PD == 1 ? 768 : 512) void mask_march4_kernel(const 
     }
   }
   const int nt_mode = (swizzle & 4) ? 1 : ((swizzle & 16) ? 2 : 0);   // 1: all loads nontemporal, 2: only rows no other wavefront reads
-  auto load_plane = [&](v2d (&B)[RY + 2], double (&X)[RY], int k) {
+  auto load_plane = [&](v2d (&B)[RY + 2], double &X, int k) {
     const unsigned zo = sz * (unsigned)clampi(k, 0, DD - 1);
     for (int r = 0; r < RY + 2; r ++) {
       const bool nt = nt_mode == 1 || (nt_mode == 2 && r >= 2 && r <= RY - 1);
       const v4u raw = nt ? __builtin_amdgcn_raw_buffer_load_b128(rS, cb, zo + roff[r], 2) : __builtin_amdgcn_raw_buffer_load_b128(rS, cb, zo + roff[r], 0);
       B[r] = __builtin_bit_cast(v2d, raw);
     }
-    // every lane executes the edge loads (no branch around them: a path without them would make the compiler's s_waitcnt
-    // bookkeeping assume the fewest loads in flight and wait for the prefetch itself); the 62 lanes that are not at a tile edge
-    // carry an out-of-range offset, which a buffer load answers with 0 without touching memory
-    for (int r = 0; r < RY; r ++) X[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rS, hb_or_oob, zo + roff[r + 1], 0));
+    X = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rS, xoff, zo, 0));
   };
 
   const bool in_row = i0 < DW;
@@ -988,20 +1022,29 @@ __global__ __launch_bounds__(PD == 1 ? 768 : 512) void mask_march4_kernel(const 
     red_mx = fmax(red_mx, a < HUGE_VAL ? a : 0.0);
   };
 
-  // one plane: prefetch plane k + 1 + PD into NN / XNN, classify plane k from (PR = k-1, CU = k, NX = k+1) and CU's edge values XC
-  auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], const v2d (&NX)[RY + 2], v2d (&NN)[RY + 2],
-                  const double (&XC)[RY], double (&XNN)[RY], int k) {
-    // Unconditional (the last steps of a chunk re-request plane z1, an L2 hit): with a branch around the prefetch the compiler
-    // has to wait for the fewest loads any path leaves in flight, i.e. for the prefetch itself (s_waitcnt vmcnt(0) per plane).
+  // one plane: prefetch plane k + 1 + PD into NN / XNN, classify plane k from (PR = k-1, CU = k, NX = k+1) and CU's edge register XC
+  auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], const v2d (&NX)[RY + 2], v2d (&NN)[RY + 2], const double XC, double &XNN, int k) {
+    // Unconditional, and no branch around any load in this loop (the last steps of a chunk re-request plane z1, an L2 hit):
+    // on a path that skips loads the compiler's s_waitcnt bookkeeping has to assume the fewest loads in flight, and it then
+    // waits for the prefetch itself (s_waitcnt vmcnt(0) per plane) -- measured, not hypothetical.
     if (ND == 3) load_plane(NN, XNN, k + 1 + PD < z1 ? k + 1 + PD : z1);
     const bool z_dom = ND == 2 || (k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2]);
     const bool z_int = ND == 2 || (k >= 1 && k < DD - 1);
     const unsigned mplane = (unsigned)P * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
     const unsigned uplane = (unsigned)m.u_pitch * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
-    for (int r = 0; r < RY; r ++) {
+    if (swizzle & 128) {   // profiling experiment: consume the loaded planes with one xor per register and nothing else
+      long long acc = __double_as_longlong(XC);
+      for (int r = 0; r < RY + 2; r ++) acc ^= __double_as_longlong(CU[r].x) ^ __double_as_longlong(CU[r].y);
+      for (int r = 1; r <= RY; r ++) acc ^= __double_as_longlong(NX[r].x) ^ __double_as_longlong(PR[r].y);
+      if (acc == 0x7ff8123456789abcll && k < z1) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)acc, rM, mcol, mplane, 0);
+      return;
+    }
+    static_for<RY>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
       const v2d c = CU[r + 1];
-      double xm = dpp_lower_or(c.y, XC[r]);                    // left neighbour of column i0
-      double xp = dpp_upper_or(c.x, XC[r]);                    // right neighbour of column i0 + 1
+      const double xe = edge_for_row<r, RY>(XC);               // lane 0: left neighbour of row r, lane 63: right neighbour
+      double xm = dpp_lower_or(c.y, xe);                       // left neighbour of column i0
+      double xp = dpp_upper_or(c.x, xe);                       // right neighbour of column i0 + 1
       if (ND == 2 && i0 + 1 == DW - 1) xp = c.y;              // 2D clamp: the right neighbour of the last column is itself
       double dx0 = c.y - xm, dx1 = xp - c.x;
       double dy0 = CU[r + 2].x - CU[r].x, dy1 = CU[r + 2].y - CU[r].y;
@@ -1015,9 +1058,14 @@ __global__ __launch_bounds__(PD == 1 ? 768 : 512) void mask_march4_kernel(const 
           if (xkeep & 0x3fu) { red_take(h * dx0); red_take(h * dy0); if (ND == 3) red_take(h * dz0); }
           if (xkeep & 0x3f00u) { red_take(h * dx1); red_take(h * dy1); if (ND == 3) red_take(h * dz1); }
         }
-        continue;
+        return;
       }
       unsigned a0 = 0, a1 = 0;
+      if (swizzle & 64) {   // profiling experiment: (almost) no arithmetic between the loads and the stores; results are garbage
+        const v2d q0 = CU[r], q2 = CU[r + 2], qn = NX[r + 1], qp = PR[r + 1];
+        a0 = (unsigned)(__double_as_longlong(c.x) ^ __double_as_longlong(q0.x) ^ __double_as_longlong(q2.x) ^ __double_as_longlong(qn.x) ^ __double_as_longlong(qp.x) ^ __double_as_longlong(XC)) & 0x3fu;
+        a1 = (unsigned)(__double_as_longlong(c.y) ^ __double_as_longlong(q0.y) ^ __double_as_longlong(q2.y) ^ __double_as_longlong(qn.y) ^ __double_as_longlong(qp.y)) & 0x3fu;
+      } else
       shift_in_signs<ND>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, tneg, tpos);
       if (ND == 2) { a0 = ((a0 & 0xcu) << 1) | (a0 & 3u); a1 = ((a1 & 0xcu) << 1) | (a1 & 3u); }   // leave the two z bits empty
       unsigned bits = a0 | (a1 << 8);
@@ -1037,20 +1085,20 @@ __global__ __launch_bounds__(PD == 1 ? 768 : 512) void mask_march4_kernel(const 
       }
       if (rok && store_ok && !word_uniform)
         __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rM, mcol, mplane + (unsigned)P * (unsigned)r, 0);
-    }
+    });
   };
 
   // the plane buffers rotate by NAME: the z loop is unrolled NB times, every index below is a compile-time constant
   v2d B[NB][RY + 2];
-  double X[NB][RY];
-  for (int b = 0; b < NB; b ++) for (int r = 0; r < RY; r ++) X[b][r] = 0.0;
+  double X[NB];
+  for (int b = 0; b < NB; b ++) X[b] = 0.0;
   load_plane(B[0], X[0], z0 - 1);
   load_plane(B[1], X[1], z0);
   if (ND == 3) { for (int b = 2; b < 2 + PD; b ++) load_plane(B[b], X[b], z0 + b - 1 < z1 ? z0 + b - 1 : z1); }
   else for (int b = 2; b < NB; b ++) for (int r = 0; r < RY + 2; r ++) B[b][r] = B[1][r];
   for (int k = z0; k < z1; k += NB) {
 #pragma unroll
-    for (int i = 0; i < NB; i ++)   // no `if (k + i < z1)` around a step (see load_plane): planes past the chunk are walked without stores
+    for (int i = 0; i < NB; i ++)   // no `if (k + i < z1)` around a step: planes past the chunk are walked without stores
       step(B[i], B[(i + 1) % NB], B[(i + 2) % NB], B[(i + 2 + PD) % NB], X[(i + 1) % NB], X[(i + 2 + PD) % NB], k + i);
   }
   if constexpr (REDUCE) {
@@ -1520,14 +1568,22 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       bool diet = use_edge;                                   // the VALU-diet kernel implements the 128-column layout only
       if (const char *e = getenv("FTKX_MASK_V")) diet = diet && atoi(e) != 2;
       if (diet) {
-        int pd = 1;
+        int pd = 1, ry = (m.nd == 3) ? 4 : 8;
         if (const char *e = getenv("FTKX_MASK_PD")) pd = atoi(e);
-#define FTKX_M4(ND_, R_, PD_) hipLaunchKernelGGL((mask_march4_kernel<ND_, R_, PD_>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle)
-        if (reduce) { if (m.nd == 2) FTKX_M4(2, true, 1); else FTKX_M4(3, true, 1); }
-        else if (m.nd == 2) FTKX_M4(2, false, 1);
-        else if (pd == 2) FTKX_M4(3, false, 2);
-        else if (pd == 3) FTKX_M4(3, false, 3);
-        else FTKX_M4(3, false, 1);
+        if (const char *e = getenv("FTKX_MASK_RY")) { if (m.nd == 3 && (atoi(e) == 4 || atoi(e) == 8)) ry = atoi(e); }
+        const dim3 grid4(grid2.x, (unsigned)((m.ext_sz[1] + wpb * ry - 1) / (wpb * ry)), grid2.z);
+        if ((swizzle & 8) && grid4.y != grid2.y) { int yg = (swizzle >> 8) & 0xff; while (yg > 1 && grid4.y % (unsigned)yg) yg --; swizzle = (swizzle & 0xff) | (yg << 8); }
+        unsigned lds = 0;                                       // experiment: dynamic LDS only to cap the workgroups per CU
+        if (const char *e = getenv("FTKX_MASK_LDS_KB")) lds = (unsigned)atoi(e) * 1024u;
+#define FTKX_M4(ND_, R_, PD_, RY_) do { if (lds) (void)hipFuncSetAttribute((const void *)mask_march4_kernel<ND_, R_, PD_, RY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+          hipLaunchKernelGGL((mask_march4_kernel<ND_, R_, PD_, RY_>), grid4, blk, lds, stream, m, d_jobs, zchunk, swizzle); } while (0)
+        if (reduce) { if (m.nd == 2) FTKX_M4(2, true, 1, 8); else FTKX_M4(3, true, 1, 4); }
+        else if (m.nd == 2) FTKX_M4(2, false, 1, 8);
+        else if (ry == 8) { if (pd == 2) FTKX_M4(3, false, 2, 8); else if (pd == 0) FTKX_M4(3, false, 0, 8); else FTKX_M4(3, false, 1, 8); }
+        else if (pd == 2) FTKX_M4(3, false, 2, 4);
+        else if (pd == 3) FTKX_M4(3, false, 3, 4);
+        else if (pd == 0) FTKX_M4(3, false, 0, 4);
+        else FTKX_M4(3, false, 1, 4);
 #undef FTKX_M4
         return;
       }

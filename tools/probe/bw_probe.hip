@@ -55,7 +55,7 @@ __global__ __launch_bounds__(1024) void seg_read_pipe(const double2 *__restrict_
 // XW: wavefronts of a workgroup side by side along x (1: all stacked in y, as the mask kernel does; 4: a whole 512-column row)
 // EDGELD: lanes 0 / 63 also fetch one 8-byte neighbour per own row (the mask kernel's x edges); USTORE: one byte per 4 lanes per
 // own row is written (the mask kernel's summary stream, 1/8 byte per vertex)
-template <int R, int NTMODE = 0, int XW = 1, int EDGELD = 0, int USTORE = 0, int YG = 0>
+template <int R, int NTMODE = 0, int XW = 1, int EDGELD = 0, int USTORE = 0, int YG = 0, int WORK = 0>
 __global__ __launch_bounds__(1024) void march_read(const char *__restrict__ S, int DW, int DH, int DD, int zchunk, double *out, unsigned char *U = nullptr)
 {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -81,13 +81,37 @@ __global__ __launch_bounds__(1024) void march_read(const char *__restrict__ S, i
     const int kc = k < 0 ? 0 : (k >= DD ? DD - 1 : k);
 #pragma unroll
     for (int r = 0; r < R + 2; r ++) {
+      if (NTMODE == 3 && ((r == 0 && wv != 0) || (r == R + 1 && wv != wpb - 1))) { nn[r] = double2{0.0, 0.0}; continue; }
       int j = j0 + r - 1; j = j < 0 ? 0 : (j >= DH ? DH - 1 : j);
+      if (WORK == 1000) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(S + (size_t)slice * sz * DD), 0, (int)(sz * (unsigned)DD), 0x00020000);
+        const unsigned vo = (unsigned)((bx * XW + wv % XW) * 128 + 2 * lane) * 8u, so = sz * (unsigned)kc + sy * (unsigned)j;
+        const bool ntl = NTMODE == 1 || (NTMODE == 2 && r >= 2 && r <= R - 1) || (NTMODE == 3 && r >= 1 && r <= R);
+        const u4 raw = ntl ? __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 2) : __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
+        nn[r] = __builtin_bit_cast(double2, raw);
+        continue;
+      }
       const double2 *q = reinterpret_cast<const double2 *>(base + (size_t)sz * kc + (size_t)sy * j);
-      if (NTMODE == 1 || (NTMODE == 2 && r >= 2 && r <= R - 1)) { nn[r].x = __builtin_nontemporal_load(&q->x); nn[r].y = __builtin_nontemporal_load(&q->y); }
+      if (NTMODE == 1 || (NTMODE == 2 && r >= 2 && r <= R - 1) || (NTMODE == 3 && r >= 1 && r <= R)) { nn[r].x = __builtin_nontemporal_load(&q->x); nn[r].y = __builtin_nontemporal_load(&q->y); }
       else nn[r] = *q;
     }
 #pragma unroll
     for (int r = 0; r < R + 2; r ++) acc += nn[r].x + nn[r].y;
+    if (WORK > 0 && WORK < 1000) {   // register-only arithmetic next to the stream: WORK x 8 independent FP64 FMAs (WORK < 0: 32-bit integer ops instead)
+      double w0 = acc, w1 = acc + 1, w2 = acc + 2, w3 = acc + 3, w4 = acc + 4, w5 = acc + 5, w6 = acc + 6, w7 = acc + 7;
+#pragma unroll
+      for (int t = 0; t < WORK; t ++) { w0 = w0 * 1.000001 + 0.5; w1 = w1 * 1.000001 + 0.5; w2 = w2 * 1.000001 + 0.5; w3 = w3 * 1.000001 + 0.5;
+                                        w4 = w4 * 1.000001 + 0.5; w5 = w5 * 1.000001 + 0.5; w6 = w6 * 1.000001 + 0.5; w7 = w7 * 1.000001 + 0.5; }
+      acc = ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7));
+    }
+    if (WORK < 0) {
+      unsigned u0 = (unsigned)acc, u1 = u0 + 1, u2 = u0 + 2, u3 = u0 + 3, u4 = u0 + 4, u5 = u0 + 5, u6 = u0 + 6, u7 = u0 + 7;
+#pragma unroll
+      for (int t = 0; t < -WORK; t ++) { u0 = u0 * 1664525u + 1013904223u; u1 = u1 * 1664525u + 1013904223u; u2 = u2 * 1664525u + 1013904223u; u3 = u3 * 1664525u + 1013904223u;
+                                         u4 = u4 * 1664525u + 1013904223u; u5 = u5 * 1664525u + 1013904223u; u6 = u6 * 1664525u + 1013904223u; u7 = u7 * 1664525u + 1013904223u; }
+      acc += (double)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7);
+    }
     if (EDGELD == 2 && (lane < R || lane >= 64 - R)) {
       const int rr = lane < R ? lane : lane - (64 - R);
       const int ic = bx * 128, ih = lane < R ? (ic > 0 ? ic - 1 : 0) : (ic + 128 < DW ? ic + 128 : DW - 1);
@@ -142,10 +166,11 @@ template <class F> float time_it(F f, int reps = 5)
   return ms / reps;
 }
 
-int main(int argc, char **)
+int main(int argc, char **argv)
 {
   const bool only_march = argc > 1;
-  const size_t bytes = 8ull << 30;
+  const int NSARG = argc > 2 ? atoi(argv[2]) : 8;
+  const size_t bytes = (size_t)NSARG << 30;
   double2 *p; double *out;
   CK(hipMalloc(&p, bytes)); CK(hipMalloc(&out, 8));
   CK(hipMemset(p, 0, bytes));
@@ -163,13 +188,14 @@ int main(int argc, char **)
   PIPE(2, 256, 4096) PIPE(4, 256, 4096) PIPE(4, 256, 2048) PIPE(8, 256, 2048) PIPE(4, 256, 1024) PIPE(6, 256, 3072) PIPE(6, 256, 768)
   }
   // marching walk over 8 slices of 512^3 (8 GiB)
-  const int DW = 512, DH = 512, DD = 512, NS = 8;
+  const int DW = 512, DH = 512, DD = 512, NS = NSARG;
 #define MARCH(R, NTM, XW, WPB, ZC) { const int nzc = DD / ZC; char nm[96]; snprintf(nm, 96, "march R=%d nt=%d xw=%d wpb=%d zchunk=%d", R, NTM, XW, WPB, ZC); \
     rep(nm, time_it([&] { hipLaunchKernelGGL((march_read<R, NTM, XW>), dim3(DW / (128 * XW), DH / (R * (WPB / XW)), nzc * NS), dim3(64 * WPB), 0, 0, (const char *)p, DW, DH, DD, ZC, out); }), (double)bytes); }
   unsigned char *U; CK(hipMalloc(&U, bytes / 64));
 #define MARCHG(R, NTM, E, US, WPB, ZC, YG) { const int nzc = DD / ZC; char nm[96]; snprintf(nm, 96, "march R=%d nt=%d edge=%d ust=%d wpb=%d zc=%d yg=%d", R, NTM, E, US, WPB, ZC, YG); \
     rep(nm, time_it([&] { hipLaunchKernelGGL((march_read<R, NTM, 1, E, US, YG>), dim3(DW / 128, DH / (R * WPB), nzc * NS), dim3(64 * WPB), 0, 0, (const char *)p, DW, DH, DD, ZC, out, U); }), (double)bytes); }
-  MARCHG(8, 2, 0, 0, 4, 32, 2) MARCHG(8, 2, 1, 0, 4, 32, 2) MARCHG(8, 2, 2, 0, 4, 32, 2) MARCHG(8, 2, 0, 1, 4, 32, 2) MARCHG(8, 2, 0, 3, 4, 32, 2) MARCHG(8, 2, 2, 3, 4, 32, 2)
-  MARCHG(4, 0, 0, 0, 4, 32, 4) MARCHG(4, 0, 1, 0, 4, 32, 4) MARCHG(4, 0, 2, 0, 4, 32, 4) MARCHG(4, 0, 0, 1, 4, 32, 4) MARCHG(4, 0, 0, 3, 4, 32, 4) MARCHG(4, 0, 2, 3, 4, 32, 4)
+#define MARCHW(R, NTM, YG, W) { const int nzc = DD / 32; char nm[96]; snprintf(nm, 96, "march R=%d nt=%d yg=%d work=%d", R, NTM, YG, W); \
+    rep(nm, time_it([&] { hipLaunchKernelGGL((march_read<R, NTM, 1, 0, 0, YG, W>), dim3(DW / 128, DH / (R * 4), nzc * NS), dim3(256), 0, 0, (const char *)p, DW, DH, DD, 32, out, U); }), (double)bytes); }
+  MARCHW(4, 0, 4, 0) MARCHW(4, 0, 4, 1000) MARCHW(8, 2, 4, 0) MARCHW(8, 2, 4, 1000) MARCHW(8, 0, 4, 0) MARCHW(8, 0, 4, 1000) MARCHW(8, 1, 4, 0) MARCHW(8, 1, 4, 1000)
   return 0;
 }
