@@ -81,6 +81,17 @@ class Context:
         self._opt = default_options(**kw)
         self._ck(self._L.ftkx_set_options(self._h, C.byref(self._opt)))
 
+    def set_coords_rectilinear(self, arrays):
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in arrays] + [None] * (3 - len(arrays))
+        args = []
+        for a in arrs:
+            args += [a.ctypes.data if a is not None else None, len(a) if a is not None else 0]
+        self._ck(self._L.ftkx_set_coords_rectilinear(self._h, *args))
+
+    def set_coords_explicit(self, coords):
+        e = np.ascontiguousarray(coords, dtype=np.float64)
+        self._ck(self._L.ftkx_set_coords_explicit(self._h, e.ctypes.data, e.shape[-1], e.shape[-2], e.shape[-3]))
+
     def set_mesh(self, domain, core, ext):
         """each = (starts, sizes), spatial axes only (x, y[, z])"""
         args = []
@@ -154,7 +165,7 @@ class Context:
     def jacobian3D(self, V_ptr, DW, DH, DD, J_ptr): self._ck(self._L.ftkx_jacobian3D(self._h, V_ptr, DW, DH, DD, J_ptr))
 
 
-def _extract(nd, scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options, device_id):
+def _extract(nd, scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options, device_id, coords=None):
     L = _lib.load()
     keep = []
     ptrs = []
@@ -168,7 +179,9 @@ def _extract(nd, scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc,
     out, n = C.c_void_p(), C.c_size_t()
     opt = C.byref(options) if options is not None else None
     if nd == 2:
-        rc = L.ftkx_extract_cp2dt(scope, current_timestep, *lat, *ptrs, 0, None, int(factor), opt, device_id, C.byref(out), C.byref(n))
+        cc = None if coords is None else np.ascontiguousarray(coords, dtype=np.float64)
+        rc = L.ftkx_extract_cp2dt(scope, current_timestep, *lat, *ptrs, 0 if cc is None else 1, None if cc is None else cc.ctypes.data, int(factor), opt, device_id,
+                                  C.byref(out), C.byref(n))
     else:
         rc = L.ftkx_extract_cp3dt(scope, current_timestep, *lat, *ptrs, int(factor), opt, device_id, C.byref(out), C.byref(n))
     _lib.check(rc)
@@ -177,9 +190,10 @@ def _extract(nd, scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc,
     return recs
 
 
-def extract_cp2dt(scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options=None, device_id=0):
-    """extract_cp2dt_cuda's argument list (critical_point_tracker_2d_regular.hh:33-63); lattices as (starts, sizes) incl. time."""
-    return _extract(2, scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options, device_id)
+def extract_cp2dt(scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options=None, device_id=0, coords=None):
+    """extract_cp2dt_cuda's argument list (critical_point_tracker_2d_regular.hh:33-63); lattices as (starts, sizes) incl. time.
+    coords: the boundary's explicit vertex coordinates, shape (DH, DW, 2) (use_explicit_coords = true), or None."""
+    return _extract(2, scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options, device_id, coords)
 
 
 def extract_cp3dt(scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options=None, device_id=0):
@@ -352,6 +366,19 @@ class _TrackerRegular:
     def set_tag_mode(self, m): self._flags["tag_mode"] = int(m)
     def set_stream(self, ptr): self._ck(self._L.ftkx_tracker_set_stream(self._h, C.c_void_p(ptr)))
     def set_coords_bounds(self, b): self._ck(self._L.ftkx_tracker_set_coords_bounds(self._h, (C.c_double * len(b))(*[float(x) for x in b])))
+
+    def set_coords_rectilinear(self, arrays):
+        """REGULAR_COORDS_RECTILINEAR: one 1-D float64 array per axis, indexed by the vertex coordinate"""
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in arrays] + [None] * (3 - len(arrays))
+        args = []
+        for a in arrs:
+            args += [a.ctypes.data if a is not None else None, len(a) if a is not None else 0]
+        self._ck(self._L.ftkx_tracker_set_coords_rectilinear(self._h, *args))
+
+    def set_coords_explicit(self, coords):
+        """REGULAR_COORDS_EXPLICIT: numpy array of shape (n1, n0, ncomp) = the reference's ndarray (ncomp, n0, n1)"""
+        e = np.ascontiguousarray(coords, dtype=np.float64)
+        self._ck(self._L.ftkx_tracker_set_coords_explicit(self._h, e.ctypes.data, e.shape[-1], e.shape[-2], e.shape[-3]))
 
     def initialize(self):
         self._ck(self._L.ftkx_tracker_set_sources(self._h, *self._src))

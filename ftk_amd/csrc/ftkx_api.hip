@@ -91,6 +91,12 @@ struct ftkx_ctx {
   // per-batch descriptors: pinned staging + device copies
   void *h_desc = nullptr, *d_desc = nullptr;
   size_t desc_cap = 0;
+  // physical coordinates (REGULAR_COORDS_RECTILINEAR / _EXPLICIT): device copies
+  double *d_rect[3] = {nullptr, nullptr, nullptr};
+  size_t rect_n[3] = {0, 0, 0};
+  double *d_expl = nullptr;
+  int expl_ncomp = 0;
+  size_t expl_n0 = 0, expl_n1 = 0;
   std::vector<Request> pending;
   ftkx_stats stats;
   // optional kernel timing (hipEvents on the context's stream)
@@ -223,6 +229,8 @@ void fill_mesh(const ftkx_ctx *c, Mesh &m)
   m.derive_jacobian = c->opt.derive_jacobian;
   m.coords_mode = c->opt.coords_mode;
   for (int i = 0; i < 6; i ++) m.coords_bounds[i] = c->opt.coords_bounds[i];
+  for (int d = 0; d < 3; d ++) m.coords_rect[d] = c->d_rect[d];
+  m.coords_expl = c->d_expl; m.coords_expl_ncomp = c->expl_ncomp; m.coords_expl_n0 = (int)c->expl_n0;
   m.hits = c->d_hits; m.counters = c->d_counters; m.capacity = c->capacity;
 }
 
@@ -493,6 +501,8 @@ void ftkx_destroy(ftkx_ctx *c)
   if (c->d_idx) (void)hipFree(c->d_idx);
   if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
   if (c->d_desc) (void)hipFree(c->d_desc);
+  for (int d = 0; d < 3; d ++) if (c->d_rect[d]) (void)hipFree(c->d_rect[d]);
+  if (c->d_expl) (void)hipFree(c->d_expl);
   if (c->h_desc) (void)hipHostFree(c->h_desc);
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -513,8 +523,43 @@ int ftkx_set_options(ftkx_ctx *c, const ftkx_options *o)
 {
   if (!c || !o) return fail(c, FTKX_E_INVALID, "null argument");
   if (o->tag_mode < FTKX_TAG_WORK_INDEX || o->tag_mode > FTKX_TAG_EXACT64) return fail(c, FTKX_E_INVALID, "bad tag_mode %d", o->tag_mode);
-  if (o->coords_mode != 0 && o->coords_mode != 1) return fail(c, FTKX_E_UNSUPPORTED, "coords_mode %d: only REGULAR_COORDS_SIMPLE (0) and _BOUNDS (1) are implemented", o->coords_mode);
+  if (o->coords_mode < 0 || o->coords_mode > 3) return fail(c, FTKX_E_INVALID, "bad coords_mode %d", o->coords_mode);
+  if (o->coords_mode == 2 && !c->d_rect[0]) return fail(c, FTKX_E_INVALID, "coords_mode RECTILINEAR: call ftkx_set_coords_rectilinear");
+  if (o->coords_mode == 3 && !c->d_expl) return fail(c, FTKX_E_INVALID, "coords_mode EXPLICIT: call ftkx_set_coords_explicit");
   c->opt = *o;
+  return FTKX_OK;
+}
+
+int ftkx_set_coords_rectilinear(ftkx_ctx *c, const double *x, size_t nx, const double *y, size_t ny, const double *z, size_t nz)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_set_coords_rectilinear: sweeps pending, collect first");
+  const double *src[3] = {x, y, z};
+  const size_t n[3] = {nx, ny, nz};
+  for (int d = 0; d < c->nd; d ++) if (!src[d] || !n[d]) return fail(c, FTKX_E_INVALID, "ftkx_set_coords_rectilinear: axis %d missing", d);
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (int d = 0; d < c->nd; d ++) {
+    if (c->d_rect[d]) { (void)hipFree(c->d_rect[d]); c->d_rect[d] = nullptr; }
+    HIP_TRY(c, hipMalloc((void **)&c->d_rect[d], n[d] * sizeof(double)));
+    HIP_TRY(c, hipMemcpy(c->d_rect[d], src[d], n[d] * sizeof(double), hipMemcpyHostToDevice));
+    c->rect_n[d] = n[d];
+  }
+  c->opt.coords_mode = 2;
+  return FTKX_OK;
+}
+
+int ftkx_set_coords_explicit(ftkx_ctx *c, const double *coords, int ncomp, size_t n0, size_t n1)
+{
+  if (!c || !coords) return fail(c, FTKX_E_INVALID, "null argument");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_set_coords_explicit: sweeps pending, collect first");
+  if (ncomp < 2 || (c->nd == 3 && ncomp < 3) || !n0 || !n1) return fail(c, FTKX_E_INVALID, "ftkx_set_coords_explicit: need %d components and a non-empty array", c->nd == 3 ? 3 : 2);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->d_expl) { (void)hipFree(c->d_expl); c->d_expl = nullptr; }
+  const size_t count = (size_t)ncomp * n0 * n1;
+  HIP_TRY(c, hipMalloc((void **)&c->d_expl, count * sizeof(double)));
+  HIP_TRY(c, hipMemcpy(c->d_expl, coords, count * sizeof(double), hipMemcpyHostToDevice));
+  c->expl_ncomp = ncomp; c->expl_n0 = n0; c->expl_n1 = n1;
+  c->opt.coords_mode = 3;
   return FTKX_OK;
 }
 
@@ -644,6 +689,13 @@ int ftkx_sweep_enqueue(ftkx_ctx *c, int t, int scope, unsigned long long factor)
   }
   if (s1 && ((s0->J == nullptr) != (s1->J == nullptr) || (s0->S == nullptr) != (s1->S == nullptr)))
     return fail(c, FTKX_E_INVALID, "sweep: slices %d and %d disagree on which of J / S are given", t, t + 1);
+  // coordinate arrays are indexed by vertex coordinates: they must cover the vertex box
+  if (c->opt.coords_mode == 2)
+    for (int d = 0; d < c->nd; d ++)
+      if (c->dom_st[d] < 0 || (size_t)(c->dom_st[d] + c->dom_sz[d]) > c->rect_n[d])
+        return fail(c, FTKX_E_INVALID, "sweep: rectilinear coordinates of axis %d have %zu entries, vertices reach %lld", d, c->rect_n[d], c->dom_st[d] + c->dom_sz[d] - 1);
+  if (c->opt.coords_mode == 3 && (c->dom_st[0] < 0 || c->dom_st[1] < 0 || (size_t)(c->dom_st[0] + c->dom_sz[0]) > c->expl_n0 || (size_t)(c->dom_st[1] + c->dom_sz[1]) > c->expl_n1))
+    return fail(c, FTKX_E_INVALID, "sweep: explicit coordinates are %zu x %zu, the vertex box needs %lld x %lld", c->expl_n0, c->expl_n1, c->dom_st[0] + c->dom_sz[0], c->dom_st[1] + c->dom_sz[1]);
   for (int d = 0; d < c->nd; d ++)
     if (c->core_sz[d] == 0) return FTKX_OK;    // empty core: nothing to enumerate
   HIP_TRY(c, hipSetDevice(c->device));
@@ -787,7 +839,7 @@ void ftkx_free(void *p) { free(p); }
 static int extract_common(int nd, int scope, int t, const long long *dst, const long long *dsz, const long long *cst, const long long *csz,
                           const long long *est, const long long *esz, const double *Vc, const double *Vn, const double *Jc, const double *Jn,
                           const double *Sc, const double *Sn, unsigned long long factor, const ftkx_options *opt, int device_id,
-                          ftkx_cp_t **out, size_t *n_out)
+                          ftkx_cp_t **out, size_t *n_out, const double *explicit_coords = nullptr)
 {
   if (!out || !n_out) return fail(nullptr, FTKX_E_INVALID, "extract: null output");
   *out = nullptr; *n_out = 0;
@@ -802,6 +854,11 @@ static int extract_common(int nd, int scope, int t, const long long *dst, const 
   ftkx_options o;
   if (opt) o = *opt; else { ftkx_default_options(&o); o.tag_mode = FTKX_TAG_WORK_INDEX; }
   long long e3[3] = {est[0], est[1], nd == 3 ? est[2] : 0}, s3[3] = {esz[0], esz[1], nd == 3 ? esz[2] : 1};
+  if (explicit_coords) {   // the boundary's `coords`: (2, DW, DH) doubles over `ext` (critical_point_tracer_2d_regular.cu:194-198)
+    if (est[0] != 0 || est[1] != 0) { ftkx_destroy(c); return fail(nullptr, FTKX_E_UNSUPPORTED, "extract: explicit coordinates need an array lattice starting at 0"); }
+    if ((rc = ftkx_set_coords_explicit(c, explicit_coords, 2, (size_t)esz[0], (size_t)esz[1]))) { g_last_error = c->err; ftkx_destroy(c); return rc; }
+    o.coords_mode = 3;
+  }
   if ((rc = ftkx_set_options(c, &o)) || (rc = ftkx_set_mesh(c, dst, dsz, cst, csz, e3, s3)) ||
       (rc = ftkx_push_slice(c, t, Vc, Jc, Sc, 0)) ||
       (scope == FTKX_SCOPE_INTERVAL && (rc = ftkx_push_slice(c, t + 1, Vn, Jn, Sn, 0)))) {
@@ -824,9 +881,9 @@ int ftkx_extract_cp2dt(int scope, int current_timestep, const long long domain_s
                        int use_explicit_coords, const double *coords, unsigned long long factor, const ftkx_options *opt, int device_id,
                        ftkx_cp_t **out, size_t *n_out)
 {
-  (void)coords;
-  if (use_explicit_coords) return fail(nullptr, FTKX_E_UNSUPPORTED, "explicit coordinates are not supported (REGULAR_COORDS_SIMPLE only)");
-  return extract_common(2, scope, current_timestep, domain_st, domain_sz, core_st, core_sz, ext_st, ext_sz, Vc, Vn, Jc, Jn, Sc, Sn, factor, opt, device_id, out, n_out);
+  if (use_explicit_coords && !coords) return fail(nullptr, FTKX_E_INVALID, "extract: use_explicit_coords without coords");
+  return extract_common(2, scope, current_timestep, domain_st, domain_sz, core_st, core_sz, ext_st, ext_sz, Vc, Vn, Jc, Jn, Sc, Sn, factor, opt, device_id, out, n_out,
+                        use_explicit_coords ? coords : nullptr);
 }
 
 int ftkx_extract_cp3dt(int scope, int current_timestep, const long long domain_st[4], const long long domain_sz[4],

@@ -224,24 +224,35 @@ __device__ __noinline__ bool make_record(const Mesh &m, const Fields &f, const i
   ftkx_cp_t r;
   r.scalar[0] = r.scalar[1] = r.scalar[2] = 0.0;
   {
-    // lerp of the lattice coordinates, left to right (linear_interpolation.hh:83-101, 129-139)
-    // simplex_coordinates: lattice integers, or image bounds ((v - array_lb) / double(array_size - 1)) * (b1 - b0) + b0
-    auto phys = [&](int d, int v) -> double {
-      if (d < ND && m.coords_mode == 1)
-        return ((double)(unsigned long long)(v - m.ext_st[d]) / (double)(m.ext_sz[d] - 1)) * (m.coords_bounds[2 * d + 1] - m.coords_bounds[2 * d]) + m.coords_bounds[2 * d];
-      return (double)v;
-    };
-    double x[4] = {0, 0, 0, 0};
-    for (int d = 0; d < N; d ++) {
-      double acc = phys(d, vx[0][d]) * mu[0];
-      for (int i = 1; i < N; i ++) acc = acc + phys(d, vx[i][d]) * mu[i];
+    // lerp of the vertex coordinates, left to right (linear_interpolation.hh:83-101, 129-139).  simplex_coordinates (2d:494-527,
+    // 3d:342-378): lattice integers; image bounds ((v - array_lb) / double(array_size - 1)) * (b1 - b0) + b0; rectilinear
+    // coords[axis][v]; explicit coords(c, x, y) -- which the 3D tracker also reads with three indices (the z = 0 plane) while
+    // reporting the vertex's z index as its time (3d:371-376): reproduced as written.
+    double X[N][4];
+    for (int i = 0; i < N; i ++) {
+      X[i][2] = 0.0;
+      X[i][3] = (double)vx[i][ND];
+      if (m.coords_mode == 1) {
+        for (int d = 0; d < ND; d ++)
+          X[i][d] = ((double)(unsigned long long)(vx[i][d] - m.ext_st[d]) / (double)(m.ext_sz[d] - 1)) * (m.coords_bounds[2 * d + 1] - m.coords_bounds[2 * d]) + m.coords_bounds[2 * d];
+      } else if (m.coords_mode == 2) {
+        for (int d = 0; d < ND; d ++) X[i][d] = m.coords_rect[d][vx[i][d]];
+      } else if (m.coords_mode == 3) {
+        const size_t at = (size_t)m.coords_expl_ncomp * ((size_t)vx[i][0] + (size_t)m.coords_expl_n0 * (size_t)vx[i][1]);
+        X[i][0] = m.coords_expl[at]; X[i][1] = m.coords_expl[at + 1];
+        if constexpr (ND == 2) X[i][2] = m.coords_expl_ncomp > 2 ? m.coords_expl[at + 2] : 0.0;
+        else { X[i][2] = m.coords_expl[at + 2]; X[i][3] = (double)vx[i][2]; }
+      } else {
+        for (int d = 0; d < ND; d ++) X[i][d] = (double)vx[i][d];
+      }
+    }
+    double x[4];
+    for (int d = 0; d < 4; d ++) {
+      double acc = X[0][d] * mu[0];
+      for (int i = 1; i < N; i ++) acc = acc + X[i][d] * mu[i];
       x[d] = acc;
     }
-    if constexpr (ND == 2) {
-      r.x[0] = x[0]; r.x[1] = x[1];
-      r.x[2] = 0.0 * mu[0] + 0.0 * mu[1] + 0.0 * mu[2];            // the reference lerps three zeros (2d:498-503)
-      r.t = x[2];
-    } else { r.x[0] = x[0]; r.x[1] = x[1]; r.x[2] = x[2]; r.t = x[3]; }
+    r.x[0] = x[0]; r.x[1] = x[1]; r.x[2] = x[2]; r.t = x[3];      // 2D: x[2] lerps three zeros unless explicit coordinates carry a z
   }
   if (f.S[0]) {
     double acc = f.S[slice[0]][arr_index<ND>(m, ai[0][0], ai[0][1], ai[0][2])] * mu[0];

@@ -26,8 +26,11 @@ struct Mesh {
   int compute_degrees, tag_mode;
   int scalar_mode;           // 1: V is not stored; it is gradient2D/3D(S) evaluated where needed (vector_field_source == DERIVED)
   int derive_jacobian;       // 1: J not stored; jacobian2D/3D of V evaluated at hit vertices (jacobian_field_source == DERIVED)
-  int coords_mode;           // 0 lattice integers, 1 image bounds
+  int coords_mode;           // REGULAR_COORDS_*: 0 lattice integers, 1 image bounds, 2 rectilinear, 3 explicit
   double coords_bounds[6];
+  const double *coords_rect[3];   // RECTILINEAR: per-axis coordinate arrays (device), indexed by the vertex coordinate
+  const double *coords_expl;      // EXPLICIT: (ncomp, n0, ...) array (device), read as p[c + ncomp * (x + n0 * y)]
+  int coords_expl_ncomp, coords_expl_n0;
   ftkx_cp_t *hits;           // device hit buffer
   u64 *counters;             // CNT_* device counters
   u64 capacity;              // records the hit buffer can hold

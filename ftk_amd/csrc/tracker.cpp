@@ -52,6 +52,14 @@ void critical_point_tracker_regular::initialize()
   o.tag_mode = tag_mode;
   o.exact_only = exact_only;
   o.derive_jacobian = jacobian_field_source == SOURCE_DERIVED;
+  if (mode_phys_coords == 2) {
+    if ((int)rectilinear_coords.size() < nd) throw ftkx_error(FTKX_E_INVALID, "initialize: set_coords_rectilinear needs one array per axis");
+    const std::vector<double> none;
+    const std::vector<double> &z = nd == 3 ? rectilinear_coords[2] : none;
+    check(ftkx_set_coords_rectilinear(ctx, rectilinear_coords[0].data(), rectilinear_coords[0].size(), rectilinear_coords[1].data(), rectilinear_coords[1].size(),
+                                      z.empty() ? nullptr : z.data(), z.size()));
+  } else if (mode_phys_coords == 3)
+    check(ftkx_set_coords_explicit(ctx, explicit_coords.data(), explicit_ncomp, explicit_n0, explicit_n1));
   o.coords_mode = mode_phys_coords;
   for (size_t i = 0; i < 6 && i < bounds_coords.size(); i ++) o.coords_bounds[i] = bounds_coords[i];
   check(ftkx_set_options(ctx, &o));
@@ -376,6 +384,17 @@ int ftkx_tracker_set_flags(ftkx_tracker *h, int robust, int use_tf, unsigned tf,
 }
 int ftkx_tracker_set_stream(ftkx_tracker *h, void *s) { return guarded(h, [&] { h->t->set_stream(s); }); }
 int ftkx_tracker_set_coords_bounds(ftkx_tracker *h, const double *b) { return guarded(h, [&] { h->t->set_coords_bounds(std::vector<double>(b, b + 2 * h->nd)); }); }
+int ftkx_tracker_set_coords_rectilinear(ftkx_tracker *h, const double *x, size_t nx, const double *y, size_t ny, const double *z, size_t nz)
+{
+  return guarded(h, [&] {
+    std::vector<std::vector<double>> c;
+    c.emplace_back(x, x + nx); c.emplace_back(y, y + ny);
+    if (h->nd == 3) c.emplace_back(z, z + nz);
+    h->t->set_coords_rectilinear(c);
+  });
+}
+int ftkx_tracker_set_coords_explicit(ftkx_tracker *h, const double *c, int ncomp, size_t n0, size_t n1)
+{ return guarded(h, [&] { if (!c || ncomp < 2) throw ftkx::ftkx_error(FTKX_E_INVALID, "set_coords_explicit: bad arguments"); h->t->set_coords_explicit(c, ncomp, n0, n1); }); }
 int ftkx_tracker_initialize(ftkx_tracker *h) { return guarded(h, [&] { h->t->initialize(); }); }
 int ftkx_tracker_push_scalar_field_snapshot(ftkx_tracker *h, const double *s, int dev) { return guarded(h, [&] { h->t->push_scalar_field_snapshot(s, dev != 0); }); }
 int ftkx_tracker_push_vector_field_snapshot(ftkx_tracker *h, const double *v, int dev) { return guarded(h, [&] { h->t->push_vector_field_snapshot(v, dev != 0); }); }

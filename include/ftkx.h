@@ -73,8 +73,10 @@ typedef struct ftkx_options {
   int exact_only;           /* 1: never apply the sign cull (every simplex gets the full integer test) */
   int derive_jacobian;      /* 1: when a slice has no J, derive it at hit vertices from V exactly like ndarray/grad.hh
                                jacobian2D/3D would (jacobian_field_source == SOURCE_DERIVED); 0: treat J as absent (zeros) */
-  int coords_mode;          /* 0 REGULAR_COORDS_SIMPLE (lattice integers), 1 REGULAR_COORDS_BOUNDS (set_coords_bounds,
-                               regular_tracker.hh:38; 2d:504-510, 3d:358-365); RECTILINEAR / EXPLICIT are not supported */
+  int coords_mode;          /* REGULAR_COORDS_* (regular_tracker.hh:12-17; simplex_coordinates 2d:494-527, 3d:342-378):
+                               0 SIMPLE (lattice integers), 1 BOUNDS (coords_bounds below), 2 RECTILINEAR and 3 EXPLICIT --
+                               the last two are selected by ftkx_set_coords_rectilinear / ftkx_set_coords_explicit, which
+                               also carry the arrays */
   double coords_bounds[6];  /* x0,x1,y0,y1[,z0,z1] */
 } ftkx_options;
 
@@ -91,6 +93,13 @@ void ftkx_default_options(ftkx_options *opt);
 int ftkx_set_mesh(ftkx_ctx *ctx, const long long domain_st[3], const long long domain_sz[3],
                   const long long core_st[3], const long long core_sz[3],
                   const long long ext_st[3], const long long ext_sz[3]);
+/* regular_tracker::set_coords_rectilinear / set_coords_explicit (regular_tracker.hh:39-40).  Host arrays, copied to the device;
+ * they replace opt.coords_mode.  Rectilinear: one array per spatial axis, indexed by the vertex coordinate (so n_d must cover the
+ * array lattice).  Explicit: ndarray (ncomp, n0, n1) with the first index fastest, read as coords[c + ncomp * (x + n0 * y)];
+ * ncomp >= 2 (2D; a third component becomes x[2]) or 3 (3D -- where the reference reads only this z = 0 plane and reports the
+ * vertex's z index as its time; reproduced).  ftkx_set_options with coords_mode 0 or 1 switches back. */
+int ftkx_set_coords_rectilinear(ftkx_ctx *ctx, const double *x, size_t nx, const double *y, size_t ny, const double *z, size_t nz);
+int ftkx_set_coords_explicit(ftkx_ctx *ctx, const double *coords, int ncomp, size_t n0, size_t n1);
 
 /* ---- slices resident in HBM (== field_data_snapshots, critical_point_tracker.hh:155-159) --------------------- */
 /* V required; J, S nullable.  on_device = 0: host pointers, copied to the device asynchronously; 1: device pointers,

@@ -98,6 +98,11 @@ public:
   void set_type_filter(unsigned int f) { use_type_filter = true; type_filter = f; }
   // regular_tracker.hh:38 -- REGULAR_COORDS_BOUNDS: x0,x1,y0,y1[,z0,z1]
   void set_coords_bounds(const std::vector<double> &b) { bounds_coords = b; mode_phys_coords = 1; }
+  // regular_tracker.hh:39-40 -- REGULAR_COORDS_RECTILINEAR: one coordinate array per axis, indexed by the vertex coordinate;
+  // REGULAR_COORDS_EXPLICIT: ndarray (ncomp, n0, n1), first index fastest
+  void set_coords_rectilinear(const std::vector<std::vector<double>> &c) { rectilinear_coords = c; mode_phys_coords = 2; }
+  void set_coords_explicit(const double *c, int ncomp, size_t n0, size_t n1)
+  { explicit_coords.assign(c, c + (size_t)ncomp * n0 * n1); explicit_ncomp = ncomp; explicit_n0 = n0; explicit_n1 = n1; mode_phys_coords = 3; }
   // tracker.hh:40-41
   void set_current_timestep(int t) { current_timestep = t; }
   int get_current_timestep() const { return current_timestep; }
@@ -163,6 +168,10 @@ protected:
   int tag_mode = FTKX_TAG_REFERENCE;
   int mode_phys_coords = 0;
   std::vector<double> bounds_coords;
+  std::vector<std::vector<double>> rectilinear_coords;
+  std::vector<double> explicit_coords;
+  int explicit_ncomp = 0;
+  size_t explicit_n0 = 0, explicit_n1 = 0;
   bool initialized = false;
 
   int current_timestep = 0;
@@ -201,6 +210,8 @@ int  ftkx_tracker_set_sources(ftkx_tracker *, int scalar, int vector, int jacobi
 int  ftkx_tracker_set_flags(ftkx_tracker *, int robust, int use_type_filter, unsigned type_filter, int compute_degrees, int exact_only, int tag_mode);
 int  ftkx_tracker_set_stream(ftkx_tracker *, void *hip_stream);
 int  ftkx_tracker_set_coords_bounds(ftkx_tracker *, const double *bounds /* 2*nd values */);
+int  ftkx_tracker_set_coords_rectilinear(ftkx_tracker *, const double *x, size_t nx, const double *y, size_t ny, const double *z, size_t nz);
+int  ftkx_tracker_set_coords_explicit(ftkx_tracker *, const double *coords, int ncomp, size_t n0, size_t n1);
 int  ftkx_tracker_initialize(ftkx_tracker *);
 int  ftkx_tracker_push_scalar_field_snapshot(ftkx_tracker *, const double *s, int on_device);
 int  ftkx_tracker_push_vector_field_snapshot(ftkx_tracker *, const double *v, int on_device);

@@ -529,13 +529,30 @@ static u64 element_tag(const sweep_ctx *c, const int *corner, int type, int mode
   return ci * (u64)c->ntypes_all + (u64)type;
 }
 
-/* simplex_coordinates: REGULAR_COORDS_SIMPLE -> the lattice integer; REGULAR_COORDS_BOUNDS ->
- * ((v - array_lb) / double(array_size - 1)) * (b1 - b0) + b0   (2d:504-510, 3d:358-365; array_domain == ext) */
-static inline double phys_coord(const ftko_sweep_args *a, int d, int v)
+/* simplex_coordinates (2d:494-527, 3d:342-378), one vertex -> X[0..3]:
+ *   SIMPLE       the lattice integers
+ *   BOUNDS       ((v - array_lb) / double(array_size - 1)) * (b1 - b0) + b0  per axis (array_domain == ext)
+ *   RECTILINEAR  rectilinear_coords[axis][v]
+ *   EXPLICIT     explicit_coords(c, x, y) for c = 0, 1 (2D: and 2 if the array has a third component, else 0);
+ *                3D reads the SAME three-index expression -- i.e. the z = 0 plane -- and reports vertices[i][2], the z
+ *                index, as the time (3d:371-376): reproduced as written */
+static inline void phys_coords(const ftko_sweep_args *a, int nd, const int *v, double X[4])
 {
-  if (a->coords_mode == 1)
-    return ((double)(unsigned long long)(v - a->ext_st[d]) / (double)(a->ext_sz[d] - 1)) * (a->bounds[2 * d + 1] - a->bounds[2 * d]) + a->bounds[2 * d];
-  return (double)v;
+  X[2] = 0.0;
+  X[3] = (double)v[nd];
+  if (a->coords_mode == 1) {
+    for (int d = 0; d < nd; d ++)
+      X[d] = ((double)(unsigned long long)(v[d] - a->ext_st[d]) / (double)(a->ext_sz[d] - 1)) * (a->bounds[2 * d + 1] - a->bounds[2 * d]) + a->bounds[2 * d];
+  } else if (a->coords_mode == 2) {
+    for (int d = 0; d < nd; d ++) X[d] = a->rect[d][v[d]];
+  } else if (a->coords_mode == 3) {
+    const size_t at = (size_t)a->expl_ncomp * ((size_t)v[0] + (size_t)a->expl_n0 * (size_t)v[1]);
+    X[0] = a->expl[at]; X[1] = a->expl[at + 1];
+    if (nd == 2) X[2] = a->expl_ncomp > 2 ? a->expl[at + 2] : 0.0;
+    else { X[2] = a->expl[at + 2]; X[3] = (double)v[2]; }
+  } else {
+    for (int d = 0; d < nd; d ++) X[d] = (double)v[d];
+  }
 }
 
 static int check_simplex(const sweep_ctx *c, u64 work_index, ftko_rec_t *rec)
@@ -596,7 +613,7 @@ static int check_simplex(const sweep_ctx *c, u64 work_index, ftko_rec_t *rec)
     memset(rec, 0, sizeof(*rec));
     /* simplex_coordinates (REGULAR_COORDS_SIMPLE) + lerp_s2v4, linear_interpolation.hh:83-101 */
     double X[3][4];
-    for (int i = 0; i < 3; i ++) { X[i][0] = phys_coord(a, 0, vx[i][0]); X[i][1] = phys_coord(a, 1, vx[i][1]); X[i][2] = 0.0; X[i][3] = vx[i][2]; }
+    for (int i = 0; i < 3; i ++) phys_coords(a, 2, vx[i], X[i]);
     rec->cp.x[0] = X[0][0] * mu[0] + X[1][0] * mu[1] + X[2][0] * mu[2];
     rec->cp.x[1] = X[0][1] * mu[0] + X[1][1] * mu[1] + X[2][1] * mu[2];
     rec->cp.x[2] = X[0][2] * mu[0] + X[1][2] * mu[1] + X[2][2] * mu[2];
@@ -645,7 +662,7 @@ static int check_simplex(const sweep_ctx *c, u64 work_index, ftko_rec_t *rec)
 
     memset(rec, 0, sizeof(*rec));
     double X[4][4];
-    for (int i = 0; i < 4; i ++) { for (int d = 0; d < 3; d ++) X[i][d] = phys_coord(a, d, vx[i][d]); X[i][3] = vx[i][3]; }
+    for (int i = 0; i < 4; i ++) phys_coords(a, 3, vx[i], X[i]);
     double x[4];
     for (int d = 0; d < 4; d ++) x[d] = X[0][d] * mu[0] + X[1][d] * mu[1] + X[2][d] * mu[2] + X[3][d] * mu[3]; /* lerp_s3v4 :129-139 */
     rec->cp.x[0] = x[0]; rec->cp.x[1] = x[1]; rec->cp.x[2] = x[2]; rec->cp.t = x[3];
@@ -946,6 +963,8 @@ size_t ftko_track(const ftko_track_args *a, ftko_rec_t **out, unsigned long long
   sa.robust = a->robust; sa.use_type_filter = a->use_type_filter; sa.type_filter = a->type_filter;
   sa.compute_degrees = a->compute_degrees; sa.tag_mode = a->tag_mode; sa.nthreads = a->nthreads;
   sa.coords_mode = a->coords_mode; for (int i = 0; i < 6; i ++) sa.bounds[i] = a->bounds[i];
+  for (int i = 0; i < 3; i ++) sa.rect[i] = a->rect[i];
+  sa.expl = a->expl; sa.expl_ncomp = a->expl_ncomp; sa.expl_n0 = a->expl_n0;
   int degenerate = 0;
   for (int d = 0; d < nd; d ++) if (sa.domain_sz[d] <= 0) degenerate = 1;
 

@@ -66,8 +66,12 @@ typedef struct {
   int compute_degrees;                    /* enable_computing_degrees (2D only)                                     */
   int tag_mode;                           /* FTKO_TAG_*                                                             */
   int nthreads;                           /* <=1: serial                                                            */
-  int coords_mode;                        /* 0 REGULAR_COORDS_SIMPLE, 1 REGULAR_COORDS_BOUNDS (regular_tracker.hh:38, 2d:504-510, 3d:358-365) */
+  int coords_mode;                        /* 0 REGULAR_COORDS_SIMPLE, 1 _BOUNDS, 2 _RECTILINEAR, 3 _EXPLICIT (regular_tracker.hh:12-17, 38-40;
+                                             simplex_coordinates 2d:494-527, 3d:342-378)                            */
   double bounds[6];                       /* x0,x1,y0,y1[,z0,z1]                                                    */
+  const double *rect[3];                  /* RECTILINEAR: one array per axis, indexed by the vertex coordinate      */
+  const double *expl;                     /* EXPLICIT: ndarray (expl_ncomp, expl_n0, ...), read as p[c + ncomp*(x + n0*y)] */
+  int expl_ncomp, expl_n0;
 } ftko_sweep_args;
 
 /* returns the number of records, writes a malloc'd array sorted by (corner t,z,y,x, type) to *out (free with ftko_free) */
@@ -117,6 +121,9 @@ typedef struct {
   int nthreads;
   int coords_mode;
   double bounds[6];
+  const double *rect[3];
+  const double *expl;
+  int expl_ncomp, expl_n0;
 } ftko_track_args;
 
 /* returns #records; *out sorted by (t,z,y,x,type); factors[k] (k < DT) = factor in force at the sweep of

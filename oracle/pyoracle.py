@@ -28,6 +28,7 @@ class SweepArgs(C.Structure):
         ("jacobian_symmetric", C.c_int), ("robust", C.c_int), ("use_type_filter", C.c_int),
         ("type_filter", C.c_uint), ("compute_degrees", C.c_int), ("tag_mode", C.c_int), ("nthreads", C.c_int),
         ("coords_mode", C.c_int), ("bounds", C.c_double * 6),
+        ("rect", C.c_void_p * 3), ("expl", C.c_void_p), ("expl_ncomp", C.c_int), ("expl_n0", C.c_int),
     ]
 
 
@@ -38,6 +39,7 @@ class TrackArgs(C.Structure):
         ("robust", C.c_int), ("use_type_filter", C.c_int), ("type_filter", C.c_uint),
         ("compute_degrees", C.c_int), ("tag_mode", C.c_int), ("nthreads", C.c_int),
         ("coords_mode", C.c_int), ("bounds", C.c_double * 6),
+        ("rect", C.c_void_p * 3), ("expl", C.c_void_p), ("expl_ncomp", C.c_int), ("expl_n0", C.c_int),
     ]
 
 
@@ -177,8 +179,9 @@ def synthetic(name, dims, k, DT, x0=None, dirv=None):
 
 
 def sweep(nd, scope, t, domain, core, ext, V, J, S, factor, jacobian_symmetric=True, robust=True,
-          type_filter=None, compute_degrees=False, tag_mode=TAG_EXACT64, nthreads=1):
-    """domain/core/ext = (starts, sizes) spatial.  V/J/S = (cur, next) numpy arrays or None."""
+          type_filter=None, compute_degrees=False, tag_mode=TAG_EXACT64, nthreads=1, explicit=None):
+    """domain/core/ext = (starts, sizes) spatial.  V/J/S = (cur, next) numpy arrays or None.
+    explicit: REGULAR_COORDS_EXPLICIT array of shape (n1, n0, ncomp)."""
     a = SweepArgs()
     a.nd, a.scope, a.current_timestep = nd, scope, t
     for name, (st, sz) in (("domain", domain), ("core", core), ("ext", ext)):
@@ -197,12 +200,16 @@ def sweep(nd, scope, t, domain, core, ext, V, J, S, factor, jacobian_symmetric=T
     a.jacobian_symmetric, a.robust = int(jacobian_symmetric), int(robust)
     a.use_type_filter, a.type_filter = int(type_filter is not None), int(type_filter or 0)
     a.compute_degrees, a.tag_mode, a.nthreads = int(compute_degrees), tag_mode, nthreads
+    if explicit is not None:
+        e = _f64(explicit); keep.append(e)
+        a.coords_mode, a.expl, a.expl_ncomp, a.expl_n0 = 3, e.ctypes.data, e.shape[-1], e.shape[-2]
     out = C.c_void_p()
     n = lib().ftko_sweep(C.byref(a), C.byref(out))
     return _take(out, n)
 
 
-def track(steps, nd, nv, robust=True, type_filter=None, compute_degrees=False, tag_mode=TAG_REFERENCE, nthreads=1, bounds=None):
+def track(steps, nd, nv, robust=True, type_filter=None, compute_degrees=False, tag_mode=TAG_REFERENCE, nthreads=1, bounds=None,
+          rectilinear=None, explicit=None):
     """steps: list of DT numpy arrays (scalar: shape reversed dims; vector: (..., nd)).
     Returns (records, factors[DT], sweep_seconds)."""
     steps = [_f64(s) for s in steps]
@@ -221,6 +228,15 @@ def track(steps, nd, nv, robust=True, type_filter=None, compute_degrees=False, t
         a.coords_mode = 1
         for i, b in enumerate(bounds):
             a.bounds[i] = float(b)
+    keep = []
+    if rectilinear is not None:       # REGULAR_COORDS_RECTILINEAR: one 1-D array per axis
+        a.coords_mode = 2
+        for d, r in enumerate(rectilinear):
+            r = _f64(r); keep.append(r); a.rect[d] = r.ctypes.data
+    if explicit is not None:          # REGULAR_COORDS_EXPLICIT: numpy array of shape (n1, n0, ncomp) = ndarray (ncomp, n0, n1)
+        e = _f64(explicit); keep.append(e)
+        a.coords_mode = 3
+        a.expl, a.expl_ncomp, a.expl_n0 = e.ctypes.data, e.shape[-1], e.shape[-2]
     factors = np.zeros(DT, dtype=np.uint64)
     secs = C.c_double()
     out = C.c_void_p()

@@ -148,6 +148,28 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
   if (type_filter) tracker.set_type_filter(type_filter);
   if (degrees) tracker.set_enable_computing_degrees(true);
   if (!bounds.empty()) tracker.set_coords_bounds(bounds);   // REGULAR_COORDS_BOUNDS, regular_tracker.hh:38
+  // REGULAR_COORDS_RECTILINEAR / _EXPLICIT (regular_tracker.hh:39-40) with closed-form, exactly representable coordinates:
+  //   FTK_REF_COORDS=rect       axis d: 0.5 i + 0.0625 ((i (d + 3)) mod 5) + d
+  //   FTK_REF_COORDS=explicit2  E(c, x, y) = 0.75 (c == 0 ? x : y) + 0.03125 ((3 x + 5 y + c) mod 11), two components
+  //   FTK_REF_COORDS=explicit3  the same with a third component 0.75 + 0.03125 ((3 x + 5 y + 2) mod 11)
+  if (const char *cm = getenv("FTK_REF_COORDS")) {
+    const std::string mode(cm);
+    if (mode == "rect") {
+      std::vector<ftk::ndarray<double>> rc(in.nd);
+      for (int d = 0; d < in.nd; d ++) {
+        rc[d].reshape((size_t)in.D[d]);
+        for (int i = 0; i < in.D[d]; i ++) rc[d][i] = 0.5 * i + 0.0625 * ((i * (d + 3)) % 5) + d;
+      }
+      tracker.set_coords_rectilinear(rc);
+    } else {
+      const int nc = mode == "explicit3" ? 3 : 2;
+      ftk::ndarray<double> ec;
+      ec.reshape((size_t)nc, DW, DH);
+      for (size_t y = 0; y < DH; y ++) for (size_t x = 0; x < DW; x ++) for (int c = 0; c < nc; c ++)
+        ec(c, x, y) = 0.75 * (c == 0 ? (double)x : c == 1 ? (double)y : 1.0) + 0.03125 * (double)((3 * x + 5 * y + c) % 11);
+      tracker.set_coords_explicit(ec);
+    }
+  }
   tracker.initialize();
 
   for (int k = 0; k < in.DT; k ++) {

@@ -37,6 +37,8 @@ def load_golden(name):
         pp=([(int(d["pp_loop"][i]), d["pp_tags"][d["pp_offsets"][i]:d["pp_offsets"][i + 1]], d["pp_types"][d["pp_offsets"][i]:d["pp_offsets"][i + 1]],
               d["pp_t"][d["pp_offsets"][i]:d["pp_offsets"][i + 1]]) for i in range(len(d["pp_loop"]))] if "pp_loop" in d else None),
         x0dir=d["x0dir"] if "x0dir" in d else None,
+        rectilinear=[d[f"rect{i}"] for i in range(int(d["nd"]))] if "rect0" in d else None,
+        explicit=d["explicit"] if "explicit" in d else None,
     )
 
 

@@ -6,7 +6,7 @@ import ftk_amd
 
 
 def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=False, tag_mode=ftk_amd.TAG_REFERENCE, device=False,
-                compute_degrees=False, bounds=None, want_curves=False, after=None):
+                compute_degrees=False, bounds=None, want_curves=False, after=None, rectilinear=None, explicit=None):
     """returns (records, ordinal, timestep, factors[DT], stats_list)"""
     import torch
     T = ftk_amd.CriticalPointTracker2DRegular if nd == 2 else ftk_amd.CriticalPointTracker3DRegular
@@ -29,6 +29,10 @@ def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=Fals
     tr.set_enable_computing_degrees(compute_degrees)
     if bounds is not None:
         tr.set_coords_bounds(bounds)
+    if rectilinear is not None:
+        tr.set_coords_rectilinear(rectilinear)
+    if explicit is not None:
+        tr.set_coords_explicit(explicit)
     tr.set_tag_mode(tag_mode)
     tr.initialize()
     DT = len(steps)

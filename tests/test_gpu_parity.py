@@ -29,7 +29,7 @@ def test_tracker_matches_reference_fixture(gpu, name, exact_only):
     from gpu_common import run_tracker
     g = load_golden(name)
     recs, factors, stats = run_tracker(g["steps"], g["nd"], g["nv"], robust=g["robust"], type_filter=g["type_filter"], exact_only=exact_only,
-                                       compute_degrees=g["degrees"], bounds=g["bounds"])
+                                       compute_degrees=g["degrees"], bounds=g["bounds"], rectilinear=g["rectilinear"], explicit=g["explicit"])
     assert np.array_equal(factors, g["factors"]), "per-step quantisation factor differs from the reference"
     assert_records_equal(recs, g["records"], coord_tol=COORD_TOL, what=name)
     assert_records_equal(recs, g["records"], coord_tol=0.0, what=name + " (bit-exact)")
@@ -91,6 +91,30 @@ def test_boundary_call_with_given_fields(gpu, oracle, name):
             refr[fld] = ref[fld]
         assert_records_equal(got, refr, coord_tol=0.0, what=f"{name} scope {scope}")
         assert np.array_equal(got["aux"] & 1, np.full(len(got), 1 if scope == gpu.SCOPE_ORDINAL else 0))
+
+
+def test_boundary_call_with_explicit_coords(gpu, oracle):
+    """extract_cp2dt(..., use_explicit_coords = true, coords): the boundary's (2, DW, DH) vertex coordinates"""
+    g = load_golden("random_2d_scalar_29x24x6_explicit2")
+    D = g["dims"]
+    dom = ([2, 2], [d - 3 for d in D])
+    S0, S1 = g["steps"][0], g["steps"][1]
+    V0, V1 = oracle.gradient2D(S0), oracle.gradient2D(S1)
+    J0, J1 = oracle.jacobian2D(V0, True), oracle.jacobian2D(V1, True)
+    factor, _ = oracle.scaling_factor(min(oracle.resolution(V0), oracle.resolution(V1)))
+    opt = gpu.default_options(jacobian_symmetric=1, tag_mode=gpu.TAG_WORK_INDEX)
+    for scope in (gpu.SCOPE_ORDINAL, gpu.SCOPE_INTERVAL):
+        ref = oracle.sweep(2, scope, 0, dom, dom, ([0, 0], D), (V0, V1), (J0, J1), (S0, S1), factor, jacobian_symmetric=True,
+                           tag_mode=oracle.TAG_WORK_INDEX, explicit=g["explicit"])
+        nxt = scope == gpu.SCOPE_INTERVAL
+        got = gpu.extract_cp2dt(scope, 0, (dom[0] + [0], dom[1] + [2 ** 31 - 1]), (dom[0] + [0], dom[1] + [1]), ([0, 0], D),
+                                V0, V1 if nxt else None, J0, J1 if nxt else None, S0, S1 if nxt else None, factor, opt, coords=g["explicit"])
+        refr = np.zeros(len(ref), dtype=got.dtype)
+        for fld in ("x", "t", "scalar", "type", "tag"):
+            refr[fld] = ref[fld]
+        assert len(got) > 20
+        assert_records_equal(got, refr, coord_tol=0.0, what=f"explicit coords, scope {scope}")
+        assert not np.array_equal(got["x"][:, 0], np.round(got["x"][:, 0]))      # really not lattice coordinates
 
 
 def test_derived_fields_bit_identical(gpu, oracle):

@@ -27,7 +27,8 @@ KNOWN_COUNTS = {
 def test_oracle_matches_reference_records(oracle, name):
     g = load_golden(name)
     recs, factors, _ = oracle.track(g["steps"], g["nd"], g["nv"], robust=g["robust"], type_filter=g["type_filter"],
-                                    compute_degrees=g["degrees"], bounds=g["bounds"], tag_mode=oracle.TAG_REFERENCE, nthreads=4)
+                                    compute_degrees=g["degrees"], bounds=g["bounds"], tag_mode=oracle.TAG_REFERENCE, nthreads=4,
+                                   rectilinear=g["rectilinear"], explicit=g["explicit"])
     assert np.array_equal(factors, g["factors"]), "per-step quantisation factor differs"
     assert_records_equal(recs, g["records"], coord_tol=0.0, what=name)
 
