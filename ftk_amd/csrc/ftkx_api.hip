@@ -91,6 +91,9 @@ struct ftkx_ctx {
   // per-batch descriptors: pinned staging + device copies
   void *h_desc = nullptr, *d_desc = nullptr;
   size_t desc_cap = 0;
+  // mask / summary arrays of dropped slices, kept for the next slice (a streaming tracker pushes and pops one slice per step:
+  // hipMalloc + hipFree per step cost more than the sweep itself).  Their padding bytes stay valid: kernels never write them.
+  std::vector<unsigned char *> pool_M, pool_U;
   // physical coordinates (REGULAR_COORDS_RECTILINEAR / _EXPLICIT): device copies
   double *d_rect[3] = {nullptr, nullptr, nullptr};
   size_t rect_n[3] = {0, 0, 0};
@@ -142,14 +145,21 @@ int u_pitch(const ftkx_ctx *c) { return (int)((((c->ext_sz[0] + 7) / 8 + 7) / 8)
 size_t u_bytes(const ftkx_ctx *c) { return (size_t)u_pitch(c) * (size_t)c->ext_sz[1] * (size_t)(c->nd == 3 ? c->ext_sz[2] : 1); }
 size_t mask_bytes(const ftkx_ctx *c) { return (size_t)mask_pitch(c) * (size_t)c->ext_sz[1] * (size_t)(c->nd == 3 ? c->ext_sz[2] : 1); }
 
-void free_slice(Slice &s)
+void free_slice(Slice &s, ftkx_ctx *pool_owner = nullptr)
 {
   if (s.ownV && s.V) (void)hipFree(s.V);
   if (s.ownJ && s.J) (void)hipFree(s.J);
   if (s.ownS && s.S) (void)hipFree(s.S);
-  if (s.M) (void)hipFree(s.M);
-  if (s.U) (void)hipFree(s.U);
+  if (s.M) { if (pool_owner && pool_owner->pool_M.size() < 4) pool_owner->pool_M.push_back(s.M); else (void)hipFree(s.M); }
+  if (s.U) { if (pool_owner && pool_owner->pool_U.size() < 4) pool_owner->pool_U.push_back(s.U); else (void)hipFree(s.U); }
   s = Slice();
+}
+
+void release_pools(ftkx_ctx *c)
+{
+  for (unsigned char *p : c->pool_M) (void)hipFree(p);
+  for (unsigned char *p : c->pool_U) (void)hipFree(p);
+  c->pool_M.clear(); c->pool_U.clear();
 }
 
 int ensure_hit_buffer(ftkx_ctx *c, u64 want)
@@ -364,13 +374,20 @@ int run_batch(ftkx_ctx *c)
       for (Slice *s : {&s0, s1}) {
         if (!s) continue;
         if (!s->M) {
-          HIP_TRY(c, hipMalloc((void **)&s->M, mask_bytes(c)));
-          // row padding and anything a kernel does not write is cull-neutral
-          HIP_TRY(c, hipMemsetAsync(s->M, 0x3f, mask_bytes(c), c->stream));
+          if (!c->pool_M.empty()) { s->M = c->pool_M.back(); c->pool_M.pop_back(); }   // padding still neutral from its first life
+          else {
+            HIP_TRY(c, hipMalloc((void **)&s->M, mask_bytes(c)));
+            // row padding and anything a kernel does not write is cull-neutral
+            HIP_TRY(c, hipMemsetAsync(s->M, 0x3f, mask_bytes(c), c->stream));
+          }
+          s->mask_factor = 0;
         }
         if (two_level && !s->U) {
-          HIP_TRY(c, hipMalloc((void **)&s->U, u_bytes(c)));
-          HIP_TRY(c, hipMemsetAsync(s->U, 0x3f, u_bytes(c), c->stream));
+          if (!c->pool_U.empty()) { s->U = c->pool_U.back(); c->pool_U.pop_back(); }
+          else {
+            HIP_TRY(c, hipMalloc((void **)&s->U, u_bytes(c)));
+            HIP_TRY(c, hipMemsetAsync(s->U, 0x3f, u_bytes(c), c->stream));
+          }
           s->mask_factor = 0;      // summaries must be produced together with the masks
         }
         if (s->mask_factor != r.factor) {
@@ -493,6 +510,7 @@ void ftkx_destroy(ftkx_ctx *c)
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto &kv : c->slices) free_slice(kv.second);
+  release_pools(c);
   if (c->d_hits) (void)hipFree(c->d_hits);
   if (c->d_list) (void)hipFree(c->d_list);
   if (c->d_refine) (void)hipFree(c->d_refine);
@@ -568,6 +586,8 @@ int ftkx_set_mesh(ftkx_ctx *c, const long long dst[3], const long long dsz[3], c
 {
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   if (!c->slices.empty()) return fail(c, FTKX_E_INVALID, "ftkx_set_mesh: drop all slices first");
+  (void)hipSetDevice(c->device);
+  release_pools(c);                       // pooled mask arrays have the old lattice's size
   for (int d = 0; d < c->nd; d ++) {
     if (dsz[d] < 0 || csz[d] < 0 || esz[d] <= 0) return fail(c, FTKX_E_INVALID, "ftkx_set_mesh: negative size on axis %d", d);
     if (dst[d] + dsz[d] > 2147483647LL || est[d] + esz[d] > 2147483647LL || cst[d] + csz[d] > 2147483647LL)
@@ -595,7 +615,7 @@ static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, con
     return fail(c, FTKX_E_INVALID, "push: scalar and vector slices cannot be mixed in one context");
   HIP_TRY(c, hipSetDevice(c->device));
   auto it = c->slices.find(t);
-  if (it != c->slices.end()) { free_slice(it->second); c->slices.erase(it); }
+  if (it != c->slices.end()) { free_slice(it->second, c); c->slices.erase(it); }
   Slice s;
   const size_t n = n_vertices(c);
   const int nd = c->nd;
@@ -634,7 +654,7 @@ int ftkx_drop_slice(ftkx_ctx *c, int t)
   if (it == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "ftkx_drop_slice: timestep %d not resident", t);
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_drop_slice: sweeps pending, collect first");
   (void)hipSetDevice(c->device);
-  free_slice(it->second);
+  free_slice(it->second, c);
   c->slices.erase(it);
   return FTKX_OK;
 }
