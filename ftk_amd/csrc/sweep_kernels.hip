@@ -1120,6 +1120,201 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Producer / consumer form of the same walk (3D, 128-column layout).  The debug bits of mask_march4_kernel show its loads alone
+// take 6.1 ms on 512^3 x 32 and the sign arithmetic adds 0.5-1 ms on top: a wavefront that is computing is not issuing loads.
+// Here the two jobs belong to different wavefronts of a workgroup:
+//   * ONE producer wavefront streams the workgroup's tile of every plane -- 16 rows + 2 halo rows of 128 columns, plus the two
+//     outside-neighbour columns -- straight into LDS with LDS-DMA buffer loads (no VGPRs, PD planes ahead), each row ONCE per
+//     workgroup (the four consumers share their halo rows through LDS instead of each re-requesting them from L2);
+//   * FOUR consumer wavefronts (4 rows each) take the next plane from LDS, keep planes k-1, k, k+1 in registers rotating by
+//     name, and do exactly mask_march4_kernel's arithmetic and stores.
+// One s_barrier per plane: when it is passed, plane k+1 has landed (the producer waited for it with s_waitcnt vmcnt) and every
+// consumer has finished reading plane k's slot, which the producer then refills with plane k+1+PD.  Same mask / summary bytes.
+// ---------------------------------------------------------------------------------------------------------------
+// TW = tile width in 128-column units (consumers side by side in x take their x neighbours from the shared LDS row, only the
+// tile's outer columns are fetched separately), CY x RY = tile rows, PD = planes in flight beyond the one consumed next.
+template <int PD, int TW, int CY, int RY>
+__global__ __launch_bounds__(64 * (TW * CY + 1)) void mask_march5_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass silently drops the stub of a kernel whose body uses the LDS-DMA builtin: give it an empty body
+  constexpr int CW = TW * CY, ROWS = RY * CY, TROWS = ROWS + 2, NS = PD + 1;
+  static_assert(ROWS <= 32, "the edge values of a plane are fetched by one wavefront instruction: 2 x ROWS lanes");
+  constexpr unsigned ROWB = 1024u * TW, EDGEB = 512, SLOT = TROWS * ROWB + EDGEB;
+  constexpr int LOADS_PER_PLANE = TROWS * TW + 2;              // row DMAs + the two halves of the edge values
+  static_assert(LOADS_PER_PLANE * (PD - 1) < 64, "vmcnt is a 6-bit counter: the wait below must be expressible (issue simply stalls beyond 63 in flight)");
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // NS slots
+  const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = m.ext_sz[2], P = m.mask_pitch;
+  const int nzc = (DD + zchunk - 1) / zchunk;
+  unsigned bx, by, bz;
+  remap_block(swizzle, bx, by, bz);
+  const MaskJob job = jobs[bz / nzc];
+  const int z0 = (int)(bz % nzc) * zchunk;
+  const int z1 = z0 + zchunk < DD ? z0 + zchunk : DD;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int jb = (int)by * ROWS;                               // the workgroup's first own row
+  const int t0c = (int)bx * 128 * TW;                          // and first column
+  if (jb >= DH) return;                                        // whole workgroup: no barrier is left waiting
+  const unsigned sy = (unsigned)DW * 8u, sz = (unsigned)DW * (unsigned)DH * 8u;
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void *)job.S, 0, (int)(sz * (unsigned)DD), 0x00020000);
+  const int nsteps = ((z1 - z0 + 2) / 3) * 3;                  // both roles walk the same, padded number of planes (3 = consumer unroll)
+  auto slot_of = [&](int q) -> unsigned { return (unsigned)(((q - (z0 - 1)) % NS + NS) % NS) * SLOT; };
+
+  if (wv == CW) {
+    // ---------------- producer ----------------
+    // column pair of this lane in each 128-column piece, clamped so that lanes beyond the row load valid memory
+    unsigned cb[TW];
+    for (int p = 0; p < TW; p ++) { const int i = t0c + 128 * p + 2 * lane; cb[p] = (unsigned)(i < DW ? i : DW - 2) * 8u; }
+    // edge values: lane l < ROWS fetches the left neighbour of own row l, lane 32 + l the right one; low and high dwords separately
+    unsigned eoff = 0xfffffff0u, eoff_hi = 0xfffffff0u;
+    if ((lane & 31) < ROWS) {
+      const int row = lane & 31;
+      const int col = lane < 32 ? (t0c > 0 ? t0c - 1 : 0) : (t0c + 128 * TW < DW ? t0c + 128 * TW : DW - 1);
+      eoff = sy * (unsigned)clampi(jb + row, 0, DH - 1) + (unsigned)col * 8u;
+      eoff_hi = eoff + 4u;
+    }
+    unsigned roff[TROWS];
+    for (int t = 0; t < TROWS; t ++) roff[t] = sy * (unsigned)clampi(jb + t - 1, 0, DH - 1);
+    const bool nt_all = (swizzle & 4) != 0, nt_private = (swizzle & 16) != 0;
+    auto issue = [&](int q) {
+      const unsigned zo = sz * (unsigned)clampi(q, 0, DD - 1);
+      const unsigned base = slot_of(q);
+      for (int t = 0; t < TROWS; t ++)
+        for (int p = 0; p < TW; p ++) {
+          __attribute__((address_space(3))) void *dst = (__attribute__((address_space(3))) void *)(lds + base + (unsigned)t * ROWB + (unsigned)p * 1024u);
+          // rows 0 and TROWS-1 are own rows of the neighbouring workgroups, rows 1 and TROWS-2 their halo rows: leave those cached
+          const bool nt = nt_all || (nt_private && t >= 2 && t <= TROWS - 3);
+          if (nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, dst, 16, cb[p], zo + roff[t], 0, 2);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, dst, 16, cb[p], zo + roff[t], 0, 0);
+        }
+      __attribute__((address_space(3))) void *elo = (__attribute__((address_space(3))) void *)(lds + base + TROWS * ROWB);
+      __attribute__((address_space(3))) void *ehi = (__attribute__((address_space(3))) void *)(lds + base + TROWS * ROWB + 256);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, elo, 4, eoff, zo, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, ehi, 4, eoff_hi, zo, 0, 0);   // (an instruction offset would shift the LDS address as well)
+    };
+    // s_waitcnt vmcnt(N) only: gfx9 encoding, vmcnt = simm16[15:14]:[3:0], expcnt [6:4], lgkmcnt [11:8] left at their maxima
+#define FTKX_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))
+    issue(z0 - 1); issue(z0);
+    FTKX_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();                              // P1: planes z0-1 and z0 are in LDS
+    __builtin_amdgcn_s_barrier();                              // P2: the consumers have taken them
+    for (int q = z0 + 1; q <= z0 + PD; q ++) issue(q < z1 ? q : z1);
+    for (int s = 0; s < nsteps; s ++) {
+      const int k = z0 + s;
+      FTKX_WAIT_VM(LOADS_PER_PLANE * (PD - 1));                 // plane k+1 has landed (planes k+2 .. k+PD may still be on their way)
+      __builtin_amdgcn_s_barrier();
+      const int q = k + 1 + PD;
+      issue(q < z1 ? q : z1);                                  // into the slot of plane k, which every consumer has finished with
+    }
+    FTKX_WAIT_VM(0);                                           // nothing may still be writing LDS when the workgroup retires
+#undef FTKX_WAIT_VM
+    return;
+  }
+
+  // ---------------- consumers ----------------
+  const int wx = wv % TW, wy = wv / TW;                        // position of this wavefront's 128 x RY patch inside the tile
+  const int i0 = t0c + 128 * wx + 2 * lane;
+  const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)job.M, 0, (int)((unsigned)P * (unsigned)DH * (unsigned)DD), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)job.U, 0, (int)((unsigned)m.u_pitch * (unsigned)DH * (unsigned)DD), 0x00020000);
+  const bool have_u = job.U != nullptr;
+  const double thr = job.threshold;
+  const double tpos = 2.0 * thr, tneg = -tpos;
+  const int j0 = jb + wy * RY;                                 // this wavefront's first own row
+  unsigned xkeep = 0, xneutral = 0;
+  for (int c = 0; c < 2; c ++) {
+    const int i = i0 + c;
+    const bool x_dom = i < DW && i + m.ext_st[0] >= m.dom_lb[0] && i + m.ext_st[0] <= m.dom_ub[0];
+    const bool x_int = i >= 1 && i < DW - 1;
+    if (x_int) xkeep |= 0x3fu << (8 * c);
+    if (!x_dom) xneutral |= 0x3fu << (8 * c);
+  }
+  unsigned row_dom = 0, row_int = 0, row_ok = 0;
+  for (int r = 0; r < RY; r ++) {
+    const int j = j0 + r;
+    if (j < DH) row_ok |= 1u << r;
+    if (j + m.ext_st[1] >= m.dom_lb[1] && j + m.ext_st[1] <= m.dom_ub[1]) row_dom |= 1u << r;
+    if (j >= 1 && j < DH - 1) row_int |= 1u << r;
+  }
+  const bool in_row = i0 < DW;
+  const bool debug_no_store = (swizzle & 2) != 0 && bits_dummy_guard(thr);
+  const bool store_ok = in_row && !debug_no_store;
+  const unsigned mcol = (unsigned)i0, ucol = (unsigned)(i0 >> 3);
+  const bool u_lane = (lane & 3) == 0 && in_row;
+  // LDS addresses of this lane inside a slot: its 16 bytes of a row, and where the two dwords of the neighbour value it carries in
+  // the fused edge register live (lane r < RY: left neighbour of own row r; lane 64 - RY + r: right neighbour; see edge_for_row):
+  // inside the tile that is the adjacent column of the same LDS row, at the tile's outer columns the separately fetched values
+  const unsigned lrow = (unsigned)(wx * 1024 + lane * 16);
+  unsigned elo_at = 0, ehi_at = 0;
+  {
+    const bool left = lane < 32;
+    const int er = lane < RY ? lane : (lane >= 64 - RY ? lane - (64 - RY) : 0);
+    const int trow = wy * RY + er;                            // own row index inside the tile (tile row trow + 1)
+    if (left ? wx > 0 : wx < TW - 1) {
+      elo_at = (unsigned)(trow + 1) * ROWB + (unsigned)(left ? wx * 1024 - 8 : (wx + 1) * 1024);
+      ehi_at = elo_at + 4u;
+    } else {
+      elo_at = TROWS * ROWB + (unsigned)((left ? 0 : 32) + trow) * 4u;
+      ehi_at = elo_at + 256u;
+    }
+  }
+  auto take_plane = [&](v2d (&B)[RY + 2], double &X, int q) {
+    const char *base = lds + slot_of(q);
+    for (int r = 0; r < RY + 2; r ++) B[r] = *reinterpret_cast<const v2d *>(base + (unsigned)(wy * RY + r) * ROWB + lrow);
+    const unsigned lo = *reinterpret_cast<const unsigned *>(base + elo_at), hi = *reinterpret_cast<const unsigned *>(base + ehi_at);
+    X = __longlong_as_double(((long long)hi << 32) | lo);
+  };
+
+  auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], v2d (&NX)[RY + 2], const double XC, double &XN, int k) {
+    __builtin_amdgcn_s_barrier();                              // plane k+1 is in LDS; nobody reads plane k's slot any more
+    take_plane(NX, XN, k + 1 < z1 ? k + 1 : z1);
+    const bool z_dom = k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2];
+    const bool z_int = k >= 1 && k < DD - 1;
+    const unsigned mplane = (unsigned)P * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
+    const unsigned uplane = (unsigned)m.u_pitch * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
+    static_for<RY>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      const v2d c = CU[r + 1];
+      const double xe = edge_for_row<r, RY>(XC);
+      const double xm = dpp_lower_or(c.y, xe), xp = dpp_upper_or(c.x, xe);
+      const double dx0 = c.y - xm, dx1 = xp - c.x;
+      const double dy0 = CU[r + 2].x - CU[r].x, dy1 = CU[r + 2].y - CU[r].y;
+      const double dz0 = NX[r + 1].x - PR[r + 1].x, dz1 = NX[r + 1].y - PR[r + 1].y;
+      const bool u_int = ((row_int >> r) & 1) && z_int, u_dom = ((row_dom >> r) & 1) && z_dom;
+      unsigned a0 = 0, a1 = 0;
+      shift_in_signs<3>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, tneg, tpos);
+      unsigned bits = a0 | (a1 << 8);
+      const unsigned keep = u_int ? xkeep : 0u;
+      const unsigned neut = u_dom ? xneutral : 0x3f3fu;
+      bits = (bits & keep) | neut;
+      bool word_uniform = false;
+      const bool rok = ((row_ok >> r) & 1) && k < z1;
+      if (have_u) {
+        int q = (int)((bits & (bits >> 8)) & 0x3fu);
+        q &= __builtin_amdgcn_update_dpp(q, q, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+        q &= __builtin_amdgcn_update_dpp(q, q, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
+        if (rok && u_lane) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)q, rU, ucol, uplane + (unsigned)m.u_pitch * (unsigned)r, 0);
+        word_uniform = q != 0;
+      }
+      if (rok && store_ok && !word_uniform)
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rM, mcol, mplane + (unsigned)P * (unsigned)r, 0);
+    });
+  };
+
+  v2d B[3][RY + 2];
+  double X[3] = {0.0, 0.0, 0.0};
+  __builtin_amdgcn_s_barrier();                                // P1
+  take_plane(B[0], X[0], z0 - 1);
+  take_plane(B[1], X[1], z0);
+  __builtin_amdgcn_s_barrier();                                // P2 (the compiler has waited for the LDS reads above: their values are used)
+  for (int s = 0; s < nsteps; s += 3) {
+    step(B[0], B[1], B[2], X[1], X[2], z0 + s);
+    step(B[1], B[2], B[0], X[2], X[0], z0 + s + 1);
+    step(B[2], B[0], B[1], X[0], X[1], z0 + s + 2);
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // FAST PATH 2/3: corner cull on the mask bytes, 8 corners per lane (SWAR), survivors -> work list
 // ---------------------------------------------------------------------------------------------------------------
 // list entry: bits 0..39 corner index inside core (x fastest), bits 40..41 scope flags (1 ordinal, 2 interval), bits 44.. step
@@ -1578,6 +1773,39 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       const dim3 blk((unsigned)(64 * wpb));
       bool diet = use_edge;                                   // the VALU-diet kernel implements the 128-column layout only
       if (const char *e = getenv("FTKX_MASK_V")) diet = diet && atoi(e) != 2;
+      if (diet && m.nd == 3 && !reduce) {
+        // default for 3D scalar slices: the producer / consumer kernel, 128 x 16 tiles, two planes in flight behind the one being
+        // consumed (6.3 vs 6.7 ms for mask_march4_kernel on 512^3 x 32, same box); FTKX_MASK_V=4 selects the latter
+        int v5 = 1, pd5 = 2;
+        if (const char *e = getenv("FTKX_MASK_V")) v5 = atoi(e) == 5 || atoi(e) == 0;
+        if (const char *e = getenv("FTKX_MASK_PD")) pd5 = atoi(e);
+        if (v5) {
+          int shape = 0;                                         // FTKX_MASK_TILE: 0 = 128 x 16, 1 = 256 x 16, 2 = 512 x 16 (RY 8), 3 = 256 x 32, 4..7 below
+          if (const char *e = getenv("FTKX_MASK_TILE")) shape = atoi(e);
+#define FTKX_M5(PD_, TW_, CY_, RY_) do { \
+            const int tw = TW_, rows = CY_ * RY_; \
+            const dim3 grid5((unsigned)((m.ext_sz[0] + 128 * tw - 1) / (128 * tw)), (unsigned)((m.ext_sz[1] + rows - 1) / rows), grid2.z); \
+            int sw = swizzle; \
+            if (sw & 8) { int yg = (sw >> 8) & 0xff; if (yg < 1) yg = 1; while (yg > 1 && grid5.y % (unsigned)yg) yg --; sw = (sw & 0xff) | (yg << 8); } \
+            const unsigned slot = (unsigned)(rows + 2) * 1024u * (unsigned)tw + 512u, bytes = (unsigned)(PD_ + 1) * slot; \
+            (void)hipFuncSetAttribute((const void *)mask_march5_kernel<PD_, TW_, CY_, RY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+            hipLaunchKernelGGL((mask_march5_kernel<PD_, TW_, CY_, RY_>), grid5, dim3(64u * (TW_ * CY_ + 1)), bytes, stream, m, d_jobs, zchunk, sw); } while (0)
+          if (shape == 1) { if (pd5 == 2) FTKX_M5(2, 2, 4, 4); else FTKX_M5(1, 2, 4, 4); }
+          else if (shape == 2) FTKX_M5(1, 4, 2, 8);
+          else if (shape == 3) FTKX_M5(1, 2, 4, 8);
+          else if (shape == 4) { if (pd5 == 3) FTKX_M5(3, 1, 2, 4); else FTKX_M5(2, 1, 2, 4); }     // 128 x 8
+          else if (shape == 5) { if (pd5 == 3) FTKX_M5(3, 1, 8, 2); else FTKX_M5(2, 1, 8, 2); }     // 128 x 16, eight consumers of 2 rows
+          else if (shape == 6) { if (pd5 == 2) FTKX_M5(2, 1, 8, 4); else FTKX_M5(1, 1, 8, 4); }     // 128 x 32
+          else if (shape == 7) { if (pd5 == 3) FTKX_M5(3, 1, 2, 8); else FTKX_M5(2, 1, 2, 8); }     // 128 x 16, two consumers of 8 rows
+          else if (shape == 8) { if (pd5 == 3) FTKX_M5(3, 1, 3, 4); else FTKX_M5(2, 1, 3, 4); }     // 128 x 12: three workgroups per CU
+          else if (shape == 9) { if (pd5 == 3) FTKX_M5(3, 1, 5, 4); else FTKX_M5(2, 1, 5, 4); }     // 128 x 20
+          else if (pd5 == 2) FTKX_M5(2, 1, 4, 4);
+          else if (pd5 == 3) FTKX_M5(3, 1, 4, 4);
+          else FTKX_M5(1, 1, 4, 4);
+#undef FTKX_M5
+          return;
+        }
+      }
       if (diet) {
         int pd = 1, ry = (m.nd == 3) ? 4 : 8;
         if (const char *e = getenv("FTKX_MASK_PD")) pd = atoi(e);
