@@ -57,12 +57,12 @@ def cpu_baseline(nd, case, want_seconds=20.0):
     ncores = os.cpu_count() or 1
     drv = os.path.join(ROOT, "oracle", "_ref", "ftk_ref_driver")
     if nd == 3:
-        dims, nt = (64, 64, 64), 4
+        dims, nt = (96, 96, 96), 6            # 2.5e8 simplices: 15-20 s of the reference's sweep on this class of host
         x0, dv = me3d_params(dims)
         sample = f"moving_extremum_3d {dims[0]}x{dims[1]}x{dims[2]}x{nt} sub-volume, same dyadic x0 offset / dir"
         extra = [repr(v) for v in x0 + dv]
     else:
-        dims, nt = (192, 192), 8
+        dims, nt = (768, 768), 16             # 1.1e8 simplices
         sample = f"{case} {dims[0]}x{dims[1]}x{nt} sub-volume"
         extra = []
     nsimp = tslab.count_simplices(nd, dims, nt, scalar_input=(case != "double_gyre"))
