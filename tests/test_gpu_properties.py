@@ -129,6 +129,7 @@ def test_reference_and_exact_tags_agree_without_overflow(gpu):
 
 
 @pytest.mark.parametrize("case,dims,nt,rough", [("moving_extremum_3d", (256, 128, 72), 4, False), ("moving_extremum_3d", (130, 70, 40), 3, True),
+                                                ("moving_extremum_3d", (126, 33, 6), 3, True), ("moving_extremum_3d", (386, 50, 35), 2, True),
                                                 ("woven", (1024, 512), 5, False), ("woven", (258, 100), 4, True)])
 def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
     """The marching mask kernel exists in two generations with the same 128-column layout (mask_march2_kernel<.., EDGE> and the
