@@ -1799,6 +1799,8 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
           else if (shape == 7) { if (pd5 == 3) FTKX_M5(3, 1, 2, 8); else FTKX_M5(2, 1, 2, 8); }     // 128 x 16, two consumers of 8 rows
           else if (shape == 8) { if (pd5 == 3) FTKX_M5(3, 1, 3, 4); else FTKX_M5(2, 1, 3, 4); }     // 128 x 12: three workgroups per CU
           else if (shape == 9) { if (pd5 == 3) FTKX_M5(3, 1, 5, 4); else FTKX_M5(2, 1, 5, 4); }     // 128 x 20
+          else if (shape == 10) FTKX_M5(2, 1, 6, 4);                                                  // 128 x 24: two workgroups fill the LDS exactly
+          else if (shape == 11) FTKX_M5(2, 1, 3, 8);                                                  // 128 x 24, three consumers of 8 rows
           else if (pd5 == 2) FTKX_M5(2, 1, 4, 4);
           else if (pd5 == 3) FTKX_M5(3, 1, 4, 4);
           else FTKX_M5(1, 1, 4, 4);
