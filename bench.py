@@ -148,8 +148,14 @@ def main():
     halo_buf = torch.empty_like(slices[own[0]]) if (world > 1 and own) else None
     torch.cuda.synchronize()
 
+    # the first call also loads the reduction kernel's code object (a one-time cost of a few ms): run it once, hand the slices
+    # over again (adopting a device pointer is free and forgets the cached reduction), and time the second pre-pass
+    ctx.slices_resolution(own)
+    for t in own:
+        (ctx.push_scalar_slice if scalar_input else ctx.push_slice)(t, slices[t])
+    torch.cuda.synchronize()
     tp0 = time.perf_counter()
-    local_rm = {t: ctx.slice_resolution(t) for t in own}
+    local_rm = ctx.slices_resolution(own)      # one reduction launch over the whole slab, one round trip
     local_res = {t: v[0] for t, v in local_rm.items()}
     if world > 1:
         factors, all_res, all_max = tslab.global_factors(local_res, nt, local_max={t: v[1] for t, v in local_rm.items()})

@@ -122,6 +122,14 @@ class Context:
         self._ck(self._L.ftkx_slice_resolution(self._h, t, C.byref(r), C.byref(m)))
         return r.value, m.value
 
+    def slices_resolution(self, ts):
+        """slice_resolution for several resident slices with one launch and one synchronise -> {t: (resolution, max_abs)}"""
+        ts = [int(t) for t in ts]
+        n = len(ts)
+        tt = (C.c_int * max(1, n))(*ts); r = (C.c_double * max(1, n))(); m = (C.c_double * max(1, n))()
+        self._ck(self._L.ftkx_slices_resolution(self._h, tt, n, r, m))
+        return {ts[i]: (r[i], m[i]) for i in range(n)}
+
     def set_slice_resolution(self, t, resolution, max_abs):
         self._ck(self._L.ftkx_set_slice_resolution(self._h, t, float(resolution), float(max_abs)))
 

@@ -94,6 +94,8 @@ struct ftkx_ctx {
   // mask / summary arrays of dropped slices, kept for the next slice (a streaming tracker pushes and pops one slice per step:
   // hipMalloc + hipFree per step cost more than the sweep itself).  Their padding bytes stay valid: kernels never write them.
   std::vector<unsigned char *> pool_M, pool_U;
+  u64 *d_red = nullptr;             // {min, max} slots of a batched resolution reduction: 128 words per slice
+  size_t red_cap = 0;
   // physical coordinates (REGULAR_COORDS_RECTILINEAR / _EXPLICIT): device copies
   double *d_rect[3] = {nullptr, nullptr, nullptr};
   size_t rect_n[3] = {0, 0, 0};
@@ -282,6 +284,12 @@ bool overflow_free(int nd, double maxabs, u64 factor)
   const long double M = floorl((long double)maxabs * (long double)factor) + 1.0L;
   const long double lim = 9223372036854775807.0L;
   return nd == 3 ? 24.0L * M * M * M < lim : 6.0L * M * M < lim;
+}
+
+__global__ void init_red_kernel(u64 *red, size_t nslots)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nslots) { red[2 * i] = 0x7fefffffffffffffull; red[2 * i + 1] = 0ull; }   // {min = DBL_MAX, max = 0} as bit patterns
 }
 
 __global__ void sort_keys_kernel(const ftkx_cp_t *__restrict__ hits, size_t n, u64 *__restrict__ keys, unsigned *__restrict__ idx)
@@ -511,6 +519,7 @@ void ftkx_destroy(ftkx_ctx *c)
   (void)hipStreamSynchronize(c->stream);
   for (auto &kv : c->slices) free_slice(kv.second);
   release_pools(c);
+  if (c->d_red) (void)hipFree(c->d_red);
   if (c->d_hits) (void)hipFree(c->d_hits);
   if (c->d_list) (void)hipFree(c->d_list);
   if (c->d_refine) (void)hipFree(c->d_refine);
@@ -669,6 +678,65 @@ int ftkx_slice_resolution(ftkx_ctx *c, int t, double *res, double *max_abs)
   if (rc) return rc;
   if (res) *res = it->second.res;
   if (max_abs) *max_abs = it->second.maxabs;
+  return FTKX_OK;
+}
+
+// the same reduction for several slices at once: one launch, one download, one synchronise (a time series that is already
+// resident does not need a round trip per slice)
+int ftkx_slices_resolution(ftkx_ctx *c, const int *ts, int n, double *res, double *max_abs)
+{
+  if (!c || (n > 0 && !ts)) return fail(c, FTKX_E_INVALID, "null argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<Slice *> todo;
+  for (int i = 0; i < n; i ++) {
+    auto it = c->slices.find(ts[i]);
+    if (it == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "ftkx_slices_resolution: timestep %d not resident", ts[i]);
+    if (!it->second.have_res) todo.push_back(&it->second);
+  }
+  Mesh m; fill_mesh(c, m);
+  if (todo.size() > 1) {
+    const size_t k = todo.size();
+    if (c->red_cap < k) {
+      if (c->d_red) { (void)hipFree(c->d_red); c->d_red = nullptr; c->red_cap = 0; }
+      HIP_TRY(c, hipMalloc((void **)&c->d_red, k * 128 * sizeof(u64)));
+      c->red_cap = k;
+    }
+    // descriptors and results share the pinned staging buffer (stream order: upload, kernel, download)
+    int rc = ensure_desc(c, std::max(k * sizeof(MaskJob), k * 128 * sizeof(u64)));
+    if (rc) return rc;
+    hipLaunchKernelGGL(init_red_kernel, dim3((unsigned)((k * 64 + 255) / 256)), dim3(256), 0, c->stream, c->d_red, k * 64);
+    if (c->scalar_mode == 1 && ftkx::march2_supported(m)) {
+      // the marching stencil kernel in reduce-only mode over all slices at once
+      MaskJob *jobs = (MaskJob *)c->h_desc;
+      for (size_t i = 0; i < k; i ++) jobs[i] = MaskJob{todo[i]->S, nullptr, nullptr, nullptr, c->d_red + i * 128, 1.0};
+      HIP_TRY(c, hipMemcpyAsync(c->d_desc, c->h_desc, k * sizeof(MaskJob), hipMemcpyHostToDevice, c->stream));
+      ftkx::launch_reduce_march(m, (const MaskJob *)c->d_desc, (int)k, c->stream);
+    } else {
+      // one launch per slice, back to back, each into its own slots
+      for (size_t i = 0; i < k; i ++) {
+        if (c->scalar_mode == 1) ftkx::launch_resolution_scalar(m, todo[i]->S, c->d_red + i * 128, c->stream);
+        else ftkx::launch_resolution(todo[i]->V, n_vertices(c) * (size_t)c->nd, c->d_red + i * 128, c->stream);
+      }
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_desc, c->d_red, k * 128 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const u64 *host = (const u64 *)c->h_desc;
+    for (size_t i = 0; i < k; i ++) {
+      u64 mn = host[i * 128], mx = host[i * 128 + 1];
+      for (int q = 1; q < 64; q ++) { mn = std::min(mn, host[i * 128 + 2 * q]); mx = std::max(mx, host[i * 128 + 2 * q + 1]); }
+      memcpy(&todo[i]->res, &mn, 8);
+      memcpy(&todo[i]->maxabs, &mx, 8);
+      todo[i]->have_res = true;
+    }
+  } else {
+    for (Slice *s : todo) { int rc = slice_resolution(c, *s); if (rc) return rc; }
+  }
+  for (int i = 0; i < n; i ++) {
+    const Slice &s = c->slices.find(ts[i])->second;
+    if (res) res[i] = s.res;
+    if (max_abs) max_abs[i] = s.maxabs;
+  }
   return FTKX_OK;
 }
 

@@ -1683,7 +1683,8 @@ __global__ __launch_bounds__(kThreads) void resolution_scalar_kernel(const Mesh 
     const u64 omn = __shfl_down(mn, o), omx = __shfl_down(mx, o);
     mn = omn < mn ? omn : mn; mx = omx > mx ? omx : mx;
   }
-  if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], mn); atomicMax(&out[1], mx); }
+  const unsigned slot = (blockIdx.x * 5u + (threadIdx.x >> 6)) & 63u;   // 64 result slots, folded by the host
+  if ((threadIdx.x & 63) == 0) { atomicMin(&out[2 * slot], mn); atomicMax(&out[2 * slot + 1], mx); }
 }
 
 void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool reduce, hipStream_t stream);

@@ -115,6 +115,8 @@ int ftkx_drop_slice(ftkx_ctx *ctx, int t);
 int ftkx_slice_resolution(ftkx_ctx *ctx, int t, double *resolution, double *max_abs);
 /* A slice received from another GPU (t-slab halo) comes with the reduction its owner already did: hand it over instead of
  * reducing the slice again. */
+/* ftkx_slice_resolution for n resident slices with one launch and one synchronise; res / max_abs: n doubles each (nullable) */
+int ftkx_slices_resolution(ftkx_ctx *ctx, const int *timesteps, int n, double *res, double *max_abs);
 int ftkx_set_slice_resolution(ftkx_ctx *ctx, int t, double resolution, double max_abs);
 /* update_vector_field_scaling_factor (critical_point_tracker.hh:850-864): nbits = clamp(ceil(log2(1/res)), 8, 21) */
 unsigned long long ftkx_scaling_factor(double resolution, int *nbits);

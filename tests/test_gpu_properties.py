@@ -193,3 +193,28 @@ def test_slices_beyond_4GiB_take_the_64bit_kernels(gpu):
     assert st_e["cull_enabled"] == 0
     inside = np.ones(len(recs), dtype=bool)
     _same(recs[inside], sub)
+
+
+def test_batched_resolution_equals_per_slice(gpu):
+    """ftkx_slices_resolution (one round trip for the whole series) == ftkx_slice_resolution slice by slice, bit for bit:
+    marching reduction (3D, 2D), the generic scalar reduction (odd row length) and vector input"""
+    import torch
+    from ftk_amd import synthetic
+    for case, dims, nt, nv in (("moving_extremum_3d", (128, 96, 40), 5, 1), ("woven", (256, 128), 6, 1), ("moving_extremum_3d", (31, 17, 9), 3, 1),
+                               ("double_gyre", (128, 64), 5, 2)):
+        nd = len(dims)
+        lo = 2 if nv == 1 else 1
+        dom = ([lo] * nd, [d - (3 if nv == 1 else 2) for d in dims])
+        got = []
+        for batched in (False, True):
+            ctx = gpu.Context(nd)
+            ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
+            ctx.set_options(jacobian_symmetric=int(nv == 1), derive_jacobian=1)
+            keep = []
+            for t in range(nt):
+                a = synthetic.generate(case, dims, t, nt, torch, torch.device("cuda", 0)); torch.cuda.synchronize(); keep.append(a)
+                (ctx.push_scalar_slice if nv == 1 else ctx.push_slice)(t, a)
+            got.append(ctx.slices_resolution(range(nt)) if batched else {t: ctx.slice_resolution(t) for t in range(nt)})
+            ctx.close()
+        assert got[0] == got[1], (case, dims)
+        assert all(r > 0 and m > 0 for r, m in got[0].values())
