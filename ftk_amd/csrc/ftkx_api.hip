@@ -36,6 +36,7 @@ void launch_gradient3d(const double *S, int DW, int DH, int DD, double *V, hipSt
 void launch_jacobian3d(const double *V, int DW, int DH, int DD, double *J, hipStream_t st);
 void launch_resolution(const double *p, size_t n, u64 *out2, hipStream_t st);
 void launch_calib_read(const void *p, size_t bytes, double *scratch, hipStream_t stream);
+const char *last_mask_kernel();
 }  // namespace ftkx
 
 using ftkx::Fields;
@@ -463,6 +464,8 @@ int run_batch(ftkx_ctx *c)
 }  // namespace
 
 extern "C" {
+
+const char *ftkx_last_mask_kernel(void) { return ftkx::last_mask_kernel(); }
 
 const char *ftkx_version(void) { return "ftkx 0.1 (gfx950)"; }
 

@@ -1687,6 +1687,11 @@ __global__ __launch_bounds__(kThreads) void resolution_scalar_kernel(const Mesh 
   if ((threadIdx.x & 63) == 0) { atomicMin(&out[2 * slot], mn); atomicMax(&out[2 * slot + 1], mx); }
 }
 
+// name of the mask-kernel instantiation the last (non pre-pass) launch used, as rocprofv3 prints it: bench.py reports it next to the
+// kernel family so that its roofline line can be matched with the profiler's summary
+static const char *g_last_mask_kernel = "";
+const char *last_mask_kernel() { return g_last_mask_kernel; }
+
 void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool reduce, hipStream_t stream);
 
 // can the marching kernel (which carries the fused reduction) walk this mesh?
@@ -1784,6 +1789,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
           int shape = 0;                                         // FTKX_MASK_TILE: 0 = 128 x 16, 1 = 256 x 16, 2 = 512 x 16 (RY 8), 3 = 256 x 32, 4..7 below
           if (const char *e = getenv("FTKX_MASK_TILE")) shape = atoi(e);
 #define FTKX_M5(PD_, TW_, CY_, RY_) do { \
+            g_last_mask_kernel = "ftkx::mask_march5_kernel<" #PD_ ", " #TW_ ", " #CY_ ", " #RY_ ">"; \
             const int tw = TW_, rows = CY_ * RY_; \
             const dim3 grid5((unsigned)((m.ext_sz[0] + 128 * tw - 1) / (128 * tw)), (unsigned)((m.ext_sz[1] + rows - 1) / rows), grid2.z); \
             int sw = swizzle; \
@@ -1817,7 +1823,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
         if ((swizzle & 8) && grid4.y != grid2.y) { int yg = (swizzle >> 8) & 0xff; while (yg > 1 && grid4.y % (unsigned)yg) yg --; swizzle = (swizzle & 0xff) | (yg << 8); }
         unsigned lds = 0;                                       // experiment: dynamic LDS only to cap the workgroups per CU
         if (const char *e = getenv("FTKX_MASK_LDS_KB")) lds = (unsigned)atoi(e) * 1024u;
-#define FTKX_M4(ND_, R_, PD_, RY_) do { if (lds) (void)hipFuncSetAttribute((const void *)mask_march4_kernel<ND_, R_, PD_, RY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+#define FTKX_M4(ND_, R_, PD_, RY_) do { if (!reduce) g_last_mask_kernel = "ftkx::mask_march4_kernel<" #ND_ ", " #R_ ", " #PD_ ", " #RY_ ">"; if (lds) (void)hipFuncSetAttribute((const void *)mask_march4_kernel<ND_, R_, PD_, RY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
           hipLaunchKernelGGL((mask_march4_kernel<ND_, R_, PD_, RY_>), grid4, blk, lds, stream, m, d_jobs, zchunk, swizzle); } while (0)
         if (reduce) { if (m.nd == 2) FTKX_M4(2, true, 1, 8); else FTKX_M4(3, true, 1, 4); }
         else if (m.nd == 2) FTKX_M4(2, false, 1, 8);
@@ -1829,7 +1835,8 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
 #undef FTKX_M4
         return;
       }
-#define FTKX_M2(ND_, E_, R_) hipLaunchKernelGGL((mask_march2_kernel<ND_, E_, R_>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle)
+#define FTKX_M2(ND_, E_, R_) do { if (!reduce) g_last_mask_kernel = "ftkx::mask_march2_kernel<" #ND_ ", " #E_ ", " #R_ ">"; \
+        hipLaunchKernelGGL((mask_march2_kernel<ND_, E_, R_>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle); } while (0)
       if (reduce) { if (m.nd == 2) { if (use_edge) FTKX_M2(2, true, true); else FTKX_M2(2, false, true); }
                     else { if (use_edge) FTKX_M2(3, true, true); else FTKX_M2(3, false, true); } }
       else { if (m.nd == 2) { if (use_edge) FTKX_M2(2, true, false); else FTKX_M2(2, false, false); }
@@ -1838,6 +1845,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       return;
     }
     const dim3 grid((unsigned)((m.mask_pitch + 63) / 64), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
+    g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_march_kernel<2>" : "ftkx::mask_march_kernel<3>";
     if (m.nd == 2) hipLaunchKernelGGL(mask_march_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs, zchunk);
     else hipLaunchKernelGGL(mask_march_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs, zchunk);
     return;
@@ -1846,6 +1854,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
   size_t bx = (n + kThreads - 1) / kThreads;
   if (bx > 4096) bx = 4096;                 // grid-stride the rest
   const dim3 grid((unsigned)bx, (unsigned)njobs);
+  g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_kernel<2>" : "ftkx::mask_kernel<3>";
   if (m.nd == 2) hipLaunchKernelGGL(mask_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs);
   else hipLaunchKernelGGL(mask_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs);
 }

@@ -237,6 +237,9 @@ int ftkx_jacobian3D(ftkx_ctx *ctx, const double *V, int DW, int DH, int DD, doub
  * rocprofv3's FETCH_SIZE can be calibrated on a known byte count (tools/calibrate_fetch.py) */
 int ftkx_debug_stream_read(ftkx_ctx *ctx, const void *device_ptr, size_t bytes);
 
+/* profiling aid: the mask-kernel instantiation of the most recent sweep in this process, spelled as rocprofv3 lists it */
+const char *ftkx_last_mask_kernel(void);
+
 /* library / device identification */
 const char *ftkx_version(void);
 int ftkx_device_count(void);

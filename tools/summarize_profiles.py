@@ -55,7 +55,7 @@ for name in sorted(set(fetch) | set(write)):
                                 "hbm_bytes_per_dispatch": f * 1024 * k + w * 1024}
 json.dump(summary, open(os.path.join(dst, f"{tag}_{cfg}_pmc_summary.json"), "w"), indent=1)
 bench = json.loads(open(one("bench_plain.json")).read().strip().splitlines()[-1])
-dom = bench["roofline"]["kernel"].replace("ftkx::", "").split("<")[0]
+dom = bench["roofline"].get("kernel_family", bench["roofline"]["kernel"]).replace("ftkx::", "").split("<")[0]
 # bench.py labels kernel families; the marching mask kernel's pre-pass instantiation (<.., true>) is not the timed one
 key = {"mask_kernel": "mask_", "cull_kernel": "cull_", "exact_kernel": "exact_", "tile_kernel": "tile_"}.get(dom, dom)
 def is_prepass(n):   # REDUCE instantiations: mask_march2_kernel<ND, EDGE, true>, mask_march4_kernel<ND, true, PD>
