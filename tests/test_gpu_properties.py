@@ -195,7 +195,7 @@ def test_slices_beyond_4GiB_take_the_64bit_kernels(gpu):
     _same(recs[inside], sub)
 
 
-def test_batched_resolution_equals_per_slice(gpu):
+def test_batched_resolution_equals_per_slice(gpu, oracle):
     """ftkx_slices_resolution (one round trip for the whole series) == ftkx_slice_resolution slice by slice, bit for bit:
     marching reduction (3D, 2D), the generic scalar reduction (odd row length) and vector input"""
     import torch
@@ -218,3 +218,10 @@ def test_batched_resolution_equals_per_slice(gpu):
             ctx.close()
         assert got[0] == got[1], (case, dims)
         assert all(r > 0 and m > 0 for r, m in got[0].values())
+        # and both equal ndarray::resolution() of the derived (or given) vector field as the oracle computes it
+        for t in range(nt):
+            a = keep[t].cpu().numpy()
+            V = a if nv == 2 else (oracle.gradient2D(a) if nd == 2 else oracle.gradient3D(a))
+            assert got[1][t][0] == oracle.resolution(V), (case, dims, t)
+            fin = np.abs(V[np.isfinite(V)])
+            assert got[1][t][1] == fin.max()
