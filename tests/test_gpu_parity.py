@@ -267,3 +267,27 @@ def test_tracker_end_to_end_curves(gpu, name):
     assert got == exp
     if name == "woven_31x37x32":
         assert len(curves) == 56      # tests/test_critical_point_tracking_woven.cpp:32-37
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_empty_and_minimal_inputs(gpu, oracle, nd):
+    """edge cases around nothing: an empty core, arrays so small that the domain [2, D-2] is empty or a single cell, a single
+    timestep (ordinal sweep only) -- the tracker must agree with the oracle (usually: no records) and never fail"""
+    from gpu_common import run_tracker
+    rng = np.random.default_rng(11)
+    ctx = gpu.Context(nd)
+    ctx.set_mesh(([2] * nd, [4] * nd), ([2] * nd, [0] + [4] * (nd - 1)), ([0] * nd, [8] * nd))      # core of size 0 along x
+    ctx.push_scalar_slice(0, rng.standard_normal((8,) * nd))
+    assert len(ctx.sweep(0, gpu.SCOPE_ORDINAL, 256)) == 0
+    ctx.close()
+    for D in (3, 4, 5, 6):
+        for nt in (1, 2, 3):
+            steps = [rng.standard_normal((D,) * nd) for _ in range(nt)]
+            ref, rfac, _ = oracle.track(steps, nd, 1, tag_mode=oracle.TAG_REFERENCE)
+            got, gfac, _ = run_tracker(steps, nd, 1)
+            assert len(got) == len(ref), (D, nt)
+            if D == 3:
+                assert len(got) == 0                            # the domain has no vertices
+            if len(ref):
+                assert np.array_equal(np.sort(got["tag"]), np.sort(ref["tag"]))
+                assert np.array_equal(gfac, rfac)
