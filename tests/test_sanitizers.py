@@ -1,0 +1,29 @@
+"""Sanitizers on the CPU build (GPU AddressSanitizer is not available on the pool): the host-side C++ of the library -- trace.cpp and
+io.cpp -- compiled with g++ -fsanitize=address,undefined and driven over every fixture plus malformed inputs."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _runtime(name):
+    p = subprocess.run(["g++", "-print-file-name=" + name], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+@pytest.mark.skipif(_runtime("libasan.so") is None or _runtime("libubsan.so") is None, reason="sanitizer runtimes not installed")
+def test_host_code_is_clean_under_asan_ubsan(tmp_path):
+    lib = tmp_path / "libftkx_host_san.so"
+    csrc = os.path.join(ROOT, "ftk_amd", "csrc")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                        "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-o", str(lib),
+                        os.path.join(csrc, "io.cpp"), os.path.join(csrc, "trace.cpp"), os.path.join(ROOT, "tests", "sanitize", "host_stub.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, FTKX_HOST_SAN_LIB=str(lib), LD_PRELOAD=_runtime("libasan.so") + ":" + _runtime("libubsan.so"),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sanitize", "run_host_code.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "sanitizer run complete" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
