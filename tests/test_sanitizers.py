@@ -27,3 +27,15 @@ def test_host_code_is_clean_under_asan_ubsan(tmp_path):
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sanitize", "run_host_code.py")], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "sanitizer run complete" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.skipif(_runtime("libubsan.so") is None, reason="UBSan runtime not installed")
+def test_device_arithmetic_headers_are_clean_under_ubsan(tmp_path):
+    """cp_device.hpp / fan_tables.hpp -- the code the HIP kernels execute per simplex -- compiled for the host with UBSan"""
+    so = tmp_path / "libhostcheck_ubsan.so"
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fsanitize=undefined", "-fno-sanitize-recover=undefined",
+                        "-o", str(so), os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sanitize", "run_hostcheck_ubsan.py"), str(so)], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "ubsan run complete" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
