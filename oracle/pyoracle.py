@@ -54,7 +54,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libftk_oracle.so")
+        path = os.environ.get("FTKO_LIB") or os.path.join(_HERE, "libftk_oracle.so")   # FTKO_LIB: e.g. a sanitizer build (tests/test_sanitizers.py)
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

@@ -39,3 +39,16 @@ def test_device_arithmetic_headers_are_clean_under_ubsan(tmp_path):
     env = dict(os.environ, UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sanitize", "run_hostcheck_ubsan.py"), str(so)], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "ubsan run complete" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.skipif(_runtime("libasan.so") is None or _runtime("libubsan.so") is None, reason="sanitizer runtimes not installed")
+def test_oracle_is_clean_under_asan_ubsan(tmp_path):
+    lib = tmp_path / "libftk_oracle_san.so"
+    r = subprocess.run(["gcc", "-O1", "-g", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fwrapv", "-pthread",
+                        "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-o", str(lib),
+                        os.path.join(ROOT, "oracle", "ftk_oracle.c"), "-lm"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, FTKO_LIB=str(lib), LD_PRELOAD=_runtime("libasan.so") + ":" + _runtime("libubsan.so"),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sanitize", "run_oracle.py")], capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0 and "oracle sanitizer run complete" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
