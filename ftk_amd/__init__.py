@@ -373,6 +373,7 @@ class _TrackerRegular:
     def set_exact_only(self, b): self._flags["exact_only"] = int(b)
     def set_tag_mode(self, m): self._flags["tag_mode"] = int(m)
     def set_stream(self, ptr): self._ck(self._L.ftkx_tracker_set_stream(self._h, C.c_void_p(ptr)))
+    def set_current_timestep(self, t): self._ck(self._L.ftkx_tracker_set_current_timestep(self._h, int(t)))
     def set_coords_bounds(self, b): self._ck(self._L.ftkx_tracker_set_coords_bounds(self._h, (C.c_double * len(b))(*[float(x) for x in b])))
 
     def set_coords_rectilinear(self, arrays):

@@ -503,14 +503,19 @@ int ftkx_create(ftkx_ctx **out, int nd, int device_id)
   c->device = device_id;
   ftkx_default_options(&c->opt);
   memset(&c->stats, 0, sizeof(c->stats));
-  HIP_TRY(c, hipSetDevice(device_id));
   // a blocking stream: it orders itself against the legacy default stream, which is where a caller that never heard of
   // streams (and torch's default stream) puts its copies and fills
-  HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
-  c->stream = c->own_stream;
-  HIP_TRY(c, hipMalloc((void **)&c->d_counters, (ftkx::CNT_N + 128) * sizeof(u64)));
-  HIP_TRY(c, hipMemset(c->d_counters, 0, (ftkx::CNT_N + 128) * sizeof(u64)));
-  HIP_TRY(c, hipHostMalloc((void **)&c->h_counters, ftkx::CNT_N * sizeof(u64), hipHostMallocDefault));
+  auto init = [&]() -> int {
+    HIP_TRY(c, hipSetDevice(device_id));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
+    c->stream = c->own_stream;
+    HIP_TRY(c, hipMalloc((void **)&c->d_counters, (ftkx::CNT_N + 128) * sizeof(u64)));
+    HIP_TRY(c, hipMemset(c->d_counters, 0, (ftkx::CNT_N + 128) * sizeof(u64)));
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_counters, ftkx::CNT_N * sizeof(u64), hipHostMallocDefault));
+    return FTKX_OK;
+  };
+  const int rc = init();
+  if (rc != FTKX_OK) { ftkx_destroy(c); return rc; }     // nothing half-built is left behind
   *out = c;
   return FTKX_OK;
 }
@@ -519,7 +524,7 @@ void ftkx_destroy(ftkx_ctx *c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto &kv : c->slices) free_slice(kv.second);
   release_pools(c);
   if (c->d_red) (void)hipFree(c->d_red);
@@ -552,6 +557,7 @@ int ftkx_set_stream(ftkx_ctx *c, void *s)
 int ftkx_set_options(ftkx_ctx *c, const ftkx_options *o)
 {
   if (!c || !o) return fail(c, FTKX_E_INVALID, "null argument");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_set_options: sweeps pending, collect first");
   if (o->tag_mode < FTKX_TAG_WORK_INDEX || o->tag_mode > FTKX_TAG_EXACT64) return fail(c, FTKX_E_INVALID, "bad tag_mode %d", o->tag_mode);
   if (o->coords_mode < 0 || o->coords_mode > 3) return fail(c, FTKX_E_INVALID, "bad coords_mode %d", o->coords_mode);
   if (o->coords_mode == 2 && !c->d_rect[0]) return fail(c, FTKX_E_INVALID, "coords_mode RECTILINEAR: call ftkx_set_coords_rectilinear");
@@ -640,10 +646,10 @@ static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, con
     return FTKX_OK;
   };
   int rc;
-  if ((rc = take(S, n, &s.S, &s.ownS))) return rc;
+  if ((rc = take(S, n, &s.S, &s.ownS))) { free_slice(s); return rc; }
   if (!scalar_only) {
-    if ((rc = take(V, n * nd, &s.V, &s.ownV))) return rc;
-    if ((rc = take(J, n * nd * nd, &s.J, &s.ownJ))) return rc;
+    if ((rc = take(V, n * nd, &s.V, &s.ownV))) { free_slice(s); return rc; }      // what was already allocated goes back
+    if ((rc = take(J, n * nd * nd, &s.J, &s.ownJ))) { free_slice(s); return rc; }
   }
   // scalar input: V = gradient2D/3D(S) is never materialised -- every kernel evaluates it where it needs it, with the
   // reference's exact operations (ndarray/grad.hh), so the slice costs 8 bytes per vertex of HBM instead of 8 + 8*nd.
@@ -793,8 +799,11 @@ int ftkx_sweep_enqueue(ftkx_ctx *c, int t, int scope, unsigned long long factor)
   const int nd = c->nd;
 
   // Is the strict-sign cull legal?  Only with the robust integer test and only while no determinant can leave int64.
+  // The masks test v >= 1/factor on doubles, which equals trunc(v * factor) >= 1 only for a power of two (the tracker always
+  // passes 1 << nbits); any other factor a direct caller hands over takes the tile path, which quantises like the reference.
+  const bool factor_pow2 = (factor & (factor - 1)) == 0 && factor <= (1ull << 53);
   bool fast = false;
-  if (!c->opt.exact_only && (nd == 2 || c->opt.robust)) {
+  if (!c->opt.exact_only && factor_pow2 && (nd == 2 || c->opt.robust)) {
     int rc = slice_resolution(c, *s0);
     if (rc) return rc;
     double mx = s0->maxabs;

@@ -182,7 +182,7 @@ void critical_point_tracker_regular::finalize()
   }
   long long dst[3] = {0, 0, 0}, dsz[3] = {1, 1, 1};
   for (int d = 0; d < nd; d ++) { dst[d] = domain.start(d); dsz[d] = domain.size(d); }
-  ftkx_curves c;
+  ftkx_curves c{};
   const int rc = ftkx_trace_curves(nd, dst, dsz, recs.data(), recs.size(), &c);
   if (rc != FTKX_OK) { ftkx_free_curves(&c); throw ftkx_error(rc, "finalize: ftkx_trace_curves failed (tags must not have overflowed int32: use FTKX_TAG_EXACT64 on very large meshes)"); }
   traced_critical_points.clear(); traced_loop.clear(); traced_id.clear();
@@ -242,7 +242,7 @@ void critical_point_tracker_regular::post_process()
   std::memset(&in, 0, sizeof(in));
   in.n_curves = traced_critical_points.size(); in.n_points = f.recs.size();
   in.offsets = f.offsets.data(); in.indices = f.indices.data(); in.loop = traced_loop.data();
-  ftkx_trajectories out;
+  ftkx_trajectories out{};
   const int rc = ftkx_post_process_curves(f.recs.data(), f.recs.size(), &in, &out);
   if (rc != FTKX_OK) { ftkx_free_trajectories(&out); throw ftkx_error(rc, "post_process failed"); }
   std::vector<std::vector<feature_point_t>> curves(out.n_curves);
@@ -348,13 +348,14 @@ extern "C" {
 int ftkx_tracker_create(ftkx_tracker **out, int nd, int device_id)
 {
   if (!out || (nd != 2 && nd != 3)) { g_tracker_error = "ftkx_tracker_create: nd must be 2 or 3"; return FTKX_E_INVALID; }
+  ftkx_tracker *h = new ftkx_tracker();
   try {
-    ftkx_tracker *h = new ftkx_tracker();
     h->nd = nd;
     h->t = new ftkx::critical_point_tracker_regular(nd, device_id);
     *out = h;
     return FTKX_OK;
-  } catch (const ftkx::ftkx_error &e) { g_tracker_error = e.what(); return e.code; }
+  } catch (const ftkx::ftkx_error &e) { delete h; g_tracker_error = e.what(); return e.code; }
+  catch (const std::exception &e) { delete h; g_tracker_error = e.what(); return FTKX_E_INVALID; }
 }
 
 void ftkx_tracker_destroy(ftkx_tracker *h) { if (h) { delete h->t; delete h; } }
@@ -383,6 +384,8 @@ int ftkx_tracker_set_flags(ftkx_tracker *h, int robust, int use_tf, unsigned tf,
   });
 }
 int ftkx_tracker_set_stream(ftkx_tracker *h, void *s) { return guarded(h, [&] { h->t->set_stream(s); }); }
+int ftkx_tracker_set_current_timestep(ftkx_tracker *h, int t)
+{ return guarded(h, [&] { if (t < 0) throw ftkx::ftkx_error(FTKX_E_INVALID, "set_current_timestep: negative timestep"); h->t->set_current_timestep(t); }); }
 int ftkx_tracker_set_coords_bounds(ftkx_tracker *h, const double *b) { return guarded(h, [&] { h->t->set_coords_bounds(std::vector<double>(b, b + 2 * h->nd)); }); }
 int ftkx_tracker_set_coords_rectilinear(ftkx_tracker *h, const double *x, size_t nx, const double *y, size_t ny, const double *z, size_t nz)
 {

@@ -123,7 +123,9 @@ unsigned long long ftkx_scaling_factor(double resolution, int *nbits);
 
 /* ---- the sweep ------------------------------------------------------------------------------------------------- */
 /* Sweeps the simplices of `scope` whose corner lies in `core` at time t (interval: [t, t+1], needs slice t+1).
- * `factor` = vector_field_scaling_factor.  Records are returned in a context-owned pinned host buffer, sorted by tag,
+ * `factor` = vector_field_scaling_factor: any non-zero value is honoured (quantisation is trunc(v * factor) like 2d:605-616), but the
+ * sign cull that makes the sweep memory-bound needs a power of two <= 2^53 (what update_vector_field_scaling_factor produces);
+ * other factors run the full integer test on every simplex.  Records are returned in a context-owned pinned host buffer, sorted by tag,
  * valid until the next call on this context.  Synchronous on the context's stream. */
 int ftkx_sweep(ftkx_ctx *ctx, int t, int scope, unsigned long long factor, const ftkx_cp_t **out, size_t *n_out);
 

@@ -104,7 +104,7 @@ public:
   void set_coords_explicit(const double *c, int ncomp, size_t n0, size_t n1)
   { explicit_coords.assign(c, c + (size_t)ncomp * n0 * n1); explicit_ncomp = ncomp; explicit_n0 = n0; explicit_n1 = n1; mode_phys_coords = 3; }
   // tracker.hh:40-41
-  void set_current_timestep(int t) { current_timestep = t; }
+  void set_current_timestep(int t) { current_timestep = t; if (field_data_snapshots.empty()) next_push_timestep = t; }   // the next snapshot pushed is timestep t
   int get_current_timestep() const { return current_timestep; }
   // not in the reference: knobs of this implementation
   void set_exact_only(bool b) { exact_only = b; }          // never cull (every simplex takes the integer test)
@@ -209,6 +209,7 @@ int  ftkx_tracker_set_array_domain(ftkx_tracker *, const long long *starts, cons
 int  ftkx_tracker_set_sources(ftkx_tracker *, int scalar, int vector, int jacobian, int jacobian_symmetric);
 int  ftkx_tracker_set_flags(ftkx_tracker *, int robust, int use_type_filter, unsigned type_filter, int compute_degrees, int exact_only, int tag_mode);
 int  ftkx_tracker_set_stream(ftkx_tracker *, void *hip_stream);
+int  ftkx_tracker_set_current_timestep(ftkx_tracker *, int t);   /* tracker::set_current_timestep (filters/tracker.hh:40), before the first push */
 int  ftkx_tracker_set_coords_bounds(ftkx_tracker *, const double *bounds /* 2*nd values */);
 int  ftkx_tracker_set_coords_rectilinear(ftkx_tracker *, const double *x, size_t nx, const double *y, size_t ny, const double *z, size_t nz);
 int  ftkx_tracker_set_coords_explicit(ftkx_tracker *, const double *coords, int ncomp, size_t n0, size_t n1);

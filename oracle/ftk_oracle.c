@@ -946,7 +946,7 @@ size_t ftko_track(const ftko_track_args *a, ftko_rec_t **out, unsigned long long
   const int scalar_in = a->nv == 1;
   snapshot_t q[2]; int nq = 0;
   double resolution = DBL_MAX;       /* vector_field_resolution, critical_point_tracker.hh:162 (sticky) */
-  int current = 0;
+  int current = a->t0;
   recvec all = {0, 0, 0};
   double tsweep = 0;
 
@@ -991,7 +991,7 @@ size_t ftko_track(const ftko_track_args *a, ftko_rec_t **out, unsigned long long
       /* update_timestep */
       for (int i = 0; i < nq; i ++) { const double r = ftko_resolution(q[i].V, N * nd); resolution = (r < resolution) ? r : resolution; }
       const u64 factor = ftko_scaling_factor(resolution, NULL);
-      if (factors) factors[current] = factor;
+      if (factors) factors[current - a->t0] = factor;
       sa.factor = factor;
       sa.current_timestep = current;
       sa.V[0] = q[0].V; sa.J[0] = q[0].J; sa.S[0] = q[0].S;

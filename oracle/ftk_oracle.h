@@ -124,6 +124,7 @@ typedef struct {
   const double *rect[3];
   const double *expl;
   int expl_ncomp, expl_n0;
+  int t0;                       /* tracker::set_current_timestep (filters/tracker.hh:40): timestep of steps[0] */
 } ftko_track_args;
 
 /* returns #records; *out sorted by (t,z,y,x,type); factors[k] (k < DT) = factor in force at the sweep of

@@ -39,7 +39,7 @@ class TrackArgs(C.Structure):
         ("robust", C.c_int), ("use_type_filter", C.c_int), ("type_filter", C.c_uint),
         ("compute_degrees", C.c_int), ("tag_mode", C.c_int), ("nthreads", C.c_int),
         ("coords_mode", C.c_int), ("bounds", C.c_double * 6),
-        ("rect", C.c_void_p * 3), ("expl", C.c_void_p), ("expl_ncomp", C.c_int), ("expl_n0", C.c_int),
+        ("rect", C.c_void_p * 3), ("expl", C.c_void_p), ("expl_ncomp", C.c_int), ("expl_n0", C.c_int), ("t0", C.c_int),
     ]
 
 
@@ -209,14 +209,14 @@ def sweep(nd, scope, t, domain, core, ext, V, J, S, factor, jacobian_symmetric=T
 
 
 def track(steps, nd, nv, robust=True, type_filter=None, compute_degrees=False, tag_mode=TAG_REFERENCE, nthreads=1, bounds=None,
-          rectilinear=None, explicit=None):
+          rectilinear=None, explicit=None, t0=0):
     """steps: list of DT numpy arrays (scalar: shape reversed dims; vector: (..., nd)).
     Returns (records, factors[DT], sweep_seconds)."""
     steps = [_f64(s) for s in steps]
     DT = len(steps)
     shp = steps[0].shape[:nd]
     a = TrackArgs()
-    a.nd, a.nv, a.DT = nd, nv, DT
+    a.nd, a.nv, a.DT, a.t0 = nd, nv, DT, int(t0)
     for d in range(nd):
         a.D[d] = shp[nd - 1 - d]
     a.D[2] = a.D[2] if nd == 3 else 1

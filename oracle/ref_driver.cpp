@@ -171,6 +171,11 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
     }
   }
   tracker.initialize();
+  // FTK_REF_T0: the series starts at a later timestep (tracker::set_current_timestep, filters/tracker.hh:40) -- with a large value
+  // the int products of element::to_integer (simplicial_regular_mesh.hh:496-502) and the int truncation of simplex_indices
+  // (regular_tracker.hh:188-194) wrap on a mesh small enough for the CPU
+  const int T0 = getenv("FTK_REF_T0") ? atoi(getenv("FTK_REF_T0")) : 0;
+  if (T0) tracker.set_current_timestep(T0);
 
   for (int k = 0; k < in.DT; k ++) {
     const auto a = make_array(in, k);
@@ -194,7 +199,7 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
   const uint64_t nf = tracker.factors.size();
   fwrite(&nf, sizeof(uint64_t), 1, fp);
   for (size_t i = 0; i < nf; i ++) {
-    const int64_t step = tracker.factor_steps[i];
+    const int64_t step = tracker.factor_steps[i] - T0;   // relative to the first timestep
     fwrite(&step, sizeof(int64_t), 1, fp);
     fwrite(&tracker.factors[i], sizeof(uint64_t), 1, fp);
   }

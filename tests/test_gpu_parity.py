@@ -6,7 +6,7 @@ assert they are BIT-identical, which holds because the FP64 hit path uses the sa
 import numpy as np
 import pytest
 
-from common import assert_records_equal, golden_names, load_golden
+from common import assert_records_equal, golden_names, load_golden, wrap_golden_names
 
 pytestmark = pytest.mark.gpu
 
@@ -35,6 +35,21 @@ def test_tracker_matches_reference_fixture(gpu, name, exact_only):
     assert_records_equal(recs, g["records"], coord_tol=0.0, what=name + " (bit-exact)")
     if exact_only:
         assert all(s["cull_enabled"] == 0 for s in stats)
+
+
+@pytest.mark.parametrize("exact_only", [False, True], ids=["cull", "exact_only"])
+@pytest.mark.parametrize("name", wrap_golden_names())
+def test_reference_tags_and_vertex_ids_where_int32_wraps(gpu, name, exact_only):
+    """FTKX_TAG_REFERENCE on a mesh whose tag products exceed 2^31 (simplicial_regular_mesh.hh:496-502) and whose SoS vertex ids
+    wrap when truncated to int (regular_tracker.hh:188-194): fixtures from the real reference started at a large timestep."""
+    from gpu_common import run_tracker
+    g = load_golden(name)
+    recs, factors, stats = run_tracker(g["steps"], g["nd"], g["nv"], exact_only=exact_only, tag_mode=gpu.TAG_REFERENCE, t0=g["t0"])
+    assert np.array_equal(factors, g["factors"])
+    assert_records_equal(recs, g["records"], coord_tol=0.0, what=name)
+    # and the 64-bit tags of the same run differ: the comparison above really exercised the wrap
+    exact, _, _ = run_tracker(g["steps"], g["nd"], g["nv"], tag_mode=gpu.TAG_EXACT64, t0=g["t0"])
+    assert len(exact) == len(recs) and not np.array_equal(np.sort(exact["tag"]), np.sort(recs["tag"]))
 
 
 @pytest.mark.parametrize("name", ["woven_31x37x32", "moving_extremum_3d_21x21x21x32", "random_3d_scalar_13x12x11x4"])

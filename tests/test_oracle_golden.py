@@ -7,7 +7,7 @@ quantisation factor identical."""
 import numpy as np
 import pytest
 
-from common import assert_records_equal, golden_names, load_golden
+from common import assert_records_equal, golden_names, load_golden, wrap_golden_names
 
 # known-answer record counts from BASELINE.md section 3 (reference CLI, --output-type discrete)
 KNOWN_COUNTS = {
@@ -31,6 +31,21 @@ def test_oracle_matches_reference_records(oracle, name):
                                    rectilinear=g["rectilinear"], explicit=g["explicit"])
     assert np.array_equal(factors, g["factors"]), "per-step quantisation factor differs"
     assert_records_equal(recs, g["records"], coord_tol=0.0, what=name)
+
+
+@pytest.mark.parametrize("name", wrap_golden_names())
+def test_oracle_matches_reference_where_int32_wraps(oracle, name):
+    """SURVEY H6 / a10 / a23: series starting at a timestep so large that element::to_integer's int products and the int
+    truncation of the SoS vertex ids wrap in the reference (tests/golden/make_golden_wrap.py).  Tags are then NOT the 64-bit
+    element tags, and the wrapped (partly negative) ids change the order the SoS cascade sees -- reproduced bit for bit."""
+    g = load_golden(name)
+    assert g["t0"] > 0
+    recs, factors, _ = oracle.track(g["steps"], g["nd"], g["nv"], tag_mode=oracle.TAG_REFERENCE, nthreads=4, t0=g["t0"])
+    assert np.array_equal(factors, g["factors"])
+    assert_records_equal(recs, g["records"], coord_tol=0.0, what=name)
+    assert recs["timestep"].min() == g["t0"]
+    exact, _, _ = oracle.track(g["steps"], g["nd"], g["nv"], tag_mode=oracle.TAG_EXACT64, nthreads=4, t0=g["t0"])
+    assert len(exact) == len(recs) and not np.array_equal(np.sort(exact["tag"]), np.sort(recs["tag"]))   # the tags really wrapped
 
 
 @pytest.mark.parametrize("name", sorted(KNOWN_COUNTS))
