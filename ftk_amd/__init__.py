@@ -130,6 +130,15 @@ class Context:
         self._ck(self._L.ftkx_slices_resolution(self._h, tt, n, r, m))
         return {ts[i]: (r[i], m[i]) for i in range(n)}
 
+    def slices_prepare(self, ts, factor_hint=0):
+        """ftkx_slices_prepare: ONE pass over the slices builds the sweep's sign masks (under factor_hint, 0 = 256) and returns
+        {t: (res_below, max_abs)} -- res_below = smallest non-zero |v| below 1 / factor_hint (DBL_MAX if none)"""
+        ts = [int(t) for t in ts]
+        n = len(ts)
+        tt = (C.c_int * max(1, n))(*ts); r = (C.c_double * max(1, n))(); m = (C.c_double * max(1, n))()
+        self._ck(self._L.ftkx_slices_prepare(self._h, tt, n, int(factor_hint), r, m))
+        return {ts[i]: (r[i], m[i]) for i in range(n)}
+
     def set_slice_resolution(self, t, resolution, max_abs):
         self._ck(self._L.ftkx_set_slice_resolution(self._h, t, float(resolution), float(max_abs)))
 

@@ -7,6 +7,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -27,6 +28,7 @@ void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, 
 void launch_exact(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, hipStream_t stream);
 bool masks_have_summary(const Mesh &m);
 bool march2_supported(const Mesh &m);
+bool masks_fuse_reduction(const Mesh &m);
 void launch_reduce_march(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream);
 void launch_cull_two_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream);
 void launch_resolution_scalar(const Mesh &m, const double *S, u64 *out2, hipStream_t stream);
@@ -54,12 +56,20 @@ struct Slice {
   unsigned char *M = nullptr;       // vertex sign masks, built lazily for `mask_factor`
   unsigned char *U = nullptr;       // per-8-vertex summaries of M (two-level cull)
   bool ownV = false, ownJ = false, ownS = false;
-  unsigned long long mask_factor = 0;
-  bool have_res = false;
+  unsigned long long mask_factor = 0;   // the (power-of-two) factor M / U were built under; 0 = not built
+  bool have_res = false;            // res = ndarray::resolution() of the slice's vector field (exact pre-pass), maxabs with it
   double res = 0, maxabs = 0;
+  bool have_fused = false;          // reduction fused into the mask pass (ftkx_slices_prepare): maxabs, and
+  double res_below = 0;             //   the smallest non-zero |v| below 1 / fused_factor (DBL_MAX if none)
+  unsigned long long fused_factor = 0;
+  bool max_known() const { return have_res || have_fused; }
 };
 
-struct Request { int t, scope; unsigned long long factor; bool fast; };
+// how a request is swept: MODE_TILE tests every simplex (exact_only, non-robust 3D, odd factors); MODE_FAST = masks -> cull ->
+// survivor list -> exact kernel; MODE_TILE_CULL = the tile kernel with its in-tile cull (same per-vertex legality rule), for
+// data on which most cells survive the cull anyway (the int64-overflow regime: a survivor list would be as large as the input)
+enum { MODE_TILE = 0, MODE_FAST = 1, MODE_TILE_CULL = 2 };
+struct Request { int t, scope; unsigned long long factor; int mode; };
 
 enum { K_MASK = 0, K_CULL = 1, K_EXACT = 2, K_TILE = 3, K_N = 4 };
 
@@ -104,6 +114,7 @@ struct ftkx_ctx {
   int expl_ncomp = 0;
   size_t expl_n0 = 0, expl_n1 = 0;
   std::vector<Request> pending;
+  int dense_collects = 0;           // > 0: the last fast collect found most cells surviving; fast requests run MODE_TILE_CULL for a while
   ftkx_stats stats;
   // optional kernel timing (hipEvents on the context's stream)
   int profiling = 0;
@@ -287,6 +298,40 @@ bool overflow_free(int nd, double maxabs, u64 factor)
   return nd == 3 ? 24.0L * M * M * M < lim : 6.0L * M * M < lim;
 }
 
+double big_threshold(int nd, u64 factor) { return (double)(nd == 3 ? ftkx::kSafeM3 : ftkx::kSafeM2) / (double)factor; }
+bool pow2_factor(u64 factor) { return factor != 0 && (factor & (factor - 1)) == 0 && factor <= (1ull << 53); }
+
+// Masks built under mask_factor serve a sweep under `factor` when they can only cull less than masks built under `factor`
+// itself: the sign thresholds need mask_factor <= factor; the per-vertex overflow rule (MaskJob::big) is factor-specific, so a
+// larger factor is accepted only when the slice's max |v| shows that no vertex is big under it either.
+bool masks_valid(const ftkx_ctx *c, const Slice &s, u64 factor, bool two_level)
+{
+  if (!s.M || (two_level && !s.U) || s.mask_factor == 0 || s.mask_factor > factor) return false;
+  return s.mask_factor == factor || (s.max_known() && overflow_free(c->nd, s.maxabs, factor));
+}
+
+int ensure_mask_arrays(ftkx_ctx *c, Slice &s, bool two_level)
+{
+  if (!s.M) {
+    if (!c->pool_M.empty()) { s.M = c->pool_M.back(); c->pool_M.pop_back(); }   // padding still neutral from its first life
+    else {
+      HIP_TRY(c, hipMalloc((void **)&s.M, mask_bytes(c)));
+      // row padding and anything a kernel does not write is cull-neutral
+      HIP_TRY(c, hipMemsetAsync(s.M, 0x3f, mask_bytes(c), c->stream));
+    }
+    s.mask_factor = 0;
+  }
+  if (two_level && !s.U) {
+    if (!c->pool_U.empty()) { s.U = c->pool_U.back(); c->pool_U.pop_back(); }
+    else {
+      HIP_TRY(c, hipMalloc((void **)&s.U, u_bytes(c)));
+      HIP_TRY(c, hipMemsetAsync(s.U, 0x3f, u_bytes(c), c->stream));
+    }
+    s.mask_factor = 0;      // summaries must be produced together with the masks
+  }
+  return FTKX_OK;
+}
+
 __global__ void init_red_kernel(u64 *red, size_t nslots)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -379,42 +424,26 @@ int run_batch(ftkx_ctx *c)
     f.S[0] = s0.S; f.V[0] = s0.V; f.J[0] = s0.J;
     if (s1) { f.S[1] = s1->S; f.V[1] = s1->V; f.J[1] = s1->J; }
     f.factor = (double)r.factor; f.t = r.t; f.scope_mask = r.scope;
-    if (r.fast) {
+    if (r.mode == MODE_FAST) {
       for (Slice *s : {&s0, s1}) {
         if (!s) continue;
-        if (!s->M) {
-          if (!c->pool_M.empty()) { s->M = c->pool_M.back(); c->pool_M.pop_back(); }   // padding still neutral from its first life
-          else {
-            HIP_TRY(c, hipMalloc((void **)&s->M, mask_bytes(c)));
-            // row padding and anything a kernel does not write is cull-neutral
-            HIP_TRY(c, hipMemsetAsync(s->M, 0x3f, mask_bytes(c), c->stream));
-          }
-          s->mask_factor = 0;
-        }
-        if (two_level && !s->U) {
-          if (!c->pool_U.empty()) { s->U = c->pool_U.back(); c->pool_U.pop_back(); }
-          else {
-            HIP_TRY(c, hipMalloc((void **)&s->U, u_bytes(c)));
-            HIP_TRY(c, hipMemsetAsync(s->U, 0x3f, u_bytes(c), c->stream));
-          }
-          s->mask_factor = 0;      // summaries must be produced together with the masks
-        }
-        if (s->mask_factor != r.factor) {
-          // masks of this slice already (re)built or used in the current sub-batch under another factor -> close it
-          bool touched = false;
-          for (const MaskJob &j : subs.back().jobs) touched = touched || j.M == s->M;
-          for (const Fields &g : subs.back().steps) touched = touched || g.M[0] == s->M || g.M[1] == s->M;
-          if (touched) subs.emplace_back();
-          subs.back().jobs.push_back(MaskJob{s->S, s->V, s->M, two_level ? s->U : nullptr, nullptr, 1.0 / (double)r.factor});
-          s->mask_factor = r.factor;
-        }
+        if (masks_valid(c, *s, r.factor, two_level)) continue;     // e.g. built by ftkx_slices_prepare, or by an earlier step
+        int rc = ensure_mask_arrays(c, *s, two_level);
+        if (rc) return rc;
+        // masks of this slice already (re)built or used in the current sub-batch under another factor -> close it
+        bool touched = false;
+        for (const MaskJob &j : subs.back().jobs) touched = touched || j.M == s->M;
+        for (const Fields &g : subs.back().steps) touched = touched || g.M[0] == s->M || g.M[1] == s->M;
+        if (touched) subs.emplace_back();
+        subs.back().jobs.push_back(MaskJob{s->S, s->V, s->M, two_level ? s->U : nullptr, nullptr, 1.0 / (double)r.factor, big_threshold(nd, r.factor)});
+        s->mask_factor = r.factor;
       }
       f.M[0] = s0.M; f.M[1] = s1 ? s1->M : nullptr;
       f.U[0] = two_level ? s0.U : nullptr; f.U[1] = (two_level && s1) ? s1->U : nullptr;
       subs.back().steps.push_back(f);
     } else {
       TileParams p;
-      p.m = m; p.f = f; p.cull = 0;
+      p.m = m; p.f = f; p.cull = r.mode == MODE_TILE_CULL ? 1 : 0;
       int tile[3];
       ftkx::tile_dims(nd, tile);
       for (int d = 0; d < 3; d ++) p.ntiles[d] = d < nd ? (int)((c->core_sz[d] + tile[d] - 1) / tile[d]) : 1;
@@ -618,6 +647,7 @@ int ftkx_set_mesh(ftkx_ctx *c, const long long dst[3], const long long dsz[3], c
   for (int d = c->nd; d < 3; d ++) { c->dom_st[d] = 0; c->dom_sz[d] = 1; c->core_st[d] = 0; c->core_sz[d] = 1; c->ext_st[d] = 0; c->ext_sz[d] = 1; }
   c->mesh_set = true;
   c->scalar_mode = -1;
+  c->dense_collects = 0;
   return FTKX_OK;
 }
 
@@ -749,6 +779,74 @@ int ftkx_slices_resolution(ftkx_ctx *c, const int *ts, int n, double *res, doubl
   return FTKX_OK;
 }
 
+// One pass over the slices for the whole sweep: the sign masks (built under factor_hint, which must not exceed the factor the
+// sweeps will use -- the scaling factor only grows, so the factor in force BEFORE these slices arrived qualifies) and, fused into
+// the same kernel, what update_vector_field_scaling_factor needs of each slice.  See MaskJob in sweep_params.hpp.
+int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long factor_hint, double *res_below, double *max_abs)
+{
+  if (!c || (n > 0 && !ts)) return fail(c, FTKX_E_INVALID, "null argument");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_slices_prepare: sweeps pending, collect first");
+  const u64 hint = factor_hint ? factor_hint : 256;          // the smallest factor there is (minbits = 8)
+  if (!pow2_factor(hint)) return fail(c, FTKX_E_INVALID, "ftkx_slices_prepare: factor_hint must be a power of two");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const double cap = 1.0 / (double)hint;
+  std::vector<Slice *> all, todo;
+  for (int i = 0; i < n; i ++) {
+    auto it = c->slices.find(ts[i]);
+    if (it == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "ftkx_slices_prepare: timestep %d not resident", ts[i]);
+    all.push_back(&it->second);
+  }
+  Mesh m; fill_mesh(c, m);
+  // contexts that never cull (exact_only, non-robust 3D) have no use for masks: the plain pre-pass serves them
+  const bool want_masks = !c->opt.exact_only && (c->nd == 2 || c->opt.robust) && c->dense_collects == 0;
+  const bool two_level = ftkx::masks_have_summary(m);
+  int rc;
+  for (Slice *s : all) {
+    if (!want_masks) { if ((rc = slice_resolution(c, *s))) return rc; continue; }
+    if (s->have_fused && s->fused_factor == hint && s->mask_factor == hint && s->M && (!two_level || s->U)) continue;
+    if (std::find(todo.begin(), todo.end(), s) == todo.end()) todo.push_back(s);
+  }
+  if (!todo.empty()) {
+    const size_t k = todo.size();
+    if (c->red_cap < k) {
+      if (c->d_red) { (void)hipFree(c->d_red); c->d_red = nullptr; c->red_cap = 0; }
+      HIP_TRY(c, hipMalloc((void **)&c->d_red, k * 128 * sizeof(u64)));
+      c->red_cap = k;
+    }
+    if ((rc = ensure_desc(c, std::max(k * sizeof(MaskJob), k * 128 * sizeof(u64))))) return rc;
+    for (Slice *s : todo) if ((rc = ensure_mask_arrays(c, *s, two_level))) return rc;
+    hipLaunchKernelGGL(init_red_kernel, dim3((unsigned)((k * 64 + 255) / 256)), dim3(256), 0, c->stream, c->d_red, k * 64);
+    MaskJob *jobs = (MaskJob *)c->h_desc;
+    for (size_t i = 0; i < k; i ++)
+      jobs[i] = MaskJob{todo[i]->S, todo[i]->V, todo[i]->M, two_level ? todo[i]->U : nullptr, c->d_red + i * 128, cap, big_threshold(c->nd, hint)};
+    HIP_TRY(c, hipMemcpyAsync(c->d_desc, c->h_desc, k * sizeof(MaskJob), hipMemcpyHostToDevice, c->stream));
+    ev_begin(c, K_MASK); ftkx::launch_masks(m, (const MaskJob *)c->d_desc, (int)k, c->stream); ev_end(c);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_desc, c->d_red, k * 128 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    ev_harvest(c);
+    const u64 *host = (const u64 *)c->h_desc;
+    std::vector<Slice *> with_inf;
+    for (size_t i = 0; i < k; i ++) {
+      u64 mn = host[i * 128], mx = host[i * 128 + 1];
+      for (int q = 1; q < 64; q ++) { mn = std::min(mn, host[i * 128 + 2 * q]); mx = std::max(mx, host[i * 128 + 2 * q + 1]); }
+      Slice &s = *todo[i];
+      memcpy(&s.res_below, &mn, 8);
+      double mxd; memcpy(&mxd, &mx, 8);
+      s.mask_factor = hint; s.fused_factor = hint; s.have_fused = true;
+      if (std::isinf(mxd)) with_inf.push_back(&s);        // the fused max cannot skip an Inf: the exact pre-pass gives max FINITE |v|
+      else if (!s.have_res) s.maxabs = mxd;
+    }
+    for (Slice *s : with_inf) if ((rc = slice_resolution(c, *s))) return rc;
+  }
+  for (int i = 0; i < n; i ++) {
+    const Slice &s = *all[i];
+    if (res_below) res_below[i] = s.have_res ? (s.res < cap ? s.res : DBL_MAX) : s.res_below;
+    if (max_abs) max_abs[i] = s.maxabs;
+  }
+  return FTKX_OK;
+}
+
 int ftkx_set_slice_resolution(ftkx_ctx *c, int t, double resolution, double max_abs)
 {
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
@@ -798,20 +896,13 @@ int ftkx_sweep_enqueue(ftkx_ctx *c, int t, int scope, unsigned long long factor)
   HIP_TRY(c, hipSetDevice(c->device));
   const int nd = c->nd;
 
-  // Is the strict-sign cull legal?  Only with the robust integer test and only while no determinant can leave int64.
-  // The masks test v >= 1/factor on doubles, which equals trunc(v * factor) >= 1 only for a power of two (the tracker always
-  // passes 1 << nbits); any other factor a direct caller hands over takes the tile path, which quantises like the reference.
-  const bool factor_pow2 = (factor & (factor - 1)) == 0 && factor <= (1ull << 53);
-  bool fast = false;
-  if (!c->opt.exact_only && factor_pow2 && (nd == 2 || c->opt.robust)) {
-    int rc = slice_resolution(c, *s0);
-    if (rc) return rc;
-    double mx = s0->maxabs;
-    if (s1) { if ((rc = slice_resolution(c, *s1))) return rc; mx = std::max(mx, s1->maxabs); }
-    fast = overflow_free(nd, mx, factor);
-  }
+  // Is the strict-sign cull usable?  Only with the robust integer test (the FP64 test of the non-robust 3D mode has no such
+  // property) and a power-of-two factor: the masks test v >= 1/factor on doubles, which equals trunc(v * factor) >= 1 only then
+  // (the tracker always passes 1 << nbits); any other factor a direct caller hands over takes the tile path, which quantises like
+  // the reference.  Determinants that could leave int64 are dealt with per vertex (MaskJob::big), not per request.
+  const bool fast = !c->opt.exact_only && pow2_factor(factor) && (nd == 2 || c->opt.robust);
   if (c->pending.empty()) memset(&c->stats, 0, sizeof(c->stats));
-  c->pending.push_back(Request{t, scope, factor, fast});
+  c->pending.push_back(Request{t, scope, factor, fast ? (c->dense_collects > 0 ? MODE_TILE_CULL : MODE_FAST) : MODE_TILE});
 
   u64 cells = 1;
   for (int d = 0; d < nd; d ++) cells *= (u64)c->core_sz[d];
@@ -832,7 +923,13 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
   int rc;
   if ((rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16)))) { c->pending.clear(); return rc; }
   bool any_fast = false;
-  for (const Request &r : c->pending) any_fast = any_fast || r.fast;
+  u64 fast_cells = 0;
+  {
+    u64 cells = 1;
+    for (int d = 0; d < c->nd; d ++) cells *= (u64)c->core_sz[d];
+    for (const Request &r : c->pending) if (r.mode == MODE_FAST) { any_fast = true; fast_cells += cells; }
+  }
+  if (c->dense_collects > 0) c->dense_collects --;          // the fast path is probed again after a while
   if (any_fast && (rc = ensure_list(c, std::max<u64>(c->list_capacity, 1u << 20)))) { c->pending.clear(); return rc; }
   if (any_fast && (rc = ensure_refine(c, std::max<u64>(c->refine_capacity, 1u << 20)))) { c->pending.clear(); return rc; }
   // upper bound of the tags this batch can emit -> number of key bits for the device sort
@@ -858,7 +955,17 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
     // a buffer was too small (records / survivors beyond capacity were only counted): grow to what this batch needs, replay it
     for (auto &e : c->events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
     c->events.clear();
-    if (attempt == 3) { c->pending.clear(); return fail(c, FTKX_E_DEVICE, "buffer overflow persisted after regrowing three times"); }
+    if (attempt == 4) { c->pending.clear(); return fail(c, FTKX_E_DEVICE, "buffer overflow persisted after regrowing four times"); }
+    // Most cells survive the cull (data whose quantised magnitudes can overflow the determinants almost everywhere):
+    // a survivor list would be as large as the input.  Such a batch goes through the tile kernel instead, which stages each
+    // tile's vertices once and applies the same cull rule in LDS.
+    if (any_fast && (listed > c->list_capacity || refined > c->refine_capacity) && (listed > fast_cells / 8 || refined * 8 > fast_cells / 8)) {
+      for (Request &r : c->pending) if (r.mode == MODE_FAST) r.mode = MODE_TILE_CULL;
+      any_fast = false;
+      c->dense_collects = 16;
+      if (hits > c->capacity && (rc = ensure_hit_buffer(c, 2 * hits + 1024))) { c->pending.clear(); return rc; }
+      continue;
+    }
     if (refined > c->refine_capacity && (rc = ensure_refine(c, refined + refined / 8 + 1024))) { c->pending.clear(); return rc; }
     if (listed > c->list_capacity && (rc = ensure_list(c, listed + listed / 8 + 1024))) { c->pending.clear(); return rc; }
     // with a truncated survivor list the hit count is a lower bound: leave generous room
@@ -905,7 +1012,8 @@ int ftkx_invalidate_masks(ftkx_ctx *c)
 {
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_invalidate_masks: sweeps pending, collect first");
-  for (auto &kv : c->slices) kv.second.mask_factor = 0;
+  for (auto &kv : c->slices) { kv.second.mask_factor = 0; kv.second.have_fused = false; }
+  c->dense_collects = 0;
   return FTKX_OK;
 }
 

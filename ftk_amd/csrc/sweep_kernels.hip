@@ -148,12 +148,18 @@ __device__ inline unsigned char classify_vertex(const Mesh &m, const double *S, 
   double v[ND];
   vector_at<ND>(m, S, V, vx[0] - m.ext_st[0], vx[1] - m.ext_st[1], ND == 3 ? vx[2] - m.ext_st[2] : 0, v);
   unsigned char mk = 0;
+  bool big = false;
   for (int j = 0; j < ND; j ++) {
     if (isnan(v[j]) || isinf(v[j])) mk |= kNonFinite;
     q[j] = quantize(v[j], factor);
     if (q[j] > 0) mk |= (unsigned char)(1u << j);
     if (q[j] < 0) mk |= (unsigned char)(8u << j);
+    big = big || q[j] >= safe_m<ND>() || q[j] <= -safe_m<ND>();
   }
+  // |q| + 1 > safe_m: a determinant with this vertex may wrap, and the wrapped sign is what the reference reports.
+  // Without sign bits the vertex never supports a cull -- the same rule the mask kernels apply in the double domain
+  // (|v| >= safe_m / factor  <=>  |trunc(v * factor)| >= safe_m, the factor being a power of two).
+  if (big) mk &= (unsigned char)~0x3fu;
   return mk;
 }
 
@@ -502,12 +508,23 @@ __global__ __launch_bounds__(kThreads) void tile_kernel(const TileParams p)
 // ---------------------------------------------------------------------------------------------------------------
 // FAST PATH 1/3: vertex sign masks.  One lane per mask byte (row pitch padded to whole 8-byte words, see Mesh::mask_pitch).
 // ---------------------------------------------------------------------------------------------------------------
+// wavefront-level fold of a kernel's {min, max} pair into one of the job's 64 slots (non-negative doubles order like their bits)
+__device__ inline void red_commit(u64 *red, double mn, double mx, unsigned slot)
+{
+  for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_down(mn, o)); mx = fmax(mx, __shfl_down(mx, o)); }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&red[2 * (slot & 63u)], (u64)__double_as_longlong(mn));
+    atomicMax(&red[2 * (slot & 63u) + 1], (u64)__double_as_longlong(mx));
+  }
+}
+
 template <int ND>
 __global__ __launch_bounds__(kThreads) void mask_kernel(const Mesh m, const MaskJob *__restrict__ jobs)
 {
   const MaskJob job = jobs[blockIdx.y];
   const int P = m.mask_pitch, DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1;
   const size_t n = (size_t)P * DH * DD;
+  double red_mn = DBL_MAX, red_mx = 0.0;
   for (size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x; idx < n; idx += (size_t)gridDim.x * kThreads) {
     const int i = (int)(idx % P), j = (int)((idx / P) % DH), k = (int)(idx / ((size_t)P * DH));
     unsigned char mk = kNeutral;   // padding, vertices outside the domain and non-finite vertices never block a cull
@@ -515,21 +532,85 @@ __global__ __launch_bounds__(kThreads) void mask_kernel(const Mesh m, const Mask
       const int vx[3] = {i + m.ext_st[0], j + m.ext_st[1], k + m.ext_st[2]};
       bool in_dom = true;
       for (int d = 0; d < ND; d ++) in_dom = in_dom && vx[d] >= m.dom_lb[d] && vx[d] <= m.dom_ub[d];
-      if (in_dom) {
-        double v[ND];
-        vector_at<ND>(m, job.S, job.V, i, j, k, v);
-        unsigned bits = 0;
-        bool finite = true;
-        for (int c = 0; c < ND; c ++) {
-          finite = finite && !(isnan(v[c]) || isinf(v[c]));
-          if (v[c] >= job.threshold) bits |= 1u << c;          // trunc(v * factor) >= 1
-          if (v[c] <= -job.threshold) bits |= 8u << c;         // trunc(v * factor) <= -1
-        }
-        mk = finite ? (unsigned char)bits : kNeutral;
+      double v[ND];
+      vector_at<ND>(m, job.S, job.V, i, j, k, v);
+      unsigned bits = 0;
+      bool finite = true, big = false;
+      for (int c = 0; c < ND; c ++) {
+        const double a = fabs(v[c]);
+        finite = finite && !(isnan(v[c]) || isinf(v[c]));
+        if (v[c] >= job.threshold) bits |= 1u << c;          // trunc(v * factor) >= 1
+        if (v[c] <= -job.threshold) bits |= 8u << c;         // trunc(v * factor) <= -1
+        big = big || a >= job.big;
+        // the reduction covers the WHOLE array, like ndarray::resolution() (ndarray.hh:770-778)
+        red_mn = fmin(red_mn, (a == 0.0 || !(a < job.threshold)) ? DBL_MAX : a);
+        red_mx = fmax(red_mx, a);
       }
+      if (in_dom) mk = finite ? (unsigned char)(big ? 0u : bits) : kNeutral;
     }
     job.M[idx] = mk;
   }
+  if (job.red) red_commit(job.red, red_mn, red_mx, blockIdx.x * 5u + (threadIdx.x >> 6));
+}
+
+// Vector input, row length a multiple of 8: four consecutive vertices per lane (ND x 32 contiguous bytes, 16-byte loads), their
+// four mask bytes stored as one word, the summary of an aligned 8-vertex word formed with the neighbouring lane (two-level cull
+// as for scalar input), and the slice's reduction (MaskJob::red) fused in -- V is read once for the whole sweep.
+template <int ND>
+__global__ __launch_bounds__(kThreads) void mask_vec_kernel(const Mesh m, const MaskJob *__restrict__ jobs)
+{
+  const MaskJob job = jobs[blockIdx.y];
+  const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch, UP = m.u_pitch;
+  const size_t ngroups = (size_t)(DW / 4), total = ngroups * (size_t)DH * (size_t)DD;   // DW % 8 == 0: total is even
+  const size_t padded = (total + 63) / 64 * 64;                                        // wave-uniform trip count (DPP, ballot)
+  const double thr = job.threshold, nthr = -job.threshold;
+  const bool have_u = job.U != nullptr;
+  double red_mn = DBL_MAX, red_mx = 0.0;
+  for (size_t gi = (size_t)blockIdx.x * kThreads + threadIdx.x; gi < padded; gi += (size_t)gridDim.x * kThreads) {
+    const bool live = gi < total;
+    const size_t gc = live ? gi : total - 1;
+    const size_t row = gc / ngroups;
+    const int g = (int)(gc - row * ngroups), j = (int)(row % (size_t)DH), k = (int)(row / (size_t)DH);
+    const double2 *src = reinterpret_cast<const double2 *>(job.V + (row * (size_t)DW + (size_t)(4 * g)) * ND);
+    double v[4 * ND];
+    for (int q = 0; q < 2 * ND; q ++) { const double2 t = src[q]; v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+    bool row_dom = j + m.ext_st[1] >= m.dom_lb[1] && j + m.ext_st[1] <= m.dom_ub[1];
+    if (ND == 3) row_dom = row_dom && k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2];
+    unsigned word = 0;
+    bool cand = false;
+    for (int q = 0; q < 4; q ++) {
+      unsigned bits = 0;
+      double mx = 0.0;
+      bool fin = true;
+      for (int c = 0; c < ND; c ++) {
+        const double x = v[q * ND + c], a = fabs(x);
+        if (x >= thr) bits |= 1u << c;
+        if (x <= nthr) bits |= 8u << c;
+        fin = fin && a < HUGE_VAL;                             // false for NaN and Inf
+        mx = fmax(mx, a);
+      }
+      red_mx = live ? fmax(red_mx, mx) : red_mx;
+      cand = cand || ((bits | (bits >> 3)) & ((1u << ND) - 1u)) != ((1u << ND) - 1u);   // a component without a strict sign
+      const int x = 4 * g + q + m.ext_st[0];
+      const bool dom = row_dom && x >= m.dom_lb[0] && x <= m.dom_ub[0];
+      if (mx >= job.big) bits = 0u;                            // may overflow a determinant: supports no cull
+      if (!fin || !dom) bits = kNeutral;                       // simplices with this vertex are rejected (2d:611, 3d:457) / never formed
+      word |= bits << (8 * q);
+    }
+    if (__builtin_amdgcn_ballot_w64(cand && live)) {           // rare on smooth data: candidates for the slice's resolution
+      if (live)
+        for (int q = 0; q < 4 * ND; q ++) { const double a = fabs(v[q]); red_mn = fmin(red_mn, (a == 0.0 || !(a < thr)) ? DBL_MAX : a); }
+    }
+    bool word_uniform = false;
+    if (have_u) {
+      int q8 = (int)(word & (word >> 16)); q8 &= q8 >> 8; q8 &= 0x3f;
+      q8 &= __builtin_amdgcn_update_dpp(q8, q8, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);   // the other half of the 8-vertex word
+      if (live && (g & 1) == 0) job.U[row * (size_t)UP + (size_t)(g >> 1)] = (unsigned char)q8;
+      word_uniform = q8 != 0;                                  // the refine kernel substitutes the summary: mask bytes not needed
+    }
+    if (live && !word_uniform) *reinterpret_cast<unsigned *>(job.M + row * (size_t)P + (size_t)(4 * g)) = word;
+  }
+  if (job.red) red_commit(job.red, red_mn, red_mx, blockIdx.x * 5u + (threadIdx.x >> 6));
 }
 
 // Scalar input: the same masks, produced by a register-marching stencil so that every S value is fetched from HBM once.
@@ -603,6 +684,7 @@ __global__ __launch_bounds__(kThreads) void mask_march_kernel(const Mesh m, cons
     for (int r = 0; r < RY; r ++) prv[r] = (ND == 3) ? pc[roff[r + 1] + zp] : 0.0;
   }
   unsigned char *mrow = job.M + (size_t)i + (size_t)P * (size_t)j0;
+  double red_mn = DBL_MAX, red_mx = 0.0;      // fused pre-pass: see MaskJob::red
 
   for (int k = z0; k < z1; k ++) {
     const size_t zo = sz * (size_t)k, zn = sz * (size_t)(k + 1 < DD ? k + 1 : DD - 1);
@@ -623,6 +705,16 @@ __global__ __launch_bounds__(kThreads) void mask_march_kernel(const Mesh m, cons
       unsigned bits = (g0 >= thr ? 1u : 0u) | (g1 >= thr ? 2u : 0u) | (g0 <= -thr ? 8u : 0u) | (g1 <= -thr ? 16u : 0u);
       if (ND == 3) bits |= (g2 >= thr ? 4u : 0u) | (g2 <= -thr ? 32u : 0u);
       const bool rbit_int = (row_int >> r) & 1, rbit_dom = (row_dom >> r) & 1;
+      const bool real = (ND == 2 || (x_int && rbit_int && z_int)) && ((row_ok >> r) & 1) && i < DW;   // a value of gradient(S)
+      if (fmax(fmax(fabs(g0), fabs(g1)), fabs(g2)) >= job.big) bits = 0;   // may overflow a determinant: supports no cull
+      if (real) {
+        const double gs[3] = {g0, g1, g2};
+        for (int c = 0; c < ND; c ++) {
+          const double a = fabs(gs[c]);
+          red_mn = fmin(red_mn, (a == 0.0 || !(a < thr)) ? DBL_MAX : a);
+          red_mx = fmax(red_mx, a);
+        }
+      }
       if (ND == 3 && !(x_int && rbit_int && z_int)) bits = 0;          // gradient3D leaves the array border at 0
       if (!(x_dom && rbit_dom && z_dom)) bits = kNeutral;               // outside the domain (or row padding): never blocks a cull
       if (((row_ok >> r) & 1) && i < P) mrow[(size_t)P * ((size_t)r + (size_t)DH * (size_t)k)] = (unsigned char)bits;
@@ -632,200 +724,10 @@ __global__ __launch_bounds__(kThreads) void mask_march_kernel(const Mesh m, cons
       cur[0] = h0; cur[RY + 1] = h1;
     }
   }
+  if (job.red) red_commit(job.red, red_mn, red_mx, blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + (unsigned)wv);
 }
 
-// Two x columns per lane, 16-byte loads, one plane of software prefetch.  A wavefront covers 128 columns of which the outer
-// lane on either side is a pure halo (it only supplies the x neighbour of the adjacent lane): tiles advance by 124 columns and
-// start at an even column, so every lane's pair stays 16-byte aligned and no lane ever needs a second, divergent load.
-// Needs an even row length and slices below 4 GiB (32-bit byte offsets); the launcher falls back to mask_march_kernel
-// otherwise.  Same arithmetic, same result bytes.
-constexpr int kMarch2Cols = 124;
 __device__ inline bool bits_dummy_guard(double thr) { return thr < 1e300; }   // always true for real thresholds; opaque to the optimiser
-
-// EDGE = true: 128 owner columns per wavefront, every lane owns its pair, the two outside neighbours are fetched by lanes 0 and
-// 63 into a spare register set (better when the row length is a multiple of 128, e.g. 512: 4 tiles instead of 5).
-template <int ND, bool EDGE, bool REDUCE>
-__global__ __launch_bounds__(768) void mask_march2_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
-{
-  constexpr int RY = (ND == 3) ? 4 : 8;
-  constexpr int TILE = EDGE ? 128 : kMarch2Cols;
-  const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
-  const int nzc = (ND == 3) ? (DD + zchunk - 1) / zchunk : 1;
-  // optional XCD-aware remap (workgroups b and b+8 share an L2): contiguous runs of tiles per XCD.  Speed only.
-  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (swizzle & 1) {
-    const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
-    unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const unsigned per = nb / 8, rem = nb % 8, xcd = b % 8, k = b / 8;
-    b = xcd * per + (xcd < rem ? xcd : rem) + k;
-    bx = b % gridDim.x; by = (b / gridDim.x) % gridDim.y; bz = b / (gridDim.x * gridDim.y);
-  }
-  if (swizzle & 8) {
-    // grouped placement: the hardware deals workgroups round-robin to the 8 XCDs, so workgroup ids b, b+8, b+16, ... share an
-    // L2.  Give each XCD, at any moment, one group of G = gridDim.x * YG neighbouring tiles (all x tiles of YG row groups): the x
-    // edge columns and y halo rows a tile needs from its neighbours are then L2 hits, while the 8 XCDs still work side by side
-    // in memory.  Groups are contiguous in the linear tile order, so the tail that does not fill 8 groups keeps the identity.
-    const unsigned YG = ((unsigned)swizzle >> 8) & 0xffu;
-    const unsigned nb = gridDim.x * gridDim.y * gridDim.z, G = gridDim.x * YG;
-    const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (b < (nb / (8u * G)) * (8u * G)) {
-      const unsigned q = b % 8u, r = b / 8u, grp = (r / G) * 8u + q, in = r % G, ngy = gridDim.y / YG;
-      bx = in % gridDim.x; by = (grp % ngy) * YG + in / gridDim.x; bz = grp / ngy;
-    }
-  }
-  const bool debug_no_store = (swizzle & 2) != 0;   // profiling experiment only (FTKX_MASK_SWIZZLE=3): results are then garbage
-  const MaskJob job = jobs[bz / nzc];
-  const int z0 = (ND == 3) ? (int)(bz % nzc) * zchunk : 0;
-  const int z1 = (ND == 3) ? (z0 + zchunk < DD ? z0 + zchunk : DD) : 1;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i0 = (int)bx * TILE + (EDGE ? 0 : -2) + 2 * lane;  // columns i0, i0 + 1 (halo variant: lane 0 / lane 63 are halo pairs)
-  const int wpb = blockDim.x >> 6;                             // wavefronts per workgroup = consecutive row groups sharing halo rows in L1/L2
-  const int j0 = (by * wpb + wv) * RY;
-  if (j0 >= DH) return;
-  const char *__restrict__ Sb = reinterpret_cast<const char *>(job.S);
-  const double thr = job.threshold, nthr = -job.threshold;
-  const unsigned sy = (unsigned)DW * 8u, sz = (unsigned)DW * (unsigned)DH * 8u;   // byte strides
-
-  const int ic = i0 < 0 ? 0 : (i0 < DW ? i0 : DW - 2);        // clamped (even) column pair for the loads
-  const bool dup_lo = i0 < 0, dup_hi = i0 >= DW;              // 2D index clamp: columns left / right of the array repeat the border
-  const bool owner = EDGE || (lane >= 1 && lane <= 62);       // this lane writes its two mask bytes
-  const bool edge = EDGE && (lane == 0 || lane == 63);
-  const int ih = lane == 0 ? (ic > 0 ? ic - 1 : 0) : (ic + 2 < DW ? ic + 2 : DW - 1);   // EDGE: outside neighbour column (clamped)
-  const unsigned hb = (unsigned)ih * 8u;
-  unsigned xkeep = 0, xneutral = 0;                           // per column: byte c of the pair
-  for (int c = 0; c < 2; c ++) {
-    const int i = i0 + c;
-    const bool x_dom = i >= 0 && i < DW && i + m.ext_st[0] >= m.dom_lb[0] && i + m.ext_st[0] <= m.dom_ub[0];
-    const bool x_int = (ND == 2) || (i >= 1 && i < DW - 1);
-    if (x_int) xkeep |= 0x3fu << (8 * c);
-    if (!x_dom) xneutral |= 0x3fu << (8 * c);
-  }
-  unsigned roff[RY + 2];
-  unsigned row_dom = 0, row_int = 0, row_ok = 0;
-  for (int r = 0; r < RY + 2; r ++) {
-    const int j = j0 + r - 1;
-    roff[r] = sy * (unsigned)clampi(j, 0, DH - 1);
-    if (r >= 1 && r <= RY) {
-      if (j < DH) row_ok |= 1u << (r - 1);
-      if (j + m.ext_st[1] >= m.dom_lb[1] && j + m.ext_st[1] <= m.dom_ub[1]) row_dom |= 1u << (r - 1);
-      if (j >= 1 && j < DH - 1) row_int |= 1u << (r - 1);
-    }
-  }
-  const unsigned cb = (unsigned)ic * 8u;
-  // swizzle bit 4: every load nontemporal; bit 16: only the rows no other wavefront reads (r = 2 .. RY-1 of 0 .. RY+1; rows 0, 1,
-  // RY, RY+1 are halo rows here or in the neighbouring wavefront and should stay cached for it)
-  const bool nt_all = (swizzle & 4) != 0, nt_private = (swizzle & 16) != 0;
-  auto ld2r = [&](unsigned off, bool nt) -> double2 {
-    const double2 *q = reinterpret_cast<const double2 *>(Sb + off);
-    double2 v;
-    if (nt) { v.x = __builtin_nontemporal_load(&q->x); v.y = __builtin_nontemporal_load(&q->y); } else v = *q;
-    if (ND == 2) { if (dup_lo) v.y = v.x; if (dup_hi) v.x = v.y; }
-    return v;
-  };
-  auto ld2 = [&](unsigned off) -> double2 { return ld2r(off, nt_all); };
-  auto row_nt = [&](int r) -> bool { return nt_all || (nt_private && r >= 2 && r <= RY - 1); };
-  auto zoff = [&](int k) -> unsigned { return sz * (unsigned)clampi(k, 0, DD - 1); };
-
-  auto ld1 = [&](unsigned off) -> double { return *reinterpret_cast<const double *>(Sb + off); };
-  double2 cur[RY + 2], prv[RY], nxt[RY + 2];
-  double ex[EDGE ? RY : 1], exn[EDGE ? RY : 1];               // EDGE: outside-neighbour column of lanes 0 / 63, planes k and k+1
-  for (int r = 0; r < (EDGE ? RY : 1); r ++) { ex[r] = 0.0; exn[r] = 0.0; }
-  {
-    const unsigned zo = zoff(z0), zp = zoff(z0 - 1), zn = zoff(z0 + 1);
-    for (int r = 0; r < RY + 2; r ++) { cur[r] = ld2r(cb + roff[r] + zo, row_nt(r)); nxt[r] = (ND == 3) ? ld2r(cb + roff[r] + zn, row_nt(r)) : cur[r]; }
-    for (int r = 0; r < RY; r ++) prv[r] = (ND == 3) ? ld2(cb + roff[r + 1] + zp) : cur[r + 1];
-    if (edge) for (int r = 0; r < RY; r ++) { ex[r] = ld1(hb + roff[r + 1] + zo); exn[r] = (ND == 3) ? ld1(hb + roff[r + 1] + zn) : 0.0; }
-  }
-  // the row padding [DW, P) is neutral for the cull: it is filled once when the mask array is allocated and never written here
-  const bool store_ok = owner && i0 >= 0 && i0 < DW && !(debug_no_store && bits_dummy_guard(thr));
-  const bool want_mask = !REDUCE;
-  // REDUCE = pre-pass instantiation: ndarray::resolution() of V = gradient(S) over the WHOLE array (ndarray.hh:770-778) with the
-  // same single walk over S; nothing is stored.  min over non-zero |v| (NaN and Inf never win), max over finite |v|.
-  double red_mn = DBL_MAX, red_mx = 0.0;
-  auto red_take = [&](double g) {
-    const double a = fabs(g);
-    red_mn = fmin(red_mn, a == 0.0 ? DBL_MAX : a);
-    red_mx = fmax(red_mx, a < HUGE_VAL ? a : 0.0);
-  };
-  unsigned char *mrow = job.M + (size_t)(i0 < 0 ? 0 : i0) + (size_t)P * (size_t)j0;
-
-  for (int k = z0; k < z1; k ++) {
-    // prefetch plane k + 2 while plane k is being classified
-    double2 nn[RY + 2];
-    double exnn[EDGE ? RY : 1];
-    if (ND == 3 && k + 2 <= z1) {                             // plane z1 is still needed (d/dz of the chunk's last plane), z1 + 1 is not
-      const unsigned z2 = zoff(k + 2);
-      for (int r = 0; r < RY + 2; r ++) nn[r] = ld2r(cb + roff[r] + z2, row_nt(r));
-      if (edge) for (int r = 0; r < RY; r ++) exnn[r] = ld1(hb + roff[r + 1] + z2);
-    }
-    const bool z_dom = ND == 2 || (k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2]);
-    const bool z_int = ND == 2 || (k >= 1 && k < DD - 1);
-    for (int r = 0; r < RY; r ++) {
-      const double2 c = cur[r + 1];
-      double xm = dpp_from_lower_lane(c.y);                   // left neighbour of column i0   (halo lane 0 serves lane 1)
-      double xp = dpp_from_upper_lane(c.x);                   // right neighbour of column i0+1 (halo lane 63 serves lane 62)
-      if constexpr (EDGE) {
-        if (lane == 0) xm = ex[r];
-        if (lane == 63) xp = ex[r];
-        if (ND == 2 && i0 + 1 == DW - 1) xp = c.y;            // 2D clamp: the right neighbour of the last column is itself
-      }
-      double gx0, gx1, gy0, gy1, gz0 = 0.0, gz1 = 0.0;
-      if constexpr (ND == 3) {
-        gx0 = 0.5 * (c.y - xm); gx1 = 0.5 * (xp - c.x);
-        gy0 = 0.5 * (cur[r + 2].x - cur[r].x); gy1 = 0.5 * (cur[r + 2].y - cur[r].y);
-        gz0 = 0.5 * (nxt[r + 1].x - prv[r].x); gz1 = 0.5 * (nxt[r + 1].y - prv[r].y);
-      } else {
-        const double fx = (double)(DW - 1), fy = (double)(DH - 1);
-        gx0 = (c.y - xm) * fx; gx1 = (xp - c.x) * fx;
-        gy0 = (cur[r + 2].x - cur[r].x) * fy; gy1 = (cur[r + 2].y - cur[r].y) * fy;
-      }
-      unsigned bits = (gx0 >= thr ? 0x0001u : 0u) | (gy0 >= thr ? 0x0002u : 0u) | (gx0 <= nthr ? 0x0008u : 0u) | (gy0 <= nthr ? 0x0010u : 0u)
-                    | (gx1 >= thr ? 0x0100u : 0u) | (gy1 >= thr ? 0x0200u : 0u) | (gx1 <= nthr ? 0x0800u : 0u) | (gy1 <= nthr ? 0x1000u : 0u);
-      if (ND == 3) bits |= (gz0 >= thr ? 0x0004u : 0u) | (gz0 <= nthr ? 0x0020u : 0u) | (gz1 >= thr ? 0x0400u : 0u) | (gz1 <= nthr ? 0x2000u : 0u);
-      // wave-uniform row / plane conditions, per-lane column conditions
-      const bool u_int = ND == 2 || (((row_int >> r) & 1) && z_int), u_dom = ((row_dom >> r) & 1) && z_dom;
-      if constexpr (REDUCE) {
-        if (u_int && ((row_ok >> r) & 1) && store_ok) {
-          if (xkeep & 0x3fu) { red_take(gx0); red_take(gy0); if (ND == 3) red_take(gz0); }
-          if (xkeep & 0x3f00u) { red_take(gx1); red_take(gy1); if (ND == 3) red_take(gz1); }
-        }
-        continue;
-      }
-      bits = u_int ? (bits & xkeep) : 0u;                     // gradient3D leaves the array border at 0
-      bits = u_dom ? (bits | xneutral) : 0x3f3fu;             // outside the domain / row padding: never blocks a cull
-      bool word_uniform = false;
-      if constexpr (EDGE) {
-        // summary byte of the aligned 8-vertex word this quad of lanes covers: the sign bits ALL eight vertices share.
-        // (lanes beyond the row contribute neutral bytes, so a partial last word summarises its real vertices only)
-        if (job.U) {
-          int q = (int)((bits & (bits >> 8)) & 0x3fu);
-          q &= __builtin_amdgcn_update_dpp(q, q, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
-          q &= __builtin_amdgcn_update_dpp(q, q, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
-          if (((row_ok >> r) & 1) && (lane & 3) == 0 && i0 < DW)
-            job.U[(size_t)(i0 >> 3) + (size_t)m.u_pitch * ((size_t)(j0 + r) + (size_t)DH * (size_t)k)] = (unsigned char)q;
-          // A word whose eight vertices share a strict sign is fully described by its summary: the refine kernel substitutes
-          // the summary for it (conservative: it may only cull less), so its eight mask bytes are not written at all --
-          // on smooth fields that is almost every word, and the mask array costs 1/8 byte per vertex of HBM writes instead of 1.
-          word_uniform = q != 0;
-        }
-      }
-      if (((row_ok >> r) & 1) && store_ok && want_mask && !word_uniform)
-        *reinterpret_cast<unsigned short *>(mrow + (size_t)P * ((size_t)r + (size_t)DH * (size_t)k)) = (unsigned short)bits;
-    }
-    if (ND == 3) {
-      for (int r = 0; r < RY; r ++) prv[r] = cur[r + 1];
-      for (int r = 0; r < RY + 2; r ++) { cur[r] = nxt[r]; nxt[r] = nn[r]; }
-      if constexpr (EDGE) for (int r = 0; r < RY; r ++) { ex[r] = exn[r]; exn[r] = exnn[r]; }
-    }
-  }
-  if constexpr (REDUCE) {
-    for (int o = 32; o > 0; o >>= 1) { red_mn = fmin(red_mn, __shfl_down(red_mn, o)); red_mx = fmax(red_mx, __shfl_down(red_mx, o)); }
-    // non-negative doubles order like their bit patterns
-    // 64 result slots (the host folds them): all wavefronts hammering one address would serialise at the memory side
-    const unsigned slot = (blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + wv) & 63u;
-    if (lane == 0) { atomicMin(&job.red[2 * slot], (u64)__double_as_longlong(red_mn)); atomicMax(&job.red[2 * slot + 1], (u64)__double_as_longlong(red_mx)); }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // The same walk as mask_march2_kernel<ND, EDGE = true, REDUCE> on a VALU diet.  rocprofv3 showed the kernel above issue-bound
@@ -946,6 +848,36 @@ __device__ inline double edge_for_row(double xe)
   return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
+// What the marching kernels do per row beside the sign bits, so that ONE pass over S serves the whole sweep (MaskJob):
+//   * running max of |d| per column (a0 / a1 = this lane's two vertices): the slice's max |v|;
+//   * candidates for the slice's resolution: only components WITHOUT a strict sign (|v| < threshold) can lower the scaling
+//     factor's running minimum below 1 / F, and on smooth data almost no row has one -- one ballot per row, the min-non-zero
+//     arithmetic runs only where it fires;
+//   * vertices that may overflow a determinant (|v| >= big) lose their sign bits.
+// d* are the raw central differences the sign bits were taken from (3D: twice the gradient, h = 0.5; 2D: the gradient, h = 1);
+// `rv` (wave-uniform): this row holds real entries of gradient(S); cmask: which of the lane's two columns do, as the bits
+// 0x07 (0x03 in 2D) of their byte.  Returns the pair of mask bytes.
+template <int ND>
+__device__ inline unsigned guard_and_reduce(unsigned a0, unsigned a1, double dx0, double dx1, double dy0, double dy1, double dz0, double dz1,
+                                            bool rv, unsigned cmask, double tbig, double h, double &acc0, double &acc1, double &red_mn)
+{
+  double m0 = fmax(fabs(dx0), fabs(dy0)), m1 = fmax(fabs(dx1), fabs(dy1));
+  if constexpr (ND == 3) { m0 = fmax(m0, fabs(dz0)); m1 = fmax(m1, fabs(dz1)); }
+  if (rv) {
+    acc0 = fmax(acc0, m0); acc1 = fmax(acc1, m1);
+    const unsigned raw = a0 | (a1 << 8);
+    const unsigned u = raw | (raw >> 3);                       // bit c of a byte: component c is strictly signed
+    if (__builtin_amdgcn_ballot_w64((~u & cmask) != 0u)) {
+      auto take = [&](double d) { const double a = fabs(h * d); red_mn = fmin(red_mn, a == 0.0 ? DBL_MAX : a); };
+      if (cmask & 0x00ffu) { take(dx0); take(dy0); if (ND == 3) take(dz0); }
+      if (cmask & 0xff00u) { take(dx1); take(dy1); if (ND == 3) take(dz1); }
+    }
+  }
+  if (m0 >= tbig) a0 = 0u;
+  if (m1 >= tbig) a1 = 0u;
+  return a0 | (a1 << 8);
+}
+
 // PD = prefetch distance: at the step for plane k the loads of plane k + 1 + PD are issued (PD = 1: three planes of registers
 // plus one in flight).  RY = rows per wavefront: a plane costs (RY + 2) * 4 + 2 VGPRs; 3D runs RY = 4 at three wavefronts per
 // SIMD or RY = 8 at two (fewer halo rows per useful row, and 6 of 10 row loads are private to the wavefront).
@@ -1032,6 +964,10 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
     red_mn = fmin(red_mn, a == 0.0 ? DBL_MAX : a);
     red_mx = fmax(red_mx, a < HUGE_VAL ? a : 0.0);
   };
+  // fused pre-pass (mask instantiations): see guard_and_reduce
+  double acc0 = 0.0, acc1 = 0.0;
+  const unsigned cmask = store_ok ? (xkeep & (ND == 3 ? 0x0707u : 0x0303u)) : 0u;
+  const double tbig = (ND == 3) ? 2.0 * job.big : job.big;
 
   // one plane: prefetch plane k + 1 + PD into NN / XNN, classify plane k from (PR = k-1, CU = k, NX = k+1) and CU's edge register XC
   auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], const v2d (&NX)[RY + 2], v2d (&NN)[RY + 2], const double XC, double &XNN, int k) {
@@ -1079,13 +1015,13 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
       } else
       shift_in_signs<ND>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, tneg, tpos);
       if (ND == 2) { a0 = ((a0 & 0xcu) << 1) | (a0 & 3u); a1 = ((a1 & 0xcu) << 1) | (a1 & 3u); }   // leave the two z bits empty
-      unsigned bits = a0 | (a1 << 8);
+      const bool rok = ((row_ok >> r) & 1) && k < z1;
+      unsigned bits = guard_and_reduce<ND>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, u_int && rok, cmask, tbig, ND == 3 ? 0.5 : 1.0, acc0, acc1, red_mn);
       // wave-uniform row / plane conditions, per-lane column conditions
       const unsigned keep = u_int ? xkeep : 0u;                // gradient3D leaves the array border at 0
       const unsigned neut = u_dom ? xneutral : 0x3f3fu;        // outside the domain / row padding: never blocks a cull
       bits = (bits & keep) | neut;
       bool word_uniform = false;
-      const bool rok = ((row_ok >> r) & 1) && k < z1;
       // summary byte of the aligned 8-vertex word this quad of lanes covers: the sign bits ALL eight vertices share
       if (have_u) {
         int q = (int)((bits & (bits >> 8)) & 0x3fu);
@@ -1112,10 +1048,12 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
     for (int i = 0; i < NB; i ++)   // no `if (k + i < z1)` around a step: planes past the chunk are walked without stores
       step(B[i], B[(i + 1) % NB], B[(i + 2) % NB], B[(i + 2 + PD) % NB], X[(i + 1) % NB], X[(i + 2 + PD) % NB], k + i);
   }
-  if constexpr (REDUCE) {
-    for (int o = 32; o > 0; o >>= 1) { red_mn = fmin(red_mn, __shfl_down(red_mn, o)); red_mx = fmax(red_mx, __shfl_down(red_mx, o)); }
-    const unsigned slot = (blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + (unsigned)wv) & 63u;
-    if (lane == 0) { atomicMin(&job.red[2 * slot], (u64)__double_as_longlong(red_mn)); atomicMax(&job.red[2 * slot + 1], (u64)__double_as_longlong(red_mx)); }
+  const unsigned slot = blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + (unsigned)wv;
+  if constexpr (REDUCE) red_commit(job.red, red_mn, red_mx, slot);
+  else if (job.red) {
+    const double h = (ND == 3) ? 0.5 : 1.0;
+    const double mx = fmax((cmask & 0x00ffu) ? acc0 : 0.0, (cmask & 0xff00u) ? acc1 : 0.0) * h;
+    red_commit(job.red, red_mn < job.threshold ? red_mn : DBL_MAX, mx, slot);
   }
 }
 
@@ -1240,6 +1178,10 @@ __global__ __launch_bounds__(64 * (TW * CY + 1)) void mask_march5_kernel(const M
   const bool store_ok = in_row && !debug_no_store;
   const unsigned mcol = (unsigned)i0, ucol = (unsigned)(i0 >> 3);
   const bool u_lane = (lane & 3) == 0 && in_row;
+  // fused pre-pass: see guard_and_reduce
+  double acc0 = 0.0, acc1 = 0.0, red_mn = DBL_MAX;
+  const unsigned cmask = in_row ? (xkeep & 0x0707u) : 0u;
+  const double tbig = 2.0 * job.big;
   // LDS addresses of this lane inside a slot: its 16 bytes of a row, and where the two dwords of the neighbour value it carries in
   // the fused edge register live (lane r < RY: left neighbour of own row r; lane 64 - RY + r: right neighbour; see edge_for_row):
   // inside the tile that is the adjacent column of the same LDS row, at the tile's outer columns the separately fetched values
@@ -1282,12 +1224,12 @@ __global__ __launch_bounds__(64 * (TW * CY + 1)) void mask_march5_kernel(const M
       const bool u_int = ((row_int >> r) & 1) && z_int, u_dom = ((row_dom >> r) & 1) && z_dom;
       unsigned a0 = 0, a1 = 0;
       shift_in_signs<3>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, tneg, tpos);
-      unsigned bits = a0 | (a1 << 8);
+      const bool rok = ((row_ok >> r) & 1) && k < z1;
+      unsigned bits = guard_and_reduce<3>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, u_int && rok, cmask, tbig, 0.5, acc0, acc1, red_mn);
       const unsigned keep = u_int ? xkeep : 0u;
       const unsigned neut = u_dom ? xneutral : 0x3f3fu;
       bits = (bits & keep) | neut;
       bool word_uniform = false;
-      const bool rok = ((row_ok >> r) & 1) && k < z1;
       if (have_u) {
         int q = (int)((bits & (bits >> 8)) & 0x3fu);
         q &= __builtin_amdgcn_update_dpp(q, q, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
@@ -1310,6 +1252,10 @@ __global__ __launch_bounds__(64 * (TW * CY + 1)) void mask_march5_kernel(const M
     step(B[0], B[1], B[2], X[1], X[2], z0 + s);
     step(B[1], B[2], B[0], X[2], X[0], z0 + s + 1);
     step(B[2], B[0], B[1], X[0], X[1], z0 + s + 2);
+  }
+  if (job.red) {
+    const double mx = fmax((cmask & 0x00ffu) ? acc0 : 0.0, (cmask & 0xff00u) ? acc1 : 0.0) * 0.5;
+    red_commit(job.red, red_mn < job.threshold ? red_mn : DBL_MAX, mx, blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + (unsigned)wv);
   }
 #endif
 }
@@ -1694,7 +1640,7 @@ const char *last_mask_kernel() { return g_last_mask_kernel; }
 
 void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool reduce, hipStream_t stream);
 
-// can the marching kernel (which carries the fused reduction) walk this mesh?
+// can the 128-column marching kernels (which also carry the exact pre-pass reduction) walk this mesh? (which carries the fused reduction) walk this mesh?
 bool march2_supported(const Mesh &m)
 {
   const int DD = m.nd == 3 ? m.ext_sz[2] : 1;
@@ -1742,6 +1688,9 @@ void tile_dims(int nd, int tile[3])
   else { tile[0] = tile_cfg<3>::TX; tile[1] = tile_cfg<3>::TY; tile[2] = tile_cfg<3>::TZ; }
 }
 
+// does this mesh take the fast vector-input kernel?
+static bool vec_fast(const Mesh &m) { return !m.scalar_mode && m.ext_sz[0] >= 8 && (m.ext_sz[0] % 8) == 0; }
+
 void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool reduce, hipStream_t stream)
 {
   if (njobs <= 0) return;
@@ -1751,25 +1700,16 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
     // z chunks: long enough to amortise the two start-up planes, short enough to fill 256 CUs several times over
     int zchunk = 32;
     if (const char *e = getenv("FTKX_MASK_ZCHUNK")) zchunk = atoi(e) > 0 ? atoi(e) : zchunk;
-    if (m.nd == 3) { while (zchunk > 8 && (size_t)((m.mask_pitch + kMarch2Cols - 1) / kMarch2Cols) * ((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)) * ((DD + zchunk - 1) / zchunk) * njobs < 8192) zchunk /= 2; }
-    int swizzle = -1;  // decided per tile variant below
+    if (m.nd == 3) { while (zchunk > 8 && (size_t)((m.mask_pitch + 127) / 128) * ((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)) * ((DD + zchunk - 1) / zchunk) * njobs < 8192) zchunk /= 2; }
+    int swizzle = 8;   // grouped placement -- the 4..8 x tiles of a row group on one XCD -- cuts the fabric reads from 47.7 to 41.4 GB per 512^3 x 32 launch
     if (const char *e = getenv("FTKX_MASK_SWIZZLE")) swizzle = atoi(e);
     const int nzc = m.nd == 3 ? (DD + zchunk - 1) / zchunk : 1;
-    const size_t slice_bytes = (size_t)m.ext_sz[0] * m.ext_sz[1] * DD * 8;
-    if ((m.ext_sz[0] % 2) == 0 && m.ext_sz[0] >= 2 && slice_bytes < (1ull << 32)) {
-      // tile variant with the fewer wavefront columns wasted: 124-column tiles with halo lanes, or 128-column tiles with edge loads
+    if (march2_supported(m)) {
+      // 128-column tiles, the two outside-neighbour columns fetched separately (line-aligned tiles)
       const int DW = m.ext_sz[0];
-      const int tiles_halo = (DW + kMarch2Cols - 1) / kMarch2Cols, tiles_edge = (DW + 127) / 128;
-      bool use_edge = tiles_edge < tiles_halo;
-      if (const char *e = getenv("FTKX_MASK_EDGE")) use_edge = atoi(e) != 0;
-      // XCD-contiguous tile mapping: needed by the 124-column variant, whose tiles straddle cache lines (8.7 vs 11.8 ms on
-      // 512^3 x 32); the line-aligned 128-column variant is ~3 % faster with the plain round-robin placement (7.25 vs 7.50 ms)
-      // (the 128-column layout: grouped placement -- the 4..8 x tiles of a row group on one XCD -- cuts the fabric reads from 47.7
-      // to 41.4 GB per 512^3 x 32 launch and is never slower: 6.62 vs 6.74 ms)
-      if (swizzle < 0) swizzle = use_edge ? 8 : 1;
       int wpb = 4;
       if (const char *e = getenv("FTKX_MASK_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 12) wpb = v; }
-      const dim3 grid2((unsigned)(use_edge ? tiles_edge : tiles_halo), (unsigned)((m.ext_sz[1] + wpb * RY - 1) / (wpb * RY)), (unsigned)(nzc * njobs));
+      const dim3 grid2((unsigned)((DW + 127) / 128), (unsigned)((m.ext_sz[1] + wpb * RY - 1) / (wpb * RY)), (unsigned)(nzc * njobs));
       if (swizzle & 8) {   // grouped placement: YG row groups per group (must divide the grid's y extent)
         int yg = 1;
         if (const char *e = getenv("FTKX_MASK_YG")) yg = atoi(e) > 0 ? atoi(e) : 1;
@@ -1777,9 +1717,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
         swizzle = (swizzle & 0xff) | (yg << 8);
       }
       const dim3 blk((unsigned)(64 * wpb));
-      bool diet = use_edge;                                   // the VALU-diet kernel implements the 128-column layout only
-      if (const char *e = getenv("FTKX_MASK_V")) diet = diet && atoi(e) != 2;
-      if (diet && m.nd == 3 && !reduce) {
+      if (m.nd == 3 && !reduce) {
         // default for 3D scalar slices: the producer / consumer kernel, 128 x 16 tiles, two planes in flight behind the one being
         // consumed (6.3 vs 6.7 ms for mask_march4_kernel on 512^3 x 32, same box); FTKX_MASK_V=4 selects the latter
         int v5 = 1, pd5 = 2;
@@ -1815,33 +1753,23 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
           return;
         }
       }
-      if (diet) {
-        int pd = 1, ry = (m.nd == 3) ? 4 : 8;
-        if (const char *e = getenv("FTKX_MASK_PD")) pd = atoi(e);
-        if (const char *e = getenv("FTKX_MASK_RY")) { if (m.nd == 3 && (atoi(e) == 4 || atoi(e) == 8)) ry = atoi(e); }
-        const dim3 grid4(grid2.x, (unsigned)((m.ext_sz[1] + wpb * ry - 1) / (wpb * ry)), grid2.z);
-        if ((swizzle & 8) && grid4.y != grid2.y) { int yg = (swizzle >> 8) & 0xff; while (yg > 1 && grid4.y % (unsigned)yg) yg --; swizzle = (swizzle & 0xff) | (yg << 8); }
-        unsigned lds = 0;                                       // experiment: dynamic LDS only to cap the workgroups per CU
-        if (const char *e = getenv("FTKX_MASK_LDS_KB")) lds = (unsigned)atoi(e) * 1024u;
+      int pd = 1, ry = (m.nd == 3) ? 4 : 8;
+      if (const char *e = getenv("FTKX_MASK_PD")) pd = atoi(e);
+      if (const char *e = getenv("FTKX_MASK_RY")) { if (m.nd == 3 && (atoi(e) == 4 || atoi(e) == 8)) ry = atoi(e); }
+      const dim3 grid4(grid2.x, (unsigned)((m.ext_sz[1] + wpb * ry - 1) / (wpb * ry)), grid2.z);
+      if ((swizzle & 8) && grid4.y != grid2.y) { int yg = (swizzle >> 8) & 0xff; while (yg > 1 && grid4.y % (unsigned)yg) yg --; swizzle = (swizzle & 0xff) | (yg << 8); }
+      unsigned lds = 0;                                       // experiment: dynamic LDS only to cap the workgroups per CU
+      if (const char *e = getenv("FTKX_MASK_LDS_KB")) lds = (unsigned)atoi(e) * 1024u;
 #define FTKX_M4(ND_, R_, PD_, RY_) do { if (!reduce) g_last_mask_kernel = "ftkx::mask_march4_kernel<" #ND_ ", " #R_ ", " #PD_ ", " #RY_ ">"; if (lds) (void)hipFuncSetAttribute((const void *)mask_march4_kernel<ND_, R_, PD_, RY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-          hipLaunchKernelGGL((mask_march4_kernel<ND_, R_, PD_, RY_>), grid4, blk, lds, stream, m, d_jobs, zchunk, swizzle); } while (0)
-        if (reduce) { if (m.nd == 2) FTKX_M4(2, true, 1, 8); else FTKX_M4(3, true, 1, 4); }
-        else if (m.nd == 2) FTKX_M4(2, false, 1, 8);
-        else if (ry == 8) { if (pd == 2) FTKX_M4(3, false, 2, 8); else if (pd == 0) FTKX_M4(3, false, 0, 8); else FTKX_M4(3, false, 1, 8); }
-        else if (pd == 2) FTKX_M4(3, false, 2, 4);
-        else if (pd == 3) FTKX_M4(3, false, 3, 4);
-        else if (pd == 0) FTKX_M4(3, false, 0, 4);
-        else FTKX_M4(3, false, 1, 4);
+        hipLaunchKernelGGL((mask_march4_kernel<ND_, R_, PD_, RY_>), grid4, blk, lds, stream, m, d_jobs, zchunk, swizzle); } while (0)
+      if (reduce) { if (m.nd == 2) FTKX_M4(2, true, 1, 8); else FTKX_M4(3, true, 1, 4); }
+      else if (m.nd == 2) FTKX_M4(2, false, 1, 8);
+      else if (ry == 8) { if (pd == 2) FTKX_M4(3, false, 2, 8); else if (pd == 0) FTKX_M4(3, false, 0, 8); else FTKX_M4(3, false, 1, 8); }
+      else if (pd == 2) FTKX_M4(3, false, 2, 4);
+      else if (pd == 3) FTKX_M4(3, false, 3, 4);
+      else if (pd == 0) FTKX_M4(3, false, 0, 4);
+      else FTKX_M4(3, false, 1, 4);
 #undef FTKX_M4
-        return;
-      }
-#define FTKX_M2(ND_, E_, R_) do { if (!reduce) g_last_mask_kernel = "ftkx::mask_march2_kernel<" #ND_ ", " #E_ ", " #R_ ">"; \
-        hipLaunchKernelGGL((mask_march2_kernel<ND_, E_, R_>), grid2, blk, 0, stream, m, d_jobs, zchunk, swizzle); } while (0)
-      if (reduce) { if (m.nd == 2) { if (use_edge) FTKX_M2(2, true, true); else FTKX_M2(2, false, true); }
-                    else { if (use_edge) FTKX_M2(3, true, true); else FTKX_M2(3, false, true); } }
-      else { if (m.nd == 2) { if (use_edge) FTKX_M2(2, true, false); else FTKX_M2(2, false, false); }
-             else { if (use_edge) FTKX_M2(3, true, false); else FTKX_M2(3, false, false); } }
-#undef FTKX_M2
       return;
     }
     const dim3 grid((unsigned)((m.mask_pitch + 63) / 64), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
@@ -1850,7 +1778,18 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
     else hipLaunchKernelGGL(mask_march_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs, zchunk);
     return;
   }
-  const size_t n = (size_t)m.mask_pitch * m.ext_sz[1] * (m.nd == 3 ? m.ext_sz[2] : 1);
+  const size_t DDv = m.nd == 3 ? (size_t)m.ext_sz[2] : 1;
+  if (vec_fast(m)) {
+    const size_t groups = (size_t)(m.ext_sz[0] / 4) * m.ext_sz[1] * DDv;
+    size_t bx = (groups + kThreads - 1) / kThreads;
+    if (bx > 2048) bx = 2048;               // grid-stride the rest: 8 workgroups per CU per job
+    const dim3 grid((unsigned)bx, (unsigned)njobs);
+    g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_vec_kernel<2>" : "ftkx::mask_vec_kernel<3>";
+    if (m.nd == 2) hipLaunchKernelGGL(mask_vec_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs);
+    else hipLaunchKernelGGL(mask_vec_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs);
+    return;
+  }
+  const size_t n = (size_t)m.mask_pitch * m.ext_sz[1] * DDv;
   size_t bx = (n + kThreads - 1) / kThreads;
   if (bx > 4096) bx = 4096;                 // grid-stride the rest
   const dim3 grid((unsigned)bx, (unsigned)njobs);
@@ -1859,19 +1798,16 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
   else hipLaunchKernelGGL(mask_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs);
 }
 
-// does launch_masks produce the per-word summaries for this mesh?  (only the 128-column edge variant of the marching kernel does)
+// does launch_masks produce the per-word summaries for this mesh?  (the 128-column marching kernels and the fast vector kernel do)
 bool masks_have_summary(const Mesh &m)
 {
-  if (!m.scalar_mode) return false;
-  const int DD = m.nd == 3 ? m.ext_sz[2] : 1;
-  const size_t slice_bytes = (size_t)m.ext_sz[0] * m.ext_sz[1] * DD * 8;
-  if ((m.ext_sz[0] % 8) != 0 || slice_bytes >= (1ull << 32)) return false;
   if (const char *e = getenv("FTKX_TWO_LEVEL")) if (atoi(e) == 0) return false;
-  const int DW = m.ext_sz[0];
-  bool use_edge = (DW + 127) / 128 < (DW + kMarch2Cols - 1) / kMarch2Cols;
-  if (const char *e = getenv("FTKX_MASK_EDGE")) use_edge = atoi(e) != 0;
-  return use_edge;
+  if (!m.scalar_mode) return vec_fast(m);
+  return march2_supported(m) && (m.ext_sz[0] % 8) == 0;
 }
+
+// are the reduction slots of MaskJob::red filled by launch_masks (the fused one-pass form)?  All mask kernels do.
+bool masks_fuse_reduction(const Mesh &) { return true; }
 
 template <bool COARSE>
 static void launch_cull_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream)

@@ -56,14 +56,30 @@ struct TileParams {
   int ntiles[3];
 };
 
-// mask kernel job: one slice
+// Largest M with 24 M^3 < 2^63 (3D: |det4| of a homogeneous 4x4 with entries <= M) / 6 M^2 < 2^63 (2D): a simplex all of whose
+// quantised components satisfy |q| + 1 <= M cannot wrap any determinant of the predicate, so the strict-sign cull is exact for it.
+constexpr i64 kSafeM3 = 727041, kSafeM2 = 1239850262;
+template <int ND> constexpr i64 safe_m() { return ND == 3 ? kSafeM3 : kSafeM2; }
+
+// mask kernel job: one slice.
+// The masks are built under a quantisation factor F = 1 / threshold that may be SMALLER than the factor a sweep later uses:
+// v >= 1/F implies trunc(v * F') >= 1 for every F' >= F, so such masks only ever cull less (the factor is a sticky running
+// minimum of resolutions, i.e. it only grows: the masks of a slice can be built before its own reduction is known).
+// `big` = safe_m / F: a vertex with some |v| >= big could take a determinant out of int64 under F; it gets NO sign bits and
+// therefore never takes part in a cull.  Under a larger factor more vertices are big: the host reuses masks built under F for
+// F' > F only when the slice's max |v| shows that no vertex is big under F' (ftkx_api.hip, masks_valid).
 struct MaskJob {
   const double *S;
   const double *V;
   unsigned char *M;
   unsigned char *U;          // summary: AND of the 8 mask bytes of each aligned x word (nullptr: not produced)
-  u64 *red;                  // pre-pass reduction output: 64 slots of {min non-zero finite |v| bits, max finite |v| bits}
-  double threshold;          // 1 / factor: q = trunc(v * factor) > 0  <=>  v >= 1/factor (factor is a power of two)
+  u64 *red;                  // reduction output, 64 slots of {min, max} as IEEE bit patterns (nullptr: none).
+                             //   pre-pass instantiations (REDUCE): min over ALL non-zero finite |v| = ndarray::resolution();
+                             //   fused into the mask kernels: min over the non-zero |v| < threshold only (all the scaling
+                             //   factor needs: anything >= threshold = 1/F cannot push nbits past log2 F), DBL_MAX if none.
+                             //   max: largest |v|, +Inf if the slice holds an Inf.
+  double threshold;          // 1 / F: q = trunc(v * F) > 0  <=>  v >= 1/F (F is a power of two)
+  double big;                // safe_m / F  (+Inf: no vertex is ever big)
 };
 
 }  // namespace ftkx

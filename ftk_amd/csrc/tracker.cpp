@@ -120,14 +120,18 @@ bool critical_point_tracker_regular::pop_field_data_snapshot()
 }
 
 // critical_point_tracker::update_vector_field_scaling_factor, critical_point_tracker.hh:850-864: sticky running minimum of
-// ndarray::resolution() over every queued snapshot; the per-slice reduction runs on the device once per slice.
+// ndarray::resolution() over every queued snapshot.  The per-slice reduction is fused into the pass that builds the slice's
+// sign masks (ftkx_slices_prepare: each snapshot is read from HBM once, when it first takes part in a step), under the factor
+// in force so far -- which the running minimum can only raise.  What comes back per slice is its smallest non-zero |v| BELOW
+// 1 / that factor (or DBL_MAX): values at or above it cannot change nbits, so the factor sequence is the reference's, while
+// vector_field_resolution itself (never observable in the reference either) is exact only once it is below 2^-8.
 void critical_point_tracker_regular::update_vector_field_scaling_factor(int minbits, int maxbits)
 {
-  for (int t : field_data_snapshots) {
-    double r = 0;
-    check(ftkx_slice_resolution(ctx, t, &r, nullptr));
-    vector_field_resolution = std::min(vector_field_resolution, r);
-  }
+  const unsigned long long hint = std::max(vector_field_scaling_factor, 1ull << minbits);   // never above the factor this step ends up with
+  std::vector<double> below(field_data_snapshots.size());
+  if (!field_data_snapshots.empty())
+    check(ftkx_slices_prepare(ctx, field_data_snapshots.data(), (int)field_data_snapshots.size(), hint, below.data(), nullptr));
+  for (double r : below) vector_field_resolution = std::min(vector_field_resolution, r);
   int nbits = (int)std::ceil(std::log2(1.0 / vector_field_resolution));
   nbits = std::max(minbits, std::min(nbits, maxbits));
   vector_field_scaling_factor = 1ull << nbits;

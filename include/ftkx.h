@@ -118,6 +118,18 @@ int ftkx_slice_resolution(ftkx_ctx *ctx, int t, double *resolution, double *max_
 /* ftkx_slice_resolution for n resident slices with one launch and one synchronise; res / max_abs: n doubles each (nullable) */
 int ftkx_slices_resolution(ftkx_ctx *ctx, const int *timesteps, int n, double *res, double *max_abs);
 int ftkx_set_slice_resolution(ftkx_ctx *ctx, int t, double resolution, double max_abs);
+/* The ONE-PASS form of the pre-pass (what the tracker and bench.py use): a single kernel reads each slice once and produces
+ * both the vertex sign masks of the sweep and the reduction update_vector_field_scaling_factor needs, so a slice is read from
+ * HBM once per sweep instead of twice.  The masks are built under `factor_hint`, a power of two that must not exceed the factor
+ * the sweeps will be given (0 = 256, the smallest factor there is; a streaming caller passes the factor in force before these
+ * slices arrived: the reference's factor is a sticky running minimum and only grows).  Masks built under a smaller factor only
+ * ever cull less, never wrongly; ftkx_sweep rebuilds them by itself in the one case that is not covered (a larger factor
+ * under which the slice has vertices that could overflow a determinant).
+ *   res_below[i] = smallest non-zero |v| of slice i that is < 1 / factor_hint, DBL_MAX if there is none.  That is all the scaling
+ *                  factor needs: running = min(running, res_below[i]) gives the same nbits = clamp(ceil(log2(1 / running)), 8, 21)
+ *                  as the running minimum of ndarray::resolution() (a value >= 1 / factor_hint cannot raise nbits past log2 hint).
+ *   max_abs[i]   = max finite |v| (both nullable). */
+int ftkx_slices_prepare(ftkx_ctx *ctx, const int *timesteps, int n, unsigned long long factor_hint, double *res_below, double *max_abs);
 /* update_vector_field_scaling_factor (critical_point_tracker.hh:850-864): nbits = clamp(ceil(log2(1/res)), 8, 21) */
 unsigned long long ftkx_scaling_factor(double resolution, int *nbits);
 

@@ -16,7 +16,7 @@ def gpu():
     return ftk_amd
 
 
-def _run(gpu, case, dims, nt, *, exact_only=False, core=None, steps=None, nv=1, tag_mode=None):
+def _run(gpu, case, dims, nt, *, exact_only=False, core=None, steps=None, nv=1, tag_mode=None, prepass="fused", hint=0):
     import torch
     from ftk_amd import synthetic, tslab
     nd = len(dims)
@@ -33,7 +33,11 @@ def _run(gpu, case, dims, nt, *, exact_only=False, core=None, steps=None, nv=1, 
         torch.cuda.synchronize()
         keep.append(a)
         (ctx.push_scalar_slice if scalar else ctx.push_slice)(t, a)
-        res.append(ctx.slice_resolution(t)[0])
+        if prepass == "exact":      # the separate pre-pass: ndarray::resolution() of every slice, masks built later under the true factor
+            res.append(ctx.slice_resolution(t)[0])
+    if prepass == "fused":          # the product's one-pass form: masks (under `hint`) and the capped reduction from one kernel
+        rm = ctx.slices_prepare(range(nt), hint)
+        res = [rm[t][0] for t in range(nt)]
     factors = tslab.factors_from_resolutions(res)
     for t in range(nt):
         ctx.sweep_enqueue(t, gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL, factors[t])
@@ -132,10 +136,10 @@ def test_reference_and_exact_tags_agree_without_overflow(gpu):
                                                 ("moving_extremum_3d", (126, 33, 6), 3, True), ("moving_extremum_3d", (386, 50, 35), 2, True),
                                                 ("woven", (1024, 512), 5, False), ("woven", (258, 100), 4, True)])
 def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
-    """The marching mask kernel exists in two generations with the same 128-column layout (mask_march2_kernel<.., EDGE> and the
-    leaner mask_march4_kernel at prefetch distances 0..3 and 4 or 8 rows per wavefront, the producer / consumer mask_march5_kernel)
-    and several workgroup placements.  Same results AND the same cull
-    statistics (cells that survive, words refined) = the same mask / summary bytes where it matters."""
+    """The marching mask kernel exists in several forms with the same 128-column layout (mask_march4_kernel at prefetch distances
+    0..3 and 4 or 8 rows per wavefront, the producer / consumer mask_march5_kernel in a dozen tile shapes) and several workgroup
+    placements.  Same results, the same fused reduction AND the same cull statistics (cells that survive, words refined) = the
+    same mask / summary bytes where it matters."""
     import os
     steps = None
     if rough:   # a field with plateaus, ties and noise: many non-uniform words, masks actually written and refined
@@ -143,9 +147,9 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
         shape = tuple(reversed(dims))
         # (values on a 1/64 grid: the resolution stays at 2^-7, so the determinants cannot overflow and the cull stays legal)
         steps = [np.round(rng.standard_normal(shape) * 2) * 0.25 + rng.integers(-2, 3, size=shape) / 64.0 for _ in range(nt)]
-    variants = [{}, {"FTKX_MASK_V": "2"}, {"FTKX_MASK_V": "4"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "2"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "3"},
+    variants = [{}, {"FTKX_MASK_V": "4"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "2"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "3"},
                 {"FTKX_MASK_SWIZZLE": "0"}, {"FTKX_MASK_SWIZZLE": "1"}, {"FTKX_MASK_V": "4", "FTKX_MASK_SWIZZLE": "1"},
-                {"FTKX_MASK_SWIZZLE": "24", "FTKX_MASK_YG": "4"}, {"FTKX_MASK_V": "2", "FTKX_MASK_SWIZZLE": "0"}, {"FTKX_MASK_EDGE": "0"},
+                {"FTKX_MASK_SWIZZLE": "24", "FTKX_MASK_YG": "4"}, {"FTKX_TWO_LEVEL": "0"},
                 {"FTKX_MASK_V": "4", "FTKX_MASK_RY": "8"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "0"}, {"FTKX_MASK_V": "5", "FTKX_MASK_PD": "1"}, {"FTKX_MASK_V": "5", "FTKX_MASK_PD": "2"},
                 {"FTKX_MASK_V": "5", "FTKX_MASK_PD": "3", "FTKX_MASK_SWIZZLE": "24"}, {"FTKX_MASK_V": "5", "FTKX_MASK_TILE": "1"},
                 {"FTKX_MASK_V": "5", "FTKX_MASK_TILE": "1", "FTKX_MASK_PD": "2"}, {"FTKX_MASK_V": "5", "FTKX_MASK_TILE": "2"}, {"FTKX_MASK_V": "5", "FTKX_MASK_TILE": "3"},
@@ -155,21 +159,20 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
-            recs, st, _ = _run(gpu, case, dims, nt, steps=steps)
+            recs, st, factors = _run(gpu, case, dims, nt, steps=steps)
         finally:
             for k, v in old.items():
                 if v is None:
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
-        key = (st["cells_survived"], st["simplices_tested"])
+        key = (st["cells_survived"], st["simplices_tested"], tuple(factors))
         if base is None:
             base = (recs, key)
             assert st["cull_enabled"] == 1
         else:
             _same(recs, base[0])
-            if env.get("FTKX_MASK_EDGE") != "0":        # the 124-column layout has no summaries: different (coarser) cull path
-                assert key == base[1], (env, key, base[1])
+            assert key == base[1], (env, key, base[1])
 
 
 def test_slices_beyond_4GiB_take_the_64bit_kernels(gpu):
@@ -225,3 +228,100 @@ def test_batched_resolution_equals_per_slice(gpu, oracle):
             assert got[1][t][0] == oracle.resolution(V), (case, dims, t)
             fin = np.abs(V[np.isfinite(V)])
             assert got[1][t][1] == fin.max()
+
+
+def test_one_pass_prepare_equals_separate_prepass(gpu, oracle):
+    """ftkx_slices_prepare (masks + reduction from ONE kernel, masks built under a factor that may be smaller than the final one)
+    against the two-pass form (exact ndarray::resolution() first, masks under the true factor): same factors, same records;
+    res_below / max_abs against the oracle's ndarray::resolution() of the same field."""
+    import torch
+    from ftk_amd import synthetic
+    DBL_MAX = float(np.finfo(np.float64).max)
+    cases = [("moving_extremum_3d", (128, 96, 40), 5, 1, None), ("woven", (256, 128), 6, 1, None), ("moving_extremum_3d", (31, 17, 9), 3, 1, None),
+             ("double_gyre", (128, 64), 5, 2, None), ("double_gyre", (101, 64), 4, 2, None), ("woven", (1024, 512), 5, 1, None)]
+    rng = np.random.default_rng(11)
+    rough3 = [np.round(rng.standard_normal((20, 36, 130)) * 2) * 0.25 + rng.integers(-2, 3, size=(20, 36, 130)) / 64.0 for _ in range(3)]
+    tiny2 = [rng.standard_normal((48, 64)) * 1e-5 for _ in range(3)]                  # every gradient below 2^-8: nothing strictly signed under the hint
+    cases += [(None, (130, 36, 20), 3, 1, rough3), (None, (64, 48), 3, 1, tiny2)]
+    for case, dims, nt, nv, steps in cases:
+        a, sa, fa = _run(gpu, case, dims, nt, nv=nv, steps=steps, prepass="fused")
+        b, sb, fb = _run(gpu, case, dims, nt, nv=nv, steps=steps, prepass="exact")
+        assert fa == fb, (case, dims, fa, fb)
+        _same(a, b)
+        for hint in (1 << 12, 1 << 21):
+            if hint <= min(fa):      # any hint up to the true factor is legal
+                c, sc, fc = _run(gpu, case, dims, nt, nv=nv, steps=steps, prepass="fused", hint=hint)
+                assert fc == fa
+                _same(a, c)
+        # the reduction itself
+        nd = len(dims)
+        lo = 2 if nv == 1 else 1
+        dom = ([lo] * nd, [d - (3 if nv == 1 else 2) for d in dims])
+        ctx = gpu.Context(nd)
+        ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
+        ctx.set_options(jacobian_symmetric=int(nv == 1), derive_jacobian=1)
+        keep = []
+        for t in range(nt):
+            x = synthetic.generate(case, dims, t, nt, torch, torch.device("cuda", 0)) if steps is None else torch.from_numpy(np.ascontiguousarray(steps[t])).cuda()
+            torch.cuda.synchronize(); keep.append(x)
+            (ctx.push_scalar_slice if nv == 1 else ctx.push_slice)(t, x)
+        for hint in (0, 1 << 14):
+            ctx.invalidate_masks()
+            got = ctx.slices_prepare(range(nt), hint)
+            cap = 1.0 / (hint or 256)
+            for t in range(nt):
+                h = keep[t].cpu().numpy()
+                V = h if nv == 2 else (oracle.gradient2D(h) if nd == 2 else oracle.gradient3D(h))
+                r = oracle.resolution(V)
+                assert got[t][0] == (r if r < cap else DBL_MAX), (case, dims, t, hint, got[t][0], r)
+                assert got[t][1] == np.abs(V[np.isfinite(V)]).max(), (case, dims, t)
+        ctx.close()
+
+
+def test_big_vertices_are_handled_per_cell(gpu):
+    """A few outliers large enough to overflow the determinants (|q| + 1 > safe_m): only the cells that touch them lose the cull,
+    the records equal the exact_only sweep (the wrapped results included), and the rest of the field is still culled."""
+    from ftk_amd import synthetic
+    import torch
+    dims, nt = (96, 80, 64), 4
+    steps = [synthetic.generate("moving_extremum_3d", dims, t, nt, torch, torch.device("cuda", 0)).cpu().numpy() for t in range(nt)]
+    rng = np.random.default_rng(3)
+    for t in range(nt):
+        for _ in range(6):
+            k, j, i = (int(rng.integers(4, d - 4)) for d in reversed(dims))
+            steps[t][k, j, i] += 3e6 * (1 + rng.random())      # gradient ~1.5e6 next to it: * 2^8 > 727041
+    a, sa, fa = _run(gpu, None, dims, nt, steps=steps)
+    b, sb, fb = _run(gpu, None, dims, nt, steps=steps, exact_only=True)
+    assert fa == fb and sa["cull_enabled"] == 1 and sb["cull_enabled"] == 0
+    _same(a, b)
+    assert 0 < sa["cells_survived"] < 0.01 * sa["cells"]
+    # 2D: same with a vector field and nbits 21
+    dims2 = (256, 128)
+    v = [synthetic.generate("double_gyre", dims2, t, 3, torch, torch.device("cuda", 0)).cpu().numpy() for t in range(3)]
+    for t in range(3):
+        v[t][40 + t, 100, 0] = 700.0; v[t][41 + t, 101, 1] = -650.0      # 700 * 2^21 > 1 239 850 262
+    a, sa, fa = _run(gpu, None, dims2, 3, steps=v, nv=2)
+    b, sb, fb = _run(gpu, None, dims2, 3, steps=v, nv=2, exact_only=True)
+    assert fa == fb == [1 << 21] * 3
+    _same(a, b)
+    assert sa["cells_survived"] < 0.05 * sa["cells"]
+
+
+def test_dense_survivors_fall_back_to_the_tile_kernel(gpu):
+    """The int64-overflow regime at a size where the survivor list would not fit (all 3.9e6 cells per step survive): the batch is
+    replayed through the tile kernel with its in-tile cull; records equal exact_only (wrapped determinants reproduced)."""
+    import torch
+    from ftk_amd import synthetic
+    dims, nt = (160, 160, 160), 2
+    x0 = [80 + 1e-7, 80 + 2e-7, 80 + 3e-7]
+    ax = [torch.arange(d, dtype=torch.float64) for d in dims]
+    steps = []
+    for k in range(nt):
+        c = [x0[a] + 0.1 * k for a in range(3)]
+        steps.append((((ax[0] - c[0]) ** 2)[None, None, :] + ((ax[1] - c[1]) ** 2)[None, :, None] + ((ax[2] - c[2]) ** 2)[:, None, None]).numpy())
+    a, sa, fa = _run(gpu, None, dims, nt, steps=steps)
+    b, sb, fb = _run(gpu, None, dims, nt, steps=steps, exact_only=True)
+    assert fa == fb == [1 << 21] * nt
+    assert sa["cull_enabled"] == 1 and sa["simplices_tested"] > 0.5 * sa["work_items"]
+    _same(a, b)
+    assert len(a) > 10000       # mostly bogus records of wrapped determinants, like the reference's (SURVEY H1)
