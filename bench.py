@@ -7,8 +7,8 @@
 One "step" = one pass of the sweep over the whole synthetic time series: every ordinal sweep and every interval sweep of the
 configured lattice, hit records downloaded to the host.  Inputs (scalar slices and the gradient field the tracker API derives
 from them at push time) are resident in HBM when the timed region starts; the quantisation-factor pre-pass (a device
-reduction per slice + one all_gather) is timed separately and reported as `prepass_ms`.  With N > 1 the lattice is cut into
-timestep slabs (ftk_amd/tslab.py).  A rank's INPUT is its slab plus the first slice of the next slab (the interval sweep across
+reduction per slice + one all_gather) is FUSED into the pass that builds the sign masks and lies inside the timed region.
+With N > 1 the lattice is cut into timestep slabs (ftk_amd/tslab.py).  A rank's INPUT is its slab plus the first slice of the next slab (the interval sweep across
 the slab boundary reads both); that boundary slice reaches it by one RCCL send/recv over xGMI, which -- like every other step
 that makes the inputs resident -- happens before the timed region and is reported on its own (`halo_exchange`: ms, bytes,
 GB/s).  The sweeps themselves then shard with no data-path collective.  `--halo-in-loop` re-sends the boundary slice in every
@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--halo-in-loop", action="store_true", help="N > 1: re-send the slab-boundary slice inside every timed pass")
     args = ap.parse_args()
 
+    # before anything initialises the HIP runtime: the host driver only supports dmabuf IPC (RCCL / device-tensor sharing across
+    # processes fails with the legacy mode)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import ftk_amd
@@ -120,7 +123,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)      # backend "nccl" is RCCL on ROCm
         else:
@@ -149,24 +151,21 @@ def main():
     halo_buf = torch.empty_like(slices[own[0]]) if (world > 1 and own) else None
     torch.cuda.synchronize()
 
-    # the first call also loads the reduction kernel's code object (a one-time cost of a few ms): run it once, hand the slices
-    # over again (adopting a device pointer is free and forgets the cached reduction), and time the second pre-pass
-    ctx.slices_resolution(own)
-    for t in own:
-        (ctx.push_scalar_slice if scalar_input else ctx.push_slice)(t, slices[t])
+    # One pass = the whole sweep from resident input to records on the host, INCLUDING what the reference does at the top of
+    # update_timestep (update_vector_field_scaling_factor): ftkx_slices_prepare reads every slice once and yields the sign masks
+    # and the per-slice reduction together; the factors follow on the host (N > 1: one all_gather of 2 nt doubles).
+    def prepare_and_factors():
+        local_rm = ctx.slices_prepare(own, 0)
+        local_res = {t: v[0] for t, v in local_rm.items()}
+        if world > 1:
+            return tslab.global_factors(local_res, nt, local_max={t: v[1] for t, v in local_rm.items()})
+        return tslab.factors_from_resolutions([local_res[t] for t in range(nt)]), None, None
+
+    factors, all_res, all_max = prepare_and_factors()      # also loads the code objects (a one-time cost of a few ms)
     torch.cuda.synchronize()
-    tp0 = time.perf_counter()
-    local_rm = ctx.slices_resolution(own)      # one reduction launch over the whole slab, one round trip
-    local_res = {t: v[0] for t, v in local_rm.items()}
-    if world > 1:
-        factors, all_res, all_max = tslab.global_factors(local_res, nt, local_max={t: v[1] for t, v in local_rm.items()})
-    else:
-        factors = tslab.factors_from_resolutions([local_res[t] for t in range(nt)])
-    torch.cuda.synchronize()
-    prepass_ms = (time.perf_counter() - tp0) * 1e3
 
     halo_pushed = [False]
-    host_ms = [0.0, 0.0]
+    host_ms = [0.0, 0.0, 0.0]
 
     def halo():
         # the slab-boundary slice: one RCCL send/recv pair per neighbour over xGMI, into a device buffer the context adopts
@@ -191,17 +190,20 @@ def main():
                      "GB/s_per_link": hbytes / (halo_ms * 1e-3) / 1e9 if halo_ms > 0 else None}
 
     def one_pass():
-        ctx.invalidate_masks()      # every pass redoes ALL the work of the sweep, including the per-slice sign masks
+        ctx.invalidate_masks()      # every pass redoes ALL the work of the sweep: masks, reduction, factors, cull, exact test, download
         if world > 1 and own and args.halo_in_loop:
             halo()
+        tp0 = time.perf_counter()
+        f, _, _ = prepare_and_factors()
         te0 = time.perf_counter()
         for t in own:
             scope = ftk_amd.SCOPE_BOTH if (t + 1 < nt) else ftk_amd.SCOPE_ORDINAL
-            ctx.sweep_enqueue(t, scope, factors[t])
+            ctx.sweep_enqueue(t, scope, f[t])
         te1 = time.perf_counter()
-        # one mask / cull / exact launch for the whole slab, then the hit download into the library's pinned host buffer
+        # one cull / exact launch for the whole slab (plus the masks of the halo slice, N > 1), then the hit download into the
+        # library's pinned host buffer
         recs = ctx.sweep_collect(copy=False)
-        host_ms[0] += (te1 - te0) * 1e3; host_ms[1] += (time.perf_counter() - te1) * 1e3
+        host_ms[2] += (te0 - tp0) * 1e3; host_ms[0] += (te1 - te0) * 1e3; host_ms[1] += (time.perf_counter() - te1) * 1e3
         st = ctx.stats()
         return recs, st
 
@@ -213,7 +215,7 @@ def main():
     for _ in range(args.warmup):
         recs, st = one_pass()
     ctx.set_profiling(True)         # HIP events around every kernel launch, on the stream the kernels run on
-    host_ms[0] = host_ms[1] = 0.0
+    host_ms[0] = host_ms[1] = host_ms[2] = 0.0
     barrier()
     tt0 = time.perf_counter()
     for _ in range(args.steps):
@@ -297,10 +299,15 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes_launch, "slices_per_launch": slices_per_launch,
                          "all_kernels_ms_per_pass": all_ms, "achieved_all_kernels": alg_bytes_pass / (all_ms * 1e-3) / 1e9,
                          "kernel_ms_per_pass": {k: v[0] / args.steps for k, v in ktimes.items()}},
-            "prepass_ms": prepass_ms,
+            # the factor pre-pass is inside the timed region now (fused into the mask kernel): nothing of the sweep is left outside
+            "prepass_ms": 0.0,
+            "end_to_end_ms": elapsed / args.steps * 1e3,
+            "roofline_end_to_end": {"achieved": alg_bytes_pass * world / (elapsed / args.steps) / 1e9 / world, "frac": alg_bytes_pass / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "algorithmic bytes of this rank's pass / wall time of the pass (prepare + factors + cull + exact + sort + download)"},
             "halo_exchange": halo_info,
             "other_halo_convention": other,
-            "wall_breakdown_ms_per_pass": {"enqueue_calls": host_ms[0] / args.steps, "collect_launch_sync_sort_download": host_ms[1] / args.steps},
+            "wall_breakdown_ms_per_pass": {"prepare_masks_and_reduction": host_ms[2] / args.steps, "enqueue_calls": host_ms[0] / args.steps,
+                                           "collect_launch_sync_sort_download": host_ms[1] / args.steps},
             "stats": {"simplices_tested_exactly": n_tested, "cells_survived_cull": n_cells},
             "check": check,
         }
