@@ -57,6 +57,7 @@ struct Slice {
   unsigned char *U = nullptr;       // per-8-vertex summaries of M (two-level cull)
   bool ownV = false, ownJ = false, ownS = false;
   unsigned long long mask_factor = 0;   // the (power-of-two) factor M / U were built under; 0 = not built
+  bool mask_big = false;            // built with the per-vertex overflow rule of that factor (MaskJob::big finite)
   bool have_res = false;            // res = ndarray::resolution() of the slice's vector field (exact pre-pass), maxabs with it
   double res = 0, maxabs = 0;
   bool have_fused = false;          // reduction fused into the mask pass (ftkx_slices_prepare): maxabs, and
@@ -307,7 +308,16 @@ bool pow2_factor(u64 factor) { return factor != 0 && (factor & (factor - 1)) == 
 bool masks_valid(const ftkx_ctx *c, const Slice &s, u64 factor, bool two_level)
 {
   if (!s.M || (two_level && !s.U) || s.mask_factor == 0 || s.mask_factor > factor) return false;
-  return s.mask_factor == factor || (s.max_known() && overflow_free(c->nd, s.maxabs, factor));
+  if (s.mask_big && s.mask_factor == factor) return true;
+  return s.max_known() && overflow_free(c->nd, s.maxabs, factor);   // no vertex is big under `factor`: the rule would change nothing
+}
+
+// the per-vertex rule costs the marching kernels a few instructions per row: it is switched on only when it can matter
+double job_big(const ftkx_ctx *c, const Slice &s, u64 factor, bool *rule_on)
+{
+  const bool off = s.max_known() && overflow_free(c->nd, s.maxabs, factor);
+  *rule_on = !off;
+  return off ? HUGE_VAL : big_threshold(c->nd, factor);
 }
 
 int ensure_mask_arrays(ftkx_ctx *c, Slice &s, bool two_level)
@@ -435,8 +445,10 @@ int run_batch(ftkx_ctx *c)
         for (const MaskJob &j : subs.back().jobs) touched = touched || j.M == s->M;
         for (const Fields &g : subs.back().steps) touched = touched || g.M[0] == s->M || g.M[1] == s->M;
         if (touched) subs.emplace_back();
-        subs.back().jobs.push_back(MaskJob{s->S, s->V, s->M, two_level ? s->U : nullptr, nullptr, 1.0 / (double)r.factor, big_threshold(nd, r.factor)});
-        s->mask_factor = r.factor;
+        bool rule_on;
+        const double big = job_big(c, *s, r.factor, &rule_on);
+        subs.back().jobs.push_back(MaskJob{s->S, s->V, s->M, two_level ? s->U : nullptr, nullptr, 1.0 / (double)r.factor, big});
+        s->mask_factor = r.factor; s->mask_big = rule_on;
       }
       f.M[0] = s0.M; f.M[1] = s1 ? s1->M : nullptr;
       f.U[0] = two_level ? s0.U : nullptr; f.U[1] = (two_level && s1) ? s1->U : nullptr;
@@ -818,7 +830,7 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
     hipLaunchKernelGGL(init_red_kernel, dim3((unsigned)((k * 64 + 255) / 256)), dim3(256), 0, c->stream, c->d_red, k * 64);
     MaskJob *jobs = (MaskJob *)c->h_desc;
     for (size_t i = 0; i < k; i ++)
-      jobs[i] = MaskJob{todo[i]->S, todo[i]->V, todo[i]->M, two_level ? todo[i]->U : nullptr, c->d_red + i * 128, cap, big_threshold(c->nd, hint)};
+      jobs[i] = MaskJob{todo[i]->S, todo[i]->V, todo[i]->M, two_level ? todo[i]->U : nullptr, c->d_red + i * 128, cap, HUGE_VAL};   // rule off: validated below
     HIP_TRY(c, hipMemcpyAsync(c->d_desc, c->h_desc, k * sizeof(MaskJob), hipMemcpyHostToDevice, c->stream));
     ev_begin(c, K_MASK); ftkx::launch_masks(m, (const MaskJob *)c->d_desc, (int)k, c->stream); ev_end(c);
     HIP_TRY(c, hipGetLastError());
@@ -833,11 +845,14 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
       Slice &s = *todo[i];
       memcpy(&s.res_below, &mn, 8);
       double mxd; memcpy(&mxd, &mx, 8);
-      s.mask_factor = hint; s.fused_factor = hint; s.have_fused = true;
+      s.mask_factor = hint; s.mask_big = false; s.fused_factor = hint; s.have_fused = true;
       if (std::isinf(mxd)) with_inf.push_back(&s);        // the fused max cannot skip an Inf: the exact pre-pass gives max FINITE |v|
       else if (!s.have_res) s.maxabs = mxd;
     }
     for (Slice *s : with_inf) if ((rc = slice_resolution(c, *s))) return rc;
+    // The masks were built without the per-vertex overflow rule.  They stand only if no vertex of the slice is big under the hint
+    // (then under no smaller factor either); otherwise the sweep rebuilds them, rule on, under its factor (masks_valid).
+    for (Slice *s : todo) if (!overflow_free(c->nd, s->maxabs, hint)) s->mask_factor = 0;
   }
   for (int i = 0; i < n; i ++) {
     const Slice &s = *all[i];

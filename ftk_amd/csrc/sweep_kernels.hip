@@ -784,7 +784,8 @@ __device__ inline void remap_block(int swizzle, unsigned &bx, unsigned &by, unsi
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
-// Shifts the sign bits of one row's vertex pair into two accumulators, most significant first:
+// Shifts the sign bits of one row's vertex pair into two accumulators (overwritten: the first add-with-carry is 0 + 0 + carry),
+// most significant first:
 //   a = [neg_z neg_y neg_x pos_z pos_y pos_x]   (2D: [neg_y neg_x pos_y pos_x], spread by the caller)
 // one compare + one add-with-carry (a = a + a + carry) per bit.  gfx950 needs two wait states between a VALU writing an
 // SGPR and a VALU reading it; the compares run three ahead of the adds, so no s_nop is needed.
@@ -794,8 +795,8 @@ __device__ inline void shift_in_signs(unsigned &a0, unsigned &a1, double dx0, do
   unsigned long long m0, m1, m2;
   if constexpr (ND == 3)
     asm("v_cmp_le_f64_e64 %[m0], %[dz0], %[tn]\n\tv_cmp_le_f64_e64 %[m1], %[dz1], %[tn]\n\tv_cmp_le_f64_e64 %[m2], %[dy0], %[tn]\n\t"
-        "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m0]\n\tv_cmp_le_f64_e64 %[m0], %[dy1], %[tn]\n\t"
-        "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m1]\n\tv_cmp_le_f64_e64 %[m1], %[dx0], %[tn]\n\t"
+        "v_addc_co_u32_e64 %[a0], vcc, 0, 0, %[m0]\n\tv_cmp_le_f64_e64 %[m0], %[dy1], %[tn]\n\t"
+        "v_addc_co_u32_e64 %[a1], vcc, 0, 0, %[m1]\n\tv_cmp_le_f64_e64 %[m1], %[dx0], %[tn]\n\t"
         "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m2]\n\tv_cmp_le_f64_e64 %[m2], %[dx1], %[tn]\n\t"
         "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m0]\n\tv_cmp_ge_f64_e64 %[m0], %[dz0], %[tp]\n\t"
         "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m1]\n\tv_cmp_ge_f64_e64 %[m1], %[dz1], %[tp]\n\t"
@@ -805,19 +806,19 @@ __device__ inline void shift_in_signs(unsigned &a0, unsigned &a1, double dx0, do
         "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m2]\n\tv_cmp_ge_f64_e64 %[m2], %[dx1], %[tp]\n\t"
         "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m0]\n\tv_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m1]\n\t"
         "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m2]"
-        : [a0] "+v"(a0), [a1] "+v"(a1), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2)
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2)
         : [dx0] "v"(dx0), [dx1] "v"(dx1), [dy0] "v"(dy0), [dy1] "v"(dy1), [dz0] "v"(dz0), [dz1] "v"(dz1), [tn] "s"(tn), [tp] "s"(tp)
         : "vcc");
   else
     asm("v_cmp_le_f64_e64 %[m0], %[dy0], %[tn]\n\tv_cmp_le_f64_e64 %[m1], %[dy1], %[tn]\n\tv_cmp_le_f64_e64 %[m2], %[dx0], %[tn]\n\t"
-        "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m0]\n\tv_cmp_le_f64_e64 %[m0], %[dx1], %[tn]\n\t"
-        "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m1]\n\tv_cmp_ge_f64_e64 %[m1], %[dy0], %[tp]\n\t"
+        "v_addc_co_u32_e64 %[a0], vcc, 0, 0, %[m0]\n\tv_cmp_le_f64_e64 %[m0], %[dx1], %[tn]\n\t"
+        "v_addc_co_u32_e64 %[a1], vcc, 0, 0, %[m1]\n\tv_cmp_ge_f64_e64 %[m1], %[dy0], %[tp]\n\t"
         "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m2]\n\tv_cmp_ge_f64_e64 %[m2], %[dy1], %[tp]\n\t"
         "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m0]\n\tv_cmp_ge_f64_e64 %[m0], %[dx0], %[tp]\n\t"
         "v_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m1]\n\tv_cmp_ge_f64_e64 %[m1], %[dx1], %[tp]\n\t"
         "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m2]\n\tv_addc_co_u32_e64 %[a0], vcc, %[a0], %[a0], %[m0]\n\t"
         "v_addc_co_u32_e64 %[a1], vcc, %[a1], %[a1], %[m1]"
-        : [a0] "+v"(a0), [a1] "+v"(a1), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2)
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2)
         : [dx0] "v"(dx0), [dx1] "v"(dx1), [dy0] "v"(dy0), [dy1] "v"(dy1), [tn] "s"(tn), [tp] "s"(tp)
         : "vcc");
 }
@@ -853,29 +854,38 @@ __device__ inline double edge_for_row(double xe)
 //   * candidates for the slice's resolution: only components WITHOUT a strict sign (|v| < threshold) can lower the scaling
 //     factor's running minimum below 1 / F, and on smooth data almost no row has one -- one ballot per row, the min-non-zero
 //     arithmetic runs only where it fires;
-//   * vertices that may overflow a determinant (|v| >= big) lose their sign bits.
+//   * vertices that may overflow a determinant (|v| >= big) lose their sign bits -- only when the job asks for it (big finite):
+//     the host first builds masks WITHOUT the rule and keeps them only if the fused max shows that no vertex is big.
 // d* are the raw central differences the sign bits were taken from (3D: twice the gradient, h = 0.5; 2D: the gradient, h = 1);
 // `rv` (wave-uniform): this row holds real entries of gradient(S); cmask: which of the lane's two columns do, as the bits
 // 0x07 (0x03 in 2D) of their byte.  Returns the pair of mask bytes.
+// v_max_f64 with |x| input modifiers, as ONE instruction: fmax() makes the compiler canonicalise both operands first (two more
+// v_max_f64 each) although arithmetic results are never signalling NaNs.  A NaN operand is ignored (IEEE maxNum).
+__device__ inline double max_abs2(double a, double b) { double r; asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ inline double max_with_abs(double acc, double b) { asm("v_max_f64 %0, %0, |%1|" : "+v"(acc) : "v"(b)); return acc; }
+__device__ inline double max_plain(double acc, double b) { asm("v_max_f64 %0, %0, %1" : "+v"(acc) : "v"(b)); return acc; }
+
 template <int ND>
 __device__ inline unsigned guard_and_reduce(unsigned a0, unsigned a1, double dx0, double dx1, double dy0, double dy1, double dz0, double dz1,
-                                            bool rv, unsigned cmask, double tbig, double h, double &acc0, double &acc1, double &red_mn)
+                                            bool rv, unsigned cmask, bool per_vertex_rule, double tbig, double h, double &acc0, double &acc1, double &red_mn)
 {
-  double m0 = fmax(fabs(dx0), fabs(dy0)), m1 = fmax(fabs(dx1), fabs(dy1));
-  if constexpr (ND == 3) { m0 = fmax(m0, fabs(dz0)); m1 = fmax(m1, fabs(dz1)); }
-  if (rv) {
-    acc0 = fmax(acc0, m0); acc1 = fmax(acc1, m1);
-    const unsigned raw = a0 | (a1 << 8);
-    const unsigned u = raw | (raw >> 3);                       // bit c of a byte: component c is strictly signed
+  double m0 = max_abs2(dx0, dy0), m1 = max_abs2(dx1, dy1);
+  if constexpr (ND == 3) { m0 = max_with_abs(m0, dz0); m1 = max_with_abs(m1, dz1); }
+  unsigned bits = a0 | (a1 << 8);
+  if (rv) {                                                    // wave-uniform
+    acc0 = max_plain(acc0, m0); acc1 = max_plain(acc1, m1);
+    const unsigned u = bits | (bits >> 3);                     // bit c of a byte: component c is strictly signed
     if (__builtin_amdgcn_ballot_w64((~u & cmask) != 0u)) {
       auto take = [&](double d) { const double a = fabs(h * d); red_mn = fmin(red_mn, a == 0.0 ? DBL_MAX : a); };
       if (cmask & 0x00ffu) { take(dx0); take(dy0); if (ND == 3) take(dz0); }
       if (cmask & 0xff00u) { take(dx1); take(dy1); if (ND == 3) take(dz1); }
     }
   }
-  if (m0 >= tbig) a0 = 0u;
-  if (m1 >= tbig) a1 = 0u;
-  return a0 | (a1 << 8);
+  if (per_vertex_rule) {                                       // wave-uniform: only slices known to hold such vertices pay for it
+    asm volatile("" ::: "memory");                             // (keeps this a branch: if-converted it costs every row 8 instructions)
+    bits = (m0 >= tbig ? 0u : (bits & 0x00ffu)) | (m1 >= tbig ? 0u : (bits & 0xff00u));
+  }
+  return bits;
 }
 
 // PD = prefetch distance: at the step for plane k the loads of plane k + 1 + PD are issued (PD = 1: three planes of registers
@@ -968,6 +978,7 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
   double acc0 = 0.0, acc1 = 0.0;
   const unsigned cmask = store_ok ? (xkeep & (ND == 3 ? 0x0707u : 0x0303u)) : 0u;
   const double tbig = (ND == 3) ? 2.0 * job.big : job.big;
+  const bool per_vertex_rule = job.big < HUGE_VAL;
 
   // one plane: prefetch plane k + 1 + PD into NN / XNN, classify plane k from (PR = k-1, CU = k, NX = k+1) and CU's edge register XC
   auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], const v2d (&NX)[RY + 2], v2d (&NN)[RY + 2], const double XC, double &XNN, int k) {
@@ -1016,7 +1027,7 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
       shift_in_signs<ND>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, tneg, tpos);
       if (ND == 2) { a0 = ((a0 & 0xcu) << 1) | (a0 & 3u); a1 = ((a1 & 0xcu) << 1) | (a1 & 3u); }   // leave the two z bits empty
       const bool rok = ((row_ok >> r) & 1) && k < z1;
-      unsigned bits = guard_and_reduce<ND>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, u_int && rok, cmask, tbig, ND == 3 ? 0.5 : 1.0, acc0, acc1, red_mn);
+      unsigned bits = guard_and_reduce<ND>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, u_int && rok, cmask, per_vertex_rule, tbig, ND == 3 ? 0.5 : 1.0, acc0, acc1, red_mn);
       // wave-uniform row / plane conditions, per-lane column conditions
       const unsigned keep = u_int ? xkeep : 0u;                // gradient3D leaves the array border at 0
       const unsigned neut = u_dom ? xneutral : 0x3f3fu;        // outside the domain / row padding: never blocks a cull
@@ -1069,18 +1080,37 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
 // One s_barrier per plane: when it is passed, plane k+1 has landed (the producer waited for it with s_waitcnt vmcnt) and every
 // consumer has finished reading plane k's slot, which the producer then refills with plane k+1+PD.  Same mask / summary bytes.
 // ---------------------------------------------------------------------------------------------------------------
-// TW = tile width in 128-column units (consumers side by side in x take their x neighbours from the shared LDS row, only the
-// tile's outer columns are fetched separately), CY x RY = tile rows, PD = planes in flight beyond the one consumed next.
-template <int PD, int TW, int CY, int RY>
-__global__ __launch_bounds__(64 * (TW * CY + 1)) void mask_march5_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
+// summary byte of an aligned 8-vertex word from the pair of mask bytes each of the quad's four lanes holds: the sign bits ALL
+// eight vertices share.  Three VALU instructions (SDWA byte select, then the AND folded into the DPP quad permutes); written by
+// hand because the compiler emits mov_dpp + and pairs (7 instructions).  s_nop 1 = the two wait states a DPP read needs after a
+// VALU write of its source.
+__device__ inline unsigned word_summary(unsigned bits)
+{
+  unsigned q;
+  asm("v_and_b32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+      "s_nop 1\n\t"
+      "v_and_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_and_b32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : "=&v"(q) : "v"(bits));
+  return q;
+}
+
+// CY x RY = tile rows (CY consumer wavefronts of RY rows each, the tile is 128 columns wide), PD = planes in flight beyond the
+// one consumed next.  LDS: PD + 1 row slots of (CY RY + 2) KiB, and a ring of PD + 2 edge entries (256 B: the left and right
+// outside-neighbour value of each own row of a plane, fetched by ONE wavefront instruction).  The ring is one entry longer than
+// the row slots so that a plane's edge values are still there during the step that classifies it: consumers read them per row,
+// when they need them (two broadcast LDS reads), instead of carrying them in registers and shuffling them between lanes.
+template <int PD, int CY, int RY>
+__global__ __launch_bounds__(64 * (CY + 1)) void mask_march5_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass silently drops the stub of a kernel whose body uses the LDS-DMA builtin: give it an empty body
-  constexpr int CW = TW * CY, ROWS = RY * CY, TROWS = ROWS + 2, NS = PD + 1;
-  static_assert(ROWS <= 32, "the edge values of a plane are fetched by one wavefront instruction: 2 x ROWS lanes");
-  constexpr unsigned ROWB = 1024u * TW, EDGEB = 512, SLOT = TROWS * ROWB + EDGEB;
-  constexpr int LOADS_PER_PLANE = TROWS * TW + 2;              // row DMAs + the two halves of the edge values
+  constexpr int CW = CY, ROWS = RY * CY, TROWS = ROWS + 2, NS = PD + 1, NE = PD + 2;
+  static_assert(ROWS <= 16, "the edge values of a plane are fetched by one wavefront instruction: 2 x ROWS doubles = 4 x ROWS lanes");
+  constexpr unsigned ROWB = 1024u, SLOT = TROWS * ROWB, EDGEB = 256u, ERING = NS * SLOT;
+  constexpr int LOADS_PER_PLANE = TROWS + 1;                    // row DMAs + the edge values
   static_assert(LOADS_PER_PLANE * (PD - 1) < 64, "vmcnt is a 6-bit counter: the wait below must be expressible (issue simply stalls beyond 63 in flight)");
-  extern __shared__ __attribute__((aligned(16))) char lds[];   // NS slots
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // NS row slots, then NE edge entries
   const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = m.ext_sz[2], P = m.mask_pitch;
   const int nzc = (DD + zchunk - 1) / zchunk;
   unsigned bx, by, bz;
@@ -1091,25 +1121,29 @@ __global__ __launch_bounds__(64 * (TW * CY + 1)) void mask_march5_kernel(const M
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int jb = (int)by * ROWS;                               // the workgroup's first own row
-  const int t0c = (int)bx * 128 * TW;                          // and first column
+  const int t0c = (int)bx * 128;                               // and first column
   if (jb >= DH) return;                                        // whole workgroup: no barrier is left waiting
   const unsigned sy = (unsigned)DW * 8u, sz = (unsigned)DW * (unsigned)DH * 8u;
   const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void *)job.S, 0, (int)(sz * (unsigned)DD), 0x00020000);
   const int nsteps = ((z1 - z0 + 2) / 3) * 3;                  // both roles walk the same, padded number of planes (3 = consumer unroll)
   auto slot_of = [&](int q) -> unsigned { return (unsigned)(((q - (z0 - 1)) % NS + NS) % NS) * SLOT; };
+  auto edge_of = [&](int q) -> unsigned { return ERING + (unsigned)(((q - (z0 - 1)) % NE + NE) % NE) * EDGEB; };
 
   if (wv == CW) {
     // ---------------- producer ----------------
-    // column pair of this lane in each 128-column piece, clamped so that lanes beyond the row load valid memory
-    unsigned cb[TW];
-    for (int p = 0; p < TW; p ++) { const int i = t0c + 128 * p + 2 * lane; cb[p] = (unsigned)(i < DW ? i : DW - 2) * 8u; }
-    // edge values: lane l < ROWS fetches the left neighbour of own row l, lane 32 + l the right one; low and high dwords separately
-    unsigned eoff = 0xfffffff0u, eoff_hi = 0xfffffff0u;
-    if ((lane & 31) < ROWS) {
-      const int row = lane & 31;
-      const int col = lane < 32 ? (t0c > 0 ? t0c - 1 : 0) : (t0c + 128 * TW < DW ? t0c + 128 * TW : DW - 1);
-      eoff = sy * (unsigned)clampi(jb + row, 0, DH - 1) + (unsigned)col * 8u;
-      eoff_hi = eoff + 4u;
+    // column pair of this lane, clamped so that lanes beyond the row load valid memory
+    const int ip = t0c + 2 * lane;
+    const unsigned cb = (unsigned)(ip < DW ? ip : DW - 2) * 8u;
+    // edge values: lanes 2e and 2e + 1 fetch the low and high dword of edge e; e < 16: left neighbour of own row e, e >= 16: right
+    // neighbour of own row e - 16 (so each lands in LDS as a whole double, at 8 e).  Lanes without an edge carry an offset
+    // beyond num_records, which a buffer load answers with 0 without touching memory.
+    unsigned eoff = 0xfffffff0u;
+    {
+      const int e = lane >> 1, row = e & 15;
+      if (row < ROWS) {
+        const int col = e < 16 ? (t0c > 0 ? t0c - 1 : 0) : (t0c + 128 < DW ? t0c + 128 : DW - 1);
+        eoff = sy * (unsigned)clampi(jb + row, 0, DH - 1) + (unsigned)col * 8u + 4u * (unsigned)(lane & 1);
+      }
     }
     unsigned roff[TROWS];
     for (int t = 0; t < TROWS; t ++) roff[t] = sy * (unsigned)clampi(jb + t - 1, 0, DH - 1);
@@ -1117,18 +1151,15 @@ __global__ __launch_bounds__(64 * (TW * CY + 1)) void mask_march5_kernel(const M
     auto issue = [&](int q) {
       const unsigned zo = sz * (unsigned)clampi(q, 0, DD - 1);
       const unsigned base = slot_of(q);
-      for (int t = 0; t < TROWS; t ++)
-        for (int p = 0; p < TW; p ++) {
-          __attribute__((address_space(3))) void *dst = (__attribute__((address_space(3))) void *)(lds + base + (unsigned)t * ROWB + (unsigned)p * 1024u);
-          // rows 0 and TROWS-1 are own rows of the neighbouring workgroups, rows 1 and TROWS-2 their halo rows: leave those cached
-          const bool nt = nt_all || (nt_private && t >= 2 && t <= TROWS - 3);
-          if (nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, dst, 16, cb[p], zo + roff[t], 0, 2);
-          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, dst, 16, cb[p], zo + roff[t], 0, 0);
-        }
-      __attribute__((address_space(3))) void *elo = (__attribute__((address_space(3))) void *)(lds + base + TROWS * ROWB);
-      __attribute__((address_space(3))) void *ehi = (__attribute__((address_space(3))) void *)(lds + base + TROWS * ROWB + 256);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, elo, 4, eoff, zo, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, ehi, 4, eoff_hi, zo, 0, 0);   // (an instruction offset would shift the LDS address as well)
+      for (int t = 0; t < TROWS; t ++) {
+        __attribute__((address_space(3))) void *dst = (__attribute__((address_space(3))) void *)(lds + base + (unsigned)t * ROWB);
+        // rows 0 and TROWS-1 are own rows of the neighbouring workgroups, rows 1 and TROWS-2 their halo rows: leave those cached
+        const bool nt = nt_all || (nt_private && t >= 2 && t <= TROWS - 3);
+        if (nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, dst, 16, cb, zo + roff[t], 0, 2);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, dst, 16, cb, zo + roff[t], 0, 0);
+      }
+      __attribute__((address_space(3))) void *edst = (__attribute__((address_space(3))) void *)(lds + edge_of(q));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, edst, 4, eoff, zo, 0, 0);
     };
     // s_waitcnt vmcnt(N) only: gfx9 encoding, vmcnt = simm16[15:14]:[3:0], expcnt [6:4], lgkmcnt [11:8] left at their maxima
 #define FTKX_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))
@@ -1141,8 +1172,10 @@ __global__ __launch_bounds__(64 * (TW * CY + 1)) void mask_march5_kernel(const M
       const int k = z0 + s;
       FTKX_WAIT_VM(LOADS_PER_PLANE * (PD - 1));                 // plane k+1 has landed (planes k+2 .. k+PD may still be on their way)
       __builtin_amdgcn_s_barrier();
+      // into the row slot of plane k, which every consumer has finished with, and the edge entry of plane k - 1 (the consumers
+      // read plane k's own edge entry during this very step: it is the one entry the ring has more than there are row slots)
       const int q = k + 1 + PD;
-      issue(q < z1 ? q : z1);                                  // into the slot of plane k, which every consumer has finished with
+      issue(q < z1 ? q : z1);
     }
     FTKX_WAIT_VM(0);                                           // nothing may still be writing LDS when the workgroup retires
 #undef FTKX_WAIT_VM
@@ -1150,8 +1183,8 @@ __global__ __launch_bounds__(64 * (TW * CY + 1)) void mask_march5_kernel(const M
   }
 
   // ---------------- consumers ----------------
-  const int wx = wv % TW, wy = wv / TW;                        // position of this wavefront's 128 x RY patch inside the tile
-  const int i0 = t0c + 128 * wx + 2 * lane;
+  const int wy = wv;                                           // position of this wavefront's 128 x RY patch inside the tile
+  const int i0 = t0c + 2 * lane;
   const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)job.M, 0, (int)((unsigned)P * (unsigned)DH * (unsigned)DD), 0x00020000);
   const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)job.U, 0, (int)((unsigned)m.u_pitch * (unsigned)DH * (unsigned)DD), 0x00020000);
   const bool have_u = job.U != nullptr;
@@ -1182,33 +1215,18 @@ __global__ __launch_bounds__(64 * (TW * CY + 1)) void mask_march5_kernel(const M
   double acc0 = 0.0, acc1 = 0.0, red_mn = DBL_MAX;
   const unsigned cmask = in_row ? (xkeep & 0x0707u) : 0u;
   const double tbig = 2.0 * job.big;
-  // LDS addresses of this lane inside a slot: its 16 bytes of a row, and where the two dwords of the neighbour value it carries in
-  // the fused edge register live (lane r < RY: left neighbour of own row r; lane 64 - RY + r: right neighbour; see edge_for_row):
-  // inside the tile that is the adjacent column of the same LDS row, at the tile's outer columns the separately fetched values
-  const unsigned lrow = (unsigned)(wx * 1024 + lane * 16);
-  unsigned elo_at = 0, ehi_at = 0;
-  {
-    const bool left = lane < 32;
-    const int er = lane < RY ? lane : (lane >= 64 - RY ? lane - (64 - RY) : 0);
-    const int trow = wy * RY + er;                            // own row index inside the tile (tile row trow + 1)
-    if (left ? wx > 0 : wx < TW - 1) {
-      elo_at = (unsigned)(trow + 1) * ROWB + (unsigned)(left ? wx * 1024 - 8 : (wx + 1) * 1024);
-      ehi_at = elo_at + 4u;
-    } else {
-      elo_at = TROWS * ROWB + (unsigned)((left ? 0 : 32) + trow) * 4u;
-      ehi_at = elo_at + 256u;
-    }
-  }
-  auto take_plane = [&](v2d (&B)[RY + 2], double &X, int q) {
+  const bool per_vertex_rule = job.big < HUGE_VAL;
+  // LDS addresses: this lane's 16 bytes of a row; the edge doubles of this wavefront's first own row inside an edge entry
+  const unsigned lrow = (unsigned)(lane * 16), eown = (unsigned)(wy * RY) * 8u;
+  auto take_plane = [&](v2d (&B)[RY + 2], int q) {
     const char *base = lds + slot_of(q);
     for (int r = 0; r < RY + 2; r ++) B[r] = *reinterpret_cast<const v2d *>(base + (unsigned)(wy * RY + r) * ROWB + lrow);
-    const unsigned lo = *reinterpret_cast<const unsigned *>(base + elo_at), hi = *reinterpret_cast<const unsigned *>(base + ehi_at);
-    X = __longlong_as_double(((long long)hi << 32) | lo);
   };
 
-  auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], v2d (&NX)[RY + 2], const double XC, double &XN, int k) {
+  auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], v2d (&NX)[RY + 2], int k) {
     __builtin_amdgcn_s_barrier();                              // plane k+1 is in LDS; nobody reads plane k's slot any more
-    take_plane(NX, XN, k + 1 < z1 ? k + 1 : z1);
+    take_plane(NX, k + 1 < z1 ? k + 1 : z1);
+    const char *eb = lds + edge_of(k < z1 ? k : z1) + eown;    // plane k's outside neighbours (planes past the chunk re-walk plane z1)
     const bool z_dom = k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2];
     const bool z_int = k >= 1 && k < DD - 1;
     const unsigned mplane = (unsigned)P * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
@@ -1216,8 +1234,9 @@ __global__ __launch_bounds__(64 * (TW * CY + 1)) void mask_march5_kernel(const M
     static_for<RY>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       const v2d c = CU[r + 1];
-      const double xe = edge_for_row<r, RY>(XC);
-      const double xm = dpp_lower_or(c.y, xe), xp = dpp_upper_or(c.x, xe);
+      // every lane reads the same two doubles (a broadcast); only lane 0 keeps the left one, lane 63 the right one (`old` of the shifts)
+      const double xl = *reinterpret_cast<const double *>(eb + 8 * r), xr = *reinterpret_cast<const double *>(eb + 128 + 8 * r);
+      const double xm = dpp_lower_or(c.y, xl), xp = dpp_upper_or(c.x, xr);
       const double dx0 = c.y - xm, dx1 = xp - c.x;
       const double dy0 = CU[r + 2].x - CU[r].x, dy1 = CU[r + 2].y - CU[r].y;
       const double dz0 = NX[r + 1].x - PR[r + 1].x, dz1 = NX[r + 1].y - PR[r + 1].y;
@@ -1225,15 +1244,13 @@ __global__ __launch_bounds__(64 * (TW * CY + 1)) void mask_march5_kernel(const M
       unsigned a0 = 0, a1 = 0;
       shift_in_signs<3>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, tneg, tpos);
       const bool rok = ((row_ok >> r) & 1) && k < z1;
-      unsigned bits = guard_and_reduce<3>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, u_int && rok, cmask, tbig, 0.5, acc0, acc1, red_mn);
+      unsigned bits = guard_and_reduce<3>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, u_int && rok, cmask, per_vertex_rule, tbig, 0.5, acc0, acc1, red_mn);
       const unsigned keep = u_int ? xkeep : 0u;
       const unsigned neut = u_dom ? xneutral : 0x3f3fu;
       bits = (bits & keep) | neut;
       bool word_uniform = false;
       if (have_u) {
-        int q = (int)((bits & (bits >> 8)) & 0x3fu);
-        q &= __builtin_amdgcn_update_dpp(q, q, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
-        q &= __builtin_amdgcn_update_dpp(q, q, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
+        const unsigned q = word_summary(bits);
         if (rok && u_lane) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)q, rU, ucol, uplane + (unsigned)m.u_pitch * (unsigned)r, 0);
         word_uniform = q != 0;
       }
@@ -1243,15 +1260,14 @@ __global__ __launch_bounds__(64 * (TW * CY + 1)) void mask_march5_kernel(const M
   };
 
   v2d B[3][RY + 2];
-  double X[3] = {0.0, 0.0, 0.0};
   __builtin_amdgcn_s_barrier();                                // P1
-  take_plane(B[0], X[0], z0 - 1);
-  take_plane(B[1], X[1], z0);
+  take_plane(B[0], z0 - 1);
+  take_plane(B[1], z0);
   __builtin_amdgcn_s_barrier();                                // P2 (the compiler has waited for the LDS reads above: their values are used)
   for (int s = 0; s < nsteps; s += 3) {
-    step(B[0], B[1], B[2], X[1], X[2], z0 + s);
-    step(B[1], B[2], B[0], X[2], X[0], z0 + s + 1);
-    step(B[2], B[0], B[1], X[0], X[1], z0 + s + 2);
+    step(B[0], B[1], B[2], z0 + s);
+    step(B[1], B[2], B[0], z0 + s + 1);
+    step(B[2], B[0], B[1], z0 + s + 2);
   }
   if (job.red) {
     const double mx = fmax((cmask & 0x00ffu) ? acc0 : 0.0, (cmask & 0xff00u) ? acc1 : 0.0) * 0.5;
@@ -1718,37 +1734,35 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       }
       const dim3 blk((unsigned)(64 * wpb));
       if (m.nd == 3 && !reduce) {
-        // default for 3D scalar slices: the producer / consumer kernel, 128 x 16 tiles, two planes in flight behind the one being
-        // consumed (6.3 vs 6.7 ms for mask_march4_kernel on 512^3 x 32, same box); FTKX_MASK_V=4 selects the latter
+        // default for 3D scalar slices: the producer / consumer kernel, 128 x 12 tiles (three workgroups per CU), two planes in
+        // flight behind the one being consumed; FTKX_MASK_V=4 selects mask_march4_kernel
         int v5 = 1, pd5 = 2;
         if (const char *e = getenv("FTKX_MASK_V")) v5 = atoi(e) == 5 || atoi(e) == 0;
         if (const char *e = getenv("FTKX_MASK_PD")) pd5 = atoi(e);
         if (v5) {
-          int shape = 0;                                         // FTKX_MASK_TILE: 0 = 128 x 16, 1 = 256 x 16, 2 = 512 x 16 (RY 8), 3 = 256 x 32, 4..7 below
+          int shape = 0;
           if (const char *e = getenv("FTKX_MASK_TILE")) shape = atoi(e);
-#define FTKX_M5(PD_, TW_, CY_, RY_) do { \
-            g_last_mask_kernel = "ftkx::mask_march5_kernel<" #PD_ ", " #TW_ ", " #CY_ ", " #RY_ ">"; \
-            const int tw = TW_, rows = CY_ * RY_; \
-            const dim3 grid5((unsigned)((m.ext_sz[0] + 128 * tw - 1) / (128 * tw)), (unsigned)((m.ext_sz[1] + rows - 1) / rows), grid2.z); \
+#define FTKX_M5(PD_, CY_, RY_) do { \
+            g_last_mask_kernel = "ftkx::mask_march5_kernel<" #PD_ ", " #CY_ ", " #RY_ ">"; \
+            const int rows = CY_ * RY_; \
+            const dim3 grid5((unsigned)((m.ext_sz[0] + 127) / 128), (unsigned)((m.ext_sz[1] + rows - 1) / rows), grid2.z); \
             int sw = swizzle; \
             if (sw & 8) { int yg = (sw >> 8) & 0xff; if (yg < 1) yg = 1; while (yg > 1 && grid5.y % (unsigned)yg) yg --; sw = (sw & 0xff) | (yg << 8); } \
-            const unsigned slot = (unsigned)(rows + 2) * 1024u * (unsigned)tw + 512u, bytes = (unsigned)(PD_ + 1) * slot; \
-            (void)hipFuncSetAttribute((const void *)mask_march5_kernel<PD_, TW_, CY_, RY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
-            hipLaunchKernelGGL((mask_march5_kernel<PD_, TW_, CY_, RY_>), grid5, dim3(64u * (TW_ * CY_ + 1)), bytes, stream, m, d_jobs, zchunk, sw); } while (0)
-          if (shape == 1) { if (pd5 == 2) FTKX_M5(2, 2, 4, 4); else FTKX_M5(1, 2, 4, 4); }
-          else if (shape == 2) FTKX_M5(1, 4, 2, 8);
-          else if (shape == 3) FTKX_M5(1, 2, 4, 8);
-          else if (shape == 4) { if (pd5 == 3) FTKX_M5(3, 1, 2, 4); else FTKX_M5(2, 1, 2, 4); }     // 128 x 8
-          else if (shape == 5) { if (pd5 == 3) FTKX_M5(3, 1, 8, 2); else FTKX_M5(2, 1, 8, 2); }     // 128 x 16, eight consumers of 2 rows
-          else if (shape == 6) { if (pd5 == 2) FTKX_M5(2, 1, 8, 4); else FTKX_M5(1, 1, 8, 4); }     // 128 x 32
-          else if (shape == 7) { if (pd5 == 3) FTKX_M5(3, 1, 2, 8); else FTKX_M5(2, 1, 2, 8); }     // 128 x 16, two consumers of 8 rows
-          else if (shape == 8) { if (pd5 == 3) FTKX_M5(3, 1, 3, 4); else FTKX_M5(2, 1, 3, 4); }     // 128 x 12: three workgroups per CU
-          else if (shape == 9) { if (pd5 == 3) FTKX_M5(3, 1, 5, 4); else FTKX_M5(2, 1, 5, 4); }     // 128 x 20
-          else if (shape == 10) FTKX_M5(2, 1, 6, 4);                                                  // 128 x 24: two workgroups fill the LDS exactly
-          else if (shape == 11) FTKX_M5(2, 1, 3, 8);                                                  // 128 x 24, three consumers of 8 rows
-          else if (pd5 == 2) FTKX_M5(2, 1, 4, 4);
-          else if (pd5 == 3) FTKX_M5(3, 1, 4, 4);
-          else FTKX_M5(1, 1, 4, 4);
+            const unsigned bytes = (unsigned)(PD_ + 1) * (unsigned)(rows + 2) * 1024u + (unsigned)(PD_ + 2) * 256u; \
+            (void)hipFuncSetAttribute((const void *)mask_march5_kernel<PD_, CY_, RY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+            hipLaunchKernelGGL((mask_march5_kernel<PD_, CY_, RY_>), grid5, dim3(64u * (CY_ + 1)), bytes, stream, m, d_jobs, zchunk, sw); } while (0)
+          // FTKX_MASK_TILE: 0 = 128 x 12 as three consumers of 4 rows (default), 1 = 128 x 16 (4 x 4), 2 = 128 x 8 (2 x 4), 3 = 128 x 16 (8 x 2),
+          // 4 = 128 x 16 (2 x 8), 5 = 128 x 12 (6 x 2), 6 = 128 x 8 (4 x 2), 7 = 128 x 10 (5 x 2)
+          if (shape == 1) { if (pd5 == 3) FTKX_M5(3, 4, 4); else if (pd5 == 1) FTKX_M5(1, 4, 4); else FTKX_M5(2, 4, 4); }
+          else if (shape == 2) { if (pd5 == 3) FTKX_M5(3, 2, 4); else FTKX_M5(2, 2, 4); }
+          else if (shape == 3) { if (pd5 == 3) FTKX_M5(3, 8, 2); else FTKX_M5(2, 8, 2); }
+          else if (shape == 4) FTKX_M5(2, 2, 8);
+          else if (shape == 5) { if (pd5 == 3) FTKX_M5(3, 6, 2); else FTKX_M5(2, 6, 2); }
+          else if (shape == 6) { if (pd5 == 3) FTKX_M5(3, 4, 2); else FTKX_M5(2, 4, 2); }
+          else if (shape == 7) FTKX_M5(2, 5, 2);
+          else if (pd5 == 1) FTKX_M5(1, 3, 4);
+          else if (pd5 == 3) FTKX_M5(3, 3, 4);
+          else FTKX_M5(2, 3, 4);
 #undef FTKX_M5
           return;
         }

@@ -150,10 +150,10 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
     variants = [{}, {"FTKX_MASK_V": "4"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "2"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "3"},
                 {"FTKX_MASK_SWIZZLE": "0"}, {"FTKX_MASK_SWIZZLE": "1"}, {"FTKX_MASK_V": "4", "FTKX_MASK_SWIZZLE": "1"},
                 {"FTKX_MASK_SWIZZLE": "24", "FTKX_MASK_YG": "4"}, {"FTKX_TWO_LEVEL": "0"},
-                {"FTKX_MASK_V": "4", "FTKX_MASK_RY": "8"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "0"}, {"FTKX_MASK_V": "5", "FTKX_MASK_PD": "1"}, {"FTKX_MASK_V": "5", "FTKX_MASK_PD": "2"},
-                {"FTKX_MASK_V": "5", "FTKX_MASK_PD": "3", "FTKX_MASK_SWIZZLE": "24"}, {"FTKX_MASK_V": "5", "FTKX_MASK_TILE": "1"},
-                {"FTKX_MASK_V": "5", "FTKX_MASK_TILE": "1", "FTKX_MASK_PD": "2"}, {"FTKX_MASK_V": "5", "FTKX_MASK_TILE": "2"}, {"FTKX_MASK_V": "5", "FTKX_MASK_TILE": "3"},
-                {"FTKX_MASK_TILE": "4"}, {"FTKX_MASK_TILE": "5", "FTKX_MASK_PD": "3"}, {"FTKX_MASK_TILE": "6"}, {"FTKX_MASK_TILE": "7"}, {"FTKX_MASK_TILE": "8"}, {"FTKX_MASK_TILE": "9"}]
+                {"FTKX_MASK_V": "4", "FTKX_MASK_RY": "8"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "0"}, {"FTKX_MASK_PD": "1"}, {"FTKX_MASK_PD": "3"},
+                {"FTKX_MASK_TILE": "1"}, {"FTKX_MASK_TILE": "1", "FTKX_MASK_PD": "3", "FTKX_MASK_SWIZZLE": "24"}, {"FTKX_MASK_TILE": "1", "FTKX_MASK_PD": "1"},
+                {"FTKX_MASK_TILE": "2"}, {"FTKX_MASK_TILE": "3"}, {"FTKX_MASK_TILE": "3", "FTKX_MASK_PD": "3"}, {"FTKX_MASK_TILE": "4"},
+                {"FTKX_MASK_TILE": "5"}, {"FTKX_MASK_TILE": "6"}, {"FTKX_MASK_TILE": "6", "FTKX_MASK_PD": "3"}, {"FTKX_MASK_TILE": "7"}]
     base = None
     for env in variants:
         old = {k: os.environ.get(k) for k in env}
@@ -172,7 +172,10 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
             assert st["cull_enabled"] == 1
         else:
             _same(recs, base[0])
-            assert key == base[1], (env, key, base[1])
+            if env.get("FTKX_TWO_LEVEL") == "0":        # one-level cull: words the summaries stand in for are culled on their real bytes
+                assert key[1:] == base[1][1:] and key[0] <= base[1][0], (env, key, base[1])
+            else:
+                assert key == base[1], (env, key, base[1])
 
 
 def test_slices_beyond_4GiB_take_the_64bit_kernels(gpu):
