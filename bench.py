@@ -274,17 +274,23 @@ def main():
         achieved = alg_bytes_launch / (avg_ms * 1e-3) / 1e9
         all_ms = sum(v[0] for v in ktimes.values()) / args.steps
         alg_bytes_pass = 8.0 * c * n_vertex * len(own) + 72.0 * len(recs)
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
-            try:
-                traffic = json.load(open(tj)).get(args.config, {}).get("hbm_bytes_per_launch")
-            except Exception:   # noqa: BLE001
-                traffic = None
         # the profiler's name of the dominant kernel (the mask family has several instantiations; the library says which one ran)
         kernel_symbol = "ftkx::%s<%d>" % (dom, nd)
         if dom == "mask_kernel":
             kernel_symbol = (ctx._L.ftkx_last_mask_kernel() or b"").decode() or kernel_symbol
+        # HBM bytes per launch from the committed PMC passes (profiles/traffic.json, written by tools/summarize_profiles.py): only
+        # for the very kernel instantiation that ran here -- a profile of another kernel generation is not this kernel's traffic
+        traffic, traffic_source = None, None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                ent = json.load(open(tj)).get(args.config, {})
+                if ent.get("kernel") == kernel_symbol:
+                    traffic, traffic_source = ent.get("hbm_bytes_per_launch"), ent.get("source")
+                else:
+                    traffic_source = "profiles/traffic.json holds %s, not the kernel that ran: no traffic figure" % ent.get("kernel")
+            except Exception:   # noqa: BLE001
+                traffic = None
         out = {
             "metric": "space-time simplices/sec", "value": total_simplices * args.steps / elapsed, "unit": "simplices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -295,7 +301,7 @@ def main():
                        "nbits": int(np.log2(max(factors))), "cull": bool(st["cull_enabled"]),
                        "input_resident": "the field the tracker API is given (S, or V for vector input) in HBM; gradient/Jacobian evaluated in flight"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": kernel_symbol, "kernel_family": "ftkx::%s<%d>" % (dom, nd), "avg_launch_ms": avg_ms, "launches_timed": int(dom_n),
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_symbol, "kernel_family": "ftkx::%s<%d>" % (dom, nd), "avg_launch_ms": avg_ms, "launches_timed": int(dom_n),
                          "algorithmic_bytes_per_launch": alg_bytes_launch, "slices_per_launch": slices_per_launch,
                          "all_kernels_ms_per_pass": all_ms, "achieved_all_kernels": alg_bytes_pass / (all_ms * 1e-3) / 1e9,
                          "kernel_ms_per_pass": {k: v[0] / args.steps for k, v in ktimes.items()}},

@@ -1225,7 +1225,14 @@ __global__ __launch_bounds__(64 * (CY + 1)) void mask_march5_kernel(const Mesh m
 
   auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], v2d (&NX)[RY + 2], int k) {
     __builtin_amdgcn_s_barrier();                              // plane k+1 is in LDS; nobody reads plane k's slot any more
+    if (swizzle & 128) return;                                 // profiling experiment: the producer's stream alone (results are garbage)
     take_plane(NX, k + 1 < z1 ? k + 1 : z1);
+    if (swizzle & 64) {                                        // profiling experiment: + the consumers' LDS reads, no arithmetic, no stores
+      long long acc = 0;
+      for (int r = 0; r < RY + 2; r ++) acc ^= __double_as_longlong(NX[r].x) ^ __double_as_longlong(NX[r].y);
+      if (acc == 0x7ff8123456789abcll) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)acc, rM, mcol, 0, 0);
+      return;
+    }
     const char *eb = lds + edge_of(k < z1 ? k : z1) + eown;    // plane k's outside neighbours (planes past the chunk re-walk plane z1)
     const bool z_dom = k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2];
     const bool z_int = k >= 1 && k < DD - 1;
@@ -1726,9 +1733,11 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       int wpb = 4;
       if (const char *e = getenv("FTKX_MASK_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 12) wpb = v; }
       const dim3 grid2((unsigned)((DW + 127) / 128), (unsigned)((m.ext_sz[1] + wpb * RY - 1) / (wpb * RY)), (unsigned)(nzc * njobs));
-      if (swizzle & 8) {   // grouped placement: YG row groups per group (must divide the grid's y extent)
-        int yg = 1;
-        if (const char *e = getenv("FTKX_MASK_YG")) yg = atoi(e) > 0 ? atoi(e) : 1;
+      int yg_want = 4;       // grouped placement: YG row groups per group -- y-neighbouring tiles on one XCD share their halo rows in its L2
+      if (const char *e = getenv("FTKX_MASK_YG")) yg_want = atoi(e) > 0 ? atoi(e) : 1;
+      if (yg_want > 255) yg_want = 255;
+      if (swizzle & 8) {     // (mask_march4_kernel: the group height must divide the grid's y extent)
+        int yg = yg_want;
         while (yg > 1 && grid2.y % (unsigned)yg) yg --;
         swizzle = (swizzle & 0xff) | (yg << 8);
       }
@@ -1745,9 +1754,10 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
 #define FTKX_M5(PD_, CY_, RY_) do { \
             g_last_mask_kernel = "ftkx::mask_march5_kernel<" #PD_ ", " #CY_ ", " #RY_ ">"; \
             const int rows = CY_ * RY_; \
-            const dim3 grid5((unsigned)((m.ext_sz[0] + 127) / 128), (unsigned)((m.ext_sz[1] + rows - 1) / rows), grid2.z); \
+            dim3 grid5((unsigned)((m.ext_sz[0] + 127) / 128), (unsigned)((m.ext_sz[1] + rows - 1) / rows), grid2.z); \
             int sw = swizzle; \
-            if (sw & 8) { int yg = (sw >> 8) & 0xff; if (yg < 1) yg = 1; while (yg > 1 && grid5.y % (unsigned)yg) yg --; sw = (sw & 0xff) | (yg << 8); } \
+            /* grouped placement needs a y extent that is a multiple of the group height: pad it (workgroups past the last row leave at once) */ \
+            if (sw & 8) { int yg = yg_want; if (yg > (int)grid5.y) yg = (int)grid5.y; grid5.y = (grid5.y + (unsigned)yg - 1) / (unsigned)yg * (unsigned)yg; sw = (sw & 0xff) | (yg << 8); } \
             const unsigned bytes = (unsigned)(PD_ + 1) * (unsigned)(rows + 2) * 1024u + (unsigned)(PD_ + 2) * 256u; \
             (void)hipFuncSetAttribute((const void *)mask_march5_kernel<PD_, CY_, RY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
             hipLaunchKernelGGL((mask_march5_kernel<PD_, CY_, RY_>), grid5, dim3(64u * (CY_ + 1)), bytes, stream, m, d_jobs, zchunk, sw); } while (0)

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""A/B timing of mask-kernel variants inside ONE process (the library reads its FTKX_MASK_* knobs at every launch): the variants
+are interleaved round-robin so that box-to-box and minute-to-minute drift hits all of them alike.  Reports per variant the
+mean / min of the fused mask kernel's device time (HIP events inside the library) over the rounds.
+usage: python tools/ab_mask.py [config] [rounds] -- "TILE=0 YG=1" "TILE=1 YG=4" ...   (names without the FTKX_MASK_ prefix)"""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import ftk_amd  # noqa: E402
+from ftk_amd import synthetic  # noqa: E402
+
+args = sys.argv[1:]
+sep = args.index("--") if "--" in args else len(args)
+cfg = args[0] if sep > 0 else "c4"
+rounds = int(args[1]) if sep > 1 else 6
+variants = args[sep + 1:] or ["TILE=0"]
+CONFIGS = {"c4": (3, "moving_extremum_3d", (512, 512, 512), 32), "c3": (3, "moving_extremum_3d", (256, 256, 256), 16),
+           "c2": (2, "woven", (1024, 1024), 64)}
+nd, case, dims, nt = CONFIGS[cfg]
+dev = torch.device("cuda", 0)
+stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream)
+ctx = ftk_amd.Context(nd); ctx.set_stream(stream.cuda_stream)
+dom = ([2] * nd, [d - 3 for d in dims])
+ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
+ctx.set_options(jacobian_symmetric=1, derive_jacobian=1, tag_mode=ftk_amd.TAG_EXACT64)
+keep = []
+for t in range(nt):
+    a = synthetic.generate(case, dims, t, nt, torch, dev); torch.cuda.synchronize(); keep.append(a)
+    ctx.push_scalar_slice(t, a)
+ctx.set_profiling(True)
+times = {v: [] for v in variants}
+for rnd in range(rounds + 1):
+    for v in variants:
+        old = {}
+        for kv in v.split():
+            k, val = kv.split("=")
+            old["FTKX_MASK_" + k] = os.environ.get("FTKX_MASK_" + k)
+            os.environ["FTKX_MASK_" + k] = val
+        ctx.invalidate_masks()
+        ctx.set_profiling(True)      # resets the accumulated kernel times
+        ctx.slices_prepare(range(nt), 0)
+        ms = ctx.kernel_times()["mask_kernel"][0]
+        if rnd > 0:                  # round 0 = warm-up (code object load)
+            times[v].append(ms)
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+for v in variants:
+    t = times[v]
+    print(f"{cfg} {v:28s} mean {sum(t) / len(t):.3f} ms  min {min(t):.3f}  max {max(t):.3f}  ({len(t)} rounds)")
