@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: dry run of the N>1 path (host-staged halo)")
     ap.add_argument("--single-device", action="store_true", help="all ranks on cuda:0 (dry run of the N>1 logic on a 1-GPU box)")
     ap.add_argument("--halo-in-loop", action="store_true", help="N > 1: re-send the slab-boundary slice inside every timed pass")
+    ap.add_argument("--dump-merged", default=None, help="rank 0 writes the merged records and the curves traced from them (npz)")
     args = ap.parse_args()
 
     # before anything initialises the HIP runtime: the host driver only supports dmabuf IPC (RCCL / device-tensor sharing across
@@ -254,20 +255,40 @@ def main():
         other = {"halo_in_timed_region": flip, "steps": k2, "ms_per_step": float(e2.item()) / k2 * 1e3,
                  "value": total_simplices * k2 / float(e2.item())}
 
+    # ---- after the timed region: merge the slabs' hit buffers on rank 0 and run pass 2 on the merged set ("host merge of
+    # hit buffers into the union_find / trace stage"; critical_point_tracker.hh:689-717).  Curves cross slab boundaries.
+    tm0 = time.perf_counter()
+    merged = tslab.gather_records(np.array(recs), 0) if world > 1 else np.array(recs)
+    tm1 = time.perf_counter()
+    pass2 = None
+    if rank == 0:
+        curves, loop, nspecial = ftk_amd.trace_curves(nd, dom, merged)
+        tm2 = time.perf_counter()
+        trajs = ftk_amd.post_process(nd, dom, merged)
+        tm3 = time.perf_counter()
+        pass2 = {"records": int(len(merged)), "curves": len(curves), "branching_points_dropped": int(nspecial), "trajectories_after_post_process": len(trajs),
+                 "gather_ms": (tm1 - tm0) * 1e3, "trace_ms": (tm2 - tm1) * 1e3, "post_process_ms": (tm3 - tm2) * 1e3,
+                 "note": "untimed region: merge of the ranks' records on rank 0, ftkx_trace_curves and ftkx_post_process_curves on the merged set (host side)"}
+        if args.dump_merged:
+            np.savez(args.dump_merged, records=merged, curve_offsets=np.cumsum([0] + [len(c) for c in curves]),
+                     curve_indices=np.concatenate(curves) if curves else np.zeros(0, dtype=np.int64), curve_loop=np.asarray(loop))
+        n_hits = len(merged)
+
     # sanity of the result itself (cheap, size-independent): the single extremum must sit on x0 + dir * t
     check = {"hits": n_hits}
-    if case == "moving_extremum_3d" and len(recs):
+    if case == "moving_extremum_3d" and rank == 0 and len(merged):
         x0, dv = me3d_params(dims)
-        err = max(float(np.abs(recs["x"][:, a] - (x0[a] + dv[a] * recs["t"])).max()) for a in range(3))
+        err = max(float(np.abs(merged["x"][:, a] - (x0[a] + dv[a] * merged["t"])).max()) for a in range(3))
         check["max_abs_position_error_vs_analytic"] = err
-        check["types"] = sorted(set(int(v) for v in recs["type"]))
+        check["types"] = sorted(set(int(v) for v in merged["type"]))
+        check["curves"] = pass2["curves"]
 
     if rank == 0:
         n_vertex = int(np.prod(dims))
         c = 1 if scalar_input else nd
         # dominant kernel = the one with the most device time; one launch of it covers `len(own)` slices (batched launch)
-        dom = max(ktimes, key=lambda k: ktimes[k][0])
-        dom_ms, dom_n = ktimes[dom]
+        domk = max(ktimes, key=lambda k: ktimes[k][0])
+        dom_ms, dom_n = ktimes[domk]
         avg_ms = dom_ms / max(1, dom_n)
         slices_per_launch = len(own) * args.steps / max(1, dom_n)
         alg_bytes_launch = (8.0 * c * n_vertex) * slices_per_launch + 72.0 * len(recs) * args.steps / max(1, dom_n)
@@ -275,8 +296,8 @@ def main():
         all_ms = sum(v[0] for v in ktimes.values()) / args.steps
         alg_bytes_pass = 8.0 * c * n_vertex * len(own) + 72.0 * len(recs)
         # the profiler's name of the dominant kernel (the mask family has several instantiations; the library says which one ran)
-        kernel_symbol = "ftkx::%s<%d>" % (dom, nd)
-        if dom == "mask_kernel":
+        kernel_symbol = "ftkx::%s<%d>" % (domk, nd)
+        if domk == "mask_kernel":
             kernel_symbol = (ctx._L.ftkx_last_mask_kernel() or b"").decode() or kernel_symbol
         # HBM bytes per launch from the committed PMC passes (profiles/traffic.json, written by tools/summarize_profiles.py): only
         # for the very kernel instantiation that ran here -- a profile of another kernel generation is not this kernel's traffic
@@ -301,7 +322,7 @@ def main():
                        "nbits": int(np.log2(max(factors))), "cull": bool(st["cull_enabled"]),
                        "input_resident": "the field the tracker API is given (S, or V for vector input) in HBM; gradient/Jacobian evaluated in flight"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_symbol, "kernel_family": "ftkx::%s<%d>" % (dom, nd), "avg_launch_ms": avg_ms, "launches_timed": int(dom_n),
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_symbol, "kernel_family": "ftkx::%s<%d>" % (domk, nd), "avg_launch_ms": avg_ms, "launches_timed": int(dom_n),
                          "algorithmic_bytes_per_launch": alg_bytes_launch, "slices_per_launch": slices_per_launch,
                          "all_kernels_ms_per_pass": all_ms, "achieved_all_kernels": alg_bytes_pass / (all_ms * 1e-3) / 1e9,
                          "kernel_ms_per_pass": {k: v[0] / args.steps for k, v in ktimes.items()}},
@@ -312,6 +333,7 @@ def main():
                                     "note": "algorithmic bytes of this rank's pass / wall time of the pass (prepare + factors + cull + exact + sort + download)"},
             "halo_exchange": halo_info,
             "other_halo_convention": other,
+            "pass2": pass2,
             "wall_breakdown_ms_per_pass": {"prepare_masks_and_reduction": host_ms[2] / args.steps, "enqueue_calls": host_ms[0] / args.steps,
                                            "collect_launch_sync_sort_download": host_ms[1] / args.steps},
             "stats": {"simplices_tested_exactly": n_tested, "cells_survived_cull": n_cells},

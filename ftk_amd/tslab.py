@@ -94,6 +94,38 @@ def exchange_halo(first_slice, recv_buffer, nt, group=None):
     return got
 
 
+def gather_records(recs, dst=0, group=None):
+    """The merge step of the t-slab partition (SURVEY 8e; what critical_point_tracker.hh:689 does with `diy::mpi::gather` of
+    the discrete points): every rank's hit records go to rank `dst`, which gets them as ONE array sorted by tag -- ready for
+    ftkx_trace_curves, whose neighbourhoods cross slab boundaries like any other cell boundary.  Other ranks get None.
+    Variable-length point-to-point transfers (a rank's hit count is data dependent); with 64-bit element tags the slabs are
+    already in tag order (time is the slowest axis of the tag), the final sort only makes that independent of the tag mode."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    recs = np.ascontiguousarray(recs)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.tensor([len(recs)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(counts, mine, group=group)
+    counts = [int(c.item()) for c in counts]
+    item = recs.dtype.itemsize
+    if rank != dst:
+        if len(recs):
+            dist.send(torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()).to(dev), dst, group=group)
+        return None
+    parts = []
+    for r in range(world):
+        if r == dst:
+            parts.append(recs)
+        elif counts[r]:
+            buf = torch.empty((counts[r] * item,), dtype=torch.uint8, device=dev)
+            dist.recv(buf, src=r, group=group)
+            parts.append(buf.cpu().numpy().view(recs.dtype))
+    merged = np.concatenate(parts) if parts else recs
+    return merged[np.argsort(merged["tag"], kind="stable")]
+
+
 def count_simplices(nd, dims, nt, scalar_input=True):
     """work items of the whole job: corners x (n_ord*nt + n_int*(nt-1))   (simplicial_regular_mesh.hh:1042)"""
     n_ord, n_int = (2, 10) if nd == 2 else (6, 54)

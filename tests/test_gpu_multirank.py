@@ -1,12 +1,14 @@
-"""The N > 1 path of bench.py (t-slab partition, halo slice, global factors, merged hits) exercised on ONE GPU: two and three
-ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one device), everything else is the code the driver runs with
-`--gpus N`.  The hit set and the exact-test statistics must not depend on the number of slabs."""
+"""The N > 1 path of bench.py (t-slab partition, halo slice, global factors, records merged on rank 0 and traced there) exercised
+on ONE GPU: two and three ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one device), everything else is the
+code the driver runs with `--gpus N`.  The merged record set and the curves traced from it must not depend on the number of
+slabs: bit for bit the single-rank result."""
 import json
 import os
 import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -18,8 +20,10 @@ def _free_port():
     return p
 
 
-def _bench(n, cfg, extra=()):
+def _bench(n, cfg, extra=(), dump=None):
     common = ["bench.py", "--gpus", str(n), "--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *extra]
+    if dump:
+        common += ["--dump-merged", str(dump)]
     if n == 1:
         cmd = [sys.executable, *common]
     else:
@@ -32,11 +36,19 @@ def _bench(n, cfg, extra=()):
 
 
 @pytest.mark.parametrize("cfg", ["small3", "small2"])
-def test_slab_count_does_not_change_the_result(cfg):
-    one = _bench(1, cfg)
+def test_slab_count_does_not_change_the_result(cfg, tmp_path):
+    one = _bench(1, cfg, dump=tmp_path / "one.npz")
     assert one["n_gpus"] == 1 and one["check"]["hits"] > 0
+    ref = np.load(tmp_path / "one.npz")
+    assert one["pass2"]["records"] == len(ref["records"]) == one["check"]["hits"] and one["pass2"]["curves"] == len(ref["curve_loop"]) > 0
     for n, extra in ((2, ()), (3, ()), (2, ("--halo-in-loop",))):
-        many = _bench(n, cfg, extra)
+        many = _bench(n, cfg, extra, dump=tmp_path / f"many{n}.npz")
+        got = np.load(tmp_path / f"many{n}.npz")
+        # the merged record set (72-byte records, bit for bit) and the curves traced from it: identical to the single-rank run
+        assert got["records"].tobytes() == ref["records"].tobytes()
+        for k in ("curve_offsets", "curve_indices", "curve_loop"):
+            assert np.array_equal(got[k], ref[k]), k
+        assert many["pass2"]["curves"] == one["pass2"]["curves"] and many["pass2"]["trajectories_after_post_process"] == one["pass2"]["trajectories_after_post_process"]
         assert many["n_gpus"] == n and many["scaling"] == "strong"
         assert many["check"]["hits"] == one["check"]["hits"]
         assert many["config"]["simplices_per_step"] == one["config"]["simplices_per_step"]

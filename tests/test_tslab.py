@@ -85,3 +85,101 @@ def test_halo_and_factor_exchange_world2_gloo(nt):
             assert halo == float(t1)        # first slice of the next slab
         else:
             assert halo is None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# merge of the slabs' records -> pass 2 (critical_point_tracker.hh:689-717): every rank sweeps ITS timesteps (here with the
+# oracle standing in for the GPU sweep: this is a CPU test of the host logic), receives its halo slice and the global factors
+# exactly as bench.py does, the records are gathered on rank 0 and traced there.  The merged set must be the single-rank record
+# set and the curves the reference's own traced curves (fixtures from the real reference), bit for bit.
+# ---------------------------------------------------------------------------------------------------------------
+def _merge_worker(rank, world, port, name, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pyoracle as oracle
+        import ftk_amd
+        from common import load_golden
+        g = load_golden(name)
+        nd, nv, D, nt = g["nd"], g["nv"], g["dims"], g["DT"]
+        scalar = nv == 1
+        t0, t1 = tslab.slab_range(nt, world, rank)
+        own = list(range(t0, t1))
+
+        def derive(a):
+            if scalar:
+                V = oracle.gradient2D(a) if nd == 2 else oracle.gradient3D(a)
+                return V, (oracle.jacobian2D(V, True) if nd == 2 else oracle.jacobian3D(V)), a
+            return a, (oracle.jacobian2D(a, False) if nd == 2 else oracle.jacobian3D(a)), None
+
+        slices = {t: torch.from_numpy(np.ascontiguousarray(g["steps"][t])) for t in own}       # this rank sees ONLY its slab ...
+        buf = torch.empty_like(torch.from_numpy(np.ascontiguousarray(g["steps"][0])))
+        got = tslab.exchange_halo(slices[t0] if own else buf, buf, nt)                          # ... plus the first slice of the next one
+        if got:
+            slices[t1] = buf
+        fields = {t: derive(s.numpy()) for t, s in slices.items()}
+        factors, _, _ = tslab.global_factors({t: oracle.resolution(fields[t][0]) for t in own}, nt, local_max={t: 1.0 for t in own})
+        assert factors == [int(f) for f in g["factors"]]
+        lo = 2 if scalar else 1
+        dom = ([lo] * nd, [d - (3 if scalar else 2) for d in D])
+        parts = []
+        for t in own:
+            for scope in (1, 2):
+                if scope == 2 and t + 1 >= nt:
+                    continue
+                f0, f1 = fields[t], fields.get(t + 1)
+                r = oracle.sweep(nd, scope, t, dom, dom, ([0] * nd, D), (f0[0], f1[0] if f1 else None), (f0[1], f1[1] if f1 else None),
+                                 (f0[2], f1[2] if f1 else None) if scalar else None, factors[t], jacobian_symmetric=scalar, tag_mode=oracle.TAG_EXACT64)
+                c = np.zeros(len(r), dtype=ftk_amd.CP_DTYPE)
+                for fld in ("x", "t", "type", "tag"):
+                    c[fld] = r[fld]
+                c["scalar"] = r["scalar"]
+                c["aux"] = (r["ordinal"].astype(np.uint32) & 1) | (np.uint32(t) << 1)
+                parts.append(c)
+        mine = np.concatenate(parts) if parts else np.zeros(0, dtype=ftk_amd.CP_DTYPE)
+        merged = tslab.gather_records(mine, 0)
+        if rank != 0:
+            assert merged is None
+            q.put((rank, len(mine), None))
+            return
+        ref = g["records"]
+        order = np.argsort(ref["tag"], kind="stable")
+        assert len(merged) == len(ref) and np.array_equal(merged["tag"], ref["tag"][order]) and np.array_equal(merged["type"], ref["type"][order])
+        assert np.array_equal(merged["x"], ref["x"][order]) and np.array_equal(merged["t"], ref["t"][order])
+        assert np.array_equal(merged["aux"] >> 1, ref["timestep"][order].astype(np.uint32))
+        curves, loop, _ = ftk_amd.trace_curves(nd, dom, merged)
+        gotc = sorted((tuple(merged["tag"][c].tolist()), int(l)) for c, l in zip(curves, loop))
+        expc = sorted((tuple(tg.tolist()), int(l)) for l, tg in g["curves"])
+        assert gotc == expc
+        # curves that no single slab could have formed: points from more than one rank's timesteps
+        crossing = sum(1 for c in curves if len(set(tslab.owner_of(int(ts), nt, world) for ts in (merged["aux"][c] >> 1))) > 1)
+        trajs = ftk_amd.trace_and_post_process(nd, dom, merged)
+        gotp = sorted((tuple(merged["tag"][i].tolist()), tuple(ty.tolist()), tuple(tt.tolist()), lp) for i, ty, tt, lp in trajs)
+        expp = sorted((tuple(tg.tolist()), tuple(ty.tolist()), tuple(tt.tolist()), lp) for lp, tg, ty, tt in g["pp"])
+        assert gotp == expp
+        q.put((rank, len(mine), (len(merged), len(curves), crossing, len(trajs))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world,expect", [("woven_31x37x32", 2, (4491, 56, 56)), ("woven_31x37x32", 3, (4491, 56, 56)),
+                                               ("moving_extremum_3d_21x21x21x32", 3, (126, 1, 1)), ("double_gyre_64x32x50", 2, (879, 2, 2))])
+def test_merged_slabs_trace_to_the_reference_curves_gloo(oracle, name, world, expect):
+    from ftk_amd import build
+    build.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_merge_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    n_records, n_curves, crossing, n_trajs = out[0][2]
+    assert (n_records, n_curves, n_trajs) == expect
+    assert sum(o[1] for o in out) == n_records and all(o[1] > 0 for o in out)     # every rank contributed
+    assert crossing > 0                                                           # and curves do cross the slab boundaries
