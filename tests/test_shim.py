@@ -73,3 +73,45 @@ def test_shim_returns_oracle_records(name, tmp_path, oracle):
             assert np.array_equal(got[fld][o], ref[fld][p]), fld
         for fld in ("x", "t"):
             assert np.array_equal(got[fld][o], ref[fld][p], equal_nan=True), fld
+
+
+SHIM_DRIVER = os.path.join(ROOT, "oracle", "_ref", "ftk_shim_driver")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,case,args,curves,trajs", [
+    ("woven_31x37x32", "woven", (31, 37, 1, 32), 56, 56),                                  # tests/test_critical_point_tracking_woven.cpp:32-37
+    ("moving_extremum_3d_21x21x21x32", "moving_extremum_3d", (21, 21, 21, 32), 1, 1),
+    ("double_gyre_64x32x50", "double_gyre", (64, 32, 1, 50), 2, 2),                        # vector input, reference-derived Jacobian
+    ("merger_2d_32x32x100", "merger_2d", (32, 32, 1, 100), 5, 9),
+    ("moving_extremum_3d_21x21x21x4_overflow", "moving_extremum_3d", (21, 21, 21, 4), 23208, None),   # wrapped determinants included
+])
+def test_real_reference_tracker_runs_through_the_shim(name, case, args, curves, trajs, tmp_path):
+    """The drop-in, executed: oracle/_ref/ftk_shim_driver is the REAL ftk::critical_point_tracker_{2d,3d}_regular (compiled from
+    /root/reference in the build container) whose update_timestep() takes the reference's accelerator branch with the call sites
+    bound to libftkx.so through include/ftkx_shim.hh; the reference's own from_work_index / to_integer, its own std::map and its own
+    finalize() consume what the HIP kernels return.  Result: the CPU fixture of the same reference, record for record, the
+    per-step factors, the traced curves and the post-processed trajectories (56 on the woven test, as the reference's test asserts)."""
+    if not os.path.exists(SHIM_DRIVER):
+        pytest.skip("oracle/_ref/ftk_shim_driver not built (needs the build container: make -C oracle ref)")
+    from refdump import read_dump
+    g = load_golden(name)
+    out = tmp_path / "o.bin"
+    cmd = [SHIM_DRIVER, "synthetic", case] + [str(a) for a in args] + [str(out)]
+    if len(g["x0dir"]):
+        cmd += [repr(float(v)) for v in g["x0dir"]]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = read_dump(str(out))
+    assert np.array_equal(d["factors"], g["factors"])
+    got, ref = d["records"], g["records"]
+    assert len(got) == len(ref)
+    o, p = np.argsort(got["tag"], kind="stable"), np.argsort(ref["tag"], kind="stable")
+    for f in ("tag", "type", "ordinal", "timestep"):
+        assert np.array_equal(got[f][o], ref[f][p]), f
+    for f in ("x", "t", "scalar"):
+        assert np.array_equal(got[f][o], ref[f][p], equal_nan=True), f            # bit-identical (north_star asks for 1e-6)
+    assert len(d["curves"]) == curves == len(g["curves"])
+    assert sorted((tuple(t.tolist()), l) for l, t in d["curves"]) == sorted((tuple(t.tolist()), l) for l, t in g["curves"])
+    if trajs is not None:
+        assert len(d["pp"]) == trajs
