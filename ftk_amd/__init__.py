@@ -348,10 +348,16 @@ class _TrackerRegular:
     """ftkx::critical_point_tracker_regular (include/ftkx_tracker.hh) through its C handle; method names are the reference's."""
     ND = 0
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, device_ids=None, block=2):
+        """device_ids: several GPUs behind one tracker (timesteps dealt to them in blocks of `block` steps, one host thread per
+        device; a device may be listed more than once)"""
         self._L = _lib.load()
         self._h = C.c_void_p()
-        _lib.check(self._L.ftkx_tracker_create(C.byref(self._h), self.ND, device_id), None, True)
+        if device_ids is not None:
+            ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+            _lib.check(self._L.ftkx_tracker_create_multi(C.byref(self._h), self.ND, ids, len(device_ids), int(block)), None, True)
+        else:
+            _lib.check(self._L.ftkx_tracker_create(C.byref(self._h), self.ND, device_id), None, True)
         self._src = [SOURCE_NONE, SOURCE_NONE, SOURCE_NONE, 0]
         self._flags = dict(robust=1, use_type_filter=0, type_filter=0, compute_degrees=0, exact_only=0, tag_mode=TAG_REFERENCE)
         self._keep = []
@@ -421,6 +427,7 @@ class _TrackerRegular:
         self._keep = self._keep[-2:]
 
     def update_timestep(self): self._ck(self._L.ftkx_tracker_update_timestep(self._h))
+    def sync(self): self._ck(self._L.ftkx_tracker_sync(self._h))
 
     def get_critical_points(self):
         """(records[CP_DTYPE], ordinal[int32], timestep[int32]) in the reference's std::map order (by element tag)"""

@@ -34,13 +34,28 @@ def up_to_date():
 
 
 def build(force=False, verbose=False):
+    """one object per source under ftk_amd/csrc/build/ (rebuilt when the source or any header is newer), then one link"""
     if not force and up_to_date():
         return OUT
-    cmd = [hipcc()] + FLAGS + ["-o", OUT] + SRC
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    objdir = os.path.join(HERE, "csrc", "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [p for p in deps() if p not in SRC]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    cflags = [f for f in FLAGS if f != "-shared"]
+    objs, procs = [], []
+    for src in SRC:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            cmd = [hipcc()] + cflags + ["-c", src, "-o", obj]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
     return OUT
 
 

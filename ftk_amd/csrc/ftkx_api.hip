@@ -668,6 +668,7 @@ static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, con
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "push: call ftkx_set_mesh first");
   if (t < 0) return fail(c, FTKX_E_INVALID, "push: negative timestep");
+  if (on_device < 0 || on_device > 2) return fail(c, FTKX_E_INVALID, "push: on_device must be 0, 1 or 2");
   if (scalar_only ? !S : !V) return fail(c, FTKX_E_INVALID, "push: missing field pointer");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "push: sweeps pending, collect first");
   if (c->slices.empty()) c->scalar_mode = -1;
@@ -681,10 +682,11 @@ static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, con
   const int nd = c->nd;
   auto take = [&](const double *src, size_t count, double **dst, bool *own) -> int {
     if (!src) { *dst = nullptr; *own = false; return FTKX_OK; }
-    if (on_device) { *dst = const_cast<double *>(src); *own = false; return FTKX_OK; }
+    if (on_device == 1) { *dst = const_cast<double *>(src); *own = false; return FTKX_OK; }
     HIP_TRY(c, hipMalloc((void **)dst, count * sizeof(double)));
     *own = true;
-    HIP_TRY(c, hipMemcpyAsync(*dst, src, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // 0: host memory; 2: device memory of ANY device (a multi-device tracker hands one snapshot to two contexts), copied
+    HIP_TRY(c, hipMemcpyAsync(*dst, src, count * sizeof(double), on_device == 2 ? hipMemcpyDefault : hipMemcpyHostToDevice, c->stream));
     return FTKX_OK;
   };
   int rc;
@@ -695,7 +697,7 @@ static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, con
   }
   // scalar input: V = gradient2D/3D(S) is never materialised -- every kernel evaluates it where it needs it, with the
   // reference's exact operations (ndarray/grad.hh), so the slice costs 8 bytes per vertex of HBM instead of 8 + 8*nd.
-  if (!on_device) HIP_TRY(c, hipStreamSynchronize(c->stream));   // host buffers may be reused by the caller on return
+  if (on_device != 1) HIP_TRY(c, hipStreamSynchronize(c->stream));   // the source buffers may be reused by the caller on return
   c->slices[t] = s;
   c->scalar_mode = scalar_only ? 1 : 0;
   return FTKX_OK;

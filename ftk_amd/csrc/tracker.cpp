@@ -5,7 +5,13 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <set>
+#include <thread>
 
 namespace ftkx {
 
@@ -20,7 +26,141 @@ critical_point_tracker_regular::critical_point_tracker_regular(int nd_, int devi
   }
 }
 
-critical_point_tracker_regular::~critical_point_tracker_regular() { ftkx_destroy(ctx); }
+// ---- several devices behind one tracker ---------------------------------------------------------------------------------------
+struct critical_point_tracker_regular::multi_engine {
+  struct worker {
+    ftkx_ctx *ctx = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    bool stop = false, busy = false;
+  };
+  std::vector<std::unique_ptr<worker>> w;
+  int block = 2, t_first = -1;
+  std::map<int, std::set<int>> resident;       // timestep -> workers that hold the slice
+  // the reduction board: what each slice contributes to the sticky running minimum, published by whichever step reduces it first
+  std::mutex bmu;
+  std::condition_variable bcv;
+  std::map<int, double> res_below;
+  double base_resolution = std::numeric_limits<double>::max();   // the running minimum before this series (never reset, like the reference's)
+  // errors raised inside jobs surface at the next sync()
+  std::mutex emu;
+  int error_code = 0;
+  std::string error;
+  std::mutex rmu;                              // guards the tracker's result members while jobs write them
+
+  int dev_of(int t) const { return ((t - t_first) / block) % (int)w.size(); }
+
+  void run(worker *W)
+  {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(W->mu);
+        W->cv.wait(lk, [&] { return W->stop || !W->q.empty(); });
+        if (W->q.empty()) return;
+        f = std::move(W->q.front()); W->q.pop_front(); W->busy = true;
+      }
+      try { f(); }
+      catch (const ftkx_error &e) { std::lock_guard<std::mutex> g(emu); if (!error_code) { error_code = e.code; error = e.what(); } bcv.notify_all(); }
+      catch (const std::exception &e) { std::lock_guard<std::mutex> g(emu); if (!error_code) { error_code = FTKX_E_INVALID; error = e.what(); } bcv.notify_all(); }
+      { std::lock_guard<std::mutex> lk(W->mu); W->busy = false; }
+      W->cv.notify_all();
+    }
+  }
+  void post(int d, std::function<void()> f)
+  {
+    { std::lock_guard<std::mutex> lk(w[d]->mu); w[d]->q.push_back(std::move(f)); }
+    w[d]->cv.notify_all();
+  }
+  void wait(int d)
+  {
+    std::unique_lock<std::mutex> lk(w[d]->mu);
+    w[d]->cv.wait(lk, [&] { return w[d]->q.empty() && !w[d]->busy; });
+  }
+  void wait_all() { for (size_t d = 0; d < w.size(); d ++) wait((int)d); }
+  bool failed() { std::lock_guard<std::mutex> g(emu); return error_code != 0; }
+  void rethrow()
+  {
+    std::lock_guard<std::mutex> g(emu);
+    if (error_code) { const int c = error_code; const std::string m = error; error_code = 0; error.clear(); throw ftkx_error(c, m); }
+  }
+  // running minimum over what has been published of the slices BEFORE t (any subset of them bounds the factor from below)
+  double known_before(int t)
+  {
+    std::lock_guard<std::mutex> g(bmu);
+    double r = base_resolution;
+    for (const auto &kv : res_below) if (kv.first < t) r = std::min(r, kv.second);
+    return r;
+  }
+  void publish(const std::vector<int> &ts, const std::vector<double> &below)
+  {
+    {
+      std::lock_guard<std::mutex> g(bmu);
+      for (size_t i = 0; i < ts.size(); i ++) {
+        auto it = res_below.find(ts[i]);
+        if (it == res_below.end()) res_below[ts[i]] = below[i]; else it->second = std::min(it->second, below[i]);
+      }
+    }
+    bcv.notify_all();
+  }
+  // the reference's vector_field_resolution at the step whose last snapshot is t_last: needs every slice up to it
+  double wait_running_min(int t_last)
+  {
+    std::unique_lock<std::mutex> lk(bmu);
+    bcv.wait(lk, [&] {
+      if (failed()) return true;
+      for (int s = t_first; s <= t_last; s ++) if (!res_below.count(s)) return false;
+      return true;
+    });
+    double r = base_resolution;
+    for (int s = t_first; s <= t_last; s ++) { auto it = res_below.find(s); if (it != res_below.end()) r = std::min(r, it->second); }
+    return r;
+  }
+  ~multi_engine()
+  {
+    for (auto &W : w) { { std::lock_guard<std::mutex> lk(W->mu); W->stop = true; } W->cv.notify_all(); }
+    for (auto &W : w) if (W->th.joinable()) W->th.join();
+    for (auto &W : w) ftkx_destroy(W->ctx);
+  }
+};
+
+critical_point_tracker_regular::critical_point_tracker_regular(int nd_, const std::vector<int> &device_ids, int block) : nd(nd_)
+{
+  std::memset(&last_stats, 0, sizeof(last_stats));
+  if (device_ids.empty() || block < 1) throw ftkx_error(FTKX_E_INVALID, "critical_point_tracker_regular: need at least one device and block >= 1");
+  if (device_ids.size() == 1) {
+    const int rc = ftkx_create(&ctx, nd, device_ids[0]);
+    if (rc != FTKX_OK) { char buf[512]; ftkx_last_error(nullptr, buf, sizeof(buf)); throw ftkx_error(rc, buf); }
+    return;
+  }
+  multi.reset(new multi_engine());
+  multi->block = block;
+  for (int dev : device_ids) {
+    std::unique_ptr<multi_engine::worker> W(new multi_engine::worker());
+    const int rc = ftkx_create(&W->ctx, nd, dev);
+    if (rc != FTKX_OK) { char buf[512]; ftkx_last_error(nullptr, buf, sizeof(buf)); multi.reset(); throw ftkx_error(rc, buf); }
+    multi->w.push_back(std::move(W));
+  }
+  for (auto &W : multi->w) { multi_engine *e = multi.get(); multi_engine::worker *wp = W.get(); W->th = std::thread([e, wp] { e->run(wp); }); }
+  ctx = multi->w[0]->ctx;     // (context() of a multi-device tracker: its first device's)
+}
+
+critical_point_tracker_regular::~critical_point_tracker_regular()
+{
+  if (multi) multi.reset();   // joins the workers, destroys their contexts (ctx is one of them)
+  else ftkx_destroy(ctx);
+}
+
+void critical_point_tracker_regular::sync() const
+{
+  if (!multi) return;
+  multi->wait_all();
+  multi->rethrow();
+}
+
+int critical_point_tracker_regular::num_devices() const { return multi ? (int)multi->w.size() : 1; }
 
 void critical_point_tracker_regular::check(int rc) const
 {
@@ -30,18 +170,20 @@ void critical_point_tracker_regular::check(int rc) const
   throw ftkx_error(rc, buf);
 }
 
-void critical_point_tracker_regular::set_stream(void *s) { check(ftkx_set_stream(ctx, s)); }
+void critical_point_tracker_regular::set_stream(void *s)
+{
+  if (multi) throw ftkx_error(FTKX_E_UNSUPPORTED, "set_stream: a multi-device tracker runs each device on its context's own stream");
+  check(ftkx_set_stream(ctx, s));
+}
 
 // regular_tracker::initialize, regular_tracker.hh:105-149.  Single process per GPU: the partitioner returns the whole domain
 // (local_domain == domain) and, with is_input_array_partial == false, local_array_domain == array_domain.
-void critical_point_tracker_regular::initialize()
+void critical_point_tracker_regular::apply_configuration(ftkx_ctx *c)
 {
-  if ((int)domain.nd() != nd || (int)array_domain.nd() != nd) throw ftkx_error(FTKX_E_INVALID, "initialize: set_domain / set_array_domain first");
-  local_domain = domain;
-  local_array_domain = array_domain;
+  auto ck = [&](int rc) { if (rc != FTKX_OK) { char buf[512]; ftkx_last_error(c, buf, sizeof(buf)); throw ftkx_error(rc, buf); } };
   long long dst[3] = {0, 0, 0}, dsz[3] = {1, 1, 1}, est[3] = {0, 0, 0}, esz[3] = {1, 1, 1};
   for (int d = 0; d < nd; d ++) { dst[d] = domain.start(d); dsz[d] = domain.size(d); est[d] = array_domain.start(d); esz[d] = array_domain.size(d); }
-  check(ftkx_set_mesh(ctx, dst, dsz, dst, dsz, est, esz));
+  ck(ftkx_set_mesh(c, dst, dsz, dst, dsz, est, esz));
   ftkx_options o;
   ftkx_default_options(&o);
   o.jacobian_symmetric = is_jacobian_field_symmetric;
@@ -56,13 +198,22 @@ void critical_point_tracker_regular::initialize()
     if ((int)rectilinear_coords.size() < nd) throw ftkx_error(FTKX_E_INVALID, "initialize: set_coords_rectilinear needs one array per axis");
     const std::vector<double> none;
     const std::vector<double> &z = nd == 3 ? rectilinear_coords[2] : none;
-    check(ftkx_set_coords_rectilinear(ctx, rectilinear_coords[0].data(), rectilinear_coords[0].size(), rectilinear_coords[1].data(), rectilinear_coords[1].size(),
-                                      z.empty() ? nullptr : z.data(), z.size()));
+    ck(ftkx_set_coords_rectilinear(c, rectilinear_coords[0].data(), rectilinear_coords[0].size(), rectilinear_coords[1].data(), rectilinear_coords[1].size(),
+                                   z.empty() ? nullptr : z.data(), z.size()));
   } else if (mode_phys_coords == 3)
-    check(ftkx_set_coords_explicit(ctx, explicit_coords.data(), explicit_ncomp, explicit_n0, explicit_n1));
+    ck(ftkx_set_coords_explicit(c, explicit_coords.data(), explicit_ncomp, explicit_n0, explicit_n1));
   o.coords_mode = mode_phys_coords;
   for (size_t i = 0; i < 6 && i < bounds_coords.size(); i ++) o.coords_bounds[i] = bounds_coords[i];
-  check(ftkx_set_options(ctx, &o));
+  ck(ftkx_set_options(c, &o));
+}
+
+void critical_point_tracker_regular::initialize()
+{
+  if ((int)domain.nd() != nd || (int)array_domain.nd() != nd) throw ftkx_error(FTKX_E_INVALID, "initialize: set_domain / set_array_domain first");
+  local_domain = domain;
+  local_array_domain = array_domain;
+  if (multi) { sync(); for (auto &W : multi->w) apply_configuration(W->ctx); }
+  else apply_configuration(ctx);
   // the discrete points are kept in the reference's element order, which needs the mesh sizes
   element_order ord;
   ord.nd = nd;
@@ -77,18 +228,46 @@ void critical_point_tracker_regular::initialize()
 // Like the reference, the running resolution is NOT reset.
 void critical_point_tracker_regular::reset()
 {
+  sync();
+  if (multi) { multi->base_resolution = vector_field_resolution; multi->res_below.clear(); multi->t_first = -1; }
   current_timestep = 0;
   while (pop_field_data_snapshot()) {}
   next_push_timestep = 0;
   discrete_critical_points.clear();
 }
 
+// one snapshot -> the context(s) whose steps read it.  kind: 0 scalar (V derived), 1 vector, 2 all three given
+static int push_to(ftkx_ctx *c, int kind, int t, const double *s, const double *v, const double *j, int on_device)
+{
+  if (kind == 0) return ftkx_push_scalar_slice(c, t, s, on_device);
+  if (kind == 1) return ftkx_push_slice(c, t, v, nullptr, nullptr, on_device);
+  return ftkx_push_slice(c, t, v, j, s, on_device);
+}
+
+void critical_point_tracker_regular::push_everywhere(int kind, int t, const double *s, const double *v, const double *j, bool device)
+{
+  auto fail = [](ftkx_ctx *c, int rc) { char buf[512]; ftkx_last_error(c, buf, sizeof(buf)); throw ftkx_error(rc, buf); };
+  if (!multi) { const int rc = push_to(ctx, kind, t, s, v, j, device ? 1 : 0); if (rc) fail(ctx, rc); return; }
+  if (multi->t_first < 0) multi->t_first = t;
+  std::set<int> targets;
+  targets.insert(multi->dev_of(t));
+  if (t > multi->t_first) targets.insert(multi->dev_of(t - 1));        // the interval sweep [t-1, t] of the previous block reads it too
+  // device memory is COPIED into each context (a peer copy where the devices differ): the caller's buffer is free again on return
+  for (int d : targets) {
+    ftkx_ctx *c = multi->w[d]->ctx;
+    multi->post(d, [=] { const int rc = push_to(c, kind, t, s, v, j, device ? 2 : 0); if (rc) { char buf[512]; ftkx_last_error(c, buf, sizeof(buf)); throw ftkx_error(rc, buf); } });
+  }
+  for (int d : targets) multi->wait(d);
+  multi->rethrow();
+  multi->resident[t] = targets;
+}
+
 void critical_point_tracker_regular::push_scalar_field_snapshot(const double *s, bool device)
 {
   if (!initialized) throw ftkx_error(FTKX_E_INVALID, "push: initialize() first");
+  if (vector_field_source != SOURCE_DERIVED) throw ftkx_error(FTKX_E_INVALID, "push_scalar_field_snapshot: vector_field_source must be SOURCE_DERIVED");
   const int t = next_push_timestep;
-  if (vector_field_source == SOURCE_DERIVED) check(ftkx_push_scalar_slice(ctx, t, s, device));   // V = gradientND(s) on the device
-  else throw ftkx_error(FTKX_E_INVALID, "push_scalar_field_snapshot: vector_field_source must be SOURCE_DERIVED");
+  push_everywhere(0, t, s, nullptr, nullptr, device);       // V = gradientND(s) on the device
   field_data_snapshots.push_back(t);
   next_push_timestep ++;
 }
@@ -97,7 +276,7 @@ void critical_point_tracker_regular::push_vector_field_snapshot(const double *v,
 {
   if (!initialized) throw ftkx_error(FTKX_E_INVALID, "push: initialize() first");
   const int t = next_push_timestep;
-  check(ftkx_push_slice(ctx, t, v, nullptr, nullptr, device));   // J derived at hits when jacobian_field_source == SOURCE_DERIVED
+  push_everywhere(1, t, nullptr, v, nullptr, device);       // J derived at hits when jacobian_field_source == SOURCE_DERIVED
   field_data_snapshots.push_back(t);
   next_push_timestep ++;
 }
@@ -106,7 +285,7 @@ void critical_point_tracker_regular::push_field_data_snapshot(const double *s, c
 {
   if (!initialized) throw ftkx_error(FTKX_E_INVALID, "push: initialize() first");
   const int t = next_push_timestep;
-  check(ftkx_push_slice(ctx, t, v, j, s, device));
+  push_everywhere(2, t, s, v, j, device);
   field_data_snapshots.push_back(t);
   next_push_timestep ++;
 }
@@ -114,7 +293,14 @@ void critical_point_tracker_regular::push_field_data_snapshot(const double *s, c
 bool critical_point_tracker_regular::pop_field_data_snapshot()
 {
   if (field_data_snapshots.empty()) return false;
-  check(ftkx_drop_slice(ctx, field_data_snapshots.front()));
+  const int t = field_data_snapshots.front();
+  if (multi) {
+    for (int d : multi->resident[t]) {           // queued behind the steps that still read the slice
+      ftkx_ctx *c = multi->w[d]->ctx;
+      multi->post(d, [=] { const int rc = ftkx_drop_slice(c, t); if (rc) { char buf[512]; ftkx_last_error(c, buf, sizeof(buf)); throw ftkx_error(rc, buf); } });
+    }
+    multi->resident.erase(t);
+  } else check(ftkx_drop_slice(ctx, t));
   field_data_snapshots.erase(field_data_snapshots.begin());
   return true;
 }
@@ -139,14 +325,8 @@ void critical_point_tracker_regular::update_vector_field_scaling_factor(int minb
 
 // critical_point_tracker_{2d,3d}_regular::update_timestep (2d:263-433, 3d:150-308): ordinal sweep at current_timestep and,
 // when two snapshots are queued, the interval sweep [current, current+1] -- here one launch, one download.
-void critical_point_tracker_regular::update_timestep()
+void critical_point_tracker_regular::take_records(const ftkx_cp_t *recs, size_t n, int timestep)
 {
-  if (field_data_snapshots.empty()) return;
-  update_vector_field_scaling_factor();
-  const int scope = field_data_snapshots.size() >= 2 ? FTKX_SCOPE_BOTH : FTKX_SCOPE_ORDINAL;
-  const ftkx_cp_t *recs = nullptr;
-  size_t n = 0;
-  check(ftkx_sweep(ctx, current_timestep, scope, vector_field_scaling_factor, &recs, &n));
   for (size_t i = 0; i < n; i ++) {
     feature_point_t cp;
     for (int k = 0; k < 3; k ++) { cp.x[k] = recs[i].x[k]; cp.scalar[k] = recs[i].scalar[k]; }
@@ -154,11 +334,54 @@ void critical_point_tracker_regular::update_timestep()
     cp.type = recs[i].type;
     cp.tag = recs[i].tag;
     cp.ordinal = ftkx_cp_ordinal(&recs[i]) != 0;
-    cp.timestep = current_timestep;
+    cp.timestep = timestep;
     if (scalar_field_source == SOURCE_NONE) cp.scalar[0] = 0.0;   // 2d:642-646: scalar only when a scalar field exists
     discrete_critical_points[cp.tag] = cp;
   }
-  check(ftkx_get_stats(ctx, &last_stats));
+}
+
+void critical_point_tracker_regular::update_timestep()
+{
+  if (field_data_snapshots.empty()) return;
+  const int scope = field_data_snapshots.size() >= 2 ? FTKX_SCOPE_BOTH : FTKX_SCOPE_ORDINAL;
+  if (!multi) {
+    update_vector_field_scaling_factor();
+    const ftkx_cp_t *recs = nullptr;
+    size_t n = 0;
+    check(ftkx_sweep(ctx, current_timestep, scope, vector_field_scaling_factor, &recs, &n));
+    take_records(recs, n, current_timestep);
+    check(ftkx_get_stats(ctx, &last_stats));
+    return;
+  }
+  // Several devices: the step is queued on the device that owns its timestep and this call returns.  Inside the job: reduce
+  // (and mask) the step's slices under the factor known so far, publish their contribution, wait for the contributions of ALL
+  // earlier slices -- other devices publish theirs before they sweep, so this is a wait for reductions only -- and sweep under
+  // the factor the reference would have at this step.
+  multi->rethrow();
+  const int t = current_timestep, d = multi->dev_of(t);
+  multi_engine *e = multi.get();
+  ftkx_ctx *c = e->w[d]->ctx;
+  std::vector<int> ts(field_data_snapshots.begin(), field_data_snapshots.begin() + (scope == FTKX_SCOPE_BOTH ? 2 : 1));
+  e->post(d, [this, e, c, t, scope, ts] {
+    auto ck = [&](int rc) { if (rc != FTKX_OK) { char buf[512]; ftkx_last_error(c, buf, sizeof(buf)); throw ftkx_error(rc, buf); } };
+    const int minbits = 8, maxbits = 21;
+    auto factor_of = [&](double res) { int nb = (int)std::ceil(std::log2(1.0 / res)); nb = std::max(minbits, std::min(nb, maxbits)); return 1ull << nb; };
+    std::vector<double> below(ts.size());
+    ck(ftkx_slices_prepare(c, ts.data(), (int)ts.size(), factor_of(e->known_before(t)), below.data(), nullptr));
+    e->publish(ts, below);
+    const double res = e->wait_running_min(ts.back());
+    if (e->failed()) return;                    // another step failed: do not sweep with a partial minimum
+    const unsigned long long factor = factor_of(res);
+    const ftkx_cp_t *recs = nullptr;
+    size_t n = 0;
+    ck(ftkx_sweep(c, t, scope, factor, &recs, &n));
+    ftkx_stats st;
+    ck(ftkx_get_stats(c, &st));
+    std::lock_guard<std::mutex> g(e->rmu);
+    take_records(recs, n, t);
+    // steps finish out of order: the members keep the values of the LATEST timestep, as a sequential run would leave them
+    if (t >= result_timestep) { result_timestep = t; last_stats = st; vector_field_scaling_factor = factor; vector_field_resolution = res; }
+  });
 }
 
 // critical_point_tracker::advance_timestep, critical_point_tracker.hh:841-848
@@ -174,6 +397,7 @@ bool critical_point_tracker_regular::advance_timestep()
 // traced_critical_points = trace_critical_points_offline(discrete_critical_points, neighbours-sharing-a-cell)
 void critical_point_tracker_regular::finalize()
 {
+  sync();
   std::vector<ftkx_cp_t> recs;
   std::vector<const feature_point_t *> pts;
   recs.reserve(discrete_critical_points.size());
@@ -266,6 +490,7 @@ void critical_point_tracker_regular::post_process()
 
 void critical_point_tracker_regular::write_discrete(const std::string &filename, int format) const
 {
+  sync();
   std::vector<ftkx_cp_t> recs;
   recs.reserve(discrete_critical_points.size());
   for (const auto &kv : discrete_critical_points) recs.push_back(record_of(kv.second));
@@ -280,6 +505,7 @@ void critical_point_tracker_regular::write_critical_points_text(const std::strin
 // critical_point_tracker_regular::put_critical_points (critical_point_tracker_regular.hh:40-46): tags are trusted as keys
 void critical_point_tracker_regular::put_critical_points(const std::vector<feature_point_t> &cps)
 {
+  sync();
   for (const auto &cp : cps) discrete_critical_points[cp.tag] = cp;
 }
 
@@ -319,6 +545,7 @@ void critical_point_tracker_regular::write_traced_critical_points_text(const std
 
 std::vector<feature_point_t> critical_point_tracker_regular::get_critical_points() const
 {
+  sync();
   std::vector<feature_point_t> r;
   r.reserve(discrete_critical_points.size());
   for (const auto &kv : discrete_critical_points) r.push_back(kv.second);
@@ -361,6 +588,21 @@ int ftkx_tracker_create(ftkx_tracker **out, int nd, int device_id)
   } catch (const ftkx::ftkx_error &e) { delete h; g_tracker_error = e.what(); return e.code; }
   catch (const std::exception &e) { delete h; g_tracker_error = e.what(); return FTKX_E_INVALID; }
 }
+
+int ftkx_tracker_create_multi(ftkx_tracker **out, int nd, const int *device_ids, int ndev, int block)
+{
+  if (!out || (nd != 2 && nd != 3) || !device_ids || ndev < 1) { g_tracker_error = "ftkx_tracker_create_multi: bad arguments"; return FTKX_E_INVALID; }
+  ftkx_tracker *h = new ftkx_tracker();
+  try {
+    h->nd = nd;
+    h->t = new ftkx::critical_point_tracker_regular(nd, std::vector<int>(device_ids, device_ids + ndev), block);
+    *out = h;
+    return FTKX_OK;
+  } catch (const ftkx::ftkx_error &e) { delete h; g_tracker_error = e.what(); return e.code; }
+  catch (const std::exception &e) { delete h; g_tracker_error = e.what(); return FTKX_E_INVALID; }
+}
+
+int ftkx_tracker_sync(ftkx_tracker *h) { return guarded(h, [&] { h->t->sync(); }); }
 
 void ftkx_tracker_destroy(ftkx_tracker *h) { if (h) { delete h->t; delete h; } }
 

@@ -17,6 +17,7 @@
 #include <cstddef>
 #include <limits>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -81,6 +82,14 @@ struct ftkx_error : public std::runtime_error {
 class critical_point_tracker_regular {
 public:
   critical_point_tracker_regular(int nd /*2|3*/, int device_id = 0);
+  // Several GPUs behind ONE tracker (the reference keeps a device list on the filter, filter.hh:47-61, and partitions inside the
+  // tracker, regular_tracker.hh:127-149): timesteps are dealt to the devices in blocks of `block` consecutive steps, a snapshot
+  // goes to the device(s) whose steps read it (the first slice of a block also to the previous block's device: the t-slab halo),
+  // every device has its own context and host thread, update_timestep() only queues the step -- the devices sweep different
+  // timesteps at the same time -- and the getters / finalize() wait for the queues.  The quantisation factor stays the
+  // reference's sequential sticky minimum: each step waits for the reductions of all earlier slices (computed on whichever
+  // device holds them), never for their sweeps.  A device may be listed more than once (tests on a one-GPU box).
+  critical_point_tracker_regular(int nd, const std::vector<int> &device_ids, int block = 2);
   virtual ~critical_point_tracker_regular();
   critical_point_tracker_regular(const critical_point_tracker_regular &) = delete;
   critical_point_tracker_regular &operator=(const critical_point_tracker_regular &) = delete;
@@ -145,11 +154,13 @@ public:
   void write_traced_critical_points_text(const std::string &filename) const;
 
   std::vector<feature_point_t> get_critical_points() const; // critical_point_tracker_regular.hh:32-38 (sorted by element)
-  const discrete_map_t &get_discrete_critical_points() const { return discrete_critical_points; }
+  const discrete_map_t &get_discrete_critical_points() const { sync(); return discrete_critical_points; }
 
-  unsigned long long get_vector_field_scaling_factor() const { return vector_field_scaling_factor; }
-  double get_vector_field_resolution() const { return vector_field_resolution; }
-  ftkx_stats get_last_stats() const { return last_stats; }
+  void sync() const;                                        // multi-device: wait for every queued step (no-op with one device)
+  int num_devices() const;
+  unsigned long long get_vector_field_scaling_factor() const { sync(); return vector_field_scaling_factor; }
+  double get_vector_field_resolution() const { sync(); return vector_field_resolution; }
+  ftkx_stats get_last_stats() const { sync(); return last_stats; }
   ftkx_ctx *context() { return ctx; }
 
 protected:
@@ -175,6 +186,7 @@ protected:
   bool initialized = false;
 
   int current_timestep = 0;
+  int result_timestep = -1;                                 // multi-device: the timestep last_stats / the scaling factor belong to
   std::vector<int> field_data_snapshots;                    // timesteps resident on the device (<= 2, a deque in the reference)
   int next_push_timestep = 0;
   double vector_field_resolution = std::numeric_limits<double>::max();   // sticky running minimum (never reset)
@@ -184,6 +196,11 @@ protected:
   std::vector<int> traced_loop, traced_id;
   ftkx_stats last_stats;
 
+  struct multi_engine;                                        // per-device contexts + worker threads (tracker.cpp); null with one device
+  std::unique_ptr<multi_engine> multi;
+  void apply_configuration(ftkx_ctx *c);                      // mesh, options, coordinates of initialize() on one context
+  void take_records(const ftkx_cp_t *recs, size_t n, int timestep);
+  void push_everywhere(int kind, int t, const double *s, const double *v, const double *j, bool device);   // one snapshot -> the context(s) that read it
   void write_discrete(const std::string &filename, int format) const;
   void read_discrete(const std::string &filename, int format);
   void write_traced(const std::string &filename, int format) const;
@@ -202,6 +219,9 @@ struct critical_point_tracker_3d_regular : public critical_point_tracker_regular
 extern "C" {
 typedef struct ftkx_tracker ftkx_tracker;
 int  ftkx_tracker_create(ftkx_tracker **out, int nd, int device_id);
+/* one tracker over several devices (see the C++ constructor above); block = consecutive timesteps per device (>= 1) */
+int  ftkx_tracker_create_multi(ftkx_tracker **out, int nd, const int *device_ids, int ndev, int block);
+int  ftkx_tracker_sync(ftkx_tracker *);
 void ftkx_tracker_destroy(ftkx_tracker *);
 int  ftkx_tracker_last_error(const ftkx_tracker *, char *buf, size_t n);
 int  ftkx_tracker_set_domain(ftkx_tracker *, const long long *starts, const long long *sizes);

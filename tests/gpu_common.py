@@ -6,11 +6,12 @@ import ftk_amd
 
 
 def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=False, tag_mode=ftk_amd.TAG_REFERENCE, device=False,
-                compute_degrees=False, bounds=None, want_curves=False, after=None, rectilinear=None, explicit=None, t0=0):
+                compute_degrees=False, bounds=None, want_curves=False, after=None, rectilinear=None, explicit=None, t0=0, device_ids=None, block=2,
+                factor_each_step=True):
     """returns (records, ordinal, timestep, factors[DT], stats_list)"""
     import torch
     T = ftk_amd.CriticalPointTracker2DRegular if nd == 2 else ftk_amd.CriticalPointTracker3DRegular
-    tr = T()
+    tr = T(device_ids=device_ids, block=block) if device_ids else T()
     shp = steps[0].shape[:nd]
     D = [shp[nd - 1 - d] for d in range(nd)]
     if nv == 1:   # json_interface.hh:634-645
@@ -48,7 +49,10 @@ def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=Fals
             torch.cuda.synchronize()
         (tr.push_scalar_field_snapshot if nv == 1 else tr.push_vector_field_snapshot)(a)
         if k != 0:
-            tr.advance_timestep(); factors[cur] = tr.get_vector_field_scaling_factor(); stats.append(tr.get_last_stats()); cur += 1
+            tr.advance_timestep()
+            if factor_each_step:      # (reading the factor waits for the queued steps of a multi-device tracker)
+                factors[cur] = tr.get_vector_field_scaling_factor(); stats.append(tr.get_last_stats())
+            cur += 1
         if k == DT - 1:
             tr.update_timestep(); factors[cur] = tr.get_vector_field_scaling_factor(); stats.append(tr.get_last_stats())
     recs, o, ts = tr.get_critical_points()

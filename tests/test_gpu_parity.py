@@ -311,3 +311,21 @@ def test_empty_and_minimal_inputs(gpu, oracle, nd):
             if len(ref):
                 assert np.array_equal(np.sort(got["tag"]), np.sort(ref["tag"]))
                 assert np.array_equal(gfac, rfac)
+
+
+@pytest.mark.parametrize("name", ["woven_31x37x32", "moving_extremum_3d_21x21x21x32", "merger_2d_32x32x100", "double_gyre_64x32x50",
+                                  "random_3d_scalar_13x12x11x4", "moving_extremum_3d_21x21x21x4_overflow"])
+@pytest.mark.parametrize("ndev,block", [(2, 1), (2, 3), (3, 2), (4, 1)])
+def test_multi_device_tracker_matches_reference_fixture(gpu, name, ndev, block):
+    """ONE tracker over several devices (here the same GPU listed ndev times: own context, stream and host thread each): timesteps
+    dealt in blocks, steps queued and swept concurrently, the sticky factor formed from reductions published across devices.
+    Records and final factor identical to the reference's sequential run; with a sync after every step also the factor sequence."""
+    from gpu_common import run_tracker
+    g = load_golden(name)
+    recs, factors, _ = run_tracker(g["steps"], g["nd"], g["nv"], device_ids=[0] * ndev, block=block, factor_each_step=False)
+    assert factors[g["DT"] - 1] == g["factors"][g["DT"] - 1]
+    assert_records_equal(recs, g["records"], coord_tol=0.0, what=f"{name} on {ndev} devices, block {block}")
+    if ndev == 2:
+        recs, factors, _ = run_tracker(g["steps"], g["nd"], g["nv"], device_ids=[0] * ndev, block=block, device=True, want_curves=False)
+        assert np.array_equal(factors, g["factors"])
+        assert_records_equal(recs, g["records"], coord_tol=0.0, what=name)
