@@ -25,7 +25,8 @@ void launch_tile(const TileParams &p, hipStream_t stream);
 void tile_dims(int nd, int tile[3]);
 void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream);
 void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream);
-void launch_exact(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, hipStream_t stream);
+void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64 *d_list, u64 cap, hipStream_t stream);
+void launch_records(const Mesh &m, const Fields *d_fields, hipStream_t stream);
 bool masks_have_summary(const Mesh &m);
 bool march2_supported(const Mesh &m);
 bool masks_fuse_reduction(const Mesh &m);
@@ -85,6 +86,7 @@ struct ftkx_ctx {
   int scalar_mode = -1;             // -1 undecided, 0 vector slices, 1 scalar slices (V = gradient(S) evaluated in flight)
   std::map<int, Slice> slices;
   ftkx_cp_t *d_hits = nullptr;
+  u64 *d_pass = nullptr;            // simplices that passed the integer test, awaiting the record kernel (same capacity)
   u64 capacity = 0;
   u64 *d_list = nullptr;            // surviving corners of the fast path
   u64 list_capacity = 0;
@@ -181,7 +183,9 @@ int ensure_hit_buffer(ftkx_ctx *c, u64 want)
 {
   if (c->capacity >= want) return FTKX_OK;
   if (c->d_hits) { HIP_TRY(c, hipFree(c->d_hits)); c->d_hits = nullptr; c->capacity = 0; }
+  if (c->d_pass) { HIP_TRY(c, hipFree(c->d_pass)); c->d_pass = nullptr; }
   HIP_TRY(c, hipMalloc((void **)&c->d_hits, want * sizeof(ftkx_cp_t)));
+  HIP_TRY(c, hipMalloc((void **)&c->d_pass, want * sizeof(u64)));
   c->capacity = want;
   return FTKX_OK;
 }
@@ -256,7 +260,7 @@ void fill_mesh(const ftkx_ctx *c, Mesh &m)
   for (int i = 0; i < 6; i ++) m.coords_bounds[i] = c->opt.coords_bounds[i];
   for (int d = 0; d < 3; d ++) m.coords_rect[d] = c->d_rect[d];
   m.coords_expl = c->d_expl; m.coords_expl_ncomp = c->expl_ncomp; m.coords_expl_n0 = (int)c->expl_n0;
-  m.hits = c->d_hits; m.counters = c->d_counters; m.capacity = c->capacity;
+  m.hits = c->d_hits; m.pass = c->d_pass; m.counters = c->d_counters; m.capacity = c->capacity;
 }
 
 int slice_resolution(ftkx_ctx *c, Slice &s)
@@ -455,35 +459,43 @@ int run_batch(ftkx_ctx *c)
       subs.back().steps.push_back(f);
     } else {
       TileParams p;
-      p.m = m; p.f = f; p.cull = r.mode == MODE_TILE_CULL ? 1 : 0;
+      p.m = m; p.f = f; p.cull = r.mode == MODE_TILE_CULL ? 1 : 0; p.step = 0;
       int tile[3];
       ftkx::tile_dims(nd, tile);
       for (int d = 0; d < 3; d ++) p.ntiles[d] = d < nd ? (int)((c->core_sz[d] + tile[d] - 1) / tile[d]) : 1;
       tiles.push_back(p);
     }
   }
-  // one upload for all descriptors
+  // one upload for all descriptors: the mask jobs of each sub-batch, then ONE array of Fields for the whole batch -- the steps of
+  // sub-batch 0, 1, ... back to back (each cull / exact launch gets its slice of it) and the tile requests behind them; the
+  // record kernel looks a simplex's request up in that array by the index its pass descriptor carries
   size_t total = 0;
-  std::vector<std::pair<size_t, size_t>> offs;   // (jobs offset, steps offset) per sub-batch
-  for (const Sub &sb : subs) {
-    const size_t oj = total; total += (sb.jobs.size() * sizeof(MaskJob) + 255) / 256 * 256;
-    const size_t os = total; total += (sb.steps.size() * sizeof(Fields) + 255) / 256 * 256;
-    offs.push_back({oj, os});
-  }
+  std::vector<size_t> job_off, step_base;
+  for (const Sub &sb : subs) { job_off.push_back(total); total += (sb.jobs.size() * sizeof(MaskJob) + 255) / 256 * 256; }
+  const size_t fields_off = total;
+  size_t nfields = 0;
+  for (const Sub &sb : subs) { step_base.push_back(nfields); nfields += sb.steps.size(); }
+  const size_t tile_base = nfields;
+  nfields += tiles.size();
+  total += (nfields * sizeof(Fields) + 255) / 256 * 256;
+  if ((nfields >> (64 - ftkx::kPassStepShift)) != 0) return fail(c, FTKX_E_INVALID, "sweep: too many requests in one batch (%zu)", nfields);
   if (total) {
     int rc = ensure_desc(c, total);
     if (rc) return rc;
+    Fields *hf = (Fields *)((char *)c->h_desc + fields_off);
     for (size_t i = 0; i < subs.size(); i ++) {
-      if (!subs[i].jobs.empty()) memcpy((char *)c->h_desc + offs[i].first, subs[i].jobs.data(), subs[i].jobs.size() * sizeof(MaskJob));
-      if (!subs[i].steps.empty()) memcpy((char *)c->h_desc + offs[i].second, subs[i].steps.data(), subs[i].steps.size() * sizeof(Fields));
+      if (!subs[i].jobs.empty()) memcpy((char *)c->h_desc + job_off[i], subs[i].jobs.data(), subs[i].jobs.size() * sizeof(MaskJob));
+      if (!subs[i].steps.empty()) memcpy(hf + step_base[i], subs[i].steps.data(), subs[i].steps.size() * sizeof(Fields));
     }
+    for (size_t i = 0; i < tiles.size(); i ++) { hf[tile_base + i] = tiles[i].f; tiles[i].step = (int)(tile_base + i); }
     HIP_TRY(c, hipMemcpyAsync(c->d_desc, c->h_desc, total, hipMemcpyHostToDevice, c->stream));
   }
+  const Fields *d_fields = (const Fields *)((char *)c->d_desc + fields_off);
   for (size_t i = 0; i < subs.size(); i ++) {
     const Sub &sb = subs[i];
     if (sb.steps.empty()) continue;
-    const MaskJob *d_jobs = (const MaskJob *)((char *)c->d_desc + offs[i].first);
-    const Fields *d_steps = (const Fields *)((char *)c->d_desc + offs[i].second);
+    const MaskJob *d_jobs = (const MaskJob *)((char *)c->d_desc + job_off[i]);
+    const Fields *d_steps = d_fields + step_base[i];
     if (!sb.jobs.empty()) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs, (int)sb.jobs.size(), c->stream); ev_end(c); }
     // the survivor list is shared by the sub-batches of one collect: the exact kernel of sub-batch i must not re-test the
     // survivors of sub-batch i-1, so each sub-batch gets its own list segment by resetting the list counter in between
@@ -495,9 +507,11 @@ int run_batch(ftkx_ctx *c)
     if (two_level) ftkx::launch_cull_two_level(m, d_steps, (int)sb.steps.size(), c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
     else ftkx::launch_cull(m, d_steps, (int)sb.steps.size(), c->d_list, c->list_capacity, c->stream);
     ev_end(c);
-    ev_begin(c, K_EXACT); ftkx::launch_exact(m, d_steps, c->d_list, c->list_capacity, c->stream); ev_end(c);
+    ev_begin(c, K_EXACT); ftkx::launch_exact(m, d_steps, (int)step_base[i], c->d_list, c->list_capacity, c->stream); ev_end(c);
   }
   for (const TileParams &p : tiles) { ev_begin(c, K_TILE); ftkx::launch_tile(p, c->stream); ev_end(c); }
+  // the FP64 half, once for the whole batch: records of every simplex that passed (timed with the kernel family that fed it)
+  if (nfields) { ev_begin(c, tiles.empty() ? K_EXACT : K_TILE); ftkx::launch_records(m, d_fields, c->stream); ev_end(c); }
   HIP_TRY(c, hipGetLastError());
   return FTKX_OK;
 }
@@ -570,6 +584,7 @@ void ftkx_destroy(ftkx_ctx *c)
   release_pools(c);
   if (c->d_red) (void)hipFree(c->d_red);
   if (c->d_hits) (void)hipFree(c->d_hits);
+  if (c->d_pass) (void)hipFree(c->d_pass);
   if (c->d_list) (void)hipFree(c->d_list);
   if (c->d_refine) (void)hipFree(c->d_refine);
   if (c->d_sorted) (void)hipFree(c->d_sorted);
@@ -967,7 +982,9 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
     if ((rc = run_batch(c))) { c->pending.clear(); return rc; }
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, ftkx::CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const u64 hits = c->h_counters[ftkx::CNT_HITS], listed = c->h_counters[ftkx::CNT_LIST_PEAK], refined = c->h_counters[ftkx::CNT_REFINE_PEAK];
+    // (records <= simplices that passed: the 2D type filter may drop some; the pass list shares the hit buffer's capacity)
+    const u64 hits = std::max(c->h_counters[ftkx::CNT_HITS], c->h_counters[ftkx::CNT_PASS]);
+    const u64 listed = c->h_counters[ftkx::CNT_LIST_PEAK], refined = c->h_counters[ftkx::CNT_REFINE_PEAK];
     if (hits <= c->capacity && listed <= c->list_capacity && refined <= c->refine_capacity) { ev_harvest(c); break; }
     // a buffer was too small (records / survivors beyond capacity were only counted): grow to what this batch needs, replay it
     for (auto &e : c->events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }

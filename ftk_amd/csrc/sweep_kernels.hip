@@ -346,18 +346,6 @@ __device__ inline bool simplex_inside(const Mesh &m, const Fields &f, int cull, 
   else return origin_in_simplex3(X, ids);
 }
 
-template <int ND>
-__device__ inline bool test_simplex(const Mesh &m, const Fields &f, int cull, const int *corner, int type, unsigned tab,
-                                    const unsigned char *flags, const u64 (*X)[ND], unsigned &tested, ftkx_cp_t *rec)
-{
-  constexpr int N = ND + 1;
-  int ids[N];
-  double mu[N];
-  bool presolved;
-  if (!simplex_inside<ND>(m, f, cull, corner, tab, flags, X, tested, ids, mu, &presolved)) return false;
-  return make_record<ND>(m, f, corner, type, X, ids, presolved, mu, rec);
-}
-
 // hits of one wavefront appended with a single atomic (must be reached by all 64 lanes)
 __device__ inline void emit_hits(const Mesh &m, bool hit, const ftkx_cp_t &rec)
 {
@@ -371,6 +359,22 @@ __device__ inline void emit_hits(const Mesh &m, bool hit, const ftkx_cp_t &rec)
   if (hit) {
     const u64 slot = slot0 + (u64)__popcll(hb & ((1ull << lane) - 1ull));
     if (slot < m.capacity) m.hits[slot] = rec;
+  }
+}
+
+// simplices that passed the test: appended for record_kernel with a single atomic per wavefront (must be reached by all 64 lanes)
+__device__ inline void emit_pass(const Mesh &m, bool hit, u64 desc)
+{
+  const unsigned long long hb = __ballot(hit);
+  if (!hb) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)hb) - 1;
+  u64 slot0 = 0;
+  if (lane == leader) slot0 = atomicAdd(&m.counters[CNT_PASS], (u64)__popcll(hb));
+  slot0 = __shfl(slot0, leader);
+  if (hit) {
+    const u64 slot = slot0 + (u64)__popcll(hb & ((1ull << lane) - 1ull));
+    if (slot < m.capacity) m.pass[slot] = desc;
   }
 }
 
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(kThreads) void tile_kernel(const TileParams p)
   for (unsigned base = 0; base < total; base += kThreads) {   // wave-uniform trip count: the ballot in emit_hits stays convergent
     const unsigned w = base + tid;
     bool hit = false;
-    ftkx_cp_t rec;
+    u64 desc = 0;
     if (w < total) {
       const bool ordinal = w < items_o;
       const unsigned wl = ordinal ? w : w - items_o;
@@ -493,9 +497,11 @@ __global__ __launch_bounds__(kThreads) void tile_kernel(const TileParams p)
       corner[0] = origin[0] + ccx; corner[1] = origin[1] + ccy;
       if (ND == 3) corner[2] = origin[2] + ccz;
       corner[ND] = f.t;
-      hit = test_simplex<ND>(m, f, p.cull, corner, type, tab, flags, X, tested, &rec);
+      int ids[N]; double mu[N]; bool presolved;
+      hit = simplex_inside<ND>(m, f, p.cull, corner, tab, flags, X, tested, ids, mu, &presolved);
+      desc = core_linear<ND>(m, corner) | ((u64)type << kPassTypeShift) | ((u64)p.step << kPassStepShift);
     }
-    emit_hits(m, hit, rec);
+    emit_pass(m, hit, desc);
   }
   {
     unsigned t_sum = tested;
@@ -1515,7 +1521,7 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(const Mesh m, const Me
 // FAST PATH 3/3: exact test of the surviving corners
 // ---------------------------------------------------------------------------------------------------------------
 template <int ND>
-__global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fields *__restrict__ steps, const u64 *__restrict__ list, u64 list_capacity)
+__global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fields *__restrict__ steps, int step_base, const u64 *__restrict__ list, u64 list_capacity)
 {
   constexpr int N = ND + 1;
   constexpr int NVC = 1 << N;                 // vertices of a corner's space-time hypercube
@@ -1527,6 +1533,7 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
   __shared__ unsigned s_tab[NTYPES];
   __shared__ unsigned short s_pass[G * NTYPES];   // (corner, type) pairs that passed the predicate
   __shared__ unsigned s_npass;
+  __shared__ u64 s_base;
 
   const int tid = threadIdx.x;
   const fan_table<N> &fan = dev_fan<ND>();
@@ -1594,37 +1601,67 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
       }
     }
     __syncthreads();
+    // the few that passed go to record_kernel: one atomic per chunk
     const unsigned npass = s_npass;
-    for (unsigned base = 0; base < npass; base += kThreads) {   // uniform trip count (emit_hits ballots)
-      const unsigned h = base + tid;
-      bool hit = false;
-      ftkx_cp_t rec;
-      if (h < npass) {
+    if (npass) {
+      if (tid == 0) s_base = atomicAdd(&m.counters[CNT_PASS], (u64)npass);
+      __syncthreads();
+      for (unsigned h = tid; h < npass; h += kThreads) {
         const int w = s_pass[h];
         const int gi = w / NTYPES, type = w % NTYPES;
         const u64 e = s_entry[gi];
-        const Fields &f = steps[e >> 44];
-        u64 lin = e & 0xffffffffffull;
-        int corner[N];
-        for (int d = 0; d < ND; d ++) { corner[d] = m.core_st[d] + (int)(lin % (u64)m.core_sz[d]); lin /= (u64)m.core_sz[d]; }
-        corner[ND] = f.t;
-        const unsigned tab = s_tab[type];
-        u64 X[N][ND];
-        int ids[N];
-        for (int i = 0; i < N; i ++) {
-          const unsigned vm = (tab >> (8 * i)) & 0xffu;
-          for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[gi][vm][c];
-          ids[i] = vertex_id<ND>(m, corner, vm);
-        }
-        hit = make_record<ND>(m, f, corner, type, X, ids, false, nullptr, &rec);
+        const u64 slot = s_base + h;
+        if (slot < m.capacity) m.pass[slot] = (e & kPassLinMask) | ((u64)type << kPassTypeShift) | ((u64)(step_base + (int)(e >> 44)) << kPassStepShift);
       }
-      emit_hits(m, hit, rec);
     }
   }
   {
     unsigned t_sum = tested;
     for (int o = 32; o > 0; o >>= 1) t_sum += __shfl_down(t_sum, o);
     if ((tid & 63) == 0 && t_sum) atomicAdd(&m.counters[CNT_SIMPLICES_TESTED], (u64)t_sum);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The FP64 half of the sweep: one lane per simplex that passed the integer test (CNT_PASS descriptors written by exact_kernel /
+// tile_kernel).  Re-quantises the simplex's d+1 vertices (a handful of loads), then inverse interpolation, lerps, Jacobian and
+// classification exactly as check_simplex does after its test (2d:624-684, 3d:468-512), and the ballot-compacted append.
+// Keeping this out of the integer kernels takes their scratch from 800-944 bytes per lane to none.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ __launch_bounds__(kThreads) void record_kernel(const Mesh m, const Fields *__restrict__ fields)
+{
+  constexpr int N = ND + 1;
+  const fan_table<N> &fan = dev_fan<ND>();
+  u64 count = m.counters[CNT_PASS];
+  if (count > m.capacity) count = m.capacity;               // overflow: the host grows the buffers and replays the batch
+  const u64 padded = (count + 63) / 64 * 64;                // wave-uniform trip count: emit_hits ballots
+  for (u64 i = (u64)blockIdx.x * kThreads + threadIdx.x; i < padded; i += (u64)gridDim.x * kThreads) {
+    bool hit = false;
+    ftkx_cp_t rec;
+    if (i < count) {
+      const u64 d = m.pass[i];
+      const Fields &f = fields[d >> kPassStepShift];
+      const int type = (int)((d >> kPassTypeShift) & 63u);
+      u64 lin = d & kPassLinMask;
+      int corner[N];
+      for (int a = 0; a < ND; a ++) { corner[a] = m.core_st[a] + (int)(lin % (u64)m.core_sz[a]); lin /= (u64)m.core_sz[a]; }
+      corner[ND] = f.t;
+      u64 X[N][ND];
+      int ids[N];
+      for (int v = 0; v < N; v ++) {
+        const unsigned vm = fan.vert[type][v];
+        int vx[3] = {0, 0, 0};
+        for (int a = 0; a < ND; a ++) vx[a] = corner[a] + (int)((vm >> a) & 1u);
+        const int sl = (int)((vm >> ND) & 1u);
+        i64 q[ND];
+        classify_vertex<ND>(m, f.S[sl], f.V[sl], f.factor, vx, q);
+        for (int c = 0; c < ND; c ++) X[v][c] = (u64)q[c];
+        ids[v] = vertex_id<ND>(m, corner, vm);
+      }
+      hit = make_record<ND>(m, f, corner, type, X, ids, false, nullptr, &rec);
+    }
+    emit_hits(m, hit, rec);
   }
 }
 
@@ -1881,7 +1918,15 @@ void launch_cull_two_level(const Mesh &m, const Fields *d_steps, int nsteps, u64
   else hipLaunchKernelGGL(refine_kernel<3>, grid, dim3(kThreads), 0, stream, m, mc, d_steps, d_refine, refine_cap, d_list, cap);
 }
 
-void launch_exact(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, hipStream_t stream)
+void launch_records(const Mesh &m, const Fields *d_fields, hipStream_t stream)
+{
+  // grid-stride over a device-side count: a few workgroups per CU are plenty (hits are rare; hit-dense 2D data: 1e4-1e5 per batch)
+  const dim3 grid(256u * 2u);
+  if (m.nd == 2) hipLaunchKernelGGL(record_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_fields);
+  else hipLaunchKernelGGL(record_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_fields);
+}
+
+void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64 *d_list, u64 cap, hipStream_t stream)
 {
   // persistent-style: workgroups stride over the list, every wave exits when it is drained.  The kernel uses scratch, which
   // makes every resident wavefront expensive to start: 2D lists are long but cheap per entry and run best with fewer workgroups
@@ -1889,8 +1934,8 @@ void launch_exact(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 c
   int per_cu = m.nd == 2 ? 2 : 4;
   if (const char *e = getenv("FTKX_EXACT_WG_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 64) per_cu = v; }
   const dim3 grid(256u * (unsigned)per_cu);
-  if (m.nd == 2) hipLaunchKernelGGL(exact_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, d_list, cap);
-  else hipLaunchKernelGGL(exact_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_steps, d_list, cap);
+  if (m.nd == 2) hipLaunchKernelGGL(exact_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, step_base, d_list, cap);
+  else hipLaunchKernelGGL(exact_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_steps, step_base, d_list, cap);
 }
 
 }  // namespace ftkx

@@ -8,7 +8,12 @@ typedef unsigned long long u64;
 typedef long long i64;
 
 enum { CNT_HITS = 0, CNT_CELLS_SURVIVED = 1, CNT_SIMPLICES_TESTED = 2, CNT_SURVIVOR_LIST = 3, CNT_LIST_PEAK = 4,
-       CNT_REFINE_LIST = 5, CNT_REFINE_PEAK = 6, CNT_WORDS_REFINED = 7, CNT_N = 8 };
+       CNT_REFINE_LIST = 5, CNT_REFINE_PEAK = 6, CNT_WORDS_REFINED = 7, CNT_PASS = 8, CNT_N = 9 };
+
+// A simplex that passed the test, handed from the integer kernels (exact_kernel, tile_kernel) to record_kernel, which does all the
+// FP64 work (solve, lerp, Jacobian, classification) on densely packed lanes: corner index inside core (x fastest) | type | request.
+constexpr int kPassTypeShift = 40, kPassStepShift = 46;
+inline constexpr u64 kPassLinMask = (1ull << kPassTypeShift) - 1ull;
 
 // everything that does not change between the sweeps of one context configuration
 struct Mesh {
@@ -32,6 +37,7 @@ struct Mesh {
   const double *coords_expl;      // EXPLICIT: (ncomp, n0, ...) array (device), read as p[c + ncomp * (x + n0 * y)]
   int coords_expl_ncomp, coords_expl_n0;
   ftkx_cp_t *hits;           // device hit buffer
+  u64 *pass;                 // simplices that passed the test, awaiting record_kernel (same capacity as hits)
   u64 *counters;             // CNT_* device counters
   u64 capacity;              // records the hit buffer can hold
 };
@@ -54,6 +60,7 @@ struct TileParams {
   Fields f;
   int cull;                  // 1: strict-sign cull legal and enabled
   int ntiles[3];
+  int step;                  // index of `f` in the batch's device array of Fields (what record_kernel looks it up by)
 };
 
 // Largest M with 24 M^3 < 2^63 (3D: |det4| of a homogeneous 4x4 with entries <= M) / 6 M^2 < 2^63 (2D): a simplex all of whose

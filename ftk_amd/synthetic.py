@@ -51,6 +51,12 @@ def double_gyre(dims, k, torch, device, A=0.1, omega=2 * math.pi, eps=0.25, time
 
 
 def generate(case, dims, k, nt, torch, device):
+    if case == "moving_extremum_3d_overflow":
+        # the reference's own defaults for the velocity and a centre 1e-7 off the lattice: tiny non-zero gradient
+        # components push nbits to 21, the quantised magnitudes reach D * 2^20 and the int64 determinants wrap almost everywhere
+        n = len(dims)
+        x0 = [dims[a] / 2 + (a + 1) * 1e-7 for a in range(n)]
+        return moving_extremum(dims, k, x0, [0.1, 0.11, 0.1][:n], torch, device)
     if case in ("moving_extremum_2d", "moving_extremum_3d"):
         x0, dv = moving_extremum_params(dims)
         return moving_extremum(dims, k, x0, dv, torch, device)
