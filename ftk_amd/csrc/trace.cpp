@@ -14,10 +14,13 @@
 // the reference's (tests/test_trace.py compares against curves dumped from the real reference).
 #include <algorithm>
 #include <array>
+#include <chrono>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ftkx.h"
@@ -26,6 +29,7 @@
 namespace {
 
 typedef unsigned long long u64;
+#define ND_OF(N) ((N) - 1)
 
 struct Elem {
   int c[4];   // corner x, y, (z,) t ; unused axes 0
@@ -131,12 +135,30 @@ struct Tracer {
     e.c[ND] = (int)ci;
     return e;
   }
+  // tag -> record: open addressing over a power-of-two table at most half full (a lookup is one or two probes; the binary search
+  // over the sorted tags it replaces cost ~16 mispredicted branches per lookup, 6-8 lookups per record)
+  std::vector<u64> h_tag;
+  std::vector<int> h_rec;
+  u64 h_mask = 0;
+  static u64 mix(u64 x) { x *= 0x9e3779b97f4a7c15ull; return x ^ (x >> 29); }
+  void build_hash(const ftkx_cp_t *recs, size_t n)
+  {
+    size_t cap = 16;
+    while (cap < 2 * n + 2) cap <<= 1;
+    h_mask = cap - 1;
+    h_tag.assign(cap, 0); h_rec.assign(cap, -1);
+    for (size_t i = 0; i < n; i ++) {
+      u64 p = mix(recs[i].tag) & h_mask;
+      while (h_rec[p] >= 0) p = (p + 1) & h_mask;
+      h_tag[p] = recs[i].tag; h_rec[p] = (int)i;
+    }
+  }
   int find(const Elem &e) const
   {
     u64 tag;
     if (!encode(e, &tag)) return -1;
-    auto it = std::lower_bound(index.begin(), index.end(), std::make_pair(tag, -1));
-    return (it != index.end() && it->first == tag) ? it->second : -1;
+    for (u64 p = mix(tag) & h_mask; h_rec[p] >= 0; p = (p + 1) & h_mask) if (h_tag[p] == tag) return h_rec[p];
+    return -1;
   }
   // records that share a (d+1)-cell with e, in the element order of the reference's std::set, e itself excluded
   void neighbours(const Elem &e, std::vector<std::pair<Elem, int>> &out) const
@@ -168,39 +190,99 @@ struct UnionFind {
   void unite(int a, int b) { a = find(a); b = find(b); if (a != b) p[b] = a; }
 };
 
+// runs f(begin, end) over [0, n) on up to `cap` host threads (the per-record work of pass 2 is independent: SURVEY 8 f2 -- "the
+// sorted-tag binary searches are independent per hit")
+template <class F>
+void parallel_ranges(size_t n, F f, unsigned cap = 16)
+{
+  unsigned nt = std::thread::hardware_concurrency();
+  if (const char *e = getenv("FTKX_TRACE_THREADS")) nt = (unsigned)atoi(e);
+  if (nt > cap) nt = cap;
+  if (nt < 2 || n < 4096) { f((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; t ++) {
+    const size_t b = std::min(n, (size_t)t * per), e = std::min(n, b + per);
+    if (b < e) th.emplace_back([=] { f(b, e); });
+  }
+  for (auto &x : th) x.join();
+}
+
 template <int N>
 int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs, size_t n, ftkx_curves *out)
 {
   static const Adjacency<N> adj;
+  const bool prof = getenv("FTKX_TRACE_PROF") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::high_resolution_clock::now().time_since_epoch()).count() * 1e3; };
+  double tp[8]; int np_ = 0; tp[np_ ++] = now();
+  constexpr int MAXNB = 2 * N;                       // two cells per face, N other faces each
   Tracer<N> tr(adj, dst, dsz);
   tr.index.resize(n);
-  for (size_t i = 0; i < n; i ++) tr.index[i] = {recs[i].tag, (int)i};
-  std::sort(tr.index.begin(), tr.index.end());
+  bool sorted = true;
+  for (size_t i = 0; i < n; i ++) { tr.index[i] = {recs[i].tag, (int)i}; if (i && recs[i].tag < recs[i - 1].tag) sorted = false; }
+  if (!sorted) std::sort(tr.index.begin(), tr.index.end());          // (the sweep hands its records over sorted by tag)
   for (size_t i = 1; i < n; i ++) if (tr.index[i].first == tr.index[i - 1].first) return FTKX_E_INVALID;   // duplicate tags
 
+  tr.build_hash(recs, n);
+  tp[np_ ++] = now();
   std::vector<Elem> elem(n);
-  for (size_t i = 0; i < n; i ++) elem[i] = tr.decode(recs[i].tag);
-  // adjacency lists inside the hit set (sorted in element order), degrees
-  std::vector<std::vector<int>> nb(n);
-  std::vector<std::pair<Elem, int>> tmp;
-  for (size_t i = 0; i < n; i ++) {
-    tr.neighbours(elem[i], tmp);
-    nb[i].reserve(tmp.size());
-    for (const auto &t : tmp) nb[i].push_back(t.second);
-  }
+  // adjacency lists inside the hit set (sorted in element order), flat: at most MAXNB neighbours per record
+  std::vector<int> nbr(n * MAXNB);
+  std::vector<unsigned char> deg(n);
+  // the reference's element order (corner as a vector with x FIRST, then the type) as one integer per record
+  std::vector<std::pair<u64, int>> order_key(n);
+  parallel_ranges(n, [&](size_t b, size_t e) {
+    std::vector<std::pair<Elem, int>> tmp;
+    for (size_t i = b; i < e; i ++) {
+      elem[i] = tr.decode(recs[i].tag);
+      tr.neighbours(elem[i], tmp);
+      deg[i] = (unsigned char)tmp.size();
+      for (size_t k = 0; k < tmp.size() && k < (size_t)MAXNB; k ++) nbr[i * MAXNB + k] = tmp[k].second;
+      u64 key = 0;
+      for (int d = 0; d < ND_OF(N); d ++) key = key * (u64)dsz[d] + (u64)(elem[i].c[d] - dst[d]);
+      key = (key << 24) | (u64)(unsigned)elem[i].c[N - 1];           // (time: below 2^24 steps, else the comparator sort below)
+      order_key[i] = {key * (u64)Tracer<N>::NTYPES + (u64)elem[i].type, (int)i};
+    }
+  });
+  tp[np_ ++] = now();
+  struct NbRange { const int *b, *e; const int *begin() const { return b; } const int *end() const { return e; } size_t size() const { return (size_t)(e - b); } };
+  auto nb = [&](size_t i) { return NbRange{&nbr[i * MAXNB], &nbr[i * MAXNB] + deg[i]}; };
   std::vector<char> ordinary(n);
-  for (size_t i = 0; i < n; i ++) ordinary[i] = nb[i].size() <= 2;
+  for (size_t i = 0; i < n; i ++) ordinary[i] = deg[i] <= 2;
 
   // curves = connected components of the ordinary nodes
   UnionFind uf(n);
   for (size_t i = 0; i < n; i ++)
-    if (ordinary[i]) for (int j : nb[i]) if (ordinary[j]) uf.unite((int)i, j);
-  // seeds: the smallest element of every component, components enumerated in element order of their seed
-  std::vector<int> order(n);
-  for (size_t i = 0; i < n; i ++) order[i] = (int)i;
-  std::sort(order.begin(), order.end(), [&](int a, int b) { return elem_less(elem[a], elem[b], N); });
+    if (ordinary[i]) for (int j : nb(i)) if (ordinary[j]) uf.unite((int)i, j);
+  // seeds: the smallest element of every component (a linear pass over per-record keys), components enumerated in element
+  // order of their seed (a sort of the seeds only)
+  std::vector<int> order;
+  bool key_ok = true;
+  {
+    long double span = 16777216.0L * (long double)Tracer<N>::NTYPES;
+    for (int d = 0; d < ND_OF(N); d ++) span *= (long double)dsz[d];
+    for (size_t i = 0; i < n && key_ok; i ++) key_ok = elem[i].c[N - 1] < (1 << 24);
+    key_ok = key_ok && span < 18446744073709551615.0L;
+  }
+  if (key_ok) {
+    std::vector<int> best(n, -1);                    // per root: the member with the smallest key
+    for (size_t i = 0; i < n; i ++) {
+      if (!ordinary[i]) continue;
+      const int r = uf.find((int)i);
+      if (best[r] < 0 || order_key[i].first < order_key[best[r]].first) best[r] = (int)i;
+    }
+    std::vector<std::pair<u64, int>> seeds;
+    for (size_t r = 0; r < n; r ++) if (best[r] >= 0) seeds.push_back({order_key[best[r]].first, best[r]});
+    std::sort(seeds.begin(), seeds.end());
+    order.reserve(seeds.size());
+    for (const auto &sd : seeds) order.push_back(sd.second);
+  } else {
+    order.resize(n);
+    for (size_t i = 0; i < n; i ++) order[i] = (int)i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return elem_less(elem[a], elem[b], N); });
+  }
   std::vector<int> comp_size(n, 0);
-  for (size_t i = 0; i < n; i ++) if (ordinary[i]) comp_size[uf.find((int)i)] ++;
+  tp[np_ ++] = now();
 
   std::vector<int> seq; seq.reserve(n);
   std::vector<long long> offsets(1, 0);
@@ -216,14 +298,14 @@ int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs
     front.clear(); back.clear();
     visited[s] = 1;
     std::vector<int> seed_nb;
-    for (int j : nb[s]) if (ordinary[j]) seed_nb.push_back(j);
+    for (int j : nb(s)) if (ordinary[j]) seed_nb.push_back(j);
     for (int dir = 0; dir < 2; dir ++) {
       if (seed_nb.empty()) break;
       int cur = dir == 0 ? seed_nb.front() : seed_nb.back();
       while (true) {
         if (!visited[cur]) { (dir == 0 ? back : front).push_back(cur); visited[cur] = 1; }
         int next = -1;
-        for (int j : nb[cur]) if (ordinary[j] && !visited[j]) { next = j; break; }   // same component by construction
+        for (int j : nb(cur)) if (ordinary[j] && !visited[j]) { next = j; break; }   // same component by construction
         if (next < 0) break;
         cur = next;
       }
@@ -238,12 +320,14 @@ int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs
     int loop = 0;
     if (seq.size() - begin >= 2) {
       const int f = seq[begin], b = seq.back();
-      for (int j : nb[f]) if (j == b) loop = 1;
+      for (int j : nb(f)) if (j == b) loop = 1;
     }
     loops.push_back(loop);
     (void)comp_size;
   }
 
+  tp[np_ ++] = now();
+  if (prof) fprintf(stderr, "trace: n %zu  index %.3f  neighbours %.3f  components+order %.3f  walk %.3f ms\n", n, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3]);
   out->n_curves = loops.size();
   out->n_points = seq.size();
   out->offsets = (long long *)malloc(offsets.size() * sizeof(long long));
