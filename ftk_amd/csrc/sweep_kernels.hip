@@ -1318,7 +1318,8 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
                                                               int gx_log2, u64 *__restrict__ list, u64 list_capacity)
 {
   constexpr int kListCounter = COARSE ? CNT_REFINE_LIST : CNT_SURVIVOR_LIST;
-  constexpr int kStatCounter = COARSE ? CNT_WORDS_REFINED : CNT_CELLS_SURVIVED;
+  __shared__ unsigned s_wave_total[4];
+  __shared__ u64 s_block_base;
   constexpr u64 kAll = 0x3f3f3f3f3f3f3f3full, k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
   const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1412,18 +1413,35 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
         if (need_next) surv_i = ~((cur[zi] & nxt[zi]) + k7f) & k80 & in_core;
       }
       const u64 any = surv_o | surv_i;
-      if (__ballot(any != 0) == 0) continue;                   // the common case: nothing survives in this wavefront
-      const unsigned cnt = (unsigned)__popcll(any);
-      unsigned incl = cnt;
-      for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-      const unsigned total = __shfl(incl, 63);
-      u64 base = 0;
-      if (lane == 63) {
-        base = atomicAdd(&m.counters[kListCounter], (u64)total);
-        atomicAdd(&m.counters[kStatCounter], (u64)total);
+      u64 pos;
+      unsigned cnt;
+      if constexpr (ND == 2) {
+        // hit-dense 2D data: most wavefronts have survivors, and one returning atomic per wavefront on the single list counter
+        // serialises at the memory side (0.2 ms for 64 steps of 1024^2).  One atomic per WORKGROUP instead: wave totals through LDS.
+        if (__syncthreads_or(any != 0) == 0) continue;         // (block-uniform: no wavefront left the kernel, see the early exits above)
+        cnt = (unsigned)__popcll(any);
+        unsigned incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        if (lane == 63) s_wave_total[wv] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          unsigned run = 0;
+          for (int q = 0; q < 4; q ++) { const unsigned t = s_wave_total[q]; s_wave_total[q] = run; run += t; }
+          s_block_base = run ? atomicAdd(&m.counters[kListCounter], (u64)run) : 0ull;
+        }
+        __syncthreads();
+        pos = s_block_base + s_wave_total[wv] + (incl - cnt);
+      } else {
+        if (__ballot(any != 0) == 0) continue;                 // the common case: nothing survives in this wavefront
+        cnt = (unsigned)__popcll(any);
+        unsigned incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        const unsigned total = __shfl(incl, 63);
+        u64 base = 0;
+        if (lane == 63) base = atomicAdd(&m.counters[kListCounter], (u64)total);
+        base = __shfl(base, 63);
+        pos = base + (incl - cnt);
       }
-      base = __shfl(base, 63);
-      u64 pos = base + (incl - cnt);
       if (cnt) {
         const u64 lin0 = row_lin + (ND == 3 ? (u64)(z0 + zi + m.ext_st[2] - m.core_st[2]) * plane_sz : 0ull);
         for (int b = 0; b < 8; b ++) {
@@ -1449,8 +1467,10 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(const Mesh m, const Me
 {
   const int DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
   const int lane = threadIdx.x & 63;
+  __shared__ unsigned s_wave_total[kThreads / 64];
+  __shared__ u64 s_block_base;
   u64 count = m.counters[CNT_REFINE_LIST];
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&m.counters[CNT_REFINE_PEAK], count);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { atomicMax(&m.counters[CNT_REFINE_PEAK], count); atomicAdd(&m.counters[CNT_WORDS_REFINED], count); }
   if (count > refine_capacity) count = refine_capacity;
   const u64 k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
   for (u64 base = (u64)blockIdx.x * kThreads; base < count; base += (u64)gridDim.x * kThreads) {   // block-uniform trip count
@@ -1495,18 +1515,20 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(const Mesh m, const Me
       row_lin = (u64)(cy - m.core_st[1]) * (u64)m.core_sz[0] + (ND == 3 ? (u64)(cz - m.core_st[2]) * (u64)m.core_sz[0] * (u64)m.core_sz[1] : 0ull);
     }
     const u64 any = surv_o | surv_i;
-    if (__ballot(any != 0) == 0) continue;
+    // one list atomic per workgroup and iteration (wave totals through LDS): on hit-dense data nearly every wavefront has survivors
+    if (__syncthreads_or(any != 0) == 0) continue;             // block-uniform trip count, see the loop header
     const unsigned cnt = (unsigned)__popcll(any);
     unsigned incl = cnt;
     for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-    const unsigned total = __shfl(incl, 63);
-    u64 pbase = 0;
-    if (lane == 63) {
-      pbase = atomicAdd(&m.counters[CNT_SURVIVOR_LIST], (u64)total);
-      atomicAdd(&m.counters[CNT_CELLS_SURVIVED], (u64)total);
+    if (lane == 63) s_wave_total[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned run = 0;
+      for (int q = 0; q < kThreads / 64; q ++) { const unsigned t = s_wave_total[q]; s_wave_total[q] = run; run += t; }
+      s_block_base = run ? atomicAdd(&m.counters[CNT_SURVIVOR_LIST], (u64)run) : 0ull;
     }
-    pbase = __shfl(pbase, 63);
-    u64 pos = pbase + (incl - cnt);
+    __syncthreads();
+    u64 pos = s_block_base + s_wave_total[threadIdx.x >> 6] + (incl - cnt);
     for (int b = 0; b < 8 && cnt; b ++) {
       const unsigned fl = (unsigned)((surv_o >> (8 * b + 7)) & 1) | ((unsigned)((surv_i >> (8 * b + 7)) & 1) << 1);
       if (!fl) continue;
@@ -1538,7 +1560,10 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
   const int tid = threadIdx.x;
   const fan_table<N> &fan = dev_fan<ND>();
   u64 count = m.counters[CNT_SURVIVOR_LIST];
-  if (blockIdx.x == 0 && tid == 0) atomicMax(&m.counters[CNT_LIST_PEAK], count);   // the host checks the peak against the capacity
+  if (blockIdx.x == 0 && tid == 0) {   // the host checks the peak against the capacity; the statistic: cells that survived the cull
+    atomicMax(&m.counters[CNT_LIST_PEAK], count);
+    atomicAdd(&m.counters[CNT_CELLS_SURVIVED], count);
+  }
   if (count > list_capacity) count = list_capacity;     // overflow: the host grows the list and replays the batch
   if ((u64)blockIdx.x * G >= count) return;             // nothing for this workgroup: leave before touching LDS or scratch
   if (tid < NTYPES) {
