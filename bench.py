@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: dry run of the N>1 path (host-staged halo)")
     ap.add_argument("--single-device", action="store_true", help="all ranks on cuda:0 (dry run of the N>1 logic on a 1-GPU box)")
     ap.add_argument("--halo-in-loop", action="store_true", help="N > 1: re-send the slab-boundary slice inside every timed pass")
+    ap.add_argument("--compact-halo", action="store_true", help="N > 1: inside every timed pass, exchange sign masks + patches around the surviving cells instead of the boundary slice")
     ap.add_argument("--dump-merged", default=None, help="rank 0 writes the merged records and the curves traced from them (npz)")
     args = ap.parse_args()
 
@@ -178,7 +179,11 @@ def main():
             halo_pushed[0] = True
 
     halo_info = None
-    if world > 1:
+    compact_bytes = [0, 0, 0, 0]
+    if world > 1 and args.compact_halo:
+        args.halo_in_loop = False
+        halo_info = {"compact": True, "in_timed_region": True}
+    elif world > 1:
         # input distribution (untimed region, reported separately): a first exchange warms RCCL up, the second one is timed
         for rep in range(2):
             dist.barrier(); torch.cuda.synchronize()
@@ -197,10 +202,27 @@ def main():
             halo()
         tp0 = time.perf_counter()
         f, _, _ = prepare_and_factors()
+        t_masked = None
+        if world > 1 and args.compact_halo:
+            # compact halo, step 1: the next slab's first slice arrives as sign masks only (they were just built by its owner)
+            t_masked, sb, rb = tslab.compact_halo_masks(ctx, own, nt, scalar_input)
+            compact_bytes[0] += sb; compact_bytes[1] += rb
         te0 = time.perf_counter()
         for t in own:
             scope = ftk_amd.SCOPE_BOTH if (t + 1 < nt) else ftk_amd.SCOPE_ORDINAL
             ctx.sweep_enqueue(t, scope, f[t])
+        if world > 1 and args.compact_halo:
+            # step 2: cull, then the input values around the boundary step's surviving cells from the slice's owner -- or, where
+            # that would be more bytes than the slice (hit-dense data on small slices), the slice itself after all
+            def push_full(t, buf):
+                ctx.sweep_cancel()
+                (ctx.push_scalar_slice if scalar_input else ctx.push_slice)(t, buf)
+            ncell, sb, rb = tslab.compact_halo_patches(ctx, own, nt, t_masked, first_slice=slices[own[0]] if own else None,
+                                                       halo_buffer=halo_buf, push_full=push_full)
+            compact_bytes[0] += sb; compact_bytes[1] += rb; compact_bytes[2] += max(ncell, 0); compact_bytes[3] += 1 if ncell < 0 else 0
+            if ncell < 0:
+                for t in own:
+                    ctx.sweep_enqueue(t, ftk_amd.SCOPE_BOTH if (t + 1 < nt) else ftk_amd.SCOPE_ORDINAL, f[t])
         te1 = time.perf_counter()
         # one cull / exact launch for the whole slab (plus the masks of the halo slice, N > 1), then the hit download into the
         # library's pinned host buffer
@@ -218,6 +240,7 @@ def main():
         recs, st = one_pass()
     ctx.set_profiling(True)         # HIP events around every kernel launch, on the stream the kernels run on
     host_ms[0] = host_ms[1] = host_ms[2] = 0.0
+    compact_bytes[0] = compact_bytes[1] = compact_bytes[2] = compact_bytes[3] = 0
     barrier()
     tt0 = time.perf_counter()
     for _ in range(args.steps):
@@ -238,9 +261,14 @@ def main():
     total_simplices = tslab.count_simplices(nd, dims, nt, scalar_input)
     ktimes = ctx.kernel_times()
 
+    if world > 1 and args.compact_halo:
+        halo_info.update({"bytes_sent_per_pass_this_rank": compact_bytes[0] / args.steps, "bytes_received_per_pass_this_rank": compact_bytes[1] / args.steps,
+                          "cells_requested_per_pass_this_rank": compact_bytes[2] / args.steps,
+                          "passes_that_fell_back_to_the_whole_slice": compact_bytes[3],
+                          "full_slice_bytes": int(np.prod(dims)) * 8 * (1 if scalar_input else nd)})
     # N > 1: the other convention, for the record -- the slab-boundary slice re-sent inside every pass (same barriers, max over ranks)
     other = None
-    if world > 1:
+    if world > 1 and not args.compact_halo:
         k2 = min(args.steps, 3)
         flip = not args.halo_in_loop
         args.halo_in_loop = flip

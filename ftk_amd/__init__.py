@@ -139,6 +139,46 @@ class Context:
         self._ck(self._L.ftkx_slices_prepare(self._h, tt, n, int(factor_hint), r, m))
         return {ts[i]: (r[i], m[i]) for i in range(n)}
 
+    # ---- compact t-slab halo (torch tensors on this context's device, or on the host) ----
+    def export_masks(self, t, torch, device):
+        """owner side: (U uint8 tensor, word_index int32 tensor, words int64 tensor, mask_factor, max_abs) of a prepared slice"""
+        ub, nw, mf, mx = C.c_size_t(), C.c_size_t(), C.c_ulonglong(), C.c_double()
+        self._ck(self._L.ftkx_export_masks_size(self._h, int(t), C.byref(ub), C.byref(nw), C.byref(mf), C.byref(mx)))
+        U = torch.empty((ub.value,), dtype=torch.uint8, device=device)
+        idx = torch.empty((max(1, nw.value),), dtype=torch.int32, device=device)
+        words = torch.empty((max(1, nw.value),), dtype=torch.int64, device=device)
+        self._ck(self._L.ftkx_export_masks(self._h, int(t), U.data_ptr(), idx.data_ptr(), words.data_ptr(), 1 if U.is_cuda else 0))
+        return U, idx[:nw.value], words[:nw.value], mf.value, mx.value
+
+    def push_masked_slice(self, t, scalar_input, U, idx, words, mask_factor, max_abs):
+        self._keep[("masked", t)] = (U, idx, words)
+        self._ck(self._L.ftkx_push_masked_slice(self._h, int(t), int(bool(scalar_input)), U.data_ptr(), idx.data_ptr() if len(idx) else None,
+                                                words.data_ptr() if len(words) else None, len(idx), int(mask_factor), float(max_abs), 1 if U.is_cuda else 0))
+
+    def sweep_cull(self, t_masked, torch, device):
+        """receiver side, after sweep_enqueue: the cells (int64 tensor of core-linear indices) whose exact test reads the masked slice"""
+        n = C.c_size_t()
+        self._ck(self._L.ftkx_sweep_cull(self._h, int(t_masked), C.byref(n)))
+        cells = torch.empty((max(1, n.value),), dtype=torch.int64, device=device)
+        self._ck(self._L.ftkx_get_sparse_cells(self._h, cells.data_ptr(), 1 if cells.is_cuda else 0))
+        return cells[:n.value]
+
+    def sweep_cancel(self):
+        self._ck(self._L.ftkx_sweep_cancel(self._h))
+
+    def patch_doubles(self):
+        return int(self._L.ftkx_patch_doubles(self._h))
+
+    def gather_patches(self, t, cells, torch):
+        out = torch.empty((max(1, len(cells)) * self.patch_doubles(),), dtype=torch.float64, device=cells.device)
+        if len(cells):
+            self._ck(self._L.ftkx_gather_patches(self._h, int(t), cells.data_ptr(), len(cells), out.data_ptr(), 1 if cells.is_cuda else 0))
+        return out[:len(cells) * self.patch_doubles()]
+
+    def scatter_patches(self, t, cells, patches):
+        if len(cells):
+            self._ck(self._L.ftkx_scatter_patches(self._h, int(t), cells.data_ptr(), len(cells), patches.data_ptr(), 1 if cells.is_cuda else 0))
+
     def set_slice_resolution(self, t, resolution, max_abs):
         self._ck(self._L.ftkx_set_slice_resolution(self._h, t, float(resolution), float(max_abs)))
 

@@ -27,6 +27,10 @@ void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t s
 void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream);
 void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64 *d_list, u64 cap, hipStream_t stream);
 void launch_records(const Mesh &m, const Fields *d_fields, hipStream_t stream);
+void launch_compact_words(const Mesh &m, const unsigned char *U, const unsigned char *M, unsigned *idx, u64 *words, u64 capacity, u64 *counter, hipStream_t st);
+void launch_scatter_words(const unsigned *idx, const u64 *words, size_t n, unsigned char *M, hipStream_t st);
+void launch_sparse_cells(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, const double *sparse, u64 *cells, u64 cells_cap, hipStream_t st);
+void launch_patches(const Mesh &m, bool scatter, const u64 *cells, size_t n, int ncomp, double *field, double *patches, hipStream_t st);
 bool masks_have_summary(const Mesh &m);
 bool march2_supported(const Mesh &m);
 bool masks_fuse_reduction(const Mesh &m);
@@ -64,7 +68,8 @@ struct Slice {
   bool have_fused = false;          // reduction fused into the mask pass (ftkx_slices_prepare): maxabs, and
   double res_below = 0;             //   the smallest non-zero |v| below 1 / fused_factor (DBL_MAX if none)
   unsigned long long fused_factor = 0;
-  bool max_known() const { return have_res || have_fused; }
+  bool sparse = false;              // a halo slice that exists as masks only: its field array holds just the patches scattered into it
+  bool max_known() const { return have_res || have_fused || sparse; }
 };
 
 // how a request is swept: MODE_TILE tests every simplex (exact_only, non-robust 3D, odd factors); MODE_FAST = masks -> cull ->
@@ -118,6 +123,10 @@ struct ftkx_ctx {
   size_t expl_n0 = 0, expl_n1 = 0;
   std::vector<Request> pending;
   int dense_collects = 0;           // > 0: the last fast collect found most cells surviving; fast requests run MODE_TILE_CULL for a while
+  // compact halo: the compacted mask words of the last ftkx_export_masks_size, the surviving cells of the last ftkx_sweep_cull
+  unsigned *d_word_idx = nullptr; u64 *d_words = nullptr; size_t words_cap = 0, n_words = 0; int words_t = -1;
+  u64 *d_cells = nullptr; size_t cells_cap = 0, n_cells = 0;
+  u64 *d_patch_cells = nullptr; double *d_patches = nullptr; size_t patch_cap = 0;   // staging for host-side callers
   ftkx_stats stats;
   // optional kernel timing (hipEvents on the context's stream)
   int profiling = 0;
@@ -421,8 +430,9 @@ void ev_harvest(ftkx_ctx *c)   // after a stream synchronise
 // Fast-path requests are grouped into sub-batches (one mask / cull / exact launch each); a new sub-batch starts whenever a
 // slice's masks would be needed under a second quantisation factor (the factor is a running minimum, so it changes a few
 // times at the start of a series and then stays put).
-int run_batch(ftkx_ctx *c)
+int run_batch(ftkx_ctx *c, const double *sparse_field = nullptr)
 {
+  const bool cull_only = sparse_field != nullptr;   // ftkx_sweep_cull: stop after the cull and list the survivors that read `sparse_field`
   Mesh m;
   fill_mesh(c, m);
   const int nd = c->nd;
@@ -442,6 +452,7 @@ int run_batch(ftkx_ctx *c)
       for (Slice *s : {&s0, s1}) {
         if (!s) continue;
         if (masks_valid(c, *s, r.factor, two_level)) continue;     // e.g. built by ftkx_slices_prepare, or by an earlier step
+        if (s->sparse) return fail(c, FTKX_E_NOSLICE, "sweep: the masks of halo slice (masks only) do not serve factor %llu: send the slice itself", r.factor);
         int rc = ensure_mask_arrays(c, *s, two_level);
         if (rc) return rc;
         // masks of this slice already (re)built or used in the current sub-batch under another factor -> close it
@@ -491,6 +502,8 @@ int run_batch(ftkx_ctx *c)
     HIP_TRY(c, hipMemcpyAsync(c->d_desc, c->h_desc, total, hipMemcpyHostToDevice, c->stream));
   }
   const Fields *d_fields = (const Fields *)((char *)c->d_desc + fields_off);
+  if (cull_only && (subs.size() > 1 || !tiles.empty()))
+    return fail(c, FTKX_E_UNSUPPORTED, "ftkx_sweep_cull: the batch needs masks under two factors or the tile path (send the slice itself)");
   for (size_t i = 0; i < subs.size(); i ++) {
     const Sub &sb = subs[i];
     if (sb.steps.empty()) continue;
@@ -507,8 +520,14 @@ int run_batch(ftkx_ctx *c)
     if (two_level) ftkx::launch_cull_two_level(m, d_steps, (int)sb.steps.size(), c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
     else ftkx::launch_cull(m, d_steps, (int)sb.steps.size(), c->d_list, c->list_capacity, c->stream);
     ev_end(c);
+    if (cull_only) {
+      // (the exact kernel is what publishes the list peak; without it the host reads the list counter itself)
+      ftkx::launch_sparse_cells(m, d_steps, c->d_list, c->list_capacity, sparse_field, c->d_cells, c->cells_cap, c->stream);
+      continue;
+    }
     ev_begin(c, K_EXACT); ftkx::launch_exact(m, d_steps, (int)step_base[i], c->d_list, c->list_capacity, c->stream); ev_end(c);
   }
+  if (cull_only) { HIP_TRY(c, hipGetLastError()); return FTKX_OK; }
   for (const TileParams &p : tiles) { ev_begin(c, K_TILE); ftkx::launch_tile(p, c->stream); ev_end(c); }
   // the FP64 half, once for the whole batch: records of every simplex that passed (timed with the kernel family that fed it)
   if (nfields) { ev_begin(c, tiles.empty() ? K_EXACT : K_TILE); ftkx::launch_records(m, d_fields, c->stream); ev_end(c); }
@@ -585,6 +604,7 @@ void ftkx_destroy(ftkx_ctx *c)
   if (c->d_red) (void)hipFree(c->d_red);
   if (c->d_hits) (void)hipFree(c->d_hits);
   if (c->d_pass) (void)hipFree(c->d_pass);
+  for (void *p : {(void *)c->d_word_idx, (void *)c->d_words, (void *)c->d_cells, (void *)c->d_patch_cells, (void *)c->d_patches}) if (p) (void)hipFree(p);
   if (c->d_list) (void)hipFree(c->d_list);
   if (c->d_refine) (void)hipFree(c->d_refine);
   if (c->d_sorted) (void)hipFree(c->d_sorted);
@@ -831,6 +851,8 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
   const bool two_level = ftkx::masks_have_summary(m);
   int rc;
   for (Slice *s : all) {
+    if (s->sparse && !s->have_res) return fail(c, FTKX_E_NOSLICE, "ftkx_slices_prepare: a masked halo slice has no data to reduce (its owner's reduction: ftkx_set_slice_resolution)");
+    if (s->sparse) continue;
     if (!want_masks) { if ((rc = slice_resolution(c, *s))) return rc; continue; }
     if (s->have_fused && s->fused_factor == hint && s->mask_factor == hint && s->M && (!two_level || s->U)) continue;
     if (std::find(todo.begin(), todo.end(), s) == todo.end()) todo.push_back(s);
@@ -878,6 +900,198 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
   }
   return FTKX_OK;
 }
+
+// ---- compact t-slab halo ------------------------------------------------------------------------------------------------------
+static int copy_out(ftkx_ctx *c, void *dst, const void *src, size_t bytes, int dst_on_device)
+{
+  if (!bytes) return FTKX_OK;
+  HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+  return FTKX_OK;
+}
+
+int ftkx_export_masks_size(ftkx_ctx *c, int t, size_t *u_bytes_out, size_t *n_words, unsigned long long *mask_factor, double *max_abs)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  auto it = c->slices.find(t);
+  if (it == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "ftkx_export_masks_size: timestep %d not resident", t);
+  Slice &s = it->second;
+  if (!s.M || !s.U || !s.mask_factor || !s.max_known())
+    return fail(c, FTKX_E_UNSUPPORTED, "ftkx_export_masks_size: slice %d has no summarised masks (ftkx_slices_prepare first; needs a mesh the two-level cull supports)", t);
+  HIP_TRY(c, hipSetDevice(c->device));
+  Mesh m; fill_mesh(c, m);
+  for (int attempt = 0; attempt < 2; attempt ++) {
+    HIP_TRY(c, hipMemsetAsync(c->d_counters + ftkx::CNT_SPARSE, 0, sizeof(u64), c->stream));
+    ftkx::launch_compact_words(m, s.U, s.M, c->d_word_idx, c->d_words, c->words_cap, c->d_counters + ftkx::CNT_SPARSE, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters + ftkx::CNT_SPARSE, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)c->h_counters[0];
+    if (n <= c->words_cap) { c->n_words = n; c->words_t = t; break; }
+    if (c->d_word_idx) (void)hipFree(c->d_word_idx);
+    if (c->d_words) (void)hipFree(c->d_words);
+    c->d_word_idx = nullptr; c->d_words = nullptr; c->words_cap = 0;
+    const size_t cap = n + n / 8 + 1024;
+    HIP_TRY(c, hipMalloc((void **)&c->d_word_idx, cap * sizeof(unsigned)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_words, cap * sizeof(u64)));
+    c->words_cap = cap;
+  }
+  if (u_bytes_out) *u_bytes_out = u_bytes(c);
+  if (n_words) *n_words = c->n_words;
+  if (mask_factor) *mask_factor = s.mask_factor;
+  if (max_abs) *max_abs = s.maxabs;
+  return FTKX_OK;
+}
+
+int ftkx_export_masks(ftkx_ctx *c, int t, void *U_dst, unsigned *word_index_dst, unsigned long long *words_dst, int dst_on_device)
+{
+  if (!c || !U_dst) return fail(c, FTKX_E_INVALID, "null argument");
+  auto it = c->slices.find(t);
+  if (it == c->slices.end() || c->words_t != t) return fail(c, FTKX_E_INVALID, "ftkx_export_masks: call ftkx_export_masks_size for timestep %d first", t);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = copy_out(c, U_dst, it->second.U, u_bytes(c), dst_on_device))) return rc;
+  if (c->n_words && (!word_index_dst || !words_dst)) return fail(c, FTKX_E_INVALID, "ftkx_export_masks: null list buffers");
+  if ((rc = copy_out(c, word_index_dst, c->d_word_idx, c->n_words * sizeof(unsigned), dst_on_device))) return rc;
+  if ((rc = copy_out(c, words_dst, c->d_words, c->n_words * sizeof(u64), dst_on_device))) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return FTKX_OK;
+}
+
+int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, const unsigned *word_index, const unsigned long long *words, size_t n_words,
+                           unsigned long long mask_factor, double max_abs, int on_device)
+{
+  if (!c || !U) return fail(c, FTKX_E_INVALID, "null argument");
+  if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "push: call ftkx_set_mesh first");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "push: sweeps pending, collect first");
+  if (t < 0 || !pow2_factor(mask_factor) || !(max_abs >= 0)) return fail(c, FTKX_E_INVALID, "ftkx_push_masked_slice: bad arguments");
+  if (c->slices.empty()) c->scalar_mode = -1;
+  if (c->scalar_mode >= 0 && c->scalar_mode != (scalar_input ? 1 : 0)) return fail(c, FTKX_E_INVALID, "push: scalar and vector slices cannot be mixed in one context");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int saved_mode = c->scalar_mode;
+  c->scalar_mode = scalar_input ? 1 : 0;
+  Mesh m; fill_mesh(c, m);
+  if (!ftkx::masks_have_summary(m)) { c->scalar_mode = saved_mode; return fail(c, FTKX_E_UNSUPPORTED, "ftkx_push_masked_slice: this mesh has no summarised masks"); }
+  auto it = c->slices.find(t);
+  Slice s;
+  if (it != c->slices.end() && it->second.sparse) { s = it->second; c->slices.erase(it); }          // the same halo slice again: keep its arrays
+  else if (it != c->slices.end()) { free_slice(it->second, c); c->slices.erase(it); }
+  const size_t n = n_vertices(c), ncomp = scalar_input ? 1 : (size_t)c->nd;
+  int rc;
+  if (!s.sparse) {
+    double **field = scalar_input ? &s.S : &s.V;
+    HIP_TRY(c, hipMalloc((void **)field, n * ncomp * sizeof(double)));
+    (scalar_input ? s.ownS : s.ownV) = true;
+    HIP_TRY(c, hipMemsetAsync(*field, 0, n * ncomp * sizeof(double), c->stream));      // only patches are ever read; zeros elsewhere, not garbage
+    if ((rc = ensure_mask_arrays(c, s, true))) { free_slice(s, c); return rc; }
+    s.sparse = true;
+  }
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIP_TRY(c, hipMemcpyAsync(s.U, U, u_bytes(c), kind, c->stream));
+  if (n_words) {
+    if (c->words_cap < n_words) {
+      if (c->d_word_idx) (void)hipFree(c->d_word_idx);
+      if (c->d_words) (void)hipFree(c->d_words);
+      c->d_word_idx = nullptr; c->d_words = nullptr; c->words_cap = 0;
+      HIP_TRY(c, hipMalloc((void **)&c->d_word_idx, n_words * sizeof(unsigned)));
+      HIP_TRY(c, hipMalloc((void **)&c->d_words, n_words * sizeof(u64)));
+      c->words_cap = n_words;
+    }
+    c->words_t = -1;
+    HIP_TRY(c, hipMemcpyAsync(c->d_word_idx, word_index, n_words * sizeof(unsigned), kind, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_words, words, n_words * sizeof(u64), kind, c->stream));
+    ftkx::launch_scatter_words(c->d_word_idx, c->d_words, n_words, s.M, c->stream);
+    HIP_TRY(c, hipGetLastError());
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  s.mask_factor = mask_factor; s.mask_big = false;
+  s.maxabs = max_abs;                                                                  // (all a masked slice knows of its values)
+  c->slices[t] = s;
+  return FTKX_OK;
+}
+
+int ftkx_sweep_cull(ftkx_ctx *c, int t_sparse, size_t *n_cells)
+{
+  if (!c || !n_cells) return fail(c, FTKX_E_INVALID, "null argument");
+  *n_cells = 0;
+  auto it = c->slices.find(t_sparse);
+  if (it == c->slices.end() || !it->second.sparse) return fail(c, FTKX_E_INVALID, "ftkx_sweep_cull: timestep %d is not a masked halo slice", t_sparse);
+  if (c->pending.empty()) return FTKX_OK;
+  for (const Request &r : c->pending) if (r.mode != MODE_FAST) return fail(c, FTKX_E_UNSUPPORTED, "ftkx_sweep_cull: the pending sweeps do not use the cull (send the slice itself)");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const double *field = it->second.S ? it->second.S : it->second.V;
+  int rc;
+  if ((rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16)))) return rc;
+  if ((rc = ensure_list(c, std::max<u64>(c->list_capacity, 1u << 20))) || (rc = ensure_refine(c, std::max<u64>(c->refine_capacity, 1u << 20)))) return rc;
+  for (int attempt = 0; attempt < 4; attempt ++) {
+    if (c->cells_cap < c->list_capacity) {
+      if (c->d_cells) (void)hipFree(c->d_cells);
+      c->d_cells = nullptr; c->cells_cap = 0;
+      HIP_TRY(c, hipMalloc((void **)&c->d_cells, c->list_capacity * sizeof(u64)));
+      c->cells_cap = c->list_capacity;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, ftkx::CNT_N * sizeof(u64), c->stream));
+    if ((rc = run_batch(c, field))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, ftkx::CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto &e : c->events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    c->events.clear();
+    const u64 listed = c->h_counters[ftkx::CNT_SURVIVOR_LIST], refined = std::max(c->h_counters[ftkx::CNT_REFINE_LIST], c->h_counters[ftkx::CNT_REFINE_PEAK]);
+    if (listed <= c->list_capacity && refined <= c->refine_capacity) { c->n_cells = (size_t)c->h_counters[ftkx::CNT_SPARSE]; *n_cells = c->n_cells; return FTKX_OK; }
+    if (refined > c->refine_capacity && (rc = ensure_refine(c, refined + refined / 8 + 1024))) return rc;
+    if (listed > c->list_capacity && (rc = ensure_list(c, 2 * listed + 1024))) return rc;
+  }
+  return fail(c, FTKX_E_DEVICE, "ftkx_sweep_cull: survivor lists kept overflowing");
+}
+
+int ftkx_get_sparse_cells(ftkx_ctx *c, unsigned long long *dst, int dst_on_device)
+{
+  if (!c || (c->n_cells && !dst)) return fail(c, FTKX_E_INVALID, "null argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = copy_out(c, dst, c->d_cells, c->n_cells * sizeof(u64), dst_on_device);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return FTKX_OK;
+}
+
+size_t ftkx_patch_doubles(const ftkx_ctx *c) { return c ? (size_t)(c->nd == 3 ? 216 : 36) * (size_t)(c->scalar_mode == 1 ? 1 : c->nd) : 0; }
+
+static int patches_common(ftkx_ctx *c, int t, const unsigned long long *cells, size_t n, double *patches, int on_device, bool scatter)
+{
+  if (!c || (n && (!cells || !patches))) return fail(c, FTKX_E_INVALID, "null argument");
+  auto it = c->slices.find(t);
+  if (it == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "patches: timestep %d not resident", t);
+  if (scatter && !it->second.sparse) return fail(c, FTKX_E_INVALID, "ftkx_scatter_patches: timestep %d is not a masked halo slice", t);
+  if (!n) return FTKX_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  Mesh m; fill_mesh(c, m);
+  const int ncomp = c->scalar_mode == 1 ? 1 : c->nd;
+  double *field = c->scalar_mode == 1 ? it->second.S : it->second.V;
+  const size_t pd = ftkx_patch_doubles(c);
+  const u64 *d_cells = cells; double *d_patches = patches;
+  if (!on_device) {                              // host-side callers (gloo tests): stage through device buffers
+    if (c->patch_cap < n) {
+      if (c->d_patch_cells) (void)hipFree(c->d_patch_cells);
+      if (c->d_patches) (void)hipFree(c->d_patches);
+      c->d_patch_cells = nullptr; c->d_patches = nullptr; c->patch_cap = 0;
+      HIP_TRY(c, hipMalloc((void **)&c->d_patch_cells, n * sizeof(u64)));
+      HIP_TRY(c, hipMalloc((void **)&c->d_patches, n * pd * sizeof(double)));
+      c->patch_cap = n;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_patch_cells, cells, n * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    if (scatter) HIP_TRY(c, hipMemcpyAsync(c->d_patches, patches, n * pd * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    d_cells = c->d_patch_cells; d_patches = c->d_patches;
+  }
+  ftkx::launch_patches(m, scatter, d_cells, n, ncomp, field, d_patches, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  if (!on_device && !scatter) HIP_TRY(c, hipMemcpyAsync(patches, c->d_patches, n * pd * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return FTKX_OK;
+}
+
+int ftkx_gather_patches(ftkx_ctx *c, int t, const unsigned long long *cells, size_t n, double *patches, int on_device)
+{ return patches_common(c, t, cells, n, patches, on_device, false); }
+int ftkx_scatter_patches(ftkx_ctx *c, int t, const unsigned long long *cells, size_t n, const double *patches, int on_device)
+{ return patches_common(c, t, cells, n, const_cast<double *>(patches), on_device, true); }
 
 int ftkx_set_slice_resolution(ftkx_ctx *c, int t, double resolution, double max_abs)
 {
@@ -933,6 +1147,8 @@ int ftkx_sweep_enqueue(ftkx_ctx *c, int t, int scope, unsigned long long factor)
   // (the tracker always passes 1 << nbits); any other factor a direct caller hands over takes the tile path, which quantises like
   // the reference.  Determinants that could leave int64 are dealt with per vertex (MaskJob::big), not per request.
   const bool fast = !c->opt.exact_only && pow2_factor(factor) && (nd == 2 || c->opt.robust);
+  if ((s0->sparse || (s1 && s1->sparse)) && (!fast || c->dense_collects > 0))
+    return fail(c, FTKX_E_UNSUPPORTED, "sweep: a masked halo slice only serves sweeps that use the cull (send the slice itself)");
   if (c->pending.empty()) memset(&c->stats, 0, sizeof(c->stats));
   c->pending.push_back(Request{t, scope, factor, fast ? (c->dense_collects > 0 ? MODE_TILE_CULL : MODE_FAST) : MODE_TILE});
 
@@ -994,6 +1210,13 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
     // a survivor list would be as large as the input.  Such a batch goes through the tile kernel instead, which stages each
     // tile's vertices once and applies the same cull rule in LDS.
     if (any_fast && (listed > c->list_capacity || refined > c->refine_capacity) && (listed > fast_cells / 8 || refined * 8 > fast_cells / 8)) {
+      for (const Request &r : c->pending) {
+        auto a = c->slices.find(r.t), b = c->slices.find(r.t + 1);
+        if ((a != c->slices.end() && a->second.sparse) || ((r.scope & FTKX_SCOPE_INTERVAL) && b != c->slices.end() && b->second.sparse)) {
+          c->pending.clear();
+          return fail(c, FTKX_E_UNSUPPORTED, "sweep: most cells survive the cull and a masked halo slice is involved (send the slice itself)");
+        }
+      }
       for (Request &r : c->pending) if (r.mode == MODE_FAST) r.mode = MODE_TILE_CULL;
       any_fast = false;
       c->dense_collects = 16;
@@ -1023,6 +1246,13 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
   }
   if (out) *out = c->h_hits;
   if (n_out) *n_out = n;
+  return FTKX_OK;
+}
+
+int ftkx_sweep_cancel(ftkx_ctx *c)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  c->pending.clear();
   return FTKX_OK;
 }
 

@@ -1691,6 +1691,108 @@ __global__ __launch_bounds__(kThreads) void record_kernel(const Mesh m, const Fi
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Compact t-slab halo.  The rank that owns a boundary slice hands its neighbour the slice's sign masks -- the summary
+// array U as it is and the mask words the summaries do not describe, compacted here -- instead of the slice; the neighbour culls
+// with them, asks for the input values around the few cells that survive (sparse_cells_kernel -> gather_patches_kernel on the
+// owner -> scatter_patches_kernel into an otherwise empty array on the neighbour) and runs the exact test on those.
+// ---------------------------------------------------------------------------------------------------------------
+// words of M whose summary byte is 0 (the only ones the mask kernels write): (index of the 8-byte word in M, its 8 bytes)
+__global__ __launch_bounds__(kThreads) void compact_words_kernel(const Mesh m, const unsigned char *__restrict__ U, const unsigned char *__restrict__ M,
+                                                                 unsigned *__restrict__ idx, u64 *__restrict__ words, u64 capacity, u64 *counter)
+{
+  const int UP = m.u_pitch, P = m.mask_pitch, DH = m.ext_sz[1], DD = m.nd == 3 ? m.ext_sz[2] : 1;
+  const int ngroups = (m.ext_sz[0] + 7) / 8;
+  const size_t total = (size_t)ngroups * DH * DD, padded = (total + 63) / 64 * 64;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < padded; i += (size_t)gridDim.x * kThreads) {
+    bool take = false;
+    size_t row = 0; int g = 0;
+    if (i < total) { row = i / ngroups; g = (int)(i - row * ngroups); take = U[row * (size_t)UP + g] == 0; }
+    const unsigned long long b = __ballot(take);
+    if (!b) continue;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)b) - 1;
+    u64 base = 0;
+    if (lane == leader) base = atomicAdd(counter, (u64)__popcll(b));
+    base = __shfl(base, leader);
+    if (take) {
+      const u64 slot = base + (u64)__popcll(b & ((1ull << lane) - 1ull));
+      const size_t w = (row * (size_t)P) / 8 + (size_t)g;                 // P is a multiple of 8: whole words
+      if (slot < capacity) { idx[slot] = (unsigned)w; words[slot] = reinterpret_cast<const u64 *>(M)[w]; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void scatter_words_kernel(const unsigned *__restrict__ idx, const u64 *__restrict__ words, size_t n, unsigned char *__restrict__ M)
+{
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) reinterpret_cast<u64 *>(M)[idx[i]] = words[i];
+}
+
+// survivors of the cull whose interval sweep reads the slice `sparse` (by its S or V pointer): their corner index inside core
+__global__ __launch_bounds__(kThreads) void sparse_cells_kernel(const Mesh m, const Fields *__restrict__ steps, const u64 *__restrict__ list, u64 list_capacity,
+                                                                const double *sparse, u64 *__restrict__ cells, u64 cells_capacity)
+{
+  u64 count = m.counters[CNT_SURVIVOR_LIST];
+  if (count > list_capacity) count = list_capacity;
+  const u64 padded = (count + 63) / 64 * 64;
+  for (u64 i = (u64)blockIdx.x * kThreads + threadIdx.x; i < padded; i += (u64)gridDim.x * kThreads) {
+    bool take = false;
+    u64 lin = 0;
+    if (i < count) {
+      const u64 e = list[i];
+      const Fields &f = steps[e >> 44];
+      lin = e & 0xffffffffffull;
+      take = ((e >> 40) & 2) && (f.S[1] == sparse || f.V[1] == sparse);
+    }
+    const unsigned long long b = __ballot(take);
+    if (!b) continue;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)b) - 1;
+    u64 base = 0;
+    if (lane == leader) base = atomicAdd(&m.counters[CNT_SPARSE], (u64)__popcll(b));
+    base = __shfl(base, leader);
+    if (take) { const u64 slot = base + (u64)__popcll(b & ((1ull << lane) - 1ull)); if (slot < cells_capacity) cells[slot] = lin; }
+  }
+}
+
+// the input values a cell's exact test and record can touch: array coordinates corner - 2 .. corner + 3 on every axis (vertices
+// 0/1, +-1 for the gradient, +-1 more for the Jacobian of the gradient), clamped to the array; ncomp values per vertex
+template <bool SCATTER>
+__global__ __launch_bounds__(kThreads) void patches_kernel(const Mesh m, const u64 *__restrict__ cells, size_t n, int ncomp, double *field, double *patches)
+{
+  const int nd = m.nd, pe = nd == 3 ? 216 : 36;
+  const size_t total = n * (size_t)pe;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (size_t)gridDim.x * kThreads) {
+    const size_t cell = i / pe;
+    int p = (int)(i - cell * pe);
+    u64 lin = cells[cell];
+    size_t at = 0, stride = 1;
+    for (int a = 0; a < nd; a ++) {
+      const int corner = m.core_st[a] + (int)(lin % (u64)m.core_sz[a]) - m.ext_st[a]; lin /= (u64)m.core_sz[a];
+      const int x = clampi(corner - 2 + p % 6, 0, m.ext_sz[a] - 1); p /= 6;
+      at += (size_t)x * stride; stride *= (size_t)m.ext_sz[a];
+    }
+    for (int c = 0; c < ncomp; c ++) {
+      if (SCATTER) field[at * ncomp + c] = patches[i * ncomp + c];
+      else patches[i * ncomp + c] = field[at * ncomp + c];
+    }
+  }
+}
+
+void launch_compact_words(const Mesh &m, const unsigned char *U, const unsigned char *M, unsigned *idx, u64 *words, u64 capacity, u64 *counter, hipStream_t st)
+{ hipLaunchKernelGGL(compact_words_kernel, dim3(256 * 8), dim3(kThreads), 0, st, m, U, M, idx, words, capacity, counter); }
+void launch_scatter_words(const unsigned *idx, const u64 *words, size_t n, unsigned char *M, hipStream_t st)
+{ if (n) hipLaunchKernelGGL(scatter_words_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, idx, words, n, M); }
+void launch_sparse_cells(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, const double *sparse, u64 *cells, u64 cells_cap, hipStream_t st)
+{ hipLaunchKernelGGL(sparse_cells_kernel, dim3(256 * 2), dim3(kThreads), 0, st, m, d_steps, d_list, cap, sparse, cells, cells_cap); }
+void launch_patches(const Mesh &m, bool scatter, const u64 *cells, size_t n, int ncomp, double *field, double *patches, hipStream_t st)
+{
+  if (!n) return;
+  size_t b = (n * (m.nd == 3 ? 216 : 36) + kThreads - 1) / kThreads;
+  if (b > 4096) b = 4096;
+  if (scatter) hipLaunchKernelGGL(patches_kernel<true>, dim3((unsigned)b), dim3(kThreads), 0, st, m, cells, n, ncomp, field, patches);
+  else hipLaunchKernelGGL(patches_kernel<false>, dim3((unsigned)b), dim3(kThreads), 0, st, m, cells, n, ncomp, field, patches);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // ndarray::resolution() of V = gradient(S) without materialising V (include/ftk/ndarray.hh:770-778 over grad.hh's output):
 // min over non-zero finite |v| and max finite |v| as raw IEEE bit patterns (they order like unsigned integers for v >= 0)
 // ---------------------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ typedef unsigned long long u64;
 typedef long long i64;
 
 enum { CNT_HITS = 0, CNT_CELLS_SURVIVED = 1, CNT_SIMPLICES_TESTED = 2, CNT_SURVIVOR_LIST = 3, CNT_LIST_PEAK = 4,
-       CNT_REFINE_LIST = 5, CNT_REFINE_PEAK = 6, CNT_WORDS_REFINED = 7, CNT_PASS = 8, CNT_N = 9 };
+       CNT_REFINE_LIST = 5, CNT_REFINE_PEAK = 6, CNT_WORDS_REFINED = 7, CNT_PASS = 8, CNT_SPARSE = 9, CNT_N = 10 };
 
 // A simplex that passed the test, handed from the integer kernels (exact_kernel, tile_kernel) to record_kernel, which does all the
 // FP64 work (solve, lerp, Jacobian, classification) on densely packed lanes: corner index inside core (x fastest) | type | request.

@@ -94,6 +94,126 @@ def exchange_halo(first_slice, recv_buffer, nt, group=None):
     return got
 
 
+def _p2p(ops):
+    import torch.distributed as dist
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+def compact_halo_masks(ctx, own, nt, scalar_input, group=None):
+    """Compact halo, step 1 (instead of exchange_halo's whole slice): every rank sends the sign masks of its FIRST slice -- the
+    summary array and the mask words the summaries do not describe (ftkx_export_masks; the slice must have been prepared) -- to the
+    owner of the preceding timestep, which pushes them as a masks-only slice.  Returns (t_masked or None, bytes sent, bytes received)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t0, t1 = (own[0], own[-1] + 1) if own else (0, 0)
+    send_to = owner_of(t0 - 1, nt, world) if own and t0 > 0 else None
+    recv_from = owner_of(t1, nt, world) if own and t1 < nt else None
+    sent = received = 0
+    payload = None
+    ops = []
+    if send_to is not None:
+        U, idx, words, mf, mx = ctx.export_masks(t0, torch, dev)
+        payload = (U, idx, words)
+        head = torch.tensor([float(len(idx)), float(mf), float(mx), float(len(U))], dtype=torch.float64, device=dev)
+        ops.append(dist.P2POp(dist.isend, head, send_to, group))
+    if recv_from is not None:
+        rhead = torch.zeros((4,), dtype=torch.float64, device=dev)
+        ops.append(dist.P2POp(dist.irecv, rhead, recv_from, group))
+    _p2p(ops)
+    ops = []
+    if send_to is not None:
+        for tns in payload:
+            if len(tns):
+                ops.append(dist.P2POp(dist.isend, tns, send_to, group)); sent += tns.numel() * tns.element_size()
+    if recv_from is not None:
+        n_words, mf, mx, ub = int(rhead[0].item()), int(rhead[1].item()), float(rhead[2].item()), int(rhead[3].item())
+        rU = torch.empty((ub,), dtype=torch.uint8, device=dev)
+        ridx = torch.empty((n_words,), dtype=torch.int32, device=dev)
+        rwords = torch.empty((n_words,), dtype=torch.int64, device=dev)
+        for tns in (rU, ridx, rwords):
+            if len(tns):
+                ops.append(dist.P2POp(dist.irecv, tns, recv_from, group)); received += tns.numel() * tns.element_size()
+    _p2p(ops)
+    if recv_from is not None:
+        ctx.push_masked_slice(t1, scalar_input, rU, ridx, rwords, mf, mx)
+        return t1, sent, received
+    return None, sent, received
+
+
+def compact_halo_patches(ctx, own, nt, t_masked, first_slice=None, halo_buffer=None, push_full=None, group=None):
+    """Compact halo, step 2 (after sweep_enqueue, before sweep_collect): cull; the cells whose exact test reads the masked slice go to
+    its owner, which answers with the input values around them (6^nd vertices per cell); they are scattered into the masked slice.
+    Where that would move MORE than the slice itself (hit-dense data on small slices: thousands of surviving cells) the receiver
+    asks for the whole slice instead (count -1): the owner sends `first_slice`, the receiver takes it into `halo_buffer` and hands
+    it to `push_full(t, tensor)`, which must cancel the pending sweeps (ftkx_sweep_cancel), push it like any other slice and leave
+    it to the caller to enqueue the sweeps again.
+    Returns (cells requested or -1, bytes sent, bytes received)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t0, t1 = (own[0], own[-1] + 1) if own else (0, 0)
+    serve = owner_of(t0 - 1, nt, world) if own and t0 > 0 else None          # the rank that holds OUR first slice as masks only
+    ask = owner_of(t1, nt, world) if t_masked is not None else None
+    sent = received = 0
+    cells = ctx.sweep_cull(t_masked, torch, dev) if ask is not None else None
+    want_full = False
+    if ask is not None and halo_buffer is not None and push_full is not None:
+        want_full = len(cells) * ctx.patch_doubles() * 8 > halo_buffer.numel() * halo_buffer.element_size() // 2
+    ops = []
+    if ask is not None:
+        ops.append(dist.P2POp(dist.isend, torch.tensor([-1 if want_full else len(cells)], dtype=torch.int64, device=dev), ask, group))
+    if serve is not None:
+        n_theirs = torch.zeros((1,), dtype=torch.int64, device=dev)
+        ops.append(dist.P2POp(dist.irecv, n_theirs, serve, group))
+    _p2p(ops)
+    serve_full = serve is not None and int(n_theirs.item()) < 0
+    if want_full or serve_full:
+        # the whole slice after all (staged through host memory when the backend cannot move device tensors)
+        staged = dist.get_backend(group) != "nccl"
+        ops = []
+        if serve_full:
+            src = first_slice.cpu() if (staged and first_slice.is_cuda) else first_slice
+            ops.append(dist.P2POp(dist.isend, src, serve, group)); sent += src.numel() * src.element_size()
+        if want_full:
+            dst = torch.empty(halo_buffer.shape, dtype=halo_buffer.dtype) if (staged and halo_buffer.is_cuda) else halo_buffer
+            ops.append(dist.P2POp(dist.irecv, dst, ask, group)); received += dst.numel() * dst.element_size()
+        _p2p(ops)
+        if want_full:
+            if dst is not halo_buffer:
+                halo_buffer.copy_(dst)
+            push_full(t_masked, halo_buffer)
+        # what is left for the patch exchange below: the side(s) that did not switch to the whole slice
+        if want_full:
+            ask = None
+        if serve_full:
+            serve = None
+    ops = []
+    if ask is not None and len(cells):
+        ops.append(dist.P2POp(dist.isend, cells, ask, group)); sent += cells.numel() * 8
+    theirs = None
+    if serve is not None and int(n_theirs.item()) > 0:
+        theirs = torch.empty((int(n_theirs.item()),), dtype=torch.int64, device=dev)
+        ops.append(dist.P2POp(dist.irecv, theirs, serve, group)); received += theirs.numel() * 8
+    _p2p(ops)
+    ops = []
+    if theirs is not None:
+        out = ctx.gather_patches(t0, theirs, torch)
+        ops.append(dist.P2POp(dist.isend, out, serve, group)); sent += out.numel() * 8
+    mine = None
+    if ask is not None and len(cells):
+        mine = torch.empty((len(cells) * ctx.patch_doubles(),), dtype=torch.float64, device=dev)
+        ops.append(dist.P2POp(dist.irecv, mine, ask, group)); received += mine.numel() * 8
+    _p2p(ops)
+    if mine is not None:
+        ctx.scatter_patches(t_masked, cells, mine)
+    return (-1 if want_full else (len(cells) if cells is not None else 0)), sent, received
+
+
 def gather_records(recs, dst=0, group=None):
     """The merge step of the t-slab partition (SURVEY 8e; what critical_point_tracker.hh:689 does with `diy::mpi::gather` of
     the discrete points): every rank's hit records go to rank `dst`, which gets them as ONE array sorted by tag -- ready for

@@ -133,6 +133,29 @@ int ftkx_slices_prepare(ftkx_ctx *ctx, const int *timesteps, int n, unsigned lon
 /* update_vector_field_scaling_factor (critical_point_tracker.hh:850-864): nbits = clamp(ceil(log2(1/res)), 8, 21) */
 unsigned long long ftkx_scaling_factor(double resolution, int *nbits);
 
+/* ---- compact t-slab halo (multi-GPU, one process per GPU: DESIGN.md 6) ------------------------------------------------------
+ * A rank's last interval sweep [t-1, t] reads the first slice of the NEXT rank's slab.  Instead of that slice (1 GiB for 512^3) its
+ * owner can hand over what the sweep really uses of it: the sign masks -- factor-free since round 2: the summary array as it is
+ * plus the compacted mask words the summaries do not describe -- and, after the receiver's cull, the input values around the few
+ * cells that survived there (6^nd vertices per cell: corner - 2 .. corner + 3 on every axis).
+ *   owner:     ftkx_slices_prepare(t) ... ftkx_export_masks_size(t) -> sizes; ftkx_export_masks(t) -> buffers to send
+ *   receiver:  ftkx_push_masked_slice(t, ...); ftkx_sweep_enqueue(...) as usual; ftkx_sweep_cull(t) -> n cells;
+ *              ftkx_get_sparse_cells -> send to the owner
+ *   owner:     ftkx_gather_patches(t, cells) -> send back          receiver: ftkx_scatter_patches(t, cells, patches); ftkx_sweep_collect
+ * `*_on_device` = 1: the caller's buffers are device memory of this context's device; 0: host memory.
+ * Limits: meshes whose masks carry summaries (even row length multiple of 8, slices < 4 GiB) and sweeps that use the cull; a masked
+ * slice whose masks cannot serve the factor of the sweep (FTKX_E_NOSLICE) or any other limit (FTKX_E_UNSUPPORTED) means: send the
+ * slice itself (ftkx_push_scalar_slice). */
+int ftkx_export_masks_size(ftkx_ctx *ctx, int t, size_t *u_bytes, size_t *n_words, unsigned long long *mask_factor, double *max_abs);
+int ftkx_export_masks(ftkx_ctx *ctx, int t, void *U_dst, unsigned *word_index_dst, unsigned long long *words_dst, int dst_on_device);
+int ftkx_push_masked_slice(ftkx_ctx *ctx, int t, int scalar_input, const void *U, const unsigned *word_index, const unsigned long long *words, size_t n_words,
+                           unsigned long long mask_factor, double max_abs, int on_device);
+int ftkx_sweep_cull(ftkx_ctx *ctx, int t_masked, size_t *n_cells);
+int ftkx_get_sparse_cells(ftkx_ctx *ctx, unsigned long long *dst, int dst_on_device);
+size_t ftkx_patch_doubles(const ftkx_ctx *ctx);      /* doubles per cell in a patch buffer */
+int ftkx_gather_patches(ftkx_ctx *ctx, int t, const unsigned long long *cells, size_t n, double *patches, int on_device);
+int ftkx_scatter_patches(ftkx_ctx *ctx, int t, const unsigned long long *cells, size_t n, const double *patches, int on_device);
+
 /* ---- the sweep ------------------------------------------------------------------------------------------------- */
 /* Sweeps the simplices of `scope` whose corner lies in `core` at time t (interval: [t, t+1], needs slice t+1).
  * `factor` = vector_field_scaling_factor: any non-zero value is honoured (quantisation is trunc(v * factor) like 2d:605-616), but the
@@ -145,6 +168,7 @@ int ftkx_sweep(ftkx_ctx *ctx, int t, int scope, unsigned long long factor, const
  * launch covers every enqueued timestep), synchronises and returns the records of ALL of them (sorted by tag). */
 int ftkx_sweep_enqueue(ftkx_ctx *ctx, int t, int scope, unsigned long long factor);
 int ftkx_sweep_collect(ftkx_ctx *ctx, const ftkx_cp_t **out, size_t *n_out);
+int ftkx_sweep_cancel(ftkx_ctx *ctx);    /* forgets the enqueued, not yet collected sweeps */
 
 /* counters of the last collect: simplices visited (work items), cells/simplices surviving the cull, device-side hits */
 typedef struct ftkx_stats {

@@ -41,7 +41,7 @@ def test_slab_count_does_not_change_the_result(cfg, tmp_path):
     assert one["n_gpus"] == 1 and one["check"]["hits"] > 0
     ref = np.load(tmp_path / "one.npz")
     assert one["pass2"]["records"] == len(ref["records"]) == one["check"]["hits"] and one["pass2"]["curves"] == len(ref["curve_loop"]) > 0
-    for n, extra in ((2, ()), (3, ()), (2, ("--halo-in-loop",))):
+    for n, extra in ((2, ()), (3, ()), (2, ("--halo-in-loop",)), (2, ("--compact-halo",)), (3, ("--compact-halo",))):
         many = _bench(n, cfg, extra, dump=tmp_path / f"many{n}.npz")
         got = np.load(tmp_path / f"many{n}.npz")
         # the merged record set (72-byte records, bit for bit) and the curves traced from it: identical to the single-rank run
@@ -52,5 +52,15 @@ def test_slab_count_does_not_change_the_result(cfg, tmp_path):
         assert many["n_gpus"] == n and many["scaling"] == "strong"
         assert many["check"]["hits"] == one["check"]["hits"]
         assert many["config"]["simplices_per_step"] == one["config"]["simplices_per_step"]
-        assert many["halo_exchange"]["in_timed_region"] == (len(extra) > 0) and many["halo_exchange"]["bytes_per_rank"] > 0
+        if "--compact-halo" in extra:
+            # the boundary slice travelled as sign masks + patches around the surviving cells: a small fraction of its bytes
+            h = many["halo_exchange"]
+            moved = h["bytes_sent_per_pass_this_rank"] + h["bytes_received_per_pass_this_rank"]
+            assert h["compact"] and moved > 0
+            if cfg == "small3":     # smooth 3D data: a few cells survive at the boundary -- a small fraction of the slice's bytes
+                assert moved < 0.25 * h["full_slice_bytes"] and h["cells_requested_per_pass_this_rank"] > 0 and h["passes_that_fell_back_to_the_whole_slice"] == 0
+            else:                   # hit-dense 2D data on small slices: patches would be more bytes than the slice -> the protocol falls back to it
+                assert h["passes_that_fell_back_to_the_whole_slice"] > 0
+        else:
+            assert many["halo_exchange"]["in_timed_region"] == (len(extra) > 0) and many["halo_exchange"]["bytes_per_rank"] > 0
         assert many["config"]["nbits"] == one["config"]["nbits"]

@@ -1,0 +1,1 @@
+timeout 900 python -m pytest tests/test_gpu_multirank.py -m gpu -q -x 2>&1 | tail -15
