@@ -733,8 +733,6 @@ __global__ __launch_bounds__(kThreads) void mask_march_kernel(const Mesh m, cons
   if (job.red) red_commit(job.red, red_mn, red_mx, blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + (unsigned)wv);
 }
 
-__device__ inline bool bits_dummy_guard(double thr) { return thr < 1e300; }   // always true for real thresholds; opaque to the optimiser
-
 // ---------------------------------------------------------------------------------------------------------------
 // The same walk as mask_march2_kernel<ND, EDGE = true, REDUCE> on a VALU diet.  rocprofv3 showed the kernel above issue-bound
 // (VALUBusy 72 %, 2.96e9 VALU instructions per 512^3 x 32 launch) rather than HBM-bound, so this version removes instructions
@@ -855,6 +853,22 @@ __device__ inline double edge_for_row(double xe)
   return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
+// summary byte of an aligned 8-vertex word from the pair of mask bytes each of the quad's four lanes holds: the sign bits ALL
+// eight vertices share.  Three VALU instructions (SDWA byte select, then the AND folded into the DPP quad permutes); written by
+// hand because the compiler emits mov_dpp + and pairs (7 instructions).  s_nop 1 = the two wait states a DPP read needs after a
+// VALU write of its source.
+__device__ inline unsigned word_summary(unsigned bits)
+{
+  unsigned q;
+  asm("v_and_b32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+      "s_nop 1\n\t"
+      "v_and_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_and_b32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : "=&v"(q) : "v"(bits));
+  return q;
+}
+
 // What the marching kernels do per row beside the sign bits, so that ONE pass over S serves the whole sweep (MaskJob):
 //   * running max of |d| per column (a0 / a1 = this lane's two vertices): the slice's max |v|;
 //   * candidates for the slice's resolution: only components WITHOUT a strict sign (|v| < threshold) can lower the scaling
@@ -934,7 +948,7 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
   {
     const int t0c = (int)bx * 128;                             // the tile's first column
     const int xr = lane < RY ? lane : (lane >= 64 - RY ? lane - (64 - RY) : -1);
-    if (xr >= 0 && !(swizzle & 32)) {                          // (swizzle bit 32: profiling experiment, no edge fetches, wrong results at tile edges)
+    if (xr >= 0) {
       const int col = lane < RY ? (t0c > 0 ? t0c - 1 : 0) : (t0c + 128 < DW ? t0c + 128 : DW - 1);
       xoff = sy * (unsigned)clampi(j0 + xr, 0, DH - 1) + (unsigned)col * 8u;
     }
@@ -970,8 +984,7 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
   };
 
   const bool in_row = i0 < DW;
-  const bool debug_no_store = (swizzle & 2) != 0 && bits_dummy_guard(thr);   // profiling experiment only: results are then garbage
-  const bool store_ok = in_row && !debug_no_store;
+  const bool store_ok = in_row;
   const unsigned mcol = (unsigned)i0, ucol = (unsigned)(i0 >> 3);
   const bool u_lane = (lane & 3) == 0 && in_row;
   double red_mn = DBL_MAX, red_mx = 0.0;
@@ -996,13 +1009,6 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
     const bool z_int = ND == 2 || (k >= 1 && k < DD - 1);
     const unsigned mplane = (unsigned)P * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
     const unsigned uplane = (unsigned)m.u_pitch * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
-    if (swizzle & 128) {   // profiling experiment: consume the loaded planes with one xor per register and nothing else
-      long long acc = __double_as_longlong(XC);
-      for (int r = 0; r < RY + 2; r ++) acc ^= __double_as_longlong(CU[r].x) ^ __double_as_longlong(CU[r].y);
-      for (int r = 1; r <= RY; r ++) acc ^= __double_as_longlong(NX[r].x) ^ __double_as_longlong(PR[r].y);
-      if (acc == 0x7ff8123456789abcll && k < z1) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)acc, rM, mcol, mplane, 0);
-      return;
-    }
     static_for<RY>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       const v2d c = CU[r + 1];
@@ -1025,11 +1031,6 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
         return;
       }
       unsigned a0 = 0, a1 = 0;
-      if (swizzle & 64) {   // profiling experiment: (almost) no arithmetic between the loads and the stores; results are garbage
-        const v2d q0 = CU[r], q2 = CU[r + 2], qn = NX[r + 1], qp = PR[r + 1];
-        a0 = (unsigned)(__double_as_longlong(c.x) ^ __double_as_longlong(q0.x) ^ __double_as_longlong(q2.x) ^ __double_as_longlong(qn.x) ^ __double_as_longlong(qp.x) ^ __double_as_longlong(XC)) & 0x3fu;
-        a1 = (unsigned)(__double_as_longlong(c.y) ^ __double_as_longlong(q0.y) ^ __double_as_longlong(q2.y) ^ __double_as_longlong(qn.y) ^ __double_as_longlong(qp.y)) & 0x3fu;
-      } else
       shift_in_signs<ND>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, tneg, tpos);
       if (ND == 2) { a0 = ((a0 & 0xcu) << 1) | (a0 & 3u); a1 = ((a1 & 0xcu) << 1) | (a1 & 3u); }   // leave the two z bits empty
       const bool rok = ((row_ok >> r) & 1) && k < z1;
@@ -1086,22 +1087,6 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
 // One s_barrier per plane: when it is passed, plane k+1 has landed (the producer waited for it with s_waitcnt vmcnt) and every
 // consumer has finished reading plane k's slot, which the producer then refills with plane k+1+PD.  Same mask / summary bytes.
 // ---------------------------------------------------------------------------------------------------------------
-// summary byte of an aligned 8-vertex word from the pair of mask bytes each of the quad's four lanes holds: the sign bits ALL
-// eight vertices share.  Three VALU instructions (SDWA byte select, then the AND folded into the DPP quad permutes); written by
-// hand because the compiler emits mov_dpp + and pairs (7 instructions).  s_nop 1 = the two wait states a DPP read needs after a
-// VALU write of its source.
-__device__ inline unsigned word_summary(unsigned bits)
-{
-  unsigned q;
-  asm("v_and_b32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
-      "s_nop 1\n\t"
-      "v_and_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_and_b32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-      : "=&v"(q) : "v"(bits));
-  return q;
-}
-
 // CY x RY = tile rows (CY consumer wavefronts of RY rows each, the tile is 128 columns wide), PD = planes in flight beyond the
 // one consumed next.  LDS: PD + 1 row slots of (CY RY + 2) KiB, and a ring of PD + 2 edge entries (256 B: the left and right
 // outside-neighbour value of each own row of a plane, fetched by ONE wavefront instruction).  The ring is one entry longer than
@@ -1213,8 +1198,7 @@ __global__ __launch_bounds__(64 * (CY + 1)) void mask_march5_kernel(const Mesh m
     if (j >= 1 && j < DH - 1) row_int |= 1u << r;
   }
   const bool in_row = i0 < DW;
-  const bool debug_no_store = (swizzle & 2) != 0 && bits_dummy_guard(thr);
-  const bool store_ok = in_row && !debug_no_store;
+  const bool store_ok = in_row;
   const unsigned mcol = (unsigned)i0, ucol = (unsigned)(i0 >> 3);
   const bool u_lane = (lane & 3) == 0 && in_row;
   // fused pre-pass: see guard_and_reduce
@@ -1231,14 +1215,7 @@ __global__ __launch_bounds__(64 * (CY + 1)) void mask_march5_kernel(const Mesh m
 
   auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], v2d (&NX)[RY + 2], int k) {
     __builtin_amdgcn_s_barrier();                              // plane k+1 is in LDS; nobody reads plane k's slot any more
-    if (swizzle & 128) return;                                 // profiling experiment: the producer's stream alone (results are garbage)
     take_plane(NX, k + 1 < z1 ? k + 1 : z1);
-    if (swizzle & 64) {                                        // profiling experiment: + the consumers' LDS reads, no arithmetic, no stores
-      long long acc = 0;
-      for (int r = 0; r < RY + 2; r ++) acc ^= __double_as_longlong(NX[r].x) ^ __double_as_longlong(NX[r].y);
-      if (acc == 0x7ff8123456789abcll) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)acc, rM, mcol, 0, 0);
-      return;
-    }
     const char *eb = lds + edge_of(k < z1 ? k : z1) + eown;    // plane k's outside neighbours (planes past the chunk re-walk plane z1)
     const bool z_dom = k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2];
     const bool z_int = k >= 1 && k < DD - 1;
