@@ -1904,15 +1904,17 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
             hipLaunchKernelGGL((mask_march5_kernel<PD_, CY_, RY_>), grid5, dim3(64u * (CY_ + 1)), bytes, stream, m, d_jobs, zchunk, sw); } while (0)
           // FTKX_MASK_TILE: 0 = 128 x 12 as three consumers of 4 rows (default), 1 = 128 x 16 (4 x 4), 2 = 128 x 8 (2 x 4), 3 = 128 x 16 (8 x 2),
           // 4 = 128 x 16 (2 x 8), 5 = 128 x 12 (6 x 2), 6 = 128 x 8 (4 x 2), 7 = 128 x 10 (5 x 2)
-          if (shape == 1) { if (pd5 == 3) FTKX_M5(3, 4, 4); else if (pd5 == 1) FTKX_M5(1, 4, 4); else FTKX_M5(2, 4, 4); }
-          else if (shape == 2) { if (pd5 == 3) FTKX_M5(3, 2, 4); else FTKX_M5(2, 2, 4); }
+          if (shape == 1) { if (pd5 == 3) FTKX_M5(3, 4, 4); else if (pd5 == 1) FTKX_M5(1, 4, 4); else if (pd5 == 4) FTKX_M5(4, 4, 4); else FTKX_M5(2, 4, 4); }
+          else if (shape == 2) { if (pd5 == 3) FTKX_M5(3, 2, 4); else if (pd5 == 5) FTKX_M5(5, 2, 4); else if (pd5 == 6) FTKX_M5(6, 2, 4); else FTKX_M5(2, 2, 4); }
           else if (shape == 3) { if (pd5 == 3) FTKX_M5(3, 8, 2); else FTKX_M5(2, 8, 2); }
           else if (shape == 4) FTKX_M5(2, 2, 8);
           else if (shape == 5) { if (pd5 == 3) FTKX_M5(3, 6, 2); else FTKX_M5(2, 6, 2); }
-          else if (shape == 6) { if (pd5 == 3) FTKX_M5(3, 4, 2); else FTKX_M5(2, 4, 2); }
+          else if (shape == 6) { if (pd5 == 3) FTKX_M5(3, 4, 2); else if (pd5 == 5) FTKX_M5(5, 4, 2); else if (pd5 == 6) FTKX_M5(6, 4, 2); else FTKX_M5(2, 4, 2); }
           else if (shape == 7) FTKX_M5(2, 5, 2);
           else if (pd5 == 1) FTKX_M5(1, 3, 4);
           else if (pd5 == 3) FTKX_M5(3, 3, 4);
+          else if (pd5 == 4) FTKX_M5(4, 3, 4);
+          else if (pd5 == 5) FTKX_M5(5, 3, 4);
           else FTKX_M5(2, 3, 4);
 #undef FTKX_M5
           return;
