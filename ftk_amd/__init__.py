@@ -272,6 +272,41 @@ def trace_curves(nd, domain, records):
     return [idx[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)], loop, nspecial
 
 
+class OnlineTracer:
+    """ftkx_online_tracer: trace_critical_points_online (enable_streaming_trajectories) on record arrays"""
+
+    def __init__(self, nd, domain):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        _lib.check(self._L.ftkx_online_tracer_create(C.byref(self._h), nd, _lib.ll(domain[0]), _lib.ll(domain[1], fill=1)))
+
+    def grow(self, records):
+        recs = np.ascontiguousarray(records, dtype=CP_DTYPE)
+        _lib.check(self._L.ftkx_online_tracer_grow(self._h, recs.ctypes.data, len(recs)))
+
+    def curves(self):
+        """-> (list of record arrays, one per trajectory in order of birth; loop flags)"""
+        pts, out = C.c_void_p(), _lib.Curves()
+        _lib.check(self._L.ftkx_online_tracer_curves(self._h, C.byref(pts), C.byref(out)))
+        n = out.n_points
+        recs = np.frombuffer(C.string_at(pts.value, max(1, n) * CP_DTYPE.itemsize), dtype=CP_DTYPE)[:n].copy()
+        offs = np.ctypeslib.as_array(out.offsets, shape=(out.n_curves + 1,)).copy()
+        loop = np.ctypeslib.as_array(out.loop, shape=(max(1, out.n_curves),))[:out.n_curves].copy()
+        self._L.ftkx_free(pts); self._L.ftkx_free_curves(C.byref(out))
+        return [recs[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)], loop
+
+    def close(self):
+        if self._h:
+            self._L.ftkx_online_tracer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class TrajectorySet:
     """ftkx_trajectories as numpy arrays: curve c owns points offsets[c]:offsets[c+1]; per point the index into the record
     array, the (smoothed) type and the (adjusted) time; per curve the loop flag and its label in the reference's multimap."""
@@ -429,6 +464,7 @@ class _TrackerRegular:
     def set_tag_mode(self, m): self._flags["tag_mode"] = int(m)
     def set_stream(self, ptr): self._ck(self._L.ftkx_tracker_set_stream(self._h, C.c_void_p(ptr)))
     def set_current_timestep(self, t): self._ck(self._L.ftkx_tracker_set_current_timestep(self._h, int(t)))
+    def set_enable_streaming_trajectories(self, b): self._ck(self._L.ftkx_tracker_set_enable_streaming_trajectories(self._h, int(bool(b))))
     def set_coords_bounds(self, b): self._ck(self._L.ftkx_tracker_set_coords_bounds(self._h, (C.c_double * len(b))(*[float(x) for x in b])))
 
     def set_coords_rectilinear(self, arrays):

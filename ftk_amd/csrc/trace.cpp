@@ -343,9 +343,150 @@ int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs
   return FTKX_OK;
 }
 
+// trace_critical_points_online (filters/critical_point_tracker.hh:523-639), the enable_streaming_trajectories branch of
+// update_timestep (2d:326-330, 3d:197-201): called after every interval sweep with the discrete points found since the last call.
+//   1. every trajectory that is not complete is continued greedily, forwards from its last point and backwards from its first:
+//      the FIRST neighbour (in the element order of the reference's std::set) that is among the new points is appended and
+//      consumed, until none is left; a trajectory that could not be continued is complete;
+//   2. the points left over form new trajectories: connected components -> cc2curves, exactly as offline (trace_impl);
+//   3. the discrete points are forgotten.
+template <int N>
+int grow_impl(const long long *dst, const long long *dsz, std::vector<std::vector<ftkx_cp_t>> &curves, std::vector<int> &loop, std::vector<int> &complete,
+              const ftkx_cp_t *recs, size_t n)
+{
+  static const Adjacency<N> adj;
+  Tracer<N> tr(adj, dst, dsz);
+  {
+    std::vector<u64> tags(n);
+    for (size_t i = 0; i < n; i ++) tags[i] = recs[i].tag;
+    std::sort(tags.begin(), tags.end());
+    for (size_t i = 1; i < n; i ++) if (tags[i] == tags[i - 1]) return FTKX_E_INVALID;
+  }
+  tr.build_hash(recs, n);
+  std::vector<char> alive(n, 1);
+  std::vector<std::pair<Elem, int>> tmp;
+  for (size_t c = 0; c < curves.size(); c ++) {
+    if (complete[c] || curves[c].empty()) continue;
+    bool continued = false;
+    for (int dir = 0; dir < 2; dir ++) {
+      Elem cur = tr.decode(dir == 0 ? curves[c].back().tag : curves[c].front().tag);
+      for (;;) {
+        tr.neighbours(cur, tmp);
+        int next = -1;
+        for (const auto &cand : tmp) if (alive[cand.second]) { next = cand.second; cur = cand.first; break; }
+        if (next < 0) break;
+        if (dir == 0) curves[c].push_back(recs[next]); else curves[c].insert(curves[c].begin(), recs[next]);
+        alive[next] = 0;
+        continued = true;
+      }
+    }
+    if (!continued) complete[c] = 1;
+  }
+  std::vector<ftkx_cp_t> rest;
+  for (size_t i = 0; i < n; i ++) if (alive[i]) rest.push_back(recs[i]);
+  const size_t nr = rest.size();
+  ftkx_curves fresh;
+  memset(&fresh, 0, sizeof(fresh));
+  const int rc = trace_impl<N>(dst, dsz, rest.data(), nr, &fresh);
+  if (rc != FTKX_OK) { free(fresh.offsets); free(fresh.indices); free(fresh.loop); return rc; }
+  // The new trajectories are born in the order of the reference's extract_connected_components (algorithms/cca.hh:91-116): the
+  // components come out of union_find::get_sets (basic/union_find.hh:121-133) keyed by their ROOT element, and which member is
+  // the root follows from that union-find's union-by-size with its quirk -- uniting two members of one set (every element is
+  // united with itself: neighbors() contains it) adds the root's size to itself.  Emulated literally, sizes modulo 2^64.
+  Tracer<N> tr2(adj, dst, dsz);
+  tr2.build_hash(rest.data(), nr);
+  std::vector<Elem> el(nr);
+  for (size_t i = 0; i < nr; i ++) el[i] = tr2.decode(rest[i].tag);
+  std::vector<int> ord(nr);
+  for (size_t i = 0; i < nr; i ++) ord[i] = (int)i;
+  std::sort(ord.begin(), ord.end(), [&](int a, int b) { return elem_less(el[a], el[b], N); });
+  std::vector<int> parent(nr);
+  std::vector<u64> sz(nr, 1);
+  for (size_t i = 0; i < nr; i ++) parent[i] = (int)i;
+  auto find = [&](int x) { while (parent[x] != x) x = parent[x]; return x; };
+  for (int cur : ord) {
+    tr2.neighbours(el[cur], tmp);                         // in element order, without `cur` itself
+    bool self_done = false;
+    auto unite = [&](int a, int b) {
+      a = find(a); b = find(b);
+      if (sz[a] < sz[b]) { parent[a] = b; sz[b] += sz[a]; } else { parent[b] = a; sz[a] += sz[b]; }
+    };
+    for (const auto &cand : tmp) {
+      if (!self_done && elem_less(el[cur], cand.first, N)) { unite(cur, cur); self_done = true; }
+      unite(cur, cand.second);
+    }
+    if (!self_done) unite(cur, cur);
+  }
+  std::vector<std::pair<int, size_t>> birth;              // (rank of the component's root in element order, curve)
+  {
+    std::vector<int> rank(nr);
+    for (size_t i = 0; i < nr; i ++) rank[ord[i]] = (int)i;
+    for (size_t c = 0; c < fresh.n_curves; c ++)
+      if (fresh.offsets[c + 1] > fresh.offsets[c]) birth.push_back({rank[find((int)fresh.indices[fresh.offsets[c]])], c});
+    std::stable_sort(birth.begin(), birth.end(), [](const std::pair<int, size_t> &a, const std::pair<int, size_t> &b) { return a.first < b.first; });
+  }
+  for (const auto &bc : birth) {
+    const size_t c = bc.second;
+    std::vector<ftkx_cp_t> pts;
+    for (long long k = fresh.offsets[c]; k < fresh.offsets[c + 1]; k ++) pts.push_back(rest[(size_t)fresh.indices[k]]);
+    curves.push_back(std::move(pts)); loop.push_back(fresh.loop[c]); complete.push_back(0);
+  }
+  free(fresh.offsets); free(fresh.indices); free(fresh.loop);
+  return FTKX_OK;
+}
+
 }  // namespace
 
+struct ftkx_online_tracer {
+  int nd;
+  long long dst[3], dsz[3];
+  std::vector<std::vector<ftkx_cp_t>> curves;
+  std::vector<int> loop, complete;
+};
+
 extern "C" {
+
+int ftkx_online_tracer_create(ftkx_online_tracer **out, int nd, const long long domain_st[3], const long long domain_sz[3])
+{
+  if (!out || (nd != 2 && nd != 3) || !domain_st || !domain_sz) return FTKX_E_INVALID;
+  for (int d = 0; d < nd; d ++) if (domain_sz[d] <= 0) return FTKX_E_INVALID;
+  ftkx_online_tracer *t = new ftkx_online_tracer();
+  t->nd = nd;
+  for (int d = 0; d < 3; d ++) { t->dst[d] = d < nd ? domain_st[d] : 0; t->dsz[d] = d < nd ? domain_sz[d] : 1; }
+  *out = t;
+  return FTKX_OK;
+}
+
+void ftkx_online_tracer_destroy(ftkx_online_tracer *t) { delete t; }
+
+int ftkx_online_tracer_grow(ftkx_online_tracer *t, const ftkx_cp_t *recs, size_t n)
+{
+  if (!t || (n && !recs)) return FTKX_E_INVALID;
+  return t->nd == 2 ? grow_impl<3>(t->dst, t->dsz, t->curves, t->loop, t->complete, recs, n)
+                    : grow_impl<4>(t->dst, t->dsz, t->curves, t->loop, t->complete, recs, n);
+}
+
+int ftkx_online_tracer_curves(const ftkx_online_tracer *t, ftkx_cp_t **points, ftkx_curves *out)
+{
+  if (!t || !points || !out) return FTKX_E_INVALID;
+  memset(out, 0, sizeof(*out));
+  size_t np = 0;
+  for (const auto &c : t->curves) np += c.size();
+  *points = (ftkx_cp_t *)malloc((np ? np : 1) * sizeof(ftkx_cp_t));
+  out->offsets = (long long *)malloc((t->curves.size() + 1) * sizeof(long long));
+  out->indices = (long long *)malloc((np ? np : 1) * sizeof(long long));
+  out->loop = (int *)malloc((t->curves.size() ? t->curves.size() : 1) * sizeof(int));
+  if (!*points || !out->offsets || !out->indices || !out->loop) return FTKX_E_NOMEM;
+  size_t k = 0;
+  out->offsets[0] = 0;
+  for (size_t c = 0; c < t->curves.size(); c ++) {
+    for (const ftkx_cp_t &p : t->curves[c]) { (*points)[k] = p; out->indices[k] = (long long)k; k ++; }
+    out->offsets[c + 1] = (long long)k;
+    out->loop[c] = t->loop[c];
+  }
+  out->n_curves = t->curves.size(); out->n_points = np;
+  return FTKX_OK;
+}
 
 int ftkx_trace_curves(int nd, const long long domain_st[3], const long long domain_sz[3], const ftkx_cp_t *recs, size_t n, ftkx_curves *out)
 {

@@ -149,6 +149,7 @@ critical_point_tracker_regular::critical_point_tracker_regular(int nd_, const st
 
 critical_point_tracker_regular::~critical_point_tracker_regular()
 {
+  ftkx_online_tracer_destroy(online);
   if (multi) multi.reset();   // joins the workers, destroys their contexts (ctx is one of them)
   else ftkx_destroy(ctx);
 }
@@ -229,6 +230,7 @@ void critical_point_tracker_regular::initialize()
 void critical_point_tracker_regular::reset()
 {
   sync();
+  ftkx_online_tracer_destroy(online); online = nullptr;
   if (multi) { multi->base_resolution = vector_field_resolution; multi->res_below.clear(); multi->t_first = -1; }
   current_timestep = 0;
   while (pop_field_data_snapshot()) {}
@@ -351,8 +353,10 @@ void critical_point_tracker_regular::update_timestep()
     check(ftkx_sweep(ctx, current_timestep, scope, vector_field_scaling_factor, &recs, &n));
     take_records(recs, n, current_timestep);
     check(ftkx_get_stats(ctx, &last_stats));
+    if (enable_streaming_trajectories && scope == FTKX_SCOPE_BOTH) grow();      // 2d:326-330, 3d:197-201: only after an interval sweep
     return;
   }
+  if (enable_streaming_trajectories) throw ftkx_error(FTKX_E_UNSUPPORTED, "enable_streaming_trajectories: single-device trackers only");
   // Several devices: the step is queued on the device that owns its timestep and this call returns.  Inside the job: reduce
   // (and mask) the step's slices under the factor known so far, publish their contribution, wait for the contributions of ALL
   // earlier slices -- other devices publish theirs before they sweep, so this is a wait for reductions only -- and sweep under
@@ -395,9 +399,55 @@ bool critical_point_tracker_regular::advance_timestep()
 
 // critical_point_tracker_{2d,3d}_regular::finalize (2d:143-225, 3d:86-117) without streaming trajectories:
 // traced_critical_points = trace_critical_points_offline(discrete_critical_points, neighbours-sharing-a-cell)
+// trace_critical_points_online (critical_point_tracker.hh:523-639) on everything in discrete_critical_points, which it consumes
+void critical_point_tracker_regular::grow()
+{
+  long long dst[3] = {0, 0, 0}, dsz[3] = {1, 1, 1};
+  for (int d = 0; d < nd; d ++) { dst[d] = domain.start(d); dsz[d] = domain.size(d); }
+  if (!online) { const int rc = ftkx_online_tracer_create(&online, nd, dst, dsz); if (rc != FTKX_OK) throw ftkx_error(rc, "online tracer"); }
+  std::vector<ftkx_cp_t> recs;
+  recs.reserve(discrete_critical_points.size());
+  for (const auto &kv : discrete_critical_points) {
+    const feature_point_t &cp = kv.second;
+    ftkx_cp_t r;
+    std::memset(&r, 0, sizeof(r));
+    for (int k = 0; k < 3; k ++) { r.x[k] = cp.x[k]; r.scalar[k] = cp.scalar[k]; }
+    r.t = cp.t; r.type = cp.type; r.tag = cp.tag;
+    reinterpret_cast<unsigned int *>(&r)[15] = ((unsigned)cp.timestep << 1) | (cp.ordinal ? 1u : 0u);
+    recs.push_back(r);
+  }
+  const int rc = ftkx_online_tracer_grow(online, recs.data(), recs.size());
+  if (rc != FTKX_OK) throw ftkx_error(rc, "grow: ftkx_online_tracer_grow failed (element tags needed: FTKX_TAG_EXACT64, or REFERENCE where it does not wrap)");
+  discrete_critical_points.clear();
+}
+
 void critical_point_tracker_regular::finalize()
 {
   sync();
+  if (enable_streaming_trajectories) {             // 2d:150-151: "done" -- the trajectories are what grow() built
+    traced_critical_points.clear(); traced_loop.clear(); traced_id.clear();
+    if (!online) return;
+    ftkx_cp_t *pts = nullptr;
+    ftkx_curves c{};
+    const int rc = ftkx_online_tracer_curves(online, &pts, &c);
+    if (rc != FTKX_OK) { ftkx_free(pts); ftkx_free_curves(&c); throw ftkx_error(rc, "finalize: ftkx_online_tracer_curves failed"); }
+    for (size_t i = 0; i < c.n_curves; i ++) {
+      std::vector<feature_point_t> curve;
+      for (long long k = c.offsets[i]; k < c.offsets[i + 1]; k ++) {
+        const ftkx_cp_t &r = pts[k];
+        feature_point_t cp;
+        for (int q = 0; q < 3; q ++) { cp.x[q] = r.x[q]; cp.scalar[q] = r.scalar[q]; }
+        cp.t = r.t; cp.type = r.type; cp.tag = r.tag;
+        cp.ordinal = ftkx_cp_ordinal(&r) != 0; cp.timestep = ftkx_cp_timestep(&r);
+        curve.push_back(cp);
+      }
+      traced_critical_points.push_back(std::move(curve));
+      traced_loop.push_back(c.loop[i]);
+      traced_id.push_back((int)i);
+    }
+    ftkx_free(pts); ftkx_free_curves(&c);
+    return;
+  }
   std::vector<ftkx_cp_t> recs;
   std::vector<const feature_point_t *> pts;
   recs.reserve(discrete_critical_points.size());
@@ -630,6 +680,7 @@ int ftkx_tracker_set_flags(ftkx_tracker *h, int robust, int use_tf, unsigned tf,
   });
 }
 int ftkx_tracker_set_stream(ftkx_tracker *h, void *s) { return guarded(h, [&] { h->t->set_stream(s); }); }
+int ftkx_tracker_set_enable_streaming_trajectories(ftkx_tracker *h, int on) { return guarded(h, [&] { h->t->set_enable_streaming_trajectories(on != 0); }); }
 int ftkx_tracker_set_current_timestep(ftkx_tracker *h, int t)
 { return guarded(h, [&] { if (t < 0) throw ftkx::ftkx_error(FTKX_E_INVALID, "set_current_timestep: negative timestep"); h->t->set_current_timestep(t); }); }
 int ftkx_tracker_set_coords_bounds(ftkx_tracker *h, const double *b) { return guarded(h, [&] { h->t->set_coords_bounds(std::vector<double>(b, b + 2 * h->nd)); }); }

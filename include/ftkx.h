@@ -224,6 +224,17 @@ typedef struct ftkx_curves {
 int  ftkx_trace_curves(int nd, const long long domain_st[3], const long long domain_sz[3], const ftkx_cp_t *recs, size_t n, ftkx_curves *out);
 void ftkx_free_curves(ftkx_curves *c);
 
+/* enable_streaming_trajectories (critical_point_tracker.hh:38; update_timestep 2d:326-330, 3d:197-201): trajectories that grow while
+ * the sweep streams -- trace_critical_points_online (critical_point_tracker.hh:523-639).  After every interval sweep the caller hands
+ * over the discrete points found since the last call (they are consumed); open trajectories are continued greedily through the
+ * new points, the rest starts new trajectories.  ftkx_online_tracer_curves copies the trajectories out: *points (malloc'ed, release
+ * with ftkx_free) holds them one after the other, `out` the offsets / loop flags (indices = 0 .. n_points-1). */
+typedef struct ftkx_online_tracer ftkx_online_tracer;
+int  ftkx_online_tracer_create(ftkx_online_tracer **out, int nd, const long long domain_st[3], const long long domain_sz[3]);
+void ftkx_online_tracer_destroy(ftkx_online_tracer *);
+int  ftkx_online_tracer_grow(ftkx_online_tracer *, const ftkx_cp_t *recs, size_t n);
+int  ftkx_online_tracer_curves(const ftkx_online_tracer *, ftkx_cp_t **points, ftkx_curves *out);
+
 /* Trajectory post-processing with the defaults of json_interface::post_process (include/ftk/filters/json_interface.hh:758-800):
  * smooth_ordinal_types / smooth_interval_types / rotate, split_all, reorder / adjust_time (features/feature_curve.hh:220-348,
  * features/feature_curve_set.hh:514-532).  recs[] must carry the aux word (ordinal, timestep) the sweep writes.  Per point the

@@ -104,6 +104,9 @@ public:
   void set_jacobian_symmetric(bool s) { is_jacobian_field_symmetric = s; }
   void set_enable_robust_detection(bool b) { enable_robust_detection = b; }
   void set_enable_computing_degrees(bool b) { enable_computing_degrees = b; }
+  // critical_point_tracker.hh:38: trajectories grow after every interval sweep (trace_critical_points_online), the discrete
+  // points are consumed, finalize() only hands the trajectories over.  Single-device trackers.
+  void set_enable_streaming_trajectories(bool b) { enable_streaming_trajectories = b; }
   void set_type_filter(unsigned int f) { use_type_filter = true; type_filter = f; }
   // regular_tracker.hh:38 -- REGULAR_COORDS_BOUNDS: x0,x1,y0,y1[,z0,z1]
   void set_coords_bounds(const std::vector<double> &b) { bounds_coords = b; mode_phys_coords = 1; }
@@ -172,7 +175,9 @@ protected:
   lattice domain, array_domain, local_domain, local_array_domain;
   int scalar_field_source = SOURCE_NONE, vector_field_source = SOURCE_NONE, jacobian_field_source = SOURCE_NONE;
   bool is_jacobian_field_symmetric = false;
-  bool enable_robust_detection = true, enable_computing_degrees = false;
+  bool enable_robust_detection = true, enable_computing_degrees = false, enable_streaming_trajectories = false;
+  ftkx_online_tracer *online = nullptr;
+  void grow();                                                 // 2d:288-322: trace_critical_points_online on the points found since the last call
   bool use_type_filter = false;
   unsigned int type_filter = 0;
   bool exact_only = false;
@@ -229,7 +234,8 @@ int  ftkx_tracker_set_array_domain(ftkx_tracker *, const long long *starts, cons
 int  ftkx_tracker_set_sources(ftkx_tracker *, int scalar, int vector, int jacobian, int jacobian_symmetric);
 int  ftkx_tracker_set_flags(ftkx_tracker *, int robust, int use_type_filter, unsigned type_filter, int compute_degrees, int exact_only, int tag_mode);
 int  ftkx_tracker_set_stream(ftkx_tracker *, void *hip_stream);
-int  ftkx_tracker_set_current_timestep(ftkx_tracker *, int t);   /* tracker::set_current_timestep (filters/tracker.hh:40), before the first push */
+int  ftkx_tracker_set_current_timestep(ftkx_tracker *, int t);
+int  ftkx_tracker_set_enable_streaming_trajectories(ftkx_tracker *, int on);   /* critical_point_tracker.hh:38; before the first step */   /* tracker::set_current_timestep (filters/tracker.hh:40), before the first push */
 int  ftkx_tracker_set_coords_bounds(ftkx_tracker *, const double *bounds /* 2*nd values */);
 int  ftkx_tracker_set_coords_rectilinear(ftkx_tracker *, const double *x, size_t nx, const double *y, size_t ny, const double *z, size_t nz);
 int  ftkx_tracker_set_coords_explicit(ftkx_tracker *, const double *coords, int ncomp, size_t n0, size_t n1);

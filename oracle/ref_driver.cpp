@@ -219,6 +219,9 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
   if (type_filter) tracker.set_type_filter(type_filter);
   if (degrees) tracker.set_enable_computing_degrees(true);
   if (!bounds.empty()) tracker.set_coords_bounds(bounds);   // REGULAR_COORDS_BOUNDS, regular_tracker.hh:38
+  // FTK_REF_STREAMING: enable_streaming_trajectories (critical_point_tracker.hh:38): trajectories grow after every interval sweep
+  // (trace_critical_points_online, critical_point_tracker.hh:523-639), the discrete points are consumed, finalize() traces nothing
+  if (getenv("FTK_REF_STREAMING")) tracker.set_enable_streaming_trajectories(true);
   // REGULAR_COORDS_RECTILINEAR / _EXPLICIT (regular_tracker.hh:39-40) with closed-form, exactly representable coordinates:
   //   FTK_REF_COORDS=rect       axis d: 0.5 i + 0.0625 ((i (d + 3)) mod 5) + d
   //   FTK_REF_COORDS=explicit2  E(c, x, y) = 0.75 (c == 0 ? x : y) + 0.03125 ((3 x + 5 y + c) mod 11), two components

@@ -8,7 +8,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_names():
-    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))) if not n.startswith(("io_", "wrap_")))
+    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))) if not n.startswith(("io_", "wrap_", "streaming_")))
 
 
 def wrap_golden_names():
@@ -19,6 +19,18 @@ def wrap_golden_names():
 
 def io_golden_names():
     return sorted(os.path.basename(p)[3:-4] for p in glob.glob(os.path.join(GOLDEN, "io_*.npz")))
+
+
+def streaming_golden_names():
+    """the reference's enable_streaming_trajectories runs (tests/golden/make_golden_streaming.py): trajectories as tag sequences"""
+    return sorted(os.path.basename(p)[10:-4] for p in glob.glob(os.path.join(GOLDEN, "streaming_*.npz")))
+
+
+def load_streaming_golden(name):
+    z = np.load(os.path.join(GOLDEN, "streaming_" + name + ".npz"))
+    offs = z["curve_offsets"]
+    return dict(curves=[(int(z["curve_loop"][i]), z["curve_tags"][offs[i]:offs[i + 1]]) for i in range(len(z["curve_loop"]))],
+                leftover_tags=z["leftover_tags"], pp_count=int(z["pp_count"]))
 
 
 def load_io_golden(name):

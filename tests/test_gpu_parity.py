@@ -329,3 +329,29 @@ def test_multi_device_tracker_matches_reference_fixture(gpu, name, ndev, block):
         recs, factors, _ = run_tracker(g["steps"], g["nd"], g["nv"], device_ids=[0] * ndev, block=block, device=True, want_curves=False)
         assert np.array_equal(factors, g["factors"])
         assert_records_equal(recs, g["records"], coord_tol=0.0, what=name)
+
+
+def test_streaming_trajectories_equal_the_reference(gpu):
+    """enable_streaming_trajectories end to end on the GPU tracker: trajectories grown after every interval sweep from the HIP
+    sweep's records == the trajectories the real reference grew in the same mode (tests/golden/streaming_*.npz): same order of birth,
+    same point sequences, same loop flags; the last step's ordinal points stay behind as discrete points; post_process then gives the
+    reference's trajectory count."""
+    from gpu_common import run_tracker
+    from common import streaming_golden_names, load_streaming_golden
+    for name in streaming_golden_names():
+        g, sg = load_golden(name), load_streaming_golden(name)
+        state = {}
+
+        def after(tr):
+            tr.finalize()
+            state["curves"] = tr.get_traced_critical_points()
+            tr.post_process()
+            state["pp"] = len(tr.get_traced_critical_points()[0])
+        left, factors, _ = run_tracker(g["steps"], g["nd"], g["nv"], streaming=True, after=after)
+        assert np.array_equal(factors, g["factors"])
+        curves, loop = state["curves"]
+        got = [(tuple(c.tolist()), int(l)) for c, l in zip(curves, loop)]
+        exp = [(tuple(t.tolist()), int(l)) for l, t in sg["curves"]]
+        assert got == exp, name
+        assert np.array_equal(np.sort(left["tag"]), sg["leftover_tags"]), name
+        assert state["pp"] == sg["pp_count"], name

@@ -79,3 +79,36 @@ def test_duplicate_tags_are_rejected():
     recs = np.zeros(2, dtype=ftk_amd.CP_DTYPE)
     with pytest.raises(ftk_amd.FtkxError):
         ftk_amd.trace_curves(2, ([2, 2], [10, 10]), recs)
+
+
+def test_online_tracer_equals_reference_streaming_trajectories():
+    """enable_streaming_trajectories (critical_point_tracker.hh:523-639): fed the reference's discrete points step by step the way
+    update_timestep does (after every interval sweep everything found since the last call), ftkx_online_tracer grows the very
+    trajectories the real reference grew -- same trajectories in the same order of birth, same point sequences, same loop flags;
+    the last step's ordinal points stay behind as discrete points."""
+    import ftk_amd
+    from ftk_amd import build
+    from common import streaming_golden_names, load_streaming_golden
+    build.build()
+    names = streaming_golden_names()
+    assert len(names) >= 5
+    for name in names:
+        g, sg = load_golden(name), load_streaming_golden(name)
+        ref = g["records"]
+        recs = np.zeros(len(ref), dtype=ftk_amd.CP_DTYPE)
+        for f in ("tag", "type", "x", "t"):
+            recs[f] = ref[f]
+        recs["aux"] = (ref["ordinal"].astype(np.uint32) & 1) | (ref["timestep"].astype(np.uint32) << 1)
+        scalar = g["nv"] == 1
+        lo = 2 if scalar else 1
+        dom = ([lo] * g["nd"], [d - (3 if scalar else 2) for d in g["dims"]])
+        tr = ftk_amd.OnlineTracer(g["nd"], dom)
+        DT = g["DT"]
+        for t in range(DT - 1):                                   # the last step has no interval sweep: no grow()
+            tr.grow(recs[ref["timestep"] == t])
+        curves, loop = tr.curves()
+        got = [(tuple(c["tag"].tolist()), int(l)) for c, l in zip(curves, loop)]
+        exp = [(tuple(tg.tolist()), int(l)) for l, tg in sg["curves"]]
+        assert got == exp, name                                   # including the order in which the trajectories were born
+        assert np.array_equal(np.sort(recs["tag"][ref["timestep"] == DT - 1]), sg["leftover_tags"])
+        tr.close()
