@@ -163,6 +163,11 @@ class Context:
         self._ck(self._L.ftkx_get_sparse_cells(self._h, cells.data_ptr(), 1 if cells.is_cuda else 0))
         return cells[:n.value]
 
+    def sweep_enqueue_many(self, ts, scopes, factors):
+        n = len(ts)
+        self._ck(self._L.ftkx_sweep_enqueue_many(self._h, (C.c_int * n)(*[int(t) for t in ts]), (C.c_int * n)(*[int(v) for v in scopes]),
+                                                 (C.c_ulonglong * n)(*[int(f) for f in factors]), n))
+
     def sweep_cancel(self):
         self._ck(self._L.ftkx_sweep_cancel(self._h))
 

@@ -1249,6 +1249,13 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
   return FTKX_OK;
 }
 
+int ftkx_sweep_enqueue_many(ftkx_ctx *c, const int *ts, const int *scopes, const unsigned long long *factors, int n)
+{
+  if (!c || (n > 0 && (!ts || !scopes || !factors))) return fail(c, FTKX_E_INVALID, "null argument");
+  for (int i = 0; i < n; i ++) { const int rc = ftkx_sweep_enqueue(c, ts[i], scopes[i], factors[i]); if (rc) { c->pending.clear(); return rc; } }
+  return FTKX_OK;
+}
+
 int ftkx_sweep_cancel(ftkx_ctx *c)
 {
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");

@@ -167,6 +167,7 @@ int ftkx_sweep(ftkx_ctx *ctx, int t, int scope, unsigned long long factor, const
 /* batched form: enqueue only records the request; ftkx_sweep_collect() launches the whole batch (one mask / cull / exact
  * launch covers every enqueued timestep), synchronises and returns the records of ALL of them (sorted by tag). */
 int ftkx_sweep_enqueue(ftkx_ctx *ctx, int t, int scope, unsigned long long factor);
+int ftkx_sweep_enqueue_many(ftkx_ctx *ctx, const int *timesteps, const int *scopes, const unsigned long long *factors, int n);   /* all or nothing */
 int ftkx_sweep_collect(ftkx_ctx *ctx, const ftkx_cp_t **out, size_t *n_out);
 int ftkx_sweep_cancel(ftkx_ctx *ctx);    /* forgets the enqueued, not yet collected sweeps */
 
