@@ -20,8 +20,9 @@ def gpu():
     return ftk_amd
 
 
-def _sweep_series(gpu, case, dims, nt, *, nv=1, exact_only=False, core=None, keep_host=False, tag_mode=None):
-    """whole series resident, one batched pre-pass, one batched sweep -> (records, stats, factors, host copies or None)"""
+def _sweep_series(gpu, case, dims, nt, *, nv=1, exact_only=False, core=None, keep_host=False, tag_mode=None, prepass="fused"):
+    """whole series resident, one pass for masks + reduction (the product's path; prepass="exact": the separate exact pre-pass), one
+    batched sweep -> (records, stats, factors, host copies or None)"""
     import torch
     from ftk_amd import synthetic, tslab
     nd = len(dims)
@@ -40,7 +41,7 @@ def _sweep_series(gpu, case, dims, nt, *, nv=1, exact_only=False, core=None, kee
         if keep_host:
             host.append(a.cpu().numpy())
         (ctx.push_scalar_slice if scalar else ctx.push_slice)(t, a)
-    rm = ctx.slices_resolution(range(nt))
+    rm = ctx.slices_prepare(range(nt), 0) if prepass == "fused" else ctx.slices_resolution(range(nt))
     factors = tslab.factors_from_resolutions([rm[t][0] for t in range(nt)])
     for t in range(nt):
         ctx.sweep_enqueue(t, gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL, factors[t])
@@ -114,6 +115,9 @@ def test_c2_woven_1024x1024x64(gpu, oracle):
     recs_e, st_e, _, _ = _sweep_series(gpu, "woven", dims, nt, exact_only=True)
     assert st_e["cull_enabled"] == 0 and st_e["simplices_tested"] > 100 * st["simplices_tested"]
     _same(recs, recs_e)
+    recs_p, st_p, f_p, _ = _sweep_series(gpu, "woven", dims, nt, prepass="exact")      # masks under the true factors: fewer survivors, same records
+    assert f_p == factors and st_p["cells_survived"] <= st["cells_survived"]
+    _same(recs, recs_p)
     if (os.cpu_count() or 1) >= 32:     # ~2 s of the oracle on the GPU box's host; hours-long nowhere, but skip on small hosts
         _assert_equals_oracle(oracle, recs, host, 2, 1, factors, "c2 vs oracle")
 
