@@ -854,7 +854,9 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
     if (s->sparse && !s->have_res) return fail(c, FTKX_E_NOSLICE, "ftkx_slices_prepare: a masked halo slice has no data to reduce (its owner's reduction: ftkx_set_slice_resolution)");
     if (s->sparse) continue;
     if (!want_masks) { if ((rc = slice_resolution(c, *s))) return rc; continue; }
-    if (s->have_fused && s->fused_factor == hint && s->mask_factor == hint && s->M && (!two_level || s->U)) continue;
+    // already reduced under this hint: nothing to do -- also when its masks were then found unusable (vertices that can overflow a
+    // determinant): the sweep rebuilds those with the per-vertex rule, another pass here would only repeat the finding
+    if (s->have_fused && s->fused_factor == hint) continue;
     if (std::find(todo.begin(), todo.end(), s) == todo.end()) todo.push_back(s);
   }
   if (!todo.empty()) {
@@ -976,13 +978,15 @@ int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, 
   if (it != c->slices.end() && it->second.sparse) { s = it->second; c->slices.erase(it); }          // the same halo slice again: keep its arrays
   else if (it != c->slices.end()) { free_slice(it->second, c); c->slices.erase(it); }
   const size_t n = n_vertices(c), ncomp = scalar_input ? 1 : (size_t)c->nd;
+  // everything below that can fail runs inside `fill`: on failure the half-built slice is released, not leaked
+  auto fill = [&]() -> int {
   int rc;
   if (!s.sparse) {
     double **field = scalar_input ? &s.S : &s.V;
     HIP_TRY(c, hipMalloc((void **)field, n * ncomp * sizeof(double)));
     (scalar_input ? s.ownS : s.ownV) = true;
     HIP_TRY(c, hipMemsetAsync(*field, 0, n * ncomp * sizeof(double), c->stream));      // only patches are ever read; zeros elsewhere, not garbage
-    if ((rc = ensure_mask_arrays(c, s, true))) { free_slice(s, c); return rc; }
+    if ((rc = ensure_mask_arrays(c, s, true))) return rc;
     s.sparse = true;
   }
   const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -1003,6 +1007,10 @@ int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, 
     HIP_TRY(c, hipGetLastError());
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return FTKX_OK;
+  };
+  const int frc = fill();
+  if (frc != FTKX_OK) { free_slice(s, c); c->scalar_mode = saved_mode; return frc; }
   s.mask_factor = mask_factor; s.mask_big = false;
   s.maxabs = max_abs;                                                                  // (all a masked slice knows of its values)
   c->slices[t] = s;
