@@ -58,7 +58,7 @@ bench = json.loads(open(one("bench_plain.json")).read().strip().splitlines()[-1]
 dom = bench["roofline"].get("kernel_family", bench["roofline"]["kernel"]).replace("ftkx::", "").split("<")[0]
 # bench.py labels kernel families; the marching mask kernel's pre-pass instantiation (<.., true>) is not the timed one
 key = {"mask_kernel": "mask_", "cull_kernel": "cull_", "exact_kernel": "exact_", "tile_kernel": "tile_"}.get(dom, dom)
-def is_prepass(n):   # REDUCE instantiations: mask_march2_kernel<ND, EDGE, true>, mask_march4_kernel<ND, true, PD>
+def is_prepass(n):   # REDUCE instantiations: mask_march4_kernel<ND, true, PD, RY>
     return n.rstrip().endswith(", true>") or re.search(r"mask_march4_kernel<\d, true", n) is not None
 
 
