@@ -113,6 +113,7 @@ struct ftkx_ctx {
   // mask / summary arrays of dropped slices, kept for the next slice (a streaming tracker pushes and pops one slice per step:
   // hipMalloc + hipFree per step cost more than the sweep itself).  Their padding bytes stay valid: kernels never write them.
   std::vector<unsigned char *> pool_M, pool_U;
+  std::vector<std::pair<double *, size_t>> pool_F;   // owned field arrays (S / V / J copies) of dropped slices, by size in doubles
   u64 *d_red = nullptr;             // {min, max} slots of a batched resolution reduction: 128 words per slice
   size_t red_cap = 0;
   // physical coordinates (REGULAR_COORDS_RECTILINEAR / _EXPLICIT): device copies
@@ -173,9 +174,19 @@ size_t mask_bytes(const ftkx_ctx *c) { return (size_t)mask_pitch(c) * (size_t)c-
 
 void free_slice(Slice &s, ftkx_ctx *pool_owner = nullptr)
 {
-  if (s.ownV && s.V) (void)hipFree(s.V);
-  if (s.ownJ && s.J) (void)hipFree(s.J);
-  if (s.ownS && s.S) (void)hipFree(s.S);
+  // owned copies go back to the context's pool: a streaming caller pushes and pops one slice per step, and hipMalloc + hipFree of a
+  // slice-sized array cost more than sweeping a 256^3 slice
+  auto give_back = [&](double *p, size_t count) {
+    if (pool_owner && pool_owner->pool_F.size() < 6) pool_owner->pool_F.push_back({p, count});
+    else (void)hipFree(p);
+  };
+  size_t nv = 0;
+  if (pool_owner) { nv = 1; for (int d = 0; d < pool_owner->nd; d ++) nv *= (size_t)pool_owner->ext_sz[d]; }
+  const size_t nd_ = pool_owner ? (size_t)pool_owner->nd : 0;
+  if (s.ownV && s.V) give_back(s.V, nv * nd_);
+  if (s.ownJ && s.J) give_back(s.J, nv * nd_ * nd_);
+  if (s.ownS && s.S) give_back(s.S, nv);
+  s.ownV = s.ownJ = s.ownS = false;
   if (s.M) { if (pool_owner && pool_owner->pool_M.size() < 4) pool_owner->pool_M.push_back(s.M); else (void)hipFree(s.M); }
   if (s.U) { if (pool_owner && pool_owner->pool_U.size() < 4) pool_owner->pool_U.push_back(s.U); else (void)hipFree(s.U); }
   s = Slice();
@@ -185,7 +196,8 @@ void release_pools(ftkx_ctx *c)
 {
   for (unsigned char *p : c->pool_M) (void)hipFree(p);
   for (unsigned char *p : c->pool_U) (void)hipFree(p);
-  c->pool_M.clear(); c->pool_U.clear();
+  for (auto &p : c->pool_F) (void)hipFree(p.first);
+  c->pool_M.clear(); c->pool_U.clear(); c->pool_F.clear();
 }
 
 int ensure_hit_buffer(ftkx_ctx *c, u64 want)
@@ -543,6 +555,16 @@ const char *ftkx_last_mask_kernel(void) { return ftkx::last_mask_kernel(); }
 
 const char *ftkx_version(void) { return "ftkx 0.1 (gfx950)"; }
 
+// which device a pointer lives on: its ordinal, or -1 for host memory / unknown pointers
+int ftkx_pointer_device(const void *p)
+{
+  hipPointerAttribute_t a;
+  if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return a.type == hipMemoryTypeDevice ? a.device : -1;
+}
+
+int ftkx_context_device(const ftkx_ctx *c) { return c ? c->device : -1; }
+
 int ftkx_device_count(void)
 {
   int n = 0;
@@ -718,7 +740,10 @@ static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, con
   auto take = [&](const double *src, size_t count, double **dst, bool *own) -> int {
     if (!src) { *dst = nullptr; *own = false; return FTKX_OK; }
     if (on_device == 1) { *dst = const_cast<double *>(src); *own = false; return FTKX_OK; }
-    HIP_TRY(c, hipMalloc((void **)dst, count * sizeof(double)));
+    *dst = nullptr;
+    for (size_t i = 0; i < c->pool_F.size(); i ++)
+      if (c->pool_F[i].second == count) { *dst = c->pool_F[i].first; c->pool_F.erase(c->pool_F.begin() + (long)i); break; }
+    if (!*dst) HIP_TRY(c, hipMalloc((void **)dst, count * sizeof(double)));
     *own = true;
     // 0: host memory; 2: device memory of ANY device (a multi-device tracker hands one snapshot to two contexts), copied
     HIP_TRY(c, hipMemcpyAsync(*dst, src, count * sizeof(double), on_device == 2 ? hipMemcpyDefault : hipMemcpyHostToDevice, c->stream));

@@ -156,9 +156,31 @@ critical_point_tracker_regular::~critical_point_tracker_regular()
 
 void critical_point_tracker_regular::sync() const
 {
-  if (!multi) return;
-  multi->wait_all();
-  multi->rethrow();
+  if (multi) {
+    multi->wait_all();
+    multi->rethrow();
+  }
+  flush_points();
+}
+
+// the parked records into the ordered map: sorted by the element order's integer key first, so that a map that was empty is built
+// with end hints (linear), and later points overwrite earlier ones with the same tag like operator[] did
+void critical_point_tracker_regular::flush_points() const
+{
+  if (pending_points.empty()) return;
+  const element_order ord = discrete_critical_points.key_comp();
+  std::vector<std::pair<std::pair<unsigned long long, unsigned long long>, size_t>> order(pending_points.size());
+  for (size_t i = 0; i < pending_points.size(); i ++) order[i] = {ord.key(pending_points[i].tag), i};
+  std::sort(order.begin(), order.end());
+  if (discrete_critical_points.empty()) {
+    for (const auto &o : order) {
+      const feature_point_t &cp = pending_points[o.second];
+      auto it = discrete_critical_points.emplace_hint(discrete_critical_points.end(), cp.tag, cp);
+      it->second = cp;
+    }
+  } else
+    for (const auto &o : order) discrete_critical_points[pending_points[o.second].tag] = pending_points[o.second];
+  pending_points.clear();
 }
 
 int critical_point_tracker_regular::num_devices() const { return multi ? (int)multi->w.size() : 1; }
@@ -213,7 +235,8 @@ void critical_point_tracker_regular::initialize()
   if ((int)domain.nd() != nd || (int)array_domain.nd() != nd) throw ftkx_error(FTKX_E_INVALID, "initialize: set_domain / set_array_domain first");
   local_domain = domain;
   local_array_domain = array_domain;
-  if (multi) { sync(); for (auto &W : multi->w) apply_configuration(W->ctx); }
+  sync();
+  if (multi) { for (auto &W : multi->w) apply_configuration(W->ctx); }
   else apply_configuration(ctx);
   // the discrete points are kept in the reference's element order, which needs the mesh sizes
   element_order ord;
@@ -235,6 +258,7 @@ void critical_point_tracker_regular::reset()
   current_timestep = 0;
   while (pop_field_data_snapshot()) {}
   next_push_timestep = 0;
+  pending_points.clear();
   discrete_critical_points.clear();
 }
 
@@ -254,7 +278,9 @@ void critical_point_tracker_regular::push_everywhere(int kind, int t, const doub
   std::set<int> targets;
   targets.insert(multi->dev_of(t));
   if (t > multi->t_first) targets.insert(multi->dev_of(t - 1));        // the interval sweep [t-1, t] of the previous block reads it too
-  // device memory is COPIED into each context (a peer copy where the devices differ): the caller's buffer is free again on return
+  // Device memory is COPIED into each context (a peer copy where the devices differ; the contexts recycle their slice buffers, so
+  // no allocation per step): the steps run later than the calls that queue them, and the caller's buffer is free again on return
+  // -- adopting the pointer would tie its lifetime to a queue the caller cannot see.
   for (int d : targets) {
     ftkx_ctx *c = multi->w[d]->ctx;
     multi->post(d, [=] { const int rc = push_to(c, kind, t, s, v, j, device ? 2 : 0); if (rc) { char buf[512]; ftkx_last_error(c, buf, sizeof(buf)); throw ftkx_error(rc, buf); } });
@@ -338,7 +364,7 @@ void critical_point_tracker_regular::take_records(const ftkx_cp_t *recs, size_t 
     cp.ordinal = ftkx_cp_ordinal(&recs[i]) != 0;
     cp.timestep = timestep;
     if (scalar_field_source == SOURCE_NONE) cp.scalar[0] = 0.0;   // 2d:642-646: scalar only when a scalar field exists
-    discrete_critical_points[cp.tag] = cp;
+    pending_points.push_back(cp);                                 // -> discrete_critical_points at the next sync()
   }
 }
 
@@ -402,6 +428,7 @@ bool critical_point_tracker_regular::advance_timestep()
 // trace_critical_points_online (critical_point_tracker.hh:523-639) on everything in discrete_critical_points, which it consumes
 void critical_point_tracker_regular::grow()
 {
+  flush_points();
   long long dst[3] = {0, 0, 0}, dsz[3] = {1, 1, 1};
   for (int d = 0; d < nd; d ++) { dst[d] = domain.start(d); dsz[d] = domain.size(d); }
   if (!online) { const int rc = ftkx_online_tracer_create(&online, nd, dst, dsz); if (rc != FTKX_OK) throw ftkx_error(rc, "online tracer"); }

@@ -293,6 +293,8 @@ const char *ftkx_last_mask_kernel(void);
 /* library / device identification */
 const char *ftkx_version(void);
 int ftkx_device_count(void);
+int ftkx_pointer_device(const void *p);          /* ordinal of the device the pointer lives on, -1: host memory or unknown */
+int ftkx_context_device(const ftkx_ctx *ctx);
 
 #ifdef __cplusplus
 }
