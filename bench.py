@@ -14,7 +14,11 @@ that makes the inputs resident -- happens before the timed region and is reporte
 GB/s).  The sweeps themselves then shard with no data-path collective.  `--halo-in-loop` re-sends the boundary slice in every
 timed pass instead (1 GiB per pass for 512^3: the pass is then bound by one xGMI link, not by the sweep); whichever convention
 is timed as `value`, a few passes of the other one are timed as well and reported as `other_halo_convention`.
-Total work is fixed as N grows ("strong" scaling): N = 8 is BASELINE.json's `moving_extremum_3d 512^3 x 32, 8xMI355X` case.
+Scaling: the path shards by timestep slabs with no data-path collective, so the default is WEAK scaling -- every rank owns one
+slab of the configuration's length (N = 8 on c4: a 512^3 x 256 series in eight slabs of 32, the single-GPU workload per GPU) and
+`value` is the series' simplices over the slowest rank's time.  `--scaling strong` cuts the configuration's own series instead
+(N = 8 on c4 is BASELINE.json's literal `moving_extremum_3d 512^3 x 32, 8xMI355X` case: 4 timesteps + 1 halo slice per rank).
+`--timesteps T` overrides the series length.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
@@ -104,6 +108,8 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="all ranks on cuda:0 (dry run of the N>1 logic on a 1-GPU box)")
     ap.add_argument("--halo-in-loop", action="store_true", help="N > 1: re-send the slab-boundary slice inside every timed pass")
     ap.add_argument("--compact-halo", action="store_true", help="N > 1: inside every timed pass, exchange sign masks + patches around the surviving cells instead of the boundary slice")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = one slab of the configuration's length per rank (series of nt*N timesteps); strong = the configuration's series cut into N slabs")
+    ap.add_argument("--timesteps", type=int, default=0, help="override the length of the series")
     ap.add_argument("--dump-merged", default=None, help="rank 0 writes the merged records and the curves traced from them (npz)")
     args = ap.parse_args()
 
@@ -132,6 +138,10 @@ def main():
             dist.init_process_group("gloo")
 
     nd, nv, case, dims, nt = CONFIGS[args.config]
+    if args.timesteps > 0:
+        nt = args.timesteps
+    elif world > 1 and args.scaling == "weak":
+        nt *= world                 # per-GPU work fixed: every rank sweeps a slab as long as the configuration's whole series
     scalar_input = nv == 1
     t0_own, t1_own = tslab.slab_range(nt, world, rank)
     own = list(range(t0_own, t1_own))
@@ -344,9 +354,9 @@ def main():
         out = {
             "metric": "space-time simplices/sec", "value": total_simplices * args.steps / elapsed, "unit": "simplices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": f"{case} {'x'.join(str(d) for d in dims)}x{nt} ({args.config}), "
-                                   f"{'scalar' if scalar_input else 'vector'} input, t-slab partition over {world} GPU(s)",
+                                   f"{'scalar' if scalar_input else 'vector'} input, t-slab partition over {world} GPU(s): {len(own)} timesteps on rank 0",
                        "simplices_per_step": total_simplices, "exact_only": bool(args.exact_only),
                        "nbits": int(np.log2(max(factors))), "cull": bool(st["cull_enabled"]),
                        "input_resident": "the field the tracker API is given (S, or V for vector input) in HBM; gradient/Jacobian evaluated in flight"},

@@ -1267,6 +1267,320 @@ __global__ __launch_bounds__(64 * (CY + 1)) void mask_march5_kernel(const Mesh m
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same walk WITHOUT a dedicated producer: every wavefront of the workgroup is a consumer and issues the LDS-DMA loads of its
+// own rows (plus one of the three odd jobs: the two halo rows and the edge values).  Why: a workgroup's wavefronts land on the
+// CU's four SIMDs round-robin from a random start (tools/probe/simd_map.hip), so with 1 + 3 wavefronts per workgroup and three
+// workgroups per CU some SIMD always carries three consumers -- a third of the CU's sign arithmetic instead of a quarter -- and
+// the plane step waits for it.  Four symmetric wavefronts x three workgroups put exactly three equal shares on every SIMD.
+// What that costs:
+//   * a wavefront that issues LDS-DMA and also reads LDS gets an s_waitcnt vmcnt(0) from the compiler before every LDS read
+//     (it cannot tell the slots apart), so the LDS reads are inline assembly with their own lgkmcnt wait;
+//   * vmcnt counts this wavefront's mask stores too (gfx9: one in-order counter for loads and stores), so the stores are issued
+//     unconditionally -- lanes / rows with nothing to store carry an out-of-range offset, which a buffer store drops -- and the
+//     wait before the barrier names exactly how many younger operations may still be in flight.
+// ---------------------------------------------------------------------------------------------------------------
+// byte R of T = byte 0 & byte 1 of `bits` (R = 0 starts a new T)
+template <int R> __device__ inline void pack_pair_and(unsigned &T, unsigned bits)
+{
+  if constexpr (R == 0) asm("v_and_b32_sdwa %0, %1, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(T) : "v"(bits));
+  else if constexpr (R == 1) asm("v_and_b32_sdwa %0, %1, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1" : "+v"(T) : "v"(bits));
+  else if constexpr (R == 2) asm("v_and_b32_sdwa %0, %1, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1" : "+v"(T) : "v"(bits));
+  else asm("v_and_b32_sdwa %0, %1, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1" : "+v"(T) : "v"(bits));
+}
+// AND over the four lanes of every quad (s_nop 1: the two wait states a DPP read needs after a VALU write of its source)
+__device__ inline void quad_and(unsigned &T)
+{
+  asm("s_nop 1\n\t"
+      "v_and_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_and_b32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : "+v"(T));
+}
+// lane mask: byte R of T is not zero
+template <int R> __device__ inline void byte_nonzero(unsigned long long &mask, unsigned T, unsigned zero)
+{
+  if constexpr (R == 0) asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD" : "=s"(mask) : "v"(T), "v"(zero));
+  else if constexpr (R == 1) asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_1 src1_sel:DWORD" : "=s"(mask) : "v"(T), "v"(zero));
+  else if constexpr (R == 2) asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_2 src1_sel:DWORD" : "=s"(mask) : "v"(T), "v"(zero));
+  else asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_3 src1_sel:DWORD" : "=s"(mask) : "v"(T), "v"(zero));
+}
+// off, or an offset beyond any buffer (-16 = 0xfffffff0) in the lanes of `mask`
+__device__ inline unsigned out_of_range_where(unsigned off, unsigned long long mask)
+{
+  unsigned r;
+  asm volatile("v_cndmask_b32_e64 %0, %1, -16, %2" : "=v"(r) : "v"(off), "s"(mask));
+  return r;
+}
+template <int I> __device__ inline void lds_read128(v2d &d, unsigned a) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(I * 1024)); }
+template <int I> __device__ inline void lds_read64(double &d, unsigned a) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(I)); }
+__device__ inline void lds_tie(v2d &d) { asm volatile("" : "+v"(d)); }
+__device__ inline void lds_tie(double &d) { asm volatile("" : "+v"(d)); }
+template <int N, int... I> __device__ inline void lds_rows(v2d (&B)[N], unsigned a, std::integer_sequence<int, I...>) { (lds_read128<I>(B[I], a), ...); }
+template <int N, int... I> __device__ inline void lds_tie_rows(v2d (&B)[N], std::integer_sequence<int, I...>) { (lds_tie(B[I]), ...); }
+template <int RIGHT, int N, int... I> __device__ inline void lds_edges(double (&XL)[N], double (&XR)[N], unsigned a, std::integer_sequence<int, I...>)
+{
+  (lds_read64<8 * I>(XL[I], a), ...);
+  (lds_read64<RIGHT + 8 * I>(XR[I], a), ...);
+}
+template <int N, int... I> __device__ inline void lds_tie_edges(double (&XL)[N], double (&XR)[N], std::integer_sequence<int, I...>) { ((lds_tie(XL[I]), lds_tie(XR[I])), ...); }
+
+// mask_march6_kernel, step s of a chunk: wait until this wavefront's loads of the plane the step needs have landed.  vmcnt counts
+// loads and stores in issue order (gfx9), so the wait names how many YOUNGER operations may still be in flight: the loads of that
+// plane were issued NS steps earlier; since then the wavefront issued the S stores of that step and, per later step, at least RY
+// loads and exactly S stores.  The first NS steps wait for loads the prologue issued back to back, with no stores in between.
+template <int NS, int RY, int S>
+__device__ inline void wait_plane_landed(int s)
+{
+  static_assert((NS - 1) * RY + NS * S < 64 && NS <= 4, "vmcnt is a 6-bit counter; four early steps are spelled out");
+#define FTKX_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))
+  if (s >= NS) FTKX_WAIT_VM((NS - 1) * RY + NS * S);
+  else if (s == 1) FTKX_WAIT_VM((NS - 1) * RY + S);
+  else if (s == 2) FTKX_WAIT_VM((NS - 1) * RY + 2 * S);
+  else if (s == 3) FTKX_WAIT_VM((NS - 1) * RY + 3 * S);
+  else FTKX_WAIT_VM((NS - 1) * RY);
+#undef FTKX_WAIT_VM
+}
+
+template <int NS, int CY, int RY, bool TWOB>
+__device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int ROWS = RY * CY, TROWS = ROWS + 2, NE = NS + 1;             // NS row slots, NS + 1 edge entries
+  // edge values of a plane: up to 16 rows -> one wavefront instruction (left neighbours at 8 e, right ones at 128 + 8 e of the entry);
+  // up to 32 rows -> the left ones by wavefront 1, the right ones by wavefront 2 (at 256 + 8 e)
+  constexpr bool EDGE2 = ROWS > 16;
+  static_assert(ROWS <= 32 && CY >= (EDGE2 ? 4 : 3), "the odd jobs (two halo rows, edge values) go to different wavefronts");
+  constexpr unsigned ROWB = 1024u, SLOT = TROWS * ROWB, EDGEB = EDGE2 ? 512u : 256u, ERIGHT = EDGE2 ? 256u : 128u, ERING = NS * SLOT;
+  // TWOB: a row slot is refilled in the very step that reads it (second barrier below) -- NS planes are on their way or waiting at
+  // any time; otherwise one step later, after the next step's only barrier (NS - 1 planes).  The wait before the first barrier:
+  // wait_plane_landed.
+  constexpr int DEPTH = TWOB ? NS : NS - 1;
+  static_assert(DEPTH >= 1, "at least one plane on its way");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = m.ext_sz[2], P = m.mask_pitch;
+  const int nzc = (DD + zchunk - 1) / zchunk;
+  unsigned bx, by, bz;
+  remap_block(swizzle, bx, by, bz);
+  const MaskJob job = jobs[bz / nzc];
+  const int z0 = (int)(bz % nzc) * zchunk;
+  const int z1 = z0 + zchunk < DD ? z0 + zchunk : DD;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int jb = (int)by * ROWS, t0c = (int)bx * 128;
+  if (jb >= DH) return;
+  const unsigned sy = (unsigned)DW * 8u, sz = (unsigned)DW * (unsigned)DH * 8u;
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void *)job.S, 0, (int)(sz * (unsigned)DD), 0x00020000);
+  const int nsteps = ((z1 - z0 + 2) / 3) * 3;
+  auto slot_of = [&](int q) -> unsigned { return (unsigned)(((q - (z0 - 1)) % NS + NS) % NS) * SLOT; };
+  auto edge_of = [&](int q) -> unsigned { return ERING + (unsigned)(((q - (z0 - 1)) % NE + NE) % NE) * EDGEB; };
+
+  // ---- this wavefront's share of a plane's loads ----
+  const int ip = t0c + 2 * lane;
+  const unsigned cb = (unsigned)(ip < DW ? ip : DW - 2) * 8u;
+  unsigned eoff = 0xfffffff0u;
+  if (wv == 1 || (EDGE2 && wv == 2)) {
+    const int e = lane >> 1, row = EDGE2 ? e : (e & 15);
+    const bool left = EDGE2 ? wv == 1 : e < 16;
+    if (row < ROWS) {
+      const int col = left ? (t0c > 0 ? t0c - 1 : 0) : (t0c + 128 < DW ? t0c + 128 : DW - 1);
+      eoff = sy * (unsigned)clampi(jb + row, 0, DH - 1) + (unsigned)col * 8u + 4u * (unsigned)(lane & 1);
+    }
+  }
+  unsigned roff[RY];                                            // tile rows 1 + wv RY + r: this wavefront's own rows
+  for (int r = 0; r < RY; r ++) roff[r] = sy * (unsigned)clampi(jb + wv * RY + r, 0, DH - 1);
+  const int xt = wv == 0 ? 0 : TROWS - 1;                       // the halo row wavefront 0 / CY-1 also fetches
+  const unsigned xoff = sy * (unsigned)clampi(jb + xt - 1, 0, DH - 1);
+  auto issue = [&](int q) {
+    const unsigned zo = sz * (unsigned)clampi(q, 0, DD - 1);
+    const unsigned base = slot_of(q);
+    for (int r = 0; r < RY; r ++) {
+      __attribute__((address_space(3))) void *dst = (__attribute__((address_space(3))) void *)(lds + base + (unsigned)(1 + wv * RY + r) * ROWB);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, dst, 16, cb, zo + roff[r], 0, 0);
+    }
+    if (wv == 0 || wv == CY - 1) {
+      __attribute__((address_space(3))) void *dst = (__attribute__((address_space(3))) void *)(lds + base + (unsigned)xt * ROWB);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, dst, 16, cb, zo + xoff, 0, 0);
+    } else if (wv == 1 || (EDGE2 && wv == 2)) {
+      __attribute__((address_space(3))) void *edst = (__attribute__((address_space(3))) void *)(lds + edge_of(q) + ((EDGE2 && wv == 2) ? ERIGHT : 0u));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, edst, 4, eoff, zo, 0, 0);
+    }
+  };
+#define FTKX_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))
+
+  // ---- the consumer's constants (as in mask_march5_kernel) ----
+  const int wy = wv;
+  const int i0 = t0c + 2 * lane;
+  const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)job.M, 0, (int)((unsigned)P * (unsigned)DH * (unsigned)DD), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)job.U, 0, job.U ? (int)((unsigned)m.u_pitch * (unsigned)DH * (unsigned)DD) : 0, 0x00020000);
+  const double thr = job.threshold;
+  const double tpos = 2.0 * thr, tneg = -tpos;
+  const int j0 = jb + wy * RY;
+  unsigned xkeep = 0, xneutral = 0;
+  for (int c = 0; c < 2; c ++) {
+    const int i = i0 + c;
+    const bool x_dom = i < DW && i + m.ext_st[0] >= m.dom_lb[0] && i + m.ext_st[0] <= m.dom_ub[0];
+    const bool x_int = i >= 1 && i < DW - 1;
+    if (x_int) xkeep |= 0x3fu << (8 * c);
+    if (!x_dom) xneutral |= 0x3fu << (8 * c);
+  }
+  unsigned row_dom = 0, row_int = 0, row_ok = 0;
+  for (int r = 0; r < RY; r ++) {
+    const int j = j0 + r;
+    if (j < DH) row_ok |= 1u << r;
+    if (j + m.ext_st[1] >= m.dom_lb[1] && j + m.ext_st[1] <= m.dom_ub[1]) row_dom |= 1u << r;
+    if (j >= 1 && j < DH - 1) row_int |= 1u << r;
+  }
+  const bool in_row = i0 < DW;
+  constexpr unsigned OOB = 0xfffffff0u;                          // beyond num_records: the store is dropped
+  const bool have_u = job.U != nullptr;
+  const unsigned mcol = in_row ? (unsigned)i0 : OOB;
+  const unsigned ucol = ((lane & 3) == 0 && in_row && have_u) ? (unsigned)(i0 >> 3) : OOB;
+  double acc0 = 0.0, acc1 = 0.0, red_mn = DBL_MAX;
+  const unsigned cmask = in_row ? (xkeep & 0x0707u) : 0u;
+  const double tbig = 2.0 * job.big;
+  const bool per_vertex_rule = job.big < HUGE_VAL;
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds;
+  const unsigned lrow = lds0 + (unsigned)(wy * RY) * ROWB + (unsigned)(lane * 16);
+  const unsigned eown = lds0 + (unsigned)(wy * RY) * 8u;
+  // per-row store offsets (the plane's offset travels as the scalar operand); out of range where there is nothing to store
+  unsigned uoff[RY], moff[RY];
+  for (int r = 0; r < RY; r ++) {
+    const bool rok = (row_ok >> r) & 1;
+    uoff[r] = (rok && ucol != OOB) ? ucol + (unsigned)m.u_pitch * (unsigned)r : OOB;
+    moff[r] = (rok && in_row) ? mcol + (unsigned)P * (unsigned)r : OOB;
+  }
+  const bool wave_interior = (row_ok & row_int & row_dom) == (1u << RY) - 1u;
+  const unsigned vzero = 0u;
+
+  // LDS reads by hand (see the header): issue them all, one lgkmcnt wait, then tie the registers to the wait
+  auto take_plane = [&](v2d (&B)[RY + 2], int q) { lds_rows(B, lrow + slot_of(q), std::make_integer_sequence<int, RY + 2>{}); };
+  auto landed = [&](v2d (&B)[RY + 2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds_tie_rows(B, std::make_integer_sequence<int, RY + 2>{});
+  };
+
+  auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], v2d (&NX)[RY + 2], int k) {
+    // this wavefront's share of plane k+1 has landed: all but the operations issued after it may still be in flight
+    wait_plane_landed<DEPTH, RY, 2 * RY>(k - z0);
+    __builtin_amdgcn_s_barrier();                              // ... and so has everybody else's
+    const bool live = k < z1;                                  // (wave-uniform) padding steps of the chunk have nothing to classify or store
+    if constexpr (!TWOB) { const int q = k + NS; issue(q < z1 ? q : z1); }   // the slot read during the previous step, the edge entry of plane k-1
+    double XL[RY], XR[RY];
+    if (live) {
+      take_plane(NX, k + 1 < z1 ? k + 1 : z1);
+      lds_edges<(int)ERIGHT>(XL, XR, eown + edge_of(k), std::make_integer_sequence<int, RY>{});
+      landed(NX);
+      lds_tie_edges(XL, XR, std::make_integer_sequence<int, RY>{});
+    }
+    if constexpr (TWOB) {
+      __builtin_amdgcn_s_barrier();                            // everybody has plane k+1 (and plane k's edge values) in registers:
+      const int q = k + 1 + NS; issue(q < z1 ? q : z1);        // its row slot and that edge entry take the plane NS steps ahead
+    }
+    if (!live) return;
+    const bool z_dom = k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2];
+    const bool z_int = k >= 1 && k < DD - 1;
+    const unsigned mplane = (unsigned)P * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
+    const unsigned uplane = (unsigned)m.u_pitch * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
+    // A wavefront issues ONE instruction per four cycles, scalar or vector: per-row tests and branches cost as much as the sign
+    // arithmetic.  So the rows come in four compile-time flavours -- INTERIOR: every row of this wavefront and this plane lies inside
+    // the domain (no per-row boundary logic at all; 15 of 16 tiles, 507 of 512 planes on a 512^3 slice); RULE: the per-vertex
+    // overflow rule is on -- and what can wait is done once per step on all rows together: the summaries (packed, one pair of quad
+    // permutes), the test for components without a strict sign (on the AND of the rows), the stores.
+    unsigned bw[RY];                                            // the rows' pairs of mask bytes
+    unsigned raw_and = 0xffffffffu;                             // AND of the rows' sign bits as classified (before rule / boundary logic)
+    auto rows = [&](auto interior_c, auto rule_c) {
+      constexpr bool INTERIOR = decltype(interior_c)::value, RULE = decltype(rule_c)::value;
+      static_for<RY>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const v2d c = CU[r + 1];
+        const double xm = dpp_lower_or(c.y, XL[r]), xp = dpp_upper_or(c.x, XR[r]);
+        const double dx0 = c.y - xm, dx1 = xp - c.x;
+        const double dy0 = CU[r + 2].x - CU[r].x, dy1 = CU[r + 2].y - CU[r].y;
+        const double dz0 = NX[r + 1].x - PR[r + 1].x, dz1 = NX[r + 1].y - PR[r + 1].y;
+        unsigned a0 = 0, a1 = 0;
+        shift_in_signs<3>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, tneg, tpos);
+        double m0 = max_abs2(dx0, dy0), m1 = max_abs2(dx1, dy1);
+        m0 = max_with_abs(m0, dz0); m1 = max_with_abs(m1, dz1);
+        unsigned bits = a0 | (a1 << 8);
+        const bool u_int = INTERIOR || (((row_int >> r) & 1) && z_int), u_dom = INTERIOR || (((row_dom >> r) & 1) && z_dom);
+        if (INTERIOR || (u_int && ((row_ok >> r) & 1))) {       // this row holds real entries of gradient(S)
+          acc0 = max_plain(acc0, m0); acc1 = max_plain(acc1, m1);
+          raw_and &= bits;
+        }
+        if constexpr (RULE) bits = (m0 >= tbig ? 0u : (bits & 0x00ffu)) | (m1 >= tbig ? 0u : (bits & 0xff00u));
+        if constexpr (INTERIOR) bits = (bits & xkeep) | xneutral;
+        else bits = (bits & (u_int ? xkeep : 0u)) | (u_dom ? xneutral : 0x3f3fu);
+        bw[r] = bits;
+      });
+    };
+    const bool interior = z_int && z_dom && wave_interior;
+    if (interior) { if (per_vertex_rule) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
+    else { if (per_vertex_rule) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
+    // candidates for the slice's resolution (see guard_and_reduce): components without a strict sign.  A component that is strict
+    // in every row with one sign survives the AND; anything else sends the wavefront through the exact per-row arithmetic, which
+    // takes the minimum over ALL entries of the rows (entries at or above the threshold never lower it)
+    {
+      const unsigned u = raw_and | (raw_and >> 3);
+      if (__builtin_amdgcn_ballot_w64((~u & cmask) != 0u)) {
+        static_for<RY>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          if (((row_int >> r) & 1) && z_int && ((row_ok >> r) & 1)) {
+            const v2d c = CU[r + 1];
+            const double xm = dpp_lower_or(c.y, XL[r]), xp = dpp_upper_or(c.x, XR[r]);
+            auto take = [&](double d) { const double a = fabs(0.5 * d); red_mn = fmin(red_mn, a == 0.0 ? DBL_MAX : a); };
+            if (cmask & 0x00ffu) { take(c.y - xm); take(CU[r + 2].x - CU[r].x); take(NX[r + 1].x - PR[r + 1].x); }
+            if (cmask & 0xff00u) { take(xp - c.x); take(CU[r + 2].y - CU[r].y); take(NX[r + 1].y - PR[r + 1].y); }
+          }
+        });
+      }
+    }
+    // summaries: byte r of T = AND of row r's two mask bytes, then of the quad's four lanes -- all rows in one pair of permutes
+    unsigned T[(RY + 3) / 4];
+    static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; pack_pair_and<r % 4>(T[r / 4], bw[r]); });
+    static_for<(RY + 3) / 4>([&](auto gc) { quad_and(T[decltype(gc)::value]); });
+    if (!have_u) static_for<(RY + 3) / 4>([&](auto gc) { T[decltype(gc)::value] = 0u; });   // (wave-uniform) no summaries: every mask word is stored
+    // exactly two stores per row, whatever the data: rows / lanes without one aim beyond the buffer
+    unsigned long long wu[RY];
+    unsigned mo[RY];
+    static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; byte_nonzero<r % 4>(wu[r], T[r / 4], vzero); });
+    if constexpr (RY < 3) asm volatile("s_nop 1");
+    static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; mo[r] = out_of_range_where(moff[r], wu[r]); });
+    static_for<RY>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(T[r / 4] >> (8 * (r % 4))), rU, uoff[r], uplane, 0);
+      __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bw[r], rM, mo[r], mplane, 0);
+    });
+  };
+
+  v2d B[3][RY + 2];
+  issue(z0 - 1); issue(z0);
+  FTKX_WAIT_VM(0);
+  __builtin_amdgcn_s_barrier();                                // planes z0-1 and z0 are in LDS
+  take_plane(B[0], z0 - 1);
+  take_plane(B[1], z0);
+  landed(B[0]); landed(B[1]);
+  __builtin_amdgcn_s_barrier();                                // everybody has taken them: their slots may be refilled
+  for (int q = z0 + 1; q <= z0 + DEPTH; q ++) issue(q < z1 ? q : z1);
+  for (int s = 0; s < nsteps; s += 3) {
+    step(B[0], B[1], B[2], z0 + s);
+    step(B[1], B[2], B[0], z0 + s + 1);
+    step(B[2], B[0], B[1], z0 + s + 2);
+  }
+  FTKX_WAIT_VM(0);                                             // nothing may still be writing LDS when the workgroup retires
+#undef FTKX_WAIT_VM
+  if (job.red) {
+    const double mx = fmax((cmask & 0x00ffu) ? acc0 : 0.0, (cmask & 0xff00u) ? acc1 : 0.0) * 0.5;
+    red_commit(job.red, red_mn < job.threshold ? red_mn : DBL_MAX, mx, blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + (unsigned)wv);
+  }
+#endif
+}
+
+template <int NS, int CY, int RY, bool TWOB>
+__global__ __launch_bounds__(64 * CY) void mask_march6_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
+{
+  march6_body<NS, CY, RY, TWOB>(m, jobs, zchunk, swizzle);
+}
+// ---------------------------------------------------------------------------------------------------------------
 // FAST PATH 2/3: corner cull on the mask bytes, 8 corners per lane (SWAR), survivors -> work list
 // ---------------------------------------------------------------------------------------------------------------
 // list entry: bits 0..39 corner index inside core (x fastest), bits 40..41 scope flags (1 ordinal, 2 interval), bits 44.. step
@@ -1530,8 +1844,13 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
   __shared__ unsigned char s_flag[G][NVC];
   __shared__ u64 s_entry[G];
   __shared__ unsigned s_tab[NTYPES];
-  __shared__ unsigned short s_pass[G * NTYPES];   // (corner, type) pairs that passed the predicate
-  __shared__ unsigned s_npass;
+  // descriptors of the (corner, type) pairs that passed the predicate, parked in LDS across chunks: the counter behind m.pass is ONE
+  // address for the whole device (a same-address atomic costs ~5 ns of serialised L2 time: one per chunk was a quarter of this
+  // kernel on hit-dense 2D data), so a workgroup takes a range of it only when its buffer could overflow, and once at the end
+  constexpr unsigned OUT_CAP = 2048;
+  static_assert(G * NTYPES <= OUT_CAP / 2, "a chunk's worst case must fit twice");
+  __shared__ u64 s_out[OUT_CAP];
+  __shared__ unsigned s_nout, s_tested;
   __shared__ u64 s_base;
 
   const int tid = threadIdx.x;
@@ -1548,12 +1867,24 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
     for (int i = 0; i < N; i ++) w |= (unsigned)fan.vert[tid][i] << (8 * i);
     s_tab[tid] = w;
   }
+  if (tid == 0) { s_nout = 0; s_tested = 0; }
   unsigned tested = 0;
+
+  auto flush = [&]() {                                  // called by the whole workgroup, after a barrier that made s_nout final
+    const unsigned n = s_nout;
+    if (tid == 0) s_base = atomicAdd(&m.counters[CNT_PASS], (u64)n);
+    __syncthreads();
+    const u64 base = s_base;
+    for (unsigned h = tid; h < n; h += kThreads)
+      if (base + h < m.capacity) m.pass[base + h] = s_out[h];
+    __syncthreads();
+    if (tid == 0) s_nout = 0;
+  };
 
   for (u64 chunk = blockIdx.x; chunk * G < count; chunk += gridDim.x) {
     __syncthreads();                                    // previous chunk's LDS readers are done
+    if (s_nout > OUT_CAP - G * NTYPES) flush();         // (workgroup-uniform: s_nout was final at the barrier above)
     if (tid < G) s_entry[tid] = (chunk * G + tid < count) ? list[chunk * G + tid] : ~0ull;
-    if (tid == 0) s_npass = 0;
     __syncthreads();
     {
       const int gi = tid / NVC, vtx = tid % NVC;
@@ -1573,8 +1904,8 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
       for (int c = 0; c < ND; c ++) s_vf[gi][vtx][c] = q[c];
     }
     __syncthreads();
-    // (corner, type) pairs over all lanes; the few that pass are parked in LDS so that the expensive FP64 record
-    // construction below runs on densely packed lanes instead of one or two lanes per wavefront
+    // (corner, type) pairs over all lanes; the few that pass go to record_kernel, whose expensive FP64 record construction then
+    // runs on densely packed lanes instead of one or two lanes per wavefront
     for (int base = 0; base < G * NTYPES; base += kThreads) {
       const int w = base + tid;
       if (w < G * NTYPES) {
@@ -1598,29 +1929,19 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
           }
           int ids[N]; double mu[N]; bool presolved;
           if (simplex_inside<ND>(m, f, 1, corner, tab, flags, X, tested, ids, mu, &presolved))
-            s_pass[atomicAdd(&s_npass, 1u)] = (unsigned short)w;
+            s_out[atomicAdd(&s_nout, 1u)] = (e & kPassLinMask) | ((u64)type << kPassTypeShift) | ((u64)(step_base + (int)(e >> 44)) << kPassStepShift);
         }
       }
     }
-    __syncthreads();
-    // the few that passed go to record_kernel: one atomic per chunk
-    const unsigned npass = s_npass;
-    if (npass) {
-      if (tid == 0) s_base = atomicAdd(&m.counters[CNT_PASS], (u64)npass);
-      __syncthreads();
-      for (unsigned h = tid; h < npass; h += kThreads) {
-        const int w = s_pass[h];
-        const int gi = w / NTYPES, type = w % NTYPES;
-        const u64 e = s_entry[gi];
-        const u64 slot = s_base + h;
-        if (slot < m.capacity) m.pass[slot] = (e & kPassLinMask) | ((u64)type << kPassTypeShift) | ((u64)(step_base + (int)(e >> 44)) << kPassStepShift);
-      }
-    }
   }
+  __syncthreads();
+  if (s_nout) flush();
   {
     unsigned t_sum = tested;
     for (int o = 32; o > 0; o >>= 1) t_sum += __shfl_down(t_sum, o);
-    if ((tid & 63) == 0 && t_sum) atomicAdd(&m.counters[CNT_SIMPLICES_TESTED], (u64)t_sum);
+    if ((tid & 63) == 0 && t_sum) atomicAdd(&s_tested, t_sum);
+    __syncthreads();
+    if (tid == 0 && s_tested) atomicAdd(&m.counters[CNT_SIMPLICES_TESTED], (u64)s_tested);
   }
 }
 
@@ -1803,6 +2124,7 @@ static const char *g_last_mask_kernel = "";
 const char *last_mask_kernel() { return g_last_mask_kernel; }
 
 void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool reduce, hipStream_t stream);
+bool masks_have_summary(const Mesh &m);
 
 // can the 128-column marching kernels (which also carry the exact pre-pass reduction) walk this mesh? (which carries the fused reduction) walk this mesh?
 bool march2_supported(const Mesh &m)
@@ -1863,8 +2185,9 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
     const int DD = m.nd == 3 ? m.ext_sz[2] : 1;
     // z chunks: long enough to amortise the two start-up planes, short enough to fill 256 CUs several times over
     int zchunk = 32;
-    if (const char *e = getenv("FTKX_MASK_ZCHUNK")) zchunk = atoi(e) > 0 ? atoi(e) : zchunk;
-    if (m.nd == 3) { while (zchunk > 8 && (size_t)((m.mask_pitch + 127) / 128) * ((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)) * ((DD + zchunk - 1) / zchunk) * njobs < 8192) zchunk /= 2; }
+    bool zforced = false;
+    if (const char *e = getenv("FTKX_MASK_ZCHUNK")) if (atoi(e) > 0) { zchunk = atoi(e); zforced = true; }
+    if (m.nd == 3 && !zforced) { while (zchunk > 8 && (size_t)((m.mask_pitch + 127) / 128) * ((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)) * ((DD + zchunk - 1) / zchunk) * njobs < 4096) zchunk /= 2; }
     int swizzle = 8;   // grouped placement -- the 4..8 x tiles of a row group on one XCD -- cuts the fabric reads from 47.7 to 41.4 GB per 512^3 x 32 launch
     if (const char *e = getenv("FTKX_MASK_SWIZZLE")) swizzle = atoi(e);
     const int nzc = m.nd == 3 ? (DD + zchunk - 1) / zchunk : 1;
@@ -1884,37 +2207,61 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       }
       const dim3 blk((unsigned)(64 * wpb));
       if (m.nd == 3 && !reduce) {
-        // default for 3D scalar slices: the producer / consumer kernel, 128 x 12 tiles (three workgroups per CU), two planes in
-        // flight behind the one being consumed; FTKX_MASK_V=4 selects mask_march4_kernel
-        int v5 = 1, pd5 = 2;
-        if (const char *e = getenv("FTKX_MASK_V")) v5 = atoi(e) == 5 || atoi(e) == 0;
+        // default for 3D scalar slices: mask_march6_kernel -- 128 x 16 tiles as four wavefronts of 4 rows that all load and classify,
+        // three row slots in LDS (two workgroups per CU), one barrier per plane.  FTKX_MASK_V=5: the producer / consumer kernel
+        // (128 x 12, three consumers + one producer), FTKX_MASK_V=4: mask_march4_kernel
+        int gen = 6, pd5 = 0, shape = 0;
+        if (const char *e = getenv("FTKX_MASK_V")) { const int v = atoi(e); gen = (v == 4 || v == 5) ? v : 6; }
         if (const char *e = getenv("FTKX_MASK_PD")) pd5 = atoi(e);
-        if (v5) {
-          int shape = 0;
-          if (const char *e = getenv("FTKX_MASK_TILE")) shape = atoi(e);
+        if (const char *e = getenv("FTKX_MASK_TILE")) shape = atoi(e);
+        if (gen == 6) {
+          if (!zforced) {   // longer chunks (start-up planes and z halo amortised) as long as the launch still fills the device several times
+            zchunk = 64;
+            while (zchunk > 8 && (size_t)((DW + 127) / 128) * ((m.ext_sz[1] + 15) / 16) * ((DD + zchunk - 1) / zchunk) * njobs < 2048) zchunk /= 2;
+          }
+          const unsigned gz = (unsigned)(((DD + zchunk - 1) / zchunk) * njobs);
+#define FTKX_M6(NS_, CY_, RY_) do { \
+            g_last_mask_kernel = (swizzle & 64) ? "ftkx::mask_march6_kernel<" #NS_ ", " #CY_ ", " #RY_ ", true>" : "ftkx::mask_march6_kernel<" #NS_ ", " #CY_ ", " #RY_ ", false>"; \
+            const int rows = CY_ * RY_; \
+            dim3 grid6((unsigned)((m.ext_sz[0] + 127) / 128), (unsigned)((m.ext_sz[1] + rows - 1) / rows), gz); \
+            int sw = swizzle; \
+            /* grouped placement needs a y extent that is a multiple of the group height: pad it (workgroups past the last row leave at once) */ \
+            if (sw & 8) { int yg = yg_want; if (yg > (int)grid6.y) yg = (int)grid6.y; grid6.y = (grid6.y + (unsigned)yg - 1) / (unsigned)yg * (unsigned)yg; sw = (sw & 0xff) | (yg << 8); } \
+            const unsigned bytes = (unsigned)(NS_) * (unsigned)(rows + 2) * 1024u + (unsigned)(NS_ + 1) * (rows > 16 ? 512u : 256u); \
+            if (sw & 64) { (void)hipFuncSetAttribute((const void *)mask_march6_kernel<NS_, CY_, RY_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+              hipLaunchKernelGGL((mask_march6_kernel<NS_, CY_, RY_, true>), grid6, dim3(64u * CY_), bytes, stream, m, d_jobs, zchunk, sw); } \
+            else { (void)hipFuncSetAttribute((const void *)mask_march6_kernel<NS_, CY_, RY_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+              hipLaunchKernelGGL((mask_march6_kernel<NS_, CY_, RY_, false>), grid6, dim3(64u * CY_), bytes, stream, m, d_jobs, zchunk, sw); } } while (0)
+          // FTKX_MASK_TILE (wavefronts x rows each): 0 = 4 x 4 (default), 1 = 3 x 4, 2 = 4 x 3, 4 = 4 x 2, 6 = 8 x 2, 9 = 8 x 4; FTKX_MASK_PD = row slots in
+          // LDS (default 3); FTKX_MASK_SWIZZLE bit 64: two barriers per plane (the slot is refilled in the step that reads it)
+          if (shape == 1) FTKX_M6(3, 3, 4);
+          else if (shape == 2) { if (pd5 == 2) FTKX_M6(2, 4, 3); else if (pd5 == 4) FTKX_M6(4, 4, 3); else FTKX_M6(3, 4, 3); }
+          else if (shape == 4) FTKX_M6(3, 4, 2);
+          else if (shape == 6) FTKX_M6(3, 8, 2);
+          else if (shape == 9) { if (pd5 == 2) FTKX_M6(2, 8, 4); else FTKX_M6(3, 8, 4); }
+          else if (pd5 == 2) FTKX_M6(2, 4, 4);
+          else if (pd5 == 4) FTKX_M6(4, 4, 4);
+          else FTKX_M6(3, 4, 4);
+#undef FTKX_M6
+          return;
+        }
+        if (gen == 5) {
 #define FTKX_M5(PD_, CY_, RY_) do { \
             g_last_mask_kernel = "ftkx::mask_march5_kernel<" #PD_ ", " #CY_ ", " #RY_ ">"; \
             const int rows = CY_ * RY_; \
             dim3 grid5((unsigned)((m.ext_sz[0] + 127) / 128), (unsigned)((m.ext_sz[1] + rows - 1) / rows), grid2.z); \
             int sw = swizzle; \
-            /* grouped placement needs a y extent that is a multiple of the group height: pad it (workgroups past the last row leave at once) */ \
             if (sw & 8) { int yg = yg_want; if (yg > (int)grid5.y) yg = (int)grid5.y; grid5.y = (grid5.y + (unsigned)yg - 1) / (unsigned)yg * (unsigned)yg; sw = (sw & 0xff) | (yg << 8); } \
             const unsigned bytes = (unsigned)(PD_ + 1) * (unsigned)(rows + 2) * 1024u + (unsigned)(PD_ + 2) * 256u; \
             (void)hipFuncSetAttribute((const void *)mask_march5_kernel<PD_, CY_, RY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
             hipLaunchKernelGGL((mask_march5_kernel<PD_, CY_, RY_>), grid5, dim3(64u * (CY_ + 1)), bytes, stream, m, d_jobs, zchunk, sw); } while (0)
-          // FTKX_MASK_TILE: 0 = 128 x 12 as three consumers of 4 rows (default), 1 = 128 x 16 (4 x 4), 2 = 128 x 8 (2 x 4), 3 = 128 x 16 (8 x 2),
-          // 4 = 128 x 16 (2 x 8), 5 = 128 x 12 (6 x 2), 6 = 128 x 8 (4 x 2), 7 = 128 x 10 (5 x 2)
-          if (shape == 1) { if (pd5 == 3) FTKX_M5(3, 4, 4); else if (pd5 == 1) FTKX_M5(1, 4, 4); else if (pd5 == 4) FTKX_M5(4, 4, 4); else FTKX_M5(2, 4, 4); }
-          else if (shape == 2) { if (pd5 == 3) FTKX_M5(3, 2, 4); else if (pd5 == 5) FTKX_M5(5, 2, 4); else if (pd5 == 6) FTKX_M5(6, 2, 4); else FTKX_M5(2, 2, 4); }
-          else if (shape == 3) { if (pd5 == 3) FTKX_M5(3, 8, 2); else FTKX_M5(2, 8, 2); }
+          // FTKX_MASK_TILE (consumers x rows each): 0 = 3 x 4 (default), 1 = 4 x 4, 4 = 2 x 8, 5 = 6 x 2, 8 = 4 x 3; FTKX_MASK_PD = planes in flight (default 2)
+          if (shape == 1) FTKX_M5(2, 4, 4);
           else if (shape == 4) FTKX_M5(2, 2, 8);
-          else if (shape == 5) { if (pd5 == 3) FTKX_M5(3, 6, 2); else FTKX_M5(2, 6, 2); }
-          else if (shape == 6) { if (pd5 == 3) FTKX_M5(3, 4, 2); else if (pd5 == 5) FTKX_M5(5, 4, 2); else if (pd5 == 6) FTKX_M5(6, 4, 2); else FTKX_M5(2, 4, 2); }
-          else if (shape == 7) FTKX_M5(2, 5, 2);
+          else if (shape == 5) FTKX_M5(2, 6, 2);
+          else if (shape == 8) FTKX_M5(2, 4, 3);
           else if (pd5 == 1) FTKX_M5(1, 3, 4);
           else if (pd5 == 3) FTKX_M5(3, 3, 4);
-          else if (pd5 == 4) FTKX_M5(4, 3, 4);
-          else if (pd5 == 5) FTKX_M5(5, 3, 4);
           else FTKX_M5(2, 3, 4);
 #undef FTKX_M5
           return;
@@ -2034,10 +2381,9 @@ void launch_records(const Mesh &m, const Fields *d_fields, hipStream_t stream)
 
 void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64 *d_list, u64 cap, hipStream_t stream)
 {
-  // persistent-style: workgroups stride over the list, every wave exits when it is drained.  The kernel uses scratch, which
-  // makes every resident wavefront expensive to start: 2D lists are long but cheap per entry and run best with fewer workgroups
-  // (woven 1024^2 x 64: 0.23 ms with 2 per CU, 0.30 with 4, 1.2 with 32)
-  int per_cu = m.nd == 2 ? 2 : 4;
+  // persistent-style: workgroups stride over the list, every wave exits when it is drained (no scratch; 21-23 KB of LDS).  Four per
+  // CU: woven 1024^2 x 64 (181 853 cells) 0.084 ms with the record kernel, double_gyre 2048 x 1024 x 128 0.078 (0.097 with two)
+  int per_cu = 4;
   if (const char *e = getenv("FTKX_EXACT_WG_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 64) per_cu = v; }
   const dim3 grid(256u * (unsigned)per_cu);
   if (m.nd == 2) hipLaunchKernelGGL(exact_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, step_base, d_list, cap);

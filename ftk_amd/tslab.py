@@ -50,17 +50,19 @@ def global_factors(local_res, nt, group=None, local_max=None):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-    mine = torch.zeros((2 * nt,), dtype=torch.float64, device=dev)
-    mine[:nt] = DBL_MAX
+    # built on the host and moved in ONE transfer each way (element-wise writes to a device tensor are a launch apiece)
+    host = np.zeros((2 * nt,), dtype=np.float64)
+    host[:nt] = DBL_MAX
     for t, r in local_res.items():
-        mine[t] = r
+        host[t] = r
     for t, v in (local_max or {}).items():
-        mine[nt + t] = v
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
-    allv = torch.stack(gathered)
-    res = allv[:, :nt].min(dim=0).values.cpu().numpy()
-    mx = allv[:, nt:].max(dim=0).values.cpu().numpy()
+        host[nt + t] = v
+    mine = torch.from_numpy(host).to(dev)
+    gathered = torch.empty((world * 2 * nt,), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    allv = gathered.cpu().numpy().reshape(world, 2 * nt)
+    res = allv[:, :nt].min(axis=0)
+    mx = allv[:, nt:].max(axis=0)
     if local_max is None:
         return factors_from_resolutions(res), res
     return factors_from_resolutions(res), res, mx

@@ -42,7 +42,7 @@ def test_slab_count_does_not_change_the_result(cfg, tmp_path):
     ref = np.load(tmp_path / "one.npz")
     assert one["pass2"]["records"] == len(ref["records"]) == one["check"]["hits"] and one["pass2"]["curves"] == len(ref["curve_loop"]) > 0
     for n, extra in ((2, ()), (3, ()), (2, ("--halo-in-loop",)), (2, ("--compact-halo",)), (3, ("--compact-halo",))):
-        many = _bench(n, cfg, extra, dump=tmp_path / f"many{n}.npz")
+        many = _bench(n, cfg, ("--scaling", "strong") + extra, dump=tmp_path / f"many{n}.npz")
         got = np.load(tmp_path / f"many{n}.npz")
         # the merged record set (72-byte records, bit for bit) and the curves traced from it: identical to the single-rank run
         assert got["records"].tobytes() == ref["records"].tobytes()
@@ -64,3 +64,17 @@ def test_slab_count_does_not_change_the_result(cfg, tmp_path):
         else:
             assert many["halo_exchange"]["in_timed_region"] == (len(extra) > 0) and many["halo_exchange"]["bytes_per_rank"] > 0
         assert many["config"]["nbits"] == one["config"]["nbits"]
+
+
+def test_weak_scaling_is_the_default_and_equals_the_long_series_on_one_rank(tmp_path):
+    """`bench.py --gpus N` without flags (what the driver runs): every rank sweeps a slab of the configuration's length, i.e. the series
+    is N times as long -- and the merged records / curves are those of that long series swept by one rank"""
+    nt = 8                                                        # small3
+    one = _bench(1, "small3", ("--timesteps", str(3 * nt)), dump=tmp_path / "one.npz")
+    many = _bench(3, "small3", dump=tmp_path / "many.npz")
+    assert many["scaling"] == "weak" and one["scaling"] == "weak" and many["n_gpus"] == 3
+    assert many["config"]["simplices_per_step"] == one["config"]["simplices_per_step"] > 0
+    ref, got = np.load(tmp_path / "one.npz"), np.load(tmp_path / "many.npz")
+    assert got["records"].tobytes() == ref["records"].tobytes() and len(ref["records"]) > 0
+    for k in ("curve_offsets", "curve_indices", "curve_loop"):
+        assert np.array_equal(got[k], ref[k]), k

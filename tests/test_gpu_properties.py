@@ -136,9 +136,9 @@ def test_reference_and_exact_tags_agree_without_overflow(gpu):
                                                 ("moving_extremum_3d", (126, 33, 6), 3, True), ("moving_extremum_3d", (386, 50, 35), 2, True),
                                                 ("woven", (1024, 512), 5, False), ("woven", (258, 100), 4, True)])
 def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
-    """The marching mask kernel exists in several forms with the same 128-column layout (mask_march4_kernel at prefetch distances
-    0..3 and 4 or 8 rows per wavefront, the producer / consumer mask_march5_kernel in a dozen tile shapes) and several workgroup
-    placements.  Same results, the same fused reduction AND the same cull statistics (cells that survive, words refined) = the
+    """The marching mask kernel exists in several forms with the same 128-column layout (mask_march6_kernel -- every wavefront loads
+    through LDS and classifies -- in several tile shapes, slot counts and with one or two barriers per plane; the producer / consumer
+    mask_march5_kernel; mask_march4_kernel at prefetch distances 0..3 and 4 or 8 rows per wavefront) and several workgroup placements.  Same results, the same fused reduction AND the same cull statistics (cells that survive, words refined) = the
     same mask / summary bytes where it matters."""
     import os
     steps = None
@@ -147,13 +147,19 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
         shape = tuple(reversed(dims))
         # (values on a 1/64 grid: the resolution stays at 2^-7, so the determinants cannot overflow and the cull stays legal)
         steps = [np.round(rng.standard_normal(shape) * 2) * 0.25 + rng.integers(-2, 3, size=shape) / 64.0 for _ in range(nt)]
-    variants = [{}, {"FTKX_MASK_V": "4"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "2"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "3"},
-                {"FTKX_MASK_SWIZZLE": "0"}, {"FTKX_MASK_SWIZZLE": "1"}, {"FTKX_MASK_V": "4", "FTKX_MASK_SWIZZLE": "1"},
-                {"FTKX_MASK_SWIZZLE": "24", "FTKX_MASK_YG": "4"}, {"FTKX_TWO_LEVEL": "0"},
-                {"FTKX_MASK_V": "4", "FTKX_MASK_RY": "8"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "0"}, {"FTKX_MASK_PD": "1"}, {"FTKX_MASK_PD": "3"},
-                {"FTKX_MASK_TILE": "1"}, {"FTKX_MASK_TILE": "1", "FTKX_MASK_PD": "3", "FTKX_MASK_SWIZZLE": "24"}, {"FTKX_MASK_TILE": "1", "FTKX_MASK_PD": "1"},
-                {"FTKX_MASK_TILE": "2"}, {"FTKX_MASK_TILE": "3"}, {"FTKX_MASK_TILE": "3", "FTKX_MASK_PD": "3"}, {"FTKX_MASK_TILE": "4"},
-                {"FTKX_MASK_TILE": "5"}, {"FTKX_MASK_TILE": "6"}, {"FTKX_MASK_TILE": "6", "FTKX_MASK_PD": "3"}, {"FTKX_MASK_TILE": "7"}]
+    variants = [{},                                                                              # mask_march6_kernel<3, 4, 4, false>
+                {"FTKX_MASK_PD": "2"}, {"FTKX_MASK_PD": "4"}, {"FTKX_MASK_SWIZZLE": "72"}, {"FTKX_MASK_PD": "2", "FTKX_MASK_SWIZZLE": "72"},
+                {"FTKX_MASK_PD": "4", "FTKX_MASK_SWIZZLE": "72"}, {"FTKX_MASK_SWIZZLE": "0"}, {"FTKX_MASK_SWIZZLE": "1"}, {"FTKX_MASK_SWIZZLE": "24", "FTKX_MASK_YG": "3"},
+                {"FTKX_MASK_ZCHUNK": "16"}, {"FTKX_MASK_ZCHUNK": "7"}, {"FTKX_TWO_LEVEL": "0"},
+                {"FTKX_MASK_TILE": "1"}, {"FTKX_MASK_TILE": "1", "FTKX_MASK_SWIZZLE": "72"}, {"FTKX_MASK_TILE": "2"}, {"FTKX_MASK_TILE": "2", "FTKX_MASK_PD": "2"},
+                {"FTKX_MASK_TILE": "2", "FTKX_MASK_PD": "4", "FTKX_MASK_SWIZZLE": "72"}, {"FTKX_MASK_TILE": "4"}, {"FTKX_MASK_TILE": "6"}, {"FTKX_MASK_TILE": "6", "FTKX_MASK_SWIZZLE": "72"},
+                {"FTKX_MASK_TILE": "9"}, {"FTKX_MASK_TILE": "9", "FTKX_MASK_PD": "2", "FTKX_MASK_SWIZZLE": "72"},
+                # the producer / consumer kernel
+                {"FTKX_MASK_V": "5"}, {"FTKX_MASK_V": "5", "FTKX_MASK_PD": "1"}, {"FTKX_MASK_V": "5", "FTKX_MASK_PD": "3"}, {"FTKX_MASK_V": "5", "FTKX_MASK_SWIZZLE": "0"},
+                {"FTKX_MASK_V": "5", "FTKX_MASK_TILE": "1"}, {"FTKX_MASK_V": "5", "FTKX_MASK_TILE": "4"}, {"FTKX_MASK_V": "5", "FTKX_MASK_TILE": "5"}, {"FTKX_MASK_V": "5", "FTKX_MASK_TILE": "8"},
+                # every wavefront loads its own rows into registers
+                {"FTKX_MASK_V": "4"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "2"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "3"}, {"FTKX_MASK_V": "4", "FTKX_MASK_SWIZZLE": "1"},
+                {"FTKX_MASK_V": "4", "FTKX_MASK_RY": "8"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "0"}]
     base = None
     for env in variants:
         old = {k: os.environ.get(k) for k in env}
