@@ -1296,6 +1296,22 @@ __device__ inline void quad_and(unsigned &T)
       "v_and_b32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
       : "+v"(T));
 }
+// OR over the four quads of every 16-lane row (lanes i, i+4, i+8, i+12): two rotate-and-OR steps
+__device__ inline void row_quads_or(unsigned &x)
+{
+  asm("s_nop 1\n\t"
+      "v_or_b32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_or_b32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf"
+      : "+v"(x));
+}
+// b in the lanes of `mask`, a elsewhere
+__device__ inline unsigned select_lanes(unsigned a, unsigned b, unsigned long long mask)
+{
+  unsigned r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+  return r;
+}
 // lane mask: byte R of T is not zero
 template <int R> __device__ inline void byte_nonzero(unsigned long long &mask, unsigned T, unsigned zero)
 {
@@ -1450,6 +1466,15 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
     moff[r] = (rok && in_row) ? mcol + (unsigned)P * (unsigned)r : OOB;
   }
   const bool wave_interior = (row_ok & row_int & row_dom) == (1u << RY) - 1u;
+  // Summaries, RY == 4: ONE dword store per FOUR planes instead of four byte stores per plane (every real store of a wavefront that
+  // also streams loads costs time: see DESIGN.md).  Lane (g, a, r) = (lane / 16, lane / 4 % 4, lane % 4) keeps, for plane a of the
+  // batch, the summaries of row r at the four word columns 4 g .. 4 g + 3 -- one dword of U as it lies in memory.
+  const bool batched = RY == 4 && have_u;
+  const unsigned a_l = ((unsigned)lane >> 2) & 3u, r_l = (unsigned)lane & 3u, g_l = (unsigned)lane >> 4;
+  const unsigned uplane_stride = (unsigned)m.u_pitch * (unsigned)DH;
+  const unsigned uo4 = ((row_ok >> r_l) & 1u) ? a_l * uplane_stride + r_l * (unsigned)m.u_pitch + (unsigned)(t0c >> 3) + 4u * g_l : OOB;
+  const unsigned psel = (0x0c0c0c0cu & ~(0xffu << (8u * a_l))) | (r_l << (8u * a_l));   // v_perm: byte a <- byte r of the source, 0 elsewhere
+  unsigned uacc = 0u;
   const unsigned vzero = 0u;
 
   // LDS reads by hand (see the header): issue them all, one lgkmcnt wait, then tie the registers to the wait
@@ -1461,7 +1486,8 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
 
   auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], v2d (&NX)[RY + 2], int k) {
     // this wavefront's share of plane k+1 has landed: all but the operations issued after it may still be in flight
-    wait_plane_landed<DEPTH, RY, 2 * RY>(k - z0);
+    if (batched) wait_plane_landed<DEPTH, RY, RY>(k - z0);    // (the summaries' one store per four planes is not counted: the wait is one operation stricter then)
+    else wait_plane_landed<DEPTH, RY, 2 * RY>(k - z0);
     __builtin_amdgcn_s_barrier();                              // ... and so has everybody else's
     const bool live = k < z1;                                  // (wave-uniform) padding steps of the chunk have nothing to classify or store
     if constexpr (!TWOB) { const int q = k + NS; issue(q < z1 ? q : z1); }   // the slot read during the previous step, the edge entry of plane k-1
@@ -1545,6 +1571,20 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
     static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; byte_nonzero<r % 4>(wu[r], T[r / 4], vzero); });
     if constexpr (RY < 3) asm volatile("s_nop 1");
     static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; mo[r] = out_of_range_where(moff[r], wu[r]); });
+    if (batched) {
+      // every lane of a quad holds the quad's T (byte r = row r at the quad's word column).  Lane (a, r) moves ITS row's byte to byte a;
+      // the OR over the row's four quads then is the dword [row r at word columns 4 g .. 4 g + 3], in all four quads; quad j keeps it
+      const int j = (k - z0) & 3;
+      unsigned c = __builtin_amdgcn_perm(0u, T[0], psel);
+      row_quads_or(c);
+      uacc = select_lanes(uacc, c, 0x000f000f000f000full << (4 * j));
+      if (j == 3 || k == z1 - 1) {                             // (wave-uniform) four planes gathered, or the chunk ends
+        const unsigned off = j == 3 ? uo4 : (a_l <= (unsigned)j ? uo4 : OOB);
+        __builtin_amdgcn_raw_buffer_store_b32(uacc, rU, off, uplane - (unsigned)j * uplane_stride, 0);
+      }
+      static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bw[r], rM, mo[r], mplane, 0); });
+      return;
+    }
     static_for<RY>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(T[r / 4] >> (8 * (r % 4))), rU, uoff[r], uplane, 0);
