@@ -32,6 +32,7 @@ void launch_scatter_words(const unsigned *idx, const u64 *words, size_t n, unsig
 void launch_sparse_cells(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, const double *sparse, u64 *cells, u64 cells_cap, hipStream_t st);
 void launch_patches(const Mesh &m, bool scatter, const u64 *cells, size_t n, int ncomp, double *field, double *patches, hipStream_t st);
 bool masks_have_summary(const Mesh &m);
+int mask_summary_rows(const Mesh &m);
 bool march2_supported(const Mesh &m);
 bool masks_fuse_reduction(const Mesh &m);
 void launch_reduce_march(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream);
@@ -62,6 +63,7 @@ struct Slice {
   unsigned char *U = nullptr;       // per-8-vertex summaries of M (two-level cull)
   bool ownV = false, ownJ = false, ownS = false;
   unsigned long long mask_factor = 0;   // the (power-of-two) factor M / U were built under; 0 = not built
+  int u_rows = 1;                   // rows a byte of U stands for (Mesh::u_rows at the time the masks were built)
   bool mask_big = false;            // built with the per-vertex overflow rule of that factor (MaskJob::big finite)
   bool have_res = false;            // res = ndarray::resolution() of the slice's vector field (exact pre-pass), maxabs with it
   double res = 0, maxabs = 0;
@@ -169,7 +171,9 @@ size_t n_vertices(const ftkx_ctx *c)
 
 int mask_pitch(const ftkx_ctx *c) { return (int)(((c->ext_sz[0] + 7) / 8) * 8 + 8); }
 int u_pitch(const ftkx_ctx *c) { return (int)((((c->ext_sz[0] + 7) / 8 + 7) / 8) * 8 + 8); }
-size_t u_bytes(const ftkx_ctx *c) { return (size_t)u_pitch(c) * (size_t)c->ext_sz[1] * (size_t)(c->nd == 3 ? c->ext_sz[2] : 1); }
+size_t u_bytes(const ftkx_ctx *c) { return (size_t)u_pitch(c) * (size_t)c->ext_sz[1] * (size_t)(c->nd == 3 ? c->ext_sz[2] : 1); }   // allocation (u_rows = 1)
+// the part of a summary array that carries data: ceil(rows / u_rows) rows per plane, planes back to back
+size_t u_bytes_used(const ftkx_ctx *c, const Mesh &m) { return (size_t)u_pitch(c) * (size_t)((c->ext_sz[1] + m.u_rows - 1) / m.u_rows) * (size_t)(c->nd == 3 ? c->ext_sz[2] : 1); }
 size_t mask_bytes(const ftkx_ctx *c) { return (size_t)mask_pitch(c) * (size_t)c->ext_sz[1] * (size_t)(c->nd == 3 ? c->ext_sz[2] : 1); }
 
 void free_slice(Slice &s, ftkx_ctx *pool_owner = nullptr)
@@ -272,6 +276,7 @@ void fill_mesh(const ftkx_ctx *c, Mesh &m)
   }
   m.mask_pitch = mask_pitch(c);
   m.u_pitch = u_pitch(c);
+  m.u_rows = 1;
   m.jacobian_symmetric = c->opt.jacobian_symmetric; m.robust = c->opt.robust;
   m.use_type_filter = c->opt.use_type_filter; m.type_filter = c->opt.type_filter;
   m.compute_degrees = c->opt.compute_degrees; m.tag_mode = c->opt.tag_mode;
@@ -282,6 +287,7 @@ void fill_mesh(const ftkx_ctx *c, Mesh &m)
   for (int d = 0; d < 3; d ++) m.coords_rect[d] = c->d_rect[d];
   m.coords_expl = c->d_expl; m.coords_expl_ncomp = c->expl_ncomp; m.coords_expl_n0 = (int)c->expl_n0;
   m.hits = c->d_hits; m.pass = c->d_pass; m.counters = c->d_counters; m.capacity = c->capacity;
+  m.u_rows = ftkx::mask_summary_rows(m);
 }
 
 int slice_resolution(ftkx_ctx *c, Slice &s)
@@ -330,9 +336,10 @@ bool pow2_factor(u64 factor) { return factor != 0 && (factor & (factor - 1)) == 
 // Masks built under mask_factor serve a sweep under `factor` when they can only cull less than masks built under `factor`
 // itself: the sign thresholds need mask_factor <= factor; the per-vertex overflow rule (MaskJob::big) is factor-specific, so a
 // larger factor is accepted only when the slice's max |v| shows that no vertex is big under it either.
-bool masks_valid(const ftkx_ctx *c, const Slice &s, u64 factor, bool two_level)
+bool masks_valid(const ftkx_ctx *c, const Slice &s, u64 factor, bool two_level, int u_rows)
 {
   if (!s.M || (two_level && !s.U) || s.mask_factor == 0 || s.mask_factor > factor) return false;
+  if (two_level && s.u_rows != u_rows) return false;           // summaries of another geometry (FTKX_MASK_* changed since)
   if (s.mask_big && s.mask_factor == factor) return true;
   return s.max_known() && overflow_free(c->nd, s.maxabs, factor);   // no vertex is big under `factor`: the rule would change nothing
 }
@@ -463,7 +470,7 @@ int run_batch(ftkx_ctx *c, const double *sparse_field = nullptr)
     if (r.mode == MODE_FAST) {
       for (Slice *s : {&s0, s1}) {
         if (!s) continue;
-        if (masks_valid(c, *s, r.factor, two_level)) continue;     // e.g. built by ftkx_slices_prepare, or by an earlier step
+        if (masks_valid(c, *s, r.factor, two_level, m.u_rows)) continue;     // e.g. built by ftkx_slices_prepare, or by an earlier step
         if (s->sparse) return fail(c, FTKX_E_NOSLICE, "sweep: the masks of halo slice (masks only) do not serve factor %llu: send the slice itself", r.factor);
         int rc = ensure_mask_arrays(c, *s, two_level);
         if (rc) return rc;
@@ -475,7 +482,7 @@ int run_batch(ftkx_ctx *c, const double *sparse_field = nullptr)
         bool rule_on;
         const double big = job_big(c, *s, r.factor, &rule_on);
         subs.back().jobs.push_back(MaskJob{s->S, s->V, s->M, two_level ? s->U : nullptr, nullptr, 1.0 / (double)r.factor, big});
-        s->mask_factor = r.factor; s->mask_big = rule_on;
+        s->mask_factor = r.factor; s->mask_big = rule_on; s->u_rows = m.u_rows;
       }
       f.M[0] = s0.M; f.M[1] = s1 ? s1->M : nullptr;
       f.U[0] = two_level ? s0.U : nullptr; f.U[1] = (two_level && s1) ? s1->U : nullptr;
@@ -911,7 +918,7 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
       Slice &s = *todo[i];
       memcpy(&s.res_below, &mn, 8);
       double mxd; memcpy(&mxd, &mx, 8);
-      s.mask_factor = hint; s.mask_big = false; s.fused_factor = hint; s.have_fused = true;
+      s.mask_factor = hint; s.mask_big = false; s.fused_factor = hint; s.have_fused = true; s.u_rows = m.u_rows;
       if (std::isinf(mxd)) with_inf.push_back(&s);        // the fused max cannot skip an Inf: the exact pre-pass gives max FINITE |v|
       else if (!s.have_res) s.maxabs = mxd;
     }
@@ -962,7 +969,7 @@ int ftkx_export_masks_size(ftkx_ctx *c, int t, size_t *u_bytes_out, size_t *n_wo
     HIP_TRY(c, hipMalloc((void **)&c->d_words, cap * sizeof(u64)));
     c->words_cap = cap;
   }
-  if (u_bytes_out) *u_bytes_out = u_bytes(c);
+  if (u_bytes_out) *u_bytes_out = u_bytes_used(c, m);
   if (n_words) *n_words = c->n_words;
   if (mask_factor) *mask_factor = s.mask_factor;
   if (max_abs) *max_abs = s.maxabs;
@@ -976,7 +983,8 @@ int ftkx_export_masks(ftkx_ctx *c, int t, void *U_dst, unsigned *word_index_dst,
   if (it == c->slices.end() || c->words_t != t) return fail(c, FTKX_E_INVALID, "ftkx_export_masks: call ftkx_export_masks_size for timestep %d first", t);
   HIP_TRY(c, hipSetDevice(c->device));
   int rc;
-  if ((rc = copy_out(c, U_dst, it->second.U, u_bytes(c), dst_on_device))) return rc;
+  Mesh m; fill_mesh(c, m);
+  if ((rc = copy_out(c, U_dst, it->second.U, u_bytes_used(c, m), dst_on_device))) return rc;
   if (c->n_words && (!word_index_dst || !words_dst)) return fail(c, FTKX_E_INVALID, "ftkx_export_masks: null list buffers");
   if ((rc = copy_out(c, word_index_dst, c->d_word_idx, c->n_words * sizeof(unsigned), dst_on_device))) return rc;
   if ((rc = copy_out(c, words_dst, c->d_words, c->n_words * sizeof(u64), dst_on_device))) return rc;
@@ -1015,7 +1023,7 @@ int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, 
     s.sparse = true;
   }
   const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  HIP_TRY(c, hipMemcpyAsync(s.U, U, u_bytes(c), kind, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(s.U, U, u_bytes_used(c, m), kind, c->stream));
   if (n_words) {
     if (c->words_cap < n_words) {
       if (c->d_word_idx) (void)hipFree(c->d_word_idx);
@@ -1036,7 +1044,7 @@ int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, 
   };
   const int frc = fill();
   if (frc != FTKX_OK) { free_slice(s, c); c->scalar_mode = saved_mode; return frc; }
-  s.mask_factor = mask_factor; s.mask_big = false;
+  s.mask_factor = mask_factor; s.mask_big = false; s.u_rows = m.u_rows;
   s.maxabs = max_abs;                                                                  // (all a masked slice knows of its values)
   c->slices[t] = s;
   return FTKX_OK;

@@ -1470,9 +1470,12 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
   // also streams loads costs time: see DESIGN.md).  Lane (g, a, r) = (lane / 16, lane / 4 % 4, lane % 4) keeps, for plane a of the
   // batch, the summaries of row r at the four word columns 4 g .. 4 g + 3 -- one dword of U as it lies in memory.
   const bool batched = RY == 4 && have_u;
+  const bool block4 = batched && m.u_rows == 4;                // one summary byte per 8 x 4 block (this wavefront's four rows)
   const unsigned a_l = ((unsigned)lane >> 2) & 3u, r_l = (unsigned)lane & 3u, g_l = (unsigned)lane >> 4;
-  const unsigned uplane_stride = (unsigned)m.u_pitch * (unsigned)DH;
-  const unsigned uo4 = ((row_ok >> r_l) & 1u) ? a_l * uplane_stride + r_l * (unsigned)m.u_pitch + (unsigned)(t0c >> 3) + 4u * g_l : OOB;
+  const unsigned urows = (unsigned)((DH + m.u_rows - 1) / m.u_rows);
+  const unsigned uplane_stride = (unsigned)m.u_pitch * urows;
+  // (block summaries: the quad's four lanes hold the same dword; lane r = 0 stores it -- if the block's first row exists)
+  const unsigned uo4 = (block4 ? (r_l == 0 && (row_ok & 1u)) : ((row_ok >> r_l) & 1u)) ? a_l * uplane_stride + (block4 ? 0u : r_l * (unsigned)m.u_pitch) + (unsigned)(t0c >> 3) + 4u * g_l : OOB;
   const unsigned psel = (0x0c0c0c0cu & ~(0xffu << (8u * a_l))) | (r_l << (8u * a_l));   // v_perm: byte a <- byte r of the source, 0 elsewhere
   unsigned uacc = 0u;
   const unsigned vzero = 0u;
@@ -1506,7 +1509,7 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
     const bool z_dom = k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2];
     const bool z_int = k >= 1 && k < DD - 1;
     const unsigned mplane = (unsigned)P * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
-    const unsigned uplane = (unsigned)m.u_pitch * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
+    const unsigned uplane = (unsigned)m.u_pitch * ((unsigned)(j0 / m.u_rows) + urows * (unsigned)k);
     // A wavefront issues ONE instruction per four cycles, scalar or vector: per-row tests and branches cost as much as the sign
     // arithmetic.  So the rows come in four compile-time flavours -- INTERIOR: every row of this wavefront and this plane lies inside
     // the domain (no per-row boundary logic at all; 15 of 16 tiles, 507 of 512 planes on a 512^3 slice); RULE: the per-vertex
@@ -1560,22 +1563,35 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
         });
       }
     }
-    // summaries: byte r of T = AND of row r's two mask bytes, then of the quad's four lanes -- all rows in one pair of permutes
+    // summaries: byte r of T = AND of row r's two mask bytes, then of the quad's four lanes -- all rows in one pair of permutes.  A
+    // word (block) that has no common sign bit gets its mask words stored; the others aim beyond the buffer
     unsigned T[(RY + 3) / 4];
-    static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; pack_pair_and<r % 4>(T[r / 4], bw[r]); });
-    static_for<(RY + 3) / 4>([&](auto gc) { quad_and(T[decltype(gc)::value]); });
-    if (!have_u) static_for<(RY + 3) / 4>([&](auto gc) { T[decltype(gc)::value] = 0u; });   // (wave-uniform) no summaries: every mask word is stored
-    // exactly two stores per row, whatever the data: rows / lanes without one aim beyond the buffer
     unsigned long long wu[RY];
     unsigned mo[RY];
-    static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; byte_nonzero<r % 4>(wu[r], T[r / 4], vzero); });
-    if constexpr (RY < 3) asm volatile("s_nop 1");
-    static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; mo[r] = out_of_range_where(moff[r], wu[r]); });
+    if (block4) {
+      // ONE byte for the wavefront's four rows: the sign bits all 8 x 4 vertices share
+      if constexpr (RY == 4) {
+        unsigned all = bw[0] & bw[1];
+        all &= bw[2] & bw[3];
+        pack_pair_and<0>(T[0], all);
+        quad_and(T[0]);
+        byte_nonzero<0>(wu[0], T[0], vzero);
+        asm volatile("s_nop 1");
+        static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; mo[r] = out_of_range_where(moff[r], wu[0]); });
+      }
+    } else {
+      static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; pack_pair_and<r % 4>(T[r / 4], bw[r]); });
+      static_for<(RY + 3) / 4>([&](auto gc) { quad_and(T[decltype(gc)::value]); });
+      if (!have_u) static_for<(RY + 3) / 4>([&](auto gc) { T[decltype(gc)::value] = 0u; });   // (wave-uniform) no summaries: every mask word is stored
+      static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; byte_nonzero<r % 4>(wu[r], T[r / 4], vzero); });
+      if constexpr (RY < 3) asm volatile("s_nop 1");
+      static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; mo[r] = out_of_range_where(moff[r], wu[r]); });
+    }
     if (batched) {
       // every lane of a quad holds the quad's T (byte r = row r at the quad's word column).  Lane (a, r) moves ITS row's byte to byte a;
       // the OR over the row's four quads then is the dword [row r at word columns 4 g .. 4 g + 3], in all four quads; quad j keeps it
       const int j = (k - z0) & 3;
-      unsigned c = __builtin_amdgcn_perm(0u, T[0], psel);
+      unsigned c = block4 ? (T[0] << (8u * a_l)) : __builtin_amdgcn_perm(0u, T[0], psel);
       row_quads_or(c);
       uacc = select_lanes(uacc, c, 0x000f000f000f000full << (4 * j));
       if (j == 3 || k == z1 - 1) {                             // (wave-uniform) four planes gathered, or the chunk ends
@@ -1804,25 +1820,36 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(const Mesh m, const Me
   if (blockIdx.x == 0 && threadIdx.x == 0) { atomicMax(&m.counters[CNT_REFINE_PEAK], count); atomicAdd(&m.counters[CNT_WORDS_REFINED], count); }
   if (count > refine_capacity) count = refine_capacity;
   const u64 k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
-  for (u64 base = (u64)blockIdx.x * kThreads; base < count; base += (u64)gridDim.x * kThreads) {   // block-uniform trip count
+  // an entry of the refine list is a coarse cell: 8 corners along x times u_rows rows -- one lane per row of it
+  const u64 UR = (u64)m.u_rows, urows = (u64)((DH + m.u_rows - 1) / m.u_rows);
+  const u64 work = count * UR;
+  for (u64 base = (u64)blockIdx.x * kThreads; base < work; base += (u64)gridDim.x * kThreads) {   // block-uniform trip count
     const u64 idx = base + threadIdx.x;
     u64 surv_o = 0, surv_i = 0, row_lin = 0;
     int g = 0, step = 0;
-    if (idx < count) {
-      const u64 e = refine[idx];
+    bool mine = idx < work;
+    int j = 0, k = 0, cy = 0, cz = 0;
+    unsigned want = 0;
+    if (mine) {
+      const u64 e = refine[idx / UR];
       step = (int)(e >> 44);
-      const unsigned want = (unsigned)((e >> 40) & 3);
+      want = (unsigned)((e >> 40) & 3);
       u64 lin = e & 0xffffffffffull;
       g = mc.core_st[0] + (int)(lin % (u64)mc.core_sz[0]); lin /= (u64)mc.core_sz[0];
-      const int cy = mc.core_st[1] + (int)(lin % (u64)mc.core_sz[1]); lin /= (u64)mc.core_sz[1];
-      const int cz = (ND == 3) ? mc.core_st[2] + (int)lin : 0;
-      const int j = cy - m.ext_st[1], k = cz - m.ext_st[2];
+      const int cyc = mc.core_st[1] + (int)(lin % (u64)mc.core_sz[1]); lin /= (u64)mc.core_sz[1];   // coarse row, relative to the array
+      cz = (ND == 3) ? mc.core_st[2] + (int)lin : 0;
+      j = cyc * m.u_rows + (int)(idx % UR); k = cz - m.ext_st[2];
+      cy = j + m.ext_st[1];
+      mine = cy >= m.core_st[1] && cy < m.core_st[1] + m.core_sz[1];      // (a block at the edge of the core: not all of its rows are corners)
+    }
+    if (mine) {
       const Fields f = steps[step];
       const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0 && (want & 2);
       u64 a0 = ~0ull, a1 = ~0ull;
       // words whose summary is non-zero were not written to M (mask_march2_kernel): their summary, replicated, stands in
-      auto row_pair_and = [&](const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ Up, size_t row) -> u64 {
-        const unsigned char *u = Up + (size_t)m.u_pitch * row + g;
+      auto row_pair_and = [&](const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ Up, int jj, int kk) -> u64 {
+        const size_t row = (size_t)jj + (size_t)DH * (size_t)kk;
+        const unsigned char *u = Up + (size_t)m.u_pitch * ((size_t)(jj / m.u_rows) + (size_t)urows * (size_t)kk) + g;
         const u64 *w = reinterpret_cast<const u64 *>(Mp + (size_t)P * row) + g;
         const unsigned u0 = u[0], u1 = u[1];                       // the summary pitch has spare bytes too
         const u64 w0 = u0 ? (u64)u0 * 0x0101010101010101ull : w[0];
@@ -1832,9 +1859,8 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(const Mesh m, const Me
       for (int dz = 0; dz < (ND == 3 ? 2 : 1); dz ++)
         for (int dy = 0; dy < 2; dy ++) {
           if (j + dy >= DH || k + dz >= DD) continue;                   // row outside the array: invalid vertices, neutral
-          const size_t row = (size_t)(j + dy) + (size_t)DH * (size_t)(k + dz);
-          a0 &= row_pair_and(f.M[0], f.U[0], row);
-          if (need_next) a1 &= row_pair_and(f.M[1], f.U[1], row);
+          a0 &= row_pair_and(f.M[0], f.U[0], j + dy, k + dz);
+          if (need_next) a1 &= row_pair_and(f.M[1], f.U[1], j + dy, k + dz);
         }
       u64 in_core = 0;
       for (int b = 0; b < 8; b ++) {
@@ -2041,10 +2067,15 @@ __global__ __launch_bounds__(kThreads) void compact_words_kernel(const Mesh m, c
   const int UP = m.u_pitch, P = m.mask_pitch, DH = m.ext_sz[1], DD = m.nd == 3 ? m.ext_sz[2] : 1;
   const int ngroups = (m.ext_sz[0] + 7) / 8;
   const size_t total = (size_t)ngroups * DH * DD, padded = (total + 63) / 64 * 64;
+  const size_t urows = (size_t)((DH + m.u_rows - 1) / m.u_rows);
   for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < padded; i += (size_t)gridDim.x * kThreads) {
     bool take = false;
     size_t row = 0; int g = 0;
-    if (i < total) { row = i / ngroups; g = (int)(i - row * ngroups); take = U[row * (size_t)UP + g] == 0; }
+    if (i < total) {
+      row = i / ngroups; g = (int)(i - row * ngroups);
+      const size_t k = row / (size_t)DH, j = row - k * (size_t)DH;       // the summary of the word's block: row j / u_rows of plane k
+      take = U[(j / (size_t)m.u_rows + urows * k) * (size_t)UP + g] == 0;
+    }
     const unsigned long long b = __ballot(take);
     if (!b) continue;
     const int lane = threadIdx.x & 63, leader = __ffsll((long long)b) - 1;
@@ -2165,6 +2196,7 @@ const char *last_mask_kernel() { return g_last_mask_kernel; }
 
 void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool reduce, hipStream_t stream);
 bool masks_have_summary(const Mesh &m);
+int mask_summary_rows(const Mesh &m);
 
 // can the 128-column marching kernels (which also carry the exact pre-pass reduction) walk this mesh? (which carries the fused reduction) walk this mesh?
 bool march2_supported(const Mesh &m)
@@ -2352,6 +2384,18 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
   else hipLaunchKernelGGL(mask_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs);
 }
 
+// Rows a summary byte stands for.  mask_march6_kernel with four rows per wavefront writes ONE byte per 8 x 4 block of vertices
+// (aligned in y): a quarter of the summary bytes to write (what they cost: DESIGN.md) and for the coarse cull to read.  Everything
+// else writes one byte per word of 8.  The same decision as launch_masks_impl's choice of kernel (same environment knobs).
+int mask_summary_rows(const Mesh &m)
+{
+  if (m.nd != 3 || !m.scalar_mode || !masks_have_summary(m)) return 1;
+  if (const char *e = getenv("FTKX_MASK_V")) { const int v = atoi(e); if (v == 4 || v == 5) return 1; }
+  if (const char *e = getenv("FTKX_MASK_TILE")) { const int t = atoi(e); if (t == 2 || t == 4 || t == 6) return 1; }   // shapes with 3 or 2 rows per wavefront
+  if (const char *e = getenv("FTKX_U_ROWS")) if (atoi(e) == 1) return 1;
+  return 4;
+}
+
 // does launch_masks produce the per-word summaries for this mesh?  (the 128-column marching kernels and the fast vector kernel do)
 bool masks_have_summary(const Mesh &m)
 {
@@ -2400,10 +2444,13 @@ void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, 
 void launch_cull_two_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream)
 {
   if (nsteps <= 0) return;
-  Mesh mc = m;                                   // the coarse view: one "vertex" per aligned word of 8
+  Mesh mc = m;                                   // the coarse view: one "vertex" per aligned word of 8 (x) and u_rows rows (y)
   const int w0 = (m.core_st[0] - m.ext_st[0]) / 8, w1 = (m.core_st[0] + m.core_sz[0] - 1 - m.ext_st[0]) / 8;
   mc.ext_st[0] = 0; mc.ext_sz[0] = (m.ext_sz[0] + 7) / 8;
   mc.core_st[0] = w0; mc.core_sz[0] = w1 - w0 + 1;
+  const int r0 = (m.core_st[1] - m.ext_st[1]) / m.u_rows, r1 = (m.core_st[1] + m.core_sz[1] - 1 - m.ext_st[1]) / m.u_rows;
+  mc.ext_st[1] = 0; mc.ext_sz[1] = (m.ext_sz[1] + m.u_rows - 1) / m.u_rows;
+  mc.core_st[1] = r0; mc.core_sz[1] = r1 - r0 + 1;
   mc.mask_pitch = m.u_pitch;
   launch_cull_level<true>(mc, d_steps, nsteps, d_refine, refine_cap, stream);
   const dim3 grid(256 * 4);

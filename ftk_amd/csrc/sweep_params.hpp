@@ -26,6 +26,8 @@ struct Mesh {
   u64 exact_prod[4];         // same in 64 bits
   int mask_pitch;            // row pitch (bytes) of the vertex-mask arrays: roundup8(ext_sz[0]) + 8
   int u_pitch;               // row pitch of the per-8-vertex summary arrays: roundup8(ceil(ext_sz[0] / 8)) + 8
+  int u_rows;                // rows a summary byte stands for: 1 (a word of 8 vertices) or 4 (the 8 x 4 block of aligned rows; row
+                             // index of U = y / u_rows, ceil(ext_sz[1] / u_rows) rows per plane) -- mask_summary_rows()
   int jacobian_symmetric, robust, use_type_filter;
   unsigned type_filter;
   int compute_degrees, tag_mode;

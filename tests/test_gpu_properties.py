@@ -150,7 +150,7 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
     variants = [{},                                                                              # mask_march6_kernel<3, 4, 4, false>
                 {"FTKX_MASK_PD": "2"}, {"FTKX_MASK_PD": "4"}, {"FTKX_MASK_SWIZZLE": "72"}, {"FTKX_MASK_PD": "2", "FTKX_MASK_SWIZZLE": "72"},
                 {"FTKX_MASK_PD": "4", "FTKX_MASK_SWIZZLE": "72"}, {"FTKX_MASK_SWIZZLE": "0"}, {"FTKX_MASK_SWIZZLE": "1"}, {"FTKX_MASK_SWIZZLE": "24", "FTKX_MASK_YG": "3"},
-                {"FTKX_MASK_ZCHUNK": "16"}, {"FTKX_MASK_ZCHUNK": "7"}, {"FTKX_TWO_LEVEL": "0"},
+                {"FTKX_MASK_ZCHUNK": "16"}, {"FTKX_MASK_ZCHUNK": "7"}, {"FTKX_TWO_LEVEL": "0"}, {"FTKX_U_ROWS": "1"}, {"FTKX_U_ROWS": "1", "FTKX_MASK_ZCHUNK": "6"},
                 {"FTKX_MASK_TILE": "1"}, {"FTKX_MASK_TILE": "1", "FTKX_MASK_SWIZZLE": "72"}, {"FTKX_MASK_TILE": "2"}, {"FTKX_MASK_TILE": "2", "FTKX_MASK_PD": "2"},
                 {"FTKX_MASK_TILE": "2", "FTKX_MASK_PD": "4", "FTKX_MASK_SWIZZLE": "72"}, {"FTKX_MASK_TILE": "4"}, {"FTKX_MASK_TILE": "6"}, {"FTKX_MASK_TILE": "6", "FTKX_MASK_SWIZZLE": "72"},
                 {"FTKX_MASK_TILE": "9"}, {"FTKX_MASK_TILE": "9", "FTKX_MASK_PD": "2", "FTKX_MASK_SWIZZLE": "72"},
@@ -161,6 +161,7 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
                 {"FTKX_MASK_V": "4"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "2"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "3"}, {"FTKX_MASK_V": "4", "FTKX_MASK_SWIZZLE": "1"},
                 {"FTKX_MASK_V": "4", "FTKX_MASK_RY": "8"}, {"FTKX_MASK_V": "4", "FTKX_MASK_PD": "0"}]
     base = None
+    words = None
     for env in variants:
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
@@ -178,10 +179,18 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
             assert st["cull_enabled"] == 1
         else:
             _same(recs, base[0])
-            if env.get("FTKX_TWO_LEVEL") == "0":        # one-level cull: words the summaries stand in for are culled on their real bytes
-                assert key[1:] == base[1][1:] and key[0] <= base[1][0], (env, key, base[1])
-            else:
+            # The records never differ.  The cull statistics are those of the summary geometry: where a summary stands in for mask words
+            # that were not written, it can only cull less than the real bytes -- the one-level cull (no summaries) leaves the fewest
+            # cells, one byte per word of 8 more, one byte per 8 x 4 block (the default kernel with four rows per wavefront) the most
+            blocks = env.get("FTKX_MASK_V") in (None, "6") and env.get("FTKX_MASK_TILE") not in ("2", "4", "6") and env.get("FTKX_U_ROWS") != "1" and len(dims) == 3
+            if env.get("FTKX_TWO_LEVEL") == "0":
+                assert key[2] == base[1][2] and key[0] <= base[1][0] and key[1] <= base[1][1], (env, key, base[1])
+            elif blocks:
                 assert key == base[1], (env, key, base[1])
+            else:
+                assert key[2] == base[1][2] and key[0] <= base[1][0] and key[1] <= base[1][1], (env, key, base[1])
+                words = words or key
+                assert key == words, (env, key, words)          # all per-word kernels agree among themselves
 
 
 def test_slices_beyond_4GiB_take_the_64bit_kernels(gpu):
