@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--compact-halo", action="store_true", help="N > 1: inside every timed pass, exchange sign masks + patches around the surviving cells instead of the boundary slice")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = one slab of the configuration's length per rank (series of nt*N timesteps); strong = the configuration's series cut into N slabs")
     ap.add_argument("--timesteps", type=int, default=0, help="override the length of the series")
+    ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the kernels (what do they cost a pass?); the line then carries no roofline")
     ap.add_argument("--dump-merged", default=None, help="rank 0 writes the merged records and the curves traced from them (npz)")
     args = ap.parse_args()
 
@@ -248,7 +249,7 @@ def main():
 
     for _ in range(args.warmup):
         recs, st = one_pass()
-    ctx.set_profiling(True)         # HIP events around every kernel launch, on the stream the kernels run on
+    ctx.set_profiling(not args.no_kernel_events)         # HIP events around every kernel launch, on the stream the kernels run on
     host_ms[0] = host_ms[1] = host_ms[2] = 0.0
     compact_bytes[0] = compact_bytes[1] = compact_bytes[2] = compact_bytes[3] = 0
     barrier()
@@ -322,7 +323,10 @@ def main():
         check["types"] = sorted(set(int(v) for v in merged["type"]))
         check["curves"] = pass2["curves"]
 
-    if rank == 0:
+    if rank == 0 and args.no_kernel_events:
+        print(json.dumps({"experiment": "no kernel events", "config": args.config, "ms_per_step": elapsed / args.steps * 1e3,
+                          "wall_breakdown_ms_per_pass": {"prepare": host_ms[2] / args.steps, "enqueue": host_ms[0] / args.steps, "collect": host_ms[1] / args.steps}}))
+    elif rank == 0:
         n_vertex = int(np.prod(dims))
         c = 1 if scalar_input else nd
         # dominant kernel = the one with the most device time; one launch of it covers `len(own)` slices (batched launch)
