@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--compact-halo", action="store_true", help="N > 1: inside every timed pass, exchange sign masks + patches around the surviving cells instead of the boundary slice")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = one slab of the configuration's length per rank (series of nt*N timesteps); strong = the configuration's series cut into N slabs")
     ap.add_argument("--timesteps", type=int, default=0, help="override the length of the series")
+    ap.add_argument("--no-cull-ahead", action="store_true", help="experiment: do not announce the sweeps to slices_prepare (the cull then waits for the factors)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the kernels (what do they cost a pass?); the line then carries no roofline")
     ap.add_argument("--dump-merged", default=None, help="rank 0 writes the merged records and the curves traced from them (npz)")
     args = ap.parse_args()
@@ -168,17 +169,32 @@ def main():
     # One pass = the whole sweep from resident input to records on the host, INCLUDING what the reference does at the top of
     # update_timestep (update_vector_field_scaling_factor): ftkx_slices_prepare reads every slice once and yields the sign masks
     # and the per-slice reduction together; the factors follow on the host (N > 1: one all_gather of 2 nt doubles).
+    def scope_of(t):
+        return ftk_amd.SCOPE_BOTH if (t + 1 < nt) else ftk_amd.SCOPE_ORDINAL
+
+    ann_ts, ann_scopes = np.array(own, dtype=np.int32), np.array([scope_of(t) for t in own], dtype=np.int32)
+    own_next_resident = (not own) or t1_own >= nt       # the last slab needs no halo slice: every slice its sweeps read is its own
+
     def prepare_and_factors():
-        local_rm = ctx.slices_prepare(own, 0)
-        local_res = {t: v[0] for t, v in local_rm.items()}
+        # the sweeps that will follow are known before the factors are: announced, their cull is queued right behind the mask kernel
+        # and runs while the host waits for the reduction and forms the factors.  N > 1: the next slab's first slice, once resident,
+        # is prepared in the same launch (its owner's reduction stands: set_slice_resolution)
+        prep = list(own)
+        if halo_pushed[0] and not args.compact_halo:
+            prep.append(t1_own)
+        if not args.compact_halo and not args.no_cull_ahead and (own_next_resident or halo_pushed[0]):
+            ctx.sweep_announce(ann_ts, ann_scopes)
+        local_rm = ctx.slices_prepare(prep, 0)
+        local_res = {t: local_rm[t][0] for t in own}
+        local_rm = {t: local_rm[t] for t in own}
         if world > 1:
             return tslab.global_factors(local_res, nt, local_max={t: v[1] for t, v in local_rm.items()})
         return tslab.factors_from_resolutions([local_res[t] for t in range(nt)]), None, None
 
+    halo_pushed = [False]
     factors, all_res, all_max = prepare_and_factors()      # also loads the code objects (a one-time cost of a few ms)
     torch.cuda.synchronize()
 
-    halo_pushed = [False]
     host_ms = [0.0, 0.0, 0.0]
 
     def halo():
@@ -220,8 +236,7 @@ def main():
             compact_bytes[0] += sb; compact_bytes[1] += rb
         te0 = time.perf_counter()
         for t in own:
-            scope = ftk_amd.SCOPE_BOTH if (t + 1 < nt) else ftk_amd.SCOPE_ORDINAL
-            ctx.sweep_enqueue(t, scope, f[t])
+            ctx.sweep_enqueue(t, scope_of(t), f[t])
         if world > 1 and args.compact_halo:
             # step 2: cull, then the input values around the boundary step's surviving cells from the slice's owner -- or, where
             # that would be more bytes than the slice (hit-dense data on small slices), the slice itself after all

@@ -139,6 +139,16 @@ class Context:
         self._ck(self._L.ftkx_slices_prepare(self._h, tt, n, int(factor_hint), r, m))
         return {ts[i]: (r[i], m[i]) for i in range(n)}
 
+    def sweep_announce(self, ts, scopes):
+        """ftkx_sweep_announce: the sweeps that will be enqueued after the next slices_prepare, whose cull that call then queues
+        right behind the mask kernel (a hint: collect uses the survivor list only if the pending sweeps are exactly these)"""
+        n = len(ts)
+        # (contiguous int32 numpy arrays are handed over as they are: a caller that announces the same sweeps every pass builds them once)
+        if isinstance(ts, np.ndarray) and isinstance(scopes, np.ndarray) and ts.dtype == np.int32 and scopes.dtype == np.int32 and ts.flags.c_contiguous and scopes.flags.c_contiguous:
+            self._ck(self._L.ftkx_sweep_announce(self._h, ts.ctypes.data, scopes.ctypes.data, n))
+            return
+        self._ck(self._L.ftkx_sweep_announce(self._h, (C.c_int * max(1, n))(*[int(t) for t in ts]), (C.c_int * max(1, n))(*[int(v) for v in scopes]), n))
+
     # ---- compact t-slab halo (torch tensors on this context's device, or on the host) ----
     def export_masks(self, t, torch, device):
         """owner side: (U uint8 tensor, word_index int32 tensor, words int64 tensor, mask_factor, max_abs) of a prepared slice"""

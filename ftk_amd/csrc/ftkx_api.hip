@@ -7,6 +7,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -125,6 +126,20 @@ struct ftkx_ctx {
   int expl_ncomp = 0;
   size_t expl_n0 = 0, expl_n1 = 0;
   std::vector<Request> pending;
+  // Cull-ahead: the sweeps the caller announced (ftkx_sweep_announce) for the slices of the next ftkx_slices_prepare, and -- once that
+  // call has queued their cull right behind the mask kernel -- the survivor list it left on the device.  The cull needs the masks
+  // and the list of steps, not the factor: it runs while the host still waits for the reduction, forms the factors and queues the
+  // sweeps.  ftkx_sweep_collect takes the list over if the pending sweeps are exactly the announced ones and every mask serves its
+  // factor; anything else (and any call that touches slices or masks in between) drops it.
+  std::vector<std::pair<int, int>> announced;
+  struct AheadStep { int t, scope; const unsigned char *M[2], *U[2]; };
+  std::vector<AheadStep> ahead;     // non-empty: survivor list + counters on the device belong to these steps
+  void *h_ahead = nullptr, *d_ahead = nullptr;   // the cull-ahead's own descriptors: pinned staging (read by fetch_desc_kernel) + device copy
+  size_t ahead_cap = 0;
+  bool ahead_staged = false;        // a fetch out of h_ahead may still be queued (cleared by every full stream synchronise of collect)
+  u64 *h_red = nullptr;             // coherent pinned copy of the reduction slots + one flag word, written by readback_kernel
+  size_t h_red_cap = 0;             //   (slots it can hold; the flag lives behind them)
+  unsigned red_seq = 0;
   int dense_collects = 0;           // > 0: the last fast collect found most cells surviving; fast requests run MODE_TILE_CULL for a while
   // compact halo: the compacted mask words of the last ftkx_export_masks_size, the surviving cells of the last ftkx_sweep_cull
   unsigned *d_word_idx = nullptr; u64 *d_words = nullptr; size_t words_cap = 0, n_words = 0; int words_t = -1;
@@ -134,6 +149,7 @@ struct ftkx_ctx {
   // optional kernel timing (hipEvents on the context's stream)
   int profiling = 0;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> events;
+  std::vector<hipEvent_t> event_pool;
   double k_ms[K_N] = {0, 0, 0, 0};
   unsigned long long k_launches[K_N] = {0, 0, 0, 0};
   std::string err;
@@ -374,10 +390,48 @@ int ensure_mask_arrays(ftkx_ctx *c, Slice &s, bool two_level)
   return FTKX_OK;
 }
 
-__global__ void init_red_kernel(u64 *red, size_t nslots)
+__global__ void init_red_kernel(u64 *red, size_t nslots, u64 *counters = nullptr)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nslots) { red[2 * i] = 0x7fefffffffffffffull; red[2 * i + 1] = 0ull; }   // {min = DBL_MAX, max = 0} as bit patterns
+  if (counters && i < (size_t)ftkx::CNT_N) counters[i] = 0ull;                       // (cull-ahead: the sweep's counters, zeroed here)
+}
+
+// The reduction, folded per slice (64 {min, max} slots -> one pair; bit patterns of non-negative doubles order like the values) and
+// written into coherent pinned host memory by the GPU itself, with a sequence number stored behind it with system scope.  The host
+// spins on that word (ftkx_slices_prepare with a cull queued behind it: a stream or event wait would, in practice, also wait for
+// work queued AFTER this point).  ONE workgroup, a wavefront per slice and eight slices in flight per wavefront: a system-scope
+// release writes the L2 back, so the fewer wavefronts execute one the better (a wavefront per slice in its own workgroup cost
+// ~0.4 us per slice).
+__global__ __launch_bounds__(256) void readback_kernel(const u64 *__restrict__ red, u64 *dst, unsigned k, unsigned *flag, unsigned seq)
+{
+  const unsigned wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (unsigned base = wv * 8; base < k; base += 32) {
+    u64 mn[8], mx[8];
+#pragma unroll
+    for (int j = 0; j < 8; j ++) {
+      const unsigned i = base + j < k ? base + j : k - 1;
+      mn[j] = red[(size_t)i * 128 + 2 * lane]; mx[j] = red[(size_t)i * 128 + 2 * lane + 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j ++) {
+      for (int o = 32; o > 0; o >>= 1) {
+        const u64 a = __shfl_down(mn[j], o), b = __shfl_down(mx[j], o);
+        mn[j] = a < mn[j] ? a : mn[j]; mx[j] = b > mx[j] ? b : mx[j];
+      }
+      if (lane == 0 && base + j < k) { dst[2 * (base + j)] = mn[j]; dst[2 * (base + j) + 1] = mx[j]; }
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// descriptors from pinned host memory into device memory, by a kernel: a launch never holds the host, whereas a copy or fill queued
+// behind a running kernel was seen to (cull-ahead: everything queued behind the mask kernel is a kernel)
+__global__ __launch_bounds__(256) void fetch_desc_kernel(const u64 *__restrict__ src, u64 *__restrict__ dst, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 __global__ void sort_keys_kernel(const ftkx_cp_t *__restrict__ hits, size_t n, u64 *__restrict__ keys, unsigned *__restrict__ idx)
@@ -422,11 +476,19 @@ int sort_hits_on_device(ftkx_ctx *c, size_t n, int key_bits)
   return FTKX_OK;
 }
 
+// (events are recycled: creating and destroying a pair per kernel cost a hit-dense 2D pass several per cent)
+hipEvent_t ev_take(ftkx_ctx *c)
+{
+  if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
+void ev_give(ftkx_ctx *c, hipEvent_t e) { if (e) c->event_pool.push_back(e); }
 void ev_begin(ftkx_ctx *c, int kind)
 {
   if (!c->profiling) return;
-  hipEvent_t a, b;
-  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  hipEvent_t a = ev_take(c), b = ev_take(c);
+  if (!a || !b) { ev_give(c, a); ev_give(c, b); return; }
   (void)hipEventRecord(a, c->stream);
   c->events.push_back({kind, {a, b}});
 }
@@ -435,21 +497,23 @@ void ev_end(ftkx_ctx *c)
   if (!c->profiling || c->events.empty()) return;
   (void)hipEventRecord(c->events.back().second.second, c->stream);
 }
-void ev_harvest(ftkx_ctx *c)   // after a stream synchronise
+void ev_harvest(ftkx_ctx *c, bool all = true)   // all: after a stream synchronise; otherwise only the pairs that have completed
 {
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> later;
   for (auto &e : c->events) {
+    if (!all && hipEventQuery(e.second.second) != hipSuccess) { later.push_back(e); continue; }
     float ms = 0;
     if (hipEventElapsedTime(&ms, e.second.first, e.second.second) == hipSuccess) { c->k_ms[e.first] += ms; c->k_launches[e.first] ++; }
-    (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second);
+    ev_give(c, e.second.first); ev_give(c, e.second.second);
   }
-  c->events.clear();
+  c->events.swap(later);
 }
 
 // launches everything the pending requests need; counters must have been zeroed.
 // Fast-path requests are grouped into sub-batches (one mask / cull / exact launch each); a new sub-batch starts whenever a
 // slice's masks would be needed under a second quantisation factor (the factor is a running minimum, so it changes a few
 // times at the start of a series and then stays put).
-int run_batch(ftkx_ctx *c, const double *sparse_field = nullptr)
+int run_batch(ftkx_ctx *c, const double *sparse_field = nullptr, bool cull_done = false)
 {
   const bool cull_only = sparse_field != nullptr;   // ftkx_sweep_cull: stop after the cull and list the survivors that read `sparse_field`
   Mesh m;
@@ -535,10 +599,14 @@ int run_batch(ftkx_ctx *c, const double *sparse_field = nullptr)
       HIP_TRY(c, hipMemsetAsync(c->d_counters + ftkx::CNT_SURVIVOR_LIST, 0, sizeof(u64), c->stream));
       HIP_TRY(c, hipMemsetAsync(c->d_counters + ftkx::CNT_REFINE_LIST, 0, sizeof(u64), c->stream));
     }
-    ev_begin(c, K_CULL);
-    if (two_level) ftkx::launch_cull_two_level(m, d_steps, (int)sb.steps.size(), c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
-    else ftkx::launch_cull(m, d_steps, (int)sb.steps.size(), c->d_list, c->list_capacity, c->stream);
-    ev_end(c);
+    if (cull_done) {    // the survivor list of exactly these steps is on the device already (cull-ahead, see ftkx_ctx::ahead)
+      if (subs.size() != 1 || !sb.jobs.empty()) return fail(c, FTKX_E_DEVICE, "internal: cull-ahead taken over by a batch that rebuilds masks");
+    } else {
+      ev_begin(c, K_CULL);
+      if (two_level) ftkx::launch_cull_two_level(m, d_steps, (int)sb.steps.size(), c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
+      else ftkx::launch_cull(m, d_steps, (int)sb.steps.size(), c->d_list, c->list_capacity, c->stream);
+      ev_end(c);
+    }
     if (cull_only) {
       // (the exact kernel is what publishes the list peak; without it the host reads the list counter itself)
       ftkx::launch_sparse_cells(m, d_steps, c->d_list, c->list_capacity, sparse_field, c->d_cells, c->cells_cap, c->stream);
@@ -552,6 +620,62 @@ int run_batch(ftkx_ctx *c, const double *sparse_field = nullptr)
   if (nfields) { ev_begin(c, tiles.empty() ? K_EXACT : K_TILE); ftkx::launch_records(m, d_fields, c->stream); ev_end(c); }
   HIP_TRY(c, hipGetLastError());
   return FTKX_OK;
+}
+
+// ftkx_slices_prepare with announced sweeps.  Everything the host must hand over goes up BEFORE the mask kernel, with the mask jobs
+// (copies and fills queued behind a running kernel were seen to hold the host until it finished); behind the mask kernel only
+// kernels are queued.  ahead_steps: the announced sweeps' descriptors, or nothing whenever something is not as the fast path needs
+// it -- the sweep then culls at collect time as before.
+bool ahead_steps(ftkx_ctx *c, bool two_level, u64 hint, std::vector<Fields> &steps, std::vector<ftkx_ctx::AheadStep> &rec)
+{
+  steps.clear(); rec.clear();
+  if (c->announced.empty() || c->dense_collects > 0) return false;
+  for (int d = 0; d < c->nd; d ++) if (c->core_sz[d] == 0) return false;
+  for (const auto &ts : c->announced) {
+    auto a = c->slices.find(ts.first);
+    if (a == c->slices.end() || a->second.sparse || a->second.mask_factor != hint || a->second.mask_big) return false;
+    const Slice *s1 = nullptr;
+    if (ts.second & FTKX_SCOPE_INTERVAL) {
+      auto b = c->slices.find(ts.first + 1);
+      if (b == c->slices.end() || b->second.sparse || b->second.mask_factor != hint || b->second.mask_big) return false;
+      s1 = &b->second;
+    }
+    if (ts.second == FTKX_SCOPE_BOTH && c->opt.tag_mode == FTKX_TAG_WORK_INDEX) return false;
+    Fields f;
+    memset(&f, 0, sizeof(f));
+    f.t = ts.first; f.scope_mask = ts.second;
+    f.M[0] = a->second.M; f.M[1] = s1 ? s1->M : nullptr;
+    f.U[0] = two_level ? a->second.U : nullptr; f.U[1] = (two_level && s1) ? s1->U : nullptr;
+    steps.push_back(f);
+    rec.push_back({ts.first, ts.second, {f.M[0], f.M[1]}, {f.U[0], f.U[1]}});
+  }
+  return !steps.empty();
+}
+
+void ahead_launch(ftkx_ctx *c, const Mesh &m, bool two_level, const Fields *d_steps, int nsteps)
+{
+  ev_begin(c, K_CULL);
+  if (two_level) ftkx::launch_cull_two_level(m, d_steps, nsteps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
+  else ftkx::launch_cull(m, d_steps, nsteps, c->d_list, c->list_capacity, c->stream);
+  ev_end(c);
+}
+
+// may ftkx_sweep_collect take the cull-ahead's survivor list over?
+bool ahead_serves_pending(const ftkx_ctx *c, const Mesh &m, bool two_level)
+{
+  if (c->ahead.empty() || c->ahead.size() != c->pending.size()) return false;
+  for (size_t i = 0; i < c->pending.size(); i ++) {
+    const Request &r = c->pending[i];
+    const ftkx_ctx::AheadStep &a = c->ahead[i];
+    if (r.t != a.t || r.scope != a.scope || r.mode != MODE_FAST) return false;
+    auto s0 = c->slices.find(r.t);
+    if (s0 == c->slices.end() || s0->second.M != a.M[0] || (two_level ? s0->second.U : nullptr) != a.U[0] || !masks_valid(c, s0->second, r.factor, two_level, m.u_rows)) return false;
+    if (r.scope & FTKX_SCOPE_INTERVAL) {
+      auto s1 = c->slices.find(r.t + 1);
+      if (s1 == c->slices.end() || s1->second.M != a.M[1] || (two_level ? s1->second.U : nullptr) != a.U[1] || !masks_valid(c, s1->second, r.factor, two_level, m.u_rows)) return false;
+    }
+  }
+  return true;
 }
 
 }  // namespace
@@ -630,6 +754,11 @@ void ftkx_destroy(ftkx_ctx *c)
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto &kv : c->slices) free_slice(kv.second);
   release_pools(c);
+  for (auto &e : c->events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+  if (c->h_red) (void)hipHostFree(c->h_red);
+  if (c->h_ahead) (void)hipHostFree(c->h_ahead);
+  if (c->d_ahead) (void)hipFree(c->d_ahead);
   if (c->d_red) (void)hipFree(c->d_red);
   if (c->d_hits) (void)hipFree(c->d_hits);
   if (c->d_pass) (void)hipFree(c->d_pass);
@@ -653,6 +782,7 @@ void ftkx_destroy(ftkx_ctx *c)
 
 int ftkx_set_stream(ftkx_ctx *c, void *s)
 {
+  if (c) c->ahead.clear();
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_set_stream: sweeps pending, collect first");
   c->stream = s ? (hipStream_t)s : c->own_stream;
@@ -661,6 +791,7 @@ int ftkx_set_stream(ftkx_ctx *c, void *s)
 
 int ftkx_set_options(ftkx_ctx *c, const ftkx_options *o)
 {
+  if (c) c->ahead.clear();
   if (!c || !o) return fail(c, FTKX_E_INVALID, "null argument");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_set_options: sweeps pending, collect first");
   if (o->tag_mode < FTKX_TAG_WORK_INDEX || o->tag_mode > FTKX_TAG_EXACT64) return fail(c, FTKX_E_INVALID, "bad tag_mode %d", o->tag_mode);
@@ -707,6 +838,7 @@ int ftkx_set_coords_explicit(ftkx_ctx *c, const double *coords, int ncomp, size_
 int ftkx_set_mesh(ftkx_ctx *c, const long long dst[3], const long long dsz[3], const long long cst[3], const long long csz[3],
                   const long long est[3], const long long esz[3])
 {
+  if (c) c->ahead.clear();
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   if (!c->slices.empty()) return fail(c, FTKX_E_INVALID, "ftkx_set_mesh: drop all slices first");
   (void)hipSetDevice(c->device);
@@ -729,6 +861,7 @@ int ftkx_set_mesh(ftkx_ctx *c, const long long dst[3], const long long dsz[3], c
 
 static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, const double *S, int on_device, bool scalar_only)
 {
+  if (c) c->ahead.clear();
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "push: call ftkx_set_mesh first");
   if (t < 0) return fail(c, FTKX_E_INVALID, "push: negative timestep");
@@ -778,6 +911,7 @@ int ftkx_push_scalar_slice(ftkx_ctx *c, int t, const double *S, int on_device)
 
 int ftkx_drop_slice(ftkx_ctx *c, int t)
 {
+  if (c) c->ahead.clear();
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   auto it = c->slices.find(t);
   if (it == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "ftkx_drop_slice: timestep %d not resident", t);
@@ -869,6 +1003,7 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_slices_prepare: sweeps pending, collect first");
   const u64 hint = factor_hint ? factor_hint : 256;          // the smallest factor there is (minbits = 8)
   if (!pow2_factor(hint)) return fail(c, FTKX_E_INVALID, "ftkx_slices_prepare: factor_hint must be a power of two");
+  c->ahead.clear();
   HIP_TRY(c, hipSetDevice(c->device));
   const double cap = 1.0 / (double)hint;
   std::vector<Slice *> all, todo;
@@ -898,23 +1033,89 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
       HIP_TRY(c, hipMalloc((void **)&c->d_red, k * 128 * sizeof(u64)));
       c->red_cap = k;
     }
-    if ((rc = ensure_desc(c, std::max(k * sizeof(MaskJob), k * 128 * sizeof(u64))))) return rc;
     for (Slice *s : todo) if ((rc = ensure_mask_arrays(c, *s, two_level))) return rc;
-    hipLaunchKernelGGL(init_red_kernel, dim3((unsigned)((k * 64 + 255) / 256)), dim3(256), 0, c->stream, c->d_red, k * 64);
+    // cull-ahead: the masks are about to be built under the hint -- mark them so (the validation further down may take that back).
+    // Everything that could synchronise the device happens before the mask launch; the announced sweeps' descriptors are put
+    // together AFTER it, while the mask kernel runs (per-step host work in front of the launch would delay the kernel by as much)
+    bool ahead_ok = !c->announced.empty() && c->dense_collects == 0;
+    if (ahead_ok) {
+      for (Slice *s : todo) { s->mask_factor = hint; s->mask_big = false; s->u_rows = m.u_rows; }
+      const size_t bytes = c->announced.size() * sizeof(Fields);
+      rc = FTKX_OK;
+      if (c->ahead_staged) { HIP_TRY(c, hipStreamSynchronize(c->stream)); c->ahead_staged = false; }   // (prepare after prepare, no collect in between)
+      if (c->ahead_cap < bytes) {
+        if (c->h_ahead) { HIP_TRY(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_ahead); c->h_ahead = nullptr; }
+        if (c->d_ahead) { (void)hipFree(c->d_ahead); c->d_ahead = nullptr; }
+        c->ahead_cap = 0;
+        const size_t capb = (bytes * 2 + 4095) / 4096 * 4096;
+        HIP_TRY(c, hipHostMalloc(&c->h_ahead, capb, hipHostMallocCoherent));
+        HIP_TRY(c, hipMalloc(&c->d_ahead, capb));
+        c->ahead_cap = capb;
+      }
+      if (c->h_red_cap < k * 2) {
+        if (c->h_red) { HIP_TRY(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_red); c->h_red = nullptr; c->h_red_cap = 0; }
+        const size_t slots = (k + k / 4 + 8) * 2;
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_red, (slots + 8) * sizeof(u64), hipHostMallocCoherent));
+        c->h_red_cap = slots;
+        *reinterpret_cast<volatile unsigned *>(c->h_red + slots) = 0u;
+        c->red_seq = 0;
+      }
+      if ((rc = ensure_list(c, std::max<u64>(c->list_capacity, 1u << 20))) || (rc = ensure_refine(c, std::max<u64>(c->refine_capacity, 1u << 20)))) {
+        for (Slice *s : todo) s->mask_factor = 0;
+        return rc;
+      }
+    }
+    if ((rc = ensure_desc(c, std::max(k * sizeof(MaskJob), k * 128 * sizeof(u64))))) return rc;
+    hipLaunchKernelGGL(init_red_kernel, dim3((unsigned)((k * 64 + 255) / 256)), dim3(256), 0, c->stream, c->d_red, k * 64, ahead_ok ? c->d_counters : nullptr);
     MaskJob *jobs = (MaskJob *)c->h_desc;
     for (size_t i = 0; i < k; i ++)
       jobs[i] = MaskJob{todo[i]->S, todo[i]->V, todo[i]->M, two_level ? todo[i]->U : nullptr, c->d_red + i * 128, cap, HUGE_VAL};   // rule off: validated below
     HIP_TRY(c, hipMemcpyAsync(c->d_desc, c->h_desc, k * sizeof(MaskJob), hipMemcpyHostToDevice, c->stream));
     ev_begin(c, K_MASK); ftkx::launch_masks(m, (const MaskJob *)c->d_desc, (int)k, c->stream); ev_end(c);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_desc, c->d_red, k * 128 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    ev_harvest(c);
     const u64 *host = (const u64 *)c->h_desc;
+    std::vector<Fields> a_steps;
+    std::vector<ftkx_ctx::AheadStep> a_rec;
+    if (ahead_ok) ahead_ok = ahead_steps(c, two_level, hint, a_steps, a_rec);
+    if (ahead_ok) {
+      // behind the mask kernel, kernels only: the reduction folded and written to pinned memory with a flag behind it, the
+      // descriptors fetched from pinned memory, the cull.  The host waits for the flag ONLY; the cull runs while it forms the factors
+      unsigned *flag = reinterpret_cast<unsigned *>(c->h_red + c->h_red_cap);
+      const unsigned seq = ++ c->red_seq;
+      hipLaunchKernelGGL(readback_kernel, dim3(1), dim3(256), 0, c->stream, (const u64 *)c->d_red, c->h_red, (unsigned)k, flag, seq);
+      const size_t bytes = a_steps.size() * sizeof(Fields);
+      static_assert(sizeof(Fields) % 8 == 0, "descriptors are fetched as 8-byte words");
+      memcpy(c->h_ahead, a_steps.data(), bytes);
+      c->ahead_staged = true;
+      hipLaunchKernelGGL(fetch_desc_kernel, dim3(4), dim3(256), 0, c->stream, (const u64 *)c->h_ahead, (u64 *)c->d_ahead, bytes / 8);
+      ahead_launch(c, m, two_level, (const Fields *)c->d_ahead, (int)a_steps.size());
+      HIP_TRY(c, hipGetLastError());
+      c->ahead = a_rec;
+      // spin on the flag; a device error would leave it unset: look at the stream now and then, give up after a generous while
+      const auto t_start = std::chrono::steady_clock::now();
+      unsigned long long spins = 0;
+      while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+        if ((++ spins & 0xfffffull) == 0) {
+          const hipError_t q = hipStreamQuery(c->stream);
+          if (q != hipSuccess && q != hipErrorNotReady) return fail(c, FTKX_E_DEVICE, "ftkx_slices_prepare: %s", hipGetErrorString(q));
+          if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(c, FTKX_E_DEVICE, "ftkx_slices_prepare: the stream drained without the reduction arriving");
+          if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(120)) return fail(c, FTKX_E_DEVICE, "ftkx_slices_prepare: timed out waiting for the reduction");
+        }
+      }
+      ev_harvest(c, false);
+    } else {
+      HIP_TRY(c, hipMemcpyAsync(c->h_desc, c->d_red, k * 128 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      ev_harvest(c);
+    }
     std::vector<Slice *> with_inf;
     for (size_t i = 0; i < k; i ++) {
-      u64 mn = host[i * 128], mx = host[i * 128 + 1];
-      for (int q = 1; q < 64; q ++) { mn = std::min(mn, host[i * 128 + 2 * q]); mx = std::max(mx, host[i * 128 + 2 * q + 1]); }
+      u64 mn, mx;
+      if (ahead_ok) { mn = c->h_red[2 * i]; mx = c->h_red[2 * i + 1]; }     // folded on the device
+      else {
+        mn = host[i * 128]; mx = host[i * 128 + 1];
+        for (int q = 1; q < 64; q ++) { mn = std::min(mn, host[i * 128 + 2 * q]); mx = std::max(mx, host[i * 128 + 2 * q + 1]); }
+      }
       Slice &s = *todo[i];
       memcpy(&s.res_below, &mn, 8);
       double mxd; memcpy(&mxd, &mx, 8);
@@ -927,10 +1128,25 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
     // (then under no smaller factor either); otherwise the sweep rebuilds them, rule on, under its factor (masks_valid).
     for (Slice *s : todo) if (!overflow_free(c->nd, s->maxabs, hint)) s->mask_factor = 0;
   }
+  c->announced.clear();                                       // (an announcement holds for one prepare)
   for (int i = 0; i < n; i ++) {
     const Slice &s = *all[i];
     if (res_below) res_below[i] = s.have_res ? (s.res < cap ? s.res : DBL_MAX) : s.res_below;
     if (max_abs) max_abs[i] = s.maxabs;
+  }
+  return FTKX_OK;
+}
+
+// The sweeps that will follow the next ftkx_slices_prepare, in the order they will be enqueued: that call then queues their cull
+// right behind the mask kernel (it needs the masks, not the factor), so that it runs while the host still waits for the reduction
+// and forms the factors.  A hint, never an obligation: ftkx_sweep_collect uses the list only if the pending sweeps are exactly these.
+int ftkx_sweep_announce(ftkx_ctx *c, const int *ts, const int *scopes, int n)
+{
+  if (!c || (n > 0 && (!ts || !scopes))) return fail(c, FTKX_E_INVALID, "null argument");
+  c->announced.clear();
+  for (int i = 0; i < n; i ++) {
+    if (scopes[i] < FTKX_SCOPE_ORDINAL || scopes[i] > FTKX_SCOPE_BOTH) { c->announced.clear(); return fail(c, FTKX_E_INVALID, "ftkx_sweep_announce: bad scope %d", scopes[i]); }
+    c->announced.push_back({ts[i], scopes[i]});
   }
   return FTKX_OK;
 }
@@ -945,6 +1161,7 @@ static int copy_out(ftkx_ctx *c, void *dst, const void *src, size_t bytes, int d
 
 int ftkx_export_masks_size(ftkx_ctx *c, int t, size_t *u_bytes_out, size_t *n_words, unsigned long long *mask_factor, double *max_abs)
 {
+  if (c) c->ahead.clear();
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   auto it = c->slices.find(t);
   if (it == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "ftkx_export_masks_size: timestep %d not resident", t);
@@ -995,6 +1212,7 @@ int ftkx_export_masks(ftkx_ctx *c, int t, void *U_dst, unsigned *word_index_dst,
 int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, const unsigned *word_index, const unsigned long long *words, size_t n_words,
                            unsigned long long mask_factor, double max_abs, int on_device)
 {
+  if (c) c->ahead.clear();
   if (!c || !U) return fail(c, FTKX_E_INVALID, "null argument");
   if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "push: call ftkx_set_mesh first");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "push: sweeps pending, collect first");
@@ -1052,6 +1270,7 @@ int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, 
 
 int ftkx_sweep_cull(ftkx_ctx *c, int t_sparse, size_t *n_cells)
 {
+  if (c) c->ahead.clear();
   if (!c || !n_cells) return fail(c, FTKX_E_INVALID, "null argument");
   *n_cells = 0;
   auto it = c->slices.find(t_sparse);
@@ -1074,7 +1293,7 @@ int ftkx_sweep_cull(ftkx_ctx *c, int t_sparse, size_t *n_cells)
     if ((rc = run_batch(c, field))) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, ftkx::CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (auto &e : c->events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    for (auto &e : c->events) { ev_give(c, e.second.first); ev_give(c, e.second.second); }
     c->events.clear();
     const u64 listed = c->h_counters[ftkx::CNT_SURVIVOR_LIST], refined = std::max(c->h_counters[ftkx::CNT_REFINE_LIST], c->h_counters[ftkx::CNT_REFINE_PEAK]);
     if (listed <= c->list_capacity && refined <= c->refine_capacity) { c->n_cells = (size_t)c->h_counters[ftkx::CNT_SPARSE]; *n_cells = c->n_cells; return FTKX_OK; }
@@ -1234,17 +1453,26 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
     while (b < 64 && ldexpl(1.0L, b) <= bound) b ++;
     key_bits = b;
   }
+  bool use_ahead = false;
+  if (!c->ahead.empty()) {
+    Mesh m; fill_mesh(c, m);
+    use_ahead = ahead_serves_pending(c, m, ftkx::masks_have_summary(m));
+    c->ahead.clear();                                        // one use; and a replay below culls afresh
+  }
   for (int attempt = 0; ; attempt ++) {
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, ftkx::CNT_N * sizeof(u64), c->stream));
-    if ((rc = run_batch(c))) { c->pending.clear(); return rc; }
+    // (cull-ahead: the counters were zeroed before that cull and hold its list counts)
+    if (!use_ahead) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, ftkx::CNT_N * sizeof(u64), c->stream));
+    if ((rc = run_batch(c, nullptr, use_ahead))) { c->pending.clear(); return rc; }
+    use_ahead = false;
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, ftkx::CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->ahead_staged = false;
     // (records <= simplices that passed: the 2D type filter may drop some; the pass list shares the hit buffer's capacity)
     const u64 hits = std::max(c->h_counters[ftkx::CNT_HITS], c->h_counters[ftkx::CNT_PASS]);
     const u64 listed = c->h_counters[ftkx::CNT_LIST_PEAK], refined = c->h_counters[ftkx::CNT_REFINE_PEAK];
     if (hits <= c->capacity && listed <= c->list_capacity && refined <= c->refine_capacity) { ev_harvest(c); break; }
     // a buffer was too small (records / survivors beyond capacity were only counted): grow to what this batch needs, replay it
-    for (auto &e : c->events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    for (auto &e : c->events) { ev_give(c, e.second.first); ev_give(c, e.second.second); }
     c->events.clear();
     if (attempt == 4) { c->pending.clear(); return fail(c, FTKX_E_DEVICE, "buffer overflow persisted after regrowing four times"); }
     // Most cells survive the cull (data whose quantised magnitudes can overflow the determinants almost everywhere):
@@ -1325,6 +1553,7 @@ int ftkx_invalidate_masks(ftkx_ctx *c)
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_invalidate_masks: sweeps pending, collect first");
   for (auto &kv : c->slices) { kv.second.mask_factor = 0; kv.second.have_fused = false; }
+  c->ahead.clear();
   c->dense_collects = 0;
   return FTKX_OK;
 }

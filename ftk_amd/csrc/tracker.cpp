@@ -373,6 +373,9 @@ void critical_point_tracker_regular::update_timestep()
   if (field_data_snapshots.empty()) return;
   const int scope = field_data_snapshots.size() >= 2 ? FTKX_SCOPE_BOTH : FTKX_SCOPE_ORDINAL;
   if (!multi) {
+    // (the step that follows is known before its factor is: announced, its cull is queued right behind the mask kernel of the
+    // newly arrived snapshot and runs while the host waits for the reduction)
+    check(ftkx_sweep_announce(ctx, &current_timestep, &scope, 1));
     update_vector_field_scaling_factor();
     const ftkx_cp_t *recs = nullptr;
     size_t n = 0;
@@ -397,6 +400,7 @@ void critical_point_tracker_regular::update_timestep()
     const int minbits = 8, maxbits = 21;
     auto factor_of = [&](double res) { int nb = (int)std::ceil(std::log2(1.0 / res)); nb = std::max(minbits, std::min(nb, maxbits)); return 1ull << nb; };
     std::vector<double> below(ts.size());
+    ck(ftkx_sweep_announce(c, &t, &scope, 1));
     ck(ftkx_slices_prepare(c, ts.data(), (int)ts.size(), factor_of(e->known_before(t)), below.data(), nullptr));
     e->publish(ts, below);
     const double res = e->wait_running_min(ts.back());

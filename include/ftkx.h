@@ -130,6 +130,12 @@ int ftkx_set_slice_resolution(ftkx_ctx *ctx, int t, double resolution, double ma
  *                  as the running minimum of ndarray::resolution() (a value >= 1 / factor_hint cannot raise nbits past log2 hint).
  *   max_abs[i]   = max finite |v| (both nullable). */
 int ftkx_slices_prepare(ftkx_ctx *ctx, const int *timesteps, int n, unsigned long long factor_hint, double *res_below, double *max_abs);
+/* Cull-ahead (optional): the sweeps that will be enqueued after the NEXT ftkx_slices_prepare, in that order.  That call then queues
+ * their cull right behind the mask kernel -- the cull needs the masks and the list of steps, not the factor -- so it runs while the
+ * host still waits for the reduction and forms the factors (update_vector_field_scaling_factor, critical_point_tracker.hh:850-864).
+ * A hint, never an obligation: ftkx_sweep_collect takes the survivor list over only if the pending sweeps are exactly the announced
+ * ones and every mask serves its sweep's factor; otherwise, and after any call that touches slices or masks, it culls as usual. */
+int ftkx_sweep_announce(ftkx_ctx *ctx, const int *timesteps, const int *scopes, int n);
 /* update_vector_field_scaling_factor (critical_point_tracker.hh:850-864): nbits = clamp(ceil(log2(1/res)), 8, 21) */
 unsigned long long ftkx_scaling_factor(double resolution, int *nbits);
 

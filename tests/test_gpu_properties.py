@@ -16,7 +16,7 @@ def gpu():
     return ftk_amd
 
 
-def _run(gpu, case, dims, nt, *, exact_only=False, core=None, steps=None, nv=1, tag_mode=None, prepass="fused", hint=0):
+def _run(gpu, case, dims, nt, *, exact_only=False, core=None, steps=None, nv=1, tag_mode=None, prepass="fused", hint=0, announce=None):
     import torch
     from ftk_amd import synthetic, tslab
     nd = len(dims)
@@ -36,6 +36,9 @@ def _run(gpu, case, dims, nt, *, exact_only=False, core=None, steps=None, nv=1, 
         if prepass == "exact":      # the separate pre-pass: ndarray::resolution() of every slice, masks built later under the true factor
             res.append(ctx.slice_resolution(t)[0])
     if prepass == "fused":          # the product's one-pass form: masks (under `hint`) and the capped reduction from one kernel
+        if announce is not None:    # cull-ahead: [(t, scope)] the caller says it will sweep ("all" = what is enqueued below)
+            ann = [(t, gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL) for t in range(nt)] if announce == "all" else announce
+            ctx.sweep_announce([a[0] for a in ann], [a[1] for a in ann])
         rm = ctx.slices_prepare(range(nt), hint)
         res = [rm[t][0] for t in range(nt)]
     factors = tslab.factors_from_resolutions(res)
@@ -343,3 +346,69 @@ def test_dense_survivors_fall_back_to_the_tile_kernel(gpu):
     assert sa["cull_enabled"] == 1 and sa["simplices_tested"] > 0.5 * sa["work_items"]
     _same(a, b)
     assert len(a) > 10000       # mostly bogus records of wrapped determinants, like the reference's
+
+
+def test_cull_ahead_changes_nothing_but_the_schedule(gpu):
+    """ftkx_sweep_announce: the cull queued behind the mask kernel, before the factors exist.  Same records and statistics as the
+    plain order -- when the announcement is what gets swept, when it is not (other scopes, other steps, a subset: the list is
+    dropped), when the masks cannot serve the factor after all (vertices that can overflow a determinant), on 2D, 3D and vector
+    input, and over repeated passes on one context."""
+    import torch
+    from ftk_amd import synthetic, tslab
+    cases = [("moving_extremum_3d", (96, 80, 64), 5, 1), ("woven", (512, 256), 6, 1), ("double_gyre", (256, 128), 5, 2), ("moving_extremum_3d", (31, 17, 9), 3, 1)]
+    for case, dims, nt, nv in cases:
+        a, sa, fa = _run(gpu, case, dims, nt, nv=nv)
+        b, sb, fb = _run(gpu, case, dims, nt, nv=nv, announce="all")
+        assert fa == fb and sa == sb, (case, sa, sb)
+        _same(a, b)
+        wrong = [[(t, gpu.SCOPE_ORDINAL) for t in range(nt)],                       # other scopes
+                 [(t, gpu.SCOPE_BOTH) for t in range(nt - 1)],                      # one step short
+                 [(t, gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL) for t in reversed(range(nt))],   # another order
+                 [(nt + 5, gpu.SCOPE_ORDINAL)]]                                    # a slice that is not resident
+        for ann in wrong:
+            c, sc, fc = _run(gpu, case, dims, nt, nv=nv, announce=ann)
+            assert fc == fa and sc == sa
+            _same(a, c)
+    # masks built under the hint turn out unusable (big vertices): the cull-ahead is dropped, the sweep rebuilds them with the rule on
+    dims, nt = (96, 80, 64), 4
+    steps = [synthetic.generate("moving_extremum_3d", dims, t, nt, torch, torch.device("cuda", 0)).cpu().numpy() for t in range(nt)]
+    rng = np.random.default_rng(5)
+    for t in range(nt):
+        for _ in range(4):
+            k, j, i = (int(rng.integers(4, d - 4)) for d in reversed(dims))
+            steps[t][k, j, i] += 3e6 * (1 + rng.random())
+    a, sa, fa = _run(gpu, None, dims, nt, steps=steps)
+    b, sb, fb = _run(gpu, None, dims, nt, steps=steps, announce="all")
+    assert fa == fb and sa == sb
+    _same(a, b)
+    # repeated passes on one context, announced and not, with a slice replaced in between
+    dims, nt = (128, 64, 48), 4
+    dev = torch.device("cuda", 0)
+    dom = ([2] * 3, [d - 3 for d in dims])
+    ctx = gpu.Context(3)
+    ctx.set_mesh(dom, dom, ([0] * 3, list(dims)))
+    ctx.set_options(jacobian_symmetric=1, derive_jacobian=1, tag_mode=gpu.TAG_EXACT64)
+    keep = [synthetic.generate("moving_extremum_3d", dims, t, nt, torch, dev) for t in range(nt)]
+    torch.cuda.synchronize()
+    for t in range(nt):
+        ctx.push_scalar_slice(t, keep[t])
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+
+    def one(announce, touch=False):
+        ctx.invalidate_masks()
+        if announce:
+            ctx.sweep_announce(range(nt), scopes)
+        rm = ctx.slices_prepare(range(nt), 0)
+        if touch:                   # a call that touches a slice between prepare and collect: the list must not be used
+            ctx.push_scalar_slice(1, keep[1])
+            rm.update(ctx.slices_prepare([1], 0))
+        f = tslab.factors_from_resolutions([rm[t][0] for t in range(nt)])
+        ctx.sweep_enqueue_many(range(nt), scopes, f)
+        return ctx.sweep_collect(), ctx.stats()
+    ref, sref = one(False)
+    assert len(ref) > 0
+    for announce, touch in ((True, False), (True, False), (False, False), (True, True), (True, False)):
+        got, sg = one(announce, touch)
+        assert sg == sref
+        _same(ref, got)
+    ctx.close()
