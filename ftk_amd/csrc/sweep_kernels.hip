@@ -2369,8 +2369,11 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
         if (const char *e = getenv("FTKX_MASK_PD")) pd5 = atoi(e);
         if (const char *e = getenv("FTKX_MASK_TILE")) shape = atoi(e);
         if (gen == 6) {
-          if (!zforced) {   // longer chunks (start-up planes and z halo amortised) as long as the launch still fills the device several times
-            zchunk = 64;
+          // grouped placement: 16 row groups (all of a 256^2 plane's, half of a 512^2 plane's tiles) share an XCD's L2 -- with three
+          // workgroups per CU 4 x 16 tiles are resident per XCD at a time (4: -3.5 %, 8: -0.5 %)
+          if (!getenv("FTKX_MASK_YG")) yg_want = 16;
+          if (!zforced) {   // chunks of 32 planes (64: +0.5..1 % with 16-row groups; 16: +3 %) as long as the launch still fills the device several times
+            zchunk = 32;
             while (zchunk > 8 && (size_t)((DW + 127) / 128) * ((m.ext_sz[1] + 15) / 16) * ((DD + zchunk - 1) / zchunk) * njobs < 4096) zchunk /= 2;   // (three workgroups per CU: 768 at a time)
           }
           const unsigned gz = (unsigned)(((DD + zchunk - 1) / zchunk) * njobs);
