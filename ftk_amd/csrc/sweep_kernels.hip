@@ -648,14 +648,38 @@ __global__ __launch_bounds__(kThreads) void mask_vec_kernel(const Mesh m, const 
   const double thr = job.threshold, nthr = -job.threshold;
   const bool have_u = job.U != nullptr;
   double red_mn = DBL_MAX, red_mx = 0.0;
-  for (size_t gi = (size_t)blockIdx.x * kThreads + threadIdx.x; gi < padded; gi += (size_t)gridDim.x * kThreads) {
+  // a lane's group of 4 vertices -> (row, group in the row): 32-bit arithmetic where the slice allows it (a 64-bit division by a
+  // run-time value is ~100 instructions, per 64 bytes of input)
+  const bool small = total < (1ull << 32);                     // (wave-uniform)
+  auto locate = [&](size_t gc, size_t &row, int &g) {
+    if (small) { const unsigned r = (unsigned)gc / (unsigned)ngroups; row = r; g = (int)((unsigned)gc - r * (unsigned)ngroups); }
+    else { row = gc / ngroups; g = (int)(gc - row * ngroups); }
+  };
+  auto fetch = [&](size_t gi, double2 (&t)[2 * ND]) {
+    const size_t gc = gi < total ? gi : total - 1;
+    size_t row; int g;
+    locate(gc, row, g);
+    const double2 *src = reinterpret_cast<const double2 *>(job.V + (row * (size_t)DW + (size_t)(4 * g)) * ND);
+#pragma unroll
+    for (int q = 0; q < 2 * ND; q ++) t[q] = src[q];
+  };
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  size_t gi = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  double2 nxt[2 * ND];
+  if (gi < padded) fetch(gi, nxt);
+  for (; gi < padded; gi += stride) {
     const bool live = gi < total;
     const size_t gc = live ? gi : total - 1;
-    const size_t row = gc / ngroups;
-    const int g = (int)(gc - row * ngroups), j = (int)(row % (size_t)DH), k = (int)(row / (size_t)DH);
-    const double2 *src = reinterpret_cast<const double2 *>(job.V + (row * (size_t)DW + (size_t)(4 * g)) * ND);
+    size_t row; int g;
+    locate(gc, row, g);
+    int j, k;
+    if (ND == 2) { j = (int)row; k = 0; }
+    else if (small) { k = (int)((unsigned)row / (unsigned)DH); j = (int)((unsigned)row - (unsigned)k * (unsigned)DH); }
+    else { j = (int)(row % (size_t)DH); k = (int)(row / (size_t)DH); }
     double v[4 * ND];
-    for (int q = 0; q < 2 * ND; q ++) { const double2 t = src[q]; v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+#pragma unroll
+    for (int q = 0; q < 2 * ND; q ++) { v[2 * q] = nxt[q].x; v[2 * q + 1] = nxt[q].y; }
+    if (gi + stride < padded) fetch(gi + stride, nxt);         // the next group's loads are on their way while this one is classified
     bool row_dom = j + m.ext_st[1] >= m.dom_lb[1] && j + m.ext_st[1] <= m.dom_ub[1];
     if (ND == 3) row_dom = row_dom && k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2];
     unsigned word = 0;
@@ -2454,6 +2478,10 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
     const size_t groups = (size_t)(m.ext_sz[0] / 4) * m.ext_sz[1] * DDv;
     size_t bx = (groups + kThreads - 1) / kThreads;
     if (bx > 2048) bx = 2048;               // grid-stride the rest: 8 workgroups per CU per job
+    // ... and at least four groups per lane where the slice has them: the per-wavefront fixed costs (index arithmetic, the two
+    // reduction atomics) are paid per 16 KB instead of per 4 KB (double_gyre 2048 x 1024 x 128: 0.795 -> 0.746 ms)
+    while (bx > 256 && bx * kThreads * 4 > groups) bx /= 2;
+    if (const char *e = getenv("FTKX_VEC_BX")) { const size_t v = (size_t)atoi(e); if (v >= 1 && v < bx) bx = v; }
     const dim3 grid((unsigned)bx, (unsigned)njobs);
     g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_vec_kernel<2>" : "ftkx::mask_vec_kernel<3>";
     if (m.nd == 2) hipLaunchKernelGGL(mask_vec_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs);

@@ -20,7 +20,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/ftkx.h"
@@ -80,6 +85,30 @@ struct Adjacency {
         side_of[ft].push_back(back);
       }
     }
+    build_candidates();
+  }
+
+  // The records that can share a cell with a face of type t, as STATIC offsets from its corner: for each of the two cells around it
+  // the cell's other faces.  All candidates share the base corner, so the element order of the reference's std::set (corner as a
+  // vector, x first, then the type) is the order of (off[0], ..., off[N-1], type) -- sorted once here instead of once per record.
+  struct Cand { int type; int off[N]; };
+  std::array<std::vector<Cand>, NF> cand;
+  void build_candidates()
+  {
+    for (int t = 0; t < NF; t ++) {
+      std::vector<Cand> v;
+      for (const auto &cell : side_of[t])
+        for (const auto &face : sides[cell.type]) {
+          Cand c; c.type = face.type;
+          bool self = face.type == t;
+          for (int a = 0; a < N; a ++) { c.off[a] = cell.off[a] + face.off[a]; self = self && c.off[a] == 0; }
+          if (!self) v.push_back(c);
+        }
+      auto less = [](const Cand &a, const Cand &b) { for (int d = 0; d < N; d ++) if (a.off[d] != b.off[d]) return a.off[d] < b.off[d]; return a.type < b.type; };
+      std::sort(v.begin(), v.end(), less);
+      v.erase(std::unique(v.begin(), v.end(), [&](const Cand &a, const Cand &b) { return !less(a, b) && !less(b, a); }), v.end());
+      cand[t] = v;
+    }
   }
 
 private:
@@ -137,28 +166,44 @@ struct Tracer {
   }
   // tag -> record: open addressing over a power-of-two table at most half full (a lookup is one or two probes; the binary search
   // over the sorted tags it replaces cost ~16 mispredicted branches per lookup, 6-8 lookups per record)
-  std::vector<u64> h_tag;
-  std::vector<int> h_rec;
+  struct Slot { u64 tag; long long rec; };       // one cache line access per probe (tag and record side by side)
+  std::vector<Slot> h_slot;
   u64 h_mask = 0;
   static u64 mix(u64 x) { x *= 0x9e3779b97f4a7c15ull; return x ^ (x >> 29); }
-  void build_hash(const ftkx_cp_t *recs, size_t n)
+  // parallel = the records are claimed slot by slot with a compare-and-swap on `rec` (tags are unique and nobody looks anything up
+  // before the table is complete, so a slot whose tag is still being written only has to read as taken)
+  void build_hash(const ftkx_cp_t *recs, size_t n, bool parallel = false);
+  int find_tag(u64 tag) const
   {
-    size_t cap = 16;
-    while (cap < 2 * n + 2) cap <<= 1;
-    h_mask = cap - 1;
-    h_tag.assign(cap, 0); h_rec.assign(cap, -1);
-    for (size_t i = 0; i < n; i ++) {
-      u64 p = mix(recs[i].tag) & h_mask;
-      while (h_rec[p] >= 0) p = (p + 1) & h_mask;
-      h_tag[p] = recs[i].tag; h_rec[p] = (int)i;
-    }
+    for (u64 p = mix(tag) & h_mask; h_slot[p].rec >= 0; p = (p + 1) & h_mask) if (h_slot[p].tag == tag) return (int)h_slot[p].rec;
+    return -1;
   }
   int find(const Elem &e) const
   {
     u64 tag;
     if (!encode(e, &tag)) return -1;
-    for (u64 p = mix(tag) & h_mask; h_rec[p] >= 0; p = (p + 1) & h_mask) if (h_tag[p] == tag) return h_rec[p];
-    return -1;
+    return find_tag(tag);
+  }
+  // the neighbours of e inside the hit set, in the reference's element order, e itself excluded: record indices into out[], count
+  // returned.  Same result as neighbours() below without building, sorting and de-duplicating a list of elements per record.
+  int neighbour_records(const Elem &e, int *out, int cap) const
+  {
+    int cnt = 0;
+    for (const auto &c : adj.cand[e.type]) {
+      u64 ci = 0;
+      bool ok = true;
+      for (int d = 0; d < ND && ok; d ++) {
+        const long long rel = (long long)e.c[d] + c.off[d] - lb[d];
+        ok = rel >= 0 && rel < sz[d];
+        ci += (u64)rel * prod[d];
+      }
+      const long long tt = (long long)e.c[ND] + c.off[ND];
+      if (!ok || tt < 0) continue;
+      ci += (u64)tt * prod[ND];
+      const int r = find_tag(ci * (u64)NTYPES + (u64)c.type);
+      if (r >= 0 && cnt < cap) out[cnt ++] = r;
+    }
+    return cnt;
   }
   // records that share a (d+1)-cell with e, in the element order of the reference's std::set, e itself excluded
   void neighbours(const Elem &e, std::vector<std::pair<Elem, int>> &out) const
@@ -191,7 +236,83 @@ struct UnionFind {
 };
 
 // runs f(begin, end) over [0, n) on up to `cap` host threads (the per-record work of pass 2 is independent: SURVEY 8 f2 -- "the
-// sorted-tag binary searches are independent per hit")
+// sorted-tag binary searches are independent per hit").  The threads are kept: spawning 16 of them per call cost as much as the
+// work they then did on a hit set of 60 000 records.  Chunks are handed out through an atomic counter; the caller works too.
+class WorkerPool {
+public:
+  static WorkerPool &get()
+  {
+    // (a forked child inherits the object but not the threads: it gets a pool of its own; the parent's is leaked there)
+    static WorkerPool *pool = nullptr;
+    static pid_t owner = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    if (!pool || owner != getpid()) { pool = new WorkerPool(); owner = getpid(); }
+    return *pool;
+  }
+  void run(size_t n, unsigned want, const std::function<void(size_t, size_t)> &f)
+  {
+    std::lock_guard<std::mutex> serial(run_mu);               // one job at a time
+    grow(want > 0 ? want - 1 : 0);
+    const size_t nchunks = std::min<size_t>((size_t)want * 4, (n + 1023) / 1024);
+    {
+      std::lock_guard<std::mutex> g(mu);
+      job = &f; job_n = n; job_chunks = nchunks; next.store(0); working = (unsigned)th.size(); gen ++;
+    }
+    cv.notify_all();
+    work();
+    std::unique_lock<std::mutex> g(mu);
+    done_cv.wait(g, [&] { return working == 0; });
+    job = nullptr;
+  }
+  ~WorkerPool()
+  {
+    { std::lock_guard<std::mutex> g(mu); stop = true; }
+    cv.notify_all();
+    for (auto &t : th) t.join();
+  }
+
+private:
+  std::vector<std::thread> th;
+  std::mutex mu, run_mu;
+  std::condition_variable cv, done_cv;
+  const std::function<void(size_t, size_t)> *job = nullptr;
+  size_t job_n = 0, job_chunks = 0;
+  std::atomic<size_t> next{0};
+  unsigned working = 0;
+  unsigned long long gen = 0;
+  bool stop = false;
+
+  void work()
+  {
+    for (;;) {
+      const size_t c = next.fetch_add(1);
+      if (c >= job_chunks) break;
+      const size_t per = (job_n + job_chunks - 1) / job_chunks, b = std::min(job_n, c * per), e = std::min(job_n, b + per);
+      if (b < e) (*job)(b, e);
+    }
+  }
+  void grow(unsigned workers)
+  {
+    while (th.size() < workers) {
+      const unsigned long long seen = gen;                     // a new worker waits for the NEXT job
+      th.emplace_back([this, seen]() mutable {
+        unsigned long long last = seen;
+        for (;;) {
+          std::unique_lock<std::mutex> g(mu);
+          cv.wait(g, [&] { return stop || gen != last; });
+          if (stop) return;
+          last = gen;
+          g.unlock();
+          work();
+          g.lock();
+          if (-- working == 0) done_cv.notify_all();
+        }
+      });
+    }
+  }
+};
+
 template <class F>
 void parallel_ranges(size_t n, F f, unsigned cap = 16)
 {
@@ -199,13 +320,29 @@ void parallel_ranges(size_t n, F f, unsigned cap = 16)
   if (const char *e = getenv("FTKX_TRACE_THREADS")) nt = (unsigned)atoi(e);
   if (nt > cap) nt = cap;
   if (nt < 2 || n < 4096) { f((size_t)0, n); return; }
-  std::vector<std::thread> th;
-  const size_t per = (n + nt - 1) / nt;
-  for (unsigned t = 0; t < nt; t ++) {
-    const size_t b = std::min(n, (size_t)t * per), e = std::min(n, b + per);
-    if (b < e) th.emplace_back([=] { f(b, e); });
-  }
-  for (auto &x : th) x.join();
+  const std::function<void(size_t, size_t)> fn = f;
+  WorkerPool::get().run(n, nt, fn);
+}
+
+template <int N>
+void Tracer<N>::build_hash(const ftkx_cp_t *recs, size_t n, bool parallel)
+{
+  size_t cap = 16;
+  while (cap < 2 * n + 2) cap <<= 1;
+  h_mask = cap - 1;
+  h_slot.assign(cap, Slot{0, -1});
+  auto insert = [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; i ++) {
+      u64 p = mix(recs[i].tag) & h_mask;
+      for (;;) {
+        long long expect = -1;
+        if (__atomic_compare_exchange_n(&h_slot[p].rec, &expect, (long long)i, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+        p = (p + 1) & h_mask;
+      }
+      h_slot[p].tag = recs[i].tag;
+    }
+  };
+  if (parallel) parallel_ranges(n, insert); else insert(0, n);
 }
 
 template <int N>
@@ -217,13 +354,18 @@ int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs
   double tp[8]; int np_ = 0; tp[np_ ++] = now();
   constexpr int MAXNB = 2 * N;                       // two cells per face, N other faces each
   Tracer<N> tr(adj, dst, dsz);
-  tr.index.resize(n);
+  // duplicate tags are refused.  The sweep hands its records over sorted by tag: adjacent records are compared in place; only an
+  // unsorted set pays for an index and a sort
   bool sorted = true;
-  for (size_t i = 0; i < n; i ++) { tr.index[i] = {recs[i].tag, (int)i}; if (i && recs[i].tag < recs[i - 1].tag) sorted = false; }
-  if (!sorted) std::sort(tr.index.begin(), tr.index.end());          // (the sweep hands its records over sorted by tag)
-  for (size_t i = 1; i < n; i ++) if (tr.index[i].first == tr.index[i - 1].first) return FTKX_E_INVALID;   // duplicate tags
-
-  tr.build_hash(recs, n);
+  for (size_t i = 1; i < n && sorted; i ++) sorted = recs[i - 1].tag <= recs[i].tag;
+  if (sorted) { for (size_t i = 1; i < n; i ++) if (recs[i].tag == recs[i - 1].tag) return FTKX_E_INVALID; }
+  else {
+    tr.index.resize(n);
+    for (size_t i = 0; i < n; i ++) tr.index[i] = {recs[i].tag, (int)i};
+    std::sort(tr.index.begin(), tr.index.end());
+    for (size_t i = 1; i < n; i ++) if (tr.index[i].first == tr.index[i - 1].first) return FTKX_E_INVALID;
+  }
+  tr.build_hash(recs, n, true);
   tp[np_ ++] = now();
   std::vector<Elem> elem(n);
   // adjacency lists inside the hit set (sorted in element order), flat: at most MAXNB neighbours per record
@@ -232,12 +374,9 @@ int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs
   // the reference's element order (corner as a vector with x FIRST, then the type) as one integer per record
   std::vector<std::pair<u64, int>> order_key(n);
   parallel_ranges(n, [&](size_t b, size_t e) {
-    std::vector<std::pair<Elem, int>> tmp;
     for (size_t i = b; i < e; i ++) {
       elem[i] = tr.decode(recs[i].tag);
-      tr.neighbours(elem[i], tmp);
-      deg[i] = (unsigned char)tmp.size();
-      for (size_t k = 0; k < tmp.size() && k < (size_t)MAXNB; k ++) nbr[i * MAXNB + k] = tmp[k].second;
+      deg[i] = (unsigned char)tr.neighbour_records(elem[i], &nbr[i * MAXNB], MAXNB);
       u64 key = 0;
       for (int d = 0; d < ND_OF(N); d ++) key = key * (u64)dsz[d] + (u64)(elem[i].c[d] - dst[d]);
       key = (key << 24) | (u64)(unsigned)elem[i].c[N - 1];           // (time: below 2^24 steps, else the comparator sort below)

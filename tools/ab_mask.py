@@ -17,18 +17,19 @@ cfg = args[0] if sep > 0 else "c4"
 rounds = int(args[1]) if sep > 1 else 6
 variants = args[sep + 1:] or ["TILE=0"]
 CONFIGS = {"c4": (3, "moving_extremum_3d", (512, 512, 512), 32), "c3": (3, "moving_extremum_3d", (256, 256, 256), 16),
-           "c2": (2, "woven", (1024, 1024), 64)}
+           "c2": (2, "woven", (1024, 1024), 64), "c5": (2, "double_gyre", (2048, 1024), 128)}
 nd, case, dims, nt = CONFIGS[cfg]
+vector = case == "double_gyre"
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream)
 ctx = ftk_amd.Context(nd); ctx.set_stream(stream.cuda_stream)
-dom = ([2] * nd, [d - 3 for d in dims])
+dom = ([1] * nd, [d - 2 for d in dims]) if vector else ([2] * nd, [d - 3 for d in dims])
 ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
-ctx.set_options(jacobian_symmetric=1, derive_jacobian=1, tag_mode=ftk_amd.TAG_EXACT64)
+ctx.set_options(jacobian_symmetric=0 if vector else 1, derive_jacobian=1, tag_mode=ftk_amd.TAG_EXACT64)
 keep = []
 for t in range(nt):
     a = synthetic.generate(case, dims, t, nt, torch, dev); torch.cuda.synchronize(); keep.append(a)
-    ctx.push_scalar_slice(t, a)
+    (ctx.push_slice if vector else ctx.push_scalar_slice)(t, a)
 ctx.set_profiling(True)
 times = {v: [] for v in variants}
 for rnd in range(rounds + 1):
@@ -36,8 +37,9 @@ for rnd in range(rounds + 1):
         old = {}
         for kv in v.split():
             k, val = kv.split("=")
-            old["FTKX_MASK_" + k] = os.environ.get("FTKX_MASK_" + k)
-            os.environ["FTKX_MASK_" + k] = val
+            k = k if k.startswith("FTKX_") else "FTKX_MASK_" + k      # (full names for knobs outside the FTKX_MASK_ family)
+            old[k] = os.environ.get(k)
+            os.environ[k] = val
         ctx.invalidate_masks()
         ctx.set_profiling(True)      # resets the accumulated kernel times
         ctx.slices_prepare(range(nt), 0)
