@@ -27,7 +27,7 @@ class Options(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("work_items", C.c_ulonglong), ("cells", C.c_ulonglong), ("cells_survived", C.c_ulonglong),
-                ("simplices_tested", C.c_ulonglong), ("hits", C.c_ulonglong), ("cull_enabled", C.c_int)]
+                ("simplices_tested", C.c_ulonglong), ("hits", C.c_ulonglong), ("cull_enabled", C.c_int), ("reclassified", C.c_ulonglong)]
 
 
 class Curves(C.Structure):

@@ -258,8 +258,14 @@ FTKX_HD inline unsigned classify2(double j00, double j01, double j10, double j11
   return 64u;
 }
 
-FTKX_HD inline unsigned classify3(const double A[3][3], bool symmetric)
+// `fragile` (optional): set when an eigenvalue is so close to zero, relative to the others, that the last bits of pow / acos / cos
+// decide the class.  Those functions are not correctly rounded, and the device library's results differ from the host libm's (the
+// one the reference runs on) in the last place now and then -- enough to turn an exactly singular Hessian (plateaus, lattice-aligned
+// data: eigenvalue 0.0 on the host, -1e-17 on the device) from "degenerate" into a maximum.  The sweep re-classifies such records on
+// the host, with the host's libm (ftkx_api.hip); everything else in the record path is +, -, *, /, sqrt and fma: identical.
+FTKX_HD inline unsigned classify3(const double A[3][3], bool symmetric, bool *fragile = nullptr)
 {
+  if (fragile) *fragile = false;
   if (!symmetric) return 0u;   // critical_point_type.hh:87-91
   const double b = -(A[0][0] + A[1][1] + A[2][2]);
   const double c = A[1][1] * A[2][2] + A[0][0] * A[2][2] + A[0][0] * A[1][1] - A[0][1] * A[1][0] - A[1][2] * A[2][1] - A[0][2] * A[2][0];
@@ -282,6 +288,13 @@ FTKX_HD inline unsigned classify3(const double A[3][3], bool symmetric)
     x0 = -term1 + r13 * cos(th / 3.0);
     x1 = -term1 + r13 * cos((th + 2.0 * M_PI) / 3.0);
     x2 = -term1 + r13 * cos((th + 4.0 * M_PI) / 3.0);
+  }
+  if (fragile) {
+    const double a0 = fabs(x0), a1 = fabs(x1), a2 = fabs(x2);
+    const double big = fmax(a0, fmax(a1, a2)), small = fmin(a0, fmin(a1, a2));
+    // (NaN compares false: a NaN anywhere is fragile too.  1e-9 is many orders of magnitude above any libm discrepancy and still
+    // as good as never true on data that is not exactly degenerate)
+    *fragile = !(small > 1e-9 * big);
   }
   if (x0 * x1 * x2 == 0.0) return 1u;
   if (x0 < 0 && x1 < 0 && x2 < 0) return 8u;

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "sweep_params.hpp"
+#include "cp_device.hpp"   // classify3 on the HOST (fragile 3D records, see there)
 #include "internal.hpp"
 
 namespace ftkx {
@@ -95,6 +96,8 @@ struct ftkx_ctx {
   std::map<int, Slice> slices;
   ftkx_cp_t *d_hits = nullptr;
   u64 *d_pass = nullptr;            // simplices that passed the integer test, awaiting the record kernel (same capacity)
+  u64 *d_fragile = nullptr;         // 3D records to be re-classified on the host (slot, J[9]): cp_device.hpp, classify3
+  u64 fragile_capacity = 0;
   u64 capacity = 0;
   u64 *d_list = nullptr;            // surviving corners of the fast path
   u64 list_capacity = 0;
@@ -231,6 +234,15 @@ int ensure_hit_buffer(ftkx_ctx *c, u64 want)
   return FTKX_OK;
 }
 
+int ensure_fragile(ftkx_ctx *c, u64 want)
+{
+  if (c->fragile_capacity >= want) return FTKX_OK;
+  if (c->d_fragile) { HIP_TRY(c, hipFree(c->d_fragile)); c->d_fragile = nullptr; c->fragile_capacity = 0; }
+  HIP_TRY(c, hipMalloc((void **)&c->d_fragile, want * 10 * sizeof(u64)));
+  c->fragile_capacity = want;
+  return FTKX_OK;
+}
+
 int ensure_list(ftkx_ctx *c, u64 want)
 {
   if (c->list_capacity >= want) return FTKX_OK;
@@ -298,11 +310,13 @@ void fill_mesh(const ftkx_ctx *c, Mesh &m)
   m.compute_degrees = c->opt.compute_degrees; m.tag_mode = c->opt.tag_mode;
   m.scalar_mode = c->scalar_mode == 1;
   m.derive_jacobian = c->opt.derive_jacobian;
+  { const char *e = getenv("FTKX_RECORD_GENERAL"); m.record_general = (e && atoi(e) != 0) ? 1 : 0; }
   m.coords_mode = c->opt.coords_mode;
   for (int i = 0; i < 6; i ++) m.coords_bounds[i] = c->opt.coords_bounds[i];
   for (int d = 0; d < 3; d ++) m.coords_rect[d] = c->d_rect[d];
   m.coords_expl = c->d_expl; m.coords_expl_ncomp = c->expl_ncomp; m.coords_expl_n0 = (int)c->expl_n0;
   m.hits = c->d_hits; m.pass = c->d_pass; m.counters = c->d_counters; m.capacity = c->capacity;
+  m.fragile = c->d_fragile; m.fragile_capacity = c->fragile_capacity;
   m.u_rows = ftkx::mask_summary_rows(m);
 }
 
@@ -432,6 +446,13 @@ __global__ __launch_bounds__(256) void readback_kernel(const u64 *__restrict__ r
 __global__ __launch_bounds__(256) void fetch_desc_kernel(const u64 *__restrict__ src, u64 *__restrict__ dst, size_t n)
 {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+// types re-computed on the host written back into the hit buffer: pairs (slot, type)
+__global__ void patch_types_kernel(ftkx_cp_t *hits, const u64 *__restrict__ pairs, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) hits[pairs[2 * i]].type = (unsigned)pairs[2 * i + 1];
 }
 
 __global__ void sort_keys_kernel(const ftkx_cp_t *__restrict__ hits, size_t n, u64 *__restrict__ keys, unsigned *__restrict__ idx)
@@ -762,6 +783,7 @@ void ftkx_destroy(ftkx_ctx *c)
   if (c->d_red) (void)hipFree(c->d_red);
   if (c->d_hits) (void)hipFree(c->d_hits);
   if (c->d_pass) (void)hipFree(c->d_pass);
+  if (c->d_fragile) (void)hipFree(c->d_fragile);
   for (void *p : {(void *)c->d_word_idx, (void *)c->d_words, (void *)c->d_cells, (void *)c->d_patch_cells, (void *)c->d_patches}) if (p) (void)hipFree(p);
   if (c->d_list) (void)hipFree(c->d_list);
   if (c->d_refine) (void)hipFree(c->d_refine);
@@ -1097,9 +1119,15 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
       while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
         if ((++ spins & 0xfffffull) == 0) {
           const hipError_t q = hipStreamQuery(c->stream);
-          if (q != hipSuccess && q != hipErrorNotReady) return fail(c, FTKX_E_DEVICE, "ftkx_slices_prepare: %s", hipGetErrorString(q));
-          if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(c, FTKX_E_DEVICE, "ftkx_slices_prepare: the stream drained without the reduction arriving");
-          if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(120)) return fail(c, FTKX_E_DEVICE, "ftkx_slices_prepare: timed out waiting for the reduction");
+          const char *why = nullptr;
+          if (q != hipSuccess && q != hipErrorNotReady) why = hipGetErrorString(q);
+          else if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) why = "the stream drained without the reduction arriving";
+          else if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(120)) why = "timed out waiting for the reduction";
+          if (why) {      // nothing of this call stands: no masks, no cull-ahead, no announcement
+            for (Slice *s : todo) { s->mask_factor = 0; s->have_fused = false; }
+            c->ahead.clear(); c->announced.clear();
+            return fail(c, FTKX_E_DEVICE, "ftkx_slices_prepare: %s", why);
+          }
         }
       }
       ev_harvest(c, false);
@@ -1430,6 +1458,7 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
   if (c->pending.empty()) return FTKX_OK;
   int rc;
   if ((rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16)))) { c->pending.clear(); return rc; }
+  if (c->nd == 3 && (rc = ensure_fragile(c, std::max<u64>(c->fragile_capacity, 1u << 12)))) { c->pending.clear(); return rc; }
   bool any_fast = false;
   u64 fast_cells = 0;
   {
@@ -1470,7 +1499,8 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
     // (records <= simplices that passed: the 2D type filter may drop some; the pass list shares the hit buffer's capacity)
     const u64 hits = std::max(c->h_counters[ftkx::CNT_HITS], c->h_counters[ftkx::CNT_PASS]);
     const u64 listed = c->h_counters[ftkx::CNT_LIST_PEAK], refined = c->h_counters[ftkx::CNT_REFINE_PEAK];
-    if (hits <= c->capacity && listed <= c->list_capacity && refined <= c->refine_capacity) { ev_harvest(c); break; }
+    const u64 fragile = c->h_counters[ftkx::CNT_FRAGILE];
+    if (hits <= c->capacity && listed <= c->list_capacity && refined <= c->refine_capacity && fragile <= c->fragile_capacity) { ev_harvest(c); break; }
     // a buffer was too small (records / survivors beyond capacity were only counted): grow to what this batch needs, replay it
     for (auto &e : c->events) { ev_give(c, e.second.first); ev_give(c, e.second.second); }
     c->events.clear();
@@ -1492,6 +1522,7 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
       if (hits > c->capacity && (rc = ensure_hit_buffer(c, 2 * hits + 1024))) { c->pending.clear(); return rc; }
       continue;
     }
+    if (fragile > c->fragile_capacity && (rc = ensure_fragile(c, fragile + fragile / 8 + 1024))) { c->pending.clear(); return rc; }
     if (refined > c->refine_capacity && (rc = ensure_refine(c, refined + refined / 8 + 1024))) { c->pending.clear(); return rc; }
     if (listed > c->list_capacity && (rc = ensure_list(c, listed + listed / 8 + 1024))) { c->pending.clear(); return rc; }
     // with a truncated survivor list the hit count is a lower bound: leave generous room
@@ -1504,6 +1535,26 @@ int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
   c->stats.cells_survived = c->h_counters[ftkx::CNT_CELLS_SURVIVED];
   c->stats.simplices_tested = c->h_counters[ftkx::CNT_SIMPLICES_TESTED];
   if ((rc = ensure_host_buffer(c, n))) return rc;
+  // 3D records whose class hangs on the last bits of pow / acos / cos (an eigenvalue of the Hessian that is zero up to rounding):
+  // classified again here, with the libm the reference itself runs on, and written back before the records are sorted.  Rare -- an
+  // exactly singular Hessian takes plateaus or lattice-aligned data -- and then one small round trip.
+  if (const u64 nf = c->h_counters[ftkx::CNT_FRAGILE]) {
+    std::vector<u64> frag((size_t)nf * 10), pairs((size_t)nf * 2);
+    HIP_TRY(c, hipMemcpyAsync(frag.data(), c->d_fragile, frag.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < (size_t)nf; i ++) {
+      double A[3][3];
+      memcpy(A, &frag[i * 10 + 1], sizeof(A));
+      pairs[2 * i] = frag[i * 10];
+      pairs[2 * i + 1] = (u64)ftkx::classify3(A, c->opt.jacobian_symmetric != 0);
+    }
+    if ((rc = ensure_desc(c, pairs.size() * sizeof(u64)))) return rc;
+    memcpy(c->h_desc, pairs.data(), pairs.size() * sizeof(u64));
+    HIP_TRY(c, hipMemcpyAsync(c->d_desc, c->h_desc, pairs.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(patch_types_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, c->stream, c->d_hits, (const u64 *)c->d_desc, (size_t)nf);
+    HIP_TRY(c, hipGetLastError());
+    c->stats.reclassified = nf;
+  }
   if (n >= 4096 && n < (1ull << 31)) {
     if ((rc = sort_hits_on_device(c, n, key_bits))) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->h_hits, c->d_sorted, n * sizeof(ftkx_cp_t), hipMemcpyDeviceToHost, c->stream));

@@ -249,7 +249,7 @@ __device__ inline void gather_fast(const Mesh &m, const double *__restrict__ S, 
 template <int ND>
 __device__ inline bool record_is_fast(const Mesh &m, const Fields &f, const int *corner)
 {
-  bool ok = m.scalar_mode && f.J[0] == nullptr && m.derive_jacobian && f.S[0] != nullptr && !(ND == 2 && m.compute_degrees);
+  bool ok = m.scalar_mode && f.J[0] == nullptr && m.derive_jacobian && f.S[0] != nullptr && !(ND == 2 && m.compute_degrees) && !m.record_general;
   // the simplex's vertices are corner + {0, 1} per axis: corner - 2 .. corner + 3 must lie inside the array
   for (int d = 0; d < ND; d ++) { const int a = corner[d] - m.ext_st[d]; ok = ok && a >= 2 && a + 3 < m.ext_sz[d]; }
   return ok;
@@ -257,7 +257,8 @@ __device__ inline bool record_is_fast(const Mesh &m, const Fields &f, const int 
 
 template <int ND, bool FAST>
 __device__ inline bool make_record_impl(const Mesh &m, const Fields &f, const int *corner, int type,
-                                         const u64 (*X)[ND], const int *ids, bool presolved, const double *mu_in, ftkx_cp_t *out)
+                                         const u64 (*X)[ND], const int *ids, bool presolved, const double *mu_in, ftkx_cp_t *out,
+                                         bool *fragile, double *Jfrag /* [9], written when *fragile */)
 {
   constexpr int N = ND + 1;
   const fan_table<N> &fan = dev_fan<ND>();
@@ -373,7 +374,15 @@ __device__ inline bool make_record_impl(const Mesh &m, const Fields &f, const in
       for (int i = 0; i < 4; i ++) acc += Js[i][j][k] * mu[i];
       J[j][k] = acc;
     }
-    r.type = classify3(J, m.jacobian_symmetric != 0);
+    bool frag = false;
+    r.type = classify3(J, m.jacobian_symmetric != 0, &frag);
+    if (frag) {
+      *fragile = true;
+#pragma unroll
+      for (int j = 0; j < 3; j ++)
+#pragma unroll
+        for (int k = 0; k < 3; k ++) Jfrag[3 * j + k] = J[j][k];
+    }
   }
   const bool ordinal = fan.ordinal[type] != 0;
   const u64 work_index = core_linear<ND>(m, corner) * (u64)(ordinal ? fan_table<N>::NORD : fan_table<N>::NINT) + fan.local_index[type];
@@ -388,9 +397,10 @@ __device__ inline bool make_record_impl(const Mesh &m, const Fields &f, const in
 // scalar registers instead of behind a reference
 template <int ND>
 __device__ __noinline__ bool make_record_general(const Mesh &m, const Fields &f, const int *corner, int type,
-                                                 const u64 (*X)[ND], const int *ids, bool presolved, const double *mu_in, ftkx_cp_t *out)
+                                                 const u64 (*X)[ND], const int *ids, bool presolved, const double *mu_in, ftkx_cp_t *out,
+                                                 bool *fragile, double *Jfrag)
 {
-  return make_record_impl<ND, false>(m, f, corner, type, X, ids, presolved, mu_in, out);
+  return make_record_impl<ND, false>(m, f, corner, type, X, ids, presolved, mu_in, out, fragile, Jfrag);
 }
 
 // one simplex: vertices already classified/quantised (flags[i], X[i]).  Returns whether the origin is inside (robust integer
@@ -423,10 +433,11 @@ __device__ inline bool simplex_inside(const Mesh &m, const Fields &f, int cull, 
 }
 
 // hits of one wavefront appended with a single atomic (must be reached by all 64 lanes)
-__device__ inline void emit_hits(const Mesh &m, bool hit, const ftkx_cp_t &rec)
+// returns the record's slot in the hit buffer (~0 if it was not stored)
+__device__ inline u64 emit_hits(const Mesh &m, bool hit, const ftkx_cp_t &rec)
 {
   const unsigned long long hb = __ballot(hit);
-  if (!hb) return;
+  if (!hb) return ~0ull;
   const int lane = threadIdx.x & 63;
   const int leader = __ffsll((long long)hb) - 1;
   u64 slot0 = 0;
@@ -434,8 +445,9 @@ __device__ inline void emit_hits(const Mesh &m, bool hit, const ftkx_cp_t &rec)
   slot0 = __shfl(slot0, leader);
   if (hit) {
     const u64 slot = slot0 + (u64)__popcll(hb & ((1ull << lane) - 1ull));
-    if (slot < m.capacity) m.hits[slot] = rec;
+    if (slot < m.capacity) { m.hits[slot] = rec; return slot; }
   }
+  return ~0ull;
 }
 
 // simplices that passed the test: appended for record_kernel with a single atomic per wavefront (must be reached by all 64 lanes)
@@ -2126,7 +2138,8 @@ __global__ __launch_bounds__(kThreads) void record_kernel(const Mesh m, const Fi
   if (count > m.capacity) count = m.capacity;               // overflow: the host grows the buffers and replays the batch
   const u64 padded = (count + 63) / 64 * 64;                // wave-uniform trip count: emit_hits ballots
   for (u64 i = (u64)blockIdx.x * kThreads + threadIdx.x; i < padded; i += (u64)gridDim.x * kThreads) {
-    bool hit = false;
+    bool hit = false, fragile = false;
+    double Jfrag[9];
     ftkx_cp_t rec;
     if (i < count) {
       const u64 d = m.pass[i];
@@ -2151,10 +2164,18 @@ __global__ __launch_bounds__(kThreads) void record_kernel(const Mesh m, const Fi
         ids[v] = vertex_id<ND>(m, corner, vm);
       }
       // (per lane: records next to the array border, given J, vector input, degrees take the general path)
-      hit = record_is_fast<ND>(m, f, corner) ? make_record_impl<ND, true>(m, f, corner, type, X, ids, false, nullptr, &rec)
-                                             : make_record_general<ND>(m, f, corner, type, X, ids, false, nullptr, &rec);
+      hit = record_is_fast<ND>(m, f, corner) ? make_record_impl<ND, true>(m, f, corner, type, X, ids, false, nullptr, &rec, &fragile, Jfrag)
+                                             : make_record_general<ND>(m, f, corner, type, X, ids, false, nullptr, &rec, &fragile, Jfrag);
     }
-    emit_hits(m, hit, rec);
+    const u64 slot = emit_hits(m, hit, rec);
+    if (ND == 3 && hit && fragile && slot != ~0ull) {          // (rare) handed to the host for classification with ITS libm
+      const u64 e = atomicAdd(&m.counters[CNT_FRAGILE], 1ull);
+      if (e < m.fragile_capacity) {
+        u64 *dst = m.fragile + e * 10;
+        dst[0] = slot;
+        for (int q = 0; q < 9; q ++) dst[1 + q] = (u64)__double_as_longlong(Jfrag[q]);
+      }
+    }
   }
 }
 

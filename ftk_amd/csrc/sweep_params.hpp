@@ -8,7 +8,7 @@ typedef unsigned long long u64;
 typedef long long i64;
 
 enum { CNT_HITS = 0, CNT_CELLS_SURVIVED = 1, CNT_SIMPLICES_TESTED = 2, CNT_SURVIVOR_LIST = 3, CNT_LIST_PEAK = 4,
-       CNT_REFINE_LIST = 5, CNT_REFINE_PEAK = 6, CNT_WORDS_REFINED = 7, CNT_PASS = 8, CNT_SPARSE = 9, CNT_N = 10 };
+       CNT_REFINE_LIST = 5, CNT_REFINE_PEAK = 6, CNT_WORDS_REFINED = 7, CNT_PASS = 8, CNT_SPARSE = 9, CNT_FRAGILE = 10, CNT_N = 11 };
 
 // A simplex that passed the test, handed from the integer kernels (exact_kernel, tile_kernel) to record_kernel, which does all the
 // FP64 work (solve, lerp, Jacobian, classification) on densely packed lanes: corner index inside core (x fastest) | type | request.
@@ -33,6 +33,7 @@ struct Mesh {
   int compute_degrees, tag_mode;
   int scalar_mode;           // 1: V is not stored; it is gradient2D/3D(S) evaluated where needed (vector_field_source == DERIVED)
   int derive_jacobian;       // 1: J not stored; jacobian2D/3D of V evaluated at hit vertices (jacobian_field_source == DERIVED)
+  int record_general;        // 1: every record takes the general gather (FTKX_RECORD_GENERAL=1: cross-check of the straight-line one)
   int coords_mode;           // REGULAR_COORDS_*: 0 lattice integers, 1 image bounds, 2 rectilinear, 3 explicit
   double coords_bounds[6];
   const double *coords_rect[3];   // RECTILINEAR: per-axis coordinate arrays (device), indexed by the vertex coordinate
@@ -42,6 +43,8 @@ struct Mesh {
   u64 *pass;                 // simplices that passed the test, awaiting record_kernel (same capacity as hits)
   u64 *counters;             // CNT_* device counters
   u64 capacity;              // records the hit buffer can hold
+  u64 *fragile;              // 3D records whose class hangs on the last bits of libm (classify3): 10 words each -- slot in `hits`, J[3][3]
+  u64 fragile_capacity;
 };
 
 // the fields of one (timestep, scope) request: slice t and slice t+1

@@ -181,6 +181,9 @@ int ftkx_sweep_cancel(ftkx_ctx *ctx);    /* forgets the enqueued, not yet collec
 typedef struct ftkx_stats {
   unsigned long long work_items, cells, cells_survived, simplices_tested, hits;
   int cull_enabled;
+  unsigned long long reclassified;   /* 3D records whose Hessian has an eigenvalue that is zero up to rounding: their class was computed
+                                        on the host, with the host's libm (the device library's pow / acos / cos differ from it in the
+                                        last place, which is all such a class hangs on) */
 } ftkx_stats;
 int ftkx_get_stats(const ftkx_ctx *ctx, ftkx_stats *st);
 

@@ -1,0 +1,172 @@
+"""Randomised parity: the HIP path against the oracle on many small, seeded configurations -- sizes that are and are not multiples
+of the tile / word / group sizes, smooth and rough fields with plateaus, exact zeros, tiny and huge values, NaN / Inf, both
+dimensions, scalar and vector input, the options the reference's trackers have, and the three ways a caller drives the sweep
+(streaming tracker, batched context with the exact pre-pass, batched context with the one-pass prepare -- announced or not).
+Everything bit-exact (tags, types, ordinal / timestep, coordinates, scalars, per-step factors)."""
+import numpy as np
+import pytest
+
+from common import assert_records_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available()
+    import ftk_amd
+    from ftk_amd import build
+    build.build()
+    return ftk_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    import pyoracle
+    pyoracle.build()
+    return pyoracle
+
+
+def _field(rng, shape, kind):
+    """one time series of arrays of `shape` (numpy order: slowest axis first), as a function of the kind of trouble it makes"""
+    nt, sp = shape[0], shape[1:]
+    grids = np.meshgrid(*[np.linspace(-1.0, 1.0, n) for n in sp], indexing="ij")
+    out = []
+    c0 = rng.uniform(-0.6, 0.6, size=len(sp)); vel = rng.uniform(-0.08, 0.08, size=len(sp))
+    for k in range(nt):
+        r2 = sum((g - (c0[a] + vel[a] * k)) ** 2 for a, g in enumerate(grids))
+        if kind == "smooth":
+            a = np.exp(-3.0 * r2) + 0.3 * np.sin(3.0 * grids[0] + 0.2 * k) * np.cos(2.0 * grids[-1])
+        elif kind == "dyadic":             # exact arithmetic: many exact zeros and ties in the gradient
+            a = np.round(r2 * 64.0) / 64.0
+        elif kind == "rough":
+            a = np.cumsum(rng.standard_normal(sp), axis=-1) * 0.125 + 0.05 * k
+        elif kind == "plateau":
+            a = np.round(np.exp(-3.0 * r2) * 6.0) / 6.0
+        elif kind == "tiny":               # every gradient below 2^-8: nbits 21, nothing strictly signed under the first hint
+            a = (np.exp(-3.0 * r2) + rng.standard_normal(sp) * 0.05) * 1e-6
+        elif kind == "huge":               # quantised magnitudes that can wrap the determinants: per-vertex overflow rule, tile fallback
+            a = np.exp(-3.0 * r2) * rng.choice([3e3, 4e5, 7e8])
+        elif kind == "spikes":             # a few outliers / non-finite values in an otherwise smooth field
+            a = np.exp(-3.0 * r2) + 0.2 * np.sin(4.0 * grids[0])
+            for _ in range(3):
+                idx = tuple(int(rng.integers(0, n)) for n in sp)
+                a[idx] = rng.choice([np.nan, np.inf, -np.inf, 5e6, -2e7, 0.0])
+        else:
+            raise ValueError(kind)
+        out.append(np.ascontiguousarray(a, dtype=np.float64))
+    return out
+
+
+def _vector_series(rng, nt, sp, kind):
+    nd = len(sp)
+    comps = [_field(rng, (nt,) + sp, kind) for _ in range(nd)]
+    return [np.ascontiguousarray(np.stack([comps[c][k] for c in range(nd)], axis=-1)) for k in range(nt)]
+
+
+def _context_run(gpu, steps, nd, nv, dims, mode, tag_mode, robust, type_filter, degrees):
+    from ftk_amd import tslab
+    scalar = nv == 1
+    lo = 2 if scalar else 1
+    dom = ([lo] * nd, [d - (3 if scalar else 2) for d in dims])
+    ctx = gpu.Context(nd)
+    ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
+    opts = dict(jacobian_symmetric=int(scalar), derive_jacobian=1, tag_mode=int(tag_mode), robust=int(robust), compute_degrees=int(degrees))
+    if type_filter is not None:
+        opts.update(use_type_filter=1, type_filter=int(type_filter))
+    ctx.set_options(**opts)
+    nt = len(steps)
+    for t in range(nt):
+        (ctx.push_scalar_slice if scalar else ctx.push_slice)(t, steps[t])
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    if mode == "exact_prepass":
+        res = [ctx.slice_resolution(t)[0] for t in range(nt)]
+    else:
+        if mode == "announced":
+            ctx.sweep_announce(range(nt), scopes)
+        rm = ctx.slices_prepare(range(nt), 0)
+        res = [rm[t][0] for t in range(nt)]
+    factors = tslab.factors_from_resolutions(res)
+    ctx.sweep_enqueue_many(range(nt), scopes, factors)
+    recs = ctx.sweep_collect()
+    LAST_STATS.clear(); LAST_STATS.update(ctx.stats())
+    ctx.close()
+    out = np.zeros(len(recs), dtype=[("tag", "<u8"), ("type", "<u4"), ("ordinal", "<i4"), ("timestep", "<i4"),
+                                     ("x", "<f8", (3,)), ("t", "<f8"), ("scalar", "<f8", (3,))])
+    for f in ("tag", "type", "x", "t", "scalar"):
+        out[f] = recs[f]
+    out["ordinal"] = recs["aux"] & 1
+    out["timestep"] = recs["aux"] >> 1
+    return out, factors
+
+
+LAST_STATS = {}
+KINDS = ["smooth", "dyadic", "rough", "plateau", "tiny", "huge", "spikes"]
+COMPARED = {"cases": 0, "records": 0, "modes": set()}
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configurations_equal_the_oracle(gpu, oracle, seed):
+    from gpu_common import run_tracker
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(6):
+        nd = int(rng.choice([2, 3]))
+        nv = int(rng.choice([1, nd]))
+        nt = int(rng.integers(2, 6))
+        if nd == 2:
+            dims = (int(rng.choice([16, 24, 40, 64, 130, 136, 257])) + int(rng.integers(0, 2)), int(rng.integers(9, 70)))
+        else:
+            dims = (int(rng.choice([8, 16, 24, 40, 130])) + int(rng.integers(0, 2)), int(rng.integers(7, 36)), int(rng.integers(7, 20)))
+        sp = tuple(reversed(dims))
+        kind = str(rng.choice(KINDS))
+        steps = _field(rng, (nt,) + sp, kind) if nv == 1 else _vector_series(rng, nt, sp, kind)
+        robust = bool(rng.random() < 0.85) or nd == 2       # (the non-robust 2D mode does not exist in the reference: 2d:612-624 is always robust)
+        type_filter = int(rng.choice([1, 2, 4, 8, 16, 6, 24])) if (nd == 2 and rng.random() < 0.25) else None
+        degrees = bool(nd == 2 and rng.random() < 0.15)
+        tag_mode = oracle.TAG_REFERENCE if rng.random() < 0.5 else oracle.TAG_EXACT64
+        what = f"seed {seed} case {case}: nd {nd} nv {nv} dims {dims} nt {nt} {kind} robust {robust} filter {type_filter} degrees {degrees} tag {tag_mode}"
+        ref, rf, _ = oracle.track(steps, nd, nv, robust=robust, type_filter=type_filter, compute_degrees=degrees, tag_mode=tag_mode, nthreads=8)
+        mode = str(rng.choice(["tracker", "exact_prepass", "one_pass", "announced"]))
+        bounds = None
+        if mode == "tracker" and rng.random() < 0.3:           # REGULAR_COORDS_BOUNDS: physical coordinates from an image box
+            bounds = [float(v) for d in range(nd) for v in sorted(rng.uniform(-3.0, 5.0, size=2))]
+            what += f" bounds {bounds}"
+            ref, rf, _ = oracle.track(steps, nd, nv, robust=robust, type_filter=type_filter, compute_degrees=degrees, tag_mode=tag_mode, nthreads=8, bounds=bounds)
+        if mode == "tracker":
+            got, gf, _ = run_tracker(steps, nd, nv, robust=robust, type_filter=type_filter, compute_degrees=degrees, tag_mode=tag_mode,
+                                     device=bool(rng.random() < 0.5), bounds=bounds)
+            assert np.array_equal(np.asarray(gf, dtype=np.uint64), rf), what + f" [tracker] factors {gf} vs {rf}"
+            assert_records_equal(got, ref, coord_tol=0.0, what=what + " [tracker]")
+        else:
+            got, gf = _context_run(gpu, steps, nd, nv, dims, mode, tag_mode, robust, type_filter, degrees)
+            assert [int(f) for f in rf] == [int(f) for f in gf], what + f" [{mode}] factors {gf} vs {list(rf)}"
+            assert_records_equal(got, ref, coord_tol=0.0, what=what + f" [{mode}]")
+        COMPARED["cases"] += 1; COMPARED["records"] += len(ref); COMPARED["modes"].add(mode)
+
+
+def test_the_fuzz_compared_something(gpu):
+    """(runs after the seeds above) the comparison was not vacuous: every call path taken, a few hundred thousand records checked"""
+    assert COMPARED["cases"] == 240 and COMPARED["records"] > 500000, COMPARED
+    assert COMPARED["modes"] == {"tracker", "exact_prepass", "one_pass", "announced"}, COMPARED
+    print(COMPARED)
+
+
+def test_singular_hessians_are_classified_with_the_host_libm(gpu, oracle):
+    """3D records whose Hessian is exactly singular (plateaus: an eigenvalue that is 0.0 with the host's pow / acos / cos and -1e-17
+    with the device library's) get the class the reference computes: the device flags them, the host classifies them
+    (cp_device.hpp classify3, ftkx_sweep_collect).  Found by the fuzz above (seed 15, case 4)."""
+    rng = np.random.default_rng(77)
+    total = degenerate = 0
+    for dims in ((131, 20, 9), (40, 33, 17), (24, 24, 24), (130, 21, 10)):
+        nt = 3
+        steps = _field(rng, (nt,) + tuple(reversed(dims)), "plateau")
+        ref, rf, _ = oracle.track(steps, 3, 1, tag_mode=oracle.TAG_EXACT64, nthreads=8)
+        for mode in ("one_pass", "exact_prepass"):
+            got, gf = _context_run(gpu, steps, 3, 1, dims, mode, oracle.TAG_EXACT64, True, None, False)
+            assert [int(f) for f in rf] == [int(f) for f in gf]
+            assert_records_equal(got, ref, coord_tol=0.0, what=f"plateau {dims} [{mode}]")
+            total += LAST_STATS["reclassified"]
+        degenerate += int((np.asarray(ref["type"]) == 1).sum())
+    assert degenerate > 0, "no degenerate record in any of the cases: not a test of this"
+    assert total > 0
