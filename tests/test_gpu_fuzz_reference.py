@@ -1,7 +1,9 @@
 """Randomised parity against THE REFERENCE ITSELF: oracle/_ref/ftk_ref_driver (hguo/ftk's own trackers, compiled from its headers by
 oracle/Makefile; the binary travels to the GPU box, the sources do not) tracks seeded random series in `file` mode; the HIP path
 must produce the same records (tags in the reference's int32-wrapping form, types, ordinal / timestep, coordinates and scalars bit
-for bit), the same quantisation factors, and -- after pass 2 on the host -- the same traced curves.  Skipped where the binary was
+for bit), the same quantisation factors, -- after pass 2 on the host -- the same traced curves and the same post-processed
+trajectories (per point: tag, smoothed type, adjusted time), and in enable_streaming_trajectories mode the same trajectories in the
+same order of birth.  Skipped where the binary was
 not built (no /root/reference at build time)."""
 import os
 import subprocess
@@ -17,6 +19,7 @@ from test_gpu_fuzz import _field, _vector_series, KINDS
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "oracle", "_ref", "ftk_ref_driver")
+ABORTED = []
 
 
 @pytest.fixture(scope="module")
@@ -39,7 +42,7 @@ def _reference(steps, nd, nv, env):
 
 
 @pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/ftk_ref_driver not built")
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(25))
 def test_random_series_equal_the_real_reference(gpu, seed):
     from gpu_common import run_tracker
     rng = np.random.default_rng(5000 + seed)
@@ -62,12 +65,49 @@ def test_random_series_equal_the_real_reference(gpu, seed):
         if type_filter is not None:
             env["FTK_REF_TYPE_FILTER"] = str(type_filter)
         what = f"seed {seed} case {case}: nd {nd} nv {nv} dims {dims} nt {nt} {kind} robust {robust} filter {type_filter}"
-        ref = _reference(steps, nd, nv, env)
-        got, gf, _, (curves, loop) = run_tracker(steps, nd, nv, robust=robust, type_filter=type_filter, want_curves=True,
-                                                 device=bool(rng.random() < 0.5))
+        streaming = bool(rng.random() < 0.3)             # enable_streaming_trajectories: trajectories grown while the sweep streams
+        if streaming:
+            env["FTK_REF_STREAMING"] = "1"
+            what += " streaming"
+        try:
+            ref = _reference(steps, nd, nv, env)
+        except subprocess.CalledProcessError:
+            # the reference aborts on this input (streaming mode asserts `linear_graphs.size() == 1` in trace_critical_points_online,
+            # critical_point_tracker.hh, when new points form a branching component): nothing to compare with; the product
+            # must still come back -- with trajectories or with an error, not with a crash
+            assert streaming, what + ": the reference failed outside streaming mode"
+            try:
+                run_tracker(steps, nd, nv, robust=robust, type_filter=type_filter, streaming=True)
+            except Exception as e:   # noqa: BLE001
+                assert "ftkx" in type(e).__name__.lower() or "Ftkx" in type(e).__name__, repr(e)
+            ABORTED.append(what)
+            continue
+        state = {}
+
+        def after(tr):
+            if streaming:
+                tr.finalize()
+                state["curves"] = tr.get_traced_critical_points()
+            tr.post_process()
+            state["pp"] = tr.get_traced_trajectories()
+        out = run_tracker(steps, nd, nv, robust=robust, type_filter=type_filter, want_curves=not streaming, streaming=streaming,
+                          device=bool(rng.random() < 0.5), after=after)
+        got, gf = out[0], out[1]
         assert np.array_equal(np.asarray(gf, dtype=np.uint64), ref["factors"]), what + f": factors {gf} vs {ref['factors']}"
-        assert_records_equal(got, ref["records"], coord_tol=0.0, what=what)
-        if ref["curves"] is not None:
+        if streaming:
+            # same trajectories in the same order of birth; what is left as discrete points: the last step's ordinal points
+            curves, loop = state["curves"]
+            mine = [(tuple(c.tolist()), int(l)) for c, l in zip(curves, loop)]
+            theirs = [(tuple(t.tolist()), int(l)) for l, t in ref["curves"]]
+            assert mine == theirs, what + f": {len(mine)} trajectories, the reference grew {len(theirs)}"
+            assert np.array_equal(np.sort(got["tag"]), np.sort(ref["records"]["tag"])), what + ": discrete points left behind"
+        else:
+            assert_records_equal(got, ref["records"], coord_tol=0.0, what=what)
+            curves, loop = out[3]
             mine = sorted((tuple(c.tolist()), int(l)) for c, l in zip(curves, loop))
             theirs = sorted((tuple(t.tolist()), int(l)) for l, t in ref["curves"])
             assert mine == theirs, what + f": {len(mine)} curves, the reference traced {len(theirs)}"
+        # json_interface::post_process with its defaults: per point tag, smoothed type, adjusted time
+        mine = sorted((tuple(tg.tolist()), tuple(ty.tolist()), tuple(tt.tolist()), lp) for tg, ty, tt, lp, _ in state["pp"])
+        theirs = sorted((tuple(pts["tag"].tolist()), tuple(pts["type"].tolist()), tuple(pts["t"].tolist()), lp) for lp, pts in ref["pp"])
+        assert mine == theirs, what + f": {len(mine)} post-processed trajectories, the reference has {len(theirs)}"
