@@ -170,3 +170,56 @@ def test_singular_hessians_are_classified_with_the_host_libm(gpu, oracle):
         degenerate += int((np.asarray(ref["type"]) == 1).sum())
     assert degenerate > 0, "no degenerate record in any of the cases: not a test of this"
     assert total > 0
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_boundary_calls_equal_the_oracle(gpu, oracle, seed):
+    """The drop-in boundary itself (ftkx_extract_cp2dt / 3dt: the reference's argument list, host V / J / S given -- the general
+    record path, not the in-flight derivation) on random fields with random `core` boxes inside the domain, both scopes, every tag
+    mode, a current timestep that is not 0."""
+    rng = np.random.default_rng(3000 + seed)
+    for case in range(5):
+        nd = int(rng.choice([2, 3]))
+        nv = int(rng.choice([1, nd]))
+        if nd == 2:
+            D = [int(rng.integers(12, 70)), int(rng.integers(10, 50))]
+        else:
+            D = [int(rng.integers(9, 40)), int(rng.integers(8, 24)), int(rng.integers(8, 16))]
+        sp = tuple(reversed(D))
+        kind = str(rng.choice(["smooth", "dyadic", "rough", "plateau", "spikes"]))
+        steps = _field(rng, (2,) + sp, kind) if nv == 1 else _vector_series(rng, 2, sp, kind)
+        lo = 2 if nv == 1 else 1
+        dom = ([lo] * nd, [d - (3 if nv == 1 else 2) for d in D])
+        core_st = [int(rng.integers(dom[0][d], dom[0][d] + dom[1][d])) for d in range(nd)]
+        core_sz = [int(rng.integers(1, dom[0][d] + dom[1][d] - core_st[d] + 1)) for d in range(nd)]
+        if rng.random() < 0.4:
+            core_st, core_sz = list(dom[0]), list(dom[1])
+        fields = []
+        for k in (0, 1):
+            a = steps[k]
+            if nv == 1:
+                V = oracle.gradient2D(a) if nd == 2 else oracle.gradient3D(a)
+                J = oracle.jacobian2D(V, True) if nd == 2 else oracle.jacobian3D(V)
+                fields.append((V, J, a))
+            else:
+                J = oracle.jacobian2D(a, False) if nd == 2 else oracle.jacobian3D(a)
+                fields.append((a, J, None))
+        res = min(oracle.resolution(fields[0][0]), oracle.resolution(fields[1][0]))
+        factor, _ = oracle.scaling_factor(res)
+        t = int(rng.integers(0, 7))
+        robust = bool(rng.random() < 0.8) or nd == 2
+        for scope in (gpu.SCOPE_ORDINAL, gpu.SCOPE_INTERVAL):
+            tag_mode = int(rng.choice([oracle.TAG_WORK_INDEX, oracle.TAG_REFERENCE, oracle.TAG_EXACT64]))
+            what = f"seed {seed} case {case}: nd {nd} nv {nv} D {D} {kind} core {core_st}+{core_sz} t {t} scope {scope} tag {tag_mode} robust {robust}"
+            ref = oracle.sweep(nd, scope, t, dom, (core_st, core_sz), ([0] * nd, D), (fields[0][0], fields[1][0]), (fields[0][1], fields[1][1]),
+                               (fields[0][2], fields[1][2]) if nv == 1 else None, factor, jacobian_symmetric=(nv == 1), robust=robust, tag_mode=tag_mode)
+            opt = gpu.default_options(jacobian_symmetric=int(nv == 1), tag_mode=tag_mode, robust=int(robust))
+            f = gpu.extract_cp2dt if nd == 2 else gpu.extract_cp3dt
+            nxt = scope == gpu.SCOPE_INTERVAL
+            got = f(scope, t, (dom[0] + [0], dom[1] + [2 ** 31 - 1]), (core_st + [t], core_sz + [1]), ([0] * nd, D),
+                    fields[0][0], fields[1][0] if nxt else None, fields[0][1], fields[1][1] if nxt else None,
+                    fields[0][2], fields[1][2] if nxt else None, factor, opt)
+            refr = np.zeros(len(ref), dtype=got.dtype)
+            for fld in ("x", "t", "scalar", "type", "tag"):
+                refr[fld] = ref[fld]
+            assert_records_equal(got, refr, coord_tol=0.0, what=what)
