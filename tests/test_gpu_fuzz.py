@@ -128,14 +128,28 @@ def test_random_configurations_equal_the_oracle(gpu, oracle, seed):
         what = f"seed {seed} case {case}: nd {nd} nv {nv} dims {dims} nt {nt} {kind} robust {robust} filter {type_filter} degrees {degrees} tag {tag_mode}"
         ref, rf, _ = oracle.track(steps, nd, nv, robust=robust, type_filter=type_filter, compute_degrees=degrees, tag_mode=tag_mode, nthreads=8)
         mode = str(rng.choice(["tracker", "exact_prepass", "one_pass", "announced"]))
-        bounds = None
-        if mode == "tracker" and rng.random() < 0.3:           # REGULAR_COORDS_BOUNDS: physical coordinates from an image box
-            bounds = [float(v) for d in range(nd) for v in sorted(rng.uniform(-3.0, 5.0, size=2))]
-            what += f" bounds {bounds}"
-            ref, rf, _ = oracle.track(steps, nd, nv, robust=robust, type_filter=type_filter, compute_degrees=degrees, tag_mode=tag_mode, nthreads=8, bounds=bounds)
+        bounds = rect = expl = None
+        multi = {}
+        if mode == "tracker":
+            coords = rng.random()
+            if coords < 0.25:              # REGULAR_COORDS_BOUNDS: physical coordinates from an image box
+                bounds = [float(v) for d in range(nd) for v in sorted(rng.uniform(-3.0, 5.0, size=2))]
+            elif coords < 0.4:             # REGULAR_COORDS_RECTILINEAR: one coordinate array per axis
+                rect = [np.cumsum(rng.uniform(0.1, 2.0, size=dims[d])) - 3.0 for d in range(nd)]
+            elif coords < 0.55:            # REGULAR_COORDS_EXPLICIT: (ncomp, n0, n1) coordinates -- read with three indices in 3D too (3d:371-376)
+                expl = rng.uniform(-2.0, 2.0, size=(dims[1], dims[0], nd))
+            if bounds is not None or rect is not None or expl is not None:
+                what += " coords " + ("bounds" if bounds is not None else "rectilinear" if rect is not None else "explicit")
+                ref, rf, _ = oracle.track(steps, nd, nv, robust=robust, type_filter=type_filter, compute_degrees=degrees, tag_mode=tag_mode, nthreads=8,
+                                          bounds=bounds, rectilinear=rect, explicit=expl)
+            if rng.random() < 0.3:         # one tracker, several contexts (here: on one GPU), timesteps dealt in blocks
+                multi = dict(device_ids=[0] * int(rng.integers(2, 4)), block=int(rng.integers(1, 4)), factor_each_step=False)
+                what += f" multi {multi}"
         if mode == "tracker":
             got, gf, _ = run_tracker(steps, nd, nv, robust=robust, type_filter=type_filter, compute_degrees=degrees, tag_mode=tag_mode,
-                                     device=bool(rng.random() < 0.5), bounds=bounds)
+                                     device=bool(rng.random() < 0.5), bounds=bounds, rectilinear=rect, explicit=expl, **multi)
+            if multi:                      # (a multi-device tracker reports the factor of its latest step only)
+                gf, rf = gf[-1:], rf[-1:]
             assert np.array_equal(np.asarray(gf, dtype=np.uint64), rf), what + f" [tracker] factors {gf} vs {rf}"
             assert_records_equal(got, ref, coord_tol=0.0, what=what + " [tracker]")
         else:
