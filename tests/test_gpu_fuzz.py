@@ -237,3 +237,28 @@ def test_random_boundary_calls_equal_the_oracle(gpu, oracle, seed):
             for fld in ("x", "t", "scalar", "type", "tag"):
                 refr[fld] = ref[fld]
             assert_records_equal(got, refr, coord_tol=0.0, what=what)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_medium_sizes_equal_the_oracle(gpu, oracle, seed):
+    """Sizes that span several tiles, row groups and z chunks of the marching kernels (with ragged ends in every direction), rough
+    and spiky data: the batched context (one-pass prepare, announced or not) against the oracle on the host's threads."""
+    import os
+    rng = np.random.default_rng(9000 + seed)
+    nd = 3 if seed % 3 != 2 else 2
+    nv = 1 if seed % 2 == 0 else nd
+    nt = 3
+    if nd == 3:
+        dims = (int(rng.choice([136, 200, 264])) + 2 * int(rng.integers(0, 3)), int(rng.integers(40, 80)), int(rng.integers(34, 48)))
+    else:
+        dims = (int(rng.choice([520, 1032])) + 2 * int(rng.integers(0, 3)), int(rng.integers(200, 300)))
+    kind = str(rng.choice(["rough", "spikes", "smooth", "huge", "plateau"]))
+    sp = tuple(reversed(dims))
+    steps = _field(rng, (nt,) + sp, kind) if nv == 1 else _vector_series(rng, nt, sp, kind)
+    threads = min(64, os.cpu_count() or 8)
+    ref, rf, _ = oracle.track(steps, nd, nv, tag_mode=oracle.TAG_EXACT64, nthreads=threads)
+    for mode in ("one_pass", "announced"):
+        got, gf = _context_run(gpu, steps, nd, nv, dims, mode, oracle.TAG_EXACT64, True, None, False)
+        what = f"seed {seed}: nd {nd} nv {nv} dims {dims} {kind} [{mode}]"
+        assert [int(f) for f in rf] == [int(f) for f in gf], what
+        assert_records_equal(got, ref, coord_tol=0.0, what=what)
