@@ -25,6 +25,13 @@ for rep in range(3):
         if k != 0: tr.advance_timestep()
         if k == nt - 1: tr.update_timestep()
     dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
     recs, o, ts = tr.get_critical_points()
+    t2 = time.perf_counter()
+    tr.finalize()
+    t3 = time.perf_counter()
+    tr.post_process()
+    t4 = time.perf_counter()
     tr.close()
-    print(cfg, "tracker API: %.3f ms total, %.3f ms per timestep, %d records, %.3e simplices/s" % (dt * 1e3, dt * 1e3 / nt, len(recs), tslab.count_simplices(nd, dims, nt) / dt))
+    print(cfg, "tracker API: %.3f ms total, %.3f ms per timestep, %d records, %.3e simplices/s; get_critical_points %.3f ms, finalize %.3f ms, post_process %.3f ms"
+          % (dt * 1e3, dt * 1e3 / nt, len(recs), tslab.count_simplices(nd, dims, nt) / dt, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3))
