@@ -1470,7 +1470,7 @@ __device__ inline void wait_plane_landed(int s)
 }
 
 template <int NS, int CY, int RY, bool TWOB>
-__device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
+__device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle, int split, int main_jobs, int zc_tail)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int ROWS = RY * CY, TROWS = ROWS + 2, NE = NS + 1;             // NS row slots, NS + 1 edge entries
@@ -1486,11 +1486,16 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
   static_assert(DEPTH >= 1, "at least one plane on its way");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = m.ext_sz[2], P = m.mask_pitch;
-  const int nzc = (DD + zchunk - 1) / zchunk;
   unsigned bx, by, bz;
   remap_block(swizzle, bx, by, bz);
-  const MaskJob job = jobs[bz / nzc];
-  const int z0 = (int)(bz % nzc) * zchunk;
+  // the last slices of a launch may come in shorter chunks (z blocks from `split` on: slices main_jobs, main_jobs + 1, ... in chunks
+  // of zc_tail planes): the workgroups that run last, when the device is no longer full, are short ones
+  const bool tail = (int)bz >= split;
+  if (tail) zchunk = zc_tail;
+  const int nzc = (DD + zchunk - 1) / zchunk;
+  const int lz = tail ? (int)bz - split : (int)bz;
+  const MaskJob job = jobs[(tail ? main_jobs : 0) + lz / nzc];
+  const int z0 = (lz % nzc) * zchunk;
   const int z1 = z0 + zchunk < DD ? z0 + zchunk : DD;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1744,9 +1749,9 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
 }
 
 template <int NS, int CY, int RY, bool TWOB>
-__global__ __launch_bounds__(64 * CY) void mask_march6_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
+__global__ __launch_bounds__(64 * CY) void mask_march6_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle, int split, int main_jobs, int zc_tail)
 {
-  march6_body<NS, CY, RY, TWOB>(m, jobs, zchunk, swizzle);
+  march6_body<NS, CY, RY, TWOB>(m, jobs, zchunk, swizzle, split, main_jobs, zc_tail);
 }
 // ---------------------------------------------------------------------------------------------------------------
 // FAST PATH 2/3: corner cull on the mask bytes, 8 corners per lane (SWAR), survivors -> work list
@@ -2421,7 +2426,18 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
             zchunk = 32;
             while (zchunk > 8 && (size_t)((DW + 127) / 128) * ((m.ext_sz[1] + 15) / 16) * ((DD + zchunk - 1) / zchunk) * njobs < 4096) zchunk /= 2;   // (three workgroups per CU: 768 at a time)
           }
-          const unsigned gz = (unsigned)(((DD + zchunk - 1) / zchunk) * njobs);
+          // FTKX_MASK_TAIL="jobs,planes": the last `jobs` slices in chunks of `planes` planes (see march6_body)
+          // Default: a launch that fills the device (768 workgroups at a time) fewer than a dozen times ends with its last slice in
+          // chunks of 8 planes -- 256^3 x 16 (5.3 rounds) 0.419 -> 0.404 ms; 512^3 x 32 (43 rounds) gains nothing and keeps its chunks
+          int tail_jobs = 0, zc_tail = zchunk;
+          {
+            const size_t wgs = (size_t)((DW + 127) / 128) * ((m.ext_sz[1] + 15) / 16) * ((DD + zchunk - 1) / zchunk) * njobs;
+            if (wgs < 12 * 768 && njobs >= 2 && zchunk > 8) { tail_jobs = 1; zc_tail = 8; }
+          }
+          if (const char *e = getenv("FTKX_MASK_TAIL")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 4) { tail_jobs = a < njobs ? a : njobs; zc_tail = b; } }
+          const int main_jobs = njobs - tail_jobs;
+          const int split = tail_jobs ? main_jobs * ((DD + zchunk - 1) / zchunk) : 0x7fffffff;
+          const unsigned gz = (unsigned)(main_jobs * ((DD + zchunk - 1) / zchunk) + tail_jobs * ((DD + zc_tail - 1) / zc_tail));
 #define FTKX_M6(NS_, CY_, RY_) do { \
             g_last_mask_kernel = (swizzle & 64) ? "ftkx::mask_march6_kernel<" #NS_ ", " #CY_ ", " #RY_ ", true>" : "ftkx::mask_march6_kernel<" #NS_ ", " #CY_ ", " #RY_ ", false>"; \
             const int rows = CY_ * RY_; \
@@ -2431,9 +2447,9 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
             if (sw & 8) { int yg = yg_want; if (yg > (int)grid6.y) yg = (int)grid6.y; grid6.y = (grid6.y + (unsigned)yg - 1) / (unsigned)yg * (unsigned)yg; sw = (sw & 0xff) | (yg << 8); } \
             const unsigned bytes = (unsigned)(NS_) * (unsigned)(rows + 2) * 1024u + (unsigned)(NS_ + 1) * (rows > 16 ? 512u : 256u); \
             if (sw & 64) { (void)hipFuncSetAttribute((const void *)mask_march6_kernel<NS_, CY_, RY_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
-              hipLaunchKernelGGL((mask_march6_kernel<NS_, CY_, RY_, true>), grid6, dim3(64u * CY_), bytes, stream, m, d_jobs, zchunk, sw); } \
+              hipLaunchKernelGGL((mask_march6_kernel<NS_, CY_, RY_, true>), grid6, dim3(64u * CY_), bytes, stream, m, d_jobs, zchunk, sw, split, main_jobs, zc_tail); } \
             else { (void)hipFuncSetAttribute((const void *)mask_march6_kernel<NS_, CY_, RY_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
-              hipLaunchKernelGGL((mask_march6_kernel<NS_, CY_, RY_, false>), grid6, dim3(64u * CY_), bytes, stream, m, d_jobs, zchunk, sw); } } while (0)
+              hipLaunchKernelGGL((mask_march6_kernel<NS_, CY_, RY_, false>), grid6, dim3(64u * CY_), bytes, stream, m, d_jobs, zchunk, sw, split, main_jobs, zc_tail); } } while (0)
           // FTKX_MASK_TILE (wavefronts x rows each): 0 = 4 x 4 (default), 1 = 3 x 4, 2 = 4 x 3, 4 = 4 x 2, 6 = 8 x 2, 9 = 8 x 4; FTKX_MASK_PD = row slots in
           // LDS (default 2); FTKX_MASK_SWIZZLE bit 64: two barriers per plane (the slot is refilled in the step that reads it)
           if (shape == 1) FTKX_M6(3, 3, 4);
