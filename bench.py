@@ -235,8 +235,8 @@ def main():
             t_masked, sb, rb = tslab.compact_halo_masks(ctx, own, nt, scalar_input)
             compact_bytes[0] += sb; compact_bytes[1] += rb
         te0 = time.perf_counter()
-        for t in own:
-            ctx.sweep_enqueue(t, scope_of(t), f[t])
+        if own:     # one call for the slab's sweeps (per-sweep calls through ctypes cost a hit-dense 2D pass 5 %)
+            ctx.sweep_enqueue_many(ann_ts, ann_scopes, [f[t] for t in own])
         if world > 1 and args.compact_halo:
             # step 2: cull, then the input values around the boundary step's surviving cells from the slice's owner -- or, where
             # that would be more bytes than the slice (hit-dense data on small slices), the slice itself after all
@@ -247,8 +247,7 @@ def main():
                                                        halo_buffer=halo_buf, push_full=push_full)
             compact_bytes[0] += sb; compact_bytes[1] += rb; compact_bytes[2] += max(ncell, 0); compact_bytes[3] += 1 if ncell < 0 else 0
             if ncell < 0:
-                for t in own:
-                    ctx.sweep_enqueue(t, ftk_amd.SCOPE_BOTH if (t + 1 < nt) else ftk_amd.SCOPE_ORDINAL, f[t])
+                ctx.sweep_enqueue_many(ann_ts, ann_scopes, [f[t] for t in own])
         te1 = time.perf_counter()
         # one cull / exact launch for the whole slab (plus the masks of the halo slice, N > 1), then the hit download into the
         # library's pinned host buffer

@@ -175,6 +175,10 @@ class Context:
 
     def sweep_enqueue_many(self, ts, scopes, factors):
         n = len(ts)
+        if isinstance(ts, np.ndarray) and isinstance(scopes, np.ndarray) and ts.dtype == np.int32 and scopes.dtype == np.int32 and ts.flags.c_contiguous and scopes.flags.c_contiguous:
+            f = np.ascontiguousarray(factors, dtype=np.uint64)     # (timesteps and scopes handed over as they are: built once by the caller)
+            self._ck(self._L.ftkx_sweep_enqueue_many(self._h, ts.ctypes.data, scopes.ctypes.data, f.ctypes.data, n))
+            return
         self._ck(self._L.ftkx_sweep_enqueue_many(self._h, (C.c_int * n)(*[int(t) for t in ts]), (C.c_int * n)(*[int(v) for v in scopes]),
                                                  (C.c_ulonglong * n)(*[int(f) for f in factors]), n))
 
