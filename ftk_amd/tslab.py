@@ -39,7 +39,13 @@ def factors_from_resolutions(res):
     """res[t] = ndarray::resolution() of slice t for ALL nt slices -> factor used by the sweep of current_timestep == t"""
     nt = len(res)
     run = np.minimum.accumulate(np.minimum(np.asarray(res, dtype=np.float64), DBL_MAX))
-    return [scaling_factor(float(run[min(t + 1, nt - 1)])) for t in range(nt)]
+    vals = run[np.minimum(np.arange(1, nt + 1), nt - 1)].tolist()
+    out, last_v, last_f = [], None, None
+    for v in vals:                  # (the running minimum changes a handful of times: one log2 per change, not per timestep)
+        if v != last_v:
+            last_v, last_f = v, scaling_factor(v)
+        out.append(last_f)
+    return out
 
 
 def global_factors(local_res, nt, group=None, local_max=None):
