@@ -167,7 +167,11 @@ int ftkx_scatter_patches(ftkx_ctx *ctx, int t, const unsigned long long *cells, 
  * `factor` = vector_field_scaling_factor: any non-zero value is honoured (quantisation is trunc(v * factor) like 2d:605-616), but the
  * sign cull that makes the sweep memory-bound needs a power of two <= 2^53 (what update_vector_field_scaling_factor produces);
  * other factors run the full integer test on every simplex.  Records are returned in a context-owned pinned host buffer, sorted by tag,
- * valid until the next call on this context.  Synchronous on the context's stream. */
+ * valid until the next call on this context.  Synchronous on the context's stream.
+ * Everything in a record is computed on the device; the one exception is the TYPE of a 3D record whose Hessian has an eigenvalue
+ * that is zero up to rounding (plateaus, lattice-aligned data): the kernels flag it and hand its Jacobian over, and the class is
+ * computed here, with the host's pow / acos / cos -- the libm the reference's eigen_solver3.hh:20-47 runs on, whose last-place
+ * rounding is what such a class hangs on (ftkx_stats.reclassified counts them). */
 int ftkx_sweep(ftkx_ctx *ctx, int t, int scope, unsigned long long factor, const ftkx_cp_t **out, size_t *n_out);
 
 /* batched form: enqueue only records the request; ftkx_sweep_collect() launches the whole batch (one mask / cull / exact
