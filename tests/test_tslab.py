@@ -165,7 +165,8 @@ def _merge_worker(rank, world, port, name, q):
 
 
 @pytest.mark.parametrize("name,world,expect", [("woven_31x37x32", 2, (4491, 56, 56)), ("woven_31x37x32", 3, (4491, 56, 56)),
-                                               ("moving_extremum_3d_21x21x21x32", 3, (126, 1, 1)), ("double_gyre_64x32x50", 2, (879, 2, 2))])
+                                               ("moving_extremum_3d_21x21x21x32", 3, (126, 1, 1)), ("double_gyre_64x32x50", 2, (879, 2, 2)),
+                                               ("random_3d_scalar_13x12x11x4", 5, None)])     # more ranks than timesteps: an empty slab
 def test_merged_slabs_trace_to_the_reference_curves_gloo(oracle, name, world, expect):
     from ftk_amd import build
     build.build()
@@ -180,6 +181,12 @@ def test_merged_slabs_trace_to_the_reference_curves_gloo(oracle, name, world, ex
         p.join(60)
         assert p.exitcode == 0
     n_records, n_curves, crossing, n_trajs = out[0][2]
+    if expect is None:      # (the worker has compared records, curves and trajectories with the fixture; here: the counts add up)
+        from common import load_golden
+        g = load_golden(name)
+        assert world > g["DT"] and (n_records, n_curves, n_trajs) == (len(g["records"]), len(g["curves"]), len(g["pp"]))
+        assert sum(o[1] for o in out) == n_records and sum(1 for o in out if o[1] == 0) >= world - g["DT"]
+        return
     assert (n_records, n_curves, n_trajs) == expect
     assert sum(o[1] for o in out) == n_records and all(o[1] > 0 for o in out)     # every rank contributed
     assert crossing > 0                                                           # and curves do cross the slab boundaries
