@@ -161,7 +161,9 @@ def test_random_configurations_equal_the_oracle(gpu, oracle, seed):
 
 def test_the_fuzz_compared_something(gpu):
     """(runs after the seeds above) the comparison was not vacuous: every call path taken, a few hundred thousand records checked"""
-    assert COMPARED["cases"] == 240 and COMPARED["records"] > 500000, COMPARED
+    if COMPARED["cases"] != 240:
+        pytest.skip("the seeds above did not all run in this process (test selection / several workers)")
+    assert COMPARED["records"] > 500000, COMPARED
     assert COMPARED["modes"] == {"tracker", "exact_prepass", "one_pass", "announced"}, COMPARED
     print(COMPARED)
 
