@@ -1117,6 +1117,9 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
       const auto t_start = std::chrono::steady_clock::now();
       unsigned long long spins = 0;
       while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();                                  // (a spin-wait hint: the sibling hyperthread keeps its issue slots)
+#endif
         if ((++ spins & 0xfffffull) == 0) {
           const hipError_t q = hipStreamQuery(c->stream);
           const char *why = nullptr;
