@@ -235,6 +235,34 @@ struct UnionFind {
   void unite(int a, int b) { a = find(a); b = find(b); if (a != b) p[b] = a; }
 };
 
+// The same for several threads at once: a root is only ever linked under a root with a SMALLER index (compare-and-swap on the
+// root's own parent entry), so parents decrease along every path -- no cycles, no locks; path halving is a benign race.  When all
+// unions are in, the root of a component is its smallest member.
+struct ConcurrentUnionFind {
+  std::vector<int> p;
+  explicit ConcurrentUnionFind(size_t n) : p(n) { for (size_t i = 0; i < n; i ++) p[i] = (int)i; }
+  int find(int x)
+  {
+    for (;;) {
+      const int px = __atomic_load_n(&p[x], __ATOMIC_RELAXED);
+      if (px == x) return x;
+      const int ppx = __atomic_load_n(&p[px], __ATOMIC_RELAXED);
+      if (ppx != px) { int e = px; __atomic_compare_exchange_n(&p[x], &e, ppx, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); }
+      x = px;
+    }
+  }
+  void unite(int a, int b)
+  {
+    for (;;) {
+      a = find(a); b = find(b);
+      if (a == b) return;
+      if (a < b) std::swap(a, b);                              // a > b: a goes under b
+      int e = a;
+      if (__atomic_compare_exchange_n(&p[a], &e, b, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return;
+    }
+  }
+};
+
 // runs f(begin, end) over [0, n) on up to `cap` host threads (the per-record work of pass 2 is independent: SURVEY 8 f2 -- "the
 // sorted-tag binary searches are independent per hit").  The threads are kept: spawning 16 of them per call cost as much as the
 // work they then did on a hit set of 60 000 records.  Chunks are handed out through an atomic counter; the caller works too.
@@ -389,12 +417,15 @@ int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs
   std::vector<char> ordinary(n);
   for (size_t i = 0; i < n; i ++) ordinary[i] = deg[i] <= 2;
 
-  // curves = connected components of the ordinary nodes
-  UnionFind uf(n);
-  for (size_t i = 0; i < n; i ++)
-    if (ordinary[i]) for (int j : nb(i)) if (ordinary[j]) uf.unite((int)i, j);
-  // seeds: the smallest element of every component (a linear pass over per-record keys), components enumerated in element
-  // order of their seed (a sort of the seeds only)
+  // curves = connected components of the ordinary nodes (threads: the unions of a range of records each, then everybody's root)
+  ConcurrentUnionFind uf(n);
+  parallel_ranges(n, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; i ++)
+      if (ordinary[i]) for (int j : nb(i)) if (ordinary[j] && j < (int)i) uf.unite((int)i, j);     // (every edge is seen from both ends: once is enough)
+  });
+  std::vector<int> root(n);
+  parallel_ranges(n, [&](size_t b, size_t e) { for (size_t i = b; i < e; i ++) root[i] = uf.find((int)i); });
+  // seeds: the smallest element of every component, components enumerated in element order of their seed (a sort of the seeds only)
   std::vector<int> order;
   bool key_ok = true;
   {
@@ -404,12 +435,21 @@ int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs
     key_ok = key_ok && span < 18446744073709551615.0L;
   }
   if (key_ok) {
-    std::vector<int> best(n, -1);                    // per root: the member with the smallest key
-    for (size_t i = 0; i < n; i ++) {
-      if (!ordinary[i]) continue;
-      const int r = uf.find((int)i);
-      if (best[r] < 0 || order_key[i].first < order_key[best[r]].first) best[r] = (int)i;
-    }
+    // per root the smallest key of its members (atomic minimum), then the member that holds it (keys are unique: one writer)
+    std::vector<u64> best_key(n, ~0ull);
+    std::vector<int> best(n, -1);
+    parallel_ranges(n, [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; i ++) {
+        if (!ordinary[i]) continue;
+        u64 *slot = &best_key[root[i]];
+        const u64 k = order_key[i].first;
+        u64 cur = __atomic_load_n(slot, __ATOMIC_RELAXED);
+        while (k < cur && !__atomic_compare_exchange_n(slot, &cur, k, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+      }
+    });
+    parallel_ranges(n, [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; i ++) if (ordinary[i] && order_key[i].first == best_key[root[i]]) best[root[i]] = (int)i;
+    });
     std::vector<std::pair<u64, int>> seeds;
     for (size_t r = 0; r < n; r ++) if (best[r] >= 0) seeds.push_back({order_key[best[r]].first, best[r]});
     std::sort(seeds.begin(), seeds.end());
@@ -420,27 +460,22 @@ int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs
     for (size_t i = 0; i < n; i ++) order[i] = (int)i;
     std::sort(order.begin(), order.end(), [&](int a, int b) { return elem_less(elem[a], elem[b], N); });
   }
-  std::vector<int> comp_size(n, 0);
   tp[np_ ++] = now();
 
   std::vector<int> seq; seq.reserve(n);
   std::vector<long long> offsets(1, 0);
   std::vector<int> loops;
-  std::vector<char> visited(n, 0), seeded(n, 0);
-  std::vector<int> front, back;
-  for (int s : order) {
-    if (!ordinary[s]) continue;
-    const int root = uf.find(s);
-    if (seeded[root]) continue;
-    seeded[root] = 1;
-    // cc2curves.hh:48-105
+  std::vector<char> visited(n, 0);
+  // one curve from its seed (cc2curves.hh:48-105): first towards the seed's smallest neighbour, then the other way; is_loop
+  // (cc2curves.hh:113-122).  Touches `visited` of its own component only: curves can be walked side by side.
+  auto walk = [&](int s, std::vector<int> &out_seq, std::vector<int> &front, std::vector<int> &back) -> int {
     front.clear(); back.clear();
     visited[s] = 1;
-    std::vector<int> seed_nb;
-    for (int j : nb(s)) if (ordinary[j]) seed_nb.push_back(j);
+    int seed_nb[2 * N], nseed = 0;
+    for (int j : nb(s)) if (ordinary[j]) seed_nb[nseed ++] = j;
     for (int dir = 0; dir < 2; dir ++) {
-      if (seed_nb.empty()) break;
-      int cur = dir == 0 ? seed_nb.front() : seed_nb.back();
+      if (nseed == 0) break;
+      int cur = dir == 0 ? seed_nb[0] : seed_nb[nseed - 1];
       while (true) {
         if (!visited[cur]) { (dir == 0 ? back : front).push_back(cur); visited[cur] = 1; }
         int next = -1;
@@ -448,21 +483,50 @@ int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs
         if (next < 0) break;
         cur = next;
       }
-      if (seed_nb.size() == 1) break;
+      if (nseed == 1) break;
     }
-    const size_t begin = seq.size();
-    for (size_t i = front.size(); i > 0; i --) seq.push_back(front[i - 1]);
-    seq.push_back(s);
-    for (int v : back) seq.push_back(v);
-    offsets.push_back((long long)seq.size());
-    // is_loop, cc2curves.hh:113-122
+    const size_t begin = out_seq.size();
+    for (size_t i = front.size(); i > 0; i --) out_seq.push_back(front[i - 1]);
+    out_seq.push_back(s);
+    for (int v : back) out_seq.push_back(v);
     int loop = 0;
-    if (seq.size() - begin >= 2) {
-      const int f = seq[begin], b = seq.back();
-      for (int j : nb(f)) if (j == b) loop = 1;
+    if (out_seq.size() - begin >= 2) {
+      const int f = out_seq[begin], l = out_seq.back();
+      for (int j : nb(f)) if (j == l) loop = 1;
     }
-    loops.push_back(loop);
-    (void)comp_size;
+    return loop;
+  };
+  if (key_ok && order.size() >= 8 && n >= 4096) {
+    // `order` holds one seed per component: the curves are walked on the worker threads, each into its own list, and strung
+    // together in seed order
+    const size_t nc = order.size();
+    std::vector<std::vector<int>> part(nc);
+    std::vector<int> part_loop(nc, 0);
+    std::atomic<size_t> next_curve{0};
+    parallel_ranges(n, [&](size_t, size_t) {                   // (ranges ignored: the curves are handed out one by one)
+      std::vector<int> front, back;
+      for (;;) {
+        const size_t c = next_curve.fetch_add(1);
+        if (c >= nc) break;
+        part_loop[c] = walk(order[c], part[c], front, back);
+      }
+    });
+    for (size_t c = 0; c < nc; c ++) {
+      seq.insert(seq.end(), part[c].begin(), part[c].end());
+      offsets.push_back((long long)seq.size());
+      loops.push_back(part_loop[c]);
+    }
+  } else {
+    std::vector<char> seeded(n, 0);
+    std::vector<int> front, back;
+    for (int s : order) {
+      if (!ordinary[s]) continue;
+      if (seeded[root[s]]) continue;
+      seeded[root[s]] = 1;
+      const int loop = walk(s, seq, front, back);
+      offsets.push_back((long long)seq.size());
+      loops.push_back(loop);
+    }
   }
 
   tp[np_ ++] = now();
