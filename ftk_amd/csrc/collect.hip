@@ -1,0 +1,421 @@
+// The batched sweep: ftkx_sweep_enqueue / ftkx_sweep_collect (masks where missing -> cull -> exact test -> records -> device sort ->
+// download) and the kernel timing that goes with it.  Reference counterpart: the per-call host wrapper extract_cp2dt<scope> /
+// extract_cp3dt<scope> (src/filters/critical_point_tracer_2d_regular.cu:168-272, ..._3d_regular.cu:144-250).
+#include "ctx.hpp"
+#include "cp_device.hpp"   // classify3 on the HOST (fragile 3D records, see there)
+#include <hipcub/hipcub.hpp>
+
+using namespace ftkxh;
+
+namespace ftkxh {
+
+// types re-computed on the host written back into the hit buffer: pairs (slot, type)
+__global__ void patch_types_kernel(ftkx_cp_t *hits, const u64 *__restrict__ pairs, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) hits[pairs[2 * i]].type = (unsigned)pairs[2 * i + 1];
+}
+
+__global__ void sort_keys_kernel(const ftkx_cp_t *__restrict__ hits, size_t n, u64 *__restrict__ keys, unsigned *__restrict__ idx)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { keys[i] = hits[i].tag; idx[i] = (unsigned)i; }
+}
+
+__global__ void sort_gather_kernel(const ftkx_cp_t *__restrict__ hits, const unsigned *__restrict__ idx, size_t n, ftkx_cp_t *__restrict__ out)
+{
+  // 72-byte records moved as nine 8-byte words by nine consecutive lanes: coalesced stores
+  const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n * 9) {
+    const size_t r = w / 9, k = w % 9;
+    reinterpret_cast<u64 *>(out)[w] = reinterpret_cast<const u64 *>(hits)[(size_t)idx[r] * 9 + k];
+  }
+}
+
+// the reference keeps hits in a std::map ordered by element; device append order is arbitrary
+int sort_hits_on_device(ftkx_ctx *c, size_t n, int key_bits)
+{
+  if (c->sort_cap < n) {
+    for (void *p : {(void *)c->d_sorted, (void *)c->d_keys, (void *)c->d_idx, c->d_sort_tmp}) if (p) (void)hipFree(p);
+    c->d_sorted = nullptr; c->d_keys = nullptr; c->d_idx = nullptr; c->d_sort_tmp = nullptr; c->sort_cap = 0;
+    const size_t cap = n + n / 4 + 1024;
+    HIP_TRY(c, hipMalloc((void **)&c->d_sorted, cap * sizeof(ftkx_cp_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_keys, 2 * cap * sizeof(u64)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_idx, 2 * cap * sizeof(unsigned)));
+    size_t tmp = 0;
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, c->d_keys, c->d_keys + cap, c->d_idx, c->d_idx + cap, (int)cap, 0, 64, c->stream));
+    HIP_TRY(c, hipMalloc(&c->d_sort_tmp, tmp));
+    c->sort_tmp_bytes = tmp;
+    c->sort_cap = cap;
+  }
+  const size_t cap = c->sort_cap;
+  hipLaunchKernelGGL(sort_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_hits, n, c->d_keys, c->d_idx);
+  size_t tmp = c->sort_tmp_bytes;
+  // only the bits a tag of this batch can have take part: an 8-bit digit pass less per byte saved
+  HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys + cap, c->d_idx, c->d_idx + cap, (int)n, 0, key_bits, c->stream));
+  hipLaunchKernelGGL(sort_gather_kernel, dim3((unsigned)((n * 9 + 255) / 256)), dim3(256), 0, c->stream, c->d_hits, c->d_idx + cap, n, c->d_sorted);
+  HIP_TRY(c, hipGetLastError());
+  return FTKX_OK;
+}
+
+// (events are recycled: creating and destroying a pair per kernel cost a hit-dense 2D pass several per cent)
+hipEvent_t ev_take(ftkx_ctx *c)
+{
+  if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
+void ev_give(ftkx_ctx *c, hipEvent_t e) { if (e) c->event_pool.push_back(e); }
+void ev_begin(ftkx_ctx *c, int kind)
+{
+  if (!c->profiling) return;
+  hipEvent_t a = ev_take(c), b = ev_take(c);
+  if (!a || !b) { ev_give(c, a); ev_give(c, b); return; }
+  (void)hipEventRecord(a, c->stream);
+  c->events.push_back({kind, {a, b}});
+}
+void ev_end(ftkx_ctx *c)
+{
+  if (!c->profiling || c->events.empty()) return;
+  (void)hipEventRecord(c->events.back().second.second, c->stream);
+}
+void ev_harvest(ftkx_ctx *c, bool all)
+{
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> later;
+  for (auto &e : c->events) {
+    if (!all && hipEventQuery(e.second.second) != hipSuccess) { later.push_back(e); continue; }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e.second.first, e.second.second) == hipSuccess) { c->k_ms[e.first] += ms; c->k_launches[e.first] ++; }
+    ev_give(c, e.second.first); ev_give(c, e.second.second);
+  }
+  c->events.swap(later);
+}
+
+// launches everything the pending requests need; counters must have been zeroed.
+// Fast-path requests are grouped into sub-batches (one mask / cull / exact launch each); a new sub-batch starts whenever a
+// slice's masks would be needed under a second quantisation factor (the factor is a running minimum, so it changes a few
+// times at the start of a series and then stays put).
+int run_batch(ftkx_ctx *c, const double *sparse_field, bool cull_done)
+{
+  const bool cull_only = sparse_field != nullptr;   // ftkx_sweep_cull: stop after the cull and list the survivors that read `sparse_field`
+  Mesh m;
+  fill_mesh(c, m);
+  const int nd = c->nd;
+  struct Sub { std::vector<MaskJob> jobs; std::vector<Fields> steps; };
+  std::vector<Sub> subs(1);
+  const bool two_level = ftkx::masks_have_summary(m);
+  std::vector<TileParams> tiles;
+  for (const Request &r : c->pending) {
+    Slice &s0 = c->slices[r.t];
+    Slice *s1 = (r.scope & FTKX_SCOPE_INTERVAL) ? &c->slices[r.t + 1] : nullptr;
+    Fields f;
+    memset(&f, 0, sizeof(f));
+    f.S[0] = s0.S; f.V[0] = s0.V; f.J[0] = s0.J;
+    if (s1) { f.S[1] = s1->S; f.V[1] = s1->V; f.J[1] = s1->J; }
+    f.factor = (double)r.factor; f.t = r.t; f.scope_mask = r.scope;
+    if (r.mode == MODE_FAST) {
+      for (Slice *s : {&s0, s1}) {
+        if (!s) continue;
+        if (masks_valid(c, *s, r.factor, two_level, m.u_rows)) continue;     // e.g. built by ftkx_slices_prepare, or by an earlier step
+        if (s->sparse) return fail(c, FTKX_E_NOSLICE, "sweep: the masks of halo slice (masks only) do not serve factor %llu: send the slice itself", r.factor);
+        int rc = ensure_mask_arrays(c, *s, two_level);
+        if (rc) return rc;
+        // masks of this slice already (re)built or used in the current sub-batch under another factor -> close it
+        bool touched = false;
+        for (const MaskJob &j : subs.back().jobs) touched = touched || j.M == s->M;
+        for (const Fields &g : subs.back().steps) touched = touched || g.M[0] == s->M || g.M[1] == s->M;
+        if (touched) subs.emplace_back();
+        bool rule_on;
+        const double big = job_big(c, *s, r.factor, &rule_on);
+        subs.back().jobs.push_back(MaskJob{s->S, s->V, s->M, two_level ? s->U : nullptr, nullptr, 1.0 / (double)r.factor, big});
+        s->mask_factor = r.factor; s->mask_big = rule_on; s->u_rows = m.u_rows;
+      }
+      f.M[0] = s0.M; f.M[1] = s1 ? s1->M : nullptr;
+      f.U[0] = two_level ? s0.U : nullptr; f.U[1] = (two_level && s1) ? s1->U : nullptr;
+      subs.back().steps.push_back(f);
+    } else {
+      TileParams p;
+      p.m = m; p.f = f; p.cull = r.mode == MODE_TILE_CULL ? 1 : 0; p.step = 0;
+      int tile[3];
+      ftkx::tile_dims(nd, tile);
+      for (int d = 0; d < 3; d ++) p.ntiles[d] = d < nd ? (int)((c->core_sz[d] + tile[d] - 1) / tile[d]) : 1;
+      tiles.push_back(p);
+    }
+  }
+  // one upload for all descriptors: the mask jobs of each sub-batch, then ONE array of Fields for the whole batch -- the steps of
+  // sub-batch 0, 1, ... back to back (each cull / exact launch gets its slice of it) and the tile requests behind them; the
+  // record kernel looks a simplex's request up in that array by the index its pass descriptor carries
+  size_t total = 0;
+  std::vector<size_t> job_off, step_base;
+  for (const Sub &sb : subs) { job_off.push_back(total); total += (sb.jobs.size() * sizeof(MaskJob) + 255) / 256 * 256; }
+  const size_t fields_off = total;
+  size_t nfields = 0;
+  for (const Sub &sb : subs) { step_base.push_back(nfields); nfields += sb.steps.size(); }
+  const size_t tile_base = nfields;
+  nfields += tiles.size();
+  total += (nfields * sizeof(Fields) + 255) / 256 * 256;
+  if ((nfields >> (64 - ftkx::kPassStepShift)) != 0) return fail(c, FTKX_E_INVALID, "sweep: too many requests in one batch (%zu)", nfields);
+  if (total) {
+    int rc = ensure_desc(c, total);
+    if (rc) return rc;
+    Fields *hf = (Fields *)((char *)c->h_desc + fields_off);
+    for (size_t i = 0; i < subs.size(); i ++) {
+      if (!subs[i].jobs.empty()) memcpy((char *)c->h_desc + job_off[i], subs[i].jobs.data(), subs[i].jobs.size() * sizeof(MaskJob));
+      if (!subs[i].steps.empty()) memcpy(hf + step_base[i], subs[i].steps.data(), subs[i].steps.size() * sizeof(Fields));
+    }
+    for (size_t i = 0; i < tiles.size(); i ++) { hf[tile_base + i] = tiles[i].f; tiles[i].step = (int)(tile_base + i); }
+    HIP_TRY(c, hipMemcpyAsync(c->d_desc, c->h_desc, total, hipMemcpyHostToDevice, c->stream));
+  }
+  const Fields *d_fields = (const Fields *)((char *)c->d_desc + fields_off);
+  if (cull_only && (subs.size() > 1 || !tiles.empty()))
+    return fail(c, FTKX_E_UNSUPPORTED, "ftkx_sweep_cull: the batch needs masks under two factors or the tile path (send the slice itself)");
+  for (size_t i = 0; i < subs.size(); i ++) {
+    const Sub &sb = subs[i];
+    if (sb.steps.empty()) continue;
+    const MaskJob *d_jobs = (const MaskJob *)((char *)c->d_desc + job_off[i]);
+    const Fields *d_steps = d_fields + step_base[i];
+    if (!sb.jobs.empty()) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs, (int)sb.jobs.size(), c->stream); ev_end(c); }
+    // the survivor list is shared by the sub-batches of one collect: the exact kernel of sub-batch i must not re-test the
+    // survivors of sub-batch i-1, so each sub-batch gets its own list segment by resetting the list counter in between
+    if (i > 0) {
+      HIP_TRY(c, hipMemsetAsync(c->d_counters + ftkx::CNT_SURVIVOR_LIST, 0, sizeof(u64), c->stream));
+      HIP_TRY(c, hipMemsetAsync(c->d_counters + ftkx::CNT_REFINE_LIST, 0, sizeof(u64), c->stream));
+    }
+    if (cull_done) {    // the survivor list of exactly these steps is on the device already (cull-ahead, see ftkx_ctx::ahead)
+      if (subs.size() != 1 || !sb.jobs.empty()) return fail(c, FTKX_E_DEVICE, "internal: cull-ahead taken over by a batch that rebuilds masks");
+    } else {
+      ev_begin(c, K_CULL);
+      if (two_level) ftkx::launch_cull_two_level(m, d_steps, (int)sb.steps.size(), c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
+      else ftkx::launch_cull(m, d_steps, (int)sb.steps.size(), c->d_list, c->list_capacity, c->stream);
+      ev_end(c);
+    }
+    if (cull_only) {
+      // (the exact kernel is what publishes the list peak; without it the host reads the list counter itself)
+      ftkx::launch_sparse_cells(m, d_steps, c->d_list, c->list_capacity, sparse_field, c->d_cells, c->cells_cap, c->stream);
+      continue;
+    }
+    ev_begin(c, K_EXACT); ftkx::launch_exact(m, d_steps, (int)step_base[i], c->d_list, c->list_capacity, c->stream); ev_end(c);
+  }
+  if (cull_only) { HIP_TRY(c, hipGetLastError()); return FTKX_OK; }
+  for (const TileParams &p : tiles) { ev_begin(c, K_TILE); ftkx::launch_tile(p, c->stream); ev_end(c); }
+  // the FP64 half, once for the whole batch: records of every simplex that passed (timed with the kernel family that fed it)
+  if (nfields) { ev_begin(c, tiles.empty() ? K_EXACT : K_TILE); ftkx::launch_records(m, d_fields, c->stream); ev_end(c); }
+  HIP_TRY(c, hipGetLastError());
+  return FTKX_OK;
+}
+
+// may ftkx_sweep_collect take the cull-ahead's survivor list over?
+bool ahead_serves_pending(const ftkx_ctx *c, const Mesh &m, bool two_level)
+{
+  if (c->ahead.empty() || c->ahead.size() != c->pending.size()) return false;
+  for (size_t i = 0; i < c->pending.size(); i ++) {
+    const Request &r = c->pending[i];
+    const ftkx_ctx::AheadStep &a = c->ahead[i];
+    if (r.t != a.t || r.scope != a.scope || r.mode != MODE_FAST) return false;
+    auto s0 = c->slices.find(r.t);
+    if (s0 == c->slices.end() || s0->second.M != a.M[0] || (two_level ? s0->second.U : nullptr) != a.U[0] || !masks_valid(c, s0->second, r.factor, two_level, m.u_rows)) return false;
+    if (r.scope & FTKX_SCOPE_INTERVAL) {
+      auto s1 = c->slices.find(r.t + 1);
+      if (s1 == c->slices.end() || s1->second.M != a.M[1] || (two_level ? s1->second.U : nullptr) != a.U[1] || !masks_valid(c, s1->second, r.factor, two_level, m.u_rows)) return false;
+    }
+  }
+  return true;
+}
+
+}  // namespace ftkxh
+
+extern "C" {
+
+int ftkx_sweep_enqueue(ftkx_ctx *c, int t, int scope, unsigned long long factor)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "sweep: call ftkx_set_mesh first");
+  if (scope < FTKX_SCOPE_ORDINAL || scope > FTKX_SCOPE_BOTH) return fail(c, FTKX_E_INVALID, "sweep: bad scope %d", scope);
+  if (scope == FTKX_SCOPE_BOTH && c->opt.tag_mode == FTKX_TAG_WORK_INDEX)
+    return fail(c, FTKX_E_INVALID, "sweep: FTKX_SCOPE_BOTH needs an element tag (work indices of the two scopes collide)");
+  if (factor == 0) return fail(c, FTKX_E_INVALID, "sweep: factor must be non-zero");
+  auto it0 = c->slices.find(t);
+  if (it0 == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "sweep: slice %d not resident", t);
+  Slice *s0 = &it0->second, *s1 = nullptr;
+  if (scope & FTKX_SCOPE_INTERVAL) {
+    auto it1 = c->slices.find(t + 1);
+    if (it1 == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "sweep: interval [%d, %d] needs slice %d", t, t + 1, t + 1);
+    s1 = &it1->second;
+  }
+  if (s1 && ((s0->J == nullptr) != (s1->J == nullptr) || (s0->S == nullptr) != (s1->S == nullptr)))
+    return fail(c, FTKX_E_INVALID, "sweep: slices %d and %d disagree on which of J / S are given", t, t + 1);
+  // coordinate arrays are indexed by vertex coordinates: they must cover the vertex box
+  if (c->opt.coords_mode == 2)
+    for (int d = 0; d < c->nd; d ++)
+      if (c->dom_st[d] < 0 || (size_t)(c->dom_st[d] + c->dom_sz[d]) > c->rect_n[d])
+        return fail(c, FTKX_E_INVALID, "sweep: rectilinear coordinates of axis %d have %zu entries, vertices reach %lld", d, c->rect_n[d], c->dom_st[d] + c->dom_sz[d] - 1);
+  if (c->opt.coords_mode == 3 && (c->dom_st[0] < 0 || c->dom_st[1] < 0 || (size_t)(c->dom_st[0] + c->dom_sz[0]) > c->expl_n0 || (size_t)(c->dom_st[1] + c->dom_sz[1]) > c->expl_n1))
+    return fail(c, FTKX_E_INVALID, "sweep: explicit coordinates are %zu x %zu, the vertex box needs %lld x %lld", c->expl_n0, c->expl_n1, c->dom_st[0] + c->dom_sz[0], c->dom_st[1] + c->dom_sz[1]);
+  for (int d = 0; d < c->nd; d ++)
+    if (c->core_sz[d] == 0) return FTKX_OK;    // empty core: nothing to enumerate
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int nd = c->nd;
+
+  // Is the strict-sign cull usable?  Only with the robust integer test (the FP64 test of the non-robust 3D mode has no such
+  // property) and a power-of-two factor: the masks test v >= 1/factor on doubles, which equals trunc(v * factor) >= 1 only then
+  // (the tracker always passes 1 << nbits); any other factor a direct caller hands over takes the tile path, which quantises like
+  // the reference.  Determinants that could leave int64 are dealt with per vertex (MaskJob::big), not per request.
+  const bool fast = !c->opt.exact_only && pow2_factor(factor) && (nd == 2 || c->opt.robust);
+  if ((s0->sparse || (s1 && s1->sparse)) && (!fast || c->dense_collects > 0))
+    return fail(c, FTKX_E_UNSUPPORTED, "sweep: a masked halo slice only serves sweeps that use the cull (send the slice itself)");
+  if (c->pending.empty()) memset(&c->stats, 0, sizeof(c->stats));
+  c->pending.push_back(Request{t, scope, factor, fast ? (c->dense_collects > 0 ? MODE_TILE_CULL : MODE_FAST) : MODE_TILE});
+
+  u64 cells = 1;
+  for (int d = 0; d < nd; d ++) cells *= (u64)c->core_sz[d];
+  const u64 n_ord = nd == 2 ? 2 : 6, n_int = nd == 2 ? 10 : 54;
+  c->stats.cells += cells;
+  c->stats.work_items += cells * (((scope & 1) ? n_ord : 0) + ((scope & 2) ? n_int : 0));
+  c->stats.cull_enabled = fast ? 1 : 0;
+  return FTKX_OK;
+}
+
+int ftkx_sweep_collect(ftkx_ctx *c, const ftkx_cp_t **out, size_t *n_out)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (out) *out = nullptr;
+  if (n_out) *n_out = 0;
+  if (c->pending.empty()) return FTKX_OK;
+  int rc;
+  if ((rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16)))) { c->pending.clear(); return rc; }
+  if (c->nd == 3 && (rc = ensure_fragile(c, std::max<u64>(c->fragile_capacity, 1u << 12)))) { c->pending.clear(); return rc; }
+  bool any_fast = false;
+  u64 fast_cells = 0;
+  {
+    u64 cells = 1;
+    for (int d = 0; d < c->nd; d ++) cells *= (u64)c->core_sz[d];
+    for (const Request &r : c->pending) if (r.mode == MODE_FAST) { any_fast = true; fast_cells += cells; }
+  }
+  if (c->dense_collects > 0) c->dense_collects --;          // the fast path is probed again after a while
+  if (any_fast && (rc = ensure_list(c, std::max<u64>(c->list_capacity, 1u << 20)))) { c->pending.clear(); return rc; }
+  if (any_fast && (rc = ensure_refine(c, std::max<u64>(c->refine_capacity, 1u << 20)))) { c->pending.clear(); return rc; }
+  // upper bound of the tags this batch can emit -> number of key bits for the device sort
+  int key_bits = 64;
+  if (c->opt.tag_mode != FTKX_TAG_REFERENCE) {            // REFERENCE tags go through int32 products and may wrap to anything
+    int t_max = 0;
+    for (const Request &r : c->pending) t_max = std::max(t_max, r.t);
+    long double bound = c->nd == 2 ? 12.0L : 60.0L;
+    const bool work_index = c->opt.tag_mode == FTKX_TAG_WORK_INDEX;
+    for (int d = 0; d < c->nd; d ++) bound *= (long double)(work_index ? c->core_sz[d] : c->dom_sz[d]);
+    if (!work_index) bound *= (long double)(t_max + 2);
+    int b = 1;
+    while (b < 64 && ldexpl(1.0L, b) <= bound) b ++;
+    key_bits = b;
+  }
+  bool use_ahead = false;
+  if (!c->ahead.empty()) {
+    Mesh m; fill_mesh(c, m);
+    use_ahead = ahead_serves_pending(c, m, ftkx::masks_have_summary(m));
+    c->ahead.clear();                                        // one use; and a replay below culls afresh
+  }
+  for (int attempt = 0; ; attempt ++) {
+    // (cull-ahead: the counters were zeroed before that cull and hold its list counts)
+    if (!use_ahead) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, ftkx::CNT_N * sizeof(u64), c->stream));
+    if ((rc = run_batch(c, nullptr, use_ahead))) { c->pending.clear(); return rc; }
+    use_ahead = false;
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, ftkx::CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->ahead_staged = false;
+    // (records <= simplices that passed: the 2D type filter may drop some; the pass list shares the hit buffer's capacity)
+    const u64 hits = std::max(c->h_counters[ftkx::CNT_HITS], c->h_counters[ftkx::CNT_PASS]);
+    const u64 listed = c->h_counters[ftkx::CNT_LIST_PEAK], refined = c->h_counters[ftkx::CNT_REFINE_PEAK];
+    const u64 fragile = c->h_counters[ftkx::CNT_FRAGILE];
+    if (hits <= c->capacity && listed <= c->list_capacity && refined <= c->refine_capacity && fragile <= c->fragile_capacity) { ev_harvest(c); break; }
+    // a buffer was too small (records / survivors beyond capacity were only counted): grow to what this batch needs, replay it
+    for (auto &e : c->events) { ev_give(c, e.second.first); ev_give(c, e.second.second); }
+    c->events.clear();
+    if (attempt == 4) { c->pending.clear(); return fail(c, FTKX_E_DEVICE, "buffer overflow persisted after regrowing four times"); }
+    // Most cells survive the cull (data whose quantised magnitudes can overflow the determinants almost everywhere):
+    // a survivor list would be as large as the input.  Such a batch goes through the tile kernel instead, which stages each
+    // tile's vertices once and applies the same cull rule in LDS.
+    if (any_fast && (listed > c->list_capacity || refined > c->refine_capacity) && (listed > fast_cells / 8 || refined * 8 > fast_cells / 8)) {
+      for (const Request &r : c->pending) {
+        auto a = c->slices.find(r.t), b = c->slices.find(r.t + 1);
+        if ((a != c->slices.end() && a->second.sparse) || ((r.scope & FTKX_SCOPE_INTERVAL) && b != c->slices.end() && b->second.sparse)) {
+          c->pending.clear();
+          return fail(c, FTKX_E_UNSUPPORTED, "sweep: most cells survive the cull and a masked halo slice is involved (send the slice itself)");
+        }
+      }
+      for (Request &r : c->pending) if (r.mode == MODE_FAST) r.mode = MODE_TILE_CULL;
+      any_fast = false;
+      c->dense_collects = 16;
+      if (hits > c->capacity && (rc = ensure_hit_buffer(c, 2 * hits + 1024))) { c->pending.clear(); return rc; }
+      continue;
+    }
+    if (fragile > c->fragile_capacity && (rc = ensure_fragile(c, fragile + fragile / 8 + 1024))) { c->pending.clear(); return rc; }
+    if (refined > c->refine_capacity && (rc = ensure_refine(c, refined + refined / 8 + 1024))) { c->pending.clear(); return rc; }
+    if (listed > c->list_capacity && (rc = ensure_list(c, listed + listed / 8 + 1024))) { c->pending.clear(); return rc; }
+    // with a truncated survivor list the hit count is a lower bound: leave generous room
+    const u64 want_hits = std::max<u64>(hits + hits / 8 + 1024, (listed > c->list_capacity || refined > c->refine_capacity) ? 2 * hits + 1024 : 0);
+    if (want_hits > c->capacity && (rc = ensure_hit_buffer(c, want_hits))) { c->pending.clear(); return rc; }
+  }
+  c->pending.clear();
+  const size_t n = (size_t)c->h_counters[ftkx::CNT_HITS];
+  c->stats.hits = n;
+  c->stats.cells_survived = c->h_counters[ftkx::CNT_CELLS_SURVIVED];
+  c->stats.simplices_tested = c->h_counters[ftkx::CNT_SIMPLICES_TESTED];
+  if ((rc = ensure_host_buffer(c, n))) return rc;
+  // 3D records whose class hangs on the last bits of pow / acos / cos (an eigenvalue of the Hessian that is zero up to rounding):
+  // classified again here, with the libm the reference itself runs on, and written back before the records are sorted.  Rare -- an
+  // exactly singular Hessian takes plateaus or lattice-aligned data -- and then one small round trip.
+  if (const u64 nf = c->h_counters[ftkx::CNT_FRAGILE]) {
+    std::vector<u64> frag((size_t)nf * 10), pairs((size_t)nf * 2);
+    HIP_TRY(c, hipMemcpyAsync(frag.data(), c->d_fragile, frag.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < (size_t)nf; i ++) {
+      double A[3][3];
+      memcpy(A, &frag[i * 10 + 1], sizeof(A));
+      pairs[2 * i] = frag[i * 10];
+      pairs[2 * i + 1] = (u64)ftkx::classify3(A, c->opt.jacobian_symmetric != 0);
+    }
+    if ((rc = ensure_desc(c, pairs.size() * sizeof(u64)))) return rc;
+    memcpy(c->h_desc, pairs.data(), pairs.size() * sizeof(u64));
+    HIP_TRY(c, hipMemcpyAsync(c->d_desc, c->h_desc, pairs.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(patch_types_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, c->stream, c->d_hits, (const u64 *)c->d_desc, (size_t)nf);
+    HIP_TRY(c, hipGetLastError());
+    c->stats.reclassified = nf;
+  }
+  if (n >= 4096 && n < (1ull << 31)) {
+    if ((rc = sort_hits_on_device(c, n, key_bits))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_hits, c->d_sorted, n * sizeof(ftkx_cp_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  } else if (n) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_hits, c->d_hits, n * sizeof(ftkx_cp_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::sort(c->h_hits, c->h_hits + n, [](const ftkx_cp_t &a, const ftkx_cp_t &b) { return a.tag < b.tag; });
+  }
+  if (out) *out = c->h_hits;
+  if (n_out) *n_out = n;
+  return FTKX_OK;
+}
+
+int ftkx_sweep_enqueue_many(ftkx_ctx *c, const int *ts, const int *scopes, const unsigned long long *factors, int n)
+{
+  if (!c || (n > 0 && (!ts || !scopes || !factors))) return fail(c, FTKX_E_INVALID, "null argument");
+  for (int i = 0; i < n; i ++) { const int rc = ftkx_sweep_enqueue(c, ts[i], scopes[i], factors[i]); if (rc) { c->pending.clear(); return rc; } }
+  return FTKX_OK;
+}
+
+int ftkx_sweep_cancel(ftkx_ctx *c)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  c->pending.clear();
+  return FTKX_OK;
+}
+
+int ftkx_sweep(ftkx_ctx *c, int t, int scope, unsigned long long factor, const ftkx_cp_t **out, size_t *n_out)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_sweep: asynchronous sweeps pending, collect first");
+  int rc = ftkx_sweep_enqueue(c, t, scope, factor);
+  if (rc) return rc;
+  return ftkx_sweep_collect(c, out, n_out);
+}
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+// Shared between the translation units of libftkx.so that implement the C ABI of include/ftkx.h (ftkx_api.hip: context, slices,
+// options, one-shot calls; prepare.hip: the one-pass mask + reduction pre-pass; collect.hip: the batched sweep; halo.hip: the compact
+// t-slab halo; series.hip: the device-driven pass over a resident series).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "sweep_params.hpp"
+#include "internal.hpp"
+
+namespace ftkx {
+void launch_tile(const TileParams &p, hipStream_t stream);
+void tile_dims(int nd, int tile[3]);
+void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream);
+void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream);
+void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64 *d_list, u64 cap, hipStream_t stream);
+void launch_records(const Mesh &m, const Fields *d_fields, hipStream_t stream);
+void launch_compact_words(const Mesh &m, const unsigned char *U, const unsigned char *M, unsigned *idx, u64 *words, u64 capacity, u64 *counter, hipStream_t st);
+void launch_scatter_words(const unsigned *idx, const u64 *words, size_t n, unsigned char *M, hipStream_t st);
+void launch_sparse_cells(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, const double *sparse, u64 *cells, u64 cells_cap, hipStream_t st);
+void launch_patches(const Mesh &m, bool scatter, const u64 *cells, size_t n, int ncomp, double *field, double *patches, hipStream_t st);
+bool masks_have_summary(const Mesh &m);
+int mask_summary_rows(const Mesh &m);
+bool march2_supported(const Mesh &m);
+bool masks_fuse_reduction(const Mesh &m);
+void launch_reduce_march(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream);
+void launch_cull_two_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream);
+void launch_resolution_scalar(const Mesh &m, const double *S, u64 *out2, hipStream_t stream);
+void launch_gradient2d(const double *S, int DW, int DH, double *V, hipStream_t st);
+void launch_jacobian2d(const double *V, int DW, int DH, int symmetric, double *J, hipStream_t st);
+void launch_gradient3d(const double *S, int DW, int DH, int DD, double *V, hipStream_t st);
+void launch_jacobian3d(const double *V, int DW, int DH, int DD, double *J, hipStream_t st);
+void launch_resolution(const double *p, size_t n, u64 *out2, hipStream_t st);
+void launch_calib_read(const void *p, size_t bytes, double *scratch, hipStream_t stream);
+const char *last_mask_kernel();
+}  // namespace ftkx
+
+using ftkx::Fields;
+using ftkx::MaskJob;
+using ftkx::Mesh;
+using ftkx::TileParams;
+using ftkx::u64;
+
+namespace ftkxh {
+
+struct Slice {
+  double *V = nullptr, *J = nullptr, *S = nullptr;
+  unsigned char *M = nullptr;       // vertex sign masks, built lazily for `mask_factor`
+  unsigned char *U = nullptr;       // per-8-vertex summaries of M (two-level cull)
+  bool ownV = false, ownJ = false, ownS = false;
+  unsigned long long mask_factor = 0;   // the (power-of-two) factor M / U were built under; 0 = not built
+  int u_rows = 1;                   // rows a byte of U stands for (Mesh::u_rows at the time the masks were built)
+  bool mask_big = false;            // built with the per-vertex overflow rule of that factor (MaskJob::big finite)
+  bool have_res = false;            // res = ndarray::resolution() of the slice's vector field (exact pre-pass), maxabs with it
+  double res = 0, maxabs = 0;
+  bool have_fused = false;          // reduction fused into the mask pass (ftkx_slices_prepare): maxabs, and
+  double res_below = 0;             //   the smallest non-zero |v| below 1 / fused_factor (DBL_MAX if none)
+  unsigned long long fused_factor = 0;
+  bool sparse = false;              // a halo slice that exists as masks only: its field array holds just the patches scattered into it
+  bool max_known() const { return have_res || have_fused || sparse; }
+};
+
+// how a request is swept: MODE_TILE tests every simplex (exact_only, non-robust 3D, odd factors); MODE_FAST = masks -> cull ->
+// survivor list -> exact kernel; MODE_TILE_CULL = the tile kernel with its in-tile cull (same per-vertex legality rule), for
+// data on which most cells survive the cull anyway (the int64-overflow regime: a survivor list would be as large as the input)
+enum { MODE_TILE = 0, MODE_FAST = 1, MODE_TILE_CULL = 2 };
+struct Request { int t, scope; unsigned long long factor; int mode; };
+
+enum { K_MASK = 0, K_CULL = 1, K_EXACT = 2, K_TILE = 3, K_N = 4 };
+
+
+}  // namespace ftkxh
+
+struct ftkx_ctx {
+  int nd = 0, device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  ftkx_options opt;
+  long long dom_st[3] = {0, 0, 0}, dom_sz[3] = {1, 1, 1}, core_st[3] = {0, 0, 0}, core_sz[3] = {1, 1, 1}, ext_st[3] = {0, 0, 0}, ext_sz[3] = {1, 1, 1};
+  bool mesh_set = false;
+  int scalar_mode = -1;             // -1 undecided, 0 vector slices, 1 scalar slices (V = gradient(S) evaluated in flight)
+  std::map<int, ftkxh::Slice> slices;
+  ftkx_cp_t *d_hits = nullptr;
+  u64 *d_pass = nullptr;            // simplices that passed the integer test, awaiting the record kernel (same capacity)
+  u64 *d_fragile = nullptr;         // 3D records to be re-classified on the host (slot, J[9]): cp_device.hpp, classify3
+  u64 fragile_capacity = 0;
+  u64 capacity = 0;
+  u64 *d_list = nullptr;            // surviving corners of the fast path
+  u64 list_capacity = 0;
+  u64 *d_refine = nullptr;          // words the summary level could not rule out (two-level cull)
+  u64 refine_capacity = 0;
+  u64 *d_counters = nullptr;        // CNT_N counters + 128 words (64 {min, max} slots) for the resolution reduction
+  u64 *h_counters = nullptr;        // pinned
+  ftkx_cp_t *h_hits = nullptr;      // pinned
+  size_t h_cap = 0;
+  // device-side ordering of the hit records by tag (radix sort of (tag, index) pairs + one gather)
+  ftkx_cp_t *d_sorted = nullptr;
+  u64 *d_keys = nullptr;            // 2 * sort_cap
+  unsigned *d_idx = nullptr;        // 2 * sort_cap
+  void *d_sort_tmp = nullptr;
+  size_t sort_cap = 0, sort_tmp_bytes = 0;
+  // per-batch descriptors: pinned staging + device copies
+  void *h_desc = nullptr, *d_desc = nullptr;
+  size_t desc_cap = 0;
+  // mask / summary arrays of dropped slices, kept for the next slice (a streaming tracker pushes and pops one slice per step:
+  // hipMalloc + hipFree per step cost more than the sweep itself).  Their padding bytes stay valid: kernels never write them.
+  std::vector<unsigned char *> pool_M, pool_U;
+  std::vector<std::pair<double *, size_t>> pool_F;   // owned field arrays (S / V / J copies) of dropped slices, by size in doubles
+  u64 *d_red = nullptr;             // {min, max} slots of a batched resolution reduction: 128 words per slice
+  size_t red_cap = 0;
+  // physical coordinates (REGULAR_COORDS_RECTILINEAR / _EXPLICIT): device copies
+  double *d_rect[3] = {nullptr, nullptr, nullptr};
+  size_t rect_n[3] = {0, 0, 0};
+  double *d_expl = nullptr;
+  int expl_ncomp = 0;
+  size_t expl_n0 = 0, expl_n1 = 0;
+  std::vector<ftkxh::Request> pending;
+  // Cull-ahead: the sweeps the caller announced (ftkx_sweep_announce) for the slices of the next ftkx_slices_prepare, and -- once that
+  // call has queued their cull right behind the mask kernel -- the survivor list it left on the device.  The cull needs the masks
+  // and the list of steps, not the factor: it runs while the host still waits for the reduction, forms the factors and queues the
+  // sweeps.  ftkx_sweep_collect takes the list over if the pending sweeps are exactly the announced ones and every mask serves its
+  // factor; anything else (and any call that touches slices or masks in between) drops it.
+  std::vector<std::pair<int, int>> announced;
+  struct AheadStep { int t, scope; const unsigned char *M[2], *U[2]; };
+  std::vector<AheadStep> ahead;     // non-empty: survivor list + counters on the device belong to these steps
+  void *h_ahead = nullptr, *d_ahead = nullptr;   // the cull-ahead's own descriptors: pinned staging (read by fetch_desc_kernel) + device copy
+  size_t ahead_cap = 0;
+  bool ahead_staged = false;        // a fetch out of h_ahead may still be queued (cleared by every full stream synchronise of collect)
+  u64 *h_red = nullptr;             // coherent pinned copy of the reduction slots + one flag word, written by readback_kernel
+  size_t h_red_cap = 0;             //   (slots it can hold; the flag lives behind them)
+  unsigned red_seq = 0;
+  int dense_collects = 0;           // > 0: the last fast collect found most cells surviving; fast requests run MODE_TILE_CULL for a while
+  // compact halo: the compacted mask words of the last ftkx_export_masks_size, the surviving cells of the last ftkx_sweep_cull
+  unsigned *d_word_idx = nullptr; u64 *d_words = nullptr; size_t words_cap = 0, n_words = 0; int words_t = -1;
+  u64 *d_cells = nullptr; size_t cells_cap = 0, n_cells = 0;
+  u64 *d_patch_cells = nullptr; double *d_patches = nullptr; size_t patch_cap = 0;   // staging for host-side callers
+  ftkx_stats stats;
+  // optional kernel timing (hipEvents on the context's stream)
+  int profiling = 0;
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> events;
+  std::vector<hipEvent_t> event_pool;
+  double k_ms[ftkxh::K_N] = {0, 0, 0, 0};
+  unsigned long long k_launches[ftkxh::K_N] = {0, 0, 0, 0};
+  std::string err;
+};
+
+namespace ftkx {
+// waits for a sequence number a kernel stores, with system scope, into coherent pinned memory (ftkx_api.hip); nullptr or what went wrong
+const char *wait_flag(const unsigned *flag, unsigned seq, hipStream_t stream);
+}
+
+namespace ftkxh {
+
+int fail(ftkx_ctx *c, int code, const char *fmt, ...);
+
+#define HIP_TRY(c, call)                                                                                   \
+  do {                                                                                                     \
+    hipError_t e_ = (call);                                                                                \
+    if (e_ != hipSuccess) return fail((c), e_ == hipErrorOutOfMemory ? FTKX_E_NOMEM : FTKX_E_DEVICE,       \
+                                      "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// ftkx_api.hip
+size_t n_vertices(const ftkx_ctx *c);
+int mask_pitch(const ftkx_ctx *c);
+int u_pitch(const ftkx_ctx *c);
+size_t u_bytes(const ftkx_ctx *c);
+size_t u_bytes_used(const ftkx_ctx *c, const Mesh &m);
+size_t mask_bytes(const ftkx_ctx *c);
+void free_slice(Slice &s, ftkx_ctx *pool_owner = nullptr);
+void release_pools(ftkx_ctx *c);
+int ensure_hit_buffer(ftkx_ctx *c, u64 want);
+int ensure_fragile(ftkx_ctx *c, u64 want);
+int ensure_list(ftkx_ctx *c, u64 want);
+int ensure_refine(ftkx_ctx *c, u64 want);
+int ensure_desc(ftkx_ctx *c, size_t bytes);
+int ensure_host_buffer(ftkx_ctx *c, size_t want);
+void fill_mesh(const ftkx_ctx *c, Mesh &m);
+int slice_resolution(ftkx_ctx *c, Slice &s);
+bool overflow_free(int nd, double maxabs, u64 factor);
+double big_threshold(int nd, u64 factor);
+bool pow2_factor(u64 factor);
+bool masks_valid(const ftkx_ctx *c, const Slice &s, u64 factor, bool two_level, int u_rows);
+double job_big(const ftkx_ctx *c, const Slice &s, u64 factor, bool *rule_on);
+int ensure_mask_arrays(ftkx_ctx *c, Slice &s, bool two_level);
+// prepare.hip
+void launch_init_red(u64 *red, size_t nslots, u64 *counters, hipStream_t st);        // {min = DBL_MAX, max = 0} slots; counters (nullable) zeroed
+void launch_fetch_desc(const void *pinned_src, void *device_dst, size_t bytes, hipStream_t st);   // pinned -> device by a kernel (bytes % 8 == 0)
+// collect.hip
+hipEvent_t ev_take(ftkx_ctx *c);
+void ev_give(ftkx_ctx *c, hipEvent_t e);
+void ev_begin(ftkx_ctx *c, int kind);
+void ev_end(ftkx_ctx *c);
+void ev_harvest(ftkx_ctx *c, bool all = true);   // all: after a stream synchronise; otherwise only the pairs that have completed
+int run_batch(ftkx_ctx *c, const double *sparse_field = nullptr, bool cull_done = false);
+bool ahead_serves_pending(const ftkx_ctx *c, const Mesh &m, bool two_level);
+int sort_hits_on_device(ftkx_ctx *c, size_t n, int key_bits);
+int finish_records(ftkx_ctx *c, size_t n, int key_bits);
+
+}  // namespace ftkxh

@@ -63,11 +63,19 @@ struct critical_point_tracker_regular::multi_engine {
         f = std::move(W->q.front()); W->q.pop_front(); W->busy = true;
       }
       try { f(); }
-      catch (const ftkx_error &e) { std::lock_guard<std::mutex> g(emu); if (!error_code) { error_code = e.code; error = e.what(); } bcv.notify_all(); }
-      catch (const std::exception &e) { std::lock_guard<std::mutex> g(emu); if (!error_code) { error_code = FTKX_E_INVALID; error = e.what(); } bcv.notify_all(); }
+      catch (const ftkx_error &e) { raise(e.code, e.what()); }
+      catch (const std::exception &e) { raise(FTKX_E_INVALID, e.what()); }
       { std::lock_guard<std::mutex> lk(W->mu); W->busy = false; }
       W->cv.notify_all();
     }
+  }
+  // A failing job wakes every step that waits on the board.  The error is set under emu, the notify goes out under bmu: a waiter that
+  // has evaluated its predicate (failed() == false) and not yet blocked holds bmu, so the notify cannot fall into that gap.
+  void raise(int code, const char *what)
+  {
+    { std::lock_guard<std::mutex> g(emu); if (!error_code) { error_code = code; error = what; } }
+    { std::lock_guard<std::mutex> g(bmu); }
+    bcv.notify_all();
   }
   void post(int d, std::function<void()> f)
   {
