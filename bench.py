@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--timesteps", type=int, default=0, help="override the length of the series")
     ap.add_argument("--no-cull-ahead", action="store_true", help="experiment: do not announce the sweeps to slices_prepare (the cull then waits for the factors)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the kernels (what do they cost a pass?); the line then carries no roofline")
+    ap.add_argument("--host-driven", action="store_true", help="N = 1: the host-driven batch (slices_prepare, factors on the host, enqueue, collect) instead of the device-driven ftkx_sweep_series")
     ap.add_argument("--dump-merged", default=None, help="rank 0 writes the merged records and the curves traced from them (npz)")
     args = ap.parse_args()
 
@@ -223,8 +224,20 @@ def main():
         halo_info = {"in_timed_region": bool(args.halo_in_loop), "ms": halo_ms, "bytes_per_rank": hbytes,
                      "GB/s_per_link": hbytes / (halo_ms * 1e-3) / 1e9 if halo_ms > 0 else None}
 
+    series_paths = {}
+
     def one_pass():
         ctx.invalidate_masks()      # every pass redoes ALL the work of the sweep: masks, reduction, factors, cull, exact test, download
+        if world == 1 and not args.host_driven:
+            # one GPU: the device-driven pass -- masks + reduction, factors (on the device), cull, exact test, records, their order and
+            # their way into the pinned host buffer queued at once; the host waits once (ftkx_sweep_series)
+            tp0 = time.perf_counter()
+            recs, f, _ = ctx.sweep_series(ann_ts, ann_scopes, copy=False)
+            host_ms[1] += (time.perf_counter() - tp0) * 1e3
+            p = ctx.series_last_path()
+            series_paths[p] = series_paths.get(p, 0) + 1
+            one_pass.factors = f
+            return recs, ctx.stats()
         if world > 1 and own and args.halo_in_loop:
             halo()
         tp0 = time.perf_counter()
@@ -376,7 +389,9 @@ def main():
             "config": {"workload": f"{case} {'x'.join(str(d) for d in dims)}x{nt} ({args.config}), "
                                    f"{'scalar' if scalar_input else 'vector'} input, t-slab partition over {world} GPU(s): {len(own)} timesteps on rank 0",
                        "simplices_per_step": total_simplices, "exact_only": bool(args.exact_only),
-                       "nbits": int(np.log2(max(factors))), "cull": bool(st["cull_enabled"]),
+                       "nbits": int(np.log2(max(int(v) for v in getattr(one_pass, "factors", factors)))), "cull": bool(st["cull_enabled"]),
+                       "pass": ("device-driven (ftkx_sweep_series): paths taken {(path, status): passes} = %s" % {str(k): v for k, v in series_paths.items()}) if series_paths
+                               else "host-driven batch (slices_prepare, host factors, enqueue, collect)",
                        "input_resident": "the field the tracker API is given (S, or V for vector input) in HBM; gradient/Jacobian evaluated in flight"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_symbol, "kernel_family": "ftkx::%s<%d>" % (domk, nd), "avg_launch_ms": avg_ms, "launches_timed": int(dom_n),

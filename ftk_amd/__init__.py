@@ -182,6 +182,26 @@ class Context:
         self._ck(self._L.ftkx_sweep_enqueue_many(self._h, (C.c_int * n)(*[int(t) for t in ts]), (C.c_int * n)(*[int(v) for v in scopes]),
                                                  (C.c_ulonglong * n)(*[int(f) for f in factors]), n))
 
+    def sweep_series(self, ts, scopes, running_resolution=None, copy=True):
+        """ftkx_sweep_series: the steps (ts[i], scopes[i]) over resident slices under the reference's sticky factor, formed on the
+        device; one host wait.  -> (records, factors (uint64 array), running resolution after these slices).
+        ts / scopes: int32 arrays (handed over as they are) or sequences."""
+        n = len(ts)
+        if not (isinstance(ts, np.ndarray) and ts.dtype == np.int32 and ts.flags.c_contiguous):
+            ts = np.ascontiguousarray(ts, dtype=np.int32)
+        if not (isinstance(scopes, np.ndarray) and scopes.dtype == np.int32 and scopes.flags.c_contiguous):
+            scopes = np.ascontiguousarray(scopes, dtype=np.int32)
+        run = C.c_double(np.finfo(np.float64).max if running_resolution is None else float(running_resolution))
+        f = np.empty((max(1, n),), dtype=np.uint64)
+        out, cnt = C.c_void_p(), C.c_size_t()
+        self._ck(self._L.ftkx_sweep_series(self._h, ts.ctypes.data, scopes.ctypes.data, n, C.byref(run), f.ctypes.data, C.byref(out), C.byref(cnt)))
+        return _lib.records_from(out.value, cnt.value, copy), f[:n], run.value
+
+    def series_last_path(self):
+        """(path, status bits) of the last sweep_series: 1 device-driven, 2 finished by the single-workgroup tail, 0 host-driven batch"""
+        st = C.c_ulonglong()
+        return int(self._L.ftkx_series_last_path(self._h, C.byref(st))), int(st.value)
+
     def sweep_cancel(self):
         self._ck(self._L.ftkx_sweep_cancel(self._h))
 

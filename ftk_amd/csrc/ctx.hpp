@@ -44,6 +44,16 @@ void launch_jacobian3d(const double *V, int DW, int DH, int DD, double *J, hipSt
 void launch_resolution(const double *p, size_t n, u64 *out2, hipStream_t st);
 void launch_calib_read(const void *p, size_t bytes, double *scratch, hipStream_t stream);
 const char *last_mask_kernel();
+void launch_cull_coarse(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, hipStream_t stream);
+void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream);
+void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st);
+void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, double safe_m,
+                           u64 *results, hipStream_t st);
+void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff, u64 *sorted, u64 *results, hipStream_t st);
+void launch_bucket_scan(unsigned *hist, unsigned *boff, unsigned nbins, u64 *counters, hipStream_t st);
+void launch_bucket_scatter(const Mesh &m, unsigned *boff, u64 *bucketed, hipStream_t st);
+void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, hipStream_t st);
+void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, hipStream_t st);
 }  // namespace ftkx
 
 using ftkx::Fields;
@@ -144,6 +154,18 @@ struct ftkx_ctx {
   unsigned *d_word_idx = nullptr; u64 *d_words = nullptr; size_t words_cap = 0, n_words = 0; int words_t = -1;
   u64 *d_cells = nullptr; size_t cells_cap = 0, n_cells = 0;
   u64 *d_patch_cells = nullptr; double *d_patches = nullptr; size_t patch_cap = 0;   // staging for host-side callers
+  // series pass (series.hip): results block (device + coherent pinned copy with the flag word behind it), ordering buffers
+  u64 *sr_results = nullptr, *sr_h_results = nullptr;
+  size_t sr_results_cap = 0, sr_h_results_cap = 0;     // words (the pinned copy also holds the fragile list; the flag lives behind it)
+  unsigned sr_seq = 0;
+  unsigned *sr_hist = nullptr, *sr_boff = nullptr;
+  size_t sr_bins_cap = 0;
+  u64 *sr_bucketed = nullptr;
+  size_t sr_bucketed_cap = 0;
+  u64 *sr_sorted = nullptr;
+  size_t sr_sorted_cap = 0;
+  int sr_last_path = 0;              // which way the last ftkx_sweep_series went: 1 device-driven, 2 early single-workgroup tail, 0 the host-driven batch
+  unsigned long long sr_last_status = 0;
   ftkx_stats stats;
   // optional kernel timing (hipEvents on the context's stream)
   int profiling = 0;

@@ -363,6 +363,8 @@ void ftkx_destroy(ftkx_ctx *c)
   if (c->d_pass) (void)hipFree(c->d_pass);
   if (c->d_fragile) (void)hipFree(c->d_fragile);
   for (void *p : {(void *)c->d_word_idx, (void *)c->d_words, (void *)c->d_cells, (void *)c->d_patch_cells, (void *)c->d_patches}) if (p) (void)hipFree(p);
+  for (void *p : {(void *)c->sr_results, (void *)c->sr_hist, (void *)c->sr_boff, (void *)c->sr_bucketed, (void *)c->sr_sorted}) if (p) (void)hipFree(p);
+  if (c->sr_h_results) (void)hipHostFree(c->sr_h_results);
   if (c->d_list) (void)hipFree(c->d_list);
   if (c->d_refine) (void)hipFree(c->d_refine);
   if (c->d_sorted) (void)hipFree(c->d_sorted);

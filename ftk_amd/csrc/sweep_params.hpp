@@ -8,7 +8,11 @@ typedef unsigned long long u64;
 typedef long long i64;
 
 enum { CNT_HITS = 0, CNT_CELLS_SURVIVED = 1, CNT_SIMPLICES_TESTED = 2, CNT_SURVIVOR_LIST = 3, CNT_LIST_PEAK = 4,
-       CNT_REFINE_LIST = 5, CNT_REFINE_PEAK = 6, CNT_WORDS_REFINED = 7, CNT_PASS = 8, CNT_SPARSE = 9, CNT_FRAGILE = 10, CNT_N = 11 };
+       CNT_REFINE_LIST = 5, CNT_REFINE_PEAK = 6, CNT_WORDS_REFINED = 7, CNT_PASS = 8, CNT_SPARSE = 9, CNT_FRAGILE = 10,
+       CNT_SERIES_DONE = 11,   // series pass: non-zero once the pass has been finished early (sparse data: one workgroup did the whole tail) --
+                               // the kernels queued behind that point leave at once
+       CNT_BUCKET_MAX = 12,    // series pass: the fullest bucket of the ordering step
+       CNT_N = 13 };
 
 // A simplex that passed the test, handed from the integer kernels (exact_kernel, tile_kernel) to record_kernel, which does all the
 // FP64 work (solve, lerp, Jacobian, classification) on densely packed lanes: corner index inside core (x fastest) | type | request.
@@ -45,7 +49,20 @@ struct Mesh {
   u64 capacity;              // records the hit buffer can hold
   u64 *fragile;              // 3D records whose class hangs on the last bits of libm (classify3): 10 words each -- slot in `hits`, J[3][3]
   u64 fragile_capacity;
+  // series pass (series.hip): the exact kernel also counts the simplices that passed per bucket of their order key
+  unsigned *hist;            // nullptr: no histogram
+  int hist_shift;            // bucket = order_key >> hist_shift
+  u64 core_cells;            // corners in core: order_key = ((step * core_cells + corner index) << 6) | type
 };
+
+// The order of the records of one series pass: by (step, corner index inside core, simplex type) -- which IS the order of the element
+// tags when the steps come in ascending time and the tags do not wrap (simplicial_regular_mesh.hh:496-502).  A pass descriptor
+// (kPass* below) rearranged into one ascending integer:
+__host__ __device__ inline u64 order_key(u64 pass_desc, u64 core_cells)
+{
+  const u64 lin = pass_desc & ((1ull << 40) - 1ull), type = (pass_desc >> 40) & 63ull, step = pass_desc >> 46;
+  return ((step * core_cells + lin) << 6) | type;
+}
 
 // the fields of one (timestep, scope) request: slice t and slice t+1
 struct Fields {
@@ -93,5 +110,29 @@ struct MaskJob {
   double threshold;          // 1 / F: q = trunc(v * F) > 0  <=>  v >= 1/F (F is a power of two)
   double big;                // safe_m / F  (+Inf: no vertex is ever big)
 };
+
+constexpr int kSeriesMaxSlices = 2048;    // slices (and steps) one series pass takes: their reductions are folded in LDS
+constexpr int kSeriesMaxBins = 1 << 16;    // buckets of the ordering step
+
+// ---- series pass: sticky factor on the device (critical_point_tracker.hh:850-864) -----------------------------------------------
+struct SeriesSlice {
+  int t;
+  int red_index;             // which 64-slot block of `red` holds this slice's fused reduction; -1: reduced earlier (known_* stand)
+  double known_res;          // smallest non-zero |v| below 1 / (the factor its masks were built under), or DBL_MAX; DBL_MAX if not known
+  double known_max;          // max |v|; 0 if not known
+};
+struct SeriesStep {
+  int slice0, slice1;        // indices of the step's slices (slice1 = -1: ordinal sweep only)
+  int last;                  // the sticky minimum of this step runs over slices 0 .. last (every slice with timestep <= t + 1)
+  int pad;
+};
+enum { SERIES_AMBIGUOUS = 1,        // 1 / resolution so close above a power of two that the last bit of the host's log2 decides nbits
+       SERIES_MASKS_INVALID = 2,    // a slice has vertices that could overflow a determinant under its step's factor: masks need the per-vertex rule
+       SERIES_INF = 4,              // a slice holds an Inf: the fused maximum is not the max FINITE |v|
+       SERIES_OVERFLOW = 8,         // a list / pass / fragile buffer was too small
+       SERIES_FIX_ORDER = 16,       // a bucket of the ordering step was too full to rank on the device: its records are unordered among themselves
+       SERIES_EARLY = 32 };         // (informational) the single-workgroup tail finished the pass
+// results block (device copy and coherent pinned copy, same layout; u64 words)
+enum { SR_STATUS = 0, SR_RUNNING = 1, SR_NHITS = 2, SR_NFRAGILE = 3, SR_COUNTERS = 4, SR_HEAD = 4 + CNT_N };   // then factors[nsteps], res[nslices], max[nslices], fragile[cap * 10]
 
 }  // namespace ftkx

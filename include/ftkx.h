@@ -181,6 +181,23 @@ int ftkx_sweep_enqueue_many(ftkx_ctx *ctx, const int *timesteps, const int *scop
 int ftkx_sweep_collect(ftkx_ctx *ctx, const ftkx_cp_t **out, size_t *n_out);
 int ftkx_sweep_cancel(ftkx_ctx *ctx);    /* forgets the enqueued, not yet collected sweeps */
 
+/* The device-driven pass over a series of resident slices -- what the tracker and bench.py use; the calls above remain for callers
+ * that form the factors themselves (several ranks: ftk_amd/tslab.py).  Sweeps the steps (timesteps[i], scopes[i]), timesteps strictly
+ * ascending, each under the reference's sticky factor (update_vector_field_scaling_factor, critical_point_tracker.hh:850-864):
+ *   factor(i) = scaling_factor(min(*running_resolution, resolution of every slice the steps read with timestep <= timesteps[i] + 1))
+ * with the running minimum and nbits formed ON THE DEVICE between the mask kernel and the exact test: the whole pass -- masks and
+ * reduction, cull, factors, exact test, records, their ordering by tag and their transfer into the pinned host buffer -- is queued at
+ * once and the host waits once.  *running_resolution: in = the minimum before these slices (DBL_MAX: none), out = the minimum after
+ * them (as exact as ftkx_slices_prepare's res_below makes it: exact once it is below 2^-8).  factors (nullable): n values out.
+ * Whatever the device-driven form does not cover (options that need the tile path, a type filter, wrapped reference tags, a factor that
+ * hangs on the last bit of the host's log2, slices with vertices that can overflow a determinant, ...) is swept by the calls above
+ * inside this one, with the same result.  Records as for ftkx_sweep_collect: sorted by tag, valid until the next call. */
+int ftkx_sweep_series(ftkx_ctx *ctx, const int *timesteps, const int *scopes, int n, double *running_resolution,
+                      unsigned long long *factors, const ftkx_cp_t **out, size_t *n_out);
+/* which way the last ftkx_sweep_series went: 1 = device-driven, 2 = device-driven and finished by the single-workgroup tail (sparse
+ * data), 0 = host-driven batch; *status (nullable) = the SERIES_* bits the kernels raised (csrc/sweep_params.hpp) */
+int ftkx_series_last_path(const ftkx_ctx *ctx, unsigned long long *status);
+
 /* counters of the last collect: simplices visited (work items), cells/simplices surviving the cull, device-side hits */
 typedef struct ftkx_stats {
   unsigned long long work_items, cells, cells_survived, simplices_tested, hits;

@@ -1,0 +1,215 @@
+"""ftkx_sweep_series -- the device-driven pass over a resident series (factors formed on the device, records ordered without a sort and
+written into the pinned host buffer by the record kernel, one host wait) -- against the reference's fixtures, against the host-driven
+batch, and through its own fallbacks."""
+import os
+
+import numpy as np
+import pytest
+
+from common import assert_records_equal, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+DBL_MAX = float(np.finfo(np.float64).max)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import ftk_amd
+    from ftk_amd import build
+    build.build()
+    return ftk_amd
+
+
+def _ctx(gpu, g_or_dims, nd, nv, **opts):
+    dims = g_or_dims
+    scalar = nv == 1
+    lo = 2 if scalar else 1
+    dom = ([lo] * nd, [d - (3 if scalar else 2) for d in dims])
+    ctx = gpu.Context(nd)
+    ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
+    o = dict(jacobian_symmetric=int(scalar), derive_jacobian=1, tag_mode=gpu.TAG_REFERENCE)
+    o.update(opts)
+    ctx.set_options(**o)
+    return ctx
+
+
+def _as_fixture(recs):
+    out = np.zeros(len(recs), dtype=[("tag", "<u8"), ("type", "<u4"), ("ordinal", "<i4"), ("timestep", "<i4"), ("x", "<f8", (3,)), ("t", "<f8"), ("scalar", "<f8", (3,))])
+    for f in ("tag", "type", "x", "t", "scalar"):
+        out[f] = recs[f]
+    out["ordinal"] = recs["aux"] & 1
+    out["timestep"] = recs["aux"] >> 1
+    return out
+
+
+def _push_all(ctx, steps, nv):
+    for t, a in enumerate(steps):
+        (ctx.push_scalar_slice if nv == 1 else ctx.push_slice)(t, a)
+
+
+def _same(a, b):
+    """record arrays identical byte for byte (NaN coordinates included)"""
+    return len(a) == len(b) and np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes()
+
+
+def _plain(g):
+    return g["bounds"] is None and g["rectilinear"] is None and g["explicit"] is None
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names()])
+def test_series_pass_matches_reference_fixture(gpu, name):
+    """the whole series in ONE call: records, their order, the per-step factors and the running resolution"""
+    g = load_golden(name)
+    if not _plain(g):
+        pytest.skip("physical coordinates are set on the tracker")
+    nd, nv, nt = g["nd"], g["nv"], g["DT"]
+    opts = dict(robust=int(g["robust"]), compute_degrees=int(g["degrees"]))
+    if g["type_filter"] is not None:
+        opts.update(use_type_filter=1, type_filter=g["type_filter"])
+    ctx = _ctx(gpu, g["dims"], nd, nv, **opts)
+    _push_all(ctx, g["steps"], nv)
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    recs, factors, run = ctx.sweep_series(range(nt), scopes)
+    path, status = ctx.series_last_path()
+    assert np.array_equal(factors, g["factors"]), f"{name}: factors {factors} vs {g['factors']} (path {path}, status {status})"
+    assert np.all(recs["tag"][1:] >= recs["tag"][:-1]), f"{name}: records not in tag order (path {path}, status {status})"
+    assert_records_equal(_as_fixture(recs), g["records"], coord_tol=0.0, what=f"{name} (path {path}, status {status})")
+    # a second pass over the same (now masked and reduced) slices: nothing left to mask, same result
+    recs2, factors2, run2 = ctx.sweep_series(range(nt), scopes)
+    assert np.array_equal(factors2, factors) and run2 == run
+    assert _same(recs2, recs)
+    ctx.close()
+
+
+def test_the_device_driven_form_is_what_runs(gpu):
+    """on the data the path was built for the call must not quietly take the host-driven batch"""
+    taken = {}
+    for name in ("woven_128x128x10", "woven_31x37x32", "double_gyre_64x32x50", "moving_extremum_3d_32x32x32x8_dyadic", "merger_2d_32x32x100"):
+        g = load_golden(name)
+        nt = g["DT"]
+        ctx = _ctx(gpu, g["dims"], g["nd"], g["nv"], tag_mode=gpu.TAG_EXACT64)
+        _push_all(ctx, g["steps"], g["nv"])
+        scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+        recs, factors, _ = ctx.sweep_series(range(nt), scopes)
+        taken[name] = ctx.series_last_path()
+        st = ctx.stats()
+        assert st["hits"] == len(recs) == len(g["records"]) and st["cull_enabled"] == 1
+        assert np.array_equal(factors, g["factors"])
+        ctx.close()
+    assert all(p[0] in (1, 2) for p in taken.values()), taken
+
+
+@pytest.mark.parametrize("name", ["woven_31x37x32", "merger_2d_32x32x100", "moving_extremum_3d_21x21x21x32", "double_gyre_64x32x50"])
+def test_series_step_by_step_is_the_streaming_tracker(gpu, name):
+    """one call per timestep with the running resolution handed on -- what update_timestep does -- gives the factor sequence and the
+    records of the reference's streaming run; slice t of a step keeps the masks it got as slice t + 1 of the step before"""
+    g = load_golden(name)
+    nd, nv, nt = g["nd"], g["nv"], g["DT"]
+    ctx = _ctx(gpu, g["dims"], nd, nv)
+    run = DBL_MAX
+    got, factors = [], []
+    for k in range(nt):
+        (ctx.push_scalar_slice if nv == 1 else ctx.push_slice)(k, g["steps"][k])
+        if k == 0:
+            continue
+        r, f, run = ctx.sweep_series([k - 1], [gpu.SCOPE_BOTH], run)
+        got.append(r); factors.append(int(f[0]))
+        ctx.drop_slice(k - 1)
+    r, f, run = ctx.sweep_series([nt - 1], [gpu.SCOPE_ORDINAL], run)
+    got.append(r); factors.append(int(f[0]))
+    assert factors == [int(v) for v in g["factors"]]
+    assert_records_equal(_as_fixture(np.concatenate(got)), g["records"], coord_tol=0.0, what=name)
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_series_equals_the_host_driven_batch_on_random_fields(gpu, seed):
+    """seeded random series (smooth / rough / plateaus / tiny / huge / NaN), 2D and 3D, scalar and vector input, every tag mode:
+    ftkx_sweep_series == slices_prepare + host factors + enqueue + collect, record for record and in the same order"""
+    from ftk_amd import tslab
+    from test_gpu_fuzz import _field, _vector_series, KINDS
+    rng = np.random.default_rng(7000 + seed)
+    for case in range(5):
+        nd = int(rng.choice([2, 3]))
+        nv = int(rng.choice([1, nd]))
+        nt = int(rng.integers(2, 7))
+        dims = ((int(rng.choice([24, 40, 64, 136, 257])) + int(rng.integers(0, 2)), int(rng.integers(9, 90))) if nd == 2 else
+                (int(rng.choice([16, 24, 40, 130])) + int(rng.integers(0, 2)), int(rng.integers(7, 36)), int(rng.integers(7, 24))))
+        sp = tuple(reversed(dims))
+        kind = str(rng.choice(KINDS))
+        steps = _field(rng, (nt,) + sp, kind) if nv == 1 else _vector_series(rng, nt, sp, kind)
+        tag_mode = int(rng.choice([gpu.TAG_REFERENCE, gpu.TAG_EXACT64]))
+        what = f"seed {seed} case {case}: nd {nd} nv {nv} dims {dims} nt {nt} {kind} tag {tag_mode}"
+        scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+        ctx = _ctx(gpu, dims, nd, nv, tag_mode=tag_mode)
+        _push_all(ctx, steps, nv)
+        rm = ctx.slices_prepare(range(nt), 0)
+        ref_f = tslab.factors_from_resolutions([rm[t][0] for t in range(nt)])
+        ctx.sweep_enqueue_many(range(nt), scopes, ref_f)
+        ref = ctx.sweep_collect()
+        ctx.invalidate_masks()
+        got, f, _ = ctx.sweep_series(range(nt), scopes)
+        path, status = ctx.series_last_path()
+        assert [int(v) for v in f] == [int(v) for v in ref_f], what + f" factors (path {path} status {status})"
+        assert _same(got, ref), what + f" (path {path} status {status}): {len(got)} vs {len(ref)} records"
+        ctx.close()
+
+
+def test_series_fallbacks_give_the_same_records(gpu, monkeypatch):
+    """the ways out of the device-driven form -- buffers that are too small (tiny initial capacities cannot be forced from outside, so: a
+    hit-dense series larger than the default buffers), buckets too full to rank on the device (FTKX_SERIES_RANK_MAX=0: the host orders
+    every bucket), the form switched off (FTKX_SERIES=0) -- all return what the device-driven form returns"""
+    g = load_golden("woven_128x128x10")
+    nt = g["DT"]
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+
+    def run():
+        ctx = _ctx(gpu, g["dims"], 2, 1, tag_mode=gpu.TAG_EXACT64)
+        _push_all(ctx, g["steps"], 1)
+        recs, f, _ = ctx.sweep_series(range(nt), scopes)
+        p = ctx.series_last_path()
+        ctx.close()
+        return recs, f, p
+    base, bf, bp = run()
+    assert bp[0] in (1, 2)
+    assert_records_equal(_as_fixture(base), g["records"], coord_tol=0.0, what="device-driven")
+    monkeypatch.setenv("FTKX_SERIES_RANK_MAX", "0")
+    r, f, p = run()
+    assert p[0] == 1 and (p[1] & 16), p                   # SERIES_FIX_ORDER raised, ordered on the host
+    assert _same(r, base) and np.array_equal(f, bf)
+    monkeypatch.delenv("FTKX_SERIES_RANK_MAX")
+    monkeypatch.setenv("FTKX_SERIES", "0")
+    r, f, p = run()
+    assert p[0] == 0
+    assert _same(r, base) and np.array_equal(f, bf)
+
+
+def test_series_overflowing_buffers_replays_through_the_batch(gpu):
+    """more records than the initial hit buffer holds (65 536): flagged by the finish kernel, swept again by the host-driven batch, and
+    the NEXT call fits"""
+    from ftk_amd import synthetic
+    import torch
+    dims, nt = (512, 512), 40
+    ctx = _ctx(gpu, dims, 2, 1, tag_mode=gpu.TAG_EXACT64)
+    dev = torch.device("cuda", 0)
+    keep = []
+    for t in range(nt):
+        s = synthetic.generate("woven", dims, t, nt, torch, dev); keep.append(s)
+        torch.cuda.synchronize()
+        ctx.push_scalar_slice(t, s)
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    r1, f1, _ = ctx.sweep_series(range(nt), scopes)
+    p1 = ctx.series_last_path()
+    if len(r1) <= 65536:
+        pytest.skip(f"only {len(r1)} records: the initial buffer holds them")
+    assert p1[0] == 0 and (p1[1] & 8), p1
+    ctx.invalidate_masks()
+    r2, f2, _ = ctx.sweep_series(range(nt), scopes)
+    p2 = ctx.series_last_path()
+    assert p2[0] == 1, p2
+    assert _same(r1, r2) and np.array_equal(f1, f2)
+    assert np.all(r2["tag"][1:] > r2["tag"][:-1])
+    ctx.close()
