@@ -96,6 +96,62 @@ def cpu_baseline(nd, case, want_seconds=20.0):
     return out, port
 
 
+def side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=5, warmup=2):
+    """A few passes of another BASELINE configuration on this GPU (after the timed region of the headline one): the same pass -- resident
+    input to records on the host, ftkx_sweep_series -- measured the same way.  -> the entry of `configs` in the JSON line."""
+    nd, nv, case, dims, nt = CONFIGS[name]
+    scalar_input = nv == 1
+    stream = torch.cuda.current_stream()
+    ctx = ftk_amd.Context(nd, dev.index or 0)
+    ctx.set_stream(stream.cuda_stream)
+    lo = 2 if scalar_input else 1
+    dom = ([lo] * nd, [d - (3 if scalar_input else 2) for d in dims])
+    ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
+    ctx.set_options(jacobian_symmetric=scalar_input, derive_jacobian=1, tag_mode=ftk_amd.TAG_EXACT64)
+    keep = []
+    for t in range(nt):
+        a = synthetic.generate(case, dims, t, nt, torch, dev)
+        keep.append(a)
+        torch.cuda.synchronize()
+        (ctx.push_scalar_slice if scalar_input else ctx.push_slice)(t, a)
+    ts = np.arange(nt, dtype=np.int32)
+    scopes = np.array([ftk_amd.SCOPE_BOTH if t + 1 < nt else ftk_amd.SCOPE_ORDINAL for t in range(nt)], dtype=np.int32)
+    paths = {}
+    for _ in range(warmup):
+        ctx.invalidate_masks()
+        recs, f, _r = ctx.sweep_series(ts, scopes, copy=False)
+    ctx.set_profiling(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.invalidate_masks()
+        recs, f, _r = ctx.sweep_series(ts, scopes, copy=False)
+        p = ctx.series_last_path()
+        paths[str(p)] = paths.get(str(p), 0) + 1
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kt = ctx.kernel_times()
+    st = ctx.stats()
+    domk = max(kt, key=lambda k: kt[k][0])
+    dom_ms, dom_n = kt[domk]
+    c = 1 if scalar_input else nd
+    alg = 8.0 * c * float(np.prod(dims)) * nt + 72.0 * len(recs)
+    nsimp = tslab.count_simplices(nd, dims, nt, scalar_input)
+    symbol = "ftkx::%s<%d>" % (domk, nd)
+    if domk == "mask_kernel":
+        symbol = (ctx._L.ftkx_last_mask_kernel() or b"").decode() or symbol
+    out = {"workload": f"{case} {'x'.join(str(d) for d in dims)}x{nt}", "steps": steps, "ms_per_step": elapsed / steps * 1e3, "value": nsimp * steps / elapsed,
+           "simplices_per_step": nsimp, "kernel": symbol, "kernel_avg_launch_ms": dom_ms / max(1, dom_n),
+           "frac": alg / (dom_ms / max(1, dom_n) * 1e-3) / 1e9 / HBM_PEAK_GBS if dom_n else None,
+           "end_to_end_frac": alg / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg,
+           "hits": int(len(recs)), "simplices_tested_exactly": int(st["simplices_tested"]), "nbits": int(np.log2(max(int(v) for v in f))),
+           "series_paths": paths}
+    ctx.close()
+    del keep
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +169,7 @@ def main():
     ap.add_argument("--no-cull-ahead", action="store_true", help="experiment: do not announce the sweeps to slices_prepare (the cull then waits for the factors)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the kernels (what do they cost a pass?); the line then carries no roofline")
     ap.add_argument("--host-driven", action="store_true", help="N = 1: the host-driven batch (slices_prepare, factors on the host, enqueue, collect) instead of the device-driven ftkx_sweep_series")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the few passes of the other BASELINE configurations that follow the timed region")
     ap.add_argument("--dump-merged", default=None, help="rank 0 writes the merged records and the curves traced from them (npz)")
     args = ap.parse_args()
 
@@ -411,6 +468,24 @@ def main():
             "stats": {"simplices_tested_exactly": n_tested, "cells_survived_cull": n_cells},
             "check": check,
         }
+        if world == 1 and not args.no_other_configs and not args.exact_only:
+            # every BASELINE configuration in the driver's line: the headline fields stay on --config (c4); the others get a few passes each
+            for r in list(slices):
+                ctx.drop_slice(r)
+            slices.clear(); halo_buf = None
+            torch.cuda.empty_cache()
+            others = {}
+            for name in ("c1", "c2", "c3", "c4", "c5"):
+                if name == args.config:
+                    others[name] = {"workload": out["config"]["workload"], "steps": args.steps, "ms_per_step": out["ms_per_step"], "value": out["value"],
+                                    "kernel": kernel_symbol, "kernel_avg_launch_ms": avg_ms, "frac": achieved / HBM_PEAK_GBS,
+                                    "end_to_end_frac": out["roofline_end_to_end"]["frac"], "hits": n_hits, "headline": True}
+                    continue
+                try:
+                    others[name] = side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=3 if name == "c4" else 8, warmup=2)
+                except Exception as e:   # noqa: BLE001
+                    others[name] = {"error": repr(e)}
+            out["configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             base, port = cpu_baseline(nd, case)
             out["cpu_baseline"] = base

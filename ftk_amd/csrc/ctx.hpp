@@ -53,6 +53,9 @@ void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff
 void launch_bucket_scan(unsigned *hist, unsigned *boff, unsigned nbins, u64 *counters, hipStream_t st);
 void launch_bucket_scatter(const Mesh &m, unsigned *boff, u64 *bucketed, hipStream_t st);
 void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, hipStream_t st);
+Mesh coarse_view(const Mesh &m);
+void launch_series_small(const Mesh &m, const Mesh &mc, const Fields *d_steps, bool two_level, const u64 *d_refine, const u64 *d_list, ftkx_cp_t *out,
+                         u64 *results, size_t nwords, u64 *h_results, unsigned *flag, unsigned seq, unsigned *done, hipStream_t st);
 void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, hipStream_t st);
 }  // namespace ftkx
 

@@ -222,9 +222,13 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   else ftkx::launch_cull(m, d_steps, n, c->d_list, c->list_capacity, c->stream);
   ftkx::launch_series_factors(d_steps, n, d_slices, (int)k, d_sinfo, c->d_red, *running_resolution, (double)(nd == 3 ? ftkx::kSafeM3 : ftkx::kSafeM2),
                               c->sr_results, c->stream);
-  if (two_level) ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
   ev_end(c);
   ev_begin(c, K_EXACT);
+  // sparse data: one workgroup does the rest of the pass (and the kernels below leave at once)
+  static const bool small_on = !(getenv("FTKX_SERIES_SMALL") && atoi(getenv("FTKX_SERIES_SMALL")) == 0);
+  if (small_on) ftkx::launch_series_small(m, two_level ? ftkx::coarse_view(m) : m, d_steps, two_level, c->d_refine, c->d_list, c->h_hits, c->sr_results, nwords,
+                                          c->sr_h_results, flag, seq, reinterpret_cast<unsigned *>(c->d_counters + ftkx::CNT_SMALL_DONE), c->stream);
+  if (two_level) ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
   ftkx::launch_exact(m, d_steps, 0, c->d_list, c->list_capacity, c->stream);
   ftkx::launch_bucket_scan(c->sr_hist, c->sr_boff, (unsigned)nbins, c->d_counters, c->stream);
   ftkx::launch_bucket_scatter(m, c->sr_boff, c->sr_bucketed, c->stream);
@@ -287,6 +291,14 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
     if (e[0] < nrec) c->h_hits[e[0]].type = (unsigned)ftkx::classify3(A, c->opt.jacobian_symmetric != 0);
   }
   c->stats.reclassified = nf;
+  if (status & ftkx::SERIES_UNORDERED) {                     // (the fused tail with more records than its last workgroup ranks: rare) sort an index, move once
+    std::vector<std::pair<unsigned long long, size_t>> order(nrec);
+    for (size_t i = 0; i < nrec; i ++) order[i] = {c->h_hits[i].tag, i};
+    std::sort(order.begin(), order.end());
+    std::vector<ftkx_cp_t> tmp(nrec);
+    for (size_t i = 0; i < nrec; i ++) tmp[i] = c->h_hits[order[i].second];
+    if (nrec) memcpy(c->h_hits, tmp.data(), nrec * sizeof(ftkx_cp_t));
+  }
   if (status & ftkx::SERIES_FIX_ORDER) {
     // A bucket too full to rank on the device: its records sit in their own run of the output, unordered among themselves; everything
     // before the run is smaller, everything behind it larger.  Find each such run from an inversion, widen it until both ends are in

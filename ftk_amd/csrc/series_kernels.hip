@@ -45,7 +45,7 @@ __device__ inline int nbits_of(double resolution, bool &ambiguous)
 // time order, and writes every step's factor into its descriptor.  Masks were built without the per-vertex overflow rule: they stand
 // only if no vertex of a step's slices is big under the step's factor (max |v| * factor < safe_m) -- otherwise the pass is flagged.
 // nslices <= kSeriesMaxSlices: the per-slice values live in LDS (a chain of dependent global loads per slice cost 0.4 us apiece).
-__global__ __launch_bounds__(256) void series_factors_kernel(Fields *__restrict__ steps, int nsteps, const SeriesSlice *__restrict__ slices, int nslices,
+__global__ __launch_bounds__(1024) void series_factors_kernel(Fields *__restrict__ steps, int nsteps, const SeriesSlice *__restrict__ slices, int nslices,
                                                              const SeriesStep *__restrict__ sinfo, const u64 *__restrict__ red, double running_in,
                                                              double safe_m, u64 *__restrict__ results)
 {
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void series_factors_kernel(Fields *__restrict_
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) s_status = 0;
   __syncthreads();
-  for (int j = wv; j < nslices; j += 4) {              // a wavefront per slice
+  for (int j = wv; j < nslices; j += 16) {             // a wavefront per slice
     const SeriesSlice sl = slices[j];
     u64 mn = 0x7fefffffffffffffull, mxb = 0ull;
     if (sl.red_index >= 0) {
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void series_factors_kernel(Fields *__restrict_
     }
   }
   __syncthreads();
-  for (int j = tid; j < nslices; j += 256) {
+  for (int j = tid; j < nslices; j += 1024) {
     results[SR_HEAD + nsteps + j] = (u64)__double_as_longlong(res[j]);
     results[SR_HEAD + nsteps + nslices + j] = (u64)__double_as_longlong(mx[j]);
   }
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void series_factors_kernel(Fields *__restrict_
     if (lane == 63) { const double total = incl < running_in ? incl : running_in; results[SR_RUNNING] = (u64)__double_as_longlong(total); }
   }
   __syncthreads();
-  for (int i = tid; i < nsteps; i += 256) {
+  for (int i = tid; i < nsteps; i += 1024) {
     const SeriesStep st = sinfo[i];
     bool amb = false;
     const int nbits = nbits_of(res[st.last], amb);
@@ -111,42 +111,43 @@ __global__ __launch_bounds__(256) void series_factors_kernel(Fields *__restrict_
 
 // ---- ordering without a sort ---------------------------------------------------------------------------------------------------------
 // counts per bucket -> offsets (exclusive scan).  One workgroup of 16 wavefronts; a wavefront owns a contiguous sixteenth of the bins
-// and holds it in registers, 64 consecutive bins per row (row r, lane l = bin base + 64 r + l: every load and store is one contiguous
-// 256-byte run), so that the whole scan costs two passes over memory.  The counts are zeroed for their second life as scatter cursors;
-// the fullest bucket is published (CNT_BUCKET_MAX).  nbins <= kSeriesMaxBins.
+// and walks it in rows of 64 consecutive bins (every load and store is one contiguous 256-byte run): a first pass for the wavefront's
+// total, a second one -- the counts come from the L2 now -- for the offsets.  The counts are zeroed for their second life as scatter
+// cursors; the fullest bucket is published (CNT_BUCKET_MAX).  nbins <= kSeriesMaxBins.
 __global__ __launch_bounds__(1024) void bucket_scan_kernel(unsigned *__restrict__ hist, unsigned *__restrict__ boff, unsigned nbins, u64 *__restrict__ counters)
 {
-  constexpr int ROWS = kSeriesMaxBins / 1024;          // rows of 64 bins per wavefront
   __shared__ unsigned s_wave[16];
   __shared__ unsigned s_max;
   if (counters[CNT_SERIES_DONE]) return;
   const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const unsigned seg = (nbins + 15u) / 16u, seg64 = (seg + 63u) / 64u * 64u;      // bins per wavefront, rounded up to whole rows
-  const unsigned base = wv * seg64;
+  const unsigned seg = (nbins + 15u) / 16u, rows = (seg + 63u) / 64u;      // rows of 64 bins per wavefront
+  const unsigned base = wv * rows * 64u;
   if (tid == 0) s_max = 0;
   __syncthreads();
-  unsigned v[ROWS];
   unsigned sum = 0, mxc = 0;
-#pragma unroll
-  for (int r = 0; r < ROWS; r ++) {
-    const unsigned i = base + 64u * (unsigned)r + lane;
-    v[r] = (64u * (unsigned)r < seg64 && i < nbins) ? hist[i] : 0u;
-    sum += v[r]; mxc = v[r] > mxc ? v[r] : mxc;
+#pragma unroll 8
+  for (unsigned r = 0; r < rows; r ++) {
+    const unsigned i = base + 64u * r + lane;
+    const unsigned v = i < nbins ? hist[i] : 0u;
+    sum += v; mxc = v > mxc ? v : mxc;
   }
-  unsigned tot = sum;
-  for (int o = 32; o > 0; o >>= 1) { tot += __shfl_down(tot, o); const unsigned w = __shfl_down(mxc, o); mxc = w > mxc ? w : mxc; }
-  if (lane == 0) { s_wave[wv] = tot; if (mxc) atomicMax(&s_max, mxc); }
+  for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o); const unsigned w = __shfl_down(mxc, o); mxc = w > mxc ? w : mxc; }
+  if (lane == 0) { s_wave[wv] = sum; if (mxc) atomicMax(&s_max, mxc); }
   __syncthreads();
   unsigned carry = 0;
   for (unsigned q = 0; q < wv; q ++) carry += s_wave[q];
+  for (unsigned r0 = 0; r0 < rows; r0 += 8) {            // eight rows' loads in flight, then their scans
+    unsigned v[8];
 #pragma unroll
-  for (int r = 0; r < ROWS; r ++) {
-    if (64u * (unsigned)r >= seg64) break;               // (wave-uniform)
-    unsigned incl = v[r];
-    for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= (unsigned)o) incl += up; }
-    const unsigned i = base + 64u * (unsigned)r + lane;
-    if (i < nbins) { boff[i] = carry + incl - v[r]; hist[i] = 0u; }
-    carry += __shfl(incl, 63);
+    for (int k = 0; k < 8; k ++) { const unsigned i = base + 64u * (r0 + (unsigned)k) + lane; v[k] = (r0 + (unsigned)k < rows && i < nbins) ? hist[i] : 0u; }
+#pragma unroll
+    for (int k = 0; k < 8; k ++) {
+      const unsigned i = base + 64u * (r0 + (unsigned)k) + lane;
+      unsigned incl = v[k];
+      for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= (unsigned)o) incl += up; }
+      if (r0 + (unsigned)k < rows && i < nbins) { boff[i] = carry + incl - v[k]; hist[i] = 0u; }
+      carry += __shfl(incl, 63);
+    }
   }
   if (tid == 1023) boff[nbins] = carry;                  // (the last wavefront's carry is the total)
   if (tid == 0) counters[CNT_BUCKET_MAX] = s_max;
@@ -254,6 +255,307 @@ __global__ __launch_bounds__(kThreads) void series_record_kernel(const Mesh m, c
   }
 }
 
+// ---- the whole tail in one kernel (sparse data) -----------------------------------------------------------------------------------------
+// Where almost everything is culled -- one moving extremum in 512^3 x 32: a few hundred coarse cells survive -- refine, exact test,
+// ordering, records and the hand-over to the host are each a kernel that waits for a memory latency or two and does next to nothing; the
+// kernel boundaries between them (launch, drain, ~10 us apiece) were most of the tail of a pass.  This kernel runs right behind the
+// coarse cull and the factor kernel.  If few cells survived, every workgroup takes a handful of them through ALL of it on its own --
+// refine, exact test of the surviving corners, records of the simplices that passed (appended to the device hit buffer, unordered) --
+// and the workgroup that finishes last puts the records in tag order while it copies them into the pinned host buffer, publishes the
+// results block, stores the flag the host waits for and raises CNT_SERIES_DONE, on which the kernels queued behind this one leave at
+// once.  With more survivors than that it changes nothing and leaves the pass to those kernels.
+constexpr int kSmallGrid = 2048;                         // workgroups
+constexpr unsigned kSmallPer = 1;                        // coarse cells (two-level) per workgroup; without summaries: 64 corners
+constexpr unsigned kSmallRank = 1024;                    // records the last workgroup ranks in LDS (more: SERIES_UNORDERED, the host sorts)
+
+template <int ND>
+__global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, const Mesh mc, const Fields *__restrict__ steps, int two_level,
+                                                                const u64 *__restrict__ refine, const u64 *__restrict__ list,
+                                                                ftkx_cp_t *__restrict__ out /* pinned */, u64 *__restrict__ results, size_t nwords,
+                                                                u64 *__restrict__ h_results /* pinned, coherent */, unsigned *flag, unsigned seq, unsigned *__restrict__ done)
+{
+  constexpr int N = ND + 1, NVC = 1 << N, G = kThreads / NVC, NTYPES = fan_table<N>::NTYPES;
+  constexpr unsigned LIST_CAP = kSmallPer * 64, PASS_CAP = 2048;
+  __shared__ unsigned s_rank[kSmallRank];
+  static_assert(G * NTYPES <= (int)PASS_CAP / 2, "a batch's worst case must fit twice");
+  __shared__ u64 s_list[LIST_CAP];
+  __shared__ u64 s_pass[PASS_CAP];                       // order keys of the simplices that passed; the last workgroup: all keys of the pass
+  __shared__ i64 s_vf[G][NVC][ND];
+  __shared__ unsigned char s_flag[G][NVC];
+  __shared__ unsigned s_tab[NTYPES];
+  __shared__ unsigned s_nlist, s_npass, s_tested, s_last;
+  __shared__ u64 s_base;
+  const int tid = threadIdx.x;
+  const fan_table<N> &fan = dev_fan<ND>();
+  const u64 redo = (u64)(SERIES_AMBIGUOUS | SERIES_MASKS_INVALID | SERIES_INF);
+  if (results[SR_STATUS] & redo) return;                 // the host takes this pass over anyway
+  const u64 count = m.counters[two_level ? CNT_REFINE_LIST : CNT_SURVIVOR_LIST];
+  const u64 per = two_level ? (u64)kSmallPer : (u64)LIST_CAP;
+  if (count > per * (u64)kSmallGrid) return;             // (the same for every workgroup) too much for this kernel: nothing has been changed
+  const unsigned nwork = count ? (unsigned)((count + per - 1) / per) : 1u;      // workgroups that take part (workgroup 0 always does: somebody must finish)
+  if (blockIdx.x >= nwork) return;
+  if (tid == 0) { s_nlist = 0; s_npass = 0; s_tested = 0; }
+  if (tid < NTYPES) {
+    unsigned w = 0;
+    for (int i = 0; i < N; i ++) w |= (unsigned)fan.vert[tid][i] << (8 * i);
+    s_tab[tid] = w;
+  }
+  __syncthreads();
+  const u64 first = (u64)blockIdx.x * per, last = first + per < count ? first + per : count;
+
+  // ---- refine (the second level of the cull, as refine_kernel does it): this workgroup's coarse cells, one lane per row of a cell ----
+  if (two_level) {
+    const int DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
+    const u64 k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
+    const u64 UR = (u64)m.u_rows, urows = (u64)((DH + m.u_rows - 1) / m.u_rows);
+    for (u64 idx = first * UR + tid; idx < last * UR; idx += kThreads) {
+      const u64 e = refine[idx / UR];
+      const int step = (int)(e >> 44);
+      const unsigned want = (unsigned)((e >> 40) & 3);
+      u64 lin = e & 0xffffffffffull;
+      const int g = mc.core_st[0] + (int)(lin % (u64)mc.core_sz[0]); lin /= (u64)mc.core_sz[0];
+      const int cyc = mc.core_st[1] + (int)(lin % (u64)mc.core_sz[1]); lin /= (u64)mc.core_sz[1];
+      const int cz = (ND == 3) ? mc.core_st[2] + (int)lin : 0;
+      const int j = cyc * m.u_rows + (int)(idx % UR), k = cz - m.ext_st[2];
+      const int cy = j + m.ext_st[1];
+      if (!(cy >= m.core_st[1] && cy < m.core_st[1] + m.core_sz[1])) continue;
+      const Fields f = steps[step];
+      const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0 && (want & 2);
+      // (all summary bytes first, then all mask words, unconditionally -- a word whose summary is non-zero was not written and its
+      // summary, replicated, stands in: three memory latencies per lane instead of ten dependent ones)
+      constexpr int NR = (ND == 3) ? 4 : 2;
+      unsigned uu[2][NR][2];
+      u64 ww[2][NR][2];
+      bool rok[NR];
+#pragma unroll
+      for (int r = 0; r < NR; r ++) {
+        const int dy = r & 1, dz = r >> 1;
+        rok[r] = j + dy < DH && k + dz < DD;
+        const int jj = rok[r] ? j + dy : j, kk = rok[r] ? k + dz : k;
+#pragma unroll
+        for (int sl = 0; sl < 2; sl ++) {
+          const unsigned char *Up = (sl && need_next) ? f.U[1] : f.U[0];
+          const unsigned char *u = Up + (size_t)m.u_pitch * ((size_t)(jj / m.u_rows) + (size_t)urows * (size_t)kk) + g;
+          uu[sl][r][0] = u[0]; uu[sl][r][1] = u[1];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NR; r ++) {
+        const int dy = r & 1, dz = r >> 1;
+        const int jj = rok[r] ? j + dy : j, kk = rok[r] ? k + dz : k;
+        const size_t row = (size_t)jj + (size_t)DH * (size_t)kk;
+#pragma unroll
+        for (int sl = 0; sl < 2; sl ++) {
+          const unsigned char *Mp = (sl && need_next) ? f.M[1] : f.M[0];
+          const u64 *w = reinterpret_cast<const u64 *>(Mp + (size_t)P * row) + g;
+          ww[sl][r][0] = w[0]; ww[sl][r][1] = w[1];
+        }
+      }
+      u64 a0 = ~0ull, a1 = ~0ull;
+#pragma unroll
+      for (int r = 0; r < NR; r ++) {
+        if (!rok[r]) continue;                                            // row outside the array: invalid vertices, neutral
+#pragma unroll
+        for (int sl = 0; sl < 2; sl ++) {
+          const u64 w0 = uu[sl][r][0] ? (u64)uu[sl][r][0] * 0x0101010101010101ull : ww[sl][r][0];
+          const u64 w1 = uu[sl][r][1] ? (u64)uu[sl][r][1] * 0x0101010101010101ull : ww[sl][r][1];
+          const u64 v = w0 & ((w0 >> 8) | (w1 << 56));
+          if (sl == 0) a0 &= v; else if (need_next) a1 &= v;
+        }
+      }
+      u64 in_core = 0;
+      for (int b = 0; b < 8; b ++) {
+        const int cx = g * 8 + b + m.ext_st[0];
+        if (cx >= m.core_st[0] && cx < m.core_st[0] + m.core_sz[0]) in_core |= 0x80ull << (8 * b);
+      }
+      u64 surv_o = 0, surv_i = 0;
+      if ((f.scope_mask & FTKX_SCOPE_ORDINAL) && (want & 1)) surv_o = ~(a0 + k7f) & k80 & in_core;
+      if (need_next) surv_i = ~((a0 & a1) + k7f) & k80 & in_core;
+      if (!(surv_o | surv_i)) continue;
+      const u64 row_lin = (u64)(cy - m.core_st[1]) * (u64)m.core_sz[0] + (ND == 3 ? (u64)(cz - m.core_st[2]) * (u64)m.core_sz[0] * (u64)m.core_sz[1] : 0ull);
+      for (int b = 0; b < 8; b ++) {
+        const unsigned fl = (unsigned)((surv_o >> (8 * b + 7)) & 1) | ((unsigned)((surv_i >> (8 * b + 7)) & 1) << 1);
+        if (!fl) continue;
+        s_list[atomicAdd(&s_nlist, 1u)] = (row_lin + (u64)(g * 8 + b + m.ext_st[0] - m.core_st[0])) | ((u64)fl << 40) | ((u64)step << 44);   // (at most 8 x u_rows corners per coarse cell: fits)
+      }
+    }
+  } else {
+    for (u64 i = first + tid; i < last; i += kThreads) s_list[i - first] = list[i];
+    if (tid == 0) s_nlist = last > first ? (unsigned)(last - first) : 0u;
+  }
+  __syncthreads();
+  const unsigned nlist = s_nlist;
+
+  // records of the simplices parked in s_pass: appended to the device hit buffer (unordered; their order keys next to them in m.pass)
+  auto flush_records = [&]() {                           // called by the whole workgroup, after a barrier that made s_npass final
+    const unsigned np = s_npass;
+    if (tid == 0) s_base = np ? atomicAdd(&m.counters[CNT_HITS], (u64)np) : 0ull;
+    __syncthreads();
+    const u64 slot0 = s_base;
+    for (unsigned p = tid; p < np; p += kThreads) {
+      const u64 key = s_pass[p];
+      const int type = (int)(key & 63u);
+      const u64 q = key >> 6, step = q / m.core_cells;
+      u64 lin = q - step * m.core_cells;
+      const Fields &f = steps[step];
+      int corner[N];
+      for (int a = 0; a < ND; a ++) { corner[a] = m.core_st[a] + (int)(lin % (u64)m.core_sz[a]); lin /= (u64)m.core_sz[a]; }
+      corner[ND] = f.t;
+      u64 X[N][ND];
+      int ids[N];
+      if (ND == 2 && m.compute_degrees)
+      for (int v = 0; v < N; v ++) {
+        const unsigned vm = fan.vert[type][v];
+        int vx[3] = {0, 0, 0};
+        for (int a = 0; a < ND; a ++) vx[a] = corner[a] + (int)((vm >> a) & 1u);
+        const int sl = (int)((vm >> ND) & 1u);
+        i64 qq[ND];
+        classify_vertex<ND>(m, f.S[sl], f.V[sl], f.factor, vx, qq);
+        for (int c = 0; c < ND; c ++) X[v][c] = (u64)qq[c];
+        ids[v] = vertex_id<ND>(m, corner, vm);
+      }
+      bool fragile = false;
+      double Jfrag[9];
+      ftkx_cp_t rec;
+      if (record_is_fast<ND>(m, f, corner)) make_record_impl<ND, true>(m, f, corner, type, X, ids, false, nullptr, &rec, &fragile, Jfrag);
+      else make_record_general<ND>(m, f, corner, type, X, ids, false, nullptr, &rec, &fragile, Jfrag);
+      const u64 slot = slot0 + p;
+      if (slot < m.capacity) { m.hits[slot] = rec; m.pass[slot] = key; }
+      if (ND == 3 && fragile) {
+        const u64 e = atomicAdd(&m.counters[CNT_FRAGILE], 1ull);
+        if (e < m.fragile_capacity) {
+          u64 *fd = m.fragile + e * 10;
+          fd[0] = slot;
+          for (int k = 0; k < 9; k ++) fd[1 + k] = (u64)__double_as_longlong(Jfrag[k]);
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_npass = 0;
+    __syncthreads();
+  };
+
+  // ---- exact test (as exact_kernel does it: one lane per hypercube vertex while staging, then (corner, type) pairs over all lanes) ----
+  unsigned tested = 0;
+  for (unsigned base = 0; base < nlist; base += G) {
+    __syncthreads();
+    if (s_npass > PASS_CAP - G * NTYPES) flush_records();   // (workgroup-uniform: s_npass was final at the barrier above)
+    {
+      const int gi = tid / NVC, vtx = tid % NVC;
+      const u64 e = base + gi < nlist ? s_list[base + gi] : ~0ull;
+      i64 q[ND];
+      unsigned char fl = kInvalid;
+      for (int c = 0; c < ND; c ++) q[c] = 0;
+      if (e != ~0ull) {
+        const Fields &f = steps[e >> 44];
+        u64 lin = e & 0xffffffffffull;
+        int vx[3] = {0, 0, 0};
+        for (int d = 0; d < ND; d ++) { vx[d] = m.core_st[d] + (int)(lin % (u64)m.core_sz[d]) + ((vtx >> d) & 1); lin /= (u64)m.core_sz[d]; }
+        const int sl = (vtx >> ND) & 1;
+        if (sl == 0 || (f.scope_mask & FTKX_SCOPE_INTERVAL)) fl = classify_vertex<ND>(m, f.S[sl], f.V[sl], f.factor, vx, q);
+      }
+      s_flag[gi][vtx] = fl;
+      for (int c = 0; c < ND; c ++) s_vf[gi][vtx][c] = q[c];
+    }
+    __syncthreads();
+    for (int wb = 0; wb < G * NTYPES; wb += kThreads) {
+      const int w = wb + tid;
+      if (w >= G * NTYPES) continue;
+      const int gi = w / NTYPES, type = w % NTYPES;
+      if (base + gi >= nlist) continue;
+      const u64 e = s_list[base + gi];
+      const unsigned scope_flags = (unsigned)((e >> 40) & 3);
+      const bool wanted = fan.ordinal[type] ? (scope_flags & 1) : (scope_flags & 2);
+      if (!wanted) continue;
+      const Fields &f = steps[e >> 44];
+      u64 lin = e & 0xffffffffffull;
+      int corner[N];
+      for (int d = 0; d < ND; d ++) { corner[d] = m.core_st[d] + (int)(lin % (u64)m.core_sz[d]); lin /= (u64)m.core_sz[d]; }
+      corner[ND] = f.t;
+      const unsigned tab = s_tab[type];
+      unsigned char flags[N];
+      u64 X[N][ND];
+      for (int i = 0; i < N; i ++) {
+        const unsigned vm = (tab >> (8 * i)) & 0xffu;
+        flags[i] = s_flag[gi][vm];
+        for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[gi][vm][c];
+      }
+      int ids[N]; double mu[N]; bool presolved;
+      if (simplex_inside<ND>(m, f, 1, corner, tab, flags, X, tested, ids, mu, &presolved))
+        s_pass[atomicAdd(&s_npass, 1u)] = order_key((e & kPassLinMask) | ((u64)type << kPassTypeShift) | ((e >> 44) << kPassStepShift), m.core_cells);
+    }
+  }
+  __syncthreads();
+  if (s_npass) flush_records();                          // (workgroup-uniform)
+  {
+    unsigned t_sum = tested;
+    for (int o = 32; o > 0; o >>= 1) t_sum += __shfl_down(t_sum, o);
+    if ((tid & 63) == 0 && t_sum) atomicAdd(&s_tested, t_sum);
+    __syncthreads();
+    if (tid == 0) {
+      if (s_tested) atomicAdd(&m.counters[CNT_SIMPLICES_TESTED], (u64)s_tested);
+      if (nlist) atomicAdd(&m.counters[CNT_CELLS_SURVIVED], (u64)nlist);
+    }
+  }
+
+  // ---- the workgroup that finishes last hands the pass over to the host ----
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(done, 1u) == nwork - 1u ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const u64 nrec_all = m.counters[CNT_HITS], nfrag = m.counters[CNT_FRAGILE];
+  const bool over = nrec_all > m.capacity || nfrag > m.fragile_capacity;
+  const u64 nrec = over ? 0ull : nrec_all;
+  const bool ranked = nrec <= (u64)kSmallRank && nrec <= (u64)PASS_CAP;
+  u64 status = (u64)SERIES_EARLY | (over ? (u64)SERIES_OVERFLOW : 0ull) | (ranked ? 0ull : (u64)SERIES_UNORDERED);
+  // rank of every record (by counting the smaller order keys), records copied into the pinned host buffer at their rank
+  if (ranked) {
+    for (u64 i = tid; i < nrec; i += kThreads) s_pass[i] = m.pass[i];
+    __syncthreads();
+    for (u64 i = tid; i < nrec; i += kThreads) {
+      const u64 key = s_pass[i];
+      unsigned r = 0;
+      for (u64 q = 0; q < nrec; q ++) r += s_pass[q] < key ? 1u : 0u;
+      s_rank[i] = r;
+    }
+    __syncthreads();
+  }
+  for (u64 w = tid; w < nrec * 9; w += kThreads) {                       // nine consecutive lanes move one record
+    const u64 i = w / 9, k = w - i * 9;
+    const u64 at = ranked ? (u64)s_rank[i] : i;
+    __hip_atomic_store(reinterpret_cast<u64 *>(out + at) + k, reinterpret_cast<const u64 *>(m.hits + i)[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const u64 nf = over ? 0ull : nfrag;
+  for (u64 w = tid; w < nf * 10; w += kThreads) {
+    const u64 e = w / 10, k = w - e * 10;
+    u64 v = m.fragile[w];
+    if (k == 0 && ranked) v = s_rank[v];
+    h_results[nwords + w] = v;
+  }
+  for (size_t i = tid; i < nwords; i += kThreads) {
+    u64 v = results[i];
+    if (i == (size_t)SR_STATUS) v |= status;
+    else if (i == (size_t)SR_NHITS) v = nrec_all;
+    else if (i == (size_t)SR_NFRAGILE) v = nfrag;
+    else if (i >= (size_t)SR_COUNTERS && i < (size_t)SR_HEAD) {
+      const int cidx = (int)i - SR_COUNTERS;
+      v = m.counters[cidx];
+      if (cidx == CNT_PASS) v = nrec_all;
+      if (cidx == CNT_LIST_PEAK) v = m.counters[CNT_CELLS_SURVIVED];
+      if (cidx == CNT_REFINE_PEAK) v = two_level ? count : 0ull;
+    }
+    h_results[i] = v;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    m.counters[CNT_SERIES_DONE] = 1ull;                  // the kernels queued behind this one leave at once
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ---- finish: counters, factors and reductions to the host, then the flag --------------------------------------------------------------
 // One workgroup.  Runs behind the record kernel (a kernel boundary: its stores have been released); copies the device results block
 // into coherent pinned memory and stores the sequence number behind it with system scope -- the ONE thing the host waits for.
@@ -293,7 +595,7 @@ void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist,
 
 void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, double safe_m,
                            u64 *results, hipStream_t st)
-{ hipLaunchKernelGGL(series_factors_kernel, dim3(1), dim3(256), 0, st, steps, nsteps, slices, nslices, sinfo, red, running_in, safe_m, results); }
+{ hipLaunchKernelGGL(series_factors_kernel, dim3(1), dim3(1024), 0, st, steps, nsteps, slices, nslices, sinfo, red, running_in, safe_m, results); }
 
 void launch_bucket_scan(unsigned *hist, unsigned *boff, unsigned nbins, u64 *counters, hipStream_t st)
 { hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, hist, boff, nbins, counters); }
@@ -313,6 +615,13 @@ void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sor
   const dim3 grid(256u * 2u);
   if (m.nd == 2) hipLaunchKernelGGL(series_record_kernel<2>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out);
   else hipLaunchKernelGGL(series_record_kernel<3>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out);
+}
+
+void launch_series_small(const Mesh &m, const Mesh &mc, const Fields *d_steps, bool two_level, const u64 *d_refine, const u64 *d_list, ftkx_cp_t *out,
+                         u64 *results, size_t nwords, u64 *h_results, unsigned *flag, unsigned seq, unsigned *done, hipStream_t st)
+{
+  if (m.nd == 2) hipLaunchKernelGGL(series_small_kernel<2>, dim3(kSmallGrid), dim3(kThreads), 0, st, m, mc, d_steps, two_level ? 1 : 0, d_refine, d_list, out, results, nwords, h_results, flag, seq, done);
+  else hipLaunchKernelGGL(series_small_kernel<3>, dim3(kSmallGrid), dim3(kThreads), 0, st, m, mc, d_steps, two_level ? 1 : 0, d_refine, d_list, out, results, nwords, h_results, flag, seq, done);
 }
 
 void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, hipStream_t st)

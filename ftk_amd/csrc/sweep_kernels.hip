@@ -2160,7 +2160,7 @@ void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, 
 }
 
 // two-level form: summaries first (1/8 of the bytes), vertex masks only for the words the summaries could not rule out
-static Mesh coarse_view(const Mesh &m)
+Mesh coarse_view(const Mesh &m)
 {
   Mesh mc = m;                                   // the coarse view: one "vertex" per aligned word of 8 (x) and u_rows rows (y)
   const int w0 = (m.core_st[0] - m.ext_st[0]) / 8, w1 = (m.core_st[0] + m.core_sz[0] - 1 - m.ext_st[0]) / 8;

@@ -12,7 +12,8 @@ enum { CNT_HITS = 0, CNT_CELLS_SURVIVED = 1, CNT_SIMPLICES_TESTED = 2, CNT_SURVI
        CNT_SERIES_DONE = 11,   // series pass: non-zero once the pass has been finished early (sparse data: one workgroup did the whole tail) --
                                // the kernels queued behind that point leave at once
        CNT_BUCKET_MAX = 12,    // series pass: the fullest bucket of the ordering step
-       CNT_N = 13 };
+       CNT_SMALL_DONE = 13,    // series pass: workgroups of the fused tail kernel that have finished (32-bit counter in this word)
+       CNT_N = 14 };
 
 // A simplex that passed the test, handed from the integer kernels (exact_kernel, tile_kernel) to record_kernel, which does all the
 // FP64 work (solve, lerp, Jacobian, classification) on densely packed lanes: corner index inside core (x fastest) | type | request.
@@ -131,7 +132,8 @@ enum { SERIES_AMBIGUOUS = 1,        // 1 / resolution so close above a power of 
        SERIES_INF = 4,              // a slice holds an Inf: the fused maximum is not the max FINITE |v|
        SERIES_OVERFLOW = 8,         // a list / pass / fragile buffer was too small
        SERIES_FIX_ORDER = 16,       // a bucket of the ordering step was too full to rank on the device: its records are unordered among themselves
-       SERIES_EARLY = 32 };         // (informational) the single-workgroup tail finished the pass
+       SERIES_EARLY = 32,           // (informational) the fused tail kernel finished the pass
+       SERIES_UNORDERED = 64 };     // the fused tail found more records than its last workgroup ranks: they come unordered, the host sorts them
 // results block (device copy and coherent pinned copy, same layout; u64 words)
 enum { SR_STATUS = 0, SR_RUNNING = 1, SR_NHITS = 2, SR_NFRAGILE = 3, SR_COUNTERS = 4, SR_HEAD = 4 + CNT_N };   // then factors[nsteps], res[nslices], max[nslices], fragile[cap * 10]
 

@@ -80,16 +80,21 @@ def _context_run(gpu, steps, nd, nv, dims, mode, tag_mode, robust, type_filter, 
     for t in range(nt):
         (ctx.push_scalar_slice if scalar else ctx.push_slice)(t, steps[t])
     scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
-    if mode == "exact_prepass":
+    if mode == "series":            # the device-driven pass: factors formed on the device, one host wait (ftkx_sweep_series)
+        recs, factors, _ = ctx.sweep_series(range(nt), scopes)
+        assert np.all(recs["tag"][1:] >= recs["tag"][:-1]), "series: records not in tag order"
+        factors = [int(f) for f in factors]
+    elif mode == "exact_prepass":
         res = [ctx.slice_resolution(t)[0] for t in range(nt)]
     else:
         if mode == "announced":
             ctx.sweep_announce(range(nt), scopes)
         rm = ctx.slices_prepare(range(nt), 0)
         res = [rm[t][0] for t in range(nt)]
-    factors = tslab.factors_from_resolutions(res)
-    ctx.sweep_enqueue_many(range(nt), scopes, factors)
-    recs = ctx.sweep_collect()
+    if mode != "series":
+        factors = tslab.factors_from_resolutions(res)
+        ctx.sweep_enqueue_many(range(nt), scopes, factors)
+        recs = ctx.sweep_collect()
     LAST_STATS.clear(); LAST_STATS.update(ctx.stats())
     ctx.close()
     out = np.zeros(len(recs), dtype=[("tag", "<u8"), ("type", "<u4"), ("ordinal", "<i4"), ("timestep", "<i4"),
@@ -127,7 +132,7 @@ def test_random_configurations_equal_the_oracle(gpu, oracle, seed):
         tag_mode = oracle.TAG_REFERENCE if rng.random() < 0.5 else oracle.TAG_EXACT64
         what = f"seed {seed} case {case}: nd {nd} nv {nv} dims {dims} nt {nt} {kind} robust {robust} filter {type_filter} degrees {degrees} tag {tag_mode}"
         ref, rf, _ = oracle.track(steps, nd, nv, robust=robust, type_filter=type_filter, compute_degrees=degrees, tag_mode=tag_mode, nthreads=8)
-        mode = str(rng.choice(["tracker", "exact_prepass", "one_pass", "announced"]))
+        mode = str(rng.choice(["tracker", "exact_prepass", "one_pass", "announced", "series"]))
         bounds = rect = expl = None
         multi = {}
         if mode == "tracker":
@@ -164,7 +169,7 @@ def test_the_fuzz_compared_something(gpu):
     if COMPARED["cases"] != 240:
         pytest.skip("the seeds above did not all run in this process (test selection / several workers)")
     assert COMPARED["records"] > 500000, COMPARED
-    assert COMPARED["modes"] == {"tracker", "exact_prepass", "one_pass", "announced"}, COMPARED
+    assert COMPARED["modes"] == {"tracker", "exact_prepass", "one_pass", "announced", "series"}, COMPARED
     print(COMPARED)
 
 

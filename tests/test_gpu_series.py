@@ -55,6 +55,9 @@ def _same(a, b):
     return len(a) == len(b) and np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes()
 
 
+PATHS = {}      # (path, status) -> fixtures that went that way
+
+
 def _plain(g):
     return g["bounds"] is None and g["rectilinear"] is None and g["explicit"] is None
 
@@ -74,6 +77,7 @@ def test_series_pass_matches_reference_fixture(gpu, name):
     scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
     recs, factors, run = ctx.sweep_series(range(nt), scopes)
     path, status = ctx.series_last_path()
+    PATHS.setdefault((path, status), []).append(name)
     assert np.array_equal(factors, g["factors"]), f"{name}: factors {factors} vs {g['factors']} (path {path}, status {status})"
     assert np.all(recs["tag"][1:] >= recs["tag"][:-1]), f"{name}: records not in tag order (path {path}, status {status})"
     assert_records_equal(_as_fixture(recs), g["records"], coord_tol=0.0, what=f"{name} (path {path}, status {status})")
@@ -82,6 +86,20 @@ def test_series_pass_matches_reference_fixture(gpu, name):
     assert np.array_equal(factors2, factors) and run2 == run
     assert _same(recs2, recs)
     ctx.close()
+
+
+def test_every_way_through_the_series_pass_was_taken(gpu):
+    """(runs after the fixtures above) the fixtures exercised the kernel chain (path 1), the fused tail kernel (path 2) -- with its
+    records ranked on the device and, past 1024 records, sorted on the host (status bit 64) -- and the hand-over to the host-driven batch,
+    both decided up front (status 0) and raised by the kernels (masks that need the per-vertex overflow rule: bit 2)"""
+    if sum(len(v) for v in PATHS.values()) < 20:
+        pytest.skip("the fixture tests above did not run in this process")
+    print({k: len(v) for k, v in PATHS.items()})
+    assert any(p == 1 for p, _ in PATHS), PATHS
+    assert any(p == 2 and not (st & 64) for p, st in PATHS), PATHS
+    assert any(p == 2 and (st & 64) for p, st in PATHS), PATHS
+    assert any(p == 0 and st == 0 for p, st in PATHS) or any(p == 0 for p, _ in PATHS), PATHS
+    assert any(p == 0 and (st & 2) for p, st in PATHS), PATHS
 
 
 def test_the_device_driven_form_is_what_runs(gpu):
@@ -192,7 +210,7 @@ def test_series_overflowing_buffers_replays_through_the_batch(gpu):
     the NEXT call fits"""
     from ftk_amd import synthetic
     import torch
-    dims, nt = (512, 512), 40
+    dims, nt = (1024, 1024), 72
     ctx = _ctx(gpu, dims, 2, 1, tag_mode=gpu.TAG_EXACT64)
     dev = torch.device("cuda", 0)
     keep = []
