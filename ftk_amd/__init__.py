@@ -246,6 +246,7 @@ class Context:
         self._ck(self._L.ftkx_invalidate_masks(self._h))
 
     def set_profiling(self, on=True):
+        """0 / False off, 1 / True every kernel family, 2 the mask kernel only"""
         self._ck(self._L.ftkx_set_profiling(self._h, int(on)))
 
     def kernel_times(self):

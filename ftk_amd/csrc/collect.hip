@@ -68,15 +68,18 @@ hipEvent_t ev_take(ftkx_ctx *c)
 void ev_give(ftkx_ctx *c, hipEvent_t e) { if (e) c->event_pool.push_back(e); }
 void ev_begin(ftkx_ctx *c, int kind)
 {
-  if (!c->profiling) return;
+  c->ev_open = false;
+  if (!c->profiling || (c->profiling == 2 && kind != K_MASK)) return;     // level 2: the dominant kernel only (an event pair costs the stream ~10 us of idle time)
   hipEvent_t a = ev_take(c), b = ev_take(c);
   if (!a || !b) { ev_give(c, a); ev_give(c, b); return; }
   (void)hipEventRecord(a, c->stream);
   c->events.push_back({kind, {a, b}});
+  c->ev_open = true;
 }
 void ev_end(ftkx_ctx *c)
 {
-  if (!c->profiling || c->events.empty()) return;
+  if (!c->profiling || !c->ev_open || c->events.empty()) return;
+  c->ev_open = false;
   (void)hipEventRecord(c->events.back().second.second, c->stream);
 }
 void ev_harvest(ftkx_ctx *c, bool all)

@@ -167,11 +167,13 @@ struct ftkx_ctx {
   size_t sr_bucketed_cap = 0;
   u64 *sr_sorted = nullptr;
   size_t sr_sorted_cap = 0;
+  int sr_skip_small = 0;             // passes for which the fused tail kernel is not launched (the data was hit-dense a moment ago)
   int sr_last_path = 0;              // which way the last ftkx_sweep_series went: 1 device-driven, 2 early single-workgroup tail, 0 the host-driven batch
   unsigned long long sr_last_status = 0;
   ftkx_stats stats;
   // optional kernel timing (hipEvents on the context's stream)
-  int profiling = 0;
+  int profiling = 0;               // 0 off, 1 every kernel family, 2 the mask kernel only
+  bool ev_open = false;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> events;
   std::vector<hipEvent_t> event_pool;
   double k_ms[ftkxh::K_N] = {0, 0, 0, 0};

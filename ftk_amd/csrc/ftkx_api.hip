@@ -645,7 +645,7 @@ int ftkx_debug_stream_read(ftkx_ctx *c, const void *device_ptr, size_t bytes)
 int ftkx_set_profiling(ftkx_ctx *c, int on)
 {
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
-  c->profiling = on != 0;
+  c->profiling = on < 0 ? 0 : (on > 2 ? 1 : on);
   for (int k = 0; k < K_N; k ++) { c->k_ms[k] = 0; c->k_launches[k] = 0; }
   return FTKX_OK;
 }
@@ -653,6 +653,7 @@ int ftkx_set_profiling(ftkx_ctx *c, int on)
 int ftkx_get_kernel_times(const ftkx_ctx *c, double ms[4], unsigned long long launches[4])
 {
   if (!c || !ms || !launches) return fail(nullptr, FTKX_E_INVALID, "null argument");
+  ev_harvest(const_cast<ftkx_ctx *>(c), false);          // (pairs that have completed since the last call that waited)
   for (int k = 0; k < K_N; k ++) { ms[k] = c->k_ms[k]; launches[k] = c->k_launches[k]; }
   return FTKX_OK;
 }

@@ -226,7 +226,11 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   ev_begin(c, K_EXACT);
   // sparse data: one workgroup does the rest of the pass (and the kernels below leave at once)
   static const bool small_on = !(getenv("FTKX_SERIES_SMALL") && atoi(getenv("FTKX_SERIES_SMALL")) == 0);
-  if (small_on) ftkx::launch_series_small(m, two_level ? ftkx::coarse_view(m) : m, d_steps, two_level, c->d_refine, c->d_list, c->h_hits, c->sr_results, nwords,
+  // (a pass that has just found far more survivors than the fused kernel takes does not launch it for a while: finding nothing to do
+  // costs its 256 workgroups of 256-VGPR wavefronts ~15 us)
+  const bool small_now = small_on && c->sr_skip_small == 0;
+  if (c->sr_skip_small > 0) c->sr_skip_small --;
+  if (small_now) ftkx::launch_series_small(m, two_level ? ftkx::coarse_view(m) : m, d_steps, two_level, c->d_refine, c->d_list, c->h_hits, c->sr_results, nwords,
                                           c->sr_h_results, flag, seq, reinterpret_cast<unsigned *>(c->d_counters + ftkx::CNT_SMALL_DONE), c->stream);
   if (two_level) ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
   ftkx::launch_exact(m, d_steps, 0, c->d_list, c->list_capacity, c->stream);
@@ -271,6 +275,7 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   }
   c->sr_last_path = (status & ftkx::SERIES_EARLY) ? 2 : 1;
   const u64 *cnt = R + ftkx::SR_COUNTERS;
+  if (!(status & ftkx::SERIES_EARLY) && (two_level ? cnt[ftkx::CNT_REFINE_PEAK] : cnt[ftkx::CNT_LIST_PEAK]) > 4 * 2048ull) c->sr_skip_small = 16;
   const size_t nrec = (size_t)R[ftkx::SR_NHITS];
   memset(&c->stats, 0, sizeof(c->stats));
   {

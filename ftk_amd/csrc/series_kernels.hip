@@ -55,17 +55,22 @@ __global__ __launch_bounds__(1024) void series_factors_kernel(Fields *__restrict
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) s_status = 0;
   __syncthreads();
-  for (int j = wv; j < nslices; j += 16) {             // a wavefront per slice
-    const SeriesSlice sl = slices[j];
+  for (int j0 = 0; j0 < nslices; j0 += 64) {           // sixteen lanes per slice, four {min, max} slots per lane: 64 slices per round
+    const int j = j0 + (tid >> 4), sub = tid & 15;
     u64 mn = 0x7fefffffffffffffull, mxb = 0ull;
-    if (sl.red_index >= 0) {
-      mn = red[(size_t)sl.red_index * 128 + 2 * lane]; mxb = red[(size_t)sl.red_index * 128 + 2 * lane + 1];
-      for (int o = 32; o > 0; o >>= 1) {               // bit patterns of non-negative doubles order like the values
-        const u64 a = __shfl_down(mn, o), b = __shfl_down(mxb, o);
-        mn = a < mn ? a : mn; mxb = b > mxb ? b : mxb;
-      }
+    SeriesSlice sl;
+    sl.red_index = -1; sl.known_res = 0; sl.known_max = 0; sl.t = 0;
+    if (j < nslices) sl = slices[j];
+    if (j < nslices && sl.red_index >= 0) {
+      const u64 *r = red + (size_t)sl.red_index * 128 + (size_t)sub * 8;
+#pragma unroll
+      for (int q = 0; q < 4; q ++) { const u64 a = r[2 * q], b = r[2 * q + 1]; mn = a < mn ? a : mn; mxb = b > mxb ? b : mxb; }   // (bit patterns of non-negative doubles order like the values)
     }
-    if (lane == 0) {
+    for (int o = 8; o > 0; o >>= 1) {
+      const u64 a = __shfl_xor(mn, o), b = __shfl_xor(mxb, o);
+      mn = a < mn ? a : mn; mxb = b > mxb ? b : mxb;
+    }
+    if (sub == 0 && j < nslices) {
       double r = __longlong_as_double((long long)mn), x = __longlong_as_double((long long)mxb);
       if (sl.known_res < r) r = sl.known_res;
       if (sl.known_max > x) x = sl.known_max;
@@ -109,6 +114,19 @@ __global__ __launch_bounds__(1024) void series_factors_kernel(Fields *__restrict
   if (tid == 0 && s_status) atomicOr((unsigned long long *)&results[SR_STATUS], (unsigned long long)s_status);
 }
 
+// inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts and row broadcasts (no LDS crossbar: __shfl_up is a
+// ds_bpermute, ~100 cycles a step, and the scan kernel does 64 of these scans back to back)
+__device__ inline unsigned wave_inclusive_sum(unsigned v)
+{
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8: every row of 16 lanes scanned
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // ---- ordering without a sort ---------------------------------------------------------------------------------------------------------
 // counts per bucket -> offsets (exclusive scan).  One workgroup of 16 wavefronts; a wavefront owns a contiguous sixteenth of the bins
 // and walks it in rows of 64 consecutive bins (every load and store is one contiguous 256-byte run): a first pass for the wavefront's
@@ -125,8 +143,8 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(unsigned *__restrict_
   if (tid == 0) s_max = 0;
   __syncthreads();
   unsigned sum = 0, mxc = 0;
-#pragma unroll 8
-  for (unsigned r = 0; r < rows; r ++) {
+#pragma unroll 32
+  for (unsigned r = 0; r < rows; r ++) {                 // (an L2 hit is ~1 us away on this part: as many loads in flight as registers allow)
     const unsigned i = base + 64u * r + lane;
     const unsigned v = i < nbins ? hist[i] : 0u;
     sum += v; mxc = v > mxc ? v : mxc;
@@ -136,17 +154,16 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(unsigned *__restrict_
   __syncthreads();
   unsigned carry = 0;
   for (unsigned q = 0; q < wv; q ++) carry += s_wave[q];
-  for (unsigned r0 = 0; r0 < rows; r0 += 8) {            // eight rows' loads in flight, then their scans
-    unsigned v[8];
+  for (unsigned r0 = 0; r0 < rows; r0 += 16) {           // sixteen rows' loads in flight, then their scans
+    unsigned v[16];
 #pragma unroll
-    for (int k = 0; k < 8; k ++) { const unsigned i = base + 64u * (r0 + (unsigned)k) + lane; v[k] = (r0 + (unsigned)k < rows && i < nbins) ? hist[i] : 0u; }
+    for (int k = 0; k < 16; k ++) { const unsigned i = base + 64u * (r0 + (unsigned)k) + lane; v[k] = (r0 + (unsigned)k < rows && i < nbins) ? hist[i] : 0u; }
 #pragma unroll
-    for (int k = 0; k < 8; k ++) {
+    for (int k = 0; k < 16; k ++) {
       const unsigned i = base + 64u * (r0 + (unsigned)k) + lane;
-      unsigned incl = v[k];
-      for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= (unsigned)o) incl += up; }
+      const unsigned incl = wave_inclusive_sum(v[k]);
       if (r0 + (unsigned)k < rows && i < nbins) { boff[i] = carry + incl - v[k]; hist[i] = 0u; }
-      carry += __shfl(incl, 63);
+      carry += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
     }
   }
   if (tid == 1023) boff[nbins] = carry;                  // (the last wavefront's carry is the total)
@@ -167,22 +184,41 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const u64 *__restri
   }
 }
 
-// the descriptors of a bucket in order: every descriptor counts the smaller ones of its bucket and takes that place.  Buckets fuller
+// the descriptors of a bucket in order: every descriptor counts the smaller ones of its bucket and takes that place.  A workgroup takes
+// 256 consecutive positions; the buckets they lie in form one contiguous span of the array, which is staged in LDS when it fits (hits
+// cluster: a bucket of a hit-dense series holds hundreds of descriptors, and every one of them reads all of them).  Buckets fuller
 // than rank_max stay as they are (SERIES_FIX_ORDER: the host orders those runs of the output).
 __global__ __launch_bounds__(256) void bucket_rank_kernel(const u64 *__restrict__ bucketed, u64 capacity, const unsigned *__restrict__ boff, int shift, unsigned rank_max,
                                                           u64 *__restrict__ sorted, const u64 *__restrict__ counters, u64 *__restrict__ results)
 {
+  constexpr unsigned SPAN = 4096;
+  __shared__ u64 s_keys[SPAN];
+  __shared__ unsigned s_lo, s_hi;
   if (counters[CNT_SERIES_DONE]) return;
   u64 count = counters[CNT_PASS];
   if (count > capacity) count = capacity;
   if (blockIdx.x == 0 && threadIdx.x == 0 && counters[CNT_BUCKET_MAX] > rank_max) atomicOr((unsigned long long *)&results[SR_STATUS], (unsigned long long)SERIES_FIX_ORDER);
-  for (u64 p = (u64)blockIdx.x * 256 + threadIdx.x; p < count; p += (u64)gridDim.x * 256) {
-    const u64 key = bucketed[p];
-    const unsigned b = (unsigned)(key >> shift), lo = boff[b], hi = boff[b + 1];
+  for (u64 p0 = (u64)blockIdx.x * 256; p0 < count; p0 += (u64)gridDim.x * 256) {      // (block-uniform trip count)
+    const u64 p = p0 + threadIdx.x;
+    const bool mine = p < count;
+    const u64 key = mine ? bucketed[p] : 0ull;
+    unsigned lo = 0, hi = 0;
+    if (mine) { const unsigned b = (unsigned)(key >> shift); lo = boff[b]; hi = boff[b + 1]; }
+    __syncthreads();                                       // (the previous round's readers of s_keys are done)
+    if (threadIdx.x == 0) s_lo = lo;                       // the first position's bucket starts the span ...
+    const u64 plast = (p0 + 255 < count ? p0 + 255 : count - 1);
+    if (p == plast) s_hi = hi;                             // ... the last position's bucket ends it
+    __syncthreads();
+    const unsigned span_lo = s_lo, span_hi = s_hi;
+    const bool staged = span_hi - span_lo <= SPAN;
+    if (staged) for (unsigned q = span_lo + threadIdx.x; q < span_hi; q += 256) s_keys[q - span_lo] = bucketed[q];
+    __syncthreads();
+    if (!mine) continue;
     u64 at = p;
     if (hi - lo > 1 && hi - lo <= rank_max) {
       unsigned r = 0;
-      for (unsigned q = lo; q < hi; q ++) r += bucketed[q] < key ? 1u : 0u;
+      if (staged) for (unsigned q = lo; q < hi; q ++) r += s_keys[q - span_lo] < key ? 1u : 0u;
+      else for (unsigned q = lo; q < hi; q ++) r += bucketed[q] < key ? 1u : 0u;
       at = lo + r;
     }
     sorted[at] = key;
@@ -250,7 +286,7 @@ __global__ __launch_bounds__(kThreads) void series_record_kernel(const Mesh m, c
     const unsigned nvalid = count - p0 >= 64 ? 64u : (unsigned)(count - p0);
     u64 *dst = reinterpret_cast<u64 *>(out) + p0 * 9;
     for (unsigned w8 = lane; w8 < nvalid * 9; w8 += 64)
-      __hip_atomic_store(dst + w8, s_rec[wv][w8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(dst + w8, s_rec[wv][w8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (16-byte and non-temporal stores: the same 45 GB/s)
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -264,8 +300,9 @@ __global__ __launch_bounds__(kThreads) void series_record_kernel(const Mesh m, c
 // and the workgroup that finishes last puts the records in tag order while it copies them into the pinned host buffer, publishes the
 // results block, stores the flag the host waits for and raises CNT_SERIES_DONE, on which the kernels queued behind this one leave at
 // once.  With more survivors than that it changes nothing and leaves the pass to those kernels.
-constexpr int kSmallGrid = 2048;                         // workgroups
-constexpr unsigned kSmallPer = 1;                        // coarse cells (two-level) per workgroup; without summaries: 64 corners
+constexpr int kSmallGrid = 256;                          // workgroups: one per CU (256 VGPRs -- 1024 wavefronts are resident at a time, and the launch costs
+                                                         // hit-dense passes, where it finds nothing to do, a round of dispatches per 256 workgroups)
+constexpr unsigned kSmallPer = 8;                        // coarse cells (two-level) per workgroup at most, dealt round-robin; without summaries: 8 x 32 corners
 constexpr unsigned kSmallRank = 1024;                    // records the last workgroup ranks in LDS (more: SERIES_UNORDERED, the host sorts)
 
 template <int ND>
@@ -275,7 +312,7 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
                                                                 u64 *__restrict__ h_results /* pinned, coherent */, unsigned *flag, unsigned seq, unsigned *__restrict__ done)
 {
   constexpr int N = ND + 1, NVC = 1 << N, G = kThreads / NVC, NTYPES = fan_table<N>::NTYPES;
-  constexpr unsigned LIST_CAP = kSmallPer * 64, PASS_CAP = 2048;
+  constexpr unsigned LIST_CAP = kSmallPer * 32, PASS_CAP = 2048;
   __shared__ unsigned s_rank[kSmallRank];
   static_assert(G * NTYPES <= (int)PASS_CAP / 2, "a batch's worst case must fit twice");
   __shared__ u64 s_list[LIST_CAP];
@@ -292,7 +329,7 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
   const u64 count = m.counters[two_level ? CNT_REFINE_LIST : CNT_SURVIVOR_LIST];
   const u64 per = two_level ? (u64)kSmallPer : (u64)LIST_CAP;
   if (count > per * (u64)kSmallGrid) return;             // (the same for every workgroup) too much for this kernel: nothing has been changed
-  const unsigned nwork = count ? (unsigned)((count + per - 1) / per) : 1u;      // workgroups that take part (workgroup 0 always does: somebody must finish)
+  const unsigned nwork = count ? (count < (u64)kSmallGrid ? (unsigned)count : (unsigned)kSmallGrid) : 1u;   // workgroups that take part (workgroup 0 always does: somebody must finish)
   if (blockIdx.x >= nwork) return;
   if (tid == 0) { s_nlist = 0; s_npass = 0; s_tested = 0; }
   if (tid < NTYPES) {
@@ -301,15 +338,16 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
     s_tab[tid] = w;
   }
   __syncthreads();
-  const u64 first = (u64)blockIdx.x * per, last = first + per < count ? first + per : count;
+  // this workgroup's entries: blockIdx.x, + kSmallGrid, + 2 kSmallGrid, ... (at most `per` of them)
+  const u64 mine_n = count > (u64)blockIdx.x ? (count - 1 - (u64)blockIdx.x) / (u64)kSmallGrid + 1 : 0ull;
 
   // ---- refine (the second level of the cull, as refine_kernel does it): this workgroup's coarse cells, one lane per row of a cell ----
   if (two_level) {
     const int DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
     const u64 k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
     const u64 UR = (u64)m.u_rows, urows = (u64)((DH + m.u_rows - 1) / m.u_rows);
-    for (u64 idx = first * UR + tid; idx < last * UR; idx += kThreads) {
-      const u64 e = refine[idx / UR];
+    for (u64 idx = tid; idx < mine_n * UR; idx += kThreads) {
+      const u64 e = refine[(u64)blockIdx.x + (idx / UR) * (u64)kSmallGrid];
       const int step = (int)(e >> 44);
       const unsigned want = (unsigned)((e >> 40) & 3);
       u64 lin = e & 0xffffffffffull;
@@ -380,8 +418,8 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
       }
     }
   } else {
-    for (u64 i = first + tid; i < last; i += kThreads) s_list[i - first] = list[i];
-    if (tid == 0) s_nlist = last > first ? (unsigned)(last - first) : 0u;
+    for (u64 i = tid; i < mine_n; i += kThreads) s_list[i] = list[(u64)blockIdx.x + i * (u64)kSmallGrid];
+    if (tid == 0) s_nlist = (unsigned)mine_n;
   }
   __syncthreads();
   const unsigned nlist = s_nlist;

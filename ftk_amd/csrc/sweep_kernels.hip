@@ -1345,6 +1345,23 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
   constexpr int kListCounter = COARSE ? CNT_REFINE_LIST : CNT_SURVIVOR_LIST;
   __shared__ unsigned s_wave_total[4];
   __shared__ u64 s_block_base;
+  // 2D: the survivors of a workgroup's steps are parked in LDS and appended with ONE atomic at the end (or when the buffer could
+  // overflow): on hit-dense data every workgroup has survivors in every step, and the list counter is a single address -- 4 096
+  // returning atomics on it were half of this kernel's 40 us on 64 steps of 1024^2
+  constexpr unsigned STAGE_CAP = (ND == 2) ? 2048u : 1u;             // (a step's worst case: 256 lanes x 8 corners)
+  __shared__ u64 s_stage[STAGE_CAP];
+  __shared__ unsigned s_staged, s_run;
+  if (ND == 2) { if (threadIdx.x == 0) s_staged = 0; __syncthreads(); }
+  auto flush_stage = [&]() {                                   // called by the whole workgroup, after a barrier that made s_staged final
+    const unsigned n = s_staged;
+    if (threadIdx.x == 0) s_block_base = n ? atomicAdd(&m.counters[kListCounter], (u64)n) : 0ull;
+    __syncthreads();
+    const u64 base = s_block_base;
+    for (unsigned h = threadIdx.x; h < n; h += kThreads) if (base + h < list_capacity) list[base + h] = s_stage[h];
+    __syncthreads();
+    if (threadIdx.x == 0) s_staged = 0;
+    __syncthreads();
+  };
   constexpr u64 kAll = 0x3f3f3f3f3f3f3f3full, k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
   const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1441,8 +1458,8 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
       u64 pos;
       unsigned cnt;
       if constexpr (ND == 2) {
-        // hit-dense 2D data: most wavefronts have survivors, and one returning atomic per wavefront on the single list counter
-        // serialises at the memory side (0.2 ms for 64 steps of 1024^2).  One atomic per WORKGROUP instead: wave totals through LDS.
+        // hit-dense 2D data: most wavefronts have survivors.  Wave totals through LDS give every lane its place in the workgroup's
+        // staging buffer; the list counter is touched once per workgroup (flush_stage).
         if (__syncthreads_or(any != 0) == 0) continue;         // (block-uniform: no wavefront left the kernel, see the early exits above)
         cnt = (unsigned)__popcll(any);
         unsigned incl = cnt;
@@ -1452,10 +1469,22 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
         if (threadIdx.x == 0) {
           unsigned run = 0;
           for (int q = 0; q < 4; q ++) { const unsigned t = s_wave_total[q]; s_wave_total[q] = run; run += t; }
-          s_block_base = run ? atomicAdd(&m.counters[kListCounter], (u64)run) : 0ull;
+          s_run = run;
         }
         __syncthreads();
-        pos = s_block_base + s_wave_total[wv] + (incl - cnt);
+        if (s_staged + s_run > STAGE_CAP) flush_stage();       // (block-uniform)
+        unsigned at = s_staged + s_wave_total[wv] + (incl - cnt);
+        if (cnt) {
+          const u64 lin0 = row_lin;
+          for (int b = 0; b < 8; b ++) {
+            const unsigned fl = (unsigned)((surv_o >> (8 * b + 7)) & 1) | ((unsigned)((surv_i >> (8 * b + 7)) & 1) << 1);
+            if (!fl) continue;
+            s_stage[at ++] = (lin0 + (u64)(g * 8 + b + m.ext_st[0] - m.core_st[0])) | ((u64)fl << 40) | ((u64)s << 44);
+          }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_staged += s_run;
+        continue;                                              // (the staged entries go out at the end of the kernel)
       } else {
         if (__ballot(any != 0) == 0) continue;                 // the common case: nothing survives in this wavefront
         cnt = (unsigned)__popcll(any);
@@ -1480,6 +1509,7 @@ __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, cons
     }
     if (need_next) for (int zi = 0; zi < ZC; zi ++) cur[zi] = nxt[zi];
   }
+  if constexpr (ND == 2) { __syncthreads(); if (s_staged) flush_stage(); }   // (block-uniform)
 }
 
 // Second level of the two-level cull: one lane per refine-list entry (an aligned word of 8 corners whose summaries could not
@@ -2137,7 +2167,7 @@ static void launch_cull_level(const Mesh &m, const Fields *d_steps, int nsteps, 
   // steps per lane: consecutive steps reuse the shared slice from registers; more chunks = more parallelism
   // (3D: 4 -- a chunk re-reads one slice, a quarter more bytes of arrays that are 1/256 of the input, and gives four times the
   // wavefronts: the coarse cull of 256^3 x 16 0.052 -> 0.026 ms, of 512^3 x 32 0.089 -> 0.081 ms)
-  int step_chunk = m.nd == 3 ? 4 : 1;   // 2D slices are small and survivors common: prefer parallelism
+  int step_chunk = 4;   // (2D: the survivors of a workgroup's four steps leave with one atomic on the list counter)
   if (const char *e = getenv("FTKX_CULL_STEP_CHUNK")) step_chunk = atoi(e) > 0 ? atoi(e) : step_chunk;
   const int nsc = (nsteps + step_chunk - 1) / step_chunk;
   const dim3 grid((unsigned)((groups + GX - 1) / GX), (unsigned)((m.ext_sz[1] + rows_per_block - 1) / rows_per_block), (unsigned)(nzc * nsc));

@@ -214,7 +214,7 @@ int ftkx_invalidate_masks(ftkx_ctx *ctx);
 
 /* optional kernel timing with HIP events on the context's stream (for bench.py's roofline figure).  Index: 0 mask_kernel,
  * 1 cull_kernel, 2 exact_kernel, 3 tile_kernel; ms[] = summed device time, launches[] = launches timed since set_profiling(1). */
-int ftkx_set_profiling(ftkx_ctx *ctx, int on);
+int ftkx_set_profiling(ftkx_ctx *ctx, int on);      /* 0 off, 1 every kernel family, 2 the mask kernel only (an event pair costs the stream a few us) */
 int ftkx_get_kernel_times(const ftkx_ctx *ctx, double ms[4], unsigned long long launches[4]);
 
 /* ---- stateless one-shot calls with the reference boundary's argument list ------------------------------------ */
