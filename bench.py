@@ -152,6 +152,76 @@ def side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=5, warmup=2):
     return out
 
 
+def streaming_tracker(nd, case, dims, nt_run, torch, dev, ftk_amd, synthetic, host_steps=4):
+    """The drop-in's everyday use (critical_point_tracker_regular: push_*_snapshot / advance_timestep per timestep, the records of every
+    step on the host before the next push): per-step wall time with device-resident input, and the same fed from HOST arrays -- what the
+    reference's accelerator boundary hands over (critical_point_tracker_2d_regular.hh:369-384) -- as a rate against the box's own pinned
+    hipMemcpyAsync."""
+    T = ftk_amd.CriticalPointTracker3DRegular if nd == 3 else ftk_amd.CriticalPointTracker2DRegular
+
+    def make():
+        tr = T()
+        tr.set_scalar_field_source(ftk_amd.SOURCE_GIVEN); tr.set_vector_field_source(ftk_amd.SOURCE_DERIVED)
+        tr.set_jacobian_field_source(ftk_amd.SOURCE_DERIVED); tr.set_jacobian_symmetric(True)
+        tr.set_domain([2] * nd, [d - 3 for d in dims]); tr.set_array_domain([0] * nd, list(dims))
+        tr.set_tag_mode(ftk_amd.TAG_EXACT64)
+        tr.initialize()
+        return tr
+
+    def drive(tr, snaps):
+        n = len(snaps)
+        t0 = time.perf_counter()
+        for k in range(n):
+            tr.push_scalar_field_snapshot(snaps[k])
+            if k != 0:
+                tr.advance_timestep()
+            if k == n - 1:
+                tr.update_timestep()
+        return time.perf_counter() - t0
+
+    out = {}
+    dev_snaps = [synthetic.generate(case, dims, t, nt_run, torch, dev) for t in range(nt_run)]
+    torch.cuda.synchronize()
+    best = None
+    for rep in range(3):
+        tr = make()
+        dt = drive(tr, dev_snaps)
+        nrec = len(tr.get_critical_points()[0])
+        tr.close()
+        best = dt if best is None or dt < best else best
+    out["device_resident"] = {"timesteps": nt_run, "ms_per_step": best / nt_run * 1e3, "records": int(nrec),
+                              "note": "push (device pointer, copied into the tracker's slice buffer) + advance_timestep per step; best of 3 series"}
+    # host-fed: numpy arrays in pageable memory, like an ndarray<double> of the reference
+    h = min(host_steps, nt_run)
+    host_snaps = [dev_snaps[t].cpu().numpy() for t in range(h)]
+    bytes_each = host_snaps[0].nbytes
+    del dev_snaps
+    torch.cuda.empty_cache()
+    # the box's own rate: one pinned buffer, hipMemcpyAsync into a device buffer
+    pin = torch.empty(host_snaps[0].shape, dtype=torch.float64, pin_memory=True)
+    pin.copy_(torch.from_numpy(host_snaps[0]))
+    dst = torch.empty(host_snaps[0].shape, dtype=torch.float64, device=dev)
+    rates = []
+    for rep in range(4):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        dst.copy_(pin, non_blocking=True); torch.cuda.synchronize()
+        rates.append(bytes_each / (time.perf_counter() - t0) / 1e9)
+    pinned_rate = max(rates[1:])
+    del pin, dst
+    best = None
+    for rep in range(2):
+        tr = make()
+        dt = drive(tr, host_snaps)
+        tr.sync() if hasattr(tr, "sync") else None
+        torch.cuda.synchronize()
+        tr.close()
+        best = dt if best is None or dt < best else best
+    out["host_fed"] = {"timesteps": h, "bytes_per_step": bytes_each, "ms_per_step": best / h * 1e3, "GB/s": bytes_each * h / best / 1e9,
+                       "pinned_hipMemcpyAsync_GB/s": pinned_rate, "frac_of_pinned": bytes_each * h / best / 1e9 / pinned_rate,
+                       "note": "pageable host arrays (numpy), uploaded by the push; the sweep of every step included"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +239,7 @@ def main():
     ap.add_argument("--no-cull-ahead", action="store_true", help="experiment: do not announce the sweeps to slices_prepare (the cull then waits for the factors)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the kernels (what do they cost a pass?); the line then carries no roofline")
     ap.add_argument("--host-driven", action="store_true", help="N = 1: the host-driven batch (slices_prepare, factors on the host, enqueue, collect) instead of the device-driven ftkx_sweep_series")
+    ap.add_argument("--no-streaming-tracker", action="store_true", help="N = 1: skip the per-timestep tracker measurement (device-resident and host-fed) that follows the timed region")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the few passes of the other BASELINE configurations that follow the timed region")
     ap.add_argument("--dump-merged", default=None, help="rank 0 writes the merged records and the curves traced from them (npz)")
     args = ap.parse_args()
@@ -500,6 +571,15 @@ def main():
                 except Exception as e:   # noqa: BLE001
                     others[name] = {"error": repr(e)}
             out["configs"] = others
+        if world == 1 and not args.no_streaming_tracker and not args.exact_only and scalar_input:
+            for r in list(slices):
+                ctx.drop_slice(r)
+            slices.clear(); halo_buf = None
+            torch.cuda.empty_cache()
+            try:
+                out["streaming_tracker"] = streaming_tracker(nd, case, dims, min(nt, 12), torch, dev, ftk_amd, synthetic)
+            except Exception as e:   # noqa: BLE001
+                out["streaming_tracker"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             base, port = cpu_baseline(nd, case)
             out["cpu_baseline"] = base

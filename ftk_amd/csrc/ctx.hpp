@@ -220,6 +220,7 @@ bool pow2_factor(u64 factor);
 bool masks_valid(const ftkx_ctx *c, const Slice &s, u64 factor, bool two_level, int u_rows);
 double job_big(const ftkx_ctx *c, const Slice &s, u64 factor, bool *rule_on);
 int ensure_mask_arrays(ftkx_ctx *c, Slice &s, bool two_level);
+int upload_from_host(ftkx_ctx *c, void *dst, const void *src, size_t bytes);
 // prepare.hip
 void launch_init_red(u64 *red, size_t nslots, u64 *counters, hipStream_t st);        // {min = DBL_MAX, max = 0} slots; counters (nullable) zeroed
 void launch_fetch_desc(const void *pinned_src, void *device_dst, size_t bytes, hipStream_t st);   // pinned -> device by a kernel (bytes % 8 == 0)

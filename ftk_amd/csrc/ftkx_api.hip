@@ -255,6 +255,19 @@ double job_big(const ftkx_ctx *c, const Slice &s, u64 factor, bool *rule_on)
   return off ? HUGE_VAL : big_threshold(c->nd, factor);
 }
 
+// ---- host memory -> HBM -------------------------------------------------------------------------------------------------------------
+// The reference boundary hands HOST arrays over on every call (critical_point_tracker_2d_regular.hh:369-384; its CUDA back-end
+// cudaMemcpy's them from pageable memory, src/filters/critical_point_tracer_2d_regular.cu:194-232).  A 512^3 slice is 1 GiB: the
+// upload, not the sweep, is what such a call costs.  The runtime's own pageable copy runs at 96 % of a pinned hipMemcpyAsync on this
+// platform (54.6 of 56.8 GB/s measured, bench.py `streaming_tracker.host_fed`); a hand-made ring of pinned staging buffers filled by
+// eight host threads reached 33 GB/s and was dropped again.
+int upload_from_host(ftkx_ctx *c, void *dst, const void *src, size_t bytes)
+{
+  HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));            // (the caller may reuse its array on return)
+  return FTKX_OK;
+}
+
 int ensure_mask_arrays(ftkx_ctx *c, Slice &s, bool two_level)
 {
   if (!s.M) {
@@ -488,7 +501,8 @@ static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, con
     if (!*dst) HIP_TRY(c, hipMalloc((void **)dst, count * sizeof(double)));
     *own = true;
     // 0: host memory; 2: device memory of ANY device (a multi-device tracker hands one snapshot to two contexts), copied
-    HIP_TRY(c, hipMemcpyAsync(*dst, src, count * sizeof(double), on_device == 2 ? hipMemcpyDefault : hipMemcpyHostToDevice, c->stream));
+    if (on_device == 0) return upload_from_host(c, *dst, src, count * sizeof(double));
+    HIP_TRY(c, hipMemcpyAsync(*dst, src, count * sizeof(double), hipMemcpyDefault, c->stream));
     return FTKX_OK;
   };
   int rc;
@@ -499,7 +513,9 @@ static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, con
   }
   // scalar input: V = gradient2D/3D(S) is never materialised -- every kernel evaluates it where it needs it, with the
   // reference's exact operations (ndarray/grad.hh), so the slice costs 8 bytes per vertex of HBM instead of 8 + 8*nd.
-  if (on_device != 1) HIP_TRY(c, hipStreamSynchronize(c->stream));   // the source buffers may be reused by the caller on return
+  // the source buffers may be reused by the caller on return: a device source (2) has to be read first; a host source has been staged
+  // completely by upload_from_host (nothing to wait for: the DMAs run on while the caller produces its next snapshot)
+  if (on_device == 2) HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->slices[t] = s;
   c->scalar_mode = scalar_only ? 1 : 0;
   return FTKX_OK;

@@ -383,11 +383,20 @@ void critical_point_tracker_regular::update_timestep()
   if (!multi) {
     // (the step that follows is known before its factor is: announced, its cull is queued right behind the mask kernel of the
     // newly arrived snapshot and runs while the host waits for the reduction)
-    check(ftkx_sweep_announce(ctx, &current_timestep, &scope, 1));
-    update_vector_field_scaling_factor();
     const ftkx_cp_t *recs = nullptr;
     size_t n = 0;
-    check(ftkx_sweep(ctx, current_timestep, scope, vector_field_scaling_factor, &recs, &n));
+    if (field_data_snapshots.size() <= 2 && field_data_snapshots.front() == current_timestep) {
+      // The device-driven pass (ftkx_sweep_series): the newly arrived snapshot's masks and reduction, the sticky factor (formed on the
+      // device from the running minimum handed in), cull, exact test and records are queued at once and waited for once.
+      unsigned long long f = 0;
+      check(ftkx_sweep_series(ctx, &current_timestep, &scope, 1, &vector_field_resolution, &f, &recs, &n));
+      vector_field_scaling_factor = f;
+    } else {
+      // (more than two snapshots queued: the reference's factor takes every queued snapshot into account, critical_point_tracker.hh:853)
+      check(ftkx_sweep_announce(ctx, &current_timestep, &scope, 1));
+      update_vector_field_scaling_factor();
+      check(ftkx_sweep(ctx, current_timestep, scope, vector_field_scaling_factor, &recs, &n));
+    }
     take_records(recs, n, current_timestep);
     check(ftkx_get_stats(ctx, &last_stats));
     if (enable_streaming_trajectories && scope == FTKX_SCOPE_BOTH) grow();      // 2d:326-330, 3d:197-201: only after an interval sweep
