@@ -233,8 +233,13 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: dry run of the N>1 path (host-staged halo)")
     ap.add_argument("--single-device", action="store_true", help="all ranks on cuda:0 (dry run of the N>1 logic on a 1-GPU box)")
     ap.add_argument("--halo-in-loop", action="store_true", help="N > 1: re-send the slab-boundary slice inside every timed pass")
-    ap.add_argument("--compact-halo", action="store_true", help="N > 1: inside every timed pass, exchange sign masks + patches around the surviving cells instead of the boundary slice")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = one slab of the configuration's length per rank (series of nt*N timesteps); strong = the configuration's series cut into N slabs")
+    ap.add_argument("--compact-halo", dest="compact_halo", action="store_true", default=True,
+                    help="N > 1 (default): inside every timed pass, exchange sign masks + patches around the surviving cells instead of the boundary slice")
+    ap.add_argument("--full-halo", dest="compact_halo", action="store_false", help="N > 1: the boundary slice itself (before the timed region, or with --halo-in-loop inside it)")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong (default) = the configuration's own series cut into N slabs (c4 over 8 GPUs is BASELINE.json's literal 512^3 x 32 case); weak = one slab of the configuration's length per rank (series of nt*N timesteps)")
+    ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: skip the few weak-scaling passes reported as `other`")
+    ap.add_argument("--force-dist", action="store_true", help="take the several-rank code paths (process group, all_gather of the reductions, halo protocol, record gather) even with one rank")
     ap.add_argument("--timesteps", type=int, default=0, help="override the length of the series")
     ap.add_argument("--no-cull-ahead", action="store_true", help="experiment: do not announce the sweeps to slices_prepare (the cull then waits for the factors)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the kernels (what do they cost a pass?); the line then carries no roofline")
@@ -262,12 +267,36 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist       # take the several-rank code paths (collectives, halo protocol, record gather)
+    if multi:
+        if world == 1:                          # --force-dist without a launcher: a process group of one
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)      # backend "nccl" is RCCL on ROCm
         else:
             dist.init_process_group("gloo")
 
+    env = (torch, dist, ftk_amd, synthetic, tslab, world, rank, local_rank, dev, multi)
+    out = job(args, env)
+    if world > 1 and args.scaling == "strong" and not args.no_other_scaling:
+        # the other way to scale, for the record: every rank a slab of the configuration's whole length (weak scaling), a few passes
+        import copy
+        a2 = copy.copy(args)
+        a2.scaling, a2.steps, a2.warmup, a2.light = "weak", min(args.steps, 3), 1, True
+        o2 = job(a2, env)
+        if rank == 0:
+            out["other"] = {k: o2[k] for k in ("scaling", "steps", "ms_per_step", "value", "config", "halo_exchange", "roofline_end_to_end")}
+    if rank == 0:
+        print(json.dumps(out))
+    if multi:
+        dist.destroy_process_group()
+
+
+def job(args, env):
+    """one measurement: set-up, warm-up, timed passes, the JSON line's dictionary (rank 0; None elsewhere)"""
+    torch, dist, ftk_amd, synthetic, tslab, world, rank, local_rank, dev, multi = env
+    light = getattr(args, "light", False)
     nd, nv, case, dims, nt = CONFIGS[args.config]
     if args.timesteps > 0:
         nt = args.timesteps
@@ -292,7 +321,7 @@ def main():
         slices[t] = synthetic.generate(case, dims, t, nt, torch, dev)
         torch.cuda.synchronize()
         (ctx.push_scalar_slice if scalar_input else ctx.push_slice)(t, slices[t])
-    halo_buf = torch.empty_like(slices[own[0]]) if (world > 1 and own) else None
+    halo_buf = torch.empty_like(slices[own[0]]) if (multi and own) else None
     torch.cuda.synchronize()
 
     # One pass = the whole sweep from resident input to records on the host, INCLUDING what the reference does at the top of
@@ -316,7 +345,7 @@ def main():
         local_rm = ctx.slices_prepare(prep, 0)
         local_res = {t: local_rm[t][0] for t in own}
         local_rm = {t: local_rm[t] for t in own}
-        if world > 1:
+        if multi:
             return tslab.global_factors(local_res, nt, local_max={t: v[1] for t, v in local_rm.items()})
         return tslab.factors_from_resolutions([local_res[t] for t in range(nt)]), None, None
 
@@ -336,10 +365,10 @@ def main():
 
     halo_info = None
     compact_bytes = [0, 0, 0, 0]
-    if world > 1 and args.compact_halo:
+    if multi and args.compact_halo:
         args.halo_in_loop = False
         halo_info = {"compact": True, "in_timed_region": True}
-    elif world > 1:
+    elif multi:
         # input distribution (untimed region, reported separately): a first exchange warms RCCL up, the second one is timed
         for rep in range(2):
             dist.barrier(); torch.cuda.synchronize()
@@ -356,7 +385,7 @@ def main():
 
     def one_pass():
         ctx.invalidate_masks()      # every pass redoes ALL the work of the sweep: masks, reduction, factors, cull, exact test, download
-        if world == 1 and not args.host_driven:
+        if not multi and not args.host_driven:
             # one GPU: the device-driven pass -- masks + reduction, factors (on the device), cull, exact test, records, their order and
             # their way into the pinned host buffer queued at once; the host waits once (ftkx_sweep_series)
             tp0 = time.perf_counter()
@@ -366,19 +395,19 @@ def main():
             series_paths[p] = series_paths.get(p, 0) + 1
             one_pass.factors = f
             return recs, ctx.stats()
-        if world > 1 and own and args.halo_in_loop:
+        if multi and own and args.halo_in_loop:
             halo()
         tp0 = time.perf_counter()
-        f, _, _ = prepare_and_factors()
+        f, _, mx_all = prepare_and_factors()
         t_masked = None
-        if world > 1 and args.compact_halo:
+        if multi and args.compact_halo:
             # compact halo, step 1: the next slab's first slice arrives as sign masks only (they were just built by its owner)
-            t_masked, sb, rb = tslab.compact_halo_masks(ctx, own, nt, scalar_input)
+            t_masked, sb, rb = tslab.compact_halo_masks(ctx, own, nt, scalar_input, mask_factor=256, max_abs=mx_all)
             compact_bytes[0] += sb; compact_bytes[1] += rb
         te0 = time.perf_counter()
         if own:     # one call for the slab's sweeps (per-sweep calls through ctypes cost a hit-dense 2D pass 5 %)
             ctx.sweep_enqueue_many(ann_ts, ann_scopes, [f[t] for t in own])
-        if world > 1 and args.compact_halo:
+        if multi and args.compact_halo:
             # step 2: cull, then the input values around the boundary step's surviving cells from the slice's owner -- or, where
             # that would be more bytes than the slice (hit-dense data on small slices), the slice itself after all
             def push_full(t, buf):
@@ -398,7 +427,7 @@ def main():
         return recs, st
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -415,7 +444,7 @@ def main():
         recs, st = one_pass()
     barrier()
     elapsed = time.perf_counter() - tt0
-    if world > 1:
+    if multi:
         cdev = dev if args.backend == "nccl" else "cpu"
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -430,7 +459,7 @@ def main():
     torch.cuda.synchronize()
     ktimes = ctx.kernel_times()
     ktimes_all, k_all = None, 3
-    if not args.no_kernel_events and not (world > 1 and args.compact_halo):
+    if not args.no_kernel_events and not (multi and args.compact_halo):
         ctx.set_profiling(1)
         for _ in range(k_all):
             one_pass()
@@ -438,14 +467,14 @@ def main():
         ktimes_all = ctx.kernel_times()
         ctx.set_profiling(0)
 
-    if world > 1 and args.compact_halo:
+    if multi and args.compact_halo:
         halo_info.update({"bytes_sent_per_pass_this_rank": compact_bytes[0] / args.steps, "bytes_received_per_pass_this_rank": compact_bytes[1] / args.steps,
                           "cells_requested_per_pass_this_rank": compact_bytes[2] / args.steps,
                           "passes_that_fell_back_to_the_whole_slice": compact_bytes[3],
                           "full_slice_bytes": int(np.prod(dims)) * 8 * (1 if scalar_input else nd)})
     # N > 1: the other convention, for the record -- the slab-boundary slice re-sent inside every pass (same barriers, max over ranks)
     other = None
-    if world > 1 and not args.compact_halo:
+    if multi and not args.compact_halo and not light:
         k2 = min(args.steps, 3)
         flip = not args.halo_in_loop
         args.halo_in_loop = flip
@@ -464,7 +493,7 @@ def main():
     # ---- after the timed region: merge the slabs' hit buffers on rank 0 and run pass 2 on the merged set ("host merge of
     # hit buffers into the union_find / trace stage"; critical_point_tracker.hh:689-717).  Curves cross slab boundaries.
     tm0 = time.perf_counter()
-    merged = tslab.gather_records(np.array(recs), 0) if world > 1 else np.array(recs)
+    merged = tslab.gather_records(np.array(recs), 0) if multi else np.array(recs)
     tm1 = time.perf_counter()
     pass2 = None
     if rank == 0:
@@ -489,9 +518,10 @@ def main():
         check["types"] = sorted(set(int(v) for v in merged["type"]))
         check["curves"] = pass2["curves"]
 
+    out = None
     if rank == 0 and args.no_kernel_events:
-        print(json.dumps({"experiment": "no kernel events", "config": args.config, "ms_per_step": elapsed / args.steps * 1e3,
-                          "wall_breakdown_ms_per_pass": {"prepare": host_ms[2] / args.steps, "enqueue": host_ms[0] / args.steps, "collect": host_ms[1] / args.steps}}))
+        out = {"experiment": "no kernel events", "config": args.config, "ms_per_step": elapsed / args.steps * 1e3,
+               "wall_breakdown_ms_per_pass": {"prepare": host_ms[2] / args.steps, "enqueue": host_ms[0] / args.steps, "collect": host_ms[1] / args.steps}}
     elif rank == 0:
         n_vertex = int(np.prod(dims))
         c = 1 if scalar_input else nd
@@ -553,7 +583,7 @@ def main():
             "stats": {"simplices_tested_exactly": n_tested, "cells_survived_cull": n_cells},
             "check": check,
         }
-        if world == 1 and not args.no_other_configs and not args.exact_only:
+        if not multi and not light and not args.no_other_configs and not args.exact_only:
             # every BASELINE configuration in the driver's line: the headline fields stay on --config (c4); the others get a few passes each
             for r in list(slices):
                 ctx.drop_slice(r)
@@ -571,7 +601,7 @@ def main():
                 except Exception as e:   # noqa: BLE001
                     others[name] = {"error": repr(e)}
             out["configs"] = others
-        if world == 1 and not args.no_streaming_tracker and not args.exact_only and scalar_input:
+        if not multi and not light and not args.no_streaming_tracker and not args.exact_only and scalar_input:
             for r in list(slices):
                 ctx.drop_slice(r)
             slices.clear(); halo_buf = None
@@ -580,15 +610,15 @@ def main():
                 out["streaming_tracker"] = streaming_tracker(nd, case, dims, min(nt, 12), torch, dev, ftk_amd, synthetic)
             except Exception as e:   # noqa: BLE001
                 out["streaming_tracker"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not light and not args.no_cpu_baseline:
             base, port = cpu_baseline(nd, case)
             out["cpu_baseline"] = base
             if port:
                 out["cpu_port"] = port
-        print(json.dumps(out))
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    slices.clear()
+    torch.cuda.empty_cache()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -162,8 +162,23 @@ class Context:
 
     def push_masked_slice(self, t, scalar_input, U, idx, words, mask_factor, max_abs):
         self._keep[("masked", t)] = (U, idx, words)
-        self._ck(self._L.ftkx_push_masked_slice(self._h, int(t), int(bool(scalar_input)), U.data_ptr(), idx.data_ptr() if len(idx) else None,
+        self._ck(self._L.ftkx_push_masked_slice(self._h, int(t), int(bool(scalar_input)), U.data_ptr(), U.numel() * U.element_size(), idx.data_ptr() if len(idx) else None,
                                                 words.data_ptr() if len(words) else None, len(idx), int(mask_factor), float(max_abs), 1 if U.is_cuda else 0))
+
+    def packed_masks_bytes(self):
+        """size of a packed mask message for this context's mesh (0: the mesh has no summarised masks), word capacity"""
+        cap = C.c_size_t()
+        n = self._L.ftkx_packed_masks_bytes(self._h, C.byref(cap))
+        return int(n), int(cap.value)
+
+    def export_masks_packed(self, t, out):
+        """owner side: a prepared slice's masks as ONE message in `out` (uint8 tensor of packed_masks_bytes() bytes); a device tensor is
+        filled by work queued on the context's stream -- nothing is waited for"""
+        self._ck(self._L.ftkx_export_masks_packed(self._h, int(t), out.data_ptr(), 1 if out.is_cuda else 0))
+
+    def push_masked_slice_packed(self, t, scalar_input, buf, mask_factor, max_abs):
+        self._keep[("masked", t)] = buf
+        self._ck(self._L.ftkx_push_masked_slice_packed(self._h, int(t), int(bool(scalar_input)), buf.data_ptr(), 1 if buf.is_cuda else 0, int(mask_factor), float(max_abs)))
 
     def sweep_cull(self, t_masked, torch, device):
         """receiver side, after sweep_enqueue: the cells (int64 tensor of core-linear indices) whose exact test reads the masked slice"""

@@ -27,7 +27,9 @@ void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, 
 void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64 *d_list, u64 cap, hipStream_t stream);
 void launch_records(const Mesh &m, const Fields *d_fields, hipStream_t stream);
 void launch_compact_words(const Mesh &m, const unsigned char *U, const unsigned char *M, unsigned *idx, u64 *words, u64 capacity, u64 *counter, hipStream_t st);
-void launch_scatter_words(const unsigned *idx, const u64 *words, size_t n, unsigned char *M, hipStream_t st);
+void launch_scatter_words(const unsigned *idx, const u64 *words, size_t n, unsigned char *M, size_t mask_words, u64 *bad, hipStream_t st);
+void launch_packed_header(u64 *hdr, const u64 *counter, u64 u_bytes, u64 capacity, hipStream_t st);
+void launch_scatter_packed(const u64 *hdr, const unsigned *idx, const u64 *words, u64 u_bytes, u64 capacity, unsigned char *M, size_t mask_words, u64 *bad, hipStream_t st);
 void launch_sparse_cells(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, const double *sparse, u64 *cells, u64 cells_cap, hipStream_t st);
 void launch_patches(const Mesh &m, bool scatter, const u64 *cells, size_t n, int ncomp, double *field, double *patches, hipStream_t st);
 bool masks_have_summary(const Mesh &m);
@@ -157,6 +159,7 @@ struct ftkx_ctx {
   unsigned *d_word_idx = nullptr; u64 *d_words = nullptr; size_t words_cap = 0, n_words = 0; int words_t = -1;
   u64 *d_cells = nullptr; size_t cells_cap = 0, n_cells = 0;
   u64 *d_patch_cells = nullptr; double *d_patches = nullptr; size_t patch_cap = 0;   // staging for host-side callers
+  void *d_packed = nullptr; size_t packed_cap = 0;                                   // staging of a packed mask message for host-side callers
   // series pass (series.hip): results block (device + coherent pinned copy with the flag word behind it), ordering buffers
   u64 *sr_results = nullptr, *sr_h_results = nullptr;
   size_t sr_results_cap = 0, sr_h_results_cap = 0;     // words (the pinned copy also holds the fragile list; the flag lives behind it)

@@ -348,8 +348,9 @@ int ftkx_create(ftkx_ctx **out, int nd, int device_id)
     HIP_TRY(c, hipSetDevice(device_id));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
     c->stream = c->own_stream;
-    HIP_TRY(c, hipMalloc((void **)&c->d_counters, (ftkx::CNT_N + 128) * sizeof(u64)));
-    HIP_TRY(c, hipMemset(c->d_counters, 0, (ftkx::CNT_N + 128) * sizeof(u64)));
+    // CNT_N counters, 128 words of reduction slots, one word that says "a halo message did not fit this mesh" (halo.hip; survives the sweeps' resets)
+    HIP_TRY(c, hipMalloc((void **)&c->d_counters, (ftkx::CNT_N + 128 + 8) * sizeof(u64)));
+    HIP_TRY(c, hipMemset(c->d_counters, 0, (ftkx::CNT_N + 128 + 8) * sizeof(u64)));
     HIP_TRY(c, hipHostMalloc((void **)&c->h_counters, ftkx::CNT_N * sizeof(u64), hipHostMallocDefault));
     return FTKX_OK;
   };
@@ -375,7 +376,7 @@ void ftkx_destroy(ftkx_ctx *c)
   if (c->d_hits) (void)hipFree(c->d_hits);
   if (c->d_pass) (void)hipFree(c->d_pass);
   if (c->d_fragile) (void)hipFree(c->d_fragile);
-  for (void *p : {(void *)c->d_word_idx, (void *)c->d_words, (void *)c->d_cells, (void *)c->d_patch_cells, (void *)c->d_patches}) if (p) (void)hipFree(p);
+  for (void *p : {(void *)c->d_word_idx, (void *)c->d_words, (void *)c->d_cells, (void *)c->d_patch_cells, (void *)c->d_patches, c->d_packed}) if (p) (void)hipFree(p);
   for (void *p : {(void *)c->sr_results, (void *)c->sr_hist, (void *)c->sr_boff, (void *)c->sr_bucketed, (void *)c->sr_sorted}) if (p) (void)hipFree(p);
   if (c->sr_h_results) (void)hipHostFree(c->sr_h_results);
   if (c->d_list) (void)hipFree(c->d_list);

@@ -65,7 +65,15 @@ int ftkx_export_masks(ftkx_ctx *c, int t, void *U_dst, unsigned *word_index_dst,
   return FTKX_OK;
 }
 
-int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, const unsigned *word_index, const unsigned long long *words, size_t n_words,
+namespace {
+u64 *halo_bad_flag(ftkx_ctx *c) { return c->d_counters + ftkx::CNT_N + 128; }
+size_t pad8(size_t v) { return (v + 7) / 8 * 8; }
+// capacity of the word list in a packed mask message: the mask kernels write a word only where its summary is 0 -- a thin shell around
+// the zero sets of the components; 1/64 of all words is generous for smooth data, and a slice that needs more is sent as it is
+size_t packed_word_capacity(const ftkx_ctx *c) { return std::max<size_t>(4096, mask_bytes(c) / 8 / 64); }
+}
+
+int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, size_t u_bytes_given, const unsigned *word_index, const unsigned long long *words, size_t n_words,
                            unsigned long long mask_factor, double max_abs, int on_device)
 {
   if (c) c->ahead.clear();
@@ -80,6 +88,10 @@ int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, 
   c->scalar_mode = scalar_input ? 1 : 0;
   Mesh m; fill_mesh(c, m);
   if (!ftkx::masks_have_summary(m)) { c->scalar_mode = saved_mode; return fail(c, FTKX_E_UNSUPPORTED, "ftkx_push_masked_slice: this mesh has no summarised masks"); }
+  // (the summary array's size follows from the mesh AND the mask settings -- rows per summary byte: a sender configured differently
+  // must not be read past its buffer, nor be taken for what it is not)
+  if (u_bytes_given != u_bytes_used(c, m)) { c->scalar_mode = saved_mode; return fail(c, FTKX_E_INVALID, "ftkx_push_masked_slice: %zu summary bytes given, this mesh has %zu (different extents or FTKX_MASK_* settings on the sender?)", u_bytes_given, u_bytes_used(c, m)); }
+  if (n_words > mask_bytes(c) / 8) { c->scalar_mode = saved_mode; return fail(c, FTKX_E_INVALID, "ftkx_push_masked_slice: more mask words (%zu) than the slice has", n_words); }
   auto it = c->slices.find(t);
   Slice s;
   if (it != c->slices.end() && it->second.sparse) { s = it->second; c->slices.erase(it); }          // the same halo slice again: keep its arrays
@@ -110,16 +122,112 @@ int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, 
     c->words_t = -1;
     HIP_TRY(c, hipMemcpyAsync(c->d_word_idx, word_index, n_words * sizeof(unsigned), kind, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_words, words, n_words * sizeof(u64), kind, c->stream));
-    ftkx::launch_scatter_words(c->d_word_idx, c->d_words, n_words, s.M, c->stream);
+    HIP_TRY(c, hipMemsetAsync(halo_bad_flag(c), 0, sizeof(u64), c->stream));
+    ftkx::launch_scatter_words(c->d_word_idx, c->d_words, n_words, s.M, mask_bytes(c) / 8, halo_bad_flag(c), c->stream);
     HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters, halo_bad_flag(c), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (n_words && c->h_counters[0]) return fail(c, FTKX_E_INVALID, "ftkx_push_masked_slice: word indices outside the mask array (a sender with another mesh?)");
   return FTKX_OK;
   };
   const int frc = fill();
   if (frc != FTKX_OK) { free_slice(s, c); c->scalar_mode = saved_mode; return frc; }
   s.mask_factor = mask_factor; s.mask_big = false; s.u_rows = m.u_rows;
   s.maxabs = max_abs;                                                                  // (all a masked slice knows of its values)
+  c->slices[t] = s;
+  return FTKX_OK;
+}
+
+// ---- the same hand-over as ONE message whose numbers stay on the device ------------------------------------------------------------
+size_t ftkx_packed_masks_bytes(const ftkx_ctx *c, size_t *word_capacity)
+{
+  if (!c || !c->mesh_set) return 0;
+  Mesh m; fill_mesh(c, m);
+  if (!ftkx::masks_have_summary(m)) return 0;
+  const size_t cap = packed_word_capacity(c);
+  if (word_capacity) *word_capacity = cap;
+  return 32 + pad8(u_bytes_used(c, m)) + pad8(cap * sizeof(unsigned)) + cap * sizeof(u64);
+}
+
+int ftkx_export_masks_packed(ftkx_ctx *c, int t, void *dst, int dst_on_device)
+{
+  if (c) c->ahead.clear();
+  if (!c || !dst) return fail(c, FTKX_E_INVALID, "null argument");
+  auto it = c->slices.find(t);
+  if (it == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "ftkx_export_masks_packed: timestep %d not resident", t);
+  Slice &s = it->second;
+  if (!s.M || !s.U || !s.mask_factor || !s.max_known())
+    return fail(c, FTKX_E_UNSUPPORTED, "ftkx_export_masks_packed: slice %d has no summarised masks (ftkx_slices_prepare first; needs a mesh the two-level cull supports)", t);
+  HIP_TRY(c, hipSetDevice(c->device));
+  Mesh m; fill_mesh(c, m);
+  size_t cap = 0;
+  const size_t total = ftkx_packed_masks_bytes(c, &cap), ub = u_bytes_used(c, m);
+  char *out = (char *)dst;
+  if (!dst_on_device) {                                    // host-side callers (gloo): build it in device memory, copy out
+    if (c->packed_cap < total) { if (c->d_packed) (void)hipFree(c->d_packed); c->d_packed = nullptr; c->packed_cap = 0; HIP_TRY(c, hipMalloc(&c->d_packed, total)); c->packed_cap = total; }
+    out = (char *)c->d_packed;
+  }
+  unsigned *idx = (unsigned *)(out + 32 + pad8(ub));
+  u64 *words = (u64 *)(out + 32 + pad8(ub) + pad8(cap * sizeof(unsigned)));
+  HIP_TRY(c, hipMemsetAsync(c->d_counters + ftkx::CNT_SPARSE, 0, sizeof(u64), c->stream));
+  ftkx::launch_compact_words(m, s.U, s.M, idx, words, cap, c->d_counters + ftkx::CNT_SPARSE, c->stream);
+  HIP_TRY(c, hipMemcpyAsync(out + 32, s.U, ub, hipMemcpyDeviceToDevice, c->stream));
+  ftkx::launch_packed_header((u64 *)out, c->d_counters + ftkx::CNT_SPARSE, ub, cap, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  if (!dst_on_device) { HIP_TRY(c, hipMemcpyAsync(dst, out, total, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(c, hipStreamSynchronize(c->stream)); }
+  return FTKX_OK;                                          // (device destination: queued on the context's stream, nothing waited for)
+}
+
+int ftkx_push_masked_slice_packed(ftkx_ctx *c, int t, int scalar_input, const void *src, int src_on_device, unsigned long long mask_factor, double max_abs)
+{
+  if (c) c->ahead.clear();
+  if (!c || !src) return fail(c, FTKX_E_INVALID, "null argument");
+  if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "push: call ftkx_set_mesh first");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "push: sweeps pending, collect first");
+  if (t < 0 || !pow2_factor(mask_factor) || !(max_abs >= 0)) return fail(c, FTKX_E_INVALID, "ftkx_push_masked_slice_packed: bad arguments");
+  if (c->slices.empty()) c->scalar_mode = -1;
+  if (c->scalar_mode >= 0 && c->scalar_mode != (scalar_input ? 1 : 0)) return fail(c, FTKX_E_INVALID, "push: scalar and vector slices cannot be mixed in one context");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int saved_mode = c->scalar_mode;
+  c->scalar_mode = scalar_input ? 1 : 0;
+  Mesh m; fill_mesh(c, m);
+  size_t cap = 0;
+  const size_t total = ftkx_packed_masks_bytes(c, &cap), ub = u_bytes_used(c, m);
+  if (!total) { c->scalar_mode = saved_mode; return fail(c, FTKX_E_UNSUPPORTED, "ftkx_push_masked_slice_packed: this mesh has no summarised masks"); }
+  auto it = c->slices.find(t);
+  Slice s;
+  if (it != c->slices.end() && it->second.sparse) { s = it->second; c->slices.erase(it); }          // the same halo slice again: keep its arrays
+  else if (it != c->slices.end()) { free_slice(it->second, c); c->slices.erase(it); }
+  const size_t n = n_vertices(c), ncomp = scalar_input ? 1 : (size_t)c->nd;
+  auto fill = [&]() -> int {
+    int rc;
+    if (!s.sparse) {
+      double **field = scalar_input ? &s.S : &s.V;
+      HIP_TRY(c, hipMalloc((void **)field, n * ncomp * sizeof(double)));
+      (scalar_input ? s.ownS : s.ownV) = true;
+      HIP_TRY(c, hipMemsetAsync(*field, 0, n * ncomp * sizeof(double), c->stream));      // only patches are ever read; zeros elsewhere, not garbage
+      if ((rc = ensure_mask_arrays(c, s, true))) return rc;
+      s.sparse = true;
+    }
+    const char *in = (const char *)src;
+    if (!src_on_device) {
+      if (c->packed_cap < total) { if (c->d_packed) (void)hipFree(c->d_packed); c->d_packed = nullptr; c->packed_cap = 0; HIP_TRY(c, hipMalloc(&c->d_packed, total)); c->packed_cap = total; }
+      HIP_TRY(c, hipMemcpyAsync(c->d_packed, src, total, hipMemcpyHostToDevice, c->stream));
+      in = (const char *)c->d_packed;
+    }
+    HIP_TRY(c, hipMemcpyAsync(s.U, in + 32, ub, hipMemcpyDeviceToDevice, c->stream));
+    // the words: count, geometry and every index are checked on the device; a message that does not fit raises the flag ftkx_sweep_cull looks at
+    ftkx::launch_scatter_packed((const u64 *)in, (const unsigned *)(in + 32 + pad8(ub)), (const u64 *)(in + 32 + pad8(ub) + pad8(cap * sizeof(unsigned))), ub, cap, s.M,
+                                mask_bytes(c) / 8, halo_bad_flag(c), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    if (!src_on_device) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FTKX_OK;
+  };
+  const int frc = fill();
+  if (frc != FTKX_OK) { free_slice(s, c); c->scalar_mode = saved_mode; return frc; }
+  s.mask_factor = mask_factor; s.mask_big = false; s.u_rows = m.u_rows;
+  s.maxabs = max_abs;
   c->slices[t] = s;
   return FTKX_OK;
 }
@@ -148,7 +256,13 @@ int ftkx_sweep_cull(ftkx_ctx *c, int t_sparse, size_t *n_cells)
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, ftkx::CNT_N * sizeof(u64), c->stream));
     if ((rc = run_batch(c, field))) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, ftkx::CNT_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    u64 halo_bad = 0;
+    HIP_TRY(c, hipMemcpyAsync(&halo_bad, halo_bad_flag(c), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (halo_bad) {      // the packed mask message of this slice did not fit (more words than it holds, or another geometry): its masks are incomplete
+      HIP_TRY(c, hipMemsetAsync(halo_bad_flag(c), 0, sizeof(u64), c->stream));
+      return fail(c, FTKX_E_NOSLICE, "ftkx_sweep_cull: the packed masks of halo slice %d were incomplete (send the slice itself)", t_sparse);
+    }
     for (auto &e : c->events) { ev_give(c, e.second.first); ev_give(c, e.second.second); }
     c->events.clear();
     const u64 listed = c->h_counters[ftkx::CNT_SURVIVOR_LIST], refined = std::max(c->h_counters[ftkx::CNT_REFINE_LIST], c->h_counters[ftkx::CNT_REFINE_PEAK]);

@@ -1817,10 +1817,37 @@ __global__ __launch_bounds__(kThreads) void compact_words_kernel(const Mesh m, c
   }
 }
 
-__global__ __launch_bounds__(kThreads) void scatter_words_kernel(const unsigned *__restrict__ idx, const u64 *__restrict__ words, size_t n, unsigned char *__restrict__ M)
+// (word indices come from another rank: anything outside the mask array is dropped and flagged, never written)
+__global__ __launch_bounds__(kThreads) void scatter_words_kernel(const unsigned *__restrict__ idx, const u64 *__restrict__ words, size_t n, unsigned char *__restrict__ M,
+                                                                 size_t mask_words, u64 *bad)
 {
   const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i < n) reinterpret_cast<u64 *>(M)[idx[i]] = words[i];
+  if (i >= n) return;
+  const size_t w = idx[i];
+  if (w < mask_words) reinterpret_cast<u64 *>(M)[w] = words[i];
+  else if (bad) atomicOr((unsigned long long *)bad, 1ull);
+}
+
+// Packed form of a slice's masks -- ONE message for the compact halo: u64 header {words, summary bytes, word capacity, magic}, the
+// summary array, the word indices (capacity entries), the words (capacity entries).  The header is written on the device (the count of
+// compacted words lives there) and read on the device: neither side waits for the other's numbers on the host.
+constexpr u64 kPackedMagic = 0x66746b786d61736bull;       // "ftkxmask"
+__global__ void packed_header_kernel(u64 *hdr, const u64 *counter, u64 u_bytes, u64 capacity)
+{ hdr[0] = *counter; hdr[1] = u_bytes; hdr[2] = capacity; hdr[3] = kPackedMagic; }
+
+__global__ __launch_bounds__(kThreads) void scatter_packed_kernel(const u64 *__restrict__ hdr, const unsigned *__restrict__ idx, const u64 *__restrict__ words,
+                                                                  u64 u_bytes, u64 capacity, unsigned char *__restrict__ M, size_t mask_words, u64 *bad)
+{
+  const u64 n = hdr[0];
+  if (hdr[1] != u_bytes || hdr[2] != capacity || hdr[3] != kPackedMagic || n > capacity) {   // another geometry, or more words than the message holds
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr((unsigned long long *)bad, 1ull);
+    return;
+  }
+  for (u64 i = (u64)blockIdx.x * kThreads + threadIdx.x; i < n; i += (u64)gridDim.x * kThreads) {
+    const size_t w = idx[i];
+    if (w < mask_words) reinterpret_cast<u64 *>(M)[w] = words[i];
+    else atomicOr((unsigned long long *)bad, 1ull);
+  }
 }
 
 // survivors of the cull whose interval sweep reads the slice `sparse` (by its S or V pointer): their corner index inside core
@@ -1875,8 +1902,12 @@ __global__ __launch_bounds__(kThreads) void patches_kernel(const Mesh m, const u
 
 void launch_compact_words(const Mesh &m, const unsigned char *U, const unsigned char *M, unsigned *idx, u64 *words, u64 capacity, u64 *counter, hipStream_t st)
 { hipLaunchKernelGGL(compact_words_kernel, dim3(256 * 8), dim3(kThreads), 0, st, m, U, M, idx, words, capacity, counter); }
-void launch_scatter_words(const unsigned *idx, const u64 *words, size_t n, unsigned char *M, hipStream_t st)
-{ if (n) hipLaunchKernelGGL(scatter_words_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, idx, words, n, M); }
+void launch_scatter_words(const unsigned *idx, const u64 *words, size_t n, unsigned char *M, size_t mask_words, u64 *bad, hipStream_t st)
+{ if (n) hipLaunchKernelGGL(scatter_words_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, idx, words, n, M, mask_words, bad); }
+void launch_packed_header(u64 *hdr, const u64 *counter, u64 u_bytes, u64 capacity, hipStream_t st)
+{ hipLaunchKernelGGL(packed_header_kernel, dim3(1), dim3(1), 0, st, hdr, counter, u_bytes, capacity); }
+void launch_scatter_packed(const u64 *hdr, const unsigned *idx, const u64 *words, u64 u_bytes, u64 capacity, unsigned char *M, size_t mask_words, u64 *bad, hipStream_t st)
+{ hipLaunchKernelGGL(scatter_packed_kernel, dim3(64), dim3(kThreads), 0, st, hdr, idx, words, u_bytes, capacity, M, mask_words, bad); }
 void launch_sparse_cells(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, const double *sparse, u64 *cells, u64 cells_cap, hipStream_t st)
 { hipLaunchKernelGGL(sparse_cells_kernel, dim3(256 * 2), dim3(kThreads), 0, st, m, d_steps, d_list, cap, sparse, cells, cells_cap); }
 void launch_patches(const Mesh &m, bool scatter, const u64 *cells, size_t n, int ncomp, double *field, double *patches, hipStream_t st)

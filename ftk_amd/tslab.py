@@ -109,10 +109,16 @@ def _p2p(ops):
             req.wait()
 
 
-def compact_halo_masks(ctx, own, nt, scalar_input, group=None):
+CELL_CAP = 4096      # cells a patch request carries; more survivors than that and the whole slice is cheaper anyway
+
+
+def compact_halo_masks(ctx, own, nt, scalar_input, group=None, mask_factor=256, max_abs=None):
     """Compact halo, step 1 (instead of exchange_halo's whole slice): every rank sends the sign masks of its FIRST slice -- the
-    summary array and the mask words the summaries do not describe (ftkx_export_masks; the slice must have been prepared) -- to the
-    owner of the preceding timestep, which pushes them as a masks-only slice.  Returns (t_masked or None, bytes sent, bytes received)."""
+    summary array and the mask words the summaries do not describe (the slice must have been prepared) -- to the owner of the
+    preceding timestep, which pushes them as a masks-only slice.  ONE message each way, of a size both sides know from the mesh
+    (ftkx_packed_masks_bytes); its header is written and read on the device, so neither side waits for the other's numbers.
+    mask_factor: the hint the slices were prepared under; max_abs: {t: max |v|} of every slice (the all_gather of the reductions).
+    Returns (t_masked or None, bytes sent, bytes received)."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -120,34 +126,21 @@ def compact_halo_masks(ctx, own, nt, scalar_input, group=None):
     t0, t1 = (own[0], own[-1] + 1) if own else (0, 0)
     send_to = owner_of(t0 - 1, nt, world) if own and t0 > 0 else None
     recv_from = owner_of(t1, nt, world) if own and t1 < nt else None
+    nbytes, _cap = ctx.packed_masks_bytes()
+    if nbytes == 0:
+        raise RuntimeError("compact halo: this mesh has no summarised masks")
     sent = received = 0
-    payload = None
     ops = []
     if send_to is not None:
-        U, idx, words, mf, mx = ctx.export_masks(t0, torch, dev)
-        payload = (U, idx, words)
-        head = torch.tensor([float(len(idx)), float(mf), float(mx), float(len(U))], dtype=torch.float64, device=dev)
-        ops.append(dist.P2POp(dist.isend, head, send_to, group))
+        out = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        ctx.export_masks_packed(t0, out)
+        ops.append(dist.P2POp(dist.isend, out, send_to, group)); sent += nbytes
     if recv_from is not None:
-        rhead = torch.zeros((4,), dtype=torch.float64, device=dev)
-        ops.append(dist.P2POp(dist.irecv, rhead, recv_from, group))
-    _p2p(ops)
-    ops = []
-    if send_to is not None:
-        for tns in payload:
-            if len(tns):
-                ops.append(dist.P2POp(dist.isend, tns, send_to, group)); sent += tns.numel() * tns.element_size()
-    if recv_from is not None:
-        n_words, mf, mx, ub = int(rhead[0].item()), int(rhead[1].item()), float(rhead[2].item()), int(rhead[3].item())
-        rU = torch.empty((ub,), dtype=torch.uint8, device=dev)
-        ridx = torch.empty((n_words,), dtype=torch.int32, device=dev)
-        rwords = torch.empty((n_words,), dtype=torch.int64, device=dev)
-        for tns in (rU, ridx, rwords):
-            if len(tns):
-                ops.append(dist.P2POp(dist.irecv, tns, recv_from, group)); received += tns.numel() * tns.element_size()
+        inn = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        ops.append(dist.P2POp(dist.irecv, inn, recv_from, group)); received += nbytes
     _p2p(ops)
     if recv_from is not None:
-        ctx.push_masked_slice(t1, scalar_input, rU, ridx, rwords, mf, mx)
+        ctx.push_masked_slice_packed(t1, scalar_input, inn, mask_factor, 0.0 if max_abs is None else float(max_abs[t1]))
         return t1, sent, received
     return None, sent, received
 
@@ -155,68 +148,63 @@ def compact_halo_masks(ctx, own, nt, scalar_input, group=None):
 def compact_halo_patches(ctx, own, nt, t_masked, first_slice=None, halo_buffer=None, push_full=None, group=None):
     """Compact halo, step 2 (after sweep_enqueue, before sweep_collect): cull; the cells whose exact test reads the masked slice go to
     its owner, which answers with the input values around them (6^nd vertices per cell); they are scattered into the masked slice.
-    Where that would move MORE than the slice itself (hit-dense data on small slices: thousands of surviving cells) the receiver
-    asks for the whole slice instead (count -1): the owner sends `first_slice`, the receiver takes it into `halo_buffer` and hands
-    it to `push_full(t, tensor)`, which must cancel the pending sweeps (ftkx_sweep_cancel), push it like any other slice and leave
-    it to the caller to enqueue the sweeps again.
+    ONE round trip: a fixed-size request (count + up to CELL_CAP cells), a reply whose size both sides derive from the count.  Where
+    patches would move MORE than the slice itself (hit-dense data on small slices: thousands of surviving cells), or the packed masks
+    did not fit their message, the receiver asks for the whole slice instead (count -1): the owner sends `first_slice`, the receiver
+    takes it into `halo_buffer` and hands it to `push_full(t, tensor)`, which must cancel the pending sweeps (ftkx_sweep_cancel), push
+    it like any other slice and leave it to the caller to enqueue the sweeps again.
     Returns (cells requested or -1, bytes sent, bytes received)."""
     import torch
     import torch.distributed as dist
+    from . import FtkxError
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     t0, t1 = (own[0], own[-1] + 1) if own else (0, 0)
     serve = owner_of(t0 - 1, nt, world) if own and t0 > 0 else None          # the rank that holds OUR first slice as masks only
     ask = owner_of(t1, nt, world) if t_masked is not None else None
     sent = received = 0
-    cells = ctx.sweep_cull(t_masked, torch, dev) if ask is not None else None
-    want_full = False
-    if ask is not None and halo_buffer is not None and push_full is not None:
-        want_full = len(cells) * ctx.patch_doubles() * 8 > halo_buffer.numel() * halo_buffer.element_size() // 2
+    cells, want_full = None, False
+    if ask is not None:
+        try:
+            cells = ctx.sweep_cull(t_masked, torch, dev)
+        except FtkxError:              # the masks did not fit their message (or do not serve this factor): the slice itself
+            cells, want_full = torch.zeros((0,), dtype=torch.int64, device=dev), True
+        if halo_buffer is not None and push_full is not None:
+            want_full = want_full or len(cells) > CELL_CAP or len(cells) * ctx.patch_doubles() * 8 > halo_buffer.numel() * halo_buffer.element_size() // 2
+        elif want_full or len(cells) > CELL_CAP:
+            raise RuntimeError("compact halo: the whole slice is needed but no halo_buffer / push_full was given")
     ops = []
     if ask is not None:
-        ops.append(dist.P2POp(dist.isend, torch.tensor([-1 if want_full else len(cells)], dtype=torch.int64, device=dev), ask, group))
+        req = torch.zeros((1 + CELL_CAP,), dtype=torch.int64, device=dev)
+        req[0] = -1 if want_full else len(cells)
+        if not want_full and len(cells):
+            req[1:1 + len(cells)] = cells
+        ops.append(dist.P2POp(dist.isend, req, ask, group)); sent += req.numel() * 8
     if serve is not None:
-        n_theirs = torch.zeros((1,), dtype=torch.int64, device=dev)
-        ops.append(dist.P2POp(dist.irecv, n_theirs, serve, group))
-    _p2p(ops)
-    serve_full = serve is not None and int(n_theirs.item()) < 0
-    if want_full or serve_full:
-        # the whole slice after all (staged through host memory when the backend cannot move device tensors)
-        staged = dist.get_backend(group) != "nccl"
-        ops = []
-        if serve_full:
-            src = first_slice.cpu() if (staged and first_slice.is_cuda) else first_slice
-            ops.append(dist.P2POp(dist.isend, src, serve, group)); sent += src.numel() * src.element_size()
-        if want_full:
-            dst = torch.empty(halo_buffer.shape, dtype=halo_buffer.dtype) if (staged and halo_buffer.is_cuda) else halo_buffer
-            ops.append(dist.P2POp(dist.irecv, dst, ask, group)); received += dst.numel() * dst.element_size()
-        _p2p(ops)
-        if want_full:
-            if dst is not halo_buffer:
-                halo_buffer.copy_(dst)
-            push_full(t_masked, halo_buffer)
-        # what is left for the patch exchange below: the side(s) that did not switch to the whole slice
-        if want_full:
-            ask = None
-        if serve_full:
-            serve = None
-    ops = []
-    if ask is not None and len(cells):
-        ops.append(dist.P2POp(dist.isend, cells, ask, group)); sent += cells.numel() * 8
-    theirs = None
-    if serve is not None and int(n_theirs.item()) > 0:
-        theirs = torch.empty((int(n_theirs.item()),), dtype=torch.int64, device=dev)
+        theirs = torch.zeros((1 + CELL_CAP,), dtype=torch.int64, device=dev)
         ops.append(dist.P2POp(dist.irecv, theirs, serve, group)); received += theirs.numel() * 8
     _p2p(ops)
+    n_theirs = int(theirs[0].item()) if serve is not None else 0              # (the one number the owner has to see on the host: it sizes the reply)
+    staged = dist.get_backend(group) != "nccl"
     ops = []
-    if theirs is not None:
-        out = ctx.gather_patches(t0, theirs, torch)
+    if serve is not None and n_theirs < 0:
+        src = first_slice.cpu() if (staged and first_slice.is_cuda) else first_slice
+        ops.append(dist.P2POp(dist.isend, src, serve, group)); sent += src.numel() * src.element_size()
+    elif serve is not None and n_theirs > 0:
+        out = ctx.gather_patches(t0, theirs[1:1 + n_theirs].contiguous(), torch)
         ops.append(dist.P2POp(dist.isend, out, serve, group)); sent += out.numel() * 8
-    mine = None
-    if ask is not None and len(cells):
+    mine = dst = None
+    if ask is not None and want_full:
+        dst = torch.empty(halo_buffer.shape, dtype=halo_buffer.dtype) if (staged and halo_buffer.is_cuda) else halo_buffer
+        ops.append(dist.P2POp(dist.irecv, dst, ask, group)); received += dst.numel() * dst.element_size()
+    elif ask is not None and len(cells):
         mine = torch.empty((len(cells) * ctx.patch_doubles(),), dtype=torch.float64, device=dev)
         ops.append(dist.P2POp(dist.irecv, mine, ask, group)); received += mine.numel() * 8
     _p2p(ops)
+    if dst is not None:
+        if dst is not halo_buffer:
+            halo_buffer.copy_(dst)
+        push_full(t_masked, halo_buffer)
     if mine is not None:
         ctx.scatter_patches(t_masked, cells, mine)
     return (-1 if want_full else (len(cells) if cells is not None else 0)), sent, received

@@ -154,8 +154,18 @@ unsigned long long ftkx_scaling_factor(double resolution, int *nbits);
  * slice itself (ftkx_push_scalar_slice). */
 int ftkx_export_masks_size(ftkx_ctx *ctx, int t, size_t *u_bytes, size_t *n_words, unsigned long long *mask_factor, double *max_abs);
 int ftkx_export_masks(ftkx_ctx *ctx, int t, void *U_dst, unsigned *word_index_dst, unsigned long long *words_dst, int dst_on_device);
-int ftkx_push_masked_slice(ftkx_ctx *ctx, int t, int scalar_input, const void *U, const unsigned *word_index, const unsigned long long *words, size_t n_words,
+/* (u_bytes: the size of the summary array as the SENDER exported it; it must equal this context's -- same extents, same mask settings) */
+int ftkx_push_masked_slice(ftkx_ctx *ctx, int t, int scalar_input, const void *U, size_t u_bytes, const unsigned *word_index, const unsigned long long *words, size_t n_words,
                            unsigned long long mask_factor, double max_abs, int on_device);
+/* The same hand-over as ONE message of a size both sides know from the mesh alone (ftkx_packed_masks_bytes: 32-byte header, the summary
+ * array, a capacity-bounded list of mask words).  The owner's export is queued on its stream and the receiver's import reads the header
+ * -- word count, geometry -- ON THE DEVICE: neither side waits on the host for the other's numbers.  A message that did not fit (more
+ * words than its capacity, another geometry, an index outside the mask array) is found by ftkx_sweep_cull: FTKX_E_NOSLICE, send the
+ * slice itself.  mask_factor / max_abs: what the owner prepared the slice under (the factor hint) and its max |v| (it is part of the
+ * all_gather of the reductions every rank takes part in anyway). */
+size_t ftkx_packed_masks_bytes(const ftkx_ctx *ctx, size_t *word_capacity);
+int ftkx_export_masks_packed(ftkx_ctx *ctx, int t, void *dst, int dst_on_device);
+int ftkx_push_masked_slice_packed(ftkx_ctx *ctx, int t, int scalar_input, const void *src, int src_on_device, unsigned long long mask_factor, double max_abs);
 int ftkx_sweep_cull(ftkx_ctx *ctx, int t_masked, size_t *n_cells);
 int ftkx_get_sparse_cells(ftkx_ctx *ctx, unsigned long long *dst, int dst_on_device);
 size_t ftkx_patch_doubles(const ftkx_ctx *ctx);      /* doubles per cell in a patch buffer */

@@ -21,7 +21,7 @@ def _free_port():
 
 
 def _bench(n, cfg, extra=(), dump=None):
-    common = ["bench.py", "--gpus", str(n), "--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *extra]
+    common = ["bench.py", "--gpus", str(n), "--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-streaming-tracker", *extra]
     if dump:
         common += ["--dump-merged", str(dump)]
     if n == 1:
@@ -41,8 +41,8 @@ def test_slab_count_does_not_change_the_result(cfg, tmp_path):
     assert one["n_gpus"] == 1 and one["check"]["hits"] > 0
     ref = np.load(tmp_path / "one.npz")
     assert one["pass2"]["records"] == len(ref["records"]) == one["check"]["hits"] and one["pass2"]["curves"] == len(ref["curve_loop"]) > 0
-    for n, extra in ((2, ()), (3, ()), (2, ("--halo-in-loop",)), (2, ("--compact-halo",)), (3, ("--compact-halo",))):
-        many = _bench(n, cfg, ("--scaling", "strong") + extra, dump=tmp_path / f"many{n}.npz")
+    for n, extra in ((2, ("--full-halo",)), (3, ("--full-halo",)), (2, ("--full-halo", "--halo-in-loop")), (2, ("--compact-halo",)), (3, ())):
+        many = _bench(n, cfg, ("--no-other-scaling",) + extra, dump=tmp_path / f"many{n}.npz")
         got = np.load(tmp_path / f"many{n}.npz")
         # the merged record set (72-byte records, bit for bit) and the curves traced from it: identical to the single-rank run
         assert got["records"].tobytes() == ref["records"].tobytes()
@@ -52,7 +52,7 @@ def test_slab_count_does_not_change_the_result(cfg, tmp_path):
         assert many["n_gpus"] == n and many["scaling"] == "strong"
         assert many["check"]["hits"] == one["check"]["hits"]
         assert many["config"]["simplices_per_step"] == one["config"]["simplices_per_step"]
-        if "--compact-halo" in extra:
+        if "--full-halo" not in extra:         # (the compact halo is the default)
             # the boundary slice travelled as sign masks + patches around the surviving cells: a small fraction of its bytes
             h = many["halo_exchange"]
             moved = h["bytes_sent_per_pass_this_rank"] + h["bytes_received_per_pass_this_rank"]
@@ -62,19 +62,47 @@ def test_slab_count_does_not_change_the_result(cfg, tmp_path):
             else:                   # hit-dense 2D data on small slices: patches would be more bytes than the slice -> the protocol falls back to it
                 assert h["passes_that_fell_back_to_the_whole_slice"] > 0
         else:
-            assert many["halo_exchange"]["in_timed_region"] == (len(extra) > 0) and many["halo_exchange"]["bytes_per_rank"] > 0
+            assert many["halo_exchange"]["in_timed_region"] == ("--halo-in-loop" in extra) and many["halo_exchange"]["bytes_per_rank"] > 0
         assert many["config"]["nbits"] == one["config"]["nbits"]
 
 
-def test_weak_scaling_is_the_default_and_equals_the_long_series_on_one_rank(tmp_path):
-    """`bench.py --gpus N` without flags (what the driver runs): every rank sweeps a slab of the configuration's length, i.e. the series
-    is N times as long -- and the merged records / curves are those of that long series swept by one rank"""
+def test_strong_scaling_with_the_compact_halo_is_the_default_and_weak_scaling_is_reported_beside_it(tmp_path):
+    """`bench.py --gpus N` without flags (what the driver runs): BASELINE's literal configuration cut over the ranks (strong scaling),
+    the slab boundary exchanged as sign masks + patches inside the timed region; a few weak-scaling passes are reported as `other`.
+    `--scaling weak`: every rank sweeps a slab of the configuration's length, i.e. the series is N times as long -- and the merged
+    records / curves are those of that long series swept by one rank."""
+    many = _bench(2, "small3")
+    assert many["scaling"] == "strong" and many["n_gpus"] == 2
+    assert many["halo_exchange"]["compact"] is True and many["halo_exchange"]["in_timed_region"] is True
+    assert many["other"]["scaling"] == "weak" and many["other"]["value"] > 0 and "x16 " in many["other"]["config"]["workload"]
     nt = 8                                                        # small3
     one = _bench(1, "small3", ("--timesteps", str(3 * nt)), dump=tmp_path / "one.npz")
-    many = _bench(3, "small3", dump=tmp_path / "many.npz")
-    assert many["scaling"] == "weak" and one["scaling"] == "weak" and many["n_gpus"] == 3
-    assert many["config"]["simplices_per_step"] == one["config"]["simplices_per_step"] > 0
+    weak = _bench(3, "small3", ("--scaling", "weak"), dump=tmp_path / "many.npz")
+    assert weak["scaling"] == "weak" and weak["n_gpus"] == 3
+    assert weak["config"]["simplices_per_step"] == one["config"]["simplices_per_step"] > 0
     ref, got = np.load(tmp_path / "one.npz"), np.load(tmp_path / "many.npz")
     assert got["records"].tobytes() == ref["records"].tobytes() and len(ref["records"]) > 0
     for k in ("curve_offsets", "curve_indices", "curve_loop"):
         assert np.array_equal(got[k], ref[k]), k
+
+
+def test_the_collectives_run_on_rccl(tmp_path):
+    """One rank, `--force-dist --backend nccl`: init_process_group("nccl") (RCCL), the all_gather_into_tensor of the reductions, the
+    barriers, the all_reduce of the timings and the record gather execute on RCCL -- with nobody to talk to, but through the very calls
+    the driver's 8-GPU run makes -- and the result is the plain single-rank one."""
+    one = _bench(1, "small3", dump=tmp_path / "one.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, "bench.py", "--gpus", "1", "--config", "small3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--force-dist", "--backend", "nccl",
+           "--dump-merged", str(tmp_path / "rccl.npz")]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["halo_exchange"]["compact"] is True
+    assert "host-driven" in out["config"]["pass"]            # (several ranks form the factors on the host, after the all_gather)
+    ref, got = np.load(tmp_path / "one.npz"), np.load(tmp_path / "rccl.npz")
+    assert got["records"].tobytes() == ref["records"].tobytes() and len(ref["records"]) > 0
+    for full in (("--full-halo",), ("--full-halo", "--halo-in-loop")):
+        r = subprocess.run(cmd[:-2] + list(full), cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+
+
