@@ -49,6 +49,16 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def glibc_version():
+    try:
+        import ctypes
+        f = ctypes.CDLL(None).gnu_get_libc_version
+        f.restype = ctypes.c_char_p
+        return "glibc " + f().decode()
+    except Exception:   # noqa: BLE001
+        return "unknown"
+
+
 def me3d_params(dims):
     from ftk_amd import synthetic
     x0, dv = synthetic.moving_extremum_params(dims)
@@ -497,13 +507,12 @@ def job(args, env):
     tm1 = time.perf_counter()
     pass2 = None
     if rank == 0:
-        curves, loop, nspecial = ftk_amd.trace_curves(nd, dom, merged)
-        tm2 = time.perf_counter()
-        trajs = ftk_amd.post_process(nd, dom, merged)
-        tm3 = time.perf_counter()
+        ftk_amd.pass2(nd, dom, merged)                    # (first call: the worker threads start)
+        curves, loop, nspecial, trajs, ms_trace, ms_post = ftk_amd.pass2(nd, dom, merged)
         pass2 = {"records": int(len(merged)), "curves": len(curves), "branching_points_dropped": int(nspecial), "trajectories_after_post_process": len(trajs),
-                 "gather_ms": (tm1 - tm0) * 1e3, "trace_ms": (tm2 - tm1) * 1e3, "post_process_ms": (tm3 - tm2) * 1e3,
-                 "note": "untimed region: merge of the ranks' records on rank 0, ftkx_trace_curves and ftkx_post_process_curves on the merged set (host side)"}
+                 "gather_ms": (tm1 - tm0) * 1e3, "trace_ms": ms_trace, "post_process_ms": ms_post,
+                 "end_to_end_with_pass2_ms": elapsed / args.steps * 1e3 + ms_trace + ms_post,
+                 "note": "untimed region: merge of the ranks' records on rank 0, ftkx_trace_curves and ftkx_post_process_curves on the merged set (host threads; the C calls timed by themselves)"}
         if args.dump_merged:
             np.savez(args.dump_merged, records=merged, curve_offsets=np.cumsum([0] + [len(c) for c in curves]),
                      curve_indices=np.concatenate(curves) if curves else np.zeros(0, dtype=np.int64), curve_loop=np.asarray(loop))
@@ -582,6 +591,9 @@ def job(args, env):
                                            "collect_launch_sync_sort_download": host_ms[1] / args.steps},
             "stats": {"simplices_tested_exactly": n_tested, "cells_survived_cull": n_cells},
             "check": check,
+            # the C library of this box: the one corner of the record path that depends on it (the class of a 3D record with a near-singular
+            # Hessian, classified on the host with pow / acos / cos) is pinned by tests/test_gpu_libm.py against fixtures made with glibc 2.35
+            "host_libc": glibc_version(),
         }
         if not multi and not light and not args.no_other_configs and not args.exact_only:
             # every BASELINE configuration in the driver's line: the headline fields stay on --config (c4); the others get a few passes each

@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import (CP_DTYPE, FORMAT_BINARY, FORMAT_JSON, FORMAT_TEXT, SCOPE_BOTH, SCOPE_INTERVAL, SCOPE_ORDINAL, SOURCE_DERIVED, SOURCE_GIVEN, SOURCE_NONE,  # noqa: F401
                    TAG_EXACT64, TAG_REFERENCE, TAG_WORK_INDEX, FtkxError, Options, Stats)
 
-__all__ = ["trace_curves", "trace_and_post_process", "post_process", "TrajectorySet", "write_critical_points", "read_critical_points",
+__all__ = ["trace_curves", "pass2", "trace_and_post_process", "post_process", "TrajectorySet", "write_critical_points", "read_critical_points",
            "write_traced_critical_points", "read_traced_critical_points", "Context", "CriticalPointTracker2DRegular", "CriticalPointTracker3DRegular", "extract_cp2dt", "extract_cp3dt",
            "scaling_factor", "CP_DTYPE", "FtkxError"]
 
@@ -410,6 +410,30 @@ def post_process(nd, domain, records):
     ts = TrajectorySet._from_c(out)
     L.ftkx_free_trajectories(C.byref(out))
     return ts
+
+
+def pass2(nd, domain, records):
+    """ftkx_trace_curves, then ftkx_post_process_curves on its result, each timed by itself (the C calls only)
+    -> (curves as index arrays, loop flags, n_special, TrajectorySet, ms_trace, ms_post_process)"""
+    import time
+    L = _lib.load()
+    recs = np.ascontiguousarray(records, dtype=CP_DTYPE)
+    cur = _lib.Curves()
+    t0 = time.perf_counter()
+    _lib.check(L.ftkx_trace_curves(nd, _lib.ll(domain[0]), _lib.ll(domain[1], fill=1), recs.ctypes.data, len(recs), C.byref(cur)))
+    t1 = time.perf_counter()
+    out = _lib.Trajectories()
+    rc = L.ftkx_post_process_curves(recs.ctypes.data, len(recs), C.byref(cur), C.byref(out))
+    t2 = time.perf_counter()
+    offs = np.ctypeslib.as_array(cur.offsets, shape=(cur.n_curves + 1,)).copy()
+    idx = np.ctypeslib.as_array(cur.indices, shape=(max(1, cur.n_points),))[:cur.n_points].copy()
+    loop = np.ctypeslib.as_array(cur.loop, shape=(max(1, cur.n_curves),))[:cur.n_curves].copy()
+    nspecial = cur.n_special
+    L.ftkx_free_curves(C.byref(cur))
+    _lib.check(rc)
+    ts = TrajectorySet._from_c(out)
+    L.ftkx_free_trajectories(C.byref(out))
+    return [idx[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)], loop, nspecial, ts, (t1 - t0) * 1e3, (t2 - t1) * 1e3
 
 
 def trace_and_post_process(nd, domain, records):

@@ -2,6 +2,7 @@
 // snapshot window, sticky quantisation factor, ordinal + interval sweep per step, record bookkeeping.
 // Reference counterparts are cited per method.
 #include "../../include/ftkx_tracker.hh"
+#include "host_sort.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -162,33 +163,57 @@ critical_point_tracker_regular::~critical_point_tracker_regular()
   else ftkx_destroy(ctx);
 }
 
-void critical_point_tracker_regular::sync() const
+void critical_point_tracker_regular::wait_devices() const
 {
   if (multi) {
     multi->wait_all();
     multi->rethrow();
   }
+}
+
+void critical_point_tracker_regular::sync() const
+{
+  wait_devices();
   flush_points();
 }
 
-// the parked records into the ordered map: sorted by the element order's integer key first, so that a map that was empty is built
-// with end hints (linear), and later points overwrite earlier ones with the same tag like operator[] did
+// the parked records into the flat store: ordered by the element order's integer key, merged with what is there (a later point with
+// the same tag replaces the earlier one, like operator[] of the reference's map)
 void critical_point_tracker_regular::flush_points() const
 {
   if (pending_points.empty()) return;
-  const element_order ord = discrete_critical_points.key_comp();
-  std::vector<std::pair<std::pair<unsigned long long, unsigned long long>, size_t>> order(pending_points.size());
-  for (size_t i = 0; i < pending_points.size(); i ++) order[i] = {ord.key(pending_points[i].tag), i};
-  std::sort(order.begin(), order.end());
-  if (discrete_critical_points.empty()) {
-    for (const auto &o : order) {
-      const feature_point_t &cp = pending_points[o.second];
-      auto it = discrete_critical_points.emplace_hint(discrete_critical_points.end(), cp.tag, cp);
-      it->second = cp;
+  typedef std::pair<std::pair<unsigned long long, unsigned long long>, size_t> keyed;
+  std::vector<keyed> order(pending_points.size());
+  for (size_t i = 0; i < pending_points.size(); i ++) order[i] = {order_.key(pending_points[i].tag), i};
+  ftkx::sort_on_threads(order);                                  // (equal keys = equal tags: their insertion order, the index, breaks the tie)
+  std::vector<feature_point_t> merged;
+  std::vector<std::pair<unsigned long long, unsigned long long>> keys;
+  merged.reserve(points.size() + order.size()); keys.reserve(points.size() + order.size());
+  size_t a = 0, b = 0;
+  while (a < points.size() || b < order.size()) {
+    if (b < order.size() && b + 1 < order.size() && order[b + 1].first == order[b].first) { b ++; continue; }   // the later of two pending points with one tag
+    if (b == order.size() || (a < points.size() && point_keys[a] < order[b].first)) { merged.push_back(points[a]); keys.push_back(point_keys[a]); a ++; }
+    else {
+      if (a < points.size() && point_keys[a] == order[b].first) a ++;                                            // replaced
+      merged.push_back(pending_points[order[b].second]); keys.push_back(order[b].first); b ++;
     }
-  } else
-    for (const auto &o : order) discrete_critical_points[pending_points[o.second].tag] = pending_points[o.second];
+  }
+  points.swap(merged); point_keys.swap(keys);
   pending_points.clear();
+  pending_ascending = true;
+  map_valid = false;
+}
+
+const discrete_map_t &critical_point_tracker_regular::get_discrete_critical_points() const
+{
+  sync();
+  if (!map_valid) {
+    discrete_map_t fresh(order_);
+    for (const feature_point_t &cp : points) fresh.emplace_hint(fresh.end(), cp.tag, cp);     // (already in the map's order: linear)
+    discrete_critical_points.swap(fresh);
+    map_valid = true;
+  }
+  return discrete_critical_points;
 }
 
 int critical_point_tracker_regular::num_devices() const { return multi ? (int)multi->w.size() : 1; }
@@ -246,13 +271,18 @@ void critical_point_tracker_regular::initialize()
   sync();
   if (multi) { for (auto &W : multi->w) apply_configuration(W->ctx); }
   else apply_configuration(ctx);
-  // the discrete points are kept in the reference's element order, which needs the mesh sizes
-  element_order ord;
-  ord.nd = nd;
-  for (int d = 0; d < nd; d ++) ord.n[d] = domain.size(d);
-  discrete_map_t ordered(ord);
-  for (const auto &kv : discrete_critical_points) ordered.insert(kv);
-  discrete_critical_points.swap(ordered);
+  // the discrete points are kept in the reference's element order, which needs the mesh sizes: what is there is ordered afresh
+  order_.nd = nd;
+  for (int d = 0; d < nd; d ++) order_.n[d] = domain.size(d);
+  if (!points.empty()) {
+    std::vector<feature_point_t> again;
+    again.swap(points); point_keys.clear();
+    again.insert(again.end(), pending_points.begin(), pending_points.end());
+    pending_points.swap(again);
+    pending_ascending = false;
+  }
+  discrete_critical_points = discrete_map_t(order_);
+  map_valid = false;
   initialized = true;
 }
 
@@ -266,8 +296,9 @@ void critical_point_tracker_regular::reset()
   current_timestep = 0;
   while (pop_field_data_snapshot()) {}
   next_push_timestep = 0;
-  pending_points.clear();
-  discrete_critical_points.clear();
+  pending_points.clear(); pending_ascending = true;
+  points.clear(); point_keys.clear();
+  discrete_critical_points.clear(); map_valid = true;
 }
 
 // one snapshot -> the context(s) whose steps read it.  kind: 0 scalar (V derived), 1 vector, 2 all three given
@@ -372,7 +403,8 @@ void critical_point_tracker_regular::take_records(const ftkx_cp_t *recs, size_t 
     cp.ordinal = ftkx_cp_ordinal(&recs[i]) != 0;
     cp.timestep = timestep;
     if (scalar_field_source == SOURCE_NONE) cp.scalar[0] = 0.0;   // 2d:642-646: scalar only when a scalar field exists
-    pending_points.push_back(cp);                                 // -> discrete_critical_points at the next sync()
+    if (!pending_points.empty() && pending_points.back().tag >= cp.tag) pending_ascending = false;
+    pending_points.push_back(cp);                                 // -> the flat store at the next sync()
   }
 }
 
@@ -454,9 +486,8 @@ void critical_point_tracker_regular::grow()
   for (int d = 0; d < nd; d ++) { dst[d] = domain.start(d); dsz[d] = domain.size(d); }
   if (!online) { const int rc = ftkx_online_tracer_create(&online, nd, dst, dsz); if (rc != FTKX_OK) throw ftkx_error(rc, "online tracer"); }
   std::vector<ftkx_cp_t> recs;
-  recs.reserve(discrete_critical_points.size());
-  for (const auto &kv : discrete_critical_points) {
-    const feature_point_t &cp = kv.second;
+  recs.reserve(points.size());
+  for (const feature_point_t &cp : points) {
     ftkx_cp_t r;
     std::memset(&r, 0, sizeof(r));
     for (int k = 0; k < 3; k ++) { r.x[k] = cp.x[k]; r.scalar[k] = cp.scalar[k]; }
@@ -466,59 +497,55 @@ void critical_point_tracker_regular::grow()
   }
   const int rc = ftkx_online_tracer_grow(online, recs.data(), recs.size());
   if (rc != FTKX_OK) throw ftkx_error(rc, "grow: ftkx_online_tracer_grow failed (element tags needed: FTKX_TAG_EXACT64, or REFERENCE where it does not wrap)");
-  discrete_critical_points.clear();
+  points.clear(); point_keys.clear();
+  discrete_critical_points.clear(); map_valid = true;
 }
 
 void critical_point_tracker_regular::finalize()
 {
-  sync();
-  if (enable_streaming_trajectories) {             // 2d:150-151: "done" -- the trajectories are what grow() built
-    traced_critical_points.clear(); traced_loop.clear(); traced_id.clear();
+  wait_devices();
+  if (enable_streaming_trajectories) {
+    flush_points();             // 2d:150-151: "done" -- the trajectories are what grow() built
+    traced_points.clear(); traced_offsets.assign(1, 0); traced_nested_valid = false; traced_loop.clear(); traced_id.clear();
     if (!online) return;
     ftkx_cp_t *pts = nullptr;
     ftkx_curves c{};
     const int rc = ftkx_online_tracer_curves(online, &pts, &c);
     if (rc != FTKX_OK) { ftkx_free(pts); ftkx_free_curves(&c); throw ftkx_error(rc, "finalize: ftkx_online_tracer_curves failed"); }
     for (size_t i = 0; i < c.n_curves; i ++) {
-      std::vector<feature_point_t> curve;
       for (long long k = c.offsets[i]; k < c.offsets[i + 1]; k ++) {
         const ftkx_cp_t &r = pts[k];
         feature_point_t cp;
         for (int q = 0; q < 3; q ++) { cp.x[q] = r.x[q]; cp.scalar[q] = r.scalar[q]; }
         cp.t = r.t; cp.type = r.type; cp.tag = r.tag;
         cp.ordinal = ftkx_cp_ordinal(&r) != 0; cp.timestep = ftkx_cp_timestep(&r);
-        curve.push_back(cp);
+        traced_points.push_back(cp);
       }
-      traced_critical_points.push_back(std::move(curve));
+      traced_offsets.push_back((long long)traced_points.size());
       traced_loop.push_back(c.loop[i]);
       traced_id.push_back((int)i);
     }
     ftkx_free(pts); ftkx_free_curves(&c);
     return;
   }
-  std::vector<ftkx_cp_t> recs;
-  std::vector<const feature_point_t *> pts;
-  recs.reserve(discrete_critical_points.size());
-  for (const auto &kv : discrete_critical_points) {
-    ftkx_cp_t r;
-    std::memset(&r, 0, sizeof(r));
-    r.tag = kv.first;
-    recs.push_back(r);
-    pts.push_back(&kv.second);
-  }
+  // Nothing has to be ordered for this: ftkx_trace_curves takes the points in any order (it indexes them by tag) and returns the curves
+  // in the reference's order.  Sweeps in time order with 64-bit tags deliver ascending tags: the pending points are traced as they are.
+  if (!(points.empty() && pending_ascending)) flush_points();
+  const std::vector<feature_point_t> &src = points.empty() ? pending_points : points;
+  std::vector<ftkx_cp_t> recs(src.size());
+  if (!src.empty()) std::memset(recs.data(), 0, recs.size() * sizeof(ftkx_cp_t));
+  for (size_t i = 0; i < src.size(); i ++) recs[i].tag = src[i].tag;
   long long dst[3] = {0, 0, 0}, dsz[3] = {1, 1, 1};
   for (int d = 0; d < nd; d ++) { dst[d] = domain.start(d); dsz[d] = domain.size(d); }
   ftkx_curves c{};
   const int rc = ftkx_trace_curves(nd, dst, dsz, recs.data(), recs.size(), &c);
   if (rc != FTKX_OK) { ftkx_free_curves(&c); throw ftkx_error(rc, "finalize: ftkx_trace_curves failed (tags must not have overflowed int32: use FTKX_TAG_EXACT64 on very large meshes)"); }
-  traced_critical_points.clear(); traced_loop.clear(); traced_id.clear();
-  for (size_t i = 0; i < c.n_curves; i ++) {
-    std::vector<feature_point_t> curve;
-    for (long long k = c.offsets[i]; k < c.offsets[i + 1]; k ++) curve.push_back(*pts[c.indices[k]]);
-    traced_critical_points.push_back(std::move(curve));
-    traced_loop.push_back(c.loop[i]);
-    traced_id.push_back((int)i);
-  }
+  // the curves stay flat -- the points of all curves one after the other; one vector per curve is built only if somebody asks for it
+  traced_points.resize(c.n_points); traced_offsets.assign(c.offsets, c.offsets + c.n_curves + 1);
+  traced_loop.assign(c.loop, c.loop + c.n_curves); traced_id.resize(c.n_curves);
+  for (size_t k = 0; k < c.n_points; k ++) traced_points[k] = src[(size_t)c.indices[k]];
+  for (size_t i = 0; i < c.n_curves; i ++) traced_id[i] = (int)i;
+  traced_nested_valid = false;
   ftkx_free_curves(&c);
 }
 
@@ -540,16 +567,12 @@ feature_point_t point_of(const ftkx_cp_t &r)
   cp.ordinal = ftkx_cp_ordinal(&r) != 0; cp.timestep = ftkx_cp_timestep(&r);
   return cp;
 }
-struct flat_curves {   // traced curves as one record array + offsets (points in curve order)
+struct flat_curves {   // traced curves as one record array (points in curve order) + the identity as index list
   std::vector<ftkx_cp_t> recs;
-  std::vector<long long> offsets, indices;
-  flat_curves(const std::vector<std::vector<feature_point_t>> &curves)
+  std::vector<long long> indices;
+  flat_curves(const std::vector<feature_point_t> &pts) : recs(pts.size()), indices(pts.size())
   {
-    offsets.push_back(0);
-    for (const auto &c : curves) {
-      for (const auto &p : c) { indices.push_back((long long)recs.size()); recs.push_back(record_of(p)); }
-      offsets.push_back((long long)recs.size());
-    }
+    for (size_t i = 0; i < pts.size(); i ++) { recs[i] = record_of(pts[i]); indices[i] = (long long)i; }
   }
 };
 std::string io_error()
@@ -563,35 +586,45 @@ std::string io_error()
 // json_interface::post_process (filters/json_interface.hh:758-800) with the options it defaults to
 void critical_point_tracker_regular::post_process()
 {
-  flat_curves f(traced_critical_points);
+  flat_curves f(traced_points);
   ftkx_curves in;
   std::memset(&in, 0, sizeof(in));
-  in.n_curves = traced_critical_points.size(); in.n_points = f.recs.size();
-  in.offsets = f.offsets.data(); in.indices = f.indices.data(); in.loop = traced_loop.data();
+  in.n_curves = num_traced_curves(); in.n_points = f.recs.size();
+  in.offsets = traced_offsets.data(); in.indices = f.indices.data(); in.loop = traced_loop.data();
   ftkx_trajectories out{};
   const int rc = ftkx_post_process_curves(f.recs.data(), f.recs.size(), &in, &out);
   if (rc != FTKX_OK) { ftkx_free_trajectories(&out); throw ftkx_error(rc, "post_process failed"); }
-  std::vector<std::vector<feature_point_t>> curves(out.n_curves);
+  std::vector<feature_point_t> pts(out.n_points);
   std::vector<int> loop(out.n_curves), ids(out.n_curves);
-  for (size_t c = 0; c < out.n_curves; c ++) {
-    // a split piece keeps its parent's label; labels of traced curves are their own (possibly already post-processed) ids
-    loop[c] = out.loop[c]; ids[c] = traced_id[out.id[c]];
-    for (long long k = out.offsets[c]; k < out.offsets[c + 1]; k ++) {
-      feature_point_t p = point_of(f.recs[out.indices[k]]);
-      p.type = out.type[k]; p.t = out.t[k];
-      curves[c].push_back(p);
-    }
+  for (size_t k = 0; k < out.n_points; k ++) {
+    pts[k] = traced_points[(size_t)out.indices[k]];
+    pts[k].type = out.type[k]; pts[k].t = out.t[k];
   }
+  // a split piece keeps its parent's label; labels of traced curves are their own (possibly already post-processed) ids
+  for (size_t c = 0; c < out.n_curves; c ++) { loop[c] = out.loop[c]; ids[c] = traced_id[out.id[c]]; }
+  traced_offsets.assign(out.offsets, out.offsets + out.n_curves + 1);
   ftkx_free_trajectories(&out);
-  traced_critical_points.swap(curves); traced_loop.swap(loop); traced_id.swap(ids);
+  traced_points.swap(pts); traced_loop.swap(loop); traced_id.swap(ids);
+  traced_nested_valid = false;
+}
+
+const std::vector<std::vector<feature_point_t>> &critical_point_tracker_regular::get_traced_critical_points() const
+{
+  if (!traced_nested_valid) {
+    traced_critical_points.assign(num_traced_curves(), std::vector<feature_point_t>());
+    for (size_t c = 0; c < num_traced_curves(); c ++)
+      traced_critical_points[c].assign(traced_points.begin() + traced_offsets[c], traced_points.begin() + traced_offsets[c + 1]);
+    traced_nested_valid = true;
+  }
+  return traced_critical_points;
 }
 
 void critical_point_tracker_regular::write_discrete(const std::string &filename, int format) const
 {
   sync();
   std::vector<ftkx_cp_t> recs;
-  recs.reserve(discrete_critical_points.size());
-  for (const auto &kv : discrete_critical_points) recs.push_back(record_of(kv.second));
+  recs.reserve(points.size());
+  for (const feature_point_t &cp : points) recs.push_back(record_of(cp));
   // text labels: the reference's scalar_components default to {"scalar"} whether or not a scalar field exists
   const int rc = ftkx_write_critical_points(filename.c_str(), format, recs.data(), recs.size(), nullptr, nullptr, nullptr, -1);
   if (rc != FTKX_OK) throw ftkx_error(rc, io_error());
@@ -603,8 +636,10 @@ void critical_point_tracker_regular::write_critical_points_text(const std::strin
 // critical_point_tracker_regular::put_critical_points (critical_point_tracker_regular.hh:40-46): tags are trusted as keys
 void critical_point_tracker_regular::put_critical_points(const std::vector<feature_point_t> &cps)
 {
-  sync();
-  for (const auto &cp : cps) discrete_critical_points[cp.tag] = cp;
+  for (const auto &cp : cps) {
+    if (!pending_points.empty() && pending_points.back().tag >= cp.tag) pending_ascending = false;
+    pending_points.push_back(cp);
+  }
 }
 
 void critical_point_tracker_regular::read_discrete(const std::string &filename, int format)
@@ -624,16 +659,17 @@ void critical_point_tracker_regular::read_critical_points_binary(const std::stri
 
 void critical_point_tracker_regular::write_traced(const std::string &filename, int format) const
 {
-  flat_curves f(traced_critical_points);
+  flat_curves f(traced_points);
   std::vector<unsigned> type(f.recs.size() ? f.recs.size() : 1);
   std::vector<double> t(f.recs.size() ? f.recs.size() : 1);
   for (size_t i = 0; i < f.recs.size(); i ++) { type[i] = f.recs[i].type; t[i] = f.recs[i].t; }
   std::vector<int> loop(traced_loop), ids(traced_id);
-  loop.resize(traced_critical_points.size() + 1); ids.resize(traced_critical_points.size() + 1);
+  loop.resize(num_traced_curves() + 1); ids.resize(num_traced_curves() + 1);
+  std::vector<long long> offsets(traced_offsets);
   ftkx_trajectories tr;
   std::memset(&tr, 0, sizeof(tr));
-  tr.n_curves = traced_critical_points.size(); tr.n_points = f.recs.size();
-  tr.offsets = f.offsets.data(); tr.indices = f.indices.data(); tr.loop = loop.data(); tr.type = type.data(); tr.t = t.data(); tr.id = ids.data();
+  tr.n_curves = num_traced_curves(); tr.n_points = f.recs.size();
+  tr.offsets = offsets.data(); tr.indices = f.indices.data(); tr.loop = loop.data(); tr.type = type.data(); tr.t = t.data(); tr.id = ids.data();
   const int rc = ftkx_write_traced_critical_points(filename.c_str(), format, f.recs.data(), f.recs.size(), &tr, nullptr, -1);
   if (rc != FTKX_OK) throw ftkx_error(rc, io_error());
 }
@@ -644,10 +680,7 @@ void critical_point_tracker_regular::write_traced_critical_points_text(const std
 std::vector<feature_point_t> critical_point_tracker_regular::get_critical_points() const
 {
   sync();
-  std::vector<feature_point_t> r;
-  r.reserve(discrete_critical_points.size());
-  for (const auto &kv : discrete_critical_points) r.push_back(kv.second);
-  return r;
+  return points;
 }
 
 }  // namespace ftkx
@@ -754,7 +787,7 @@ int ftkx_tracker_update_timestep(ftkx_tracker *h) { return guarded(h, [&] { h->t
 int ftkx_tracker_num_critical_points(const ftkx_tracker *h, size_t *n)
 {
   if (!h || !h->t || !n) return FTKX_E_INVALID;
-  *n = h->t->get_discrete_critical_points().size();
+  *n = h->t->num_discrete_critical_points();
   return FTKX_OK;
 }
 
@@ -762,9 +795,9 @@ int ftkx_tracker_get_critical_points(const ftkx_tracker *h, ftkx_cp_t *out, int 
 {
   if (!h || !h->t || !out) return FTKX_E_INVALID;
   size_t i = 0;
-  for (const auto &kv : h->t->get_discrete_critical_points()) {
+  const std::vector<ftkx::feature_point_t> pts = h->t->get_critical_points();
+  for (const ftkx::feature_point_t &cp : pts) {
     if (i >= cap) break;
-    const ftkx::feature_point_t &cp = kv.second;
     std::memset(&out[i], 0, sizeof(ftkx_cp_t));
     for (int k = 0; k < 3; k ++) { out[i].x[k] = cp.x[k]; out[i].scalar[k] = cp.scalar[k]; }
     out[i].t = cp.t; out[i].type = cp.type; out[i].tag = cp.tag;
@@ -788,23 +821,19 @@ int ftkx_tracker_finalize(ftkx_tracker *h) { return guarded(h, [&] { h->t->final
 int ftkx_tracker_num_curves(const ftkx_tracker *h, size_t *n_curves, size_t *n_points)
 {
   if (!h || !h->t || !n_curves || !n_points) return FTKX_E_INVALID;
-  *n_curves = h->t->get_traced_critical_points().size();
-  size_t np = 0;
-  for (const auto &c : h->t->get_traced_critical_points()) np += c.size();
-  *n_points = np;
+  *n_curves = h->t->num_traced_curves();
+  *n_points = h->t->get_traced_points().size();
   return FTKX_OK;
 }
 
 int ftkx_tracker_get_curves(const ftkx_tracker *h, long long *offsets, unsigned long long *tags, int *loop)
 {
   if (!h || !h->t || !offsets || !tags || !loop) return FTKX_E_INVALID;
-  size_t k = 0, i = 0;
-  offsets[0] = 0;
-  for (const auto &c : h->t->get_traced_critical_points()) {
-    for (const auto &p : c) tags[k ++] = p.tag;
-    loop[i] = h->t->get_traced_loop_flags()[i];
-    offsets[++ i] = (long long)k;
-  }
+  const auto &pts = h->t->get_traced_points();
+  const auto &off = h->t->get_traced_offsets();
+  for (size_t k = 0; k < pts.size(); k ++) tags[k] = pts[k].tag;
+  for (size_t i = 0; i < off.size(); i ++) offsets[i] = off[i];
+  for (size_t i = 0; i + 1 < off.size(); i ++) loop[i] = h->t->get_traced_loop_flags()[i];
   return FTKX_OK;
 }
 
@@ -813,12 +842,9 @@ int ftkx_tracker_post_process(ftkx_tracker *h) { return guarded(h, [&] { h->t->p
 int ftkx_tracker_get_curve_points(const ftkx_tracker *h, unsigned int *type, double *t, int *ids)
 {
   if (!h || !h->t) return FTKX_E_INVALID;
-  size_t k = 0, i = 0;
-  for (const auto &c : h->t->get_traced_critical_points()) {
-    for (const auto &p : c) { if (type) type[k] = p.type; if (t) t[k] = p.t; k ++; }
-    if (ids) ids[i] = h->t->get_traced_ids()[i];
-    i ++;
-  }
+  const auto &pts = h->t->get_traced_points();
+  for (size_t k = 0; k < pts.size(); k ++) { if (type) type[k] = pts[k].type; if (t) t[k] = pts[k].t; }
+  if (ids) for (size_t i = 0; i < h->t->num_traced_curves(); i ++) ids[i] = h->t->get_traced_ids()[i];
   return FTKX_OK;
 }
 

@@ -151,7 +151,11 @@ public:
 
   void finalize();                                          // 2d:143-225, 3d:86-117 -> trace_critical_points_offline
   // traced curves after finalize(): each an ordered list of points (feature_curve_t), loop flag alongside
-  const std::vector<std::vector<feature_point_t>> &get_traced_critical_points() const { return traced_critical_points; }
+  const std::vector<std::vector<feature_point_t>> &get_traced_critical_points() const;      // (one vector per curve: built from the flat form when asked for)
+  // the traced curves as finalize() / post_process() keep them: the points of all curves one after the other, curve c = [offsets[c], offsets[c + 1])
+  const std::vector<feature_point_t> &get_traced_points() const { return traced_points; }
+  const std::vector<long long> &get_traced_offsets() const { return traced_offsets; }
+  size_t num_traced_curves() const { return traced_offsets.size() - 1; }
   const std::vector<int> &get_traced_loop_flags() const { return traced_loop; }
   const std::vector<int> &get_traced_ids() const { return traced_id; }   // label of each curve in the reference's multimap
   // json_interface::post_process, default options (filters/json_interface.hh:758-800): smooth types, rotate, split_all,
@@ -170,7 +174,8 @@ public:
   void write_traced_critical_points_text(const std::string &filename) const;
 
   std::vector<feature_point_t> get_critical_points() const; // critical_point_tracker_regular.hh:32-38 (sorted by element)
-  const discrete_map_t &get_discrete_critical_points() const { sync(); return discrete_critical_points; }
+  const discrete_map_t &get_discrete_critical_points() const;   // (the std::map view: built from the flat store when asked for)
+  size_t num_discrete_critical_points() const { sync(); return points.size(); }
 
   void sync() const;                                        // multi-device: wait for every queued step (no-op with one device)
   int num_devices() const;
@@ -209,13 +214,24 @@ protected:
   int next_push_timestep = 0;
   double vector_field_resolution = std::numeric_limits<double>::max();   // sticky running minimum (never reset)
   unsigned long long vector_field_scaling_factor = 1;
-  // keyed by element tag, iterated in the reference's element order.  The sweep's records are first parked in `pending_points`
-  // (a streaming run inserts ~10^3 points per step; the ordered map costs ~0.3 us per insert) and merged in bulk the first time
-  // anything looks at the map (every accessor goes through sync()).
-  mutable discrete_map_t discrete_critical_points;
+  // The discrete points (the reference keeps a std::map<element_t, feature_point_t>): a flat array in the reference's element order with
+  // unique tags (`points`, its order keys beside it), what the sweeps have delivered since it was last brought up to date
+  // (`pending_points`: a streaming run delivers ~10^3 points per step), and -- only when somebody asks for it -- the std::map view.
+  // Sweeps in time order with 64-bit tags deliver strictly ascending tags (`pending_ascending`): finalize() then traces the pending
+  // points as they are, without ordering anything.
+  mutable std::vector<feature_point_t> points;
+  mutable std::vector<std::pair<unsigned long long, unsigned long long>> point_keys;
   mutable std::vector<feature_point_t> pending_points;
+  mutable bool pending_ascending = true;
+  mutable discrete_map_t discrete_critical_points;
+  mutable bool map_valid = true;
+  element_order order_;
+  void wait_devices() const;
   void flush_points() const;
-  std::vector<std::vector<feature_point_t>> traced_critical_points;
+  std::vector<feature_point_t> traced_points;
+  std::vector<long long> traced_offsets = std::vector<long long>(1, 0);
+  mutable std::vector<std::vector<feature_point_t>> traced_critical_points;
+  mutable bool traced_nested_valid = true;
   std::vector<int> traced_loop, traced_id;
   ftkx_stats last_stats;
 
