@@ -49,16 +49,17 @@ const char *last_mask_kernel();
 void launch_cull_coarse(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, hipStream_t stream);
 void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream);
 void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st);
-void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, double safe_m,
-                           u64 *results, hipStream_t st);
+void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,
+                           double safe_m, u64 *results, hipStream_t st);
 void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff, u64 *sorted, u64 *results, hipStream_t st);
 void launch_bucket_scan(unsigned *hist, unsigned *boff, unsigned nbins, u64 *counters, hipStream_t st);
 void launch_bucket_scatter(const Mesh &m, unsigned *boff, u64 *bucketed, hipStream_t st);
-void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, hipStream_t st);
+void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, const u64 *base_from, hipStream_t st);
 Mesh coarse_view(const Mesh &m);
 void launch_series_small(const Mesh &m, const Mesh &mc, const Fields *d_steps, bool two_level, const u64 *d_refine, const u64 *d_list, ftkx_cp_t *out,
                          u64 *results, size_t nwords, u64 *h_results, unsigned *flag, unsigned seq, unsigned *done, hipStream_t st);
-void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, hipStream_t st);
+void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, const u64 *base_from,
+                          hipStream_t st);
 }  // namespace ftkx
 
 using ftkx::Fields;
@@ -96,6 +97,19 @@ enum { K_MASK = 0, K_CULL = 1, K_EXACT = 2, K_TILE = 3, K_N = 4 };
 
 
 }  // namespace ftkxh
+
+// One chunk of a chunked series pass (series.hip): everything a chunk's tail -- cull, factors, exact test, ordering, records -- writes, so
+// that the tail of chunk k runs on its own stream next to the mask kernel of chunk k + 1.
+struct ftkx_series_slot {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_masks = nullptr, ev_factors = nullptr, ev_done = nullptr;
+  u64 *counters = nullptr;                      // CNT_N words
+  u64 *list = nullptr, *refine = nullptr, *pass = nullptr, *fragile = nullptr, *bucketed = nullptr, *sorted = nullptr, *results = nullptr, *h_results = nullptr;
+  u64 list_cap = 0, refine_cap = 0, capacity = 0, fragile_cap = 0;
+  unsigned *hist = nullptr, *boff = nullptr;
+  size_t bins_cap = 0, results_cap = 0, h_results_cap = 0;
+  unsigned seq = 0;
+};
 
 struct ftkx_ctx {
   int nd = 0, device = 0;
@@ -170,6 +184,7 @@ struct ftkx_ctx {
   size_t sr_bucketed_cap = 0;
   u64 *sr_sorted = nullptr;
   size_t sr_sorted_cap = 0;
+  std::vector<ftkx_series_slot> sr_slots;   // chunked pass: one slot per chunk
   int sr_skip_small = 0;             // passes for which the fused tail kernel is not launched (the data was hit-dense a moment ago)
   int sr_last_path = 0;              // which way the last ftkx_sweep_series went: 1 device-driven, 2 early single-workgroup tail, 0 the host-driven batch
   unsigned long long sr_last_status = 0;

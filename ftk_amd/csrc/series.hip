@@ -60,6 +60,279 @@ template <class T> int grow_device(ftkx_ctx *c, T **p, size_t *cap, size_t want)
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
+int slot_prepare(ftkx_ctx *c, ftkx_series_slot &sl, size_t nbins, size_t nwords)
+{
+  int rc;
+  if (!sl.stream) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIP_TRY(c, hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, hi));     // (the tails are latency chains: they go first wherever a slot frees up)
+    for (hipEvent_t *e : {&sl.ev_masks, &sl.ev_factors, &sl.ev_done}) HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    HIP_TRY(c, hipMalloc((void **)&sl.counters, (size_t)ftkx::CNT_N * sizeof(u64)));
+  }
+  size_t cap;
+  cap = (size_t)sl.list_cap; if ((rc = grow_device(c, &sl.list, &cap, std::max<size_t>(cap, 1u << 20)))) return rc; sl.list_cap = cap;
+  cap = (size_t)sl.refine_cap; if ((rc = grow_device(c, &sl.refine, &cap, std::max<size_t>(cap, 1u << 20)))) return rc; sl.refine_cap = cap;
+  if (sl.capacity < (1u << 16)) {
+    for (void *p : {(void *)sl.pass, (void *)sl.bucketed, (void *)sl.sorted}) if (p) (void)hipFree(p);
+    sl.pass = sl.bucketed = sl.sorted = nullptr; sl.capacity = 0;
+  }
+  if (!sl.pass) {
+    const size_t want = std::max<size_t>((size_t)sl.capacity, 1u << 16);
+    HIP_TRY(c, hipMalloc((void **)&sl.pass, want * sizeof(u64)));
+    HIP_TRY(c, hipMalloc((void **)&sl.bucketed, want * sizeof(u64)));
+    HIP_TRY(c, hipMalloc((void **)&sl.sorted, want * sizeof(u64)));
+    sl.capacity = want;
+  }
+  cap = (size_t)sl.fragile_cap; if ((rc = grow_device(c, &sl.fragile, &cap, std::max<size_t>(cap * 10, (size_t)(1u << 12) * 10)))) return rc; sl.fragile_cap = cap / 10;
+  if (sl.bins_cap < nbins + 1) {
+    for (void *p : {(void *)sl.hist, (void *)sl.boff}) if (p) (void)hipFree(p);
+    sl.hist = sl.boff = nullptr; sl.bins_cap = 0;
+    const size_t want = std::max<size_t>(nbins + 1, (1u << 16) + 1);
+    HIP_TRY(c, hipMalloc((void **)&sl.hist, want * sizeof(unsigned)));
+    HIP_TRY(c, hipMalloc((void **)&sl.boff, want * sizeof(unsigned)));
+    sl.bins_cap = want;
+  }
+  if ((rc = grow_device(c, &sl.results, &sl.results_cap, std::max<size_t>(nwords, 1024)))) return rc;
+  const size_t h_words = nwords + (size_t)sl.fragile_cap * 10;
+  if (sl.h_results_cap < h_words) {
+    if (sl.h_results) { HIP_TRY(c, hipStreamSynchronize(sl.stream)); (void)hipHostFree(sl.h_results); sl.h_results = nullptr; sl.h_results_cap = 0; }
+    const size_t want = h_words + h_words / 4 + 1024;
+    HIP_TRY(c, hipHostMalloc((void **)&sl.h_results, (want + 8) * sizeof(u64), hipHostMallocCoherent));
+    sl.h_results_cap = want;
+    *reinterpret_cast<volatile unsigned *>(sl.h_results + want) = 0u;
+    sl.seq = 0;
+  }
+  return FTKX_OK;
+}
+
+// The pass in chunks of consecutive steps.  Hit-dense data: the tail of a pass -- cull, exact test, ordering, records and their way over
+// PCIe -- is work in proportion to the hits, not a fixed latency, and the mask kernel does not need it: the tail of chunk k runs on a
+// stream of its own, next to the mask kernel of chunk k + 1 on the context's stream.  Every chunk has its own counters, lists and results
+// block (ftkx_series_slot); what links them is on the device: a chunk's factor kernel takes the running minimum from the results of the
+// chunk before it, its record kernel the place where its records start.  Returns 1 if the pass was done here, 0 if the caller should do
+// it in one piece (a kernel raised a flag: the host-driven batch takes over), a negative code on errors.
+int series_chunked(ftkx_ctx *c, int nchunks, const int *ts, const int *scopes, int n, const std::vector<int> &slice_ts, std::vector<Slice *> &sl, std::vector<int> &red_index,
+                   size_t ntodo, bool two_level, u64 cells, unsigned long long hint, double *running_resolution, unsigned long long *factors, const ftkx_cp_t **out, size_t *n_out)
+{
+  const int nd = c->nd;
+  const size_t k = sl.size();
+  int rc;
+  if ((int)c->sr_slots.size() < nchunks) c->sr_slots.resize((size_t)nchunks);
+  // the chunks: steps [b[q], b[q + 1]), their slices [j0[q], j1[q]] of the time-ordered slice list, the mask jobs [r0[q], r1[q]) that are theirs
+  std::vector<int> b((size_t)nchunks + 1), j0((size_t)nchunks), j1((size_t)nchunks), r0((size_t)nchunks), r1((size_t)nchunks);
+  for (int q = 0; q <= nchunks; q ++) b[(size_t)q] = (int)((long long)n * q / nchunks);
+  int r_seen = 0, j_seen = -1;
+  for (int q = 0; q < nchunks; q ++) {
+    const int first = b[(size_t)q], last = b[(size_t)q + 1] - 1;
+    j0[(size_t)q] = (int)(std::lower_bound(slice_ts.begin(), slice_ts.end(), ts[first]) - slice_ts.begin());
+    j1[(size_t)q] = (int)(std::lower_bound(slice_ts.begin(), slice_ts.end(), ts[last] + ((scopes[last] & FTKX_SCOPE_INTERVAL) ? 1 : 0)) - slice_ts.begin());
+    r0[(size_t)q] = r_seen;
+    for (int j = std::max(j_seen + 1, j0[(size_t)q]); j <= j1[(size_t)q]; j ++) if (red_index[(size_t)j] >= 0) r_seen = red_index[(size_t)j] + 1;
+    r1[(size_t)q] = r_seen;
+    j_seen = std::max(j_seen, j1[(size_t)q]);
+  }
+  // buffers
+  for (size_t j = 0; j < k; j ++) if (red_index[j] >= 0 && (rc = ensure_mask_arrays(c, *sl[j], two_level))) return rc;
+  if (c->red_cap < std::max<size_t>(ntodo, 1)) {
+    if (c->d_red) { (void)hipFree(c->d_red); c->d_red = nullptr; c->red_cap = 0; }
+    HIP_TRY(c, hipMalloc((void **)&c->d_red, std::max<size_t>(ntodo, 1) * 128 * sizeof(u64)));
+    c->red_cap = std::max<size_t>(ntodo, 1);
+  }
+  std::vector<int> shift((size_t)nchunks);
+  std::vector<size_t> nbins((size_t)nchunks), nwords((size_t)nchunks);
+  size_t total_cap = 0;
+  for (int q = 0; q < nchunks; q ++) {
+    const int nq = b[(size_t)q + 1] - b[(size_t)q], kq = j1[(size_t)q] - j0[(size_t)q] + 1;
+    const u64 max_key = (u64)nq * cells * 64ull;
+    int key_bits = 1;
+    while (key_bits < 63 && (1ull << key_bits) < max_key) key_bits ++;
+    shift[(size_t)q] = std::max(0, key_bits - 16);
+    nbins[(size_t)q] = (size_t)((max_key - 1) >> shift[(size_t)q]) + 1;
+    nwords[(size_t)q] = (size_t)ftkx::SR_HEAD + (size_t)nq + 2 * (size_t)kq;
+    if ((rc = slot_prepare(c, c->sr_slots[(size_t)q], nbins[(size_t)q], nwords[(size_t)q]))) return rc;
+    total_cap += (size_t)c->sr_slots[(size_t)q].capacity;
+  }
+  if ((rc = ensure_host_buffer(c, total_cap))) return rc;
+  // descriptors: mask jobs | steps | per chunk: slice table, step table
+  size_t total = 0;
+  const size_t off_jobs = 0; total += align256(ntodo * sizeof(MaskJob));
+  const size_t off_steps = total; total += align256((size_t)n * sizeof(Fields));
+  std::vector<size_t> off_slices((size_t)nchunks), off_sinfo((size_t)nchunks);
+  for (int q = 0; q < nchunks; q ++) {
+    off_slices[(size_t)q] = total; total += align256((size_t)(j1[(size_t)q] - j0[(size_t)q] + 1) * sizeof(ftkx::SeriesSlice));
+    off_sinfo[(size_t)q] = total; total += align256((size_t)(b[(size_t)q + 1] - b[(size_t)q]) * sizeof(ftkx::SeriesStep));
+  }
+  if ((rc = ensure_desc(c, total))) return rc;
+  {
+    MaskJob *jobs = (MaskJob *)((char *)c->h_desc + off_jobs);
+    Fields *steps = (Fields *)((char *)c->h_desc + off_steps);
+    const double cap = 1.0 / (double)hint;
+    for (size_t j = 0; j < k; j ++)
+      if (red_index[j] >= 0) { const Slice &s = *sl[j]; jobs[red_index[j]] = MaskJob{s.S, s.V, s.M, two_level ? s.U : nullptr, c->d_red + (size_t)red_index[j] * 128, cap, HUGE_VAL}; }
+    for (int i = 0; i < n; i ++) {
+      const size_t ja = (size_t)(std::lower_bound(slice_ts.begin(), slice_ts.end(), ts[i]) - slice_ts.begin());
+      const bool interval = (scopes[i] & FTKX_SCOPE_INTERVAL) != 0;
+      const Slice &s0 = *sl[ja];
+      Fields f;
+      memset(&f, 0, sizeof(f));
+      f.S[0] = s0.S; f.V[0] = s0.V; f.J[0] = s0.J; f.M[0] = s0.M; f.U[0] = two_level ? s0.U : nullptr;
+      if (interval) { const Slice &s1 = *sl[ja + 1]; f.S[1] = s1.S; f.V[1] = s1.V; f.J[1] = s1.J; f.M[1] = s1.M; f.U[1] = two_level ? s1.U : nullptr; }
+      f.factor = 0.0; f.t = ts[i]; f.scope_mask = scopes[i];
+      steps[i] = f;
+    }
+    for (int q = 0; q < nchunks; q ++) {
+      ftkx::SeriesSlice *ss = (ftkx::SeriesSlice *)((char *)c->h_desc + off_slices[(size_t)q]);
+      ftkx::SeriesStep *si = (ftkx::SeriesStep *)((char *)c->h_desc + off_sinfo[(size_t)q]);
+      for (int j = j0[(size_t)q]; j <= j1[(size_t)q]; j ++) {
+        const Slice &s = *sl[(size_t)j];
+        ftkx::SeriesSlice &e = ss[j - j0[(size_t)q]];
+        e.t = slice_ts[(size_t)j]; e.red_index = red_index[(size_t)j];
+        e.known_res = DBL_MAX; e.known_max = 0.0;
+        if (s.have_res) { e.known_res = s.res < cap ? s.res : DBL_MAX; e.known_max = s.maxabs; }
+        else if (red_index[(size_t)j] < 0) { e.known_res = s.res_below; e.known_max = s.maxabs; }
+      }
+      int last = 0;
+      for (int i = b[(size_t)q]; i < b[(size_t)q + 1]; i ++) {
+        const int ja = (int)(std::lower_bound(slice_ts.begin(), slice_ts.end(), ts[i]) - slice_ts.begin());
+        const bool interval = (scopes[i] & FTKX_SCOPE_INTERVAL) != 0;
+        while (j0[(size_t)q] + last + 1 <= j1[(size_t)q] && slice_ts[(size_t)(j0[(size_t)q] + last + 1)] <= ts[i] + 1) last ++;
+        ftkx::SeriesStep &e = si[i - b[(size_t)q]];
+        e.slice0 = ja - j0[(size_t)q]; e.slice1 = interval ? ja + 1 - j0[(size_t)q] : -1; e.last = last; e.pad = 0;
+      }
+    }
+  }
+  const MaskJob *d_jobs = (const MaskJob *)((char *)c->d_desc + off_jobs);
+  Fields *d_steps = (Fields *)((char *)c->d_desc + off_steps);
+
+  // ---- queue everything ----
+  struct MarkGuard { std::vector<Slice *> *v; std::vector<int> *todo; bool armed; ~MarkGuard() { if (armed) for (size_t j = 0; j < v->size(); j ++) if ((*todo)[j] >= 0) { (*v)[j]->mask_factor = 0; (*v)[j]->have_fused = false; } } } marks{&sl, &red_index, true};
+  for (size_t j = 0; j < k; j ++) if (red_index[j] >= 0) { sl[j]->mask_factor = 0; sl[j]->have_fused = false; }
+  std::vector<Mesh> ms((size_t)nchunks);
+  std::vector<unsigned> seqs((size_t)nchunks);
+  for (int q = 0; q < nchunks; q ++) {
+    ftkx_series_slot &S = c->sr_slots[(size_t)q];
+    Mesh &m = ms[(size_t)q];
+    fill_mesh(c, m);
+    m.hits = nullptr; m.pass = S.pass; m.counters = S.counters; m.capacity = S.capacity; m.fragile = S.fragile; m.fragile_capacity = S.fragile_cap;
+    m.hist = S.hist; m.hist_shift = shift[(size_t)q]; m.core_cells = cells;
+    ftkx::launch_series_begin(S.counters, q == 0 ? c->d_red : nullptr, q == 0 ? ntodo * 64 : 0, S.hist, nbins[(size_t)q] + 1, S.results, nwords[(size_t)q], c->stream);
+    seqs[(size_t)q] = ++ S.seq;
+  }
+  launch_fetch_desc(c->h_desc, c->d_desc, total, c->stream);
+  const double safe_m = (double)(nd == 3 ? ftkx::kSafeM3 : ftkx::kSafeM2);
+  for (int q = 0; q < nchunks; q ++) {
+    ftkx_series_slot &S = c->sr_slots[(size_t)q];
+    const Mesh &m = ms[(size_t)q];
+    const int nq = b[(size_t)q + 1] - b[(size_t)q], kq = j1[(size_t)q] - j0[(size_t)q] + 1;
+    Fields *steps_q = d_steps + b[(size_t)q];
+    const ftkx::SeriesSlice *slices_q = (const ftkx::SeriesSlice *)((char *)c->d_desc + off_slices[(size_t)q]);
+    const ftkx::SeriesStep *sinfo_q = (const ftkx::SeriesStep *)((char *)c->d_desc + off_sinfo[(size_t)q]);
+    const ftkx_series_slot *P = q > 0 ? &c->sr_slots[(size_t)q - 1] : nullptr;
+    if (r1[(size_t)q] > r0[(size_t)q]) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs + r0[(size_t)q], r1[(size_t)q] - r0[(size_t)q], c->stream); ev_end(c); }
+    HIP_TRY(c, hipEventRecord(S.ev_masks, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(S.stream, S.ev_masks, 0));
+    if (two_level) ftkx::launch_cull_coarse(m, steps_q, nq, S.refine, S.refine_cap, S.stream);
+    else ftkx::launch_cull(m, steps_q, nq, S.list, S.list_cap, S.stream);
+    if (P) HIP_TRY(c, hipStreamWaitEvent(S.stream, P->ev_factors, 0));
+    ftkx::launch_series_factors(steps_q, nq, slices_q, kq, sinfo_q, c->d_red, *running_resolution, P ? P->results : nullptr, safe_m, S.results, S.stream);
+    HIP_TRY(c, hipEventRecord(S.ev_factors, S.stream));
+    if (two_level) ftkx::launch_refine(m, steps_q, S.refine, S.refine_cap, S.list, S.list_cap, S.stream);
+    ftkx::launch_exact(m, steps_q, 0, S.list, S.list_cap, S.stream);
+    ftkx::launch_bucket_scan(S.hist, S.boff, (unsigned)nbins[(size_t)q], S.counters, S.stream);
+    ftkx::launch_bucket_scatter(m, S.boff, S.bucketed, S.stream);
+    ftkx::launch_bucket_rank(m, S.bucketed, S.boff, S.sorted, S.results, S.stream);
+    if (P) HIP_TRY(c, hipStreamWaitEvent(S.stream, P->ev_done, 0));                       // (where this chunk's records start is known when the chunk before it is through)
+    const u64 *base_from = P ? P->results + ftkx::SR_BASE_NEXT : nullptr;
+    ftkx::launch_series_records(m, steps_q, S.sorted, c->h_hits, base_from, S.stream);
+    ftkx::launch_series_finish(m, S.results, nwords[(size_t)q], S.list_cap, S.refine_cap, S.h_results, reinterpret_cast<unsigned *>(S.h_results + S.h_results_cap), seqs[(size_t)q], base_from, S.stream);
+    HIP_TRY(c, hipEventRecord(S.ev_done, S.stream));
+  }
+  HIP_TRY(c, hipGetLastError());
+  for (int q = 0; q < nchunks; q ++) {
+    ftkx_series_slot &S = c->sr_slots[(size_t)q];
+    if (const char *why = ftkx::wait_flag(reinterpret_cast<unsigned *>(S.h_results + S.h_results_cap), seqs[(size_t)q], S.stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+  }
+  ev_harvest(c, false);
+
+  // ---- what came back ----
+  unsigned long long status = 0;
+  for (int q = 0; q < nchunks; q ++) status |= c->sr_slots[(size_t)q].h_results[ftkx::SR_STATUS];
+  c->sr_last_status = status;
+  marks.armed = false;
+  std::vector<char> seen(k, 0);
+  for (int q = 0; q < nchunks; q ++) {
+    const u64 *R = c->sr_slots[(size_t)q].h_results;
+    const int nq = b[(size_t)q + 1] - b[(size_t)q], kq = j1[(size_t)q] - j0[(size_t)q] + 1;
+    for (int jj = 0; jj < kq; jj ++) {
+      const size_t j = (size_t)(j0[(size_t)q] + jj);
+      if (red_index[j] < 0 || seen[j]) continue;
+      seen[j] = 1;
+      Slice &s = *sl[j];
+      double r, x;
+      memcpy(&r, &R[ftkx::SR_HEAD + nq + jj], 8); memcpy(&x, &R[ftkx::SR_HEAD + nq + kq + jj], 8);
+      if (std::isinf(x)) { s.mask_factor = 0; s.have_fused = false; continue; }
+      s.res_below = r; s.fused_factor = hint; s.have_fused = true;
+      if (!s.have_res) s.maxabs = x;
+      s.mask_factor = overflow_free(nd, s.maxabs, hint) ? hint : 0;
+      s.mask_big = false; s.u_rows = ms[0].u_rows;
+    }
+  }
+  const unsigned long long redo = ftkx::SERIES_AMBIGUOUS | ftkx::SERIES_MASKS_INVALID | ftkx::SERIES_INF | ftkx::SERIES_OVERFLOW;
+  if (status & redo) {
+    for (int q = 0; q < nchunks && (status & ftkx::SERIES_OVERFLOW); q ++) {      // grow what was too small in this chunk's slot
+      ftkx_series_slot &S = c->sr_slots[(size_t)q];
+      const u64 *cnt = S.h_results + ftkx::SR_COUNTERS;
+      const u64 hits = cnt[ftkx::CNT_PASS], listed = cnt[ftkx::CNT_LIST_PEAK], refined = cnt[ftkx::CNT_REFINE_PEAK], fragile = cnt[ftkx::CNT_FRAGILE];
+      size_t cap;
+      if (hits > S.capacity) {
+        for (void *p : {(void *)S.pass, (void *)S.bucketed, (void *)S.sorted}) if (p) (void)hipFree(p);
+        S.pass = S.bucketed = S.sorted = nullptr;
+        S.capacity = hits + hits / 8 + 1024;                                       // (slot_prepare allocates)
+      }
+      cap = (size_t)S.list_cap; if (listed > S.list_cap && (rc = grow_device(c, &S.list, &cap, (size_t)(listed + listed / 8 + 1024)))) return rc; S.list_cap = cap;
+      cap = (size_t)S.refine_cap; if (refined > S.refine_cap && (rc = grow_device(c, &S.refine, &cap, (size_t)(refined + refined / 8 + 1024)))) return rc; S.refine_cap = cap;
+      cap = (size_t)S.fragile_cap * 10; if (fragile > S.fragile_cap && (rc = grow_device(c, &S.fragile, &cap, (size_t)(fragile + fragile / 8 + 1024) * 10))) return rc; S.fragile_cap = cap / 10;
+    }
+    return 0;
+  }
+  c->sr_last_path = 3;
+  memset(&c->stats, 0, sizeof(c->stats));
+  {
+    const u64 n_ord = nd == 2 ? 2 : 6, n_int = nd == 2 ? 10 : 54;
+    for (int i = 0; i < n; i ++) { c->stats.cells += cells; c->stats.work_items += cells * (((scopes[i] & 1) ? n_ord : 0) + ((scopes[i] & 2) ? n_int : 0)); }
+  }
+  c->stats.cull_enabled = 1;
+  size_t base = 0;
+  auto less = [](const ftkx_cp_t &p, const ftkx_cp_t &q) { return p.tag < q.tag; };
+  for (int q = 0; q < nchunks; q ++) {
+    const u64 *R = c->sr_slots[(size_t)q].h_results;
+    const u64 *cnt = R + ftkx::SR_COUNTERS;
+    const size_t nrec = (size_t)R[ftkx::SR_NHITS];
+    c->stats.cells_survived += cnt[ftkx::CNT_CELLS_SURVIVED];
+    c->stats.simplices_tested += cnt[ftkx::CNT_SIMPLICES_TESTED];
+    const size_t nf = (size_t)R[ftkx::SR_NFRAGILE];
+    for (size_t i = 0; i < nf; i ++) {
+      const u64 *e = R + nwords[(size_t)q] + i * 10;
+      double A[3][3];
+      memcpy(A, e + 1, sizeof(A));
+      if (e[0] < nrec) c->h_hits[base + e[0]].type = (unsigned)ftkx::classify3(A, c->opt.jacobian_symmetric != 0);
+    }
+    c->stats.reclassified += nf;
+    if ((R[ftkx::SR_STATUS] & ftkx::SERIES_FIX_ORDER) && !std::is_sorted(c->h_hits + base, c->h_hits + base + nrec, less))
+      std::sort(c->h_hits + base, c->h_hits + base + nrec, less);              // (a bucket too full to rank on the device)
+    if (factors) for (int i = b[(size_t)q]; i < b[(size_t)q + 1]; i ++) factors[i] = R[ftkx::SR_HEAD + (i - b[(size_t)q])];
+    base += nrec;
+  }
+  c->stats.hits = base;
+  double run;
+  memcpy(&run, &c->sr_slots[(size_t)nchunks - 1].h_results[ftkx::SR_RUNNING], 8);
+  *running_resolution = run;
+  if (out) *out = c->h_hits;
+  if (n_out) *n_out = base;
+  return 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -127,8 +400,29 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   }
   if (!ok) return series_by_host(c, ts, scopes, n, slice_ts, running_resolution, factors, out, n_out);
 
-  // ---- buffers (persistent; they only ever grow) -----------------------------------------------------------------------------------
+  // ---- the pass in chunks, the tail of one next to the mask kernel of the next: built, exact (tests/test_gpu_series.py) -- and OFF unless
+  // FTKX_SERIES_CHUNKS asks for it: measured on hit-dense data (double_gyre 2048 x 1024 x 128: 1.05 ms in one piece, 1.10 / 1.17 / 1.52 ms
+  // in 2 / 3 / 4 chunks; woven 1024^2 x 64: 0.35 -> 0.43 / 0.52 / 0.57 ms) the tail kernels of chunk k get next to nothing done while the
+  // mask kernel of chunk k + 1 saturates the memory system and occupies every workgroup slot (coarse cull 27 -> 108 us, the one-workgroup
+  // factor kernel 8 -> 253 us waiting for a slot, stream priority notwithstanding): the tail still ends after the last mask kernel, and
+  // the extra launches and events are paid on top ----
   int rc;
+  {
+    int nchunks = 1;
+    if (const char *e = getenv("FTKX_SERIES_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 8) nchunks = n >= 2 * v ? v : 1; }   // (an explicit choice: tests, experiments)
+    if (nchunks > 1) {
+      rc = series_chunked(c, nchunks, ts, scopes, n, slice_ts, sl, red_index, ntodo, two_level, cells, hint, running_resolution, factors, out, n_out);
+      if (rc < 0) return rc;
+      if (rc == 1) {
+        // still hit-dense?  Then the next pass is chunked again; otherwise it is queued in one piece, with the fused tail kernel
+        c->sr_skip_small = c->stats.cells_survived > 4 * 2048ull ? 16 : 0;
+        return FTKX_OK;
+      }
+      return series_by_host(c, ts, scopes, n, slice_ts, running_resolution, factors, out, n_out);
+    }
+  }
+
+  // ---- buffers (persistent; they only ever grow) -----------------------------------------------------------------------------------
   if ((rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16)))) return rc;
   if ((rc = ensure_fragile(c, std::max<u64>(c->fragile_capacity, 1u << 12)))) return rc;
   if ((rc = ensure_list(c, std::max<u64>(c->list_capacity, 1u << 20))) || (rc = ensure_refine(c, std::max<u64>(c->refine_capacity, 1u << 20)))) return rc;
@@ -220,7 +514,7 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   ev_begin(c, K_CULL);
   if (two_level) ftkx::launch_cull_coarse(m, d_steps, n, c->d_refine, c->refine_capacity, c->stream);
   else ftkx::launch_cull(m, d_steps, n, c->d_list, c->list_capacity, c->stream);
-  ftkx::launch_series_factors(d_steps, n, d_slices, (int)k, d_sinfo, c->d_red, *running_resolution, (double)(nd == 3 ? ftkx::kSafeM3 : ftkx::kSafeM2),
+  ftkx::launch_series_factors(d_steps, n, d_slices, (int)k, d_sinfo, c->d_red, *running_resolution, nullptr, (double)(nd == 3 ? ftkx::kSafeM3 : ftkx::kSafeM2),
                               c->sr_results, c->stream);
   ev_end(c);
   ev_begin(c, K_EXACT);
@@ -237,9 +531,9 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   ftkx::launch_bucket_scan(c->sr_hist, c->sr_boff, (unsigned)nbins, c->d_counters, c->stream);
   ftkx::launch_bucket_scatter(m, c->sr_boff, c->sr_bucketed, c->stream);
   ftkx::launch_bucket_rank(m, c->sr_bucketed, c->sr_boff, c->sr_sorted, c->sr_results, c->stream);
-  ftkx::launch_series_records(m, d_steps, c->sr_sorted, c->h_hits, c->stream);
+  ftkx::launch_series_records(m, d_steps, c->sr_sorted, c->h_hits, nullptr, c->stream);
   ev_end(c);
-  ftkx::launch_series_finish(m, c->sr_results, nwords, c->list_capacity, c->refine_capacity, c->sr_h_results, flag, seq, c->stream);
+  ftkx::launch_series_finish(m, c->sr_results, nwords, c->list_capacity, c->refine_capacity, c->sr_h_results, flag, seq, nullptr, c->stream);
   HIP_TRY(c, hipGetLastError());
   if (const char *why = ftkx::wait_flag(flag, seq, c->stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
   ev_harvest(c, false);

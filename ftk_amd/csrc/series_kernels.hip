@@ -47,8 +47,10 @@ __device__ inline int nbits_of(double resolution, bool &ambiguous)
 // nslices <= kSeriesMaxSlices: the per-slice values live in LDS (a chain of dependent global loads per slice cost 0.4 us apiece).
 __global__ __launch_bounds__(1024) void series_factors_kernel(Fields *__restrict__ steps, int nsteps, const SeriesSlice *__restrict__ slices, int nslices,
                                                              const SeriesStep *__restrict__ sinfo, const u64 *__restrict__ red, double running_in,
+                                                             const u64 *__restrict__ running_from /* a previous chunk's results block, or nullptr */,
                                                              double safe_m, u64 *__restrict__ results)
 {
+  if (running_from) { const double r = __longlong_as_double((long long)running_from[SR_RUNNING]); running_in = r < running_in ? r : running_in; }
   __shared__ double res[kSeriesMaxSlices], mx[kSeriesMaxSlices];
   __shared__ double s_lane_min[64];
   __shared__ unsigned s_status;
@@ -229,8 +231,9 @@ __global__ __launch_bounds__(256) void bucket_rank_kernel(const u64 *__restrict_
 
 template <int ND>
 __global__ __launch_bounds__(kThreads) void series_record_kernel(const Mesh m, const Fields *__restrict__ fields, const u64 *__restrict__ sorted,
-                                                                 ftkx_cp_t *__restrict__ out /* pinned host memory */)
+                                                                 ftkx_cp_t *__restrict__ out /* pinned host memory */, const u64 *__restrict__ base_from /* records of the chunks before this one, or nullptr */)
 {
+  if (base_from) out += base_from[0];
   constexpr int N = ND + 1;
   __shared__ u64 s_rec[kThreads / 64][64 * 9];
   if (m.counters[CNT_SERIES_DONE]) return;
@@ -598,7 +601,8 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
 // One workgroup.  Runs behind the record kernel (a kernel boundary: its stores have been released); copies the device results block
 // into coherent pinned memory and stores the sequence number behind it with system scope -- the ONE thing the host waits for.
 __global__ __launch_bounds__(256) void series_finish_kernel(const u64 *__restrict__ counters, u64 *__restrict__ results, size_t nwords, u64 capacity, u64 list_capacity, u64 refine_capacity,
-                                                            const u64 *__restrict__ fragile, u64 fragile_capacity, u64 *__restrict__ h_results, unsigned *flag, unsigned seq)
+                                                            const u64 *__restrict__ fragile, u64 fragile_capacity, u64 *__restrict__ h_results, unsigned *flag, unsigned seq,
+                                                            const u64 *__restrict__ base_from)
 {
   if (counters[CNT_SERIES_DONE]) return;                // (the early tail has published everything already)
   __shared__ unsigned s_over;
@@ -610,6 +614,7 @@ __global__ __launch_bounds__(256) void series_finish_kernel(const u64 *__restric
     s_over = over;
     results[SR_NHITS] = hits;
     results[SR_NFRAGILE] = counters[CNT_FRAGILE];
+    results[SR_BASE_NEXT] = (base_from ? base_from[0] : 0ull) + (hits > capacity ? capacity : hits);   // where the next chunk's records start
   }
   __syncthreads();
   if (tid < (unsigned)CNT_N) results[SR_COUNTERS + tid] = counters[tid];
@@ -631,9 +636,9 @@ void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist,
   hipLaunchKernelGGL(series_begin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, counters, red, nslots, hist, nbins, results, nresults);
 }
 
-void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, double safe_m,
-                           u64 *results, hipStream_t st)
-{ hipLaunchKernelGGL(series_factors_kernel, dim3(1), dim3(1024), 0, st, steps, nsteps, slices, nslices, sinfo, red, running_in, safe_m, results); }
+void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,
+                           double safe_m, u64 *results, hipStream_t st)
+{ hipLaunchKernelGGL(series_factors_kernel, dim3(1), dim3(1024), 0, st, steps, nsteps, slices, nslices, sinfo, red, running_in, running_from, safe_m, results); }
 
 void launch_bucket_scan(unsigned *hist, unsigned *boff, unsigned nbins, u64 *counters, hipStream_t st)
 { hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, hist, boff, nbins, counters); }
@@ -648,11 +653,11 @@ void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff
   hipLaunchKernelGGL(bucket_rank_kernel, dim3(256), dim3(256), 0, st, bucketed, m.capacity, boff, m.hist_shift, rank_max, sorted, m.counters, results);
 }
 
-void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, hipStream_t st)
+void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, const u64 *base_from, hipStream_t st)
 {
   const dim3 grid(256u * 2u);
-  if (m.nd == 2) hipLaunchKernelGGL(series_record_kernel<2>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out);
-  else hipLaunchKernelGGL(series_record_kernel<3>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out);
+  if (m.nd == 2) hipLaunchKernelGGL(series_record_kernel<2>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out, base_from);
+  else hipLaunchKernelGGL(series_record_kernel<3>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out, base_from);
 }
 
 void launch_series_small(const Mesh &m, const Mesh &mc, const Fields *d_steps, bool two_level, const u64 *d_refine, const u64 *d_list, ftkx_cp_t *out,
@@ -662,10 +667,11 @@ void launch_series_small(const Mesh &m, const Mesh &mc, const Fields *d_steps, b
   else hipLaunchKernelGGL(series_small_kernel<3>, dim3(kSmallGrid), dim3(kThreads), 0, st, m, mc, d_steps, two_level ? 1 : 0, d_refine, d_list, out, results, nwords, h_results, flag, seq, done);
 }
 
-void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, hipStream_t st)
+void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, const u64 *base_from,
+                          hipStream_t st)
 {
   hipLaunchKernelGGL(series_finish_kernel, dim3(1), dim3(256), 0, st, m.counters, results, nwords, m.capacity, list_capacity, refine_capacity, m.fragile, m.fragile_capacity,
-                     h_results, flag, seq);
+                     h_results, flag, seq, base_from);
 }
 
 }  // namespace ftkx

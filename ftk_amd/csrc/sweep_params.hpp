@@ -135,6 +135,7 @@ enum { SERIES_AMBIGUOUS = 1,        // 1 / resolution so close above a power of 
        SERIES_EARLY = 32,           // (informational) the fused tail kernel finished the pass
        SERIES_UNORDERED = 64 };     // the fused tail found more records than its last workgroup ranks: they come unordered, the host sorts them
 // results block (device copy and coherent pinned copy, same layout; u64 words)
-enum { SR_STATUS = 0, SR_RUNNING = 1, SR_NHITS = 2, SR_NFRAGILE = 3, SR_COUNTERS = 4, SR_HEAD = 4 + CNT_N };   // then factors[nsteps], res[nslices], max[nslices], fragile[cap * 10]
+enum { SR_STATUS = 0, SR_RUNNING = 1, SR_NHITS = 2, SR_NFRAGILE = 3, SR_BASE_NEXT = 4 /* chunked pass: records of this chunk and the ones before it */,
+       SR_COUNTERS = 5, SR_HEAD = 5 + CNT_N };   // then factors[nsteps], res[nslices], max[nslices], fragile[cap * 10]
 
 }  // namespace ftkx

@@ -204,8 +204,8 @@ int ftkx_sweep_cancel(ftkx_ctx *ctx);    /* forgets the enqueued, not yet collec
  * inside this one, with the same result.  Records as for ftkx_sweep_collect: sorted by tag, valid until the next call. */
 int ftkx_sweep_series(ftkx_ctx *ctx, const int *timesteps, const int *scopes, int n, double *running_resolution,
                       unsigned long long *factors, const ftkx_cp_t **out, size_t *n_out);
-/* which way the last ftkx_sweep_series went: 1 = device-driven, 2 = device-driven and finished by the single-workgroup tail (sparse
- * data), 0 = host-driven batch; *status (nullable) = the SERIES_* bits the kernels raised (csrc/sweep_params.hpp) */
+/* which way the last ftkx_sweep_series went: 1 = device-driven, 2 = device-driven and finished by the fused tail kernel (sparse
+ * data), 3 = device-driven in chunks (hit-dense data: the tail of a chunk runs next to the mask kernel of the next), 0 = host-driven batch; *status (nullable) = the SERIES_* bits the kernels raised (csrc/sweep_params.hpp) */
 int ftkx_series_last_path(const ftkx_ctx *ctx, unsigned long long *status);
 
 /* counters of the last collect: simplices visited (work items), cells/simplices surviving the cull, device-side hits */

@@ -176,6 +176,32 @@ def test_series_equals_the_host_driven_batch_on_random_fields(gpu, seed):
         ctx.close()
 
 
+@pytest.mark.parametrize("nchunks", [2, 3, 4])
+@pytest.mark.parametrize("name", ["woven_128x128x10", "woven_31x37x32", "double_gyre_64x32x50", "merger_2d_32x32x100", "moving_extremum_3d_21x21x21x32",
+                                  "singular_terraces_44x40x36x5", "random_3d_scalar_13x12x11x4", "huge_nan_2d_vector_16x14x4", "moving_extremum_3d_21x21x21x4_overflow"])
+def test_the_chunked_pass_gives_the_same_records(gpu, monkeypatch, name, nchunks):
+    """FTKX_SERIES_CHUNKS: the pass in 2 .. 4 chunks of consecutive steps, each with its own tail stream, counters and results block, linked
+    on the device (running minimum, where a chunk's records start) -- the reference's records and factors, in tag order"""
+    g = load_golden(name)
+    nd, nv, nt = g["nd"], g["nv"], g["DT"]
+    monkeypatch.setenv("FTKX_SERIES_CHUNKS", str(nchunks))
+    ctx = _ctx(gpu, g["dims"], nd, nv)
+    _push_all(ctx, g["steps"], nv)
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    for rep in range(2):
+        if rep:
+            ctx.invalidate_masks()
+        recs, factors, run = ctx.sweep_series(range(nt), scopes)
+        path, status = ctx.series_last_path()
+        what = f"{name} in {nchunks} chunks (path {path}, status {status}, repetition {rep})"
+        assert path == (3 if nt >= 2 * nchunks and not (status & 15) else path), what
+        assert np.array_equal(factors, g["factors"]), what
+        assert np.all(recs["tag"][1:] >= recs["tag"][:-1]), what
+        assert_records_equal(_as_fixture(recs), g["records"], coord_tol=0.0, what=what)
+        PATHS.setdefault((path, status), []).append(name)
+    ctx.close()
+
+
 def test_series_fallbacks_give_the_same_records(gpu, monkeypatch):
     """the ways out of the device-driven form -- buffers that are too small (tiny initial capacities cannot be forced from outside, so: a
     hit-dense series larger than the default buffers), buckets too full to rank on the device (FTKX_SERIES_RANK_MAX=0: the host orders
