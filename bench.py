@@ -507,12 +507,13 @@ def job(args, env):
     tm1 = time.perf_counter()
     pass2 = None
     if rank == 0:
-        ftk_amd.pass2(nd, dom, merged)                    # (first call: the worker threads start)
-        curves, loop, nspecial, trajs, ms_trace, ms_post = ftk_amd.pass2(nd, dom, merged)
+        ftk_amd.pass2(nd, dom, merged, ctx)               # (first call: the worker threads start, the candidate tables go up)
+        curves, loop, nspecial, trajs, ms_trace, ms_post = ftk_amd.pass2(nd, dom, merged, ctx)
+        _c, _l, _n, _t, ms_trace_host, _p = ftk_amd.pass2(nd, dom, merged)
         pass2 = {"records": int(len(merged)), "curves": len(curves), "branching_points_dropped": int(nspecial), "trajectories_after_post_process": len(trajs),
-                 "gather_ms": (tm1 - tm0) * 1e3, "trace_ms": ms_trace, "post_process_ms": ms_post,
+                 "gather_ms": (tm1 - tm0) * 1e3, "trace_ms": ms_trace, "trace_ms_host_only": ms_trace_host, "post_process_ms": ms_post,
                  "end_to_end_with_pass2_ms": elapsed / args.steps * 1e3 + ms_trace + ms_post,
-                 "note": "untimed region: merge of the ranks' records on rank 0, ftkx_trace_curves and ftkx_post_process_curves on the merged set (host threads; the C calls timed by themselves)"}
+                 "note": "untimed region: merge of the ranks' records on rank 0, ftkx_trace_curves_ctx (neighbour search + component labelling on the GPU, seeds and walks on host threads) and ftkx_post_process_curves (host threads) on the merged set; the C calls timed by themselves"}
         if args.dump_merged:
             np.savez(args.dump_merged, records=merged, curve_offsets=np.cumsum([0] + [len(c) for c in curves]),
                      curve_indices=np.concatenate(curves) if curves else np.zeros(0, dtype=np.int64), curve_loop=np.asarray(loop))

@@ -313,12 +313,16 @@ def extract_cp3dt(scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc
     return _extract(3, scope, current_timestep, domain, core, ext, Vc, Vn, Jc, Jn, Sc, Sn, factor, options, device_id)
 
 
-def trace_curves(nd, domain, records):
-    """Pass 2 (ftkx_trace_curves): records (CP_DTYPE, element tags) -> (list of index arrays into `records`, loop flags, n_special)."""
+def trace_curves(nd, domain, records, ctx=None):
+    """Pass 2 (ftkx_trace_curves): records (CP_DTYPE, element tags) -> (list of index arrays into `records`, loop flags, n_special).
+    ctx: a Context whose GPU does the neighbour search and the component labelling (ftkx_trace_curves_ctx); same curves."""
     L = _lib.load()
     recs = np.ascontiguousarray(records, dtype=CP_DTYPE)
     out = _lib.Curves()
-    _lib.check(L.ftkx_trace_curves(nd, _lib.ll(domain[0]), _lib.ll(domain[1], fill=1), recs.ctypes.data, len(recs), C.byref(out)))
+    if ctx is not None:
+        _lib.check(L.ftkx_trace_curves_ctx(ctx._h, nd, _lib.ll(domain[0]), _lib.ll(domain[1], fill=1), recs.ctypes.data, len(recs), C.byref(out)), ctx._h)
+    else:
+        _lib.check(L.ftkx_trace_curves(nd, _lib.ll(domain[0]), _lib.ll(domain[1], fill=1), recs.ctypes.data, len(recs), C.byref(out)))
     offs = np.ctypeslib.as_array(out.offsets, shape=(out.n_curves + 1,)).copy()
     idx = np.ctypeslib.as_array(out.indices, shape=(max(1, out.n_points),))[:out.n_points].copy()
     loop = np.ctypeslib.as_array(out.loop, shape=(max(1, out.n_curves),))[:out.n_curves].copy()
@@ -412,15 +416,19 @@ def post_process(nd, domain, records):
     return ts
 
 
-def pass2(nd, domain, records):
-    """ftkx_trace_curves, then ftkx_post_process_curves on its result, each timed by itself (the C calls only)
+def pass2(nd, domain, records, ctx=None):
+    """ftkx_trace_curves (ctx given: ftkx_trace_curves_ctx, its data-parallel half on that context's GPU), then ftkx_post_process_curves
+    on its result, each timed by itself (the C calls only)
     -> (curves as index arrays, loop flags, n_special, TrajectorySet, ms_trace, ms_post_process)"""
     import time
     L = _lib.load()
     recs = np.ascontiguousarray(records, dtype=CP_DTYPE)
     cur = _lib.Curves()
     t0 = time.perf_counter()
-    _lib.check(L.ftkx_trace_curves(nd, _lib.ll(domain[0]), _lib.ll(domain[1], fill=1), recs.ctypes.data, len(recs), C.byref(cur)))
+    if ctx is not None:
+        _lib.check(L.ftkx_trace_curves_ctx(ctx._h, nd, _lib.ll(domain[0]), _lib.ll(domain[1], fill=1), recs.ctypes.data, len(recs), C.byref(cur)), ctx._h)
+    else:
+        _lib.check(L.ftkx_trace_curves(nd, _lib.ll(domain[0]), _lib.ll(domain[1], fill=1), recs.ctypes.data, len(recs), C.byref(cur)))
     t1 = time.perf_counter()
     out = _lib.Trajectories()
     rc = L.ftkx_post_process_curves(recs.ctypes.data, len(recs), C.byref(cur), C.byref(out))

@@ -188,6 +188,10 @@ struct ftkx_ctx {
   int sr_skip_small = 0;             // passes for which the fused tail kernel is not launched (the data was hit-dense a moment ago)
   int sr_last_path = 0;              // which way the last ftkx_sweep_series went: 1 device-driven, 2 early single-workgroup tail, 0 the host-driven batch
   unsigned long long sr_last_status = 0;
+  // pass 2 on the device (trace_device.hip): tags up, neighbours / degrees / roots down
+  void *tr_dev = nullptr, *tr_host = nullptr, *tr_parent = nullptr, *tr_tables = nullptr;
+  size_t tr_cap = 0;
+  int tr_tables_nd = 0;
   ftkx_stats stats;
   // optional kernel timing (hipEvents on the context's stream)
   int profiling = 0;               // 0 off, 1 every kernel family, 2 the mask kernel only

@@ -379,6 +379,8 @@ void ftkx_destroy(ftkx_ctx *c)
   for (void *p : {(void *)c->d_word_idx, (void *)c->d_words, (void *)c->d_cells, (void *)c->d_patch_cells, (void *)c->d_patches, c->d_packed}) if (p) (void)hipFree(p);
   for (void *p : {(void *)c->sr_results, (void *)c->sr_hist, (void *)c->sr_boff, (void *)c->sr_bucketed, (void *)c->sr_sorted}) if (p) (void)hipFree(p);
   if (c->sr_h_results) (void)hipHostFree(c->sr_h_results);
+  for (void *p : {c->tr_dev, c->tr_parent, c->tr_tables}) if (p) (void)hipFree(p);
+  if (c->tr_host) (void)hipHostFree(c->tr_host);
   for (ftkx_series_slot &sl : c->sr_slots) {
     if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
     for (hipEvent_t e : {sl.ev_masks, sl.ev_factors, sl.ev_done}) if (e) (void)hipEventDestroy(e);

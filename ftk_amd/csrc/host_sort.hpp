@@ -33,4 +33,17 @@ void sort_on_threads(std::vector<T> &v)
   }
 }
 
+
+// f(begin, end) over [0, n) on a few host threads (plain std::thread: for loops of ~10^5 elements that copy or convert)
+template <class F>
+void for_ranges_on_threads(size_t n, F f)
+{
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned parts = n < 16384 ? 1u : std::min(8u, hw);
+  if (parts <= 1) { f((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (unsigned i = 1; i < parts; i ++) th.emplace_back([&, i] { f(n * i / parts, n * (i + 1) / parts); });
+  f((size_t)0, n / parts);
+  for (auto &t : th) t.join();
+}
 }  // namespace ftkx

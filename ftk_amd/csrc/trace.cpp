@@ -346,8 +346,8 @@ template <class F>
 void parallel_ranges(size_t n, F f, unsigned cap = 16, size_t min_n = 4096)
 {
   unsigned nt = std::thread::hardware_concurrency();
-  if (const char *e = getenv("FTKX_TRACE_THREADS")) nt = (unsigned)atoi(e);
   if (nt > cap) nt = cap;
+  if (const char *e = getenv("FTKX_TRACE_THREADS")) nt = (unsigned)atoi(e);      // (an explicit choice is taken as it is)
   if (nt < 2 || n < min_n) { f((size_t)0, n); return; }
   const std::function<void(size_t, size_t)> fn = f;
   WorkerPool::get().run(n, nt, fn);
@@ -374,8 +374,12 @@ void Tracer<N>::build_hash(const ftkx_cp_t *recs, size_t n, bool parallel)
   if (parallel) parallel_ranges(n, insert); else insert(0, n);
 }
 
+// what the device has already done for a record set (trace_device.hip): the neighbours of every record inside the set, in the
+// reference's element order (`maxnb` slots per record, `deg` of them filled), and the component root of every ordinary record
+struct DevicePhase { const int *nbr; const unsigned char *deg; const int *root; int maxnb; };
+
 template <int N>
-int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs, size_t n, ftkx_curves *out)
+int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs, size_t n, ftkx_curves *out, const DevicePhase *dev = nullptr)
 {
   static const Adjacency<N> adj;
   const bool prof = getenv("FTKX_TRACE_PROF") != nullptr;
@@ -385,27 +389,33 @@ int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs
   Tracer<N> tr(adj, dst, dsz);
   // duplicate tags are refused.  The sweep hands its records over sorted by tag: adjacent records are compared in place; only an
   // unsorted set pays for an index and a sort
-  bool sorted = true;
-  for (size_t i = 1; i < n && sorted; i ++) sorted = recs[i - 1].tag <= recs[i].tag;
-  if (sorted) { for (size_t i = 1; i < n; i ++) if (recs[i].tag == recs[i - 1].tag) return FTKX_E_INVALID; }
+  if (dev) { if (dev->maxnb != MAXNB) return FTKX_E_INVALID; }       // (the caller has checked the tags: strictly ascending)
   else {
-    tr.index.resize(n);
-    for (size_t i = 0; i < n; i ++) tr.index[i] = {recs[i].tag, (int)i};
-    ftkx::sort_on_threads(tr.index);
-    for (size_t i = 1; i < n; i ++) if (tr.index[i].first == tr.index[i - 1].first) return FTKX_E_INVALID;
+    bool sorted = true;
+    for (size_t i = 1; i < n && sorted; i ++) sorted = recs[i - 1].tag <= recs[i].tag;
+    if (sorted) { for (size_t i = 1; i < n; i ++) if (recs[i].tag == recs[i - 1].tag) return FTKX_E_INVALID; }
+    else {
+      tr.index.resize(n);
+      for (size_t i = 0; i < n; i ++) tr.index[i] = {recs[i].tag, (int)i};
+      ftkx::sort_on_threads(tr.index);
+      for (size_t i = 1; i < n; i ++) if (tr.index[i].first == tr.index[i - 1].first) return FTKX_E_INVALID;
+    }
+    tr.build_hash(recs, n, true);
   }
-  tr.build_hash(recs, n, true);
   tp[np_ ++] = now();
   std::vector<Elem> elem(n);
   // adjacency lists inside the hit set (sorted in element order), flat: at most MAXNB neighbours per record
-  std::vector<int> nbr(n * MAXNB);
-  std::vector<unsigned char> deg(n);
+  std::vector<int> nbr_own(dev ? 0 : n * MAXNB);
+  std::vector<unsigned char> deg_own(dev ? 0 : n);
+  int *const nbr_w = nbr_own.data(); unsigned char *const deg_w = deg_own.data();
+  const int *const nbr = dev ? dev->nbr : nbr_own.data();          // (the device's lists are used where they lie: pinned, cached host memory)
+  const unsigned char *const deg = dev ? dev->deg : deg_own.data();
   // the reference's element order (corner as a vector with x FIRST, then the type) as one integer per record
   std::vector<std::pair<u64, int>> order_key(n);
   parallel_ranges(n, [&](size_t b, size_t e) {
     for (size_t i = b; i < e; i ++) {
       elem[i] = tr.decode(recs[i].tag);
-      deg[i] = (unsigned char)tr.neighbour_records(elem[i], &nbr[i * MAXNB], MAXNB);
+      if (!dev) deg_w[i] = (unsigned char)tr.neighbour_records(elem[i], &nbr_w[i * MAXNB], MAXNB);
       u64 key = 0;
       for (int d = 0; d < ND_OF(N); d ++) key = key * (u64)dsz[d] + (u64)(elem[i].c[d] - dst[d]);
       key = (key << 24) | (u64)(unsigned)elem[i].c[N - 1];           // (time: below 2^24 steps, else the comparator sort below)
@@ -419,13 +429,17 @@ int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs
   for (size_t i = 0; i < n; i ++) ordinary[i] = deg[i] <= 2;
 
   // curves = connected components of the ordinary nodes (threads: the unions of a range of records each, then everybody's root)
-  ConcurrentUnionFind uf(n);
-  parallel_ranges(n, [&](size_t b, size_t e) {
-    for (size_t i = b; i < e; i ++)
-      if (ordinary[i]) for (int j : nb(i)) if (ordinary[j] && j < (int)i) uf.unite((int)i, j);     // (every edge is seen from both ends: once is enough)
-  });
-  std::vector<int> root(n);
-  parallel_ranges(n, [&](size_t b, size_t e) { for (size_t i = b; i < e; i ++) root[i] = uf.find((int)i); });
+  std::vector<int> root_own(dev ? 0 : n);
+  const int *const root = dev ? dev->root : root_own.data();
+  if (!dev) {
+    int *const root_w = root_own.data();
+    ConcurrentUnionFind uf(n);
+    parallel_ranges(n, [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; i ++)
+        if (ordinary[i]) for (int j : nb(i)) if (ordinary[j] && j < (int)i) uf.unite((int)i, j);     // (every edge is seen from both ends: once is enough)
+    });
+    parallel_ranges(n, [&](size_t b, size_t e) { for (size_t i = b; i < e; i ++) root_w[i] = uf.find((int)i); });
+  }
   // seeds: the smallest element of every component, components enumerated in element order of their seed (a sort of the seeds only)
   std::vector<int> order;
   bool key_ok = true;
@@ -648,6 +662,35 @@ struct ftkx_online_tracer {
   std::vector<int> loop, complete;
 };
 
+namespace ftkx {
+// the candidate tables of the neighbour search, flattened for the device: per face type the (type, offset[N]) of every record that can
+// share a cell with it, in the reference's element order; cand_off has NTYPES + 1 entries; returns the slots per record (2 N)
+int trace_candidates(int nd, std::vector<int> &cand_off, std::vector<int> &cand_flat)
+{
+  cand_off.clear(); cand_flat.clear();
+  auto fill = [&](auto &adj, int N) {
+    cand_off.push_back(0);
+    for (const auto &v : adj.cand) {
+      for (const auto &c : v) { cand_flat.push_back(c.type); for (int a = 0; a < N; a ++) cand_flat.push_back(c.off[a]); for (int a = N; a < 4; a ++) cand_flat.push_back(0); }
+      cand_off.push_back((int)(cand_flat.size() / 5));
+    }
+  };
+  if (nd == 2) { static const Adjacency<3> adj; fill(adj, 3); return 6; }
+  static const Adjacency<4> adj; fill(adj, 4); return 8;
+}
+
+// ftkx_trace_curves with the neighbour search and the component labelling done elsewhere (tags strictly ascending)
+int trace_curves_with(int nd, const long long *dst, const long long *dsz, const ftkx_cp_t *recs, size_t n, ftkx_curves *out,
+                      const int *nbr, const unsigned char *deg, const int *root, int maxnb)
+{
+  if ((nd != 2 && nd != 3) || !dst || !dsz || (!recs && n) || !out) return FTKX_E_INVALID;
+  memset(out, 0, sizeof(*out));
+  const DevicePhase dp{nbr, deg, root, maxnb};
+  try { return nd == 2 ? trace_impl<3>(dst, dsz, recs, n, out, &dp) : trace_impl<4>(dst, dsz, recs, n, out, &dp); }
+  catch (const std::bad_alloc &) { return FTKX_E_NOMEM; }
+}
+}  // namespace ftkx
+
 extern "C" {
 
 int ftkx_online_tracer_create(ftkx_online_tracer **out, int nd, const long long domain_st[3], const long long domain_sz[3])
@@ -718,106 +761,113 @@ int ftkx_post_process_curves(const ftkx_cp_t *recs, size_t n, const ftkx_curves 
   if (!out || !in || (n && !recs)) return FTKX_E_INVALID;
   memset(out, 0, sizeof(*out));
   struct Pt { long long idx; unsigned type; double t; int ordinal, timestep; };
-  struct Curve { std::vector<Pt> p; int loop; int id; };
-  // Every traced curve is worked on by itself -- smoothing, rotation, splitting, and the re-ordering / time adjustment of its pieces --
-  // so the curves are dealt to the host threads in ONE parallel region (62 181 points in 72 curves: 2.9 ms on one thread); a second
-  // region copies the pieces out.
-  const size_t per_curve_min = in->n_points >= 8192 ? 2 : (size_t)-1;      // (few points: the hand-over to the threads costs more than the work)
-  std::vector<std::vector<Curve>> pieces(in->n_curves);
+  struct Piece { size_t b, e; int loop, id; };               // a trajectory: points [b, e) of the flat array
+  // Every traced curve is worked on by itself, in place in ONE flat array of points (smoothing, rotation; the pieces split_all cuts it
+  // into are sub-ranges of its range; re-ordering and time adjustment work on those): no allocation per curve, and the curves are
+  // handed to the host threads one by one (62 181 points in 72 curves of very different lengths: 2.9 ms on one thread with a vector
+  // per curve, 0.9 ms on 16 threads with vectors, the allocator in everybody's way).
+  const size_t nc = in->n_curves, np_in = in->n_points;
+  for (size_t c = 0; c < nc; c ++) if (in->offsets[c] < 0 || in->offsets[c + 1] < in->offsets[c] || (size_t)in->offsets[c + 1] > np_in) return FTKX_E_INVALID;
+  std::vector<Pt> P(np_in);
+  std::vector<std::vector<Piece>> pieces(nc);
   std::atomic<int> bad{0};
-  auto ordinals_of = [](const std::vector<Pt> &p) { std::vector<int> o; for (size_t i = 0; i < p.size(); i ++) if (p[i].ordinal) o.push_back((int)i); return o; };
-  parallel_ranges(in->n_curves, [&](size_t cb, size_t ce) {
-  for (size_t c = cb; c < ce; c ++) {
-    Curve cv;
-    cv.loop = in->loop[c];
-    cv.id = (int)c;                              // feature_curve_set_t::add numbers traced curves 0, 1, 2, ... (feature_curve_set.hh:458-465)
-    std::vector<Pt> &p = cv.p;
-    p.reserve((size_t)(in->offsets[c + 1] - in->offsets[c]));
-    for (long long k = in->offsets[c]; k < in->offsets[c + 1]; k ++) {
-      const long long i = in->indices[k];
-      if (i < 0 || (size_t)i >= n) { bad = 1; break; }
-      p.push_back(Pt{i, recs[i].type, recs[i].t, ftkx_cp_ordinal(&recs[i]), ftkx_cp_timestep(&recs[i])});
-    }
-    if (bad) return;
-    {   // smooth_ordinal_types(half_window_size = 2)
-      const int h = 2;
-      const std::vector<int> o = ordinals_of(p);
-      if ((int)o.size() >= 2 * h + 1) {
-        std::vector<std::pair<int, unsigned>> pending;
-        for (int i = h; i < (int)o.size() - h; i ++) {
-          unsigned consistent = p[o[i - h]].type;
-          for (int j = i - h; j <= i + h; j ++) {
-            if (j == i) continue;
-            if (consistent != p[o[j]].type) { consistent = 0; break; }
+  std::atomic<size_t> next_curve{0};
+  auto work = [&](size_t, size_t) {                            // (ranges ignored: the curves are handed out one by one)
+    std::vector<int> o;                                        // positions of the ordinal points of the curve in hand
+    std::vector<std::pair<int, unsigned>> pending;
+    for (;;) {
+      const size_t c = next_curve.fetch_add(1);
+      if (c >= nc) break;
+      const size_t b0 = (size_t)in->offsets[c], e0 = (size_t)in->offsets[c + 1], len = e0 - b0;
+      Pt *p = P.data() + b0;
+      for (size_t k = 0; k < len; k ++) {
+        const long long i = in->indices[b0 + k];
+        if (i < 0 || (size_t)i >= n) { bad = 1; break; }
+        p[k] = Pt{i, recs[i].type, recs[i].t, ftkx_cp_ordinal(&recs[i]), ftkx_cp_timestep(&recs[i])};
+      }
+      if (bad) break;
+      const int loop = in->loop[c];
+      auto ordinals = [&]() { o.clear(); for (size_t i = 0; i < len; i ++) if (p[i].ordinal) o.push_back((int)i); };
+      {   // smooth_ordinal_types(half_window_size = 2)
+        const int h = 2;
+        ordinals();
+        if ((int)o.size() >= 2 * h + 1) {
+          pending.clear();
+          for (int i = h; i < (int)o.size() - h; i ++) {
+            unsigned consistent = p[o[i - h]].type;
+            for (int j = i - h; j <= i + h; j ++) {
+              if (j == i) continue;
+              if (consistent != p[o[j]].type) { consistent = 0; break; }
+            }
+            if (consistent != 0 && p[o[i]].type != consistent) pending.push_back({o[i], consistent});
           }
-          if (consistent != 0 && p[o[i]].type != consistent) pending.push_back({o[i], consistent});
+          for (const auto &kv : pending) p[kv.first].type = kv.second;
         }
-        for (const auto &kv : pending) p[kv.first].type = kv.second;
       }
-    }
-    {   // smooth_interval_types
-      const std::vector<int> o = ordinals_of(p);
-      if (!o.empty()) {
-        const unsigned ft = p[o.front()].type;
-        for (int i = 0; i < o.front(); i ++) p[i].type = ft;
-        const unsigned bt = p[o.back()].type;
-        for (int i = o.back(); i < (int)p.size(); i ++) p[i].type = bt;
-        for (size_t i = 0; i + 1 < o.size(); i ++) {
-          if (p[o[i]].type == p[o[i + 1]].type) {
-            const unsigned it = p[o[i]].type;
-            for (int j = o[i]; j < o[i + 1]; j ++) p[j].type = it;
-          } else {
-            const unsigned lt = p[o[i]].type, rt = p[o[i + 1]].type;
-            int j;
-            for (j = o[i]; j < o[i + 1]; j ++) if (p[j].type != lt) break;
-            for (; j < o[i + 1]; j ++) p[j].type = rt;
+      {   // smooth_interval_types (the ordinal positions are the same: types changed, places did not)
+        if (!o.empty()) {
+          const unsigned ft = p[o.front()].type;
+          for (int i = 0; i < o.front(); i ++) p[i].type = ft;
+          const unsigned bt = p[o.back()].type;
+          for (int i = o.back(); i < (int)len; i ++) p[i].type = bt;
+          for (size_t i = 0; i + 1 < o.size(); i ++) {
+            if (p[o[i]].type == p[o[i + 1]].type) {
+              const unsigned it = p[o[i]].type;
+              for (int j = o[i]; j < o[i + 1]; j ++) p[j].type = it;
+            } else {
+              const unsigned lt = p[o[i]].type, rt = p[o[i + 1]].type;
+              int j;
+              for (j = o[i]; j < o[i + 1]; j ++) if (p[j].type != lt) break;
+              for (; j < o[i + 1]; j ++) p[j].type = rt;
+            }
           }
         }
       }
-    }
-    // rotate
-    if (cv.loop && !p.empty() && p.front().type == p.back().type) {
-      size_t i = 0;
-      for (; i < p.size(); i ++) if (p.front().type != p[i].type) break;
-      if (i < p.size()) std::rotate(p.begin(), p.begin() + i, p.end());
-    }
-    // split_all
-    std::vector<Curve> &result = pieces[c];
-    unsigned consistent = p.empty() ? 1u : p[0].type;
-    for (const Pt &q : p) if (q.type != consistent) { consistent = 0; break; }
-    if (p.empty() || consistent != 0) result.push_back(std::move(cv));
-    else {
-      Curve sub; sub.loop = 0; sub.id = cv.id;   // split_all re-adds the pieces under their parent's label (feature_curve_set.hh:530-531)
-      unsigned current = 0;
-      for (size_t i = 0; i < p.size(); i ++) {
-        if (sub.p.empty()) current = p[i].type;
-        if (p[i].type == current) sub.p.push_back(p[i]);
-        if (p[i].type != current || i == p.size() - 1) {
-          if (!sub.p.empty()) { result.push_back(sub); sub.p.clear(); }
+      // rotate
+      if (loop && len && p[0].type == p[len - 1].type) {
+        size_t i = 0;
+        for (; i < len; i ++) if (p[0].type != p[i].type) break;
+        if (i < len) std::rotate(p, p + i, p + len);
+      }
+      // split_all: runs of one type; the point that ends a run belongs to no piece (feature_curve.hh:220-243, reproduced)
+      std::vector<Piece> &result = pieces[c];
+      unsigned consistent = len ? p[0].type : 1u;
+      for (size_t i = 0; i < len; i ++) if (p[i].type != consistent) { consistent = 0; break; }
+      if (!len || consistent != 0) result.push_back(Piece{b0, e0, loop, (int)c});     // feature_curve_set_t::add numbers traced curves 0, 1, 2, ... (feature_curve_set.hh:458-465)
+      else {
+        size_t run_b = 0, run_n = 0;
+        unsigned current = 0;
+        for (size_t i = 0; i < len; i ++) {
+          if (run_n == 0) { current = p[i].type; run_b = i; }
+          if (p[i].type == current) run_n ++;
+          if (p[i].type != current || i == len - 1) {
+            if (run_n) { result.push_back(Piece{b0 + run_b, b0 + run_b + run_n, 0, (int)c}); run_n = 0; }   // split_all re-adds the pieces under their parent's label (feature_curve_set.hh:530-531)
+          }
         }
       }
-    }
-    for (Curve &piece : result) {
-      std::vector<Pt> &q = piece.p;
-      if (!q.empty() && !piece.loop) {   // reorder
-        bool reverse = false;
-        if (q.front().timestep == q.back().timestep) { if (q.front().t > q.back().t) reverse = true; }
-        else if (q.front().timestep > q.back().timestep) reverse = true;
-        if (reverse) std::reverse(q.begin(), q.end());
+      for (const Piece &pc : result) {
+        Pt *q = P.data() + pc.b;
+        const size_t m = pc.e - pc.b;
+        if (m && !pc.loop) {   // reorder
+          bool reverse = false;
+          if (q[0].timestep == q[m - 1].timestep) { if (q[0].t > q[m - 1].t) reverse = true; }
+          else if (q[0].timestep > q[m - 1].timestep) reverse = true;
+          if (reverse) std::reverse(q, q + m);
+        }
+        // adjust_time
+        for (size_t i = 0; i < m; i ++) { if (i == 0 || q[i].ordinal) continue; q[i].t = std::max(q[i - 1].t, q[i].t); }
+        for (size_t i = m; i -- > 0; ) { if (i == m - 1 || q[i].ordinal) continue; q[i].t = std::min(q[i + 1].t, q[i].t); }
       }
-      // adjust_time
-      for (size_t i = 0; i < q.size(); i ++) { if (i == 0 || q[i].ordinal) continue; q[i].t = std::max(q[i - 1].t, q[i].t); }
-      for (size_t i = q.size(); i -- > 0; ) { if (i == q.size() - 1 || q[i].ordinal) continue; q[i].t = std::min(q[i + 1].t, q[i].t); }
     }
-  }
-  }, 16, per_curve_min);
+  };
+  parallel_ranges(np_in, work, 16, 8192);
   if (bad) return FTKX_E_INVALID;
   // the pieces strung together in the curves' order
-  std::vector<size_t> first(in->n_curves + 1, 0);
-  for (size_t c = 0; c < in->n_curves; c ++) first[c + 1] = first[c] + pieces[c].size();
-  const size_t nres = first[in->n_curves];
+  std::vector<size_t> first(nc + 1, 0);
+  for (size_t c = 0; c < nc; c ++) first[c + 1] = first[c] + pieces[c].size();
+  const size_t nres = first[nc];
   size_t np = 0;
-  for (const auto &pc : pieces) for (const Curve &cv : pc) np += cv.p.size();
+  for (const auto &pc : pieces) for (const Piece &q : pc) np += q.e - q.b;
   out->n_curves = nres; out->n_points = np;
   out->offsets = (long long *)malloc((nres + 1) * sizeof(long long));
   out->indices = (long long *)malloc((np ? np : 1) * sizeof(long long));
@@ -827,18 +877,22 @@ int ftkx_post_process_curves(const ftkx_cp_t *recs, size_t n, const ftkx_curves 
   out->id = (int *)malloc((nres ? nres : 1) * sizeof(int));
   if (!out->offsets || !out->indices || !out->loop || !out->type || !out->t || !out->id) return FTKX_E_NOMEM;
   out->offsets[0] = 0;
-  for (size_t c = 0; c < in->n_curves; c ++)
-    for (size_t j = 0; j < pieces[c].size(); j ++) out->offsets[first[c] + j + 1] = out->offsets[first[c] + j] + (long long)pieces[c][j].p.size();
-  parallel_ranges(in->n_curves, [&](size_t cb, size_t ce) {
-    for (size_t c = cb; c < ce; c ++)
+  for (size_t c = 0; c < nc; c ++)
+    for (size_t j = 0; j < pieces[c].size(); j ++) out->offsets[first[c] + j + 1] = out->offsets[first[c] + j] + (long long)(pieces[c][j].e - pieces[c][j].b);
+  std::atomic<size_t> next_out{0};
+  parallel_ranges(np_in, [&](size_t, size_t) {
+    for (;;) {
+      const size_t c = next_out.fetch_add(1);
+      if (c >= nc) break;
       for (size_t j = 0; j < pieces[c].size(); j ++) {
         const size_t r = first[c] + j;
         size_t k = (size_t)out->offsets[r];
-        for (const Pt &q : pieces[c][j].p) { out->indices[k] = q.idx; out->type[k] = q.type; out->t[k] = q.t; k ++; }
+        for (size_t i = pieces[c][j].b; i < pieces[c][j].e; i ++) { out->indices[k] = P[i].idx; out->type[k] = P[i].type; out->t[k] = P[i].t; k ++; }
         out->loop[r] = pieces[c][j].loop;
         out->id[r] = pieces[c][j].id;
       }
-  }, 16, per_curve_min);
+    }
+  }, 16, 8192);
   return FTKX_OK;
 }
 

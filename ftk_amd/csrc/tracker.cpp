@@ -532,18 +532,29 @@ void critical_point_tracker_regular::finalize()
   // in the reference's order.  Sweeps in time order with 64-bit tags deliver ascending tags: the pending points are traced as they are.
   if (!(points.empty() && pending_ascending)) flush_points();
   const std::vector<feature_point_t> &src = points.empty() ? pending_points : points;
+  // (the flat store is in the reference's element order; the trace's device phases want ascending tags: an index sorted on a few
+  // threads, and the curves' indices mapped back through it)
+  std::vector<std::pair<unsigned long long, size_t>> by_tag;
+  if (!points.empty()) {
+    by_tag.resize(src.size());
+    for (size_t i = 0; i < src.size(); i ++) by_tag[i] = {src[i].tag, i};
+    ftkx::sort_on_threads(by_tag);
+  }
   std::vector<ftkx_cp_t> recs(src.size());
   if (!src.empty()) std::memset(recs.data(), 0, recs.size() * sizeof(ftkx_cp_t));
-  for (size_t i = 0; i < src.size(); i ++) recs[i].tag = src[i].tag;
+  for (size_t i = 0; i < src.size(); i ++) recs[i].tag = by_tag.empty() ? src[i].tag : by_tag[i].first;
   long long dst[3] = {0, 0, 0}, dsz[3] = {1, 1, 1};
   for (int d = 0; d < nd; d ++) { dst[d] = domain.start(d); dsz[d] = domain.size(d); }
   ftkx_curves c{};
-  const int rc = ftkx_trace_curves(nd, dst, dsz, recs.data(), recs.size(), &c);
+  // (neighbour search and component labelling on the tracker's GPU where the record set is large enough to pay for the round trip)
+  const int rc = ftkx_trace_curves_ctx(ctx, nd, dst, dsz, recs.data(), recs.size(), &c);
   if (rc != FTKX_OK) { ftkx_free_curves(&c); throw ftkx_error(rc, "finalize: ftkx_trace_curves failed (tags must not have overflowed int32: use FTKX_TAG_EXACT64 on very large meshes)"); }
   // the curves stay flat -- the points of all curves one after the other; one vector per curve is built only if somebody asks for it
   traced_points.resize(c.n_points); traced_offsets.assign(c.offsets, c.offsets + c.n_curves + 1);
   traced_loop.assign(c.loop, c.loop + c.n_curves); traced_id.resize(c.n_curves);
-  for (size_t k = 0; k < c.n_points; k ++) traced_points[k] = src[(size_t)c.indices[k]];
+  ftkx::for_ranges_on_threads(c.n_points, [&](size_t b, size_t e) {
+    for (size_t k = b; k < e; k ++) traced_points[k] = src[by_tag.empty() ? (size_t)c.indices[k] : by_tag[(size_t)c.indices[k]].second];
+  });
   for (size_t i = 0; i < c.n_curves; i ++) traced_id[i] = (int)i;
   traced_nested_valid = false;
   ftkx_free_curves(&c);
@@ -572,7 +583,7 @@ struct flat_curves {   // traced curves as one record array (points in curve ord
   std::vector<long long> indices;
   flat_curves(const std::vector<feature_point_t> &pts) : recs(pts.size()), indices(pts.size())
   {
-    for (size_t i = 0; i < pts.size(); i ++) { recs[i] = record_of(pts[i]); indices[i] = (long long)i; }
+    ftkx::for_ranges_on_threads(pts.size(), [&](size_t b, size_t e) { for (size_t i = b; i < e; i ++) { recs[i] = record_of(pts[i]); indices[i] = (long long)i; } });
   }
 };
 std::string io_error()
@@ -596,10 +607,12 @@ void critical_point_tracker_regular::post_process()
   if (rc != FTKX_OK) { ftkx_free_trajectories(&out); throw ftkx_error(rc, "post_process failed"); }
   std::vector<feature_point_t> pts(out.n_points);
   std::vector<int> loop(out.n_curves), ids(out.n_curves);
-  for (size_t k = 0; k < out.n_points; k ++) {
-    pts[k] = traced_points[(size_t)out.indices[k]];
-    pts[k].type = out.type[k]; pts[k].t = out.t[k];
-  }
+  ftkx::for_ranges_on_threads(out.n_points, [&](size_t b, size_t e) {
+    for (size_t k = b; k < e; k ++) {
+      pts[k] = traced_points[(size_t)out.indices[k]];
+      pts[k].type = out.type[k]; pts[k].t = out.t[k];
+    }
+  });
   // a split piece keeps its parent's label; labels of traced curves are their own (possibly already post-processed) ids
   for (size_t c = 0; c < out.n_curves; c ++) { loop[c] = out.loop[c]; ids[c] = traced_id[out.id[c]]; }
   traced_offsets.assign(out.offsets, out.offsets + out.n_curves + 1);

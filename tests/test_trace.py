@@ -112,3 +112,27 @@ def test_online_tracer_equals_reference_streaming_trajectories():
         assert got == exp, name                                   # including the order in which the trajectories were born
         assert np.array_equal(np.sort(recs["tag"][ref["timestep"] == DT - 1]), sg["leftover_tags"])
         tr.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["woven_31x37x32", "woven_128x128x10", "moving_extremum_3d_21x21x21x4_overflow", "singular_terraces_72x64x56x8", "double_gyre_64x32x50"])
+def test_device_phases_give_the_host_curves(name):
+    """ftkx_trace_curves_ctx -- neighbour search (binary search in the sorted tags) and component labelling (lock-free union-find) on
+    the GPU, seeds and walks on host threads -- against ftkx_trace_curves: the same curves, point for point (and so the reference's,
+    which the tests above hold the host path to)"""
+    import torch
+    import ftk_amd
+    assert torch.cuda.is_available()
+    g = load_golden(name)
+    recs, _c, _l, _n = _trace(g)
+    recs = recs[np.argsort(recs["tag"], kind="stable")]             # (the sweep delivers its records in tag order: what the device path takes)
+    lo = 2 if g["nv"] == 1 else 1
+    dom = ([lo] * g["nd"], [d - (3 if g["nv"] == 1 else 2) for d in g["dims"]])
+    curves, loop, nspecial = ftk_amd.trace_curves(g["nd"], dom, recs)
+    ctx = ftk_amd.Context(g["nd"])
+    for rep in range(2):
+        c2, l2, n2 = ftk_amd.trace_curves(g["nd"], dom, recs, ctx=ctx)
+        assert n2 == nspecial and len(c2) == len(curves) and np.array_equal(l2, loop)
+        for a, b in zip(c2, curves):
+            assert np.array_equal(a, b)
+    ctx.close()

@@ -26,7 +26,7 @@ for t in range(nt):
 recs = np.array(ctx.sweep_collect())
 print("records", len(recs), "host threads", os.cpu_count())
 os.environ["FTKX_TRACE_PROF"] = "1"
-for threads in (1, 2, 4, 8, 16):
+for threads in (8, 16, 24, 32, 48, 64):
     os.environ["FTKX_TRACE_THREADS"] = str(threads)
     best = 1e9
     for rep in range(5):
