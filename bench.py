@@ -558,7 +558,9 @@ def job(args, env):
             try:
                 ent = json.load(open(tj)).get(args.config, {})
                 if ent.get("kernel") == kernel_symbol:
-                    traffic, traffic_source = ent.get("hbm_bytes_per_launch"), ent.get("source")
+                    # (not measured in this run: a PMC pass cannot run inside it -- the figure is the committed profile's, named with the
+                    # commit whose kernel sources it was taken from)
+                    traffic, traffic_source = ent.get("hbm_bytes_per_launch"), "from %s (kernel sources at %s)" % (ent.get("source"), ent.get("kernel_sources_at", "round 2"))
                 else:
                     traffic_source = "profiles/traffic.json holds %s, not the kernel that ran: no traffic figure" % ent.get("kernel")
             except Exception:   # noqa: BLE001

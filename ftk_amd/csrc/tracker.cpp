@@ -36,6 +36,7 @@ struct critical_point_tracker_regular::multi_engine {
     std::condition_variable cv;
     std::deque<std::function<void()>> q;
     bool stop = false, busy = false;
+    unsigned long long posted = 0, done = 0;     // jobs handed in / finished (FIFO: `done >= ticket` says a particular job is through)
   };
   std::vector<std::unique_ptr<worker>> w;
   int block = 2, t_first = -1;
@@ -66,7 +67,7 @@ struct critical_point_tracker_regular::multi_engine {
       try { f(); }
       catch (const ftkx_error &e) { raise(e.code, e.what()); }
       catch (const std::exception &e) { raise(FTKX_E_INVALID, e.what()); }
-      { std::lock_guard<std::mutex> lk(W->mu); W->busy = false; }
+      { std::lock_guard<std::mutex> lk(W->mu); W->busy = false; W->done ++; }
       W->cv.notify_all();
     }
   }
@@ -78,10 +79,19 @@ struct critical_point_tracker_regular::multi_engine {
     { std::lock_guard<std::mutex> g(bmu); }
     bcv.notify_all();
   }
-  void post(int d, std::function<void()> f)
+  unsigned long long post(int d, std::function<void()> f)
   {
-    { std::lock_guard<std::mutex> lk(w[d]->mu); w[d]->q.push_back(std::move(f)); }
+    unsigned long long ticket;
+    { std::lock_guard<std::mutex> lk(w[d]->mu); w[d]->q.push_back(std::move(f)); ticket = ++ w[d]->posted; }
     w[d]->cv.notify_all();
+    return ticket;
+  }
+  // waits for ONE job (its ticket), not for the device's queue to drain: a push only has to know that its own copy is through, while the
+  // sweeps queued behind it on that device run on
+  void wait_job(int d, unsigned long long ticket)
+  {
+    std::unique_lock<std::mutex> lk(w[d]->mu);
+    w[d]->cv.wait(lk, [&] { return w[d]->done >= ticket; });
   }
   void wait(int d)
   {
@@ -320,11 +330,12 @@ void critical_point_tracker_regular::push_everywhere(int kind, int t, const doub
   // Device memory is COPIED into each context (a peer copy where the devices differ; the contexts recycle their slice buffers, so
   // no allocation per step): the steps run later than the calls that queue them, and the caller's buffer is free again on return
   // -- adopting the pointer would tie its lifetime to a queue the caller cannot see.
+  std::vector<std::pair<int, unsigned long long>> tickets;
   for (int d : targets) {
     ftkx_ctx *c = multi->w[d]->ctx;
-    multi->post(d, [=] { const int rc = push_to(c, kind, t, s, v, j, device ? 2 : 0); if (rc) { char buf[512]; ftkx_last_error(c, buf, sizeof(buf)); throw ftkx_error(rc, buf); } });
+    tickets.push_back({d, multi->post(d, [=] { const int rc = push_to(c, kind, t, s, v, j, device ? 2 : 0); if (rc) { char buf[512]; ftkx_last_error(c, buf, sizeof(buf)); throw ftkx_error(rc, buf); } })});
   }
-  for (int d : targets) multi->wait(d);
+  for (const auto &tk : tickets) multi->wait_job(tk.first, tk.second);     // (the caller's buffer is free again once these copies are through)
   multi->rethrow();
   multi->resident[t] = targets;
 }

@@ -1,12 +1,15 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): rocprofv3 kernel trace + separate PMC passes for one bench config, plus the FETCH_SIZE calibration.
-# usage: bash tools/collect_profiles.sh <config> <tag>
-CFG=${1:-c4}; TAG=${2:-r01}
+# Runs on the GPU box (gpurun): rocprofv3 kernel trace + separate PMC passes for one bench config, plus the FETCH_SIZE calibration and
+# the timeline of one pass.   usage: bash tools/collect_profiles.sh <config> <tag>
+CFG=${1:-c4}; TAG=${2:-r03}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/profiles_${TAG}_${CFG}; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --config $CFG --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_under_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_pmc_write.log 2>&1
+LIGHT="--no-cpu-baseline --no-other-configs --no-streaming-tracker"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --config $CFG --steps 5 --warmup 2 $LIGHT > $OUT/bench_under_trace.log 2>&1
+python3 tools/pass_timeline.py $OUT/trace --first series_begin_kernel > $OUT/timeline.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --config $CFG --steps 2 --warmup 1 $LIGHT > $OUT/bench_under_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --config $CFG --steps 2 --warmup 1 $LIGHT > $OUT/bench_under_pmc_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calib -- python3 tools/calibrate_fetch.py > $OUT/calib.log 2>&1
-python3 bench.py --config $CFG --steps 5 --warmup 1 > $OUT/bench_plain.json 2> $OUT/bench_plain.err
-tail -1 $OUT/bench_plain.json | cut -c1-400
+python3 bench.py --config $CFG --steps 20 --warmup 3 $LIGHT > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+find $OUT -name "*kernel_trace.csv" -size +3M -delete
+tail -1 $OUT/bench_plain.json | cut -c1-300

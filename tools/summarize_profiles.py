@@ -28,6 +28,14 @@ def one(pattern):
 
 
 shutil.copy(one("trace/*/*kernel_stats.csv"), os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "timeline.txt")):
+    shutil.copy(os.path.join(src, "timeline.txt"), os.path.join(dst, f"{tag}_{cfg}_pass_timeline.txt"))
+import subprocess
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "ftk_amd/csrc"], cwd=ROOT, capture_output=True, text=True).stdout.strip())
+except Exception:   # noqa: BLE001
+    commit, dirty = "unknown", False
 shutil.copy(one("bench_plain.json"), os.path.join(dst, f"{tag}_{cfg}_bench.json"))
 
 
@@ -68,7 +76,7 @@ traffic = json.load(open(tj)) if os.path.exists(tj) else {}
 if cand:
     best = max(cand, key=lambda v: v["hbm_bytes_per_dispatch"])
     traffic[cfg] = {"kernel": bench["roofline"]["kernel"], "hbm_bytes_per_launch": best["hbm_bytes_per_dispatch"],
-                    "source": f"profiles/{tag}_{cfg}_pmc_summary.json"}
+                    "source": f"profiles/{tag}_{cfg}_pmc_summary.json", "kernel_sources_at": commit + (" + uncommitted changes" if dirty else "")}
 json.dump(traffic, open(tj, "w"), indent=1)
 print(json.dumps(summary, indent=1))
 print("bench:", bench["value"], bench["roofline"]["frac"], bench["roofline"]["kernel_ms_per_pass"])
