@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "oracle", "_ref", "ftk_ref_driver")
 ABORTED = []
+COMPARED = {"cases": 0}
 
 
 @pytest.fixture(scope="module")
@@ -81,8 +82,10 @@ def test_random_series_equal_the_real_reference(gpu, seed):
             except Exception as e:   # noqa: BLE001
                 assert "ftkx" in type(e).__name__.lower() or "Ftkx" in type(e).__name__, repr(e)
             ABORTED.append(what)
+            COMPARED["cases"] += 1
             continue
         state = {}
+        COMPARED["cases"] += 1
 
         def after(tr):
             if streaming:
@@ -111,3 +114,12 @@ def test_random_series_equal_the_real_reference(gpu, seed):
         mine = sorted((tuple(tg.tolist()), tuple(ty.tolist()), tuple(tt.tolist()), lp) for tg, ty, tt, lp, _ in state["pp"])
         theirs = sorted((tuple(pts["tag"].tolist()), tuple(pts["type"].tolist()), tuple(pts["t"].tolist()), lp) for lp, pts in ref["pp"])
         assert mine == theirs, what + f": {len(mine)} post-processed trajectories, the reference has {len(theirs)}"
+
+
+def test_the_reference_aborted_on_few_series():
+    """(runs after the seeds above) the series skipped because the REFERENCE aborts on them in streaming mode stay a small minority: the
+    comparison above is not quietly hollowed out"""
+    import pytest
+    if not COMPARED.get("cases"):
+        pytest.skip("the seeds above did not run in this process")
+    assert len(ABORTED) <= max(3, COMPARED["cases"] // 8), (len(ABORTED), COMPARED["cases"], ABORTED[:5])

@@ -412,3 +412,79 @@ def test_cull_ahead_changes_nothing_but_the_schedule(gpu):
         assert sg == sref
         _same(ref, got)
     ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["smooth", "tiny"])
+@pytest.mark.parametrize("halo", ["full", "masked"])
+@pytest.mark.parametrize("announce", [False, True])
+def test_announced_x_masked_halo_x_factor_change(gpu, kind, halo, announce):
+    """The product the batched state machine has to get right: sweeps {announced before slices_prepare, not announced} x the slab's
+    boundary slice {resident in full, resident as sign masks + patches only} x the factor {the hint the masks were built under (256),
+    a larger one that only the other slices' reduction reveals (nbits 21)}.  Two contexts on one GPU play two ranks; the records of
+    the first rank's steps must be those of one context that holds the whole series."""
+    import torch
+    from ftk_amd import tslab
+    dims, nt, split = (72, 40, 24), 5, 3                      # rank A: steps 0 .. 2 (its last interval reads slice 3), rank B: slices 3, 4
+    rng = np.random.default_rng(11)
+    grids = np.meshgrid(*[np.linspace(-1.0, 1.0, n) for n in reversed(dims)], indexing="ij")
+    steps = []
+    for k in range(nt):
+        a = np.exp(-3.0 * sum((g - 0.07 * k) ** 2 for g in grids)) + 0.2 * np.sin(3.0 * grids[-1] + 0.3 * k)
+        if kind == "tiny" and k >= split:                     # tiny gradients arrive with rank B's slices: the factor of A's last step is not the hint's
+            a = a + 1e-6 * rng.standard_normal(a.shape)
+        steps.append(np.ascontiguousarray(a))
+    dom = ([2] * 3, [d - 3 for d in dims])
+    dev = torch.device("cuda", 0)
+
+    def make():
+        c = gpu.Context(3)
+        c.set_mesh(dom, dom, ([0] * 3, list(dims)))
+        c.set_options(jacobian_symmetric=1, derive_jacobian=1, tag_mode=gpu.TAG_EXACT64)
+        return c
+    # the whole series on one context
+    whole = make()
+    for t in range(nt):
+        whole.push_scalar_slice(t, steps[t])
+    rm = whole.slices_prepare(range(nt), 0)
+    factors = tslab.factors_from_resolutions([rm[t][0] for t in range(nt)])
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    whole.sweep_enqueue_many(range(nt), scopes, factors)
+    ref = np.array(whole.sweep_collect())
+    ref = ref[(ref["aux"] >> 1) < split]
+    if kind == "tiny":
+        assert factors[split - 1] > 256, factors               # the factor of A's boundary step really differs from the hint
+    # two ranks
+    A, B = make(), make()
+    for t in range(split):
+        A.push_scalar_slice(t, steps[t])
+    for t in range(split, nt):
+        B.push_scalar_slice(t, steps[t])
+    rmB = B.slices_prepare(range(split, nt), 0)
+    own = list(range(split))
+    if announce:
+        A.sweep_announce(own, [gpu.SCOPE_BOTH] * split)
+    if halo == "full":
+        A.push_scalar_slice(split, steps[split])
+        A.set_slice_resolution(split, rm[split][0] if rm[split][0] < 1.0 / 256 else 1e300, rm[split][1])
+        A.slices_prepare(own + [split], 0)
+    else:
+        A.slices_prepare(own, 0)
+        nbytes, _cap = B.packed_masks_bytes()
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        B.export_masks_packed(split, buf)
+        A.push_masked_slice_packed(split, True, buf, 256, rmB[split][1])
+    A.sweep_enqueue_many(own, [gpu.SCOPE_BOTH] * split, [factors[t] for t in own])
+    if halo == "masked":
+        try:
+            cells = A.sweep_cull(split, torch, dev)
+            if len(cells):
+                A.scatter_patches(split, cells, B.gather_patches(split, cells, torch))
+        except gpu.FtkxError:                                  # the masks do not serve this factor: the slice itself, as the protocol does
+            A.sweep_cancel()
+            A.push_scalar_slice(split, steps[split])
+            A.sweep_enqueue_many(own, [gpu.SCOPE_BOTH] * split, [factors[t] for t in own])
+    got = np.array(A.sweep_collect())
+    assert len(got) == len(ref) > 0, (kind, halo, announce, len(got), len(ref))
+    assert got.tobytes() == ref.tobytes(), (kind, halo, announce)
+    for c in (whole, A, B):
+        c.close()
