@@ -236,7 +236,7 @@ def test_series_overflowing_buffers_replays_through_the_batch(gpu):
     the NEXT call fits"""
     from ftk_amd import synthetic
     import torch
-    dims, nt = (1024, 1024), 72
+    dims, nt = (2048, 2048), 12
     ctx = _ctx(gpu, dims, 2, 1, tag_mode=gpu.TAG_EXACT64)
     dev = torch.device("cuda", 0)
     keep = []
