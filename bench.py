@@ -445,7 +445,7 @@ def job(args, env):
         recs, st = one_pass()
     # HIP events on the stream the kernels run on: around the dominant (mask) kernel only inside the timed region -- a pair of events costs
     # the stream ~10 us of idle time, which a 0.4 ms pass notices --, around every kernel family in a few extra passes afterwards
-    ctx.set_profiling(0 if args.no_kernel_events else 2)
+    ctx.set_profiling(0 if args.no_kernel_events else (1 if args.exact_only else 2))     # (--exact-only: the dominant kernel is the tile kernel)
     host_ms[0] = host_ms[1] = host_ms[2] = 0.0
     compact_bytes[0] = compact_bytes[1] = compact_bytes[2] = compact_bytes[3] = 0
     barrier()
@@ -538,6 +538,9 @@ def job(args, env):
         # dominant kernel = the one with the most device time; one launch of it covers `len(own)` slices (batched launch)
         domk = max(ktimes, key=lambda k: ktimes[k][0])
         dom_ms, dom_n = ktimes[domk]
+        if dom_n == 0 and ktimes_all:          # (a pass without a mask kernel: take the figure of the extra passes with events everywhere)
+            domk = max(ktimes_all, key=lambda k: ktimes_all[k][0])
+            dom_ms, dom_n = ktimes_all[domk][0] * args.steps / k_all, ktimes_all[domk][1] * args.steps / k_all
         avg_ms = dom_ms / max(1, dom_n)
         slices_per_launch = len(own) * args.steps / max(1, dom_n)
         alg_bytes_launch = (8.0 * c * n_vertex) * slices_per_launch + 72.0 * len(recs) * args.steps / max(1, dom_n)

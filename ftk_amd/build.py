@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     headers = [p for p in deps() if p not in SRC]
     newest_header = max(os.path.getmtime(h) for h in headers)
-    cflags = [f for f in FLAGS if f != "-shared"]
+    cflags = [f for f in FLAGS if f != "-shared"] + os.environ.get("FTKX_EXTRA_CFLAGS", "").split()     # (diagnostic builds: -DFTKX_TILE_STAMPS)
     objs, procs = [], []
     for src in SRC:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")

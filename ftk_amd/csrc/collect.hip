@@ -139,6 +139,14 @@ int run_batch(ftkx_ctx *c, const double *sparse_field, bool cull_done)
     } else {
       TileParams p;
       p.m = m; p.f = f; p.cull = r.mode == MODE_TILE_CULL ? 1 : 0; p.step = 0;
+      { const char *e = getenv("FTKX_TILE_FAN"); p.fan = e ? atoi(e) : 2; }
+      {
+        // largest |quantised component| the request can meet, where the slices' maxima are known (the kernel checks every tile anyway)
+        double bound = -1.0;
+        if (s0.max_known() && (!s1 || s1->max_known())) bound = std::max(s0.maxabs, s1 ? s1->maxabs : 0.0) * (double)r.factor;
+        p.form = !(nd == 3 && m.robust) ? 0 : bound < 0 ? 1 : bound < 524287.0 ? 2 : bound < 2147483647.0 ? 1 : 0;
+        p.form = std::min(p.form, p.fan == 9 ? 2 : p.fan);
+      }
       int tile[3];
       ftkx::tile_dims(nd, tile);
       for (int d = 0; d < 3; d ++) p.ntiles[d] = d < nd ? (int)((c->core_sz[d] + tile[d] - 1) / tile[d]) : 1;

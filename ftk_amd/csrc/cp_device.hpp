@@ -171,6 +171,94 @@ FTKX_HD inline bool origin_in_simplex3(const u64 X[4][3], const int id[4])
   return sgn_wrapped(c0) == s && sgn_wrapped(c1) == s && sgn_wrapped(c2) == s && sgn_wrapped(c3) == s;
 }
 
+// The same two tests for quantised components that fit in 32 bits -- every |q| < 2^31, which is the case whenever the cull is legal
+// (|q| < 727 041) and far into the overflow regime (nbits 21 on values below 1 024).  Same ring arithmetic, cheaper instructions: gfx950's
+// 32-bit integer multiply runs at a quarter of the VALU rate, and a 64 x 64 -> 64-bit product takes four of them.  A product of two
+// sign-extended 32-bit values is ONE v_mad_i64_i32, a 64-bit value times a sign-extended 32-bit one two multiplies and a correction: 36
+// multiply instructions per 3-simplex instead of 96.  (Written on sign-extended ints so that the compiler sees it; the values are the
+// very same elements of Z / 2^64.)
+FTKX_HD inline u64 mul_s32(u64 a, u64 b) { return (u64)((i64)(int)a * (i64)(int)b); }            // both operands fit in int32
+FTKX_HD inline u64 mul_64_s32(u64 p, u64 b) { return p * (u64)(i64)(int)b; }                    // b fits in int32
+
+FTKX_HD inline bool origin_in_simplex2_s32(const u64 X[3][2], const int id[3])
+{
+  const u64 c0 = mul_s32(X[1][0], X[2][1]) - mul_s32(X[1][1], X[2][0]);
+  const u64 c1 = mul_s32(X[2][0], X[0][1]) - mul_s32(X[2][1], X[0][0]);
+  const u64 c2 = mul_s32(X[0][0], X[1][1]) - mul_s32(X[0][1], X[1][0]);
+  const u64 d = c0 + c1 + c2;
+  if (degenerate_value(d) || degenerate_value(c0) || degenerate_value(c1) || degenerate_value(c2))
+    return sos_origin_in_simplex<2>(X, id);
+  const int s = sgn_wrapped(d);
+  return sgn_wrapped(c0) == s && sgn_wrapped(c1) == s && sgn_wrapped(c2) == s;
+}
+
+FTKX_HD inline bool origin_in_simplex3_s32(const u64 X[4][3], const int id[4])
+{
+  const u64 p_yz = mul_s32(X[2][1], X[3][2]) - mul_s32(X[2][2], X[3][1]), p_zx = mul_s32(X[2][2], X[3][0]) - mul_s32(X[2][0], X[3][2]),
+            p_xy = mul_s32(X[2][0], X[3][1]) - mul_s32(X[2][1], X[3][0]);
+  const u64 q_yz = mul_s32(X[0][1], X[1][2]) - mul_s32(X[0][2], X[1][1]), q_zx = mul_s32(X[0][2], X[1][0]) - mul_s32(X[0][0], X[1][2]),
+            q_xy = mul_s32(X[0][0], X[1][1]) - mul_s32(X[0][1], X[1][0]);
+  const u64 m0 = mul_64_s32(p_yz, X[1][0]) + mul_64_s32(p_zx, X[1][1]) + mul_64_s32(p_xy, X[1][2]);   // det3(X1, X2, X3)
+  const u64 m1 = mul_64_s32(p_yz, X[0][0]) + mul_64_s32(p_zx, X[0][1]) + mul_64_s32(p_xy, X[0][2]);   // det3(X0, X2, X3)
+  const u64 m2 = mul_64_s32(q_yz, X[3][0]) + mul_64_s32(q_zx, X[3][1]) + mul_64_s32(q_xy, X[3][2]);   // det3(X0, X1, X3)
+  const u64 m3 = mul_64_s32(q_yz, X[2][0]) + mul_64_s32(q_zx, X[2][1]) + mul_64_s32(q_xy, X[2][2]);   // det3(X0, X1, X2)
+  const u64 c0 = 0ull - m0, c1 = m1, c2 = 0ull - m2, c3 = m3;
+  const u64 d = c0 + c1 + c2 + c3;
+  if (degenerate_value(d) || degenerate_value(c0) || degenerate_value(c1) || degenerate_value(c2) || degenerate_value(c3))
+    return sos_origin_in_simplex<3>(X, id);
+  const int s = sgn_wrapped(d);
+  return sgn_wrapped(c0) == s && sgn_wrapped(c1) == s && sgn_wrapped(c2) == s && sgn_wrapped(c3) == s;
+}
+
+FTKX_HD inline bool fits_s32(i64 q) { return q == (i64)(int)q; }
+
+// The fast tests again, WITHOUT the vertex ids: 1 inside, 0 outside, -1 a degenerate value was met.  Only the literal cascade needs the
+// SoS vertex ids (four 64-bit multiply-adds each): the kernels compute them when this says -1, not for every simplex.
+FTKX_HD inline int origin_in_simplex2_try(const u64 X[3][2], bool narrow)
+{
+  u64 c0, c1, c2;
+  if (narrow) {
+    c0 = mul_s32(X[1][0], X[2][1]) - mul_s32(X[1][1], X[2][0]);
+    c1 = mul_s32(X[2][0], X[0][1]) - mul_s32(X[2][1], X[0][0]);
+    c2 = mul_s32(X[0][0], X[1][1]) - mul_s32(X[0][1], X[1][0]);
+  } else {
+    c0 = X[1][0] * X[2][1] - X[1][1] * X[2][0];
+    c1 = X[2][0] * X[0][1] - X[2][1] * X[0][0];
+    c2 = X[0][0] * X[1][1] - X[0][1] * X[1][0];
+  }
+  const u64 d = c0 + c1 + c2;
+  if (degenerate_value(d) || degenerate_value(c0) || degenerate_value(c1) || degenerate_value(c2)) return -1;
+  const int s = sgn_wrapped(d);
+  return (sgn_wrapped(c0) == s && sgn_wrapped(c1) == s && sgn_wrapped(c2) == s) ? 1 : 0;
+}
+
+FTKX_HD inline int origin_in_simplex3_try(const u64 X[4][3], bool narrow)
+{
+  u64 m0, m1, m2, m3;
+  if (narrow) {
+    const u64 p_yz = mul_s32(X[2][1], X[3][2]) - mul_s32(X[2][2], X[3][1]), p_zx = mul_s32(X[2][2], X[3][0]) - mul_s32(X[2][0], X[3][2]),
+              p_xy = mul_s32(X[2][0], X[3][1]) - mul_s32(X[2][1], X[3][0]);
+    const u64 q_yz = mul_s32(X[0][1], X[1][2]) - mul_s32(X[0][2], X[1][1]), q_zx = mul_s32(X[0][2], X[1][0]) - mul_s32(X[0][0], X[1][2]),
+              q_xy = mul_s32(X[0][0], X[1][1]) - mul_s32(X[0][1], X[1][0]);
+    m0 = mul_64_s32(p_yz, X[1][0]) + mul_64_s32(p_zx, X[1][1]) + mul_64_s32(p_xy, X[1][2]);
+    m1 = mul_64_s32(p_yz, X[0][0]) + mul_64_s32(p_zx, X[0][1]) + mul_64_s32(p_xy, X[0][2]);
+    m2 = mul_64_s32(q_yz, X[3][0]) + mul_64_s32(q_zx, X[3][1]) + mul_64_s32(q_xy, X[3][2]);
+    m3 = mul_64_s32(q_yz, X[2][0]) + mul_64_s32(q_zx, X[2][1]) + mul_64_s32(q_xy, X[2][2]);
+  } else {
+    const u64 p_yz = X[2][1] * X[3][2] - X[2][2] * X[3][1], p_zx = X[2][2] * X[3][0] - X[2][0] * X[3][2], p_xy = X[2][0] * X[3][1] - X[2][1] * X[3][0];
+    const u64 q_yz = X[0][1] * X[1][2] - X[0][2] * X[1][1], q_zx = X[0][2] * X[1][0] - X[0][0] * X[1][2], q_xy = X[0][0] * X[1][1] - X[0][1] * X[1][0];
+    m0 = X[1][0] * p_yz + X[1][1] * p_zx + X[1][2] * p_xy;
+    m1 = X[0][0] * p_yz + X[0][1] * p_zx + X[0][2] * p_xy;
+    m2 = X[3][0] * q_yz + X[3][1] * q_zx + X[3][2] * q_xy;
+    m3 = X[2][0] * q_yz + X[2][1] * q_zx + X[2][2] * q_xy;
+  }
+  const u64 c0 = 0ull - m0, c1 = m1, c2 = 0ull - m2, c3 = m3;
+  const u64 d = c0 + c1 + c2 + c3;
+  if (degenerate_value(d) || degenerate_value(c0) || degenerate_value(c1) || degenerate_value(c2) || degenerate_value(c3)) return -1;
+  const int s = sgn_wrapped(d);
+  return (sgn_wrapped(c0) == s && sgn_wrapped(c1) == s && sgn_wrapped(c2) == s && sgn_wrapped(c3) == s) ? 1 : 0;
+}
+
 // positive2 (orientation only), for enable_computing_degrees
 FTKX_HD inline int orientation2(const u64 X[3][2], const int id[3]) { return sos_orientation<2>(X, id); }
 

@@ -50,7 +50,7 @@ void launch_cull_coarse(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d
 void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream);
 void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st);
 void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,
-                           double safe_m, u64 *results, hipStream_t st);
+                           double safe_m, u64 *results, u64 *counters, hipStream_t st);
 void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff, u64 *sorted, u64 *results, hipStream_t st);
 void launch_bucket_scan(unsigned *hist, unsigned *boff, unsigned nbins, u64 *counters, hipStream_t st);
 void launch_bucket_scatter(const Mesh &m, unsigned *boff, u64 *bucketed, hipStream_t st);

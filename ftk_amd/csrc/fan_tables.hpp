@@ -87,6 +87,27 @@ static_assert(k_fan3.vert[4][1] == 0b010 && k_fan3.vert[4][2] == 0b011, "2D+t ty
 // type 16 of the 3D+t fan is 0000 0010 0110 1110 (xyzt): masks z, y|z, x|y|z
 static_assert(k_fan4.vert[16][1] == 0b0100 && k_fan4.vert[16][2] == 0b0110 && k_fan4.vert[16][3] == 0b0111, "3D+t type 16");
 
+// The 3 x 3 minors the 60 simplices of a 3D+t corner share.  A simplex is a chain 0 < m1 < m2 < m3 of vertex masks; three of its four
+// "vertex replaced by the origin" determinants contain the corner -- det(X_0, X_a, X_b) for a pair a < b of its masks -- and there are
+// only 50 such pairs in the whole fan (each used by 3.6 simplices on average); the fourth, det(X_m1, X_m2, X_m3), is the simplex's own.
+struct fan_pairs {
+  signed char index[16][16];        // (a, b), a a proper non-empty subset of b -> 0 .. 49; -1 otherwise
+  unsigned char a[50], b[50];
+};
+constexpr fan_pairs make_fan_pairs()
+{
+  fan_pairs p{};
+  for (int i = 0; i < 16; i ++) for (int j = 0; j < 16; j ++) p.index[i][j] = -1;
+  int n = 0;
+  for (unsigned a = 1; a < 16; a ++)
+    for (unsigned b = 1; b < 16; b ++)
+      if (a != b && (a & b) == a) { p.index[a][b] = (signed char)n; p.a[n] = (unsigned char)a; p.b[n] = (unsigned char)b; n ++; }
+  return p;
+}
+inline constexpr fan_pairs k_fan_pairs = make_fan_pairs();
+static_assert(k_fan_pairs.index[7][15] == 49 - 7 || k_fan_pairs.index[7][15] >= 0, "pairs enumerated");
+static_assert(k_fan_pairs.b[49] == 15 && k_fan_pairs.a[49] == 14, "50 nested pairs of non-empty masks over four axes");
+
 template <int N> struct fan_of;
 template <> struct fan_of<3> { static constexpr const fan_table<3> &get() { return k_fan3; } };
 template <> struct fan_of<4> { static constexpr const fan_table<4> &get() { return k_fan4; } };

@@ -235,7 +235,7 @@ int series_chunked(ftkx_ctx *c, int nchunks, const int *ts, const int *scopes, i
     if (two_level) ftkx::launch_cull_coarse(m, steps_q, nq, S.refine, S.refine_cap, S.stream);
     else ftkx::launch_cull(m, steps_q, nq, S.list, S.list_cap, S.stream);
     if (P) HIP_TRY(c, hipStreamWaitEvent(S.stream, P->ev_factors, 0));
-    ftkx::launch_series_factors(steps_q, nq, slices_q, kq, sinfo_q, c->d_red, *running_resolution, P ? P->results : nullptr, safe_m, S.results, S.stream);
+    ftkx::launch_series_factors(steps_q, nq, slices_q, kq, sinfo_q, c->d_red, *running_resolution, P ? P->results : nullptr, safe_m, S.results, S.counters, S.stream);
     HIP_TRY(c, hipEventRecord(S.ev_factors, S.stream));
     if (two_level) ftkx::launch_refine(m, steps_q, S.refine, S.refine_cap, S.list, S.list_cap, S.stream);
     ftkx::launch_exact(m, steps_q, 0, S.list, S.list_cap, S.stream);
@@ -515,7 +515,7 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   if (two_level) ftkx::launch_cull_coarse(m, d_steps, n, c->d_refine, c->refine_capacity, c->stream);
   else ftkx::launch_cull(m, d_steps, n, c->d_list, c->list_capacity, c->stream);
   ftkx::launch_series_factors(d_steps, n, d_slices, (int)k, d_sinfo, c->d_red, *running_resolution, nullptr, (double)(nd == 3 ? ftkx::kSafeM3 : ftkx::kSafeM2),
-                              c->sr_results, c->stream);
+                              c->sr_results, c->d_counters, c->stream);
   ev_end(c);
   ev_begin(c, K_EXACT);
   // sparse data: one workgroup does the rest of the pass (and the kernels below leave at once)

@@ -48,7 +48,7 @@ __device__ inline int nbits_of(double resolution, bool &ambiguous)
 __global__ __launch_bounds__(1024) void series_factors_kernel(Fields *__restrict__ steps, int nsteps, const SeriesSlice *__restrict__ slices, int nslices,
                                                              const SeriesStep *__restrict__ sinfo, const u64 *__restrict__ red, double running_in,
                                                              const u64 *__restrict__ running_from /* a previous chunk's results block, or nullptr */,
-                                                             double safe_m, u64 *__restrict__ results)
+                                                             double safe_m, u64 *__restrict__ results, u64 *__restrict__ counters)
 {
   if (running_from) { const double r = __longlong_as_double((long long)running_from[SR_RUNNING]); running_in = r < running_in ? r : running_in; }
   __shared__ double res[kSeriesMaxSlices], mx[kSeriesMaxSlices];
@@ -113,7 +113,12 @@ __global__ __launch_bounds__(1024) void series_factors_kernel(Fields *__restrict
     results[SR_HEAD + i] = 1ull << nbits;
   }
   __syncthreads();
-  if (tid == 0 && s_status) atomicOr((unsigned long long *)&results[SR_STATUS], (unsigned long long)s_status);
+  if (tid == 0 && s_status) {
+    atomicOr((unsigned long long *)&results[SR_STATUS], (unsigned long long)s_status);
+    // the host takes this pass over: the kernels queued behind this one (refine, exact test, ordering, records) leave at once -- on data that
+    // needs the per-vertex overflow rule they would chew through a survivor list as long as the input -- and only the finish kernel reports
+    if (counters) counters[CNT_SERIES_DONE] = 2ull;
+  }
 }
 
 // inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts and row broadcasts (no LDS crossbar: __shfl_up is a
@@ -478,6 +483,7 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
 
   // ---- exact test (as exact_kernel does it: one lane per hypercube vertex while staging, then (corner, type) pairs over all lanes) ----
   unsigned tested = 0;
+  bool narrow = false;
   for (unsigned base = 0; base < nlist; base += G) {
     __syncthreads();
     if (s_npass > PASS_CAP - G * NTYPES) flush_records();   // (workgroup-uniform: s_npass was final at the barrier above)
@@ -496,9 +502,10 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
         if (sl == 0 || (f.scope_mask & FTKX_SCOPE_INTERVAL)) fl = classify_vertex<ND>(m, f.S[sl], f.V[sl], f.factor, vx, q);
       }
       s_flag[gi][vtx] = fl;
-      for (int c = 0; c < ND; c ++) s_vf[gi][vtx][c] = q[c];
+      bool mine_narrow = true;
+      for (int c = 0; c < ND; c ++) { s_vf[gi][vtx][c] = q[c]; mine_narrow = mine_narrow && fits_s32(q[c]); }
+      narrow = __syncthreads_and(mine_narrow) != 0;
     }
-    __syncthreads();
     for (int wb = 0; wb < G * NTYPES; wb += kThreads) {
       const int w = wb + tid;
       if (w >= G * NTYPES) continue;
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
         for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[gi][vm][c];
       }
       int ids[N]; double mu[N]; bool presolved;
-      if (simplex_inside<ND>(m, f, 1, corner, tab, flags, X, tested, ids, mu, &presolved))
+      if (simplex_inside<ND>(m, f, 1, corner, tab, flags, X, tested, ids, mu, &presolved, narrow))
         s_pass[atomicAdd(&s_npass, 1u)] = order_key((e & kPassLinMask) | ((u64)type << kPassTypeShift) | ((e >> 44) << kPassStepShift), m.core_cells);
     }
   }
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(256) void series_finish_kernel(const u64 *__restric
                                                             const u64 *__restrict__ fragile, u64 fragile_capacity, u64 *__restrict__ h_results, unsigned *flag, unsigned seq,
                                                             const u64 *__restrict__ base_from)
 {
-  if (counters[CNT_SERIES_DONE]) return;                // (the early tail has published everything already)
+  if (counters[CNT_SERIES_DONE] == 1) return;           // (the fused tail has published everything already; 2 = abandoned by the factor kernel: reported here)
   __shared__ unsigned s_over;
   const unsigned tid = threadIdx.x;
   if (tid == 0) {
@@ -637,8 +644,8 @@ void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist,
 }
 
 void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,
-                           double safe_m, u64 *results, hipStream_t st)
-{ hipLaunchKernelGGL(series_factors_kernel, dim3(1), dim3(1024), 0, st, steps, nsteps, slices, nslices, sinfo, red, running_in, running_from, safe_m, results); }
+                           double safe_m, u64 *results, u64 *counters, hipStream_t st)
+{ hipLaunchKernelGGL(series_factors_kernel, dim3(1), dim3(1024), 0, st, steps, nsteps, slices, nslices, sinfo, red, running_in, running_from, safe_m, results, counters); }
 
 void launch_bucket_scan(unsigned *hist, unsigned *boff, unsigned nbins, u64 *counters, hipStream_t st)
 { hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, hist, boff, nbins, counters); }

@@ -121,12 +121,8 @@ __device__ inline bool vertex_usable(const Mesh &m, const int *vx)
 
 // quantised vertex + classification byte (bits 0..2 strictly positive, 3..5 strictly negative, kNonFinite, kInvalid)
 template <int ND>
-__device__ inline unsigned char classify_vertex(const Mesh &m, const double *S, const double *V, double factor, const int *vx, i64 q[ND])
+__device__ inline unsigned char classify_value(const double *v, double factor, i64 q[ND])
 {
-  for (int j = 0; j < ND; j ++) q[j] = 0;
-  if (!vertex_usable<ND>(m, vx)) return kInvalid;
-  double v[ND];
-  vector_at<ND>(m, S, V, vx[0] - m.ext_st[0], vx[1] - m.ext_st[1], ND == 3 ? vx[2] - m.ext_st[2] : 0, v);
   unsigned char mk = 0;
   bool big = false;
   for (int j = 0; j < ND; j ++) {
@@ -141,6 +137,16 @@ __device__ inline unsigned char classify_vertex(const Mesh &m, const double *S, 
   // (|v| >= safe_m / factor  <=>  |trunc(v * factor)| >= safe_m, the factor being a power of two).
   if (big) mk &= (unsigned char)~0x3fu;
   return mk;
+}
+
+template <int ND>
+__device__ inline unsigned char classify_vertex(const Mesh &m, const double *S, const double *V, double factor, const int *vx, i64 q[ND])
+{
+  for (int j = 0; j < ND; j ++) q[j] = 0;
+  if (!vertex_usable<ND>(m, vx)) return kInvalid;
+  double v[ND];
+  vector_at<ND>(m, S, V, vx[0] - m.ext_st[0], vx[1] - m.ext_st[1], ND == 3 ? vx[2] - m.ext_st[2] : 0, v);
+  return classify_value<ND>(v, factor, q);
 }
 
 // e.to_integer(m), mesh/simplicial_regular_mesh.hh:496-502
@@ -385,9 +391,10 @@ __device__ __noinline__ bool make_record_general(const Mesh &m, const Fields &f,
 
 // one simplex: vertices already classified/quantised (flags[i], X[i]).  Returns whether the origin is inside (robust integer
 // test; or the FP64 solve when enable_robust_detection is off, in which case mu is filled and *presolved set).
+// narrow: every quantised component the caller staged fits in 32 bits (checked while staging: fits_s32) -- the cheaper multiplies apply
 template <int ND>
 __device__ inline bool simplex_inside(const Mesh &m, const Fields &f, int cull, const int *corner, unsigned tab,
-                                      const unsigned char *flags, const u64 (*X)[ND], unsigned &tested, int *ids, double *mu, bool *presolved)
+                                      const unsigned char *flags, const u64 (*X)[ND], unsigned &tested, int *ids, double *mu, bool *presolved, bool narrow = false)
 {
   constexpr int N = ND + 1;
   unsigned m_and = 0x3f, m_or = 0;
@@ -395,8 +402,8 @@ __device__ inline bool simplex_inside(const Mesh &m, const Fields &f, int cull, 
   *presolved = false;
   if ((m_or & (kInvalid | kNonFinite)) || (cull && (m_and & 0x3f))) return false;
   tested ++;
-  for (int i = 0; i < N; i ++) ids[i] = vertex_id<ND>(m, corner, (tab >> (8 * i)) & 0xffu);
   if (ND == 3 && !m.robust) {
+    for (int i = 0; i < N; i ++) ids[i] = vertex_id<ND>(m, corner, (tab >> (8 * i)) & 0xffu);
     // enable_robust_detection == false (3d:465-467): the FP64 solve decides
     double v[N][ND];
     for (int i = 0; i < N; i ++) {
@@ -408,8 +415,13 @@ __device__ inline bool simplex_inside(const Mesh &m, const Fields &f, int cull, 
     *presolved = true;
     if constexpr (ND == 3) return solve_barycentric3(v, mu); else return false;
   }
-  if constexpr (ND == 2) return origin_in_simplex2(X, ids);
-  else return origin_in_simplex3(X, ids);
+  // the sort-free test on cofactors; a degenerate value (a zero, INT64_MIN) takes the literal cascade, and only that needs the SoS vertex
+  // ids (regular_tracker.hh:188-194: four 64-bit multiply-adds per vertex -- computed for every simplex they cost as much as the test)
+  int r;
+  if constexpr (ND == 2) r = origin_in_simplex2_try(X, narrow); else r = origin_in_simplex3_try(X, narrow);
+  if (r >= 0) return r != 0;
+  for (int i = 0; i < N; i ++) ids[i] = vertex_id<ND>(m, corner, (tab >> (8 * i)) & 0xffu);
+  return sos_origin_in_simplex<ND>(X, ids);
 }
 
 // hits of one wavefront appended with a single atomic (must be reached by all 64 lanes)

@@ -27,6 +27,22 @@ void hc_batch_in_simplex2(int n, const long long *X, const int *ids, int *out_fa
 void hc_batch_in_simplex3(int n, const long long *X, const int *ids, int *out_fast, int *out_sos)
 { for (int i = 0; i < n; i ++) { out_fast[i] = hc_origin_in_simplex3(X + 12 * i, ids + 4 * i); out_sos[i] = hc_sos_origin_in_simplex3(X + 12 * i, ids + 4 * i); } }
 
+// the 32-bit-operand forms of the fast path (every component must fit in int32)
+void hc_batch_in_simplex2_s32(int n, const long long *X, const int *ids, int *out)
+{ for (int i = 0; i < n; i ++) out[i] = origin_in_simplex2_s32((const u64 (*)[2])(X + 6 * i), ids + 3 * i); }
+void hc_batch_in_simplex3_s32(int n, const long long *X, const int *ids, int *out)
+{ for (int i = 0; i < n; i ++) out[i] = origin_in_simplex3_s32((const u64 (*)[3])(X + 12 * i), ids + 4 * i); }
+
+// the id-free forms the kernels use: 1 / 0, or -1 = degenerate value (then the literal cascade decides)
+void hc_batch_in_simplex_try(int nd, int n, const long long *X, const int *ids, int narrow, int *out)
+{
+  for (int i = 0; i < n; i ++) {
+    int r = nd == 2 ? origin_in_simplex2_try((const u64 (*)[2])(X + 6 * i), narrow != 0) : origin_in_simplex3_try((const u64 (*)[3])(X + 12 * i), narrow != 0);
+    if (r < 0) r = nd == 2 ? (int)sos_origin_in_simplex<2>((const u64 (*)[2])(X + 6 * i), ids + 3 * i) : (int)sos_origin_in_simplex<3>((const u64 (*)[3])(X + 12 * i), ids + 4 * i);
+    out[i] = r;
+  }
+}
+
 int hc_fan(int n, int *verts /* [ntypes][n][n] */, int *ordinal, int *ord_types, int *int_types)
 {
   if (n == 3) {

@@ -348,6 +348,38 @@ def test_dense_survivors_fall_back_to_the_tile_kernel(gpu):
     assert len(a) > 10000       # mostly bogus records of wrapped determinants, like the reference's
 
 
+@pytest.mark.parametrize("scale", [1.0, 300.0, 3e5, 3e9], ids=["16bit", "32bit", "mixed", "64bit"])
+def test_tile_kernel_forms_agree(gpu, monkeypatch, scale):
+    """The 3D tile kernel has three forms of the same integer test: (corner, type) pairs over the lanes with 64-bit multiplies; one corner
+    per lane with the fan's shared minors in registers, 32-bit operands; the same with 16-bit operands.  Which one a tile takes depends
+    on the magnitudes in it: the same series at four scales (all three forms, tiles of different forms side by side, degenerate
+    values from planted zeros, NaN vertices), swept under FTKX_TILE_FAN = 0 / 1 / 2, exact_only and with the in-tile cull: equal
+    records, equal counts of simplices tested."""
+    rng = np.random.default_rng(17)
+    dims, nt = (40, 33, 21), 3
+    steps = []
+    for t in range(nt):
+        f = rng.standard_normal(tuple(reversed(dims))) * 0.05 * scale
+        f[4:9, 5:12, 6:14] = np.round(f[4:9, 5:12, 6:14] / (0.05 * scale) * 4) / 4 * scale      # many equal values: zero determinants
+        f[12:20, 14:30, 2:38] = np.round(f[12:20, 14:30, 2:38] / (0.05 * scale)) * scale         # (thousands per tile: more than its list holds)
+        if scale == 3e5:
+            f[:, :, :20] *= 1e-4                                                     # half the tiles small, half large
+        f[10, 11, 12] = np.nan
+        steps.append(f)
+    got = {}
+    for fan in ("0", "1", "2"):
+        monkeypatch.setenv("FTKX_TILE_FAN", fan)
+        got[fan] = _run(gpu, None, dims, nt, steps=steps, exact_only=True)
+    monkeypatch.delenv("FTKX_TILE_FAN")
+    for fan in ("1", "2"):
+        _same(got["0"][0], got[fan][0])
+        assert got["0"][2] == got[fan][2]
+        assert got["0"][1]["simplices_tested"] == got[fan][1]["simplices_tested"], fan
+    assert len(got["0"][0]) > 50
+    culled = _run(gpu, None, dims, nt, steps=steps)
+    _same(culled[0], got["0"][0])
+
+
 def test_cull_ahead_changes_nothing_but_the_schedule(gpu):
     """ftkx_sweep_announce: the cull queued behind the mask kernel, before the factors exist.  Same records and statistics as the
     plain order -- when the announcement is what gets swept, when it is not (other scopes, other steps, a subset: the list is

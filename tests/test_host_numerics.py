@@ -42,7 +42,7 @@ def _cases(rng, n, nd, mag):
 
 
 @pytest.mark.parametrize("nd", [2, 3])
-@pytest.mark.parametrize("mag", [1, 2, 5, 1000, 2 ** 20, 2 ** 31, 2 ** 40, 2 ** 62])
+@pytest.mark.parametrize("mag", [1, 2, 5, 1000, 2 ** 20, 2 ** 28, 2 ** 31 - 1, 2 ** 31, 2 ** 40, 2 ** 62])
 def test_integer_predicate_matches_oracle(hc, oracle, nd, mag):
     """mag 1..5: almost every simplex is degenerate (SoS cascade); 2**31 and up: determinants wrap in int64."""
     rng = np.random.default_rng(nd * 1000 + int(np.log2(mag)))
@@ -56,6 +56,16 @@ def test_integer_predicate_matches_oracle(hc, oracle, nd, mag):
     ref = _oracle_batch(oracle, f"ftko_hook_cp_in_simplex{nd}", X, ids, nd)
     assert np.array_equal(sos, ref), "literal cascade differs from the oracle"
     assert np.array_equal(fast, ref), "cofactor fast path differs from the oracle"
+    tri = np.zeros(n, dtype=np.int32)
+    hc.hc_batch_in_simplex_try(nd, n, _ptr(X), _ptr(ids), 0, _ptr(tri))
+    assert np.array_equal(tri, ref), "id-free fast path + cascade differs from the oracle"
+    if mag < 2 ** 31:
+        hc.hc_batch_in_simplex_try(nd, n, _ptr(X), _ptr(ids), 1, _ptr(tri))
+        assert np.array_equal(tri, ref), "id-free 32-bit-operand fast path + cascade differs from the oracle"
+    if mag < 2 ** 31:          # every component fits in 32 bits: the cheaper-multiply form of the fast path (what the kernels take then)
+        narrow = np.zeros(n, dtype=np.int32)
+        getattr(hc, f"hc_batch_in_simplex{nd}_s32")(n, _ptr(X), _ptr(ids), _ptr(narrow))
+        assert np.array_equal(narrow, ref), "32-bit-operand fast path differs from the oracle"
     if mag <= 1000:
         assert ref.any() and not ref.all()
 
