@@ -127,17 +127,25 @@ def side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=5, warmup=2):
     ts = np.arange(nt, dtype=np.int32)
     scopes = np.array([ftk_amd.SCOPE_BOTH if t + 1 < nt else ftk_amd.SCOPE_ORDINAL for t in range(nt)], dtype=np.int32)
     paths = {}
-    for _ in range(warmup):
+
+    def passes(k, count):
+        # two passes in flight, like the headline run (main(): passes)
         ctx.invalidate_masks()
-        recs, f, _r = ctx.sweep_series(ts, scopes, copy=False)
+        ctx.sweep_series_submit(ts, scopes)
+        for i in range(1, k + 1):
+            if i < k:
+                ctx.invalidate_masks()
+                ctx.sweep_series_submit(ts, scopes)
+            recs, f, _r = ctx.sweep_series_complete(copy=False)
+            if count:
+                p = ctx.series_last_path()
+                paths[str(p)] = paths.get(str(p), 0) + 1
+        return recs
+    recs = passes(max(warmup, 1), False)
     ctx.set_profiling(2)            # events around the dominant (mask) kernel only
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        ctx.invalidate_masks()
-        recs, f, _r = ctx.sweep_series(ts, scopes, copy=False)
-        p = ctx.series_last_path()
-        paths[str(p)] = paths.get(str(p), 0) + 1
+    recs = passes(steps, True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kt = ctx.kernel_times()
@@ -253,6 +261,7 @@ def main():
     ap.add_argument("--timesteps", type=int, default=0, help="override the length of the series")
     ap.add_argument("--no-cull-ahead", action="store_true", help="experiment: do not announce the sweeps to slices_prepare (the cull then waits for the factors)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the kernels (what do they cost a pass?); the line then carries no roofline")
+    ap.add_argument("--no-pipeline", action="store_true", help="N = 1: one pass after the other (ftkx_sweep_series) instead of two passes in flight (ftkx_sweep_series_submit / _complete)")
     ap.add_argument("--host-driven", action="store_true", help="N = 1: the host-driven batch (slices_prepare, factors on the host, enqueue, collect) instead of the device-driven ftkx_sweep_series")
     ap.add_argument("--no-streaming-tracker", action="store_true", help="N = 1: skip the per-timestep tracker measurement (device-resident and host-fed) that follows the timed region")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the few passes of the other BASELINE configurations that follow the timed region")
@@ -441,8 +450,32 @@ def job(args, env):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        recs, st = one_pass()
+    pipelined = (not multi) and (not args.host_driven) and (not args.no_pipeline) and (not args.exact_only)
+
+    def passes(k):
+        """k passes.  One GPU, device-driven: two passes in flight (ftkx_sweep_series_submit / _complete) -- the host prepares and queues
+        pass i + 1 while the device works on pass i, and the records of pass i cross PCIe on a copy engine while the mask kernel of pass
+        i + 1 runs; every pass still does ALL the work and hands its records to the host.  Otherwise: one pass after the other."""
+        if not pipelined or k < 2:
+            for _ in range(k):
+                out = one_pass()
+            return out
+        tp0 = time.perf_counter()
+        ctx.invalidate_masks()
+        ctx.sweep_series_submit(ann_ts, ann_scopes)
+        for i in range(1, k + 1):
+            if i < k:
+                ctx.invalidate_masks()
+                ctx.sweep_series_submit(ann_ts, ann_scopes)
+            recs, f, _ = ctx.sweep_series_complete(copy=False)
+            p = ctx.series_last_path()
+            series_paths[p] = series_paths.get(p, 0) + 1
+        host_ms[1] += (time.perf_counter() - tp0) * 1e3
+        one_pass.factors = f
+        return recs, ctx.stats()
+
+    if args.warmup:
+        recs, st = passes(args.warmup)
     # HIP events on the stream the kernels run on: around the dominant (mask) kernel only inside the timed region -- a pair of events costs
     # the stream ~10 us of idle time, which a 0.4 ms pass notices --, around every kernel family in a few extra passes afterwards
     ctx.set_profiling(0 if args.no_kernel_events else (1 if args.exact_only else 2))     # (--exact-only: the dominant kernel is the tile kernel)
@@ -450,8 +483,7 @@ def job(args, env):
     compact_bytes[0] = compact_bytes[1] = compact_bytes[2] = compact_bytes[3] = 0
     barrier()
     tt0 = time.perf_counter()
-    for _ in range(args.steps):
-        recs, st = one_pass()
+    recs, st = passes(args.steps)
     barrier()
     elapsed = time.perf_counter() - tt0
     if multi:
@@ -468,6 +500,18 @@ def job(args, env):
     total_simplices = tslab.count_simplices(nd, dims, nt, scalar_input)
     torch.cuda.synchronize()
     ktimes = ctx.kernel_times()
+    latency_ms = None
+    if pipelined:
+        # the same pass on its own (ftkx_sweep_series, nothing else in flight): what one call takes from its first launch to the records
+        saved = list(host_ms)
+        ctx.set_profiling(0)
+        barrier()
+        tl0 = time.perf_counter()
+        for _ in range(3):
+            one_pass()
+        barrier()
+        latency_ms = (time.perf_counter() - tl0) / 3 * 1e3
+        host_ms[0], host_ms[1], host_ms[2] = saved
     ktimes_all, k_all = None, 3
     if not args.no_kernel_events and not (multi and args.compact_halo):
         ctx.set_profiling(1)
@@ -576,7 +620,8 @@ def job(args, env):
                                    f"{'scalar' if scalar_input else 'vector'} input, t-slab partition over {world} GPU(s): {len(own)} timesteps on rank 0",
                        "simplices_per_step": total_simplices, "exact_only": bool(args.exact_only),
                        "nbits": int(np.log2(max(int(v) for v in getattr(one_pass, "factors", factors)))), "cull": bool(st["cull_enabled"]),
-                       "pass": ("device-driven (ftkx_sweep_series): paths taken {(path, status): passes} = %s" % {str(k): v for k, v in series_paths.items()}) if series_paths
+                       "pass": (("device-driven, two passes in flight (ftkx_sweep_series_submit / _complete)" if pipelined else "device-driven (ftkx_sweep_series)") +
+                                ": paths taken {(path, status): passes} = %s" % {str(k): v for k, v in series_paths.items()}) if series_paths
                                else "host-driven batch (slices_prepare, host factors, enqueue, collect)",
                        "input_resident": "the field the tracker API is given (S, or V for vector input) in HBM; gradient/Jacobian evaluated in flight"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -588,6 +633,7 @@ def job(args, env):
             # the factor pre-pass is inside the timed region now (fused into the mask kernel): nothing of the sweep is left outside
             "prepass_ms": 0.0,
             "end_to_end_ms": elapsed / args.steps * 1e3,
+            "single_pass_latency_ms": latency_ms,
             "roofline_end_to_end": {"achieved": alg_bytes_pass * world / (elapsed / args.steps) / 1e9 / world, "frac": alg_bytes_pass / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                                     "note": "algorithmic bytes of this rank's pass / wall time of the pass (prepare + factors + cull + exact + sort + download)"},
             "halo_exchange": halo_info,

@@ -212,6 +212,29 @@ class Context:
         self._ck(self._L.ftkx_sweep_series(self._h, ts.ctypes.data, scopes.ctypes.data, n, C.byref(run), f.ctypes.data, C.byref(out), C.byref(cnt)))
         return _lib.records_from(out.value, cnt.value, copy), f[:n], run.value
 
+    def sweep_series_submit(self, ts, scopes, running_resolution=None, chain=False):
+        """ftkx_sweep_series_submit: queue the pass and return.  chain=True: continue from the pass queued before it (still open)."""
+        n = len(ts)
+        ts = np.ascontiguousarray(ts, dtype=np.int32)
+        scopes = np.ascontiguousarray(scopes, dtype=np.int32)
+        if chain:
+            run_p = None
+        else:
+            run = C.c_double(np.finfo(np.float64).max if running_resolution is None else float(running_resolution))
+            run_p = C.addressof(run)
+        self._ck(self._L.ftkx_sweep_series_submit(self._h, ts.ctypes.data, scopes.ctypes.data, n, run_p))
+        self._open_series = getattr(self, "_open_series", [])
+        self._open_series.append(n)
+
+    def sweep_series_complete(self, copy=True):
+        """ftkx_sweep_series_complete: the oldest open pass -> (records, factors, running resolution), as sweep_series returns them"""
+        n = self._open_series.pop(0)
+        run = C.c_double(0.0)
+        f = np.empty((max(1, n),), dtype=np.uint64)
+        out, cnt = C.c_void_p(), C.c_size_t()
+        self._ck(self._L.ftkx_sweep_series_complete(self._h, C.byref(run), f.ctypes.data, C.byref(out), C.byref(cnt)))
+        return _lib.records_from(out.value, cnt.value, copy), f[:n], run.value
+
     def series_last_path(self):
         """(path, status bits) of the last sweep_series: 1 device-driven, 2 finished by the single-workgroup tail, 0 host-driven batch"""
         st = C.c_ulonglong()

@@ -241,6 +241,7 @@ int ftkx_sweep_enqueue(ftkx_ctx *c, int t, int scope, unsigned long long factor)
 {
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "sweep: call ftkx_set_mesh first");
+  if (c->sr_open && !c->sr_internal) return fail(c, FTKX_E_INVALID, "ftkx_sweep_enqueue: series passes open (ftkx_sweep_series_submit), complete them first");
   if (scope < FTKX_SCOPE_ORDINAL || scope > FTKX_SCOPE_BOTH) return fail(c, FTKX_E_INVALID, "sweep: bad scope %d", scope);
   if (scope == FTKX_SCOPE_BOTH && c->opt.tag_mode == FTKX_TAG_WORK_INDEX)
     return fail(c, FTKX_E_INVALID, "sweep: FTKX_SCOPE_BOTH needs an element tag (work indices of the two scopes collide)");
@@ -424,6 +425,7 @@ int ftkx_sweep(ftkx_ctx *c, int t, int scope, unsigned long long factor, const f
 {
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_sweep: asynchronous sweeps pending, collect first");
+  if (c->sr_open && !c->sr_internal) return fail(c, FTKX_E_INVALID, "ftkx_sweep: series passes open (ftkx_sweep_series_submit), complete them first");
   int rc = ftkx_sweep_enqueue(c, t, scope, factor);
   if (rc) return rc;
   return ftkx_sweep_collect(c, out, n_out);

@@ -23,7 +23,7 @@ namespace ftkx {
 void launch_tile(const TileParams &p, hipStream_t stream);
 void tile_dims(int nd, int tile[3]);
 void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream);
-void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream);
+void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream, const FactorJob *job = nullptr);
 void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64 *d_list, u64 cap, hipStream_t stream);
 void launch_records(const Mesh &m, const Fields *d_fields, hipStream_t stream);
 void launch_compact_words(const Mesh &m, const unsigned char *U, const unsigned char *M, unsigned *idx, u64 *words, u64 capacity, u64 *counter, hipStream_t st);
@@ -46,7 +46,7 @@ void launch_jacobian3d(const double *V, int DW, int DH, int DD, double *J, hipSt
 void launch_resolution(const double *p, size_t n, u64 *out2, hipStream_t st);
 void launch_calib_read(const void *p, size_t bytes, double *scratch, hipStream_t stream);
 const char *last_mask_kernel();
-void launch_cull_coarse(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, hipStream_t stream);
+void launch_cull_coarse(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, hipStream_t stream, const FactorJob *job = nullptr);
 void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream);
 void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st);
 void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,
@@ -57,7 +57,7 @@ void launch_bucket_scatter(const Mesh &m, unsigned *boff, u64 *bucketed, hipStre
 void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, const u64 *base_from, hipStream_t st);
 Mesh coarse_view(const Mesh &m);
 void launch_series_small(const Mesh &m, const Mesh &mc, const Fields *d_steps, bool two_level, const u64 *d_refine, const u64 *d_list, ftkx_cp_t *out,
-                         u64 *results, size_t nwords, u64 *h_results, unsigned *flag, unsigned seq, unsigned *done, hipStream_t st);
+                         u64 *results, size_t nwords, u64 *h_results, unsigned *flag, unsigned seq, unsigned *done, bool report_decline, hipStream_t st);
 void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, const u64 *base_from,
                           hipStream_t st);
 }  // namespace ftkx
@@ -109,6 +109,35 @@ struct ftkx_series_slot {
   unsigned *hist = nullptr, *boff = nullptr;
   size_t bins_cap = 0, results_cap = 0, h_results_cap = 0;
   unsigned seq = 0;
+};
+
+// A series pass that has been queued (ftkx_sweep_series_submit) and not yet collected (ftkx_sweep_series_complete): what the second half
+// of the call needs.  Two may be open at a time: the host prepares and queues pass N + 1 while the device still works on pass N, and the
+// records of pass N cross PCIe (a copy engine, not a kernel) while the mask kernel of pass N + 1 runs.
+struct ftkx_series_pending {
+  bool open = false;
+  bool by_host = false;             // not queued: the host-driven batch sweeps it when it is collected
+  std::vector<int> ts, scopes, slice_ts, red_index;
+  int n = 0, buf = 0;
+  size_t k = 0, nwords = 0, nbins = 0, total_desc = 0;
+  unsigned long long hint = 0, epoch = 0;
+  bool two_level = false, short_chain = false, small_now = false, to_device = false;
+  int u_rows = 1;
+  u64 cells = 0;
+  unsigned seq = 0;
+  double running_in = 0;
+  bool chained = false;             // the running minimum came from the pass before it on the device (running_in: what the host knew)
+  size_t off_steps = 0;
+};
+
+// what one of the (two) passes in flight writes that the host reads, or that a copy engine reads after the pass
+struct ftkx_series_buffers {
+  u64 *results = nullptr, *h_results = nullptr;       // device block; coherent pinned copy with the flag word behind it
+  size_t results_cap = 0, h_results_cap = 0;
+  unsigned seq = 0;
+  ftkx_cp_t *out = nullptr; size_t out_cap = 0;       // pinned: the records as the caller reads them
+  ftkx_cp_t *d_out = nullptr; size_t d_out_cap = 0;   // device: the records of a pass whose download is left to the copy engine
+  void *h_desc = nullptr, *d_desc = nullptr; size_t desc_cap = 0;
 };
 
 struct ftkx_ctx {
@@ -174,10 +203,16 @@ struct ftkx_ctx {
   u64 *d_cells = nullptr; size_t cells_cap = 0, n_cells = 0;
   u64 *d_patch_cells = nullptr; double *d_patches = nullptr; size_t patch_cap = 0;   // staging for host-side callers
   void *d_packed = nullptr; size_t packed_cap = 0;                                   // staging of a packed mask message for host-side callers
-  // series pass (series.hip): results block (device + coherent pinned copy with the flag word behind it), ordering buffers
-  u64 *sr_results = nullptr, *sr_h_results = nullptr;
-  size_t sr_results_cap = 0, sr_h_results_cap = 0;     // words (the pinned copy also holds the fragile list; the flag lives behind it)
-  unsigned sr_seq = 0;
+  // series pass (series.hip): per pass in flight the results block (device + coherent pinned copy: it also holds the fragile list, the flag
+  // lives behind it), the record buffers and the descriptors; shared, in stream order: the ordering buffers
+  ftkx_series_buffers sr_buf[2];
+  ftkx_series_pending sr_pend[2];
+  int sr_open = 0, sr_head = 0;       // passes open, and which of sr_pend is the oldest
+  bool sr_internal = false;           // the host-driven batch is sweeping for a series pass: its calls are let through while passes are open
+  int sr_next_buf = 0;
+  hipStream_t sr_copy_stream = nullptr;
+  unsigned long long mask_epoch = 0;  // bumped by everything that (re)builds or drops masks: a pass collected later does not mark slices over it
+  double sr_last_running = 0;         // the running minimum the host knew when it last collected a pass (hint of a chained pass)
   unsigned *sr_hist = nullptr, *sr_boff = nullptr;
   size_t sr_bins_cap = 0;
   u64 *sr_bucketed = nullptr;
@@ -186,6 +221,7 @@ struct ftkx_ctx {
   size_t sr_sorted_cap = 0;
   std::vector<ftkx_series_slot> sr_slots;   // chunked pass: one slot per chunk
   int sr_skip_small = 0;             // passes for which the fused tail kernel is not launched (the data was hit-dense a moment ago)
+  bool sr_short_chain = false;       // the last pass was finished by the fused tail kernel: the next one is queued without the kernels behind it
   int sr_last_path = 0;              // which way the last ftkx_sweep_series went: 1 device-driven, 2 early single-workgroup tail, 0 the host-driven batch
   unsigned long long sr_last_status = 0;
   // pass 2 on the device (trace_device.hip): tags up, neighbours / degrees / roots down

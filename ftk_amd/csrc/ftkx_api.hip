@@ -70,6 +70,7 @@ size_t mask_bytes(const ftkx_ctx *c) { return (size_t)mask_pitch(c) * (size_t)c-
 
 void free_slice(Slice &s, ftkx_ctx *pool_owner)
 {
+  if (pool_owner) pool_owner->mask_epoch ++;
   // owned copies go back to the context's pool: a streaming caller pushes and pops one slice per step, and hipMalloc + hipFree of a
   // slice-sized array cost more than sweeping a 256^3 slice
   auto give_back = [&](double *p, size_t count) {
@@ -270,6 +271,7 @@ int upload_from_host(ftkx_ctx *c, void *dst, const void *src, size_t bytes)
 
 int ensure_mask_arrays(ftkx_ctx *c, Slice &s, bool two_level)
 {
+  c->mask_epoch ++;                 // (every builder of masks comes through here: a series pass collected later leaves the slices' marks alone)
   if (!s.M) {
     if (!c->pool_M.empty()) { s.M = c->pool_M.back(); c->pool_M.pop_back(); }   // padding still neutral from its first life
     else {
@@ -377,8 +379,12 @@ void ftkx_destroy(ftkx_ctx *c)
   if (c->d_pass) (void)hipFree(c->d_pass);
   if (c->d_fragile) (void)hipFree(c->d_fragile);
   for (void *p : {(void *)c->d_word_idx, (void *)c->d_words, (void *)c->d_cells, (void *)c->d_patch_cells, (void *)c->d_patches, c->d_packed}) if (p) (void)hipFree(p);
-  for (void *p : {(void *)c->sr_results, (void *)c->sr_hist, (void *)c->sr_boff, (void *)c->sr_bucketed, (void *)c->sr_sorted}) if (p) (void)hipFree(p);
-  if (c->sr_h_results) (void)hipHostFree(c->sr_h_results);
+  for (void *p : {(void *)c->sr_hist, (void *)c->sr_boff, (void *)c->sr_bucketed, (void *)c->sr_sorted}) if (p) (void)hipFree(p);
+  for (ftkx_series_buffers &B : c->sr_buf) {
+    for (void *p : {(void *)B.results, (void *)B.d_out, B.d_desc}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)B.h_results, (void *)B.out, B.h_desc}) if (p) (void)hipHostFree(p);
+  }
+  if (c->sr_copy_stream) (void)hipStreamDestroy(c->sr_copy_stream);
   for (void *p : {c->tr_dev, c->tr_parent, c->tr_tables}) if (p) (void)hipFree(p);
   if (c->tr_host) (void)hipHostFree(c->tr_host);
   for (ftkx_series_slot &sl : c->sr_slots) {
@@ -410,6 +416,7 @@ int ftkx_set_stream(ftkx_ctx *c, void *s)
   if (c) c->ahead.clear();
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_set_stream: sweeps pending, collect first");
+  if (c->sr_open && !c->sr_internal) return fail(c, FTKX_E_INVALID, "ftkx_set_stream: series passes open (ftkx_sweep_series_submit), complete them first");
   c->stream = s ? (hipStream_t)s : c->own_stream;
   return FTKX_OK;
 }
@@ -419,6 +426,7 @@ int ftkx_set_options(ftkx_ctx *c, const ftkx_options *o)
   if (c) c->ahead.clear();
   if (!c || !o) return fail(c, FTKX_E_INVALID, "null argument");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_set_options: sweeps pending, collect first");
+  if (c->sr_open && !c->sr_internal) return fail(c, FTKX_E_INVALID, "ftkx_set_options: series passes open (ftkx_sweep_series_submit), complete them first");
   if (o->tag_mode < FTKX_TAG_WORK_INDEX || o->tag_mode > FTKX_TAG_EXACT64) return fail(c, FTKX_E_INVALID, "bad tag_mode %d", o->tag_mode);
   if (o->coords_mode < 0 || o->coords_mode > 3) return fail(c, FTKX_E_INVALID, "bad coords_mode %d", o->coords_mode);
   if (o->coords_mode == 2 && !c->d_rect[0]) return fail(c, FTKX_E_INVALID, "coords_mode RECTILINEAR: call ftkx_set_coords_rectilinear");
@@ -527,6 +535,7 @@ static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, con
   // completely by upload_from_host (nothing to wait for: the DMAs run on while the caller produces its next snapshot)
   if (on_device == 2) HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->slices[t] = s;
+  c->mask_epoch ++;
   c->scalar_mode = scalar_only ? 1 : 0;
   return FTKX_OK;
 }
@@ -653,6 +662,7 @@ int ftkx_invalidate_masks(ftkx_ctx *c)
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_invalidate_masks: sweeps pending, collect first");
   for (auto &kv : c->slices) { kv.second.mask_factor = 0; kv.second.have_fused = false; }
+  c->mask_epoch ++;
   c->ahead.clear();
   c->dense_collects = 0;
   return FTKX_OK;

@@ -136,6 +136,7 @@ int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, 
   s.mask_factor = mask_factor; s.mask_big = false; s.u_rows = m.u_rows;
   s.maxabs = max_abs;                                                                  // (all a masked slice knows of its values)
   c->slices[t] = s;
+  c->mask_epoch ++;
   return FTKX_OK;
 }
 
@@ -229,6 +230,7 @@ int ftkx_push_masked_slice_packed(ftkx_ctx *c, int t, int scalar_input, const vo
   s.mask_factor = mask_factor; s.mask_big = false; s.u_rows = m.u_rows;
   s.maxabs = max_abs;
   c->slices[t] = s;
+  c->mask_epoch ++;
   return FTKX_OK;
 }
 

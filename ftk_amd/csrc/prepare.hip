@@ -110,6 +110,7 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
 {
   if (!c || (n > 0 && !ts)) return fail(c, FTKX_E_INVALID, "null argument");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_slices_prepare: sweeps pending, collect first");
+  if (c->sr_open && !c->sr_internal) return fail(c, FTKX_E_INVALID, "ftkx_slices_prepare: series passes open (ftkx_sweep_series_submit), complete them first");
   const u64 hint = factor_hint ? factor_hint : 256;          // the smallest factor there is (minbits = 8)
   if (!pow2_factor(hint)) return fail(c, FTKX_E_INVALID, "ftkx_slices_prepare: factor_hint must be a power of two");
   c->ahead.clear();

@@ -29,6 +29,8 @@ int series_by_host(ftkx_ctx *c, const int *ts, const int *scopes, int n, const s
                    const ftkx_cp_t **out, size_t *n_out)
 {
   c->sr_last_path = 0;
+  struct Through { ftkx_ctx *c; bool was; ~Through() { c->sr_internal = was; } } through{c, c->sr_internal};
+  c->sr_internal = true;
   const unsigned long long hint = std::max<unsigned long long>(factor_of(*running), 256ull);
   std::vector<double> below(slice_ts.size());
   int rc = ftkx_sweep_announce(c, ts, scopes, n);
@@ -333,45 +335,26 @@ int series_chunked(ftkx_ctx *c, int nchunks, const int *ts, const int *scopes, i
   return 1;
 }
 
-}  // namespace
-
-extern "C" {
-
-int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, double *running_resolution, unsigned long long *factors,
-                      const ftkx_cp_t **out, size_t *n_out)
+// ---- the device-driven pass in two halves -------------------------------------------------------------------------------------------
+// what of a pass can be checked without the device: the steps, the slices they read in time order
+int series_steps(ftkx_ctx *c, const int *ts, const int *scopes, int n, std::vector<int> &slice_ts)
 {
-  if (!c || (n > 0 && (!ts || !scopes)) || !running_resolution) return fail(c, FTKX_E_INVALID, "null argument");
-  if (out) *out = nullptr;
-  if (n_out) *n_out = 0;
-  if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "sweep: call ftkx_set_mesh first");
-  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series: sweeps pending, collect first");
-  if (!(*running_resolution > 0)) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series: the running resolution must be positive (DBL_MAX: none yet)");
-  if (n == 0) return FTKX_OK;
-  c->ahead.clear(); c->announced.clear();
-  HIP_TRY(c, hipSetDevice(c->device));
-  const int nd = c->nd;
-
-  // ---- the steps, and the slices they read in time order -----------------------------------------------------------------------------
-  std::vector<int> slice_ts;
   for (int i = 0; i < n; i ++) {
     if (scopes[i] < FTKX_SCOPE_ORDINAL || scopes[i] > FTKX_SCOPE_BOTH) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series: bad scope %d", scopes[i]);
     if (i > 0 && ts[i] <= ts[i - 1]) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series: timesteps must be strictly ascending");
     if (slice_ts.empty() || slice_ts.back() != ts[i]) slice_ts.push_back(ts[i]);
     if (scopes[i] & FTKX_SCOPE_INTERVAL) slice_ts.push_back(ts[i] + 1);
   }
-  std::vector<Slice *> sl(slice_ts.size());
-  for (size_t j = 0; j < slice_ts.size(); j ++) {
-    auto it = c->slices.find(slice_ts[j]);
-    if (it == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "ftkx_sweep_series: slice %d not resident", slice_ts[j]);
-    sl[j] = &it->second;
-  }
-  const size_t k = sl.size();
+  for (size_t j = 0; j < slice_ts.size(); j ++)
+    if (c->slices.find(slice_ts[j]) == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "ftkx_sweep_series: slice %d not resident", slice_ts[j]);
+  return FTKX_OK;
+}
 
-  // ---- is the device-driven form applicable? ---------------------------------------------------------------------------------------
-  Mesh m; fill_mesh(c, m);
-  const bool two_level = ftkx::masks_have_summary(m);
-  u64 cells = 1;
-  for (int d = 0; d < nd; d ++) cells *= (u64)c->core_sz[d];
+// does the device-driven form cover these steps?  (What it does not is swept by the host-driven batch.)
+bool series_applicable(ftkx_ctx *c, const int *ts, const int *scopes, int n, const std::vector<int> &slice_ts, const std::vector<Slice *> &sl, u64 cells)
+{
+  const int nd = c->nd;
+  const size_t k = sl.size();
   bool ok = !c->opt.exact_only && (nd == 2 || c->opt.robust) && c->dense_collects == 0 && !c->opt.use_type_filter && cells > 0 && n <= ftkx::kSeriesMaxSlices && k <= (size_t)ftkx::kSeriesMaxSlices;
   if (const char *e = getenv("FTKX_SERIES")) ok = ok && atoi(e) != 0;
   // the order of (step, corner, type) must be the order of the tags
@@ -389,44 +372,101 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
     if ((a.J == nullptr) != (b.J == nullptr) || (a.S == nullptr) != (b.S == nullptr)) ok = false;
   }
   if (ok && (c->opt.coords_mode == 2 || c->opt.coords_mode == 3)) ok = false;     // (their bounds checks live in ftkx_sweep_enqueue)
-  const unsigned long long hint = std::max<unsigned long long>(factor_of(*running_resolution), 256ull);
+  (void)slice_ts;
+  return ok;
+}
+
+int ensure_series_buffers(ftkx_ctx *c, ftkx_series_buffers &B, size_t nwords, size_t desc_bytes, bool to_device)
+{
+  int rc;
+  if ((rc = grow_device(c, &B.results, &B.results_cap, std::max<size_t>(nwords, 1024)))) return rc;
+  const size_t h_words = nwords + (size_t)c->fragile_capacity * 10;
+  if (B.h_results_cap < h_words) {
+    if (B.h_results) { HIP_TRY(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(B.h_results); B.h_results = nullptr; B.h_results_cap = 0; }
+    const size_t cap = h_words + h_words / 4 + 1024;
+    HIP_TRY(c, hipHostMalloc((void **)&B.h_results, (cap + 8) * sizeof(u64), hipHostMallocCoherent));
+    B.h_results_cap = cap;
+    *reinterpret_cast<volatile unsigned *>(B.h_results + cap) = 0u;
+    B.seq = 0;
+  }
+  if (B.out_cap < (size_t)c->capacity) {
+    if (B.out) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipHostFree(B.out)); B.out = nullptr; B.out_cap = 0; }
+    // (non-coherent = ordinary cached host memory for the CPU, as ensure_host_buffer has it)
+    HIP_TRY(c, hipHostMalloc((void **)&B.out, (size_t)c->capacity * sizeof(ftkx_cp_t), hipHostMallocNonCoherent));
+    B.out_cap = (size_t)c->capacity;
+  }
+  if (to_device && B.d_out_cap < (size_t)c->capacity) {
+    if (B.d_out) { HIP_TRY(c, hipFree(B.d_out)); B.d_out = nullptr; B.d_out_cap = 0; }
+    HIP_TRY(c, hipMalloc((void **)&B.d_out, (size_t)c->capacity * sizeof(ftkx_cp_t)));
+    B.d_out_cap = (size_t)c->capacity;
+  }
+  if (B.desc_cap < desc_bytes) {
+    if (B.h_desc) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipHostFree(B.h_desc)); B.h_desc = nullptr; }
+    if (B.d_desc) { HIP_TRY(c, hipFree(B.d_desc)); B.d_desc = nullptr; }
+    const size_t cap = std::max<size_t>(desc_bytes + desc_bytes / 4, 1 << 16);
+    HIP_TRY(c, hipHostMalloc(&B.h_desc, cap, hipHostMallocDefault));
+    HIP_TRY(c, hipMalloc(&B.d_desc, cap));
+    B.desc_cap = cap;
+  }
+  return FTKX_OK;
+}
+
+// the kernels behind the fused tail: refine, exact test, ordering, records, finish
+void series_queue_rest(ftkx_ctx *c, const ftkx_series_pending &P, const Mesh &m, unsigned seq)
+{
+  ftkx_series_buffers &B = c->sr_buf[P.buf];
+  Fields *d_steps = (Fields *)((char *)B.d_desc + P.off_steps);
+  unsigned *flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
+  if (P.two_level) ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
+  ftkx::launch_exact(m, d_steps, 0, c->d_list, c->list_capacity, c->stream);
+  ftkx::launch_bucket_scan(c->sr_hist, c->sr_boff, (unsigned)P.nbins, c->d_counters, c->stream);
+  ftkx::launch_bucket_scatter(m, c->sr_boff, c->sr_bucketed, c->stream);
+  ftkx::launch_bucket_rank(m, c->sr_bucketed, c->sr_boff, c->sr_sorted, B.results, c->stream);
+  ftkx::launch_series_records(m, d_steps, c->sr_sorted, P.to_device ? B.d_out : B.out, nullptr, c->stream);
+  ev_end(c);
+  ftkx::launch_series_finish(m, B.results, P.nwords, c->list_capacity, c->refine_capacity, B.h_results, flag, seq, nullptr, c->stream);
+}
+
+// First half: everything of the pass is queued on the context's stream.  `prev`: the pass queued before this one and not yet collected,
+// whose running minimum this one continues from (on the device), or nullptr: *running_in is the value.
+int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *scopes, int n, double running_in, const ftkx_series_pending *prev, bool pipelined)
+{
+  const int nd = c->nd;
+  P = ftkx_series_pending();
+  P.ts.assign(ts, ts + n); P.scopes.assign(scopes, scopes + n); P.n = n;
+  P.running_in = running_in; P.chained = prev != nullptr;
+  int rc;
+  if ((rc = series_steps(c, ts, scopes, n, P.slice_ts))) return rc;
+  const std::vector<int> &slice_ts = P.slice_ts;
+  const size_t k = slice_ts.size();
+  P.k = k;
+  std::vector<Slice *> sl(k);
+  for (size_t j = 0; j < k; j ++) sl[j] = &c->slices.find(slice_ts[j])->second;
+
+  // ---- is the device-driven form applicable? ---------------------------------------------------------------------------------------
+  Mesh m; fill_mesh(c, m);
+  const bool two_level = ftkx::masks_have_summary(m);
+  u64 cells = 1;
+  for (int d = 0; d < nd; d ++) cells *= (u64)c->core_sz[d];
+  bool ok = series_applicable(c, ts, scopes, n, slice_ts, sl, cells);
+  if (prev && prev->by_host) ok = false;                     // (its running minimum will not be on the device)
+  const unsigned long long hint = std::max<unsigned long long>(factor_of(running_in), 256ull);
+  P.hint = hint; P.two_level = two_level; P.cells = cells; P.u_rows = m.u_rows;
+  if (!ok) { P.by_host = true; P.open = true; return FTKX_OK; }
   // slices whose masks and reduction stand from an earlier call (a streaming tracker: slice t of this step was slice t + 1 of the last)
-  std::vector<int> red_index(k, -1);
+  P.red_index.assign(k, -1);
+  std::vector<int> &red_index = P.red_index;
   size_t ntodo = 0;
-  for (size_t j = 0; ok && j < k; j ++) {
+  for (size_t j = 0; j < k; j ++) {
     const Slice &s = *sl[j];
     const bool ready = s.M && (!two_level || (s.U && s.u_rows == m.u_rows)) && s.mask_factor != 0 && s.mask_factor <= hint && !s.mask_big && (s.have_fused || s.have_res);
     if (!ready) red_index[j] = (int)ntodo ++;
-  }
-  if (!ok) return series_by_host(c, ts, scopes, n, slice_ts, running_resolution, factors, out, n_out);
-
-  // ---- the pass in chunks, the tail of one next to the mask kernel of the next: built, exact (tests/test_gpu_series.py) -- and OFF unless
-  // FTKX_SERIES_CHUNKS asks for it: measured on hit-dense data (double_gyre 2048 x 1024 x 128: 1.05 ms in one piece, 1.10 / 1.17 / 1.52 ms
-  // in 2 / 3 / 4 chunks; woven 1024^2 x 64: 0.35 -> 0.43 / 0.52 / 0.57 ms) the tail kernels of chunk k get next to nothing done while the
-  // mask kernel of chunk k + 1 saturates the memory system and occupies every workgroup slot (coarse cull 27 -> 108 us, the one-workgroup
-  // factor kernel 8 -> 253 us waiting for a slot, stream priority notwithstanding): the tail still ends after the last mask kernel, and
-  // the extra launches and events are paid on top ----
-  int rc;
-  {
-    int nchunks = 1;
-    if (const char *e = getenv("FTKX_SERIES_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 8) nchunks = n >= 2 * v ? v : 1; }   // (an explicit choice: tests, experiments)
-    if (nchunks > 1) {
-      rc = series_chunked(c, nchunks, ts, scopes, n, slice_ts, sl, red_index, ntodo, two_level, cells, hint, running_resolution, factors, out, n_out);
-      if (rc < 0) return rc;
-      if (rc == 1) {
-        // still hit-dense?  Then the next pass is chunked again; otherwise it is queued in one piece, with the fused tail kernel
-        c->sr_skip_small = c->stats.cells_survived > 4 * 2048ull ? 16 : 0;
-        return FTKX_OK;
-      }
-      return series_by_host(c, ts, scopes, n, slice_ts, running_resolution, factors, out, n_out);
-    }
   }
 
   // ---- buffers (persistent; they only ever grow) -----------------------------------------------------------------------------------
   if ((rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16)))) return rc;
   if ((rc = ensure_fragile(c, std::max<u64>(c->fragile_capacity, 1u << 12)))) return rc;
   if ((rc = ensure_list(c, std::max<u64>(c->list_capacity, 1u << 20))) || (rc = ensure_refine(c, std::max<u64>(c->refine_capacity, 1u << 20)))) return rc;
-  if ((rc = ensure_host_buffer(c, (size_t)c->capacity))) return rc;
   for (size_t j = 0; j < k; j ++) if (red_index[j] >= 0 && (rc = ensure_mask_arrays(c, *sl[j], two_level))) return rc;
   if (c->red_cap < std::max<size_t>(ntodo, 1)) {
     if (c->d_red) { (void)hipFree(c->d_red); c->d_red = nullptr; c->red_cap = 0; }
@@ -439,6 +479,7 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   while (key_bits < 63 && (1ull << key_bits) < max_key) key_bits ++;
   const int shift = std::max(0, key_bits - 16);
   const size_t nbins = (size_t)((max_key - 1) >> shift) + 1;
+  P.nbins = nbins;
   if (c->sr_bins_cap < nbins + 1) {
     const size_t cap = std::max<size_t>(nbins + 1, (1u << 16) + 1);
     for (void *p : {(void *)c->sr_hist, (void *)c->sr_boff}) if (p) (void)hipFree(p);
@@ -450,28 +491,27 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   if ((rc = grow_device(c, &c->sr_bucketed, &c->sr_bucketed_cap, (size_t)c->capacity))) return rc;
   if ((rc = grow_device(c, &c->sr_sorted, &c->sr_sorted_cap, (size_t)c->capacity))) return rc;
   const size_t nwords = (size_t)ftkx::SR_HEAD + (size_t)n + 2 * k;
-  if ((rc = grow_device(c, &c->sr_results, &c->sr_results_cap, std::max<size_t>(nwords, 1024)))) return rc;
-  const size_t h_words = nwords + (size_t)c->fragile_capacity * 10;
-  if (c->sr_h_results_cap < h_words) {
-    if (c->sr_h_results) { HIP_TRY(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->sr_h_results); c->sr_h_results = nullptr; c->sr_h_results_cap = 0; }
-    const size_t cap = h_words + h_words / 4 + 1024;
-    HIP_TRY(c, hipHostMalloc((void **)&c->sr_h_results, (cap + 8) * sizeof(u64), hipHostMallocCoherent));
-    c->sr_h_results_cap = cap;
-    *reinterpret_cast<volatile unsigned *>(c->sr_h_results + cap) = 0u;
-    c->sr_seq = 0;
-  }
-  fill_mesh(c, m);                                           // (the buffers may have moved)
-  m.hist = c->sr_hist; m.hist_shift = shift; m.core_cells = cells;
-
+  P.nwords = nwords;
   // ---- descriptors: mask jobs | steps | slice table | step table, one pinned block fetched by a kernel -------------------------------
   const size_t off_jobs = 0, off_steps = align256(ntodo * sizeof(MaskJob)), off_slices = off_steps + align256((size_t)n * sizeof(Fields)),
                off_sinfo = off_slices + align256(k * sizeof(ftkx::SeriesSlice)), total = off_sinfo + align256((size_t)n * sizeof(ftkx::SeriesStep));
-  if ((rc = ensure_desc(c, total))) return rc;
+  P.off_steps = off_steps; P.total_desc = total;
+  // A pass with many records, queued while another is still out: the record kernel leaves them in device memory and a copy engine takes
+  // them over PCIe once the host knows how many there are -- next to the mask kernel of the pass queued behind.  (A record kernel that
+  // writes through PCIe itself holds its stream for the transfer: 106 us of woven 1024^2 x 64's 363.)
+  static const bool sdma_on = !(getenv("FTKX_SERIES_COPY") && atoi(getenv("FTKX_SERIES_COPY")) == 0);
+  P.to_device = pipelined && sdma_on && c->stats.hits > 4096;
+  P.buf = c->sr_next_buf; c->sr_next_buf ^= 1;
+  ftkx_series_buffers &B = c->sr_buf[P.buf];
+  if ((rc = ensure_series_buffers(c, B, nwords, total, P.to_device))) return rc;
+  if (P.to_device && !c->sr_copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->sr_copy_stream, hipStreamNonBlocking));
+  fill_mesh(c, m);                                           // (the buffers may have moved)
+  m.hist = c->sr_hist; m.hist_shift = shift; m.core_cells = cells;
   {
-    MaskJob *jobs = (MaskJob *)((char *)c->h_desc + off_jobs);
-    Fields *steps = (Fields *)((char *)c->h_desc + off_steps);
-    ftkx::SeriesSlice *ss = (ftkx::SeriesSlice *)((char *)c->h_desc + off_slices);
-    ftkx::SeriesStep *si = (ftkx::SeriesStep *)((char *)c->h_desc + off_sinfo);
+    MaskJob *jobs = (MaskJob *)((char *)B.h_desc + off_jobs);
+    Fields *steps = (Fields *)((char *)B.h_desc + off_steps);
+    ftkx::SeriesSlice *ss = (ftkx::SeriesSlice *)((char *)B.h_desc + off_slices);
+    ftkx::SeriesStep *si = (ftkx::SeriesStep *)((char *)B.h_desc + off_sinfo);
     const double cap = 1.0 / (double)hint;
     for (size_t j = 0; j < k; j ++) {
       const Slice &s = *sl[j];
@@ -497,84 +537,145 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
       si[i].slice0 = (int)j0; si[i].slice1 = interval ? (int)j0 + 1 : -1; si[i].last = (int)last; si[i].pad = 0;
     }
   }
-  const MaskJob *d_jobs = (const MaskJob *)((char *)c->d_desc + off_jobs);
-  Fields *d_steps = (Fields *)((char *)c->d_desc + off_steps);
-  const ftkx::SeriesSlice *d_slices = (const ftkx::SeriesSlice *)((char *)c->d_desc + off_slices);
-  const ftkx::SeriesStep *d_sinfo = (const ftkx::SeriesStep *)((char *)c->d_desc + off_sinfo);
+  const MaskJob *d_jobs = (const MaskJob *)((char *)B.d_desc + off_jobs);
+  Fields *d_steps = (Fields *)((char *)B.d_desc + off_steps);
+  const ftkx::SeriesSlice *d_slices = (const ftkx::SeriesSlice *)((char *)B.d_desc + off_slices);
+  const ftkx::SeriesStep *d_sinfo = (const ftkx::SeriesStep *)((char *)B.d_desc + off_sinfo);
 
   // ---- the whole pass, queued ------------------------------------------------------------------------------------------------------
-  unsigned *flag = reinterpret_cast<unsigned *>(c->sr_h_results + c->sr_h_results_cap);
-  const unsigned seq = ++ c->sr_seq;
-  // (marks set before the masks exist are taken back on every error exit, like ftkx_slices_prepare does)
-  struct MarkGuard { std::vector<Slice *> *v; std::vector<int> *todo; bool armed; ~MarkGuard() { if (armed) for (size_t j = 0; j < v->size(); j ++) if ((*todo)[j] >= 0) { (*v)[j]->mask_factor = 0; (*v)[j]->have_fused = false; } } } marks{&sl, &red_index, true};
+  unsigned *flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
+  const unsigned seq = ++ B.seq;
+  P.seq = seq;
+  // (the masks of the slices this pass rebuilds are nobody's until it has been collected; whatever else touches masks meanwhile bumps the
+  // epoch, and the marks of this pass are then not applied)
   for (size_t j = 0; j < k; j ++) if (red_index[j] >= 0) { sl[j]->mask_factor = 0; sl[j]->have_fused = false; }
-  ftkx::launch_series_begin(c->d_counters, c->d_red, ntodo * 64, c->sr_hist, nbins + 1, c->sr_results, nwords, c->stream);
-  launch_fetch_desc(c->h_desc, c->d_desc, total, c->stream);
+  P.epoch = ++ c->mask_epoch;
+  ftkx::launch_series_begin(c->d_counters, c->d_red, ntodo * 64, c->sr_hist, nbins + 1, B.results, nwords, c->stream);
+  launch_fetch_desc(B.h_desc, B.d_desc, total, c->stream);
   if (ntodo) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs, (int)ntodo, c->stream); ev_end(c); }
   ev_begin(c, K_CULL);
-  if (two_level) ftkx::launch_cull_coarse(m, d_steps, n, c->d_refine, c->refine_capacity, c->stream);
-  else ftkx::launch_cull(m, d_steps, n, c->d_list, c->list_capacity, c->stream);
-  ftkx::launch_series_factors(d_steps, n, d_slices, (int)k, d_sinfo, c->d_red, *running_resolution, nullptr, (double)(nd == 3 ? ftkx::kSafeM3 : ftkx::kSafeM2),
-                              c->sr_results, c->d_counters, c->stream);
+  {
+    // the factors need what the mask kernel left, the cull does not need the factors: one extra workgroup of the cull kernel forms them
+    // (series_device.hpp) -- a kernel boundary and a one-workgroup launch less than the factor kernel behind the cull
+    const double safe_m = (double)(nd == 3 ? ftkx::kSafeM3 : ftkx::kSafeM2);
+    const u64 *running_from = prev ? c->sr_buf[prev->buf].results : nullptr;
+    ftkx::FactorJob fj;
+    memset(&fj, 0, sizeof(fj));
+    fj.steps = d_steps; fj.slices = d_slices; fj.sinfo = d_sinfo; fj.red = c->d_red; fj.running_from = running_from; fj.results = B.results; fj.counters = c->d_counters;
+    fj.running_in = prev ? DBL_MAX : running_in; fj.safe_m = safe_m; fj.nsteps = n; fj.nslices = (int)k;
+    static const bool fold_on = !(getenv("FTKX_SERIES_FOLD") && atoi(getenv("FTKX_SERIES_FOLD")) == 0);
+    fj.enabled = (fold_on && k <= (size_t)ftkx::kFoldMaxSlices) ? 1 : 0;
+    if (two_level) ftkx::launch_cull_coarse(m, d_steps, n, c->d_refine, c->refine_capacity, c->stream, &fj);
+    else ftkx::launch_cull(m, d_steps, n, c->d_list, c->list_capacity, c->stream, &fj);
+    if (!fj.enabled) ftkx::launch_series_factors(d_steps, n, d_slices, (int)k, d_sinfo, c->d_red, fj.running_in, running_from, safe_m, B.results, c->d_counters, c->stream);
+  }
   ev_end(c);
   ev_begin(c, K_EXACT);
-  // sparse data: one workgroup does the rest of the pass (and the kernels below leave at once)
+  // sparse data: one kernel does the rest of the pass (and the kernels below leave at once)
   static const bool small_on = !(getenv("FTKX_SERIES_SMALL") && atoi(getenv("FTKX_SERIES_SMALL")) == 0);
   // (a pass that has just found far more survivors than the fused kernel takes does not launch it for a while: finding nothing to do
   // costs its 256 workgroups of 256-VGPR wavefronts ~15 us)
-  const bool small_now = small_on && c->sr_skip_small == 0;
+  const bool small_now = small_on && c->sr_skip_small == 0 && !P.to_device;
   if (c->sr_skip_small > 0) c->sr_skip_small --;
-  if (small_now) ftkx::launch_series_small(m, two_level ? ftkx::coarse_view(m) : m, d_steps, two_level, c->d_refine, c->d_list, c->h_hits, c->sr_results, nwords,
-                                          c->sr_h_results, flag, seq, reinterpret_cast<unsigned *>(c->d_counters + ftkx::CNT_SMALL_DONE), c->stream);
-  if (two_level) ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
-  ftkx::launch_exact(m, d_steps, 0, c->d_list, c->list_capacity, c->stream);
-  ftkx::launch_bucket_scan(c->sr_hist, c->sr_boff, (unsigned)nbins, c->d_counters, c->stream);
-  ftkx::launch_bucket_scatter(m, c->sr_boff, c->sr_bucketed, c->stream);
-  ftkx::launch_bucket_rank(m, c->sr_bucketed, c->sr_boff, c->sr_sorted, c->sr_results, c->stream);
-  ftkx::launch_series_records(m, d_steps, c->sr_sorted, c->h_hits, nullptr, c->stream);
-  ev_end(c);
-  ftkx::launch_series_finish(m, c->sr_results, nwords, c->list_capacity, c->refine_capacity, c->sr_h_results, flag, seq, nullptr, c->stream);
+  // (the fused tail finished the last pass too: this one is queued WITHOUT the seven kernels behind it -- each of them costs a few us just
+  // to find out that it has nothing to do.  Should the fused tail decline this time, it says so itself and the rest is queued then -- which
+  // needs the device to itself: not with another pass queued behind.)
+  static const bool short_on = !(getenv("FTKX_SERIES_SHORT") && atoi(getenv("FTKX_SERIES_SHORT")) == 0);
+  P.small_now = small_now;
+  P.short_chain = small_now && short_on && c->sr_short_chain && !pipelined;
+  if (small_now) ftkx::launch_series_small(m, two_level ? ftkx::coarse_view(m) : m, d_steps, two_level, c->d_refine, c->d_list, B.out, B.results, nwords,
+                                          B.h_results, flag, seq, reinterpret_cast<unsigned *>(c->d_counters + ftkx::CNT_SMALL_DONE), P.short_chain, c->stream);
+  if (!P.short_chain) series_queue_rest(c, P, m, seq);
   HIP_TRY(c, hipGetLastError());
-  if (const char *why = ftkx::wait_flag(flag, seq, c->stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+  P.open = true;
+  return FTKX_OK;
+}
+
+// Second half: the host waits (once) for the pass, marks the slices, patches what has to be patched on the host, or has the host-driven
+// batch sweep the steps again where a kernel raised a flag.
+int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolution, unsigned long long *factors, const ftkx_cp_t **out, size_t *n_out)
+{
+  const int nd = c->nd, n = P.n;
+  const size_t k = P.k;
+  P.open = false;
+  double running = *running_resolution;                       // (what the pass started from: the host-driven batch, if it comes to that, starts there too)
+  if (P.by_host) {
+    int rc = series_by_host(c, P.ts.data(), P.scopes.data(), n, P.slice_ts, &running, factors, out, n_out);
+    if (rc == FTKX_OK) *running_resolution = running;
+    return rc;
+  }
+  ftkx_series_buffers &B = c->sr_buf[P.buf];
+  unsigned *flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
+  Mesh m; fill_mesh(c, m);
+  {
+    const u64 max_key = (u64)n * P.cells * 64ull;
+    int key_bits = 1;
+    while (key_bits < 63 && (1ull << key_bits) < max_key) key_bits ++;
+    m.hist = c->sr_hist; m.hist_shift = std::max(0, key_bits - 16); m.core_cells = P.cells;
+  }
+  if (const char *why = ftkx::wait_flag(flag, P.seq, c->stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+  if (P.short_chain) {
+    const unsigned long long st = B.h_results[ftkx::SR_STATUS];
+    if (st & ftkx::SERIES_TAIL_PENDING) {
+      const unsigned seq2 = ++ B.seq;
+      series_queue_rest(c, P, m, seq2);
+      HIP_TRY(c, hipGetLastError());
+      if (const char *why = ftkx::wait_flag(flag, seq2, c->stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+    } else ev_end(c);
+  }
   ev_harvest(c, false);
 
   // ---- what came back ----------------------------------------------------------------------------------------------------------------
-  const u64 *R = c->sr_h_results;
+  const u64 *R = B.h_results;
   const unsigned long long status = R[ftkx::SR_STATUS];
   c->sr_last_status = status;
-  // the masks and reductions of this pass stand whichever way the records are made: the slices are marked like ftkx_slices_prepare marks them
-  marks.armed = false;
-  for (size_t j = 0; j < k; j ++) {
-    if (red_index[j] < 0) continue;
-    Slice &s = *sl[j];
-    double r, x;
-    memcpy(&r, &R[ftkx::SR_HEAD + n + j], 8); memcpy(&x, &R[ftkx::SR_HEAD + n + k + j], 8);
-    if (std::isinf(x)) { s.mask_factor = 0; s.have_fused = false; continue; }     // the fused max is not the max FINITE |v|: the host-driven path reduces it exactly
-    s.res_below = r; s.fused_factor = hint; s.have_fused = true;
-    if (!s.have_res) s.maxabs = x;
-    s.mask_factor = overflow_free(nd, s.maxabs, hint) ? hint : 0;
-    s.mask_big = false; s.u_rows = m.u_rows;
-  }
+  // the masks and reductions of this pass stand whichever way the records are made: the slices are marked like ftkx_slices_prepare marks
+  // them -- unless something has rebuilt or dropped masks since the pass was queued
+  if (c->mask_epoch == P.epoch)
+    for (size_t j = 0; j < k; j ++) {
+      if (P.red_index[j] < 0) continue;
+      auto it = c->slices.find(P.slice_ts[j]);
+      if (it == c->slices.end()) continue;
+      Slice &s = it->second;
+      double r, x;
+      memcpy(&r, &R[ftkx::SR_HEAD + n + j], 8); memcpy(&x, &R[ftkx::SR_HEAD + n + k + j], 8);
+      if (std::isinf(x)) { s.mask_factor = 0; s.have_fused = false; continue; }     // the fused max is not the max FINITE |v|: the host-driven path reduces it exactly
+      s.res_below = r; s.fused_factor = P.hint; s.have_fused = true;
+      if (!s.have_res) s.maxabs = x;
+      s.mask_factor = overflow_free(nd, s.maxabs, P.hint) ? P.hint : 0;
+      s.mask_big = false; s.u_rows = P.u_rows;
+    }
   const unsigned long long redo = ftkx::SERIES_AMBIGUOUS | ftkx::SERIES_MASKS_INVALID | ftkx::SERIES_INF | ftkx::SERIES_OVERFLOW;
   if (status & redo) {
+    c->sr_short_chain = false;
+    int rc;
     if (status & ftkx::SERIES_OVERFLOW) {                    // grow what was too small (the host-driven batch would find out the same way, one replay later)
       const u64 *cnt = R + ftkx::SR_COUNTERS;
       const u64 hits = cnt[ftkx::CNT_PASS], listed = cnt[ftkx::CNT_LIST_PEAK], refined = cnt[ftkx::CNT_REFINE_PEAK], fragile = cnt[ftkx::CNT_FRAGILE];
+      if (c->sr_open > 0) HIP_TRY(c, hipStreamSynchronize(c->stream));   // (a pass queued behind this one still uses the buffers)
       if (hits > c->capacity && (rc = ensure_hit_buffer(c, hits + hits / 8 + 1024))) return rc;
       if (listed > c->list_capacity && (rc = ensure_list(c, listed + listed / 8 + 1024))) return rc;
       if (refined > c->refine_capacity && (rc = ensure_refine(c, refined + refined / 8 + 1024))) return rc;
       if (fragile > c->fragile_capacity && (rc = ensure_fragile(c, fragile + fragile / 8 + 1024))) return rc;
     }
-    return series_by_host(c, ts, scopes, n, slice_ts, running_resolution, factors, out, n_out);
+    rc = series_by_host(c, P.ts.data(), P.scopes.data(), n, P.slice_ts, &running, factors, out, n_out);
+    if (rc == FTKX_OK) *running_resolution = running;
+    return rc;
   }
   c->sr_last_path = (status & ftkx::SERIES_EARLY) ? 2 : 1;
+  c->sr_short_chain = (status & ftkx::SERIES_EARLY) != 0;
   const u64 *cnt = R + ftkx::SR_COUNTERS;
-  if (!(status & ftkx::SERIES_EARLY) && (two_level ? cnt[ftkx::CNT_REFINE_PEAK] : cnt[ftkx::CNT_LIST_PEAK]) > 4 * 2048ull) c->sr_skip_small = 16;
+  if (!(status & ftkx::SERIES_EARLY) && (P.two_level ? cnt[ftkx::CNT_REFINE_PEAK] : cnt[ftkx::CNT_LIST_PEAK]) > 4 * 2048ull) c->sr_skip_small = 16;
   const size_t nrec = (size_t)R[ftkx::SR_NHITS];
+  ftkx_cp_t *H = B.out;
+  if (P.to_device && nrec) {                                 // (the copy engine; the mask kernel of the pass queued behind this one is running meanwhile)
+    HIP_TRY(c, hipMemcpyAsync(H, B.d_out, nrec * sizeof(ftkx_cp_t), hipMemcpyDeviceToHost, c->sr_copy_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->sr_copy_stream));
+  }
   memset(&c->stats, 0, sizeof(c->stats));
   {
     const u64 n_ord = nd == 2 ? 2 : 6, n_int = nd == 2 ? 10 : 54;
-    for (int i = 0; i < n; i ++) { c->stats.cells += cells; c->stats.work_items += cells * (((scopes[i] & 1) ? n_ord : 0) + ((scopes[i] & 2) ? n_int : 0)); }
+    for (int i = 0; i < n; i ++) { c->stats.cells += P.cells; c->stats.work_items += P.cells * (((P.scopes[i] & 1) ? n_ord : 0) + ((P.scopes[i] & 2) ? n_int : 0)); }
   }
   c->stats.cull_enabled = 1;
   c->stats.hits = nrec;
@@ -584,26 +685,26 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   // the same), patched in place -- the records are in host memory already
   const size_t nf = (size_t)R[ftkx::SR_NFRAGILE];
   for (size_t i = 0; i < nf; i ++) {
-    const u64 *e = R + nwords + i * 10;
+    const u64 *e = R + P.nwords + i * 10;
     double A[3][3];
     memcpy(A, e + 1, sizeof(A));
-    if (e[0] < nrec) c->h_hits[e[0]].type = (unsigned)ftkx::classify3(A, c->opt.jacobian_symmetric != 0);
+    if (e[0] < nrec) H[e[0]].type = (unsigned)ftkx::classify3(A, c->opt.jacobian_symmetric != 0);
   }
   c->stats.reclassified = nf;
   if (status & ftkx::SERIES_UNORDERED) {                     // (the fused tail with more records than its last workgroup ranks: rare) sort an index, move once
     std::vector<std::pair<unsigned long long, size_t>> order(nrec);
-    for (size_t i = 0; i < nrec; i ++) order[i] = {c->h_hits[i].tag, i};
+    for (size_t i = 0; i < nrec; i ++) order[i] = {H[i].tag, i};
     std::sort(order.begin(), order.end());
     std::vector<ftkx_cp_t> tmp(nrec);
-    for (size_t i = 0; i < nrec; i ++) tmp[i] = c->h_hits[order[i].second];
-    if (nrec) memcpy(c->h_hits, tmp.data(), nrec * sizeof(ftkx_cp_t));
+    for (size_t i = 0; i < nrec; i ++) tmp[i] = H[order[i].second];
+    if (nrec) memcpy(H, tmp.data(), nrec * sizeof(ftkx_cp_t));
   }
   if (status & ftkx::SERIES_FIX_ORDER) {
     // A bucket too full to rank on the device: its records sit in their own run of the output, unordered among themselves; everything
     // before the run is smaller, everything behind it larger.  Find each such run from an inversion, widen it until both ends are in
     // order with their neighbours, sort it.
     auto less = [](const ftkx_cp_t &p, const ftkx_cp_t &q) { return p.tag < q.tag; };
-    ftkx_cp_t *h = c->h_hits;
+    ftkx_cp_t *h = H;
     for (size_t a = 0; a + 1 < nrec; a ++) {
       if (h[a].tag <= h[a + 1].tag) continue;
       size_t lo = a, hi = a + 2;
@@ -621,9 +722,106 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   memcpy(&run, &R[ftkx::SR_RUNNING], 8);
   *running_resolution = run;
   if (factors) for (int i = 0; i < n; i ++) factors[i] = R[ftkx::SR_HEAD + i];
-  if (out) *out = c->h_hits;
+  if (out) *out = H;
   if (n_out) *n_out = nrec;
   return FTKX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ftkx_sweep_series_submit(ftkx_ctx *c, const int *ts, const int *scopes, int n, const double *running_resolution)
+{
+  if (!c || n <= 0 || !ts || !scopes) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: null argument or no steps");
+  if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "sweep: call ftkx_set_mesh first");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: sweeps pending, collect first");
+  if (c->sr_open >= 2) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: two passes are open, complete one first");
+  if (!running_resolution && c->sr_open == 0) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: no pass open to continue from, give the running resolution");
+  if (running_resolution && !(*running_resolution > 0)) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: the running resolution must be positive (DBL_MAX: none yet)");
+  c->ahead.clear(); c->announced.clear();
+  HIP_TRY(c, hipSetDevice(c->device));
+  const ftkx_series_pending *prev = (!running_resolution) ? &c->sr_pend[(c->sr_head + c->sr_open - 1) & 1] : nullptr;
+  ftkx_series_pending &P = c->sr_pend[(c->sr_head + c->sr_open) & 1];
+  const double running_in = running_resolution ? *running_resolution : (c->sr_last_running > 0 ? c->sr_last_running : DBL_MAX);
+  int rc = series_submit(c, P, ts, scopes, n, running_in, prev, true);
+  if (rc) { P.open = false; return rc; }
+  c->sr_open ++;
+  return FTKX_OK;
+}
+
+int ftkx_sweep_series_complete(ftkx_ctx *c, double *running_resolution, unsigned long long *factors, const ftkx_cp_t **out, size_t *n_out)
+{
+  if (!c || !running_resolution) return fail(c, FTKX_E_INVALID, "null argument");
+  if (out) *out = nullptr;
+  if (n_out) *n_out = 0;
+  if (c->sr_open == 0) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_complete: no pass open");
+  HIP_TRY(c, hipSetDevice(c->device));
+  ftkx_series_pending &P = c->sr_pend[c->sr_head];
+  c->sr_head ^= 1; c->sr_open --;
+  *running_resolution = P.chained ? c->sr_last_running : P.running_in;   // (a chained pass continues from what the pass before it returned)
+  int rc = series_complete(c, P, running_resolution, factors, out, n_out);
+  if (rc == FTKX_OK) c->sr_last_running = *running_resolution;
+  return rc;
+}
+
+int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, double *running_resolution, unsigned long long *factors,
+                      const ftkx_cp_t **out, size_t *n_out)
+{
+  if (!c || (n > 0 && (!ts || !scopes)) || !running_resolution) return fail(c, FTKX_E_INVALID, "null argument");
+  if (out) *out = nullptr;
+  if (n_out) *n_out = 0;
+  if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "sweep: call ftkx_set_mesh first");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series: sweeps pending, collect first");
+  if (c->sr_open) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series: passes open (ftkx_sweep_series_submit), complete them first");
+  if (!(*running_resolution > 0)) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series: the running resolution must be positive (DBL_MAX: none yet)");
+  if (n == 0) return FTKX_OK;
+  c->ahead.clear(); c->announced.clear();
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+
+  // ---- the pass in chunks, the tail of one next to the mask kernel of the next: built, exact (tests/test_gpu_series.py) -- and OFF unless
+  // FTKX_SERIES_CHUNKS asks for it: measured on hit-dense data (double_gyre 2048 x 1024 x 128: 1.05 ms in one piece, 1.10 / 1.17 / 1.52 ms
+  // in 2 / 3 / 4 chunks; woven 1024^2 x 64: 0.35 -> 0.43 / 0.52 / 0.57 ms) the tail kernels of chunk k get next to nothing done while the
+  // mask kernel of chunk k + 1 saturates the memory system and occupies every workgroup slot (coarse cull 27 -> 108 us, the one-workgroup
+  // factor kernel 8 -> 253 us waiting for a slot, stream priority notwithstanding): the tail still ends after the last mask kernel, and
+  // the extra launches and events are paid on top ----
+  {
+    int nchunks = 1;
+    if (const char *e = getenv("FTKX_SERIES_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 8) nchunks = n >= 2 * v ? v : 1; }   // (an explicit choice: tests, experiments)
+    if (nchunks > 1) {
+      ftkx_series_pending Q;
+      if ((rc = series_steps(c, ts, scopes, n, Q.slice_ts))) return rc;
+      std::vector<Slice *> sl(Q.slice_ts.size());
+      for (size_t j = 0; j < sl.size(); j ++) sl[j] = &c->slices.find(Q.slice_ts[j])->second;
+      Mesh m; fill_mesh(c, m);
+      const bool two_level = ftkx::masks_have_summary(m);
+      u64 cells = 1;
+      for (int d = 0; d < c->nd; d ++) cells *= (u64)c->core_sz[d];
+      if (series_applicable(c, ts, scopes, n, Q.slice_ts, sl, cells)) {
+        const unsigned long long hint = std::max<unsigned long long>(factor_of(*running_resolution), 256ull);
+        std::vector<int> red_index(sl.size(), -1);
+        size_t ntodo = 0;
+        for (size_t j = 0; j < sl.size(); j ++) {
+          const Slice &s = *sl[j];
+          const bool ready = s.M && (!two_level || (s.U && s.u_rows == m.u_rows)) && s.mask_factor != 0 && s.mask_factor <= hint && !s.mask_big && (s.have_fused || s.have_res);
+          if (!ready) red_index[j] = (int)ntodo ++;
+        }
+        c->mask_epoch ++;
+        rc = series_chunked(c, nchunks, ts, scopes, n, Q.slice_ts, sl, red_index, ntodo, two_level, cells, hint, running_resolution, factors, out, n_out);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+          // still hit-dense?  Then the next pass is chunked again; otherwise it is queued in one piece, with the fused tail kernel
+          c->sr_skip_small = c->stats.cells_survived > 4 * 2048ull ? 16 : 0;
+          return FTKX_OK;
+        }
+      }
+      return series_by_host(c, ts, scopes, n, Q.slice_ts, running_resolution, factors, out, n_out);
+    }
+  }
+  ftkx_series_pending &P = c->sr_pend[0];
+  if ((rc = series_submit(c, P, ts, scopes, n, *running_resolution, nullptr, false))) { P.open = false; return rc; }
+  return series_complete(c, P, running_resolution, factors, out, n_out);
 }
 
 int ftkx_series_last_path(const ftkx_ctx *c, unsigned long long *status)

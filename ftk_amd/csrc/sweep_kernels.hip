@@ -23,6 +23,7 @@
 //
 // No MFMA: 64-bit integer VALU work on 8-24 bytes per vertex, HBM-bound once the cull applies.
 #include "sweep_device.hpp"
+#include "series_device.hpp"
 
 namespace ftkx {
 
@@ -1648,8 +1649,13 @@ __device__ inline u64 dpp_u64_from_upper_lane(u64 v)
 // "corner" is an aligned group of 8 corners, and what survives is appended to the refine list instead of the final list.
 template <int ND, int ZC, bool COARSE>
 __global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, const Fields *__restrict__ steps, int nsteps, int step_chunk,
-                                                              int gx_log2, u64 *__restrict__ list, u64 list_capacity)
+                                                              int gx_log2, u64 *__restrict__ list, u64 list_capacity, const FactorJob fj)
 {
+  if (fj.enabled && blockIdx.z == gridDim.z - 1) {             // the extra layer of the grid: one of its workgroups forms the factors
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+      series_factors_body<kThreads, kFoldMaxSlices>(fj.steps, fj.nsteps, fj.slices, fj.nslices, fj.sinfo, fj.red, fj.running_in, fj.running_from, fj.safe_m, fj.results, fj.counters);
+    return;
+  }
   constexpr int kListCounter = COARSE ? CNT_REFINE_LIST : CNT_SURVIVOR_LIST;
   __shared__ unsigned s_wave_total[4];
   __shared__ u64 s_block_base;
@@ -2508,8 +2514,10 @@ bool masks_have_summary(const Mesh &m)
 bool masks_fuse_reduction(const Mesh &) { return true; }
 
 template <bool COARSE>
-static void launch_cull_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream)
+static void launch_cull_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream, const FactorJob *job = nullptr)
 {
+  FactorJob fj = FactorJob();
+  if (job) fj = *job;
   int ZC = m.nd == 3 ? 4 : 1;
   if (const char *e = getenv("FTKX_CULL_ZC")) { const int v = atoi(e); if (m.nd == 3 && (v == 2 || v == 4 || v == 8)) ZC = v; }
   const int groups = (m.ext_sz[0] + 7) / 8;
@@ -2523,8 +2531,8 @@ static void launch_cull_level(const Mesh &m, const Fields *d_steps, int nsteps, 
   int step_chunk = 4;   // (2D: the survivors of a workgroup's four steps leave with one atomic on the list counter)
   if (const char *e = getenv("FTKX_CULL_STEP_CHUNK")) step_chunk = atoi(e) > 0 ? atoi(e) : step_chunk;
   const int nsc = (nsteps + step_chunk - 1) / step_chunk;
-  const dim3 grid((unsigned)((groups + GX - 1) / GX), (unsigned)((m.ext_sz[1] + rows_per_block - 1) / rows_per_block), (unsigned)(nzc * nsc));
-#define FTKX_CULL_LAUNCH(ND_, ZC_) hipLaunchKernelGGL((cull_march_kernel<ND_, ZC_, COARSE>), grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, step_chunk, gx_log2, d_list, cap)
+  const dim3 grid((unsigned)((groups + GX - 1) / GX), (unsigned)((m.ext_sz[1] + rows_per_block - 1) / rows_per_block), (unsigned)(nzc * nsc) + (fj.enabled ? 1u : 0u));
+#define FTKX_CULL_LAUNCH(ND_, ZC_) hipLaunchKernelGGL((cull_march_kernel<ND_, ZC_, COARSE>), grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, step_chunk, gx_log2, d_list, cap, fj)
   if (m.nd == 2) FTKX_CULL_LAUNCH(2, 1);
   else if (ZC == 2) FTKX_CULL_LAUNCH(3, 2);
   else if (ZC == 8) FTKX_CULL_LAUNCH(3, 8);
@@ -2536,10 +2544,10 @@ void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t s
 // pre-pass: only valid when march2_supported(m)
 void launch_reduce_march(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream) { launch_masks_impl(m, d_jobs, njobs, true, stream); }
 
-void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream)
+void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream, const FactorJob *job)
 {
   if (nsteps <= 0) return;
-  launch_cull_level<false>(m, d_steps, nsteps, d_list, cap, stream);
+  launch_cull_level<false>(m, d_steps, nsteps, d_list, cap, stream, job);
 }
 
 // two-level form: summaries first (1/8 of the bytes), vertex masks only for the words the summaries could not rule out
@@ -2557,10 +2565,10 @@ Mesh coarse_view(const Mesh &m)
 }
 
 // the two levels as separate launches (the series pass puts its factor kernel between them)
-void launch_cull_coarse(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, hipStream_t stream)
+void launch_cull_coarse(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, hipStream_t stream, const FactorJob *job)
 {
   if (nsteps <= 0) return;
-  launch_cull_level<true>(coarse_view(m), d_steps, nsteps, d_refine, refine_cap, stream);
+  launch_cull_level<true>(coarse_view(m), d_steps, nsteps, d_refine, refine_cap, stream, job);
 }
 
 void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream)
@@ -2574,7 +2582,7 @@ void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u6
 void launch_cull_two_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream)
 {
   if (nsteps <= 0) return;
-  launch_cull_coarse(m, d_steps, nsteps, d_refine, refine_cap, stream);
+  launch_cull_coarse(m, d_steps, nsteps, d_refine, refine_cap, stream, nullptr);
   launch_refine(m, d_steps, d_refine, refine_cap, d_list, cap, stream);
 }
 

@@ -116,6 +116,7 @@ struct MaskJob {
 
 constexpr int kSeriesMaxSlices = 2048;    // slices (and steps) one series pass takes: their reductions are folded in LDS
 constexpr int kSeriesMaxBins = 1 << 16;    // buckets of the ordering step
+constexpr int kFoldMaxSlices = 256;        // up to this many slices the factor job rides in the cull kernel (FactorJob); above: its own kernel
 
 // ---- series pass: sticky factor on the device (critical_point_tracker.hh:850-864) -----------------------------------------------
 struct SeriesSlice {
@@ -123,6 +124,17 @@ struct SeriesSlice {
   int red_index;             // which 64-slot block of `red` holds this slice's fused reduction; -1: reduced earlier (known_* stand)
   double known_res;          // smallest non-zero |v| below 1 / (the factor its masks were built under), or DBL_MAX; DBL_MAX if not known
   double known_max;          // max |v|; 0 if not known
+};
+struct SeriesStep;
+struct SeriesSlice;
+struct Fields;
+// The arguments of series_factors_body when the job is done by one extra workgroup of the cull kernel (which does not need the factors,
+// only what the mask kernel left: the two run side by side instead of one behind the other -- a kernel boundary and a one-workgroup
+// kernel less per pass).  enabled = 0: no such workgroup.
+struct FactorJob {
+  Fields *steps; const SeriesSlice *slices; const SeriesStep *sinfo; const u64 *red; const u64 *running_from; u64 *results; u64 *counters;
+  double running_in, safe_m;
+  int nsteps, nslices, enabled, pad;
 };
 struct SeriesStep {
   int slice0, slice1;        // indices of the step's slices (slice1 = -1: ordinal sweep only)
@@ -135,7 +147,8 @@ enum { SERIES_AMBIGUOUS = 1,        // 1 / resolution so close above a power of 
        SERIES_OVERFLOW = 8,         // a list / pass / fragile buffer was too small
        SERIES_FIX_ORDER = 16,       // a bucket of the ordering step was too full to rank on the device: its records are unordered among themselves
        SERIES_EARLY = 32,           // (informational) the fused tail kernel finished the pass
-       SERIES_UNORDERED = 64 };     // the fused tail found more records than its last workgroup ranks: they come unordered, the host sorts them
+       SERIES_UNORDERED = 64,       // the fused tail found more records than its last workgroup ranks: they come unordered, the host sorts them
+       SERIES_TAIL_PENDING = 128 }; // the pass was queued in its short form (mask, cull, fused tail) and the fused tail declined: the host queues the rest
 // results block (device copy and coherent pinned copy, same layout; u64 words)
 enum { SR_STATUS = 0, SR_RUNNING = 1, SR_NHITS = 2, SR_NFRAGILE = 3, SR_BASE_NEXT = 4 /* chunked pass: records of this chunk and the ones before it */,
        SR_COUNTERS = 5, SR_HEAD = 5 + CNT_N };   // then factors[nsteps], res[nslices], max[nslices], fragile[cap * 10]

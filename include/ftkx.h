@@ -204,6 +204,17 @@ int ftkx_sweep_cancel(ftkx_ctx *ctx);    /* forgets the enqueued, not yet collec
  * inside this one, with the same result.  Records as for ftkx_sweep_collect: sorted by tag, valid until the next call. */
 int ftkx_sweep_series(ftkx_ctx *ctx, const int *timesteps, const int *scopes, int n, double *running_resolution,
                       unsigned long long *factors, const ftkx_cp_t **out, size_t *n_out);
+/* The same pass in two halves, for callers that keep the device busy across passes (a streaming tracker, bench.py): _submit queues a
+ * pass and returns; _complete waits for the OLDEST open pass and returns what ftkx_sweep_series returns.  At most two passes are open at
+ * a time: submit(N), submit(N + 1), complete(N), submit(N + 2), complete(N + 1), ...  While pass N + 1's mask kernel runs, the host
+ * collects pass N, and the records of a pass with many of them cross PCIe on a copy engine instead of holding the stream.
+ * running_resolution of _submit: the running minimum before this pass, or NULL = continue from the pass queued before it, still open
+ * (the minimum is handed on ON THE DEVICE; _complete then reports the chained value).  Between _submit and _complete only slices may be
+ * pushed or dropped and further passes submitted; the sweeps above and ftkx_slices_prepare fail until every open pass is complete.
+ * Records of a pass: valid until the second _submit after its _complete.  Results are those of ftkx_sweep_series on the same steps:
+ * tests/test_gpu_series.py::test_pipelined_passes_equal_the_plain_ones. */
+int ftkx_sweep_series_submit(ftkx_ctx *ctx, const int *timesteps, const int *scopes, int n, const double *running_resolution);
+int ftkx_sweep_series_complete(ftkx_ctx *ctx, double *running_resolution, unsigned long long *factors, const ftkx_cp_t **out, size_t *n_out);
 /* which way the last ftkx_sweep_series went: 1 = device-driven, 2 = device-driven and finished by the fused tail kernel (sparse
  * data), 3 = device-driven in chunks (hit-dense data: the tail of a chunk runs next to the mask kernel of the next), 0 = host-driven batch; *status (nullable) = the SERIES_* bits the kernels raised (csrc/sweep_params.hpp) */
 int ftkx_series_last_path(const ftkx_ctx *ctx, unsigned long long *status);

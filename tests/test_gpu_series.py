@@ -231,6 +231,131 @@ def test_series_fallbacks_give_the_same_records(gpu, monkeypatch):
     assert _same(r, base) and np.array_equal(f, bf)
 
 
+def test_short_chain_and_its_way_back(gpu, monkeypatch):
+    """Sparse data: the fused tail kernel finishes a pass, and the NEXT pass is queued without the kernels behind it (refine, exact, scan,
+    scatter, rank, records, finish).  When that pass then has more survivors than the fused tail takes, the kernel says so itself and the
+    host queues the rest: sparse, dense, sparse, dense, sparse on one context -- every pass equals the same sweep on a fresh context with
+    the short chain (and the factor job inside the cull kernel) switched off."""
+    import torch
+    from ftk_amd import synthetic
+    dev = torch.device("cuda", 0)
+    dims, nt = (96, 80), 6
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    sparse = [synthetic.generate("moving_extremum_2d", dims, t, nt, torch, dev).cpu().numpy() for t in range(nt)]
+    dense = [synthetic.generate("woven", dims, t, nt, torch, dev).cpu().numpy() * 1.0 for t in range(nt)]
+    rng = np.random.default_rng(5)
+    dense = [d + 0.3 * rng.standard_normal(d.shape) for d in dense]          # thousands of critical points
+    series = [sparse, dense, sparse, dense, sparse]
+
+    def sweep(ctx, steps):
+        for t in list(range(nt)):
+            ctx.push_scalar_slice(t, steps[t])
+        recs, f, _ = ctx.sweep_series(range(nt), scopes)
+        return recs.copy(), [int(v) for v in f], ctx.series_last_path()
+
+    monkeypatch.setenv("FTKX_SERIES_SHORT", "0")
+    monkeypatch.setenv("FTKX_SERIES_FOLD", "0")
+    want = []
+    for steps in series:
+        ctx = _ctx(gpu, dims, 2, 1, tag_mode=gpu.TAG_EXACT64)
+        want.append(sweep(ctx, steps))
+        ctx.close()
+    monkeypatch.delenv("FTKX_SERIES_SHORT")
+    monkeypatch.delenv("FTKX_SERIES_FOLD")
+    ctx = _ctx(gpu, dims, 2, 1, tag_mode=gpu.TAG_EXACT64)
+    paths = []
+    for i, steps in enumerate(series):
+        got = sweep(ctx, steps)
+        paths.append(got[2][0])
+        assert got[1] == want[i][1], (i, got[1], want[i][1])
+        assert _same(got[0], want[i][0]), (i, len(got[0]), len(want[i][0]), got[2], want[i][2])
+    ctx.close()
+    assert paths[0] == 2 and paths[2] == 2 and paths[4] == 2, (paths, [w[2] for w in want])      # the fused tail did the sparse passes
+    # ... and declined the dense ones, both times out of the short chain: the first outgrew the buffers on top (replayed by the host-driven
+    # batch, which grows them), the second had its seven kernels queued behind the report
+    assert paths[1] in (0, 1) and paths[3] == 1, (paths, [w[2] for w in want])
+    assert len(want[1][0]) > 2000
+
+
+@pytest.mark.parametrize("name", ["woven_128x128x10", "woven_31x37x32", "double_gyre_64x32x50", "merger_2d_32x32x100", "moving_extremum_3d_21x21x21x32",
+                                  "adversarial_3d_scalar_9x9x9x4"])
+def test_pipelined_passes_equal_the_plain_ones(gpu, name):
+    """ftkx_sweep_series_submit / _complete, two passes open at a time: (a) the whole series swept again and again, masks dropped in
+    between (what bench.py times), (b) the series in consecutive pieces, each continuing on the device from the running minimum of the one
+    before it, while the host has not even seen that one yet (a streaming caller).  Records, factors and running minima are those of
+    ftkx_sweep_series on the same steps; the copy engine carries the records of the later passes (more than 4096 of them, where the
+    fixture has that many)."""
+    g = load_golden(name)
+    nd, nv, nt = g["nd"], g["nv"], g["DT"]
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    ctx = _ctx(gpu, g["dims"], nd, nv, tag_mode=gpu.TAG_EXACT64, robust=int(g["robust"]), compute_degrees=int(g["degrees"]))
+    _push_all(ctx, g["steps"], nv)
+    want, wf, wrun = ctx.sweep_series(range(nt), scopes)
+    # (a)
+    ctx.invalidate_masks()
+    ctx.sweep_series_submit(range(nt), scopes)
+    for it in range(4):
+        ctx.invalidate_masks()
+        ctx.sweep_series_submit(range(nt), scopes)
+        got, f, run = ctx.sweep_series_complete()
+        assert _same(got, want) and np.array_equal(f, wf) and run == wrun, (name, it, len(got), len(want))
+    got, f, run = ctx.sweep_series_complete()
+    assert _same(got, want) and np.array_equal(f, wf) and run == wrun
+    with pytest.raises(Exception):
+        ctx.sweep_series_complete()
+    # (b) pieces of the series; the reference: the same pieces through ftkx_sweep_series, the running minimum carried by the caller
+    pieces = [list(range(a, min(a + 3, nt))) for a in range(0, nt, 3)]
+    ctx.invalidate_masks()
+    ref, run = [], None
+    for p in pieces:
+        sc = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in p]
+        r, f, run = ctx.sweep_series(p, sc, running_resolution=run)
+        ref.append((r, [int(v) for v in f], run))
+    assert sum(len(r[0]) for r in ref) == len(want)
+    ctx.invalidate_masks()
+    done = []
+    for i, p in enumerate(pieces):
+        sc = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in p]
+        ctx.sweep_series_submit(p, sc, chain=i > 0)
+        if i > 0:
+            done.append(ctx.sweep_series_complete())
+    done.append(ctx.sweep_series_complete())
+    for i, (r, f, run) in enumerate(done):
+        assert _same(r, ref[i][0]) and [int(v) for v in f] == ref[i][1] and run == ref[i][2], (name, i, len(r), len(ref[i][0]), run, ref[i][2])
+    # the plain call still works, other sweeps are refused while a pass is open
+    ctx.sweep_series_submit(range(nt), scopes)
+    with pytest.raises(Exception):
+        ctx.slices_prepare(range(nt), 0)
+    got, f, run = ctx.sweep_series_complete()
+    assert _same(got, want)
+    ctx.close()
+
+
+def test_pipelined_records_through_the_copy_engine(gpu):
+    """more than 4096 records per pass: from the second pipelined pass on the record kernel leaves them in device memory and the copy
+    engine brings them over while the next pass runs; records and factors as ftkx_sweep_series returns them"""
+    import torch
+    from ftk_amd import synthetic
+    dev = torch.device("cuda", 0)
+    dims, nt = (1024, 512), 16
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    ctx = _ctx(gpu, dims, 2, 1, tag_mode=gpu.TAG_EXACT64)
+    for t in range(nt):
+        ctx.push_scalar_slice(t, synthetic.generate("woven", dims, t, nt, torch, dev))
+    want, wf, wrun = ctx.sweep_series(range(nt), scopes)
+    assert len(want) > 4096
+    ctx.invalidate_masks()
+    ctx.sweep_series_submit(range(nt), scopes)
+    for it in range(3):
+        ctx.invalidate_masks()
+        ctx.sweep_series_submit(range(nt), scopes)
+        got, f, run = ctx.sweep_series_complete()
+        assert _same(got, want) and np.array_equal(f, wf) and run == wrun, (it, len(got), len(want))
+    got, f, run = ctx.sweep_series_complete()
+    assert _same(got, want) and np.array_equal(f, wf) and run == wrun
+    ctx.close()
+
+
 def test_series_overflowing_buffers_replays_through_the_batch(gpu):
     """more records than the initial hit buffer holds (65 536): flagged by the finish kernel, swept again by the host-driven batch, and
     the NEXT call fits"""
