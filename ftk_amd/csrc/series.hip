@@ -62,6 +62,14 @@ template <class T> int grow_device(ftkx_ctx *c, T **p, size_t *cap, size_t want)
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
+// buckets of the ordering step: 2^this over the keys a pass can produce (at most kSeriesMaxBins).  2^14: the scan of the counts is a
+// one-workgroup kernel (18 us over 2^16 of them), the ranking inside a bucket costs next to nothing more with four records than with one
+int bins_log2()
+{
+  static const int v = [] { const char *e = getenv("FTKX_SERIES_BINS_LOG2"); const int b = e ? atoi(e) : 0; return b >= 8 && b <= 16 ? b : 14; }();
+  return v;
+}
+
 int slot_prepare(ftkx_ctx *c, ftkx_series_slot &sl, size_t nbins, size_t nwords)
 {
   int rc;
@@ -149,7 +157,7 @@ int series_chunked(ftkx_ctx *c, int nchunks, const int *ts, const int *scopes, i
     const u64 max_key = (u64)nq * cells * 64ull;
     int key_bits = 1;
     while (key_bits < 63 && (1ull << key_bits) < max_key) key_bits ++;
-    shift[(size_t)q] = std::max(0, key_bits - 16);
+    shift[(size_t)q] = std::max(0, key_bits - bins_log2());
     nbins[(size_t)q] = (size_t)((max_key - 1) >> shift[(size_t)q]) + 1;
     nwords[(size_t)q] = (size_t)ftkx::SR_HEAD + (size_t)nq + 2 * (size_t)kq;
     if ((rc = slot_prepare(c, c->sr_slots[(size_t)q], nbins[(size_t)q], nwords[(size_t)q]))) return rc;
@@ -387,6 +395,7 @@ int ensure_series_buffers(ftkx_ctx *c, ftkx_series_buffers &B, size_t nwords, si
     HIP_TRY(c, hipHostMalloc((void **)&B.h_results, (cap + 8) * sizeof(u64), hipHostMallocCoherent));
     B.h_results_cap = cap;
     *reinterpret_cast<volatile unsigned *>(B.h_results + cap) = 0u;
+    *(reinterpret_cast<volatile unsigned *>(B.h_results + cap) + 2) = 0u;          // (the copy kernel's flag)
     B.seq = 0;
   }
   if (B.out_cap < (size_t)c->capacity) {
@@ -400,6 +409,12 @@ int ensure_series_buffers(ftkx_ctx *c, ftkx_series_buffers &B, size_t nwords, si
     HIP_TRY(c, hipMalloc((void **)&B.d_out, (size_t)c->capacity * sizeof(ftkx_cp_t)));
     B.d_out_cap = (size_t)c->capacity;
   }
+  if (to_device && !B.copy_done) {
+    HIP_TRY(c, hipMalloc((void **)&B.copy_done, sizeof(unsigned)));
+    HIP_TRY(c, hipMemsetAsync(B.copy_done, 0, sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipEventCreateWithFlags(&B.ev_finished, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&B.ev_copied, hipEventDisableTiming));
+  }
   if (B.desc_cap < desc_bytes) {
     if (B.h_desc) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipHostFree(B.h_desc)); B.h_desc = nullptr; }
     if (B.d_desc) { HIP_TRY(c, hipFree(B.d_desc)); B.d_desc = nullptr; }
@@ -410,6 +425,8 @@ int ensure_series_buffers(ftkx_ctx *c, ftkx_series_buffers &B, size_t nwords, si
   }
   return FTKX_OK;
 }
+
+void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, hipEvent_t also_after);
 
 // the kernels behind the fused tail: refine, exact test, ordering, records, finish
 void series_queue_rest(ftkx_ctx *c, const ftkx_series_pending &P, const Mesh &m, unsigned seq)
@@ -422,14 +439,31 @@ void series_queue_rest(ftkx_ctx *c, const ftkx_series_pending &P, const Mesh &m,
   ftkx::launch_bucket_scan(c->sr_hist, c->sr_boff, (unsigned)P.nbins, c->d_counters, c->stream);
   ftkx::launch_bucket_scatter(m, c->sr_boff, c->sr_bucketed, c->stream);
   ftkx::launch_bucket_rank(m, c->sr_bucketed, c->sr_boff, c->sr_sorted, B.results, c->stream);
+  if (B.copy_out) { (void)hipStreamWaitEvent(c->stream, B.ev_copied, 0); B.copy_out = false; }   // (the copy of the pass that used these buffers last: long through)
   ftkx::launch_series_records(m, d_steps, c->sr_sorted, P.to_device ? B.d_out : B.out, nullptr, c->stream);
   ev_end(c);
   ftkx::launch_series_finish(m, B.results, P.nwords, c->list_capacity, c->refine_capacity, B.h_results, flag, seq, nullptr, c->stream);
+  if (P.to_device) (void)hipEventRecord(B.ev_finished, c->stream);      // (series_queue_copy waits for it)
+}
+
+// the records' way over PCIe: a small kernel on its own stream, behind the finish kernel (the count is final) and next to whatever the
+// context's stream does then -- the mask kernel of the pass queued behind this one
+void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, hipEvent_t also_after)
+{
+  ftkx_series_buffers &B = c->sr_buf[P.buf];
+  unsigned *flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
+  (void)hipStreamWaitEvent(c->sr_copy_stream, B.ev_finished, 0);
+  if (also_after) (void)hipStreamWaitEvent(c->sr_copy_stream, also_after, 0);
+  ftkx::launch_series_copy_out(B.d_out, B.out, (u64)B.d_out_cap, B.results, B.copy_done, flag + 2, P.seq, c->sr_copy_stream);
+  (void)hipEventRecord(B.ev_copied, c->sr_copy_stream);
+  B.copy_out = true;
+  P.copy_pending = false;
 }
 
 // First half: everything of the pass is queued on the context's stream.  `prev`: the pass queued before this one and not yet collected,
 // whose running minimum this one continues from (on the device), or nullptr: *running_in is the value.
-int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *scopes, int n, double running_in, const ftkx_series_pending *prev, bool pipelined)
+int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *scopes, int n, double running_in, const ftkx_series_pending *prev, bool pipelined,
+                  ftkx_series_pending *before = nullptr /* the pass queued before this one, if it is still open */)
 {
   const int nd = c->nd;
   P = ftkx_series_pending();
@@ -477,7 +511,7 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
   const u64 max_key = (u64)n * cells * 64ull;
   int key_bits = 1;
   while (key_bits < 63 && (1ull << key_bits) < max_key) key_bits ++;
-  const int shift = std::max(0, key_bits - 16);
+  const int shift = std::max(0, key_bits - bins_log2());
   const size_t nbins = (size_t)((max_key - 1) >> shift) + 1;
   P.nbins = nbins;
   if (c->sr_bins_cap < nbins + 1) {
@@ -496,9 +530,9 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
   const size_t off_jobs = 0, off_steps = align256(ntodo * sizeof(MaskJob)), off_slices = off_steps + align256((size_t)n * sizeof(Fields)),
                off_sinfo = off_slices + align256(k * sizeof(ftkx::SeriesSlice)), total = off_sinfo + align256((size_t)n * sizeof(ftkx::SeriesStep));
   P.off_steps = off_steps; P.total_desc = total;
-  // A pass with many records, queued while another is still out: the record kernel leaves them in device memory and a copy engine takes
-  // them over PCIe once the host knows how many there are -- next to the mask kernel of the pass queued behind.  (A record kernel that
-  // writes through PCIe itself holds its stream for the transfer: 106 us of woven 1024^2 x 64's 363.)
+  // A pass with many records, queued while another is still out: the record kernel leaves them in device memory and a small kernel on a
+  // stream of its own takes them over PCIe -- next to the mask kernel of the pass queued behind.  (A record kernel that writes through
+  // PCIe itself holds its stream for the transfer: 106 us of woven 1024^2 x 64's 363.)
   static const bool sdma_on = !(getenv("FTKX_SERIES_COPY") && atoi(getenv("FTKX_SERIES_COPY")) == 0);
   P.to_device = pipelined && sdma_on && c->stats.hits > 4096;
   P.buf = c->sr_next_buf; c->sr_next_buf ^= 1;
@@ -550,8 +584,16 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
   // epoch, and the marks of this pass are then not applied)
   for (size_t j = 0; j < k; j ++) if (red_index[j] >= 0) { sl[j]->mask_factor = 0; sl[j]->have_fused = false; }
   P.epoch = ++ c->mask_epoch;
-  ftkx::launch_series_begin(c->d_counters, c->d_red, ntodo * 64, c->sr_hist, nbins + 1, B.results, nwords, c->stream);
-  launch_fetch_desc(B.h_desc, B.d_desc, total, c->stream);
+  ftkx::launch_series_begin(c->d_counters, c->d_red, ntodo * 64, c->sr_hist, nbins + 1, B.results, nwords, c->stream, B.h_desc, B.d_desc, total);
+  if (before && before->open && before->copy_pending) {
+    // The pass queued before this one left its records in device memory.  Their way over PCIe starts HERE, behind this pass's descriptor
+    // fetch: that fetch is a read of the device over PCIe, and a read does not overtake the writes queued in front of it -- started
+    // together with the copy, 4 us became 65, with the mask kernel waiting behind.
+    ftkx_series_buffers &Bp = c->sr_buf[before->buf];
+    if (!Bp.ev_fetched) HIP_TRY(c, hipEventCreateWithFlags(&Bp.ev_fetched, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(Bp.ev_fetched, c->stream));
+    series_queue_copy(c, *before, Bp.ev_fetched);
+  }
   if (ntodo) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs, (int)ntodo, c->stream); ev_end(c); }
   ev_begin(c, K_CULL);
   {
@@ -578,14 +620,15 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
   const bool small_now = small_on && c->sr_skip_small == 0 && !P.to_device;
   if (c->sr_skip_small > 0) c->sr_skip_small --;
   // (the fused tail finished the last pass too: this one is queued WITHOUT the seven kernels behind it -- each of them costs a few us just
-  // to find out that it has nothing to do.  Should the fused tail decline this time, it says so itself and the rest is queued then -- which
-  // needs the device to itself: not with another pass queued behind.)
+  // to find out that it has nothing to do.  Should the fused tail decline this time, it says so itself and the rest is queued then (or,
+  // with another pass queued behind already, the host-driven batch sweeps the steps).)
   static const bool short_on = !(getenv("FTKX_SERIES_SHORT") && atoi(getenv("FTKX_SERIES_SHORT")) == 0);
   P.small_now = small_now;
-  P.short_chain = small_now && short_on && c->sr_short_chain && !pipelined;
+  P.short_chain = small_now && short_on && c->sr_short_chain;
   if (small_now) ftkx::launch_series_small(m, two_level ? ftkx::coarse_view(m) : m, d_steps, two_level, c->d_refine, c->d_list, B.out, B.results, nwords,
                                           B.h_results, flag, seq, reinterpret_cast<unsigned *>(c->d_counters + ftkx::CNT_SMALL_DONE), P.short_chain, c->stream);
   if (!P.short_chain) series_queue_rest(c, P, m, seq);
+  P.copy_pending = P.to_device;
   HIP_TRY(c, hipGetLastError());
   P.open = true;
   return FTKX_OK;
@@ -611,11 +654,20 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     const u64 max_key = (u64)n * P.cells * 64ull;
     int key_bits = 1;
     while (key_bits < 63 && (1ull << key_bits) < max_key) key_bits ++;
-    m.hist = c->sr_hist; m.hist_shift = std::max(0, key_bits - 16); m.core_cells = P.cells;
+    m.hist = c->sr_hist; m.hist_shift = std::max(0, key_bits - bins_log2()); m.core_cells = P.cells;
   }
   if (const char *why = ftkx::wait_flag(flag, P.seq, c->stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
   if (P.short_chain) {
     const unsigned long long st = B.h_results[ftkx::SR_STATUS];
+    if ((st & ftkx::SERIES_TAIL_PENDING) && c->sr_open > 0) {
+      // (the rest of this pass cannot be queued behind the pass that is already out -- that one has the counters and lists now: the
+      // host-driven batch sweeps the steps; it happens once, when sparse data turns dense)
+      c->sr_short_chain = false;
+      ev_end(c);
+      int rc = series_by_host(c, P.ts.data(), P.scopes.data(), n, P.slice_ts, &running, factors, out, n_out);
+      if (rc == FTKX_OK) *running_resolution = running;
+      return rc;
+    }
     if (st & ftkx::SERIES_TAIL_PENDING) {
       const unsigned seq2 = ++ B.seq;
       series_queue_rest(c, P, m, seq2);
@@ -668,9 +720,9 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
   if (!(status & ftkx::SERIES_EARLY) && (P.two_level ? cnt[ftkx::CNT_REFINE_PEAK] : cnt[ftkx::CNT_LIST_PEAK]) > 4 * 2048ull) c->sr_skip_small = 16;
   const size_t nrec = (size_t)R[ftkx::SR_NHITS];
   ftkx_cp_t *H = B.out;
-  if (P.to_device && nrec) {                                 // (the copy engine; the mask kernel of the pass queued behind this one is running meanwhile)
-    HIP_TRY(c, hipMemcpyAsync(H, B.d_out, nrec * sizeof(ftkx_cp_t), hipMemcpyDeviceToHost, c->sr_copy_stream));
-    HIP_TRY(c, hipStreamSynchronize(c->sr_copy_stream));
+  if (P.to_device) {                                         // (the copy kernel; the mask kernel of the pass queued behind this one is running meanwhile)
+    if (P.copy_pending) series_queue_copy(c, P, nullptr);    // (no pass was queued behind this one)
+    if (const char *why = ftkx::wait_flag(flag + 2, P.seq, c->sr_copy_stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
   }
   memset(&c->stats, 0, sizeof(c->stats));
   {
@@ -741,10 +793,11 @@ int ftkx_sweep_series_submit(ftkx_ctx *c, const int *ts, const int *scopes, int 
   if (running_resolution && !(*running_resolution > 0)) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: the running resolution must be positive (DBL_MAX: none yet)");
   c->ahead.clear(); c->announced.clear();
   HIP_TRY(c, hipSetDevice(c->device));
-  const ftkx_series_pending *prev = (!running_resolution) ? &c->sr_pend[(c->sr_head + c->sr_open - 1) & 1] : nullptr;
+  ftkx_series_pending *before = c->sr_open > 0 ? &c->sr_pend[(c->sr_head + c->sr_open - 1) & 1] : nullptr;
+  const ftkx_series_pending *prev = (!running_resolution) ? before : nullptr;
   ftkx_series_pending &P = c->sr_pend[(c->sr_head + c->sr_open) & 1];
   const double running_in = running_resolution ? *running_resolution : (c->sr_last_running > 0 ? c->sr_last_running : DBL_MAX);
-  int rc = series_submit(c, P, ts, scopes, n, running_in, prev, true);
+  int rc = series_submit(c, P, ts, scopes, n, running_in, prev, true, before);
   if (rc) { P.open = false; return rc; }
   c->sr_open ++;
   return FTKX_OK;

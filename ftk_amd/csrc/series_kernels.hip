@@ -14,9 +14,12 @@
 namespace ftkx {
 
 // ---- begin: every counter, reduction slot and histogram bin of the pass in one launch ------------------------------------------------
-__global__ __launch_bounds__(256) void series_begin_kernel(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults)
+__global__ __launch_bounds__(256) void series_begin_kernel(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults,
+                                                           const u64 *__restrict__ desc_src /* pinned; nullable */, u64 *__restrict__ desc_dst, size_t desc_words)
 {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // (the pass's descriptors, pinned host -> device: the first workgroups, so that the read over PCIe is under way at once)
+  for (size_t w = i; w < desc_words; w += (size_t)gridDim.x * 256) desc_dst[w] = desc_src[w];
   if (i < (size_t)CNT_N) counters[i] = 0ull;
   if (i < nslots) { red[2 * i] = 0x7fefffffffffffffull; red[2 * i + 1] = 0ull; }   // {min = DBL_MAX, max = 0} as bit patterns
   if (i < nbins) hist[i] = 0u;
@@ -554,12 +557,54 @@ __global__ __launch_bounds__(256) void series_finish_kernel(const u64 *__restric
   if (tid == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The records of a pass that left them in device memory, into the pinned host buffer: a FEW workgroups on a stream of their own, next to
+// the mask kernel of the pass queued behind (a copy queued through the runtime turned out to be a blit kernel with a grid that took the
+// mask kernel's slots: 109 -> 183 us).  How many there are is on the device (results[SR_NHITS], final: this runs behind the finish
+// kernel); the last workgroup stores the sequence number the host waits for.
+__global__ __launch_bounds__(256) void series_copy_out_kernel(const ftkx_cp_t *__restrict__ src, ftkx_cp_t *__restrict__ dst /* pinned */, u64 capacity,
+                                                              const u64 *__restrict__ results, unsigned *__restrict__ done, unsigned *flag, unsigned seq)
+{
+  u64 n = results[SR_NHITS];
+  if (n > capacity) n = capacity;
+  const size_t nvec = (size_t)n * sizeof(ftkx_cp_t) / 8;     // (72 bytes a record: nine words)
+  const u64 *s = reinterpret_cast<const u64 *>(src);
+  u64 *d = reinterpret_cast<u64 *>(dst);
+  // a wavefront moves runs of 64 x 8 x 8 bytes: eight loads in flight per lane, 512-byte bursts over PCIe
+  const size_t per = (size_t)gridDim.x * 256 * 8;
+  for (size_t base = (size_t)blockIdx.x * 256 * 8; base < nvec; base += per) {
+    u64 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k ++) { const size_t i = base + (size_t)k * 256 + threadIdx.x; v[k] = i < nvec ? s[i] : 0ull; }
+#pragma unroll
+    for (int k = 0; k < 8; k ++) { const size_t i = base + (size_t)k * 256 + threadIdx.x; if (i < nvec) __builtin_nontemporal_store(v[k], &d[i]); }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned before = atomicAdd(done, 1u);
+    if (before + 1 == gridDim.x) {
+      *done = 0;
+      __threadfence_system();
+      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+void launch_series_copy_out(const ftkx_cp_t *src, ftkx_cp_t *dst, u64 capacity, const u64 *results, unsigned *done, unsigned *flag, unsigned seq, hipStream_t st)
+{
+  static const int wgs = [] { const char *e = getenv("FTKX_COPY_WGS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 1024 ? v : 16; }();
+  hipLaunchKernelGGL(series_copy_out_kernel, dim3((unsigned)wgs), dim3(256), 0, st, src, dst, capacity, results, done, flag, seq);
+}
+
 // ---- launchers -----------------------------------------------------------------------------------------------------------------------
-void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st)
+void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st,
+                         const void *desc_src, void *desc_dst, size_t desc_bytes)
 {
   size_t n = (size_t)CNT_N;
   n = n > nslots ? n : nslots; n = n > nbins ? n : nbins; n = n > nresults ? n : nresults;
-  hipLaunchKernelGGL(series_begin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, counters, red, nslots, hist, nbins, results, nresults);
+  if (desc_src && n < 1024) n = 1024;
+  hipLaunchKernelGGL(series_begin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, counters, red, nslots, hist, nbins, results, nresults,
+                     (const u64 *)desc_src, (u64 *)desc_dst, desc_src ? desc_bytes / 8 : (size_t)0);
 }
 
 void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,

@@ -3,7 +3,7 @@
 duration and the idle gap in front of it (what the fixed tail of a pass is made of).
 
     rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 bench.py --config c2 --steps 5 --warmup 1 --no-cpu-baseline
-    python3 tools/pass_timeline.py DIR [--first KERNEL_SUBSTRING]
+    python3 tools/pass_timeline.py DIR [--first KERNEL_SUBSTRING] [--skip N]
 
 A pass starts at the dispatch whose name contains --first (default: init_red_kernel, the first launch of ftkx_slices_prepare /
 series_begin_kernel of the series pass)."""
@@ -43,7 +43,10 @@ def main():
     starts = [i for i, r in enumerate(rows) if any(s in r[2] for s in firsts)]
     if len(starts) < 2:
         sys.exit("fewer than two passes found")
-    a, b = starts[-2], starts[-1]          # the last COMPLETE pass
+    skip = int(sys.argv[sys.argv.index("--skip") + 1]) if "--skip" in sys.argv else 0   # passes to leave out at the end (bench.py's latency / per-kernel passes)
+    if len(starts) < 2 + skip:
+        sys.exit("fewer passes than --skip leaves")
+    a, b = starts[-2 - skip], starts[-1 - skip]          # the last COMPLETE pass (before the skipped ones)
     t0 = rows[a][0]
     prev_end = t0
     out = []
