@@ -140,12 +140,12 @@ def side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=5, warmup=2):
             if count:
                 p = ctx.series_last_path()
                 paths[str(p)] = paths.get(str(p), 0) + 1
-        return recs
-    recs = passes(max(warmup, 1), False)
+        return recs, f
+    recs, f = passes(max(warmup, 3), False)      # (see main(): everything a pass allocates exists before the clock starts)
     ctx.set_profiling(2)            # events around the dominant (mask) kernel only
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    recs = passes(steps, True)
+    recs, f = passes(steps, True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kt = ctx.kernel_times()
@@ -475,7 +475,9 @@ def job(args, env):
         return recs, ctx.stats()
 
     if args.warmup:
-        recs, st = passes(args.warmup)
+        # (two in flight, and a third pass so that one has been queued KNOWING how many records the data gives: both sets of buffers, the
+        # device-side record buffers and the copy stream exist before the clock starts)
+        recs, st = passes(max(args.warmup, 3) if pipelined else args.warmup)
     # HIP events on the stream the kernels run on: around the dominant (mask) kernel only inside the timed region -- a pair of events costs
     # the stream ~10 us of idle time, which a 0.4 ms pass notices --, around every kernel family in a few extra passes afterwards
     ctx.set_profiling(0 if args.no_kernel_events else (1 if args.exact_only else 2))     # (--exact-only: the dominant kernel is the tile kernel)

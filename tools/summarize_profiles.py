@@ -30,6 +30,8 @@ def one(pattern):
 shutil.copy(one("trace/*/*kernel_stats.csv"), os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "timeline.txt")):
     shutil.copy(os.path.join(src, "timeline.txt"), os.path.join(dst, f"{tag}_{cfg}_pass_timeline.txt"))
+if os.path.exists(os.path.join(src, "timeline_single.txt")):
+    shutil.copy(os.path.join(src, "timeline_single.txt"), os.path.join(dst, f"{tag}_{cfg}_pass_timeline_single.txt"))
 import subprocess
 try:
     commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
