@@ -70,6 +70,13 @@ def load():
         return _L
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m ftk_amd.build` (hipcc --offload-arch=gfx950)")
+    # PyTorch (this package's plumbing: device memory, streams, torch.distributed) ships a HIP runtime of its own.  Whichever runtime is
+    # loaded first serves the whole process, and with the system's loaded first torch finds no device afterwards ("no ROCm-capable device",
+    # seen when __graft_entry__.build() loaded this library before smoke() imported torch): torch goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, ll3, dbl = C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p
     L.ftkx_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
