@@ -1,5 +1,5 @@
 #!/bin/bash
-# full GPU suite
+# The whole `-m gpu` suite in one process on the GPU box, log under gpurun_out/:   gpurun --timeout 1150 -- 'bash tools/gpu_suite.sh'
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03_g05; rm -rf $O; mkdir -p $O
+O=gpurun_out/gpu_suite; rm -rf $O; mkdir -p $O
 timeout -k 10 1100 python3 -m pytest tests -m gpu -x -q -rs > $O/gpu_tests.log 2>&1; echo "rc=$?"; tail -15 $O/gpu_tests.log
