@@ -177,13 +177,15 @@ def streaming_tracker(nd, case, dims, nt_run, torch, dev, ftk_amd, synthetic, ho
     hipMemcpyAsync."""
     T = ftk_amd.CriticalPointTracker3DRegular if nd == 3 else ftk_amd.CriticalPointTracker2DRegular
 
-    def make():
+    def make(deferred=False):
         tr = T()
         tr.set_scalar_field_source(ftk_amd.SOURCE_GIVEN); tr.set_vector_field_source(ftk_amd.SOURCE_DERIVED)
         tr.set_jacobian_field_source(ftk_amd.SOURCE_DERIVED); tr.set_jacobian_symmetric(True)
         tr.set_domain([2] * nd, [d - 3 for d in dims]); tr.set_array_domain([0] * nd, list(dims))
         tr.set_tag_mode(ftk_amd.TAG_EXACT64)
         tr.initialize()
+        if deferred:
+            tr.set_deferred_collection(True)
         return tr
 
     def drive(tr, snaps):
@@ -208,7 +210,20 @@ def streaming_tracker(nd, case, dims, nt_run, torch, dev, ftk_amd, synthetic, ho
         tr.close()
         best = dt if best is None or dt < best else best
     out["device_resident"] = {"timesteps": nt_run, "ms_per_step": best / nt_run * 1e3, "records": int(nrec),
-                              "note": "push (device pointer, copied into the tracker's slice buffer) + advance_timestep per step; best of 3 series"}
+                              "note": "push (device pointer, borrowed) + advance_timestep per step, every step's records on the host before the next push; best of 3 series"}
+    best = None
+    for rep in range(3):
+        tr = make(deferred=True)
+        t0 = time.perf_counter()
+        drive(tr, dev_snaps)
+        tr.sync()                      # (the steps still out are collected inside the timed series)
+        dt = time.perf_counter() - t0
+        nrec2 = len(tr.get_critical_points()[0])
+        tr.close()
+        best = dt if best is None or dt < best else best
+    out["device_resident_deferred"] = {"timesteps": nt_run, "ms_per_step": best / nt_run * 1e3, "records": int(nrec2),
+                                       "note": "set_deferred_collection(True): step t+1's sweep is queued (continuing on the device from step t's running minimum) before "
+                                               "step t's records are collected; same records, visible one step later; sync() inside the timed series; best of 3"}
     # host-fed: numpy arrays in pageable memory, like an ndarray<double> of the reference
     h = min(host_steps, nt_run)
     host_snaps = [dev_snaps[t].cpu().numpy() for t in range(h)]

@@ -574,6 +574,12 @@ class _TrackerRegular:
     def set_tag_mode(self, m): self._flags["tag_mode"] = int(m)
     def set_stream(self, ptr): self._ck(self._L.ftkx_tracker_set_stream(self._h, C.c_void_p(ptr)))
     def set_current_timestep(self, t): self._ck(self._L.ftkx_tracker_set_current_timestep(self._h, int(t)))
+    def set_deferred_collection(self, b):
+        """the sweep of step t + 1 is queued before the records of step t are collected (ftkx_tracker.hh); pushed device tensors are kept alive
+        one step longer"""
+        self._deferred = bool(b)
+        self._ck(self._L.ftkx_tracker_set_deferred_collection(self._h, int(bool(b))))
+
     def set_enable_streaming_trajectories(self, b): self._ck(self._L.ftkx_tracker_set_enable_streaming_trajectories(self._h, int(bool(b))))
     def set_coords_bounds(self, b): self._ck(self._L.ftkx_tracker_set_coords_bounds(self._h, (C.c_double * len(b))(*[float(x) for x in b])))
 
@@ -610,7 +616,7 @@ class _TrackerRegular:
 
     def advance_timestep(self):
         self._ck(self._L.ftkx_tracker_advance_timestep(self._h))
-        self._keep = self._keep[-2:]
+        self._keep = self._keep[-(3 if getattr(self, "_deferred", False) else 2):]
 
     def update_timestep(self): self._ck(self._L.ftkx_tracker_update_timestep(self._h))
     def sync(self): self._ck(self._L.ftkx_tracker_sync(self._h))

@@ -53,7 +53,7 @@ EXPORTS = [
     "ftkx_trace_curves", "ftkx_trace_curves_ctx", "ftkx_free_curves", "ftkx_post_process_curves", "ftkx_free_trajectories", "ftkx_format_from_path", "ftkx_write_critical_points", "ftkx_read_critical_points", "ftkx_write_traced_critical_points", "ftkx_read_traced_critical_points", "ftkx_gradient2D", "ftkx_jacobian2D", "ftkx_gradient3D", "ftkx_jacobian3D", "ftkx_version", "ftkx_device_count", "ftkx_pointer_device", "ftkx_context_device", "ftkx_last_mask_kernel",
     "ftkx_tracker_post_process", "ftkx_tracker_get_curve_points", "ftkx_tracker_write", "ftkx_tracker_read_critical_points",
     "ftkx_tracker_create", "ftkx_tracker_create_multi", "ftkx_tracker_sync", "ftkx_tracker_destroy", "ftkx_tracker_last_error", "ftkx_tracker_set_domain", "ftkx_tracker_set_array_domain",
-    "ftkx_tracker_set_sources", "ftkx_tracker_set_flags", "ftkx_tracker_set_stream", "ftkx_tracker_set_current_timestep", "ftkx_tracker_set_enable_streaming_trajectories", "ftkx_online_tracer_create", "ftkx_online_tracer_destroy", "ftkx_online_tracer_grow", "ftkx_online_tracer_curves", "ftkx_tracker_set_coords_bounds", "ftkx_tracker_set_coords_rectilinear", "ftkx_tracker_set_coords_explicit", "ftkx_set_coords_rectilinear", "ftkx_set_coords_explicit", "ftkx_tracker_initialize",
+    "ftkx_tracker_set_sources", "ftkx_tracker_set_flags", "ftkx_tracker_set_stream", "ftkx_tracker_set_current_timestep", "ftkx_tracker_set_enable_streaming_trajectories", "ftkx_tracker_set_deferred_collection", "ftkx_online_tracer_create", "ftkx_online_tracer_destroy", "ftkx_online_tracer_grow", "ftkx_online_tracer_curves", "ftkx_tracker_set_coords_bounds", "ftkx_tracker_set_coords_rectilinear", "ftkx_tracker_set_coords_explicit", "ftkx_set_coords_rectilinear", "ftkx_set_coords_explicit", "ftkx_tracker_initialize",
     "ftkx_tracker_push_scalar_field_snapshot", "ftkx_tracker_push_vector_field_snapshot", "ftkx_tracker_push_field_data_snapshot",
     "ftkx_tracker_advance_timestep", "ftkx_tracker_update_timestep", "ftkx_tracker_num_critical_points",
     "ftkx_tracker_get_critical_points", "ftkx_tracker_get_scaling", "ftkx_tracker_get_stats",
@@ -130,6 +130,7 @@ def load():
     L.ftkx_tracker_sync.argtypes = [vp]
     L.ftkx_tracker_set_current_timestep.argtypes = [vp, C.c_int]
     L.ftkx_tracker_set_enable_streaming_trajectories.argtypes = [vp, C.c_int]
+    L.ftkx_tracker_set_deferred_collection.argtypes = [vp, C.c_int]
     L.ftkx_online_tracer_create.argtypes = [C.POINTER(vp), C.c_int, ll3, ll3]
     L.ftkx_online_tracer_destroy.argtypes = [vp]
     L.ftkx_online_tracer_destroy.restype = None

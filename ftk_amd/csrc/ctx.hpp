@@ -86,6 +86,7 @@ struct Slice {
   double res_below = 0;             //   the smallest non-zero |v| below 1 / fused_factor (DBL_MAX if none)
   unsigned long long fused_factor = 0;
   bool sparse = false;              // a halo slice that exists as masks only: its field array holds just the patches scattered into it
+  unsigned long long mask_gen = 0;  // changes whenever the masks are (re)built, dropped or the slice replaced: a series pass collected later marks only what is still its own
   bool max_known() const { return have_res || have_fused || sparse; }
 };
 
@@ -120,9 +121,10 @@ struct ftkx_series_pending {
   bool open = false;
   bool by_host = false;             // not queued: the host-driven batch sweeps it when it is collected
   std::vector<int> ts, scopes, slice_ts, red_index;
+  std::vector<unsigned long long> gen;   // per slice: Slice::mask_gen as this pass left it
   int n = 0, buf = 0;
   size_t k = 0, nwords = 0, nbins = 0, total_desc = 0;
-  unsigned long long hint = 0, epoch = 0;
+  unsigned long long hint = 0;
   bool two_level = false, short_chain = false, small_now = false, to_device = false;
   bool copy_pending = false;        // to_device: the copy kernel has not been queued yet (it goes behind the descriptor fetch of the next pass, or is queued when the pass is collected)
   int u_rows = 1;
@@ -217,7 +219,7 @@ struct ftkx_ctx {
   bool sr_internal = false;           // the host-driven batch is sweeping for a series pass: its calls are let through while passes are open
   int sr_next_buf = 0;
   hipStream_t sr_copy_stream = nullptr, sr_fetch_stream = nullptr;
-  unsigned long long mask_epoch = 0;  // bumped by everything that (re)builds or drops masks: a pass collected later does not mark slices over it
+  unsigned long long mask_epoch = 0;  // source of Slice::mask_gen values
   double sr_last_running = 0;         // the running minimum the host knew when it last collected a pass (hint of a chained pass)
   unsigned *sr_hist = nullptr, *sr_boff = nullptr;
   size_t sr_bins_cap = 0;

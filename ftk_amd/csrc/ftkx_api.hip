@@ -70,7 +70,6 @@ size_t mask_bytes(const ftkx_ctx *c) { return (size_t)mask_pitch(c) * (size_t)c-
 
 void free_slice(Slice &s, ftkx_ctx *pool_owner)
 {
-  if (pool_owner) pool_owner->mask_epoch ++;
   // owned copies go back to the context's pool: a streaming caller pushes and pops one slice per step, and hipMalloc + hipFree of a
   // slice-sized array cost more than sweeping a 256^3 slice
   auto give_back = [&](double *p, size_t count) {
@@ -271,7 +270,7 @@ int upload_from_host(ftkx_ctx *c, void *dst, const void *src, size_t bytes)
 
 int ensure_mask_arrays(ftkx_ctx *c, Slice &s, bool two_level)
 {
-  c->mask_epoch ++;                 // (every builder of masks comes through here: a series pass collected later leaves the slices' marks alone)
+  s.mask_gen = ++ c->mask_epoch;    // (every builder of masks comes through here: a series pass collected later leaves this slice's marks alone)
   if (!s.M) {
     if (!c->pool_M.empty()) { s.M = c->pool_M.back(); c->pool_M.pop_back(); }   // padding still neutral from its first life
     else {
@@ -538,8 +537,8 @@ static int push_common(ftkx_ctx *c, int t, const double *V, const double *J, con
   // the source buffers may be reused by the caller on return: a device source (2) has to be read first; a host source has been staged
   // completely by upload_from_host (nothing to wait for: the DMAs run on while the caller produces its next snapshot)
   if (on_device == 2) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  s.mask_gen = ++ c->mask_epoch;
   c->slices[t] = s;
-  c->mask_epoch ++;
   c->scalar_mode = scalar_only ? 1 : 0;
   return FTKX_OK;
 }
@@ -665,8 +664,7 @@ int ftkx_invalidate_masks(ftkx_ctx *c)
 {
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_invalidate_masks: sweeps pending, collect first");
-  for (auto &kv : c->slices) { kv.second.mask_factor = 0; kv.second.have_fused = false; }
-  c->mask_epoch ++;
+  for (auto &kv : c->slices) { kv.second.mask_factor = 0; kv.second.have_fused = false; kv.second.mask_gen = ++ c->mask_epoch; }
   c->ahead.clear();
   c->dense_collects = 0;
   return FTKX_OK;

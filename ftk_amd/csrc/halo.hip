@@ -135,8 +135,8 @@ int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, 
   if (frc != FTKX_OK) { free_slice(s, c); c->scalar_mode = saved_mode; return frc; }
   s.mask_factor = mask_factor; s.mask_big = false; s.u_rows = m.u_rows;
   s.maxabs = max_abs;                                                                  // (all a masked slice knows of its values)
+  s.mask_gen = ++ c->mask_epoch;
   c->slices[t] = s;
-  c->mask_epoch ++;
   return FTKX_OK;
 }
 
@@ -229,8 +229,8 @@ int ftkx_push_masked_slice_packed(ftkx_ctx *c, int t, int scalar_input, const vo
   if (frc != FTKX_OK) { free_slice(s, c); c->scalar_mode = saved_mode; return frc; }
   s.mask_factor = mask_factor; s.mask_big = false; s.u_rows = m.u_rows;
   s.maxabs = max_abs;
+  s.mask_gen = ++ c->mask_epoch;
   c->slices[t] = s;
-  c->mask_epoch ++;
   return FTKX_OK;
 }
 

@@ -198,7 +198,7 @@ int series_chunked(ftkx_ctx *c, int nchunks, const int *ts, const int *scopes, i
         const Slice &s = *sl[(size_t)j];
         ftkx::SeriesSlice &e = ss[j - j0[(size_t)q]];
         e.t = slice_ts[(size_t)j]; e.red_index = red_index[(size_t)j];
-        e.known_res = DBL_MAX; e.known_max = 0.0;
+        e.known_res = DBL_MAX; e.known_max = 0.0; e.from_res = nullptr; e.from_max = nullptr;
         if (s.have_res) { e.known_res = s.res < cap ? s.res : DBL_MAX; e.known_max = s.maxabs; }
         else if (red_index[(size_t)j] < 0) { e.known_res = s.res_below; e.known_max = s.maxabs; }
       }
@@ -489,11 +489,28 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
   if (!ok) { P.by_host = true; P.open = true; return FTKX_OK; }
   // slices whose masks and reduction stand from an earlier call (a streaming tracker: slice t of this step was slice t + 1 of the last)
   P.red_index.assign(k, -1);
+  P.gen.assign(k, 0);
   std::vector<int> &red_index = P.red_index;
+  // ... or are being built by the pass queued before this one, which is still out: their masks will be there in stream order, and what the
+  // factor job needs of their reductions it reads from that pass's results block on the device (a streaming caller queues step t + 1
+  // before it has collected step t: slice t + 1 is masked ONCE)
+  std::vector<const u64 *> from_res(k, nullptr), from_max(k, nullptr);
   size_t ntodo = 0;
   for (size_t j = 0; j < k; j ++) {
     const Slice &s = *sl[j];
-    const bool ready = s.M && (!two_level || (s.U && s.u_rows == m.u_rows)) && s.mask_factor != 0 && s.mask_factor <= hint && !s.mask_big && (s.have_fused || s.have_res);
+    bool ready = s.M && (!two_level || (s.U && s.u_rows == m.u_rows)) && s.mask_factor != 0 && s.mask_factor <= hint && !s.mask_big && (s.have_fused || s.have_res);
+    if (!ready && before && before->open && !before->by_host && before->hint <= hint && before->two_level == two_level && before->u_rows == m.u_rows) {
+      const auto it = std::lower_bound(before->slice_ts.begin(), before->slice_ts.end(), slice_ts[j]);
+      if (it != before->slice_ts.end() && *it == slice_ts[j]) {
+        const size_t jj = (size_t)(it - before->slice_ts.begin());
+        if (before->red_index[jj] >= 0 && before->gen[jj] == s.mask_gen && s.M && (!two_level || s.U)) {
+          const u64 *R = c->sr_buf[before->buf].results;
+          from_res[j] = R + ftkx::SR_HEAD + (size_t)before->n + jj;
+          from_max[j] = R + ftkx::SR_HEAD + (size_t)before->n + before->k + jj;
+          ready = true;
+        }
+      }
+    }
     if (!ready) red_index[j] = (int)ntodo ++;
   }
 
@@ -551,8 +568,9 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
       const Slice &s = *sl[j];
       ss[j].t = slice_ts[j]; ss[j].red_index = red_index[j];
       ss[j].known_res = DBL_MAX; ss[j].known_max = 0.0;
+      ss[j].from_res = from_res[j]; ss[j].from_max = from_max[j];
       if (s.have_res) { ss[j].known_res = s.res < cap ? s.res : DBL_MAX; ss[j].known_max = s.maxabs; }
-      else if (red_index[j] < 0) { ss[j].known_res = s.res_below; ss[j].known_max = s.maxabs; }
+      else if (red_index[j] < 0 && !from_res[j]) { ss[j].known_res = s.res_below; ss[j].known_max = s.maxabs; }
       if (red_index[j] >= 0)
         jobs[red_index[j]] = MaskJob{s.S, s.V, s.M, two_level ? s.U : nullptr, c->d_red + (size_t)red_index[j] * 128, cap, HUGE_VAL};   // rule off: validated by the factor kernel
     }
@@ -582,8 +600,10 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
   P.seq = seq;
   // (the masks of the slices this pass rebuilds are nobody's until it has been collected; whatever else touches masks meanwhile bumps the
   // epoch, and the marks of this pass are then not applied)
-  for (size_t j = 0; j < k; j ++) if (red_index[j] >= 0) { sl[j]->mask_factor = 0; sl[j]->have_fused = false; }
-  P.epoch = ++ c->mask_epoch;
+  for (size_t j = 0; j < k; j ++) {
+    if (red_index[j] >= 0) { sl[j]->mask_factor = 0; sl[j]->have_fused = false; sl[j]->mask_gen = ++ c->mask_epoch; }
+    P.gen[j] = sl[j]->mask_gen;
+  }
   ftkx::launch_series_begin(c->d_counters, c->d_red, ntodo * 64, c->sr_hist, nbins + 1, B.results, nwords, c->stream, B.h_desc, B.d_desc, total);
   if (before && before->open && before->copy_pending) {
     // The pass queued before this one left its records in device memory.  Their way over PCIe starts HERE, behind this pass's descriptor
@@ -682,12 +702,12 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
   const unsigned long long status = R[ftkx::SR_STATUS];
   c->sr_last_status = status;
   // the masks and reductions of this pass stand whichever way the records are made: the slices are marked like ftkx_slices_prepare marks
-  // them -- unless something has rebuilt or dropped masks since the pass was queued
-  if (c->mask_epoch == P.epoch)
+  // them -- slice by slice, unless something has rebuilt or dropped its masks, or replaced it, since the pass was queued
+  {
     for (size_t j = 0; j < k; j ++) {
       if (P.red_index[j] < 0) continue;
       auto it = c->slices.find(P.slice_ts[j]);
-      if (it == c->slices.end()) continue;
+      if (it == c->slices.end() || it->second.mask_gen != P.gen[j]) continue;
       Slice &s = it->second;
       double r, x;
       memcpy(&r, &R[ftkx::SR_HEAD + n + j], 8); memcpy(&x, &R[ftkx::SR_HEAD + n + k + j], 8);
@@ -697,6 +717,7 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
       s.mask_factor = overflow_free(nd, s.maxabs, P.hint) ? P.hint : 0;
       s.mask_big = false; s.u_rows = P.u_rows;
     }
+  }
   const unsigned long long redo = ftkx::SERIES_AMBIGUOUS | ftkx::SERIES_MASKS_INVALID | ftkx::SERIES_INF | ftkx::SERIES_OVERFLOW;
   if (status & redo) {
     c->sr_short_chain = false;

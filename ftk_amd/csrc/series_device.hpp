@@ -47,7 +47,7 @@ __device__ __forceinline__ void series_factors_body(Fields *__restrict__ steps, 
     const int j = j0 + tid / LPS, sub = tid % LPS;
     u64 mn = 0x7fefffffffffffffull, mxb = 0ull;
     SeriesSlice sl;
-    sl.red_index = -1; sl.known_res = 0; sl.known_max = 0; sl.t = 0;
+    sl.red_index = -1; sl.known_res = 0; sl.known_max = 0; sl.t = 0; sl.from_res = nullptr; sl.from_max = nullptr;
     if (j < nslices) sl = slices[j];
     if (j < nslices && sl.red_index >= 0) {
       const u64 *r = red + (size_t)sl.red_index * 128 + (size_t)sub * (2 * SLOTS);
@@ -60,6 +60,7 @@ __device__ __forceinline__ void series_factors_body(Fields *__restrict__ steps, 
     }
     if (sub == 0 && j < nslices) {
       double r = __longlong_as_double((long long)mn), x = __longlong_as_double((long long)mxb);
+      if (sl.from_res) { sl.known_res = __longlong_as_double((long long)*sl.from_res); sl.known_max = __longlong_as_double((long long)*sl.from_max); }
       if (sl.known_res < r) r = sl.known_res;
       if (sl.known_max > x) x = sl.known_max;
       res[j] = r; mx[j] = x;

@@ -124,6 +124,7 @@ struct SeriesSlice {
   int red_index;             // which 64-slot block of `red` holds this slice's fused reduction; -1: reduced earlier (known_* stand)
   double known_res;          // smallest non-zero |v| below 1 / (the factor its masks were built under), or DBL_MAX; DBL_MAX if not known
   double known_max;          // max |v|; 0 if not known
+  const u64 *from_res, *from_max;   // non-null: the two values as the pass queued before this one leaves them in ITS results block (the host has not seen them yet)
 };
 struct SeriesStep;
 struct SeriesSlice;

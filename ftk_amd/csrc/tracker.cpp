@@ -179,6 +179,25 @@ void critical_point_tracker_regular::wait_devices() const
     multi->wait_all();
     multi->rethrow();
   }
+  while (!open_steps.empty()) collect_open_step();             // deferred collection: what is still out
+}
+
+// deferred collection: the oldest queued sweep -> its records, factor, running minimum and statistics, as update_timestep leaves them
+void critical_point_tracker_regular::collect_open_step() const
+{
+  critical_point_tracker_regular *self = const_cast<critical_point_tracker_regular *>(this);
+  const int t = open_steps.front();
+  open_steps.erase(open_steps.begin());
+  const ftkx_cp_t *recs = nullptr;
+  size_t n = 0;
+  unsigned long long f = 0;
+  double res = vector_field_resolution;
+  const int rc = ftkx_sweep_series_complete(ctx, &res, &f, &recs, &n);
+  if (rc != FTKX_OK) { open_steps.clear(); check(rc); }
+  self->vector_field_resolution = res;
+  self->vector_field_scaling_factor = f;
+  self->take_records(recs, n, t);
+  check(ftkx_get_stats(ctx, &self->last_stats));
 }
 
 void critical_point_tracker_regular::sync() const
@@ -428,6 +447,16 @@ void critical_point_tracker_regular::update_timestep()
     // newly arrived snapshot and runs while the host waits for the reduction)
     const ftkx_cp_t *recs = nullptr;
     size_t n = 0;
+    if (deferred_collection && !enable_streaming_trajectories && field_data_snapshots.size() <= 2 && field_data_snapshots.front() == current_timestep) {
+      // queue this step (continuing, on the device, from the running minimum of the step queued before it if that one is still out),
+      // then collect the step before it
+      const bool chained = !open_steps.empty();
+      check(ftkx_sweep_series_submit(ctx, &current_timestep, &scope, 1, chained ? nullptr : &vector_field_resolution));
+      open_steps.push_back(current_timestep);
+      if (open_steps.size() >= 2) collect_open_step();
+      return;
+    }
+    while (!open_steps.empty()) collect_open_step();
     if (field_data_snapshots.size() <= 2 && field_data_snapshots.front() == current_timestep) {
       // The device-driven pass (ftkx_sweep_series): the newly arrived snapshot's masks and reduction, the sticky factor (formed on the
       // device from the running minimum handed in), cull, exact test and records are queued at once and waited for once.
@@ -785,6 +814,7 @@ int ftkx_tracker_set_flags(ftkx_tracker *h, int robust, int use_tf, unsigned tf,
   });
 }
 int ftkx_tracker_set_stream(ftkx_tracker *h, void *s) { return guarded(h, [&] { h->t->set_stream(s); }); }
+int ftkx_tracker_set_deferred_collection(ftkx_tracker *h, int on) { return guarded(h, [&] { h->t->set_deferred_collection(on != 0); }); }
 int ftkx_tracker_set_enable_streaming_trajectories(ftkx_tracker *h, int on) { return guarded(h, [&] { h->t->set_enable_streaming_trajectories(on != 0); }); }
 int ftkx_tracker_set_current_timestep(ftkx_tracker *h, int t)
 { return guarded(h, [&] { if (t < 0) throw ftkx::ftkx_error(FTKX_E_INVALID, "set_current_timestep: negative timestep"); h->t->set_current_timestep(t); }); }

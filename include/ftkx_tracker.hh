@@ -134,6 +134,12 @@ public:
   // not in the reference: knobs of this implementation
   void set_exact_only(bool b) { exact_only = b; }          // never cull (every simplex takes the integer test)
   void set_tag_mode(int m) { tag_mode = m; }               // FTKX_TAG_REFERENCE (default) | FTKX_TAG_EXACT64
+  // Deferred collection (single-device trackers without streaming trajectories): update_timestep() QUEUES the step's sweep and
+  // collects the step before it -- the device works on step t + 1 (continuing on the device from step t's running minimum) while the
+  // host takes step t's records.  Same records, factors and statistics; they become visible one step later, and every accessor,
+  // sync() and finalize() collect what is still out first.  A snapshot pushed as a DEVICE pointer is borrowed, not copied: with this on
+  // it must stay valid until the step AFTER the one that pops it has been advanced (or sync() has been called).
+  void set_deferred_collection(bool b) { sync(); deferred_collection = b; }
   void set_stream(void *hip_stream);
 
   void initialize();                                        // regular_tracker.hh:105-149 (single rank: local == global)
@@ -194,6 +200,9 @@ protected:
   int scalar_field_source = SOURCE_NONE, vector_field_source = SOURCE_NONE, jacobian_field_source = SOURCE_NONE;
   bool is_jacobian_field_symmetric = false;
   bool enable_robust_detection = true, enable_computing_degrees = false, enable_streaming_trajectories = false;
+  bool deferred_collection = false;
+  mutable std::vector<int> open_steps;                      // deferred collection: the timesteps of the sweeps that are queued and not yet collected (at most two)
+  void collect_open_step() const;
   ftkx_online_tracer *online = nullptr;
   void grow();                                                 // 2d:288-322: trace_critical_points_online on the points found since the last call
   bool use_type_filter = false;
@@ -269,6 +278,7 @@ int  ftkx_tracker_set_sources(ftkx_tracker *, int scalar, int vector, int jacobi
 int  ftkx_tracker_set_flags(ftkx_tracker *, int robust, int use_type_filter, unsigned type_filter, int compute_degrees, int exact_only, int tag_mode);
 int  ftkx_tracker_set_stream(ftkx_tracker *, void *hip_stream);
 int  ftkx_tracker_set_current_timestep(ftkx_tracker *, int t);
+int  ftkx_tracker_set_deferred_collection(ftkx_tracker *, int on);   /* not in the reference: see critical_point_tracker_regular::set_deferred_collection */
 int  ftkx_tracker_set_enable_streaming_trajectories(ftkx_tracker *, int on);   /* critical_point_tracker.hh:38; before the first step */   /* tracker::set_current_timestep (filters/tracker.hh:40), before the first push */
 int  ftkx_tracker_set_coords_bounds(ftkx_tracker *, const double *bounds /* 2*nd values */);
 int  ftkx_tracker_set_coords_rectilinear(ftkx_tracker *, const double *x, size_t nx, const double *y, size_t ny, const double *z, size_t nz);

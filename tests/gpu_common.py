@@ -7,7 +7,7 @@ import ftk_amd
 
 def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=False, tag_mode=ftk_amd.TAG_REFERENCE, device=False,
                 compute_degrees=False, bounds=None, want_curves=False, after=None, rectilinear=None, explicit=None, t0=0, device_ids=None, block=2,
-                factor_each_step=True, streaming=False):
+                factor_each_step=True, streaming=False, deferred=False):
     """returns (records, ordinal, timestep, factors[DT], stats_list)"""
     import torch
     T = ftk_amd.CriticalPointTracker2DRegular if nd == 2 else ftk_amd.CriticalPointTracker3DRegular
@@ -38,6 +38,8 @@ def run_tracker(steps, nd, nv, *, robust=True, type_filter=None, exact_only=Fals
     if streaming:
         tr.set_enable_streaming_trajectories(True)
     tr.initialize()
+    if deferred:
+        tr.set_deferred_collection(True)
     if t0:
         tr.set_current_timestep(t0)
     DT = len(steps)

@@ -331,6 +331,28 @@ def test_pipelined_passes_equal_the_plain_ones(gpu, name):
     ctx.close()
 
 
+@pytest.mark.parametrize("each_step", [True, False], ids=["factor_read_each_step", "never_looked_at"])
+@pytest.mark.parametrize("name", ["woven_128x128x10", "woven_31x37x32", "double_gyre_64x32x50", "merger_2d_32x32x100", "moving_extremum_3d_21x21x21x32",
+                                  "adversarial_3d_scalar_9x9x9x4", "adversarial_3d_vector_8x8x8x3"])
+def test_tracker_with_deferred_collection(gpu, name, each_step):
+    """critical_point_tracker_regular with set_deferred_collection(True): every step's sweep is queued -- continuing on the device from the
+    running minimum of the step before it, whose records the host has not seen yet, and masking each snapshot once -- before the step before
+    it is collected.  Same records and factors as the fixture, whether the caller looks at the tracker after every step (which collects
+    what is out) or only at the end; device-resident snapshots."""
+    from gpu_common import run_tracker
+    g = load_golden(name)
+    if not _plain(g):
+        pytest.skip("physical coordinates are set on the tracker")
+    out = run_tracker(g["steps"], g["nd"], g["nv"], robust=g["robust"], type_filter=g["type_filter"], compute_degrees=g["degrees"],
+                      device=True, deferred=True, factor_each_step=each_step)
+    recs, factors = out[0], out[1]
+    if each_step:
+        assert np.array_equal(np.asarray(factors, dtype=np.uint64), g["factors"]), (factors, g["factors"])
+    else:
+        assert int(factors[-1]) == int(g["factors"][-1])
+    assert_records_equal(recs, g["records"], coord_tol=0.0, what=f"{name} deferred")
+
+
 def test_pipelined_records_through_the_copy_engine(gpu):
     """more than 4096 records per pass: from the second pipelined pass on the record kernel leaves them in device memory and the copy
     engine brings them over while the next pass runs; records and factors as ftkx_sweep_series returns them"""
