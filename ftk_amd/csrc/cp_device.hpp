@@ -102,19 +102,28 @@ template <int ND>
 FTKX_HD inline int sos_orientation(const u64 X[ND + 1][ND], const int id[ND + 1])
 {
   constexpr int n = ND + 1;
-  int key[n], ord[n];
-  for (int i = 0; i < n; i ++) { key[i] = id[i]; ord[i] = i; }
-  int swaps = 0;
-  for (int i = 0; i < n - 1; i ++)          // the reference's bubble sort; its swap count parity is what matters
-    for (int j = 0; j < n - i - 1; j ++)
-      if (key[j] > key[j + 1]) {
-        int t = key[j]; key[j] = key[j + 1]; key[j + 1] = t;
-        t = ord[j]; ord[j] = ord[j + 1]; ord[j + 1] = t;
-        swaps ++;
-      }
+  // the reference's bubble sort by vertex id (its swap count's parity is what matters), on the ROWS themselves with compile-time indices:
+  // sorting an index array and gathering the rows through it puts all of this into scratch memory on the device -- one cascade was 16 us
+  int key[n];
   u64 R[n][ND];
-  for (int i = 0; i < n; i ++)
-    for (int j = 0; j < ND; j ++) R[i][j] = X[ord[i]][j];
+#pragma unroll
+  for (int i = 0; i < n; i ++) {
+    key[i] = id[i];
+#pragma unroll
+    for (int j = 0; j < ND; j ++) R[i][j] = X[i][j];
+  }
+  int swaps = 0;
+#pragma unroll
+  for (int i = 0; i < n - 1; i ++)
+#pragma unroll
+    for (int j = 0; j < n - i - 1; j ++) {
+      const bool sw = key[j] > key[j + 1];
+      const int ka = key[j], kb = key[j + 1];
+      key[j] = sw ? kb : ka; key[j + 1] = sw ? ka : kb;
+#pragma unroll
+      for (int c = 0; c < ND; c ++) { const u64 a = R[j][c], b = R[j + 1][c]; R[j][c] = sw ? b : a; R[j + 1][c] = sw ? a : b; }
+      swaps += sw ? 1 : 0;
+    }
   int d;
   if constexpr (ND == 2) d = sos_sign3(R); else d = sos_sign4(R);
   return (swaps & 1) ? -d : d;
@@ -126,10 +135,13 @@ FTKX_HD inline bool sos_origin_in_simplex(const u64 X[ND + 1][ND], const int id[
 {
   constexpr int n = ND + 1;
   const int s = sos_orientation<ND>(X, id);
+#pragma unroll
   for (int i = 0; i < n; i ++) {
     u64 Y[n][ND]; int yid[n];
+#pragma unroll
     for (int j = 0; j < n; j ++) {
       yid[j] = (j == i) ? -1 : id[j];
+#pragma unroll
       for (int k = 0; k < ND; k ++) Y[j][k] = (j == i) ? 0ull : X[j][k];
     }
     if (sos_orientation<ND>(Y, yid) != s) return false;

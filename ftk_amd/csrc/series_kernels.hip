@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void series_record_kernel(const Mesh m, c
       u64 lin = q - step * m.core_cells;
       const Fields &f = fields[step];
       int corner[N];
-      for (int a = 0; a < ND; a ++) { corner[a] = m.core_st[a] + (int)(lin % (u64)m.core_sz[a]); lin /= (u64)m.core_sz[a]; }
+      core_corner<ND>(m, lin, corner);
       corner[ND] = f.t;
       u64 X[N][ND];
       int ids[N];
@@ -221,10 +221,24 @@ __global__ __launch_bounds__(kThreads) void series_record_kernel(const Mesh m, c
 // and the workgroup that finishes last puts the records in tag order while it copies them into the pinned host buffer, publishes the
 // results block, stores the flag the host waits for and raises CNT_SERIES_DONE, on which the kernels queued behind this one leave at
 // once.  With more survivors than that it changes nothing and leaves the pass to those kernels.
-constexpr int kSmallGrid = 256;                          // workgroups: one per CU (256 VGPRs -- 1024 wavefronts are resident at a time, and the launch costs
-                                                         // hit-dense passes, where it finds nothing to do, a round of dispatches per 256 workgroups)
+constexpr int kSmallGrid = 256;                          // workgroups: one per CU (256 VGPRs + 100 AGPRs: one wavefront per SIMD -- a second round of
+                                                         // workgroups would start when the first has finished)
 constexpr unsigned kSmallPer = 8;                        // coarse cells (two-level) per workgroup at most, dealt round-robin; without summaries: 8 x 32 corners
+                                                         // (dealt as single ROWS of coarse cells the refine phase took twice as long and the rest no less)
 constexpr unsigned kSmallRank = 1024;                    // records the last workgroup ranks in LDS (more: SERIES_UNORDERED, the host sorts)
+
+#ifdef FTKX_SMALL_STAMPS
+__device__ unsigned long long g_small_stamps[16];      // [0] earliest start (min), [k] the latest passage of phase boundary k (max)
+#define SMALL_STAMP(k) do { if (threadIdx.x == 0) atomicMax(&g_small_stamps[k], (unsigned long long)wall_clock64()); } while (0)
+extern "C" void ftkx_debug_small_stamps(unsigned long long *out, int reset)
+{
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_stamps), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16]; for (auto &x : z) x = 0; z[0] = ~0ull; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_small_stamps), z, sizeof(z)); }
+}
+#else
+#define SMALL_STAMP(k) do { } while (0)
+#endif
 
 template <int ND>
 __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, const Mesh mc, const Fields *__restrict__ steps, int two_level,
@@ -239,18 +253,24 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
   static_assert(G * NTYPES <= (int)PASS_CAP / 2, "a batch's worst case must fit twice");
   __shared__ u64 s_list[LIST_CAP];
   __shared__ u64 s_pass[PASS_CAP];                       // order keys of the simplices that passed; the last workgroup: all keys of the pass
-  __shared__ i64 s_vf[G][NVC][ND];
-  __shared__ unsigned char s_flag[G][NVC];
+  constexpr int SUB = 4;                                 // rounds of G corners staged together
+  __shared__ i64 s_vf[SUB * G][NVC][ND];
+  __shared__ unsigned char s_flag[SUB * G][NVC];
   __shared__ unsigned s_tab[NTYPES];
-  __shared__ unsigned s_nlist, s_npass, s_tested, s_last;
+  __shared__ unsigned short s_deg[G * NTYPES];           // (corner of the round, type) of the simplices with a degenerate value
+  __shared__ unsigned s_nlist, s_npass, s_tested, s_last, s_ndeg;
   __shared__ u64 s_base;
   const int tid = threadIdx.x;
+#ifdef FTKX_SMALL_STAMPS
+  if (tid == 0) atomicMin(&g_small_stamps[0], (unsigned long long)wall_clock64());
+#endif
   const fan_table<N> &fan = dev_fan<ND>();
   const u64 redo = (u64)(SERIES_AMBIGUOUS | SERIES_MASKS_INVALID | SERIES_INF);
   const u64 count = m.counters[two_level ? CNT_REFINE_LIST : CNT_SURVIVOR_LIST];
   const u64 per = two_level ? (u64)kSmallPer : (u64)LIST_CAP;
+  const u64 units = count;
   const bool is_redo = (results[SR_STATUS] & redo) != 0;  // the host takes this pass over anyway
-  if (is_redo || count > per * (u64)kSmallGrid) {         // (the same for every workgroup) too much for this kernel: nothing has been changed
+  if (is_redo || units > per * (u64)kSmallGrid) {         // (the same for every workgroup) too much for this kernel: nothing has been changed
     if (report_decline && blockIdx.x == 0) {
       for (size_t i = tid; i < nwords; i += kThreads) h_results[i] = (i == (size_t)SR_STATUS && !is_redo) ? (results[i] | (u64)SERIES_TAIL_PENDING) : results[i];
       __threadfence_system();
@@ -259,17 +279,18 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
     }
     return;
   }
-  const unsigned nwork = count ? (count < (u64)kSmallGrid ? (unsigned)count : (unsigned)kSmallGrid) : 1u;   // workgroups that take part (workgroup 0 always does: somebody must finish)
+  const unsigned nwork = units ? (units < (u64)kSmallGrid ? (unsigned)units : (unsigned)kSmallGrid) : 1u;   // workgroups that take part (workgroup 0 always does: somebody must finish)
   if (blockIdx.x >= nwork) return;
-  if (tid == 0) { s_nlist = 0; s_npass = 0; s_tested = 0; }
+  if (tid == 0) { s_nlist = 0; s_npass = 0; s_tested = 0; s_ndeg = 0; }
   if (tid < NTYPES) {
     unsigned w = 0;
     for (int i = 0; i < N; i ++) w |= (unsigned)fan.vert[tid][i] << (8 * i);
     s_tab[tid] = w;
   }
   __syncthreads();
-  // this workgroup's entries: blockIdx.x, + kSmallGrid, + 2 kSmallGrid, ... (at most `per` of them)
-  const u64 mine_n = count > (u64)blockIdx.x ? (count - 1 - (u64)blockIdx.x) / (u64)kSmallGrid + 1 : 0ull;
+  SMALL_STAMP(1);
+  // this workgroup's units: blockIdx.x, + kSmallGrid, + 2 kSmallGrid, ... (at most `per` of them)
+  const u64 mine_n = units > (u64)blockIdx.x ? (units - 1 - (u64)blockIdx.x) / (u64)kSmallGrid + 1 : 0ull;
 
   // ---- refine (the second level of the cull, as refine_kernel does it): this workgroup's coarse cells, one lane per row of a cell ----
   if (two_level) {
@@ -352,6 +373,7 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
     if (tid == 0) s_nlist = (unsigned)mine_n;
   }
   __syncthreads();
+  SMALL_STAMP(2);
   const unsigned nlist = s_nlist;
 
   // records of the simplices parked in s_pass: appended to the device hit buffer (unordered; their order keys next to them in m.pass)
@@ -367,7 +389,7 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
       u64 lin = q - step * m.core_cells;
       const Fields &f = steps[step];
       int corner[N];
-      for (int a = 0; a < ND; a ++) { corner[a] = m.core_st[a] + (int)(lin % (u64)m.core_sz[a]); lin /= (u64)m.core_sz[a]; }
+      core_corner<ND>(m, lin, corner);
       corner[ND] = f.t;
       u64 X[N][ND];
       int ids[N];
@@ -404,59 +426,149 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
   };
 
   // ---- exact test (as exact_kernel does it: one lane per hypercube vertex while staging, then (corner, type) pairs over all lanes) ----
+  // Staging is a chain of two memory round trips (the step's descriptor, then the field values) and a workgroup has the CU to itself: the
+  // vertices of SUB x G corners are fetched in one go -- descriptors of all of them, then field values of all of them, then the
+  // arithmetic -- instead of G corners per round trip pair (the cell-richest workgroup of 256^3 x 16 walked four of those: 32 of the
+  // kernel's 63 us).  The test itself still goes G corners at a time, so that s_pass can be emptied in between.
   unsigned tested = 0;
   bool narrow = false;
-  for (unsigned base = 0; base < nlist; base += G) {
-    __syncthreads();
-    if (s_npass > PASS_CAP - G * NTYPES) flush_records();   // (workgroup-uniform: s_npass was final at the barrier above)
+  for (unsigned base = 0; base < nlist; base += SUB * G) {
+    __syncthreads();                                     // (the staged vertices of the previous round are no longer read)
     {
-      const int gi = tid / NVC, vtx = tid % NVC;
-      const u64 e = base + gi < nlist ? s_list[base + gi] : ~0ull;
-      i64 q[ND];
-      unsigned char fl = kInvalid;
-      for (int c = 0; c < ND; c ++) q[c] = 0;
-      if (e != ~0ull) {
-        const Fields &f = steps[e >> 44];
-        u64 lin = e & 0xffffffffffull;
-        int vx[3] = {0, 0, 0};
-        for (int d = 0; d < ND; d ++) { vx[d] = m.core_st[d] + (int)(lin % (u64)m.core_sz[d]) + ((vtx >> d) & 1); lin /= (u64)m.core_sz[d]; }
-        const int sl = (vtx >> ND) & 1;
-        if (sl == 0 || (f.scope_mask & FTKX_SCOPE_INTERVAL)) fl = classify_vertex<ND>(m, f.S[sl], f.V[sl], f.factor, vx, q);
+      const int vtx = tid % NVC, sl = (vtx >> ND) & 1;
+      u64 ent[SUB];
+      const double *pS[SUB], *pV[SUB];
+      double factor[SUB];
+      bool live[SUB];
+#pragma unroll
+      for (int r = 0; r < SUB; r ++) {                   // descriptors
+        const unsigned gi = (unsigned)r * G + (unsigned)(tid / NVC);
+        ent[r] = base + gi < nlist ? s_list[base + gi] : ~0ull;
+        live[r] = false; pS[r] = nullptr; pV[r] = nullptr; factor[r] = 0.0;
+        if (ent[r] != ~0ull) {
+          const Fields &f = steps[ent[r] >> 44];
+          live[r] = sl == 0 || (f.scope_mask & FTKX_SCOPE_INTERVAL);
+          pS[r] = f.S[sl]; pV[r] = f.V[sl]; factor[r] = f.factor;
+        }
       }
-      s_flag[gi][vtx] = fl;
+      double raw[SUB][6];
+      int vxs[SUB][3];
+      bool usable[SUB], inner[SUB];
+#pragma unroll
+      for (int r = 0; r < SUB; r ++) {                   // field values: every load of the round in flight before the first is used
+        for (int k = 0; k < 6; k ++) raw[r][k] = 0.0;
+        for (int d = 0; d < 3; d ++) vxs[r][d] = 0;
+        core_corner<ND>(m, ent[r] & 0xffffffffffull, vxs[r]);
+        for (int d = 0; d < ND; d ++) vxs[r][d] += (vtx >> d) & 1;
+        usable[r] = live[r] && vertex_usable<ND>(m, vxs[r]);
+        inner[r] = false;
+        if (usable[r]) {
+          const int i = vxs[r][0] - m.ext_st[0], j = vxs[r][1] - m.ext_st[1], k = ND == 3 ? vxs[r][2] - m.ext_st[2] : 0;
+          const int DW = m.ext_sz[0], DH = m.ext_sz[1];
+          if (!m.scalar_mode) {
+            const size_t at = arr_index<ND>(m, i, j, k) * ND;
+            for (int c = 0; c < ND; c ++) raw[r][c] = pV[r][at + c];
+          } else if constexpr (ND == 2) {                // gradient2D (grad.hh:17-28): clamped indices
+            const int ip = clampi(i + 1, 0, DW - 1), im = clampi(i - 1, 0, DW - 1), jp = clampi(j + 1, 0, DH - 1), jm = clampi(j - 1, 0, DH - 1);
+            const int ic = clampi(i, 0, DW - 1), jc = clampi(j, 0, DH - 1);
+            raw[r][0] = pS[r][(size_t)ip + (size_t)DW * jc]; raw[r][1] = pS[r][(size_t)im + (size_t)DW * jc];
+            raw[r][2] = pS[r][(size_t)ic + (size_t)DW * jp]; raw[r][3] = pS[r][(size_t)ic + (size_t)DW * jm];
+          } else {                                       // gradient3D (grad.hh:138-146): interior vertices only
+            const int DD = m.ext_sz[2];
+            inner[r] = i >= 1 && i < DW - 1 && j >= 1 && j < DH - 1 && k >= 1 && k < DD - 1;
+            if (inner[r]) {
+              const size_t sy = (size_t)DW, sz = (size_t)DW * DH, c = (size_t)i + sy * j + sz * k;
+              raw[r][0] = pS[r][c + 1]; raw[r][1] = pS[r][c - 1]; raw[r][2] = pS[r][c + sy]; raw[r][3] = pS[r][c - sy]; raw[r][4] = pS[r][c + sz]; raw[r][5] = pS[r][c - sz];
+            }
+          }
+        }
+      }
       bool mine_narrow = true;
-      for (int c = 0; c < ND; c ++) { s_vf[gi][vtx][c] = q[c]; mine_narrow = mine_narrow && fits_s32(q[c]); }
+#pragma unroll
+      for (int r = 0; r < SUB; r ++) {                   // the same operations as vector_at / gradient_at on the same values, then classify_vertex's
+        const unsigned gi = (unsigned)r * G + (unsigned)(tid / NVC);
+        i64 q[ND];
+        for (int c = 0; c < ND; c ++) q[c] = 0;
+        unsigned char fl = kInvalid;
+        if (usable[r]) {
+          double v[ND];
+          if (!m.scalar_mode) { for (int c = 0; c < ND; c ++) v[c] = raw[r][c]; }
+          else if constexpr (ND == 2) { v[0] = (raw[r][0] - raw[r][1]) * (double)(m.ext_sz[0] - 1); v[1] = (raw[r][2] - raw[r][3]) * (double)(m.ext_sz[1] - 1); }
+          else {
+            if (inner[r]) { v[0] = 0.5 * (raw[r][0] - raw[r][1]); v[1] = 0.5 * (raw[r][2] - raw[r][3]); v[2] = 0.5 * (raw[r][4] - raw[r][5]); }
+            else { v[0] = 0.0; v[1] = 0.0; v[2] = 0.0; }
+          }
+          fl = classify_value<ND>(v, factor[r], q);
+        }
+        s_flag[gi][vtx] = fl;
+        for (int c = 0; c < ND; c ++) { s_vf[gi][vtx][c] = q[c]; mine_narrow = mine_narrow && fits_s32(q[c]); }
+      }
       narrow = __syncthreads_and(mine_narrow) != 0;
     }
-    for (int wb = 0; wb < G * NTYPES; wb += kThreads) {
-      const int w = wb + tid;
-      if (w >= G * NTYPES) continue;
-      const int gi = w / NTYPES, type = w % NTYPES;
-      if (base + gi >= nlist) continue;
-      const u64 e = s_list[base + gi];
-      const unsigned scope_flags = (unsigned)((e >> 40) & 3);
-      const bool wanted = fan.ordinal[type] ? (scope_flags & 1) : (scope_flags & 2);
-      if (!wanted) continue;
-      const Fields &f = steps[e >> 44];
-      u64 lin = e & 0xffffffffffull;
-      int corner[N];
-      for (int d = 0; d < ND; d ++) { corner[d] = m.core_st[d] + (int)(lin % (u64)m.core_sz[d]); lin /= (u64)m.core_sz[d]; }
-      corner[ND] = f.t;
-      const unsigned tab = s_tab[type];
-      unsigned char flags[N];
-      u64 X[N][ND];
-      for (int i = 0; i < N; i ++) {
-        const unsigned vm = (tab >> (8 * i)) & 0xffu;
-        flags[i] = s_flag[gi][vm];
-        for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[gi][vm][c];
+    SMALL_STAMP(10);
+    for (unsigned sub = 0; sub < (unsigned)SUB && base + sub * G < nlist; sub ++) {
+      if (sub) __syncthreads();
+      if (s_npass > PASS_CAP - G * NTYPES) flush_records();   // (workgroup-uniform: s_npass was final at the barrier above)
+      const unsigned sbase = base + sub * G;
+      for (int wb = 0; wb < G * NTYPES; wb += kThreads) {
+        const int w = wb + tid;
+        if (w >= G * NTYPES) continue;
+        const int gi = w / NTYPES, type = w % NTYPES;
+        if (sbase + gi >= nlist) continue;
+        const u64 e = s_list[sbase + gi];
+        const unsigned scope_flags = (unsigned)((e >> 40) & 3);
+        const bool wanted = fan.ordinal[type] ? (scope_flags & 1) : (scope_flags & 2);
+        if (!wanted) continue;
+        const Fields &f = steps[e >> 44];
+        int corner[N];
+        core_corner<ND>(m, e & 0xffffffffffull, corner);
+        corner[ND] = f.t;
+        const unsigned tab = s_tab[type];
+        unsigned char flags[N];
+        u64 X[N][ND];
+        for (int i = 0; i < N; i ++) {
+          const unsigned vm = (tab >> (8 * i)) & 0xffu;
+          flags[i] = s_flag[sub * G + gi][vm];
+          for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[sub * G + gi][vm][c];
+        }
+        int ids[N]; double mu[N]; bool presolved, degenerate = false;
+        if (simplex_inside<ND>(m, f, 1, corner, tab, flags, X, tested, ids, mu, &presolved, narrow, &degenerate))
+          s_pass[atomicAdd(&s_npass, 1u)] = order_key((e & kPassLinMask) | ((u64)type << kPassTypeShift) | ((e >> 44) << kPassStepShift), m.core_cells);
+        if (degenerate) s_deg[atomicAdd(&s_ndeg, 1u)] = (unsigned short)((gi << 6) | type);   // (G * NTYPES entries at most: fits)
       }
-      int ids[N]; double mu[N]; bool presolved;
-      if (simplex_inside<ND>(m, f, 1, corner, tab, flags, X, tested, ids, mu, &presolved, narrow))
-        s_pass[atomicAdd(&s_npass, 1u)] = order_key((e & kPassLinMask) | ((u64)type << kPassTypeShift) | ((e >> 44) << kPassStepShift), m.core_cells);
+      SMALL_STAMP(11);
+      // A degenerate value takes the literal cascade -- thousands of instructions.  In line it held its wavefront in every one of the
+      // loop's rounds that had one (the bowl of moving_extremum has them everywhere: 28 of this kernel's 63 us on 256^3 x 16); listed
+      // and dealt over all lanes they all run at once.
+      __syncthreads();
+      const unsigned ndeg = s_ndeg;
+      for (unsigned it = tid; it < ndeg; it += kThreads) {
+        const unsigned item = s_deg[it];
+        const int gi = (int)(item >> 6), type = (int)(item & 63u);
+        const u64 e = s_list[sbase + gi];
+        const Fields &f = steps[e >> 44];
+        int corner[N];
+        core_corner<ND>(m, e & 0xffffffffffull, corner);
+        corner[ND] = f.t;
+        const unsigned tab = s_tab[type];
+        u64 X[N][ND];
+        int ids[N];
+        for (int i = 0; i < N; i ++) {
+          const unsigned vm = (tab >> (8 * i)) & 0xffu;
+          for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[sub * G + gi][vm][c];
+          ids[i] = vertex_id<ND>(m, corner, vm);
+        }
+        if (sos_origin_in_simplex<ND>(X, ids))
+          s_pass[atomicAdd(&s_npass, 1u)] = order_key((e & kPassLinMask) | ((u64)type << kPassTypeShift) | ((e >> 44) << kPassStepShift), m.core_cells);
+      }
+      __syncthreads();
+      if (tid == 0) s_ndeg = 0;
     }
   }
   __syncthreads();
+  SMALL_STAMP(3);
   if (s_npass) flush_records();                          // (workgroup-uniform)
+  SMALL_STAMP(4);
   {
     unsigned t_sum = tested;
     for (int o = 32; o > 0; o >>= 1) t_sum += __shfl_down(t_sum, o);
@@ -473,8 +585,10 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
   __syncthreads();
   if (tid == 0) s_last = atomicAdd(done, 1u) == nwork - 1u ? 1u : 0u;
   __syncthreads();
+  SMALL_STAMP(5);
   if (!s_last) return;
   __threadfence();
+  SMALL_STAMP(6);
   const u64 nrec_all = m.counters[CNT_HITS], nfrag = m.counters[CNT_FRAGILE];
   const bool over = nrec_all > m.capacity || nfrag > m.fragile_capacity;
   const u64 nrec = over ? 0ull : nrec_all;
@@ -492,6 +606,7 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
     }
     __syncthreads();
   }
+  SMALL_STAMP(7);
   for (u64 w = tid; w < nrec * 9; w += kThreads) {                       // nine consecutive lanes move one record
     const u64 i = w / 9, k = w - i * 9;
     const u64 at = ranked ? (u64)s_rank[i] : i;
@@ -518,8 +633,10 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
     }
     h_results[i] = v;
   }
+  SMALL_STAMP(8);
   __threadfence_system();
   __syncthreads();
+  SMALL_STAMP(9);
   if (tid == 0) {
     m.counters[CNT_SERIES_DONE] = 1ull;                  // the kernels queued behind this one leave at once
     __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

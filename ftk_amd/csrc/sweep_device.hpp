@@ -119,6 +119,20 @@ __device__ inline bool vertex_usable(const Mesh &m, const int *vx)
   return ok;
 }
 
+// a linear index over the core's corners (x fastest) -> the corner.  Cores below 2^32 corners: 32-bit division (a 64-bit one by a run-time
+// value is ~100 instructions, three per corner)
+template <int ND>
+__device__ inline void core_corner(const Mesh &m, u64 lin, int *corner)
+{
+  u64 cells = 1;
+  for (int d = 0; d < ND; d ++) cells *= (u64)m.core_sz[d];
+  if (lin < (1ull << 32) && cells < (1ull << 32)) {
+    unsigned l = (unsigned)lin;
+    for (int d = 0; d < ND; d ++) { const unsigned sz = (unsigned)m.core_sz[d], q = l / sz; corner[d] = m.core_st[d] + (int)(l - q * sz); l = q; }
+  } else
+    for (int d = 0; d < ND; d ++) { corner[d] = m.core_st[d] + (int)(lin % (u64)m.core_sz[d]); lin /= (u64)m.core_sz[d]; }
+}
+
 // quantised vertex + classification byte (bits 0..2 strictly positive, 3..5 strictly negative, kNonFinite, kInvalid)
 template <int ND>
 __device__ inline unsigned char classify_value(const double *v, double factor, i64 q[ND])
@@ -394,7 +408,8 @@ __device__ __noinline__ bool make_record_general(const Mesh &m, const Fields &f,
 // narrow: every quantised component the caller staged fits in 32 bits (checked while staging: fits_s32) -- the cheaper multiplies apply
 template <int ND>
 __device__ inline bool simplex_inside(const Mesh &m, const Fields &f, int cull, const int *corner, unsigned tab,
-                                      const unsigned char *flags, const u64 (*X)[ND], unsigned &tested, int *ids, double *mu, bool *presolved, bool narrow = false)
+                                      const unsigned char *flags, const u64 (*X)[ND], unsigned &tested, int *ids, double *mu, bool *presolved, bool narrow = false,
+                                      bool *degenerate = nullptr /* non-null: a degenerate value is reported instead of taken through the cascade here */)
 {
   constexpr int N = ND + 1;
   unsigned m_and = 0x3f, m_or = 0;
@@ -420,6 +435,7 @@ __device__ inline bool simplex_inside(const Mesh &m, const Fields &f, int cull, 
   int r;
   if constexpr (ND == 2) r = origin_in_simplex2_try(X, narrow); else r = origin_in_simplex3_try(X, narrow);
   if (r >= 0) return r != 0;
+  if (degenerate) { *degenerate = true; return false; }
   for (int i = 0; i < N; i ++) ids[i] = vertex_id<ND>(m, corner, (tab >> (8 * i)) & 0xffu);
   return sos_origin_in_simplex<ND>(X, ids);
 }

@@ -1991,7 +1991,8 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
         const Fields &f = steps[e >> 44];
         u64 lin = e & 0xffffffffffull;
         int vx[3] = {0, 0, 0};
-        for (int d = 0; d < ND; d ++) { vx[d] = m.core_st[d] + (int)(lin % (u64)m.core_sz[d]) + ((vtx >> d) & 1); lin /= (u64)m.core_sz[d]; }
+        core_corner<ND>(m, lin, vx);
+        for (int d = 0; d < ND; d ++) vx[d] += (vtx >> d) & 1;
         const int sl = (vtx >> ND) & 1;
         if (sl == 0 || (f.scope_mask & FTKX_SCOPE_INTERVAL)) fl = classify_vertex<ND>(m, f.S[sl], f.V[sl], f.factor, vx, q);
       }
@@ -2013,7 +2014,7 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
           const Fields &f = steps[e >> 44];
           u64 lin = e & 0xffffffffffull;
           int corner[N];
-          for (int d = 0; d < ND; d ++) { corner[d] = m.core_st[d] + (int)(lin % (u64)m.core_sz[d]); lin /= (u64)m.core_sz[d]; }
+          core_corner<ND>(m, lin, corner);
           corner[ND] = f.t;
           const unsigned tab = s_tab[type];
           unsigned char flags[N];
@@ -2065,7 +2066,7 @@ __global__ __launch_bounds__(kThreads) void record_kernel(const Mesh m, const Fi
       const int type = (int)((d >> kPassTypeShift) & 63u);
       u64 lin = d & kPassLinMask;
       int corner[N];
-      for (int a = 0; a < ND; a ++) { corner[a] = m.core_st[a] + (int)(lin % (u64)m.core_sz[a]); lin /= (u64)m.core_sz[a]; }
+      core_corner<ND>(m, lin, corner);
       corner[ND] = f.t;
       u64 X[N][ND];
       int ids[N];
