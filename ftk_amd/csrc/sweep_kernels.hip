@@ -1929,9 +1929,10 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
   constexpr int NVC = 1 << N;                 // vertices of a corner's space-time hypercube
   constexpr int G = kThreads / NVC;           // corners per chunk: one lane per hypercube vertex while staging
   constexpr int NTYPES = fan_table<N>::NTYPES;
-  __shared__ i64 s_vf[G][NVC][ND];
-  __shared__ unsigned char s_flag[G][NVC];
-  __shared__ u64 s_entry[G];
+  constexpr int SUB = 4;                      // rounds of G corners staged together
+  __shared__ i64 s_vf[SUB * G][NVC][ND];
+  __shared__ unsigned char s_flag[SUB * G][NVC];
+  __shared__ u64 s_entry[SUB * G];
   __shared__ unsigned s_tab[NTYPES];
   // descriptors of the (corner, type) pairs that passed the predicate, parked in LDS across chunks: the counter behind m.pass is ONE
   // address for the whole device (a same-address atomic costs ~5 ns of serialised L2 time: one per chunk was a quarter of this
@@ -1951,7 +1952,7 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
     atomicAdd(&m.counters[CNT_CELLS_SURVIVED], count);
   }
   if (count > list_capacity) count = list_capacity;     // overflow: the host grows the list and replays the batch
-  if ((u64)blockIdx.x * G >= count) return;             // nothing for this workgroup: leave before touching LDS or scratch
+  if ((u64)blockIdx.x * (SUB * G) >= count) return;     // nothing for this workgroup: leave before touching LDS or scratch
   if (tid < NTYPES) {
     unsigned w = 0;
     for (int i = 0; i < N; i ++) w |= (unsigned)fan.vert[tid][i] << (8 * i);
@@ -1975,58 +1976,113 @@ __global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fie
     if (tid == 0) s_nout = 0;
   };
 
+  // Staging is a chain of dependent memory round trips (list entry, the step's descriptor, the field values) with barriers in between:
+  // SUB x G corners are fetched per chain instead of G (woven 1024^2 x 64: 5.5 chains per workgroup -> 1.4).  The test itself goes G
+  // corners at a time, so that s_out can be emptied in between.
   bool narrow = false;
-  for (u64 chunk = blockIdx.x; chunk * G < count; chunk += gridDim.x) {
+  for (u64 chunk = blockIdx.x; chunk * (SUB * G) < count; chunk += gridDim.x) {
     __syncthreads();                                    // previous chunk's LDS readers are done
-    if (s_nout > OUT_CAP - G * NTYPES) flush();         // (workgroup-uniform: s_nout was final at the barrier above)
-    if (tid < G) s_entry[tid] = (chunk * G + tid < count) ? list[chunk * G + tid] : ~0ull;
+    if (tid < SUB * G) s_entry[tid] = (chunk * (SUB * G) + tid < count) ? list[chunk * (SUB * G) + tid] : ~0ull;
     __syncthreads();
     {
-      const int gi = tid / NVC, vtx = tid % NVC;
-      const u64 e = s_entry[gi];
-      i64 q[ND];
-      unsigned char fl = kInvalid;
-      for (int c = 0; c < ND; c ++) q[c] = 0;
-      if (e != ~0ull) {
-        const Fields &f = steps[e >> 44];
-        u64 lin = e & 0xffffffffffull;
-        int vx[3] = {0, 0, 0};
-        core_corner<ND>(m, lin, vx);
-        for (int d = 0; d < ND; d ++) vx[d] += (vtx >> d) & 1;
-        const int sl = (vtx >> ND) & 1;
-        if (sl == 0 || (f.scope_mask & FTKX_SCOPE_INTERVAL)) fl = classify_vertex<ND>(m, f.S[sl], f.V[sl], f.factor, vx, q);
+      const int vtx = tid % NVC, sl = (vtx >> ND) & 1;
+      u64 ent[SUB];
+      const double *pS[SUB], *pV[SUB];
+      double factor[SUB];
+      bool live[SUB];
+#pragma unroll
+      for (int r = 0; r < SUB; r ++) {                  // descriptors
+        ent[r] = s_entry[r * G + tid / NVC];
+        live[r] = false; pS[r] = nullptr; pV[r] = nullptr; factor[r] = 0.0;
+        if (ent[r] != ~0ull) {
+          const Fields &f = steps[ent[r] >> 44];
+          live[r] = sl == 0 || (f.scope_mask & FTKX_SCOPE_INTERVAL);
+          pS[r] = f.S[sl]; pV[r] = f.V[sl]; factor[r] = f.factor;
+        }
       }
-      s_flag[gi][vtx] = fl;
+      double raw[SUB][6];
+      int vxs[SUB][3];
+      bool usable[SUB], inner[SUB];
+#pragma unroll
+      for (int r = 0; r < SUB; r ++) {                  // field values: every load of the round in flight before the first is used
+        for (int k = 0; k < 6; k ++) raw[r][k] = 0.0;
+        for (int d = 0; d < 3; d ++) vxs[r][d] = 0;
+        core_corner<ND>(m, ent[r] & 0xffffffffffull, vxs[r]);
+        for (int d = 0; d < ND; d ++) vxs[r][d] += (vtx >> d) & 1;
+        usable[r] = live[r] && vertex_usable<ND>(m, vxs[r]);
+        inner[r] = false;
+        if (usable[r]) {
+          const int i = vxs[r][0] - m.ext_st[0], j = vxs[r][1] - m.ext_st[1], k = ND == 3 ? vxs[r][2] - m.ext_st[2] : 0;
+          const int DW = m.ext_sz[0], DH = m.ext_sz[1];
+          if (!m.scalar_mode) {
+            const size_t at = arr_index<ND>(m, i, j, k) * ND;
+            for (int c = 0; c < ND; c ++) raw[r][c] = pV[r][at + c];
+          } else if constexpr (ND == 2) {               // gradient2D (grad.hh:17-28): clamped indices
+            const int ip = clampi(i + 1, 0, DW - 1), im = clampi(i - 1, 0, DW - 1), jp = clampi(j + 1, 0, DH - 1), jm = clampi(j - 1, 0, DH - 1);
+            const int ic = clampi(i, 0, DW - 1), jc = clampi(j, 0, DH - 1);
+            raw[r][0] = pS[r][(size_t)ip + (size_t)DW * jc]; raw[r][1] = pS[r][(size_t)im + (size_t)DW * jc];
+            raw[r][2] = pS[r][(size_t)ic + (size_t)DW * jp]; raw[r][3] = pS[r][(size_t)ic + (size_t)DW * jm];
+          } else {                                      // gradient3D (grad.hh:138-146): interior vertices only
+            const int DD = m.ext_sz[2];
+            inner[r] = i >= 1 && i < DW - 1 && j >= 1 && j < DH - 1 && k >= 1 && k < DD - 1;
+            if (inner[r]) {
+              const size_t sy = (size_t)DW, sz = (size_t)DW * DH, c = (size_t)i + sy * j + sz * k;
+              raw[r][0] = pS[r][c + 1]; raw[r][1] = pS[r][c - 1]; raw[r][2] = pS[r][c + sy]; raw[r][3] = pS[r][c - sy]; raw[r][4] = pS[r][c + sz]; raw[r][5] = pS[r][c - sz];
+            }
+          }
+        }
+      }
       bool mine_narrow = true;
-      for (int c = 0; c < ND; c ++) { s_vf[gi][vtx][c] = q[c]; mine_narrow = mine_narrow && fits_s32(q[c]); }
+#pragma unroll
+      for (int r = 0; r < SUB; r ++) {                  // the same operations as vector_at / gradient_at on the same values, then classify_vertex's
+        const int gi = r * G + tid / NVC;
+        i64 q[ND];
+        for (int c = 0; c < ND; c ++) q[c] = 0;
+        unsigned char fl = kInvalid;
+        if (usable[r]) {
+          double v[ND];
+          if (!m.scalar_mode) { for (int c = 0; c < ND; c ++) v[c] = raw[r][c]; }
+          else if constexpr (ND == 2) { v[0] = (raw[r][0] - raw[r][1]) * (double)(m.ext_sz[0] - 1); v[1] = (raw[r][2] - raw[r][3]) * (double)(m.ext_sz[1] - 1); }
+          else {
+            if (inner[r]) { v[0] = 0.5 * (raw[r][0] - raw[r][1]); v[1] = 0.5 * (raw[r][2] - raw[r][3]); v[2] = 0.5 * (raw[r][4] - raw[r][5]); }
+            else { v[0] = 0.0; v[1] = 0.0; v[2] = 0.0; }
+          }
+          fl = classify_value<ND>(v, factor[r], q);
+        }
+        s_flag[gi][vtx] = fl;
+        for (int c = 0; c < ND; c ++) { s_vf[gi][vtx][c] = q[c]; mine_narrow = mine_narrow && fits_s32(q[c]); }
+      }
       narrow = __syncthreads_and(mine_narrow) != 0;       // (the barrier between staging and testing, with the chunk's "fits in 32 bits" on it)
     }
     // (corner, type) pairs over all lanes; the few that pass go to record_kernel, whose expensive FP64 record construction then
     // runs on densely packed lanes instead of one or two lanes per wavefront
-    for (int base = 0; base < G * NTYPES; base += kThreads) {
-      const int w = base + tid;
-      if (w < G * NTYPES) {
-        const int gi = w / NTYPES, type = w % NTYPES;
-        const u64 e = s_entry[gi];
-        const unsigned scope_flags = (e == ~0ull) ? 0u : (unsigned)((e >> 40) & 3);
-        const bool wanted = fan.ordinal[type] ? (scope_flags & 1) : (scope_flags & 2);
-        if (wanted) {
-          const Fields &f = steps[e >> 44];
-          u64 lin = e & 0xffffffffffull;
-          int corner[N];
-          core_corner<ND>(m, lin, corner);
-          corner[ND] = f.t;
-          const unsigned tab = s_tab[type];
-          unsigned char flags[N];
-          u64 X[N][ND];
-          for (int i = 0; i < N; i ++) {
-            const unsigned vm = (tab >> (8 * i)) & 0xffu;   // the axis bitmask IS the hypercube vertex index
-            flags[i] = s_flag[gi][vm];
-            for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[gi][vm][c];
+    for (int sub = 0; sub < SUB && (chunk * SUB + (u64)sub) * G < count; sub ++) {
+      if (sub) __syncthreads();
+      if (s_nout > OUT_CAP - G * NTYPES) flush();       // (workgroup-uniform: s_nout was final at the barrier above)
+      for (int base = 0; base < G * NTYPES; base += kThreads) {
+        const int w = base + tid;
+        if (w < G * NTYPES) {
+          const int gi = sub * G + w / NTYPES, type = w % NTYPES;
+          const u64 e = s_entry[gi];
+          const unsigned scope_flags = (e == ~0ull) ? 0u : (unsigned)((e >> 40) & 3);
+          const bool wanted = fan.ordinal[type] ? (scope_flags & 1) : (scope_flags & 2);
+          if (wanted) {
+            const Fields &f = steps[e >> 44];
+            int corner[N];
+            core_corner<ND>(m, e & 0xffffffffffull, corner);
+            corner[ND] = f.t;
+            const unsigned tab = s_tab[type];
+            unsigned char flags[N];
+            u64 X[N][ND];
+            for (int i = 0; i < N; i ++) {
+              const unsigned vm = (tab >> (8 * i)) & 0xffu;   // the axis bitmask IS the hypercube vertex index
+              flags[i] = s_flag[gi][vm];
+              for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[gi][vm][c];
+            }
+            int ids[N]; double mu[N]; bool presolved;
+            if (simplex_inside<ND>(m, f, 1, corner, tab, flags, X, tested, ids, mu, &presolved, narrow))
+              s_out[atomicAdd(&s_nout, 1u)] = (e & kPassLinMask) | ((u64)type << kPassTypeShift) | ((u64)(step_base + (int)(e >> 44)) << kPassStepShift);
           }
-          int ids[N]; double mu[N]; bool presolved;
-          if (simplex_inside<ND>(m, f, 1, corner, tab, flags, X, tested, ids, mu, &presolved, narrow))
-            s_out[atomicAdd(&s_nout, 1u)] = (e & kPassLinMask) | ((u64)type << kPassTypeShift) | ((u64)(step_base + (int)(e >> 44)) << kPassStepShift);
         }
       }
     }
