@@ -211,7 +211,7 @@ int ftkx_sweep_series(ftkx_ctx *ctx, const int *timesteps, const int *scopes, in
  * running_resolution of _submit: the running minimum before this pass, or NULL = continue from the pass queued before it, still open
  * (the minimum is handed on ON THE DEVICE; _complete then reports the chained value).  Between _submit and _complete only slices may be
  * pushed or dropped and further passes submitted; the sweeps above and ftkx_slices_prepare fail until every open pass is complete.
- * Records of a pass: valid until the second _submit after its _complete.  Results are those of ftkx_sweep_series on the same steps:
+ * Records of a pass: valid until the next _submit (or any other sweep call) after its _complete -- that pass takes over its buffers.  Results are those of ftkx_sweep_series on the same steps:
  * tests/test_gpu_series.py::test_pipelined_passes_equal_the_plain_ones. */
 int ftkx_sweep_series_submit(ftkx_ctx *ctx, const int *timesteps, const int *scopes, int n, const double *running_resolution);
 int ftkx_sweep_series_complete(ftkx_ctx *ctx, double *running_resolution, unsigned long long *factors, const ftkx_cp_t **out, size_t *n_out);

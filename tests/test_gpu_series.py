@@ -378,6 +378,42 @@ def test_pipelined_records_through_the_copy_engine(gpu):
     ctx.close()
 
 
+def test_pipelined_passes_through_buffers_that_are_too_small(gpu):
+    """two passes in flight on a series with more records than the initial hit buffer holds: the first is flagged, swept again by the
+    host-driven batch (which grows the buffers) while the second is still out; the second is flagged as well; from the third on the passes
+    fit -- every pass returns the records of the plain call"""
+    import torch
+    from ftk_amd import synthetic
+    dev = torch.device("cuda", 0)
+    dims, nt = (2048, 2048), 12
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    ref = _ctx(gpu, dims, 2, 1, tag_mode=gpu.TAG_EXACT64)
+    snaps = [synthetic.generate("woven", dims, t, nt, torch, dev) for t in range(nt)]
+    for t in range(nt):
+        ref.push_scalar_slice(t, snaps[t])
+    want, wf, wrun = ref.sweep_series(range(nt), scopes)
+    ref.close()
+    if len(want) <= 65536:
+        pytest.skip(f"only {len(want)} records: the buffers would fit")
+    ctx = _ctx(gpu, dims, 2, 1, tag_mode=gpu.TAG_EXACT64)
+    for t in range(nt):
+        ctx.push_scalar_slice(t, snaps[t])
+    paths = []
+    ctx.sweep_series_submit(range(nt), scopes)
+    for it in range(4):
+        ctx.invalidate_masks()
+        ctx.sweep_series_submit(range(nt), scopes)
+        got, f, run = ctx.sweep_series_complete()
+        paths.append(ctx.series_last_path())
+        assert _same(got, want) and np.array_equal(f, wf) and run == wrun, (it, len(got), len(want), paths)
+    got, f, run = ctx.sweep_series_complete()
+    paths.append(ctx.series_last_path())
+    assert _same(got, want) and np.array_equal(f, wf) and run == wrun, paths
+    assert paths[0][0] == 0 and (paths[0][1] & 8), paths            # flagged SERIES_OVERFLOW, replayed by the batch
+    assert paths[-1][0] == 1, paths                                  # ... and the later passes fit
+    ctx.close()
+
+
 def test_series_overflowing_buffers_replays_through_the_batch(gpu):
     """more records than the initial hit buffer holds (65 536): flagged by the finish kernel, swept again by the host-driven batch, and
     the NEXT call fits"""
