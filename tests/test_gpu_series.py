@@ -278,7 +278,7 @@ def test_short_chain_and_its_way_back(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["woven_128x128x10", "woven_31x37x32", "double_gyre_64x32x50", "merger_2d_32x32x100", "moving_extremum_3d_21x21x21x32",
-                                  "adversarial_3d_scalar_9x9x9x4"])
+                                  "adversarial_3d_scalar_9x9x9x4", "random_2d_scalar_29x24x6_saddles", "adversarial_3d_scalar_9x9x9x3_norobust"])
 def test_pipelined_passes_equal_the_plain_ones(gpu, name):
     """ftkx_sweep_series_submit / _complete, two passes open at a time: (a) the whole series swept again and again, masks dropped in
     between (what bench.py times), (b) the series in consecutive pieces, each continuing on the device from the running minimum of the one
@@ -288,7 +288,10 @@ def test_pipelined_passes_equal_the_plain_ones(gpu, name):
     g = load_golden(name)
     nd, nv, nt = g["nd"], g["nv"], g["DT"]
     scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
-    ctx = _ctx(gpu, g["dims"], nd, nv, tag_mode=gpu.TAG_EXACT64, robust=int(g["robust"]), compute_degrees=int(g["degrees"]))
+    opts = dict(tag_mode=gpu.TAG_EXACT64, robust=int(g["robust"]), compute_degrees=int(g["degrees"]))
+    if g["type_filter"] is not None:      # (a type filter, non-robust 3D: not the device-driven form -- the passes are swept by the host-driven batch when collected)
+        opts.update(use_type_filter=1, type_filter=g["type_filter"])
+    ctx = _ctx(gpu, g["dims"], nd, nv, **opts)
     _push_all(ctx, g["steps"], nv)
     want, wf, wrun = ctx.sweep_series(range(nt), scopes)
     # (a)
