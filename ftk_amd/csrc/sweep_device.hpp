@@ -396,7 +396,7 @@ __device__ inline bool make_record_impl(const Mesh &m, const Fields &f, const in
 // the general path stays a call (rare, and large); the straight-line one is inlined into the record kernel, where the mesh lives in
 // scalar registers instead of behind a reference
 template <int ND>
-__device__ __noinline__ bool make_record_general(const Mesh &m, const Fields &f, const int *corner, int type,
+__device__ __forceinline__ bool make_record_general(const Mesh &m, const Fields &f, const int *corner, int type,
                                                  const u64 (*X)[ND], const int *ids, bool presolved, const double *mu_in, ftkx_cp_t *out,
                                                  bool *fragile, double *Jfrag)
 {
