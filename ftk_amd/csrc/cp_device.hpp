@@ -149,6 +149,48 @@ FTKX_HD inline bool sos_origin_in_simplex(const u64 X[ND + 1][ND], const int id[
   return true;
 }
 
+// The cascade only where it is needed.  A value that is neither 0 nor INT64_MIN has its own sign under the reference's convention too:
+// sorting the rows by vertex id negates the determinant once per swap -- exactly, in Z / 2^64 --, and sos_sign3 / sos_sign4 return the
+// sign of their first determinant when it is not zero.  So of the d + 2 determinants of a simplex (the full one, and one per vertex
+// replaced by the origin) only the degenerate ones go through sos_orientation: typically one, where the literal form above sorts and
+// expands all of them again.  Same result (tests/test_host_numerics.py: against the literal cascade from all-degenerate to all-wrapped).
+template <int ND>
+FTKX_HD inline bool sos_origin_in_simplex_resolved(const u64 X[ND + 1][ND], const int id[ND + 1])
+{
+  constexpr int n = ND + 1;
+  u64 c[n], d;
+  if constexpr (ND == 2) {
+    c[0] = X[1][0] * X[2][1] - X[1][1] * X[2][0];
+    c[1] = X[2][0] * X[0][1] - X[2][1] * X[0][0];
+    c[2] = X[0][0] * X[1][1] - X[0][1] * X[1][0];
+    d = c[0] + c[1] + c[2];
+  } else {
+    const u64 p_yz = X[2][1] * X[3][2] - X[2][2] * X[3][1], p_zx = X[2][2] * X[3][0] - X[2][0] * X[3][2], p_xy = X[2][0] * X[3][1] - X[2][1] * X[3][0];
+    const u64 q_yz = X[0][1] * X[1][2] - X[0][2] * X[1][1], q_zx = X[0][2] * X[1][0] - X[0][0] * X[1][2], q_xy = X[0][0] * X[1][1] - X[0][1] * X[1][0];
+    const u64 m0 = X[1][0] * p_yz + X[1][1] * p_zx + X[1][2] * p_xy, m1 = X[0][0] * p_yz + X[0][1] * p_zx + X[0][2] * p_xy;
+    const u64 m2 = X[3][0] * q_yz + X[3][1] * q_zx + X[3][2] * q_xy, m3 = X[2][0] * q_yz + X[2][1] * q_zx + X[2][2] * q_xy;
+    c[0] = 0ull - m0; c[1] = m1; c[2] = 0ull - m2; c[3] = m3;
+    d = c[0] + c[1] + c[2] + c[3];
+  }
+  const int s = degenerate_value(d) ? sos_orientation<ND>(X, id) : sgn_wrapped(d);
+#pragma unroll
+  for (int i = 0; i < n; i ++) {
+    int si;
+    if (degenerate_value(c[i])) {
+      u64 Y[n][ND]; int yid[n];
+#pragma unroll
+      for (int j = 0; j < n; j ++) {
+        yid[j] = (j == i) ? -1 : id[j];
+#pragma unroll
+        for (int k = 0; k < ND; k ++) Y[j][k] = (j == i) ? 0ull : X[j][k];
+      }
+      si = sos_orientation<ND>(Y, yid);
+    } else si = sgn_wrapped(c[i]);
+    if (si != s) return false;
+  }
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // fast path
 // ---------------------------------------------------------------------------------------------------------------

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
           for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[sub * G + gi][vm][c];
           ids[i] = vertex_id<ND>(m, corner, vm);
         }
-        if (sos_origin_in_simplex<ND>(X, ids))
+        if (sos_origin_in_simplex_resolved<ND>(X, ids))
           s_pass[atomicAdd(&s_npass, 1u)] = order_key((e & kPassLinMask) | ((u64)type << kPassTypeShift) | ((e >> 44) << kPassStepShift), m.core_cells);
       }
       __syncthreads();

@@ -437,7 +437,7 @@ __device__ inline bool simplex_inside(const Mesh &m, const Fields &f, int cull, 
   if (r >= 0) return r != 0;
   if (degenerate) { *degenerate = true; return false; }
   for (int i = 0; i < N; i ++) ids[i] = vertex_id<ND>(m, corner, (tab >> (8 * i)) & 0xffu);
-  return sos_origin_in_simplex<ND>(X, ids);
+  return sos_origin_in_simplex_resolved<ND>(X, ids);
 }
 
 // hits of one wavefront appended with a single atomic (must be reached by all 64 lanes)

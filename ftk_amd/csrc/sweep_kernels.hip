@@ -349,7 +349,7 @@ __global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile
           ids[i] = vertex_id<3>(m, lc, vm);
         }
         const int r = origin_in_simplex3_try(X, true);
-        return r < 0 ? sos_origin_in_simplex<3>(X, ids) : r != 0;
+        return r < 0 ? sos_origin_in_simplex_resolved<3>(X, ids) : r != 0;
       };
       for (;;) {                                                 // (one round unless the tile has more than kItems of them)
         while (__any(unsure != 0)) {                             // append (wave-uniform trip count)

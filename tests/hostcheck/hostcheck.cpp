@@ -43,6 +43,13 @@ void hc_batch_in_simplex_try(int nd, int n, const long long *X, const int *ids, 
   }
 }
 
+// the cascade only for the degenerate ones of a simplex's determinants (what the kernels call)
+void hc_batch_in_simplex_resolved(int nd, int n, const long long *X, const int *ids, int *out)
+{
+  for (int i = 0; i < n; i ++)
+    out[i] = nd == 2 ? (int)sos_origin_in_simplex_resolved<2>((const u64 (*)[2])(X + 6 * i), ids + 3 * i) : (int)sos_origin_in_simplex_resolved<3>((const u64 (*)[3])(X + 12 * i), ids + 4 * i);
+}
+
 int hc_fan(int n, int *verts /* [ntypes][n][n] */, int *ordinal, int *ord_types, int *int_types)
 {
   if (n == 3) {

@@ -59,6 +59,8 @@ def test_integer_predicate_matches_oracle(hc, oracle, nd, mag):
     tri = np.zeros(n, dtype=np.int32)
     hc.hc_batch_in_simplex_try(nd, n, _ptr(X), _ptr(ids), 0, _ptr(tri))
     assert np.array_equal(tri, ref), "id-free fast path + cascade differs from the oracle"
+    hc.hc_batch_in_simplex_resolved(nd, n, _ptr(X), _ptr(ids), _ptr(tri))
+    assert np.array_equal(tri, ref), "the cascade for the degenerate determinants only differs from the oracle"
     if mag < 2 ** 31:
         hc.hc_batch_in_simplex_try(nd, n, _ptr(X), _ptr(ids), 1, _ptr(tri))
         assert np.array_equal(tri, ref), "id-free 32-bit-operand fast path + cascade differs from the oracle"
@@ -80,6 +82,9 @@ def test_predicate_with_truncated_and_negative_ids(hc, oracle):
         getattr(hc, f"hc_batch_in_simplex{nd}")(n, _ptr(X), _ptr(ids), _ptr(fast), _ptr(sos))
         ref = _oracle_batch(oracle, f"ftko_hook_cp_in_simplex{nd}", X, ids, nd)
         assert np.array_equal(fast, ref) and np.array_equal(sos, ref)
+        res = np.zeros(n, dtype=np.int32)
+        hc.hc_batch_in_simplex_resolved(nd, n, _ptr(X), _ptr(ids), _ptr(res))
+        assert np.array_equal(res, ref)
 
 
 def test_fp64_solvers_bit_identical(hc, oracle):
