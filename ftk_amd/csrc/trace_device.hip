@@ -8,6 +8,7 @@
 // tags go up (8 bytes per record), a kernel finds every record's neighbours by binary search in the sorted tags, a lock-free union-find
 // labels the components, and neighbours, degrees and roots come back (29-37 bytes per record).  What stays on the host is what is
 // serial per curve -- seeds in the reference's element order, the walk along each curve -- in trace.cpp, unchanged.
+#include <chrono>
 #include "ctx.hpp"
 
 using namespace ftkxh;
@@ -93,6 +94,8 @@ extern "C" {
 int ftkx_trace_curves_ctx(ftkx_ctx *c, int nd, const long long domain_st[3], const long long domain_sz[3], const ftkx_cp_t *recs, size_t n, ftkx_curves *out)
 {
   if (!c) return ftkx_trace_curves(nd, domain_st, domain_sz, recs, n, out);
+  static const bool timing = getenv("FTKX_TRACE_TIMING") != nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
   if ((nd != 2 && nd != 3) || !domain_st || !domain_sz || (!recs && n) || !out) return fail(c, FTKX_E_INVALID, "ftkx_trace_curves_ctx: bad arguments");
   // few records, or tags that do not come strictly ascending (the sweep delivers them so): the host does it all
   bool ascending = n < (1u << 30);
@@ -131,6 +134,7 @@ int ftkx_trace_curves_ctx(ftkx_ctx *c, int nd, const long long domain_st[3], con
   u64 *h_tags = (u64 *)c->tr_host;
   for (size_t i = 0; i < n; i ++) h_tags[i] = recs[i].tag;
   char *d = (char *)c->tr_dev;
+  const auto tp1 = std::chrono::steady_clock::now();
   HIP_TRY(c, hipMemcpyAsync(d, c->tr_host, n * 8, hipMemcpyHostToDevice, c->stream));
   TraceGeom g;
   memset(&g, 0, sizeof(g));
@@ -145,8 +149,15 @@ int ftkx_trace_curves_ctx(ftkx_ctx *c, int nd, const long long domain_st[3], con
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync((char *)c->tr_host + off_nbr, d + off_nbr, off_deg + n - off_nbr, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const auto tp2 = std::chrono::steady_clock::now();
   const char *h = (const char *)c->tr_host;
   const int rc = ftkx::trace_curves_with(nd, domain_st, domain_sz, recs, n, out, (const int *)(h + off_nbr), (const unsigned char *)(h + off_deg), (const int *)(h + off_root), maxnb);
+  if (timing) {
+    const auto tp3 = std::chrono::steady_clock::now();
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "ftkx_trace_curves_ctx: %zu records, maxnb %d: checks + tags %.0f us, device (up, 3 kernels, down %zu bytes) %.0f us, host (seeds, walks, curves) %.0f us\n",
+            n, maxnb, us(tp0, tp1), off_deg + n - off_nbr, us(tp1, tp2), us(tp2, tp3));
+  }
   if (rc != FTKX_OK) return fail(c, rc, "ftkx_trace_curves_ctx: tracing failed (%d)", rc);
   return FTKX_OK;
 }
