@@ -10,7 +10,8 @@ void set_global_error(const char *msg);
 namespace ftkx {
 // pass 2 with the neighbour search and the component labelling done on the device (trace.cpp <-> trace_device.hip)
 int trace_candidates(int nd, std::vector<int> &cand_off, std::vector<int> &cand_flat);
-int trace_curves_with(int nd, const long long *dst, const long long *dsz, const ftkx_cp_t *recs, size_t n, ftkx_curves *out,
+int trace_curves_with(int nd, const long long *dst, const long long *dsz, const unsigned long long *tags, size_t n, ftkx_curves *out,
                       const int *nbr, const unsigned char *deg, const int *root, int maxnb);
+int trace_curves_tags(int nd, const long long *dst, const long long *dsz, const unsigned long long *tags, size_t n, ftkx_curves *out);   // host only
 }
 #endif

@@ -37,6 +37,15 @@ namespace {
 typedef unsigned long long u64;
 #define ND_OF(N) ((N) - 1)
 
+// the tags of a record set: inside records (72 bytes apart) or as an array of their own (a caller that holds its points in another form --
+// the C++ tracker -- hands over 8 bytes per record instead of building records around them)
+struct TagView {
+  const unsigned char *p; size_t stride;
+  TagView(const ftkx_cp_t *recs) : p(reinterpret_cast<const unsigned char *>(recs) + offsetof(ftkx_cp_t, tag)), stride(sizeof(ftkx_cp_t)) {}
+  TagView(const unsigned long long *tags) : p(reinterpret_cast<const unsigned char *>(tags)), stride(sizeof(unsigned long long)) {}
+  u64 operator[](size_t i) const { u64 v; memcpy(&v, p + i * stride, sizeof(v)); return v; }
+};
+
 struct Elem {
   int c[4];   // corner x, y, (z,) t ; unused axes 0
   int type;
@@ -174,6 +183,7 @@ struct Tracer {
   // parallel = the records are claimed slot by slot with a compare-and-swap on `rec` (tags are unique and nobody looks anything up
   // before the table is complete, so a slot whose tag is still being written only has to read as taken)
   void build_hash(const ftkx_cp_t *recs, size_t n, bool parallel = false);
+  template <class Tags> void build_hash_tags(const Tags &tags, size_t n, bool parallel);
   int find_tag(u64 tag) const
   {
     for (u64 p = mix(tag) & h_mask; h_slot[p].rec >= 0; p = (p + 1) & h_mask) if (h_slot[p].tag == tag) return (int)h_slot[p].rec;
@@ -354,7 +364,11 @@ void parallel_ranges(size_t n, F f, unsigned cap = 16, size_t min_n = 4096)
 }
 
 template <int N>
-void Tracer<N>::build_hash(const ftkx_cp_t *recs, size_t n, bool parallel)
+void Tracer<N>::build_hash(const ftkx_cp_t *recs, size_t n, bool parallel) { build_hash_tags(TagView(recs), n, parallel); }
+
+template <int N>
+template <class Tags>
+void Tracer<N>::build_hash_tags(const Tags &tags, size_t n, bool parallel)
 {
   size_t cap = 16;
   while (cap < 2 * n + 2) cap <<= 1;
@@ -362,13 +376,13 @@ void Tracer<N>::build_hash(const ftkx_cp_t *recs, size_t n, bool parallel)
   h_slot.assign(cap, Slot{0, -1});
   auto insert = [&](size_t b, size_t e) {
     for (size_t i = b; i < e; i ++) {
-      u64 p = mix(recs[i].tag) & h_mask;
+      u64 p = mix(tags[i]) & h_mask;
       for (;;) {
         long long expect = -1;
         if (__atomic_compare_exchange_n(&h_slot[p].rec, &expect, (long long)i, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
         p = (p + 1) & h_mask;
       }
-      h_slot[p].tag = recs[i].tag;
+      h_slot[p].tag = tags[i];
     }
   };
   if (parallel) parallel_ranges(n, insert); else insert(0, n);
@@ -378,8 +392,9 @@ void Tracer<N>::build_hash(const ftkx_cp_t *recs, size_t n, bool parallel)
 // reference's element order (`maxnb` slots per record, `deg` of them filled), and the component root of every ordinary record
 struct DevicePhase { const int *nbr; const unsigned char *deg; const int *root; int maxnb; };
 
+
 template <int N>
-int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs, size_t n, ftkx_curves *out, const DevicePhase *dev = nullptr)
+int trace_impl(const long long *dst, const long long *dsz, const TagView tags, size_t n, ftkx_curves *out, const DevicePhase *dev = nullptr)
 {
   static const Adjacency<N> adj;
   const bool prof = getenv("FTKX_TRACE_PROF") != nullptr;
@@ -392,15 +407,15 @@ int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs
   if (dev) { if (dev->maxnb != MAXNB) return FTKX_E_INVALID; }       // (the caller has checked the tags: strictly ascending)
   else {
     bool sorted = true;
-    for (size_t i = 1; i < n && sorted; i ++) sorted = recs[i - 1].tag <= recs[i].tag;
-    if (sorted) { for (size_t i = 1; i < n; i ++) if (recs[i].tag == recs[i - 1].tag) return FTKX_E_INVALID; }
+    for (size_t i = 1; i < n && sorted; i ++) sorted = tags[i - 1] <= tags[i];
+    if (sorted) { for (size_t i = 1; i < n; i ++) if (tags[i] == tags[i - 1]) return FTKX_E_INVALID; }
     else {
       tr.index.resize(n);
-      for (size_t i = 0; i < n; i ++) tr.index[i] = {recs[i].tag, (int)i};
+      for (size_t i = 0; i < n; i ++) tr.index[i] = {tags[i], (int)i};
       ftkx::sort_on_threads(tr.index);
       for (size_t i = 1; i < n; i ++) if (tr.index[i].first == tr.index[i - 1].first) return FTKX_E_INVALID;
     }
-    tr.build_hash(recs, n, true);
+    tr.build_hash_tags(tags, n, true);
   }
   tp[np_ ++] = now();
   std::vector<Elem> elem(n);
@@ -414,7 +429,7 @@ int trace_impl(const long long *dst, const long long *dsz, const ftkx_cp_t *recs
   std::vector<std::pair<u64, int>> order_key(n);
   parallel_ranges(n, [&](size_t b, size_t e) {
     for (size_t i = b; i < e; i ++) {
-      elem[i] = tr.decode(recs[i].tag);
+      elem[i] = tr.decode(tags[i]);
       if (!dev) deg_w[i] = (unsigned char)tr.neighbour_records(elem[i], &nbr_w[i * MAXNB], MAXNB);
       u64 key = 0;
       for (int d = 0; d < ND_OF(N); d ++) key = key * (u64)dsz[d] + (u64)(elem[i].c[d] - dst[d]);
@@ -680,13 +695,22 @@ int trace_candidates(int nd, std::vector<int> &cand_off, std::vector<int> &cand_
 }
 
 // ftkx_trace_curves with the neighbour search and the component labelling done elsewhere (tags strictly ascending)
-int trace_curves_with(int nd, const long long *dst, const long long *dsz, const ftkx_cp_t *recs, size_t n, ftkx_curves *out,
+int trace_curves_with(int nd, const long long *dst, const long long *dsz, const unsigned long long *tags, size_t n, ftkx_curves *out,
                       const int *nbr, const unsigned char *deg, const int *root, int maxnb)
 {
-  if ((nd != 2 && nd != 3) || !dst || !dsz || (!recs && n) || !out) return FTKX_E_INVALID;
+  if ((nd != 2 && nd != 3) || !dst || !dsz || (!tags && n) || !out) return FTKX_E_INVALID;
   memset(out, 0, sizeof(*out));
   const DevicePhase dp{nbr, deg, root, maxnb};
-  try { return nd == 2 ? trace_impl<3>(dst, dsz, recs, n, out, &dp) : trace_impl<4>(dst, dsz, recs, n, out, &dp); }
+  try { return nd == 2 ? trace_impl<3>(dst, dsz, TagView(tags), n, out, &dp) : trace_impl<4>(dst, dsz, TagView(tags), n, out, &dp); }
+  catch (const std::bad_alloc &) { return FTKX_E_NOMEM; }
+}
+
+// (host only) the same on a tag array
+int trace_curves_tags(int nd, const long long *dst, const long long *dsz, const unsigned long long *tags, size_t n, ftkx_curves *out)
+{
+  if ((nd != 2 && nd != 3) || !dst || !dsz || (!tags && n) || !out) return FTKX_E_INVALID;
+  memset(out, 0, sizeof(*out));
+  try { return nd == 2 ? trace_impl<3>(dst, dsz, TagView(tags), n, out) : trace_impl<4>(dst, dsz, TagView(tags), n, out); }
   catch (const std::bad_alloc &) { return FTKX_E_NOMEM; }
 }
 }  // namespace ftkx
@@ -740,7 +764,7 @@ int ftkx_trace_curves(int nd, const long long domain_st[3], const long long doma
   if (!out || (n && !recs) || (nd != 2 && nd != 3)) return FTKX_E_INVALID;
   memset(out, 0, sizeof(*out));
   for (int d = 0; d < nd; d ++) if (domain_sz[d] <= 0) return FTKX_E_INVALID;
-  return nd == 2 ? trace_impl<3>(domain_st, domain_sz, recs, n, out) : trace_impl<4>(domain_st, domain_sz, recs, n, out);
+  return nd == 2 ? trace_impl<3>(domain_st, domain_sz, TagView(recs), n, out) : trace_impl<4>(domain_st, domain_sz, TagView(recs), n, out);
 }
 
 void ftkx_free_curves(ftkx_curves *c)

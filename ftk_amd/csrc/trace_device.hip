@@ -91,16 +91,18 @@ __global__ __launch_bounds__(256) void trace_roots_kernel(int n, int *parent, in
 
 extern "C" {
 
-int ftkx_trace_curves_ctx(ftkx_ctx *c, int nd, const long long domain_st[3], const long long domain_sz[3], const ftkx_cp_t *recs, size_t n, ftkx_curves *out)
+static int trace_curves_ctx_impl(ftkx_ctx *c, int nd, const long long domain_st[3], const long long domain_sz[3], const ftkx_cp_t *recs, const unsigned long long *tags, size_t n, ftkx_curves *out)
 {
-  if (!c) return ftkx_trace_curves(nd, domain_st, domain_sz, recs, n, out);
+  auto tag_of = [&](size_t i) { return tags ? tags[i] : recs[i].tag; };
+  auto on_host = [&]() { return tags ? ftkx::trace_curves_tags(nd, domain_st, domain_sz, tags, n, out) : ftkx_trace_curves(nd, domain_st, domain_sz, recs, n, out); };
+  if (!c) return on_host();
   static const bool timing = getenv("FTKX_TRACE_TIMING") != nullptr;
   const auto tp0 = std::chrono::steady_clock::now();
-  if ((nd != 2 && nd != 3) || !domain_st || !domain_sz || (!recs && n) || !out) return fail(c, FTKX_E_INVALID, "ftkx_trace_curves_ctx: bad arguments");
+  if ((nd != 2 && nd != 3) || !domain_st || !domain_sz || (!recs && !tags && n) || !out) return fail(c, FTKX_E_INVALID, "ftkx_trace_curves_ctx: bad arguments");
   // few records, or tags that do not come strictly ascending (the sweep delivers them so): the host does it all
   bool ascending = n < (1u << 30);
-  for (size_t i = 1; i < n && ascending; i ++) ascending = recs[i - 1].tag < recs[i].tag;
-  if (n < 4096 || !ascending) return ftkx_trace_curves(nd, domain_st, domain_sz, recs, n, out);
+  for (size_t i = 1; i < n && ascending; i ++) ascending = tag_of(i - 1) < tag_of(i);
+  if (n < 4096 || !ascending) return on_host();
   HIP_TRY(c, hipSetDevice(c->device));
   static thread_local std::vector<int> cand_off[2], cand_flat[2];
   static thread_local int maxnb_of[2] = {0, 0};
@@ -132,7 +134,7 @@ int ftkx_trace_curves_ctx(ftkx_ctx *c, int nd, const long long domain_st[3], con
   // layout (8-byte aligned pieces): tags u64[n] | nbr int[n * maxnb] | root int[n] | deg u8[n]
   const size_t off_nbr = n * 8, off_root = off_nbr + n * (size_t)maxnb * 4, off_deg = off_root + n * 4;
   u64 *h_tags = (u64 *)c->tr_host;
-  for (size_t i = 0; i < n; i ++) h_tags[i] = recs[i].tag;
+  if (tags) memcpy(h_tags, tags, n * sizeof(u64)); else for (size_t i = 0; i < n; i ++) h_tags[i] = recs[i].tag;
   char *d = (char *)c->tr_dev;
   const auto tp1 = std::chrono::steady_clock::now();
   HIP_TRY(c, hipMemcpyAsync(d, c->tr_host, n * 8, hipMemcpyHostToDevice, c->stream));
@@ -151,7 +153,7 @@ int ftkx_trace_curves_ctx(ftkx_ctx *c, int nd, const long long domain_st[3], con
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const auto tp2 = std::chrono::steady_clock::now();
   const char *h = (const char *)c->tr_host;
-  const int rc = ftkx::trace_curves_with(nd, domain_st, domain_sz, recs, n, out, (const int *)(h + off_nbr), (const unsigned char *)(h + off_deg), (const int *)(h + off_root), maxnb);
+  const int rc = ftkx::trace_curves_with(nd, domain_st, domain_sz, h_tags, n, out, (const int *)(h + off_nbr), (const unsigned char *)(h + off_deg), (const int *)(h + off_root), maxnb);
   if (timing) {
     const auto tp3 = std::chrono::steady_clock::now();
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -161,5 +163,12 @@ int ftkx_trace_curves_ctx(ftkx_ctx *c, int nd, const long long domain_st[3], con
   if (rc != FTKX_OK) return fail(c, rc, "ftkx_trace_curves_ctx: tracing failed (%d)", rc);
   return FTKX_OK;
 }
+
+
+int ftkx_trace_curves_ctx(ftkx_ctx *c, int nd, const long long domain_st[3], const long long domain_sz[3], const ftkx_cp_t *recs, size_t n, ftkx_curves *out)
+{ return trace_curves_ctx_impl(c, nd, domain_st, domain_sz, recs, nullptr, n, out); }
+
+int ftkx_trace_curves_tags_ctx(ftkx_ctx *c, int nd, const long long domain_st[3], const long long domain_sz[3], const unsigned long long *tags, size_t n, ftkx_curves *out)
+{ return trace_curves_ctx_impl(c, nd, domain_st, domain_sz, nullptr, tags, n, out); }
 
 }  // extern "C"

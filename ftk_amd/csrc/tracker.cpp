@@ -5,6 +5,7 @@
 #include "host_sort.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
@@ -570,7 +571,11 @@ void critical_point_tracker_regular::finalize()
   }
   // Nothing has to be ordered for this: ftkx_trace_curves takes the points in any order (it indexes them by tag) and returns the curves
   // in the reference's order.  Sweeps in time order with 64-bit tags deliver ascending tags: the pending points are traced as they are.
+  static const bool timing = getenv("FTKX_TRACE_TIMING") != nullptr;
+  typedef std::chrono::steady_clock clk;
+  const clk::time_point tq0 = clk::now();
   if (!(points.empty() && pending_ascending)) flush_points();
+  const clk::time_point tq1 = clk::now();
   const std::vector<feature_point_t> &src = points.empty() ? pending_points : points;
   // (the flat store is in the reference's element order; the trace's device phases want ascending tags: an index sorted on a few
   // threads, and the curves' indices mapped back through it)
@@ -580,14 +585,15 @@ void critical_point_tracker_regular::finalize()
     for (size_t i = 0; i < src.size(); i ++) by_tag[i] = {src[i].tag, i};
     ftkx::sort_on_threads(by_tag);
   }
-  std::vector<ftkx_cp_t> recs(src.size());
-  if (!src.empty()) std::memset(recs.data(), 0, recs.size() * sizeof(ftkx_cp_t));
-  for (size_t i = 0; i < src.size(); i ++) recs[i].tag = by_tag.empty() ? src[i].tag : by_tag[i].first;
+  std::vector<unsigned long long> tags(src.size());           // (the trace reads nothing but the tags)
+  for (size_t i = 0; i < src.size(); i ++) tags[i] = by_tag.empty() ? src[i].tag : by_tag[i].first;
   long long dst[3] = {0, 0, 0}, dsz[3] = {1, 1, 1};
   for (int d = 0; d < nd; d ++) { dst[d] = domain.start(d); dsz[d] = domain.size(d); }
   ftkx_curves c{};
+  const clk::time_point tq2 = clk::now();
   // (neighbour search and component labelling on the tracker's GPU where the record set is large enough to pay for the round trip)
-  const int rc = ftkx_trace_curves_ctx(ctx, nd, dst, dsz, recs.data(), recs.size(), &c);
+  const int rc = ftkx_trace_curves_tags_ctx(ctx, nd, dst, dsz, tags.data(), tags.size(), &c);
+  const clk::time_point tq3 = clk::now();
   if (rc != FTKX_OK) { ftkx_free_curves(&c); throw ftkx_error(rc, "finalize: ftkx_trace_curves failed (tags must not have overflowed int32: use FTKX_TAG_EXACT64 on very large meshes)"); }
   // the curves stay flat -- the points of all curves one after the other; one vector per curve is built only if somebody asks for it
   traced_points.resize(c.n_points); traced_offsets.assign(c.offsets, c.offsets + c.n_curves + 1);
@@ -598,6 +604,10 @@ void critical_point_tracker_regular::finalize()
   for (size_t i = 0; i < c.n_curves; i ++) traced_id[i] = (int)i;
   traced_nested_valid = false;
   ftkx_free_curves(&c);
+  if (timing) {
+    auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "tracker finalize: flush %.0f us, tag index + records %.0f us, trace %.0f us, curves -> points %.0f us\n", us(tq0, tq1), us(tq1, tq2), us(tq2, tq3), us(tq3, clk::now()));
+  }
 }
 
 namespace {

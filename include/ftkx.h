@@ -279,6 +279,8 @@ void ftkx_free_curves(ftkx_curves *c);
  * GPU (tags up, neighbours and component roots down; what is serial per curve stays on host threads): identical curves.  Record sets
  * below 4 096 records, or whose tags do not come strictly ascending, take ftkx_trace_curves as it is; ctx == NULL likewise. */
 int  ftkx_trace_curves_ctx(ftkx_ctx *ctx, int nd, const long long domain_st[3], const long long domain_sz[3], const ftkx_cp_t *recs, size_t n, ftkx_curves *out);
+/* the same on the tags alone (8 bytes per record): a caller that holds its points in another form need not build records around them */
+int  ftkx_trace_curves_tags_ctx(ftkx_ctx *ctx, int nd, const long long domain_st[3], const long long domain_sz[3], const unsigned long long *tags, size_t n, ftkx_curves *out);
 
 /* enable_streaming_trajectories (critical_point_tracker.hh:38; update_timestep 2d:326-330, 3d:197-201): trajectories that grow while
  * the sweep streams -- trace_critical_points_online (critical_point_tracker.hh:523-639).  After every interval sweep the caller hands
