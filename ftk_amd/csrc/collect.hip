@@ -144,7 +144,8 @@ int run_batch(ftkx_ctx *c, const double *sparse_field, bool cull_done)
         // largest |quantised component| the request can meet, where the slices' maxima are known (the kernel checks every tile anyway)
         double bound = -1.0;
         if (s0.max_known() && (!s1 || s1->max_known())) bound = std::max(s0.maxabs, s1 ? s1->maxabs : 0.0) * (double)r.factor;
-        p.form = !(nd == 3 && m.robust) ? 0 : bound < 0 ? 1 : bound < 524287.0 ? 2 : bound < 2147483647.0 ? 1 : 0;
+        const double fp_bound = nd == 3 ? 524287.0 : 33554431.0;     // below 2^19 (3D: error-bounded fp64) / 2^25 (2D: exact fp64)
+        p.form = (nd == 3 && !m.robust) ? 0 : bound < 0 ? 1 : bound < fp_bound ? 2 : bound < 2147483647.0 ? 1 : 0;
         p.form = std::min(p.form, p.fan == 9 ? 2 : p.fan);
       }
       int tile[3];
@@ -208,7 +209,14 @@ int run_batch(ftkx_ctx *c, const double *sparse_field, bool cull_done)
     ev_begin(c, K_EXACT); ftkx::launch_exact(m, d_steps, (int)step_base[i], c->d_list, c->list_capacity, c->stream); ev_end(c);
   }
   if (cull_only) { HIP_TRY(c, hipGetLastError()); return FTKX_OK; }
-  for (const TileParams &p : tiles) { ev_begin(c, K_TILE); ftkx::launch_tile(p, c->stream); ev_end(c); }
+  if (!tiles.empty()) {
+    if (!c->d_tile_stats) {
+      HIP_TRY(c, hipMalloc((void **)&c->d_tile_stats, 512 * sizeof(u64)));
+      HIP_TRY(c, hipMemsetAsync(c->d_tile_stats, 0, 512 * sizeof(u64), c->stream));
+    }
+    for (TileParams &p : tiles) { p.stats = c->d_tile_stats; ev_begin(c, K_TILE); ftkx::launch_tile(p, c->stream); ev_end(c); }
+    ftkx::launch_tile_stats_fold(c->d_tile_stats, m.counters, c->stream);
+  }
   // the FP64 half, once for the whole batch: records of every simplex that passed (timed with the kernel family that fed it)
   if (nfields) { ev_begin(c, tiles.empty() ? K_EXACT : K_TILE); ftkx::launch_records(m, d_fields, c->stream); ev_end(c); }
   HIP_TRY(c, hipGetLastError());

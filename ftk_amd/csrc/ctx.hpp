@@ -21,6 +21,7 @@
 
 namespace ftkx {
 void launch_tile(const TileParams &p, hipStream_t stream);
+void launch_tile_stats_fold(u64 *slots, u64 *counters, hipStream_t stream);
 void tile_dims(int nd, int tile[3]);
 void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream);
 void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream, const FactorJob *job = nullptr);
@@ -166,6 +167,7 @@ struct ftkx_ctx {
   u64 *d_refine = nullptr;          // words the summary level could not rule out (two-level cull)
   u64 refine_capacity = 0;
   u64 *d_counters = nullptr;        // CNT_N counters + 128 words (64 {min, max} slots) for the resolution reduction
+  u64 *d_tile_stats = nullptr;      // 512 words: the tile kernels' statistics in 256 slots (TileParams::stats)
   u64 *h_counters = nullptr;        // pinned
   ftkx_cp_t *h_hits = nullptr;      // pinned
   size_t h_cap = 0;

@@ -374,6 +374,7 @@ void ftkx_destroy(ftkx_ctx *c)
   if (c->h_ahead) (void)hipHostFree(c->h_ahead);
   if (c->d_ahead) (void)hipFree(c->d_ahead);
   if (c->d_red) (void)hipFree(c->d_red);
+  if (c->d_tile_stats) (void)hipFree(c->d_tile_stats);
   if (c->d_hits) (void)hipFree(c->d_hits);
   if (c->d_pass) (void)hipFree(c->d_pass);
   if (c->d_fragile) (void)hipFree(c->d_fragile);

@@ -148,6 +148,72 @@ __device__ __forceinline__ fan_result fan_of_corner3(At &&at, unsigned inv, cons
   return r;
 }
 
+// The 2D+t fan of one corner on one lane: 12 triangles over the 8 vertices of the corner's space-time cube.  A triangle is a chain
+// 0 < m1 < m2; of its three "vertex replaced by the origin" determinants two contain the corner -- det(X_0, X_a), seven of them for the
+// whole fan -- and one, det(X_m1, X_m2), is its own: C0 = det(X_m1, X_m2), C1 = -det(X_0, X_m2), C2 = det(X_0, X_m1), D = their sum
+// (origin_in_simplex2).  Integer: components below 2^31, minors from 32 x 32 -> 64 multiplies, D in Z / 2^64 as the reference has it.  fp64:
+// components below 2^25 -- products below 2^50, every value an integer below 2^53: the evaluation is EXACT, and only a true zero is "unsure".
+template <class comp_t, class At>
+__device__ __forceinline__ fan_result fan_of_corner2(At &&at, unsigned inv, const unsigned (&pos)[3], const unsigned (&neg)[3],
+                                                     bool do_ord, bool do_int, int cull, double clear)
+{
+  constexpr bool FP = std::is_same<comp_t, double>::value;
+  using minor_t = std::conditional_t<FP, double, u64>;
+  auto minor = [&](auto I, auto J) __attribute__((always_inline)) -> minor_t {          // det(X_i, X_j)
+    const comp_t a = at(I, 0), b = at(J, 1), c = at(I, 1), d = at(J, 0);
+    if constexpr (FP) return fma(a, b, -(c * d));
+    else return (u64)((i64)a * (i64)b) - (u64)((i64)c * (i64)d);
+  };
+  minor_t M[8];                                                // det(X_0, X_a)
+  M[0] = minor_t(0);
+  fan_for<7>([&](auto IC) __attribute__((always_inline)) {
+    constexpr int a = decltype(IC)::value + 1;
+    M[a] = minor(std::integral_constant<int, 0>{}, std::integral_constant<int, a>{});
+  });
+  auto word = [](minor_t x) __attribute__((always_inline)) -> unsigned {
+    if constexpr (FP) return (unsigned)__double2hiint(x) & 0x7fffffffu;
+    else return (unsigned)x | ((unsigned)(x >> 32) << 1);
+  };
+  auto top = [](minor_t x) __attribute__((always_inline)) -> unsigned {
+    if constexpr (FP) return (unsigned)__double2hiint(x); else return (unsigned)(x >> 32);
+  };
+  const unsigned clear_word = FP ? (unsigned)__double2hiint(clear) : 0u;
+  unsigned h0 = 0, g0 = 0, tested = 0;
+  fan_for<12>([&](auto IC) __attribute__((always_inline)) {
+    constexpr int T = decltype(IC)::value;
+    constexpr int m1 = k_fan3.vert[T][1], m2 = k_fan3.vert[T][2];
+    constexpr unsigned tm = 1u | (1u << m1) | (1u << m2);
+    constexpr bool ordinal = k_fan3.ordinal[T] != 0;
+    constexpr unsigned bit = 1u << T;
+    bool active = (ordinal ? do_ord : do_int) && !(inv & tm);
+    if (cull) {
+      const bool same = (pos[0] & tm) == tm || (neg[0] & tm) == tm || (pos[1] & tm) == tm || (neg[1] & tm) == tm;
+      active = active && !same;
+    }
+    if (active) {
+      tested ++;
+      // C1 = -M[m2] and C2 = M[m1] first: clear of zero and of different signs -> outside, whatever C0 and D are
+      const minor_t n1 = M[m2], n2 = M[m1];
+      const unsigned w1 = top(n1), w2 = top(n2);
+      const bool sure2 = min(word(n1), word(n2)) > clear_word;
+      const bool agree2 = (int)(w1 ^ w2) < 0;                    // sign(-n1) == sign(n2)
+      unsigned is_hit = 0, is_unsure = sure2 ? 0u : bit;
+      if (sure2 && agree2) {
+        const minor_t n0 = minor(std::integral_constant<int, m1>{}, std::integral_constant<int, m2>{});
+        const minor_t d = (n0 - n1) + n2;
+        const bool sure = min(word(n0), word(d)) > clear_word;
+        const unsigned w0 = top(n0), wd = top(d);
+        is_hit = (sure && (int)((w0 ^ wd) | (w2 ^ wd)) >= 0) ? bit : 0u;
+        is_unsure = sure ? 0u : bit;
+      }
+      h0 |= is_hit; g0 |= is_unsure;
+    }
+  });
+  fan_result r;
+  r.hits[0] = h0; r.hits[1] = 0; r.unsure[0] = g0; r.unsure[1] = 0; r.tested = tested;
+  return r;
+}
+
 // FORM 0: (corner, type) pairs over the lanes for every tile.  FORM 1 (3D, robust test): tiles whose components fit in 32 bits take the
 // integer fan, the others the pairs.  FORM 2: tiles with |component| < 2^19 take the fp64 fan, else as FORM 1.  The host picks the form
 // from what it knows of the slices' magnitudes (launch_tile); every form is correct on every tile -- the forms differ in registers.
@@ -160,7 +226,6 @@ __global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile
   constexpr int NH = HX * HY * HZ;
   constexpr int NORD = fan_table<N>::NORD, NINT = fan_table<N>::NINT;
   static_assert(cfg::TX * cfg::TY * cfg::TZ == kThreads, "one corner per lane");
-  static_assert(FORM == 0 || ND == 3, "the fan forms are 3D");
 
   // 3D, scalar input: the gradients of a tile's 17 x 5 x 5 x 2 vertices read a 19 x 7 x 7 x 2 block of S -- loaded once into LDS with every
   // load of a lane in flight together (one round trip), instead of six dependent global loads per vertex and 2.7 reads per value
@@ -258,7 +323,7 @@ __global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile
       if constexpr (FORM >= 2) s_vd[(sl * ND + j) * NH + hv] = (double)q[j];
       mine_narrow = mine_narrow && fits_s32(q[j]);
       const u64 aq = (u64)(q[j] < 0 ? -q[j] : q[j]);
-      mine_mid = mine_mid && aq < (1ull << 19); mine_small = mine_small && aq < (1ull << 16);
+      mine_mid = mine_mid && aq < (1ull << (ND == 3 ? 19 : 25)); mine_small = mine_small && aq < (1ull << (ND == 3 ? 16 : 25));
     }
   }
   TILE_STAMP(1);
@@ -274,7 +339,7 @@ __global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile
   for (int w = 0; w < kThreads / 64; w ++) tile_bits &= s_wflags[w];
   const bool narrow = (tile_bits & 1u) != 0;
   TILE_STAMP(2);
-  const bool fan_int = FORM >= 1 && narrow && m.robust && p.fan >= 1;
+  const bool fan_int = FORM >= 1 && narrow && (ND == 2 || m.robust) && p.fan >= 1;
   const bool fan_fp = FORM >= 2 && fan_int && p.fan >= 2 && (tile_bits & 2u);
   const bool small = fan_fp && (tile_bits & 4u);
 
@@ -302,32 +367,39 @@ __global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile
   const unsigned long long ballot_o = __ballot(keep_o), ballot_i = __ballot(keep_i);
   unsigned tested = 0;
   if constexpr (FORM >= 1) {
-    // ---- test, one corner per lane (fan_of_corner3) ----
+    // ---- test, one corner per lane (fan_of_corner3 / fan_of_corner2) ----
     if (fan_int && p.fan != 9) {
       u64 hits = 0, unsure = 0;
-      int corner[4] = {origin[0] + cx, origin[1] + cy, origin[2] + cz, f.t};
+      constexpr int NV = 1 << N;                                  // vertices of the corner's space-time hypercube
+      int corner[N];
+      corner[0] = origin[0] + cx; corner[1] = origin[1] + cy;
+      if (ND == 3) corner[2] = origin[2] + cz;
+      corner[ND] = f.t;
+      // (vertex v of the corner's hypercube: bit d = one step along axis d, bit ND = the next slice)
+      auto offset = [](int v) constexpr { return (v & 1) + HX * (((v >> 1) & 1) + (ND == 3 ? HY * ((v >> 2) & 1) : 0)); };
       if (ballot_o | ballot_i) {                                 // (a wavefront nothing of which survived its cull: nothing to do)
         unsigned inv = 0, pos[3] = {0, 0, 0}, neg[3] = {0, 0, 0};
 #pragma unroll
-        for (int v = 0; v < 16; v ++) {
+        for (int v = 0; v < NV; v ++) {
           unsigned mk = kInvalid;
-          if ((v >> 3) == 0 || need_next) mk = s_mask[v >> 3][hbase + (v & 1) + HX * (((v >> 1) & 1) + HY * ((v >> 2) & 1))];
+          if ((v >> ND) == 0 || need_next) mk = s_mask[v >> ND][hbase + offset(v)];
           if (mk & (kInvalid | kNonFinite)) inv |= 1u << v;
 #pragma unroll
-          for (int c = 0; c < 3; c ++) { if (mk & (1u << c)) pos[c] |= 1u << v; if (mk & (8u << c)) neg[c] |= 1u << v; }
+          for (int c = 0; c < ND; c ++) { if (mk & (1u << c)) pos[c] |= 1u << v; if (mk & (8u << c)) neg[c] |= 1u << v; }
         }
-        // (vertex v of the corner's hypercube, component c; slice 1 of an ordinal-only request is not staged: whatever is read there
-        // only enters simplices that `inv` switches off)
-        auto offset = [](int v) constexpr { return (v & 1) + HX * (((v >> 1) & 1) + HY * ((v >> 2) & 1)); };
+        // (component c of vertex v; slice 1 of an ordinal-only request is not staged: whatever is read there only enters simplices that
+        // `inv` switches off)
         fan_result fr;
         if (FORM >= 2 && fan_fp) {
           const double *base = s_vd + hbase;
-          fr = fan_of_corner3<double>([&](auto V, int c) __attribute__((always_inline)) { constexpr int v = decltype(V)::value; return base[((v >> 3) * 3 + c) * NH + offset(v)]; },
-                                      inv, pos, neg, keep_o, keep_i, p.cull, small ? 0.5 : 4096.0);
+          auto at = [&](auto V, int c) __attribute__((always_inline)) { constexpr int v = decltype(V)::value; return base[((v >> ND) * ND + c) * NH + offset(v)]; };
+          if constexpr (ND == 3) fr = fan_of_corner3<double>(at, inv, pos, neg, keep_o, keep_i, p.cull, small ? 0.5 : 4096.0);
+          else fr = fan_of_corner2<double>(at, inv, pos, neg, keep_o, keep_i, p.cull, 0.5);
         } else {
           const i64 *base = &s_vf[0][0][0] + hbase;
-          fr = fan_of_corner3<int>([&](auto V, int c) __attribute__((always_inline)) { constexpr int v = decltype(V)::value; return (int)base[((v >> 3) * 3 + c) * NH + offset(v)]; },
-                                   inv, pos, neg, keep_o, keep_i, p.cull, 0.0);
+          auto at = [&](auto V, int c) __attribute__((always_inline)) { constexpr int v = decltype(V)::value; return (int)base[((v >> ND) * ND + c) * NH + offset(v)]; };
+          if constexpr (ND == 3) fr = fan_of_corner3<int>(at, inv, pos, neg, keep_o, keep_i, p.cull, 0.0);
+          else fr = fan_of_corner2<int>(at, inv, pos, neg, keep_o, keep_i, p.cull, 0.0);
         }
         tested += fr.tested;
         hits = (u64)fr.hits[0] | ((u64)fr.hits[1] << 32); unsure = (u64)fr.unsure[0] | ((u64)fr.unsure[1] << 32);
@@ -336,20 +408,27 @@ __global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile
       // A value that is zero / INT64_MIN (fp64: not clear of zero): the integer test and the literal cascade on the vertices as staged.
       // One simplex in thousands, but a long computation: the (lane, type) pairs of the whole tile go on a list and are dealt to the lanes
       // again (a lane that walked its own would hold its wavefront for each of them).
-      auto resolve = [&](int lane_tid, int type) -> bool {
+      auto corner_of = [&](int lane_tid, int (&lc)[N]) -> int {
         const int lx = lane_tid % cfg::TX, ly = (lane_tid / cfg::TX) % cfg::TY, lz = lane_tid / (cfg::TX * cfg::TY);
-        const int hb = lx + HX * (ly + HY * lz);
-        const int lc[4] = {origin[0] + lx, origin[1] + ly, origin[2] + lz, f.t};
+        lc[0] = origin[0] + lx; lc[1] = origin[1] + ly;
+        if (ND == 3) lc[2] = origin[2] + lz;
+        lc[ND] = f.t;
+        return lx + HX * (ly + HY * lz);
+      };
+      auto resolve = [&](int lane_tid, int type) -> bool {
+        int lc[N];
+        const int hb = corner_of(lane_tid, lc);
         const unsigned tab = s_tab[type];
-        u64 X[4][3]; int ids[4];
-        for (int i = 0; i < 4; i ++) {
+        u64 X[N][ND]; int ids[N];
+        for (int i = 0; i < N; i ++) {
           const unsigned vm = (tab >> (8 * i)) & 0xffu;
-          const int hidx = hb + (vm & 1) + HX * (((vm >> 1) & 1) + HY * ((vm >> 2) & 1));
-          for (int j = 0; j < 3; j ++) X[i][j] = (u64)s_vf[(vm >> 3) & 1][j][hidx];
-          ids[i] = vertex_id<3>(m, lc, vm);
+          const int hidx = hb + (vm & 1) + HX * (((vm >> 1) & 1) + (ND == 3 ? HY * ((vm >> 2) & 1) : 0));
+          for (int j = 0; j < ND; j ++) X[i][j] = (u64)s_vf[(vm >> ND) & 1][j][hidx];
+          ids[i] = vertex_id<ND>(m, lc, vm);
         }
-        const int r = origin_in_simplex3_try(X, true);
-        return r < 0 ? sos_origin_in_simplex_resolved<3>(X, ids) : r != 0;
+        int r;
+        if constexpr (ND == 2) r = origin_in_simplex2_try(X, true); else r = origin_in_simplex3_try(X, true);
+        return r < 0 ? sos_origin_in_simplex_resolved<ND>(X, ids) : r != 0;
       };
       for (;;) {                                                 // (one round unless the tile has more than kItems of them)
         while (__any(unsure != 0)) {                             // append (wave-uniform trip count)
@@ -374,7 +453,8 @@ __global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile
             const unsigned item = s_items[it];
             const int lane_tid = (int)(item >> 6), type = (int)(item & 63u);
             hit = resolve(lane_tid, type);
-            const int lc[4] = {origin[0] + lane_tid % cfg::TX, origin[1] + (lane_tid / cfg::TX) % cfg::TY, origin[2] + lane_tid / (cfg::TX * cfg::TY), f.t};
+            int lc[N];
+            (void)corner_of(lane_tid, lc);
             desc = core_linear<ND>(m, lc) | ((u64)type << kPassTypeShift) | ((u64)p.step << kPassStepShift);
           }
           emit_pass(m, hit, desc);
@@ -456,8 +536,9 @@ __global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile
       if (kept) atomicAdd(&s_stat[1], kept);
     }
     __syncthreads();
-    if (tid == 0 && s_stat[0]) atomicAdd(&m.counters[CNT_SIMPLICES_TESTED], (u64)s_stat[0]);
-    if (tid == 64 && s_stat[1]) atomicAdd(&m.counters[CNT_CELLS_SURVIVED], (u64)s_stat[1]);
+    u64 *slot = p.stats + 2u * (blockIdx.x & 255u);
+    if (tid == 0 && s_stat[0]) atomicAdd(&slot[0], (u64)s_stat[0]);
+    if (tid == 64 && s_stat[1]) atomicAdd(&slot[1], (u64)s_stat[1]);
   }
   TILE_STAMP(5);
 #ifdef FTKX_TILE_STAMPS
@@ -2363,6 +2444,19 @@ void launch_calib_read(const void *p, size_t bytes, double *scratch, hipStream_t
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
+// the tile kernels' statistics, 256 slots -> the two counters (and the slots cleared for the next batch)
+__global__ __launch_bounds__(256) void tile_stats_fold_kernel(u64 *__restrict__ slots, u64 *__restrict__ counters)
+{
+  u64 a = slots[2 * threadIdx.x], b = slots[2 * threadIdx.x + 1];
+  slots[2 * threadIdx.x] = 0; slots[2 * threadIdx.x + 1] = 0;
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+  if ((threadIdx.x & 63) == 0) {
+    if (a) atomicAdd(&counters[CNT_SIMPLICES_TESTED], a);
+    if (b) atomicAdd(&counters[CNT_CELLS_SURVIVED], b);
+  }
+}
+void launch_tile_stats_fold(u64 *slots, u64 *counters, hipStream_t stream) { hipLaunchKernelGGL(tile_stats_fold_kernel, dim3(1), dim3(256), 0, stream, slots, counters); }
+
 #ifdef FTKX_TILE_STAMPS
 extern "C" void ftkx_debug_tile_stamps(unsigned long long *out, int reset)
 {
@@ -2377,7 +2471,11 @@ void launch_tile(const TileParams &p, hipStream_t stream)
 {
   const unsigned nblocks = (unsigned)p.ntiles[0] * p.ntiles[1] * p.ntiles[2];
   if (nblocks == 0) return;
-  if (p.m.nd == 2) hipLaunchKernelGGL((tile_kernel<2, 0>), dim3(nblocks), dim3(kThreads), 0, stream, p);
+  if (p.m.nd == 2) {
+    if (p.form >= 2) hipLaunchKernelGGL((tile_kernel<2, 2>), dim3(nblocks), dim3(kThreads), 0, stream, p);
+    else if (p.form == 1) hipLaunchKernelGGL((tile_kernel<2, 1>), dim3(nblocks), dim3(kThreads), 0, stream, p);
+    else hipLaunchKernelGGL((tile_kernel<2, 0>), dim3(nblocks), dim3(kThreads), 0, stream, p);
+  }
   else if (p.form >= 2) hipLaunchKernelGGL((tile_kernel<3, 2>), dim3(nblocks), dim3(kThreads), 0, stream, p);
   else if (p.form == 1) hipLaunchKernelGGL((tile_kernel<3, 1>), dim3(nblocks), dim3(kThreads), 0, stream, p);
   else hipLaunchKernelGGL((tile_kernel<3, 0>), dim3(nblocks), dim3(kThreads), 0, stream, p);

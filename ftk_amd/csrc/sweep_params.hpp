@@ -85,7 +85,9 @@ struct TileParams {
   int ntiles[3];
   int step;                  // index of `f` in the batch's device array of Fields (what record_kernel looks it up by)
   int fan;                   // the tests' knob (FTKX_TILE_FAN): 0 = (corner, type) pairs over the lanes everywhere, 1 = no fp64 fan, 2 = as the tiles allow
-  int form;                  // which tile_kernel<3, FORM> to launch: from the slices' largest magnitude x factor where the context knows it
+  int form;                  // which tile_kernel<ND, FORM> to launch: from the slices' largest magnitude x factor where the context knows it
+  u64 *stats;                // 256 x {simplices tested, cells survived}: a workgroup adds to slot blockIdx % 256, tile_stats_fold_kernel sums
+                             // them into the counters (one address for 65 536 workgroups is 0.65 ms of serialised atomics per launch)
 };
 
 // Largest M with 24 M^3 < 2^63 (3D: |det4| of a homogeneous 4x4 with entries <= M) / 6 M^2 < 2^63 (2D): a simplex all of whose

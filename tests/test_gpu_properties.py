@@ -348,6 +348,34 @@ def test_dense_survivors_fall_back_to_the_tile_kernel(gpu):
     assert len(a) > 10000       # mostly bogus records of wrapped determinants, like the reference's
 
 
+@pytest.mark.parametrize("scale", [1.0, 3e4, 3e6, 3e9], ids=["25bit", "32bit", "mixed", "64bit"])
+def test_tile_kernel_forms_agree_2d(gpu, monkeypatch, scale):
+    """the same for the 2D tile kernel (12 triangles per corner; fp64 exact below 2^25, integer below 2^31, pairs above)"""
+    rng = np.random.default_rng(23)
+    dims, nt = (70, 41), 4
+    steps = []
+    for t in range(nt):
+        f = rng.standard_normal(tuple(reversed(dims))) * 0.05 * scale
+        f[5:12, 6:30] = np.round(f[5:12, 6:30] / (0.05 * scale) * 4) / 4 * scale           # many equal values: zero determinants
+        f[20:36, 2:66] = np.round(f[20:36, 2:66] / (0.05 * scale)) * scale                  # (more per tile than its list holds)
+        if scale == 3e6:
+            f[:, :35] *= 1e-4                                                             # half the tiles small, half large
+        f[15, 17] = np.nan
+        steps.append(f)
+    got = {}
+    for fan in ("0", "1", "2"):
+        monkeypatch.setenv("FTKX_TILE_FAN", fan)
+        got[fan] = _run(gpu, None, dims, nt, steps=steps, exact_only=True)
+    monkeypatch.delenv("FTKX_TILE_FAN")
+    for fan in ("1", "2"):
+        _same(got["0"][0], got[fan][0])
+        assert got["0"][2] == got[fan][2]
+        assert got["0"][1]["simplices_tested"] == got[fan][1]["simplices_tested"], fan
+    assert len(got["0"][0]) > 50
+    culled = _run(gpu, None, dims, nt, steps=steps)
+    _same(culled[0], got["0"][0])
+
+
 @pytest.mark.parametrize("scale", [1.0, 300.0, 3e5, 3e9], ids=["16bit", "32bit", "mixed", "64bit"])
 def test_tile_kernel_forms_agree(gpu, monkeypatch, scale):
     """The 3D tile kernel has three forms of the same integer test: (corner, type) pairs over the lanes with 64-bit multiplies; one corner
