@@ -489,9 +489,9 @@ def job(args, env):
         one_pass.factors = f
         return recs, ctx.stats()
 
-    if args.warmup:
+    if args.warmup or pipelined:
         # (two in flight, and a third pass so that one has been queued KNOWING how many records the data gives: both sets of buffers, the
-        # device-side record buffers and the copy stream exist before the clock starts)
+        # device-side record buffers and the copy stream exist before the clock starts -- also when --warmup 0 is asked for)
         recs, st = passes(max(args.warmup, 3) if pipelined else args.warmup)
     # HIP events on the stream the kernels run on: around the dominant (mask) kernel only inside the timed region -- a pair of events costs
     # the stream ~10 us of idle time, which a 0.4 ms pass notices --, around every kernel family in a few extra passes afterwards
