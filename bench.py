@@ -47,6 +47,53 @@ CONFIGS = {
     "small2": (2, 1, "woven", (256, 256), 8),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+STREAM_CEILING_GBS = 6290.0   # what a bare streaming read reaches on this part (same guide: achievable HBM read bandwidth)
+
+# what a pass of each configuration must return (checked in the JSON line, `configs.*.check`):
+#   c1: the reference's own count and type histogram (woven 128 x 128 x 10)
+#   c2 / c5: the count the oracle gives on the very arrays the GPU sweeps (tests/test_gpu_fullsize_series.py holds record-for-record equality)
+#   c3 / c4: the analytic trajectory of the single extremum
+EXPECT = {
+    "c1": {"hits": 7357, "types": {2: 1861, 4: 3657, 8: 1839}, "source": "reference (BASELINE.md section 3)"},
+    "c2": {"hits": 62181, "source": "oracle on the swept arrays (tests/test_gpu_fullsize_series.py::test_c2_series_*)"},
+    "c5": {"hits": 56766, "types_only": [4], "source": "oracle on the swept arrays (tests/test_gpu_fullsize_series.py::test_c5_series_*)"},
+}
+
+
+def spread(samples_ms):
+    """per-pass wall times -> min / median / max"""
+    a = np.sort(np.asarray(samples_ms, dtype=np.float64))
+    return {"ms_per_step_min": float(a[0]), "ms_per_step_median": float(np.median(a)), "ms_per_step_max": float(a[-1])} if len(a) else {}
+
+
+def check_records(name, case, dims, nt, recs, paths, want_paths):
+    """the result of the timed passes against what the configuration must give; -> the `check` object (ok: everything held)"""
+    from ftk_amd import synthetic
+    asc = bool(np.all(np.diff(recs["tag"].astype(np.uint64)) > 0)) if len(recs) > 1 else True
+    out = {"hits": int(len(recs)), "device_driven": all(p in want_paths for p in paths), "paths": sorted(set(str(p) for p in paths)),
+           "tags_ascending_unique": asc}
+    ok = out["device_driven"] and asc
+    exp = EXPECT.get(name)
+    if exp:
+        out["expected_hits"], out["expected_from"] = exp["hits"], exp["source"]
+        ok = ok and len(recs) == exp["hits"]
+        if "types" in exp:
+            t, c = np.unique(recs["type"], return_counts=True)
+            out["types"] = {int(a): int(b) for a, b in zip(t, c)}
+            ok = ok and out["types"] == exp["types"]
+        if "types_only" in exp:
+            out["types"] = sorted(set(int(v) for v in recs["type"]))
+            ok = ok and out["types"] == exp["types_only"]
+    if case == "moving_extremum_3d" and len(recs):
+        x0, dv = synthetic.moving_extremum_params(dims)
+        err = max(float(np.abs(recs["x"][:, a] - (x0[a] + dv[a] * recs["t"])).max()) for a in range(3))
+        out["max_abs_position_error_vs_analytic"] = err
+        out["types"] = sorted(set(int(v) for v in recs["type"]))
+        crossed = len(np.unique(recs["aux"] >> 1)) == nt
+        out["every_timestep_crossed"] = bool(crossed)
+        ok = ok and err < 1e-6 and out["types"] == [2] and crossed and len(recs) >= 2 * nt - 1
+    out["ok"] = bool(ok)
+    return out
 
 
 def glibc_version():
@@ -127,6 +174,8 @@ def side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=5, warmup=2):
     ts = np.arange(nt, dtype=np.int32)
     scopes = np.array([ftk_amd.SCOPE_BOTH if t + 1 < nt else ftk_amd.SCOPE_ORDINAL for t in range(nt)], dtype=np.int32)
     paths = {}
+    path_list = []
+    stamps = []
 
     def passes(k, count):
         # two passes in flight, like the headline run (main(): passes)
@@ -138,18 +187,28 @@ def side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=5, warmup=2):
                 ctx.sweep_series_submit(ts, scopes)
             recs, f, _r = ctx.sweep_series_complete(copy=False)
             if count:
+                stamps.append(time.perf_counter())
                 p = ctx.series_last_path()
+                path_list.append(p)
                 paths[str(p)] = paths.get(str(p), 0) + 1
         return recs, f
     recs, f = passes(max(warmup, 3), False)      # (see main(): everything a pass allocates exists before the clock starts)
-    ctx.set_profiling(2)            # events around the dominant (mask) kernel only
+    # no HIP events inside the timed region of a side configuration: a pair costs the stream ~10 us, which a 0.2 ms pass notices; the
+    # dominant kernel is timed in extra passes behind it
+    ctx.set_profiling(0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     recs, f = passes(steps, True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kt = ctx.kernel_times()
+    recs = np.array(recs)
+    per_pass = np.diff(np.array([t0] + stamps)) * 1e3
     st = ctx.stats()
+    ctx.set_profiling(2)            # events around the dominant (mask) kernel only
+    passes(4, False)
+    torch.cuda.synchronize()
+    kt = ctx.kernel_times()
+    ctx.set_profiling(0)
     domk = max(kt, key=lambda k: kt[k][0])
     dom_ms, dom_n = kt[domk]
     c = 1 if scalar_input else nd
@@ -158,12 +217,16 @@ def side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=5, warmup=2):
     symbol = "ftkx::%s<%d>" % (domk, nd)
     if domk == "mask_kernel":
         symbol = (ctx._L.ftkx_last_mask_kernel() or b"").decode() or symbol
+    want_paths = [(2, 32)] if case == "moving_extremum_3d" else ([(1, 0), (2, 32)] if name == "c1" else [(1, 0)])
     out = {"workload": f"{case} {'x'.join(str(d) for d in dims)}x{nt}", "steps": steps, "ms_per_step": elapsed / steps * 1e3, "value": nsimp * steps / elapsed,
            "simplices_per_step": nsimp, "kernel": symbol, "kernel_avg_launch_ms": dom_ms / max(1, dom_n),
            "frac": alg / (dom_ms / max(1, dom_n) * 1e-3) / 1e9 / HBM_PEAK_GBS if dom_n else None,
+           "frac_of_streaming_ceiling": alg / (dom_ms / max(1, dom_n) * 1e-3) / 1e9 / STREAM_CEILING_GBS if dom_n else None,
            "end_to_end_frac": alg / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg,
            "hits": int(len(recs)), "simplices_tested_exactly": int(st["simplices_tested"]), "nbits": int(np.log2(max(int(v) for v in f))),
-           "series_paths": paths}
+           "series_paths": paths, "check": check_records(name, case, dims, nt, recs, path_list, want_paths),
+           "kernel_timing": "HIP events around the mask kernel in 4 passes BEHIND the timed region (none inside it)"}
+    out.update(spread(per_pass))
     ctx.close()
     del keep
     torch.cuda.empty_cache()
@@ -416,6 +479,7 @@ def job(args, env):
                      "GB/s_per_link": hbytes / (halo_ms * 1e-3) / 1e9 if halo_ms > 0 else None}
 
     series_paths = {}
+    pass_stamps, path_list = [], []      # wall-clock time at which each timed pass's records were on the host; the way each pass went
 
     def one_pass():
         ctx.invalidate_masks()      # every pass redoes ALL the work of the sweep: masks, reduction, factors, cull, exact test, download
@@ -427,6 +491,7 @@ def job(args, env):
             host_ms[1] += (time.perf_counter() - tp0) * 1e3
             p = ctx.series_last_path()
             series_paths[p] = series_paths.get(p, 0) + 1
+            path_list.append(p)
             one_pass.factors = f
             return recs, ctx.stats()
         if multi and own and args.halo_in_loop:
@@ -474,6 +539,7 @@ def job(args, env):
         if not pipelined or k < 2:
             for _ in range(k):
                 out = one_pass()
+                pass_stamps.append(time.perf_counter())
             return out
         tp0 = time.perf_counter()
         ctx.invalidate_masks()
@@ -483,8 +549,10 @@ def job(args, env):
                 ctx.invalidate_masks()
                 ctx.sweep_series_submit(ann_ts, ann_scopes)
             recs, f, _ = ctx.sweep_series_complete(copy=False)
+            pass_stamps.append(time.perf_counter())
             p = ctx.series_last_path()
             series_paths[p] = series_paths.get(p, 0) + 1
+            path_list.append(p)
         host_ms[1] += (time.perf_counter() - tp0) * 1e3
         one_pass.factors = f
         return recs, ctx.stats()
@@ -499,10 +567,14 @@ def job(args, env):
     host_ms[0] = host_ms[1] = host_ms[2] = 0.0
     compact_bytes[0] = compact_bytes[1] = compact_bytes[2] = compact_bytes[3] = 0
     barrier()
+    series_paths.clear()
+    del pass_stamps[:], path_list[:]
     tt0 = time.perf_counter()
     recs, st = passes(args.steps)
     barrier()
     elapsed = time.perf_counter() - tt0
+    per_pass_ms = np.diff(np.array([tt0] + pass_stamps[:args.steps])) * 1e3      # (pipelined: the time between consecutive completions)
+    timed_paths = list(path_list)
     if multi:
         cdev = dev if args.backend == "nccl" else "cpu"
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -580,14 +652,17 @@ def job(args, env):
                      curve_indices=np.concatenate(curves) if curves else np.zeros(0, dtype=np.int64), curve_loop=np.asarray(loop))
         n_hits = len(merged)
 
-    # sanity of the result itself (cheap, size-independent): the single extremum must sit on x0 + dir * t
+    # the result itself against what the configuration must give (cheap, size-independent): the device-driven form was what ran, tags
+    # ascending and unique, the expected count / type histogram (c1, c2, c5) or the single extremum on x0 + dir * t (c3, c4)
     check = {"hits": n_hits}
-    if case == "moving_extremum_3d" and rank == 0 and len(merged) and not args.exact_only:
-        x0, dv = me3d_params(dims)
-        err = max(float(np.abs(merged["x"][:, a] - (x0[a] + dv[a] * merged["t"])).max()) for a in range(3))
-        check["max_abs_position_error_vs_analytic"] = err
-        check["types"] = sorted(set(int(v) for v in merged["type"]))
-        check["curves"] = pass2["curves"]
+    if rank == 0 and not args.exact_only:
+        if not multi and not args.host_driven:
+            want_paths = [(2, 32)] if case == "moving_extremum_3d" else ([(1, 0), (2, 32)] if args.config == "c1" else [(1, 0)])
+            check = check_records(args.config if args.timesteps == 0 else "", case, dims, nt, merged, timed_paths, want_paths)
+        elif case == "moving_extremum_3d" and len(merged):
+            check = check_records("", case, dims, nt, merged, [], [])
+        if pass2:
+            check["curves"] = pass2["curves"]
 
     out = None
     if rank == 0 and args.no_kernel_events:
@@ -632,6 +707,7 @@ def job(args, env):
         out = {
             "metric": "space-time simplices/sec", "value": total_simplices * args.steps / elapsed, "unit": "simplices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            **spread(per_pass_ms),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": f"{case} {'x'.join(str(d) for d in dims)}x{nt} ({args.config}), "
                                    f"{'scalar' if scalar_input else 'vector'} input, t-slab partition over {world} GPU(s): {len(own)} timesteps on rank 0",
@@ -642,7 +718,9 @@ def job(args, env):
                                else "host-driven batch (slices_prepare, host factors, enqueue, collect)",
                        "input_resident": "the field the tracker API is given (S, or V for vector input) in HBM; gradient/Jacobian evaluated in flight"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_symbol, "kernel_family": "ftkx::%s<%d>" % (domk, nd), "avg_launch_ms": avg_ms, "launches_timed": int(dom_n),
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_ratio": (traffic / alg_bytes_launch) if traffic else None,     # HBM bytes moved / algorithmic bytes: > 1 = re-reads
+                         "streaming_ceiling": STREAM_CEILING_GBS, "frac_of_streaming_ceiling": achieved / STREAM_CEILING_GBS, "kernel": kernel_symbol, "kernel_family": "ftkx::%s<%d>" % (domk, nd), "avg_launch_ms": avg_ms, "launches_timed": int(dom_n),
                          "algorithmic_bytes_per_launch": alg_bytes_launch, "slices_per_launch": slices_per_launch,
                          "all_kernels_ms_per_pass": all_ms, "achieved_all_kernels": alg_bytes_pass / (all_ms * 1e-3) / 1e9,
                          "kernel_ms_per_pass": {k: v[0] / n_break for k, v in kt_break.items()},
@@ -675,7 +753,8 @@ def job(args, env):
                 if name == args.config:
                     others[name] = {"workload": out["config"]["workload"], "steps": args.steps, "ms_per_step": out["ms_per_step"], "value": out["value"],
                                     "kernel": kernel_symbol, "kernel_avg_launch_ms": avg_ms, "frac": achieved / HBM_PEAK_GBS,
-                                    "end_to_end_frac": out["roofline_end_to_end"]["frac"], "hits": n_hits, "headline": True}
+                                    "frac_of_streaming_ceiling": achieved / STREAM_CEILING_GBS,
+                                    "end_to_end_frac": out["roofline_end_to_end"]["frac"], "hits": n_hits, "check": check, "headline": True, **spread(per_pass_ms)}
                     continue
                 try:
                     others[name] = side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=3 if name == "c4" else 16, warmup=3)

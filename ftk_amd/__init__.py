@@ -235,6 +235,11 @@ class Context:
         self._ck(self._L.ftkx_sweep_series_complete(self._h, C.byref(run), f.ctypes.data, C.byref(out), C.byref(cnt)))
         return _lib.records_from(out.value, cnt.value, copy), f[:n], run.value
 
+    def sweep_series_abort(self):
+        """ftkx_sweep_series_abort: discard the open passes (after a failed submit / complete, or to give up)"""
+        self._open_series = []
+        self._ck(self._L.ftkx_sweep_series_abort(self._h))
+
     def series_last_path(self):
         """(path, status bits) of the last sweep_series: 1 device-driven, 2 finished by the single-workgroup tail, 0 host-driven batch"""
         st = C.c_ulonglong()

@@ -131,6 +131,7 @@ struct ftkx_series_pending {
   int u_rows = 1;
   u64 cells = 0;
   unsigned seq = 0;
+  unsigned long long uid = 0;       // ftkx_ctx::sr_pass_uid when the pass was queued (owner stamp of the counters and lists)
   double running_in = 0;
   bool chained = false;             // the running minimum came from the pass before it on the device (running_in: what the host knew)
   size_t off_steps = 0;
@@ -219,7 +220,10 @@ struct ftkx_ctx {
   ftkx_series_pending sr_pend[2];
   int sr_open = 0, sr_head = 0;       // passes open, and which of sr_pend is the oldest
   bool sr_internal = false;           // the host-driven batch is sweeping for a series pass: its calls are let through while passes are open
-  int sr_next_buf = 0;
+  // which pass the context's counters and survivor lists (d_counters, d_list, d_refine, d_pass) belong to right now: stamped when a pass's
+  // cull is queued, cleared whenever the host-driven batch takes them (series.hip: a pass whose fused tail declined may queue the rest of
+  // its chain only while they are still its own)
+  unsigned long long sr_pass_uid = 0, sr_lists_owner = 0;
   hipStream_t sr_copy_stream = nullptr, sr_fetch_stream = nullptr;
   unsigned long long mask_epoch = 0;  // source of Slice::mask_gen values
   double sr_last_running = 0;         // the running minimum the host knew when it last collected a pass (hint of a chained pass)

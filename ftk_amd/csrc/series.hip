@@ -29,6 +29,7 @@ int series_by_host(ftkx_ctx *c, const int *ts, const int *scopes, int n, const s
                    const ftkx_cp_t **out, size_t *n_out)
 {
   c->sr_last_path = 0;
+  c->sr_lists_owner = 0;                                      // (the batch takes the counters and the survivor lists over)
   struct Through { ftkx_ctx *c; bool was; ~Through() { c->sr_internal = was; } } through{c, c->sr_internal};
   c->sr_internal = true;
   const unsigned long long hint = std::max<unsigned long long>(factor_of(*running), 256ull);
@@ -552,7 +553,7 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
   // PCIe itself holds its stream for the transfer: 106 us of woven 1024^2 x 64's 363.)
   static const bool sdma_on = !(getenv("FTKX_SERIES_COPY") && atoi(getenv("FTKX_SERIES_COPY")) == 0);
   P.to_device = pipelined && sdma_on && c->stats.hits > 4096;
-  P.buf = c->sr_next_buf; c->sr_next_buf ^= 1;
+  P.buf = (int)(&P - c->sr_pend);                             // (a pass's buffers go with its place in sr_pend: nothing to undo when a step below fails)
   ftkx_series_buffers &B = c->sr_buf[P.buf];
   if ((rc = ensure_series_buffers(c, B, nwords, total, P.to_device))) return rc;
   if (P.to_device && !c->sr_copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->sr_copy_stream, hipStreamNonBlocking));
@@ -616,6 +617,8 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
   }
   if (ntodo) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs, (int)ntodo, c->stream); ev_end(c); }
   ev_begin(c, K_CULL);
+  P.uid = ++ c->sr_pass_uid;
+  c->sr_lists_owner = P.uid;                                  // (from here on the counters and lists hold this pass's cull)
   {
     // the factors need what the mask kernel left, the cull does not need the factors: one extra workgroup of the cull kernel forms them
     // (series_device.hpp) -- a kernel boundary and a one-workgroup launch less than the factor kernel behind the cull
@@ -679,9 +682,10 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
   if (const char *why = ftkx::wait_flag(flag, P.seq, c->stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
   if (P.short_chain) {
     const unsigned long long st = B.h_results[ftkx::SR_STATUS];
-    if ((st & ftkx::SERIES_TAIL_PENDING) && c->sr_open > 0) {
-      // (the rest of this pass cannot be queued behind the pass that is already out -- that one has the counters and lists now: the
-      // host-driven batch sweeps the steps; it happens once, when sparse data turns dense)
+    if ((st & ftkx::SERIES_TAIL_PENDING) && (c->sr_open > 0 || c->sr_lists_owner != P.uid)) {
+      // (the rest of this pass cannot be queued: the counters and lists are not this pass's any more -- the pass queued behind it has them
+      // now, or the host-driven batch took them when the pass BEFORE this one fell back (two short-chain passes that both declined,
+      // completed back to back).  The host-driven batch sweeps the steps; it happens when sparse data turns dense)
       c->sr_short_chain = false;
       ev_end(c);
       int rc = series_by_host(c, P.ts.data(), P.scopes.data(), n, P.slice_ts, &running, factors, out, n_out);
@@ -837,6 +841,31 @@ int ftkx_sweep_series_complete(ftkx_ctx *c, double *running_resolution, unsigned
   int rc = series_complete(c, P, running_resolution, factors, out, n_out);
   if (rc == FTKX_OK) c->sr_last_running = *running_resolution;
   return rc;
+}
+
+int ftkx_sweep_series_abort(ftkx_ctx *c)
+{
+  if (!c) return FTKX_E_INVALID;
+  if (c->sr_open == 0) return FTKX_OK;
+  (void)hipSetDevice(c->device);
+  // whatever the open passes queued runs to its end (their kernels write buffers that stay allocated); nothing of it is read
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (c->sr_copy_stream && e == hipSuccess) e = hipStreamSynchronize(c->sr_copy_stream);
+  for (ftkx_series_pending &P : c->sr_pend) {
+    if (!P.open) continue;
+    // the masks this pass was building are nobody's: built, but never marked
+    for (size_t j = 0; j < P.k && j < P.red_index.size(); j ++) {
+      auto it = c->slices.find(P.slice_ts[j]);
+      if (P.red_index[j] >= 0 && it != c->slices.end() && it->second.mask_gen == P.gen[j]) { it->second.mask_factor = 0; it->second.have_fused = false; }
+    }
+    P.open = false; P.copy_pending = false;
+  }
+  for (ftkx_series_buffers &B : c->sr_buf) B.copy_out = false;
+  c->sr_open = 0; c->sr_head = 0;
+  c->sr_short_chain = false; c->sr_lists_owner = 0; c->sr_last_running = 0;
+  c->ahead.clear(); c->announced.clear();
+  if (e != hipSuccess) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series_abort: %s", hipGetErrorString(e));
+  return FTKX_OK;
 }
 
 int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, double *running_resolution, unsigned long long *factors,

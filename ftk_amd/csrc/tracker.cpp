@@ -194,7 +194,15 @@ void critical_point_tracker_regular::collect_open_step() const
   unsigned long long f = 0;
   double res = vector_field_resolution;
   const int rc = ftkx_sweep_series_complete(ctx, &res, &f, &recs, &n);
-  if (rc != FTKX_OK) { open_steps.clear(); check(rc); }
+  if (rc != FTKX_OK) {
+    // the other open pass (if any) is discarded with it: the context is left as if nothing had been queued, so that the tracker's later
+    // calls do not fail with "passes open" or chain from a stale running minimum
+    char why[512] = "";
+    ftkx_last_error(ctx, why, sizeof(why));
+    open_steps.clear();
+    (void)ftkx_sweep_series_abort(ctx);
+    throw ftkx_error(rc, why);
+  }
   self->vector_field_resolution = res;
   self->vector_field_scaling_factor = f;
   self->take_records(recs, n, t);

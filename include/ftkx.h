@@ -211,10 +211,15 @@ int ftkx_sweep_series(ftkx_ctx *ctx, const int *timesteps, const int *scopes, in
  * running_resolution of _submit: the running minimum before this pass, or NULL = continue from the pass queued before it, still open
  * (the minimum is handed on ON THE DEVICE; _complete then reports the chained value).  Between _submit and _complete only slices may be
  * pushed or dropped and further passes submitted; the sweeps above and ftkx_slices_prepare fail until every open pass is complete.
- * Records of a pass: valid until the next _submit (or any other sweep call) after its _complete -- that pass takes over its buffers.  Results are those of ftkx_sweep_series on the same steps:
- * tests/test_gpu_series.py::test_pipelined_passes_equal_the_plain_ones. */
+ * Records of a pass: valid until the next _submit OR the next _complete (or any other sweep call) after its own _complete -- a pass that
+ * the host-driven batch had to sweep returns the context's shared host buffer, which the next such completion overwrites; a device-driven
+ * pass's buffers are taken over by the second _submit after it.  Copy what must live longer.  Results are those of ftkx_sweep_series on
+ * the same steps: tests/test_gpu_series.py::test_pipelined_passes_equal_the_plain_ones.
+ * _abort: after a failed _submit / _complete (or to give up): waits for whatever the open passes queued, discards them and leaves the
+ * context as if no pass had been submitted (masks they were building are rebuilt by the next sweep); FTKX_OK with nothing open. */
 int ftkx_sweep_series_submit(ftkx_ctx *ctx, const int *timesteps, const int *scopes, int n, const double *running_resolution);
 int ftkx_sweep_series_complete(ftkx_ctx *ctx, double *running_resolution, unsigned long long *factors, const ftkx_cp_t **out, size_t *n_out);
+int ftkx_sweep_series_abort(ftkx_ctx *ctx);
 /* which way the last ftkx_sweep_series went: 1 = device-driven, 2 = device-driven and finished by the fused tail kernel (sparse
  * data), 3 = device-driven in chunks (hit-dense data: the tail of a chunk runs next to the mask kernel of the next), 0 = host-driven batch; *status (nullable) = the SERIES_* bits the kernels raised (csrc/sweep_params.hpp) */
 int ftkx_series_last_path(const ftkx_ctx *ctx, unsigned long long *status);

@@ -1,0 +1,200 @@
+"""The TIMED path at the TIMED sizes.  bench.py's `passes()` (bench.py: job) is `invalidate_masks` + `ftkx_sweep_series_submit`, two passes in
+flight, `ftkx_sweep_series_complete`; its latency figure is `ftkx_sweep_series` on its own.  These tests run exactly that on BASELINE.json's
+configurations C2 .. C5 at their full sizes and hold EVERY pass -- the first pipelined one, the last, the one on its own -- to
+
+  * the oracle on the very arrays the GPU swept (C2 woven 1024^2 x 64, C5 double_gyre 2048 x 1024 x 128),
+  * the analytic trajectory and an `exact_only` sweep of a 64^3 core around it (C3 256^3 x 16, C4 512^3 x 32),
+  * record-for-record equality with the host-driven batch (ftkx_slices_prepare / _enqueue / _collect) on the same context,
+
+and assert `ftkx_series_last_path`: a pass that silently fell back to the host-driven batch does not pass as the device-driven one.
+Reference behaviour: critical_point_tracker_2d_regular.hh:263-433, critical_point_tracker_3d_regular.hh:150-308 (update_timestep)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SERIES_EARLY = 32          # csrc/sweep_params.hpp: the fused tail kernel finished the pass
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available()
+    import ftk_amd
+    from ftk_amd import build
+    build.build()
+    return ftk_amd
+
+
+def _bytes_equal(a, b):
+    return len(a) == len(b) and np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes()
+
+
+class Resident:
+    """a BASELINE configuration resident on the GPU, driven the way bench.py drives it"""
+
+    def __init__(self, gpu, case, dims, nt, nv=1, keep_host=False, core=None, exact_only=False):
+        import torch
+        from ftk_amd import synthetic
+        self.gpu, self.torch, self.nt, self.nd, self.nv = gpu, torch, nt, len(dims), nv
+        scalar = nv == 1
+        dev = torch.device("cuda", 0)
+        lo = 2 if scalar else 1
+        dom = ([lo] * self.nd, [d - (3 if scalar else 2) for d in dims])
+        stream = torch.cuda.Stream(device=dev)          # a real stream shared with the library, as in bench.py
+        torch.cuda.set_stream(stream)
+        self.ctx = gpu.Context(self.nd)
+        self.ctx.set_stream(stream.cuda_stream)
+        self.ctx.set_mesh(dom, core or dom, ([0] * self.nd, list(dims)))
+        self.ctx.set_options(jacobian_symmetric=scalar, derive_jacobian=1, tag_mode=gpu.TAG_EXACT64, exact_only=exact_only)
+        self.keep, self.host = [], []
+        for t in range(nt):
+            a = synthetic.generate(case, dims, t, nt, torch, dev)
+            torch.cuda.synchronize()
+            self.keep.append(a)
+            if keep_host:
+                self.host.append(a.cpu().numpy())
+            (self.ctx.push_scalar_slice if scalar else self.ctx.push_slice)(t, a)
+        self.ts = np.arange(nt, dtype=np.int32)
+        self.scopes = np.array([gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)], dtype=np.int32)
+
+    def pipelined(self, k):
+        """bench.py's passes(k): -> [(records, factors, path)] of every pass"""
+        ctx, out = self.ctx, []
+        ctx.invalidate_masks()
+        ctx.sweep_series_submit(self.ts, self.scopes)
+        for i in range(1, k + 1):
+            if i < k:
+                ctx.invalidate_masks()
+                ctx.sweep_series_submit(self.ts, self.scopes)
+            recs, f, _ = ctx.sweep_series_complete(copy=True)
+            out.append((recs, [int(v) for v in f], ctx.series_last_path()))
+        return out
+
+    def alone(self):
+        """bench.py's one_pass(): ftkx_sweep_series with nothing else in flight"""
+        self.ctx.invalidate_masks()
+        recs, f, _ = self.ctx.sweep_series(self.ts, self.scopes, copy=True)
+        return recs, [int(v) for v in f], self.ctx.series_last_path(), self.ctx.stats()
+
+    def batch(self):
+        """the host-driven batch on the same context: slices_prepare, factors on the host, enqueue, collect"""
+        from ftk_amd import tslab
+        self.ctx.invalidate_masks()
+        rm = self.ctx.slices_prepare(range(self.nt), 0)
+        factors = tslab.factors_from_resolutions([rm[t][0] for t in range(self.nt)])
+        self.ctx.sweep_enqueue_many(self.ts, self.scopes, factors)
+        return self.ctx.sweep_collect(copy=True), [int(f) for f in factors], self.ctx.stats()
+
+    def close(self):
+        self.ctx.close()
+        self.keep = None
+        self.torch.cuda.set_stream(self.torch.cuda.default_stream())
+        self.torch.cuda.empty_cache()
+
+
+def _timed_path(gpu, case, dims, nt, nv, want_path, keep_host=False, k=5):
+    """-> (records, factors, host arrays, stats of the pass on its own) after every form of the pass has been held to every other"""
+    R = Resident(gpu, case, dims, nt, nv, keep_host=keep_host)
+    try:
+        R.pipelined(3)                                   # bench.py's warm-up: both buffer sets, the copy stream, the record count known
+        runs = R.pipelined(k)
+        for i, (recs, f, path) in enumerate(runs):
+            assert path == want_path, (i, path, "a pass of the timed loop left the device-driven form")
+            assert f == runs[0][1], (i, "factors differ between passes")
+            assert _bytes_equal(recs, runs[0][0]), (i, len(recs), len(runs[0][0]), "pass %d differs from the first pipelined pass" % i)
+        recs, f, path, st = R.alone()
+        assert path == want_path, path
+        assert f == runs[0][1] and _bytes_equal(recs, runs[0][0]), "ftkx_sweep_series on its own differs from the pipelined passes"
+        b_recs, b_f, b_st = R.batch()
+        assert b_f == f, (b_f[:4], f[:4])
+        assert _bytes_equal(b_recs, recs), (len(b_recs), len(recs), "the host-driven batch differs")
+        assert b_st["work_items"] == st["work_items"]
+        # and back: the context that has just run the batch takes the device-driven form again
+        again = R.pipelined(2)
+        assert all(p == want_path and _bytes_equal(r, recs) for r, _, p in again), [p for _, _, p in again]
+        return recs, f, R.host, st
+    finally:
+        R.close()
+
+
+def _assert_equals_oracle(oracle, recs, host_steps, nd, nv, factors, what):
+    ref, rf, secs = oracle.track(host_steps, nd, nv, tag_mode=oracle.TAG_EXACT64, nthreads=os.cpu_count() or 1)
+    assert [int(f) for f in rf] == [int(f) for f in factors], what
+    assert len(ref) == len(recs), (what, len(ref), len(recs))
+    ref = ref[np.argsort(ref["tag"], kind="stable")]
+    assert np.array_equal(ref["tag"], recs["tag"]) and np.array_equal(ref["type"], recs["type"]), what
+    assert np.array_equal(ref["ordinal"].astype(np.uint32), recs["aux"] & 1) and np.array_equal(ref["timestep"].astype(np.uint32), recs["aux"] >> 1), what
+    for f in ("x", "t"):
+        assert np.array_equal(ref[f], recs[f]), (what, f)           # bit-identical (north_star asks for 1e-6)
+    assert np.array_equal(ref["scalar"][:, 0], recs["scalar"][:, 0]), what
+
+
+def _analytic_3d(gpu, recs, st, f, dims, nt):
+    from ftk_amd import synthetic, tslab
+    assert st["work_items"] == tslab.count_simplices(3, dims, nt) and st["cull_enabled"] == 1
+    assert set(f) == {256}                                                             # dyadic parameters: nbits 8
+    x0, dv = synthetic.moving_extremum_params(dims)
+    assert len(recs) >= 2 * nt - 1 and set(recs["type"].tolist()) == {2}               # one minimum, every record a MIN
+    for a in range(3):
+        assert np.abs(recs["x"][:, a] - (x0[a] + dv[a] * recs["t"])).max() < 1e-6      # north_star tolerance (observed ~1e-13)
+    assert np.all(np.diff(recs["tag"].astype(np.uint64)) > 0)                         # in tag order, unique
+    ordinal = recs[(recs["aux"] & 1) == 1]
+    assert np.array_equal(ordinal["t"], (ordinal["aux"] >> 1).astype(float))
+    assert np.array_equal(np.unique(recs["aux"] >> 1), np.arange(nt))                  # the trajectory crosses every slice
+    # every simplex of a 64^3 core around the path through the integer test: exactly the records of the culled, device-driven pass
+    lo = [int(x0[a]) - 24 for a in range(3)]
+    E = Resident(gpu, "moving_extremum_3d", dims, nt, core=(lo, [64, 64, 64]), exact_only=True)
+    try:
+        sub, sub_f, path, st_e = E.alone()
+    finally:
+        E.close()
+    assert path[0] == 0                                 # (exact_only is the host-driven batch's: the tile kernel)
+    assert st_e["cull_enabled"] == 0 and st_e["simplices_tested"] > 1000 * st["simplices_tested"]
+    c = recs["x"]
+    assert all(lo[a] <= c[:, a].min() and c[:, a].max() < lo[a] + 64 for a in range(3))
+    assert sub_f == f and _bytes_equal(sub, recs)
+
+
+def test_c2_series_woven_1024x1024x64(gpu, oracle):
+    """BASELINE configs[1] through the timed path: hit-dense 2D, the bucket-ordering chain (path 1), records over the copy kernel"""
+    from ftk_amd import tslab
+    dims, nt = (1024, 1024), 64
+    big_host = (os.cpu_count() or 1) >= 32
+    recs, f, host, st = _timed_path(gpu, "woven", dims, nt, 1, (1, 0), keep_host=big_host)
+    assert st["work_items"] == tslab.count_simplices(2, dims, nt) == 790170278 and st["cull_enabled"] == 1
+    assert len(recs) > 50000 and set(recs["type"].tolist()) <= {1, 2, 4, 8}
+    assert np.all(np.diff(recs["tag"].astype(np.uint64)) > 0)
+    if big_host:
+        _assert_equals_oracle(oracle, recs, host, 2, 1, f, "c2 series vs oracle")
+
+
+def test_c5_series_double_gyre_2048x1024x128(gpu, oracle):
+    """BASELINE configs[4] through the timed path: vector input, nbits 21"""
+    from ftk_amd import tslab
+    dims, nt = (2048, 1024), 128
+    big_host = (os.cpu_count() or 1) >= 32
+    recs, f, host, st = _timed_path(gpu, "double_gyre", dims, nt, 2, (1, 0), keep_host=big_host)
+    assert st["work_items"] == tslab.count_simplices(2, dims, nt, scalar_input=False) == 3190884312 and st["cull_enabled"] == 1
+    assert set(f) == {1 << 21}
+    assert len(recs) > nt and set(recs["type"].tolist()) == {4}
+    assert np.all(np.diff(recs["tag"].astype(np.uint64)) > 0)
+    if big_host:
+        _assert_equals_oracle(oracle, recs, host, 2, 2, f, "c5 series vs oracle")
+
+
+def test_c3_series_moving_extremum_256cubed_x16(gpu):
+    """BASELINE configs[2] through the timed path: sparse 3D, the fused tail (path 2)"""
+    dims, nt = (256, 256, 256), 16
+    recs, f, _, st = _timed_path(gpu, "moving_extremum_3d", dims, nt, 1, (2, SERIES_EARLY))
+    _analytic_3d(gpu, recs, st, f, dims, nt)
+
+
+def test_c4_series_moving_extremum_512cubed_x32(gpu):
+    """BASELINE configs[3], the headline: 512^3 x 32 through the timed path (tail-chunked mask launch, fused tail)"""
+    dims, nt = (512, 512, 512), 32
+    recs, f, _, st = _timed_path(gpu, "moving_extremum_3d", dims, nt, 1, (2, SERIES_EARLY), k=4)
+    assert st["work_items"] == 246073579314
+    _analytic_3d(gpu, recs, st, f, dims, nt)

@@ -276,6 +276,54 @@ def test_short_chain_and_its_way_back(gpu, monkeypatch):
     assert paths[1] in (0, 1) and paths[3] == 1, (paths, [w[2] for w in want])
     assert len(want[1][0]) > 2000
 
+def test_two_declined_short_chain_passes_completed_back_to_back(gpu, monkeypatch):
+    """ADVICE r03 (series.hip): sparse data puts the context into the short chain; then TWO dense passes are submitted, both fused tails
+    decline, and both are completed with no submit in between.  The first falls to the host-driven batch (a pass is open behind it), which
+    takes the counters and survivor lists the second pass's cull left -- the second must not queue the rest of its chain on them."""
+    import torch
+    from ftk_amd import synthetic
+    dev = torch.device("cuda", 0)
+    dims, nt = (96, 80), 6
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    sparse = [synthetic.generate("moving_extremum_2d", dims, t, nt, torch, dev).cpu().numpy() for t in range(nt)]
+    rng = np.random.default_rng(5)
+    dense_a = [synthetic.generate("woven", dims, t, nt, torch, dev).cpu().numpy() + 0.3 * rng.standard_normal(dims[::-1]) for t in range(nt)]
+    dense_b = [d + 0.2 * rng.standard_normal(d.shape) for d in dense_a]
+
+    def push(ctx, steps, t0=0):
+        for t in range(nt):
+            ctx.push_scalar_slice(t0 + t, steps[t])
+
+    monkeypatch.setenv("FTKX_SERIES_SHORT", "0")
+    want = []
+    for steps in (dense_a, dense_b):
+        ctx = _ctx(gpu, dims, 2, 1, tag_mode=gpu.TAG_EXACT64)
+        push(ctx, steps)
+        r, f, _ = ctx.sweep_series(range(nt), scopes)
+        want.append((r.copy(), [int(v) for v in f]))
+        ctx.close()
+    monkeypatch.delenv("FTKX_SERIES_SHORT")
+    ctx = _ctx(gpu, dims, 2, 1, tag_mode=gpu.TAG_EXACT64)
+    push(ctx, sparse)
+    ctx.sweep_series(range(nt), scopes)
+    assert ctx.series_last_path()[0] == 2                       # the fused tail finished it: the next passes go out as short chains
+    # the two dense series live side by side at timesteps 100.. and 200.. (tags carry the timestep: compare everything else)
+    push(ctx, dense_a, 100); push(ctx, dense_b, 200)
+    ctx.sweep_series_submit(np.arange(100, 100 + nt), scopes)
+    ctx.sweep_series_submit(np.arange(200, 200 + nt), scopes)
+    got = []
+    for _ in range(2):
+        r, f, _ = ctx.sweep_series_complete()
+        got.append((r.copy(), [int(v) for v in f], ctx.series_last_path()))
+    ctx.close()
+    for i, t0 in enumerate((100, 200)):
+        g, w = got[i][0], want[i][0]
+        assert got[i][1] == want[i][1], (i, got[i][1], want[i][1])
+        assert len(g) == len(w) and len(w) > 2000, (i, len(g), len(w), got[i][2])
+        assert np.array_equal(g["type"], w["type"]) and np.array_equal(g["x"][:, :2], w["x"][:, :2]) and np.allclose(g["t"], w["t"] + t0, rtol=0, atol=1e-9), (i, got[i][2])
+        assert np.array_equal(g["scalar"], w["scalar"]) and np.array_equal(g["aux"] & 1, w["aux"] & 1) and np.array_equal(g["aux"] >> 1, (w["aux"] >> 1) + t0)
+
+
 
 @pytest.mark.parametrize("name", ["woven_128x128x10", "woven_31x37x32", "double_gyre_64x32x50", "merger_2d_32x32x100", "moving_extremum_3d_21x21x21x32",
                                   "adversarial_3d_scalar_9x9x9x4", "random_2d_scalar_29x24x6_saddles", "adversarial_3d_scalar_9x9x9x3_norobust"])
