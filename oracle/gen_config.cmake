@@ -2,6 +2,8 @@
 # (/root/reference/include/ftk/config.hh.in, consumed by /root/reference/CMakeLists.txt:355-359)
 # with every optional dependency OFF -- the reference's default configuration.
 # Run as: cmake -DREF=/root/reference -DOUT=<dir> -P gen_config.cmake
+# -DFTK_HAVE_HIP=1 (oracle/Makefile, shim target): the same generation from the PATCHED template of patches/ftk-xl-hip.patch, with the
+# one option that patch adds switched on.
 # This is the ONLY use of cmake: the reference's build system (its CMakeLists.txt) is never run.
 file(READ "${REF}/version.txt" FTK_VERSION)
 string(STRIP "${FTK_VERSION}" FTK_VERSION)

@@ -30,74 +30,14 @@
 #include <ftk/filters/critical_point_tracker_3d_regular.hh>
 
 #ifdef FTKX_SHIM
-// Built a second time as oracle/_ref/ftk_shim_driver: the same REAL reference trackers, but update_timestep() takes the
-// reference's ACCELERATOR branch (critical_point_tracker_2d_regular.hh:332-429, ..._3d_regular.hh:203-304) with the call sites
-// bound to libftkx.so through include/ftkx_shim.hh -- i.e. the patch INTEGRATION.md sections 3-4 describe, executed: the
-// reference's own lattices, its own from_work_index / to_integer round trip (2d:387-395), its own std::map and its own
-// finalize().  The two caller defects the patch must not inherit are fixed as INTEGRATION.md says (domain sizes, Sl in 3D).
-#include "ftkx_shim.hh"
-
-struct hip_tracker_2d : public ftk::critical_point_tracker_2d_regular {
-  hip_tracker_2d(diy::mpi::communicator comm) : ftk::critical_point_tracker_2d_regular(comm), ftk::tracker(comm) {}
-  void update_timestep() override {
-    update_vector_field_scaling_factor();                                  // 2d:267-269
-    typedef ftk::simplicial_regular_mesh_element element_t;
-    const auto &s0 = field_data_snapshots[0];
-    ftk::lattice domain3({domain.start(0), domain.start(1), 0}, {domain.size(0), domain.size(1), (size_t)std::numeric_limits<int>::max()});   // NOT size - 1
-    ftk::lattice core({local_domain.start(0), local_domain.start(1), static_cast<size_t>(current_timestep)}, {local_domain.size(0), local_domain.size(1), 1});
-    ftk::lattice ext({0, 0}, {s0.vector.dim(1), s0.vector.dim(2)});
-    auto sdata = [](const ftk::ndarray<double> &a) -> const double * { return a.empty() ? NULL : a.data(); };
-    for (int scope : {ftk::ELEMENT_SCOPE_ORDINAL, ftk::ELEMENT_SCOPE_INTERVAL}) {
-      const bool interval = scope == ftk::ELEMENT_SCOPE_INTERVAL;
-      if (interval && field_data_snapshots.size() < 2) break;
-      const auto *s1 = interval ? &field_data_snapshots[1] : nullptr;
-      auto results = ftkx::extract_cp2dt_hip<ftk::feature_point_lite_t>(scope, current_timestep, domain3, core, ext,
-          s0.vector.data(), s1 ? s1->vector.data() : NULL, sdata(s0.jacobian), s1 ? sdata(s1->jacobian) : NULL, sdata(s0.scalar), s1 ? sdata(s1->scalar) : NULL,
-          use_explicit_coords, coords.data(), vector_field_scaling_factor, is_jacobian_field_symmetric, use_type_filter, type_filter);
-      for (auto lcp : results) {                                           // 2d:387-395, 416-424, verbatim
-        ftk::feature_point_t cp(lcp);
-        element_t e(3, 2);
-        e.from_work_index(m, cp.tag, core, scope);
-        cp.tag = e.to_integer(m);
-        cp.ordinal = !interval;
-        cp.timestep = current_timestep;
-        discrete_critical_points[e] = cp;
-      }
-    }
-  }
-};
-
-struct hip_tracker_3d : public ftk::critical_point_tracker_3d_regular {
-  hip_tracker_3d(diy::mpi::communicator comm) : ftk::critical_point_tracker_3d_regular(comm), ftk::tracker(comm) {}
-  void update_timestep() override {
-    update_vector_field_scaling_factor();                                  // 3d:155-157
-    typedef ftk::simplicial_regular_mesh_element element_t;
-    const auto &s0 = field_data_snapshots[0];
-    ftk::lattice domain4({domain.start(0), domain.start(1), domain.start(2), 0},
-                         {domain.size(0), domain.size(1), domain.size(2), (size_t)std::numeric_limits<int>::max()});
-    ftk::lattice core({local_domain.start(0), local_domain.start(1), local_domain.start(2), static_cast<size_t>(current_timestep)},
-                      {local_domain.size(0), local_domain.size(1), local_domain.size(2), 1});
-    ftk::lattice ext({0, 0, 0}, {s0.vector.dim(1), s0.vector.dim(2), s0.vector.dim(3)});
-    auto sdata = [](const ftk::ndarray<double> &a) -> const double * { return a.empty() ? NULL : a.data(); };
-    for (int scope : {ftk::ELEMENT_SCOPE_ORDINAL, ftk::ELEMENT_SCOPE_INTERVAL}) {
-      const bool interval = scope == ftk::ELEMENT_SCOPE_INTERVAL;
-      if (interval && field_data_snapshots.size() < 2) break;
-      const auto *s1 = interval ? &field_data_snapshots[1] : nullptr;
-      auto results = ftkx::extract_cp3dt_hip<ftk::feature_point_lite_t>(scope, current_timestep, domain4, core, ext,
-          s0.vector.data(), s1 ? s1->vector.data() : NULL, sdata(s0.jacobian), s1 ? sdata(s1->jacobian) : NULL, sdata(s0.scalar), s1 ? sdata(s1->scalar) : NULL /* snapshot 1, not 0 twice */,
-          vector_field_scaling_factor, is_jacobian_field_symmetric, enable_robust_detection);
-      for (auto lcp : results) {                                           // 3d:262-270, 288-296, verbatim
-        ftk::feature_point_t cp(lcp);
-        element_t e(4, 3);
-        e.from_work_index(m, cp.tag, core, scope);
-        cp.tag = e.to_integer(m);
-        cp.ordinal = !interval;
-        cp.timestep = current_timestep;
-        discrete_critical_points[e] = cp;
-      }
-    }
-  }
-};
+// Built a second time as oracle/_ref/ftk_shim_driver, against the reference's headers WITH patches/ftk-xl-hip.patch applied (oracle/Makefile
+// applies it to a scratch copy) and linked with the patch's new source file: the same REAL reference trackers, told use_accelerator("hip").
+// Nothing is overridden here: update_timestep() is the reference's, its accelerator branch (critical_point_tracker_2d_regular.hh:332-429,
+// ..._3d_regular.hh:203-304) calls libftkx.so through the patch's extract_cp{2,3}dt_hip, and the reference's own lattices, its own
+// from_work_index / to_integer round trip (2d:387-395), its own std::map and its own finalize() consume the records.
+#if !FTK_HAVE_HIP
+#error "FTKX_SHIM: build against the patched reference headers (oracle/Makefile, target shim)"
+#endif
 #endif
 
 struct input_t {
@@ -244,6 +184,9 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
       tracker.set_coords_explicit(ec);
     }
   }
+#ifdef FTKX_SHIM
+  tracker.use_accelerator("hip");      // filter.hh (patched): FTK_XL_HIP -- update_timestep() takes the accelerator branch into libftkx.so
+#endif
   tracker.initialize();
   // FTK_REF_T0: the series starts at a later timestep (tracker::set_current_timestep, filters/tracker.hh:40) -- with a large value
   // the int products of element::to_integer (simplicial_regular_mesh.hh:496-502) and the int truncation of simplex_indices
@@ -413,12 +356,7 @@ int main(int argc, char **argv)
     if (argc > 3) nthreads = atoi(argv[3]);
   } else return 2;
 
-#ifdef FTKX_SHIM
-  if (in.nd == 2) run<hip_tracker_2d>(in, nthreads, out, robust, type_filter, degrees, bounds);
-  else run<hip_tracker_3d>(in, nthreads, out, robust, type_filter, degrees, bounds);
-#else
   if (in.nd == 2) run<ftk::critical_point_tracker_2d_regular>(in, nthreads, out, robust, type_filter, degrees, bounds);
   else run<ftk::critical_point_tracker_3d_regular>(in, nthreads, out, robust, type_filter, degrees, bounds);
-#endif
   return 0;
 }
