@@ -478,11 +478,27 @@ def job(args, env):
         halo_info = {"in_timed_region": bool(args.halo_in_loop), "ms": halo_ms, "bytes_per_rank": hbytes,
                      "GB/s_per_link": hbytes / (halo_ms * 1e-3) / 1e9 if halo_ms > 0 else None}
 
+    # N > 1: the device-driven slab pass (ftk_amd/tslab.py: SlabSeries over ftkx_series_dist_*) -- masks + reduction, the all_gather of
+    # the ranks' contributions, the compact halo's three neighbour messages, cull, factors, exact test and records queued on the stream,
+    # ONE host wait per pass, two passes in flight; --host-driven: round 2's sequence (prepare, host all_gather, enqueue, collect)
+    slab = None
+    if multi and not args.host_driven and args.compact_halo and not args.exact_only:
+        slab = tslab.SlabSeries(ctx, nt, own, scalar_input, torch, dev, first_slice=slices[own[0]] if own else None)
     series_paths = {}
     pass_stamps, path_list = [], []      # wall-clock time at which each timed pass's records were on the host; the way each pass went
 
     def one_pass():
         ctx.invalidate_masks()      # every pass redoes ALL the work of the sweep: masks, reduction, factors, cull, exact test, download
+        if slab is not None:
+            tp0 = time.perf_counter()
+            slab.submit()
+            recs, f, _ = slab.complete(copy=False)
+            host_ms[1] += (time.perf_counter() - tp0) * 1e3
+            if own:
+                series_paths[slab.last_path] = series_paths.get(slab.last_path, 0) + 1
+                path_list.append(slab.last_path)
+            one_pass.factors = f if own else factors
+            return recs, ctx.stats()
         if not multi and not args.host_driven:
             # one GPU: the device-driven pass -- masks + reduction, factors (on the device), cull, exact test, records, their order and
             # their way into the pinned host buffer queued at once; the host waits once (ftkx_sweep_series)
@@ -530,7 +546,7 @@ def job(args, env):
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipelined = (not multi) and (not args.host_driven) and (not args.no_pipeline) and (not args.exact_only)
+    pipelined = (not multi or slab is not None) and (not args.host_driven) and (not args.no_pipeline) and (not args.exact_only)
 
     def passes(k):
         """k passes.  One GPU, device-driven: two passes in flight (ftkx_sweep_series_submit / _complete) -- the host prepares and queues
@@ -542,19 +558,22 @@ def job(args, env):
                 pass_stamps.append(time.perf_counter())
             return out
         tp0 = time.perf_counter()
-        ctx.invalidate_masks()
-        ctx.sweep_series_submit(ann_ts, ann_scopes)
+
+        def submit():
+            ctx.invalidate_masks()
+            slab.submit() if slab is not None else ctx.sweep_series_submit(ann_ts, ann_scopes)
+        submit()
         for i in range(1, k + 1):
             if i < k:
-                ctx.invalidate_masks()
-                ctx.sweep_series_submit(ann_ts, ann_scopes)
-            recs, f, _ = ctx.sweep_series_complete(copy=False)
+                submit()
+            recs, f, _ = slab.complete(copy=False) if slab is not None else ctx.sweep_series_complete(copy=False)
             pass_stamps.append(time.perf_counter())
-            p = ctx.series_last_path()
-            series_paths[p] = series_paths.get(p, 0) + 1
-            path_list.append(p)
+            p = slab.last_path if slab is not None else ctx.series_last_path()
+            if own:
+                series_paths[p] = series_paths.get(p, 0) + 1
+                path_list.append(p)
         host_ms[1] += (time.perf_counter() - tp0) * 1e3
-        one_pass.factors = f
+        one_pass.factors = f if own else factors
         return recs, ctx.stats()
 
     if args.warmup or pipelined:
@@ -566,6 +585,8 @@ def job(args, env):
     ctx.set_profiling(0 if args.no_kernel_events else (1 if args.exact_only else 2))     # (--exact-only: the dominant kernel is the tile kernel)
     host_ms[0] = host_ms[1] = host_ms[2] = 0.0
     compact_bytes[0] = compact_bytes[1] = compact_bytes[2] = compact_bytes[3] = 0
+    if slab is not None:
+        slab.bytes_sent = slab.bytes_received = slab.fallbacks = 0
     barrier()
     series_paths.clear()
     del pass_stamps[:], path_list[:]
@@ -610,6 +631,11 @@ def job(args, env):
         ktimes_all = ctx.kernel_times()
         ctx.set_profiling(0)
 
+    if slab is not None:
+        npass = args.steps + (3 if pipelined else 0)      # (the latency passes behind the timed region count as well)
+        compact_bytes[0], compact_bytes[1], compact_bytes[3] = slab.bytes_sent * args.steps / npass, slab.bytes_received * args.steps / npass, slab.fallbacks
+        compact_bytes[2] = max(getattr(slab, "last_asked", 0), 0) * args.steps
+        halo_info["protocol"] = "queued on the stream between the stages of the slab pass (ftkx_series_dist_*): all_gather of 4 doubles per rank, masks, request, reply"
     if multi and args.compact_halo:
         halo_info.update({"bytes_sent_per_pass_this_rank": compact_bytes[0] / args.steps, "bytes_received_per_pass_this_rank": compact_bytes[1] / args.steps,
                           "cells_requested_per_pass_this_rank": compact_bytes[2] / args.steps,
@@ -656,7 +682,7 @@ def job(args, env):
     # ascending and unique, the expected count / type histogram (c1, c2, c5) or the single extremum on x0 + dir * t (c3, c4)
     check = {"hits": n_hits}
     if rank == 0 and not args.exact_only:
-        if not multi and not args.host_driven:
+        if (not multi or slab is not None) and not args.host_driven:
             want_paths = [(2, 32)] if case == "moving_extremum_3d" else ([(1, 0), (2, 32)] if args.config == "c1" else [(1, 0)])
             check = check_records(args.config if args.timesteps == 0 else "", case, dims, nt, merged, timed_paths, want_paths)
         elif case == "moving_extremum_3d" and len(merged):
@@ -713,7 +739,8 @@ def job(args, env):
                                    f"{'scalar' if scalar_input else 'vector'} input, t-slab partition over {world} GPU(s): {len(own)} timesteps on rank 0",
                        "simplices_per_step": total_simplices, "exact_only": bool(args.exact_only),
                        "nbits": int(np.log2(max(int(v) for v in getattr(one_pass, "factors", factors)))), "cull": bool(st["cull_enabled"]),
-                       "pass": (("device-driven, two passes in flight (ftkx_sweep_series_submit / _complete)" if pipelined else "device-driven (ftkx_sweep_series)") +
+                       "pass": ((("device-driven slab pass (ftkx_series_dist_* with the collectives queued between its stages)" + (", two passes in flight" if pipelined else "")) if slab is not None else
+                                 "device-driven, two passes in flight (ftkx_sweep_series_submit / _complete)" if pipelined else "device-driven (ftkx_sweep_series)") +
                                 ": paths taken {(path, status): passes} = %s" % {str(k): v for k, v in series_paths.items()}) if series_paths
                                else "host-driven batch (slices_prepare, host factors, enqueue, collect)",
                        "input_resident": "the field the tracker API is given (S, or V for vector input) in HBM; gradient/Jacobian evaluated in flight"},

@@ -235,6 +235,38 @@ class Context:
         self._ck(self._L.ftkx_sweep_series_complete(self._h, C.byref(run), f.ctypes.data, C.byref(out), C.byref(cnt)))
         return _lib.records_from(out.value, cnt.value, copy), f[:n], run.value
 
+    # ---- the slab pass (ftkx_series_dist_*): one rank's device-driven pass, queued in stages; ftk_amd/tslab.py drives it ----
+    def series_dist_cells(self):
+        return int(self._L.ftkx_series_dist_cells(self._h))
+
+    def series_dist_begin(self, ts, scopes, running_resolution, rank, nranks, halo, contrib, gathered, masks_out):
+        """tensors: device memory of this context's device (masks_out: None without a lower neighbour)"""
+        n = len(ts)
+        ts = np.ascontiguousarray(ts, dtype=np.int32)
+        scopes = np.ascontiguousarray(scopes, dtype=np.int32)
+        run = C.c_double(np.finfo(np.float64).max if running_resolution is None else float(running_resolution))
+        self._ck(self._L.ftkx_series_dist_begin(self._h, ts.ctypes.data, scopes.ctypes.data, n, C.byref(run), int(rank), int(nranks), int(bool(halo)),
+                                                contrib.data_ptr(), gathered.data_ptr(), masks_out.data_ptr() if masks_out is not None else None))
+        self._dist_n = n
+
+    def series_dist_cull(self, masks_in, request_out):
+        self._ck(self._L.ftkx_series_dist_cull(self._h, masks_in.data_ptr() if masks_in is not None else None, request_out.data_ptr() if request_out is not None else None))
+
+    def series_dist_serve(self, request_in, reply_out):
+        self._ck(self._L.ftkx_series_dist_serve(self._h, request_in.data_ptr() if request_in is not None else None, reply_out.data_ptr() if reply_out is not None else None))
+
+    def series_dist_finish(self, reply_in):
+        self._ck(self._L.ftkx_series_dist_finish(self._h, reply_in.data_ptr() if reply_in is not None else None))
+        self._open_series = getattr(self, "_open_series", [])
+        self._open_series.append(self._dist_n)
+
+    def series_dist_status(self, nranks):
+        """of the slab pass completed last -> (asked, served, gathered[nranks, 4])"""
+        a, s_ = C.c_longlong(), C.c_longlong()
+        g = np.zeros((nranks, 4), dtype=np.float64)
+        self._ck(self._L.ftkx_series_dist_status(self._h, C.byref(a), C.byref(s_), g.ctypes.data, int(nranks)))
+        return int(a.value), int(s_.value), g
+
     def sweep_series_abort(self):
         """ftkx_sweep_series_abort: discard the open passes (after a failed submit / complete, or to give up)"""
         self._open_series = []

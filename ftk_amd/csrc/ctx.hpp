@@ -29,8 +29,9 @@ void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64
 void launch_records(const Mesh &m, const Fields *d_fields, hipStream_t stream);
 void launch_compact_words(const Mesh &m, const unsigned char *U, const unsigned char *M, unsigned *idx, u64 *words, u64 capacity, u64 *counter, hipStream_t st);
 void launch_scatter_words(const unsigned *idx, const u64 *words, size_t n, unsigned char *M, size_t mask_words, u64 *bad, hipStream_t st);
-void launch_packed_header(u64 *hdr, const u64 *counter, u64 u_bytes, u64 capacity, hipStream_t st);
-void launch_scatter_packed(const u64 *hdr, const unsigned *idx, const u64 *words, u64 u_bytes, u64 capacity, unsigned char *M, size_t mask_words, u64 *bad, hipStream_t st);
+void launch_pack_masks(u64 *hdr, const u64 *counter, const unsigned char *U, u64 u_bytes, u64 capacity, int u_rows, int factor_log2, hipStream_t st);
+void launch_scatter_packed(const u64 *hdr, const unsigned *idx, const u64 *words, u64 u_bytes, u64 capacity, int u_rows, int max_factor_log2, unsigned char *U, unsigned char *M,
+                           size_t mask_words, u64 *bad, hipStream_t st);
 void launch_sparse_cells(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, const double *sparse, u64 *cells, u64 cells_cap, hipStream_t st);
 void launch_patches(const Mesh &m, bool scatter, const u64 *cells, size_t n, int ncomp, double *field, double *patches, hipStream_t st);
 bool masks_have_summary(const Mesh &m);
@@ -63,6 +64,11 @@ void launch_series_small(const Mesh &m, const Mesh &mc, const Fields *d_steps, b
 void launch_series_copy_out(const ftkx_cp_t *src, ftkx_cp_t *dst, u64 capacity, const u64 *results, unsigned *done, unsigned *flag, unsigned seq, hipStream_t st);
 void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, const u64 *base_from,
                           hipStream_t st);
+// dist_kernels.hip: the slab pass
+void launch_dist_contrib(const SeriesSlice *slices, int nown, const u64 *red, u64 *contrib, u64 *block, hipStream_t st);
+void launch_dist_prefix(const u64 *gathered, int rank, int nranks, double running_in, u64 *block, u64 *results_tail, hipStream_t st);
+void launch_dist_request(u64 *request, u64 cap, const u64 *counters, u64 list_capacity, u64 refine_capacity, const u64 *block, u64 *results, u64 *counters_w, hipStream_t st);
+void launch_dist_patches(const Mesh &m, bool scatter, const u64 *request, u64 cap, int ncomp, double *field, double *patches, u64 *served, hipStream_t st);
 }  // namespace ftkx
 
 using ftkx::Fields;
@@ -134,7 +140,18 @@ struct ftkx_series_pending {
   unsigned long long uid = 0;       // ftkx_ctx::sr_pass_uid when the pass was queued (owner stamp of the counters and lists)
   double running_in = 0;
   bool chained = false;             // the running minimum came from the pass before it on the device (running_in: what the host knew)
-  size_t off_steps = 0;
+  size_t off_steps = 0, off_slices = 0, off_sinfo = 0, ntodo = 0;
+  int shift = 0;                    // order key -> bucket
+  const u64 *running_from = nullptr;   // a results block on the device whose SR_RUNNING word this pass continues from (the pass before it, or a slab pass's stub)
+  bool pipelined = false;
+  bool refined = false;             // the refine kernel has been queued already (a slab pass lists the halo's cells from its output)
+  // slab pass (ftkx_series_dist_*): one rank's part of a series cut into timestep slabs, queued in stages with the caller's collectives between them
+  bool dist = false;
+  int dist_stage = 0;               // 1 begun (masks, contribution, outgoing masks), 2 culled (request written), 3 served (reply written), 4 finished = open
+  int t_halo = -1;                  // the slice this rank's last interval sweep reads and does not own: masks + patches arrive inside the pass; -1: none
+  int dist_rank = 0, dist_nranks = 1;
+  const u64 *gathered = nullptr;    // device, kDistContrib words per rank: where the caller's all_gather puts the contributions
+  u64 *request_out = nullptr;       // device: this rank's request to its upper neighbour (count, cells)
 };
 
 // what one of the (two) passes in flight writes that the host reads, or that a copy engine reads after the pass
@@ -148,6 +165,7 @@ struct ftkx_series_buffers {
   hipEvent_t ev_finished = nullptr, ev_copied = nullptr, ev_fetched = nullptr;
   bool copy_out = false;                               // a copy has been queued since the buffers were last used: the next record kernel waits for it
   void *h_desc = nullptr, *d_desc = nullptr; size_t desc_cap = 0;
+  u64 *dist_block = nullptr;                           // slab pass: DB_N words (sweep_params.hpp)
 };
 
 struct ftkx_ctx {
@@ -236,6 +254,8 @@ struct ftkx_ctx {
   std::vector<ftkx_series_slot> sr_slots;   // chunked pass: one slot per chunk
   int sr_skip_small = 0;             // passes for which the fused tail kernel is not launched (the data was hit-dense a moment ago)
   bool sr_short_chain = false;       // the last pass was finished by the fused tail kernel: the next one is queued without the kernels behind it
+  int sr_last_buf = 0;               // the buffers of the pass completed last (ftkx_series_dist_status reads its results block)
+  size_t sr_last_gathered_off = 0; int sr_last_nranks = 0;   // where its gathered contributions sit in that block (0 ranks: not a slab pass)
   int sr_last_path = 0;              // which way the last ftkx_sweep_series went: 1 device-driven, 2 early single-workgroup tail, 0 the host-driven batch
   unsigned long long sr_last_status = 0;
   // pass 2 on the device (trace_device.hip): tags up, neighbours / degrees / roots down
@@ -293,6 +313,9 @@ bool masks_valid(const ftkx_ctx *c, const Slice &s, u64 factor, bool two_level, 
 double job_big(const ftkx_ctx *c, const Slice &s, u64 factor, bool *rule_on);
 int ensure_mask_arrays(ftkx_ctx *c, Slice &s, bool two_level);
 int upload_from_host(ftkx_ctx *c, void *dst, const void *src, size_t bytes);
+// halo.hip
+bool packed_layout(const ftkx_ctx *c, const Mesh &m, size_t *ub, size_t *cap, size_t *off_idx, size_t *off_words, size_t *total);
+int ensure_sparse_slice(ftkx_ctx *c, int t, int scalar_input);
 // prepare.hip
 void launch_init_red(u64 *red, size_t nslots, u64 *counters, hipStream_t st);        // {min = DBL_MAX, max = 0} slots; counters (nullable) zeroed
 void launch_fetch_desc(const void *pinned_src, void *device_dst, size_t bytes, hipStream_t st);   // pinned -> device by a kernel (bytes % 8 == 0)

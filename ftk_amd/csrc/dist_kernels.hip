@@ -1,0 +1,125 @@
+// Kernels of the device-driven pass over a timestep SLAB (several ranks, one per GPU; host side: series.hip, ftkx_series_dist_*).
+//
+// What links the ranks of a t-slab partition is small: the sticky running minimum of update_vector_field_scaling_factor
+// (include/ftk/filters/critical_point_tracker.hh:850-864) runs over the slices in time order, so rank r needs the minimum over the slabs
+// before it and the reduction of the one slice it shares with rank r + 1; and its last interval sweep reads that slice -- as sign masks
+// plus the input values around the cells that survive the cull (the compact halo, sweep_kernels.hip).  Every one of these numbers is
+// produced and consumed by a kernel here, so that the collectives between them (an all_gather of four doubles per rank, three
+// neighbour messages) are queued on the stream by the caller and the host waits once per pass, as with one rank.
+#include "sweep_device.hpp"
+#include "series_device.hpp"
+
+namespace ftkx {
+
+// ---- what this rank contributes: {min, max} of its slab's fused reductions, and those of its first slice ----------------------------
+// `slices`: the pass's slice table (series.hip); the first `nown` entries are this rank's own slices in time order.  One workgroup, a
+// wavefront per slice at a time.  Also zeroes the per-pass dist counters.
+__global__ __launch_bounds__(256) void dist_contrib_kernel(const SeriesSlice *__restrict__ slices, int nown, const u64 *__restrict__ red, u64 *__restrict__ contrib,
+                                                           u64 *__restrict__ block)
+{
+  __shared__ u64 s_min[4], s_max[4], s_first[2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  u64 wmin = 0x7fefffffffffffffull, wmax = 0ull;
+  for (int j = wv; j < nown; j += 4) {
+    const SeriesSlice sl = slices[j];
+    u64 mn = 0x7fefffffffffffffull, mx = 0ull;
+    if (sl.red_index >= 0) { const u64 *r = red + (size_t)sl.red_index * 128; mn = r[2 * lane]; mx = r[2 * lane + 1]; }
+    for (int o = 32; o > 0; o >>= 1) { const u64 a = __shfl_xor(mn, o), b = __shfl_xor(mx, o); mn = a < mn ? a : mn; mx = b > mx ? b : mx; }
+    // (bit patterns of non-negative doubles order like the values; what is known from before this pass counts too)
+    u64 kr = (u64)__double_as_longlong(sl.known_res), kx = (u64)__double_as_longlong(sl.known_max);
+    if (sl.from_res) { kr = *sl.from_res; kx = *sl.from_max; }
+    mn = kr < mn ? kr : mn;                               // (DBL_MAX / 0 where nothing is known: neutral, as in series_factors_body)
+    mx = kx > mx ? kx : mx;
+    if (j == 0 && lane == 0) { s_first[0] = mn; s_first[1] = mx; }
+    wmin = mn < wmin ? mn : wmin; wmax = mx > wmax ? mx : wmax;
+  }
+  if (lane == 0) { s_min[wv] = wmin; s_max[wv] = wmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 mn = s_min[0], mx = s_max[0];
+    for (int q = 1; q < 4; q ++) { mn = s_min[q] < mn ? s_min[q] : mn; mx = s_max[q] > mx ? s_max[q] : mx; }
+    contrib[0] = mn; contrib[1] = mx;
+    contrib[2] = nown > 0 ? s_first[0] : 0x7fefffffffffffffull; contrib[3] = nown > 0 ? s_first[1] : 0ull;
+  }
+  if (threadIdx.x < DB_PSEUDO) block[threadIdx.x] = 0ull;
+}
+
+// ---- after the all_gather: the running minimum before this rank's slab, and the gathered block into the results (for the host) ------
+__global__ __launch_bounds__(64) void dist_prefix_kernel(const u64 *__restrict__ gathered, int rank, int nranks, double running_in, u64 *__restrict__ block, u64 *__restrict__ results_tail)
+{
+  const int lane = threadIdx.x;
+  u64 mn = (u64)__double_as_longlong(running_in);
+  for (int r = lane; r < rank; r += 64) { const u64 v = gathered[4 * r]; mn = v < mn ? v : mn; }
+  for (int o = 32; o > 0; o >>= 1) { const u64 a = __shfl_xor(mn, o); mn = a < mn ? a : mn; }
+  if (lane == 0) block[DB_PSEUDO + SR_RUNNING] = mn;
+  for (int i = lane; i < 4 * nranks; i += 64) results_tail[i] = gathered[i];
+}
+
+// ---- the request: surviving cells whose exact test reads the halo slice, or -1 = "send the slice itself" ----------------------------
+// (count beyond the request's capacity, a mask message that did not fit, survivor lists that overflowed, or a pass whose masks will be
+// rebuilt by the host -- per-vertex overflow rule, Inf: its cull may then keep cells no patch was asked for)
+__global__ void dist_request_kernel(u64 *__restrict__ request, u64 cap, const u64 *__restrict__ counters, u64 list_capacity, u64 refine_capacity, const u64 *__restrict__ block,
+                                    u64 *__restrict__ results, u64 *__restrict__ counters_w)
+{
+  const u64 n = counters[CNT_SPARSE];
+  const bool overflow = counters[CNT_SURVIVOR_LIST] > list_capacity || counters[CNT_REFINE_LIST] > refine_capacity || counters[CNT_REFINE_PEAK] > refine_capacity;
+  const bool remask = (results[SR_STATUS] & (u64)(SERIES_MASKS_INVALID | SERIES_INF)) != 0;
+  const bool full = n > cap || block[DB_BAD] != 0 || overflow || remask;
+  const long long asked = full ? -1ll : (long long)n;
+  request[0] = (u64)asked;
+  results[SR_HALO_ASKED] = (u64)asked;
+  if (full) {
+    atomicOr((unsigned long long *)&results[SR_STATUS], (unsigned long long)SERIES_HALO_FULL);
+    counters_w[CNT_SERIES_DONE] = 2ull;                 // (the rest of the chain leaves at once; the finish kernel reports)
+  }
+}
+
+// ---- patches: the input values a cell's exact test and record can touch (corner - 2 .. corner + 3 on every axis, clamped to the array),
+// ncomp values per vertex.  The cell count is the request's first word, read HERE: the owner gathers into a reply of fixed size without
+// ever seeing the count on the host; the asker scatters the reply into its masks-only slice. ------------------------------------------
+template <bool SCATTER>
+__global__ __launch_bounds__(kThreads) void dist_patches_kernel(const Mesh m, const u64 *__restrict__ request, u64 cap, int ncomp, double *field, double *patches, u64 *served /* nullable */)
+{
+  const long long asked = (long long)request[0];
+  if (served && blockIdx.x == 0 && threadIdx.x == 0) *served = (u64)asked;
+  if (asked <= 0 || (u64)asked > cap) return;
+  const u64 *cells = request + 1;
+  const int nd = m.nd, pe = nd == 3 ? 216 : 36;
+  const size_t total = (size_t)asked * (size_t)pe;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (size_t)gridDim.x * kThreads) {
+    const size_t cell = i / pe;
+    int p = (int)(i - cell * pe);
+    u64 lin = cells[cell];
+    size_t at = 0, stride = 1;
+    bool ok = true;
+    for (int a = 0; a < nd; a ++) {
+      const u64 c = lin % (u64)m.core_sz[a]; lin /= (u64)m.core_sz[a];
+      const int corner = m.core_st[a] + (int)c - m.ext_st[a];
+      const int x = clampi(corner - 2 + p % 6, 0, m.ext_sz[a] - 1); p /= 6;
+      at += (size_t)x * stride; stride *= (size_t)m.ext_sz[a];
+    }
+    ok = lin == 0;                                        // (a cell index from another rank: outside the core = ignored, never an address)
+    if (!ok) { if (!SCATTER) for (int c = 0; c < ncomp; c ++) patches[i * ncomp + c] = 0.0; continue; }
+    for (int c = 0; c < ncomp; c ++) {
+      if (SCATTER) field[at * ncomp + c] = patches[i * ncomp + c];
+      else patches[i * ncomp + c] = field[at * ncomp + c];
+    }
+  }
+}
+
+void launch_dist_contrib(const SeriesSlice *slices, int nown, const u64 *red, u64 *contrib, u64 *block, hipStream_t st)
+{ hipLaunchKernelGGL(dist_contrib_kernel, dim3(1), dim3(256), 0, st, slices, nown, red, contrib, block); }
+void launch_dist_prefix(const u64 *gathered, int rank, int nranks, double running_in, u64 *block, u64 *results_tail, hipStream_t st)
+{ hipLaunchKernelGGL(dist_prefix_kernel, dim3(1), dim3(64), 0, st, gathered, rank, nranks, running_in, block, results_tail); }
+void launch_dist_request(u64 *request, u64 cap, const u64 *counters, u64 list_capacity, u64 refine_capacity, const u64 *block, u64 *results, u64 *counters_w, hipStream_t st)
+{ hipLaunchKernelGGL(dist_request_kernel, dim3(1), dim3(1), 0, st, request, cap, counters, list_capacity, refine_capacity, block, results, counters_w); }
+void launch_dist_patches(const Mesh &m, bool scatter, const u64 *request, u64 cap, int ncomp, double *field, double *patches, u64 *served, hipStream_t st)
+{
+  size_t b = (cap * (size_t)(m.nd == 3 ? 216 : 36) + kThreads - 1) / kThreads;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  if (scatter) hipLaunchKernelGGL(dist_patches_kernel<true>, dim3((unsigned)b), dim3(kThreads), 0, st, m, request, cap, ncomp, field, patches, served);
+  else hipLaunchKernelGGL(dist_patches_kernel<false>, dim3((unsigned)b), dim3(kThreads), 0, st, m, request, cap, ncomp, field, patches, served);
+}
+
+}  // namespace ftkx

@@ -381,7 +381,7 @@ void ftkx_destroy(ftkx_ctx *c)
   for (void *p : {(void *)c->d_word_idx, (void *)c->d_words, (void *)c->d_cells, (void *)c->d_patch_cells, (void *)c->d_patches, c->d_packed}) if (p) (void)hipFree(p);
   for (void *p : {(void *)c->sr_hist, (void *)c->sr_boff, (void *)c->sr_bucketed, (void *)c->sr_sorted}) if (p) (void)hipFree(p);
   for (ftkx_series_buffers &B : c->sr_buf) {
-    for (void *p : {(void *)B.results, (void *)B.d_out, B.d_desc, (void *)B.copy_done}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)B.results, (void *)B.d_out, B.d_desc, (void *)B.copy_done, (void *)B.dist_block}) if (p) (void)hipFree(p);
     if (B.ev_finished) (void)hipEventDestroy(B.ev_finished);
     if (B.ev_copied) (void)hipEventDestroy(B.ev_copied);
     if (B.ev_fetched) (void)hipEventDestroy(B.ev_fetched);

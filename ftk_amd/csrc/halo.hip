@@ -68,10 +68,54 @@ int ftkx_export_masks(ftkx_ctx *c, int t, void *U_dst, unsigned *word_index_dst,
 namespace {
 u64 *halo_bad_flag(ftkx_ctx *c) { return c->d_counters + ftkx::CNT_N + 128; }
 size_t pad8(size_t v) { return (v + 7) / 8 * 8; }
+int factor_log2(unsigned long long f) { int b = 0; while (b < 63 && (1ull << b) < f) b ++; return b; }
 // capacity of the word list in a packed mask message: the mask kernels write a word only where its summary is 0 -- a thin shell around
 // the zero sets of the components; 1/64 of all words is generous for smooth data, and a slice that needs more is sent as it is
 size_t packed_word_capacity(const ftkx_ctx *c) { return std::max<size_t>(4096, mask_bytes(c) / 8 / 64); }
 }
+
+}  // extern "C"
+
+namespace ftkxh {
+// layout of a packed mask message for this context's mesh: 32-byte header | summary array | word indices | words
+bool packed_layout(const ftkx_ctx *c, const Mesh &m, size_t *ub, size_t *cap, size_t *off_idx, size_t *off_words, size_t *total)
+{
+  if (!ftkx::masks_have_summary(m)) return false;
+  *ub = u_bytes_used(c, m); *cap = packed_word_capacity(c);
+  *off_idx = 32 + pad8(*ub); *off_words = *off_idx + pad8(*cap * sizeof(unsigned)); *total = *off_words + *cap * sizeof(u64);
+  return true;
+}
+
+// a slice that exists as masks only (the halo of a t-slab partition): zeroed field array (only patches are ever read), mask and summary
+// arrays; an existing masks-only slice at t is kept as it is, a full slice there is an error (the caller drops it first)
+int ensure_sparse_slice(ftkx_ctx *c, int t, int scalar_input)
+{
+  if (c->slices.empty()) c->scalar_mode = -1;
+  if (c->scalar_mode >= 0 && c->scalar_mode != (scalar_input ? 1 : 0)) return fail(c, FTKX_E_INVALID, "halo slice: scalar and vector slices cannot be mixed in one context");
+  auto it = c->slices.find(t);
+  if (it != c->slices.end()) return it->second.sparse ? FTKX_OK : fail(c, FTKX_E_INVALID, "halo slice: timestep %d is resident as a full slice (drop it first)", t);
+  c->scalar_mode = scalar_input ? 1 : 0;
+  Slice s;
+  const size_t n = n_vertices(c), ncomp = scalar_input ? 1 : (size_t)c->nd;
+  auto fill = [&]() -> int {
+    int rc;
+    double **field = scalar_input ? &s.S : &s.V;
+    HIP_TRY(c, hipMalloc((void **)field, n * ncomp * sizeof(double)));
+    (scalar_input ? s.ownS : s.ownV) = true;
+    HIP_TRY(c, hipMemsetAsync(*field, 0, n * ncomp * sizeof(double), c->stream));
+    if ((rc = ensure_mask_arrays(c, s, true))) return rc;
+    return FTKX_OK;
+  };
+  const int rc = fill();
+  if (rc != FTKX_OK) { free_slice(s, c); return rc; }
+  s.sparse = true;
+  s.mask_gen = ++ c->mask_epoch;
+  c->slices[t] = s;
+  return FTKX_OK;
+}
+}  // namespace ftkxh
+
+extern "C" {
 
 int ftkx_push_masked_slice(ftkx_ctx *c, int t, int scalar_input, const void *U, size_t u_bytes_given, const unsigned *word_index, const unsigned long long *words, size_t n_words,
                            unsigned long long mask_factor, double max_abs, int on_device)
@@ -173,8 +217,8 @@ int ftkx_export_masks_packed(ftkx_ctx *c, int t, void *dst, int dst_on_device)
   u64 *words = (u64 *)(out + 32 + pad8(ub) + pad8(cap * sizeof(unsigned)));
   HIP_TRY(c, hipMemsetAsync(c->d_counters + ftkx::CNT_SPARSE, 0, sizeof(u64), c->stream));
   ftkx::launch_compact_words(m, s.U, s.M, idx, words, cap, c->d_counters + ftkx::CNT_SPARSE, c->stream);
-  HIP_TRY(c, hipMemcpyAsync(out + 32, s.U, ub, hipMemcpyDeviceToDevice, c->stream));
-  ftkx::launch_packed_header((u64 *)out, c->d_counters + ftkx::CNT_SPARSE, ub, cap, c->stream);
+  // (the header says under which factor the masks were built and how many rows a summary byte stands for: the receiver checks both)
+  ftkx::launch_pack_masks((u64 *)out, c->d_counters + ftkx::CNT_SPARSE, s.U, ub, cap, s.u_rows, factor_log2(s.mask_factor), c->stream);
   HIP_TRY(c, hipGetLastError());
   if (!dst_on_device) { HIP_TRY(c, hipMemcpyAsync(dst, out, total, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(c, hipStreamSynchronize(c->stream)); }
   return FTKX_OK;                                          // (device destination: queued on the context's stream, nothing waited for)
@@ -217,10 +261,11 @@ int ftkx_push_masked_slice_packed(ftkx_ctx *c, int t, int scalar_input, const vo
       HIP_TRY(c, hipMemcpyAsync(c->d_packed, src, total, hipMemcpyHostToDevice, c->stream));
       in = (const char *)c->d_packed;
     }
-    HIP_TRY(c, hipMemcpyAsync(s.U, in + 32, ub, hipMemcpyDeviceToDevice, c->stream));
-    // the words: count, geometry and every index are checked on the device; a message that does not fit raises the flag ftkx_sweep_cull looks at
-    ftkx::launch_scatter_packed((const u64 *)in, (const unsigned *)(in + 32 + pad8(ub)), (const u64 *)(in + 32 + pad8(ub) + pad8(cap * sizeof(unsigned))), ub, cap, s.M,
-                                mask_bytes(c) / 8, halo_bad_flag(c), c->stream);
+    // summaries and words: count, geometry, the sender's mask settings and factor (it must not exceed the factor the receiver was told:
+    // masks serve their own factor and larger ones) and every index are checked on the device; a message that does not fit raises the
+    // flag ftkx_sweep_cull looks at
+    ftkx::launch_scatter_packed((const u64 *)in, (const unsigned *)(in + 32 + pad8(ub)), (const u64 *)(in + 32 + pad8(ub) + pad8(cap * sizeof(unsigned))), ub, cap, m.u_rows,
+                                factor_log2(mask_factor), s.U, s.M, mask_bytes(c) / 8, halo_bad_flag(c), c->stream);
     HIP_TRY(c, hipGetLastError());
     if (!src_on_device) HIP_TRY(c, hipStreamSynchronize(c->stream));
     return FTKX_OK;

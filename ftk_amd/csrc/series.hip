@@ -360,7 +360,7 @@ int series_steps(ftkx_ctx *c, const int *ts, const int *scopes, int n, std::vect
 }
 
 // does the device-driven form cover these steps?  (What it does not is swept by the host-driven batch.)
-bool series_applicable(ftkx_ctx *c, const int *ts, const int *scopes, int n, const std::vector<int> &slice_ts, const std::vector<Slice *> &sl, u64 cells)
+bool series_applicable(ftkx_ctx *c, const int *ts, const int *scopes, int n, const std::vector<int> &slice_ts, const std::vector<Slice *> &sl, u64 cells, int t_halo = -1)
 {
   const int nd = c->nd;
   const size_t k = sl.size();
@@ -374,10 +374,11 @@ bool series_applicable(ftkx_ctx *c, const int *ts, const int *scopes, int n, con
     ok = bound * (long double)(ts[n - 1] + 2) < 2147483648.0L;
   }
   if (ok && (long double)n * (long double)cells * 64.0L >= 4611686018427387904.0L) ok = false;   // the order key must fit
-  for (size_t j = 0; ok && j < k; j ++) ok = !sl[j]->sparse;
+  for (size_t j = 0; ok && j < k; j ++) ok = !sl[j]->sparse || slice_ts[j] == t_halo;      // (a slab pass's halo slice: masks + patches arrive inside the pass)
   for (int i = 0; ok && i < n; i ++) {                       // the same consistency rule as ftkx_sweep_enqueue
     if (!(scopes[i] & FTKX_SCOPE_INTERVAL)) continue;
     const Slice &a = c->slices[ts[i]], &b = c->slices[ts[i] + 1];
+    if (b.sparse) { if (a.J != nullptr) ok = false; continue; }      // (a masks-only slice carries S or V, never J)
     if ((a.J == nullptr) != (b.J == nullptr) || (a.S == nullptr) != (b.S == nullptr)) ok = false;
   }
   if (ok && (c->opt.coords_mode == 2 || c->opt.coords_mode == 3)) ok = false;     // (their bounds checks live in ftkx_sweep_enqueue)
@@ -435,7 +436,7 @@ void series_queue_rest(ftkx_ctx *c, const ftkx_series_pending &P, const Mesh &m,
   ftkx_series_buffers &B = c->sr_buf[P.buf];
   Fields *d_steps = (Fields *)((char *)B.d_desc + P.off_steps);
   unsigned *flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
-  if (P.two_level) ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
+  if (P.two_level && !P.refined) ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);   // (a slab pass refines before it asks for patches)
   ftkx::launch_exact(m, d_steps, 0, c->d_list, c->list_capacity, c->stream);
   ftkx::launch_bucket_scan(c->sr_hist, c->sr_boff, (unsigned)P.nbins, c->d_counters, c->stream);
   ftkx::launch_bucket_scatter(m, c->sr_boff, c->sr_bucketed, c->stream);
@@ -463,11 +464,19 @@ void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, hipEvent_t also_afte
 
 // First half: everything of the pass is queued on the context's stream.  `prev`: the pass queued before this one and not yet collected,
 // whose running minimum this one continues from (on the device), or nullptr: *running_in is the value.
-int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *scopes, int n, double running_in, const ftkx_series_pending *prev, bool pipelined,
-                  ftkx_series_pending *before = nullptr /* the pass queued before this one, if it is still open */)
+// what a slab pass (ftkx_series_dist_*) adds to the plan of a pass: the halo slice and where the gathered contributions will be
+struct DistPlan { int t_halo; int rank, nranks; const u64 *gathered; u64 *contrib; void *masks_out; };
+
+int series_queue_cull(ftkx_ctx *c, ftkx_series_pending &P);
+int series_queue_tail(ftkx_ctx *c, ftkx_series_pending &P);
+
+// First half, stage 1: the pass is planned -- buffers, descriptors -- and its begin and mask kernels are queued.
+int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *scopes, int n, double running_in, const ftkx_series_pending *prev, bool pipelined,
+                ftkx_series_pending *before = nullptr /* the pass queued before this one, if it is still open */, const DistPlan *dist = nullptr)
 {
   const int nd = c->nd;
   P = ftkx_series_pending();
+  if (dist) { P.dist = true; P.t_halo = dist->t_halo; P.dist_rank = dist->rank; P.dist_nranks = dist->nranks; P.gathered = dist->gathered; }
   P.ts.assign(ts, ts + n); P.scopes.assign(scopes, scopes + n); P.n = n;
   P.running_in = running_in; P.chained = prev != nullptr;
   int rc;
@@ -483,8 +492,9 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
   const bool two_level = ftkx::masks_have_summary(m);
   u64 cells = 1;
   for (int d = 0; d < nd; d ++) cells *= (u64)c->core_sz[d];
-  bool ok = series_applicable(c, ts, scopes, n, slice_ts, sl, cells);
+  bool ok = series_applicable(c, ts, scopes, n, slice_ts, sl, cells, dist ? dist->t_halo : -1);
   if (prev && prev->by_host) ok = false;                     // (its running minimum will not be on the device)
+  if (dist && !two_level) ok = false;                        // (the halo's masks travel as summaries + the words they do not describe)
   const unsigned long long hint = std::max<unsigned long long>(factor_of(running_in), 256ull);
   P.hint = hint; P.two_level = two_level; P.cells = cells; P.u_rows = m.u_rows;
   if (!ok) { P.by_host = true; P.open = true; return FTKX_OK; }
@@ -512,8 +522,16 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
         }
       }
     }
+    if (dist && slice_ts[j] == dist->t_halo && s.sparse) {
+      // the halo slice: its masks are imported behind the mask kernel (ftkx_series_dist_cull), its reduction is its owner's -- words 2, 3 of
+      // the upper neighbour's contribution to the all_gather
+      ready = true;
+      from_res[j] = dist->gathered + (size_t)ftkx::kDistContrib * (size_t)(dist->rank + 1) + 2;
+      from_max[j] = from_res[j] + 1;
+    }
     if (!ready) red_index[j] = (int)ntodo ++;
   }
+  P.ntodo = ntodo;
 
   // ---- buffers (persistent; they only ever grow) -----------------------------------------------------------------------------------
   if ((rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16)))) return rc;
@@ -542,12 +560,12 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
   }
   if ((rc = grow_device(c, &c->sr_bucketed, &c->sr_bucketed_cap, (size_t)c->capacity))) return rc;
   if ((rc = grow_device(c, &c->sr_sorted, &c->sr_sorted_cap, (size_t)c->capacity))) return rc;
-  const size_t nwords = (size_t)ftkx::SR_HEAD + (size_t)n + 2 * k;
+  const size_t nwords = (size_t)ftkx::SR_HEAD + (size_t)n + 2 * k + (dist ? (size_t)ftkx::kDistContrib * (size_t)dist->nranks : 0);
   P.nwords = nwords;
   // ---- descriptors: mask jobs | steps | slice table | step table, one pinned block fetched by a kernel -------------------------------
   const size_t off_jobs = 0, off_steps = align256(ntodo * sizeof(MaskJob)), off_slices = off_steps + align256((size_t)n * sizeof(Fields)),
                off_sinfo = off_slices + align256(k * sizeof(ftkx::SeriesSlice)), total = off_sinfo + align256((size_t)n * sizeof(ftkx::SeriesStep));
-  P.off_steps = off_steps; P.total_desc = total;
+  P.off_steps = off_steps; P.off_slices = off_slices; P.off_sinfo = off_sinfo; P.total_desc = total; P.shift = shift;
   // A pass with many records, queued while another is still out: the record kernel leaves them in device memory and a small kernel on a
   // stream of its own takes them over PCIe -- next to the mask kernel of the pass queued behind.  (A record kernel that writes through
   // PCIe itself holds its stream for the transfer: 106 us of woven 1024^2 x 64's 363.)
@@ -572,6 +590,7 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
       ss[j].from_res = from_res[j]; ss[j].from_max = from_max[j];
       if (s.have_res) { ss[j].known_res = s.res < cap ? s.res : DBL_MAX; ss[j].known_max = s.maxabs; }
       else if (red_index[j] < 0 && !from_res[j]) { ss[j].known_res = s.res_below; ss[j].known_max = s.maxabs; }
+      if (from_res[j] && s.sparse) { ss[j].known_res = DBL_MAX; ss[j].known_max = 0.0; }      // (the halo slice: nothing of an earlier pass stands)
       if (red_index[j] >= 0)
         jobs[red_index[j]] = MaskJob{s.S, s.V, s.M, two_level ? s.U : nullptr, c->d_red + (size_t)red_index[j] * 128, cap, HUGE_VAL};   // rule off: validated by the factor kernel
     }
@@ -603,6 +622,11 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
   // epoch, and the marks of this pass are then not applied)
   for (size_t j = 0; j < k; j ++) {
     if (red_index[j] >= 0) { sl[j]->mask_factor = 0; sl[j]->have_fused = false; sl[j]->mask_gen = ++ c->mask_epoch; }
+    if (dist && slice_ts[j] == dist->t_halo && sl[j]->sparse) {
+      // (the halo's masks of this pass: built by its owner under the owner's hint, which the import checks against ours on the device)
+      sl[j]->mask_factor = hint; sl[j]->mask_big = false; sl[j]->u_rows = m.u_rows; sl[j]->have_res = false; sl[j]->have_fused = false;
+      sl[j]->mask_gen = ++ c->mask_epoch;
+    }
     P.gen[j] = sl[j]->mask_gen;
   }
   ftkx::launch_series_begin(c->d_counters, c->d_red, ntodo * 64, c->sr_hist, nbins + 1, B.results, nwords, c->stream, B.h_desc, B.d_desc, total);
@@ -616,6 +640,29 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
     series_queue_copy(c, *before, Bp.ev_fetched);
   }
   if (ntodo) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs, (int)ntodo, c->stream); ev_end(c); }
+  P.running_from = prev ? c->sr_buf[prev->buf].results : nullptr;
+  P.pipelined = pipelined;
+  HIP_TRY(c, hipGetLastError());
+  (void)d_steps; (void)d_slices; (void)d_sinfo; (void)flag;
+  return FTKX_OK;
+}
+
+void series_mesh(ftkx_ctx *c, const ftkx_series_pending &P, Mesh &m)
+{
+  fill_mesh(c, m);
+  m.hist = c->sr_hist; m.hist_shift = P.shift; m.core_cells = P.cells;
+}
+
+// stage 2: the cull, with the factor job riding in it
+int series_queue_cull(ftkx_ctx *c, ftkx_series_pending &P)
+{
+  const int nd = c->nd, n = P.n;
+  const size_t k = P.k;
+  ftkx_series_buffers &B = c->sr_buf[P.buf];
+  Mesh m; series_mesh(c, P, m);
+  Fields *d_steps = (Fields *)((char *)B.d_desc + P.off_steps);
+  const ftkx::SeriesSlice *d_slices = (const ftkx::SeriesSlice *)((char *)B.d_desc + P.off_slices);
+  const ftkx::SeriesStep *d_sinfo = (const ftkx::SeriesStep *)((char *)B.d_desc + P.off_sinfo);
   ev_begin(c, K_CULL);
   P.uid = ++ c->sr_pass_uid;
   c->sr_lists_owner = P.uid;                                  // (from here on the counters and lists hold this pass's cull)
@@ -623,18 +670,32 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
     // the factors need what the mask kernel left, the cull does not need the factors: one extra workgroup of the cull kernel forms them
     // (series_device.hpp) -- a kernel boundary and a one-workgroup launch less than the factor kernel behind the cull
     const double safe_m = (double)(nd == 3 ? ftkx::kSafeM3 : ftkx::kSafeM2);
-    const u64 *running_from = prev ? c->sr_buf[prev->buf].results : nullptr;
+    const u64 *running_from = P.running_from;
     ftkx::FactorJob fj;
     memset(&fj, 0, sizeof(fj));
     fj.steps = d_steps; fj.slices = d_slices; fj.sinfo = d_sinfo; fj.red = c->d_red; fj.running_from = running_from; fj.results = B.results; fj.counters = c->d_counters;
-    fj.running_in = prev ? DBL_MAX : running_in; fj.safe_m = safe_m; fj.nsteps = n; fj.nslices = (int)k;
+    fj.running_in = running_from ? DBL_MAX : P.running_in; fj.safe_m = safe_m; fj.nsteps = n; fj.nslices = (int)k;
     static const bool fold_on = !(getenv("FTKX_SERIES_FOLD") && atoi(getenv("FTKX_SERIES_FOLD")) == 0);
     fj.enabled = (fold_on && k <= (size_t)ftkx::kFoldMaxSlices) ? 1 : 0;
-    if (two_level) ftkx::launch_cull_coarse(m, d_steps, n, c->d_refine, c->refine_capacity, c->stream, &fj);
+    if (P.two_level) ftkx::launch_cull_coarse(m, d_steps, n, c->d_refine, c->refine_capacity, c->stream, &fj);
     else ftkx::launch_cull(m, d_steps, n, c->d_list, c->list_capacity, c->stream, &fj);
     if (!fj.enabled) ftkx::launch_series_factors(d_steps, n, d_slices, (int)k, d_sinfo, c->d_red, fj.running_in, running_from, safe_m, B.results, c->d_counters, c->stream);
   }
   ev_end(c);
+  HIP_TRY(c, hipGetLastError());
+  return FTKX_OK;
+}
+
+// stage 3: everything behind the cull -- the fused tail for sparse data, or refine, exact test, ordering, records, finish
+int series_queue_tail(ftkx_ctx *c, ftkx_series_pending &P)
+{
+  ftkx_series_buffers &B = c->sr_buf[P.buf];
+  Mesh m; series_mesh(c, P, m);
+  Fields *d_steps = (Fields *)((char *)B.d_desc + P.off_steps);
+  unsigned *flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
+  const unsigned seq = P.seq;
+  const bool two_level = P.two_level;
+  const size_t nwords = P.nwords;
   ev_begin(c, K_EXACT);
   // sparse data: one kernel does the rest of the pass (and the kernels below leave at once)
   static const bool small_on = !(getenv("FTKX_SERIES_SMALL") && atoi(getenv("FTKX_SERIES_SMALL")) == 0);
@@ -653,6 +714,17 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
   if (!P.short_chain) series_queue_rest(c, P, m, seq);
   P.copy_pending = P.to_device;
   HIP_TRY(c, hipGetLastError());
+  return FTKX_OK;
+}
+
+// First half: everything of the pass is queued on the context's stream.  `prev`: the pass queued before this one and not yet collected,
+// whose running minimum this one continues from (on the device), or nullptr: *running_in is the value.
+int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *scopes, int n, double running_in, const ftkx_series_pending *prev, bool pipelined,
+                  ftkx_series_pending *before = nullptr /* the pass queued before this one, if it is still open */)
+{
+  int rc = series_plan(c, P, ts, scopes, n, running_in, prev, pipelined, before, nullptr);
+  if (rc || P.by_host) return rc;
+  if ((rc = series_queue_cull(c, P)) || (rc = series_queue_tail(c, P))) return rc;
   P.open = true;
   return FTKX_OK;
 }
@@ -720,6 +792,26 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
       if (!s.have_res) s.maxabs = x;
       s.mask_factor = overflow_free(nd, s.maxabs, P.hint) ? P.hint : 0;
       s.mask_big = false; s.u_rows = P.u_rows;
+    }
+  }
+  c->sr_last_buf = P.buf; c->sr_last_nranks = 0;
+  if (P.dist) {
+    // a slab pass: what the other ranks contributed came back with the results -- the running minimum before this slab and the halo
+    // slice's reduction are what the host-driven batch needs, should it have to take the pass over
+    c->sr_last_nranks = P.dist_nranks; c->sr_last_gathered_off = (size_t)ftkx::SR_HEAD + (size_t)n + 2 * k;
+    const u64 *G = R + c->sr_last_gathered_off;
+    for (int r = 0; r < P.dist_rank; r ++) { double v; memcpy(&v, &G[(size_t)ftkx::kDistContrib * r], 8); running = std::min(running, v); }
+    auto it = P.t_halo >= 0 ? c->slices.find(P.t_halo) : c->slices.end();
+    if (it != c->slices.end() && it->second.sparse && P.dist_rank + 1 < P.dist_nranks) {
+      Slice &h = it->second;
+      double r, x;
+      memcpy(&r, &G[(size_t)ftkx::kDistContrib * (P.dist_rank + 1) + 2], 8); memcpy(&x, &G[(size_t)ftkx::kDistContrib * (P.dist_rank + 1) + 3], 8);
+      h.have_res = true; h.res = r; h.maxabs = x; h.res_below = r;
+    }
+    if (status & ftkx::SERIES_HALO_FULL) {
+      c->sr_short_chain = false;
+      *running_resolution = running;
+      return fail(c, FTKX_E_NOSLICE, "slab pass: the halo slice %d is needed as a whole (request -1: too many surviving cells, a mask message that did not fit, or masks the host rebuilds): nothing was swept", P.t_halo);
     }
   }
   const unsigned long long redo = ftkx::SERIES_AMBIGUOUS | ftkx::SERIES_MASKS_INVALID | ftkx::SERIES_INF | ftkx::SERIES_OVERFLOW;
@@ -843,6 +935,169 @@ int ftkx_sweep_series_complete(ftkx_ctx *c, double *running_resolution, unsigned
   return rc;
 }
 
+// ---- the slab pass: one rank's part of a series cut into timestep slabs, queued in stages -----------------------------------------------
+namespace {
+int factor_log2_of(unsigned long long f) { int b = 0; while (b < 63 && (1ull << b) < f) b ++; return b; }
+size_t dist_cells_cap(const ftkx_ctx *c)
+{
+  // cells a request carries: the reply has a FIXED size (the owner never sees the count on the host) -- at most 2 MiB of patches
+  const size_t pd = ftkx_patch_doubles(c) * sizeof(double);
+  static const long forced = getenv("FTKX_DIST_CELLS") ? atol(getenv("FTKX_DIST_CELLS")) : 0;      // (tests: a small request forces the whole-slice way)
+  if (forced > 0) return (size_t)forced;
+  return pd ? std::max<size_t>(64, std::min<size_t>(4096, ((size_t)2 << 20) / pd)) : 0;
+}
+ftkx_series_pending *dist_pending(ftkx_ctx *c, int stage, const char *who)
+{
+  ftkx_series_pending &P = c->sr_pend[(c->sr_head + c->sr_open) & 1];
+  if (!P.dist || P.dist_stage != stage) { fail(c, FTKX_E_INVALID, "%s: no slab pass at that stage (ftkx_series_dist_begin, _cull, _serve, _finish in this order)", who); return nullptr; }
+  return &P;
+}
+}
+
+size_t ftkx_series_dist_cells(const ftkx_ctx *c) { return c && c->mesh_set && c->scalar_mode >= 0 ? dist_cells_cap(c) : 0; }
+
+int ftkx_series_dist_begin(ftkx_ctx *c, const int *ts, const int *scopes, int n, const double *running_resolution, int rank, int nranks, int halo,
+                           void *contrib, const void *gathered, void *masks_out)
+{
+  if (!c || n <= 0 || !ts || !scopes || !running_resolution || !contrib || !gathered) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: null argument or no steps");
+  if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "sweep: call ftkx_set_mesh first");
+  if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: sweeps pending, collect first");
+  if (c->sr_open >= 2) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: two passes are open, complete one first");
+  if (rank < 0 || rank >= nranks) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: rank %d of %d", rank, nranks);
+  if (!(*running_resolution > 0)) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: the running resolution must be positive (DBL_MAX: none yet)");
+  if (halo && (rank + 1 >= nranks || !(scopes[n - 1] & FTKX_SCOPE_INTERVAL))) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: a halo needs an upper neighbour and an interval sweep as the last step");
+  if (c->scalar_mode < 0) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: push this rank's slices first");
+  c->ahead.clear(); c->announced.clear();
+  HIP_TRY(c, hipSetDevice(c->device));
+  ftkx_series_pending &Q = c->sr_pend[(c->sr_head + c->sr_open) & 1];
+  if (Q.dist && Q.dist_stage > 0 && Q.dist_stage < 4) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: a slab pass is half queued (finish or abort it)");
+  int rc;
+  const int t_halo = halo ? ts[n - 1] + 1 : -1;
+  if (halo && (rc = ensure_sparse_slice(c, t_halo, c->scalar_mode))) return rc;
+  ftkx_series_pending *before = c->sr_open > 0 ? &c->sr_pend[(c->sr_head + c->sr_open - 1) & 1] : nullptr;
+  DistPlan dp{t_halo, rank, nranks, (const u64 *)gathered, (u64 *)contrib, masks_out};
+  if ((rc = series_plan(c, Q, ts, scopes, n, *running_resolution, nullptr, true, before, &dp))) { Q.open = false; Q.dist = false; return rc; }
+  if (Q.by_host) {      // (options the device-driven form does not cover: a slab pass has no host-driven form of its own -- the caller's protocol does)
+    Q.open = false; Q.dist = false;
+    return fail(c, FTKX_E_UNSUPPORTED, "ftkx_series_dist_begin: these options / this mesh are not covered by the device-driven pass (use the host-driven calls)");
+  }
+  ftkx_series_buffers &B = c->sr_buf[Q.buf];
+  if (!B.dist_block) { HIP_TRY(c, hipMalloc((void **)&B.dist_block, (size_t)ftkx::DB_N * sizeof(u64))); HIP_TRY(c, hipMemsetAsync(B.dist_block, 0, (size_t)ftkx::DB_N * sizeof(u64), c->stream)); }
+  Q.running_from = B.dist_block + ftkx::DB_PSEUDO;
+  // this rank's contribution (its slab's reductions folded) and, for a lower neighbour, the masks of its first slice as ONE message
+  const ftkx::SeriesSlice *d_slices = (const ftkx::SeriesSlice *)((char *)B.d_desc + Q.off_slices);
+  const int nown = (int)Q.k - (halo ? 1 : 0);
+  ftkx::launch_dist_contrib(d_slices, nown, c->d_red, (u64 *)contrib, B.dist_block, c->stream);
+  if (masks_out) {
+    Mesh m; fill_mesh(c, m);
+    size_t ub, cap, off_idx, off_words, total;
+    if (!packed_layout(c, m, &ub, &cap, &off_idx, &off_words, &total)) return fail(c, FTKX_E_UNSUPPORTED, "ftkx_series_dist_begin: this mesh has no summarised masks");
+    const Slice &s0 = c->slices.find(Q.slice_ts[0])->second;
+    char *out = (char *)masks_out;
+    ftkx::launch_compact_words(m, s0.U, s0.M, (unsigned *)(out + off_idx), (u64 *)(out + off_words), cap, B.dist_block + ftkx::DB_WORDS, c->stream);
+    ftkx::launch_pack_masks((u64 *)out, B.dist_block + ftkx::DB_WORDS, s0.U, ub, cap, m.u_rows, factor_log2_of(Q.hint), c->stream);
+  }
+  HIP_TRY(c, hipGetLastError());
+  Q.dist_stage = 1;
+  return FTKX_OK;
+}
+
+int ftkx_series_dist_cull(ftkx_ctx *c, const void *masks_in, void *request_out)
+{
+  if (!c) return FTKX_E_INVALID;
+  ftkx_series_pending *Pp = dist_pending(c, 1, "ftkx_series_dist_cull");
+  if (!Pp) return FTKX_E_INVALID;
+  ftkx_series_pending &P = *Pp;
+  if ((P.t_halo >= 0) != (masks_in != nullptr) || (P.t_halo >= 0) != (request_out != nullptr)) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_cull: masks_in / request_out go with a halo, and only with one");
+  HIP_TRY(c, hipSetDevice(c->device));
+  ftkx_series_buffers &B = c->sr_buf[P.buf];
+  Mesh m; series_mesh(c, P, m);
+  // the running minimum before this slab (and the gathered block into the results, for the host)
+  ftkx::launch_dist_prefix(P.gathered, P.dist_rank, P.dist_nranks, P.running_in, B.dist_block, B.results + (size_t)ftkx::SR_HEAD + (size_t)P.n + 2 * P.k, c->stream);
+  if (P.t_halo >= 0) {
+    size_t ub, cap, off_idx, off_words, total;
+    if (!packed_layout(c, m, &ub, &cap, &off_idx, &off_words, &total)) return fail(c, FTKX_E_UNSUPPORTED, "ftkx_series_dist_cull: this mesh has no summarised masks");
+    Slice &h = c->slices.find(P.t_halo)->second;
+    const char *in = (const char *)masks_in;
+    ftkx::launch_scatter_packed((const u64 *)in, (const unsigned *)(in + off_idx), (const u64 *)(in + off_words), ub, cap, m.u_rows, factor_log2_of(P.hint), h.U, h.M,
+                                mask_bytes(c) / 8, B.dist_block + ftkx::DB_BAD, c->stream);
+  }
+  int rc;
+  if ((rc = series_queue_cull(c, P))) return rc;
+  if (P.t_halo >= 0) {
+    // the cells whose exact test reads the halo slice: refine now (the rest of the chain will not refine again), list them, write the request
+    Fields *d_steps = (Fields *)((char *)B.d_desc + P.off_steps);
+    const Slice &h = c->slices.find(P.t_halo)->second;
+    ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
+    P.refined = true;
+    u64 *req = (u64 *)request_out;
+    const size_t cap = dist_cells_cap(c);
+    ftkx::launch_sparse_cells(m, d_steps, c->d_list, c->list_capacity, h.S ? h.S : h.V, req + 1, cap, c->stream);
+    ftkx::launch_dist_request(req, cap, c->d_counters, c->list_capacity, c->refine_capacity, B.dist_block, B.results, c->d_counters, c->stream);
+    P.request_out = req;
+  }
+  HIP_TRY(c, hipGetLastError());
+  P.dist_stage = 2;
+  return FTKX_OK;
+}
+
+int ftkx_series_dist_serve(ftkx_ctx *c, const void *request_in, void *reply_out)
+{
+  if (!c) return FTKX_E_INVALID;
+  ftkx_series_pending *Pp = dist_pending(c, 2, "ftkx_series_dist_serve");
+  if (!Pp) return FTKX_E_INVALID;
+  ftkx_series_pending &P = *Pp;
+  if ((request_in != nullptr) != (reply_out != nullptr)) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_serve: a request and a reply buffer, or neither");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (request_in) {
+    // the lower neighbour's cells around THIS rank's first slice: count read on the device, reply of fixed size
+    ftkx_series_buffers &B = c->sr_buf[P.buf];
+    Mesh m; series_mesh(c, P, m);
+    const Slice &s0 = c->slices.find(P.slice_ts[0])->second;
+    const int ncomp = c->scalar_mode == 1 ? 1 : c->nd;
+    ftkx::launch_dist_patches(m, false, (const u64 *)request_in, dist_cells_cap(c), ncomp, c->scalar_mode == 1 ? s0.S : s0.V, (double *)reply_out, B.results + ftkx::SR_HALO_SERVED, c->stream);
+    HIP_TRY(c, hipGetLastError());
+  }
+  P.dist_stage = 3;
+  return FTKX_OK;
+}
+
+int ftkx_series_dist_finish(ftkx_ctx *c, const void *reply_in)
+{
+  if (!c) return FTKX_E_INVALID;
+  ftkx_series_pending *Pp = dist_pending(c, 3, "ftkx_series_dist_finish");
+  if (!Pp) return FTKX_E_INVALID;
+  ftkx_series_pending &P = *Pp;
+  if ((P.t_halo >= 0) != (reply_in != nullptr)) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_finish: a reply goes with a halo, and only with one");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (P.t_halo >= 0) {
+    Mesh m; series_mesh(c, P, m);
+    Slice &h = c->slices.find(P.t_halo)->second;
+    const int ncomp = c->scalar_mode == 1 ? 1 : c->nd;
+    ftkx::launch_dist_patches(m, true, P.request_out, dist_cells_cap(c), ncomp, c->scalar_mode == 1 ? h.S : h.V, const_cast<double *>((const double *)reply_in), nullptr, c->stream);
+  }
+  int rc;
+  if ((rc = series_queue_tail(c, P))) return rc;
+  P.dist_stage = 4;
+  P.open = true;
+  c->sr_open ++;
+  return FTKX_OK;
+}
+
+int ftkx_series_dist_status(const ftkx_ctx *c, long long *asked, long long *served, double *gathered, int nranks)
+{
+  if (!c) return FTKX_E_INVALID;
+  const ftkx_series_buffers &B = c->sr_buf[c->sr_last_buf];
+  if (!B.h_results || c->sr_last_nranks == 0) return FTKX_E_INVALID;
+  if (asked) *asked = (long long)B.h_results[ftkx::SR_HALO_ASKED];
+  if (served) *served = (long long)B.h_results[ftkx::SR_HALO_SERVED];
+  if (gathered) {
+    if (nranks != c->sr_last_nranks) return FTKX_E_INVALID;
+    memcpy(gathered, B.h_results + c->sr_last_gathered_off, (size_t)ftkx::kDistContrib * (size_t)nranks * sizeof(double));
+  }
+  return FTKX_OK;
+}
+
 int ftkx_sweep_series_abort(ftkx_ctx *c)
 {
   if (!c) return FTKX_E_INVALID;
@@ -852,13 +1107,14 @@ int ftkx_sweep_series_abort(ftkx_ctx *c)
   hipError_t e = hipStreamSynchronize(c->stream);
   if (c->sr_copy_stream && e == hipSuccess) e = hipStreamSynchronize(c->sr_copy_stream);
   for (ftkx_series_pending &P : c->sr_pend) {
+    if (P.dist && P.dist_stage > 0 && P.dist_stage < 4) { P.open = true; }      // (a slab pass that was never finished: its masks are nobody's either)
     if (!P.open) continue;
     // the masks this pass was building are nobody's: built, but never marked
     for (size_t j = 0; j < P.k && j < P.red_index.size(); j ++) {
       auto it = c->slices.find(P.slice_ts[j]);
       if (P.red_index[j] >= 0 && it != c->slices.end() && it->second.mask_gen == P.gen[j]) { it->second.mask_factor = 0; it->second.have_fused = false; }
     }
-    P.open = false; P.copy_pending = false;
+    P.open = false; P.copy_pending = false; P.dist_stage = 0;
   }
   for (ftkx_series_buffers &B : c->sr_buf) B.copy_out = false;
   c->sr_open = 0; c->sr_head = 0;

@@ -2282,21 +2282,36 @@ __global__ __launch_bounds__(kThreads) void scatter_words_kernel(const unsigned 
   else if (bad) atomicOr((unsigned long long *)bad, 1ull);
 }
 
-// Packed form of a slice's masks -- ONE message for the compact halo: u64 header {words, summary bytes, word capacity, magic}, the
-// summary array, the word indices (capacity entries), the words (capacity entries).  The header is written on the device (the count of
-// compacted words lives there) and read on the device: neither side waits for the other's numbers on the host.
+// Packed form of a slice's masks -- ONE message for the compact halo: u64 header {words, summary bytes, word capacity | rows per summary
+// byte << 48 | log2(factor the masks were built under) << 56, magic}, the summary array, the word indices (capacity entries), the words
+// (capacity entries).  The header is written on the device (the count of compacted words lives there) and read on the device: neither
+// side waits for the other's numbers on the host.  The summary array travels through these kernels too (a copy queued through the
+// runtime behind a running kernel holds the host until that kernel has finished: DESIGN.md 4, cull-ahead).
 constexpr u64 kPackedMagic = 0x66746b786d61736bull;       // "ftkxmask"
-__global__ void packed_header_kernel(u64 *hdr, const u64 *counter, u64 u_bytes, u64 capacity)
-{ hdr[0] = *counter; hdr[1] = u_bytes; hdr[2] = capacity; hdr[3] = kPackedMagic; }
-
-__global__ __launch_bounds__(kThreads) void scatter_packed_kernel(const u64 *__restrict__ hdr, const unsigned *__restrict__ idx, const u64 *__restrict__ words,
-                                                                  u64 u_bytes, u64 capacity, unsigned char *__restrict__ M, size_t mask_words, u64 *bad)
+__global__ __launch_bounds__(kThreads) void pack_masks_kernel(u64 *__restrict__ hdr, const u64 *__restrict__ counter, const u64 *__restrict__ U, u64 u_bytes, u64 capacity,
+                                                              unsigned u_rows, unsigned factor_log2)
 {
-  const u64 n = hdr[0];
-  if (hdr[1] != u_bytes || hdr[2] != capacity || hdr[3] != kPackedMagic || n > capacity) {   // another geometry, or more words than the message holds
+  u64 *dst = hdr + 4;
+  const u64 nw = (u_bytes + 7) / 8;                        // (U is allocated in whole words: u_pitch is a multiple of 8)
+  for (u64 i = (u64)blockIdx.x * kThreads + threadIdx.x; i < nw; i += (u64)gridDim.x * kThreads) dst[i] = U[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = *counter; hdr[1] = u_bytes; hdr[2] = capacity | ((u64)u_rows << 48) | ((u64)factor_log2 << 56); hdr[3] = kPackedMagic; }
+}
+
+// import: header checked (geometry, rows per summary byte, and the factor the sender built the masks under must not exceed max_factor_log2:
+// masks only serve factors at least as large as their own), summary array and words into the slice's arrays
+__global__ __launch_bounds__(kThreads) void scatter_packed_kernel(const u64 *__restrict__ hdr, const unsigned *__restrict__ idx, const u64 *__restrict__ words,
+                                                                  u64 u_bytes, u64 capacity, unsigned u_rows, unsigned max_factor_log2, u64 *__restrict__ U,
+                                                                  unsigned char *__restrict__ M, size_t mask_words, u64 *bad)
+{
+  const u64 n = hdr[0], geo = hdr[2];
+  if (hdr[1] != u_bytes || (geo & ((1ull << 48) - 1ull)) != capacity || ((geo >> 48) & 0xffull) != (u64)u_rows || (geo >> 56) > (u64)max_factor_log2 ||
+      hdr[3] != kPackedMagic || n > capacity) {            // another geometry or mask setting, a larger factor, or more words than the message holds
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr((unsigned long long *)bad, 1ull);
     return;
   }
+  const u64 *src = hdr + 4;
+  const u64 nw = (u_bytes + 7) / 8;
+  for (u64 i = (u64)blockIdx.x * kThreads + threadIdx.x; i < nw; i += (u64)gridDim.x * kThreads) U[i] = src[i];
   for (u64 i = (u64)blockIdx.x * kThreads + threadIdx.x; i < n; i += (u64)gridDim.x * kThreads) {
     const size_t w = idx[i];
     if (w < mask_words) reinterpret_cast<u64 *>(M)[w] = words[i];
@@ -2358,10 +2373,11 @@ void launch_compact_words(const Mesh &m, const unsigned char *U, const unsigned 
 { hipLaunchKernelGGL(compact_words_kernel, dim3(256 * 8), dim3(kThreads), 0, st, m, U, M, idx, words, capacity, counter); }
 void launch_scatter_words(const unsigned *idx, const u64 *words, size_t n, unsigned char *M, size_t mask_words, u64 *bad, hipStream_t st)
 { if (n) hipLaunchKernelGGL(scatter_words_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, idx, words, n, M, mask_words, bad); }
-void launch_packed_header(u64 *hdr, const u64 *counter, u64 u_bytes, u64 capacity, hipStream_t st)
-{ hipLaunchKernelGGL(packed_header_kernel, dim3(1), dim3(1), 0, st, hdr, counter, u_bytes, capacity); }
-void launch_scatter_packed(const u64 *hdr, const unsigned *idx, const u64 *words, u64 u_bytes, u64 capacity, unsigned char *M, size_t mask_words, u64 *bad, hipStream_t st)
-{ hipLaunchKernelGGL(scatter_packed_kernel, dim3(64), dim3(kThreads), 0, st, hdr, idx, words, u_bytes, capacity, M, mask_words, bad); }
+void launch_pack_masks(u64 *hdr, const u64 *counter, const unsigned char *U, u64 u_bytes, u64 capacity, int u_rows, int factor_log2, hipStream_t st)
+{ hipLaunchKernelGGL(pack_masks_kernel, dim3(128), dim3(kThreads), 0, st, hdr, counter, reinterpret_cast<const u64 *>(U), u_bytes, capacity, (unsigned)u_rows, (unsigned)factor_log2); }
+void launch_scatter_packed(const u64 *hdr, const unsigned *idx, const u64 *words, u64 u_bytes, u64 capacity, int u_rows, int max_factor_log2, unsigned char *U, unsigned char *M,
+                           size_t mask_words, u64 *bad, hipStream_t st)
+{ hipLaunchKernelGGL(scatter_packed_kernel, dim3(128), dim3(kThreads), 0, st, hdr, idx, words, u_bytes, capacity, (unsigned)u_rows, (unsigned)max_factor_log2, reinterpret_cast<u64 *>(U), M, mask_words, bad); }
 void launch_sparse_cells(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, const double *sparse, u64 *cells, u64 cells_cap, hipStream_t st)
 { hipLaunchKernelGGL(sparse_cells_kernel, dim3(256 * 2), dim3(kThreads), 0, st, m, d_steps, d_list, cap, sparse, cells, cells_cap); }
 void launch_patches(const Mesh &m, bool scatter, const u64 *cells, size_t n, int ncomp, double *field, double *patches, hipStream_t st)

@@ -151,9 +151,17 @@ enum { SERIES_AMBIGUOUS = 1,        // 1 / resolution so close above a power of 
        SERIES_FIX_ORDER = 16,       // a bucket of the ordering step was too full to rank on the device: its records are unordered among themselves
        SERIES_EARLY = 32,           // (informational) the fused tail kernel finished the pass
        SERIES_UNORDERED = 64,       // the fused tail found more records than its last workgroup ranks: they come unordered, the host sorts them
-       SERIES_TAIL_PENDING = 128 }; // the pass was queued in its short form (mask, cull, fused tail) and the fused tail declined: the host queues the rest
+       SERIES_TAIL_PENDING = 128,   // the pass was queued in its short form (mask, cull, fused tail) and the fused tail declined: the host queues the rest
+       SERIES_HALO_FULL = 256 };    // slab pass (ftkx_series_dist_*): the halo slice is needed as a whole (too many surviving cells for a request, a mask
+                                    // message that did not fit, masks the host will rebuild): the request said -1, nothing was swept
 // results block (device copy and coherent pinned copy, same layout; u64 words)
 enum { SR_STATUS = 0, SR_RUNNING = 1, SR_NHITS = 2, SR_NFRAGILE = 3, SR_BASE_NEXT = 4 /* chunked pass: records of this chunk and the ones before it */,
-       SR_COUNTERS = 5, SR_HEAD = 5 + CNT_N };   // then factors[nsteps], res[nslices], max[nslices], fragile[cap * 10]
+       SR_HALO_ASKED = 5,    // slab pass: cells this rank asked its upper neighbour for (-1: the whole slice), 0 without a halo
+       SR_HALO_SERVED = 6,   // slab pass: what the lower neighbour asked this rank for (-1: it needs this rank's first slice as a whole)
+       SR_COUNTERS = 7, SR_HEAD = 7 + CNT_N };   // then factors[nsteps], res[nslices], max[nslices], [slab pass: 4 words per rank as gathered], fragile[cap * 10]
+// slab pass: the per-pass block of device words next to the results (series.hip): counters of the halo hand-over and a stub shaped like a
+// results block whose SR_RUNNING word is the running minimum BEFORE this rank's slab (what FactorJob::running_from reads)
+enum { DB_WORDS = 0 /* mask words compacted into the outgoing message */, DB_BAD = 1 /* the incoming mask message did not fit / did not match */, DB_PSEUDO = 8, DB_N = 16 };
+constexpr int kDistContrib = 4;            // words a rank contributes to the all_gather: slab min resolution, slab max |v|, the same of its FIRST slice
 
 }  // namespace ftkx

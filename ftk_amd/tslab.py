@@ -14,6 +14,7 @@ import math
 import numpy as np
 
 DBL_MAX = float(np.finfo(np.float64).max)
+E_NOSLICE, E_UNSUPPORTED = -4, -5      # include/ftkx.h
 
 
 def slab_range(nt, world, rank):
@@ -163,20 +164,23 @@ def compact_halo_patches(ctx, own, nt, t_masked, first_slice=None, halo_buffer=N
     serve = owner_of(t0 - 1, nt, world) if own and t0 > 0 else None          # the rank that holds OUR first slice as masks only
     ask = owner_of(t1, nt, world) if t_masked is not None else None
     sent = received = 0
-    cells, want_full = None, False
+    cells, want_full, fatal = None, False, None
     if ask is not None:
         try:
             cells = ctx.sweep_cull(t_masked, torch, dev)
-        except FtkxError:              # the masks did not fit their message (or do not serve this factor): the slice itself
+        except FtkxError as e:         # the masks did not fit their message, or do not serve this factor: the slice itself
+            if e.code not in (E_NOSLICE, E_UNSUPPORTED):
+                raise                  # (a device error is not a reason to ask for the slice)
             cells, want_full = torch.zeros((0,), dtype=torch.int64, device=dev), True
         if halo_buffer is not None and push_full is not None:
             want_full = want_full or len(cells) > CELL_CAP or len(cells) * ctx.patch_doubles() * 8 > halo_buffer.numel() * halo_buffer.element_size() // 2
         elif want_full or len(cells) > CELL_CAP:
-            raise RuntimeError("compact halo: the whole slice is needed but no halo_buffer / push_full was given")
+            # nobody can take the slice here: say so to the owner too (a request of -2 = "giving up"), so that it does not block in its receive
+            fatal = RuntimeError("compact halo: the whole slice is needed but no halo_buffer / push_full was given")
     ops = []
     if ask is not None:
         req = torch.zeros((1 + CELL_CAP,), dtype=torch.int64, device=dev)
-        req[0] = -1 if want_full else len(cells)
+        req[0] = -2 if fatal is not None else (-1 if want_full else len(cells))
         if not want_full and len(cells):
             req[1:1 + len(cells)] = cells
         ops.append(dist.P2POp(dist.isend, req, ask, group)); sent += req.numel() * 8
@@ -185,6 +189,10 @@ def compact_halo_patches(ctx, own, nt, t_masked, first_slice=None, halo_buffer=N
         ops.append(dist.P2POp(dist.irecv, theirs, serve, group)); received += theirs.numel() * 8
     _p2p(ops)
     n_theirs = int(theirs[0].item()) if serve is not None else 0              # (the one number the owner has to see on the host: it sizes the reply)
+    if fatal is not None:
+        raise fatal
+    if n_theirs == -2:
+        raise RuntimeError("compact halo: the neighbour below gave up (it needs the whole slice and cannot take it)")
     staged = dist.get_backend(group) != "nccl"
     ops = []
     if serve is not None and n_theirs < 0:
@@ -208,6 +216,150 @@ def compact_halo_patches(ctx, own, nt, t_masked, first_slice=None, halo_buffer=N
     if mine is not None:
         ctx.scatter_patches(t_masked, cells, mine)
     return (-1 if want_full else (len(cells) if cells is not None else 0)), sent, received
+
+
+class SlabSeries:
+    """One rank's DEVICE-DRIVEN pass over its timestep slab (include/ftkx.h: ftkx_series_dist_*), with the ranks' links -- the sticky
+    running minimum across slabs (critical_point_tracker.hh:850-864) and the compact halo -- as collectives queued between the stages:
+
+        begin (masks, reduction, contribution, outgoing masks)  | all_gather of 4 doubles per rank; masks -> lower neighbour
+        cull  (masks imported, factors, cull, request)          | request -> upper neighbour
+        serve (patches around the neighbour's cells)            | reply -> lower neighbour
+        finish (patches scattered, exact test, records)         | complete(): the ONE host wait of the pass
+
+    Backend nccl (= RCCL): every collective is queued on torch's current stream, which must be the context's stream
+    (`torch.cuda.set_stream(s); ctx.set_stream(s.cuda_stream)`): nothing waits on the host.  Backend gloo (dry runs, tests): the same
+    stages with the messages staged through host memory.  Two passes may be in flight (submit, submit, complete, ...).
+    Where the halo is needed as a whole slice (request -1) both sides learn it from the same number, exchange `first_slice`, and the
+    asker sweeps again with the full slice (`push` = ctx.push_scalar_slice / push_slice); the next pass starts compact again."""
+
+    def __init__(self, ctx, nt, own, scalar_input, torch, device, first_slice=None, group=None):
+        import torch.distributed as dist
+        self.ctx, self.nt, self.own, self.scalar, self.torch, self.dist, self.group = ctx, nt, list(own), scalar_input, torch, dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.staged = dist.get_backend(group) != "nccl"
+        self.dev = device
+        t0, t1 = (self.own[0], self.own[-1] + 1) if self.own else (0, 0)
+        self.t_halo = t1 if (self.own and t1 < nt) else None
+        self.lower = owner_of(t0 - 1, nt, self.world) if self.own and t0 > 0 else None      # the rank whose last interval sweep reads OUR first slice
+        self.upper = owner_of(t1, nt, self.world) if self.t_halo is not None else None
+        self.first_slice = first_slice
+        self.full_halo = None
+        self.ts = np.array(self.own, dtype=np.int32)
+        self.scopes = np.array([3 if t + 1 < nt else 1 for t in self.own], dtype=np.int32)      # FTKX_SCOPE_BOTH / _ORDINAL
+        nbytes, _ = ctx.packed_masks_bytes() if self.own else (0, 0)
+        cells = ctx.series_dist_cells() if self.own else 0
+        pd = ctx.patch_doubles() if self.own else 0
+        if self.own and (nbytes == 0 or cells == 0) and (self.lower is not None or self.upper is not None):
+            raise RuntimeError("slab pass: this mesh has no summarised masks (use the host-driven protocol)")
+        f64, i64, u8 = torch.float64, torch.int64, torch.uint8
+        z = lambda n, dt: torch.zeros((max(int(n), 1),), dtype=dt, device=device)
+        self.sets = []
+        for _ in range(2):
+            self.sets.append(dict(contrib=torch.tensor([DBL_MAX, 0.0, DBL_MAX, 0.0], dtype=f64, device=device), gathered=z(4 * self.world, f64),
+                                  masks_out=z(nbytes, u8) if self.lower is not None else None, masks_in=z(nbytes, u8) if self.upper is not None else None,
+                                  req_out=z(1 + cells, i64) if self.upper is not None else None, req_in=z(1 + cells, i64) if self.lower is not None else None,
+                                  reply_out=z(cells * pd, f64) if self.lower is not None else None, reply_in=z(cells * pd, f64) if self.upper is not None else None))
+        self.k = 0
+        self.open = []              # buffer sets of the passes in flight, oldest first
+        self.stash = []             # outcomes of passes completed early (a recovery needed the context free)
+        self.bytes_sent = self.bytes_received = 0
+        self.fallbacks = 0
+
+    # ---- the collectives: queued on the stream (nccl) or staged through the host (gloo) ----
+    def _all_gather(self, out, mine):
+        if self.staged:
+            self.torch.cuda.current_stream().synchronize() if mine.is_cuda else None
+            h = self.torch.empty((out.numel(),), dtype=out.dtype)
+            self.dist.all_gather_into_tensor(h, mine.cpu(), group=self.group)
+            out.copy_(h)
+        else:
+            self.dist.all_gather_into_tensor(out, mine, group=self.group)
+
+    def _exchange(self, send, to, recv, frm):
+        ops, back = [], None
+        if to is not None:
+            if self.staged and send.is_cuda:
+                self.torch.cuda.current_stream().synchronize()
+            ops.append(self.dist.P2POp(self.dist.isend, send.cpu() if self.staged else send, to, self.group))
+            self.bytes_sent += send.numel() * send.element_size()
+        if frm is not None:
+            back = self.torch.empty(recv.shape, dtype=recv.dtype) if self.staged else recv
+            ops.append(self.dist.P2POp(self.dist.irecv, back, frm, self.group))
+            self.bytes_received += recv.numel() * recv.element_size()
+        if ops:
+            for r in self.dist.batch_isend_irecv(ops):
+                r.wait()               # (nccl: the CURRENT STREAM waits, not the host)
+        if frm is not None and self.staged:
+            recv.copy_(back)
+
+    def submit(self, running_resolution=None):
+        b = self.sets[self.k]
+        self.k ^= 1
+        if not self.own:               # (more ranks than timesteps: this rank only takes part in the all_gather)
+            self._all_gather(b["gathered"], b["contrib"])
+            self.open.append(b)
+            return
+        ctx = self.ctx
+        ctx.series_dist_begin(self.ts, self.scopes, running_resolution, self.rank, self.world, self.upper is not None, b["contrib"], b["gathered"], b["masks_out"])
+        self._all_gather(b["gathered"], b["contrib"])
+        self._exchange(b["masks_out"], self.lower, b["masks_in"], self.upper)
+        ctx.series_dist_cull(b["masks_in"], b["req_out"])
+        self._exchange(b["req_out"], self.upper, b["req_in"], self.lower)
+        ctx.series_dist_serve(b["req_in"], b["reply_out"])
+        self._exchange(b["reply_out"], self.lower, b["reply_in"], self.upper)
+        ctx.series_dist_finish(b["reply_in"])
+        b["running_in"] = DBL_MAX if running_resolution is None else float(running_resolution)
+        self.open.append(b)
+
+    def _complete_local(self, copy):
+        from . import FtkxError
+        try:
+            recs, f, run = self.ctx.sweep_series_complete(copy=copy)
+            failed = False
+        except FtkxError as e:
+            if e.code != E_NOSLICE:
+                raise
+            recs, f, run, failed = None, None, None, True
+        asked, served, g = self.ctx.series_dist_status(self.world)
+        return dict(recs=recs, f=f, run=run, failed=failed, asked=asked, served=served, gathered=g, path=self.ctx.series_last_path())
+
+    def complete(self, copy=True, push=None):
+        """the oldest pass in flight -> (records, factors, running resolution)"""
+        b = self.open.pop(0)
+        if not self.own:
+            return np.zeros((0,), dtype=_empty_records_dtype()), np.zeros((0,), dtype=np.uint64), DBL_MAX
+        o = self.stash.pop(0) if self.stash else self._complete_local(copy)
+        need, give = o["asked"] < 0 and self.upper is not None, o["served"] < 0 and self.lower is not None
+        if need or give:
+            # the whole slice after all: both sides know from the same number.  The context must be free for the second sweep: the pass
+            # queued behind this one (if any) is collected first, its outcome kept for the next call
+            if need and self.open and not self.stash:
+                self.stash.append(self._complete_local(True))
+            self.fallbacks += 1 if need else 0
+            buf = None
+            if need:
+                if self.full_halo is None:
+                    self.full_halo = self.torch.empty_like(self.first_slice)
+                buf = self.full_halo
+            self._exchange(self.first_slice if give else None, self.lower if give else None, buf, self.upper if need else None)
+            if need:
+                self.torch.cuda.current_stream().synchronize() if buf.is_cuda else None
+                ctx = self.ctx
+                ctx.drop_slice(self.t_halo)
+                (ctx.push_scalar_slice if self.scalar else ctx.push_slice)(self.t_halo, buf)
+                run_in = min([b.get("running_in", DBL_MAX)] + [float(v) for v in o["gathered"][:self.rank, 0]])
+                recs, f, run = ctx.sweep_series(self.ts, self.scopes, run_in, copy=True)
+                o.update(recs=recs, f=f, run=run, path=ctx.series_last_path())
+                ctx.drop_slice(self.t_halo)          # (the next pass starts compact again)
+        self.last_path = o["path"]
+        self.last_asked = o["asked"]
+        return o["recs"], o["f"], o["run"]
+
+
+def _empty_records_dtype():
+    from . import CP_DTYPE
+    return CP_DTYPE
 
 
 def gather_records(recs, dst=0, group=None):

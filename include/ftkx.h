@@ -220,6 +220,39 @@ int ftkx_sweep_series(ftkx_ctx *ctx, const int *timesteps, const int *scopes, in
 int ftkx_sweep_series_submit(ftkx_ctx *ctx, const int *timesteps, const int *scopes, int n, const double *running_resolution);
 int ftkx_sweep_series_complete(ftkx_ctx *ctx, double *running_resolution, unsigned long long *factors, const ftkx_cp_t **out, size_t *n_out);
 int ftkx_sweep_series_abort(ftkx_ctx *ctx);
+/* ---- the slab pass: the device-driven pass of ONE RANK of a series cut into timestep slabs (one process per GPU) ----------
+ * The reference's sticky factor (critical_point_tracker.hh:850-864) runs over ALL slices in time order and rank r's last interval sweep
+ * reads the first slice of rank r + 1.  Both links are small and both are closed ON THE DEVICE: the pass is queued in four stages, and
+ * between them the caller queues its collectives on the context's stream (RCCL: ncclAllGather / ncclSend / ncclRecv, or
+ * torch.distributed with that stream current) -- nothing is waited for on the host until ftkx_sweep_series_complete:
+ *   _begin   masks + reduction of this rank's slices; `contrib` (4 doubles: min resolution and max |v| of the slab, and of its FIRST slice)
+ *            and, with masks_out, the first slice's sign masks as one message of ftkx_packed_masks_bytes() bytes
+ *      caller: all_gather(contrib -> gathered, 4 doubles per rank); masks_out -> lower neighbour, upper neighbour's -> masks_in
+ *   _cull    the halo's masks imported, the running minimum before this slab from `gathered`, cull + factors, and `request_out`:
+ *            1 + ftkx_series_dist_cells() words -- the count of surviving cells whose exact test reads the halo slice and their indices
+ *            (-1: send the slice itself)
+ *      caller: request_out -> upper neighbour, lower neighbour's -> request_in
+ *   _serve   the patches around the lower neighbour's cells, gathered from this rank's first slice into `reply_out`:
+ *            ftkx_series_dist_cells() * ftkx_patch_doubles() doubles, a FIXED size (the count is read on the device)
+ *      caller: reply_out -> lower neighbour, upper neighbour's -> reply_in
+ *   _finish  patches scattered into the halo slice; exact test, records, finish.  The pass is open: ftkx_sweep_series_complete as usual
+ * All buffers are device memory of this context's device and must stay untouched until the pass is complete; ranks without a lower /
+ * upper neighbour pass NULL for the corresponding buffers (halo = 0: the last step's slices are all this rank's own).  Two slab passes
+ * may be in flight like any two passes (separate buffers each).  ftkx_sweep_series_complete returns FTKX_E_NOSLICE when the request said
+ * -1 (nothing was swept: fetch the slice itself, push it, and sweep with ftkx_sweep_series from the running minimum
+ * ftkx_series_dist_status reports); the owner learns the same from `served` = -1.  Options the device-driven pass does not cover:
+ * FTKX_E_UNSUPPORTED from _begin (same on every rank: they share options and mesh) -- use ftkx_slices_prepare / ftkx_sweep_enqueue /
+ * ftkx_sweep_cull / ftkx_sweep_collect. */
+size_t ftkx_series_dist_cells(const ftkx_ctx *ctx);
+int ftkx_series_dist_begin(ftkx_ctx *ctx, const int *timesteps, const int *scopes, int n, const double *running_resolution, int rank, int nranks, int halo,
+                           void *contrib, const void *gathered, void *masks_out);
+int ftkx_series_dist_cull(ftkx_ctx *ctx, const void *masks_in, void *request_out);
+int ftkx_series_dist_serve(ftkx_ctx *ctx, const void *request_in, void *reply_out);
+int ftkx_series_dist_finish(ftkx_ctx *ctx, const void *reply_in);
+/* of the slab pass completed last: what it asked its upper neighbour for and what its lower neighbour asked of it (cells, -1: the whole
+ * slice, 0: nothing), and the gathered contributions (4 * nranks doubles, nullable) */
+int ftkx_series_dist_status(const ftkx_ctx *ctx, long long *asked, long long *served, double *gathered, int nranks);
+
 /* which way the last ftkx_sweep_series went: 1 = device-driven, 2 = device-driven and finished by the fused tail kernel (sparse
  * data), 3 = device-driven in chunks (hit-dense data: the tail of a chunk runs next to the mask kernel of the next), 0 = host-driven batch; *status (nullable) = the SERIES_* bits the kernels raised (csrc/sweep_params.hpp) */
 int ftkx_series_last_path(const ftkx_ctx *ctx, unsigned long long *status);

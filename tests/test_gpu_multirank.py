@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _bench(n, cfg, extra=(), dump=None):
+def _bench(n, cfg, extra=(), dump=None, env=None):
     common = ["bench.py", "--gpus", str(n), "--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-streaming-tracker", *extra]
     if dump:
         common += ["--dump-merged", str(dump)]
@@ -29,7 +29,7 @@ def _bench(n, cfg, extra=(), dump=None):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), *common, "--backend", "gloo", "--single-device"]
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     return json.loads(line)
@@ -41,8 +41,11 @@ def test_slab_count_does_not_change_the_result(cfg, tmp_path):
     assert one["n_gpus"] == 1 and one["check"]["hits"] > 0
     ref = np.load(tmp_path / "one.npz")
     assert one["pass2"]["records"] == len(ref["records"]) == one["check"]["hits"] and one["pass2"]["curves"] == len(ref["curve_loop"]) > 0
-    for n, extra in ((2, ("--full-halo",)), (3, ("--full-halo",)), (2, ("--full-halo", "--halo-in-loop")), (2, ("--compact-halo",)), (3, ())):
-        many = _bench(n, cfg, ("--no-other-scaling",) + extra, dump=tmp_path / f"many{n}.npz")
+    # host-driven batch with the whole slice / with the compact halo's host-side protocol; the device-driven slab pass (the default);
+    # the slab pass with requests so small that the halo goes as a whole slice after all (both sides learn it from the same number)
+    for n, extra, env in ((2, ("--full-halo",), None), (3, ("--full-halo",), None), (2, ("--full-halo", "--halo-in-loop"), None), (2, ("--compact-halo", "--host-driven"), None),
+                          (2, ("--compact-halo",), None), (3, (), None), (2, ("--no-pipeline",), None), (3, (), {"FTKX_DIST_CELLS": "2"})):
+        many = _bench(n, cfg, ("--no-other-scaling",) + extra, dump=tmp_path / f"many{n}.npz", env=env)
         got = np.load(tmp_path / f"many{n}.npz")
         # the merged record set (72-byte records, bit for bit) and the curves traced from it: identical to the single-rank run
         assert got["records"].tobytes() == ref["records"].tobytes()
@@ -57,9 +60,15 @@ def test_slab_count_does_not_change_the_result(cfg, tmp_path):
             h = many["halo_exchange"]
             moved = h["bytes_sent_per_pass_this_rank"] + h["bytes_received_per_pass_this_rank"]
             assert h["compact"] and moved > 0
-            if cfg == "small3":     # smooth 3D data: a few cells survive at the boundary -- a small fraction of the slice's bytes
+            slab = "--host-driven" not in extra
+            assert ("slab pass" in many["config"]["pass"]) == slab
+            if slab and env is None:      # the device-driven form was what ran on rank 0, every pass
+                assert many["check"]["device_driven"] and many["check"]["ok"], many["check"]
+            if env is not None:     # requests of two cells: the whole slice after all, on every pass
+                assert h["passes_that_fell_back_to_the_whole_slice"] > 0
+            elif cfg == "small3":   # smooth 3D data: a few cells survive at the boundary -- a small fraction of the slice's bytes
                 assert moved < 0.25 * h["full_slice_bytes"] and h["cells_requested_per_pass_this_rank"] > 0 and h["passes_that_fell_back_to_the_whole_slice"] == 0
-            else:                   # hit-dense 2D data on small slices: patches would be more bytes than the slice -> the protocol falls back to it
+            elif not slab:          # hit-dense 2D data on small slices: patches would be more bytes than the slice -> the host-side protocol falls back to it
                 assert h["passes_that_fell_back_to_the_whole_slice"] > 0
         else:
             assert many["halo_exchange"]["in_timed_region"] == ("--halo-in-loop" in extra) and many["halo_exchange"]["bytes_per_rank"] > 0
@@ -98,10 +107,11 @@ def test_the_collectives_run_on_rccl(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["halo_exchange"]["compact"] is True
-    assert "host-driven" in out["config"]["pass"]            # (several ranks form the factors on the host, after the all_gather)
+    # the device-driven slab pass: the all_gather of the contributions queued on the stream between its stages (nobody to exchange a halo with)
+    assert "slab pass" in out["config"]["pass"] and out["check"]["device_driven"] and out["check"]["ok"], (out["config"]["pass"], out["check"])
     ref, got = np.load(tmp_path / "one.npz"), np.load(tmp_path / "rccl.npz")
     assert got["records"].tobytes() == ref["records"].tobytes() and len(ref["records"]) > 0
-    for full in (("--full-halo",), ("--full-halo", "--halo-in-loop")):
+    for full in (("--full-halo",), ("--full-halo", "--halo-in-loop"), ("--compact-halo", "--host-driven")):
         r = subprocess.run(cmd[:-2] + list(full), cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
 
