@@ -940,11 +940,13 @@ namespace {
 int factor_log2_of(unsigned long long f) { int b = 0; while (b < 63 && (1ull << b) < f) b ++; return b; }
 size_t dist_cells_cap(const ftkx_ctx *c)
 {
-  // cells a request carries: the reply has a FIXED size (the owner never sees the count on the host) -- at most 2 MiB of patches
+  // cells a request carries: the reply has a FIXED size (the owner never sees the count on the host) -- at most 1 MiB of patches
+  // (~15 us of one xGMI link) and at most a sixteenth of the slice it stands for
   const size_t pd = ftkx_patch_doubles(c) * sizeof(double);
   static const long forced = getenv("FTKX_DIST_CELLS") ? atol(getenv("FTKX_DIST_CELLS")) : 0;      // (tests: a small request forces the whole-slice way)
   if (forced > 0) return (size_t)forced;
-  return pd ? std::max<size_t>(64, std::min<size_t>(4096, ((size_t)2 << 20) / pd)) : 0;
+  const size_t slice_bytes = n_vertices(c) * (size_t)(c->scalar_mode == 1 ? 1 : c->nd) * sizeof(double);
+  return pd ? std::max<size_t>(16, std::min<size_t>(4096, std::min<size_t>((size_t)1 << 20, slice_bytes / 16) / pd)) : 0;
 }
 ftkx_series_pending *dist_pending(ftkx_ctx *c, int stage, const char *who)
 {

@@ -346,7 +346,11 @@ class SlabSeries:
             if need:
                 self.torch.cuda.current_stream().synchronize() if buf.is_cuda else None
                 ctx = self.ctx
-                ctx.drop_slice(self.t_halo)
+                try:
+                    ctx.drop_slice(self.t_halo)      # the masks-only slice (gone already if the pass before this one needed the slice too)
+                except Exception as e:               # noqa: BLE001
+                    if getattr(e, "code", None) != E_NOSLICE:
+                        raise
                 (ctx.push_scalar_slice if self.scalar else ctx.push_slice)(self.t_halo, buf)
                 run_in = min([b.get("running_in", DBL_MAX)] + [float(v) for v in o["gathered"][:self.rank, 0]])
                 recs, f, run = ctx.sweep_series(self.ts, self.scopes, run_in, copy=True)
