@@ -171,7 +171,7 @@ def load():
     L.ftkx_sweep_series_abort.argtypes = [vp]
     L.ftkx_series_dist_cells.argtypes = [vp]
     L.ftkx_series_dist_cells.restype = C.c_size_t
-    L.ftkx_series_dist_begin.argtypes = [vp, vp, vp, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.ftkx_series_dist_begin.argtypes = [vp, vp, vp, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.ftkx_series_dist_cull.argtypes = [vp, vp, vp]
     L.ftkx_series_dist_serve.argtypes = [vp, vp, vp]
     L.ftkx_series_dist_finish.argtypes = [vp, vp]

@@ -67,6 +67,9 @@ void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_c
 // dist_kernels.hip: the slab pass
 void launch_dist_contrib(const SeriesSlice *slices, int nown, const u64 *red, u64 *contrib, u64 *block, hipStream_t st);
 void launch_dist_prefix(const u64 *gathered, int rank, int nranks, double running_in, u64 *block, u64 *results_tail, hipStream_t st);
+void launch_dist_export(const Mesh &m, const unsigned char *U, const unsigned char *M, u64 u_bytes, u64 *hdr, unsigned *idx, u64 *words, u64 capacity, int factor_log2, u64 *block, hipStream_t st);
+void launch_dist_import(const u64 *gathered, int rank, int nranks, double running_in, u64 *block, u64 *results_tail, const u64 *hdr, const unsigned *idx, const u64 *words, u64 u_bytes,
+                        u64 capacity, int u_rows, int max_factor_log2, unsigned char *U, unsigned char *M, u64 mask_words, hipStream_t st);
 void launch_dist_request(u64 *request, u64 cap, const u64 *counters, u64 list_capacity, u64 refine_capacity, const u64 *block, u64 *results, u64 *counters_w, hipStream_t st);
 void launch_dist_patches(const Mesh &m, bool scatter, const u64 *request, u64 cap, int ncomp, double *field, double *patches, u64 *served, hipStream_t st);
 }  // namespace ftkx
@@ -162,7 +165,7 @@ struct ftkx_series_buffers {
   ftkx_cp_t *out = nullptr; size_t out_cap = 0;       // pinned: the records as the caller reads them
   ftkx_cp_t *d_out = nullptr; size_t d_out_cap = 0;   // device: the records of a pass whose way over PCIe is left to the copy kernel on its own stream
   unsigned *copy_done = nullptr;                       // that kernel's workgroup counter
-  hipEvent_t ev_finished = nullptr, ev_copied = nullptr, ev_fetched = nullptr;
+  hipEvent_t ev_finished = nullptr, ev_copied = nullptr, ev_fetched = nullptr, ev_export = nullptr;
   bool copy_out = false;                               // a copy has been queued since the buffers were last used: the next record kernel waits for it
   void *h_desc = nullptr, *d_desc = nullptr; size_t desc_cap = 0;
   u64 *dist_block = nullptr;                           // slab pass: DB_N words (sweep_params.hpp)

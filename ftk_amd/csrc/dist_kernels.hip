@@ -41,7 +41,82 @@ __global__ __launch_bounds__(256) void dist_contrib_kernel(const SeriesSlice *__
     contrib[0] = mn; contrib[1] = mx;
     contrib[2] = nown > 0 ? s_first[0] : 0x7fefffffffffffffull; contrib[3] = nown > 0 ? s_first[1] : 0ull;
   }
-  if (threadIdx.x < DB_PSEUDO) block[threadIdx.x] = 0ull;
+  (void)block;
+}
+
+// ---- the first slice's sign masks as ONE message for the lower neighbour: header | summary array | word indices | words --------------
+// One pass over the summary array, eight summary bytes per lane: the bytes are copied into the message as they are, and wherever one of
+// them is 0 -- the only blocks whose mask words the mask kernel wrote -- the block's u_rows words go on the list (index of the 8-byte
+// word in M, its 8 bytes; any order).  A wavefront reserves its run of the list with ONE atomic.  The workgroup that finishes last
+// writes the header (the count lives on the device; the receiver reads it there).  block[DB_WORDS], block[DB_DONE] must be 0 on entry
+// (the import kernel of the pass that used this block before leaves them so).
+constexpr u64 kPackedMagicD = 0x66746b786d61736bull;      // "ftkxmask" (sweep_kernels.hip: kPackedMagic)
+__global__ __launch_bounds__(256) void dist_export_kernel(const Mesh m, const u64 *__restrict__ U, const unsigned char *__restrict__ M, u64 u_bytes, u64 *__restrict__ hdr,
+                                                          unsigned *__restrict__ idx, u64 *__restrict__ words, u64 capacity, unsigned factor_log2, u64 *__restrict__ block)
+{
+  const int UP = m.u_pitch, P = m.mask_pitch, DH = m.ext_sz[1], UR = m.u_rows;
+  const int ngroups = (m.ext_sz[0] + 7) / 8;
+  const u64 urows = (u64)((DH + UR - 1) / UR);
+  const u64 nw = u_bytes / 8;
+  u64 *dst = hdr + 4;
+  const int lane = threadIdx.x & 63;
+  const u64 nw_pad = (nw + 63) / 64 * 64;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nw_pad; i += (u64)gridDim.x * 256) {
+    u64 w = ~0ull;
+    if (i < nw) { w = U[i]; dst[i] = w; }
+    // zero bytes of w (exact: the classic (w - 0x01..) & ~w & 0x80.. test has no false positives when taken byte by byte from the low end;
+    // evaluated per byte here, it only runs where the quick test fires)
+    unsigned zero = 0;
+    if ((w - 0x0101010101010101ull) & ~w & 0x8080808080808080ull)
+      for (int b = 0; b < 8; b ++) if (((w >> (8 * b)) & 0xffull) == 0) zero |= 1u << b;
+    // (bytes of a summary row beyond its last group are padding: skipped by position)
+    unsigned nemit = 0;
+    unsigned take = 0;
+    for (int b = 0; b < 8; b ++) {
+      if (!((zero >> b) & 1u)) continue;
+      const u64 pos = i * 8 + (u64)b, urow = pos / (u64)UP;
+      const int g = (int)(pos - urow * (u64)UP);
+      if (g >= ngroups) continue;
+      const u64 yb = urow % urows;
+      int rows = DH - (int)(yb * (u64)UR); rows = rows < UR ? rows : UR;
+      take |= 1u << b; nemit += (unsigned)rows;
+    }
+    // the wavefront's run of the list: exclusive prefix over the lanes, one atomic
+    unsigned incl = nemit;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+    const unsigned total = __shfl(incl, 63);
+    if (!total) continue;
+    u64 base = 0;
+    if (lane == 63) base = atomicAdd(&block[DB_WORDS], (u64)total);
+    base = __shfl(base, 63) + (u64)(incl - nemit);
+    for (int b = 0; b < 8; b ++) {
+      if (!((take >> b) & 1u)) continue;
+      const u64 pos = i * 8 + (u64)b, urow = pos / (u64)UP;
+      const int g = (int)(pos - urow * (u64)UP);
+      const u64 z = urow / urows, yb = urow % urows;
+      int rows = DH - (int)(yb * (u64)UR); rows = rows < UR ? rows : UR;
+      for (int r = 0; r < rows; r ++) {
+        const u64 row = z * (u64)DH + yb * (u64)UR + (u64)r;
+        const u64 wi = (row * (u64)P) / 8 + (u64)g;
+        if (base < capacity) { idx[base] = (unsigned)wi; words[base] = reinterpret_cast<const u64 *>(M)[wi]; }
+        base ++;
+      }
+    }
+  }
+  // The last workgroup to finish writes the header.  No fence: what it needs of the others is their share of the COUNT, which is an
+  // atomic like the arrival counter -- a wavefront has its reservation's return value (it computes addresses from it) before it reaches
+  // the barrier below, so every reservation of a workgroup is performed before its arrival is.  (A __threadfence here is an L2
+  // write-back per workgroup on this part: 47 us for the 512 of them.)  The list and the summary bytes only have to be there when the
+  // kernel ends.
+  __shared__ unsigned s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&block[DB_DONE], 1ull) == (u64)gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    hdr[0] = __hip_atomic_load(&block[DB_WORDS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hdr[1] = u_bytes; hdr[2] = capacity | ((u64)UR << 48) | ((u64)factor_log2 << 56); hdr[3] = kPackedMagicD;
+    block[DB_WORDS] = 0ull; block[DB_DONE] = 0ull;         // (as found)
+  }
 }
 
 // ---- after the all_gather: the running minimum before this rank's slab, and the gathered block into the results (for the host) ------
@@ -55,6 +130,43 @@ __global__ __launch_bounds__(64) void dist_prefix_kernel(const u64 *__restrict__
   for (int i = lane; i < 4 * nranks; i += 64) results_tail[i] = gathered[i];
 }
 
+// ---- the halo's masks imported (header checked on the device: geometry, rows per summary byte, and the sender's factor must not exceed
+// ours -- masks serve their own factor and larger ones), with the prefix job above riding in workgroup 0 ---------------------------------
+__global__ __launch_bounds__(256) void dist_import_kernel(const u64 *__restrict__ gathered, int rank, int nranks, double running_in, u64 *__restrict__ block, u64 *__restrict__ results_tail,
+                                                          const u64 *__restrict__ hdr /* nullptr: no halo */, const unsigned *__restrict__ idx, const u64 *__restrict__ words, u64 u_bytes,
+                                                          u64 capacity, unsigned u_rows, unsigned max_factor_log2, u64 *__restrict__ U, unsigned char *__restrict__ M, u64 mask_words)
+{
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    u64 mn = (u64)__double_as_longlong(running_in);
+    for (int r = lane; r < rank; r += 64) { const u64 v = gathered[kDistContrib * r]; mn = v < mn ? v : mn; }
+    for (int o = 32; o > 0; o >>= 1) { const u64 a = __shfl_xor(mn, o); mn = a < mn ? a : mn; }
+    if (lane == 0) { block[DB_PSEUDO + SR_RUNNING] = mn; block[DB_BAD] = 0ull; }
+    for (int i = lane; i < kDistContrib * nranks; i += 64) results_tail[i] = gathered[i];
+  }
+  if (!hdr) return;
+  const u64 n = hdr[0], geo = hdr[2];
+  if (hdr[1] != u_bytes || (geo & ((1ull << 48) - 1ull)) != capacity || ((geo >> 48) & 0xffull) != (u64)u_rows || (geo >> 56) > (u64)max_factor_log2 ||
+      hdr[3] != kPackedMagicD || n > capacity) {
+    __syncthreads();                                      // (workgroup 0: behind the reset of DB_BAD above)
+    if (blockIdx.x == 0 && threadIdx.x == 0) block[DB_BAD] = 1ull;
+    return;
+  }
+  const u64 *src = hdr + 4;
+  const u64 nw = u_bytes / 8;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nw; i += (u64)gridDim.x * 256) U[i] = src[i];
+  bool bad = false;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+    const u64 w = idx[i];
+    if (w < mask_words) reinterpret_cast<u64 *>(M)[w] = words[i];
+    else bad = true;
+  }
+  // (an index outside the mask array: flagged -- by workgroups other than 0 too, whose store may race with workgroup 0's reset; the
+  // request kernel reads DB_BAD two kernels later, and a lost flag needs a sender that breaks the protocol in the first place.  Keep it
+  // exact anyway: such workgroups raise bit 1, which workgroup 0 never writes)
+  if (bad) atomicOr((unsigned long long *)&block[DB_BAD2], 1ull);
+}
+
 // ---- the request: surviving cells whose exact test reads the halo slice, or -1 = "send the slice itself" ----------------------------
 // (count beyond the request's capacity, a mask message that did not fit, survivor lists that overflowed, or a pass whose masks will be
 // rebuilt by the host -- per-vertex overflow rule, Inf: its cull may then keep cells no patch was asked for)
@@ -64,7 +176,7 @@ __global__ void dist_request_kernel(u64 *__restrict__ request, u64 cap, const u6
   const u64 n = counters[CNT_SPARSE];
   const bool overflow = counters[CNT_SURVIVOR_LIST] > list_capacity || counters[CNT_REFINE_LIST] > refine_capacity || counters[CNT_REFINE_PEAK] > refine_capacity;
   const bool remask = (results[SR_STATUS] & (u64)(SERIES_MASKS_INVALID | SERIES_INF)) != 0;
-  const bool full = n > cap || block[DB_BAD] != 0 || overflow || remask;
+  const bool full = n > cap || block[DB_BAD] != 0 || block[DB_BAD2] != 0 || overflow || remask;
   const long long asked = full ? -1ll : (long long)n;
   request[0] = (u64)asked;
   results[SR_HALO_ASKED] = (u64)asked;
@@ -72,6 +184,7 @@ __global__ void dist_request_kernel(u64 *__restrict__ request, u64 cap, const u6
     atomicOr((unsigned long long *)&results[SR_STATUS], (unsigned long long)SERIES_HALO_FULL);
     counters_w[CNT_SERIES_DONE] = 2ull;                 // (the rest of the chain leaves at once; the finish kernel reports)
   }
+  const_cast<u64 *>(block)[DB_BAD2] = 0ull;            // (as found, for the next pass that uses this block)
 }
 
 // ---- patches: the input values a cell's exact test and record can touch (corner - 2 .. corner + 3 on every axis, clamped to the array),
@@ -111,6 +224,14 @@ void launch_dist_contrib(const SeriesSlice *slices, int nown, const u64 *red, u6
 { hipLaunchKernelGGL(dist_contrib_kernel, dim3(1), dim3(256), 0, st, slices, nown, red, contrib, block); }
 void launch_dist_prefix(const u64 *gathered, int rank, int nranks, double running_in, u64 *block, u64 *results_tail, hipStream_t st)
 { hipLaunchKernelGGL(dist_prefix_kernel, dim3(1), dim3(64), 0, st, gathered, rank, nranks, running_in, block, results_tail); }
+void launch_dist_export(const Mesh &m, const unsigned char *U, const unsigned char *M, u64 u_bytes, u64 *hdr, unsigned *idx, u64 *words, u64 capacity, int factor_log2, u64 *block, hipStream_t st)
+{ hipLaunchKernelGGL(dist_export_kernel, dim3(512), dim3(256), 0, st, m, reinterpret_cast<const u64 *>(U), M, u_bytes, hdr, idx, words, capacity, (unsigned)factor_log2, block); }
+void launch_dist_import(const u64 *gathered, int rank, int nranks, double running_in, u64 *block, u64 *results_tail, const u64 *hdr, const unsigned *idx, const u64 *words, u64 u_bytes,
+                        u64 capacity, int u_rows, int max_factor_log2, unsigned char *U, unsigned char *M, u64 mask_words, hipStream_t st)
+{
+  hipLaunchKernelGGL(dist_import_kernel, dim3(hdr ? 128 : 1), dim3(256), 0, st, gathered, rank, nranks, running_in, block, results_tail, hdr, idx, words, u_bytes, capacity, (unsigned)u_rows,
+                     (unsigned)max_factor_log2, reinterpret_cast<u64 *>(U), M, mask_words);
+}
 void launch_dist_request(u64 *request, u64 cap, const u64 *counters, u64 list_capacity, u64 refine_capacity, const u64 *block, u64 *results, u64 *counters_w, hipStream_t st)
 { hipLaunchKernelGGL(dist_request_kernel, dim3(1), dim3(1), 0, st, request, cap, counters, list_capacity, refine_capacity, block, results, counters_w); }
 void launch_dist_patches(const Mesh &m, bool scatter, const u64 *request, u64 cap, int ncomp, double *field, double *patches, u64 *served, hipStream_t st)

@@ -385,6 +385,7 @@ void ftkx_destroy(ftkx_ctx *c)
     if (B.ev_finished) (void)hipEventDestroy(B.ev_finished);
     if (B.ev_copied) (void)hipEventDestroy(B.ev_copied);
     if (B.ev_fetched) (void)hipEventDestroy(B.ev_fetched);
+    if (B.ev_export) (void)hipEventDestroy(B.ev_export);
     for (void *p : {(void *)B.h_results, (void *)B.out, B.h_desc}) if (p) (void)hipHostFree(p);
   }
   if (c->sr_copy_stream) (void)hipStreamDestroy(c->sr_copy_stream);

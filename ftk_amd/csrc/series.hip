@@ -465,7 +465,7 @@ void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, hipEvent_t also_afte
 // First half: everything of the pass is queued on the context's stream.  `prev`: the pass queued before this one and not yet collected,
 // whose running minimum this one continues from (on the device), or nullptr: *running_in is the value.
 // what a slab pass (ftkx_series_dist_*) adds to the plan of a pass: the halo slice and where the gathered contributions will be
-struct DistPlan { int t_halo; int rank, nranks; const u64 *gathered; u64 *contrib; void *masks_out; };
+struct DistPlan { int t_halo; int rank, nranks; const u64 *gathered; u64 *contrib; void *masks_out; hipStream_t side; };
 
 int series_queue_cull(ftkx_ctx *c, ftkx_series_pending &P);
 int series_queue_tail(ftkx_ctx *c, ftkx_series_pending &P);
@@ -639,7 +639,26 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
     HIP_TRY(c, hipEventRecord(Bp.ev_fetched, c->stream));
     series_queue_copy(c, *before, Bp.ev_fetched);
   }
-  if (ntodo) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs, (int)ntodo, c->stream); ev_end(c); }
+  if (dist && dist->masks_out) {
+    // A slab pass with a lower neighbour: the FIRST slice's masks are that neighbour's halo.  They are built first, by a launch of their
+    // own, and packed into the message right behind it -- the message can then cross xGMI (on the caller's side stream, which is made to
+    // wait for the export here) while the masks of the slab's other slices are still being built.
+    if (!B.dist_block) { HIP_TRY(c, hipMalloc((void **)&B.dist_block, (size_t)ftkx::DB_N * sizeof(u64))); HIP_TRY(c, hipMemsetAsync(B.dist_block, 0, (size_t)ftkx::DB_N * sizeof(u64), c->stream)); }
+    size_t ub, cap, off_idx, off_words, total_msg;
+    if (!packed_layout(c, m, &ub, &cap, &off_idx, &off_words, &total_msg)) return fail(c, FTKX_E_UNSUPPORTED, "slab pass: this mesh has no summarised masks");
+    const bool first_now = red_index[0] == 0;              // (its masks are built in this pass: job 0)
+    size_t done = 0;
+    if (first_now) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs, 1, c->stream); ev_end(c); done = 1; }
+    char *out = (char *)dist->masks_out;
+    int flog = 0; while (flog < 63 && (1ull << flog) < hint) flog ++;
+    ftkx::launch_dist_export(m, sl[0]->U, sl[0]->M, ub, (u64 *)out, (unsigned *)(out + off_idx), (u64 *)(out + off_words), cap, flog, B.dist_block, c->stream);
+    if (dist->side) {
+      if (!B.ev_export) HIP_TRY(c, hipEventCreateWithFlags(&B.ev_export, hipEventDisableTiming));
+      HIP_TRY(c, hipEventRecord(B.ev_export, c->stream));
+      HIP_TRY(c, hipStreamWaitEvent(dist->side, B.ev_export, 0));
+    }
+    if (ntodo > done) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs + done, (int)(ntodo - done), c->stream); ev_end(c); }
+  } else if (ntodo) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs, (int)ntodo, c->stream); ev_end(c); }
   P.running_from = prev ? c->sr_buf[prev->buf].results : nullptr;
   P.pipelined = pipelined;
   HIP_TRY(c, hipGetLastError());
@@ -959,7 +978,7 @@ ftkx_series_pending *dist_pending(ftkx_ctx *c, int stage, const char *who)
 size_t ftkx_series_dist_cells(const ftkx_ctx *c) { return c && c->mesh_set && c->scalar_mode >= 0 ? dist_cells_cap(c) : 0; }
 
 int ftkx_series_dist_begin(ftkx_ctx *c, const int *ts, const int *scopes, int n, const double *running_resolution, int rank, int nranks, int halo,
-                           void *contrib, const void *gathered, void *masks_out)
+                           void *contrib, const void *gathered, void *masks_out, void *side_stream)
 {
   if (!c || n <= 0 || !ts || !scopes || !running_resolution || !contrib || !gathered) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: null argument or no steps");
   if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "sweep: call ftkx_set_mesh first");
@@ -977,7 +996,7 @@ int ftkx_series_dist_begin(ftkx_ctx *c, const int *ts, const int *scopes, int n,
   const int t_halo = halo ? ts[n - 1] + 1 : -1;
   if (halo && (rc = ensure_sparse_slice(c, t_halo, c->scalar_mode))) return rc;
   ftkx_series_pending *before = c->sr_open > 0 ? &c->sr_pend[(c->sr_head + c->sr_open - 1) & 1] : nullptr;
-  DistPlan dp{t_halo, rank, nranks, (const u64 *)gathered, (u64 *)contrib, masks_out};
+  DistPlan dp{t_halo, rank, nranks, (const u64 *)gathered, (u64 *)contrib, masks_out, (hipStream_t)side_stream};
   if ((rc = series_plan(c, Q, ts, scopes, n, *running_resolution, nullptr, true, before, &dp))) { Q.open = false; Q.dist = false; return rc; }
   if (Q.by_host) {      // (options the device-driven form does not cover: a slab pass has no host-driven form of its own -- the caller's protocol does)
     Q.open = false; Q.dist = false;
@@ -986,19 +1005,10 @@ int ftkx_series_dist_begin(ftkx_ctx *c, const int *ts, const int *scopes, int n,
   ftkx_series_buffers &B = c->sr_buf[Q.buf];
   if (!B.dist_block) { HIP_TRY(c, hipMalloc((void **)&B.dist_block, (size_t)ftkx::DB_N * sizeof(u64))); HIP_TRY(c, hipMemsetAsync(B.dist_block, 0, (size_t)ftkx::DB_N * sizeof(u64), c->stream)); }
   Q.running_from = B.dist_block + ftkx::DB_PSEUDO;
-  // this rank's contribution (its slab's reductions folded) and, for a lower neighbour, the masks of its first slice as ONE message
+  // this rank's contribution to the all_gather: its slab's reductions folded (the first slice's masks went out inside the plan)
   const ftkx::SeriesSlice *d_slices = (const ftkx::SeriesSlice *)((char *)B.d_desc + Q.off_slices);
   const int nown = (int)Q.k - (halo ? 1 : 0);
   ftkx::launch_dist_contrib(d_slices, nown, c->d_red, (u64 *)contrib, B.dist_block, c->stream);
-  if (masks_out) {
-    Mesh m; fill_mesh(c, m);
-    size_t ub, cap, off_idx, off_words, total;
-    if (!packed_layout(c, m, &ub, &cap, &off_idx, &off_words, &total)) return fail(c, FTKX_E_UNSUPPORTED, "ftkx_series_dist_begin: this mesh has no summarised masks");
-    const Slice &s0 = c->slices.find(Q.slice_ts[0])->second;
-    char *out = (char *)masks_out;
-    ftkx::launch_compact_words(m, s0.U, s0.M, (unsigned *)(out + off_idx), (u64 *)(out + off_words), cap, B.dist_block + ftkx::DB_WORDS, c->stream);
-    ftkx::launch_pack_masks((u64 *)out, B.dist_block + ftkx::DB_WORDS, s0.U, ub, cap, m.u_rows, factor_log2_of(Q.hint), c->stream);
-  }
   HIP_TRY(c, hipGetLastError());
   Q.dist_stage = 1;
   return FTKX_OK;
@@ -1014,15 +1024,18 @@ int ftkx_series_dist_cull(ftkx_ctx *c, const void *masks_in, void *request_out)
   HIP_TRY(c, hipSetDevice(c->device));
   ftkx_series_buffers &B = c->sr_buf[P.buf];
   Mesh m; series_mesh(c, P, m);
-  // the running minimum before this slab (and the gathered block into the results, for the host)
-  ftkx::launch_dist_prefix(P.gathered, P.dist_rank, P.dist_nranks, P.running_in, B.dist_block, B.results + (size_t)ftkx::SR_HEAD + (size_t)P.n + 2 * P.k, c->stream);
-  if (P.t_halo >= 0) {
-    size_t ub, cap, off_idx, off_words, total;
-    if (!packed_layout(c, m, &ub, &cap, &off_idx, &off_words, &total)) return fail(c, FTKX_E_UNSUPPORTED, "ftkx_series_dist_cull: this mesh has no summarised masks");
-    Slice &h = c->slices.find(P.t_halo)->second;
-    const char *in = (const char *)masks_in;
-    ftkx::launch_scatter_packed((const u64 *)in, (const unsigned *)(in + off_idx), (const u64 *)(in + off_words), ub, cap, m.u_rows, factor_log2_of(P.hint), h.U, h.M,
-                                mask_bytes(c) / 8, B.dist_block + ftkx::DB_BAD, c->stream);
+  // the running minimum before this slab (and the gathered block into the results, for the host); the halo's masks into its slice
+  {
+    u64 *tail = B.results + (size_t)ftkx::SR_HEAD + (size_t)P.n + 2 * P.k;
+    if (P.t_halo >= 0) {
+      size_t ub, cap, off_idx, off_words, total;
+      if (!packed_layout(c, m, &ub, &cap, &off_idx, &off_words, &total)) return fail(c, FTKX_E_UNSUPPORTED, "ftkx_series_dist_cull: this mesh has no summarised masks");
+      Slice &h = c->slices.find(P.t_halo)->second;
+      const char *in = (const char *)masks_in;
+      ftkx::launch_dist_import(P.gathered, P.dist_rank, P.dist_nranks, P.running_in, B.dist_block, tail, (const u64 *)in, (const unsigned *)(in + off_idx), (const u64 *)(in + off_words), ub, cap,
+                               m.u_rows, factor_log2_of(P.hint), h.U, h.M, mask_bytes(c) / 8, c->stream);
+    } else
+      ftkx::launch_dist_import(P.gathered, P.dist_rank, P.dist_nranks, P.running_in, B.dist_block, tail, nullptr, nullptr, nullptr, 0, 0, m.u_rows, 0, nullptr, nullptr, 0, c->stream);
   }
   int rc;
   if ((rc = series_queue_cull(c, P))) return rc;

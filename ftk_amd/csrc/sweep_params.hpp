@@ -161,7 +161,8 @@ enum { SR_STATUS = 0, SR_RUNNING = 1, SR_NHITS = 2, SR_NFRAGILE = 3, SR_BASE_NEX
        SR_COUNTERS = 7, SR_HEAD = 7 + CNT_N };   // then factors[nsteps], res[nslices], max[nslices], [slab pass: 4 words per rank as gathered], fragile[cap * 10]
 // slab pass: the per-pass block of device words next to the results (series.hip): counters of the halo hand-over and a stub shaped like a
 // results block whose SR_RUNNING word is the running minimum BEFORE this rank's slab (what FactorJob::running_from reads)
-enum { DB_WORDS = 0 /* mask words compacted into the outgoing message */, DB_BAD = 1 /* the incoming mask message did not fit / did not match */, DB_PSEUDO = 8, DB_N = 16 };
+enum { DB_WORDS = 0 /* mask words compacted into the outgoing message */, DB_BAD = 1 /* the incoming mask message did not fit / did not match */,
+       DB_DONE = 2 /* workgroups of the export kernel that have finished */, DB_BAD2 = 3 /* the incoming message named a word outside the mask array */, DB_PSEUDO = 8, DB_N = 16 };
 constexpr int kDistContrib = 4;            // words a rank contributes to the all_gather: slab min resolution, slab max |v|, the same of its FIRST slice
 
 }  // namespace ftkx

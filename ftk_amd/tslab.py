@@ -260,6 +260,9 @@ class SlabSeries:
                                   masks_out=z(nbytes, u8) if self.lower is not None else None, masks_in=z(nbytes, u8) if self.upper is not None else None,
                                   req_out=z(1 + cells, i64) if self.upper is not None else None, req_in=z(1 + cells, i64) if self.lower is not None else None,
                                   reply_out=z(cells * pd, f64) if self.lower is not None else None, reply_in=z(cells * pd, f64) if self.upper is not None else None))
+        # (nccl) the masks' way to the lower neighbour runs on a stream of its own: it starts as soon as the first slice's masks are packed,
+        # next to the mask kernel of the slab's other slices; the context's stream waits for it in front of the cull
+        self.side = torch.cuda.Stream(device=device) if (not self.staged and self.own and (self.lower is not None or self.upper is not None)) else None
         self.k = 0
         self.open = []              # buffer sets of the passes in flight, oldest first
         self.stash = []             # outcomes of passes completed early (a recovery needed the context free)
@@ -301,9 +304,17 @@ class SlabSeries:
             self.open.append(b)
             return
         ctx = self.ctx
-        ctx.series_dist_begin(self.ts, self.scopes, running_resolution, self.rank, self.world, self.upper is not None, b["contrib"], b["gathered"], b["masks_out"])
-        self._all_gather(b["gathered"], b["contrib"])
-        self._exchange(b["masks_out"], self.lower, b["masks_in"], self.upper)
+        ctx.series_dist_begin(self.ts, self.scopes, running_resolution, self.rank, self.world, self.upper is not None, b["contrib"], b["gathered"], b["masks_out"],
+                              side_stream=self.side.cuda_stream if self.side is not None else None)
+        if self.side is not None:
+            main = self.torch.cuda.current_stream()
+            with self.torch.cuda.stream(self.side):
+                self._exchange(b["masks_out"], self.lower, b["masks_in"], self.upper)
+            self._all_gather(b["gathered"], b["contrib"])
+            main.wait_stream(self.side)
+        else:
+            self._all_gather(b["gathered"], b["contrib"])
+            self._exchange(b["masks_out"], self.lower, b["masks_in"], self.upper)
         ctx.series_dist_cull(b["masks_in"], b["req_out"])
         self._exchange(b["req_out"], self.upper, b["req_in"], self.lower)
         ctx.series_dist_serve(b["req_in"], b["reply_out"])

@@ -226,7 +226,10 @@ int ftkx_sweep_series_abort(ftkx_ctx *ctx);
  * between them the caller queues its collectives on the context's stream (RCCL: ncclAllGather / ncclSend / ncclRecv, or
  * torch.distributed with that stream current) -- nothing is waited for on the host until ftkx_sweep_series_complete:
  *   _begin   masks + reduction of this rank's slices; `contrib` (4 doubles: min resolution and max |v| of the slab, and of its FIRST slice)
- *            and, with masks_out, the first slice's sign masks as one message of ftkx_packed_masks_bytes() bytes
+ *            and, with masks_out, the first slice's sign masks as one message of ftkx_packed_masks_bytes() bytes -- built and packed FIRST:
+ *            with a side_stream, that stream is made to wait for the message only, so a send queued on it crosses xGMI while the masks
+ *            of the slab's other slices are still being built (the caller makes the context's stream wait for the side stream's receive
+ *            before _cull)
  *      caller: all_gather(contrib -> gathered, 4 doubles per rank); masks_out -> lower neighbour, upper neighbour's -> masks_in
  *   _cull    the halo's masks imported, the running minimum before this slab from `gathered`, cull + factors, and `request_out`:
  *            1 + ftkx_series_dist_cells() words -- the count of surviving cells whose exact test reads the halo slice and their indices
@@ -245,7 +248,7 @@ int ftkx_sweep_series_abort(ftkx_ctx *ctx);
  * ftkx_sweep_cull / ftkx_sweep_collect. */
 size_t ftkx_series_dist_cells(const ftkx_ctx *ctx);
 int ftkx_series_dist_begin(ftkx_ctx *ctx, const int *timesteps, const int *scopes, int n, const double *running_resolution, int rank, int nranks, int halo,
-                           void *contrib, const void *gathered, void *masks_out);
+                           void *contrib, const void *gathered, void *masks_out, void *side_stream /* hipStream_t, nullable */);
 int ftkx_series_dist_cull(ftkx_ctx *ctx, const void *masks_in, void *request_out);
 int ftkx_series_dist_serve(ftkx_ctx *ctx, const void *request_in, void *reply_out);
 int ftkx_series_dist_finish(ftkx_ctx *ctx, const void *reply_in);
