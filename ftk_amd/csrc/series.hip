@@ -79,7 +79,8 @@ int slot_prepare(ftkx_ctx *c, ftkx_series_slot &sl, size_t nbins, size_t nwords)
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     HIP_TRY(c, hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, hi));     // (the tails are latency chains: they go first wherever a slot frees up)
     for (hipEvent_t *e : {&sl.ev_masks, &sl.ev_factors, &sl.ev_done}) HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
-    HIP_TRY(c, hipMalloc((void **)&sl.counters, (size_t)ftkx::CNT_N * sizeof(u64)));
+    HIP_TRY(c, hipMalloc((void **)&sl.counters, (size_t)(ftkx::CNT_N + 128 + 8) * sizeof(u64)));      // (as ftkx_ctx::d_counters: the words behind the counters hold a kernel's queue)
+    HIP_TRY(c, hipMemsetAsync(sl.counters, 0, (size_t)(ftkx::CNT_N + 128 + 8) * sizeof(u64), c->stream));
   }
   size_t cap;
   cap = (size_t)sl.list_cap; if ((rc = grow_device(c, &sl.list, &cap, std::max<size_t>(cap, 1u << 20)))) return rc; sl.list_cap = cap;

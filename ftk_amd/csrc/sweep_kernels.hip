@@ -682,120 +682,6 @@ __global__ __launch_bounds__(kThreads) void mask_vec_kernel(const Mesh m, const 
   if (job.red) red_commit(job.red, red_mn, red_mx, blockIdx.x * 5u + (threadIdx.x >> 6));
 }
 
-// Scalar input: the same masks, produced by a register-marching stencil so that every S value is fetched from HBM once.
-//   lane        = one x column (a wavefront is a 64-wide x row; x neighbours come from the adjacent lanes by DPP wavefront
-//                 shifts, the two tile-edge lanes fetch their outside neighbour themselves);
-//   wavefront   = RY consecutive y rows held in registers (+1 halo row either side for d/dy);
-//   march       = along z (3D): planes z-1, z, z+1 of the wavefront's rows rotate through registers, one new plane is loaded
-//                 per step; in 2D there is nothing to march over, the RY rows give the y reuse.
-// All loads are unconditional at CLAMPED array coordinates: in 2D that is literally gradient2D's index clamp (grad.hh:17-21);
-// in 3D a clamped value is only ever read for a vertex that is not interior, whose gradient is 0 by definition.
-// A NaN component compares false both ways and simply never contributes to a cull; +-Inf culls by its sign, which is safe
-// because any simplex that contains that vertex is rejected by the exact path anyway.
-__device__ inline double dpp_from_lower_lane(double v)   // lane n <- lane n-1 (lane 0 keeps its own value)
-{
-  const long long b = __double_as_longlong(v);
-  int lo = (int)b, hi = (int)(b >> 32);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-__device__ inline double dpp_from_upper_lane(double v)   // lane n <- lane n+1 (lane 63 keeps its own value)
-{
-  const long long b = __double_as_longlong(v);
-  int lo = (int)b, hi = (int)(b >> 32);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-
-template <int ND>
-__global__ __launch_bounds__(kThreads) void mask_march_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk)
-{
-  constexpr int RY = (ND == 3) ? 4 : 8;
-  const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
-  const int nzc = (ND == 3) ? (DD + zchunk - 1) / zchunk : 1;
-  const MaskJob job = jobs[blockIdx.z / nzc];
-  const int z0 = (ND == 3) ? (int)(blockIdx.z % nzc) * zchunk : 0;
-  const int z1 = (ND == 3) ? (z0 + zchunk < DD ? z0 + zchunk : DD) : 1;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + lane;                       // array x of this lane (may lie in the row padding)
-  const int j0 = (blockIdx.y * 4 + wv) * RY;                  // first own row
-  if (j0 >= DH) return;                                       // whole wavefront outside (no barriers in this kernel)
-  const double *__restrict__ S = job.S;
-  const double thr = job.threshold;
-  const size_t sy = (size_t)DW, sz = (size_t)DW * DH;
-
-  // column: own (clamped) and, for the two edge lanes, the outside neighbour (clamped)
-  const int ic = i < DW ? i : DW - 1;
-  const bool edge = lane == 0 || lane == 63;
-  const int ih = lane == 0 ? (ic > 0 ? ic - 1 : 0) : (ic + 1 < DW ? ic + 1 : DW - 1);
-  const bool x_dom = i < DW && i + m.ext_st[0] >= m.dom_lb[0] && i + m.ext_st[0] <= m.dom_ub[0];
-  const bool x_int = i >= 1 && i < DW - 1;
-  // rows -1 .. RY: clamped row offsets; per-row flags as bit sets
-  size_t roff[RY + 2];
-  unsigned row_dom = 0, row_int = 0, row_ok = 0;
-  for (int r = 0; r < RY + 2; r ++) {
-    const int j = j0 + r - 1;
-    roff[r] = sy * (size_t)clampi(j, 0, DH - 1);
-    if (r >= 1 && r <= RY) {
-      if (j < DH) row_ok |= 1u << (r - 1);
-      if (j + m.ext_st[1] >= m.dom_lb[1] && j + m.ext_st[1] <= m.dom_ub[1]) row_dom |= 1u << (r - 1);
-      if (j >= 1 && j < DH - 1) row_int |= 1u << (r - 1);
-    }
-  }
-  const double *pc = S + ic, *ph = S + ih;
-
-  double cur[RY + 2], prv[RY], nxt[RY];                       // cur[r+1] = own row r; cur[0], cur[RY+1] = y halo rows
-  {
-    const size_t zo = sz * (size_t)z0, zp = sz * (size_t)(z0 > 0 ? z0 - 1 : 0);
-    for (int r = 0; r < RY + 2; r ++) cur[r] = pc[roff[r] + zo];
-    for (int r = 0; r < RY; r ++) prv[r] = (ND == 3) ? pc[roff[r + 1] + zp] : 0.0;
-  }
-  unsigned char *mrow = job.M + (size_t)i + (size_t)P * (size_t)j0;
-  double red_mn = DBL_MAX, red_mx = 0.0;      // fused pre-pass: see MaskJob::red
-
-  for (int k = z0; k < z1; k ++) {
-    const size_t zo = sz * (size_t)k, zn = sz * (size_t)(k + 1 < DD ? k + 1 : DD - 1);
-    double h0 = 0.0, h1 = 0.0;
-    if (ND == 3) {
-      for (int r = 0; r < RY; r ++) nxt[r] = pc[roff[r + 1] + zn];
-      h0 = pc[roff[0] + zn]; h1 = pc[roff[RY + 1] + zn];       // next plane's y halo rows
-    }
-    const bool z_dom = ND == 2 || (k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2]);
-    const bool z_int = ND == 2 || (k >= 1 && k < DD - 1);
-    for (int r = 0; r < RY; r ++) {
-      const double c = cur[r + 1];
-      double xm = dpp_from_lower_lane(c), xp = dpp_from_upper_lane(c);
-      if (edge) { const double h = ph[roff[r + 1] + zo]; if (lane == 0) xm = h; else xp = h; }
-      double g0, g1, g2 = 0.0;
-      if constexpr (ND == 3) { g0 = 0.5 * (xp - xm); g1 = 0.5 * (cur[r + 2] - cur[r]); g2 = 0.5 * (nxt[r] - prv[r]); }
-      else { g0 = (xp - xm) * (double)(DW - 1); g1 = (cur[r + 2] - cur[r]) * (double)(DH - 1); }
-      unsigned bits = (g0 >= thr ? 1u : 0u) | (g1 >= thr ? 2u : 0u) | (g0 <= -thr ? 8u : 0u) | (g1 <= -thr ? 16u : 0u);
-      if (ND == 3) bits |= (g2 >= thr ? 4u : 0u) | (g2 <= -thr ? 32u : 0u);
-      const bool rbit_int = (row_int >> r) & 1, rbit_dom = (row_dom >> r) & 1;
-      const bool real = (ND == 2 || (x_int && rbit_int && z_int)) && ((row_ok >> r) & 1) && i < DW;   // a value of gradient(S)
-      if (fmax(fmax(fabs(g0), fabs(g1)), fabs(g2)) >= job.big) bits = 0;   // may overflow a determinant: supports no cull
-      if (real) {
-        const double gs[3] = {g0, g1, g2};
-        for (int c = 0; c < ND; c ++) {
-          const double a = fabs(gs[c]);
-          red_mn = fmin(red_mn, (a == 0.0 || !(a < thr)) ? DBL_MAX : a);
-          red_mx = fmax(red_mx, a);
-        }
-      }
-      if (ND == 3 && !(x_int && rbit_int && z_int)) bits = 0;          // gradient3D leaves the array border at 0
-      if (!(x_dom && rbit_dom && z_dom)) bits = kNeutral;               // outside the domain (or row padding): never blocks a cull
-      if (((row_ok >> r) & 1) && i < P) mrow[(size_t)P * ((size_t)r + (size_t)DH * (size_t)k)] = (unsigned char)bits;
-    }
-    if (ND == 3) {
-      for (int r = 0; r < RY; r ++) { prv[r] = cur[r + 1]; cur[r + 1] = nxt[r]; }
-      cur[0] = h0; cur[RY + 1] = h1;
-    }
-  }
-  if (job.red) red_commit(job.red, red_mn, red_mx, blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + (unsigned)wv);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // The same walk as mask_march2_kernel<ND, EDGE = true, REDUCE> on a VALU diet.  rocprofv3 showed the kernel above issue-bound
 // (VALUBusy 72 %, 2.96e9 VALU instructions per 512^3 x 32 launch) rather than HBM-bound, so this version removes instructions
@@ -1139,197 +1025,6 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Producer / consumer form of the same walk (3D, 128-column layout).  The debug bits of mask_march4_kernel show its loads alone
-// take 6.1 ms on 512^3 x 32 and the sign arithmetic adds 0.5-1 ms on top: a wavefront that is computing is not issuing loads.
-// Here the two jobs belong to different wavefronts of a workgroup:
-//   * ONE producer wavefront streams the workgroup's tile of every plane -- 16 rows + 2 halo rows of 128 columns, plus the two
-//     outside-neighbour columns -- straight into LDS with LDS-DMA buffer loads (no VGPRs, PD planes ahead), each row ONCE per
-//     workgroup (the four consumers share their halo rows through LDS instead of each re-requesting them from L2);
-//   * FOUR consumer wavefronts (4 rows each) take the next plane from LDS, keep planes k-1, k, k+1 in registers rotating by
-//     name, and do exactly mask_march4_kernel's arithmetic and stores.
-// One s_barrier per plane: when it is passed, plane k+1 has landed (the producer waited for it with s_waitcnt vmcnt) and every
-// consumer has finished reading plane k's slot, which the producer then refills with plane k+1+PD.  Same mask / summary bytes.
-// ---------------------------------------------------------------------------------------------------------------
-// CY x RY = tile rows (CY consumer wavefronts of RY rows each, the tile is 128 columns wide), PD = planes in flight beyond the
-// one consumed next.  LDS: PD + 1 row slots of (CY RY + 2) KiB, and a ring of PD + 2 edge entries (256 B: the left and right
-// outside-neighbour value of each own row of a plane, fetched by ONE wavefront instruction).  The ring is one entry longer than
-// the row slots so that a plane's edge values are still there during the step that classifies it: consumers read them per row,
-// when they need them (two broadcast LDS reads), instead of carrying them in registers and shuffling them between lanes.
-template <int PD, int CY, int RY>
-__global__ __launch_bounds__(64 * (CY + 1)) void mask_march5_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle)
-{
-#if defined(__HIP_DEVICE_COMPILE__)   // the host pass silently drops the stub of a kernel whose body uses the LDS-DMA builtin: give it an empty body
-  constexpr int CW = CY, ROWS = RY * CY, TROWS = ROWS + 2, NS = PD + 1, NE = PD + 2;
-  static_assert(ROWS <= 16, "the edge values of a plane are fetched by one wavefront instruction: 2 x ROWS doubles = 4 x ROWS lanes");
-  constexpr unsigned ROWB = 1024u, SLOT = TROWS * ROWB, EDGEB = 256u, ERING = NS * SLOT;
-  constexpr int LOADS_PER_PLANE = TROWS + 1;                    // row DMAs + the edge values
-  static_assert(LOADS_PER_PLANE * (PD - 1) < 64, "vmcnt is a 6-bit counter: the wait below must be expressible (issue simply stalls beyond 63 in flight)");
-  extern __shared__ __attribute__((aligned(16))) char lds[];   // NS row slots, then NE edge entries
-  const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = m.ext_sz[2], P = m.mask_pitch;
-  const int nzc = (DD + zchunk - 1) / zchunk;
-  unsigned bx, by, bz;
-  remap_block(swizzle, bx, by, bz);
-  const MaskJob job = jobs[bz / nzc];
-  const int z0 = (int)(bz % nzc) * zchunk;
-  const int z1 = z0 + zchunk < DD ? z0 + zchunk : DD;
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int jb = (int)by * ROWS;                               // the workgroup's first own row
-  const int t0c = (int)bx * 128;                               // and first column
-  if (jb >= DH) return;                                        // whole workgroup: no barrier is left waiting
-  const unsigned sy = (unsigned)DW * 8u, sz = (unsigned)DW * (unsigned)DH * 8u;
-  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void *)job.S, 0, (int)(sz * (unsigned)DD), 0x00020000);
-  const int nsteps = ((z1 - z0 + 2) / 3) * 3;                  // both roles walk the same, padded number of planes (3 = consumer unroll)
-  auto slot_of = [&](int q) -> unsigned { return (unsigned)(((q - (z0 - 1)) % NS + NS) % NS) * SLOT; };
-  auto edge_of = [&](int q) -> unsigned { return ERING + (unsigned)(((q - (z0 - 1)) % NE + NE) % NE) * EDGEB; };
-
-  if (wv == CW) {
-    // ---------------- producer ----------------
-    // column pair of this lane, clamped so that lanes beyond the row load valid memory
-    const int ip = t0c + 2 * lane;
-    const unsigned cb = (unsigned)(ip < DW ? ip : DW - 2) * 8u;
-    // edge values: lanes 2e and 2e + 1 fetch the low and high dword of edge e; e < 16: left neighbour of own row e, e >= 16: right
-    // neighbour of own row e - 16 (so each lands in LDS as a whole double, at 8 e).  Lanes without an edge carry an offset
-    // beyond num_records, which a buffer load answers with 0 without touching memory.
-    unsigned eoff = 0xfffffff0u;
-    {
-      const int e = lane >> 1, row = e & 15;
-      if (row < ROWS) {
-        const int col = e < 16 ? (t0c > 0 ? t0c - 1 : 0) : (t0c + 128 < DW ? t0c + 128 : DW - 1);
-        eoff = sy * (unsigned)clampi(jb + row, 0, DH - 1) + (unsigned)col * 8u + 4u * (unsigned)(lane & 1);
-      }
-    }
-    unsigned roff[TROWS];
-    for (int t = 0; t < TROWS; t ++) roff[t] = sy * (unsigned)clampi(jb + t - 1, 0, DH - 1);
-    const bool nt_all = (swizzle & 4) != 0, nt_private = (swizzle & 16) != 0;
-    auto issue = [&](int q) {
-      const unsigned zo = sz * (unsigned)clampi(q, 0, DD - 1);
-      const unsigned base = slot_of(q);
-      for (int t = 0; t < TROWS; t ++) {
-        __attribute__((address_space(3))) void *dst = (__attribute__((address_space(3))) void *)(lds + base + (unsigned)t * ROWB);
-        // rows 0 and TROWS-1 are own rows of the neighbouring workgroups, rows 1 and TROWS-2 their halo rows: leave those cached
-        const bool nt = nt_all || (nt_private && t >= 2 && t <= TROWS - 3);
-        if (nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, dst, 16, cb, zo + roff[t], 0, 2);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, dst, 16, cb, zo + roff[t], 0, 0);
-      }
-      __attribute__((address_space(3))) void *edst = (__attribute__((address_space(3))) void *)(lds + edge_of(q));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, edst, 4, eoff, zo, 0, 0);
-    };
-    // s_waitcnt vmcnt(N) only: gfx9 encoding, vmcnt = simm16[15:14]:[3:0], expcnt [6:4], lgkmcnt [11:8] left at their maxima
-#define FTKX_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))
-    issue(z0 - 1); issue(z0);
-    FTKX_WAIT_VM(0);
-    __builtin_amdgcn_s_barrier();                              // P1: planes z0-1 and z0 are in LDS
-    __builtin_amdgcn_s_barrier();                              // P2: the consumers have taken them
-    for (int q = z0 + 1; q <= z0 + PD; q ++) issue(q < z1 ? q : z1);
-    for (int s = 0; s < nsteps; s ++) {
-      const int k = z0 + s;
-      FTKX_WAIT_VM(LOADS_PER_PLANE * (PD - 1));                 // plane k+1 has landed (planes k+2 .. k+PD may still be on their way)
-      __builtin_amdgcn_s_barrier();
-      // into the row slot of plane k, which every consumer has finished with, and the edge entry of plane k - 1 (the consumers
-      // read plane k's own edge entry during this very step: it is the one entry the ring has more than there are row slots)
-      const int q = k + 1 + PD;
-      issue(q < z1 ? q : z1);
-    }
-    FTKX_WAIT_VM(0);                                           // nothing may still be writing LDS when the workgroup retires
-#undef FTKX_WAIT_VM
-    return;
-  }
-
-  // ---------------- consumers ----------------
-  const int wy = wv;                                           // position of this wavefront's 128 x RY patch inside the tile
-  const int i0 = t0c + 2 * lane;
-  const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)job.M, 0, (int)((unsigned)P * (unsigned)DH * (unsigned)DD), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)job.U, 0, (int)((unsigned)m.u_pitch * (unsigned)DH * (unsigned)DD), 0x00020000);
-  const bool have_u = job.U != nullptr;
-  const double thr = job.threshold;
-  const double tpos = 2.0 * thr, tneg = -tpos;
-  const int j0 = jb + wy * RY;                                 // this wavefront's first own row
-  unsigned xkeep = 0, xneutral = 0;
-  for (int c = 0; c < 2; c ++) {
-    const int i = i0 + c;
-    const bool x_dom = i < DW && i + m.ext_st[0] >= m.dom_lb[0] && i + m.ext_st[0] <= m.dom_ub[0];
-    const bool x_int = i >= 1 && i < DW - 1;
-    if (x_int) xkeep |= 0x3fu << (8 * c);
-    if (!x_dom) xneutral |= 0x3fu << (8 * c);
-  }
-  unsigned row_dom = 0, row_int = 0, row_ok = 0;
-  for (int r = 0; r < RY; r ++) {
-    const int j = j0 + r;
-    if (j < DH) row_ok |= 1u << r;
-    if (j + m.ext_st[1] >= m.dom_lb[1] && j + m.ext_st[1] <= m.dom_ub[1]) row_dom |= 1u << r;
-    if (j >= 1 && j < DH - 1) row_int |= 1u << r;
-  }
-  const bool in_row = i0 < DW;
-  const bool store_ok = in_row;
-  const unsigned mcol = (unsigned)i0, ucol = (unsigned)(i0 >> 3);
-  const bool u_lane = (lane & 3) == 0 && in_row;
-  // fused pre-pass: see guard_and_reduce
-  double acc0 = 0.0, acc1 = 0.0, red_mn = DBL_MAX;
-  const unsigned cmask = in_row ? (xkeep & 0x0707u) : 0u;
-  const double tbig = 2.0 * job.big;
-  const bool per_vertex_rule = job.big < HUGE_VAL;
-  // LDS addresses: this lane's 16 bytes of a row; the edge doubles of this wavefront's first own row inside an edge entry
-  const unsigned lrow = (unsigned)(lane * 16), eown = (unsigned)(wy * RY) * 8u;
-  auto take_plane = [&](v2d (&B)[RY + 2], int q) {
-    const char *base = lds + slot_of(q);
-    for (int r = 0; r < RY + 2; r ++) B[r] = *reinterpret_cast<const v2d *>(base + (unsigned)(wy * RY + r) * ROWB + lrow);
-  };
-
-  auto step = [&](const v2d (&PR)[RY + 2], const v2d (&CU)[RY + 2], v2d (&NX)[RY + 2], int k) {
-    __builtin_amdgcn_s_barrier();                              // plane k+1 is in LDS; nobody reads plane k's slot any more
-    take_plane(NX, k + 1 < z1 ? k + 1 : z1);
-    const char *eb = lds + edge_of(k < z1 ? k : z1) + eown;    // plane k's outside neighbours (planes past the chunk re-walk plane z1)
-    const bool z_dom = k + m.ext_st[2] >= m.dom_lb[2] && k + m.ext_st[2] <= m.dom_ub[2];
-    const bool z_int = k >= 1 && k < DD - 1;
-    const unsigned mplane = (unsigned)P * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
-    const unsigned uplane = (unsigned)m.u_pitch * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
-    static_for<RY>([&](auto rc) {
-      constexpr int r = decltype(rc)::value;
-      const v2d c = CU[r + 1];
-      // every lane reads the same two doubles (a broadcast); only lane 0 keeps the left one, lane 63 the right one (`old` of the shifts)
-      const double xl = *reinterpret_cast<const double *>(eb + 8 * r), xr = *reinterpret_cast<const double *>(eb + 128 + 8 * r);
-      const double xm = dpp_lower_or(c.y, xl), xp = dpp_upper_or(c.x, xr);
-      const double dx0 = c.y - xm, dx1 = xp - c.x;
-      const double dy0 = CU[r + 2].x - CU[r].x, dy1 = CU[r + 2].y - CU[r].y;
-      const double dz0 = NX[r + 1].x - PR[r + 1].x, dz1 = NX[r + 1].y - PR[r + 1].y;
-      const bool u_int = ((row_int >> r) & 1) && z_int, u_dom = ((row_dom >> r) & 1) && z_dom;
-      unsigned a0 = 0, a1 = 0;
-      shift_in_signs<3>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, tneg, tpos);
-      const bool rok = ((row_ok >> r) & 1) && k < z1;
-      unsigned bits = guard_and_reduce<3>(a0, a1, dx0, dx1, dy0, dy1, dz0, dz1, u_int && rok, cmask, per_vertex_rule, tbig, 0.5, acc0, acc1, red_mn);
-      const unsigned keep = u_int ? xkeep : 0u;
-      const unsigned neut = u_dom ? xneutral : 0x3f3fu;
-      bits = (bits & keep) | neut;
-      bool word_uniform = false;
-      if (have_u) {
-        const unsigned q = word_summary(bits);
-        if (rok && u_lane) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)q, rU, ucol, uplane + (unsigned)m.u_pitch * (unsigned)r, 0);
-        word_uniform = q != 0;
-      }
-      if (rok && store_ok && !word_uniform)
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rM, mcol, mplane + (unsigned)P * (unsigned)r, 0);
-    });
-  };
-
-  v2d B[3][RY + 2];
-  __builtin_amdgcn_s_barrier();                                // P1
-  take_plane(B[0], z0 - 1);
-  take_plane(B[1], z0);
-  __builtin_amdgcn_s_barrier();                                // P2 (the compiler has waited for the LDS reads above: their values are used)
-  for (int s = 0; s < nsteps; s += 3) {
-    step(B[0], B[1], B[2], z0 + s);
-    step(B[1], B[2], B[0], z0 + s + 1);
-    step(B[2], B[0], B[1], z0 + s + 2);
-  }
-  if (job.red) {
-    const double mx = fmax((cmask & 0x00ffu) ? acc0 : 0.0, (cmask & 0xff00u) ? acc1 : 0.0) * 0.5;
-    red_commit(job.red, red_mn < job.threshold ? red_mn : DBL_MAX, mx, blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + (unsigned)wv);
-  }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // The same walk WITHOUT a dedicated producer: every wavefront of the workgroup is a consumer and issues the LDS-DMA loads of its
 // own rows (plus one of the three odd jobs: the two halo rows and the edge values).  Why: a workgroup's wavefronts land on the
 // CU's four SIMDs round-robin from a random start (tools/probe/simd_map.hip), so with 1 + 3 wavefronts per workgroup and three
@@ -1420,8 +1115,20 @@ __device__ inline void wait_plane_landed(int s)
 #undef FTKX_WAIT_VM
 }
 
+// The z extent of a slice in PIECES of unequal length, the same for every tile column: blockIdx.z = piece * njobs + slice, pieces in
+// order of decreasing length.  The hardware hands workgroups out in order of their index as slots free up -- a queue --, so the long
+// pieces (up to half a column) go out first and the launch ends on pieces of a few planes: the device stays full until a few
+// microseconds before the end whatever the size of the series (equal chunks of 32 planes: 256^3 x 16 is 5.3 rounds of workgroups, a
+// 512^3 slice on its own 2.7), and the two start-up planes of a march are paid per piece -- 7 pieces per 512 planes on 512^3 x 32
+// instead of 16 chunks.  (Persistent workgroups pulling such pieces from a queue of their own were built and measured: the loop state
+// costs the kernel 36 more SGPR spills and 12 VGPRs of scratch at three wavefronts per SIMD -- 7.6 ms against 5.7 on 512^3 x 32.)
+struct ZPlan {
+  unsigned npieces;
+  unsigned z0[47], len[47];
+};
+
 template <int NS, int CY, int RY, bool TWOB>
-__device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle, int split, int main_jobs, int zc_tail)
+__device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__restrict__ jobs, int swizzle, int njobs, const ZPlan &plan)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int ROWS = RY * CY, TROWS = ROWS + 2, NE = NS + 1;             // NS row slots, NS + 1 edge entries
@@ -1439,15 +1146,10 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
   const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = m.ext_sz[2], P = m.mask_pitch;
   unsigned bx, by, bz;
   remap_block(swizzle, bx, by, bz);
-  // the last slices of a launch may come in shorter chunks (z blocks from `split` on: slices main_jobs, main_jobs + 1, ... in chunks
-  // of zc_tail planes): the workgroups that run last, when the device is no longer full, are short ones
-  const bool tail = (int)bz >= split;
-  if (tail) zchunk = zc_tail;
-  const int nzc = (DD + zchunk - 1) / zchunk;
-  const int lz = tail ? (int)bz - split : (int)bz;
-  const MaskJob job = jobs[(tail ? main_jobs : 0) + lz / nzc];
-  const int z0 = (lz % nzc) * zchunk;
-  const int z1 = z0 + zchunk < DD ? z0 + zchunk : DD;
+  const unsigned piece = bz / (unsigned)njobs;
+  const MaskJob job = jobs[bz - piece * (unsigned)njobs];
+  const int z0 = (int)plan.z0[piece];
+  const int z1 = z0 + (int)plan.len[piece];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int jb = (int)by * ROWS, t0c = (int)bx * 128;
@@ -1491,7 +1193,7 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
   };
 #define FTKX_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))
 
-  // ---- the consumer's constants (as in mask_march5_kernel) ----
+  // ---- what the classification of a plane needs ----
   const int wy = wv;
   const int i0 = t0c + 2 * lane;
   const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)job.M, 0, (int)((unsigned)P * (unsigned)DH * (unsigned)DD), 0x00020000);
@@ -1700,9 +1402,9 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
 }
 
 template <int NS, int CY, int RY, bool TWOB>
-__global__ __launch_bounds__(64 * CY) void mask_march6_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int zchunk, int swizzle, int split, int main_jobs, int zc_tail)
+__global__ __launch_bounds__(64 * CY) void mask_march6_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int swizzle, int njobs, const ZPlan plan)
 {
-  march6_body<NS, CY, RY, TWOB>(m, jobs, zchunk, swizzle, split, main_jobs, zc_tail);
+  march6_body<NS, CY, RY, TWOB>(m, jobs, swizzle, njobs, plan);
 }
 // ---------------------------------------------------------------------------------------------------------------
 // FAST PATH 2/3: corner cull on the mask bytes, 8 corners per lane (SWAR), survivors -> work list
@@ -2509,137 +2211,86 @@ static bool vec_fast(const Mesh &m) { return !m.scalar_mode && m.ext_sz[0] >= 8 
 void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool reduce, hipStream_t stream)
 {
   if (njobs <= 0) return;
-  if (m.scalar_mode) {
-    const int RY = (m.nd == 3) ? 4 : 8;
-    const int DD = m.nd == 3 ? m.ext_sz[2] : 1;
-    // z chunks: long enough to amortise the two start-up planes, short enough to fill 256 CUs several times over
-    int zchunk = 32;
-    bool zforced = false;
-    if (const char *e = getenv("FTKX_MASK_ZCHUNK")) if (atoi(e) > 0) { zchunk = atoi(e); zforced = true; }
-    if (m.nd == 3 && !zforced) { while (zchunk > 8 && (size_t)((m.mask_pitch + 127) / 128) * ((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)) * ((DD + zchunk - 1) / zchunk) * njobs < 4096) zchunk /= 2; }
-    int swizzle = 8;   // grouped placement -- the 4..8 x tiles of a row group on one XCD -- cuts the fabric reads from 47.7 to 41.4 GB per 512^3 x 32 launch
+  if (m.scalar_mode && march2_supported(m)) {
+    // scalar slices with an even row length below 4 GiB: the marching kernels on 128-column, line-aligned tiles
+    const int DW = m.ext_sz[0], DD = m.nd == 3 ? m.ext_sz[2] : 1;
+    int swizzle = 8;   // grouped placement -- the x tiles of some row groups on one XCD -- cuts the fabric reads from 47.7 to 41.4 GB per 512^3 x 32 launch
     // 2D: the rows of a wavefront's block that no other wavefront reads (all but its first and last two) are loaded non-temporally -- they are
     // read once, and keeping them out of the caches leaves the halo rows there for the neighbours: woven 1024^2 x 64 0.115 -> 0.102 ms (all
     // loads non-temporal: 0.106; 3D, where the planes are re-read by the z march: 256^3 x 16 -1 %, 512^3 x 32 +1.3 %: left as it is.  The
     // vector-input kernel, whose every value is read once, does NOT like non-temporal loads: double_gyre 0.73 -> 1.30 ms)
     if (m.nd == 2) swizzle |= 16;
     if (const char *e = getenv("FTKX_MASK_SWIZZLE")) swizzle = atoi(e);
-    const int nzc = m.nd == 3 ? (DD + zchunk - 1) / zchunk : 1;
-    if (march2_supported(m)) {
-      // 128-column tiles, the two outside-neighbour columns fetched separately (line-aligned tiles)
-      const int DW = m.ext_sz[0];
-      int wpb = 4;
-      if (const char *e = getenv("FTKX_MASK_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 12) wpb = v; }
-      const dim3 grid2((unsigned)((DW + 127) / 128), (unsigned)((m.ext_sz[1] + wpb * RY - 1) / (wpb * RY)), (unsigned)(nzc * njobs));
-      int yg_want = 4;       // grouped placement: YG row groups per group -- y-neighbouring tiles on one XCD share their halo rows in its L2
+    int zchunk = 32;
+    bool zforced = false;
+    if (const char *e = getenv("FTKX_MASK_ZCHUNK")) if (atoi(e) > 0) { zchunk = atoi(e); zforced = true; }
+    if (m.nd == 3 && !reduce) {
+      // 3D: mask_march6_kernel -- 128 x 16 tiles as four wavefronts of 4 rows that all load (LDS-DMA) and classify, TWO row slots in
+      // LDS (37 KB: three workgroups = twelve wavefronts per CU, which its 164 VGPRs allow), one barrier per plane; grouped placement:
+      // 16 row groups (all of a 256^2 plane's, half of a 512^2 plane's tiles) of one piece of planes share an XCD's L2 (4: +3.5 %, 8: +0.5 %)
+      int yg_want = 16;
       if (const char *e = getenv("FTKX_MASK_YG")) yg_want = atoi(e) > 0 ? atoi(e) : 1;
       if (yg_want > 255) yg_want = 255;
-      if (swizzle & 8) {     // (mask_march4_kernel: the group height must divide the grid's y extent)
-        int yg = yg_want;
-        while (yg > 1 && grid2.y % (unsigned)yg) yg --;
-        swizzle = (swizzle & 0xff) | (yg << 8);
-      }
-      const dim3 blk((unsigned)(64 * wpb));
-      if (m.nd == 3 && !reduce) {
-        // default for 3D scalar slices: mask_march6_kernel -- 128 x 16 tiles as four wavefronts of 4 rows that all load and classify,
-        // TWO row slots in LDS (37 KB: three workgroups = twelve wavefronts per CU, which the 159 VGPRs allow; one plane on its way
-        // per workgroup instead of two, but a third workgroup to cover for it: 1 % faster on 512^3 x 32, 4-8 % on 256^3 x 16 than
-        // three slots at two workgroups per CU), one barrier per plane.  FTKX_MASK_V=5: the producer / consumer kernel
-        // (128 x 12, three consumers + one producer), FTKX_MASK_V=4: mask_march4_kernel
-        int gen = 6, pd5 = 0, shape = 0;
-        if (const char *e = getenv("FTKX_MASK_V")) { const int v = atoi(e); gen = (v == 4 || v == 5) ? v : 6; }
-        if (const char *e = getenv("FTKX_MASK_PD")) pd5 = atoi(e);
-        if (const char *e = getenv("FTKX_MASK_TILE")) shape = atoi(e);
-        if (gen == 6) {
-          // grouped placement: 16 row groups (all of a 256^2 plane's, half of a 512^2 plane's tiles) share an XCD's L2 -- with three
-          // workgroups per CU 4 x 16 tiles are resident per XCD at a time (4: -3.5 %, 8: -0.5 %)
-          if (!getenv("FTKX_MASK_YG")) yg_want = 16;
-          if (!zforced) {   // chunks of 32 planes (64: +0.5..1 % with 16-row groups; 16: +3 %) as long as the launch still fills the device several times
-            zchunk = 32;
-            while (zchunk > 8 && (size_t)((DW + 127) / 128) * ((m.ext_sz[1] + 15) / 16) * ((DD + zchunk - 1) / zchunk) * njobs < 4096) zchunk /= 2;   // (three workgroups per CU: 768 at a time)
-          }
-          // FTKX_MASK_TAIL="jobs,planes": the last `jobs` slices in chunks of `planes` planes (see march6_body)
-          // Default: a launch that fills the device (768 workgroups at a time) fewer than a dozen times ends with its last slice in
-          // chunks of 8 planes -- 256^3 x 16 (5.3 rounds) 0.419 -> 0.404 ms; 512^3 x 32 (43 rounds) gains nothing and keeps its chunks
-          int tail_jobs = 0, zc_tail = zchunk;
-          {
-            const size_t wgs = (size_t)((DW + 127) / 128) * ((m.ext_sz[1] + 15) / 16) * ((DD + zchunk - 1) / zchunk) * njobs;
-            if (wgs < 12 * 768 && njobs >= 2 && zchunk > 8) { tail_jobs = 1; zc_tail = 8; }
-          }
-          if (const char *e = getenv("FTKX_MASK_TAIL")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 4) { tail_jobs = a < njobs ? a : njobs; zc_tail = b; } }
-          const int main_jobs = njobs - tail_jobs;
-          const int split = tail_jobs ? main_jobs * ((DD + zchunk - 1) / zchunk) : 0x7fffffff;
-          const unsigned gz = (unsigned)(main_jobs * ((DD + zchunk - 1) / zchunk) + tail_jobs * ((DD + zc_tail - 1) / zc_tail));
-#define FTKX_M6(NS_, CY_, RY_) do { \
-            g_last_mask_kernel = (swizzle & 64) ? "ftkx::mask_march6_kernel<" #NS_ ", " #CY_ ", " #RY_ ", true>" : "ftkx::mask_march6_kernel<" #NS_ ", " #CY_ ", " #RY_ ", false>"; \
-            const int rows = CY_ * RY_; \
-            dim3 grid6((unsigned)((m.ext_sz[0] + 127) / 128), (unsigned)((m.ext_sz[1] + rows - 1) / rows), gz); \
-            int sw = swizzle; \
-            /* grouped placement needs a y extent that is a multiple of the group height: pad it (workgroups past the last row leave at once) */ \
-            if (sw & 8) { int yg = yg_want; if (yg > (int)grid6.y) yg = (int)grid6.y; grid6.y = (grid6.y + (unsigned)yg - 1) / (unsigned)yg * (unsigned)yg; sw = (sw & 0xff) | (yg << 8); } \
-            const unsigned bytes = (unsigned)(NS_) * (unsigned)(rows + 2) * 1024u + (unsigned)(NS_ + 1) * (rows > 16 ? 512u : 256u); \
-            if (sw & 64) { (void)hipFuncSetAttribute((const void *)mask_march6_kernel<NS_, CY_, RY_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
-              hipLaunchKernelGGL((mask_march6_kernel<NS_, CY_, RY_, true>), grid6, dim3(64u * CY_), bytes, stream, m, d_jobs, zchunk, sw, split, main_jobs, zc_tail); } \
-            else { (void)hipFuncSetAttribute((const void *)mask_march6_kernel<NS_, CY_, RY_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
-              hipLaunchKernelGGL((mask_march6_kernel<NS_, CY_, RY_, false>), grid6, dim3(64u * CY_), bytes, stream, m, d_jobs, zchunk, sw, split, main_jobs, zc_tail); } } while (0)
-          // FTKX_MASK_TILE (wavefronts x rows each): 0 = 4 x 4 (default), 1 = 3 x 4, 2 = 4 x 3, 4 = 4 x 2, 6 = 8 x 2, 9 = 8 x 4; FTKX_MASK_PD = row slots in
-          // LDS (default 2); FTKX_MASK_SWIZZLE bit 64: two barriers per plane (the slot is refilled in the step that reads it)
-          if (shape == 1) FTKX_M6(3, 3, 4);
-          else if (shape == 2) { if (pd5 == 2) FTKX_M6(2, 4, 3); else if (pd5 == 4) FTKX_M6(4, 4, 3); else FTKX_M6(3, 4, 3); }
-          else if (shape == 4) FTKX_M6(3, 4, 2);
-          else if (shape == 6) FTKX_M6(3, 8, 2);
-          else if (shape == 9) { if (pd5 == 2) FTKX_M6(2, 8, 4); else FTKX_M6(3, 8, 4); }
-          else if (pd5 == 3) FTKX_M6(3, 4, 4);
-          else if (pd5 == 4) FTKX_M6(4, 4, 4);
-          else FTKX_M6(2, 4, 4);
-#undef FTKX_M6
-          return;
+      // The pieces a tile column is marched in (ZPlan).  A launch that fills the device (768 workgroups at a time) a dozen times or more:
+      // equal chunks of 32 planes -- measured, not derived: LONGER marches are slower although they pay fewer start-up planes (64: +0.5..1 %,
+      // 128: +2 %, half columns: +3.7 % on 512^3 x 32; the tiles of a group drift apart and stop sharing their halo rows in the L2), 16: +3 %.
+      // Smaller launches end on a partial round of workgroups, which costs them up to a tenth of their time: their columns are cut
+      // into pieces of at most 24 planes, each at most half of what is left of the column and at least 6, handed out longest first
+      // (256^3 x 16: 0.393 -> 0.379 ms, one 512^3 slice: 0.204 -> 0.195, four: 0.735 -> 0.724; 512^3 x 32 the same way: +0.8 %).
+      // FTKX_MASK_ZCHUNK = n: equal chunks of n planes; FTKX_MASK_LCAP / _LMIN: the two bounds
+      ZPlan plan = ZPlan();
+      {
+        const size_t columns = (size_t)((DW + 127) / 128) * ((m.ext_sz[1] + 15) / 16) * (size_t)njobs;
+        const bool many_rounds = columns * (size_t)((DD + 31) / 32) >= 12 * 768;
+        int lmin = 6, lcap = 24;
+        bool planned = !zforced && !many_rounds;
+        if (const char *e = getenv("FTKX_MASK_LMIN")) if (atoi(e) >= 1) { lmin = atoi(e); planned = !zforced; }
+        if (const char *e = getenv("FTKX_MASK_LCAP")) if (atoi(e) >= 1) { lcap = atoi(e); planned = !zforced; }
+        if (lcap < lmin) lcap = lmin;
+        std::vector<int> lens;
+        int rem = DD;
+        if (!planned) while (rem > 0) { const int l = rem < zchunk ? rem : zchunk; lens.push_back(l); rem -= l; }
+        while (rem > 0) {
+          int l = (rem + 1) / 2;
+          if (l > lcap) l = lcap;
+          if (l < lmin) l = lmin;
+          if (l > rem || rem - l < (lmin + 1) / 2) l = rem;
+          lens.push_back(l); rem -= l;
         }
-        if (gen == 5) {
-#define FTKX_M5(PD_, CY_, RY_) do { \
-            g_last_mask_kernel = "ftkx::mask_march5_kernel<" #PD_ ", " #CY_ ", " #RY_ ">"; \
-            const int rows = CY_ * RY_; \
-            dim3 grid5((unsigned)((m.ext_sz[0] + 127) / 128), (unsigned)((m.ext_sz[1] + rows - 1) / rows), grid2.z); \
-            int sw = swizzle; \
-            if (sw & 8) { int yg = yg_want; if (yg > (int)grid5.y) yg = (int)grid5.y; grid5.y = (grid5.y + (unsigned)yg - 1) / (unsigned)yg * (unsigned)yg; sw = (sw & 0xff) | (yg << 8); } \
-            const unsigned bytes = (unsigned)(PD_ + 1) * (unsigned)(rows + 2) * 1024u + (unsigned)(PD_ + 2) * 256u; \
-            (void)hipFuncSetAttribute((const void *)mask_march5_kernel<PD_, CY_, RY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
-            hipLaunchKernelGGL((mask_march5_kernel<PD_, CY_, RY_>), grid5, dim3(64u * (CY_ + 1)), bytes, stream, m, d_jobs, zchunk, sw); } while (0)
-          // FTKX_MASK_TILE (consumers x rows each): 0 = 3 x 4 (default), 1 = 4 x 4, 4 = 2 x 8, 5 = 6 x 2, 8 = 4 x 3; FTKX_MASK_PD = planes in flight (default 2)
-          if (shape == 1) FTKX_M5(2, 4, 4);
-          else if (shape == 4) FTKX_M5(2, 2, 8);
-          else if (shape == 5) FTKX_M5(2, 6, 2);
-          else if (shape == 8) FTKX_M5(2, 4, 3);
-          else if (pd5 == 1) FTKX_M5(1, 3, 4);
-          else if (pd5 == 3) FTKX_M5(3, 3, 4);
-          else FTKX_M5(2, 3, 4);
-#undef FTKX_M5
-          return;
-        }
+        while (lens.size() > 47) { const int l = lens.back(); lens.pop_back(); lens.back() += l; }      // (more pieces than the table holds: merged from the end)
+        std::stable_sort(lens.begin(), lens.end(), [](int a, int b) { return a > b; });
+        plan.npieces = (unsigned)lens.size();
+        int z = 0;
+        for (size_t i = 0; i < lens.size(); i ++) { plan.z0[i] = (unsigned)z; plan.len[i] = (unsigned)lens[i]; z += lens[i]; }
       }
-      int pd = 1, ry = (m.nd == 3) ? 4 : 8;
-      if (const char *e = getenv("FTKX_MASK_PD")) pd = atoi(e);
-      if (const char *e = getenv("FTKX_MASK_RY")) { if (m.nd == 3 && (atoi(e) == 4 || atoi(e) == 8)) ry = atoi(e); }
-      const dim3 grid4(grid2.x, (unsigned)((m.ext_sz[1] + wpb * ry - 1) / (wpb * ry)), grid2.z);
-      if ((swizzle & 8) && grid4.y != grid2.y) { int yg = (swizzle >> 8) & 0xff; while (yg > 1 && grid4.y % (unsigned)yg) yg --; swizzle = (swizzle & 0xff) | (yg << 8); }
-      unsigned lds = 0;                                       // experiment: dynamic LDS only to cap the workgroups per CU
-      if (const char *e = getenv("FTKX_MASK_LDS_KB")) lds = (unsigned)atoi(e) * 1024u;
-#define FTKX_M4(ND_, R_, PD_, RY_) do { if (!reduce) g_last_mask_kernel = "ftkx::mask_march4_kernel<" #ND_ ", " #R_ ", " #PD_ ", " #RY_ ">"; if (lds) (void)hipFuncSetAttribute((const void *)mask_march4_kernel<ND_, R_, PD_, RY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((mask_march4_kernel<ND_, R_, PD_, RY_>), grid4, blk, lds, stream, m, d_jobs, zchunk, swizzle); } while (0)
-      if (reduce) { if (m.nd == 2) FTKX_M4(2, true, 1, 8); else FTKX_M4(3, true, 1, 4); }
-      else if (m.nd == 2) FTKX_M4(2, false, 1, 8);
-      else if (ry == 8) { if (pd == 2) FTKX_M4(3, false, 2, 8); else if (pd == 0) FTKX_M4(3, false, 0, 8); else FTKX_M4(3, false, 1, 8); }
-      else if (pd == 2) FTKX_M4(3, false, 2, 4);
-      else if (pd == 3) FTKX_M4(3, false, 3, 4);
-      else if (pd == 0) FTKX_M4(3, false, 0, 4);
-      else FTKX_M4(3, false, 1, 4);
-#undef FTKX_M4
+      constexpr int NS6 = 2, CY6 = 4, RY6 = 4, rows = CY6 * RY6;
+      g_last_mask_kernel = "ftkx::mask_march6_kernel<2, 4, 4, false>";
+      dim3 grid6((unsigned)((DW + 127) / 128), (unsigned)((m.ext_sz[1] + rows - 1) / rows), plan.npieces * (unsigned)njobs);
+      int sw = swizzle;
+      // grouped placement needs a y extent that is a multiple of the group height: pad it (workgroups past the last row leave at once)
+      if (sw & 8) { int yg = yg_want; if (yg > (int)grid6.y) yg = (int)grid6.y; grid6.y = (grid6.y + (unsigned)yg - 1) / (unsigned)yg * (unsigned)yg; sw = (sw & 0xff) | (yg << 8); }
+      const unsigned bytes = (unsigned)NS6 * (unsigned)(rows + 2) * 1024u + (unsigned)(NS6 + 1) * 256u;
+      (void)hipFuncSetAttribute((const void *)mask_march6_kernel<NS6, CY6, RY6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      hipLaunchKernelGGL((mask_march6_kernel<NS6, CY6, RY6, false>), grid6, dim3(64u * CY6), bytes, stream, m, d_jobs, sw, njobs, plan);
       return;
     }
-    const dim3 grid((unsigned)((m.mask_pitch + 63) / 64), (unsigned)((m.ext_sz[1] + 4 * RY - 1) / (4 * RY)), (unsigned)(nzc * njobs));
-    g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_march_kernel<2>" : "ftkx::mask_march_kernel<3>";
-    if (m.nd == 2) hipLaunchKernelGGL(mask_march_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs, zchunk);
-    else hipLaunchKernelGGL(mask_march_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs, zchunk);
+    // 2D, and the exact stand-alone reduction (ftkx_slice_resolution) of either dimension: mask_march4_kernel -- every wavefront loads
+    // its rows into registers (4 wavefronts of 8 rows in 2D, of 4 rows marching along z in 3D)
+    const int RY = (m.nd == 3) ? 4 : 8, wpb = 4;
+    const int nzc = m.nd == 3 ? (DD + zchunk - 1) / zchunk : 1;
+    const dim3 grid4((unsigned)((DW + 127) / 128), (unsigned)((m.ext_sz[1] + wpb * RY - 1) / (wpb * RY)), (unsigned)(nzc * njobs));
+    if (swizzle & 8) {     // (the group height must divide the grid's y extent)
+      int yg = 4;
+      if (const char *e = getenv("FTKX_MASK_YG")) yg = atoi(e) > 0 ? (atoi(e) > 255 ? 255 : atoi(e)) : 1;
+      while (yg > 1 && grid4.y % (unsigned)yg) yg --;
+      swizzle = (swizzle & 0xff) | (yg << 8);
+    }
+    const dim3 blk((unsigned)(64 * wpb));
+#define FTKX_M4(ND_, R_, PD_, RY_) do { if (!reduce) g_last_mask_kernel = "ftkx::mask_march4_kernel<" #ND_ ", " #R_ ", " #PD_ ", " #RY_ ">"; \
+      hipLaunchKernelGGL((mask_march4_kernel<ND_, R_, PD_, RY_>), grid4, blk, 0, stream, m, d_jobs, zchunk, swizzle); } while (0)
+    if (reduce) { if (m.nd == 2) FTKX_M4(2, true, 1, 8); else FTKX_M4(3, true, 1, 4); }
+    else FTKX_M4(2, false, 1, 8);
+#undef FTKX_M4
     return;
   }
   const size_t DDv = m.nd == 3 ? (size_t)m.ext_sz[2] : 1;
@@ -2657,6 +2308,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
     else hipLaunchKernelGGL(mask_vec_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs);
     return;
   }
+  // the one generic form (odd row lengths, slices of 4 GiB and more, vector rows that are not a multiple of 8): one lane per mask byte
   const size_t n = (size_t)m.mask_pitch * m.ext_sz[1] * DDv;
   size_t bx = (n + kThreads - 1) / kThreads;
   if (bx > 4096) bx = 4096;                 // grid-stride the rest
@@ -2672,8 +2324,6 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
 int mask_summary_rows(const Mesh &m)
 {
   if (m.nd != 3 || !m.scalar_mode || !masks_have_summary(m)) return 1;
-  if (const char *e = getenv("FTKX_MASK_V")) { const int v = atoi(e); if (v == 4 || v == 5) return 1; }
-  if (const char *e = getenv("FTKX_MASK_TILE")) { const int t = atoi(e); if (t == 2 || t == 4 || t == 6) return 1; }   // shapes with 3 or 2 rows per wavefront
   if (const char *e = getenv("FTKX_U_ROWS")) if (atoi(e) == 1) return 1;
   return 4;
 }

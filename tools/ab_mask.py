@@ -17,6 +17,7 @@ cfg = args[0] if sep > 0 else "c4"
 rounds = int(args[1]) if sep > 1 else 6
 variants = args[sep + 1:] or ["TILE=0"]
 CONFIGS = {"c4": (3, "moving_extremum_3d", (512, 512, 512), 32), "c3": (3, "moving_extremum_3d", (256, 256, 256), 16),
+           "c4s": (3, "moving_extremum_3d", (512, 512, 512), 1), "c4n4": (3, "moving_extremum_3d", (512, 512, 512), 4),
            "c2": (2, "woven", (1024, 1024), 64), "c5": (2, "double_gyre", (2048, 1024), 128)}
 nd, case, dims, nt = CONFIGS[cfg]
 vector = case == "double_gyre"
