@@ -1122,6 +1122,8 @@ __device__ inline void wait_plane_landed(int s)
 // 512^3 slice on its own 2.7), and the two start-up planes of a march are paid per piece -- 7 pieces per 512 planes on 512^3 x 32
 // instead of 16 chunks.  (Persistent workgroups pulling such pieces from a queue of their own were built and measured: the loop state
 // costs the kernel 36 more SGPR spills and 12 VGPRs of scratch at three wavefronts per SIMD -- 7.6 ms against 5.7 on 512^3 x 32.)
+// Equal chunks (launches of a dozen rounds and more) go out slice by slice instead: neighbouring chunks of a slice then run at the same
+// time and find each other's start-up planes in the caches.
 struct ZPlan {
   unsigned npieces;
   unsigned z0[47], len[47];
@@ -1146,8 +1148,10 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
   const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = m.ext_sz[2], P = m.mask_pitch;
   unsigned bx, by, bz;
   remap_block(swizzle, bx, by, bz);
-  const unsigned piece = bz / (unsigned)njobs;
-  const MaskJob job = jobs[bz - piece * (unsigned)njobs];
+  // (njobs < 0: slice-major -- blockIdx.z = slice * npieces + piece, the pieces of a slice back to back)
+  const unsigned nj = (unsigned)(njobs < 0 ? -njobs : njobs);
+  const unsigned piece = njobs < 0 ? bz % plan.npieces : bz / nj;
+  const MaskJob job = jobs[njobs < 0 ? bz / plan.npieces : bz - piece * nj];
   const int z0 = (int)plan.z0[piece];
   const int z1 = z0 + (int)plan.len[piece];
   const int lane = threadIdx.x & 63;
@@ -2231,21 +2235,23 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       int yg_want = 16;
       if (const char *e = getenv("FTKX_MASK_YG")) yg_want = atoi(e) > 0 ? atoi(e) : 1;
       if (yg_want > 255) yg_want = 255;
-      // The pieces a tile column is marched in (ZPlan).  A launch that fills the device (768 workgroups at a time) a dozen times or more:
-      // equal chunks of 32 planes -- measured, not derived: LONGER marches are slower although they pay fewer start-up planes (64: +0.5..1 %,
-      // 128: +2 %, half columns: +3.7 % on 512^3 x 32; the tiles of a group drift apart and stop sharing their halo rows in the L2), 16: +3 %.
-      // Smaller launches end on a partial round of workgroups, which costs them up to a tenth of their time: their columns are cut
-      // into pieces of at most 24 planes, each at most half of what is left of the column and at least 6, handed out longest first
-      // (256^3 x 16: 0.393 -> 0.379 ms, one 512^3 slice: 0.204 -> 0.195, four: 0.735 -> 0.724; 512^3 x 32 the same way: +0.8 %).
-      // FTKX_MASK_ZCHUNK = n: equal chunks of n planes; FTKX_MASK_LCAP / _LMIN: the two bounds
+      // The pieces a tile column is marched in (ZPlan): at most 24 planes, at most half of what is left of the column, at least 6,
+      // multiples of 3 (the march is unrolled three planes deep), handed out longest first.  Measured, not derived (tools/ab_mask.py,
+      // interleaved on one box): against equal chunks of 32 planes 256^3 x 16 0.418 -> 0.405 ms, one 512^3 slice 0.206 -> 0.197, four
+      // 0.756 -> 0.748, 512^3 x 32 5.72 -> 5.69.  LONGER marches are slower although they pay fewer start-up planes (caps of 28 / 32 / 48:
+      // +9 / +5 / +1..2 % on 512^3 x 32; half columns +3.7 %: the tiles of a group drift apart and stop sharing their halo rows in the L2),
+      // equal chunks swing by +-3 % with their length (24: 5.89, 27: 5.68, 30: 5.98, 32: 5.72, 33: 5.84 ms -- what is left over at a
+      // column's top decides).  Order of the workgroups: slice by slice where a slice alone fills the device (neighbouring pieces of a
+      // slice then run together and find each other's start-up planes in the caches: 512^3 x 32 5.59 against 5.85 ms piece by piece),
+      // piece by piece over all slices otherwise (256^3 x 16: 0.379 against 0.399).
+      // FTKX_MASK_ZCHUNK = n: equal chunks of n planes; FTKX_MASK_LCAP / _LMIN: the two bounds; FTKX_MASK_ORDER = 0 / 1
       ZPlan plan = ZPlan();
+      bool planned = false;
       {
-        const size_t columns = (size_t)((DW + 127) / 128) * ((m.ext_sz[1] + 15) / 16) * (size_t)njobs;
-        const bool many_rounds = columns * (size_t)((DD + 31) / 32) >= 12 * 768;
         int lmin = 6, lcap = 24;
-        bool planned = !zforced && !many_rounds;
-        if (const char *e = getenv("FTKX_MASK_LMIN")) if (atoi(e) >= 1) { lmin = atoi(e); planned = !zforced; }
-        if (const char *e = getenv("FTKX_MASK_LCAP")) if (atoi(e) >= 1) { lcap = atoi(e); planned = !zforced; }
+        planned = !zforced;
+        if (const char *e = getenv("FTKX_MASK_LMIN")) if (atoi(e) >= 1) lmin = atoi(e);
+        if (const char *e = getenv("FTKX_MASK_LCAP")) if (atoi(e) >= 1) lcap = atoi(e);
         if (lcap < lmin) lcap = lmin;
         std::vector<int> lens;
         int rem = DD;
@@ -2254,6 +2260,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
           int l = (rem + 1) / 2;
           if (l > lcap) l = lcap;
           if (l < lmin) l = lmin;
+          if (l >= 3) l -= l % 3;      // (the march is unrolled three planes deep: a length that is no multiple of 3 pays for up to two empty steps)
           if (l > rem || rem - l < (lmin + 1) / 2) l = rem;
           lens.push_back(l); rem -= l;
         }
@@ -2271,7 +2278,9 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       if (sw & 8) { int yg = yg_want; if (yg > (int)grid6.y) yg = (int)grid6.y; grid6.y = (grid6.y + (unsigned)yg - 1) / (unsigned)yg * (unsigned)yg; sw = (sw & 0xff) | (yg << 8); }
       const unsigned bytes = (unsigned)NS6 * (unsigned)(rows + 2) * 1024u + (unsigned)(NS6 + 1) * 256u;
       (void)hipFuncSetAttribute((const void *)mask_march6_kernel<NS6, CY6, RY6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-      hipLaunchKernelGGL((mask_march6_kernel<NS6, CY6, RY6, false>), grid6, dim3(64u * CY6), bytes, stream, m, d_jobs, sw, njobs, plan);
+      bool slice_major = (size_t)grid6.x * ((m.ext_sz[1] + rows - 1) / rows) * plan.npieces >= 768;      // a slice alone fills the device (three workgroups per CU)
+      if (const char *e = getenv("FTKX_MASK_ORDER")) slice_major = atoi(e) == 0;
+      hipLaunchKernelGGL((mask_march6_kernel<NS6, CY6, RY6, false>), grid6, dim3(64u * CY6), bytes, stream, m, d_jobs, sw, slice_major ? -njobs : njobs, plan);
       return;
     }
     // 2D, and the exact stand-alone reduction (ftkx_slice_resolution) of either dimension: mask_march4_kernel -- every wavefront loads

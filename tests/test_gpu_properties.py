@@ -155,7 +155,7 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
                 {"FTKX_MASK_ZCHUNK": "16"}, {"FTKX_MASK_ZCHUNK": "7"}, {"FTKX_TWO_LEVEL": "0"}, {"FTKX_U_ROWS": "1"}, {"FTKX_U_ROWS": "1", "FTKX_MASK_ZCHUNK": "6"},
                 # the pieces a column is marched in: short ones only, one piece per column, many tiny ones (more than the table holds: merged)
                 {"FTKX_MASK_LMIN": "1", "FTKX_MASK_LCAP": "3"}, {"FTKX_MASK_LCAP": "100000"}, {"FTKX_MASK_LMIN": "1", "FTKX_MASK_LCAP": "1"}, {"FTKX_MASK_ZCHUNK": "1"},
-                {"FTKX_MASK_ZCHUNK": "32"}, {"FTKX_MASK_LMIN": "6", "FTKX_MASK_LCAP": "24"}]
+                {"FTKX_MASK_ZCHUNK": "32"}, {"FTKX_MASK_LMIN": "6", "FTKX_MASK_LCAP": "24"}, {"FTKX_MASK_ORDER": "0"}, {"FTKX_MASK_ORDER": "1"}, {"FTKX_MASK_ORDER": "0", "FTKX_MASK_ZCHUNK": "5"}]
     base = None
     words = None
     for env in variants:
