@@ -61,9 +61,15 @@ EXPECT = {
 
 
 def spread(samples_ms):
-    """per-pass wall times -> min / median / max"""
-    a = np.sort(np.asarray(samples_ms, dtype=np.float64))
-    return {"ms_per_step_min": float(a[0]), "ms_per_step_median": float(np.median(a)), "ms_per_step_max": float(a[-1])} if len(a) else {}
+    """per-pass wall times (the time between consecutive completions) -> min / median / max.  With two passes in flight the first sample
+    holds the filling of the pipeline (two submits before the first completion) and the last one a pass with nothing queued behind it:
+    the three figures are taken over the passes in between (all samples are listed)"""
+    inner = samples_ms[1:-1] if len(samples_ms) >= 4 else samples_ms
+    a = np.sort(np.asarray(inner, dtype=np.float64))
+    if not len(a):
+        return {}
+    return {"ms_per_step_min": float(a[0]), "ms_per_step_median": float(np.median(a)), "ms_per_step_max": float(a[-1]),
+            "ms_per_step_samples": [round(float(v), 4) for v in np.asarray(samples_ms, dtype=np.float64)[:64]]}     # (in the order the passes completed)
 
 
 def check_records(name, case, dims, nt, recs, paths, want_paths):
