@@ -45,6 +45,7 @@ CONFIGS = {
     "c3o": (3, 1, "moving_extremum_3d_overflow", (256, 256, 256), 4),   # the int64-overflow regime (nbits 21): every cell takes the integer test
     "small3": (3, 1, "moving_extremum_3d", (96, 96, 96), 8),
     "small2": (2, 1, "woven", (256, 256), 8),
+    "mid2": (2, 1, "woven", (512, 512), 12),                  # enough records per rank for the copy kernel of a pipelined pass (tests)
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 STREAM_CEILING_GBS = 6290.0   # what a bare streaming read reaches on this part (same guide: achievable HBM read bandwidth)

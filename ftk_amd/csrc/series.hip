@@ -403,8 +403,15 @@ int ensure_series_buffers(ftkx_ctx *c, ftkx_series_buffers &B, size_t nwords, si
   }
   if (B.out_cap < (size_t)c->capacity) {
     if (B.out) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipHostFree(B.out)); B.out = nullptr; B.out_cap = 0; }
-    // (non-coherent = ordinary cached host memory for the CPU, as ensure_host_buffer has it)
-    HIP_TRY(c, hipHostMalloc((void **)&B.out, (size_t)c->capacity * sizeof(ftkx_cp_t), hipHostMallocNonCoherent));
+    // Non-coherent = ordinary cached host memory for the CPU (as ensure_host_buffer has it): the host reads the records after it has seen
+    // the flag, which a LATER kernel on the same stream (series_finish / the copy kernel's last workgroup) stores with system scope
+    // behind a __threadfence_system().  What this relies on -- gfx950 behaviour, not the HIP programming model, which promises
+    // visibility of coarse-grained host memory only at synchronisation points -- is that the record kernel's stores have left the
+    // device when that later kernel starts (they are system-scope stores, and a kernel boundary on one queue writes the L2 back) and
+    // that PCIe writes snoop the CPU's caches (x86).  FTKX_SERIES_OUT_COHERENT=1 allocates the buffer coherent (fine-grained) instead:
+    // the model's guarantee, at the price of uncached CPU reads of the records.
+    static const bool coherent_out = getenv("FTKX_SERIES_OUT_COHERENT") && atoi(getenv("FTKX_SERIES_OUT_COHERENT")) != 0;
+    HIP_TRY(c, hipHostMalloc((void **)&B.out, (size_t)c->capacity * sizeof(ftkx_cp_t), coherent_out ? hipHostMallocCoherent : hipHostMallocNonCoherent));
     B.out_cap = (size_t)c->capacity;
   }
   if (to_device && B.d_out_cap < (size_t)c->capacity) {

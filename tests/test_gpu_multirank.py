@@ -75,6 +75,23 @@ def test_slab_count_does_not_change_the_result(cfg, tmp_path):
         assert many["config"]["nbits"] == one["config"]["nbits"]
 
 
+def test_slab_pass_with_many_records_and_more_ranks(tmp_path):
+    """The device-driven slab pass where a rank's records leave through the copy kernel of a pipelined pass (more than 4 096 per rank), and
+    with four and five ranks (uneven slabs) on smooth 3D data: the merged records and curves are the single-rank ones, bit for bit."""
+    for cfg, ranks in (("mid2", (2, 3)), ("small3", (4, 5))):
+        one = _bench(1, cfg, dump=tmp_path / f"one_{cfg}.npz")
+        ref = np.load(tmp_path / f"one_{cfg}.npz")
+        if cfg == "mid2":
+            assert one["check"]["hits"] > 3 * 4096
+        for n in ranks:
+            many = _bench(n, cfg, ("--no-other-scaling",), dump=tmp_path / f"many_{cfg}_{n}.npz")
+            got = np.load(tmp_path / f"many_{cfg}_{n}.npz")
+            assert got["records"].tobytes() == ref["records"].tobytes() and len(ref["records"]) > 0, (cfg, n)
+            for k in ("curve_offsets", "curve_indices", "curve_loop"):
+                assert np.array_equal(got[k], ref[k]), (cfg, n, k)
+            assert "slab pass" in many["config"]["pass"] and many["check"]["device_driven"], (cfg, n, many["config"]["pass"], many["check"])
+
+
 def test_strong_scaling_with_the_compact_halo_is_the_default_and_weak_scaling_is_reported_beside_it(tmp_path):
     """`bench.py --gpus N` without flags (what the driver runs): BASELINE's literal configuration cut over the ranks (strong scaling),
     the slab boundary exchanged as sign masks + patches inside the timed region; a few weak-scaling passes are reported as `other`.
