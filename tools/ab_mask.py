@@ -18,7 +18,7 @@ rounds = int(args[1]) if sep > 1 else 6
 variants = args[sep + 1:] or ["TILE=0"]
 CONFIGS = {"c4": (3, "moving_extremum_3d", (512, 512, 512), 32), "c3": (3, "moving_extremum_3d", (256, 256, 256), 16),
            "c4s": (3, "moving_extremum_3d", (512, 512, 512), 1), "c4n4": (3, "moving_extremum_3d", (512, 512, 512), 4),
-           "c2": (2, "woven", (1024, 1024), 64), "c5": (2, "double_gyre", (2048, 1024), 128)}
+           "c2": (2, "woven", (1024, 1024), 64), "c2x4": (2, "woven", (2048, 2048), 64), "c2w": (2, "woven", (4096, 4096), 16), "c2l": (2, "woven", (1024, 1024), 256), "c5": (2, "double_gyre", (2048, 1024), 128)}
 nd, case, dims, nt = CONFIGS[cfg]
 vector = case == "double_gyre"
 dev = torch.device("cuda", 0)
@@ -52,6 +52,8 @@ for rnd in range(rounds + 1):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = val
+nbytes = 8.0 * (nd if vector else 1) * float(__import__("numpy").prod(dims)) * nt
 for v in variants:
     t = times[v]
+    print(f"   -> {nbytes / (min(t) * 1e-3) / 1e12:.2f} TB/s at the minimum, {nbytes / (sum(t) / len(t) * 1e-3) / 1e12:.2f} at the mean")
     print(f"{cfg} {v:28s} mean {sum(t) / len(t):.3f} ms  min {min(t):.3f}  max {max(t):.3f}  ({len(t)} rounds)")
