@@ -190,3 +190,196 @@ def test_merged_slabs_trace_to_the_reference_curves_gloo(oracle, name, world, ex
     assert (n_records, n_curves, n_trajs) == expect
     assert sum(o[1] for o in out) == n_records and all(o[1] > 0 for o in out)     # every rank contributed
     assert crossing > 0                                                           # and curves do cross the slab boundaries
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# tslab.SlabSeries -- the driver of the device-driven slab pass (ftkx_series_dist_*) -- over gloo on the CPU, with the ORACLE standing in
+# for the context: the stages' contract (include/ftkx.h) restated on host tensors.  What is under test is the host logic: which
+# collective is issued between which stages, by whom and to whom (ranks without a lower / upper neighbour, empty slabs), two passes
+# in flight, and the whole-slice recovery both sides derive from the same number -- also when two passes in flight both need it.
+# ---------------------------------------------------------------------------------------------------------------
+class OracleSlabCtx:
+    """include/ftkx.h: ftkx_series_dist_begin / _cull / _serve / _finish, ftkx_sweep_series_complete, ftkx_series_dist_status -- on the CPU.
+    The "mask message" of this stand-in carries the slice itself; a request is 0 cells (everything needed came with the masks) or -1."""
+
+    def __init__(self, oracle, ftk_amd, nd, nv, dims, nt, ask_full=()):
+        self.o, self.f, self.nd, self.nv, self.D, self.nt = oracle, ftk_amd, nd, nv, dims, nt
+        self.scalar = nv == 1
+        self.slices, self.passes, self.done = {}, [], None
+        self.ask_full = set(ask_full)           # pass numbers (0, 1, ...) in which this rank asks for the whole slice
+        self.npass = 0
+        self.nvals = int(np.prod(dims)) * (1 if self.scalar else nd)
+
+    def _derive(self, a):
+        o, nd = self.o, self.nd
+        if self.scalar:
+            V = o.gradient2D(a) if nd == 2 else o.gradient3D(a)
+            return V, (o.jacobian2D(V, True) if nd == 2 else o.jacobian3D(V)), a
+        return a, (o.jacobian2D(a, False) if nd == 2 else o.jacobian3D(a)), None
+
+    def push_scalar_slice(self, t, a): self.slices[t] = np.array(a.numpy() if hasattr(a, "numpy") else a, dtype=np.float64).reshape(self._shape())
+    push_slice = push_scalar_slice
+
+    def _shape(self):
+        return tuple(reversed(self.D)) + (() if self.scalar else (self.nd,))
+
+    def drop_slice(self, t):
+        if t not in self.slices:
+            raise self.f.FtkxError(tslab.E_NOSLICE, "not resident")
+        del self.slices[t]
+
+    def packed_masks_bytes(self): return self.nvals * 8, 0
+    def series_dist_cells(self): return 4
+    def patch_doubles(self): return 1
+    def series_last_path(self): return (1, 0)
+
+    def series_dist_begin(self, ts, scopes, running, rank, world, halo, contrib, gathered, masks_out, side_stream=None):
+        assert side_stream is None
+        self.cur = dict(ts=[int(t) for t in ts], scopes=[int(s) for s in scopes], run=tslab.DBL_MAX if running is None else running, rank=rank, world=world, halo=halo, gathered=gathered,
+                        n=self.npass)
+        self.npass += 1
+        res = [self.o.resolution(self._derive(self.slices[t])[0]) for t in self.cur["ts"]]
+        contrib[0], contrib[1], contrib[2], contrib[3] = min(res), 1.0, res[0], 1.0
+        if masks_out is not None:
+            masks_out.copy_(torch.from_numpy(self.slices[self.cur["ts"][0]].reshape(-1).view(np.uint8)))
+
+    def series_dist_cull(self, masks_in, req_out):
+        c = self.cur
+        assert (masks_in is not None) == bool(c["halo"]) == (req_out is not None)
+        c["asked"] = 0
+        if masks_in is not None:
+            c["halo_data"] = masks_in.numpy().view(np.float64).reshape(self._shape()).copy()
+            c["asked"] = -1 if c["n"] in self.ask_full else 0
+            req_out[0] = c["asked"]
+
+    def series_dist_serve(self, req_in, reply_out):
+        self.cur["served"] = int(req_in[0]) if req_in is not None else 0
+
+    def series_dist_finish(self, reply_in):
+        assert (reply_in is not None) == bool(self.cur["halo"])
+        self.cur["G"] = self.cur["gathered"].numpy().reshape(-1, 4).copy()      # (what the all_gather put there: read behind it, as the cull stage does on the device)
+        self.passes.append(self.cur)
+
+    def _sweep(self, ts, scopes, run_in, halo_data):
+        # (every pass of a test sweeps the same data: once is enough)
+        key = (tuple(ts), tuple(scopes), run_in, None if halo_data is None else halo_data.tobytes(), self.slices[ts[-1] + 1].tobytes() if ts[-1] + 1 in self.slices else None)
+        if not hasattr(self, "_memo"):
+            self._memo = {}
+        if key not in self._memo:
+            self._memo[key] = self._sweep_now(ts, scopes, run_in, halo_data)
+        return self._memo[key]
+
+    def _sweep_now(self, ts, scopes, run_in, halo_data):
+        o, nd = self.o, self.nd
+        lo = 2 if self.scalar else 1
+        dom = ([lo] * nd, [d - (3 if self.scalar else 2) for d in self.D])
+        fields = {t: self._derive(self.slices[t]) for t in ts}
+        if halo_data is not None:
+            fields[ts[-1] + 1] = self._derive(halo_data)
+        elif ts[-1] + 1 in self.slices:
+            fields[ts[-1] + 1] = self._derive(self.slices[ts[-1] + 1])      # (the whole slice, pushed after a request of -1)
+        run, parts, factors = run_in, [], []
+        for t, sc in zip(ts, scopes):
+            run = min([run] + [o.resolution(fields[u][0]) for u in (t, t + 1) if u in fields])
+            factor = tslab.scaling_factor(run)
+            factors.append(factor)
+            for scope in (1, 2):
+                if not (sc & scope):
+                    continue
+                f0, f1 = fields[t], fields.get(t + 1) if scope == 2 else None
+                r = o.sweep(nd, scope, t, dom, dom, ([0] * nd, self.D), (f0[0], f1[0] if f1 else None), (f0[1], f1[1] if f1 else None),
+                            (f0[2], f1[2] if f1 else None) if self.scalar else None, factor, jacobian_symmetric=self.scalar, tag_mode=o.TAG_EXACT64)
+                c = np.zeros(len(r), dtype=self.f.CP_DTYPE)
+                for fld in ("x", "t", "type", "tag", "scalar"):
+                    c[fld] = r[fld]
+                c["aux"] = (r["ordinal"].astype(np.uint32) & 1) | (np.uint32(t) << 1)
+                parts.append(c)
+        recs = np.concatenate(parts) if parts else np.zeros(0, dtype=self.f.CP_DTYPE)
+        return recs[np.argsort(recs["tag"], kind="stable")], np.array(factors, dtype=np.uint64), run
+
+    def sweep_series_complete(self, copy=True):
+        c = self.passes.pop(0)
+        self.done = c
+        if c["asked"] < 0:
+            raise self.f.FtkxError(tslab.E_NOSLICE, "the halo slice is needed as a whole")
+        run_in = min([c["run"]] + [float(v) for v in c["G"][:c["rank"], 0]])
+        return self._sweep(c["ts"], c["scopes"], run_in, c.get("halo_data"))
+
+    def series_dist_status(self, world):
+        return self.done["asked"], self.done["served"], self.done["G"]
+
+    def sweep_series(self, ts, scopes, running, copy=True):
+        assert not self.passes, "the context must be free for the second sweep"
+        ts = [int(t) for t in ts]
+        assert ts[-1] + 1 in self.slices, "the whole halo slice was pushed"
+        recs, f, run = self._sweep(ts, [int(s) for s in scopes], running, None)
+        return recs, f, run
+
+
+def _slab_worker(rank, world, port, name, ask_full, pipelined, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pyoracle as oracle
+        import ftk_amd
+        from common import load_golden
+        g = load_golden(name)
+        nd, nv, D, nt = g["nd"], g["nv"], g["dims"], g["DT"]
+        t0, t1 = tslab.slab_range(nt, world, rank)
+        own = list(range(t0, t1))
+        ctx = OracleSlabCtx(oracle, ftk_amd, nd, nv, D, nt, ask_full=ask_full.get(rank, ()))
+        for t in own:
+            ctx.push_scalar_slice(t, np.ascontiguousarray(g["steps"][t]))
+        first = torch.from_numpy(np.ascontiguousarray(g["steps"][t0], dtype=np.float64)) if own else None
+        slab = tslab.SlabSeries(ctx, nt, own, nv == 1, torch, torch.device("cpu"), first_slice=first)
+        outs = []
+        npass = 3
+        if pipelined:
+            slab.submit()
+            for i in range(1, npass + 1):
+                if i < npass:
+                    slab.submit()
+                outs.append(slab.complete())
+        else:
+            for _ in range(npass):
+                slab.submit()
+                outs.append(slab.complete())
+        for recs, f, run in outs[1:]:
+            assert recs.tobytes() == outs[0][0].tobytes() and list(f) == list(outs[0][1])
+        merged = tslab.gather_records(np.array(outs[-1][0]), 0)
+        if own:
+            assert [int(v) for v in outs[-1][1]] == [int(g["factors"][t]) for t in own], (rank, outs[-1][1])
+        if rank == 0:
+            ref = g["records"]
+            order = np.argsort(ref["tag"], kind="stable")
+            assert len(merged) == len(ref) and np.array_equal(merged["tag"], ref["tag"][order]) and np.array_equal(merged["type"], ref["type"][order])
+            assert np.array_equal(merged["x"], ref["x"][order]) and np.array_equal(merged["t"], ref["t"][order])
+        q.put((rank, len(outs[-1][0]), slab.fallbacks, slab.bytes_sent, slab.bytes_received))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world,ask_full,pipelined", [
+    ("woven_31x37x32", 2, {}, True), ("woven_31x37x32", 3, {}, False),
+    ("woven_31x37x32", 3, {0: (1,), 1: (0, 1, 2)}, True),          # whole-slice recovery: rank 0 in its second pass, rank 1 in every pass -- with two passes in flight
+    ("moving_extremum_3d_21x21x21x32", 4, {2: (0,)}, False),
+    ("random_3d_scalar_13x12x11x4", 5, {}, True),                  # more ranks than timesteps: an empty slab takes part in the all_gather only
+])
+def test_slab_series_protocol_gloo(oracle, name, world, ask_full, pipelined):
+    from ftk_amd import build
+    build.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slab_worker, args=(r, world, port, name, ask_full, pipelined, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, nrec, fallbacks, sent, received in out:
+        assert fallbacks == len(ask_full.get(rank, ())), (rank, fallbacks)
+    assert sum(o[1] for o in out) > 0
