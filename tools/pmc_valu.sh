@@ -1,12 +1,12 @@
 #!/bin/bash
 # Integer / FP VALU utilisation next to the HBM figure: separate PMC passes over one bench run each (derived metrics need
-# several raw counters; no trace domains mixed in).  usage: bash tools/pmc_valu.sh <config> [extra bench args]   -> profiles/r02_<config>_valu_summary.json
+# several raw counters; no trace domains mixed in).  usage: bash tools/pmc_valu.sh <config> [extra bench args]   -> gpurun_out/r04_<config>_valu_summary.json (copy into profiles/)
 CFG=${1:-c4}; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_valu_$CFG; rm -rf $OUT; mkdir -p $OUT
 for c in "SQ_INSTS_VALU SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "GRBM_GUI_ACTIVE" VALUBusy; do
   d=$OUT/$(echo $c | tr ' ' '_')
-  rocprofv3 --pmc $c --output-format csv -d $d -- python3 bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline "$@" > $d.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $d -- python3 bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --no-streaming-tracker "$@" > $d.log 2>&1
 done
 python3 - "$CFG" <<'PY'
 import csv, glob, collections, json, os, sys
@@ -31,7 +31,7 @@ for k, cs in sorted(acc.items()):
     out[k] = d
 os.makedirs('profiles', exist_ok=True)
 json.dump({'config': cfg, 'note': 'average per dispatch; rocprofv3 --pmc, one counter group per run of bench.py --steps 1; derived VALUBusy uses the gfx94x formula (no gfx950 section in ROCm 7.2)', 'kernels': out},
-          open(f'gpurun_out/r02_{cfg}_valu_summary.json', 'w'), indent=1)
+          open(f'gpurun_out/r04_{cfg}_valu_summary.json', 'w'), indent=1)
 for k, d in out.items():
     print(k, {c: (round(v, 4) if v < 1000 else int(v)) for c, v in d.items()})
 PY
