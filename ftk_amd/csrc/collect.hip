@@ -130,7 +130,7 @@ int run_batch(ftkx_ctx *c, const double *sparse_field, bool cull_done)
         if (touched) subs.emplace_back();
         bool rule_on;
         const double big = job_big(c, *s, r.factor, &rule_on);
-        subs.back().jobs.push_back(MaskJob{s->S, s->V, s->M, two_level ? s->U : nullptr, nullptr, 1.0 / (double)r.factor, big});
+        subs.back().jobs.push_back(with_lean_thresholds(MaskJob{s->S, s->V, s->M, two_level ? s->U : nullptr, nullptr, 1.0 / (double)r.factor, big}, m));
         s->mask_factor = r.factor; s->mask_big = rule_on; s->u_rows = m.u_rows;
       }
       f.M[0] = s0.M; f.M[1] = s1 ? s1->M : nullptr;

@@ -82,6 +82,16 @@ using ftkx::u64;
 
 namespace ftkxh {
 
+// 2D scalar slices: gradient2D's (D - 1) scaling folded into exact thresholds of the unscaled differences (MaskJob::tx, ty)
+inline MaskJob with_lean_thresholds(MaskJob j, const Mesh &m)
+{
+  if (m.nd == 2 && m.scalar_mode && j.threshold > 0.0) {
+    j.tx = ftkx::exact_threshold(j.threshold, (double)(m.ext_sz[0] - 1));
+    j.ty = ftkx::exact_threshold(j.threshold, (double)(m.ext_sz[1] - 1));
+  }
+  return j;
+}
+
 struct Slice {
   double *V = nullptr, *J = nullptr, *S = nullptr;
   unsigned char *M = nullptr;       // vertex sign masks, built lazily for `mask_factor`

@@ -185,7 +185,7 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
     launch_init_red(c->d_red, k * 64, ahead_ok ? c->d_counters : nullptr, c->stream);
     MaskJob *jobs = (MaskJob *)c->h_desc;
     for (size_t i = 0; i < k; i ++)
-      jobs[i] = MaskJob{todo[i]->S, todo[i]->V, todo[i]->M, two_level ? todo[i]->U : nullptr, c->d_red + i * 128, cap, HUGE_VAL};   // rule off: validated below
+      jobs[i] = with_lean_thresholds(MaskJob{todo[i]->S, todo[i]->V, todo[i]->M, two_level ? todo[i]->U : nullptr, c->d_red + i * 128, cap, HUGE_VAL}, m);   // rule off: validated below
     HIP_TRY(c, hipMemcpyAsync(c->d_desc, c->h_desc, k * sizeof(MaskJob), hipMemcpyHostToDevice, c->stream));
     ev_begin(c, K_MASK); ftkx::launch_masks(m, (const MaskJob *)c->d_desc, (int)k, c->stream); ev_end(c);
     HIP_TRY(c, hipGetLastError());

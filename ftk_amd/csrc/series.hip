@@ -181,7 +181,7 @@ int series_chunked(ftkx_ctx *c, int nchunks, const int *ts, const int *scopes, i
     Fields *steps = (Fields *)((char *)c->h_desc + off_steps);
     const double cap = 1.0 / (double)hint;
     for (size_t j = 0; j < k; j ++)
-      if (red_index[j] >= 0) { const Slice &s = *sl[j]; jobs[red_index[j]] = MaskJob{s.S, s.V, s.M, two_level ? s.U : nullptr, c->d_red + (size_t)red_index[j] * 128, cap, HUGE_VAL}; }
+      if (red_index[j] >= 0) { const Slice &s = *sl[j]; jobs[red_index[j]] = MaskJob{s.S, s.V, s.M, two_level ? s.U : nullptr, c->d_red + (size_t)red_index[j] * 128, cap, HUGE_VAL}; }      // (the chunked pass: thresholds found by the kernel)
     for (int i = 0; i < n; i ++) {
       const size_t ja = (size_t)(std::lower_bound(slice_ts.begin(), slice_ts.end(), ts[i]) - slice_ts.begin());
       const bool interval = (scopes[i] & FTKX_SCOPE_INTERVAL) != 0;
@@ -600,7 +600,7 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
       else if (red_index[j] < 0 && !from_res[j]) { ss[j].known_res = s.res_below; ss[j].known_max = s.maxabs; }
       if (from_res[j] && s.sparse) { ss[j].known_res = DBL_MAX; ss[j].known_max = 0.0; }      // (the halo slice: nothing of an earlier pass stands)
       if (red_index[j] >= 0)
-        jobs[red_index[j]] = MaskJob{s.S, s.V, s.M, two_level ? s.U : nullptr, c->d_red + (size_t)red_index[j] * 128, cap, HUGE_VAL};   // rule off: validated by the factor kernel
+        jobs[red_index[j]] = with_lean_thresholds(MaskJob{s.S, s.V, s.M, two_level ? s.U : nullptr, c->d_red + (size_t)red_index[j] * 128, cap, HUGE_VAL}, m);   // rule off: validated by the factor kernel
     }
     size_t last = 0;
     for (int i = 0; i < n; i ++) {

@@ -114,7 +114,26 @@ struct MaskJob {
                              //   max: largest |v|, +Inf if the slice holds an Inf.
   double threshold;          // 1 / F: q = trunc(v * F) > 0  <=>  v >= 1/F (F is a power of two)
   double big;                // safe_m / F  (+Inf: no vertex is ever big)
+  double tx, ty;             // 2D scalar input: the smallest T with fl(T (D - 1)) >= threshold per axis -- gradient2D's scaling folded into the
+                             // compare (set_lean_thresholds; 0: not set, the kernel finds them itself)
 };
+
+// The smallest T with fl(T * f) >= thr (f an integer-valued double >= 1, thr > 0): rounding is monotone, so fl(d * f) >= thr <=> d >= T and,
+// round-to-nearest being symmetric, fl(d * f) <= -thr <=> d <= -T, for every d including the infinities; a NaN compares false both ways with or
+// without the multiplication.  A division and at most a few steps to a neighbouring double.  f == 0 (a slice one row high: its y differences
+// are x - x = 0 or NaN) gives +Inf: no difference passes, as no product with 0 does.
+__host__ __device__ inline double exact_threshold(double thr, double f)
+{
+  double T = thr / f;
+  if (!(T < 1.7976931348623157e308)) return __builtin_huge_val();
+  for (int it = 0; it < 4 && T * f < thr; it ++) { long long b; __builtin_memcpy(&b, &T, 8); b ++; __builtin_memcpy(&T, &b, 8); }
+  for (int it = 0; it < 4; it ++) {
+    long long b; __builtin_memcpy(&b, &T, 8); b --;
+    double below; __builtin_memcpy(&below, &b, 8);
+    if (below > 0.0 && below * f >= thr) T = below; else break;
+  }
+  return T;
+}
 
 constexpr int kSeriesMaxSlices = 2048;    // slices (and steps) one series pass takes: their reductions are folded in LDS
 constexpr int kSeriesMaxBins = 1 << 16;    // buckets of the ordering step
