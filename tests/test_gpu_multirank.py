@@ -77,8 +77,8 @@ def test_slab_count_does_not_change_the_result(cfg, tmp_path):
 
 def test_slab_pass_with_many_records_and_more_ranks(tmp_path):
     """The device-driven slab pass where a rank's records leave through the copy kernel of a pipelined pass (more than 4 096 per rank), and
-    with four and five ranks (uneven slabs) on smooth 3D data: the merged records and curves are the single-rank ones, bit for bit."""
-    for cfg, ranks in (("mid2", (2, 3)), ("small3", (4, 5))):
+    with four ranks on smooth 3D data (five and more: tests/test_tslab.py, on the CPU): the merged records and curves are the single-rank ones, bit for bit."""
+    for cfg, ranks in (("mid2", (2, 3)), ("small3", (4,))):      # (at most 6 processes may hold the GPU at once: this one + 4 ranks + a margin)
         one = _bench(1, cfg, dump=tmp_path / f"one_{cfg}.npz")
         ref = np.load(tmp_path / f"one_{cfg}.npz")
         if cfg == "mid2":

@@ -324,6 +324,43 @@ def test_two_declined_short_chain_passes_completed_back_to_back(gpu, monkeypatch
         assert np.array_equal(g["scalar"], w["scalar"]) and np.array_equal(g["aux"] & 1, w["aux"] & 1) and np.array_equal(g["aux"] >> 1, (w["aux"] >> 1) + t0)
 
 
+def test_abort_discards_the_open_passes_and_leaves_the_context_usable(gpu):
+    """ftkx_sweep_series_abort: two passes submitted, none completed, aborted -- the context then sweeps as if nothing had
+    been queued (the masks the discarded passes were building are rebuilt), other sweep calls are let through again, and aborting with
+    nothing open is a no-op.  The streaming tracker uses it after a failed completion."""
+    import torch
+    from ftk_amd import synthetic
+    dev = torch.device("cuda", 0)
+    dims, nt = (96, 80), 6
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    steps = [synthetic.generate("woven", dims, t, nt, torch, dev).cpu().numpy() for t in range(nt)]
+    ref = _ctx(gpu, dims, 2, 1, tag_mode=gpu.TAG_EXACT64)
+    _push_all(ref, steps, 1)
+    want, wf, _ = ref.sweep_series(range(nt), scopes)
+    want = want.copy()
+    ref.close()
+    ctx = _ctx(gpu, dims, 2, 1, tag_mode=gpu.TAG_EXACT64)
+    _push_all(ctx, steps, 1)
+    ctx.sweep_series_abort()                                    # nothing open: fine
+    ctx.sweep_series_submit(range(nt), scopes)
+    ctx.sweep_series_submit(range(nt), scopes)
+    with pytest.raises(gpu.FtkxError):
+        ctx.slices_prepare(range(nt), 0)                        # passes open: refused
+    ctx.sweep_series_abort()
+    rm = ctx.slices_prepare(range(nt), 0)                       # let through again
+    assert len(rm) == nt
+    got, f, _ = ctx.sweep_series(range(nt), scopes)
+    assert _same(got, want) and [int(v) for v in f] == [int(v) for v in wf]
+    ctx.sweep_series_submit(range(nt), scopes)                  # and the two-in-flight form works as before
+    ctx.sweep_series_submit(range(nt), scopes)
+    for _ in range(2):
+        got, f, _ = ctx.sweep_series_complete()
+        assert _same(got, want)
+    with pytest.raises((gpu.FtkxError, IndexError)):
+        ctx.sweep_series_complete()                             # nothing left
+    ctx.close()
+
+
 
 @pytest.mark.parametrize("name", ["woven_128x128x10", "woven_31x37x32", "double_gyre_64x32x50", "merger_2d_32x32x100", "moving_extremum_3d_21x21x21x32",
                                   "adversarial_3d_scalar_9x9x9x4", "random_2d_scalar_29x24x6_saddles", "adversarial_3d_scalar_9x9x9x3_norobust"])
