@@ -66,11 +66,10 @@ void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_c
                           hipStream_t st);
 // dist_kernels.hip: the slab pass
 void launch_dist_contrib(const SeriesSlice *slices, int nown, const u64 *red, u64 *contrib, u64 *block, hipStream_t st);
-void launch_dist_prefix(const u64 *gathered, int rank, int nranks, double running_in, u64 *block, u64 *results_tail, hipStream_t st);
 void launch_dist_export(const Mesh &m, const unsigned char *U, const unsigned char *M, u64 u_bytes, u64 *hdr, unsigned *idx, u64 *words, u64 capacity, int factor_log2, u64 *block, hipStream_t st);
 void launch_dist_import(const u64 *gathered, int rank, int nranks, double running_in, u64 *block, u64 *results_tail, const u64 *hdr, const unsigned *idx, const u64 *words, u64 u_bytes,
                         u64 capacity, int u_rows, int max_factor_log2, unsigned char *U, unsigned char *M, u64 mask_words, hipStream_t st);
-void launch_dist_request(u64 *request, u64 cap, const u64 *counters, u64 list_capacity, u64 refine_capacity, const u64 *block, u64 *results, u64 *counters_w, hipStream_t st);
+void launch_dist_cells(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 list_capacity, u64 refine_capacity, const double *halo_field, u64 *request, u64 cap, u64 *block, u64 *results, hipStream_t st);
 void launch_dist_patches(const Mesh &m, bool scatter, const u64 *request, u64 cap, int ncomp, double *field, double *patches, u64 *served, hipStream_t st);
 }  // namespace ftkx
 

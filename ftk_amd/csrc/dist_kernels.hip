@@ -119,19 +119,9 @@ __global__ __launch_bounds__(256) void dist_export_kernel(const Mesh m, const u6
   }
 }
 
-// ---- after the all_gather: the running minimum before this rank's slab, and the gathered block into the results (for the host) ------
-__global__ __launch_bounds__(64) void dist_prefix_kernel(const u64 *__restrict__ gathered, int rank, int nranks, double running_in, u64 *__restrict__ block, u64 *__restrict__ results_tail)
-{
-  const int lane = threadIdx.x;
-  u64 mn = (u64)__double_as_longlong(running_in);
-  for (int r = lane; r < rank; r += 64) { const u64 v = gathered[4 * r]; mn = v < mn ? v : mn; }
-  for (int o = 32; o > 0; o >>= 1) { const u64 a = __shfl_xor(mn, o); mn = a < mn ? a : mn; }
-  if (lane == 0) block[DB_PSEUDO + SR_RUNNING] = mn;
-  for (int i = lane; i < 4 * nranks; i += 64) results_tail[i] = gathered[i];
-}
-
 // ---- the halo's masks imported (header checked on the device: geometry, rows per summary byte, and the sender's factor must not exceed
-// ours -- masks serve their own factor and larger ones), with the prefix job above riding in workgroup 0 ---------------------------------
+// ours -- masks serve their own factor and larger ones), with the prefix job riding in workgroup 0: the running minimum BEFORE this rank's slab (min over the lower ranks' contributions) into the stub the
+// factor job reads, and the gathered block into the results (for the host) ---------------------------------
 __global__ __launch_bounds__(256) void dist_import_kernel(const u64 *__restrict__ gathered, int rank, int nranks, double running_in, u64 *__restrict__ block, u64 *__restrict__ results_tail,
                                                           const u64 *__restrict__ hdr /* nullptr: no halo */, const unsigned *__restrict__ idx, const u64 *__restrict__ words, u64 u_bytes,
                                                           u64 capacity, unsigned u_rows, unsigned max_factor_log2, u64 *__restrict__ U, unsigned char *__restrict__ M, u64 mask_words)
@@ -167,14 +157,41 @@ __global__ __launch_bounds__(256) void dist_import_kernel(const u64 *__restrict_
   if (bad) atomicOr((unsigned long long *)&block[DB_BAD2], 1ull);
 }
 
-// ---- the request: surviving cells whose exact test reads the halo slice, or -1 = "send the slice itself" ----------------------------
-// (count beyond the request's capacity, a mask message that did not fit, survivor lists that overflowed, or a pass whose masks will be
-// rebuilt by the host -- per-vertex overflow rule, Inf: its cull may then keep cells no patch was asked for)
-__global__ void dist_request_kernel(u64 *__restrict__ request, u64 cap, const u64 *__restrict__ counters, u64 list_capacity, u64 refine_capacity, const u64 *__restrict__ block,
-                                    u64 *__restrict__ results, u64 *__restrict__ counters_w)
+// ---- the request: the cells listed (as sparse_cells_kernel does: survivors of the cull whose interval sweep reads the halo slice,
+// a wavefront's run reserved with one atomic) and the request's header written by the workgroup that arrives last -- the count is an atomic,
+// read back where atomics are performed; the cells only have to be there when the kernel ends ---------------------------------------------
+__global__ __launch_bounds__(256) void dist_cells_kernel(const Mesh m, const Fields *__restrict__ steps, const u64 *__restrict__ list, u64 list_capacity, u64 refine_capacity,
+                                                         const double *halo_field, u64 *__restrict__ request, u64 cap, u64 *__restrict__ block, u64 *__restrict__ results)
 {
-  const u64 n = counters[CNT_SPARSE];
-  const bool overflow = counters[CNT_SURVIVOR_LIST] > list_capacity || counters[CNT_REFINE_LIST] > refine_capacity || counters[CNT_REFINE_PEAK] > refine_capacity;
+  u64 count = m.counters[CNT_SURVIVOR_LIST];
+  if (count > list_capacity) count = list_capacity;
+  u64 *cells = request + 1;
+  const u64 padded = (count + 63) / 64 * 64;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < padded; i += (u64)gridDim.x * 256) {
+    bool take = false;
+    u64 lin = 0;
+    if (i < count) {
+      const u64 e = list[i];
+      const Fields &f = steps[e >> 44];
+      lin = e & 0xffffffffffull;
+      take = ((e >> 40) & 2) && (f.S[1] == halo_field || f.V[1] == halo_field);
+    }
+    const unsigned long long b = __ballot(take);
+    if (!b) continue;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)b) - 1;
+    u64 base = 0;
+    if (lane == leader) base = atomicAdd(&m.counters[CNT_SPARSE], (u64)__popcll(b));
+    base = __shfl(base, leader);
+    if (take) { const u64 slot = base + (u64)__popcll(b & ((1ull << lane) - 1ull)); if (slot < cap) cells[slot] = lin; }
+  }
+  __shared__ unsigned s_last;
+  __syncthreads();                                        // (every wavefront has its reservation's return value: the count is complete when all have arrived)
+  if (threadIdx.x == 0) s_last = atomicAdd(&block[DB_DONE], 1ull) == (u64)gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last || threadIdx.x != 0) return;
+  block[DB_DONE] = 0ull;
+  const u64 n = __hip_atomic_load(&m.counters[CNT_SPARSE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool overflow = m.counters[CNT_SURVIVOR_LIST] > list_capacity || m.counters[CNT_REFINE_LIST] > refine_capacity || m.counters[CNT_REFINE_PEAK] > refine_capacity;
   const bool remask = (results[SR_STATUS] & (u64)(SERIES_MASKS_INVALID | SERIES_INF)) != 0;
   const bool full = n > cap || block[DB_BAD] != 0 || block[DB_BAD2] != 0 || overflow || remask;
   const long long asked = full ? -1ll : (long long)n;
@@ -182,9 +199,9 @@ __global__ void dist_request_kernel(u64 *__restrict__ request, u64 cap, const u6
   results[SR_HALO_ASKED] = (u64)asked;
   if (full) {
     atomicOr((unsigned long long *)&results[SR_STATUS], (unsigned long long)SERIES_HALO_FULL);
-    counters_w[CNT_SERIES_DONE] = 2ull;                 // (the rest of the chain leaves at once; the finish kernel reports)
+    m.counters[CNT_SERIES_DONE] = 2ull;                  // (the rest of the chain leaves at once; the finish kernel reports)
   }
-  const_cast<u64 *>(block)[DB_BAD2] = 0ull;            // (as found, for the next pass that uses this block)
+  block[DB_BAD2] = 0ull;                                 // (as found, for the next pass that uses this block)
 }
 
 // ---- patches: the input values a cell's exact test and record can touch (corner - 2 .. corner + 3 on every axis, clamped to the array),
@@ -222,8 +239,6 @@ __global__ __launch_bounds__(kThreads) void dist_patches_kernel(const Mesh m, co
 
 void launch_dist_contrib(const SeriesSlice *slices, int nown, const u64 *red, u64 *contrib, u64 *block, hipStream_t st)
 { hipLaunchKernelGGL(dist_contrib_kernel, dim3(1), dim3(256), 0, st, slices, nown, red, contrib, block); }
-void launch_dist_prefix(const u64 *gathered, int rank, int nranks, double running_in, u64 *block, u64 *results_tail, hipStream_t st)
-{ hipLaunchKernelGGL(dist_prefix_kernel, dim3(1), dim3(64), 0, st, gathered, rank, nranks, running_in, block, results_tail); }
 void launch_dist_export(const Mesh &m, const unsigned char *U, const unsigned char *M, u64 u_bytes, u64 *hdr, unsigned *idx, u64 *words, u64 capacity, int factor_log2, u64 *block, hipStream_t st)
 { hipLaunchKernelGGL(dist_export_kernel, dim3(512), dim3(256), 0, st, m, reinterpret_cast<const u64 *>(U), M, u_bytes, hdr, idx, words, capacity, (unsigned)factor_log2, block); }
 void launch_dist_import(const u64 *gathered, int rank, int nranks, double running_in, u64 *block, u64 *results_tail, const u64 *hdr, const unsigned *idx, const u64 *words, u64 u_bytes,
@@ -232,8 +247,8 @@ void launch_dist_import(const u64 *gathered, int rank, int nranks, double runnin
   hipLaunchKernelGGL(dist_import_kernel, dim3(hdr ? 128 : 1), dim3(256), 0, st, gathered, rank, nranks, running_in, block, results_tail, hdr, idx, words, u_bytes, capacity, (unsigned)u_rows,
                      (unsigned)max_factor_log2, reinterpret_cast<u64 *>(U), M, mask_words);
 }
-void launch_dist_request(u64 *request, u64 cap, const u64 *counters, u64 list_capacity, u64 refine_capacity, const u64 *block, u64 *results, u64 *counters_w, hipStream_t st)
-{ hipLaunchKernelGGL(dist_request_kernel, dim3(1), dim3(1), 0, st, request, cap, counters, list_capacity, refine_capacity, block, results, counters_w); }
+void launch_dist_cells(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 list_capacity, u64 refine_capacity, const double *halo_field, u64 *request, u64 cap, u64 *block, u64 *results, hipStream_t st)
+{ hipLaunchKernelGGL(dist_cells_kernel, dim3(256), dim3(256), 0, st, m, d_steps, d_list, list_capacity, refine_capacity, halo_field, request, cap, block, results); }
 void launch_dist_patches(const Mesh &m, bool scatter, const u64 *request, u64 cap, int ncomp, double *field, double *patches, u64 *served, hipStream_t st)
 {
   size_t b = (cap * (size_t)(m.nd == 3 ? 216 : 36) + kThreads - 1) / kThreads;

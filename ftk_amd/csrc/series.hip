@@ -1055,8 +1055,7 @@ int ftkx_series_dist_cull(ftkx_ctx *c, const void *masks_in, void *request_out)
     P.refined = true;
     u64 *req = (u64 *)request_out;
     const size_t cap = dist_cells_cap(c);
-    ftkx::launch_sparse_cells(m, d_steps, c->d_list, c->list_capacity, h.S ? h.S : h.V, req + 1, cap, c->stream);
-    ftkx::launch_dist_request(req, cap, c->d_counters, c->list_capacity, c->refine_capacity, B.dist_block, B.results, c->d_counters, c->stream);
+    ftkx::launch_dist_cells(m, d_steps, c->d_list, c->list_capacity, c->refine_capacity, h.S ? h.S : h.V, req, cap, B.dist_block, B.results, c->stream);
     P.request_out = req;
   }
   HIP_TRY(c, hipGetLastError());
