@@ -490,7 +490,12 @@ def job(args, env):
     # ONE host wait per pass, two passes in flight; --host-driven: round 2's sequence (prepare, host all_gather, enqueue, collect)
     slab = None
     if multi and not args.host_driven and args.compact_halo and not args.exact_only:
-        slab = tslab.SlabSeries(ctx, nt, own, scalar_input, torch, dev, first_slice=slices[own[0]] if own else None)
+        try:
+            slab = tslab.SlabSeries(ctx, nt, own, scalar_input, torch, dev, first_slice=slices[own[0]] if own else None)
+        except RuntimeError as e:      # (a mesh without summarised masks -- the same on every rank: they share it -- takes the host-driven sequence)
+            if rank == 0:
+                print("bench.py: %s; the host-driven sequence instead" % e, file=sys.stderr)
+            slab = None
     series_paths = {}
     pass_stamps, path_list = [], []      # wall-clock time at which each timed pass's records were on the host; the way each pass went
 

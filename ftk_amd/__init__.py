@@ -239,14 +239,14 @@ class Context:
     def series_dist_cells(self):
         return int(self._L.ftkx_series_dist_cells(self._h))
 
-    def series_dist_begin(self, ts, scopes, running_resolution, rank, nranks, halo, contrib, gathered, masks_out, side_stream=None):
-        """tensors: device memory of this context's device (masks_out: None without a lower neighbour); side_stream: a hipStream_t (int)
-        that is made to wait for masks_out only"""
+    def series_dist_begin(self, ts, scopes, running_resolution, rank, nranks, upper, contrib, gathered, masks_out, side_stream=None):
+        """upper: the rank that owns the slice behind this slab (None: no halo).  Tensors: device memory of this context's device
+        (masks_out: None without a lower neighbour); side_stream: a hipStream_t (int) that is made to wait for masks_out only"""
         n = len(ts)
         ts = np.ascontiguousarray(ts, dtype=np.int32)
         scopes = np.ascontiguousarray(scopes, dtype=np.int32)
         run = C.c_double(np.finfo(np.float64).max if running_resolution is None else float(running_resolution))
-        self._ck(self._L.ftkx_series_dist_begin(self._h, ts.ctypes.data, scopes.ctypes.data, n, C.byref(run), int(rank), int(nranks), int(bool(halo)),
+        self._ck(self._L.ftkx_series_dist_begin(self._h, ts.ctypes.data, scopes.ctypes.data, n, C.byref(run), int(rank), int(nranks), -1 if upper is None else int(upper),
                                                 contrib.data_ptr(), gathered.data_ptr(), masks_out.data_ptr() if masks_out is not None else None,
                                                 C.c_void_p(side_stream) if side_stream else None))
         self._dist_n = n

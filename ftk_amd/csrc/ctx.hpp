@@ -161,7 +161,7 @@ struct ftkx_series_pending {
   bool dist = false;
   int dist_stage = 0;               // 1 begun (masks, contribution, outgoing masks), 2 culled (request written), 3 served (reply written), 4 finished = open
   int t_halo = -1;                  // the slice this rank's last interval sweep reads and does not own: masks + patches arrive inside the pass; -1: none
-  int dist_rank = 0, dist_nranks = 1;
+  int dist_rank = 0, dist_nranks = 1, dist_upper = -1;     // dist_upper: the rank that owns t_halo (not rank + 1 where slabs are empty)
   const u64 *gathered = nullptr;    // device, kDistContrib words per rank: where the caller's all_gather puts the contributions
   u64 *request_out = nullptr;       // device: this rank's request to its upper neighbour (count, cells)
 };

@@ -473,7 +473,7 @@ void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, hipEvent_t also_afte
 // First half: everything of the pass is queued on the context's stream.  `prev`: the pass queued before this one and not yet collected,
 // whose running minimum this one continues from (on the device), or nullptr: *running_in is the value.
 // what a slab pass (ftkx_series_dist_*) adds to the plan of a pass: the halo slice and where the gathered contributions will be
-struct DistPlan { int t_halo; int rank, nranks; const u64 *gathered; u64 *contrib; void *masks_out; hipStream_t side; };
+struct DistPlan { int t_halo; int rank, nranks, upper; const u64 *gathered; u64 *contrib; void *masks_out; hipStream_t side; };
 
 int series_queue_cull(ftkx_ctx *c, ftkx_series_pending &P);
 int series_queue_tail(ftkx_ctx *c, ftkx_series_pending &P);
@@ -484,7 +484,7 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
 {
   const int nd = c->nd;
   P = ftkx_series_pending();
-  if (dist) { P.dist = true; P.t_halo = dist->t_halo; P.dist_rank = dist->rank; P.dist_nranks = dist->nranks; P.gathered = dist->gathered; }
+  if (dist) { P.dist = true; P.t_halo = dist->t_halo; P.dist_rank = dist->rank; P.dist_nranks = dist->nranks; P.dist_upper = dist->upper; P.gathered = dist->gathered; }
   P.ts.assign(ts, ts + n); P.scopes.assign(scopes, scopes + n); P.n = n;
   P.running_in = running_in; P.chained = prev != nullptr;
   int rc;
@@ -532,9 +532,9 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
     }
     if (dist && slice_ts[j] == dist->t_halo && s.sparse) {
       // the halo slice: its masks are imported behind the mask kernel (ftkx_series_dist_cull), its reduction is its owner's -- words 2, 3 of
-      // the upper neighbour's contribution to the all_gather
+      // the upper neighbour's contribution to the all_gather (the rank that owns the next timestep: not rank + 1 where slabs are empty)
       ready = true;
-      from_res[j] = dist->gathered + (size_t)ftkx::kDistContrib * (size_t)(dist->rank + 1) + 2;
+      from_res[j] = dist->gathered + (size_t)ftkx::kDistContrib * (size_t)dist->upper + 2;
       from_max[j] = from_res[j] + 1;
     }
     if (!ready) red_index[j] = (int)ntodo ++;
@@ -829,10 +829,10 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     const u64 *G = R + c->sr_last_gathered_off;
     for (int r = 0; r < P.dist_rank; r ++) { double v; memcpy(&v, &G[(size_t)ftkx::kDistContrib * r], 8); running = std::min(running, v); }
     auto it = P.t_halo >= 0 ? c->slices.find(P.t_halo) : c->slices.end();
-    if (it != c->slices.end() && it->second.sparse && P.dist_rank + 1 < P.dist_nranks) {
+    if (it != c->slices.end() && it->second.sparse && P.dist_upper >= 0 && P.dist_upper < P.dist_nranks) {
       Slice &h = it->second;
       double r, x;
-      memcpy(&r, &G[(size_t)ftkx::kDistContrib * (P.dist_rank + 1) + 2], 8); memcpy(&x, &G[(size_t)ftkx::kDistContrib * (P.dist_rank + 1) + 3], 8);
+      memcpy(&r, &G[(size_t)ftkx::kDistContrib * P.dist_upper + 2], 8); memcpy(&x, &G[(size_t)ftkx::kDistContrib * P.dist_upper + 3], 8);
       h.have_res = true; h.res = r; h.maxabs = x; h.res_below = r;
     }
     if (status & ftkx::SERIES_HALO_FULL) {
@@ -985,26 +985,31 @@ ftkx_series_pending *dist_pending(ftkx_ctx *c, int stage, const char *who)
 
 size_t ftkx_series_dist_cells(const ftkx_ctx *c) { return c && c->mesh_set && c->scalar_mode >= 0 ? dist_cells_cap(c) : 0; }
 
-int ftkx_series_dist_begin(ftkx_ctx *c, const int *ts, const int *scopes, int n, const double *running_resolution, int rank, int nranks, int halo,
+int ftkx_series_dist_begin(ftkx_ctx *c, const int *ts, const int *scopes, int n, const double *running_resolution, int rank, int nranks, int upper,
                            void *contrib, const void *gathered, void *masks_out, void *side_stream)
 {
+  const bool halo = upper >= 0;
   if (!c || n <= 0 || !ts || !scopes || !running_resolution || !contrib || !gathered) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: null argument or no steps");
   if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "sweep: call ftkx_set_mesh first");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: sweeps pending, collect first");
   if (c->sr_open >= 2) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: two passes are open, complete one first");
   if (rank < 0 || rank >= nranks) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: rank %d of %d", rank, nranks);
   if (!(*running_resolution > 0)) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: the running resolution must be positive (DBL_MAX: none yet)");
-  if (halo && (rank + 1 >= nranks || !(scopes[n - 1] & FTKX_SCOPE_INTERVAL))) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: a halo needs an upper neighbour and an interval sweep as the last step");
+  if (halo && (upper <= rank || upper >= nranks || !(scopes[n - 1] & FTKX_SCOPE_INTERVAL))) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: the upper neighbour must be a later rank, and the last step an interval sweep");
   if (c->scalar_mode < 0) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: push this rank's slices first");
   c->ahead.clear(); c->announced.clear();
   HIP_TRY(c, hipSetDevice(c->device));
   ftkx_series_pending &Q = c->sr_pend[(c->sr_head + c->sr_open) & 1];
   if (Q.dist && Q.dist_stage > 0 && Q.dist_stage < 4) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: a slab pass is half queued (finish or abort it)");
   int rc;
+  {
+    Mesh m0; fill_mesh(c, m0);                               // (before anything is allocated for a halo slice that will not be used)
+    if (!ftkx::masks_have_summary(m0)) return fail(c, FTKX_E_UNSUPPORTED, "ftkx_series_dist_begin: this mesh has no summarised masks (use the host-driven calls)");
+  }
   const int t_halo = halo ? ts[n - 1] + 1 : -1;
   if (halo && (rc = ensure_sparse_slice(c, t_halo, c->scalar_mode))) return rc;
   ftkx_series_pending *before = c->sr_open > 0 ? &c->sr_pend[(c->sr_head + c->sr_open - 1) & 1] : nullptr;
-  DistPlan dp{t_halo, rank, nranks, (const u64 *)gathered, (u64 *)contrib, masks_out, (hipStream_t)side_stream};
+  DistPlan dp{t_halo, rank, nranks, upper, (const u64 *)gathered, (u64 *)contrib, masks_out, (hipStream_t)side_stream};
   if ((rc = series_plan(c, Q, ts, scopes, n, *running_resolution, nullptr, true, before, &dp))) { Q.open = false; Q.dist = false; return rc; }
   if (Q.by_host) {      // (options the device-driven form does not cover: a slab pass has no host-driven form of its own -- the caller's protocol does)
     Q.open = false; Q.dist = false;
@@ -1038,7 +1043,9 @@ int ftkx_series_dist_cull(ftkx_ctx *c, const void *masks_in, void *request_out)
     if (P.t_halo >= 0) {
       size_t ub, cap, off_idx, off_words, total;
       if (!packed_layout(c, m, &ub, &cap, &off_idx, &off_words, &total)) return fail(c, FTKX_E_UNSUPPORTED, "ftkx_series_dist_cull: this mesh has no summarised masks");
-      Slice &h = c->slices.find(P.t_halo)->second;
+      auto hit = c->slices.find(P.t_halo);
+      if (hit == c->slices.end() || !hit->second.sparse) return fail(c, FTKX_E_NOSLICE, "ftkx_series_dist_cull: the halo slice %d was dropped or replaced between the stages", P.t_halo);
+      Slice &h = hit->second;
       const char *in = (const char *)masks_in;
       ftkx::launch_dist_import(P.gathered, P.dist_rank, P.dist_nranks, P.running_in, B.dist_block, tail, (const u64 *)in, (const unsigned *)(in + off_idx), (const u64 *)(in + off_words), ub, cap,
                                m.u_rows, factor_log2_of(P.hint), h.U, h.M, mask_bytes(c) / 8, c->stream);
@@ -1050,7 +1057,7 @@ int ftkx_series_dist_cull(ftkx_ctx *c, const void *masks_in, void *request_out)
   if (P.t_halo >= 0) {
     // the cells whose exact test reads the halo slice: refine now (the rest of the chain will not refine again), list them, write the request
     Fields *d_steps = (Fields *)((char *)B.d_desc + P.off_steps);
-    const Slice &h = c->slices.find(P.t_halo)->second;
+    const Slice &h = c->slices.find(P.t_halo)->second;          // (checked above)
     ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);
     P.refined = true;
     u64 *req = (u64 *)request_out;
@@ -1075,7 +1082,9 @@ int ftkx_series_dist_serve(ftkx_ctx *c, const void *request_in, void *reply_out)
     // the lower neighbour's cells around THIS rank's first slice: count read on the device, reply of fixed size
     ftkx_series_buffers &B = c->sr_buf[P.buf];
     Mesh m; series_mesh(c, P, m);
-    const Slice &s0 = c->slices.find(P.slice_ts[0])->second;
+    auto it0 = c->slices.find(P.slice_ts[0]);
+    if (it0 == c->slices.end() || it0->second.sparse) return fail(c, FTKX_E_NOSLICE, "ftkx_series_dist_serve: this rank's first slice %d was dropped between the stages", P.slice_ts[0]);
+    const Slice &s0 = it0->second;
     const int ncomp = c->scalar_mode == 1 ? 1 : c->nd;
     ftkx::launch_dist_patches(m, false, (const u64 *)request_in, dist_cells_cap(c), ncomp, c->scalar_mode == 1 ? s0.S : s0.V, (double *)reply_out, B.results + ftkx::SR_HALO_SERVED, c->stream);
     HIP_TRY(c, hipGetLastError());
@@ -1094,7 +1103,9 @@ int ftkx_series_dist_finish(ftkx_ctx *c, const void *reply_in)
   HIP_TRY(c, hipSetDevice(c->device));
   if (P.t_halo >= 0) {
     Mesh m; series_mesh(c, P, m);
-    Slice &h = c->slices.find(P.t_halo)->second;
+    auto hit = c->slices.find(P.t_halo);
+    if (hit == c->slices.end() || !hit->second.sparse) return fail(c, FTKX_E_NOSLICE, "ftkx_series_dist_finish: the halo slice %d was dropped or replaced between the stages", P.t_halo);
+    Slice &h = hit->second;
     const int ncomp = c->scalar_mode == 1 ? 1 : c->nd;
     ftkx::launch_dist_patches(m, true, P.request_out, dist_cells_cap(c), ncomp, c->scalar_mode == 1 ? h.S : h.V, const_cast<double *>((const double *)reply_in), nullptr, c->stream);
   }

@@ -304,7 +304,7 @@ class SlabSeries:
             self.open.append(b)
             return
         ctx = self.ctx
-        ctx.series_dist_begin(self.ts, self.scopes, running_resolution, self.rank, self.world, self.upper is not None, b["contrib"], b["gathered"], b["masks_out"],
+        ctx.series_dist_begin(self.ts, self.scopes, running_resolution, self.rank, self.world, self.upper, b["contrib"], b["gathered"], b["masks_out"],
                               side_stream=self.side.cuda_stream if self.side is not None else None)
         if self.side is not None:
             main = self.torch.cuda.current_stream()

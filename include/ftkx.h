@@ -240,14 +240,16 @@ int ftkx_sweep_series_abort(ftkx_ctx *ctx);
  *      caller: reply_out -> lower neighbour, upper neighbour's -> reply_in
  *   _finish  patches scattered into the halo slice; exact test, records, finish.  The pass is open: ftkx_sweep_series_complete as usual
  * All buffers are device memory of this context's device and must stay untouched until the pass is complete; ranks without a lower /
- * upper neighbour pass NULL for the corresponding buffers (halo = 0: the last step's slices are all this rank's own).  Two slab passes
+ * upper neighbour pass NULL for the corresponding buffers (upper = -1: the last step's slices are all this rank's own; with more ranks than
+ * timesteps the neighbours are the nearest ranks that own timesteps, not rank - 1 / rank + 1).  Two slab passes
  * may be in flight like any two passes (separate buffers each).  ftkx_sweep_series_complete returns FTKX_E_NOSLICE when the request said
  * -1 (nothing was swept: fetch the slice itself, push it, and sweep with ftkx_sweep_series from the running minimum
  * ftkx_series_dist_status reports); the owner learns the same from `served` = -1.  Options the device-driven pass does not cover:
  * FTKX_E_UNSUPPORTED from _begin (same on every rank: they share options and mesh) -- use ftkx_slices_prepare / ftkx_sweep_enqueue /
  * ftkx_sweep_cull / ftkx_sweep_collect. */
 size_t ftkx_series_dist_cells(const ftkx_ctx *ctx);
-int ftkx_series_dist_begin(ftkx_ctx *ctx, const int *timesteps, const int *scopes, int n, const double *running_resolution, int rank, int nranks, int halo,
+int ftkx_series_dist_begin(ftkx_ctx *ctx, const int *timesteps, const int *scopes, int n, const double *running_resolution, int rank, int nranks,
+                           int upper /* the rank that owns the slice behind this slab, -1: none (every slice the steps read is this rank's own) */,
                            void *contrib, const void *gathered, void *masks_out, void *side_stream /* hipStream_t, nullable */);
 int ftkx_series_dist_cull(ftkx_ctx *ctx, const void *masks_in, void *request_out);
 int ftkx_series_dist_serve(ftkx_ctx *ctx, const void *request_in, void *reply_out);

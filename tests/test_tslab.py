@@ -233,7 +233,9 @@ class OracleSlabCtx:
     def patch_doubles(self): return 1
     def series_last_path(self): return (1, 0)
 
-    def series_dist_begin(self, ts, scopes, running, rank, world, halo, contrib, gathered, masks_out, side_stream=None):
+    def series_dist_begin(self, ts, scopes, running, rank, world, upper, contrib, gathered, masks_out, side_stream=None):
+        halo = upper is not None
+        assert upper is None or upper == tslab.owner_of(int(ts[-1]) + 1, self.nt, world)      # (the rank that owns the next timestep: not rank + 1 where slabs are empty)
         assert side_stream is None
         self.cur = dict(ts=[int(t) for t in ts], scopes=[int(s) for s in scopes], run=tslab.DBL_MAX if running is None else running, rank=rank, world=world, halo=halo, gathered=gathered,
                         n=self.npass)

@@ -70,7 +70,7 @@ def main():
     def submit(k):
         b = sets[k & 1]
         ctx.invalidate_masks()
-        ctx.series_dist_begin(ts, scopes, None, 0, 2, halo, b["contrib"], b["gathered"], b["masks"] if halo else None, side_stream=side.cuda_stream if (halo and side is not None) else None)
+        ctx.series_dist_begin(ts, scopes, None, 0, 2, 1 if halo else None, b["contrib"], b["gathered"], b["masks"] if halo else None, side_stream=side.cuda_stream if (halo and side is not None) else None)
         if halo and side is not None:                                    # (where the masks would cross xGMI: a copy of the message on the side stream)
             with torch.cuda.stream(side):
                 b["masks_rx"].copy_(b["masks"], non_blocking=True)
