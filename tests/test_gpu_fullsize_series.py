@@ -198,3 +198,79 @@ def test_c4_series_moving_extremum_512cubed_x32(gpu):
     recs, f, _, st = _timed_path(gpu, "moving_extremum_3d", dims, nt, 1, (2, SERIES_EARLY), k=4)
     assert st["work_items"] == 246073579314
     _analytic_3d(gpu, recs, st, f, dims, nt)
+
+
+def test_c4_series_eight_slabs_in_one_process(gpu):
+    """BASELINE configs[3] in its literal form -- moving_extremum_3d 512^3 x 32 cut into EIGHT timestep slabs -- at full size: eight contexts
+    on this one GPU, one per rank, each with its four slices, running the device-driven slab pass (ftkx_series_dist_*) with the messages
+    handed from context to context as they would cross xGMI (tests/test_gpu_slab_inprocess.py).  The merged records are the one-context
+    pass's, byte for byte; every rank took the fused tail; what crossed the slab boundaries was a few dozen cells' patches."""
+    import torch
+    from ftk_amd import synthetic
+    import test_gpu_slab_inprocess as S
+    dims, nt, world = (512, 512, 512), 32, 8
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    try:
+        slices = []
+        for t in range(nt):
+            slices.append(synthetic.generate("moving_extremum_3d", dims, t, nt, torch, dev))
+            torch.cuda.synchronize()
+        one = S._make_ctx(gpu, 3, 1, dims, stream)
+        for t in range(nt):
+            one.push_scalar_slice(t, slices[t])
+        scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+        want, wf, _ = one.sweep_series(range(nt), scopes, copy=True)
+        assert one.series_last_path() == (2, SERIES_EARLY) and len(want) >= 2 * nt - 1
+        one.close()
+
+        class DeviceRank(S.Rank):            # (the slices are on the device already: adopt them instead of uploading numpy arrays)
+            def __init__(self, rank):
+                self._steps = None
+                import numpy as np_
+                from ftk_amd import tslab
+                self.gpu, self.torch, self.rank, self.world, self.nt = gpu, torch, rank, world, nt
+                t0, t1 = tslab.slab_range(nt, world, rank)
+                self.own = list(range(t0, t1))
+                self.scalar = True
+                self.ctx = S._make_ctx(gpu, 3, 1, dims, stream)
+                self.dev_slices = {t: slices[t] for t in self.own}
+                for t in self.own:
+                    self.ctx.push_scalar_slice(t, slices[t])
+                self.open, self.stash = 0, []
+                self.t_halo = t1 if t1 < nt else None
+                self.lower = tslab.owner_of(t0 - 1, nt, world) if t0 > 0 else None
+                self.upper = tslab.owner_of(t1, nt, world) if self.t_halo is not None else None
+                self.ts = np_.array(self.own, dtype=np_.int32)
+                self.scopes = np_.array([gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in self.own], dtype=np_.int32)
+                nbytes, _ = self.ctx.packed_masks_bytes()
+                cells, pd = self.ctx.series_dist_cells(), self.ctx.patch_doubles()
+                z = lambda n, dt: torch.zeros((max(int(n), 1),), dtype=dt, device=dev)
+                self.sets = [dict(contrib=z(4, torch.float64), gathered=z(4 * world, torch.float64), masks_out=z(nbytes, torch.uint8), masks_in=z(nbytes, torch.uint8),
+                                  req_out=z(1 + cells, torch.int64), req_in=z(1 + cells, torch.int64), reply_out=z(cells * pd, torch.float64), reply_in=z(cells * pd, torch.float64))
+                             for _ in range(2)]
+
+        ranks = [DeviceRank(r) for r in range(world)]
+        try:
+            S._slab_pass(ranks, 0)
+            S._slab_pass(ranks, 1)                   # two passes in flight
+            first, rec1 = S._complete(ranks)
+            second, rec2 = S._complete(ranks)
+            assert rec1 == 0 and rec2 == 0           # nobody needed a whole slice
+            for (r, a), (_, b) in zip(first, second):
+                assert a[1] == b[1] and a[0].tobytes() == b[0].tobytes()
+                assert r.ctx.series_last_path() == (2, SERIES_EARLY), (r.rank, r.ctx.series_last_path())
+                asked, served, g = r.ctx.series_dist_status(world)
+                assert 0 <= asked <= 512 and (asked > 0) == (r.upper is not None), (r.rank, asked)      # a few dozen cells around the extremum cross each boundary
+            merged = np.concatenate([res[0] for _, res in first])
+            merged = merged[np.argsort(merged["tag"], kind="stable")]
+            got_f = [f for r, res in first for f in res[1]]
+            assert got_f == [int(v) for v in wf]
+            assert merged.tobytes() == np.ascontiguousarray(want).tobytes()
+        finally:
+            for r in ranks:
+                r.ctx.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        torch.cuda.empty_cache()
