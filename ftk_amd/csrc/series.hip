@@ -887,14 +887,6 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     if (e[0] < nrec) H[e[0]].type = (unsigned)ftkx::classify3(A, c->opt.jacobian_symmetric != 0);
   }
   c->stats.reclassified = nf;
-  if (status & ftkx::SERIES_UNORDERED) {                     // (the fused tail with more records than its last workgroup ranks: rare) sort an index, move once
-    std::vector<std::pair<unsigned long long, size_t>> order(nrec);
-    for (size_t i = 0; i < nrec; i ++) order[i] = {H[i].tag, i};
-    std::sort(order.begin(), order.end());
-    std::vector<ftkx_cp_t> tmp(nrec);
-    for (size_t i = 0; i < nrec; i ++) tmp[i] = H[order[i].second];
-    if (nrec) memcpy(H, tmp.data(), nrec * sizeof(ftkx_cp_t));
-  }
   if (status & ftkx::SERIES_FIX_ORDER) {
     // A bucket too full to rank on the device: its records sit in their own run of the output, unordered among themselves; everything
     // before the run is smaller, everything behind it larger.  Find each such run from an inversion, widen it until both ends are in

@@ -225,7 +225,7 @@ constexpr int kSmallGrid = 256;                          // workgroups: one per 
                                                          // workgroups would start when the first has finished)
 constexpr unsigned kSmallPer = 8;                        // coarse cells (two-level) per workgroup at most, dealt round-robin; without summaries: 8 x 32 corners
                                                          // (dealt as single ROWS of coarse cells the refine phase took twice as long and the rest no less)
-constexpr unsigned kSmallRank = 1024;                    // records the last workgroup ranks in LDS (more: SERIES_UNORDERED, the host sorts)
+constexpr unsigned kSmallRank = 1024;                    // records the last workgroup ranks in LDS (more: the kernel declines after all and the bucket chain orders them)
 
 #ifdef FTKX_SMALL_STAMPS
 __device__ unsigned long long g_small_stamps[16];      // [0] earliest start (min), [k] the latest passage of phase boundary k (max)
@@ -593,7 +593,24 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
   const bool over = nrec_all > m.capacity || nfrag > m.fragile_capacity;
   const u64 nrec = over ? 0ull : nrec_all;
   const bool ranked = nrec <= (u64)kSmallRank && nrec <= (u64)PASS_CAP;
-  u64 status = (u64)SERIES_EARLY | (over ? (u64)SERIES_OVERFLOW : 0ull) | (ranked ? 0ull : (u64)SERIES_UNORDERED);
+  if (!ranked && !over) {
+    // More records than this workgroup can put in order (few coarse cells, many hits in them: small hit-dense 2D series).  Declined after
+    // all: what this kernel counted is taken back and the pass is left to the kernels behind it, which walk the same lists again and
+    // order with buckets -- tens of microseconds lost, against a host that would have to sort (rounds 3-4a: SERIES_UNORDERED; the bit now says that this happened)
+    if (tid == 0) {
+      m.counters[CNT_HITS] = 0ull; m.counters[CNT_FRAGILE] = 0ull; m.counters[CNT_SIMPLICES_TESTED] = 0ull; m.counters[CNT_CELLS_SURVIVED] = 0ull;
+      results[SR_STATUS] |= (u64)SERIES_LATE_DECLINE;       // (for the record: the finish kernel hands it to the host with the rest)
+    }
+    __syncthreads();
+    if (report_decline) {
+      for (size_t i = tid; i < nwords; i += kThreads) h_results[i] = (i == (size_t)SR_STATUS) ? (results[i] | (u64)SERIES_TAIL_PENDING) : results[i];
+      __threadfence_system();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  u64 status = (u64)SERIES_EARLY | (over ? (u64)SERIES_OVERFLOW : 0ull);
   // rank of every record (by counting the smaller order keys), records copied into the pinned host buffer at their rank
   if (ranked) {
     for (u64 i = tid; i < nrec; i += kThreads) s_pass[i] = m.pass[i];

@@ -876,6 +876,196 @@ __device__ inline unsigned guard_and_reduce(unsigned a0, unsigned a1, double dx0
   return bits;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// mask_vec_kernel with ONE summary byte per 8 x 4 block of vertices (Mesh::u_rows == 4) and on a VALU diet (round 4).
+// Why blocks: every byte of summary a streaming kernel stores costs far more than its share of the traffic (on
+// double_gyre 2048 x 1024 x 128 the 32 summary bytes per 4 KB of input are 39 us of the kernel's 726 -- tools/probe/bw_probe.hip
+// `v` shows the same on a bare read walk); a quarter of the bytes is three quarters of that gone, and the coarse cull reads a
+// quarter too.  A wavefront therefore takes a unit of 4 rows x 64 groups (16 KB): the block's summary is an AND across its own
+// registers and one neighbouring lane.
+// Why the diet: rocprofv3 had the kernel above at VALUBusy 68 %, 279 VALU instructions per 4 KB of input
+// (profiles/r04_c5_valu_summary.json) -- two 32-bit divisions per step to find (row, group), 64-bit address arithmetic for every
+// load and store, a compare + select + or per sign bit, per-vertex domain / finiteness / magnitude tests whose outcome is the same
+// for all but a few wavefronts.  Here
+//   * a unit's coordinates are wave-uniform and advance by additions on the scalar unit; loads and stores go through buffer
+//     resources (SGPR offset + one constant per-lane offset);
+//   * a component is strictly signed iff |x| >= thr -- ONE compare, shifted into an accumulator by add-with-carry -- and its sign is
+//     the top bit of the double, shifted into a second accumulator by v_alignbit: pos = strict & ~sign, neg = strict & sign
+//     (thr = 1 / F > 0: neither a zero nor a NaN is strict);
+//   * the border of the domain, non-finite values and values past `big` are detected per WAVEFRONT and row (scalar comparisons of
+//     the chunk's ends with the domain; one v_max chain, which the reduction needs anyway, and one unordered-compare per pair of
+//     values); only then are the row's vertices walked one by one as the kernel above does.
+// (The diet alone, on the kernel above's linear walk: 0.744 -> 0.742 ms -- the kernel was not waiting for its arithmetic.)
+// Same fused reduction and records as mask_vec_kernel; the same mask words wherever both write them (tests/test_gpu_properties.py:
+// fields with NaNs, infinities, big values and plateaus).  Needs rows of at least 64 groups and byte offsets that fit 31 bits:
+// vec_lean() below.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ND>
+__device__ inline void push_vertex_signs(unsigned &S, unsigned &G, const double *x, double thr)
+{
+  // S = S << ND | strict bits, G = G << ND | sign bits, most significant component first; the compares run ahead of the
+  // add-with-carry that consumes them (two wait states between a VALU writing an SGPR and a VALU reading it)
+  unsigned long long m0, m1, m2;
+  if constexpr (ND == 2)
+    asm("v_cmp_ge_f64_e64 %[m0], |%[x1]|, %[thr]\n\tv_cmp_ge_f64_e64 %[m1], |%[x0]|, %[thr]\n\t"
+        "v_alignbit_b32 %[G], %[G], %[h1], 31\n\tv_alignbit_b32 %[G], %[G], %[h0], 31\n\t"
+        "v_addc_co_u32_e64 %[S], vcc, %[S], %[S], %[m0]\n\tv_addc_co_u32_e64 %[S], vcc, %[S], %[S], %[m1]"
+        : [S] "+v"(S), [G] "+v"(G), [m0] "=&s"(m0), [m1] "=&s"(m1)
+        : [x0] "v"(x[0]), [x1] "v"(x[1]), [h0] "v"((int)(__double_as_longlong(x[0]) >> 32)), [h1] "v"((int)(__double_as_longlong(x[1]) >> 32)), [thr] "s"(thr)
+        : "vcc");
+  else
+    asm("v_cmp_ge_f64_e64 %[m0], |%[x2]|, %[thr]\n\tv_cmp_ge_f64_e64 %[m1], |%[x1]|, %[thr]\n\tv_cmp_ge_f64_e64 %[m2], |%[x0]|, %[thr]\n\t"
+        "v_alignbit_b32 %[G], %[G], %[h2], 31\n\tv_addc_co_u32_e64 %[S], vcc, %[S], %[S], %[m0]\n\t"
+        "v_alignbit_b32 %[G], %[G], %[h1], 31\n\tv_addc_co_u32_e64 %[S], vcc, %[S], %[S], %[m1]\n\t"
+        "v_alignbit_b32 %[G], %[G], %[h0], 31\n\tv_addc_co_u32_e64 %[S], vcc, %[S], %[S], %[m2]"
+        : [S] "+v"(S), [G] "+v"(G), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2)
+        : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[ND - 1]), [h0] "v"((int)(__double_as_longlong(x[0]) >> 32)), [h1] "v"((int)(__double_as_longlong(x[1]) >> 32)),
+          [h2] "v"((int)(__double_as_longlong(x[ND - 1]) >> 32)), [thr] "s"(thr)
+        : "vcc");
+}
+
+// AND of the four mask bytes of a word, then with the neighbouring lane's: the summary of the aligned 8-vertex word (mask bytes never
+// carry bits 6 and 7)
+__device__ inline unsigned word_summary4(unsigned word)
+{
+  unsigned q;
+  asm("v_and_b32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+      "s_nop 0\n\t"
+      "v_and_b32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+      "s_nop 1\n\t"
+      "v_and_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "=&v"(q) : "v"(word));
+  return q;
+}
+
+template <int ND>
+__global__ __launch_bounds__(kThreads) void mask_vec2_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int dbg)
+{
+  constexpr int NV = 4 * ND, NL = 2 * ND;                      // values and 16-byte loads per lane and row
+  constexpr unsigned GB = 32u * ND;                            // bytes of a group of 4 vertices
+  constexpr unsigned FULL = (ND == 2) ? 0x03030303u : 0x07070707u;
+  const MaskJob job = jobs[blockIdx.y];
+  const unsigned DW = (unsigned)m.ext_sz[0], DH = (unsigned)m.ext_sz[1], DD = (ND == 3) ? (unsigned)m.ext_sz[2] : 1u;
+  const unsigned P = (unsigned)m.mask_pitch, UP = (unsigned)m.u_pitch;
+  const unsigned ngroups = DW / 4u, nch = (ngroups + 63u) / 64u, nby = (DH + 3u) / 4u, nunits = nch * nby * DD;
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned W = gridDim.x * (unsigned)(kThreads / 64);    // units between a wavefront's units
+  const double thr = job.threshold;
+  const bool have_u = job.U != nullptr;
+  const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void *)job.V, 0, (int)(ngroups * DH * DD * GB), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)job.M, 0, (dbg & 2) ? 0 : (int)(P * DH * DD), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)job.U, 0, (have_u && !(dbg & 1)) ? (int)(UP * nby * DD) : 0, 0x00020000);
+
+  // unit u = (chunk ch of 64 groups, block jb of 4 rows, plane k), chunks fastest: found once by division, then advanced by additions
+  unsigned u = blockIdx.x * (unsigned)(kThreads / 64) + wv;
+  unsigned ch, jb, k;
+  { const unsigned t = u / nch; ch = u - t * nch; k = t / nby; jb = t - k * nby; }
+  unsigned dch, djb, dk;
+  { const unsigned t = W / nch; dch = W - t * nch; dk = t / nby; djb = t - dk * nby; }
+  // groups whose four vertices all lie inside the domain along x: glo .. ghi
+  const int xl = m.dom_lb[0] - m.ext_st[0], xh = m.dom_ub[0] - m.ext_st[0];
+  const int glo = xl <= 0 ? 0 : (xl + 3) / 4, ghi = xh < 3 ? -1 : (xh - 3) / 4;
+
+  const unsigned lv = lane * GB, lm = lane * 4u, lu = lane >> 1;
+  const bool u_lane = (lane & 1u) == 0;
+  double red_mn = DBL_MAX, red_mx = 0.0;
+  while (u < nunits) {
+    // (wave-uniform by construction; said again, the compiler keeps the unit's coordinates and everything derived from them on the scalar
+    // unit -- without it the loads' offsets end up in a VGPR and every load in a waterfall loop)
+    u = (unsigned)__builtin_amdgcn_readfirstlane((int)u); ch = (unsigned)__builtin_amdgcn_readfirstlane((int)ch);
+    jb = (unsigned)__builtin_amdgcn_readfirstlane((int)jb); k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+    const unsigned g0 = ch * 64u, j0 = jb * 4u;
+    const bool lane_live = g0 + lane < ngroups;                // (only a row's last chunk has lanes past its end)
+    v4u D[4][NL];
+#pragma unroll
+    for (int r = 0; r < 4; r ++) {                             // all four rows' loads, then the rows as they arrive (rows past the slice: the last row again)
+      const unsigned j = j0 + (unsigned)r < DH ? j0 + (unsigned)r : DH - 1u;
+      const unsigned so = ((k * DH + j) * ngroups + g0) * GB;
+#pragma unroll
+      for (int q = 0; q < NL; q ++) D[r][q] = __builtin_amdgcn_raw_buffer_load_b128(rV, lv + 16u * (unsigned)q, so, 0);
+    }
+    const bool x_edge = (int)g0 < glo || (int)(g0 + 63u) > ghi;  // (a chunk with lanes past the row's end: g0 + 63 > ngroups - 1 >= ghi)
+    const bool k_dom = ND == 2 || ((int)k + m.ext_st[2] >= m.dom_lb[2] && (int)k + m.ext_st[2] <= m.dom_ub[2]);
+    unsigned wr[4];
+#pragma unroll
+    for (int r = 0; r < 4; r ++) {
+      const unsigned j = j0 + (unsigned)r;
+      if (!(j < DH)) { wr[r] = 0x3f3f3f3fu; continue; }        // (wave-uniform) no such row: neutral for the block's summary
+      double v[NV];
+#pragma unroll
+      for (int q = 0; q < NL; q ++) { const v2d t = __builtin_bit_cast(v2d, D[r][q]); v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+      // strict / sign bits of the lane's four vertices, vertex 3 first: byte q of S and G = vertex q
+      unsigned S = 0, G = 0;
+#pragma unroll
+      for (int q = 3; q >= 0; q --) {
+        if (q < 3) { S <<= 8 - ND; G <<= 8 - ND; }
+        push_vertex_signs<ND>(S, G, &v[q * ND], thr);
+      }
+      const unsigned neg = S & G;
+      unsigned word = (S ^ neg) | (neg << 3);
+      double mxl = max_abs2(v[0], v[1]);
+#pragma unroll
+      for (int q = 2; q < NV; q ++) mxl = max_with_abs(mxl, v[q]);
+      bool odd = mxl >= job.big;                               // (a NaN is ignored by the maximum: the unordered compares find it)
+#pragma unroll
+      for (int q = 0; q < NV; q += 2) odd = odd || __builtin_isunordered(v[q], v[q + 1]);
+      const bool row_dom = k_dom && (int)j + m.ext_st[1] >= m.dom_lb[1] && (int)j + m.ext_st[1] <= m.dom_ub[1];
+      const bool cand = (S & FULL) != FULL;                    // a component without a strict sign: a candidate for the slice's resolution (rare on smooth data)
+      if (x_edge || !row_dom || __builtin_amdgcn_ballot_w64(odd)) {   // the vertices one by one, as mask_vec_kernel does
+        asm volatile("" ::: "memory");
+        const unsigned g = g0 + lane;
+        word = 0;
+        for (int q = 0; q < 4; q ++) {
+          unsigned bits = 0;
+          double mx = 0.0;
+          bool fin = true;
+          for (int c = 0; c < ND; c ++) {
+            const double x = v[q * ND + c], a = fabs(x);
+            if (x >= thr) bits |= 1u << c;
+            if (x <= -thr) bits |= 8u << c;
+            fin = fin && a < HUGE_VAL;
+            mx = fmax(mx, a);
+          }
+          red_mx = lane_live ? fmax(red_mx, mx) : red_mx;
+          const int x = 4 * (int)g + q + m.ext_st[0];
+          const bool dom = row_dom && x >= m.dom_lb[0] && x <= m.dom_ub[0];
+          if (mx >= job.big) bits = 0u;
+          if (!fin || !dom) bits = kNeutral;
+          word |= bits << (8 * q);
+        }
+        if (!lane_live) word = 0x3f3f3f3fu;
+        if (__builtin_amdgcn_ballot_w64(cand && lane_live)) {
+          if (lane_live)
+            for (int q = 0; q < NV; q ++) { const double a = fabs(v[q]); red_mn = fmin(red_mn, (a == 0.0 || !(a < thr)) ? DBL_MAX : a); }
+        }
+      } else {
+        red_mx = max_plain(red_mx, mxl);
+        if (__builtin_amdgcn_ballot_w64(cand))
+          for (int q = 0; q < NV; q ++) { const double a = fabs(v[q]); red_mn = fmin(red_mn, (a == 0.0 || !(a < thr)) ? DBL_MAX : a); }
+      }
+      wr[r] = word;
+    }
+    // the block's summary: the sign bits all 8 x 4 vertices share; its mask words are stored where there is none
+    bool uniform = false;
+    if (have_u) {
+      const unsigned q8 = word_summary4((wr[0] & wr[1]) & (wr[2] & wr[3]));
+      if (lane_live && u_lane) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)q8, rU, lu, (k * nby + jb) * UP + (g0 >> 1), 0);
+      uniform = q8 != 0;
+    }
+    if (lane_live && !uniform) {
+#pragma unroll
+      for (int r = 0; r < 4; r ++)
+        if (j0 + (unsigned)r < DH) __builtin_amdgcn_raw_buffer_store_b32(wr[r], rM, lm, (k * DH + j0 + (unsigned)r) * P + g0 * 4u, 0);
+    }
+    // the next unit (scalar unit)
+    u += W; ch += dch; jb += djb; k += dk;
+    if (ch >= nch) { ch -= nch; jb ++; }
+    if (jb >= nby) { jb -= nby; k ++; }
+  }
+  if (job.red) red_commit(job.red, red_mn, red_mx, blockIdx.x * 5u + (threadIdx.x >> 6));
+}
+
 // PD = prefetch distance: at the step for plane k the loads of plane k + 1 + PD are issued (PD = 1: three planes of registers
 // plus one in flight).  RY = rows per wavefront: a plane costs (RY + 2) * 4 + 2 VGPRs; 3D runs RY = 4 at three wavefronts per
 // SIMD or RY = 8 at two (fewer halo rows per useful row, and 6 of 10 row loads are private to the wavefront).
@@ -909,6 +1099,7 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
   const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)job.M, 0, (int)((unsigned)P * (unsigned)DH * (unsigned)DD), 0x00020000);
   const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)job.U, 0, (int)((unsigned)m.u_pitch * (unsigned)DH * (unsigned)DD), 0x00020000);
   const bool have_u = job.U != nullptr;
+  const bool block4 = ND == 2 && RY % 4 == 0 && have_u && m.u_rows == 4;   // (wave-uniform) one summary byte per 8 x 4 block
   const double thr = job.threshold;
   // what the raw central difference (a - b) is compared with: 3D g = 0.5 (a - b); 2D g = (a - b) (D - 1) keeps its multiply
   const double tpos = (ND == 3) ? 2.0 * thr : thr, tneg = -tpos;
@@ -986,6 +1177,7 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
     const bool z_int = ND == 2 || (k >= 1 && k < DD - 1);
     const unsigned mplane = (unsigned)P * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
     const unsigned uplane = (unsigned)m.u_pitch * ((unsigned)j0 + (unsigned)DH * (unsigned)k);
+    unsigned bw[RY];                                           // (block summaries) the rows' pairs of mask bytes
     static_for<RY>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       const v2d c = CU[r + 1];
@@ -1037,6 +1229,7 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
       const unsigned keep = u_int ? xkeep : 0u;                // gradient3D leaves the array border at 0
       const unsigned neut = u_dom ? xneutral : 0x3f3fu;        // outside the domain / row padding: never blocks a cull
       bits = (bits & keep) | neut;
+      if (block4) { bw[r] = rok ? bits : 0x3f3fu; return; }   // (wave-uniform) summaries per 8 x 4 block: below, once the block's rows are known
       bool word_uniform = false;
       // summary byte of the aligned 8-vertex word this quad of lanes covers: the sign bits ALL eight vertices share
       if (have_u) {
@@ -1049,6 +1242,24 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
       if (rok && store_ok && !word_uniform)
         __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rM, mcol, mplane + (unsigned)P * (unsigned)r, 0);
     });
+    // One summary byte per 8 x 4 block (Mesh::u_rows == 4; 2D): the sign bits all 32 vertices share -- a quarter of the summary bytes, and
+    // every byte of them costs (the summary stores).  The mask words of a block are stored where it has no such bit.
+    if constexpr (ND == 2 && RY % 4 == 0 && !REDUCE) if (block4) {
+      static_for<RY / 4>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        const unsigned all = (bw[4 * b] & bw[4 * b + 1]) & (bw[4 * b + 2] & bw[4 * b + 3]);
+        int q = (int)((all & (all >> 8)) & 0x3fu);
+        q &= __builtin_amdgcn_update_dpp(q, q, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+        q &= __builtin_amdgcn_update_dpp(q, q, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
+        const bool first_ok = ((row_ok >> (4 * b)) & 1) && k < z1;
+        if (first_ok && u_lane) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)q, rU, ucol, (unsigned)m.u_pitch * ((unsigned)(j0 / 4 + b) + (unsigned)((DH + 3) / 4) * (unsigned)k), 0);
+        if (q == 0 && store_ok) {
+#pragma unroll
+          for (int r = 4 * b; r < 4 * b + 4; r ++)
+            if (((row_ok >> r) & 1) && k < z1) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bw[r], rM, mcol, mplane + (unsigned)P * (unsigned)r, 0);
+        }
+      });
+    }
   };
 
   // the plane buffers rotate by NAME: the z loop is unrolled NB times, every index below is a compile-time constant
@@ -2265,6 +2476,14 @@ void tile_dims(int nd, int tile[3])
 
 // does this mesh take the fast vector-input kernel?
 static bool vec_fast(const Mesh &m) { return !m.scalar_mode && m.ext_sz[0] >= 8 && (m.ext_sz[0] % 8) == 0; }
+// ... its form with block summaries (mask_vec2_kernel)?  Rows of at least 64 groups, byte offsets that fit 31 bits.  FTKX_VEC_LEAN=0: never
+static bool vec_lean(const Mesh &m)
+{
+  if (!vec_fast(m) || m.ext_sz[0] < 256) return false;
+  if (const char *e = getenv("FTKX_VEC_LEAN")) if (atoi(e) == 0) return false;
+  const size_t n = (size_t)m.ext_sz[1] * (m.nd == 3 ? (size_t)m.ext_sz[2] : 1);
+  return (size_t)m.ext_sz[0] * n * 8 * (size_t)m.nd < (1ull << 31) && (size_t)m.mask_pitch * n < (1ull << 31);
+}
 
 void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool reduce, hipStream_t stream)
 {
@@ -2366,6 +2585,20 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
     while (bx > 256 && bx * kThreads * 4 > groups) bx /= 2;
     if (const char *e = getenv("FTKX_VEC_BX")) { const size_t v = (size_t)atoi(e); if (v >= 1 && v < bx) bx = v; }
     const dim3 grid((unsigned)bx, (unsigned)njobs);
+    // mask_vec2_kernel (units of 4 rows x 64 groups, one summary byte per 8 x 4 block): where the mesh carries block summaries
+    if (m.u_rows == 4 && vec_lean(m)) {
+      const size_t units = (size_t)((m.ext_sz[0] / 4 + 63) / 64) * ((m.ext_sz[1] + 3) / 4) * DDv;
+      size_t bx2 = (units + 7) / 8;             // two units (32 KB) per wavefront where the slice has them (four: +1.3 %, one: +0.3 % on double_gyre 2048 x 1024 x 128)
+      if (bx2 > 2048) bx2 = 2048;
+      if (const char *e = getenv("FTKX_VEC_BX")) { const size_t v = (size_t)atoi(e); if (v >= 1) bx2 = v; }
+      const dim3 grid((unsigned)bx2, (unsigned)njobs);
+      g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_vec2_kernel<2>" : "ftkx::mask_vec2_kernel<3>";
+      int dbg = 0;
+      if (const char *e = getenv("FTKX_VEC_DROP")) dbg = atoi(e);      // (measurement only: 1 = summary stores dropped in the address unit, 2 = mask words)
+      if (m.nd == 2) hipLaunchKernelGGL(mask_vec2_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs, dbg);
+      else hipLaunchKernelGGL(mask_vec2_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs, dbg);
+      return;
+    }
     g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_vec_kernel<2>" : "ftkx::mask_vec_kernel<3>";
     if (m.nd == 2) hipLaunchKernelGGL(mask_vec_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs);
     else hipLaunchKernelGGL(mask_vec_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs);
@@ -2386,9 +2619,10 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
 // else writes one byte per word of 8.  The same decision as launch_masks_impl's choice of kernel (same environment knobs).
 int mask_summary_rows(const Mesh &m)
 {
-  if (m.nd != 3 || !m.scalar_mode || !masks_have_summary(m)) return 1;
+  if (!masks_have_summary(m)) return 1;
   if (const char *e = getenv("FTKX_U_ROWS")) if (atoi(e) == 1) return 1;
-  return 4;
+  if (!m.scalar_mode) return vec_lean(m) ? 4 : 1;              // mask_vec2_kernel / mask_vec_kernel
+  return 4;                                                    // mask_march6_kernel (3D), mask_march4_kernel<2, ...> (2D): a wavefront's rows in blocks of four
 }
 
 // does launch_masks produce the per-word summaries for this mesh?  (the 128-column marching kernels and the fast vector kernel do)

@@ -169,7 +169,8 @@ enum { SERIES_AMBIGUOUS = 1,        // 1 / resolution so close above a power of 
        SERIES_OVERFLOW = 8,         // a list / pass / fragile buffer was too small
        SERIES_FIX_ORDER = 16,       // a bucket of the ordering step was too full to rank on the device: its records are unordered among themselves
        SERIES_EARLY = 32,           // (informational) the fused tail kernel finished the pass
-       SERIES_UNORDERED = 64,       // the fused tail found more records than its last workgroup ranks: they come unordered, the host sorts them
+       SERIES_LATE_DECLINE = 64,    // the fused tail found more records than its last workgroup orders, took back what it had counted and left the pass to
+                                    // the bucket chain (informational: the records are complete and ordered; rounds 3-4a sent them unordered for the host to sort)
        SERIES_TAIL_PENDING = 128,   // the pass was queued in its short form (mask, cull, fused tail) and the fused tail declined: the host queues the rest
        SERIES_HALO_FULL = 256 };    // slab pass (ftkx_series_dist_*): the halo slice is needed as a whole (too many surviving cells for a request, a mask
                                     // message that did not fit, masks the host will rebuild): the request said -1, nothing was swept

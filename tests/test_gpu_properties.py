@@ -178,7 +178,7 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
             # The records never differ.  The cull statistics are those of the summary geometry: where a summary stands in for mask words
             # that were not written, it can only cull less than the real bytes -- the one-level cull (no summaries) leaves the fewest
             # cells, one byte per word of 8 more, one byte per 8 x 4 block (the default kernel with four rows per wavefront) the most
-            blocks = env.get("FTKX_U_ROWS") != "1" and len(dims) == 3
+            blocks = env.get("FTKX_U_ROWS") != "1"          # (both dimensions: one byte per 8 x 4 block by default)
             if env.get("FTKX_TWO_LEVEL") == "0":
                 assert key[2] == base[1][2] and key[0] <= base[1][0] and key[1] <= base[1][1], (env, key, base[1])
             elif blocks:
@@ -541,3 +541,126 @@ def test_announced_x_masked_halo_x_factor_change(gpu, kind, halo, announce):
     assert got.tobytes() == ref.tobytes(), (kind, halo, announce)
     for c in (whole, A, B):
         c.close()
+
+
+def _vector_field(rng, dims, kind):
+    """a vector field (components last) with what the vector mask kernels treat specially"""
+    nd = len(dims)
+    shape = tuple(reversed(dims)) + (nd,)
+    grids = np.meshgrid(*[np.linspace(-1.0, 1.0, n) for n in reversed(dims)], indexing="ij")
+    v = np.stack([np.sin(2.1 * grids[(c + 1) % nd] + 0.3 * c) + 0.5 * np.cos(1.7 * grids[c]) for c in range(nd)], axis=-1)
+    if kind == "rough":          # plateaus, zeros, values right at and just below the threshold 1 / 256, negative zero
+        v = np.round(v * 4.0) * 0.25
+        pick = rng.random(shape) < 0.08
+        v[pick] = rng.choice([0.0, -0.0, 1.0 / 256, -1.0 / 256, 1.0 / 512, -1.0 / 1024, 3e-7, np.nextafter(1.0 / 256, 0.0), -np.nextafter(1.0 / 256, 0.0)], size=int(pick.sum()))
+    elif kind == "odd":          # NaNs (quiet and signalling), infinities and values past `big`, alone and in clusters
+        flat = v.reshape(-1)
+        n = flat.size
+        for val in (np.nan, np.inf, -np.inf, 1e300, -3e299):
+            flat[rng.integers(0, n, size=5)] = val
+        snan = np.frombuffer(np.array([0x7ff0000000000001], dtype=np.uint64).tobytes(), dtype=np.float64)[0]
+        u = flat.view(np.uint64)
+        u[rng.integers(0, n, size=4)] = np.array([snan]).view(np.uint64)[0]
+        v[tuple(0 for _ in range(nd))] = np.nan                  # the slice's very first and very last vertex
+        v[tuple(s - 1 for s in shape[:-1])] = np.inf
+    return np.ascontiguousarray(v)
+
+
+@pytest.mark.parametrize("dims,core", [((2048, 14), None), ((264, 42), None), ((512, 33), ((5, 3), (500, 29))), ((256, 17, 7), None), ((328, 9, 6), ((2, 1, 1), (320, 7, 4)))])
+@pytest.mark.parametrize("kind", ["smooth", "rough", "odd"])
+def test_vector_mask_kernels_agree(gpu, dims, core, kind):
+    """mask_vec2_kernel (units of 4 rows x 64 groups, one summary byte per 8 x 4 block, wave-uniform addressing, one compare per component,
+    the vertices one by one only where a wavefront meets the domain's border / a non-finite or big value) against mask_vec_kernel
+    (FTKX_VEC_LEAN=0: one summary byte per word): the same mask words wherever both write them, block summaries = the AND of the word
+    summaries, the same fused reduction, the same records and number of simplices tested -- rows of 64 groups exactly, rows whose last
+    chunk is ragged, row counts that are no multiple of 4, a domain inside the array, fields with plateaus / zeros / values at the threshold
+    and fields with NaNs, infinities and values past `big`."""
+    import os
+    import torch
+    from ftk_amd import tslab
+    nd, nt = len(dims), 3
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    steps = [_vector_field(rng, dims, kind) for _ in range(nt)]
+    dom = core or ([1] * nd, [d - 2 for d in dims])
+    out = {}
+    for lean in ("0", "1"):
+        old = os.environ.get("FTKX_VEC_LEAN")
+        os.environ["FTKX_VEC_LEAN"] = lean
+        try:
+            ctx = gpu.Context(nd)
+            ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
+            ctx.set_options(jacobian_symmetric=0, derive_jacobian=1, tag_mode=gpu.TAG_EXACT64)
+            keep = [torch.from_numpy(s).to(dev) for s in steps]
+            for t in range(nt):
+                ctx.push_slice(t, keep[t])
+            rm = ctx.slices_prepare(range(nt), 0)
+            name = (ctx._L.ftkx_last_mask_kernel() or b"").decode()
+            # the sweep first: where a slice holds big values the masks of slices_prepare do not stand and the sweep builds them again, under
+            # its factor and with the per-vertex rule (job.big finite) -- those are then the masks exported below
+            res = [rm[t][0] for t in range(nt)]
+            factors = tslab.factors_from_resolutions(res)
+            for t in range(nt):
+                ctx.sweep_enqueue(t, gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL, factors[t])
+            recs = np.array(ctx.sweep_collect())
+            st = ctx.stats()
+            name2 = (ctx._L.ftkx_last_mask_kernel() or b"").decode()
+            nbytes, cap = ctx.packed_masks_bytes()
+            packed = []
+            for t in range(nt):
+                buf = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
+                try:
+                    ctx.export_masks_packed(t, buf)
+                except gpu.FtkxError as e:      # (no summarised masks for this slice: then for neither kernel)
+                    packed.append(e.code)
+                    continue
+                torch.cuda.synchronize()
+                h = buf.cpu().numpy()
+                head = h[:32].view(np.uint64)
+                count, ub = int(head[0]), int(head[1])
+                assert count <= cap, (count, cap)
+                off_idx = 32 + (ub + 7) // 8 * 8
+                off_words = off_idx + (cap * 4 + 7) // 8 * 8
+                idx = h[off_idx:off_idx + 4 * count].view(np.uint32)
+                words = h[off_words:off_words + 8 * count].view(np.uint64)
+                order = np.argsort(idx, kind="stable")
+                packed.append((int(head[2] >> 48) & 0xff, h[32:32 + ub].copy(), idx[order].copy(), words[order].copy()))
+            assert name2 == name, (name, name2)
+            ctx.close()
+        finally:
+            if old is None:
+                os.environ.pop("FTKX_VEC_LEAN", None)
+            else:
+                os.environ["FTKX_VEC_LEAN"] = old
+        out[lean] = (name, {t: (np.float64(a).tobytes(), np.float64(b).tobytes()) for t, (a, b) in rm.items()}, packed, recs, st)
+    assert "mask_vec_kernel" in out["0"][0] and "mask_vec2_kernel" in out["1"][0], (out["0"][0], out["1"][0])
+    assert out["0"][1] == out["1"][1], "fused reduction"
+    # the masks: mask_vec_kernel writes one summary byte per word of 8 vertices (the AND of its mask bytes) and the words whose summary is 0;
+    # mask_vec2_kernel one byte per 8 x 4 block and ALL words of the blocks whose summary is 0
+    DW, DH, DD = dims[0], dims[1], (dims[2] if nd == 3 else 1)
+    PW, UP, ncols, nby = ((DW + 7) // 8 * 8 + 8) // 8, ((DW + 7) // 8 + 7) // 8 * 8 + 8, DW // 8, (DH + 3) // 4
+    for t in range(nt):
+        a, b = out["0"][2][t], out["1"][2][t]
+        if isinstance(a, int) or isinstance(b, int):
+            assert a == b, (t, a, b)
+            continue
+        assert (a[0], b[0]) == (1, 4), (a[0], b[0])
+        Ua, Ub = a[1].reshape(DD, DH, UP)[:, :, :ncols], b[1].reshape(DD, nby, UP)[:, :, :ncols]
+        pad = np.full((DD, nby * 4, ncols), 0x3f, dtype=np.uint8)
+        pad[:, :DH] = Ua
+        assert np.array_equal(np.bitwise_and.reduce(pad.reshape(DD, nby, 4, ncols), axis=2), Ub), (t, "block summaries")
+        wa, wb = dict(zip(a[2].tolist(), a[3].tolist())), dict(zip(b[2].tolist(), b[3].tolist()))
+        assert len(wa) == len(a[2]) and len(wb) == len(b[2])
+        for w, val in wa.items():
+            assert wb.get(w) == val, (t, "a word both kernels write", w, val, wb.get(w))
+        flatUa = Ua.reshape(DD * DH, ncols)
+        for w, val in wb.items():
+            row, g = divmod(w, PW)
+            bytes8 = np.frombuffer(np.uint64(val).tobytes(), dtype=np.uint8)
+            assert g < ncols and int(np.bitwise_and.reduce(bytes8)) == int(flatUa[row, g]), (t, "a word only the block kernel writes", w)
+            assert Ub.reshape(DD * nby, ncols)[(row // DH) * nby + (row % DH) // 4, g] == 0
+    assert out["0"][3].tobytes() == out["1"][3].tobytes()
+    assert out["0"][4]["simplices_tested"] == out["1"][4]["simplices_tested"]
+    # (cells_survived counts coarse cells of the cull -- words of 8 vertices there, blocks of 8 x 4 here: not comparable)
+    if kind == "smooth":
+        assert len(out["1"][3]) > 0 and not any(isinstance(x, int) for x in out["1"][2])

@@ -166,6 +166,81 @@ template <class F> float time_it(F f, int reps = 5)
   return ms / reps;
 }
 
+// the vector mask kernel's walk without its arithmetic: a wavefront reads runs of 4 KB (64 groups of 4 vertices x 16 bytes), grid-stride
+// over one slice per blockIdx.y, the next run's loads in flight while the current one is consumed.
+// PAT 0: lane l reads its group's 64 contiguous bytes (4 loads 16 B apart: every wave instruction touches all 32 lines of the run);
+// PAT 1: load q of lane l reads bytes q * 1024 + l * 16 (every wave instruction reads 1 KB contiguous: 8 whole lines)
+// ST 1: the even lanes store one summary byte per run and lane (32 contiguous bytes per wave instruction); ST 2: every lane its mask word too;
+// ST 3: the summary bytes gathered into one 8-byte store per 8 lanes' worth (4 lanes store a dword each... no: lanes 0..3 store 8 bytes each)
+template <int PAT, int ST = 0>
+__global__ __launch_bounds__(256) void vec_read(const char *__restrict__ p, unsigned groups_per_slice, double *out, unsigned char *U = nullptr, unsigned *M = nullptr)
+{
+  const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const char *base = p + (size_t)blockIdx.y * groups_per_slice * 64u;
+  const unsigned step = gridDim.x * 256u;
+  const unsigned lo = PAT == 0 ? lane * 64u : lane * 16u, qs = PAT == 0 ? 16u : 1024u;
+  double acc = 0.0;
+  double2 cur[4], nxt[4];
+  unsigned gw = (blockIdx.x * 4u + wv) * 64u;
+  if (gw < groups_per_slice) for (int q = 0; q < 4; q ++) cur[q] = *(const double2 *)(base + (size_t)gw * 64u + lo + q * qs);
+  unsigned char held = 0; size_t held_at = ~(size_t)0;      // ST 5: the summary byte of the previous run, stored right behind the next run's loads
+  for (; gw < groups_per_slice; gw += step) {
+    const unsigned gn = gw + step < groups_per_slice ? gw + step : gw;
+#pragma unroll
+    for (int q = 0; q < 4; q ++) nxt[q] = *(const double2 *)(base + (size_t)gn * 64u + lo + q * qs);
+    if (ST == 5 && held_at != ~(size_t)0 && (lane & 1) == 0) U[held_at] = held;
+#pragma unroll
+    for (int q = 0; q < 4; q ++) { acc += cur[q].x + cur[q].y; cur[q] = nxt[q]; }
+    if (ST == 1 || ST == 2) { if ((lane & 1) == 0) U[(size_t)blockIdx.y * (groups_per_slice / 2) + (gw + lane) / 2] = (unsigned char)(acc != 0.0); }
+    if (ST == 2) M[(size_t)blockIdx.y * groups_per_slice + gw + lane] = (unsigned)(acc != 0.0);
+    if (ST == 6) { if ((lane & 1) == 0) __builtin_nontemporal_store((unsigned char)(acc != 0.0), &U[(size_t)blockIdx.y * (groups_per_slice / 2) + (gw + lane) / 2]); }
+    if (ST == 7) {      // the workgroup's four runs are side by side: their 4 x 32 summary bytes through LDS, ONE 128-byte store (wave 0, 32 lanes x 4 bytes)
+      __shared__ unsigned char s_u[128];
+      if ((lane & 1) == 0) s_u[wv * 32u + lane / 2] = (unsigned char)(acc != 0.0);
+      __syncthreads();
+      const unsigned g_wg = gw - wv * 64u;      // the workgroup's first group of this round
+      if (wv == 0 && lane < 32) ((unsigned *)(U + (size_t)blockIdx.y * (groups_per_slice / 2) + g_wg / 2))[lane] = ((const unsigned *)s_u)[lane];
+      __syncthreads();
+    }
+    if (ST == 5) { held = (unsigned char)(acc != 0.0); held_at = (size_t)blockIdx.y * (groups_per_slice / 2) + (gw + lane) / 2; }
+    if (ST == 3) {      // the run's 32 summary bytes as four 8-byte stores (lanes 0 .. 3)
+      const unsigned long long b = __builtin_amdgcn_ballot_w64(acc != 0.0);
+      if (lane < 4) ((unsigned long long *)U)[((size_t)blockIdx.y * (groups_per_slice / 2) + gw / 2) / 8 + lane] = b >> lane;
+    }
+  }
+  if (ST == 5 && held_at != ~(size_t)0 && (lane & 1) == 0) U[held_at] = held;
+  if (acc == 1.2345e300) out[0] = acc;
+}
+
+// the same walk with CONSECUTIVE runs per wavefront: NC runs of 4 KB side by side (the 32 summary bytes of each land in the same 128-byte
+// line, written from one CU), then on by gridDim.x * 4 * NC runs
+template <int NC, int ST>
+__global__ __launch_bounds__(256) void vec_read_consec(const char *__restrict__ p, unsigned groups_per_slice, double *out, unsigned char *U)
+{
+  const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const char *base = p + (size_t)blockIdx.y * groups_per_slice * 64u;
+  const unsigned step = gridDim.x * 256u * NC;
+  const unsigned lo = lane * 64u;
+  double acc = 0.0;
+  double2 cur[4], nxt[4];
+  unsigned g0 = (blockIdx.x * 4u + wv) * 64u * NC;
+  unsigned i = 0;
+  if (g0 < groups_per_slice) for (int q = 0; q < 4; q ++) cur[q] = *(const double2 *)(base + (size_t)g0 * 64u + lo + q * 16u);
+  while (g0 < groups_per_slice) {
+    const unsigned gw = g0 + i * 64u;
+    unsigned ni = i + 1, ng0 = g0;
+    if (ni == NC) { ni = 0; ng0 = g0 + step; }
+    const unsigned gn = ng0 < groups_per_slice ? ng0 + ni * 64u : gw;
+#pragma unroll
+    for (int q = 0; q < 4; q ++) nxt[q] = *(const double2 *)(base + (size_t)gn * 64u + lo + q * 16u);
+#pragma unroll
+    for (int q = 0; q < 4; q ++) { acc += cur[q].x + cur[q].y; cur[q] = nxt[q]; }
+    if (ST == 1) { if ((lane & 1) == 0) U[(size_t)blockIdx.y * (groups_per_slice / 2) + (gw + lane) / 2] = (unsigned char)(acc != 0.0); }
+    i = ni; g0 = ng0;
+  }
+  if (acc == 1.2345e300) out[0] = acc;
+}
+
 int main(int argc, char **argv)
 {
   const bool only_march = argc > 1;
@@ -176,6 +251,38 @@ int main(int argc, char **argv)
   CK(hipMemset(p, 0, bytes));
   printf("%-44s %8s %8s\n", "variant", "ms", "TB/s");
   auto rep = [&](const char *name, float ms, double b) { printf("%-44s %8.3f %8.2f\n", name, ms, b / ms / 1e9); fflush(stdout); };
+  if (argc > 1 && argv[1][0] == 'v') {      // double_gyre 2048 x 1024 x 128: 128 slices of 32 MiB
+    const unsigned gps = 2048u * 1024u / 4u;
+    for (int bx : {256, 512, 1024}) for (int rep_ = 0; rep_ < 2; rep_ ++) {
+      char nm[96];
+      snprintf(nm, 96, "vec PAT=0 (64 B per lane) grid=%dx128", bx);
+      rep(nm, time_it([&] { hipLaunchKernelGGL((vec_read<0>), dim3(bx, 128), dim3(256), 0, 0, (const char *)p, gps, out); }), 128.0 * gps * 64.0);
+      snprintf(nm, 96, "vec PAT=1 (1 KB per instruction) grid=%dx128", bx);
+      rep(nm, time_it([&] { hipLaunchKernelGGL((vec_read<1>), dim3(bx, 128), dim3(256), 0, 0, (const char *)p, gps, out); }), 128.0 * gps * 64.0);
+      unsigned char *Uv = (unsigned char *)p + (5ull << 30); unsigned *Mv = (unsigned *)((char *)p + (6ull << 30));      // (beyond the 4 GiB that are read)
+      snprintf(nm, 96, "vec PAT=0 + summary byte stores grid=%dx128", bx);
+      rep(nm, time_it([&] { hipLaunchKernelGGL((vec_read<0, 1>), dim3(bx, 128), dim3(256), 0, 0, (const char *)p, gps, out, Uv, Mv); }), 128.0 * gps * 64.0);
+      snprintf(nm, 96, "vec PAT=0 + summary bytes + mask words grid=%dx128", bx);
+      rep(nm, time_it([&] { hipLaunchKernelGGL((vec_read<0, 2>), dim3(bx, 128), dim3(256), 0, 0, (const char *)p, gps, out, Uv, Mv); }), 128.0 * gps * 64.0);
+      snprintf(nm, 96, "vec PAT=0 + summary bytes one run late grid=%dx128", bx);
+      rep(nm, time_it([&] { hipLaunchKernelGGL((vec_read<0, 5>), dim3(bx, 128), dim3(256), 0, 0, (const char *)p, gps, out, Uv, Mv); }), 128.0 * gps * 64.0);
+      snprintf(nm, 96, "vec PAT=0 + summary bytes nontemporal grid=%dx128", bx);
+      rep(nm, time_it([&] { hipLaunchKernelGGL((vec_read<0, 6>), dim3(bx, 128), dim3(256), 0, 0, (const char *)p, gps, out, Uv, Mv); }), 128.0 * gps * 64.0);
+      snprintf(nm, 96, "vec PAT=0 + summaries 128 B per workgroup grid=%dx128", bx);
+      rep(nm, time_it([&] { hipLaunchKernelGGL((vec_read<0, 7>), dim3(bx, 128), dim3(256), 0, 0, (const char *)p, gps, out, Uv, Mv); }), 128.0 * gps * 64.0);
+      snprintf(nm, 96, "vec 4 consecutive runs, no stores grid=%dx128", bx / 4);
+      rep(nm, time_it([&] { hipLaunchKernelGGL((vec_read_consec<4, 0>), dim3(bx / 4, 128), dim3(256), 0, 0, (const char *)p, gps, out, Uv); }), 128.0 * gps * 64.0);
+      snprintf(nm, 96, "vec 4 consecutive runs + summary bytes grid=%dx128", bx / 4);
+      rep(nm, time_it([&] { hipLaunchKernelGGL((vec_read_consec<4, 1>), dim3(bx / 4, 128), dim3(256), 0, 0, (const char *)p, gps, out, Uv); }), 128.0 * gps * 64.0);
+      snprintf(nm, 96, "vec 4 consecutive runs + summary bytes grid=%dx128", bx);
+      rep(nm, time_it([&] { hipLaunchKernelGGL((vec_read_consec<4, 1>), dim3(bx, 128), dim3(256), 0, 0, (const char *)p, gps, out, Uv); }), 128.0 * gps * 64.0);
+      snprintf(nm, 96, "vec 8 consecutive runs + summary bytes grid=%dx128", bx / 4);
+      rep(nm, time_it([&] { hipLaunchKernelGGL((vec_read_consec<8, 1>), dim3(bx / 4, 128), dim3(256), 0, 0, (const char *)p, gps, out, Uv); }), 128.0 * gps * 64.0);
+      snprintf(nm, 96, "vec PAT=0 + summaries as 4 x 8 B grid=%dx128", bx);
+      rep(nm, time_it([&] { hipLaunchKernelGGL((vec_read<0, 3>), dim3(bx, 128), dim3(256), 0, 0, (const char *)p, gps, out, Uv, Mv); }), 128.0 * gps * 64.0);
+    }
+    return 0;
+  }
 #define SEG(U, NT, BD, GRID) { const size_t nseg = bytes / ((size_t)BD * U * 16); char nm[96]; snprintf(nm, 96, "seg U=%d nt=%d block=%d grid=%d", U, NT, BD, GRID); \
     rep(nm, time_it([&] { hipLaunchKernelGGL((seg_read<U, NT>), dim3(GRID), dim3(BD), 0, 0, p, nseg, out); }), (double)bytes); }
   if (!only_march) {
