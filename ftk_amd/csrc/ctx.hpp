@@ -51,7 +51,7 @@ const char *last_mask_kernel();
 void launch_cull_coarse(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, hipStream_t stream, const FactorJob *job = nullptr);
 void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream);
 void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st,
-                         const void *desc_src = nullptr, void *desc_dst = nullptr, size_t desc_bytes = 0);   // (+ the pass's descriptors, pinned -> device)
+                         const void *desc_src = nullptr, void *desc_dst = nullptr, size_t desc_bytes = 0, unsigned *fetched = nullptr, unsigned fetched_val = 0);
 void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,
                            double safe_m, u64 *results, u64 *counters, hipStream_t st);
 void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff, u64 *sorted, u64 *results, hipStream_t st);
@@ -61,7 +61,8 @@ void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sor
 Mesh coarse_view(const Mesh &m);
 void launch_series_small(const Mesh &m, const Mesh &mc, const Fields *d_steps, bool two_level, const u64 *d_refine, const u64 *d_list, ftkx_cp_t *out,
                          u64 *results, size_t nwords, u64 *h_results, unsigned *flag, unsigned seq, unsigned *done, bool report_decline, hipStream_t st);
-void launch_series_copy_out(const ftkx_cp_t *src, ftkx_cp_t *dst, u64 capacity, const u64 *results, unsigned *done, unsigned *flag, unsigned seq, hipStream_t st);
+void launch_series_copy_out(const ftkx_cp_t *src, ftkx_cp_t *dst, u64 capacity, const u64 *results, unsigned *done, unsigned *flag, unsigned seq, hipStream_t st,
+                            const unsigned *wait_flag = nullptr, unsigned wait_val = 0);
 void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, const u64 *base_from,
                           hipStream_t st);
 // dist_kernels.hip: the slab pass
@@ -174,7 +175,7 @@ struct ftkx_series_buffers {
   ftkx_cp_t *out = nullptr; size_t out_cap = 0;       // pinned: the records as the caller reads them
   ftkx_cp_t *d_out = nullptr; size_t d_out_cap = 0;   // device: the records of a pass whose way over PCIe is left to the copy kernel on its own stream
   unsigned *copy_done = nullptr;                       // that kernel's workgroup counter
-  hipEvent_t ev_finished = nullptr, ev_copied = nullptr, ev_fetched = nullptr, ev_export = nullptr;
+  hipEvent_t ev_finished = nullptr, ev_copied = nullptr, ev_export = nullptr;
   bool copy_out = false;                               // a copy has been queued since the buffers were last used: the next record kernel waits for it
   void *h_desc = nullptr, *d_desc = nullptr; size_t desc_cap = 0;
   u64 *dist_block = nullptr;                           // slab pass: DB_N words (sweep_params.hpp)
@@ -255,6 +256,8 @@ struct ftkx_ctx {
   // its chain only while they are still its own)
   unsigned long long sr_pass_uid = 0, sr_lists_owner = 0;
   hipStream_t sr_copy_stream = nullptr, sr_fetch_stream = nullptr;
+  unsigned *sr_fetch_flag = nullptr;   // device: [0] the number of the last pass whose descriptors have been fetched (series_begin_kernel), [1] its arrival counter
+  unsigned sr_fetch_seq = 0;
   unsigned long long mask_epoch = 0;  // source of Slice::mask_gen values
   double sr_last_running = 0;         // the running minimum the host knew when it last collected a pass (hint of a chained pass)
   unsigned *sr_hist = nullptr, *sr_boff = nullptr;

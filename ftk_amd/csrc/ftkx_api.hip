@@ -384,11 +384,11 @@ void ftkx_destroy(ftkx_ctx *c)
     for (void *p : {(void *)B.results, (void *)B.d_out, B.d_desc, (void *)B.copy_done, (void *)B.dist_block}) if (p) (void)hipFree(p);
     if (B.ev_finished) (void)hipEventDestroy(B.ev_finished);
     if (B.ev_copied) (void)hipEventDestroy(B.ev_copied);
-    if (B.ev_fetched) (void)hipEventDestroy(B.ev_fetched);
     if (B.ev_export) (void)hipEventDestroy(B.ev_export);
     for (void *p : {(void *)B.h_results, (void *)B.out, B.h_desc}) if (p) (void)hipHostFree(p);
   }
   if (c->sr_copy_stream) (void)hipStreamDestroy(c->sr_copy_stream);
+  if (c->sr_fetch_flag) (void)hipFree(c->sr_fetch_flag);
   if (c->sr_fetch_stream) (void)hipStreamDestroy(c->sr_fetch_stream);
   for (void *p : {c->tr_dev, c->tr_parent, c->tr_tables}) if (p) (void)hipFree(p);
   if (c->tr_host) (void)hipHostFree(c->tr_host);

@@ -436,7 +436,7 @@ int ensure_series_buffers(ftkx_ctx *c, ftkx_series_buffers &B, size_t nwords, si
   return FTKX_OK;
 }
 
-void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, hipEvent_t also_after);
+void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, const unsigned *wait_flag, unsigned wait_val);
 
 // the kernels behind the fused tail: refine, exact test, ordering, records, finish
 void series_queue_rest(ftkx_ctx *c, const ftkx_series_pending &P, const Mesh &m, unsigned seq)
@@ -458,13 +458,12 @@ void series_queue_rest(ftkx_ctx *c, const ftkx_series_pending &P, const Mesh &m,
 
 // the records' way over PCIe: a small kernel on its own stream, behind the finish kernel (the count is final) and next to whatever the
 // context's stream does then -- the mask kernel of the pass queued behind this one
-void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, hipEvent_t also_after)
+void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, const unsigned *wait_flag, unsigned wait_val)
 {
   ftkx_series_buffers &B = c->sr_buf[P.buf];
   unsigned *flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
   (void)hipStreamWaitEvent(c->sr_copy_stream, B.ev_finished, 0);
-  if (also_after) (void)hipStreamWaitEvent(c->sr_copy_stream, also_after, 0);
-  ftkx::launch_series_copy_out(B.d_out, B.out, (u64)B.d_out_cap, B.results, B.copy_done, flag + 2, P.seq, c->sr_copy_stream);
+  ftkx::launch_series_copy_out(B.d_out, B.out, (u64)B.d_out_cap, B.results, B.copy_done, flag + 2, P.seq, c->sr_copy_stream, wait_flag, wait_val);
   (void)hipEventRecord(B.ev_copied, c->sr_copy_stream);
   B.copy_out = true;
   P.copy_pending = false;
@@ -637,16 +636,13 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
     }
     P.gen[j] = sl[j]->mask_gen;
   }
-  ftkx::launch_series_begin(c->d_counters, c->d_red, ntodo * 64, c->sr_hist, nbins + 1, B.results, nwords, c->stream, B.h_desc, B.d_desc, total);
-  if (before && before->open && before->copy_pending) {
-    // The pass queued before this one left its records in device memory.  Their way over PCIe starts HERE, behind this pass's descriptor
-    // fetch: that fetch is a read of the device over PCIe, and a read does not overtake the writes queued in front of it -- started
-    // together with the copy, 4 us became 65, with the mask kernel waiting behind.
-    ftkx_series_buffers &Bp = c->sr_buf[before->buf];
-    if (!Bp.ev_fetched) HIP_TRY(c, hipEventCreateWithFlags(&Bp.ev_fetched, hipEventDisableTiming));
-    HIP_TRY(c, hipEventRecord(Bp.ev_fetched, c->stream));
-    series_queue_copy(c, *before, Bp.ev_fetched);
-  }
+  // (the pass queued before this one left its records in device memory: their way over PCIe starts behind this pass's descriptor fetch,
+  // which the begin kernel announces in a word of device memory -- series_copy_out_kernel)
+  const bool copy_behind = before && before->open && before->copy_pending;
+  if (copy_behind && !c->sr_fetch_flag) { HIP_TRY(c, hipMalloc((void **)&c->sr_fetch_flag, 2 * sizeof(unsigned))); HIP_TRY(c, hipMemset(c->sr_fetch_flag, 0, 2 * sizeof(unsigned))); }   // (once per context; synchronous: the copy stream reads it)
+  const unsigned fetch_val = copy_behind ? ++ c->sr_fetch_seq : 0u;
+  ftkx::launch_series_begin(c->d_counters, c->d_red, ntodo * 64, c->sr_hist, nbins + 1, B.results, nwords, c->stream, B.h_desc, B.d_desc, total, copy_behind ? c->sr_fetch_flag : nullptr, fetch_val);
+  if (copy_behind) series_queue_copy(c, *before, c->sr_fetch_flag, fetch_val);
   if (dist && dist->masks_out) {
     // A slab pass with a lower neighbour: the FIRST slice's masks are that neighbour's halo.  They are built first, by a launch of their
     // own, and packed into the message right behind it -- the message can then cross xGMI (on the caller's side stream, which is made to
@@ -865,7 +861,7 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
   const size_t nrec = (size_t)R[ftkx::SR_NHITS];
   ftkx_cp_t *H = B.out;
   if (P.to_device) {                                         // (the copy kernel; the mask kernel of the pass queued behind this one is running meanwhile)
-    if (P.copy_pending) series_queue_copy(c, P, nullptr);    // (no pass was queued behind this one)
+    if (P.copy_pending) series_queue_copy(c, P, nullptr, 0);    // (no pass was queued behind this one)
     if (const char *why = ftkx::wait_flag(flag + 2, P.seq, c->sr_copy_stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
   }
   memset(&c->stats, 0, sizeof(c->stats));

@@ -15,7 +15,8 @@ namespace ftkx {
 
 // ---- begin: every counter, reduction slot and histogram bin of the pass in one launch ------------------------------------------------
 __global__ __launch_bounds__(256) void series_begin_kernel(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults,
-                                                           const u64 *__restrict__ desc_src /* pinned; nullable */, u64 *__restrict__ desc_dst, size_t desc_words)
+                                                           const u64 *__restrict__ desc_src /* pinned; nullable */, u64 *__restrict__ desc_dst, size_t desc_words,
+                                                           unsigned *fetched /* nullable */, unsigned fetched_val)
 {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   // (the pass's descriptors, pinned host -> device: the first workgroups, so that the read over PCIe is under way at once)
@@ -24,6 +25,16 @@ __global__ __launch_bounds__(256) void series_begin_kernel(u64 *counters, u64 *r
   if (i < nslots) { red[2 * i] = 0x7fefffffffffffffull; red[2 * i + 1] = 0ull; }   // {min = DBL_MAX, max = 0} as bit patterns
   if (i < nbins) hist[i] = 0u;
   if (i < nresults) results[i] = 0ull;
+  // The descriptors have arrived (every lane's load had returned before its store was issued): said to series_copy_out_kernel of the
+  // pass before, which starts its writes over PCIe only now -- a read over PCIe queued behind them took 65 us instead of 4.  A word in
+  // device memory, not an event: an event recorded here held the mask kernel back by 5 us.
+  if (fetched) {
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&fetched[1], 1u) + 1u == gridDim.x) {
+      fetched[1] = 0u;
+      __hip_atomic_store(&fetched[0], fetched_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ---- the sticky factor: series_device.hpp ---------------------------------------------------------------------------------------------
@@ -696,8 +707,16 @@ __global__ __launch_bounds__(256) void series_finish_kernel(const u64 *__restric
 // mask kernel's slots: 109 -> 183 us).  How many there are is on the device (results[SR_NHITS], final: this runs behind the finish
 // kernel); the last workgroup stores the sequence number the host waits for.
 __global__ __launch_bounds__(256) void series_copy_out_kernel(const ftkx_cp_t *__restrict__ src, ftkx_cp_t *__restrict__ dst /* pinned */, u64 capacity,
-                                                              const u64 *__restrict__ results, unsigned *__restrict__ done, unsigned *flag, unsigned seq)
+                                                              const u64 *__restrict__ results, unsigned *__restrict__ done, unsigned *flag, unsigned seq,
+                                                              const unsigned *wait_flag /* nullable */, unsigned wait_val)
 {
+  // (the pass queued behind this one fetches its descriptors over PCIe: not before that read is through -- series_begin_kernel.  A matter
+  // of speed, not of correctness: after about a millisecond the copy starts anyway)
+  if (wait_flag) {
+    if (threadIdx.x == 0)
+      for (int it = 0; it < 4096 && (int)(__hip_atomic_load(wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - wait_val) < 0; it ++) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+  }
   u64 n = results[SR_NHITS];
   if (n > capacity) n = capacity;
   const size_t nvec = (size_t)n * sizeof(ftkx_cp_t) / 8;     // (72 bytes a record: nine words)
@@ -724,21 +743,22 @@ __global__ __launch_bounds__(256) void series_copy_out_kernel(const ftkx_cp_t *_
   }
 }
 
-void launch_series_copy_out(const ftkx_cp_t *src, ftkx_cp_t *dst, u64 capacity, const u64 *results, unsigned *done, unsigned *flag, unsigned seq, hipStream_t st)
+void launch_series_copy_out(const ftkx_cp_t *src, ftkx_cp_t *dst, u64 capacity, const u64 *results, unsigned *done, unsigned *flag, unsigned seq, hipStream_t st,
+                            const unsigned *wait_flag, unsigned wait_val)
 {
   static const int wgs = [] { const char *e = getenv("FTKX_COPY_WGS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 1024 ? v : 16; }();
-  hipLaunchKernelGGL(series_copy_out_kernel, dim3((unsigned)wgs), dim3(256), 0, st, src, dst, capacity, results, done, flag, seq);
+  hipLaunchKernelGGL(series_copy_out_kernel, dim3((unsigned)wgs), dim3(256), 0, st, src, dst, capacity, results, done, flag, seq, wait_flag, wait_val);
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------------------------------
 void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st,
-                         const void *desc_src, void *desc_dst, size_t desc_bytes)
+                         const void *desc_src, void *desc_dst, size_t desc_bytes, unsigned *fetched, unsigned fetched_val)
 {
   size_t n = (size_t)CNT_N;
   n = n > nslots ? n : nslots; n = n > nbins ? n : nbins; n = n > nresults ? n : nresults;
   if (desc_src && n < 1024) n = 1024;
   hipLaunchKernelGGL(series_begin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, counters, red, nslots, hist, nbins, results, nresults,
-                     (const u64 *)desc_src, (u64 *)desc_dst, desc_src ? desc_bytes / 8 : (size_t)0);
+                     (const u64 *)desc_src, (u64 *)desc_dst, desc_src ? desc_bytes / 8 : (size_t)0, fetched, fetched_val);
 }
 
 void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,
