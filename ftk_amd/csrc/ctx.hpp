@@ -175,7 +175,7 @@ struct ftkx_series_buffers {
   ftkx_cp_t *out = nullptr; size_t out_cap = 0;       // pinned: the records as the caller reads them
   ftkx_cp_t *d_out = nullptr; size_t d_out_cap = 0;   // device: the records of a pass whose way over PCIe is left to the copy kernel on its own stream
   unsigned *copy_done = nullptr;                       // that kernel's workgroup counter
-  hipEvent_t ev_finished = nullptr, ev_copied = nullptr, ev_export = nullptr;
+  hipEvent_t ev_copied = nullptr, ev_export = nullptr;
   bool copy_out = false;                               // a copy has been queued since the buffers were last used: the next record kernel waits for it
   void *h_desc = nullptr, *d_desc = nullptr; size_t desc_cap = 0;
   u64 *dist_block = nullptr;                           // slab pass: DB_N words (sweep_params.hpp)

@@ -382,7 +382,6 @@ void ftkx_destroy(ftkx_ctx *c)
   for (void *p : {(void *)c->sr_hist, (void *)c->sr_boff, (void *)c->sr_bucketed, (void *)c->sr_sorted}) if (p) (void)hipFree(p);
   for (ftkx_series_buffers &B : c->sr_buf) {
     for (void *p : {(void *)B.results, (void *)B.d_out, B.d_desc, (void *)B.copy_done, (void *)B.dist_block}) if (p) (void)hipFree(p);
-    if (B.ev_finished) (void)hipEventDestroy(B.ev_finished);
     if (B.ev_copied) (void)hipEventDestroy(B.ev_copied);
     if (B.ev_export) (void)hipEventDestroy(B.ev_export);
     for (void *p : {(void *)B.h_results, (void *)B.out, B.h_desc}) if (p) (void)hipHostFree(p);

@@ -422,7 +422,6 @@ int ensure_series_buffers(ftkx_ctx *c, ftkx_series_buffers &B, size_t nwords, si
   if (to_device && !B.copy_done) {
     HIP_TRY(c, hipMalloc((void **)&B.copy_done, sizeof(unsigned)));
     HIP_TRY(c, hipMemsetAsync(B.copy_done, 0, sizeof(unsigned), c->stream));
-    HIP_TRY(c, hipEventCreateWithFlags(&B.ev_finished, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&B.ev_copied, hipEventDisableTiming));
   }
   if (B.desc_cap < desc_bytes) {
@@ -453,7 +452,6 @@ void series_queue_rest(ftkx_ctx *c, const ftkx_series_pending &P, const Mesh &m,
   ftkx::launch_series_records(m, d_steps, c->sr_sorted, P.to_device ? B.d_out : B.out, nullptr, c->stream);
   ev_end(c);
   ftkx::launch_series_finish(m, B.results, P.nwords, c->list_capacity, c->refine_capacity, B.h_results, flag, seq, nullptr, c->stream);
-  if (P.to_device) (void)hipEventRecord(B.ev_finished, c->stream);      // (series_queue_copy waits for it)
 }
 
 // the records' way over PCIe: a small kernel on its own stream, behind the finish kernel (the count is final) and next to whatever the
@@ -462,7 +460,9 @@ void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, const unsigned *wait
 {
   ftkx_series_buffers &B = c->sr_buf[P.buf];
   unsigned *flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
-  (void)hipStreamWaitEvent(c->sr_copy_stream, B.ev_finished, 0);
+  // (no event between the pass and its copy: with a pass queued behind, the word its begin kernel stores says that THIS pass's finish kernel
+  // is through as well -- same stream, in order; without one, ftkx_sweep_series_complete has already waited for the finish kernel's flag.
+  // An event recorded behind the finish kernel stood between it and the next pass's begin kernel: ~5 us per pipelined pass)
   ftkx::launch_series_copy_out(B.d_out, B.out, (u64)B.d_out_cap, B.results, B.copy_done, flag + 2, P.seq, c->sr_copy_stream, wait_flag, wait_val);
   (void)hipEventRecord(B.ev_copied, c->sr_copy_stream);
   B.copy_out = true;

@@ -710,11 +710,14 @@ __global__ __launch_bounds__(256) void series_copy_out_kernel(const ftkx_cp_t *_
                                                               const u64 *__restrict__ results, unsigned *__restrict__ done, unsigned *flag, unsigned seq,
                                                               const unsigned *wait_flag /* nullable */, unsigned wait_val)
 {
-  // (the pass queued behind this one fetches its descriptors over PCIe: not before that read is through -- series_begin_kernel.  A matter
-  // of speed, not of correctness: after about a millisecond the copy starts anyway)
+  // With a pass queued behind the one whose records these are: not before that pass's begin kernel has stored its number (wait_val) --
+  // the records' pass is then through (same stream, in order: no event needed, and none is recorded) and the next pass's descriptors have
+  // been fetched over PCIe (a read queued behind this kernel's writes took 65 us instead of 4).  This kernel may well start while the
+  // records' pass is still running: sixteen workgroups whose first lanes sleep and poll.  (The bound -- seconds -- only keeps a begin kernel
+  // that never ran from hanging the device.)
   if (wait_flag) {
     if (threadIdx.x == 0)
-      for (int it = 0; it < 4096 && (int)(__hip_atomic_load(wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - wait_val) < 0; it ++) __builtin_amdgcn_s_sleep(8);
+      for (unsigned it = 0; it < (1u << 23) && (int)(__hip_atomic_load(wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - wait_val) < 0; it ++) __builtin_amdgcn_s_sleep(32);
     __syncthreads();
   }
   u64 n = results[SR_NHITS];
