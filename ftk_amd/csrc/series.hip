@@ -863,6 +863,7 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
   if (P.to_device) {                                         // (the copy kernel; the mask kernel of the pass queued behind this one is running meanwhile)
     if (P.copy_pending) series_queue_copy(c, P, nullptr, 0);    // (no pass was queued behind this one)
     if (const char *why = ftkx::wait_flag(flag + 2, P.seq, c->sr_copy_stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+    B.copy_out = false;                                      // (the copy is through: the pass that takes these buffers next need not wait for its event)
   }
   memset(&c->stats, 0, sizeof(c->stats));
   {
