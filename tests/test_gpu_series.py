@@ -530,3 +530,38 @@ def test_series_overflowing_buffers_replays_through_the_batch(gpu):
     assert _same(r1, r2) and np.array_equal(f1, f2)
     assert np.all(r2["tag"][1:] > r2["tag"][:-1])
     ctx.close()
+
+
+def test_a_short_chain_pass_that_declines_late(gpu):
+    """The fused tail with nothing queued behind it (the pass before was finished by it: short chain) meets few coarse cells with more
+    records in them than it orders: it takes back what it counted, says so (SERIES_LATE_DECLINE) and hands the pass to the host, which
+    queues the chain -- the records are those of the host-driven batch, and the passes after it go out as whole chains again."""
+    from ftk_amd import tslab
+    g = load_golden("woven_128x128x10")
+    nt = g["DT"]
+    late = []
+    for nsub in (2, 3, 4, 5):
+        ctx = _ctx(gpu, g["dims"], g["nd"], g["nv"], tag_mode=gpu.TAG_EXACT64)
+        _push_all(ctx, g["steps"], g["nv"])
+        ts, scopes = list(range(nsub)), [gpu.SCOPE_BOTH] * nsub
+        # the records of these steps through the host-driven batch
+        rm = ctx.slices_prepare(range(nsub + 1), 0)
+        factors = tslab.factors_from_resolutions([rm[t][0] for t in range(nsub + 1)])[:nsub]
+        ctx.sweep_enqueue_many(ts, scopes, factors)
+        want = np.array(ctx.sweep_collect())
+        ctx.invalidate_masks()
+        # a sparse pass first: one ordinal sweep (a few hundred records), which the fused tail finishes
+        recs0, _, _ = ctx.sweep_series([0], [gpu.SCOPE_ORDINAL])
+        seen = [ctx.series_last_path()]
+        assert len(recs0) > 0 and seen[0][0] == 2, seen
+        for _ in range(3):
+            got, f, _ = ctx.sweep_series(ts, scopes)
+            seen.append(ctx.series_last_path())
+            assert _same(np.array(got), want), (nsub, seen)
+            assert [int(v) for v in f] == [int(v) for v in factors]
+        print(nsub, len(want), seen)
+        if any(st & 64 for _, st in seen[1:]):
+            late.append(nsub)
+            assert seen[-1][0] == 1 and not (seen[-1][1] & 64), seen      # after a late decline the fused tail is not tried again for a while
+        ctx.close()
+    assert late, "none of the sub-series made the fused tail decline late"
