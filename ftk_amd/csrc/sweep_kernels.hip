@@ -879,7 +879,7 @@ __device__ inline unsigned guard_and_reduce(unsigned a0, unsigned a1, double dx0
 // ---------------------------------------------------------------------------------------------------------------
 // mask_vec_kernel with ONE summary byte per 8 x 4 block of vertices (Mesh::u_rows == 4) and on a VALU diet (round 4).
 // Why blocks: every byte of summary a streaming kernel stores costs far more than its share of the traffic (on
-// double_gyre 2048 x 1024 x 128 the 32 summary bytes per 4 KB of input are 39 us of the kernel's 726 -- tools/probe/bw_probe.hip
+// double_gyre 2048 x 1024 x 128 the 32 summary bytes per 4 KB of input were 39 us of the kernel's 726, measured with the stores aimed out of range -- tools/probe/bw_probe.hip
 // `v` shows the same on a bare read walk); a quarter of the bytes is three quarters of that gone, and the coarse cull reads a
 // quarter too.  A wavefront therefore takes a unit of 4 rows x 64 groups (16 KB): the block's summary is an AND across its own
 // registers and one neighbouring lane.
@@ -939,7 +939,7 @@ __device__ inline unsigned word_summary4(unsigned word)
 }
 
 template <int ND>
-__global__ __launch_bounds__(kThreads) void mask_vec2_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int dbg)
+__global__ __launch_bounds__(kThreads) void mask_vec2_kernel(const Mesh m, const MaskJob *__restrict__ jobs)
 {
   constexpr int NV = 4 * ND, NL = 2 * ND;                      // values and 16-byte loads per lane and row
   constexpr unsigned GB = 32u * ND;                            // bytes of a group of 4 vertices
@@ -954,8 +954,8 @@ __global__ __launch_bounds__(kThreads) void mask_vec2_kernel(const Mesh m, const
   const double thr = job.threshold;
   const bool have_u = job.U != nullptr;
   const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void *)job.V, 0, (int)(ngroups * DH * DD * GB), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)job.M, 0, (dbg & 2) ? 0 : (int)(P * DH * DD), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)job.U, 0, (have_u && !(dbg & 1)) ? (int)(UP * nby * DD) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)job.M, 0, (int)(P * DH * DD), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)job.U, 0, have_u ? (int)(UP * nby * DD) : 0, 0x00020000);
 
   // unit u = (chunk ch of 64 groups, block jb of 4 rows, plane k), chunks fastest: found once by division, then advanced by additions
   unsigned u = blockIdx.x * (unsigned)(kThreads / 64) + wv;
@@ -2583,20 +2583,16 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
     // ... and at least four groups per lane where the slice has them: the per-wavefront fixed costs (index arithmetic, the two
     // reduction atomics) are paid per 16 KB instead of per 4 KB (double_gyre 2048 x 1024 x 128: 0.795 -> 0.746 ms)
     while (bx > 256 && bx * kThreads * 4 > groups) bx /= 2;
-    if (const char *e = getenv("FTKX_VEC_BX")) { const size_t v = (size_t)atoi(e); if (v >= 1 && v < bx) bx = v; }
     const dim3 grid((unsigned)bx, (unsigned)njobs);
     // mask_vec2_kernel (units of 4 rows x 64 groups, one summary byte per 8 x 4 block): where the mesh carries block summaries
     if (m.u_rows == 4 && vec_lean(m)) {
       const size_t units = (size_t)((m.ext_sz[0] / 4 + 63) / 64) * ((m.ext_sz[1] + 3) / 4) * DDv;
       size_t bx2 = (units + 7) / 8;             // two units (32 KB) per wavefront where the slice has them (four: +1.3 %, one: +0.3 % on double_gyre 2048 x 1024 x 128)
       if (bx2 > 2048) bx2 = 2048;
-      if (const char *e = getenv("FTKX_VEC_BX")) { const size_t v = (size_t)atoi(e); if (v >= 1) bx2 = v; }
       const dim3 grid((unsigned)bx2, (unsigned)njobs);
       g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_vec2_kernel<2>" : "ftkx::mask_vec2_kernel<3>";
-      int dbg = 0;
-      if (const char *e = getenv("FTKX_VEC_DROP")) dbg = atoi(e);      // (measurement only: 1 = summary stores dropped in the address unit, 2 = mask words)
-      if (m.nd == 2) hipLaunchKernelGGL(mask_vec2_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs, dbg);
-      else hipLaunchKernelGGL(mask_vec2_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs, dbg);
+      if (m.nd == 2) hipLaunchKernelGGL(mask_vec2_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs);
+      else hipLaunchKernelGGL(mask_vec2_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs);
       return;
     }
     g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_vec_kernel<2>" : "ftkx::mask_vec_kernel<3>";
