@@ -3,7 +3,6 @@
 // extract_cp3dt<scope> (src/filters/critical_point_tracer_2d_regular.cu:168-272, ..._3d_regular.cu:144-250).
 #include "ctx.hpp"
 #include "cp_device.hpp"   // classify3 on the HOST (fragile 3D records, see there)
-#include <hipcub/hipcub.hpp>
 
 using namespace ftkxh;
 
@@ -32,6 +31,83 @@ __global__ void sort_gather_kernel(const ftkx_cp_t *__restrict__ hits, const uns
   }
 }
 
+// ---- the records of a batch in tag order: a radix sort of (tag, index) pairs, least significant digit first ---------------------------
+// 4-bit digits, three launches per digit: per-tile digit counts, ONE exclusive scan over (digit, tile), a stable scatter.  A tile is
+// 256 threads x 8 consecutive keys each; inside it a key's place among its digit's keys = the keys of that digit in the threads before
+// (a prefix over per-thread counts in LDS) + those before it in its own thread -- stable without a single atomic.  Only the digits a tag
+// of this batch can have take part (key_bits).  This is the host-driven batch's ordering step (the device-driven pass orders by buckets,
+// series_kernels.hip); rounds 1-3 called hipcub::DeviceRadixSort here.
+constexpr int kRsThreads = 256, kRsPer = 8, kRsTile = kRsThreads * kRsPer;
+
+__global__ __launch_bounds__(kRsThreads) void rs_count_kernel(const u64 *__restrict__ keys, size_t n, int shift, unsigned *__restrict__ counts, unsigned ntiles)
+{
+  __shared__ unsigned s_cnt[16];
+  if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * kRsTile;
+  for (int e = 0; e < kRsPer; e ++) {
+    const size_t i = base + (size_t)e * kRsThreads + threadIdx.x;
+    if (i < n) atomicAdd(&s_cnt[(unsigned)(keys[i] >> shift) & 15u], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) counts[(size_t)threadIdx.x * ntiles + blockIdx.x] = s_cnt[threadIdx.x];
+}
+
+// exclusive scan in place, one workgroup: a thread's contiguous share serially, the shares' totals by wavefront and through LDS
+__global__ __launch_bounds__(1024) void rs_scan_kernel(unsigned *__restrict__ v, unsigned n)
+{
+  __shared__ unsigned s_wave[16];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const unsigned per = (n + 1023u) / 1024u, lo = tid * per, hi = lo + per < n ? lo + per : n;
+  unsigned sum = 0;
+  for (unsigned i = lo; i < hi; i ++) sum += v[i];
+  unsigned incl = sum;
+  for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if ((int)lane >= o) incl += up; }
+  if (lane == 63u) s_wave[wv] = incl;
+  __syncthreads();
+  unsigned run = incl - sum;
+  for (unsigned q = 0; q < wv; q ++) run += s_wave[q];
+  for (unsigned i = lo; i < hi; i ++) { const unsigned c = v[i]; v[i] = run; run += c; }
+}
+
+__global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const u64 *__restrict__ keys, const unsigned *__restrict__ idx, size_t n, int shift,
+                                                                const unsigned *__restrict__ offs, unsigned ntiles, u64 *__restrict__ keys_out, unsigned *__restrict__ idx_out)
+{
+  __shared__ unsigned short s_cnt[16][kRsThreads];          // column t: thread t's keys per digit, then its first place per digit inside the tile
+  __shared__ unsigned s_base[16];
+  const unsigned tid = threadIdx.x;
+  const size_t first = (size_t)blockIdx.x * kRsTile + (size_t)tid * kRsPer;      // this thread's eight consecutive keys
+  u64 k[kRsPer];
+  unsigned v[kRsPer];
+  for (int d = 0; d < 16; d ++) s_cnt[d][tid] = 0;
+  for (int e = 0; e < kRsPer; e ++) {
+    const size_t i = first + (size_t)e;
+    k[e] = 0ull; v[e] = 0u;
+    if (i < n) { k[e] = keys[i]; v[e] = idx[i]; s_cnt[(unsigned)(k[e] >> shift) & 15u][tid] ++; }
+  }
+  if (tid < 16) s_base[tid] = offs[(size_t)tid * ntiles + blockIdx.x];
+  __syncthreads();
+  {
+    // exclusive prefix over the 256 threads, per digit: thread (d, seg) = (tid / 16, tid % 16) walks sixteen columns, the sixteen
+    // segments of a digit are sixteen consecutive lanes
+    const unsigned d = tid >> 4, seg = tid & 15u;
+    unsigned sum = 0;
+    for (unsigned j = 0; j < 16; j ++) sum += s_cnt[d][seg * 16u + j];
+    unsigned incl = sum;
+    for (int o = 1; o < 16; o <<= 1) { const unsigned up = __shfl_up(incl, o, 16); if ((int)seg >= o) incl += up; }
+    unsigned run = incl - sum;
+    for (unsigned j = 0; j < 16; j ++) { const unsigned c = s_cnt[d][seg * 16u + j]; s_cnt[d][seg * 16u + j] = (unsigned short)run; run += c; }
+  }
+  __syncthreads();
+  for (int e = 0; e < kRsPer; e ++) {
+    if (first + (size_t)e < n) {
+      const unsigned d = (unsigned)(k[e] >> shift) & 15u;
+      const size_t at = (size_t)s_base[d] + (size_t)(s_cnt[d][tid] ++);
+      keys_out[at] = k[e]; idx_out[at] = v[e];
+    }
+  }
+}
+
 // the reference keeps hits in a std::map ordered by element; device append order is arbitrary
 int sort_hits_on_device(ftkx_ctx *c, size_t n, int key_bits)
 {
@@ -42,18 +118,26 @@ int sort_hits_on_device(ftkx_ctx *c, size_t n, int key_bits)
     HIP_TRY(c, hipMalloc((void **)&c->d_sorted, cap * sizeof(ftkx_cp_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_keys, 2 * cap * sizeof(u64)));
     HIP_TRY(c, hipMalloc((void **)&c->d_idx, 2 * cap * sizeof(unsigned)));
-    size_t tmp = 0;
-    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, c->d_keys, c->d_keys + cap, c->d_idx, c->d_idx + cap, (int)cap, 0, 64, c->stream));
-    HIP_TRY(c, hipMalloc(&c->d_sort_tmp, tmp));
-    c->sort_tmp_bytes = tmp;
+    c->sort_tmp_bytes = 16 * ((cap + kRsTile - 1) / kRsTile) * sizeof(unsigned);      // digit counts per tile
+    HIP_TRY(c, hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes));
     c->sort_cap = cap;
   }
   const size_t cap = c->sort_cap;
   hipLaunchKernelGGL(sort_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_hits, n, c->d_keys, c->d_idx);
-  size_t tmp = c->sort_tmp_bytes;
-  // only the bits a tag of this batch can have take part: an 8-bit digit pass less per byte saved
-  HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, c->d_keys, c->d_keys + cap, c->d_idx, c->d_idx + cap, (int)n, 0, key_bits, c->stream));
-  hipLaunchKernelGGL(sort_gather_kernel, dim3((unsigned)((n * 9 + 255) / 256)), dim3(256), 0, c->stream, c->d_hits, c->d_idx + cap, n, c->d_sorted);
+  const unsigned ntiles = (unsigned)((n + kRsTile - 1) / kRsTile);
+  unsigned *counts = (unsigned *)c->d_sort_tmp;
+  int from = 0;                                              // which half of the ping-pong buffers holds the pairs
+  for (int shift = 0; shift < key_bits; shift += 4) {
+    const u64 *kin = c->d_keys + (from ? cap : 0);
+    const unsigned *iin = c->d_idx + (from ? cap : 0);
+    u64 *kout = c->d_keys + (from ? 0 : cap);
+    unsigned *iout = c->d_idx + (from ? 0 : cap);
+    hipLaunchKernelGGL(rs_count_kernel, dim3(ntiles), dim3(kRsThreads), 0, c->stream, kin, n, shift, counts, ntiles);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, 16u * ntiles);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(ntiles), dim3(kRsThreads), 0, c->stream, kin, iin, n, shift, counts, ntiles, kout, iout);
+    from ^= 1;
+  }
+  hipLaunchKernelGGL(sort_gather_kernel, dim3((unsigned)((n * 9 + 255) / 256)), dim3(256), 0, c->stream, c->d_hits, c->d_idx + (from ? cap : 0), n, c->d_sorted);
   HIP_TRY(c, hipGetLastError());
   return FTKX_OK;
 }

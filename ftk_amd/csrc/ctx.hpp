@@ -268,6 +268,7 @@ struct ftkx_ctx {
   size_t sr_sorted_cap = 0;
   std::vector<ftkx_series_slot> sr_slots;   // chunked pass: one slot per chunk
   int sr_skip_small = 0;             // passes for which the fused tail kernel is not launched (the data was hit-dense a moment ago)
+  int sr_late_streak = 0;            // consecutive passes the fused tail declined late
   bool sr_short_chain = false;       // the last pass was finished by the fused tail kernel: the next one is queued without the kernels behind it
   int sr_last_buf = 0;               // the buffers of the pass completed last (ftkx_series_dist_status reads its results block)
   size_t sr_last_gathered_off = 0; int sr_last_nranks = 0;   // where its gathered contributions sit in that block (0 ranks: not a slab pass)

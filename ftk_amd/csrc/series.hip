@@ -858,7 +858,9 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
   c->sr_short_chain = (status & ftkx::SERIES_EARLY) != 0;
   const u64 *cnt = R + ftkx::SR_COUNTERS;
   if (!(status & ftkx::SERIES_EARLY) && (P.two_level ? cnt[ftkx::CNT_REFINE_PEAK] : cnt[ftkx::CNT_LIST_PEAK]) > 4 * 2048ull) c->sr_skip_small = 16;
-  if (status & ftkx::SERIES_LATE_DECLINE) c->sr_skip_small = 16;   // (few coarse cells, many records in them: the fused tail would decline late again, tens of microseconds each time)
+  // (few coarse cells, many records in them: the fused tail declined late, tens of microseconds lost.  Twice in a row: the series is like that)
+  c->sr_late_streak = (status & ftkx::SERIES_LATE_DECLINE) ? c->sr_late_streak + 1 : 0;
+  if (c->sr_late_streak >= 2) c->sr_skip_small = 16;
   const size_t nrec = (size_t)R[ftkx::SR_NHITS];
   ftkx_cp_t *H = B.out;
   if (P.to_device) {                                         // (the copy kernel; the mask kernel of the pass queued behind this one is running meanwhile)
