@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
                                                                 int report_decline /* nothing is queued behind this kernel: if it declines, it says so itself */)
 {
   constexpr int N = ND + 1, NVC = 1 << N, G = kThreads / NVC, NTYPES = fan_table<N>::NTYPES;
-  constexpr unsigned LIST_CAP = kSmallPer * 32, PASS_CAP = 2048;
+  constexpr unsigned LIST_CAP = kSmallPer * 128, PASS_CAP = 2048;   // a coarse cell is 8 x u_rows corners, u_rows <= 16 (mask_summary_rows)
   __shared__ unsigned s_rank[kSmallRank];
   static_assert(G * NTYPES <= (int)PASS_CAP / 2, "a batch's worst case must fit twice");
   __shared__ u64 s_list[LIST_CAP];
@@ -278,8 +278,11 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
   const fan_table<N> &fan = dev_fan<ND>();
   const u64 redo = (u64)(SERIES_AMBIGUOUS | SERIES_MASKS_INVALID | SERIES_INF);
   const u64 count = m.counters[two_level ? CNT_REFINE_LIST : CNT_SURVIVOR_LIST];
-  const u64 per = two_level ? (u64)kSmallPer : (u64)LIST_CAP;
-  const u64 units = count;
+  // What is dealt to the workgroups (round-robin): a coarse cell of up to four rows whole, a taller one (8 x 16: u_rows == 16) in quarters of
+  // four rows -- with whole cells of 128 corners a sparse series would keep a third of the workgroups busy, each with four times the corners
+  const u64 SR = two_level ? (u64)(m.u_rows < 4 ? m.u_rows : 4) : 1ull, UQ = two_level ? (u64)m.u_rows / SR : 1ull;
+  const u64 per = two_level ? (u64)kSmallPer : (u64)(kSmallPer * 32);
+  const u64 units = count * UQ;
   const bool is_redo = (results[SR_STATUS] & redo) != 0;  // the host takes this pass over anyway
   if (is_redo || units > per * (u64)kSmallGrid) {         // (the same for every workgroup) too much for this kernel: nothing has been changed
     if (report_decline && blockIdx.x == 0) {
@@ -307,16 +310,17 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
   if (two_level) {
     const int DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
     const u64 k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
-    const u64 UR = (u64)m.u_rows, urows = (u64)((DH + m.u_rows - 1) / m.u_rows);
-    for (u64 idx = tid; idx < mine_n * UR; idx += kThreads) {
-      const u64 e = refine[(u64)blockIdx.x + (idx / UR) * (u64)kSmallGrid];
+    const u64 urows = (u64)((DH + m.u_rows - 1) / m.u_rows);
+    for (u64 idx = tid; idx < mine_n * SR; idx += kThreads) {
+      const u64 unit = (u64)blockIdx.x + (idx / SR) * (u64)kSmallGrid;      // = (coarse cell, quarter of it)
+      const u64 e = refine[unit / UQ];
       const int step = (int)(e >> 44);
       const unsigned want = (unsigned)((e >> 40) & 3);
       u64 lin = e & 0xffffffffffull;
       const int g = mc.core_st[0] + (int)(lin % (u64)mc.core_sz[0]); lin /= (u64)mc.core_sz[0];
       const int cyc = mc.core_st[1] + (int)(lin % (u64)mc.core_sz[1]); lin /= (u64)mc.core_sz[1];
       const int cz = (ND == 3) ? mc.core_st[2] + (int)lin : 0;
-      const int j = cyc * m.u_rows + (int)(idx % UR), k = cz - m.ext_st[2];
+      const int j = cyc * m.u_rows + (int)((unit % UQ) * SR + idx % SR), k = cz - m.ext_st[2];
       const int cy = j + m.ext_st[1];
       if (!(cy >= m.core_st[1] && cy < m.core_st[1] + m.core_sz[1])) continue;
       const Fields f = steps[step];
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
       for (int b = 0; b < 8; b ++) {
         const unsigned fl = (unsigned)((surv_o >> (8 * b + 7)) & 1) | ((unsigned)((surv_i >> (8 * b + 7)) & 1) << 1);
         if (!fl) continue;
-        s_list[atomicAdd(&s_nlist, 1u)] = (row_lin + (u64)(g * 8 + b + m.ext_st[0] - m.core_st[0])) | ((u64)fl << 40) | ((u64)step << 44);   // (at most 8 x u_rows corners per coarse cell: fits)
+        s_list[atomicAdd(&s_nlist, 1u)] = (row_lin + (u64)(g * 8 + b + m.ext_st[0] - m.core_st[0])) | ((u64)fl << 40) | ((u64)step << 44);   // (at most 8 x u_rows <= 128 corners per coarse cell: fits)
       }
     }
   } else {

@@ -1510,14 +1510,51 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
   // batch, the summaries of row r at the four word columns 4 g .. 4 g + 3 -- one dword of U as it lies in memory.
   const bool batched = RY == 4 && have_u;
   const bool block4 = batched && m.u_rows == 4;                // one summary byte per 8 x 4 block (this wavefront's four rows)
+  // ... or per 8 x 16 block: the workgroup's sixteen rows (u_rows == 16).  Every byte of summary stored costs (with the
+  // stores of three of the four wavefronts aimed out of range 512^3 x 32 ran in 5.45 instead of 5.61 ms, with all of them 5.39), so the
+  // four wavefronts' block bytes are ANDed through LDS: a wavefront publishes its byte at the end of step k and everybody reads the four
+  // of them behind the barrier of step k + 1 (no second barrier per plane).  The mask words are still stored by the wavefront's own
+  // rule, at once (its 8 x 4 block has no common bit); where the sixteen rows have none but a wavefront's four do, its summary goes out
+  // as mask bytes one step late (rare: a wave-uniform branch) -- a stand-in with fewer bits than the real bytes, as everywhere.
+  const bool block16 = batched && CY == 4 && m.u_rows == 16;
+  const bool blk = block4 || block16;
   const unsigned a_l = ((unsigned)lane >> 2) & 3u, r_l = (unsigned)lane & 3u, g_l = (unsigned)lane >> 4;
   const unsigned urows = (unsigned)((DH + m.u_rows - 1) / m.u_rows);
   const unsigned uplane_stride = (unsigned)m.u_pitch * urows;
   // (block summaries: the quad's four lanes hold the same dword; lane r = 0 stores it -- if the block's first row exists)
-  const unsigned uo4 = (block4 ? (r_l == 0 && (row_ok & 1u)) : ((row_ok >> r_l) & 1u)) ? a_l * uplane_stride + (block4 ? 0u : r_l * (unsigned)m.u_pitch) + (unsigned)(t0c >> 3) + 4u * g_l : OOB;
+  const unsigned uo4 = (blk ? ((block4 || wy == 0) && r_l == 0 && (row_ok & 1u)) : ((row_ok >> r_l) & 1u)) ? a_l * uplane_stride + (blk ? 0u : r_l * (unsigned)m.u_pitch) + (unsigned)(t0c >> 3) + 4u * g_l : OOB;
   const unsigned psel = (0x0c0c0c0cu & ~(0xffu << (8u * a_l))) | (r_l << (8u * a_l));   // v_perm: byte a <- byte r of the source, 0 elsewhere
   unsigned uacc = 0u;
   const unsigned vzero = 0u;
+  // (8 x 16 blocks) the exchange: two slots of 16 quads x 4 wavefronts' bytes behind the edge ring; what is pending from the previous step
+  const unsigned xch = lds0 + ERING + (unsigned)NE * EDGEB + (unsigned)(lane >> 2) * 4u;
+  unsigned t_prev = 0u;
+  int k_prev = 0;
+  bool pend = false;
+  auto finish_prev = [&](unsigned g4) {                       // g4: the four wavefronts' block bytes of plane k_prev at this quad
+    unsigned t = g4 & (g4 >> 16);
+    t &= t >> 8;
+    const unsigned G = t & 0xffu;                              // the sign bits all 8 x 16 vertices share
+    const unsigned uplane_prev = (unsigned)m.u_pitch * ((unsigned)(j0 / m.u_rows) + urows * (unsigned)k_prev);
+    if (wy == 0) {                                             // (wave-uniform) the first wavefront gathers four planes' summaries and stores them
+      const int j = (k_prev - z0) & 3;
+      unsigned c = G << (8u * a_l);
+      row_quads_or(c);
+      uacc = select_lanes(uacc, c, 0x000f000f000f000full << (4 * j));
+      if (j == 3 || k_prev == z1 - 1) {
+        const unsigned off = j == 3 ? uo4 : (a_l <= (unsigned)j ? uo4 : OOB);
+        __builtin_amdgcn_raw_buffer_store_b32(uacc, rU, off, uplane_prev - (unsigned)j * uplane_stride, 0);
+      }
+    }
+    const bool need = G == 0u && t_prev != 0u;                 // no common bit in sixteen rows, one in this wavefront's four: its words were not stored
+    if (__builtin_amdgcn_ballot_w64(need)) {
+      asm volatile("" ::: "memory");
+      const unsigned v = t_prev | (t_prev << 8);
+      const unsigned mp = (unsigned)P * ((unsigned)j0 + (unsigned)DH * (unsigned)k_prev);
+      static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, rM, need ? moff[r] : OOB, mp, 0); });
+    }
+    pend = false;
+  };
 
   // LDS reads by hand (see the header): issue them all, one lgkmcnt wait, then tie the registers to the wait
   auto take_plane = [&](v2d (&B)[RY + 2], int q) { lds_rows(B, lrow + slot_of(q), std::make_integer_sequence<int, RY + 2>{}); };
@@ -1530,16 +1567,21 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
     // this wavefront's share of plane k+1 has landed: all but the operations issued after it may still be in flight
     if (batched) wait_plane_landed<DEPTH, RY, RY>(k - z0);    // (the summaries' one store per four planes is not counted: the wait is one operation stricter then)
     else wait_plane_landed<DEPTH, RY, 2 * RY>(k - z0);
+    if (block16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the block byte this wavefront published at the end of the previous step is in LDS)
     __builtin_amdgcn_s_barrier();                              // ... and so has everybody else's
     const bool live = k < z1;                                  // (wave-uniform) padding steps of the chunk have nothing to classify or store
     if constexpr (!TWOB) { const int q = k + NS; issue(q < z1 ? q : z1); }   // the slot read during the previous step, the edge entry of plane k-1
     double XL[RY], XR[RY];
+    const bool fin = block16 && pend;                          // (wave-uniform) the previous plane's 8 x 16 summaries: the four wavefronts' bytes
+    unsigned g4 = 0u;
+    if (fin) asm volatile("ds_read_b32 %0, %1" : "=v"(g4) : "v"(xch + (unsigned)(k_prev & 1) * 64u));
     if (live) {
       take_plane(NX, k + 1 < z1 ? k + 1 : z1);
       lds_edges<(int)ERIGHT>(XL, XR, eown + edge_of(k), std::make_integer_sequence<int, RY>{});
       landed(NX);
       lds_tie_edges(XL, XR, std::make_integer_sequence<int, RY>{});
-    }
+    } else if (fin) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (fin) { asm volatile("" : "+v"(g4)); finish_prev(g4); }
     if constexpr (TWOB) {
       __builtin_amdgcn_s_barrier();                            // everybody has plane k+1 (and plane k's edge values) in registers:
       const int q = k + 1 + NS; issue(q < z1 ? q : z1);        // its row slot and that edge entry take the plane NS steps ahead
@@ -1607,7 +1649,7 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
     unsigned T[(RY + 3) / 4];
     unsigned long long wu[RY];
     unsigned mo[RY];
-    if (block4) {
+    if (blk) {
       // ONE byte for the wavefront's four rows: the sign bits all 8 x 4 vertices share
       if constexpr (RY == 4) {
         unsigned all = bw[0] & bw[1];
@@ -1625,6 +1667,14 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
       static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; byte_nonzero<r % 4>(wu[r], T[r / 4], vzero); });
       if constexpr (RY < 3) asm volatile("s_nop 1");
       static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; mo[r] = out_of_range_where(moff[r], wu[r]); });
+    }
+    if (block16) {
+      // the wavefront's block byte goes to the exchange (every lane of a quad writes the same byte to the same place); the sixteen rows'
+      // summary and whatever follows from it: finish_prev, behind the next barrier
+      asm volatile("ds_write_b8 %0, %1" :: "v"(xch + (unsigned)(k & 1) * 64u + (unsigned)wy), "v"(T[0]) : "memory");
+      t_prev = T[0]; k_prev = k; pend = true;
+      static_for<RY>([&](auto rc) { constexpr int r = decltype(rc)::value; __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bw[r], rM, mo[r], mplane, 0); });
+      return;
     }
     if (batched) {
       // every lane of a quad holds the quad's T (byte r = row r at the quad's word column).  Lane (a, r) moves ITS row's byte to byte a;
@@ -1660,6 +1710,13 @@ __device__ __forceinline__ void march6_body(const Mesh &m, const MaskJob *__rest
     step(B[0], B[1], B[2], z0 + s);
     step(B[1], B[2], B[0], z0 + s + 1);
     step(B[2], B[0], B[1], z0 + s + 2);
+  }
+  if (block16 && pend) {                                       // (workgroup-uniform) the last plane's summaries: no step follows it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    unsigned g4;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(g4) : "v"(xch + (unsigned)(k_prev & 1) * 64u) : "memory");
+    finish_prev(g4);
   }
   FTKX_WAIT_VM(0);                                             // nothing may still be writing LDS when the workgroup retires
 #undef FTKX_WAIT_VM
@@ -2549,7 +2606,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       int sw = swizzle;
       // grouped placement needs a y extent that is a multiple of the group height: pad it (workgroups past the last row leave at once)
       if (sw & 8) { int yg = yg_want; if (yg > (int)grid6.y) yg = (int)grid6.y; grid6.y = (grid6.y + (unsigned)yg - 1) / (unsigned)yg * (unsigned)yg; sw = (sw & 0xff) | (yg << 8); }
-      const unsigned bytes = (unsigned)NS6 * (unsigned)(rows + 2) * 1024u + (unsigned)(NS6 + 1) * 256u;
+      const unsigned bytes = (unsigned)NS6 * (unsigned)(rows + 2) * 1024u + (unsigned)(NS6 + 1) * 256u + 128u;   // row slots, edge ring, the summaries' exchange
       (void)hipFuncSetAttribute((const void *)mask_march6_kernel<NS6, CY6, RY6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
       bool slice_major = (size_t)grid6.x * ((m.ext_sz[1] + rows - 1) / rows) * plan.npieces >= 768;      // a slice alone fills the device (three workgroups per CU)
       if (const char *e = getenv("FTKX_MASK_ORDER")) slice_major = atoi(e) == 0;
@@ -2616,9 +2673,12 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
 int mask_summary_rows(const Mesh &m)
 {
   if (!masks_have_summary(m)) return 1;
-  if (const char *e = getenv("FTKX_U_ROWS")) if (atoi(e) == 1) return 1;
+  int want = 0;
+  if (const char *e = getenv("FTKX_U_ROWS")) want = atoi(e);
+  if (want == 1) return 1;
   if (!m.scalar_mode) return vec_lean(m) ? 4 : 1;              // mask_vec2_kernel / mask_vec_kernel
-  return 4;                                                    // mask_march6_kernel (3D), mask_march4_kernel<2, ...> (2D): a wavefront's rows in blocks of four
+  if (m.nd == 3) return want == 4 ? 4 : 16;                    // mask_march6_kernel: the workgroup's sixteen rows (FTKX_U_ROWS=4: a wavefront's four)
+  return 4;                                                    // mask_march4_kernel<2, ...>: a wavefront's rows in blocks of four
 }
 
 // does launch_masks produce the per-word summaries for this mesh?  (the 128-column marching kernels and the fast vector kernel do)

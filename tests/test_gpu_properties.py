@@ -140,8 +140,8 @@ def test_reference_and_exact_tags_agree_without_overflow(gpu):
                                                 ("woven", (1024, 512), 5, False), ("woven", (258, 100), 4, True)])
 def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
     """The marching mask kernel (3D: mask_march6_kernel, 2D: mask_march4_kernel) under every workgroup placement, every way of cutting a
-    tile column into pieces of planes, with and without summaries, with summaries per word and per 8 x 4 block: same results, the same
-    fused reduction AND the same cull statistics (cells that survive, words refined) = the same mask / summary bytes where it matters.
+    tile column into pieces of planes, with and without summaries, with summaries per word, per 8 x 4 block and (3D) per 8 x 16 block:
+    same results, the same fused reduction AND, within a geometry, the same cull statistics = the same mask / summary bytes where it matters.
     (Rounds 1-3 carried five generations of this kernel side by side; round 4 keeps one per dimension and one generic form.)"""
     import os
     steps = None
@@ -156,8 +156,9 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
                 # the pieces a column is marched in: short ones only, one piece per column, many tiny ones (more than the table holds: merged)
                 {"FTKX_MASK_LMIN": "1", "FTKX_MASK_LCAP": "3"}, {"FTKX_MASK_LCAP": "100000"}, {"FTKX_MASK_LMIN": "1", "FTKX_MASK_LCAP": "1"}, {"FTKX_MASK_ZCHUNK": "1"},
                 {"FTKX_MASK_ZCHUNK": "32"}, {"FTKX_MASK_LMIN": "6", "FTKX_MASK_LCAP": "24"}, {"FTKX_MASK_ORDER": "0"}, {"FTKX_MASK_ORDER": "1"}, {"FTKX_MASK_ORDER": "0", "FTKX_MASK_ZCHUNK": "5"}]
+    variants += [{"FTKX_U_ROWS": "4"}, {"FTKX_U_ROWS": "4", "FTKX_MASK_ZCHUNK": "7"}, {"FTKX_U_ROWS": "4", "FTKX_MASK_LCAP": "3", "FTKX_MASK_LMIN": "1"}]
     base = None
-    words = None
+    by_geometry = {}
     for env in variants:
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
@@ -171,22 +172,22 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
                     os.environ[k] = v
         key = (st["cells_survived"], st["simplices_tested"], tuple(factors))
         if base is None:
-            base = (recs, key)
+            base = recs
             assert st["cull_enabled"] == 1
-        else:
-            _same(recs, base[0])
-            # The records never differ.  The cull statistics are those of the summary geometry: where a summary stands in for mask words
-            # that were not written, it can only cull less than the real bytes -- the one-level cull (no summaries) leaves the fewest
-            # cells, one byte per word of 8 more, one byte per 8 x 4 block (the default kernel with four rows per wavefront) the most
-            blocks = env.get("FTKX_U_ROWS") != "1"          # (both dimensions: one byte per 8 x 4 block by default)
-            if env.get("FTKX_TWO_LEVEL") == "0":
-                assert key[2] == base[1][2] and key[0] <= base[1][0] and key[1] <= base[1][1], (env, key, base[1])
-            elif blocks:
-                assert key == base[1], (env, key, base[1])
-            else:
-                assert key[2] == base[1][2] and key[0] <= base[1][0] and key[1] <= base[1][1], (env, key, base[1])
-                words = words or key
-                assert key == words, (env, key, words)          # all per-word kernels agree among themselves
+        _same(recs, base)                                      # the records never differ
+        # The cull statistics are those of the summary geometry -- none (one-level cull), one byte per word of 8, per 8 x 4 block, per
+        # 8 x 16 block (3D, the default: the workgroup's sixteen rows) --: every way of placing workgroups and cutting columns gives the
+        # same numbers within a geometry, and a coarser stand-in for unwritten mask words can only let MORE simplices through to the test
+        default_rows = 16 if len(dims) == 3 else 4
+        rows = 0 if env.get("FTKX_TWO_LEVEL") == "0" else int(env.get("FTKX_U_ROWS", default_rows))
+        rows = min(rows, default_rows)
+        by_geometry.setdefault(rows, (key, env))
+        assert key == by_geometry[rows][0], (env, key, by_geometry[rows])
+    assert set(by_geometry) >= ({0, 1, 4, 16} if len(dims) == 3 else {0, 1, 4}), sorted(by_geometry)
+    order = sorted(by_geometry)
+    for fine, coarse in zip(order, order[1:]):
+        assert by_geometry[fine][0][2] == by_geometry[coarse][0][2]
+        assert by_geometry[fine][0][1] <= by_geometry[coarse][0][1], (fine, coarse, by_geometry[fine], by_geometry[coarse])
 
 
 def test_slices_beyond_4GiB_take_the_64bit_kernels(gpu):
