@@ -48,7 +48,8 @@ CONFIGS = {
     "mid2": (2, 1, "woven", (512, 512), 12),                  # enough records per rank for the copy kernel of a pipelined pass (tests)
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-STREAM_CEILING_GBS = 6290.0   # what a bare streaming read reaches on this part (same guide: achievable HBM read bandwidth)
+STREAM_CEILING_GBS = 6290.0   # what a bare streaming read reaches on this part (same guide: achievable HBM read bandwidth).  A yardstick, not a bound:
+                              # tools/probe/bw_probe.hip reads 4.3 GB at 6.4-6.6 TB/s on the faster boxes of the pool, where the mask kernel reaches 6.4 as well
 
 # what a pass of each configuration must return (checked in the JSON line, `configs.*.check`):
 #   c1: the reference's own count and type histogram (woven 128 x 128 x 10)
