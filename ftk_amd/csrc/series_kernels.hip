@@ -718,11 +718,16 @@ __global__ __launch_bounds__(256) void series_copy_out_kernel(const ftkx_cp_t *_
   // the records' pass is then through (same stream, in order: no event needed, and none is recorded) and the next pass's descriptors have
   // been fetched over PCIe (a read queued behind this kernel's writes took 65 us instead of 4).  This kernel may well start while the
   // records' pass is still running: sixteen workgroups whose first lanes sleep and poll.  (The bound -- seconds -- only keeps a begin kernel
-  // that never ran from hanging the device.)
+  // that never ran from hanging the device: the copy then does not happen and the host is told so.)
   if (wait_flag) {
-    if (threadIdx.x == 0)
-      for (unsigned it = 0; it < (1u << 23) && (int)(__hip_atomic_load(wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - wait_val) < 0; it ++) __builtin_amdgcn_s_sleep(32);
+    __shared__ int s_gave_up;
+    if (threadIdx.x == 0) {
+      unsigned it = 0;
+      while (it < (1u << 23) && (int)(__hip_atomic_load(wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - wait_val) < 0) { __builtin_amdgcn_s_sleep(32); it ++; }
+      s_gave_up = it == (1u << 23);
+    }
     __syncthreads();
+    if (s_gave_up) return;                                     // nothing copied, no flag: the host reports a stream that drained without the result
   }
   u64 n = results[SR_NHITS];
   if (n > capacity) n = capacity;
