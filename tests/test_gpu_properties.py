@@ -84,6 +84,36 @@ def test_cull_equals_exact_only_128cubed(gpu):
     _same(recs_c, recs_e)
 
 
+@pytest.mark.parametrize("dims", [(200, 150, 37), (136, 49, 18)])
+def test_rough_3d_cull_equals_exact_only(gpu, dims):
+    """Plateaus, ties and noise in 3D -- most 8 x 16 blocks have no common sign bit, many of a wavefront's 8 x 4 sub-blocks do (their
+    summaries go out as stand-in mask bytes one step late), tiles that end inside the array in x and y: the culled sweep against the
+    integer fallback that tests every simplex, and the series pass against both."""
+    nt = 3
+    rng = np.random.default_rng(23)
+    shape = tuple(reversed(dims))
+    steps = [np.round(rng.standard_normal(shape) * 2) * 0.25 + rng.integers(-2, 3, size=shape) / 64.0 for _ in range(nt)]
+    for z in range(0, shape[0], 5):       # smooth slabs in between: uniform blocks next to rough ones
+        steps[1][z] = np.linspace(1.0, 2.0, shape[2])[None, :] + np.linspace(0.0, 0.5, shape[1])[:, None]
+    recs_c, st_c, f_c = _run(gpu, "moving_extremum_3d", dims, nt, steps=steps)
+    recs_e, st_e, f_e = _run(gpu, "moving_extremum_3d", dims, nt, steps=steps, exact_only=True)
+    assert st_c["cull_enabled"] == 1 and st_e["cull_enabled"] == 0 and list(f_c) == list(f_e)
+    assert len(recs_c) > 1000
+    _same(recs_c, recs_e)
+    import torch
+    ctx = gpu.Context(3)
+    dom = ([2] * 3, [d - 3 for d in dims])
+    ctx.set_mesh(dom, dom, ([0] * 3, list(dims)))
+    ctx.set_options(jacobian_symmetric=1, derive_jacobian=1, tag_mode=gpu.TAG_EXACT64)
+    keep = [torch.from_numpy(np.ascontiguousarray(a)).to("cuda") for a in steps]
+    for t in range(nt):
+        ctx.push_scalar_slice(t, keep[t])
+    got, f, _ = ctx.sweep_series(range(nt), [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)])
+    assert [int(v) for v in f] == [int(v) for v in f_c]
+    _same(np.array(got), recs_c)
+    ctx.close()
+
+
 def test_cull_equals_exact_only_woven_1024(gpu):
     """BASELINE configs[1] geometry (1024 x 1024), 6 timesteps: ~5e4 records"""
     recs_c, st_c, f = _run(gpu, "woven", (1024, 1024), 6)
