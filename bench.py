@@ -114,6 +114,20 @@ def glibc_version():
         return "unknown"
 
 
+def pci_bus_id(torch, dev):
+    """the device's PCI address as the HIP runtime names it (hipDeviceGetPCIBusId), e.g. 0000:05:00.0"""
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(dev.index or 0)) == 0:
+            return buf.value.decode()
+    except Exception:   # noqa: BLE001
+        pass
+    pr = torch.cuda.get_device_properties(dev)
+    return "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+
+
 def me3d_params(dims):
     from ftk_amd import synthetic
     x0, dv = synthetic.moving_extremum_params(dims)
@@ -326,6 +340,76 @@ def streaming_tracker(nd, case, dims, nt_run, torch, dev, ftk_amd, synthetic, ho
     return out
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): this process touches neither torch nor the GPU; it starts N
+    fresh child processes -- one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run sets
+    them -- waits for them under a time limit, and ends with rank 0's JSON line and exit code 0, or with the failing ranks' stderr and a
+    non-zero code (the ranks still running are ended by their exact PIDs: a rank that died leaves the others waiting in a collective).
+    The reference's several-rank entry needs no wrapper either (include/ftk/filters/regular_tracker.hh:127-149; the gather at
+    include/ftk/filters/critical_point_tracker.hh:689)."""
+    import socket
+    n = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    tmp = tempfile.mkdtemp(prefix="ftkx_bench_")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        so_, se_ = open(os.path.join(tmp, f"rank{r}.out"), "wb"), open(os.path.join(tmp, f"rank{r}.err"), "wb")
+        procs.append((r, subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=so_, stderr=se_, start_new_session=True), so_, se_))
+    deadline = time.monotonic() + args.rank_timeout
+    failed, timed_out = [], False
+    while True:
+        codes = [p.poll() for _, p, _, _ in procs]
+        failed = [r for (r, _, _, _), c in zip(procs, codes) if c not in (None, 0)]
+        if failed or all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            timed_out = True
+            break
+        time.sleep(0.05)
+    if failed or timed_out:
+        time.sleep(0.5)                                      # (ranks that were about to fail the same way get to say so)
+        for r, p, _, _ in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, 15)                     # (its own session: exactly this rank and what it started)
+                except ProcessLookupError:
+                    pass
+        for r, p, _, _ in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, 9)
+                except ProcessLookupError:
+                    pass
+                p.wait()
+    for _, _, so_, se_ in procs:
+        so_.close(); se_.close()
+
+    def tail(r, what, nbytes=6000):
+        with open(os.path.join(tmp, f"rank{r}.{what}"), "rb") as f:
+            return f.read()[-nbytes:].decode(errors="replace")
+    if failed or timed_out:
+        codes = {r: p.returncode for r, p, _, _ in procs}
+        bad = failed if failed else [r for r, _, _, _ in procs]
+        print("bench.py --gpus %d: %s; exit codes by rank %s" % (n, ("rank(s) %s failed" % failed) if failed else ("no result within %d s (--rank-timeout)" % args.rank_timeout), codes), file=sys.stderr)
+        for r in bad[:4]:
+            print("---- rank %d stderr (tail) ----\n%s" % (r, tail(r, "err")), file=sys.stderr)
+        code = next((codes[r] for r in failed if codes[r] and codes[r] > 0), 1)
+        sys.exit(code if 0 < code < 256 else 1)
+    sys.stderr.write(tail(0, "err", 2000))
+    line = [ln for ln in tail(0, "out", 1 << 24).splitlines() if ln.startswith("{")]
+    if not line:
+        print("bench.py --gpus %d: every rank ended with code 0 but rank 0 printed no JSON line" % n, file=sys.stderr)
+        sys.exit(1)
+    print(line[-1])
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -352,7 +436,15 @@ def main():
     ap.add_argument("--no-streaming-tracker", action="store_true", help="N = 1: skip the per-timestep tracker measurement (device-resident and host-fed) that follows the timed region")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the few passes of the other BASELINE configurations that follow the timed region")
     ap.add_argument("--dump-merged", default=None, help="rank 0 writes the merged records and the curves traced from them (npz)")
+    ap.add_argument("--rank-timeout", type=int, default=900, help="--gpus N without a launcher: seconds the N child processes get before they are ended")
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # (tests: this rank exits with code 7 before it joins the process group)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args, sys.argv[1:])                     # (does not return; nothing above or in it touches torch or the GPU)
+    if args.fail_rank >= 0 and int(os.environ.get("RANK", "0")) == args.fail_rank:
+        print("bench.py: rank %d asked to fail (--fail-rank)" % args.fail_rank, file=sys.stderr)
+        sys.exit(7)
 
     # before anything initialises the HIP runtime: the host driver only supports dmabuf IPC (RCCL / device-tensor sharing across
     # processes fails with the legacy mode)
@@ -366,8 +458,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N` on its own, or under torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -609,6 +700,7 @@ def job(args, env):
     elapsed = time.perf_counter() - tt0
     per_pass_ms = np.diff(np.array([tt0] + pass_stamps[:args.steps])) * 1e3      # (pipelined: the time between consecutive completions)
     timed_paths = list(path_list)
+    own_elapsed = elapsed
     if multi:
         cdev = dev if args.backend == "nccl" else "cpu"
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -623,6 +715,21 @@ def job(args, env):
     total_simplices = tslab.count_simplices(nd, dims, nt, scalar_input)
     torch.cuda.synchronize()
     ktimes = ctx.kernel_times()
+    # who took part (several ranks): what the process group says its size is, every rank's device and its own wall time -- so that a line
+    # claiming N GPUs shows N distinct devices that each did a share of the work
+    ranks_info = None
+    if multi:
+        mine = {"rank": rank, "device": int(dev.index or 0), "pci_bus_id": pci_bus_id(torch, dev), "timesteps": len(own), "ms_per_step": own_elapsed / args.steps * 1e3,
+                "slab_fallbacks": int(slab.fallbacks) if slab is not None else None, "pid": os.getpid()}
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, mine)
+        try:
+            rv = torch.cuda.nccl.version() if args.backend == "nccl" else None
+            rv = ".".join(str(v) for v in rv) if isinstance(rv, (tuple, list)) else rv
+        except Exception:   # noqa: BLE001
+            rv = None
+        ranks_info = {"ranks_seen": int(dist.get_world_size()), "backend": dist.get_backend(), "rccl_version": rv,
+                      "distinct_devices": len(set(e["pci_bus_id"] for e in everyone)), "per_rank": everyone}
     latency_ms = None
     if pipelined:
         # the same pass on its own (ftkx_sweep_series, nothing else in flight): what one call takes from its first launch to the records
@@ -774,6 +881,7 @@ def job(args, env):
             "roofline_end_to_end": {"achieved": alg_bytes_pass * world / (elapsed / args.steps) / 1e9 / world, "frac": alg_bytes_pass / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                                     "note": "algorithmic bytes of this rank's pass / wall time of the pass (prepare + factors + cull + exact + sort + download)"},
             "halo_exchange": halo_info,
+            "ranks": ranks_info,
             "other_halo_convention": other,
             "pass2": pass2,
             "wall_breakdown_ms_per_pass": {"prepare_masks_and_reduction": host_ms[2] / args.steps, "enqueue_calls": host_ms[0] / args.steps,

@@ -111,6 +111,8 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const u64 *__res
 // the reference keeps hits in a std::map ordered by element; device append order is arbitrary
 int sort_hits_on_device(ftkx_ctx *c, size_t n, int key_bits)
 {
+  if (n == 0) return FTKX_OK;                                // (no tiles: nothing to launch)
+  if (n >= (size_t)1 << 31) return fail(c, FTKX_E_UNSUPPORTED, "sort_hits_on_device: %zu records (indices are 32-bit)", n);
   if (c->sort_cap < n) {
     for (void *p : {(void *)c->d_sorted, (void *)c->d_keys, (void *)c->d_idx, c->d_sort_tmp}) if (p) (void)hipFree(p);
     c->d_sorted = nullptr; c->d_keys = nullptr; c->d_idx = nullptr; c->d_sort_tmp = nullptr; c->sort_cap = 0;

@@ -258,6 +258,7 @@ struct ftkx_ctx {
   hipStream_t sr_copy_stream = nullptr, sr_fetch_stream = nullptr;
   unsigned *sr_fetch_flag = nullptr;   // device: [0] the number of the last pass whose descriptors have been fetched (series_begin_kernel), [1] its arrival counter
   unsigned sr_fetch_seq = 0;
+  hipEvent_t sr_ev_fetched = nullptr;  // slab passes: recorded behind the begin kernel, waited for by the copy of the pass before (no spin-wait there)
   unsigned long long mask_epoch = 0;  // source of Slice::mask_gen values
   double sr_last_running = 0;         // the running minimum the host knew when it last collected a pass (hint of a chained pass)
   unsigned *sr_hist = nullptr, *sr_boff = nullptr;

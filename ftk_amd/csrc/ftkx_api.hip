@@ -388,6 +388,7 @@ void ftkx_destroy(ftkx_ctx *c)
   }
   if (c->sr_copy_stream) (void)hipStreamDestroy(c->sr_copy_stream);
   if (c->sr_fetch_flag) (void)hipFree(c->sr_fetch_flag);
+  if (c->sr_ev_fetched) (void)hipEventDestroy(c->sr_ev_fetched);
   if (c->sr_fetch_stream) (void)hipStreamDestroy(c->sr_fetch_stream);
   for (void *p : {c->tr_dev, c->tr_parent, c->tr_tables}) if (p) (void)hipFree(p);
   if (c->tr_host) (void)hipHostFree(c->tr_host);

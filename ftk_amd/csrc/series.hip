@@ -639,10 +639,22 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   // (the pass queued before this one left its records in device memory: their way over PCIe starts behind this pass's descriptor fetch,
   // which the begin kernel announces in a word of device memory -- series_copy_out_kernel)
   const bool copy_behind = before && before->open && before->copy_pending;
-  if (copy_behind && !c->sr_fetch_flag) { HIP_TRY(c, hipMalloc((void **)&c->sr_fetch_flag, 2 * sizeof(unsigned))); HIP_TRY(c, hipMemset(c->sr_fetch_flag, 0, 2 * sizeof(unsigned))); }   // (once per context; synchronous: the copy stream reads it)
-  const unsigned fetch_val = copy_behind ? ++ c->sr_fetch_seq : 0u;
-  ftkx::launch_series_begin(c->d_counters, c->d_red, ntodo * 64, c->sr_hist, nbins + 1, B.results, nwords, c->stream, B.h_desc, B.d_desc, total, copy_behind ? c->sr_fetch_flag : nullptr, fetch_val);
-  if (copy_behind) series_queue_copy(c, *before, c->sr_fetch_flag, fetch_val);
+  // (single-rank passes: the copy waits on a word of device memory.  Slab passes: their begin kernel may sit behind the pass before it with
+  // its messages from other ranks for as long as a peer lags -- sixteen workgroups would spin for that long, and give up in the end; the
+  // copy is ordered behind the begin kernel by an event instead, 5 us on a path that waits for the network anyway)
+  const bool copy_by_event = copy_behind && (dist != nullptr || before->dist);
+  const bool copy_by_flag = copy_behind && !copy_by_event;
+  if (copy_by_flag && !c->sr_fetch_flag) { HIP_TRY(c, hipMalloc((void **)&c->sr_fetch_flag, 2 * sizeof(unsigned))); HIP_TRY(c, hipMemset(c->sr_fetch_flag, 0, 2 * sizeof(unsigned))); }   // (once per context; synchronous: the copy stream reads it)
+  const unsigned fetch_val = copy_by_flag ? ++ c->sr_fetch_seq : 0u;
+  ftkx::launch_series_begin(c->d_counters, c->d_red, ntodo * 64, c->sr_hist, nbins + 1, B.results, nwords, c->stream, B.h_desc, B.d_desc, total, copy_by_flag ? c->sr_fetch_flag : nullptr, fetch_val);
+  c->sr_lists_owner = 0;                                      // (the begin kernel zeroes the counters and the histogram: they are nobody's until this pass's cull is queued)
+  if (copy_by_flag) series_queue_copy(c, *before, c->sr_fetch_flag, fetch_val);
+  if (copy_by_event) {
+    if (!c->sr_ev_fetched) HIP_TRY(c, hipEventCreateWithFlags(&c->sr_ev_fetched, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->sr_ev_fetched, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->sr_copy_stream, c->sr_ev_fetched, 0));
+    series_queue_copy(c, *before, nullptr, 0);
+  }
   if (dist && dist->masks_out) {
     // A slab pass with a lower neighbour: the FIRST slice's masks are that neighbour's halo.  They are built first, by a launch of their
     // own, and packed into the message right behind it -- the message can then cross xGMI (on the caller's side stream, which is made to
@@ -775,30 +787,13 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     m.hist = c->sr_hist; m.hist_shift = std::max(0, key_bits - bins_log2()); m.core_cells = P.cells;
   }
   if (const char *why = ftkx::wait_flag(flag, P.seq, c->stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
-  if (P.short_chain) {
-    const unsigned long long st = B.h_results[ftkx::SR_STATUS];
-    if ((st & ftkx::SERIES_TAIL_PENDING) && (c->sr_open > 0 || c->sr_lists_owner != P.uid)) {
-      // (the rest of this pass cannot be queued: the counters and lists are not this pass's any more -- the pass queued behind it has them
-      // now, or the host-driven batch took them when the pass BEFORE this one fell back (two short-chain passes that both declined,
-      // completed back to back).  The host-driven batch sweeps the steps; it happens when sparse data turns dense)
-      c->sr_short_chain = false;
-      ev_end(c);
-      int rc = series_by_host(c, P.ts.data(), P.scopes.data(), n, P.slice_ts, &running, factors, out, n_out);
-      if (rc == FTKX_OK) *running_resolution = running;
-      return rc;
-    }
-    if (st & ftkx::SERIES_TAIL_PENDING) {
-      const unsigned seq2 = ++ B.seq;
-      series_queue_rest(c, P, m, seq2);
-      HIP_TRY(c, hipGetLastError());
-      if (const char *why = ftkx::wait_flag(flag, seq2, c->stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
-    } else ev_end(c);
-  }
-  ev_harvest(c, false);
 
   // ---- what came back ----------------------------------------------------------------------------------------------------------------
+  // (whoever stored the flag -- the fused tail, finishing or declining, or the finish kernel -- copied the whole results block first: the
+  // reductions, the status, a slab pass's gathered contributions.  Everything below that does not depend on HOW the records get made comes
+  // first, so that every way out of this function has done it.)
   const u64 *R = B.h_results;
-  const unsigned long long status = R[ftkx::SR_STATUS];
+  unsigned long long status = R[ftkx::SR_STATUS];
   c->sr_last_status = status;
   // the masks and reductions of this pass stand whichever way the records are made: the slices are marked like ftkx_slices_prepare marks
   // them -- slice by slice, unless something has rebuilt or dropped its masks, or replaced it, since the pass was queued
@@ -833,10 +828,34 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     }
     if (status & ftkx::SERIES_HALO_FULL) {
       c->sr_short_chain = false;
+      if (P.short_chain) ev_end(c);
+      ev_harvest(c, false);
       *running_resolution = running;
       return fail(c, FTKX_E_NOSLICE, "slab pass: the halo slice %d is needed as a whole (request -1: too many surviving cells, a mask message that did not fit, or masks the host rebuilds): nothing was swept", P.t_halo);
     }
   }
+  if (P.short_chain) {
+    if ((status & ftkx::SERIES_TAIL_PENDING) && (c->sr_open > 0 || c->sr_lists_owner != P.uid)) {
+      // (the rest of this pass cannot be queued: the counters and lists are not this pass's any more -- the pass queued behind it has them
+      // now, or the host-driven batch took them when the pass BEFORE this one fell back (two short-chain passes that both declined,
+      // completed back to back).  The host-driven batch sweeps the steps; it happens when sparse data turns dense.  A slab pass: from the
+      // running minimum the lower ranks' contributions give, over a halo slice that has its patches -- both settled above)
+      c->sr_short_chain = false;
+      ev_end(c);
+      int rc = series_by_host(c, P.ts.data(), P.scopes.data(), n, P.slice_ts, &running, factors, out, n_out);
+      if (rc == FTKX_OK) *running_resolution = running;
+      return rc;
+    }
+    if (status & ftkx::SERIES_TAIL_PENDING) {
+      const unsigned seq2 = ++ B.seq;
+      series_queue_rest(c, P, m, seq2);
+      HIP_TRY(c, hipGetLastError());
+      if (const char *why = ftkx::wait_flag(flag, seq2, c->stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+      status = R[ftkx::SR_STATUS];                           // (the finish kernel's copy of the block: the same reductions, the final counters)
+      c->sr_last_status = status;
+    } else ev_end(c);
+  }
+  ev_harvest(c, false);
   const unsigned long long redo = ftkx::SERIES_AMBIGUOUS | ftkx::SERIES_MASKS_INVALID | ftkx::SERIES_INF | ftkx::SERIES_OVERFLOW;
   if (status & redo) {
     c->sr_short_chain = false;
@@ -865,7 +884,14 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
   ftkx_cp_t *H = B.out;
   if (P.to_device) {                                         // (the copy kernel; the mask kernel of the pass queued behind this one is running meanwhile)
     if (P.copy_pending) series_queue_copy(c, P, nullptr, 0);    // (no pass was queued behind this one)
-    if (const char *why = ftkx::wait_flag(flag + 2, P.seq, c->sr_copy_stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+    if (const char *why = ftkx::wait_flag(flag + 2, P.seq, c->sr_copy_stream)) {
+      // the copy stream drained without the flag: the copy kernel gave up waiting for the begin kernel of the pass queued behind this one (a
+      // caller that took seconds to submit it).  This pass itself is through -- its own flag was waited for above --, so the copy needs no
+      // wait now: once more, unconditionally
+      if (hipStreamQuery(c->sr_copy_stream) != hipSuccess) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+      series_queue_copy(c, P, nullptr, 0);
+      if (const char *why2 = ftkx::wait_flag(flag + 2, P.seq, c->sr_copy_stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why2);
+    }
     B.copy_out = false;                                      // (the copy is through: the pass that takes these buffers next need not wait for its event)
   }
   memset(&c->stats, 0, sizeof(c->stats));
@@ -917,6 +943,14 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
 
 }  // namespace
 
+// a slab pass between ftkx_series_dist_begin and _finish: its begin kernel has wiped the counters, its slot of sr_pend is taken, and it does
+// not count in sr_open yet -- no other pass may be queued, swept or completed until it has been finished (or aborted)
+static bool slab_half_queued(const ftkx_ctx *c)
+{
+  const ftkx_series_pending &Q = c->sr_pend[(c->sr_head + c->sr_open) & 1];
+  return Q.dist && Q.dist_stage > 0 && Q.dist_stage < 4;
+}
+
 extern "C" {
 
 int ftkx_sweep_series_submit(ftkx_ctx *c, const int *ts, const int *scopes, int n, const double *running_resolution)
@@ -925,6 +959,7 @@ int ftkx_sweep_series_submit(ftkx_ctx *c, const int *ts, const int *scopes, int 
   if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "sweep: call ftkx_set_mesh first");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: sweeps pending, collect first");
   if (c->sr_open >= 2) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: two passes are open, complete one first");
+  if (slab_half_queued(c)) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: a slab pass is half queued (ftkx_series_dist_finish or ftkx_sweep_series_abort first)");
   if (!running_resolution && c->sr_open == 0) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: no pass open to continue from, give the running resolution");
   if (running_resolution && !(*running_resolution > 0)) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: the running resolution must be positive (DBL_MAX: none yet)");
   c->ahead.clear(); c->announced.clear();
@@ -945,6 +980,7 @@ int ftkx_sweep_series_complete(ftkx_ctx *c, double *running_resolution, unsigned
   if (out) *out = nullptr;
   if (n_out) *n_out = 0;
   if (c->sr_open == 0) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_complete: no pass open");
+  if (slab_half_queued(c)) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_complete: a slab pass is half queued (ftkx_series_dist_finish or ftkx_sweep_series_abort first)");
   HIP_TRY(c, hipSetDevice(c->device));
   ftkx_series_pending &P = c->sr_pend[c->sr_head];
   c->sr_head ^= 1; c->sr_open --;
@@ -992,7 +1028,7 @@ int ftkx_series_dist_begin(ftkx_ctx *c, const int *ts, const int *scopes, int n,
   c->ahead.clear(); c->announced.clear();
   HIP_TRY(c, hipSetDevice(c->device));
   ftkx_series_pending &Q = c->sr_pend[(c->sr_head + c->sr_open) & 1];
-  if (Q.dist && Q.dist_stage > 0 && Q.dist_stage < 4) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: a slab pass is half queued (finish or abort it)");
+  if (slab_half_queued(c)) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: a slab pass is half queued (finish or abort it)");
   int rc;
   {
     Mesh m0; fill_mesh(c, m0);                               // (before anything is allocated for a halo slice that will not be used)
@@ -1126,7 +1162,7 @@ int ftkx_series_dist_status(const ftkx_ctx *c, long long *asked, long long *serv
 int ftkx_sweep_series_abort(ftkx_ctx *c)
 {
   if (!c) return FTKX_E_INVALID;
-  if (c->sr_open == 0) return FTKX_OK;
+  if (c->sr_open == 0 && !slab_half_queued(c)) return FTKX_OK;
   (void)hipSetDevice(c->device);
   // whatever the open passes queued runs to its end (their kernels write buffers that stay allocated); nothing of it is read
   hipError_t e = hipStreamSynchronize(c->stream);
@@ -1158,6 +1194,7 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "sweep: call ftkx_set_mesh first");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series: sweeps pending, collect first");
   if (c->sr_open) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series: passes open (ftkx_sweep_series_submit), complete them first");
+  if (slab_half_queued(c)) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series: a slab pass is half queued (ftkx_series_dist_finish or ftkx_sweep_series_abort first)");
   if (!(*running_resolution > 0)) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series: the running resolution must be positive (DBL_MAX: none yet)");
   if (n == 0) return FTKX_OK;
   c->ahead.clear(); c->announced.clear();

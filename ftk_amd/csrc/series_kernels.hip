@@ -283,7 +283,9 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
   const u64 SR = two_level ? (u64)(m.u_rows < 4 ? m.u_rows : 4) : 1ull, UQ = two_level ? (u64)m.u_rows / SR : 1ull;
   const u64 per = two_level ? (u64)kSmallPer : (u64)(kSmallPer * 32);
   const u64 units = count * UQ;
-  const bool is_redo = (results[SR_STATUS] & redo) != 0;  // the host takes this pass over anyway
+  // the host takes this pass over anyway: a flag of the factor job, or a slab pass abandoned by dist_cells_kernel (the halo slice is needed as
+  // a whole: it has no patches, or its mask import was rejected -- nothing may be swept, and nothing more than the block is reported)
+  const bool is_redo = (results[SR_STATUS] & (redo | (u64)SERIES_HALO_FULL)) != 0 || m.counters[CNT_SERIES_DONE] == 2ull;
   if (is_redo || units > per * (u64)kSmallGrid) {         // (the same for every workgroup) too much for this kernel: nothing has been changed
     if (report_decline && blockIdx.x == 0) {
       for (size_t i = tid; i < nwords; i += kThreads) h_results[i] = (i == (size_t)SR_STATUS && !is_redo) ? (results[i] | (u64)SERIES_TAIL_PENDING) : results[i];
@@ -718,18 +720,23 @@ __global__ __launch_bounds__(256) void series_copy_out_kernel(const ftkx_cp_t *_
   // the records' pass is then through (same stream, in order: no event needed, and none is recorded) and the next pass's descriptors have
   // been fetched over PCIe (a read queued behind this kernel's writes took 65 us instead of 4).  This kernel may well start while the
   // records' pass is still running: sixteen workgroups whose first lanes sleep and poll.  (The bound -- seconds -- only keeps a begin kernel
-  // that never ran from hanging the device: the copy then does not happen and the host is told so.)
+  // that never ran from hanging the device.)  Slab passes do not take this form: their begin kernel can sit behind a peer's messages, and
+  // the copy is ordered behind it by an event instead (series.hip, series_plan).
+  // A workgroup that gives up still arrives at the counter below (marked), so that the counter is left at zero and the flag is NOT stored:
+  // the host, which has waited for the records' pass itself by then, sees the copy stream drain without the flag and queues the copy again
+  // without a wait (series.hip, series_complete) -- a late begin kernel delays the records, it does not lose them.
+  __shared__ int s_gave_up;
+  if (threadIdx.x == 0) s_gave_up = 0;
   if (wait_flag) {
-    __shared__ int s_gave_up;
     if (threadIdx.x == 0) {
       unsigned it = 0;
       while (it < (1u << 23) && (int)(__hip_atomic_load(wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - wait_val) < 0) { __builtin_amdgcn_s_sleep(32); it ++; }
       s_gave_up = it == (1u << 23);
     }
-    __syncthreads();
-    if (s_gave_up) return;                                     // nothing copied, no flag: the host reports a stream that drained without the result
   }
-  u64 n = results[SR_NHITS];
+  __syncthreads();
+  const bool gave_up = s_gave_up != 0;
+  u64 n = gave_up ? 0ull : results[SR_NHITS];
   if (n > capacity) n = capacity;
   const size_t nvec = (size_t)n * sizeof(ftkx_cp_t) / 8;     // (72 bytes a record: nine words)
   const u64 *s = reinterpret_cast<const u64 *>(src);
@@ -746,11 +753,11 @@ __global__ __launch_bounds__(256) void series_copy_out_kernel(const ftkx_cp_t *_
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned before = atomicAdd(done, 1u);
-    if (before + 1 == gridDim.x) {
+    const unsigned before = atomicAdd(done, gave_up ? 0x10001u : 1u);      // (low half: arrivals; high half: workgroups that gave up)
+    if ((before & 0xffffu) + 1 == gridDim.x) {
       *done = 0;
       __threadfence_system();
-      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((before >> 16) == 0 && !gave_up) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

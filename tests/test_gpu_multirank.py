@@ -133,3 +133,34 @@ def test_the_collectives_run_on_rccl(tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
 
 
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python3 bench.py --gpus 3 --backend gloo --single-device --config small3` with NO launcher around it (the shape of the command the
+    driver runs for N = 1): the parent starts three fresh rank processes, rank 0's JSON line comes back with every rank accounted for, and
+    the merged records are the single-rank ones byte for byte.  A rank that dies ends the run at once, the others are not waited for."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one = _bench(1, "small3", dump=tmp_path / "one.npz")
+    cmd = [sys.executable, "bench.py", "--gpus", "3", "--backend", "gloo", "--single-device", "--config", "small3", "--steps", "2", "--warmup", "1",
+           "--no-other-scaling", "--dump-merged", str(tmp_path / "three.npz")]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "ONE JSON line"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["ranks"]["ranks_seen"] == 3 and out["ranks"]["backend"] == "gloo"
+    per = out["ranks"]["per_rank"]
+    assert [e["rank"] for e in per] == [0, 1, 2] and len(set(e["pid"] for e in per)) == 3, per
+    assert all(e["ms_per_step"] > 0 and e["pci_bus_id"] for e in per) and sum(e["timesteps"] for e in per) == 8
+    assert max(e["ms_per_step"] for e in per) <= out["ms_per_step"] * 1.0001, "the line's time is the slowest rank's"
+    assert all(e["slab_fallbacks"] == 0 for e in per) and "slab pass" in out["config"]["pass"] and out["check"]["ok"], (per, out["check"])
+    ref, got = np.load(tmp_path / "one.npz"), np.load(tmp_path / "three.npz")
+    assert got["records"].tobytes() == ref["records"].tobytes() and len(ref["records"]) == one["check"]["hits"] > 0
+    for k in ("curve_offsets", "curve_indices", "curve_loop"):
+        assert np.array_equal(got[k], ref[k]), k
+    # a rank that dies before it joins the process group: the other two wait in the rendezvous -- ended by the parent, exit code = the rank's
+    import time
+    t0 = time.time()
+    r = subprocess.run(cmd + ["--fail-rank", "2"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 7 and "rank(s) [2] failed" in r.stderr and time.time() - t0 < 120, (r.returncode, r.stderr[-2000:])
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())

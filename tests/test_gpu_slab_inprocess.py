@@ -262,3 +262,73 @@ def test_small_requests_force_the_whole_slice(gpu):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, FTKX_DIST_CELLS="2"))
     assert r.returncode == 0, r.stderr[-3000:]
     assert "recovered" in r.stdout
+
+
+@pytest.mark.parametrize("dense_boundary", [False, True])
+def test_sparse_slabs_turn_dense_with_two_passes_in_flight(gpu, dense_boundary):
+    """ADVICE r04 (series.hip, series_complete): a slab pass queued as a SHORT chain -- the fused tail finished the pass before it, so nothing
+    is queued behind the fused tail -- on data that has turned dense meanwhile, with another slab pass in flight behind it.  The fused tail
+    declines, the rest of the chain cannot be queued (the counters are the next pass's), the host-driven batch sweeps the steps: it must
+    start from the running minimum the LOWER ranks' contributions give, the halo's reduction must be recorded, ftkx_series_dist_status must
+    answer for THIS pass, and a halo that is needed as a whole (dense_boundary: request -1) must be reported as such, not swept empty."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(99 + int(dense_boundary))
+    nd, nv, dims, nt, world = 2, 1, (256, 64), 6, 2
+    sp = tuple(reversed(dims))
+    # sparse: one moving bowl -- a gradient that is large everywhere but around its one zero (a handful of cells survive the cull)
+    gy, gx = np.meshgrid(np.linspace(-1.0, 1.0, sp[0]), np.linspace(-1.0, 1.0, sp[1]), indexing="ij")
+    # (its zero stays where it is: a zero that crosses a grid row between two slices flips the one sign bit whole 8 x 4 summary blocks have
+    # in common, and the cells of those blocks -- more than a request of this size holds -- would ask for the slice as a whole)
+    sparse = [np.ascontiguousarray((1.0 + 0.125 * k) * ((gx - 0.13) ** 2 + (gy + 0.07) ** 2)) for k in range(nt)]
+    rough = _field(rng, (nt,) + sp, "rough")
+    # tiny values in the LATER slab: its resolution must reach the factors of ... nobody before it, but the first slab's must reach the second's
+    rough[0] = rough[0] * 2.0 ** -7
+    dense = list(rough) if dense_boundary else [rough[0], rough[1], sparse[2], sparse[3], rough[4], rough[5]]
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    try:
+        scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+        one = _make_ctx(gpu, nd, nv, dims, stream)
+        for t in range(nt):
+            one.push_scalar_slice(t, dense[t])
+        want, wf, _ = one.sweep_series(range(nt), scopes, copy=True)
+        wf = [int(v) for v in wf]
+        one.close()
+        assert len(want) > 4096
+        ranks = [Rank(gpu, torch, dev, stream, nd, nv, dims, sparse, nt, world, r) for r in range(world)]
+        try:
+            _slab_pass(ranks, 0)
+            _, recovered = _complete(ranks)
+            assert recovered == 0
+            for r in ranks:
+                assert r.ctx.series_last_path()[0] == 2, "the sparse pass was finished by the fused tail: the next one is queued as a short chain"
+            for r in ranks:                                  # the data turns dense
+                for t in r.own:
+                    a = torch.from_numpy(np.ascontiguousarray(dense[t])).to(dev)
+                    r.dev_slices[t] = a
+                    r.ctx.push_scalar_slice(t, a)
+            _slab_pass(ranks, 0)
+            _slab_pass(ranks, 1)
+            first, rec1 = _complete(ranks)
+            paths = [r.ctx.series_last_path()[0] for r in ranks]
+            second, rec2 = _complete(ranks)
+            if dense_boundary:
+                assert rec1 >= 1, "the halo was needed as a whole: reported by the declining fused tail, recovered by the caller"
+            else:
+                assert rec1 == 0 and 0 in paths, (rec1, paths, "a rank's short-chain pass fell back to the host-driven batch with its halo patched")
+            for results in (first, second):
+                merged = np.concatenate([res[0] for _, res in results])
+                merged = merged[np.argsort(merged["tag"], kind="stable")]
+                got_f = {}
+                for r, res in results:
+                    for t, f in zip(r.own, res[1]):
+                        got_f[t] = f
+                assert [got_f[t] for t in range(nt)] == wf, ([got_f[t] for t in range(nt)], wf)
+                assert merged.tobytes() == np.ascontiguousarray(want).tobytes()
+        finally:
+            for r in ranks:
+                if r.ctx is not None:
+                    r.ctx.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
