@@ -619,6 +619,16 @@ class _TrackerRegular:
         self._deferred = bool(b)
         self._ck(self._L.ftkx_tracker_set_deferred_collection(self._h, int(bool(b))))
 
+    # several ranks behind the tracker (include/ftkx_tracker.hh: slab mode): this rank's tracker takes the snapshots of its timestep slab
+    # (tslab.slab_range), sweeps it as one device-driven pass, finalize() gathers the points on rank 0.  Pushed device tensors are kept alive.
+    def set_communicator(self, nccl_comm, rank, nranks, nt):
+        self._slab_keep = []
+        self._ck(self._L.ftkx_tracker_set_communicator(self._h, nccl_comm, int(rank), int(nranks), int(nt)))
+
+    def set_slab_hub(self, hub, rank, nt):
+        self._slab_keep = []
+        self._ck(self._L.ftkx_tracker_set_slab_hub(self._h, hub, int(rank), int(nt)))
+
     def set_enable_streaming_trajectories(self, b): self._ck(self._L.ftkx_tracker_set_enable_streaming_trajectories(self._h, int(bool(b))))
     def set_coords_bounds(self, b): self._ck(self._L.ftkx_tracker_set_coords_bounds(self._h, (C.c_double * len(b))(*[float(x) for x in b])))
 
@@ -655,6 +665,8 @@ class _TrackerRegular:
 
     def advance_timestep(self):
         self._ck(self._L.ftkx_tracker_advance_timestep(self._h))
+        if hasattr(self, "_slab_keep"):             # slab mode: the snapshots stay resident until the slab's pass has run
+            self._slab_keep += self._keep
         self._keep = self._keep[-(3 if getattr(self, "_deferred", False) else 2):]
 
     def update_timestep(self): self._ck(self._L.ftkx_tracker_update_timestep(self._h))

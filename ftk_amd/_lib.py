@@ -40,6 +40,42 @@ class Trajectories(C.Structure):
                 ("loop", C.POINTER(C.c_int)), ("type", C.POINTER(C.c_uint)), ("t", C.POINTER(C.c_double)), ("id", C.POINTER(C.c_int))]
 
 
+# include/ftkx_slab.h: the tables a caller hands to ftkx_slab_create / ftkx_slab_create_custom
+AG_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+XCHG_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+DESTROY_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class SlabTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather", AG_FN), ("exchange", XCHG_FN), ("queued", C.c_int), ("destroy", DESTROY_FN)]
+
+
+BEGIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+CULL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+FINISH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+COMPLETE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
+STATUS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong))
+RECOVER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), C.POINTER(C.c_void_p),
+                         C.POINTER(C.c_size_t))
+FIRST_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int)
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+COPY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+ABORT_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class SlabBackend(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("begin", BEGIN_FN), ("cull", CULL_FN), ("serve", CULL_FN), ("finish", FINISH_FN), ("complete", COMPLETE_FN), ("status", STATUS_FN),
+                ("recover", RECOVER_FN), ("first_slice", FIRST_FN), ("alloc", ALLOC_FN), ("release", RELEASE_FN), ("upload", COPY_FN), ("download", COPY_FN), ("abort", ABORT_FN),
+                ("masks_bytes", C.c_size_t), ("cells", C.c_size_t), ("patch_doubles", C.c_size_t), ("slice_bytes", C.c_size_t), ("stream", C.c_void_p), ("device", C.c_int)]
+
+
+class SlabInfo(C.Structure):
+    _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("t0", C.c_int), ("t1", C.c_int), ("lower", C.c_int), ("upper", C.c_int), ("bytes_sent", C.c_ulonglong),
+                ("bytes_received", C.c_ulonglong), ("fallbacks", C.c_int), ("last_asked", C.c_longlong), ("last_served", C.c_longlong), ("last_path", C.c_int),
+                ("last_status", C.c_ulonglong), ("open", C.c_int)]
+
+
 class FtkxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"ftkx error {code}: {msg}")
@@ -53,11 +89,15 @@ EXPORTS = [
     "ftkx_trace_curves", "ftkx_trace_curves_ctx", "ftkx_trace_curves_tags_ctx", "ftkx_free_curves", "ftkx_post_process_curves", "ftkx_free_trajectories", "ftkx_format_from_path", "ftkx_write_critical_points", "ftkx_read_critical_points", "ftkx_write_traced_critical_points", "ftkx_read_traced_critical_points", "ftkx_gradient2D", "ftkx_jacobian2D", "ftkx_gradient3D", "ftkx_jacobian3D", "ftkx_version", "ftkx_device_count", "ftkx_pointer_device", "ftkx_context_device", "ftkx_last_mask_kernel",
     "ftkx_tracker_post_process", "ftkx_tracker_get_curve_points", "ftkx_tracker_write", "ftkx_tracker_read_critical_points",
     "ftkx_tracker_create", "ftkx_tracker_create_multi", "ftkx_tracker_sync", "ftkx_tracker_destroy", "ftkx_tracker_last_error", "ftkx_tracker_set_domain", "ftkx_tracker_set_array_domain",
-    "ftkx_tracker_set_sources", "ftkx_tracker_set_flags", "ftkx_tracker_set_stream", "ftkx_tracker_set_current_timestep", "ftkx_tracker_set_enable_streaming_trajectories", "ftkx_tracker_set_deferred_collection", "ftkx_online_tracer_create", "ftkx_online_tracer_destroy", "ftkx_online_tracer_grow", "ftkx_online_tracer_curves", "ftkx_tracker_set_coords_bounds", "ftkx_tracker_set_coords_rectilinear", "ftkx_tracker_set_coords_explicit", "ftkx_set_coords_rectilinear", "ftkx_set_coords_explicit", "ftkx_tracker_initialize",
+    "ftkx_tracker_set_sources", "ftkx_tracker_set_flags", "ftkx_tracker_set_stream", "ftkx_tracker_set_current_timestep", "ftkx_tracker_set_enable_streaming_trajectories", "ftkx_tracker_set_deferred_collection", "ftkx_tracker_set_communicator", "ftkx_tracker_set_slab_transport", "ftkx_tracker_set_slab_hub", "ftkx_online_tracer_create", "ftkx_online_tracer_destroy", "ftkx_online_tracer_grow", "ftkx_online_tracer_curves", "ftkx_tracker_set_coords_bounds", "ftkx_tracker_set_coords_rectilinear", "ftkx_tracker_set_coords_explicit", "ftkx_set_coords_rectilinear", "ftkx_set_coords_explicit", "ftkx_tracker_initialize",
     "ftkx_tracker_push_scalar_field_snapshot", "ftkx_tracker_push_vector_field_snapshot", "ftkx_tracker_push_field_data_snapshot",
     "ftkx_tracker_advance_timestep", "ftkx_tracker_update_timestep", "ftkx_tracker_num_critical_points",
     "ftkx_tracker_get_critical_points", "ftkx_tracker_get_scaling", "ftkx_tracker_get_stats",
     "ftkx_tracker_finalize", "ftkx_tracker_num_curves", "ftkx_tracker_get_curves",
+    # include/ftkx_slab.h
+    "ftkx_slab_range", "ftkx_slab_owner", "ftkx_slab_create", "ftkx_slab_create_custom", "ftkx_slab_create_rccl", "ftkx_slab_destroy", "ftkx_slab_submit", "ftkx_slab_complete",
+    "ftkx_slab_gather_records", "ftkx_slab_get_info", "ftkx_slab_last_error", "ftkx_rccl_unique_id", "ftkx_rccl_comm_create", "ftkx_rccl_comm_destroy", "ftkx_rccl_version",
+    "ftkx_slab_transport_rccl", "ftkx_upload", "ftkx_download", "ftkx_slab_hub_create", "ftkx_slab_hub_destroy", "ftkx_slab_create_local", "ftkx_slab_hub_abort",
 ]
 
 _L = None
@@ -131,6 +171,9 @@ def load():
     L.ftkx_tracker_set_current_timestep.argtypes = [vp, C.c_int]
     L.ftkx_tracker_set_enable_streaming_trajectories.argtypes = [vp, C.c_int]
     L.ftkx_tracker_set_deferred_collection.argtypes = [vp, C.c_int]
+    L.ftkx_tracker_set_communicator.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    L.ftkx_tracker_set_slab_transport.argtypes = [vp, C.POINTER(SlabTransport), C.c_int, C.c_int, C.c_int]
+    L.ftkx_tracker_set_slab_hub.argtypes = [vp, vp, C.c_int, C.c_int]
     L.ftkx_online_tracer_create.argtypes = [C.POINTER(vp), C.c_int, ll3, ll3]
     L.ftkx_online_tracer_destroy.argtypes = [vp]
     L.ftkx_online_tracer_destroy.restype = None
@@ -189,6 +232,28 @@ def load():
     L.ftkx_tracker_get_curve_points.argtypes = [vp, vp, vp, vp]
     L.ftkx_tracker_write.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     L.ftkx_tracker_read_critical_points.argtypes = [vp, C.c_char_p, C.c_int]
+    L.ftkx_slab_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]; L.ftkx_slab_range.restype = None
+    L.ftkx_slab_owner.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.ftkx_slab_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(SlabTransport), C.POINTER(vp)]
+    L.ftkx_slab_create_custom.argtypes = [C.POINTER(SlabBackend), C.c_int, C.c_int, C.c_int, C.POINTER(SlabTransport), C.POINTER(vp)]
+    L.ftkx_slab_create_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(vp)]
+    L.ftkx_slab_destroy.argtypes = [vp]; L.ftkx_slab_destroy.restype = None
+    L.ftkx_slab_submit.argtypes = [vp, C.POINTER(C.c_double)]
+    L.ftkx_slab_complete.argtypes = [vp, C.POINTER(C.c_double), vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ftkx_slab_gather_records.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ftkx_slab_get_info.argtypes = [vp, C.POINTER(SlabInfo)]
+    L.ftkx_slab_last_error.argtypes = [vp]; L.ftkx_slab_last_error.restype = C.c_char_p
+    L.ftkx_rccl_unique_id.argtypes = [vp]
+    L.ftkx_rccl_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ftkx_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    L.ftkx_download.argtypes = [vp, vp, vp, C.c_size_t]
+    L.ftkx_rccl_comm_destroy.argtypes = [vp]; L.ftkx_rccl_comm_destroy.restype = None
+    L.ftkx_rccl_version.argtypes = []
+    L.ftkx_slab_transport_rccl.argtypes = [vp, vp, C.POINTER(SlabTransport)]
+    L.ftkx_slab_hub_create.argtypes = [C.c_int]; L.ftkx_slab_hub_create.restype = vp
+    L.ftkx_slab_hub_destroy.argtypes = [vp]; L.ftkx_slab_hub_destroy.restype = None
+    L.ftkx_slab_hub_abort.argtypes = [vp]; L.ftkx_slab_hub_abort.restype = None
+    L.ftkx_slab_create_local.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     _L = L
     return L
 

@@ -52,19 +52,20 @@ void launch_cull_coarse(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d
 void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream);
 void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st,
                          const void *desc_src = nullptr, void *desc_dst = nullptr, size_t desc_bytes = 0, unsigned *fetched = nullptr, unsigned fetched_val = 0);
+void launch_series_one(const Mesh &m, const OneArgs &a, int nwg, hipStream_t st);
+void launch_series_tail_begin(u64 *counters, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st);
 void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,
                            double safe_m, u64 *results, u64 *counters, hipStream_t st);
 void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff, u64 *sorted, u64 *results, hipStream_t st);
 void launch_bucket_scan(unsigned *hist, unsigned *boff, unsigned nbins, u64 *counters, hipStream_t st);
 void launch_bucket_scatter(const Mesh &m, unsigned *boff, u64 *bucketed, hipStream_t st);
-void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, const u64 *base_from, hipStream_t st);
+void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, hipStream_t st);
 Mesh coarse_view(const Mesh &m);
 void launch_series_small(const Mesh &m, const Mesh &mc, const Fields *d_steps, bool two_level, const u64 *d_refine, const u64 *d_list, ftkx_cp_t *out,
                          u64 *results, size_t nwords, u64 *h_results, unsigned *flag, unsigned seq, unsigned *done, bool report_decline, hipStream_t st);
 void launch_series_copy_out(const ftkx_cp_t *src, ftkx_cp_t *dst, u64 capacity, const u64 *results, unsigned *done, unsigned *flag, unsigned seq, hipStream_t st,
                             const unsigned *wait_flag = nullptr, unsigned wait_val = 0);
-void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, const u64 *base_from,
-                          hipStream_t st);
+void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, hipStream_t st);
 // dist_kernels.hip: the slab pass
 void launch_dist_contrib(const SeriesSlice *slices, int nown, const u64 *red, u64 *contrib, u64 *block, hipStream_t st);
 void launch_dist_export(const Mesh &m, const unsigned char *U, const unsigned char *M, u64 u_bytes, u64 *hdr, unsigned *idx, u64 *words, u64 capacity, int factor_log2, u64 *block, hipStream_t st);
@@ -121,19 +122,6 @@ enum { K_MASK = 0, K_CULL = 1, K_EXACT = 2, K_TILE = 3, K_N = 4 };
 
 }  // namespace ftkxh
 
-// One chunk of a chunked series pass (series.hip): everything a chunk's tail -- cull, factors, exact test, ordering, records -- writes, so
-// that the tail of chunk k runs on its own stream next to the mask kernel of chunk k + 1.
-struct ftkx_series_slot {
-  hipStream_t stream = nullptr;
-  hipEvent_t ev_masks = nullptr, ev_factors = nullptr, ev_done = nullptr;
-  u64 *counters = nullptr;                      // CNT_N words
-  u64 *list = nullptr, *refine = nullptr, *pass = nullptr, *fragile = nullptr, *bucketed = nullptr, *sorted = nullptr, *results = nullptr, *h_results = nullptr;
-  u64 list_cap = 0, refine_cap = 0, capacity = 0, fragile_cap = 0;
-  unsigned *hist = nullptr, *boff = nullptr;
-  size_t bins_cap = 0, results_cap = 0, h_results_cap = 0;
-  unsigned seq = 0;
-};
-
 // A series pass that has been queued (ftkx_sweep_series_submit) and not yet collected (ftkx_sweep_series_complete): what the second half
 // of the call needs.  Two may be open at a time: the host prepares and queues pass N + 1 while the device still works on pass N, and the
 // records of pass N cross PCIe (a copy engine, not a kernel) while the mask kernel of pass N + 1 runs.
@@ -158,6 +146,11 @@ struct ftkx_series_pending {
   const u64 *running_from = nullptr;   // a results block on the device whose SR_RUNNING word this pass continues from (the pass before it, or a slab pass's stub)
   bool pipelined = false;
   bool refined = false;             // the refine kernel has been queued already (a slab pass lists the halo's cells from its output)
+  // split pass (series.hip, "the tail next to the next mask kernel"): begin + masks on the context's stream, the tail -- counters, cull + factors,
+  // fused tail -- on the tail stream behind an event; the pass queued behind it starts its mask kernel when THIS pass's cull is through
+  bool split = false;
+  bool one = false;                 // the one-launch pass for small series (one_kernel.hip)
+  std::vector<std::pair<unsigned char *, unsigned char *>> retired;   // (M, U) arrays this pass still reads, replaced in their slices by the pass queued behind it
   // slab pass (ftkx_series_dist_*): one rank's part of a series cut into timestep slabs, queued in stages with the caller's collectives between them
   bool dist = false;
   int dist_stage = 0;               // 1 begun (masks, contribution, outgoing masks), 2 culled (request written), 3 served (reply written), 4 finished = open
@@ -176,6 +169,8 @@ struct ftkx_series_buffers {
   ftkx_cp_t *d_out = nullptr; size_t d_out_cap = 0;   // device: the records of a pass whose way over PCIe is left to the copy kernel on its own stream
   unsigned *copy_done = nullptr;                       // that kernel's workgroup counter
   hipEvent_t ev_copied = nullptr, ev_export = nullptr;
+  hipEvent_t ev_masks = nullptr, ev_cull = nullptr, ev_tail = nullptr;   // split pass: masks done (stream), cull done / tail done (tail stream)
+  u64 *red = nullptr; size_t red_cap = 0;             // the reduction slots of this pass's mask jobs (128 words per slice): its own, the next pass's begin kernel must not wipe them
   bool copy_out = false;                               // a copy has been queued since the buffers were last used: the next record kernel waits for it
   void *h_desc = nullptr, *d_desc = nullptr; size_t desc_cap = 0;
   u64 *dist_block = nullptr;                           // slab pass: DB_N words (sweep_params.hpp)
@@ -255,7 +250,9 @@ struct ftkx_ctx {
   // cull is queued, cleared whenever the host-driven batch takes them (series.hip: a pass whose fused tail declined may queue the rest of
   // its chain only while they are still its own)
   unsigned long long sr_pass_uid = 0, sr_lists_owner = 0;
-  hipStream_t sr_copy_stream = nullptr, sr_fetch_stream = nullptr;
+  hipStream_t sr_copy_stream = nullptr, sr_fetch_stream = nullptr, sr_tail_stream = nullptr;
+  int sr_one_off = 0;                  // passes for which the one-launch form is not tried (it declined a moment ago)
+  u64 *sr_one_scratch = nullptr;       // the one-launch pass's barrier counters, partial reductions and per-workgroup counts (ONE_WORDS)
   unsigned *sr_fetch_flag = nullptr;   // device: [0] the number of the last pass whose descriptors have been fetched (series_begin_kernel), [1] its arrival counter
   unsigned sr_fetch_seq = 0;
   hipEvent_t sr_ev_fetched = nullptr;  // slab passes: recorded behind the begin kernel, waited for by the copy of the pass before (no spin-wait there)
@@ -267,7 +264,6 @@ struct ftkx_ctx {
   size_t sr_bucketed_cap = 0;
   u64 *sr_sorted = nullptr;
   size_t sr_sorted_cap = 0;
-  std::vector<ftkx_series_slot> sr_slots;   // chunked pass: one slot per chunk
   int sr_skip_small = 0;             // passes for which the fused tail kernel is not launched (the data was hit-dense a moment ago)
   int sr_late_streak = 0;            // consecutive passes the fused tail declined late
   bool sr_short_chain = false;       // the last pass was finished by the fused tail kernel: the next one is queued without the kernels behind it

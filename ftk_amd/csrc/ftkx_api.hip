@@ -384,21 +384,18 @@ void ftkx_destroy(ftkx_ctx *c)
     for (void *p : {(void *)B.results, (void *)B.d_out, B.d_desc, (void *)B.copy_done, (void *)B.dist_block}) if (p) (void)hipFree(p);
     if (B.ev_copied) (void)hipEventDestroy(B.ev_copied);
     if (B.ev_export) (void)hipEventDestroy(B.ev_export);
+    for (hipEvent_t e : {B.ev_masks, B.ev_cull, B.ev_tail}) if (e) (void)hipEventDestroy(e);
+    if (B.red) (void)hipFree(B.red);
     for (void *p : {(void *)B.h_results, (void *)B.out, B.h_desc}) if (p) (void)hipHostFree(p);
   }
   if (c->sr_copy_stream) (void)hipStreamDestroy(c->sr_copy_stream);
+  if (c->sr_tail_stream) (void)hipStreamDestroy(c->sr_tail_stream);
+  if (c->sr_one_scratch) (void)hipFree(c->sr_one_scratch);
   if (c->sr_fetch_flag) (void)hipFree(c->sr_fetch_flag);
   if (c->sr_ev_fetched) (void)hipEventDestroy(c->sr_ev_fetched);
   if (c->sr_fetch_stream) (void)hipStreamDestroy(c->sr_fetch_stream);
   for (void *p : {c->tr_dev, c->tr_parent, c->tr_tables}) if (p) (void)hipFree(p);
   if (c->tr_host) (void)hipHostFree(c->tr_host);
-  for (ftkx_series_slot &sl : c->sr_slots) {
-    if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
-    for (hipEvent_t e : {sl.ev_masks, sl.ev_factors, sl.ev_done}) if (e) (void)hipEventDestroy(e);
-    for (void *p : {(void *)sl.counters, (void *)sl.list, (void *)sl.refine, (void *)sl.pass, (void *)sl.fragile, (void *)sl.bucketed, (void *)sl.sorted, (void *)sl.results, (void *)sl.hist, (void *)sl.boff})
-      if (p) (void)hipFree(p);
-    if (sl.h_results) (void)hipHostFree(sl.h_results);
-  }
   if (c->d_list) (void)hipFree(c->d_list);
   if (c->d_refine) (void)hipFree(c->d_refine);
   if (c->d_sorted) (void)hipFree(c->d_sorted);

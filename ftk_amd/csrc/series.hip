@@ -30,6 +30,9 @@ int series_by_host(ftkx_ctx *c, const int *ts, const int *scopes, int n, const s
 {
   c->sr_last_path = 0;
   c->sr_lists_owner = 0;                                      // (the batch takes the counters and the survivor lists over)
+  // (... from whatever still runs on the tail stream: the tail of a split pass queued behind the one the batch sweeps for shares them in
+  // STREAM order only with its own stream -- it must be through before the batch's kernels start on the context's stream)
+  if (c->sr_tail_stream) HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream));
   struct Through { ftkx_ctx *c; bool was; ~Through() { c->sr_internal = was; } } through{c, c->sr_internal};
   c->sr_internal = true;
   const unsigned long long hint = std::max<unsigned long long>(factor_of(*running), 256ull);
@@ -69,280 +72,6 @@ int bins_log2()
 {
   static const int v = [] { const char *e = getenv("FTKX_SERIES_BINS_LOG2"); const int b = e ? atoi(e) : 0; return b >= 8 && b <= 16 ? b : 14; }();
   return v;
-}
-
-int slot_prepare(ftkx_ctx *c, ftkx_series_slot &sl, size_t nbins, size_t nwords)
-{
-  int rc;
-  if (!sl.stream) {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    HIP_TRY(c, hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, hi));     // (the tails are latency chains: they go first wherever a slot frees up)
-    for (hipEvent_t *e : {&sl.ev_masks, &sl.ev_factors, &sl.ev_done}) HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
-    HIP_TRY(c, hipMalloc((void **)&sl.counters, (size_t)(ftkx::CNT_N + 128 + 8) * sizeof(u64)));      // (as ftkx_ctx::d_counters: the words behind the counters hold a kernel's queue)
-    HIP_TRY(c, hipMemsetAsync(sl.counters, 0, (size_t)(ftkx::CNT_N + 128 + 8) * sizeof(u64), c->stream));
-  }
-  size_t cap;
-  cap = (size_t)sl.list_cap; if ((rc = grow_device(c, &sl.list, &cap, std::max<size_t>(cap, 1u << 20)))) return rc; sl.list_cap = cap;
-  cap = (size_t)sl.refine_cap; if ((rc = grow_device(c, &sl.refine, &cap, std::max<size_t>(cap, 1u << 20)))) return rc; sl.refine_cap = cap;
-  if (sl.capacity < (1u << 16)) {
-    for (void *p : {(void *)sl.pass, (void *)sl.bucketed, (void *)sl.sorted}) if (p) (void)hipFree(p);
-    sl.pass = sl.bucketed = sl.sorted = nullptr; sl.capacity = 0;
-  }
-  if (!sl.pass) {
-    const size_t want = std::max<size_t>((size_t)sl.capacity, 1u << 16);
-    HIP_TRY(c, hipMalloc((void **)&sl.pass, want * sizeof(u64)));
-    HIP_TRY(c, hipMalloc((void **)&sl.bucketed, want * sizeof(u64)));
-    HIP_TRY(c, hipMalloc((void **)&sl.sorted, want * sizeof(u64)));
-    sl.capacity = want;
-  }
-  cap = (size_t)sl.fragile_cap; if ((rc = grow_device(c, &sl.fragile, &cap, std::max<size_t>(cap * 10, (size_t)(1u << 12) * 10)))) return rc; sl.fragile_cap = cap / 10;
-  if (sl.bins_cap < nbins + 1) {
-    for (void *p : {(void *)sl.hist, (void *)sl.boff}) if (p) (void)hipFree(p);
-    sl.hist = sl.boff = nullptr; sl.bins_cap = 0;
-    const size_t want = std::max<size_t>(nbins + 1, (1u << 16) + 1);
-    HIP_TRY(c, hipMalloc((void **)&sl.hist, want * sizeof(unsigned)));
-    HIP_TRY(c, hipMalloc((void **)&sl.boff, want * sizeof(unsigned)));
-    sl.bins_cap = want;
-  }
-  if ((rc = grow_device(c, &sl.results, &sl.results_cap, std::max<size_t>(nwords, 1024)))) return rc;
-  const size_t h_words = nwords + (size_t)sl.fragile_cap * 10;
-  if (sl.h_results_cap < h_words) {
-    if (sl.h_results) { HIP_TRY(c, hipStreamSynchronize(sl.stream)); (void)hipHostFree(sl.h_results); sl.h_results = nullptr; sl.h_results_cap = 0; }
-    const size_t want = h_words + h_words / 4 + 1024;
-    HIP_TRY(c, hipHostMalloc((void **)&sl.h_results, (want + 8) * sizeof(u64), hipHostMallocCoherent));
-    sl.h_results_cap = want;
-    *reinterpret_cast<volatile unsigned *>(sl.h_results + want) = 0u;
-    sl.seq = 0;
-  }
-  return FTKX_OK;
-}
-
-// The pass in chunks of consecutive steps.  Hit-dense data: the tail of a pass -- cull, exact test, ordering, records and their way over
-// PCIe -- is work in proportion to the hits, not a fixed latency, and the mask kernel does not need it: the tail of chunk k runs on a
-// stream of its own, next to the mask kernel of chunk k + 1 on the context's stream.  Every chunk has its own counters, lists and results
-// block (ftkx_series_slot); what links them is on the device: a chunk's factor kernel takes the running minimum from the results of the
-// chunk before it, its record kernel the place where its records start.  Returns 1 if the pass was done here, 0 if the caller should do
-// it in one piece (a kernel raised a flag: the host-driven batch takes over), a negative code on errors.
-int series_chunked(ftkx_ctx *c, int nchunks, const int *ts, const int *scopes, int n, const std::vector<int> &slice_ts, std::vector<Slice *> &sl, std::vector<int> &red_index,
-                   size_t ntodo, bool two_level, u64 cells, unsigned long long hint, double *running_resolution, unsigned long long *factors, const ftkx_cp_t **out, size_t *n_out)
-{
-  const int nd = c->nd;
-  const size_t k = sl.size();
-  int rc;
-  if ((int)c->sr_slots.size() < nchunks) c->sr_slots.resize((size_t)nchunks);
-  // the chunks: steps [b[q], b[q + 1]), their slices [j0[q], j1[q]] of the time-ordered slice list, the mask jobs [r0[q], r1[q]) that are theirs
-  std::vector<int> b((size_t)nchunks + 1), j0((size_t)nchunks), j1((size_t)nchunks), r0((size_t)nchunks), r1((size_t)nchunks);
-  for (int q = 0; q <= nchunks; q ++) b[(size_t)q] = (int)((long long)n * q / nchunks);
-  int r_seen = 0, j_seen = -1;
-  for (int q = 0; q < nchunks; q ++) {
-    const int first = b[(size_t)q], last = b[(size_t)q + 1] - 1;
-    j0[(size_t)q] = (int)(std::lower_bound(slice_ts.begin(), slice_ts.end(), ts[first]) - slice_ts.begin());
-    j1[(size_t)q] = (int)(std::lower_bound(slice_ts.begin(), slice_ts.end(), ts[last] + ((scopes[last] & FTKX_SCOPE_INTERVAL) ? 1 : 0)) - slice_ts.begin());
-    r0[(size_t)q] = r_seen;
-    for (int j = std::max(j_seen + 1, j0[(size_t)q]); j <= j1[(size_t)q]; j ++) if (red_index[(size_t)j] >= 0) r_seen = red_index[(size_t)j] + 1;
-    r1[(size_t)q] = r_seen;
-    j_seen = std::max(j_seen, j1[(size_t)q]);
-  }
-  // buffers
-  for (size_t j = 0; j < k; j ++) if (red_index[j] >= 0 && (rc = ensure_mask_arrays(c, *sl[j], two_level))) return rc;
-  if (c->red_cap < std::max<size_t>(ntodo, 1)) {
-    if (c->d_red) { (void)hipFree(c->d_red); c->d_red = nullptr; c->red_cap = 0; }
-    HIP_TRY(c, hipMalloc((void **)&c->d_red, std::max<size_t>(ntodo, 1) * 128 * sizeof(u64)));
-    c->red_cap = std::max<size_t>(ntodo, 1);
-  }
-  std::vector<int> shift((size_t)nchunks);
-  std::vector<size_t> nbins((size_t)nchunks), nwords((size_t)nchunks);
-  size_t total_cap = 0;
-  for (int q = 0; q < nchunks; q ++) {
-    const int nq = b[(size_t)q + 1] - b[(size_t)q], kq = j1[(size_t)q] - j0[(size_t)q] + 1;
-    const u64 max_key = (u64)nq * cells * 64ull;
-    int key_bits = 1;
-    while (key_bits < 63 && (1ull << key_bits) < max_key) key_bits ++;
-    shift[(size_t)q] = std::max(0, key_bits - bins_log2());
-    nbins[(size_t)q] = (size_t)((max_key - 1) >> shift[(size_t)q]) + 1;
-    nwords[(size_t)q] = (size_t)ftkx::SR_HEAD + (size_t)nq + 2 * (size_t)kq;
-    if ((rc = slot_prepare(c, c->sr_slots[(size_t)q], nbins[(size_t)q], nwords[(size_t)q]))) return rc;
-    total_cap += (size_t)c->sr_slots[(size_t)q].capacity;
-  }
-  if ((rc = ensure_host_buffer(c, total_cap))) return rc;
-  // descriptors: mask jobs | steps | per chunk: slice table, step table
-  size_t total = 0;
-  const size_t off_jobs = 0; total += align256(ntodo * sizeof(MaskJob));
-  const size_t off_steps = total; total += align256((size_t)n * sizeof(Fields));
-  std::vector<size_t> off_slices((size_t)nchunks), off_sinfo((size_t)nchunks);
-  for (int q = 0; q < nchunks; q ++) {
-    off_slices[(size_t)q] = total; total += align256((size_t)(j1[(size_t)q] - j0[(size_t)q] + 1) * sizeof(ftkx::SeriesSlice));
-    off_sinfo[(size_t)q] = total; total += align256((size_t)(b[(size_t)q + 1] - b[(size_t)q]) * sizeof(ftkx::SeriesStep));
-  }
-  if ((rc = ensure_desc(c, total))) return rc;
-  {
-    MaskJob *jobs = (MaskJob *)((char *)c->h_desc + off_jobs);
-    Fields *steps = (Fields *)((char *)c->h_desc + off_steps);
-    const double cap = 1.0 / (double)hint;
-    for (size_t j = 0; j < k; j ++)
-      if (red_index[j] >= 0) { const Slice &s = *sl[j]; jobs[red_index[j]] = MaskJob{s.S, s.V, s.M, two_level ? s.U : nullptr, c->d_red + (size_t)red_index[j] * 128, cap, HUGE_VAL}; }      // (the chunked pass: thresholds found by the kernel)
-    for (int i = 0; i < n; i ++) {
-      const size_t ja = (size_t)(std::lower_bound(slice_ts.begin(), slice_ts.end(), ts[i]) - slice_ts.begin());
-      const bool interval = (scopes[i] & FTKX_SCOPE_INTERVAL) != 0;
-      const Slice &s0 = *sl[ja];
-      Fields f;
-      memset(&f, 0, sizeof(f));
-      f.S[0] = s0.S; f.V[0] = s0.V; f.J[0] = s0.J; f.M[0] = s0.M; f.U[0] = two_level ? s0.U : nullptr;
-      if (interval) { const Slice &s1 = *sl[ja + 1]; f.S[1] = s1.S; f.V[1] = s1.V; f.J[1] = s1.J; f.M[1] = s1.M; f.U[1] = two_level ? s1.U : nullptr; }
-      f.factor = 0.0; f.t = ts[i]; f.scope_mask = scopes[i];
-      steps[i] = f;
-    }
-    for (int q = 0; q < nchunks; q ++) {
-      ftkx::SeriesSlice *ss = (ftkx::SeriesSlice *)((char *)c->h_desc + off_slices[(size_t)q]);
-      ftkx::SeriesStep *si = (ftkx::SeriesStep *)((char *)c->h_desc + off_sinfo[(size_t)q]);
-      for (int j = j0[(size_t)q]; j <= j1[(size_t)q]; j ++) {
-        const Slice &s = *sl[(size_t)j];
-        ftkx::SeriesSlice &e = ss[j - j0[(size_t)q]];
-        e.t = slice_ts[(size_t)j]; e.red_index = red_index[(size_t)j];
-        e.known_res = DBL_MAX; e.known_max = 0.0; e.from_res = nullptr; e.from_max = nullptr;
-        if (s.have_res) { e.known_res = s.res < cap ? s.res : DBL_MAX; e.known_max = s.maxabs; }
-        else if (red_index[(size_t)j] < 0) { e.known_res = s.res_below; e.known_max = s.maxabs; }
-      }
-      int last = 0;
-      for (int i = b[(size_t)q]; i < b[(size_t)q + 1]; i ++) {
-        const int ja = (int)(std::lower_bound(slice_ts.begin(), slice_ts.end(), ts[i]) - slice_ts.begin());
-        const bool interval = (scopes[i] & FTKX_SCOPE_INTERVAL) != 0;
-        while (j0[(size_t)q] + last + 1 <= j1[(size_t)q] && slice_ts[(size_t)(j0[(size_t)q] + last + 1)] <= ts[i] + 1) last ++;
-        ftkx::SeriesStep &e = si[i - b[(size_t)q]];
-        e.slice0 = ja - j0[(size_t)q]; e.slice1 = interval ? ja + 1 - j0[(size_t)q] : -1; e.last = last; e.pad = 0;
-      }
-    }
-  }
-  const MaskJob *d_jobs = (const MaskJob *)((char *)c->d_desc + off_jobs);
-  Fields *d_steps = (Fields *)((char *)c->d_desc + off_steps);
-
-  // ---- queue everything ----
-  struct MarkGuard { std::vector<Slice *> *v; std::vector<int> *todo; bool armed; ~MarkGuard() { if (armed) for (size_t j = 0; j < v->size(); j ++) if ((*todo)[j] >= 0) { (*v)[j]->mask_factor = 0; (*v)[j]->have_fused = false; } } } marks{&sl, &red_index, true};
-  for (size_t j = 0; j < k; j ++) if (red_index[j] >= 0) { sl[j]->mask_factor = 0; sl[j]->have_fused = false; }
-  std::vector<Mesh> ms((size_t)nchunks);
-  std::vector<unsigned> seqs((size_t)nchunks);
-  for (int q = 0; q < nchunks; q ++) {
-    ftkx_series_slot &S = c->sr_slots[(size_t)q];
-    Mesh &m = ms[(size_t)q];
-    fill_mesh(c, m);
-    m.hits = nullptr; m.pass = S.pass; m.counters = S.counters; m.capacity = S.capacity; m.fragile = S.fragile; m.fragile_capacity = S.fragile_cap;
-    m.hist = S.hist; m.hist_shift = shift[(size_t)q]; m.core_cells = cells;
-    ftkx::launch_series_begin(S.counters, q == 0 ? c->d_red : nullptr, q == 0 ? ntodo * 64 : 0, S.hist, nbins[(size_t)q] + 1, S.results, nwords[(size_t)q], c->stream);
-    seqs[(size_t)q] = ++ S.seq;
-  }
-  launch_fetch_desc(c->h_desc, c->d_desc, total, c->stream);
-  const double safe_m = (double)(nd == 3 ? ftkx::kSafeM3 : ftkx::kSafeM2);
-  for (int q = 0; q < nchunks; q ++) {
-    ftkx_series_slot &S = c->sr_slots[(size_t)q];
-    const Mesh &m = ms[(size_t)q];
-    const int nq = b[(size_t)q + 1] - b[(size_t)q], kq = j1[(size_t)q] - j0[(size_t)q] + 1;
-    Fields *steps_q = d_steps + b[(size_t)q];
-    const ftkx::SeriesSlice *slices_q = (const ftkx::SeriesSlice *)((char *)c->d_desc + off_slices[(size_t)q]);
-    const ftkx::SeriesStep *sinfo_q = (const ftkx::SeriesStep *)((char *)c->d_desc + off_sinfo[(size_t)q]);
-    const ftkx_series_slot *P = q > 0 ? &c->sr_slots[(size_t)q - 1] : nullptr;
-    if (r1[(size_t)q] > r0[(size_t)q]) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs + r0[(size_t)q], r1[(size_t)q] - r0[(size_t)q], c->stream); ev_end(c); }
-    HIP_TRY(c, hipEventRecord(S.ev_masks, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(S.stream, S.ev_masks, 0));
-    if (two_level) ftkx::launch_cull_coarse(m, steps_q, nq, S.refine, S.refine_cap, S.stream);
-    else ftkx::launch_cull(m, steps_q, nq, S.list, S.list_cap, S.stream);
-    if (P) HIP_TRY(c, hipStreamWaitEvent(S.stream, P->ev_factors, 0));
-    ftkx::launch_series_factors(steps_q, nq, slices_q, kq, sinfo_q, c->d_red, *running_resolution, P ? P->results : nullptr, safe_m, S.results, S.counters, S.stream);
-    HIP_TRY(c, hipEventRecord(S.ev_factors, S.stream));
-    if (two_level) ftkx::launch_refine(m, steps_q, S.refine, S.refine_cap, S.list, S.list_cap, S.stream);
-    ftkx::launch_exact(m, steps_q, 0, S.list, S.list_cap, S.stream);
-    ftkx::launch_bucket_scan(S.hist, S.boff, (unsigned)nbins[(size_t)q], S.counters, S.stream);
-    ftkx::launch_bucket_scatter(m, S.boff, S.bucketed, S.stream);
-    ftkx::launch_bucket_rank(m, S.bucketed, S.boff, S.sorted, S.results, S.stream);
-    if (P) HIP_TRY(c, hipStreamWaitEvent(S.stream, P->ev_done, 0));                       // (where this chunk's records start is known when the chunk before it is through)
-    const u64 *base_from = P ? P->results + ftkx::SR_BASE_NEXT : nullptr;
-    ftkx::launch_series_records(m, steps_q, S.sorted, c->h_hits, base_from, S.stream);
-    ftkx::launch_series_finish(m, S.results, nwords[(size_t)q], S.list_cap, S.refine_cap, S.h_results, reinterpret_cast<unsigned *>(S.h_results + S.h_results_cap), seqs[(size_t)q], base_from, S.stream);
-    HIP_TRY(c, hipEventRecord(S.ev_done, S.stream));
-  }
-  HIP_TRY(c, hipGetLastError());
-  for (int q = 0; q < nchunks; q ++) {
-    ftkx_series_slot &S = c->sr_slots[(size_t)q];
-    if (const char *why = ftkx::wait_flag(reinterpret_cast<unsigned *>(S.h_results + S.h_results_cap), seqs[(size_t)q], S.stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
-  }
-  ev_harvest(c, false);
-
-  // ---- what came back ----
-  unsigned long long status = 0;
-  for (int q = 0; q < nchunks; q ++) status |= c->sr_slots[(size_t)q].h_results[ftkx::SR_STATUS];
-  c->sr_last_status = status;
-  marks.armed = false;
-  std::vector<char> seen(k, 0);
-  for (int q = 0; q < nchunks; q ++) {
-    const u64 *R = c->sr_slots[(size_t)q].h_results;
-    const int nq = b[(size_t)q + 1] - b[(size_t)q], kq = j1[(size_t)q] - j0[(size_t)q] + 1;
-    for (int jj = 0; jj < kq; jj ++) {
-      const size_t j = (size_t)(j0[(size_t)q] + jj);
-      if (red_index[j] < 0 || seen[j]) continue;
-      seen[j] = 1;
-      Slice &s = *sl[j];
-      double r, x;
-      memcpy(&r, &R[ftkx::SR_HEAD + nq + jj], 8); memcpy(&x, &R[ftkx::SR_HEAD + nq + kq + jj], 8);
-      if (std::isinf(x)) { s.mask_factor = 0; s.have_fused = false; continue; }
-      s.res_below = r; s.fused_factor = hint; s.have_fused = true;
-      if (!s.have_res) s.maxabs = x;
-      s.mask_factor = overflow_free(nd, s.maxabs, hint) ? hint : 0;
-      s.mask_big = false; s.u_rows = ms[0].u_rows;
-    }
-  }
-  const unsigned long long redo = ftkx::SERIES_AMBIGUOUS | ftkx::SERIES_MASKS_INVALID | ftkx::SERIES_INF | ftkx::SERIES_OVERFLOW;
-  if (status & redo) {
-    for (int q = 0; q < nchunks && (status & ftkx::SERIES_OVERFLOW); q ++) {      // grow what was too small in this chunk's slot
-      ftkx_series_slot &S = c->sr_slots[(size_t)q];
-      const u64 *cnt = S.h_results + ftkx::SR_COUNTERS;
-      const u64 hits = cnt[ftkx::CNT_PASS], listed = cnt[ftkx::CNT_LIST_PEAK], refined = cnt[ftkx::CNT_REFINE_PEAK], fragile = cnt[ftkx::CNT_FRAGILE];
-      size_t cap;
-      if (hits > S.capacity) {
-        for (void *p : {(void *)S.pass, (void *)S.bucketed, (void *)S.sorted}) if (p) (void)hipFree(p);
-        S.pass = S.bucketed = S.sorted = nullptr;
-        S.capacity = hits + hits / 8 + 1024;                                       // (slot_prepare allocates)
-      }
-      cap = (size_t)S.list_cap; if (listed > S.list_cap && (rc = grow_device(c, &S.list, &cap, (size_t)(listed + listed / 8 + 1024)))) return rc; S.list_cap = cap;
-      cap = (size_t)S.refine_cap; if (refined > S.refine_cap && (rc = grow_device(c, &S.refine, &cap, (size_t)(refined + refined / 8 + 1024)))) return rc; S.refine_cap = cap;
-      cap = (size_t)S.fragile_cap * 10; if (fragile > S.fragile_cap && (rc = grow_device(c, &S.fragile, &cap, (size_t)(fragile + fragile / 8 + 1024) * 10))) return rc; S.fragile_cap = cap / 10;
-    }
-    return 0;
-  }
-  c->sr_last_path = 3;
-  memset(&c->stats, 0, sizeof(c->stats));
-  {
-    const u64 n_ord = nd == 2 ? 2 : 6, n_int = nd == 2 ? 10 : 54;
-    for (int i = 0; i < n; i ++) { c->stats.cells += cells; c->stats.work_items += cells * (((scopes[i] & 1) ? n_ord : 0) + ((scopes[i] & 2) ? n_int : 0)); }
-  }
-  c->stats.cull_enabled = 1;
-  size_t base = 0;
-  auto less = [](const ftkx_cp_t &p, const ftkx_cp_t &q) { return p.tag < q.tag; };
-  for (int q = 0; q < nchunks; q ++) {
-    const u64 *R = c->sr_slots[(size_t)q].h_results;
-    const u64 *cnt = R + ftkx::SR_COUNTERS;
-    const size_t nrec = (size_t)R[ftkx::SR_NHITS];
-    c->stats.cells_survived += cnt[ftkx::CNT_CELLS_SURVIVED];
-    c->stats.simplices_tested += cnt[ftkx::CNT_SIMPLICES_TESTED];
-    const size_t nf = (size_t)R[ftkx::SR_NFRAGILE];
-    for (size_t i = 0; i < nf; i ++) {
-      const u64 *e = R + nwords[(size_t)q] + i * 10;
-      double A[3][3];
-      memcpy(A, e + 1, sizeof(A));
-      if (e[0] < nrec) c->h_hits[base + e[0]].type = (unsigned)ftkx::classify3(A, c->opt.jacobian_symmetric != 0);
-    }
-    c->stats.reclassified += nf;
-    if ((R[ftkx::SR_STATUS] & ftkx::SERIES_FIX_ORDER) && !std::is_sorted(c->h_hits + base, c->h_hits + base + nrec, less))
-      std::sort(c->h_hits + base, c->h_hits + base + nrec, less);              // (a bucket too full to rank on the device)
-    if (factors) for (int i = b[(size_t)q]; i < b[(size_t)q + 1]; i ++) factors[i] = R[ftkx::SR_HEAD + (i - b[(size_t)q])];
-    base += nrec;
-  }
-  c->stats.hits = base;
-  double run;
-  memcpy(&run, &c->sr_slots[(size_t)nchunks - 1].h_results[ftkx::SR_RUNNING], 8);
-  *running_resolution = run;
-  if (out) *out = c->h_hits;
-  if (n_out) *n_out = base;
-  return 1;
 }
 
 // ---- the device-driven pass in two halves -------------------------------------------------------------------------------------------
@@ -437,21 +166,49 @@ int ensure_series_buffers(ftkx_ctx *c, ftkx_series_buffers &B, size_t nwords, si
 
 void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, const unsigned *wait_flag, unsigned wait_val);
 
+// ---- the tail next to the next mask kernel (round 5) -------------------------------------------------------------------------------------
+// A sparse pass ends in a latency chain -- counters, coarse cull + factors, the fused tail: ~75 us that keep a handful of workgroups busy --
+// and the mask kernel of the pass queued behind it waited for all of it.  A SPLIT pass queues only its begin and mask kernels on the
+// context's stream; its tail goes to a stream of its own behind an event, and the next pass's mask kernel waits for this pass's CULL only:
+// it then starts together with the fused tail, which gets its workgroups first (a kernel that arrives after a mask kernel has filled the
+// device does not get a slot until that kernel drains: the fused tail's wavefronts need a whole SIMD's registers -- tools/probe/anyorder.hip).
+// What the two sides share is kept apart: the reduction slots are the pass's own (ftkx_series_buffers::red), the counters and the histogram
+// are zeroed on the tail stream, and a slice whose masks the next pass rebuilds while this pass's tail still reads them gets fresh arrays
+// (`retired`: back to the pool when this pass is completed).  Taken by pipelined, single-rank passes queued as a short chain (the pass
+// before was finished by the fused tail), without kernel events.
+hipStream_t tail_stream(ftkx_ctx *c, const ftkx_series_pending &P) { return P.split ? c->sr_tail_stream : c->stream; }
+
+void release_retired(ftkx_ctx *c, ftkx_series_pending &P)
+{
+  for (auto &mu : P.retired) { if (mu.first) c->pool_M.push_back(mu.first); if (mu.second) c->pool_U.push_back(mu.second); }
+  P.retired.clear();
+}
+
+bool short_chain_now(const ftkx_ctx *c, bool to_device, bool *small_now)
+{
+  static const bool small_on = !(getenv("FTKX_SERIES_SMALL") && atoi(getenv("FTKX_SERIES_SMALL")) == 0);
+  static const bool short_on = !(getenv("FTKX_SERIES_SHORT") && atoi(getenv("FTKX_SERIES_SHORT")) == 0);
+  const bool sn = small_on && c->sr_skip_small == 0 && !to_device;
+  if (small_now) *small_now = sn;
+  return sn && short_on && c->sr_short_chain;
+}
+
 // the kernels behind the fused tail: refine, exact test, ordering, records, finish
 void series_queue_rest(ftkx_ctx *c, const ftkx_series_pending &P, const Mesh &m, unsigned seq)
 {
   ftkx_series_buffers &B = c->sr_buf[P.buf];
   Fields *d_steps = (Fields *)((char *)B.d_desc + P.off_steps);
   unsigned *flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
-  if (P.two_level && !P.refined) ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, c->stream);   // (a slab pass refines before it asks for patches)
-  ftkx::launch_exact(m, d_steps, 0, c->d_list, c->list_capacity, c->stream);
-  ftkx::launch_bucket_scan(c->sr_hist, c->sr_boff, (unsigned)P.nbins, c->d_counters, c->stream);
-  ftkx::launch_bucket_scatter(m, c->sr_boff, c->sr_bucketed, c->stream);
-  ftkx::launch_bucket_rank(m, c->sr_bucketed, c->sr_boff, c->sr_sorted, B.results, c->stream);
-  if (B.copy_out) { (void)hipStreamWaitEvent(c->stream, B.ev_copied, 0); B.copy_out = false; }   // (the copy of the pass that used these buffers last: long through)
-  ftkx::launch_series_records(m, d_steps, c->sr_sorted, P.to_device ? B.d_out : B.out, nullptr, c->stream);
-  ev_end(c);
-  ftkx::launch_series_finish(m, B.results, P.nwords, c->list_capacity, c->refine_capacity, B.h_results, flag, seq, nullptr, c->stream);
+  hipStream_t st = tail_stream(c, P);
+  if (P.two_level && !P.refined) ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, st);   // (a slab pass refines before it asks for patches)
+  ftkx::launch_exact(m, d_steps, 0, c->d_list, c->list_capacity, st);
+  ftkx::launch_bucket_scan(c->sr_hist, c->sr_boff, (unsigned)P.nbins, c->d_counters, st);
+  ftkx::launch_bucket_scatter(m, c->sr_boff, c->sr_bucketed, st);
+  ftkx::launch_bucket_rank(m, c->sr_bucketed, c->sr_boff, c->sr_sorted, B.results, st);
+  if (B.copy_out) { (void)hipStreamWaitEvent(st, B.ev_copied, 0); B.copy_out = false; }   // (the copy of the pass that used these buffers last: long through)
+  ftkx::launch_series_records(m, d_steps, c->sr_sorted, P.to_device ? B.d_out : B.out, st);
+  if (!P.split) ev_end(c);
+  ftkx::launch_series_finish(m, B.results, P.nwords, c->list_capacity, c->refine_capacity, B.h_results, flag, seq, st);
 }
 
 // the records' way over PCIe: a small kernel on its own stream, behind the finish kernel (the count is final) and next to whatever the
@@ -469,6 +226,82 @@ void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, const unsigned *wait
   P.copy_pending = false;
 }
 
+// ---- the one-launch pass for small series (one_kernel.hip) --------------------------------------------------------------------------------
+bool series_one_eligible(ftkx_ctx *c, const ftkx_series_pending &P, int n, size_t k, u64 cells, bool dist)
+{
+  const char *e = getenv("FTKX_SERIES_ONE");                  // (read at every pass: tests switch it inside one process)
+  const bool one_on = !(e && atoi(e) == 0);
+  if (!one_on || dist || c->sr_one_off > 0) { if (c->sr_one_off > 0 && !dist) c->sr_one_off --; return false; }
+  if (n > ftkx::kOneMaxSteps || k > (size_t)ftkx::kOneMaxSlices) return false;
+  // small: a few hundred corners per workgroup at most, and slices whose reduction is a few chunks' worth of reading
+  if (cells * (u64)n > (1ull << 21) || (u64)n_vertices(c) * (u64)k > (1ull << 22)) return false;
+  (void)P;
+  return true;
+}
+
+int series_plan_one(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *scopes, int n, const std::vector<Slice *> &sl, const ftkx_series_pending *prev,
+                    ftkx_series_pending *before)
+{
+  const size_t k = P.k;
+  int rc;
+  P.one = true; P.split = false; P.to_device = false; P.short_chain = false; P.small_now = false;
+  P.red_index.assign(k, -1); P.gen.assign(k, 0);               // (no masks are built: nothing to mark when the pass is collected)
+  P.ntodo = 0;
+  if ((rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16)))) return rc;
+  if ((rc = ensure_fragile(c, std::max<u64>(c->fragile_capacity, 1u << 12)))) return rc;
+  const size_t nwords = (size_t)ftkx::SR_HEAD + (size_t)n + 2 * k;
+  P.nwords = nwords;
+  P.buf = (int)(&P - c->sr_pend);
+  ftkx_series_buffers &B = c->sr_buf[P.buf];
+  if ((rc = ensure_series_buffers(c, B, nwords, 256, false))) return rc;
+  if (!c->sr_one_scratch) {
+    HIP_TRY(c, hipMalloc((void **)&c->sr_one_scratch, (size_t)ftkx::ONE_WORDS * sizeof(u64)));
+    HIP_TRY(c, hipMemsetAsync(c->sr_one_scratch, 0, (size_t)ftkx::ONE_WORDS * sizeof(u64), c->stream));
+  }
+  Mesh m; fill_mesh(c, m);
+  m.core_cells = P.cells;
+  ftkx::OneArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nsteps = n; a.nslices = (int)k;
+  for (size_t j = 0; j < k; j ++) { const Slice &s = *sl[j]; a.slice[j] = ftkx::OneSlice{s.S, s.V, s.J, P.slice_ts[j], 0}; }
+  size_t last = 0;
+  for (int i = 0; i < n; i ++) {
+    const size_t j0 = (size_t)(std::lower_bound(P.slice_ts.begin(), P.slice_ts.end(), ts[i]) - P.slice_ts.begin());
+    const bool interval = (scopes[i] & FTKX_SCOPE_INTERVAL) != 0;
+    while (last + 1 < k && P.slice_ts[last + 1] <= ts[i] + 1) last ++;
+    a.step[i] = ftkx::OneStep{ts[i], scopes[i], (int)j0, interval ? (int)j0 + 1 : -1, (int)last, 0};
+  }
+  a.running_in = prev ? DBL_MAX : P.running_in;
+  a.cap = 1.0 / (double)P.hint;
+  a.running_from = prev ? c->sr_buf[prev->buf].results : nullptr;
+  a.scratch = c->sr_one_scratch;
+  a.results = B.results; a.h_results = B.h_results; a.nwords = nwords;
+  a.flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
+  a.seq = ++ B.seq;
+  P.seq = a.seq;
+  a.out = B.out; a.capacity = std::min<u64>(c->capacity, (u64)B.out_cap);
+  a.fragile = c->d_fragile; a.fragile_capacity = c->fragile_capacity;
+  // (the pass before left its records in device memory: their copy needs this pass's launch position, no more)
+  if (before && before->open && before->copy_pending) {
+    if (!c->sr_ev_fetched) HIP_TRY(c, hipEventCreateWithFlags(&c->sr_ev_fetched, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->sr_ev_fetched, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->sr_copy_stream, c->sr_ev_fetched, 0));
+    series_queue_copy(c, *before, nullptr, 0);
+  }
+  if (before && before->open && before->split) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->sr_buf[before->buf].ev_tail, 0));   // (its tail shares the fragile list)
+  if (B.copy_out) { HIP_TRY(c, hipStreamWaitEvent(c->stream, B.ev_copied, 0)); B.copy_out = false; }
+  const u64 work = P.cells * (u64)n;
+  const int nwg = (int)std::max<u64>(8, std::min<u64>(256, (work + 255) / 256));
+  ev_begin(c, K_EXACT);
+  ftkx::launch_series_one(m, a, nwg, c->stream);
+  ev_end(c);
+  HIP_TRY(c, hipGetLastError());
+  P.uid = ++ c->sr_pass_uid;
+  P.pipelined = true;
+  P.open = true;
+  return FTKX_OK;
+}
+
 // First half: everything of the pass is queued on the context's stream.  `prev`: the pass queued before this one and not yet collected,
 // whose running minimum this one continues from (on the device), or nullptr: *running_in is the value.
 // what a slab pass (ftkx_series_dist_*) adds to the plan of a pass: the halo slice and where the gathered contributions will be
@@ -482,6 +315,7 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
                 ftkx_series_pending *before = nullptr /* the pass queued before this one, if it is still open */, const DistPlan *dist = nullptr)
 {
   const int nd = c->nd;
+  release_retired(c, P);                                     // (a slot that was abandoned with arrays still parked in it)
   P = ftkx_series_pending();
   if (dist) { P.dist = true; P.t_halo = dist->t_halo; P.dist_rank = dist->rank; P.dist_nranks = dist->nranks; P.dist_upper = dist->upper; P.gathered = dist->gathered; }
   P.ts.assign(ts, ts + n); P.scopes.assign(scopes, scopes + n); P.n = n;
@@ -505,6 +339,7 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   const unsigned long long hint = std::max<unsigned long long>(factor_of(running_in), 256ull);
   P.hint = hint; P.two_level = two_level; P.cells = cells; P.u_rows = m.u_rows;
   if (!ok) { P.by_host = true; P.open = true; return FTKX_OK; }
+  if (series_one_eligible(c, P, n, k, cells, dist != nullptr)) return series_plan_one(c, P, ts, scopes, n, sl, prev, before);
   // slices whose masks and reduction stand from an earlier call (a streaming tracker: slice t of this step was slice t + 1 of the last)
   P.red_index.assign(k, -1);
   P.gen.assign(k, 0);
@@ -544,12 +379,25 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   if ((rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16)))) return rc;
   if ((rc = ensure_fragile(c, std::max<u64>(c->fragile_capacity, 1u << 12)))) return rc;
   if ((rc = ensure_list(c, std::max<u64>(c->list_capacity, 1u << 20))) || (rc = ensure_refine(c, std::max<u64>(c->refine_capacity, 1u << 20)))) return rc;
-  for (size_t j = 0; j < k; j ++) if (red_index[j] >= 0 && (rc = ensure_mask_arrays(c, *sl[j], two_level))) return rc;
-  if (c->red_cap < std::max<size_t>(ntodo, 1)) {
-    if (c->d_red) { (void)hipFree(c->d_red); c->d_red = nullptr; c->red_cap = 0; }
-    HIP_TRY(c, hipMalloc((void **)&c->d_red, std::max<size_t>(ntodo, 1) * 128 * sizeof(u64)));
-    c->red_cap = std::max<size_t>(ntodo, 1);
+  // split?  (decided here: the begin kernel of a split pass leaves the counters to the tail stream)
+  P.to_device = false;
+  {
+    static const bool sdma_on = !(getenv("FTKX_SERIES_COPY") && atoi(getenv("FTKX_SERIES_COPY")) == 0);
+    P.to_device = pipelined && sdma_on && c->stats.hits > 4096;
+    static const bool split_on = !(getenv("FTKX_SERIES_SPLIT") && atoi(getenv("FTKX_SERIES_SPLIT")) == 0);
+    P.split = split_on && pipelined && !dist && c->profiling == 0 && short_chain_now(c, P.to_device, nullptr);
   }
+  const bool before_split = before && before->open && before->split;
+  // a slice whose masks this pass rebuilds while the tail of the pass before it -- on its own stream -- still reads them: fresh arrays here,
+  // the old ones parked with that pass until it is completed
+  if (before_split)
+    for (size_t j = 0; j < k; j ++) {
+      if (red_index[j] < 0 || !(sl[j]->M || sl[j]->U)) continue;
+      if (!std::binary_search(before->slice_ts.begin(), before->slice_ts.end(), slice_ts[j])) continue;
+      before->retired.push_back({sl[j]->M, sl[j]->U});
+      sl[j]->M = nullptr; sl[j]->U = nullptr;
+    }
+  for (size_t j = 0; j < k; j ++) if (red_index[j] >= 0 && (rc = ensure_mask_arrays(c, *sl[j], two_level))) return rc;
   // order key -> bucket: at most 2^16 buckets over the keys this pass can produce
   const u64 max_key = (u64)n * cells * 64ull;
   int key_bits = 1;
@@ -576,11 +424,23 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   // A pass with many records, queued while another is still out: the record kernel leaves them in device memory and a small kernel on a
   // stream of its own takes them over PCIe -- next to the mask kernel of the pass queued behind.  (A record kernel that writes through
   // PCIe itself holds its stream for the transfer: 106 us of woven 1024^2 x 64's 363.)
-  static const bool sdma_on = !(getenv("FTKX_SERIES_COPY") && atoi(getenv("FTKX_SERIES_COPY")) == 0);
-  P.to_device = pipelined && sdma_on && c->stats.hits > 4096;
   P.buf = (int)(&P - c->sr_pend);                             // (a pass's buffers go with its place in sr_pend: nothing to undo when a step below fails)
   ftkx_series_buffers &B = c->sr_buf[P.buf];
   if ((rc = ensure_series_buffers(c, B, nwords, total, P.to_device))) return rc;
+  if (B.red_cap < std::max<size_t>(ntodo, 1)) {              // (the pass's own reduction slots: a buffer in use by an open pass is never this one -- two buffers, two passes)
+    if (B.red) { HIP_TRY(c, hipFree(B.red)); B.red = nullptr; B.red_cap = 0; }
+    HIP_TRY(c, hipMalloc((void **)&B.red, std::max<size_t>(ntodo, 1) * 128 * sizeof(u64)));
+    B.red_cap = std::max<size_t>(ntodo, 1);
+  }
+  if (P.split || before_split) {
+    if (!c->sr_tail_stream) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      HIP_TRY(c, hipStreamCreateWithPriority(&c->sr_tail_stream, hipStreamNonBlocking, hi));    // (the tail is a latency chain: it goes first wherever a slot frees up)
+    }
+    for (ftkx_series_buffers &X : c->sr_buf)
+      for (hipEvent_t *e : {&X.ev_masks, &X.ev_cull, &X.ev_tail}) if (!*e) HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
   if (P.to_device && !c->sr_copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->sr_copy_stream, hipStreamNonBlocking));
   fill_mesh(c, m);                                           // (the buffers may have moved)
   m.hist = c->sr_hist; m.hist_shift = shift; m.core_cells = cells;
@@ -599,7 +459,7 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
       else if (red_index[j] < 0 && !from_res[j]) { ss[j].known_res = s.res_below; ss[j].known_max = s.maxabs; }
       if (from_res[j] && s.sparse) { ss[j].known_res = DBL_MAX; ss[j].known_max = 0.0; }      // (the halo slice: nothing of an earlier pass stands)
       if (red_index[j] >= 0)
-        jobs[red_index[j]] = with_lean_thresholds(MaskJob{s.S, s.V, s.M, two_level ? s.U : nullptr, c->d_red + (size_t)red_index[j] * 128, cap, HUGE_VAL}, m);   // rule off: validated by the factor kernel
+        jobs[red_index[j]] = with_lean_thresholds(MaskJob{s.S, s.V, s.M, two_level ? s.U : nullptr, B.red + (size_t)red_index[j] * 128, cap, HUGE_VAL}, m);   // rule off: validated by the factor kernel
     }
     size_t last = 0;
     for (int i = 0; i < n; i ++) {
@@ -644,9 +504,17 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   // copy is ordered behind the begin kernel by an event instead, 5 us on a path that waits for the network anyway)
   const bool copy_by_event = copy_behind && (dist != nullptr || before->dist);
   const bool copy_by_flag = copy_behind && !copy_by_event;
-  if (copy_by_flag && !c->sr_fetch_flag) { HIP_TRY(c, hipMalloc((void **)&c->sr_fetch_flag, 2 * sizeof(unsigned))); HIP_TRY(c, hipMemset(c->sr_fetch_flag, 0, 2 * sizeof(unsigned))); }   // (once per context; synchronous: the copy stream reads it)
+  if (copy_by_flag && !c->sr_fetch_flag) { HIP_TRY(c, hipMalloc((void **)&c->sr_fetch_flag, 2 * sizeof(unsigned))); HIP_TRY(c, hipMemsetAsync(c->sr_fetch_flag, 0, 2 * sizeof(unsigned), c->stream)); HIP_TRY(c, hipStreamSynchronize(c->stream)); }   // (once per context; waited for: the copy stream reads it)
   const unsigned fetch_val = copy_by_flag ? ++ c->sr_fetch_seq : 0u;
-  ftkx::launch_series_begin(c->d_counters, c->d_red, ntodo * 64, c->sr_hist, nbins + 1, B.results, nwords, c->stream, B.h_desc, B.d_desc, total, copy_by_flag ? c->sr_fetch_flag : nullptr, fetch_val);
+  // (the pass before this one has its tail on the tail stream: a pass that is not split itself shares the counters with it in STREAM order,
+  // so the context's stream waits for that tail; a split pass only needs that pass's cull -- its mask kernel must not start before the fused
+  // tail behind that cull can be placed -- and zeroes the counters on the tail stream, behind it)
+  if (before_split && !P.split) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->sr_buf[before->buf].ev_tail, 0));
+  // (a split pass: what its TAIL owns -- counters, histogram, the results block, which the tail of the pass before may still be reading as the
+  // block it continues from -- is zeroed on the tail stream)
+  ftkx::launch_series_begin(P.split ? nullptr : c->d_counters, B.red, ntodo * 64, P.split ? nullptr : c->sr_hist, P.split ? 0 : nbins + 1, P.split ? nullptr : B.results, P.split ? 0 : nwords,
+                            c->stream, B.h_desc, B.d_desc, total, copy_by_flag ? c->sr_fetch_flag : nullptr, fetch_val);
+  if (before_split && P.split) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->sr_buf[before->buf].ev_cull, 0));
   c->sr_lists_owner = 0;                                      // (the begin kernel zeroes the counters and the histogram: they are nobody's until this pass's cull is queued)
   if (copy_by_flag) series_queue_copy(c, *before, c->sr_fetch_flag, fetch_val);
   if (copy_by_event) {
@@ -675,6 +543,12 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
     }
     if (ntodo > done) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs + done, (int)(ntodo - done), c->stream); ev_end(c); }
   } else if (ntodo) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs, (int)ntodo, c->stream); ev_end(c); }
+  if (P.split) {
+    // the tail's side: behind the masks (an event), the counters and the histogram zeroed there
+    HIP_TRY(c, hipEventRecord(B.ev_masks, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->sr_tail_stream, B.ev_masks, 0));
+    ftkx::launch_series_tail_begin(c->d_counters, c->sr_hist, nbins + 1, B.results, nwords, c->sr_tail_stream);
+  }
   P.running_from = prev ? c->sr_buf[prev->buf].results : nullptr;
   P.pipelined = pipelined;
   HIP_TRY(c, hipGetLastError());
@@ -698,7 +572,8 @@ int series_queue_cull(ftkx_ctx *c, ftkx_series_pending &P)
   Fields *d_steps = (Fields *)((char *)B.d_desc + P.off_steps);
   const ftkx::SeriesSlice *d_slices = (const ftkx::SeriesSlice *)((char *)B.d_desc + P.off_slices);
   const ftkx::SeriesStep *d_sinfo = (const ftkx::SeriesStep *)((char *)B.d_desc + P.off_sinfo);
-  ev_begin(c, K_CULL);
+  hipStream_t st = tail_stream(c, P);
+  if (!P.split) ev_begin(c, K_CULL);
   P.uid = ++ c->sr_pass_uid;
   c->sr_lists_owner = P.uid;                                  // (from here on the counters and lists hold this pass's cull)
   {
@@ -708,15 +583,16 @@ int series_queue_cull(ftkx_ctx *c, ftkx_series_pending &P)
     const u64 *running_from = P.running_from;
     ftkx::FactorJob fj;
     memset(&fj, 0, sizeof(fj));
-    fj.steps = d_steps; fj.slices = d_slices; fj.sinfo = d_sinfo; fj.red = c->d_red; fj.running_from = running_from; fj.results = B.results; fj.counters = c->d_counters;
+    fj.steps = d_steps; fj.slices = d_slices; fj.sinfo = d_sinfo; fj.red = B.red; fj.running_from = running_from; fj.results = B.results; fj.counters = c->d_counters;
     fj.running_in = running_from ? DBL_MAX : P.running_in; fj.safe_m = safe_m; fj.nsteps = n; fj.nslices = (int)k;
     static const bool fold_on = !(getenv("FTKX_SERIES_FOLD") && atoi(getenv("FTKX_SERIES_FOLD")) == 0);
     fj.enabled = (fold_on && k <= (size_t)ftkx::kFoldMaxSlices) ? 1 : 0;
-    if (P.two_level) ftkx::launch_cull_coarse(m, d_steps, n, c->d_refine, c->refine_capacity, c->stream, &fj);
-    else ftkx::launch_cull(m, d_steps, n, c->d_list, c->list_capacity, c->stream, &fj);
-    if (!fj.enabled) ftkx::launch_series_factors(d_steps, n, d_slices, (int)k, d_sinfo, c->d_red, fj.running_in, running_from, safe_m, B.results, c->d_counters, c->stream);
+    if (P.two_level) ftkx::launch_cull_coarse(m, d_steps, n, c->d_refine, c->refine_capacity, st, &fj);
+    else ftkx::launch_cull(m, d_steps, n, c->d_list, c->list_capacity, st, &fj);
+    if (!fj.enabled) ftkx::launch_series_factors(d_steps, n, d_slices, (int)k, d_sinfo, B.red, fj.running_in, running_from, safe_m, B.results, c->d_counters, st);
   }
-  ev_end(c);
+  if (P.split) HIP_TRY(c, hipEventRecord(B.ev_cull, st));     // (what the mask kernel of the pass queued behind this one waits for)
+  else ev_end(c);
   HIP_TRY(c, hipGetLastError());
   return FTKX_OK;
 }
@@ -731,22 +607,22 @@ int series_queue_tail(ftkx_ctx *c, ftkx_series_pending &P)
   const unsigned seq = P.seq;
   const bool two_level = P.two_level;
   const size_t nwords = P.nwords;
-  ev_begin(c, K_EXACT);
-  // sparse data: one kernel does the rest of the pass (and the kernels below leave at once)
-  static const bool small_on = !(getenv("FTKX_SERIES_SMALL") && atoi(getenv("FTKX_SERIES_SMALL")) == 0);
-  // (a pass that has just found far more survivors than the fused kernel takes does not launch it for a while: finding nothing to do
-  // costs its 256 workgroups of 256-VGPR wavefronts ~15 us)
-  const bool small_now = small_on && c->sr_skip_small == 0 && !P.to_device;
+  hipStream_t st = tail_stream(c, P);
+  if (!P.split) ev_begin(c, K_EXACT);
+  // sparse data: one kernel does the rest of the pass (and the kernels below leave at once).  (A pass that has just found far more
+  // survivors than the fused kernel takes does not launch it for a while: finding nothing to do costs its 256 workgroups of 256-VGPR
+  // wavefronts ~15 us.)  The fused tail finished the last pass too: this one is queued WITHOUT the seven kernels behind it -- each of them
+  // costs a few us just to find out that it has nothing to do.  Should the fused tail decline this time, it says so itself and the rest is
+  // queued then (or, with another pass queued behind already, the host-driven batch sweeps the steps).
+  bool small_now = false;
+  P.short_chain = short_chain_now(c, P.to_device, &small_now) || P.split;      // (a split pass was planned as a short chain: it stays one)
+  if (P.split) small_now = true;
   if (c->sr_skip_small > 0) c->sr_skip_small --;
-  // (the fused tail finished the last pass too: this one is queued WITHOUT the seven kernels behind it -- each of them costs a few us just
-  // to find out that it has nothing to do.  Should the fused tail decline this time, it says so itself and the rest is queued then (or,
-  // with another pass queued behind already, the host-driven batch sweeps the steps).)
-  static const bool short_on = !(getenv("FTKX_SERIES_SHORT") && atoi(getenv("FTKX_SERIES_SHORT")) == 0);
   P.small_now = small_now;
-  P.short_chain = small_now && short_on && c->sr_short_chain;
   if (small_now) ftkx::launch_series_small(m, two_level ? ftkx::coarse_view(m) : m, d_steps, two_level, c->d_refine, c->d_list, B.out, B.results, nwords,
-                                          B.h_results, flag, seq, reinterpret_cast<unsigned *>(c->d_counters + ftkx::CNT_SMALL_DONE), P.short_chain, c->stream);
+                                          B.h_results, flag, seq, reinterpret_cast<unsigned *>(c->d_counters + ftkx::CNT_SMALL_DONE), P.short_chain, st);
   if (!P.short_chain) series_queue_rest(c, P, m, seq);
+  if (P.split) HIP_TRY(c, hipEventRecord(B.ev_tail, st));
   P.copy_pending = P.to_device;
   HIP_TRY(c, hipGetLastError());
   return FTKX_OK;
@@ -758,7 +634,7 @@ int series_submit(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int 
                   ftkx_series_pending *before = nullptr /* the pass queued before this one, if it is still open */)
 {
   int rc = series_plan(c, P, ts, scopes, n, running_in, prev, pipelined, before, nullptr);
-  if (rc || P.by_host) return rc;
+  if (rc || P.by_host || P.one) return rc;
   if ((rc = series_queue_cull(c, P)) || (rc = series_queue_tail(c, P))) return rc;
   P.open = true;
   return FTKX_OK;
@@ -786,7 +662,11 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     while (key_bits < 63 && (1ull << key_bits) < max_key) key_bits ++;
     m.hist = c->sr_hist; m.hist_shift = std::max(0, key_bits - bins_log2()); m.core_cells = P.cells;
   }
-  if (const char *why = ftkx::wait_flag(flag, P.seq, c->stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+  if (const char *why = ftkx::wait_flag(flag, P.seq, tail_stream(c, P))) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+  release_retired(c, P);                                     // (the tail that read them is through)
+  // (with no pass left open the tail stream is at its end: waited for, so that whatever the caller does next on the context's stream --
+  // a host-driven batch, a pass that is not split -- finds the counters and lists idle)
+  if (P.split && c->sr_open == 0) HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream));
 
   // ---- what came back ----------------------------------------------------------------------------------------------------------------
   // (whoever stored the flag -- the fused tail, finishing or declining, or the finish kernel -- copied the whole results block first: the
@@ -828,7 +708,7 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     }
     if (status & ftkx::SERIES_HALO_FULL) {
       c->sr_short_chain = false;
-      if (P.short_chain) ev_end(c);
+      if (P.short_chain && !P.split) ev_end(c);
       ev_harvest(c, false);
       *running_resolution = running;
       return fail(c, FTKX_E_NOSLICE, "slab pass: the halo slice %d is needed as a whole (request -1: too many surviving cells, a mask message that did not fit, or masks the host rebuilds): nothing was swept", P.t_halo);
@@ -841,7 +721,7 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
       // completed back to back).  The host-driven batch sweeps the steps; it happens when sparse data turns dense.  A slab pass: from the
       // running minimum the lower ranks' contributions give, over a halo slice that has its patches -- both settled above)
       c->sr_short_chain = false;
-      ev_end(c);
+      if (!P.split) ev_end(c);
       int rc = series_by_host(c, P.ts.data(), P.scopes.data(), n, P.slice_ts, &running, factors, out, n_out);
       if (rc == FTKX_OK) *running_resolution = running;
       return rc;
@@ -849,16 +729,18 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     if (status & ftkx::SERIES_TAIL_PENDING) {
       const unsigned seq2 = ++ B.seq;
       series_queue_rest(c, P, m, seq2);
+      if (P.split) HIP_TRY(c, hipEventRecord(B.ev_tail, c->sr_tail_stream));
       HIP_TRY(c, hipGetLastError());
-      if (const char *why = ftkx::wait_flag(flag, seq2, c->stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+      if (const char *why = ftkx::wait_flag(flag, seq2, tail_stream(c, P))) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
       status = R[ftkx::SR_STATUS];                           // (the finish kernel's copy of the block: the same reductions, the final counters)
       c->sr_last_status = status;
-    } else ev_end(c);
+    } else if (!P.split) ev_end(c);
   }
   ev_harvest(c, false);
   const unsigned long long redo = ftkx::SERIES_AMBIGUOUS | ftkx::SERIES_MASKS_INVALID | ftkx::SERIES_INF | ftkx::SERIES_OVERFLOW;
   if (status & redo) {
     c->sr_short_chain = false;
+    if (P.one) c->sr_one_off = 16;                           // (more hits than a workgroup parks, or the device was not this kernel's alone: the usual way for a while)
     int rc;
     if (status & ftkx::SERIES_OVERFLOW) {                    // grow what was too small (the host-driven batch would find out the same way, one replay later)
       const u64 *cnt = R + ftkx::SR_COUNTERS;
@@ -873,8 +755,8 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     if (rc == FTKX_OK) *running_resolution = running;
     return rc;
   }
-  c->sr_last_path = (status & ftkx::SERIES_EARLY) ? 2 : 1;
-  c->sr_short_chain = (status & ftkx::SERIES_EARLY) != 0;
+  c->sr_last_path = (status & ftkx::SERIES_ONE) ? 4 : (status & ftkx::SERIES_EARLY) ? 2 : 1;
+  if (!P.one) c->sr_short_chain = (status & ftkx::SERIES_EARLY) != 0;
   const u64 *cnt = R + ftkx::SR_COUNTERS;
   if (!(status & ftkx::SERIES_EARLY) && (P.two_level ? cnt[ftkx::CNT_REFINE_PEAK] : cnt[ftkx::CNT_LIST_PEAK]) > 4 * 2048ull) c->sr_skip_small = 16;
   // (few coarse cells, many records in them: the fused tail declined late, tens of microseconds lost.  Twice in a row: the series is like that)
@@ -1049,7 +931,7 @@ int ftkx_series_dist_begin(ftkx_ctx *c, const int *ts, const int *scopes, int n,
   // this rank's contribution to the all_gather: its slab's reductions folded (the first slice's masks went out inside the plan)
   const ftkx::SeriesSlice *d_slices = (const ftkx::SeriesSlice *)((char *)B.d_desc + Q.off_slices);
   const int nown = (int)Q.k - (halo ? 1 : 0);
-  ftkx::launch_dist_contrib(d_slices, nown, c->d_red, (u64 *)contrib, B.dist_block, c->stream);
+  ftkx::launch_dist_contrib(d_slices, nown, B.red, (u64 *)contrib, B.dist_block, c->stream);
   HIP_TRY(c, hipGetLastError());
   Q.dist_stage = 1;
   return FTKX_OK;
@@ -1167,6 +1049,7 @@ int ftkx_sweep_series_abort(ftkx_ctx *c)
   // whatever the open passes queued runs to its end (their kernels write buffers that stay allocated); nothing of it is read
   hipError_t e = hipStreamSynchronize(c->stream);
   if (c->sr_copy_stream && e == hipSuccess) e = hipStreamSynchronize(c->sr_copy_stream);
+  if (c->sr_tail_stream && e == hipSuccess) e = hipStreamSynchronize(c->sr_tail_stream);
   for (ftkx_series_pending &P : c->sr_pend) {
     if (P.dist && P.dist_stage > 0 && P.dist_stage < 4) { P.open = true; }      // (a slab pass that was never finished: its masks are nobody's either)
     if (!P.open) continue;
@@ -1175,6 +1058,7 @@ int ftkx_sweep_series_abort(ftkx_ctx *c)
       auto it = c->slices.find(P.slice_ts[j]);
       if (P.red_index[j] >= 0 && it != c->slices.end() && it->second.mask_gen == P.gen[j]) { it->second.mask_factor = 0; it->second.have_fused = false; }
     }
+    release_retired(c, P);
     P.open = false; P.copy_pending = false; P.dist_stage = 0;
   }
   for (ftkx_series_buffers &B : c->sr_buf) B.copy_out = false;
@@ -1201,45 +1085,8 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   HIP_TRY(c, hipSetDevice(c->device));
   int rc;
 
-  // ---- the pass in chunks, the tail of one next to the mask kernel of the next: built, exact (tests/test_gpu_series.py) -- and OFF unless
-  // FTKX_SERIES_CHUNKS asks for it: measured on hit-dense data (double_gyre 2048 x 1024 x 128: 1.05 ms in one piece, 1.10 / 1.17 / 1.52 ms
-  // in 2 / 3 / 4 chunks; woven 1024^2 x 64: 0.35 -> 0.43 / 0.52 / 0.57 ms) the tail kernels of chunk k get next to nothing done while the
-  // mask kernel of chunk k + 1 saturates the memory system and occupies every workgroup slot (coarse cull 27 -> 108 us, the one-workgroup
-  // factor kernel 8 -> 253 us waiting for a slot, stream priority notwithstanding): the tail still ends after the last mask kernel, and
-  // the extra launches and events are paid on top ----
-  {
-    int nchunks = 1;
-    if (const char *e = getenv("FTKX_SERIES_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 8) nchunks = n >= 2 * v ? v : 1; }   // (an explicit choice: tests, experiments)
-    if (nchunks > 1) {
-      ftkx_series_pending Q;
-      if ((rc = series_steps(c, ts, scopes, n, Q.slice_ts))) return rc;
-      std::vector<Slice *> sl(Q.slice_ts.size());
-      for (size_t j = 0; j < sl.size(); j ++) sl[j] = &c->slices.find(Q.slice_ts[j])->second;
-      Mesh m; fill_mesh(c, m);
-      const bool two_level = ftkx::masks_have_summary(m);
-      u64 cells = 1;
-      for (int d = 0; d < c->nd; d ++) cells *= (u64)c->core_sz[d];
-      if (series_applicable(c, ts, scopes, n, Q.slice_ts, sl, cells)) {
-        const unsigned long long hint = std::max<unsigned long long>(factor_of(*running_resolution), 256ull);
-        std::vector<int> red_index(sl.size(), -1);
-        size_t ntodo = 0;
-        for (size_t j = 0; j < sl.size(); j ++) {
-          const Slice &s = *sl[j];
-          const bool ready = s.M && (!two_level || (s.U && s.u_rows == m.u_rows)) && s.mask_factor != 0 && s.mask_factor <= hint && !s.mask_big && (s.have_fused || s.have_res);
-          if (!ready) red_index[j] = (int)ntodo ++;
-        }
-        c->mask_epoch ++;
-        rc = series_chunked(c, nchunks, ts, scopes, n, Q.slice_ts, sl, red_index, ntodo, two_level, cells, hint, running_resolution, factors, out, n_out);
-        if (rc < 0) return rc;
-        if (rc == 1) {
-          // still hit-dense?  Then the next pass is chunked again; otherwise it is queued in one piece, with the fused tail kernel
-          c->sr_skip_small = c->stats.cells_survived > 4 * 2048ull ? 16 : 0;
-          return FTKX_OK;
-        }
-      }
-      return series_by_host(c, ts, scopes, n, Q.slice_ts, running_resolution, factors, out, n_out);
-    }
-  }
+  // (the pass in chunks, the tail of one chunk next to the mask kernel of the next -- round 3, FTKX_SERIES_CHUNKS -- was measured slower on every
+  // configuration and has been removed: NOTES.md)
   ftkx_series_pending &P = c->sr_pend[0];
   if ((rc = series_submit(c, P, ts, scopes, n, *running_resolution, nullptr, false))) { P.open = false; return rc; }
   return series_complete(c, P, running_resolution, factors, out, n_out);

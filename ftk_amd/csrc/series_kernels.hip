@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void series_begin_kernel(u64 *counters, u64 *r
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   // (the pass's descriptors, pinned host -> device: the first workgroups, so that the read over PCIe is under way at once)
   for (size_t w = i; w < desc_words; w += (size_t)gridDim.x * 256) desc_dst[w] = desc_src[w];
-  if (i < (size_t)CNT_N) counters[i] = 0ull;
+  if (counters && i < (size_t)CNT_N) counters[i] = 0ull;      // (nullptr: a split pass zeroes them on its tail stream -- series.hip)
   if (i < nslots) { red[2 * i] = 0x7fefffffffffffffull; red[2 * i + 1] = 0ull; }   // {min = DBL_MAX, max = 0} as bit patterns
   if (i < nbins) hist[i] = 0u;
   if (i < nresults) results[i] = 0ull;
@@ -35,6 +35,17 @@ __global__ __launch_bounds__(256) void series_begin_kernel(u64 *counters, u64 *r
       __hip_atomic_store(&fetched[0], fetched_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// a split pass (series.hip): what the pass's TAIL owns -- the counters and the histogram -- zeroed on the tail stream, behind the tail of the pass before it
+// -- and the pass's results block: the pass before this one may still read the block's last contents (it is the block of the pass before
+// THAT, whose running minimum and reductions it continues from) until its own tail is through, which on the tail stream it is
+__global__ __launch_bounds__(256) void series_tail_begin_kernel(u64 *counters, unsigned *hist, size_t nbins, u64 *results, size_t nresults)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < (size_t)CNT_N) counters[i] = 0ull;
+  if (i < nbins) hist[i] = 0u;
+  if (i < nresults) results[i] = 0ull;
 }
 
 // ---- the sticky factor: series_device.hpp ---------------------------------------------------------------------------------------------
@@ -160,9 +171,8 @@ __global__ __launch_bounds__(256) void bucket_rank_kernel(const u64 *__restrict_
 
 template <int ND>
 __global__ __launch_bounds__(kThreads) void series_record_kernel(const Mesh m, const Fields *__restrict__ fields, const u64 *__restrict__ sorted,
-                                                                 ftkx_cp_t *__restrict__ out /* pinned host memory */, const u64 *__restrict__ base_from /* records of the chunks before this one, or nullptr */)
+                                                                 ftkx_cp_t *__restrict__ out /* pinned host memory */)
 {
-  if (base_from) out += base_from[0];
   constexpr int N = ND + 1;
   __shared__ u64 s_rec[kThreads / 64][64 * 9];
   if (m.counters[CNT_SERIES_DONE]) return;
@@ -681,8 +691,7 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
 // One workgroup.  Runs behind the record kernel (a kernel boundary: its stores have been released); copies the device results block
 // into coherent pinned memory and stores the sequence number behind it with system scope -- the ONE thing the host waits for.
 __global__ __launch_bounds__(256) void series_finish_kernel(const u64 *__restrict__ counters, u64 *__restrict__ results, size_t nwords, u64 capacity, u64 list_capacity, u64 refine_capacity,
-                                                            const u64 *__restrict__ fragile, u64 fragile_capacity, u64 *__restrict__ h_results, unsigned *flag, unsigned seq,
-                                                            const u64 *__restrict__ base_from)
+                                                            const u64 *__restrict__ fragile, u64 fragile_capacity, u64 *__restrict__ h_results, unsigned *flag, unsigned seq)
 {
   if (counters[CNT_SERIES_DONE] == 1) return;           // (the fused tail has published everything already; 2 = abandoned by the factor kernel: reported here)
   __shared__ unsigned s_over;
@@ -694,7 +703,6 @@ __global__ __launch_bounds__(256) void series_finish_kernel(const u64 *__restric
     s_over = over;
     results[SR_NHITS] = hits;
     results[SR_NFRAGILE] = counters[CNT_FRAGILE];
-    results[SR_BASE_NEXT] = (base_from ? base_from[0] : 0ull) + (hits > capacity ? capacity : hits);   // where the next chunk's records start
   }
   __syncthreads();
   if (tid < (unsigned)CNT_N) results[SR_COUNTERS + tid] = counters[tid];
@@ -780,6 +788,13 @@ void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist,
                      (const u64 *)desc_src, (u64 *)desc_dst, desc_src ? desc_bytes / 8 : (size_t)0, fetched, fetched_val);
 }
 
+void launch_series_tail_begin(u64 *counters, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st)
+{
+  size_t n = nbins > (size_t)CNT_N ? nbins : (size_t)CNT_N;
+  n = n > nresults ? n : nresults;
+  hipLaunchKernelGGL(series_tail_begin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, counters, hist, nbins, results, nresults);
+}
+
 void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,
                            double safe_m, u64 *results, u64 *counters, hipStream_t st)
 { hipLaunchKernelGGL(series_factors_kernel, dim3(1), dim3(1024), 0, st, steps, nsteps, slices, nslices, sinfo, red, running_in, running_from, safe_m, results, counters); }
@@ -797,11 +812,11 @@ void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff
   hipLaunchKernelGGL(bucket_rank_kernel, dim3(256), dim3(256), 0, st, bucketed, m.capacity, boff, m.hist_shift, rank_max, sorted, m.counters, results);
 }
 
-void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, const u64 *base_from, hipStream_t st)
+void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, hipStream_t st)
 {
   const dim3 grid(256u * 2u);
-  if (m.nd == 2) hipLaunchKernelGGL(series_record_kernel<2>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out, base_from);
-  else hipLaunchKernelGGL(series_record_kernel<3>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out, base_from);
+  if (m.nd == 2) hipLaunchKernelGGL(series_record_kernel<2>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out);
+  else hipLaunchKernelGGL(series_record_kernel<3>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out);
 }
 
 void launch_series_small(const Mesh &m, const Mesh &mc, const Fields *d_steps, bool two_level, const u64 *d_refine, const u64 *d_list, ftkx_cp_t *out,
@@ -812,11 +827,10 @@ void launch_series_small(const Mesh &m, const Mesh &mc, const Fields *d_steps, b
   else hipLaunchKernelGGL(series_small_kernel<3>, dim3(kSmallGrid), dim3(kThreads), 0, st, m, mc, d_steps, two_level ? 1 : 0, d_refine, d_list, out, results, nwords, h_results, flag, seq, done, rd);
 }
 
-void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, const u64 *base_from,
-                          hipStream_t st)
+void launch_series_finish(const Mesh &m, u64 *results, size_t nwords, u64 list_capacity, u64 refine_capacity, u64 *h_results, unsigned *flag, unsigned seq, hipStream_t st)
 {
   hipLaunchKernelGGL(series_finish_kernel, dim3(1), dim3(256), 0, st, m.counters, results, nwords, m.capacity, list_capacity, refine_capacity, m.fragile, m.fragile_capacity,
-                     h_results, flag, seq, base_from);
+                     h_results, flag, seq);
 }
 
 }  // namespace ftkx

@@ -172,10 +172,11 @@ enum { SERIES_AMBIGUOUS = 1,        // 1 / resolution so close above a power of 
        SERIES_LATE_DECLINE = 64,    // the fused tail found more records than its last workgroup orders, took back what it had counted and left the pass to
                                     // the bucket chain (informational: the records are complete and ordered; rounds 3-4a sent them unordered for the host to sort)
        SERIES_TAIL_PENDING = 128,   // the pass was queued in its short form (mask, cull, fused tail) and the fused tail declined: the host queues the rest
+       SERIES_ONE = 512,            // (informational) the one-launch pass for small series did it (one_kernel.hip)
        SERIES_HALO_FULL = 256 };    // slab pass (ftkx_series_dist_*): the halo slice is needed as a whole (too many surviving cells for a request, a mask
                                     // message that did not fit, masks the host will rebuild): the request said -1, nothing was swept
 // results block (device copy and coherent pinned copy, same layout; u64 words)
-enum { SR_STATUS = 0, SR_RUNNING = 1, SR_NHITS = 2, SR_NFRAGILE = 3, SR_BASE_NEXT = 4 /* chunked pass: records of this chunk and the ones before it */,
+enum { SR_STATUS = 0, SR_RUNNING = 1, SR_NHITS = 2, SR_NFRAGILE = 3, SR_SPARE = 4,
        SR_HALO_ASKED = 5,    // slab pass: cells this rank asked its upper neighbour for (-1: the whole slice), 0 without a halo
        SR_HALO_SERVED = 6,   // slab pass: what the lower neighbour asked this rank for (-1: it needs this rank's first slice as a whole)
        SR_COUNTERS = 7, SR_HEAD = 7 + CNT_N };   // then factors[nsteps], res[nslices], max[nslices], [slab pass: 4 words per rank as gathered], fragile[cap * 10]
@@ -183,6 +184,23 @@ enum { SR_STATUS = 0, SR_RUNNING = 1, SR_NHITS = 2, SR_NFRAGILE = 3, SR_BASE_NEX
 // results block whose SR_RUNNING word is the running minimum BEFORE this rank's slab (what FactorJob::running_from reads)
 enum { DB_WORDS = 0 /* mask words compacted into the outgoing message */, DB_BAD = 1 /* the incoming mask message did not fit / did not match */,
        DB_DONE = 2 /* workgroups of the export kernel that have finished */, DB_BAD2 = 3 /* the incoming message named a word outside the mask array */, DB_PSEUDO = 8, DB_N = 16 };
+// the one-launch pass for small series (one_kernel.hip): everything the kernel needs comes by value, in its arguments
+constexpr int kOneMaxSlices = 48, kOneMaxSteps = 47, kOneParts = 8;
+constexpr unsigned kOneKeys = 1024;             // order keys a workgroup parks in LDS
+struct OneSlice { const double *S, *V, *J; int t, pad; };
+struct OneStep { int t, scope, slice0, slice1, last, pad; };
+struct OneArgs {
+  int nsteps, nslices;
+  OneSlice slice[kOneMaxSlices];
+  OneStep step[kOneMaxSteps];
+  double running_in, cap;                      // the running minimum before this pass; 1 / hint: only components below it can lower the minimum
+  const u64 *running_from;                     // a results block on the device whose SR_RUNNING word this pass continues from (nullable)
+  u64 *scratch;                                // ONE_* words, zero between launches
+  u64 *results, *h_results; size_t nwords; unsigned *flag; unsigned seq;
+  ftkx_cp_t *out; u64 capacity; u64 *fragile; u64 fragile_capacity;
+};
+enum { ONE_BAR = 0 /* three 32-bit arrival counters */, ONE_TESTED = 2, ONE_NFRAG = 3, ONE_COUNTS = 8 /* one word per workgroup */, ONE_PARTS = 8 + 256,
+       ONE_WORDS = 8 + 256 + 2 * kOneMaxSlices * kOneParts };
 constexpr int kDistContrib = 4;            // words a rank contributes to the all_gather: slab min resolution, slab max |v|, the same of its FIRST slice
 
 }  // namespace ftkx

@@ -170,12 +170,76 @@ critical_point_tracker_regular::critical_point_tracker_regular(int nd_, const st
 critical_point_tracker_regular::~critical_point_tracker_regular()
 {
   ftkx_online_tracer_destroy(online);
+  if (slab) ftkx_slab_destroy(slab);
   if (multi) multi.reset();   // joins the workers, destroys their contexts (ctx is one of them)
   else ftkx_destroy(ctx);
 }
 
+// ---- several ranks behind the tracker: slab mode -----------------------------------------------------------------------------------------
+void critical_point_tracker_regular::enter_slab_mode(int rank, int nranks, int nt)
+{
+  if (multi) throw ftkx_error(FTKX_E_UNSUPPORTED, "slab mode: a tracker with one device (several devices of one process: one tracker per device over a ftkx_slab_hub)");
+  if (slab || !field_data_snapshots.empty()) throw ftkx_error(FTKX_E_INVALID, "slab mode: set it once, before the first snapshot is pushed");
+  if (enable_streaming_trajectories) throw ftkx_error(FTKX_E_UNSUPPORTED, "slab mode: not with streaming trajectories");
+  if (nt <= 0 || nranks <= 0 || rank < 0 || rank >= nranks) throw ftkx_error(FTKX_E_INVALID, "slab mode: bad rank / nranks / nt");
+  slab_nt = nt; slab_rank = rank; slab_nranks = nranks;
+  ftkx_slab_range(nt, nranks, rank, &slab_t0, &slab_t1);
+  current_timestep = next_push_timestep = slab_t0;          // the first snapshot this rank pushes is its slab's first timestep
+  slab_steps.clear(); slab_swept = false;
+}
+
+void critical_point_tracker_regular::set_communicator(void *comm, int rank, int nranks, int nt)
+{
+  enter_slab_mode(rank, nranks, nt);
+  check(ftkx_slab_create_rccl(ctx, nt, rank, nranks, comm, nullptr, &slab));
+}
+
+void critical_point_tracker_regular::set_slab_transport(const ftkx_slab_transport &tr, int rank, int nranks, int nt)
+{
+  enter_slab_mode(rank, nranks, nt);
+  check(ftkx_slab_create(ctx, nt, rank, nranks, &tr, &slab));
+}
+
+void critical_point_tracker_regular::set_slab_hub(ftkx_slab_hub *hub, int rank, int nt)
+{
+  if (!hub) throw ftkx_error(FTKX_E_INVALID, "set_slab_hub: null hub");
+  ftkx_slab *probe = nullptr;
+  // (the hub knows how many ranks it has: the slab says so)
+  check(ftkx_slab_create_local(ctx, nt, rank, hub, &probe));
+  ftkx_slab_info info;
+  ftkx_slab_get_info(probe, &info);
+  try { enter_slab_mode(rank, info.nranks, nt); } catch (...) { ftkx_slab_destroy(probe); throw; }
+  slab = probe;
+}
+
+// the slab's pass: every step recorded so far must be the slab's -- t0 .. t1 - 1 in order -- and every snapshot still resident
+void critical_point_tracker_regular::run_slab() const
+{
+  critical_point_tracker_regular *self = const_cast<critical_point_tracker_regular *>(this);
+  const int nown = slab_t1 - slab_t0;
+  if ((int)slab_steps.size() != nown || (int)field_data_snapshots.size() != nown)
+    throw ftkx_error(FTKX_E_INVALID, "slab mode: " + std::to_string(slab_steps.size()) + " steps recorded and " + std::to_string(field_data_snapshots.size()) +
+                     " snapshots pushed of this rank's " + std::to_string(nown) + " (push the slab's snapshots, advance_timestep() between them, update_timestep() after the last)");
+  for (int i = 0; i < nown; i ++) if (slab_steps[(size_t)i] != slab_t0 + i) throw ftkx_error(FTKX_E_INVALID, "slab mode: the steps must be the slab's timesteps in order");
+  auto slab_check = [&](int rc) { if (rc != FTKX_OK) throw ftkx_error(rc, ftkx_slab_last_error(slab)); };
+  slab_check(ftkx_slab_submit(slab, &vector_field_resolution));
+  std::vector<unsigned long long> f((size_t)std::max(nown, 1), 0ull);
+  const ftkx_cp_t *recs = nullptr;
+  size_t n = 0;
+  double run = vector_field_resolution;
+  slab_check(ftkx_slab_complete(slab, &run, f.data(), &recs, &n));
+  self->slab_swept = true;
+  if (nown > 0) {
+    self->vector_field_resolution = std::min(vector_field_resolution, run);
+    self->vector_field_scaling_factor = f[(size_t)nown - 1];
+    for (size_t i = 0; i < n; i ++) self->take_records(recs + i, 1, ftkx_cp_timestep(recs + i));
+    check(ftkx_get_stats(ctx, &self->last_stats));
+  }
+}
+
 void critical_point_tracker_regular::wait_devices() const
 {
+  if (slab) { if (!slab_swept) run_slab(); return; }
   if (multi) {
     multi->wait_all();
     multi->rethrow();
@@ -328,12 +392,13 @@ void critical_point_tracker_regular::initialize()
 // Like the reference, the running resolution is NOT reset.
 void critical_point_tracker_regular::reset()
 {
-  sync();
+  if (!slab) sync();                            // (slab mode: sync() is the slab's pass, a collective -- a reset does not sweep)
   ftkx_online_tracer_destroy(online); online = nullptr;
   if (multi) { multi->base_resolution = vector_field_resolution; multi->res_below.clear(); multi->t_first = -1; }
   current_timestep = 0;
   while (pop_field_data_snapshot()) {}
   next_push_timestep = 0;
+  if (slab) { current_timestep = next_push_timestep = slab_t0; slab_steps.clear(); slab_swept = false; }
   pending_points.clear(); pending_ascending = true;
   points.clear(); point_keys.clear();
   discrete_critical_points.clear(); map_valid = true;
@@ -350,6 +415,7 @@ static int push_to(ftkx_ctx *c, int kind, int t, const double *s, const double *
 void critical_point_tracker_regular::push_everywhere(int kind, int t, const double *s, const double *v, const double *j, bool device)
 {
   auto fail = [](ftkx_ctx *c, int rc) { char buf[512]; ftkx_last_error(c, buf, sizeof(buf)); throw ftkx_error(rc, buf); };
+  if (slab && (t < slab_t0 || t >= slab_t1)) throw ftkx_error(FTKX_E_INVALID, "slab mode: timestep " + std::to_string(t) + " is not in this rank's slab [" + std::to_string(slab_t0) + ", " + std::to_string(slab_t1) + ")");
   if (!multi) { const int rc = push_to(ctx, kind, t, s, v, j, device ? 1 : 0); if (rc) fail(ctx, rc); return; }
   if (multi->t_first < 0) multi->t_first = t;
   std::set<int> targets;
@@ -450,6 +516,11 @@ void critical_point_tracker_regular::take_records(const ftkx_cp_t *recs, size_t 
 void critical_point_tracker_regular::update_timestep()
 {
   if (field_data_snapshots.empty()) return;
+  if (slab) {                                   // slab mode: the step is recorded; the slab is swept as one pass (run_slab)
+    if (slab_swept) throw ftkx_error(FTKX_E_INVALID, "slab mode: the slab has been swept (reset() starts a new series)");
+    if (slab_steps.empty() || slab_steps.back() != current_timestep) slab_steps.push_back(current_timestep);
+    return;
+  }
   const int scope = field_data_snapshots.size() >= 2 ? FTKX_SCOPE_BOTH : FTKX_SCOPE_ORDINAL;
   if (!multi) {
     // (the step that follows is known before its factor is: announced, its cull is queued right behind the mask kernel of the
@@ -520,6 +591,7 @@ void critical_point_tracker_regular::update_timestep()
 bool critical_point_tracker_regular::advance_timestep()
 {
   update_timestep();
+  if (slab) { current_timestep ++; return current_timestep < next_push_timestep; }      // (slab mode: the snapshots stay until the slab's pass has run)
   pop_field_data_snapshot();
   current_timestep ++;
   return field_data_snapshots.size() > 0;
@@ -553,6 +625,33 @@ void critical_point_tracker_regular::grow()
 void critical_point_tracker_regular::finalize()
 {
   wait_devices();
+  if (slab) {
+    // critical_point_tracker.hh:689: the ranks' discrete points gathered on the root, which traces them -- curves cross slab boundaries like
+    // any other cell boundary.  The other ranks keep their own points and end without trajectories.
+    flush_points();
+    std::vector<ftkx_cp_t> mine(points.size());
+    for (size_t i = 0; i < points.size(); i ++) {
+      const feature_point_t &cp = points[i];
+      ftkx_cp_t r;
+      std::memset(&r, 0, sizeof(r));
+      for (int k = 0; k < 3; k ++) { r.x[k] = cp.x[k]; r.scalar[k] = cp.scalar[k]; }
+      r.t = cp.t; r.type = cp.type; r.tag = cp.tag;
+      reinterpret_cast<unsigned int *>(&r)[15] = ((unsigned)cp.timestep << 1) | (cp.ordinal ? 1u : 0u);
+      mine[i] = r;
+    }
+    ftkx_cp_t *merged = nullptr;
+    size_t nm = 0;
+    const int rc = ftkx_slab_gather_records(slab, mine.data(), mine.size(), 0, &merged, &nm);
+    if (rc != FTKX_OK) throw ftkx_error(rc, ftkx_slab_last_error(slab));
+    if (slab_rank != 0) {
+      traced_points.clear(); traced_offsets.assign(1, 0); traced_nested_valid = false; traced_loop.clear(); traced_id.clear();
+      return;
+    }
+    points.clear(); point_keys.clear(); pending_points.clear(); pending_ascending = true;
+    discrete_critical_points.clear(); map_valid = false;
+    for (size_t i = 0; i < nm; i ++) take_records(merged + i, 1, ftkx_cp_timestep(merged + i));
+    ftkx_free(merged);
+  }
   if (enable_streaming_trajectories) {
     flush_points();             // 2d:150-151: "done" -- the trajectories are what grow() built
     traced_points.clear(); traced_offsets.assign(1, 0); traced_nested_valid = false; traced_loop.clear(); traced_id.clear();
@@ -833,6 +932,10 @@ int ftkx_tracker_set_flags(ftkx_tracker *h, int robust, int use_tf, unsigned tf,
 }
 int ftkx_tracker_set_stream(ftkx_tracker *h, void *s) { return guarded(h, [&] { h->t->set_stream(s); }); }
 int ftkx_tracker_set_deferred_collection(ftkx_tracker *h, int on) { return guarded(h, [&] { h->t->set_deferred_collection(on != 0); }); }
+int ftkx_tracker_set_communicator(ftkx_tracker *h, void *comm, int rank, int nranks, int nt) { return guarded(h, [&] { h->t->set_communicator(comm, rank, nranks, nt); }); }
+int ftkx_tracker_set_slab_transport(ftkx_tracker *h, const ftkx_slab_transport *tr, int rank, int nranks, int nt)
+{ return guarded(h, [&] { if (!tr) throw ftkx::ftkx_error(FTKX_E_INVALID, "null transport"); h->t->set_slab_transport(*tr, rank, nranks, nt); }); }
+int ftkx_tracker_set_slab_hub(ftkx_tracker *h, ftkx_slab_hub *hub, int rank, int nt) { return guarded(h, [&] { h->t->set_slab_hub(hub, rank, nt); }); }
 int ftkx_tracker_set_enable_streaming_trajectories(ftkx_tracker *h, int on) { return guarded(h, [&] { h->t->set_enable_streaming_trajectories(on != 0); }); }
 int ftkx_tracker_set_current_timestep(ftkx_tracker *h, int t)
 { return guarded(h, [&] { if (t < 0) throw ftkx::ftkx_error(FTKX_E_INVALID, "set_current_timestep: negative timestep"); h->t->set_current_timestep(t); }); }
@@ -858,16 +961,17 @@ int ftkx_tracker_update_timestep(ftkx_tracker *h) { return guarded(h, [&] { h->t
 
 int ftkx_tracker_num_critical_points(const ftkx_tracker *h, size_t *n)
 {
-  if (!h || !h->t || !n) return FTKX_E_INVALID;
-  *n = h->t->num_discrete_critical_points();
-  return FTKX_OK;
+  if (!n) return FTKX_E_INVALID;
+  return guarded(const_cast<ftkx_tracker *>(h), [&] { *n = h->t->num_discrete_critical_points(); });
 }
 
 int ftkx_tracker_get_critical_points(const ftkx_tracker *h, ftkx_cp_t *out, int *ordinal, int *timestep, size_t cap)
 {
   if (!h || !h->t || !out) return FTKX_E_INVALID;
   size_t i = 0;
-  const std::vector<ftkx::feature_point_t> pts = h->t->get_critical_points();
+  std::vector<ftkx::feature_point_t> pts;
+  const int rc = guarded(const_cast<ftkx_tracker *>(h), [&] { pts = h->t->get_critical_points(); });
+  if (rc) return rc;
   for (const ftkx::feature_point_t &cp : pts) {
     if (i >= cap) break;
     std::memset(&out[i], 0, sizeof(ftkx_cp_t));
@@ -882,10 +986,11 @@ int ftkx_tracker_get_critical_points(const ftkx_tracker *h, ftkx_cp_t *out, int 
 
 int ftkx_tracker_get_scaling(const ftkx_tracker *h, unsigned long long *factor, double *resolution)
 {
-  if (!h || !h->t) return FTKX_E_INVALID;
-  if (factor) *factor = h->t->get_vector_field_scaling_factor();
-  if (resolution) *resolution = h->t->get_vector_field_resolution();
-  return FTKX_OK;
+  // (a getter waits for what is still out -- a several-device tracker's queues, a slab's pass: whatever that raises is the call's error)
+  return guarded(const_cast<ftkx_tracker *>(h), [&] {
+    if (factor) *factor = h->t->get_vector_field_scaling_factor();
+    if (resolution) *resolution = h->t->get_vector_field_resolution();
+  });
 }
 
 int ftkx_tracker_finalize(ftkx_tracker *h) { return guarded(h, [&] { h->t->finalize(); }); }
@@ -945,9 +1050,8 @@ int ftkx_tracker_read_critical_points(ftkx_tracker *h, const char *path, int for
 
 int ftkx_tracker_get_stats(const ftkx_tracker *h, ftkx_stats *st)
 {
-  if (!h || !h->t || !st) return FTKX_E_INVALID;
-  *st = h->t->get_last_stats();
-  return FTKX_OK;
+  if (!st) return FTKX_E_INVALID;
+  return guarded(const_cast<ftkx_tracker *>(h), [&] { *st = h->t->get_last_stats(); });
 }
 
 }  // extern "C"

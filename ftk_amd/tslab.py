@@ -219,157 +219,201 @@ def compact_halo_patches(ctx, own, nt, t_masked, first_slice=None, halo_buffer=N
 
 
 class SlabSeries:
-    """One rank's DEVICE-DRIVEN pass over its timestep slab (include/ftkx.h: ftkx_series_dist_*), with the ranks' links -- the sticky
-    running minimum across slabs (critical_point_tracker.hh:850-864) and the compact halo -- as collectives queued between the stages:
+    """One rank's DEVICE-DRIVEN pass over its timestep slab -- a thin caller of the C++ host, include/ftkx_slab.h (ftk_amd/csrc/slab.cpp):
 
         begin (masks, reduction, contribution, outgoing masks)  | all_gather of 4 doubles per rank; masks -> lower neighbour
         cull  (masks imported, factors, cull, request)          | request -> upper neighbour
         serve (patches around the neighbour's cells)            | reply -> lower neighbour
         finish (patches scattered, exact test, records)         | complete(): the ONE host wait of the pass
 
-    Backend nccl (= RCCL): every collective is queued on torch's current stream, which must be the context's stream
-    (`torch.cuda.set_stream(s); ctx.set_stream(s.cuda_stream)`): nothing waits on the host.  Backend gloo (dry runs, tests): the same
-    stages with the messages staged through host memory.  Two passes may be in flight (submit, submit, complete, ...).
-    Where the halo is needed as a whole slice (request -1) both sides learn it from the same number, exchange `first_slice`, and the
-    asker sweeps again with the full slice (`push` = ctx.push_scalar_slice / push_slice); the next pass starts compact again."""
+    The stages, the order of the messages, two passes in flight and the whole-slice recovery live THERE, once.  What this class adds is
+    the transport.  Backend nccl: the library's own RCCL transport (ncclAllGather, grouped ncclSend / ncclRecv on the context's stream and a
+    side stream; the communicator is made here from an id broadcast over torch.distributed).  Backend gloo (dry runs, tests): a table of
+    two Python callbacks that stage the messages through host memory and torch.distributed.  A context stand-in with a `slab_backend()`
+    method (tests/test_tslab.py: the oracle on the CPU) is driven through ftkx_slab_create_custom."""
 
     def __init__(self, ctx, nt, own, scalar_input, torch, device, first_slice=None, group=None):
+        import ctypes as C
         import torch.distributed as dist
+        from . import _lib
         self.ctx, self.nt, self.own, self.scalar, self.torch, self.dist, self.group = ctx, nt, list(own), scalar_input, torch, dist, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.staged = dist.get_backend(group) != "nccl"
-        self.dev = device
-        t0, t1 = (self.own[0], self.own[-1] + 1) if self.own else (0, 0)
-        self.t_halo = t1 if (self.own and t1 < nt) else None
-        self.lower = owner_of(t0 - 1, nt, self.world) if self.own and t0 > 0 else None      # the rank whose last interval sweep reads OUR first slice
-        self.upper = owner_of(t1, nt, self.world) if self.t_halo is not None else None
-        self.first_slice = first_slice
-        self.full_halo = None
-        self.ts = np.array(self.own, dtype=np.int32)
-        self.scopes = np.array([3 if t + 1 < nt else 1 for t in self.own], dtype=np.int32)      # FTKX_SCOPE_BOTH / _ORDINAL
-        nbytes, _ = ctx.packed_masks_bytes() if self.own else (0, 0)
-        cells = ctx.series_dist_cells() if self.own else 0
-        pd = ctx.patch_doubles() if self.own else 0
-        if self.own and (nbytes == 0 or cells == 0) and (self.lower is not None or self.upper is not None):
-            raise RuntimeError("slab pass: this mesh has no summarised masks (use the host-driven protocol)")
-        f64, i64, u8 = torch.float64, torch.int64, torch.uint8
-        z = lambda n, dt: torch.zeros((max(int(n), 1),), dtype=dt, device=device)
-        self.sets = []
-        for _ in range(2):
-            self.sets.append(dict(contrib=torch.tensor([DBL_MAX, 0.0, DBL_MAX, 0.0], dtype=f64, device=device), gathered=z(4 * self.world, f64),
-                                  masks_out=z(nbytes, u8) if self.lower is not None else None, masks_in=z(nbytes, u8) if self.upper is not None else None,
-                                  req_out=z(1 + cells, i64) if self.upper is not None else None, req_in=z(1 + cells, i64) if self.lower is not None else None,
-                                  reply_out=z(cells * pd, f64) if self.lower is not None else None, reply_in=z(cells * pd, f64) if self.upper is not None else None))
-        # (nccl) the masks' way to the lower neighbour runs on a stream of its own: it starts as soon as the first slice's masks are packed,
-        # next to the mask kernel of the slab's other slices; the context's stream waits for it in front of the cull
-        self.side = torch.cuda.Stream(device=device) if (not self.staged and self.own and (self.lower is not None or self.upper is not None)) else None
-        self.k = 0
-        self.open = []              # buffer sets of the passes in flight, oldest first
-        self.stash = []             # outcomes of passes completed early (a recovery needed the context free)
-        self.bytes_sent = self.bytes_received = 0
-        self.fallbacks = 0
-
-    # ---- the collectives: queued on the stream (nccl) or staged through the host (gloo) ----
-    def _all_gather(self, out, mine):
-        if self.staged:
-            self.torch.cuda.current_stream().synchronize() if mine.is_cuda else None
-            h = self.torch.empty((out.numel(),), dtype=out.dtype)
-            self.dist.all_gather_into_tensor(h, mine.cpu(), group=self.group)
-            out.copy_(h)
+        self._L = L = _lib.load()
+        self._C = C
+        t0, t1 = slab_range(nt, self.world, self.rank)
+        assert list(range(t0, t1)) == self.own, "the slab of this rank: slab_range(nt, world, rank)"
+        self._err = None
+        self._comm = None
+        self._h = C.c_void_p()
+        custom = hasattr(ctx, "slab_backend")
+        if custom:
+            self._backend = ctx.slab_backend()
+            self._copy_in, self._copy_out = ctx.slab_upload, ctx.slab_download
         else:
-            self.dist.all_gather_into_tensor(out, mine, group=self.group)
+            self._copy_in = lambda dst, src_np: _lib.check(L.ftkx_upload(ctx._h, dst, src_np.ctypes.data, src_np.nbytes), ctx._h)
+            self._copy_out = lambda dst_np, src: _lib.check(L.ftkx_download(ctx._h, dst_np.ctypes.data, src, dst_np.nbytes), ctx._h)
+        if self.staged or custom:
+            self._tr = _lib.SlabTransport(None, _lib.AG_FN(self._cb_all_gather), _lib.XCHG_FN(self._cb_exchange), 0, _lib.DESTROY_FN())
+            rc = (L.ftkx_slab_create_custom(C.byref(self._backend), nt, self.rank, self.world, C.byref(self._tr), C.byref(self._h)) if custom
+                  else L.ftkx_slab_create(ctx._h, nt, self.rank, self.world, C.byref(self._tr), C.byref(self._h)))
+        else:
+            # RCCL inside the library: a communicator of our own over the same ranks (torch does not hand its ncclComm_t out)
+            idbuf = torch.zeros((128,), dtype=torch.uint8, device=device)
+            if self.rank == 0:
+                raw = (C.c_ubyte * 128)()
+                _lib.check(L.ftkx_rccl_unique_id(raw))
+                idbuf.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            dist.broadcast(idbuf, 0, group=group)
+            raw = (C.c_ubyte * 128).from_buffer_copy(bytes(idbuf.cpu().numpy().tobytes()))
+            comm = C.c_void_p()
+            _lib.check(L.ftkx_rccl_comm_create(raw, self.rank, self.world, int(device.index or 0), C.byref(comm)))
+            self._comm = comm
+            rc = L.ftkx_slab_create_rccl(ctx._h, nt, self.rank, self.world, comm, None, C.byref(self._h))
+        if rc != 0:
+            msg = _lib.last_error(None)
+            if rc == E_UNSUPPORTED:
+                raise RuntimeError("slab pass: " + msg)
+            raise _lib.FtkxError(rc, msg)
+        self._base = (0, 0, 0)
+        self.last_path, self.last_asked = (0, 0), 0
 
-    def _exchange(self, send, to, recv, frm):
-        ops, back = [], None
-        if to is not None:
-            if self.staged and send.is_cuda:
-                self.torch.cuda.current_stream().synchronize()
-            ops.append(self.dist.P2POp(self.dist.isend, send.cpu() if self.staged else send, to, self.group))
-            self.bytes_sent += send.numel() * send.element_size()
-        if frm is not None:
-            back = self.torch.empty(recv.shape, dtype=recv.dtype) if self.staged else recv
-            ops.append(self.dist.P2POp(self.dist.irecv, back, frm, self.group))
-            self.bytes_received += recv.numel() * recv.element_size()
-        if ops:
-            for r in self.dist.batch_isend_irecv(ops):
-                r.wait()               # (nccl: the CURRENT STREAM waits, not the host)
-        if frm is not None and self.staged:
-            recv.copy_(back)
+    @classmethod
+    def local(cls, ctx, nt, rank, world, hub):
+        """a rank of ONE process (include/ftkx_slab.h: ftkx_slab_hub_*): peer copies between the ranks' devices, every rank driven by a thread
+        of its own.  hub: the handle ftkx_slab_hub_create(world) gave."""
+        import ctypes as C
+        from . import _lib
+        self = object.__new__(cls)
+        self.ctx, self.nt, self.world, self.rank, self.group = ctx, nt, world, rank, None
+        self._L, self._C, self._err, self._comm = _lib.load(), C, None, None
+        self.own = list(range(*slab_range(nt, world, rank)))
+        self._h = C.c_void_p()
+        _lib.check(self._L.ftkx_slab_create_local(ctx._h, nt, rank, hub, C.byref(self._h)))
+        self._base = (0, 0, 0)
+        self.last_path, self.last_asked = (0, 0), 0
+        return self
+
+    @classmethod
+    def rccl(cls, ctx, nt, rank, world, comm, side_comm=None):
+        """over a caller's ncclComm_t (ftkx_slab_create_rccl)"""
+        import ctypes as C
+        from . import _lib
+        self = object.__new__(cls)
+        self.ctx, self.nt, self.world, self.rank, self.group = ctx, nt, world, rank, None
+        self._L, self._C, self._err, self._comm = _lib.load(), C, None, None
+        self.own = list(range(*slab_range(nt, world, rank)))
+        self._h = C.c_void_p()
+        _lib.check(self._L.ftkx_slab_create_rccl(ctx._h, nt, rank, world, comm, side_comm, C.byref(self._h)))
+        self._base = (0, 0, 0)
+        self.last_path, self.last_asked = (0, 0), 0
+        return self
+
+    # ---- the host-staged transport (gloo): called back from ftkx_slab_submit / _complete ----
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except BaseException as e:      # noqa: BLE001  (an exception cannot cross the C frames: kept, re-raised by the caller of the C function)
+            self._err = e
+            return -2
+
+    def _cb_all_gather(self, user, send, recv, nbytes, stream):
+        def run():
+            torch = self.torch
+            mine = np.empty((nbytes,), dtype=np.uint8)
+            self._copy_out(mine, send)
+            out = torch.empty((nbytes * self.world,), dtype=torch.uint8)
+            self.dist.all_gather_into_tensor(out, torch.from_numpy(mine), group=self.group)
+            self._copy_in(recv, out.numpy())
+        return self._guard(run)
+
+    def _cb_exchange(self, user, send, sb, to, recv, rb, frm, stream):
+        def run():
+            torch, dist = self.torch, self.dist
+            ops, back = [], None
+            if to >= 0:
+                out = np.empty((sb,), dtype=np.uint8)
+                self._copy_out(out, send)
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(out), to, self.group))
+            if frm >= 0:
+                back = torch.empty((rb,), dtype=torch.uint8)
+                ops.append(dist.P2POp(dist.irecv, back, frm, self.group))
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+            if back is not None:
+                self._copy_in(recv, back.numpy())
+        return self._guard(run)
+
+    def _ck(self, rc):
+        err, self._err = self._err, None
+        if err is not None:
+            raise err
+        if rc != 0:
+            from . import _lib
+            raise _lib.FtkxError(rc, (self._L.ftkx_slab_last_error(self._h) or b"").decode(errors="replace"))
+
+    def _info(self):
+        from . import _lib
+        i = _lib.SlabInfo()
+        self._L.ftkx_slab_get_info(self._h, self._C.byref(i))
+        return i
+
+    # (bench.py sets these to 0 in front of its timed region)
+    bytes_sent = property(lambda self: self._info().bytes_sent - self._base[0], lambda self, v: self._rebase(0, v))
+    bytes_received = property(lambda self: self._info().bytes_received - self._base[1], lambda self, v: self._rebase(1, v))
+    fallbacks = property(lambda self: self._info().fallbacks - self._base[2], lambda self, v: self._rebase(2, v))
+
+    def _rebase(self, k, v):
+        i = self._info()
+        b = list(self._base)
+        b[k] = (i.bytes_sent, i.bytes_received, i.fallbacks)[k] - int(v)
+        self._base = tuple(b)
 
     def submit(self, running_resolution=None):
-        b = self.sets[self.k]
-        self.k ^= 1
-        if not self.own:               # (more ranks than timesteps: this rank only takes part in the all_gather)
-            self._all_gather(b["gathered"], b["contrib"])
-            self.open.append(b)
-            return
-        ctx = self.ctx
-        ctx.series_dist_begin(self.ts, self.scopes, running_resolution, self.rank, self.world, self.upper, b["contrib"], b["gathered"], b["masks_out"],
-                              side_stream=self.side.cuda_stream if self.side is not None else None)
-        if self.side is not None:
-            main = self.torch.cuda.current_stream()
-            with self.torch.cuda.stream(self.side):
-                self._exchange(b["masks_out"], self.lower, b["masks_in"], self.upper)
-            self._all_gather(b["gathered"], b["contrib"])
-            main.wait_stream(self.side)
-        else:
-            self._all_gather(b["gathered"], b["contrib"])
-            self._exchange(b["masks_out"], self.lower, b["masks_in"], self.upper)
-        ctx.series_dist_cull(b["masks_in"], b["req_out"])
-        self._exchange(b["req_out"], self.upper, b["req_in"], self.lower)
-        ctx.series_dist_serve(b["req_in"], b["reply_out"])
-        self._exchange(b["reply_out"], self.lower, b["reply_in"], self.upper)
-        ctx.series_dist_finish(b["reply_in"])
-        b["running_in"] = DBL_MAX if running_resolution is None else float(running_resolution)
-        self.open.append(b)
-
-    def _complete_local(self, copy):
-        from . import FtkxError
-        try:
-            recs, f, run = self.ctx.sweep_series_complete(copy=copy)
-            failed = False
-        except FtkxError as e:
-            if e.code != E_NOSLICE:
-                raise
-            recs, f, run, failed = None, None, None, True
-        asked, served, g = self.ctx.series_dist_status(self.world)
-        return dict(recs=recs, f=f, run=run, failed=failed, asked=asked, served=served, gathered=g, path=self.ctx.series_last_path())
+        C = self._C
+        run = C.c_double(DBL_MAX if running_resolution is None else float(running_resolution))
+        self._ck(self._L.ftkx_slab_submit(self._h, C.byref(run)))
 
     def complete(self, copy=True, push=None):
         """the oldest pass in flight -> (records, factors, running resolution)"""
-        b = self.open.pop(0)
-        if not self.own:
-            return np.zeros((0,), dtype=_empty_records_dtype()), np.zeros((0,), dtype=np.uint64), DBL_MAX
-        o = self.stash.pop(0) if self.stash else self._complete_local(copy)
-        need, give = o["asked"] < 0 and self.upper is not None, o["served"] < 0 and self.lower is not None
-        if need or give:
-            # the whole slice after all: both sides know from the same number.  The context must be free for the second sweep: the pass
-            # queued behind this one (if any) is collected first, its outcome kept for the next call
-            if need and self.open and not self.stash:
-                self.stash.append(self._complete_local(True))
-            self.fallbacks += 1 if need else 0
-            buf = None
-            if need:
-                if self.full_halo is None:
-                    self.full_halo = self.torch.empty_like(self.first_slice)
-                buf = self.full_halo
-            self._exchange(self.first_slice if give else None, self.lower if give else None, buf, self.upper if need else None)
-            if need:
-                self.torch.cuda.current_stream().synchronize() if buf.is_cuda else None
-                ctx = self.ctx
-                try:
-                    ctx.drop_slice(self.t_halo)      # the masks-only slice (gone already if the pass before this one needed the slice too)
-                except Exception as e:               # noqa: BLE001
-                    if getattr(e, "code", None) != E_NOSLICE:
-                        raise
-                (ctx.push_scalar_slice if self.scalar else ctx.push_slice)(self.t_halo, buf)
-                run_in = min([b.get("running_in", DBL_MAX)] + [float(v) for v in o["gathered"][:self.rank, 0]])
-                recs, f, run = ctx.sweep_series(self.ts, self.scopes, run_in, copy=True)
-                o.update(recs=recs, f=f, run=run, path=ctx.series_last_path())
-                ctx.drop_slice(self.t_halo)          # (the next pass starts compact again)
-        self.last_path = o["path"]
-        self.last_asked = o["asked"]
-        return o["recs"], o["f"], o["run"]
+        from . import _lib
+        C = self._C
+        run = C.c_double(0.0)
+        n = len(self.own)
+        f = np.zeros((max(1, n),), dtype=np.uint64)
+        out, cnt = C.c_void_p(), C.c_size_t()
+        self._ck(self._L.ftkx_slab_complete(self._h, C.byref(run), f.ctypes.data, C.byref(out), C.byref(cnt)))
+        i = self._info()
+        self.last_path, self.last_asked = (int(i.last_path), int(i.last_status)), int(i.last_asked)
+        return _lib.records_from(out.value, cnt.value, copy), f[:n], run.value
+
+    def gather_records(self, recs, root=0):
+        """ftkx_slab_gather_records: every rank's records on `root`, sorted by tag (None elsewhere); over the slab's own transport"""
+        from . import _lib
+        C = self._C
+        recs = np.ascontiguousarray(recs)
+        out, cnt = C.c_void_p(), C.c_size_t()
+        self._ck(self._L.ftkx_slab_gather_records(self._h, recs.ctypes.data if len(recs) else None, len(recs), int(root), C.byref(out), C.byref(cnt)))
+        if self.rank != root:
+            return None
+        merged = _lib.records_from(out.value, cnt.value, True)
+        self._L.ftkx_free(out)
+        return merged
+
+    def close(self):
+        if self._h:
+            self._L.ftkx_slab_destroy(self._h)
+            self._h = self._C.c_void_p()
+        if self._comm is not None:
+            self._L.ftkx_rccl_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
 
 
 def _empty_records_dtype():

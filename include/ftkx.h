@@ -259,7 +259,7 @@ int ftkx_series_dist_finish(ftkx_ctx *ctx, const void *reply_in);
 int ftkx_series_dist_status(const ftkx_ctx *ctx, long long *asked, long long *served, double *gathered, int nranks);
 
 /* which way the last ftkx_sweep_series went: 1 = device-driven, 2 = device-driven and finished by the fused tail kernel (sparse
- * data), 3 = device-driven in chunks (hit-dense data: the tail of a chunk runs next to the mask kernel of the next), 0 = host-driven batch; *status (nullable) = the SERIES_* bits the kernels raised (csrc/sweep_params.hpp) */
+ * data), 0 = host-driven batch; *status (nullable) = the SERIES_* bits the kernels raised (csrc/sweep_params.hpp) */
 int ftkx_series_last_path(const ftkx_ctx *ctx, unsigned long long *status);
 
 /* counters of the last collect: simplices visited (work items), cells/simplices surviving the cull, device-side hits */

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "ftkx.h"
+#include "ftkx_slab.h"
 
 namespace ftkx {
 
@@ -140,6 +141,20 @@ public:
   // sync() and finalize() collect what is still out first.  A snapshot pushed as a DEVICE pointer is borrowed, not copied: with this on
   // it must stay valid until the step AFTER the one that pops it has been advanced (or sync() has been called).
   void set_deferred_collection(bool b) { sync(); deferred_collection = b; }
+  // Several RANKS behind the tracker -- one process per GPU, or one tracker per device and thread in one process.  The reference keeps an
+  // MPI communicator on the filter and distributes inside the tracker (regular_tracker.hh:127-149), gathering the discrete points on the
+  // root in front of pass 2 (critical_point_tracker.hh:689).  Here the series of `nt` timesteps is cut in TIME (include/ftkx_slab.h): this
+  // rank pushes the snapshots of ITS slab -- ftkx_slab_range(nt, nranks, rank), the first push is timestep t0 -- and calls
+  // advance_timestep() / update_timestep() as usual, which only RECORD the steps; the slab is swept as one device-driven pass (masks,
+  // factors across slabs, the compact halo and the records queued at once: ftkx_slab_submit / _complete) when results are first asked for
+  // (sync(), a getter, finalize()), and finalize() gathers every rank's points on rank 0, which traces them (the other ranks end without
+  // trajectories, like the reference's non-root ranks).  sync() / finalize() are collective.  Snapshots stay resident until then: device
+  // pointers are borrowed for that long.  Call after the constructor, before the first push; one of:
+  void set_communicator(void *nccl_comm, int rank, int nranks, int nt);                  // RCCL: ncclComm_t over the ranks
+  void set_slab_transport(const ftkx_slab_transport &tr, int rank, int nranks, int nt);  // the caller's own transport
+  void set_slab_hub(ftkx_slab_hub *hub, int rank, int nt);                               // ranks of one process (ftkx_slab_hub_create)
+  bool slab_mode() const { return slab != nullptr; }
+  const ftkx_slab *slab_host() const { return slab; }
   void set_stream(void *hip_stream);
 
   void initialize();                                        // regular_tracker.hh:105-149 (single rank: local == global)
@@ -244,6 +259,13 @@ protected:
   std::vector<int> traced_loop, traced_id;
   ftkx_stats last_stats;
 
+  // slab mode (set_communicator / set_slab_transport / set_slab_hub): the C++ host of this rank's slab, the steps recorded so far
+  ftkx_slab *slab = nullptr;
+  int slab_nt = 0, slab_rank = 0, slab_nranks = 1, slab_t0 = 0, slab_t1 = 0;
+  mutable std::vector<int> slab_steps;
+  mutable bool slab_swept = false;
+  void enter_slab_mode(int rank, int nranks, int nt);
+  void run_slab() const;
   struct multi_engine;                                        // per-device contexts + worker threads (tracker.cpp); null with one device
   std::unique_ptr<multi_engine> multi;
   void apply_configuration(ftkx_ctx *c);                      // mesh, options, coordinates of initialize() on one context
@@ -279,6 +301,11 @@ int  ftkx_tracker_set_flags(ftkx_tracker *, int robust, int use_type_filter, uns
 int  ftkx_tracker_set_stream(ftkx_tracker *, void *hip_stream);
 int  ftkx_tracker_set_current_timestep(ftkx_tracker *, int t);
 int  ftkx_tracker_set_deferred_collection(ftkx_tracker *, int on);   /* not in the reference: see critical_point_tracker_regular::set_deferred_collection */
+/* several ranks behind the tracker (critical_point_tracker_regular::set_communicator / set_slab_transport / set_slab_hub): this rank's
+ * tracker takes the snapshots of its timestep slab, sweeps it as one device-driven pass, and ftkx_tracker_finalize gathers the points on rank 0 */
+int  ftkx_tracker_set_communicator(ftkx_tracker *, void *nccl_comm, int rank, int nranks, int nt);
+int  ftkx_tracker_set_slab_transport(ftkx_tracker *, const ftkx_slab_transport *tr, int rank, int nranks, int nt);
+int  ftkx_tracker_set_slab_hub(ftkx_tracker *, ftkx_slab_hub *hub, int rank, int nt);
 int  ftkx_tracker_set_enable_streaming_trajectories(ftkx_tracker *, int on);   /* critical_point_tracker.hh:38; before the first step */   /* tracker::set_current_timestep (filters/tracker.hh:40), before the first push */
 int  ftkx_tracker_set_coords_bounds(ftkx_tracker *, const double *bounds /* 2*nd values */);
 int  ftkx_tracker_set_coords_rectilinear(ftkx_tracker *, const double *x, size_t nx, const double *y, size_t ny, const double *z, size_t nz);

@@ -1,5 +1,5 @@
 """CPU-side checks of the drop-in boundary: the shared library loads without a GPU and exports every entry point that
-include/ftkx.h and include/ftkx_tracker.hh declare (no compute calls here)."""
+include/ftkx.h, include/ftkx_slab.h and include/ftkx_tracker.hh declare (no compute calls here)."""
 import ctypes as C
 import os
 import re
@@ -19,13 +19,13 @@ def lib():
 
 def declared_symbols():
     names = set()
-    for hdr in ("ftkx.h", "ftkx_tracker.hh"):
+    for hdr in ("ftkx.h", "ftkx_slab.h", "ftkx_tracker.hh"):
         txt = open(os.path.join(ROOT, "include", hdr)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         txt = re.sub(r"//[^\n]*", "", txt)
         for m in re.finditer(r"\b(ftkx_\w+)\s*\(", txt):
             names.add(m.group(1))
-    return sorted(names - {"ftkx_cp_aux", "ftkx_cp_ordinal", "ftkx_cp_timestep", "ftkx_error"})   # static inline helpers / C++ type
+    return sorted(names - {"ftkx_cp_aux", "ftkx_cp_ordinal", "ftkx_cp_timestep", "ftkx_error", "ftkx_slab_range("})   # static inline helpers / C++ type
 
 
 def test_library_exports_every_declared_symbol(lib):

@@ -200,6 +200,120 @@ def test_c4_series_moving_extremum_512cubed_x32(gpu):
     _analytic_3d(gpu, recs, st, f, dims, nt)
 
 
+BIG_HOST = (os.cpu_count() or 1) >= 128        # the oracle at these sizes: minutes on a laptop, about a minute each on the GPU box's 256 host threads
+
+
+@pytest.mark.skipif(not BIG_HOST, reason="the oracle over 1.5e10 simplices needs the GPU box's host threads")
+def test_c3_series_vs_oracle(gpu, oracle):
+    """BASELINE configs[2], moving_extremum_3d 256^3 x 16, at FULL size against the ORACLE (oracle/ftk_oracle.c, pinned to the reference) on the
+    very arrays the GPU swept -- not only against the analytic trajectory and this repository's own exact_only path: records bit-identical,
+    factors equal (critical_point_tracker_3d_regular.hh:150-308, 425-514)."""
+    dims, nt = (256, 256, 256), 16
+    R = Resident(gpu, "moving_extremum_3d", dims, nt, 1, keep_host=True)
+    try:
+        runs = R.pipelined(3)
+        recs, f, path = runs[-1]
+        assert path == (2, SERIES_EARLY) and all(_bytes_equal(r, recs) and p == path for r, _, p in runs)
+        host = R.host
+    finally:
+        R.close()
+    _assert_equals_oracle(oracle, recs, host, 3, 1, f, "c3 at full size vs oracle")
+
+
+@pytest.mark.skipif(not BIG_HOST, reason="the oracle over 9e9 simplices needs the GPU box's host threads")
+def test_c4_two_slices_vs_oracle(gpu, oracle):
+    """two slices of BASELINE configs[3] (512^3: the headline's slice size, its ZPlan pieces, its tile placement) against the ORACLE"""
+    dims, nt = (512, 512, 512), 2
+    R = Resident(gpu, "moving_extremum_3d", dims, nt, 1, keep_host=True)
+    try:
+        runs = R.pipelined(2)
+        recs, f, path = runs[-1]
+        assert path == (2, SERIES_EARLY) and _bytes_equal(runs[0][0], recs)
+        host = R.host
+    finally:
+        R.close()
+    _assert_equals_oracle(oracle, recs, host, 3, 1, f, "512^3 x 2 vs oracle")
+
+
+def _bumpy_3d(torch, dev, dims, nt, seed):
+    """a 3D series that is neither smooth nor rough everywhere: a tilted background (a strict sign almost everywhere), a few hundred moving
+    bumps (isolated critical points, some of them merging), and a box of noise (hit-dense: every kind of mask word, many records per cell)"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    DW, DH, DD = dims
+    z, y, x = torch.meshgrid(torch.arange(DD, dtype=torch.float64, device=dev), torch.arange(DH, dtype=torch.float64, device=dev),
+                             torch.arange(DW, dtype=torch.float64, device=dev), indexing="ij")
+    nb = 240
+    c0 = torch.rand((nb, 3), generator=g, dtype=torch.float64) * torch.tensor([DW, DH, DD], dtype=torch.float64)
+    vel = (torch.rand((nb, 3), generator=g, dtype=torch.float64) - 0.5) * 1.5
+    sig = 5.0 + 7.0 * torch.rand((nb,), generator=g, dtype=torch.float64)
+    # (nbits is 21 on any smooth field with critical points: max |gradient| stays below 727041 / 2^21 = 0.347, or every vertex could overflow a
+    # determinant and the masks would need the per-vertex rule -- the host-driven batch's)
+    amp = (0.6 * torch.rand((nb,), generator=g, dtype=torch.float64) + 0.4) * torch.where(torch.rand((nb,), generator=g) < 0.5, -1.0, 1.0)
+    noise = torch.randn((nt, 24, 70, 66), generator=g, dtype=torch.float64)
+    out = []
+    for k in range(nt):
+        a = 0.021 * x + 0.017 * y + 0.013 * z
+        for b in range(nb):
+            cx, cy, cz = (c0[b] + vel[b] * k).tolist()
+            s = float(sig[b])
+            r = int(4 * s) + 1
+            x0, x1 = max(0, int(cx) - r), min(DW, int(cx) + r + 1)
+            y0, y1 = max(0, int(cy) - r), min(DH, int(cy) + r + 1)
+            z0, z1 = max(0, int(cz) - r), min(DD, int(cz) + r + 1)
+            if x0 >= x1 or y0 >= y1 or z0 >= z1:
+                continue
+            sub = (slice(z0, z1), slice(y0, y1), slice(x0, x1))
+            a[sub] += float(amp[b]) * torch.exp(-((x[sub] - cx) ** 2 + (y[sub] - cy) ** 2 + (z[sub] - cz) ** 2) / (2 * s * s))
+        a[13:37, 101:171, 97:163] += 0.04 * noise[k].to(dev)
+        out.append(a.contiguous())
+    return out
+
+
+@pytest.mark.skipif(not BIG_HOST, reason="the oracle over 1.6e9 simplices of a hit-dense series needs the GPU box's host threads")
+def test_bumpy_3d_series_vs_oracle(gpu, oracle):
+    """A 3D series with partial tiles in x and y (517 x 515), several ZPlan pieces per tile column (50 planes) and every kind of mask block --
+    uniform, stand-in, written -- through ftkx_sweep_series_submit / _complete and on its own, against the ORACLE: records bit-identical,
+    factors equal."""
+    import torch
+    dims, nt = (517, 515, 50), 3
+    dev = torch.device("cuda", 0)
+    steps = _bumpy_3d(torch, dev, dims, nt, 77)
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    try:
+        ctx = gpu.Context(3)
+        ctx.set_stream(stream.cuda_stream)
+        dom = ([2] * 3, [d - 3 for d in dims])
+        ctx.set_mesh(dom, dom, ([0] * 3, list(dims)))
+        ctx.set_options(jacobian_symmetric=1, derive_jacobian=1, tag_mode=gpu.TAG_EXACT64)
+        for t in range(nt):
+            ctx.push_scalar_slice(t, steps[t])
+        ts = np.arange(nt, dtype=np.int32)
+        scopes = np.array([gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)], dtype=np.int32)
+        outs = []
+        ctx.sweep_series_submit(ts, scopes)
+        for i in range(1, 4):
+            if i < 3:
+                ctx.invalidate_masks()
+                ctx.sweep_series_submit(ts, scopes)
+            recs, f, _ = ctx.sweep_series_complete(copy=True)
+            outs.append((recs, [int(v) for v in f], ctx.series_last_path()))
+        ctx.invalidate_masks()
+        recs, f, _ = ctx.sweep_series(ts, scopes, copy=True)
+        outs.append((recs, [int(v) for v in f], ctx.series_last_path()))
+        ctx.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+    recs, f, path = outs[0]
+    assert path[0] in (1, 2), path                       # device-driven
+    assert len(recs) > 20000, len(recs)
+    for r2, f2, p2 in outs[1:]:
+        assert f2 == f and _bytes_equal(r2, recs), (p2, len(r2), len(recs))
+    host = [a.cpu().numpy() for a in steps]
+    _assert_equals_oracle(oracle, recs, host, 3, 1, f, "bumpy 3D 517 x 515 x 50 x 3 vs oracle")
+
+
 def test_c4_series_eight_slabs_in_one_process(gpu):
     """BASELINE configs[3] in its literal form -- moving_extremum_3d 512^3 x 32 cut into EIGHT timestep slabs -- at full size: eight contexts
     on this one GPU, one per rank, each with its four slices, running the device-driven slab pass (ftkx_series_dist_*) with the messages

@@ -62,6 +62,13 @@ def _plain(g):
     return g["bounds"] is None and g["rectilinear"] is None and g["explicit"] is None
 
 
+@pytest.fixture(autouse=True)
+def _the_chain_not_the_one_launch_pass(monkeypatch):
+    """The fixtures are small series: by default the ONE-LAUNCH pass (csrc/one_kernel.hip) would sweep them.  This module is about the kernel
+    chain, the fused tail and their fallbacks -- FTKX_SERIES_ONE=0 for its tests; the one-launch pass has its own tests at the end."""
+    monkeypatch.setenv("FTKX_SERIES_ONE", "0")
+
+
 @pytest.mark.parametrize("name", [n for n in golden_names()])
 def test_series_pass_matches_reference_fixture(gpu, name):
     """the whole series in ONE call: records, their order, the per-step factors and the running resolution"""
@@ -176,32 +183,6 @@ def test_series_equals_the_host_driven_batch_on_random_fields(gpu, seed):
         assert [int(v) for v in f] == [int(v) for v in ref_f], what + f" factors (path {path} status {status})"
         assert _same(got, ref), what + f" (path {path} status {status}): {len(got)} vs {len(ref)} records"
         ctx.close()
-
-
-@pytest.mark.parametrize("nchunks", [2, 3, 4])
-@pytest.mark.parametrize("name", ["woven_128x128x10", "woven_31x37x32", "double_gyre_64x32x50", "merger_2d_32x32x100", "moving_extremum_3d_21x21x21x32",
-                                  "singular_terraces_44x40x36x5", "random_3d_scalar_13x12x11x4", "huge_nan_2d_vector_16x14x4", "moving_extremum_3d_21x21x21x4_overflow"])
-def test_the_chunked_pass_gives_the_same_records(gpu, monkeypatch, name, nchunks):
-    """FTKX_SERIES_CHUNKS: the pass in 2 .. 4 chunks of consecutive steps, each with its own tail stream, counters and results block, linked
-    on the device (running minimum, where a chunk's records start) -- the reference's records and factors, in tag order"""
-    g = load_golden(name)
-    nd, nv, nt = g["nd"], g["nv"], g["DT"]
-    monkeypatch.setenv("FTKX_SERIES_CHUNKS", str(nchunks))
-    ctx = _ctx(gpu, g["dims"], nd, nv)
-    _push_all(ctx, g["steps"], nv)
-    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
-    for rep in range(2):
-        if rep:
-            ctx.invalidate_masks()
-        recs, factors, run = ctx.sweep_series(range(nt), scopes)
-        path, status = ctx.series_last_path()
-        what = f"{name} in {nchunks} chunks (path {path}, status {status}, repetition {rep})"
-        assert path == (3 if nt >= 2 * nchunks and not (status & 15) else path), what
-        assert np.array_equal(factors, g["factors"]), what
-        assert np.all(recs["tag"][1:] >= recs["tag"][:-1]), what
-        assert_records_equal(_as_fixture(recs), g["records"], coord_tol=0.0, what=what)
-        PATHS.setdefault((path, status), []).append(name)
-    ctx.close()
 
 
 def test_series_fallbacks_give_the_same_records(gpu, monkeypatch):
@@ -565,3 +546,67 @@ def test_a_short_chain_pass_that_declines_late(gpu):
             assert seen[-1][0] == 1 and not (seen[-1][1] & 64), seen      # after a late decline the fused tail is not tried again for a while
         ctx.close()
     assert late, "none of the sub-series made the fused tail decline late"
+
+
+# ---- the one-launch pass for small series (csrc/one_kernel.hip) ------------------------------------------------------------------------------
+ONE_TAKEN = {}
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names()])
+def test_one_launch_pass_matches_reference_fixture(gpu, monkeypatch, name):
+    """every reference fixture through ftkx_sweep_series with the one-launch pass on (the default): records, their order, factors and the
+    running resolution are what the kernel chain gives -- path 4 wherever the series is small and the options are the device-driven pass's,
+    on its own, two in flight, and chained on the device (the second pass continues from the first's running minimum)"""
+    g = load_golden(name)
+    if not _plain(g):
+        pytest.skip("physical coordinates are set on the tracker")
+    nd, nv, nt = g["nd"], g["nv"], g["DT"]
+    opts = dict(robust=int(g["robust"]), compute_degrees=int(g["degrees"]))
+    if g["type_filter"] is not None:
+        opts.update(use_type_filter=1, type_filter=g["type_filter"])
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    ctx = _ctx(gpu, g["dims"], nd, nv, **opts)
+    _push_all(ctx, g["steps"], nv)
+    want, wf, wrun = ctx.sweep_series(range(nt), scopes)          # (FTKX_SERIES_ONE=0: this module's default)
+    want, wpath = want.copy(), ctx.series_last_path()
+    ctx.close()
+    monkeypatch.setenv("FTKX_SERIES_ONE", "1")
+    ctx = _ctx(gpu, g["dims"], nd, nv, **opts)
+    _push_all(ctx, g["steps"], nv)
+    recs, factors, run = ctx.sweep_series(range(nt), scopes)
+    path, status = ctx.series_last_path()
+    ONE_TAKEN[name] = (path, status, wpath)
+    assert np.array_equal(factors, g["factors"]) and np.array_equal(factors, wf), f"{name}: factors {factors} (path {path}, status {status})"
+    assert run == wrun, (name, run, wrun)
+    assert _same(recs, want), f"{name}: {len(recs)} vs {len(want)} records (path {path}, status {status}; the chain took {wpath})"
+    assert_records_equal(_as_fixture(recs), g["records"], coord_tol=0.0, what=f"{name} (path {path}, status {status})")
+    # two in flight; then a pass in two halves, the second continuing ON THE DEVICE from the first's running minimum
+    ctx.sweep_series_submit(range(nt), scopes)
+    ctx.sweep_series_submit(range(nt), scopes)
+    for _ in range(2):
+        r2, f2, run2 = ctx.sweep_series_complete()
+        assert _same(r2, want) and np.array_equal(f2, wf) and run2 == wrun, name
+    if nt >= 4:
+        h = nt // 2
+        ctx.sweep_series_submit(range(h), [gpu.SCOPE_BOTH] * h)
+        ctx.sweep_series_submit(range(h, nt), scopes[h:], chain=True)
+        a, fa, _ = ctx.sweep_series_complete()
+        a = a.copy()
+        b, fb, runb = ctx.sweep_series_complete()
+        both = np.concatenate([a, b])
+        assert np.array_equal(np.concatenate([fa, fb]), wf) and runb == wrun and _same(both, want), name
+    ctx.close()
+
+
+def test_the_one_launch_pass_took_the_small_series(gpu):
+    if len(ONE_TAKEN) < 20:
+        pytest.skip("the fixture tests above did not run in this process")
+    took = [n for n, (p, st, wp) in ONE_TAKEN.items() if p == 4]
+    print({n: v for n, v in ONE_TAKEN.items() if v[0] != 4})
+    assert len(took) >= 20, ONE_TAKEN
+    # what the device-driven pass does not cover goes to the host-driven batch with or without it; what the chain handed to the batch for a
+    # kernel-raised flag (an ambiguous factor, ...) the one-launch pass hands over as well
+    assert all(p == 4 or wp[0] == 0 or p in (0, 1, 2) for n, (p, st, wp) in ONE_TAKEN.items())
+    for n in ("woven_128x128x10", "woven_31x37x32", "moving_extremum_3d_21x21x21x32", "double_gyre_64x32x50"):
+        if n in ONE_TAKEN:
+            assert ONE_TAKEN[n][0] == 4, (n, ONE_TAKEN[n])

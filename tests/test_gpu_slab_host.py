@@ -1,0 +1,295 @@
+"""The C++ host of the slab pass (include/ftkx_slab.h, ftk_amd/csrc/slab.cpp, slab_rccl.cpp) on the GPU.
+
+* Ranks of ONE process over the hub transport (ftkx_slab_hub_*: peer copies ordered by events, every rank driven by its own thread): up to
+  eight ranks on the one GPU, random fields, two passes in flight, the whole-slice recovery -- the merged records and the per-step factors
+  must be those of ONE context sweeping the whole series (ftkx_sweep_series), byte for byte.
+* RCCL with one rank (two ranks cannot share a GPU under RCCL): ncclCommInitRank, the ncclAllGather of the contributions queued on the
+  context's stream between the stages, ftkx_slab_gather_records -- byte-identical to ftkx_sweep_series.
+Reference: the distributed tracker of include/ftk/filters/regular_tracker.hh:127-149 and its gather, critical_point_tracker.hh:689; the
+factor across slabs: critical_point_tracker.hh:850-864."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from test_gpu_fuzz import _field, _vector_series
+from test_gpu_slab_inprocess import _make_ctx, KINDS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available()
+    import ftk_amd
+    from ftk_amd import build
+    build.build()
+    return ftk_amd
+
+
+def _whole(gpu, nd, nv, dims, nt, steps, stream):
+    one = _make_ctx(gpu, nd, nv, dims, stream)
+    for t in range(nt):
+        (one.push_scalar_slice if nv == 1 else one.push_slice)(t, steps[t])
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    want, wf, _ = one.sweep_series(range(nt), scopes, copy=True)
+    one.close()
+    return want, [int(v) for v in wf]
+
+
+def _hub_case(gpu, rng, what, world, nd, nv, dims, nt, kind, passes):
+    """`passes` passes of every rank, two in flight; -> (fallbacks, records)"""
+    import torch
+    from ftk_amd import tslab, _lib
+    L = _lib.load()
+    dev = torch.device("cuda", 0)
+    sp = tuple(reversed(dims))
+    steps = _field(rng, (nt,) + sp, kind) if nv == 1 else _vector_series(rng, nt, sp, kind)
+    main = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(main)
+    try:
+        want, wf = _whole(gpu, nd, nv, dims, nt, steps, main)
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+    hub = L.ftkx_slab_hub_create(world)
+    out, errs = [None] * world, []
+    keep = []
+
+    def rank_main(r):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            ctx = _make_ctx(gpu, nd, nv, dims, st)
+            t0, t1 = tslab.slab_range(nt, world, r)
+            for t in range(t0, t1):
+                a = torch.from_numpy(np.ascontiguousarray(steps[t])).to(dev)
+                keep.append(a)
+                (ctx.push_scalar_slice if nv == 1 else ctx.push_slice)(t, a)
+            torch.cuda.synchronize()
+            slab = tslab.SlabSeries.local(ctx, nt, r, world, hub)
+            res = []
+            slab.submit()
+            for i in range(1, passes + 1):
+                if i < passes:
+                    slab.submit()
+                recs, f, run = slab.complete(copy=True)
+                res.append((recs, [int(v) for v in f]))
+            merged = slab.gather_records(res[-1][0], 0)
+            out[r] = (res, merged, slab.fallbacks, slab.bytes_sent, slab.bytes_received)
+            slab.close()
+            ctx.close()
+        except BaseException as e:      # noqa: BLE001
+            errs.append((r, e))
+            L.ftkx_slab_hub_abort(hub)
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    alive = [t for t in th if t.is_alive()]
+    if alive:
+        L.ftkx_slab_hub_abort(hub)
+        for t in alive:
+            t.join(60)
+    L.ftkx_slab_hub_destroy(hub)
+    unsupported = [e for _, e in errs if isinstance(e, gpu.FtkxError) and e.code == -5]
+    if errs and len(unsupported) == len(errs) > 0:
+        return "unsupported", 0
+    assert not errs, (what, errs)
+    assert not alive, (what, "a rank did not finish")
+    for k in range(passes):
+        parts = [out[r][0][k][0] for r in range(world)]
+        merged = np.concatenate(parts)
+        merged = merged[np.argsort(merged["tag"], kind="stable")]
+        got_f = []
+        for r in range(world):
+            got_f += out[r][0][k][1]
+        assert got_f == wf, (what, k, got_f, wf)
+        assert merged.tobytes() == np.ascontiguousarray(want).tobytes(), (what, k, len(merged), len(want))
+    g = out[0][1]
+    assert g is not None and len(g) == len(want), (what, "ftkx_slab_gather_records", None if g is None else len(g), len(want))
+    if g.tobytes() != np.ascontiguousarray(want).tobytes():
+        bad = [i for i in range(len(g)) if g[i].tobytes() != want[i].tobytes()]
+        raise AssertionError((what, "ftkx_slab_gather_records", len(bad), bad[:5], [(g[i], want[i]) for i in bad[:2]]))
+    assert all(out[r][1] is None for r in range(1, world))
+    return "ok", sum(o[2] for o in out)
+
+
+TALLY = {"ok": 0, "unsupported": 0, "recovered": 0}
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FTKX_SLAB_HOST_SEEDS", "24"))))
+def test_hub_ranks_add_up_to_the_whole_series(gpu, seed):
+    rng = np.random.default_rng(8800 + seed)
+    for case in range(3):
+        nd = int(rng.choice([2, 3]))
+        nv = int(rng.choice([1, 1, nd]))
+        nt = int(rng.integers(2, 10))
+        world = int(rng.choice([2, 3, 4, 8]))
+        if nd == 2:
+            dims = (int(rng.choice([16, 24, 40, 64, 136, 256])), int(rng.integers(9, 70)))
+        else:
+            dims = (int(rng.choice([8, 16, 24, 40, 128])), int(rng.integers(7, 36)), int(rng.integers(7, 20)))
+        kind = str(rng.choice(KINDS))
+        passes = int(rng.choice([1, 2, 3]))
+        what = f"seed {seed} case {case}: world {world} nd {nd} nv {nv} dims {dims} nt {nt} {kind} passes {passes}"
+        verdict, fallbacks = _hub_case(gpu, rng, what, world, nd, nv, dims, nt, kind, passes)
+        TALLY[verdict] += 1
+        TALLY["recovered"] += fallbacks
+
+
+def test_the_hub_cases_took_every_way(gpu):
+    assert TALLY["ok"] >= 50 and TALLY["recovered"] >= 1, TALLY
+
+
+def test_rccl_with_one_rank_equals_the_plain_pass(gpu):
+    import torch
+    from ftk_amd import tslab, _lib
+    L = _lib.load()
+    assert L.ftkx_rccl_version() > 0
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    for nd, nv, dims, nt, kind in ((3, 1, (40, 33, 17), 5, "smooth"), (2, 1, (136, 60), 6, "rough"), (2, 2, (64, 40), 4, "smooth")):
+        sp = tuple(reversed(dims))
+        steps = _field(rng, (nt,) + sp, kind) if nv == 1 else _vector_series(rng, nt, sp, kind)
+        st = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(st)
+        try:
+            want, wf = _whole(gpu, nd, nv, dims, nt, steps, st)
+            ctx = _make_ctx(gpu, nd, nv, dims, st)
+            for t in range(nt):
+                (ctx.push_scalar_slice if nv == 1 else ctx.push_slice)(t, steps[t])
+            raw = (C.c_ubyte * 128)()
+            _lib.check(L.ftkx_rccl_unique_id(raw))
+            comm = C.c_void_p()
+            _lib.check(L.ftkx_rccl_comm_create(raw, 0, 1, 0, C.byref(comm)))
+            slab = tslab.SlabSeries.rccl(ctx, nt, 0, 1, comm)
+            slab.submit(); slab.submit()
+            a = slab.complete(copy=True)
+            slab.submit()
+            b = slab.complete(copy=True)
+            c = slab.complete(copy=True)
+            for recs, f, run in (a, b, c):
+                assert [int(v) for v in f] == wf and recs.tobytes() == np.ascontiguousarray(want).tobytes(), (nd, nv, dims, kind)
+            assert slab.last_path[0] in (1, 2), slab.last_path
+            merged = slab.gather_records(c[0], 0)
+            assert merged.tobytes() == np.ascontiguousarray(want).tobytes()
+            slab.close()
+            L.ftkx_rccl_comm_destroy(comm)
+            ctx.close()
+        finally:
+            torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def _make_tracker(gpu, nd, nv, D):
+    T = gpu.CriticalPointTracker2DRegular if nd == 2 else gpu.CriticalPointTracker3DRegular
+    tr = T()
+    if nv == 1:
+        tr.set_scalar_field_source(gpu.SOURCE_GIVEN); tr.set_vector_field_source(gpu.SOURCE_DERIVED)
+        tr.set_jacobian_field_source(gpu.SOURCE_DERIVED); tr.set_jacobian_symmetric(True)
+        tr.set_domain([2] * nd, [d - 3 for d in D])
+    else:
+        tr.set_scalar_field_source(gpu.SOURCE_NONE); tr.set_vector_field_source(gpu.SOURCE_GIVEN)
+        tr.set_jacobian_field_source(gpu.SOURCE_DERIVED); tr.set_jacobian_symmetric(False)
+        tr.set_domain([1] * nd, [d - 2 for d in D])
+    tr.set_array_domain([0] * nd, D)
+    tr.set_tag_mode(gpu.TAG_REFERENCE)      # (the fixtures' tags: the reference's own, equal to the 64-bit ones where nothing wraps)
+    tr.initialize()
+    return tr
+
+
+def _drive_slab_tracker(tr, steps, t0, t1, nv):
+    """the reference's loop (push; advance between snapshots; update after the last) over this rank's slab"""
+    for k, t in enumerate(range(t0, t1)):
+        (tr.push_scalar_field_snapshot if nv == 1 else tr.push_vector_field_snapshot)(steps[t])
+        if k != 0:
+            tr.advance_timestep()
+        if t == t1 - 1:
+            tr.update_timestep()
+
+
+@pytest.mark.parametrize("name,world", [("woven_31x37x32", 3), ("moving_extremum_3d_21x21x21x32", 4), ("double_gyre_64x32x50", 2), ("merger_2d_32x32x100", 8),
+                                        ("random_3d_scalar_13x12x11x4", 6)])
+def test_trackers_in_slab_mode_trace_the_reference_curves(gpu, name, world):
+    """critical_point_tracker_regular in slab mode (include/ftkx_tracker.hh: set_slab_hub), one tracker per rank and thread over the hub: every
+    rank pushes only its slab, finalize() gathers the points on rank 0 (critical_point_tracker.hh:689), which traces the REFERENCE's curves
+    -- curves cross the slab boundaries --, holds the reference's records, and every rank ends with the reference's factor for its last step."""
+    from common import load_golden, by_tag
+    from ftk_amd import tslab, _lib
+    L = _lib.load()
+    g = load_golden(name)
+    nd, nv, nt = g["nd"], g["nv"], g["DT"]
+    D = g["dims"]
+    hub = L.ftkx_slab_hub_create(world)
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            tr = _make_tracker(gpu, nd, nv, D)
+            tr.set_slab_hub(hub, r, nt)
+            t0, t1 = tslab.slab_range(nt, world, r)
+            _drive_slab_tracker(tr, g["steps"], t0, t1, nv)
+            factor = tr.get_vector_field_scaling_factor()        # (sync(): the slab's pass)
+            mine = tr.get_critical_points()[0]
+            tr.finalize()
+            curves, loop = tr.get_traced_critical_points()
+            allp = tr.get_critical_points()
+            out[r] = (factor, mine, curves, loop, allp, (t0, t1))
+            tr.close()
+        except BaseException as e:      # noqa: BLE001
+            errs.append((r, e))
+            L.ftkx_slab_hub_abort(hub)
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not [t for t in th if t.is_alive()] and not errs, errs
+    L.ftkx_slab_hub_destroy(hub)
+    ref = by_tag(g["records"])
+    # every rank: the reference's factor at its slab's last step, and exactly the reference's records of its timesteps
+    for r in range(world):
+        factor, mine, curves, loop, allp, (t0, t1) = out[r]
+        if t1 > t0:
+            assert int(factor) == int(g["factors"][t1 - 1]), (r, factor)
+        want = ref[(ref["timestep"] >= t0) & (ref["timestep"] < t1)] if "timestep" in ref.dtype.names else None
+        if want is not None:
+            m = by_tag(mine)
+            assert np.array_equal(m["tag"], want["tag"]) and np.array_equal(m["type"], want["type"]) and np.array_equal(m["x"], want["x"]) and np.array_equal(m["t"], want["t"]), r
+        if r != 0:
+            assert len(curves) == 0
+    _, _, curves, loop, (recs, o, ts), _ = out[0]
+    m = by_tag(recs)
+    assert np.array_equal(m["tag"], ref["tag"]) and np.array_equal(m["type"], ref["type"]) and np.array_equal(m["x"], ref["x"])
+    got = sorted((tuple(c.tolist()), int(l)) for c, l in zip(curves, loop))
+    exp = sorted((tuple(t.tolist()), int(l)) for l, t in g["curves"])
+    assert got == exp
+
+
+def test_tracker_with_an_rccl_communicator_of_one_rank(gpu):
+    """set_communicator(ncclComm_t, 0, 1, nt): the slab host over RCCL inside the C++ tracker -- the reference's records, factor and curves"""
+    from common import load_golden, by_tag
+    from ftk_amd import _lib
+    L = _lib.load()
+    g = load_golden("woven_31x37x32")
+    nd, nv, nt, D = g["nd"], g["nv"], g["DT"], g["dims"]
+    raw = (C.c_ubyte * 128)()
+    _lib.check(L.ftkx_rccl_unique_id(raw))
+    comm = C.c_void_p()
+    _lib.check(L.ftkx_rccl_comm_create(raw, 0, 1, 0, C.byref(comm)))
+    tr = _make_tracker(gpu, nd, nv, D)
+    tr.set_communicator(comm, 0, 1, nt)
+    _drive_slab_tracker(tr, g["steps"], 0, nt, nv)
+    assert int(tr.get_vector_field_scaling_factor()) == int(g["factors"][nt - 1])
+    tr.finalize()
+    curves, loop = tr.get_traced_critical_points()
+    recs = by_tag(tr.get_critical_points()[0])
+    ref = by_tag(g["records"])
+    assert np.array_equal(recs["tag"], ref["tag"]) and np.array_equal(recs["x"], ref["x"]) and np.array_equal(recs["type"], ref["type"])
+    assert sorted((tuple(c.tolist()), int(l)) for c, l in zip(curves, loop)) == sorted((tuple(t.tolist()), int(l)) for l, t in g["curves"]) and len(curves) == 56
+    tr.close()
+    L.ftkx_rccl_comm_destroy(comm)

@@ -317,6 +317,104 @@ class OracleSlabCtx:
         recs, f, run = self._sweep(ts, [int(s) for s in scopes], running, None)
         return recs, f, run
 
+    # ---- include/ftkx_slab.h: this stand-in as a ftkx_slab_backend -- the table of calls the C++ host (ftk_amd/csrc/slab.cpp) drives.  Buffers
+    # are host memory handed out by `alloc`; a stage callback sees them as torch tensors over that memory. ----
+    def slab_upload(self, dst, src_np):
+        import ctypes as C
+        C.memmove(dst, src_np.ctypes.data, src_np.nbytes)
+
+    def slab_download(self, dst_np, src):
+        import ctypes as C
+        C.memmove(dst_np.ctypes.data, src, dst_np.nbytes)
+
+    def slab_backend(self):
+        import ctypes as C
+        from ftk_amd import _lib
+        self._bufs, self._cb_err = {}, None
+        nb, cells, pd = self.nvals * 8, self.series_dist_cells(), self.patch_doubles()
+
+        def view(ptr, n, dt):
+            if not ptr:
+                return None
+            raw = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
+            return torch.from_numpy(np.frombuffer(raw, dtype=dt))
+
+        def guard(fn):
+            try:
+                r = fn()
+                return 0 if r is None else r
+            except self.f.FtkxError as e:
+                return e.code
+            except BaseException as e:      # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                self._cb_err = e
+                return -1
+
+        def begin(u, ts, scopes, n, running, rank, nranks, upper, contrib, gathered, masks_out, side):
+            return guard(lambda: self.series_dist_begin([ts[i] for i in range(n)], [scopes[i] for i in range(n)], running[0], rank, nranks, None if upper < 0 else upper,
+                                                        view(contrib, 4, np.float64), view(gathered, 4 * nranks, np.float64), view(masks_out, nb, np.uint8), side))
+
+        def cull(u, masks_in, req_out):
+            return guard(lambda: self.series_dist_cull(view(masks_in, nb, np.uint8), view(req_out, 1 + cells, np.int64)))
+
+        def serve(u, req_in, reply_out):
+            return guard(lambda: self.series_dist_serve(view(req_in, 1 + cells, np.int64), view(reply_out, cells * pd, np.float64)))
+
+        def finish(u, reply_in):
+            return guard(lambda: self.series_dist_finish(view(reply_in, cells * pd, np.float64)))
+
+        def hand_out(recs, f, run, running, factors, out, n_out):
+            self._last = np.ascontiguousarray(recs)
+            for i, v in enumerate(f):
+                factors[i] = int(v)
+            running[0] = float(run)
+            out[0] = self._last.ctypes.data if len(self._last) else None
+            n_out[0] = len(self._last)
+
+        def complete(u, running, factors, out, n_out):
+            return guard(lambda: hand_out(*self.sweep_series_complete(), running, factors, out, n_out))
+
+        def status(u, asked, served, gathered, nranks, path, path_status):
+            def run():
+                a, s_, G = self.series_dist_status(nranks)
+                asked[0], served[0] = a, s_
+                for i, v in enumerate(np.asarray(G, dtype=np.float64).reshape(-1)):
+                    gathered[i] = float(v)
+                path[0], path_status[0] = 1, 0
+            return guard(run)
+
+        def recover(u, t_halo, full, ts, scopes, n, running, factors, out, n_out):
+            def run():
+                try:
+                    self.drop_slice(t_halo)
+                except self.f.FtkxError as e:
+                    assert e.code == tslab.E_NOSLICE
+                self.push_scalar_slice(t_halo, view(full, self.nvals, np.float64).numpy().copy())
+                hand_out(*self.sweep_series([ts[i] for i in range(n)], [scopes[i] for i in range(n)], running[0]), running, factors, out, n_out)
+                self.drop_slice(t_halo)
+            return guard(run)
+
+        def first_slice(u, t):
+            self.slices[t] = np.ascontiguousarray(self.slices[t], dtype=np.float64)
+            return self.slices[t].ctypes.data
+
+        def alloc(u, n):
+            buf = (C.c_char * max(int(n), 8))()
+            self._bufs[C.addressof(buf)] = buf
+            return C.addressof(buf)
+
+        def release(u, p):
+            self._bufs.pop(p, None)
+
+        def copy(u, dst, src, n):
+            C.memmove(dst, src, n)
+            return 0
+
+        self._fns = [_lib.BEGIN_FN(begin), _lib.CULL_FN(cull), _lib.CULL_FN(serve), _lib.FINISH_FN(finish), _lib.COMPLETE_FN(complete), _lib.STATUS_FN(status), _lib.RECOVER_FN(recover),
+                     _lib.FIRST_FN(first_slice), _lib.ALLOC_FN(alloc), _lib.RELEASE_FN(release), _lib.COPY_FN(copy), _lib.COPY_FN(copy), _lib.ABORT_FN(lambda u: None)]
+        return _lib.SlabBackend(None, *self._fns, nb, cells, pd, nb, None, 0)
+
 
 def _slab_worker(rank, world, port, name, ask_full, pipelined, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -350,7 +448,10 @@ def _slab_worker(rank, world, port, name, ask_full, pipelined, q):
                 outs.append(slab.complete())
         for recs, f, run in outs[1:]:
             assert recs.tobytes() == outs[0][0].tobytes() and list(f) == list(outs[0][1])
-        merged = tslab.gather_records(np.array(outs[-1][0]), 0)
+        merged = slab.gather_records(np.array(outs[-1][0]), 0)          # (ftkx_slab_gather_records, over the same transport)
+        also = tslab.gather_records(np.array(outs[-1][0]), 0)
+        assert (merged is None) == (also is None) and (merged is None or merged.tobytes() == also.tobytes())
+        assert ctx._cb_err is None
         if own:
             assert [int(v) for v in outs[-1][1]] == [int(g["factors"][t]) for t in own], (rank, outs[-1][1])
         if rank == 0:
