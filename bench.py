@@ -789,6 +789,7 @@ def job(args, env):
         except Exception:   # noqa: BLE001
             rv = None
         ranks_info = {"ranks_seen": int(dist.get_world_size()), "backend": dist.get_backend(), "rccl_version": rv,
+                      "slab_host": ("C++ (include/ftkx_slab.h) over " + slab.transport) if slab is not None else "host-driven sequence (Python)",
                       "distinct_devices": len(set(e["pci_bus_id"] for e in everyone)), "per_rank": everyone}
     latency_ms = None
     if pipelined:
@@ -866,6 +867,8 @@ def job(args, env):
             # ((1, 64): the fused tail declined late -- few coarse cells with more records than it orders -- and the chain took the pass: device-driven
             # all the same; only the small test configurations see it)
             want_paths = [(2, 32)] if case == "moving_extremum_3d" else ([(1, 0), (2, 32), (4, 544)] if args.config == "c1" else ([(1, 0), (1, 64), (4, 544)] if args.config.startswith("small") else [(1, 0)]))
+            if multi:
+                want_paths = want_paths + [(4, 544)]      # (a rank's slab may be small enough for the one-launch pass where it sweeps on its own: the whole-slice recovery)
             check = check_records(args.config if args.timesteps == 0 else "", case, dims, nt, merged, timed_paths, want_paths)
         elif case == "moving_extremum_3d" and len(merged):
             check = check_records("", case, dims, nt, merged, [], [])
@@ -991,6 +994,8 @@ def job(args, env):
             out["cpu_baseline"] = base
             if port:
                 out["cpu_port"] = port
+    if slab is not None:
+        slab.close()                 # (the slab's streams and, over RCCL, its communicator: before the context they were made on goes)
     ctx.close()
     slices.clear()
     torch.cuda.empty_cache()

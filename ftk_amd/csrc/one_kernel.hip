@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
   __shared__ unsigned char s_flag[SUB * G][NVC];
   __shared__ unsigned s_tab[NTYPES];
   __shared__ unsigned short s_deg[G * NTYPES];
-  __shared__ unsigned s_nkeys, s_ndeg, s_status, s_tested, s_last;
+  __shared__ unsigned s_nkeys, s_ndeg, s_status, s_tested, s_cells, s_last;
   __shared__ double s_rmn[kThreads / 64], s_rmx[kThreads / 64];
   __shared__ u64 s_base, s_total;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
   unsigned *bar = reinterpret_cast<unsigned *>(a.scratch + ONE_BAR);      // [0], [1]: the two barriers, [2]: arrivals at the exit, [3]: somebody gave up
   u64 *parts = a.scratch + ONE_PARTS;                          // [nslices * kOneParts][2]
   u64 *counts = a.scratch + ONE_COUNTS;                        // [nwg]
-  if (tid == 0) { s_nkeys = 0; s_ndeg = 0; s_status = 0; s_tested = 0; s_base = 0; s_total = 0; }
+  if (tid == 0) { s_nkeys = 0; s_ndeg = 0; s_status = 0; s_tested = 0; s_cells = 0; s_base = 0; s_total = 0; }
   if (tid < NTYPES) {
     unsigned t = 0;
     for (int i = 0; i < N; i ++) t |= (unsigned)fan.vert[tid][i] << (8 * i);
@@ -183,6 +183,20 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
         }
         narrow = __syncthreads_and(mine_narrow) != 0;
       }
+      // (statistics: the cells the mask cull of the kernel chain would have let through -- no strict sign bit common to all the vertices a
+      // scope reads; vertices outside the domain and non-finite ones are neutral, as their mask bytes are)
+      for (unsigned gi = tid; gi < (unsigned)(SUB * G); gi += kThreads) {
+        const u64 cs = base + gi;
+        if (cs >= c_hi) continue;
+        const int scope = s_fields[cs / cells].scope_mask;
+        unsigned a0 = 0x3f, a1 = 0x3f;
+        for (int v = 0; v < NVC; v ++) {
+          const unsigned char fl = s_flag[gi][v];
+          const unsigned b = (fl & (kInvalid | kNonFinite)) ? 0x3fu : (unsigned)(fl & 0x3f);
+          if ((v >> ND) & 1) a1 &= b; else a0 &= b;
+        }
+        if (((scope & FTKX_SCOPE_ORDINAL) && a0 == 0) || ((scope & FTKX_SCOPE_INTERVAL) && (a0 & a1) == 0)) atomicAdd(&s_cells, 1u);
+      }
       for (unsigned sub = 0; sub < (unsigned)SUB && base + sub * G < c_hi; sub ++) {
         if (sub) __syncthreads();
         const u64 sbase = base + sub * G;
@@ -252,6 +266,7 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
   if (tid == 0) {
     __hip_atomic_store(&counts[w], (u64)(overflow ? KCAP : s_nkeys) | (overflow ? (1ull << 63) : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (s_tested) atomicAdd((unsigned long long *)(a.scratch + ONE_TESTED), (unsigned long long)s_tested);
+    if (s_cells) atomicAdd((unsigned long long *)(a.scratch + ONE_CELLS), (unsigned long long)s_cells);
   }
   alive = alive && grid_barrier(bar + 1, nwg, bar + 3);
   if (!alive && tid == 0) s_status |= (unsigned)SERIES_OVERFLOW;      // (given up: the host sweeps the steps the usual way)
@@ -330,6 +345,7 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
   if (!s_last) return;
   const u64 nfrag_all = __hip_atomic_load(a.scratch + ONE_NFRAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const u64 tested_all = __hip_atomic_load(a.scratch + ONE_TESTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u64 cells_all = __hip_atomic_load(a.scratch + ONE_CELLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   u64 st = (u64)status;
   if (nfrag_all > a.fragile_capacity || __hip_atomic_load(bar + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) st |= (u64)SERIES_OVERFLOW;
   const bool good = st == 0;
@@ -343,6 +359,7 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
     else if (i == (size_t)SR_NFRAGILE) v = nf;
     else if (i == (size_t)(SR_COUNTERS + CNT_PASS) || i == (size_t)(SR_COUNTERS + CNT_HITS)) v = s_total;
     else if (i == (size_t)(SR_COUNTERS + CNT_SIMPLICES_TESTED)) v = tested_all;
+    else if (i == (size_t)(SR_COUNTERS + CNT_CELLS_SURVIVED)) v = cells_all;
     else if (i == (size_t)(SR_COUNTERS + CNT_FRAGILE)) v = nfrag_all;
     else if (i >= (size_t)SR_HEAD && i < (size_t)(SR_HEAD + n)) v = (u64)s_fields[i - SR_HEAD].factor;
     else if (i >= (size_t)(SR_HEAD + n) && i < (size_t)(SR_HEAD + n + k)) v = (u64)__double_as_longlong(s_res[i - SR_HEAD - n]);
@@ -352,7 +369,7 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
   }
   for (u64 wd = tid; wd < nf * 10; wd += kThreads) a.h_results[a.nwords + wd] = a.fragile[wd];
   if (tid < 4) bar[tid] = 0u;                                    // as found, for the next launch
-  if (tid == 3) { a.scratch[ONE_NFRAG] = 0ull; a.scratch[ONE_TESTED] = 0ull; }
+  if (tid == 4) { a.scratch[ONE_NFRAG] = 0ull; a.scratch[ONE_TESTED] = 0ull; a.scratch[ONE_CELLS] = 0ull; }
   __threadfence_system();
   __syncthreads();
   if (tid == 0) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -70,8 +70,7 @@ size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 // one-workgroup kernel (18 us over 2^16 of them), the ranking inside a bucket costs next to nothing more with four records than with one
 int bins_log2()
 {
-  static const int v = [] { const char *e = getenv("FTKX_SERIES_BINS_LOG2"); const int b = e ? atoi(e) : 0; return b >= 8 && b <= 16 ? b : 14; }();
-  return v;
+  return 14;
 }
 
 // ---- the device-driven pass in two halves -------------------------------------------------------------------------------------------
@@ -186,8 +185,7 @@ void release_retired(ftkx_ctx *c, ftkx_series_pending &P)
 
 bool short_chain_now(const ftkx_ctx *c, bool to_device, bool *small_now)
 {
-  static const bool small_on = !(getenv("FTKX_SERIES_SMALL") && atoi(getenv("FTKX_SERIES_SMALL")) == 0);
-  static const bool short_on = !(getenv("FTKX_SERIES_SHORT") && atoi(getenv("FTKX_SERIES_SHORT")) == 0);
+  const bool small_on = ftkx::env_hook("FTKX_SERIES_HOOKS", "small", 1) != 0, short_on = ftkx::env_hook("FTKX_SERIES_HOOKS", "short", 1) != 0;
   const bool sn = small_on && c->sr_skip_small == 0 && !to_device;
   if (small_now) *small_now = sn;
   return sn && short_on && c->sr_short_chain;
@@ -229,8 +227,7 @@ void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, const unsigned *wait
 // ---- the one-launch pass for small series (one_kernel.hip) --------------------------------------------------------------------------------
 bool series_one_eligible(ftkx_ctx *c, const ftkx_series_pending &P, int n, size_t k, u64 cells, bool dist)
 {
-  const char *e = getenv("FTKX_SERIES_ONE");                  // (read at every pass: tests switch it inside one process)
-  const bool one_on = !(e && atoi(e) == 0);
+  const bool one_on = ftkx::env_hook("FTKX_SERIES_HOOKS", "one", 1) != 0;
   if (!one_on || dist || c->sr_one_off > 0) { if (c->sr_one_off > 0 && !dist) c->sr_one_off --; return false; }
   if (n > ftkx::kOneMaxSteps || k > (size_t)ftkx::kOneMaxSlices) return false;
   // small: a few hundred corners per workgroup at most, and slices whose reduction is a few chunks' worth of reading
@@ -382,10 +379,10 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   // split?  (decided here: the begin kernel of a split pass leaves the counters to the tail stream)
   P.to_device = false;
   {
-    static const bool sdma_on = !(getenv("FTKX_SERIES_COPY") && atoi(getenv("FTKX_SERIES_COPY")) == 0);
-    P.to_device = pipelined && sdma_on && c->stats.hits > 4096;
-    static const bool split_on = !(getenv("FTKX_SERIES_SPLIT") && atoi(getenv("FTKX_SERIES_SPLIT")) == 0);
-    P.split = split_on && pipelined && !dist && c->profiling == 0 && short_chain_now(c, P.to_device, nullptr);
+    P.to_device = pipelined && c->stats.hits > 4096;
+    const bool split_on = ftkx::env_hook("FTKX_SERIES_HOOKS", "split", 1) != 0;
+    // (profiling level 2 times the mask kernel only, with events on the context's stream: they do not stand between the tail and anything)
+    P.split = split_on && pipelined && !dist && (c->profiling == 0 || c->profiling == 2) && short_chain_now(c, P.to_device, nullptr);
   }
   const bool before_split = before && before->open && before->split;
   // a slice whose masks this pass rebuilds while the tail of the pass before it -- on its own stream -- still reads them: fresh arrays here,
@@ -585,7 +582,7 @@ int series_queue_cull(ftkx_ctx *c, ftkx_series_pending &P)
     memset(&fj, 0, sizeof(fj));
     fj.steps = d_steps; fj.slices = d_slices; fj.sinfo = d_sinfo; fj.red = B.red; fj.running_from = running_from; fj.results = B.results; fj.counters = c->d_counters;
     fj.running_in = running_from ? DBL_MAX : P.running_in; fj.safe_m = safe_m; fj.nsteps = n; fj.nslices = (int)k;
-    static const bool fold_on = !(getenv("FTKX_SERIES_FOLD") && atoi(getenv("FTKX_SERIES_FOLD")) == 0);
+    const bool fold_on = ftkx::env_hook("FTKX_SERIES_HOOKS", "fold", 1) != 0;
     fj.enabled = (fold_on && k <= (size_t)ftkx::kFoldMaxSlices) ? 1 : 0;
     if (P.two_level) ftkx::launch_cull_coarse(m, d_steps, n, c->d_refine, c->refine_capacity, st, &fj);
     else ftkx::launch_cull(m, d_steps, n, c->d_list, c->list_capacity, st, &fj);
@@ -849,6 +846,9 @@ int ftkx_sweep_series_submit(ftkx_ctx *c, const int *ts, const int *scopes, int 
   ftkx_series_pending *before = c->sr_open > 0 ? &c->sr_pend[(c->sr_head + c->sr_open - 1) & 1] : nullptr;
   const ftkx_series_pending *prev = (!running_resolution) ? before : nullptr;
   ftkx_series_pending &P = c->sr_pend[(c->sr_head + c->sr_open) & 1];
+  // (a chain starts here: what the host knows of its running minimum is what the caller says -- not what an earlier series left behind, whose
+  // smaller value would make the hint of the passes chained behind this one larger than their factor)
+  if (running_resolution) c->sr_last_running = *running_resolution;
   const double running_in = running_resolution ? *running_resolution : (c->sr_last_running > 0 ? c->sr_last_running : DBL_MAX);
   int rc = series_submit(c, P, ts, scopes, n, running_in, prev, true, before);
   if (rc) { P.open = false; return rc; }

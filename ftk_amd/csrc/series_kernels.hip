@@ -8,6 +8,7 @@
 // scatter puts the descriptors into their buckets, and the record kernel picks, per output position, the descriptor of that rank
 // inside its bucket.  It writes the finished records straight into the caller-visible pinned host buffer, a wavefront's 64 records as
 // one contiguous run, so that the download runs while records are still being built.
+#include "internal.hpp"
 #include "sweep_device.hpp"
 #include "series_device.hpp"
 
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(256) void series_copy_out_kernel(const ftkx_cp_t *_
 void launch_series_copy_out(const ftkx_cp_t *src, ftkx_cp_t *dst, u64 capacity, const u64 *results, unsigned *done, unsigned *flag, unsigned seq, hipStream_t st,
                             const unsigned *wait_flag, unsigned wait_val)
 {
-  static const int wgs = [] { const char *e = getenv("FTKX_COPY_WGS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 1024 ? v : 16; }();
+  constexpr int wgs = 16;      // (256 / 64 / 16 / 4 workgroups cost the mask kernel next to it 94 / 55 / 3 / 0 us; with 4 the copy becomes the long pole: NOTES.md)
   hipLaunchKernelGGL(series_copy_out_kernel, dim3((unsigned)wgs), dim3(256), 0, st, src, dst, capacity, results, done, flag, seq, wait_flag, wait_val);
 }
 
@@ -808,7 +809,7 @@ void launch_bucket_scatter(const Mesh &m, unsigned *boff, u64 *bucketed, hipStre
 void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff, u64 *sorted, u64 *results, hipStream_t st)
 {
   unsigned rank_max = 4096;
-  if (const char *e = getenv("FTKX_SERIES_RANK_MAX")) rank_max = (unsigned)atoi(e);
+  rank_max = (unsigned)env_hook("FTKX_SERIES_HOOKS", "rank_max", 4096);
   hipLaunchKernelGGL(bucket_rank_kernel, dim3(256), dim3(256), 0, st, bucketed, m.capacity, boff, m.hist_shift, rank_max, sorted, m.counters, results);
 }
 

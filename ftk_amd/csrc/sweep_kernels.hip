@@ -22,6 +22,7 @@
 //   vertex block in LDS and tests every simplex (optionally with the same cull); used as-is when the cull is illegal.
 //
 // No MFMA: 64-bit integer VALU work on 8-24 bytes per vertex, HBM-bound once the cull applies.
+#include "internal.hpp"
 #include "sweep_device.hpp"
 #include "series_device.hpp"
 
@@ -2533,11 +2534,11 @@ void tile_dims(int nd, int tile[3])
 
 // does this mesh take the fast vector-input kernel?
 static bool vec_fast(const Mesh &m) { return !m.scalar_mode && m.ext_sz[0] >= 8 && (m.ext_sz[0] % 8) == 0; }
-// ... its form with block summaries (mask_vec2_kernel)?  Rows of at least 64 groups, byte offsets that fit 31 bits.  FTKX_VEC_LEAN=0: never
+// ... its form with block summaries (mask_vec2_kernel)?  Rows of at least 64 groups, byte offsets that fit 31 bits.  FTKX_MASK_PLAN lean=0: never
 static bool vec_lean(const Mesh &m)
 {
   if (!vec_fast(m) || m.ext_sz[0] < 256) return false;
-  if (const char *e = getenv("FTKX_VEC_LEAN")) if (atoi(e) == 0) return false;
+  if (env_hook("FTKX_MASK_PLAN", "lean", 1) == 0) return false;
   const size_t n = (size_t)m.ext_sz[1] * (m.nd == 3 ? (size_t)m.ext_sz[2] : 1);
   return (size_t)m.ext_sz[0] * n * 8 * (size_t)m.nd < (1ull << 31) && (size_t)m.mask_pitch * n < (1ull << 31);
 }
@@ -2554,16 +2555,16 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
     // loads non-temporal: 0.106; 3D, where the planes are re-read by the z march: 256^3 x 16 -1 %, 512^3 x 32 +1.3 %: left as it is.  The
     // vector-input kernel, whose every value is read once, does NOT like non-temporal loads: double_gyre 0.73 -> 1.30 ms)
     if (m.nd == 2) swizzle |= 16;
-    if (const char *e = getenv("FTKX_MASK_SWIZZLE")) swizzle = atoi(e);
+    swizzle = (int)env_hook("FTKX_MASK_PLAN", "swizzle", swizzle);
     int zchunk = 32;
     bool zforced = false;
-    if (const char *e = getenv("FTKX_MASK_ZCHUNK")) if (atoi(e) > 0) { zchunk = atoi(e); zforced = true; }
+    if (env_hook("FTKX_MASK_PLAN", "zchunk", 0) > 0) { zchunk = (int)env_hook("FTKX_MASK_PLAN", "zchunk", 0); zforced = true; }
     if (m.nd == 3 && !reduce) {
       // 3D: mask_march6_kernel -- 128 x 16 tiles as four wavefronts of 4 rows that all load (LDS-DMA) and classify, TWO row slots in
       // LDS (37 KB: three workgroups = twelve wavefronts per CU, which its 164 VGPRs allow), one barrier per plane; grouped placement:
       // 16 row groups (all of a 256^2 plane's, half of a 512^2 plane's tiles) of one piece of planes share an XCD's L2 (4: +3.5 %, 8: +0.5 %)
       int yg_want = 16;
-      if (const char *e = getenv("FTKX_MASK_YG")) yg_want = atoi(e) > 0 ? atoi(e) : 1;
+      if (env_hook_set("FTKX_MASK_PLAN", "yg")) yg_want = env_hook("FTKX_MASK_PLAN", "yg", 16) > 0 ? (int)env_hook("FTKX_MASK_PLAN", "yg", 16) : 1;
       if (yg_want > 255) yg_want = 255;
       // The pieces a tile column is marched in (ZPlan): at most 24 planes, at most half of what is left of the column, at least 6,
       // multiples of 3 (the march is unrolled three planes deep), handed out longest first.  Measured, not derived (tools/ab_mask.py,
@@ -2574,14 +2575,14 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       // column's top decides).  Order of the workgroups: slice by slice where a slice alone fills the device (neighbouring pieces of a
       // slice then run together and find each other's start-up planes in the caches: 512^3 x 32 5.59 against 5.85 ms piece by piece),
       // piece by piece over all slices otherwise (256^3 x 16: 0.379 against 0.399).
-      // FTKX_MASK_ZCHUNK = n: equal chunks of n planes; FTKX_MASK_LCAP / _LMIN: the two bounds; FTKX_MASK_ORDER = 0 / 1
+      // FTKX_MASK_PLAN (test hooks): zchunk=n: equal chunks of n planes; lcap / lmin: the two bounds; order=0 / 1
       ZPlan plan = ZPlan();
       bool planned = false;
       {
         int lmin = 6, lcap = 24;
         planned = !zforced;
-        if (const char *e = getenv("FTKX_MASK_LMIN")) if (atoi(e) >= 1) lmin = atoi(e);
-        if (const char *e = getenv("FTKX_MASK_LCAP")) if (atoi(e) >= 1) lcap = atoi(e);
+        if (env_hook("FTKX_MASK_PLAN", "lmin", 0) >= 1) lmin = (int)env_hook("FTKX_MASK_PLAN", "lmin", 0);
+        if (env_hook("FTKX_MASK_PLAN", "lcap", 0) >= 1) lcap = (int)env_hook("FTKX_MASK_PLAN", "lcap", 0);
         if (lcap < lmin) lcap = lmin;
         std::vector<int> lens;
         int rem = DD;
@@ -2609,7 +2610,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       const unsigned bytes = (unsigned)NS6 * (unsigned)(rows + 2) * 1024u + (unsigned)(NS6 + 1) * 256u + 128u;   // row slots, edge ring, the summaries' exchange
       (void)hipFuncSetAttribute((const void *)mask_march6_kernel<NS6, CY6, RY6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
       bool slice_major = (size_t)grid6.x * ((m.ext_sz[1] + rows - 1) / rows) * plan.npieces >= 768;      // a slice alone fills the device (three workgroups per CU)
-      if (const char *e = getenv("FTKX_MASK_ORDER")) slice_major = atoi(e) == 0;
+      if (env_hook_set("FTKX_MASK_PLAN", "order")) slice_major = env_hook("FTKX_MASK_PLAN", "order", 0) == 0;
       hipLaunchKernelGGL((mask_march6_kernel<NS6, CY6, RY6, false>), grid6, dim3(64u * CY6), bytes, stream, m, d_jobs, sw, slice_major ? -njobs : njobs, plan);
       return;
     }
@@ -2620,7 +2621,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
     const dim3 grid4((unsigned)((DW + 127) / 128), (unsigned)((m.ext_sz[1] + wpb * RY - 1) / (wpb * RY)), (unsigned)(nzc * njobs));
     if (swizzle & 8) {     // (the group height must divide the grid's y extent)
       int yg = 4;
-      if (const char *e = getenv("FTKX_MASK_YG")) yg = atoi(e) > 0 ? (atoi(e) > 255 ? 255 : atoi(e)) : 1;
+      if (env_hook_set("FTKX_MASK_PLAN", "yg")) { const long v = env_hook("FTKX_MASK_PLAN", "yg", 4); yg = v > 0 ? (v > 255 ? 255 : (int)v) : 1; }
       while (yg > 1 && grid4.y % (unsigned)yg) yg --;
       swizzle = (swizzle & 0xff) | (yg << 8);
     }
@@ -2684,7 +2685,7 @@ int mask_summary_rows(const Mesh &m)
 // does launch_masks produce the per-word summaries for this mesh?  (the 128-column marching kernels and the fast vector kernel do)
 bool masks_have_summary(const Mesh &m)
 {
-  if (const char *e = getenv("FTKX_TWO_LEVEL")) if (atoi(e) == 0) return false;
+  if (const char *e = getenv("FTKX_U_ROWS")) if (atoi(e) < 0) return false;      // (FTKX_U_ROWS=-1: no summaries at all, the one-level cull)
   if (!m.scalar_mode) return vec_fast(m);
   return march2_supported(m) && (m.ext_sz[0] % 8) == 0;
 }
@@ -2698,7 +2699,6 @@ static void launch_cull_level(const Mesh &m, const Fields *d_steps, int nsteps, 
   FactorJob fj = FactorJob();
   if (job) fj = *job;
   int ZC = m.nd == 3 ? 4 : 1;
-  if (const char *e = getenv("FTKX_CULL_ZC")) { const int v = atoi(e); if (m.nd == 3 && (v == 2 || v == 4 || v == 8)) ZC = v; }
   const int groups = (m.ext_sz[0] + 7) / 8;
   int gx_log2 = 3;
   while (gx_log2 < 6 && (1 << gx_log2) < groups) gx_log2 ++;
@@ -2708,7 +2708,6 @@ static void launch_cull_level(const Mesh &m, const Fields *d_steps, int nsteps, 
   // (3D: 4 -- a chunk re-reads one slice, a quarter more bytes of arrays that are 1/256 of the input, and gives four times the
   // wavefronts: the coarse cull of 256^3 x 16 0.052 -> 0.026 ms, of 512^3 x 32 0.089 -> 0.081 ms)
   int step_chunk = 4;   // (2D: the survivors of a workgroup's four steps leave with one atomic on the list counter)
-  if (const char *e = getenv("FTKX_CULL_STEP_CHUNK")) step_chunk = atoi(e) > 0 ? atoi(e) : step_chunk;
   const int nsc = (nsteps + step_chunk - 1) / step_chunk;
   const dim3 grid((unsigned)((groups + GX - 1) / GX), (unsigned)((m.ext_sz[1] + rows_per_block - 1) / rows_per_block), (unsigned)(nzc * nsc) + (fj.enabled ? 1u : 0u));
 #define FTKX_CULL_LAUNCH(ND_, ZC_) hipLaunchKernelGGL((cull_march_kernel<ND_, ZC_, COARSE>), grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, step_chunk, gx_log2, d_list, cap, fj)
@@ -2778,7 +2777,6 @@ void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64
   // persistent-style: workgroups stride over the list, every wave exits when it is drained (no scratch; 21-23 KB of LDS).  Four per
   // CU: woven 1024^2 x 64 (181 853 cells) 0.084 ms with the record kernel, double_gyre 2048 x 1024 x 128 0.078 (0.097 with two)
   int per_cu = 4;
-  if (const char *e = getenv("FTKX_EXACT_WG_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 64) per_cu = v; }
   const dim3 grid(256u * (unsigned)per_cu);
   if (m.nd == 2) hipLaunchKernelGGL(exact_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, step_base, d_list, cap);
   else hipLaunchKernelGGL(exact_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_steps, step_base, d_list, cap);

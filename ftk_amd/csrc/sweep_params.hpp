@@ -199,7 +199,7 @@ struct OneArgs {
   u64 *results, *h_results; size_t nwords; unsigned *flag; unsigned seq;
   ftkx_cp_t *out; u64 capacity; u64 *fragile; u64 fragile_capacity;
 };
-enum { ONE_BAR = 0 /* three 32-bit arrival counters */, ONE_TESTED = 2, ONE_NFRAG = 3, ONE_COUNTS = 8 /* one word per workgroup */, ONE_PARTS = 8 + 256,
+enum { ONE_BAR = 0 /* three 32-bit arrival counters */, ONE_TESTED = 2, ONE_NFRAG = 3, ONE_CELLS = 4, ONE_COUNTS = 8 /* one word per workgroup */, ONE_PARTS = 8 + 256,
        ONE_WORDS = 8 + 256 + 2 * kOneMaxSlices * kOneParts };
 constexpr int kDistContrib = 4;            // words a rank contributes to the all_gather: slab min resolution, slab max |v|, the same of its FIRST slice
 

@@ -397,7 +397,7 @@ template <int N>
 int trace_impl(const long long *dst, const long long *dsz, const TagView tags, size_t n, ftkx_curves *out, const DevicePhase *dev = nullptr)
 {
   static const Adjacency<N> adj;
-  const bool prof = getenv("FTKX_TRACE_PROF") != nullptr;
+  constexpr bool prof = false;      // (phase timing to stderr: a debugging aid, compiled out)
   auto now = [] { return std::chrono::duration<double>(std::chrono::high_resolution_clock::now().time_since_epoch()).count() * 1e3; };
   double tp[8]; int np_ = 0; tp[np_ ++] = now();
   constexpr int MAXNB = 2 * N;                       // two cells per face, N other faces each

@@ -96,7 +96,7 @@ static int trace_curves_ctx_impl(ftkx_ctx *c, int nd, const long long domain_st[
   auto tag_of = [&](size_t i) { return tags ? tags[i] : recs[i].tag; };
   auto on_host = [&]() { return tags ? ftkx::trace_curves_tags(nd, domain_st, domain_sz, tags, n, out) : ftkx_trace_curves(nd, domain_st, domain_sz, recs, n, out); };
   if (!c) return on_host();
-  static const bool timing = getenv("FTKX_TRACE_TIMING") != nullptr;
+  constexpr bool timing = false;      // (phase timing to stderr: a debugging aid, compiled out)
   const auto tp0 = std::chrono::steady_clock::now();
   if ((nd != 2 && nd != 3) || !domain_st || !domain_sz || (!recs && !tags && n) || !out) return fail(c, FTKX_E_INVALID, "ftkx_trace_curves_ctx: bad arguments");
   // few records, or tags that do not come strictly ascending (the sweep delivers them so): the host does it all

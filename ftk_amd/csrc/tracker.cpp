@@ -678,7 +678,7 @@ void critical_point_tracker_regular::finalize()
   }
   // Nothing has to be ordered for this: ftkx_trace_curves takes the points in any order (it indexes them by tag) and returns the curves
   // in the reference's order.  Sweeps in time order with 64-bit tags deliver ascending tags: the pending points are traced as they are.
-  static const bool timing = getenv("FTKX_TRACE_TIMING") != nullptr;
+  constexpr bool timing = false;      // (phase timing to stderr: a debugging aid, compiled out)
   typedef std::chrono::steady_clock clk;
   const clk::time_point tq0 = clk::now();
   if (!(points.empty() && pending_ascending)) flush_points();

@@ -253,12 +253,12 @@ class SlabSeries:
         else:
             self._copy_in = lambda dst, src_np: _lib.check(L.ftkx_upload(ctx._h, dst, src_np.ctypes.data, src_np.nbytes), ctx._h)
             self._copy_out = lambda dst_np, src: _lib.check(L.ftkx_download(ctx._h, dst_np.ctypes.data, src, dst_np.nbytes), ctx._h)
-        if self.staged or custom:
-            self._tr = _lib.SlabTransport(None, _lib.AG_FN(self._cb_all_gather), _lib.XCHG_FN(self._cb_exchange), 0, _lib.DESTROY_FN())
-            rc = (L.ftkx_slab_create_custom(C.byref(self._backend), nt, self.rank, self.world, C.byref(self._tr), C.byref(self._h)) if custom
-                  else L.ftkx_slab_create(ctx._h, nt, self.rank, self.world, C.byref(self._tr), C.byref(self._h)))
-        else:
-            # RCCL inside the library: a communicator of our own over the same ranks (torch does not hand its ncclComm_t out)
+        self.transport = "callbacks (torch.distributed, staged through host memory)"
+        self._coll_dev = "cpu" if self.staged else device        # where torch.distributed wants its tensors (nccl: on the device)
+        rc = None
+        if not self.staged and not custom:
+            # RCCL inside the library: a communicator of our own over the same ranks (torch does not hand its ncclComm_t out).  Every rank
+            # learns whether EVERY rank got one (an all_reduce): either all of them take the library's transport, or all fall back
             idbuf = torch.zeros((128,), dtype=torch.uint8, device=device)
             if self.rank == 0:
                 raw = (C.c_ubyte * 128)()
@@ -267,9 +267,22 @@ class SlabSeries:
             dist.broadcast(idbuf, 0, group=group)
             raw = (C.c_ubyte * 128).from_buffer_copy(bytes(idbuf.cpu().numpy().tobytes()))
             comm = C.c_void_p()
-            _lib.check(L.ftkx_rccl_comm_create(raw, self.rank, self.world, int(device.index or 0), C.byref(comm)))
-            self._comm = comm
-            rc = L.ftkx_slab_create_rccl(ctx._h, nt, self.rank, self.world, comm, None, C.byref(self._h))
+            ok = L.ftkx_rccl_comm_create(raw, self.rank, self.world, int(device.index or 0), C.byref(comm)) == 0
+            why = "" if ok else _lib.last_error(None)
+            agreed = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=group)
+            if int(agreed.item()) == 1:
+                self._comm = comm
+                self.transport = "rccl (ftk_amd/csrc/slab_rccl.cpp: ncclAllGather, grouped ncclSend / ncclRecv), RCCL %d" % L.ftkx_rccl_version()
+                rc = L.ftkx_slab_create_rccl(ctx._h, nt, self.rank, self.world, comm, None, C.byref(self._h))
+            else:
+                if ok:
+                    L.ftkx_rccl_comm_destroy(comm)
+                self.transport += "; the library's RCCL communicator could not be made on every rank (%s)" % why
+        if rc is None:
+            self._tr = _lib.SlabTransport(None, _lib.AG_FN(self._cb_all_gather), _lib.XCHG_FN(self._cb_exchange), 0, _lib.DESTROY_FN())
+            rc = (L.ftkx_slab_create_custom(C.byref(self._backend), nt, self.rank, self.world, C.byref(self._tr), C.byref(self._h)) if custom
+                  else L.ftkx_slab_create(ctx._h, nt, self.rank, self.world, C.byref(self._tr), C.byref(self._h)))
         if rc != 0:
             msg = _lib.last_error(None)
             if rc == E_UNSUPPORTED:
@@ -287,6 +300,7 @@ class SlabSeries:
         self = object.__new__(cls)
         self.ctx, self.nt, self.world, self.rank, self.group = ctx, nt, world, rank, None
         self._L, self._C, self._err, self._comm = _lib.load(), C, None, None
+        self.transport = "hub (ranks of one process: peer copies ordered by events)"
         self.own = list(range(*slab_range(nt, world, rank)))
         self._h = C.c_void_p()
         _lib.check(self._L.ftkx_slab_create_local(ctx._h, nt, rank, hub, C.byref(self._h)))
@@ -302,6 +316,7 @@ class SlabSeries:
         self = object.__new__(cls)
         self.ctx, self.nt, self.world, self.rank, self.group = ctx, nt, world, rank, None
         self._L, self._C, self._err, self._comm = _lib.load(), C, None, None
+        self.transport = "rccl (the caller's communicator)"
         self.own = list(range(*slab_range(nt, world, rank)))
         self._h = C.c_void_p()
         _lib.check(self._L.ftkx_slab_create_rccl(ctx._h, nt, rank, world, comm, side_comm, C.byref(self._h)))
@@ -323,9 +338,9 @@ class SlabSeries:
             torch = self.torch
             mine = np.empty((nbytes,), dtype=np.uint8)
             self._copy_out(mine, send)
-            out = torch.empty((nbytes * self.world,), dtype=torch.uint8)
-            self.dist.all_gather_into_tensor(out, torch.from_numpy(mine), group=self.group)
-            self._copy_in(recv, out.numpy())
+            out = torch.empty((nbytes * self.world,), dtype=torch.uint8, device=self._coll_dev)
+            self.dist.all_gather_into_tensor(out, torch.from_numpy(mine).to(self._coll_dev), group=self.group)
+            self._copy_in(recv, out.cpu().numpy())
         return self._guard(run)
 
     def _cb_exchange(self, user, send, sb, to, recv, rb, frm, stream):
@@ -335,14 +350,16 @@ class SlabSeries:
             if to >= 0:
                 out = np.empty((sb,), dtype=np.uint8)
                 self._copy_out(out, send)
-                ops.append(dist.P2POp(dist.isend, torch.from_numpy(out), to, self.group))
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(out).to(self._coll_dev), to, self.group))
             if frm >= 0:
-                back = torch.empty((rb,), dtype=torch.uint8)
+                back = torch.empty((rb,), dtype=torch.uint8, device=self._coll_dev)
                 ops.append(dist.P2POp(dist.irecv, back, frm, self.group))
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
             if back is not None:
-                self._copy_in(recv, back.numpy())
+                if back.is_cuda:
+                    self.torch.cuda.current_stream().synchronize()
+                self._copy_in(recv, back.cpu().numpy())
         return self._guard(run)
 
     def _ck(self, rc):

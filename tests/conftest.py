@@ -18,3 +18,13 @@ def oracle():
     import pyoracle
     pyoracle.build()
     return pyoracle
+
+
+def pytest_collection_finish(session):
+    """the full-size oracle comparisons (tests/test_gpu_zz_fullsize_oracle.py) compute their oracle in the background from here on"""
+    if any("test_gpu_zz_fullsize_oracle" in item.nodeid for item in session.items):
+        try:
+            import test_gpu_zz_fullsize_oracle as Z
+            Z.start_background()
+        except Exception:   # noqa: BLE001
+            pass

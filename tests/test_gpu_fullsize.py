@@ -63,12 +63,10 @@ def _same(a, b):
 
 def _assert_equals_oracle(oracle, recs, host_steps, nd, nv, factors, what):
     """the oracle on the very arrays the GPU swept (generated on the device: torch's sin / cos are not libm's)"""
-    ncores = os.cpu_count() or 1
-    ref, rf, secs = oracle.track(host_steps, nd, nv, tag_mode=oracle.TAG_EXACT64, nthreads=ncores)
+    from gpu_common import oracle_track_cached
+    ref, rf, secs = oracle_track_cached(oracle, host_steps, nd, nv)      # (sorted by tag; shared with tests/test_gpu_fullsize_series.py)
     assert [int(f) for f in rf] == [int(f) for f in factors], what
     assert len(ref) == len(recs), (what, len(ref), len(recs))
-    order = np.argsort(ref["tag"], kind="stable")
-    ref = ref[order]
     assert np.array_equal(ref["tag"], recs["tag"]) and np.array_equal(ref["type"], recs["type"]), what
     assert np.array_equal(ref["ordinal"].astype(np.uint32), recs["aux"] & 1) and np.array_equal(ref["timestep"].astype(np.uint32), recs["aux"] >> 1), what
     for f in ("x", "t"):

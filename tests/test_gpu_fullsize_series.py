@@ -121,10 +121,10 @@ def _timed_path(gpu, case, dims, nt, nv, want_path, keep_host=False, k=5):
 
 
 def _assert_equals_oracle(oracle, recs, host_steps, nd, nv, factors, what):
-    ref, rf, secs = oracle.track(host_steps, nd, nv, tag_mode=oracle.TAG_EXACT64, nthreads=os.cpu_count() or 1)
+    from gpu_common import oracle_track_cached
+    ref, rf, secs = oracle_track_cached(oracle, host_steps, nd, nv)      # (sorted by tag; shared with tests/test_gpu_fullsize.py)
     assert [int(f) for f in rf] == [int(f) for f in factors], what
     assert len(ref) == len(recs), (what, len(ref), len(recs))
-    ref = ref[np.argsort(ref["tag"], kind="stable")]
     assert np.array_equal(ref["tag"], recs["tag"]) and np.array_equal(ref["type"], recs["type"]), what
     assert np.array_equal(ref["ordinal"].astype(np.uint32), recs["aux"] & 1) and np.array_equal(ref["timestep"].astype(np.uint32), recs["aux"] >> 1), what
     for f in ("x", "t"):
@@ -203,38 +203,6 @@ def test_c4_series_moving_extremum_512cubed_x32(gpu):
 BIG_HOST = (os.cpu_count() or 1) >= 128        # the oracle at these sizes: minutes on a laptop, about a minute each on the GPU box's 256 host threads
 
 
-@pytest.mark.skipif(not BIG_HOST, reason="the oracle over 1.5e10 simplices needs the GPU box's host threads")
-def test_c3_series_vs_oracle(gpu, oracle):
-    """BASELINE configs[2], moving_extremum_3d 256^3 x 16, at FULL size against the ORACLE (oracle/ftk_oracle.c, pinned to the reference) on the
-    very arrays the GPU swept -- not only against the analytic trajectory and this repository's own exact_only path: records bit-identical,
-    factors equal (critical_point_tracker_3d_regular.hh:150-308, 425-514)."""
-    dims, nt = (256, 256, 256), 16
-    R = Resident(gpu, "moving_extremum_3d", dims, nt, 1, keep_host=True)
-    try:
-        runs = R.pipelined(3)
-        recs, f, path = runs[-1]
-        assert path == (2, SERIES_EARLY) and all(_bytes_equal(r, recs) and p == path for r, _, p in runs)
-        host = R.host
-    finally:
-        R.close()
-    _assert_equals_oracle(oracle, recs, host, 3, 1, f, "c3 at full size vs oracle")
-
-
-@pytest.mark.skipif(not BIG_HOST, reason="the oracle over 9e9 simplices needs the GPU box's host threads")
-def test_c4_two_slices_vs_oracle(gpu, oracle):
-    """two slices of BASELINE configs[3] (512^3: the headline's slice size, its ZPlan pieces, its tile placement) against the ORACLE"""
-    dims, nt = (512, 512, 512), 2
-    R = Resident(gpu, "moving_extremum_3d", dims, nt, 1, keep_host=True)
-    try:
-        runs = R.pipelined(2)
-        recs, f, path = runs[-1]
-        assert path == (2, SERIES_EARLY) and _bytes_equal(runs[0][0], recs)
-        host = R.host
-    finally:
-        R.close()
-    _assert_equals_oracle(oracle, recs, host, 3, 1, f, "512^3 x 2 vs oracle")
-
-
 def _bumpy_3d(torch, dev, dims, nt, seed):
     """a 3D series that is neither smooth nor rough everywhere: a tilted background (a strict sign almost everywhere), a few hundred moving
     bumps (isolated critical points, some of them merging), and a box of noise (hit-dense: every kind of mask word, many records per cell)"""
@@ -292,6 +260,8 @@ def test_bumpy_3d_series_vs_oracle(gpu, oracle):
         ts = np.arange(nt, dtype=np.int32)
         scopes = np.array([gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)], dtype=np.int32)
         outs = []
+        ctx.sweep_series(ts, scopes)                     # (a first pass sizes the survivor lists and the record buffers: bench.py's warm-up)
+        ctx.invalidate_masks()
         ctx.sweep_series_submit(ts, scopes)
         for i in range(1, 4):
             if i < 3:

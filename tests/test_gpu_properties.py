@@ -189,9 +189,20 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
     variants += [{"FTKX_U_ROWS": "4"}, {"FTKX_U_ROWS": "4", "FTKX_MASK_ZCHUNK": "7"}, {"FTKX_U_ROWS": "4", "FTKX_MASK_LCAP": "3", "FTKX_MASK_LMIN": "1"}]
     base = None
     by_geometry = {}
+    def hooks(env):
+        """the variants above name one knob each; the library reads the mask kernels' launch geometry from ONE variable, FTKX_MASK_PLAN
+        ("name=value,..."), and the summary geometry from FTKX_U_ROWS (-1: no summaries, the one-level cull)"""
+        plan = ",".join("%s=%s" % (k[len("FTKX_MASK_"):].lower(), v) for k, v in env.items() if k.startswith("FTKX_MASK_"))
+        out = {"FTKX_MASK_PLAN": plan} if plan else {}
+        if env.get("FTKX_TWO_LEVEL") == "0":
+            out["FTKX_U_ROWS"] = "-1"
+        elif "FTKX_U_ROWS" in env:
+            out["FTKX_U_ROWS"] = env["FTKX_U_ROWS"]
+        return out
     for env in variants:
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
+        real = hooks(env)
+        old = {k: os.environ.get(k) for k in real}
+        os.environ.update(real)
         try:
             recs, st, factors = _run(gpu, case, dims, nt, steps=steps)
         finally:
@@ -602,7 +613,7 @@ def _vector_field(rng, dims, kind):
 def test_vector_mask_kernels_agree(gpu, dims, core, kind):
     """mask_vec2_kernel (units of 4 rows x 64 groups, one summary byte per 8 x 4 block, wave-uniform addressing, one compare per component,
     the vertices one by one only where a wavefront meets the domain's border / a non-finite or big value) against mask_vec_kernel
-    (FTKX_VEC_LEAN=0: one summary byte per word): the same mask words wherever both write them, block summaries = the AND of the word
+    (FTKX_MASK_PLAN lean=0: one summary byte per word): the same mask words wherever both write them, block summaries = the AND of the word
     summaries, the same fused reduction, the same records and number of simplices tested -- rows of 64 groups exactly, rows whose last
     chunk is ragged, row counts that are no multiple of 4, a domain inside the array, fields with plateaus / zeros / values at the threshold
     and fields with NaNs, infinities and values past `big`."""
@@ -616,8 +627,8 @@ def test_vector_mask_kernels_agree(gpu, dims, core, kind):
     dom = core or ([1] * nd, [d - 2 for d in dims])
     out = {}
     for lean in ("0", "1"):
-        old = os.environ.get("FTKX_VEC_LEAN")
-        os.environ["FTKX_VEC_LEAN"] = lean
+        old = os.environ.get("FTKX_MASK_PLAN")
+        os.environ["FTKX_MASK_PLAN"] = "lean=" + lean
         try:
             ctx = gpu.Context(nd)
             ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
@@ -660,9 +671,9 @@ def test_vector_mask_kernels_agree(gpu, dims, core, kind):
             ctx.close()
         finally:
             if old is None:
-                os.environ.pop("FTKX_VEC_LEAN", None)
+                os.environ.pop("FTKX_MASK_PLAN", None)
             else:
-                os.environ["FTKX_VEC_LEAN"] = old
+                os.environ["FTKX_MASK_PLAN"] = old
         out[lean] = (name, {t: (np.float64(a).tobytes(), np.float64(b).tobytes()) for t, (a, b) in rm.items()}, packed, recs, st)
     assert "mask_vec_kernel" in out["0"][0] and "mask_vec2_kernel" in out["1"][0], (out["0"][0], out["1"][0])
     assert out["0"][1] == out["1"][1], "fused reduction"

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""A/B timing of mask-kernel variants inside ONE process (the library reads its FTKX_MASK_* knobs at every launch): the variants
+"""A/B timing of mask-kernel variants inside ONE process (the library reads FTKX_MASK_PLAN at every launch): the variants
 are interleaved round-robin so that box-to-box and minute-to-minute drift hits all of them alike.  Reports per variant the
 mean / min of the fused mask kernel's device time (HIP events inside the library) over the rounds.
-usage: python tools/ab_mask.py [config] [rounds] -- "TILE=0 YG=1" "TILE=1 YG=4" ...   (names without the FTKX_MASK_ prefix)"""
+usage: python tools/ab_mask.py [config] [rounds] -- "TILE=0 YG=1" "TILE=1 YG=4" ...   (names of FTKX_MASK_PLAN; other variables by their full name)"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,12 +35,16 @@ ctx.set_profiling(True)
 times = {v: [] for v in variants}
 for rnd in range(rounds + 1):
     for v in variants:
-        old = {}
+        old, plan = {}, []
         for kv in v.split():
             k, val = kv.split("=")
-            k = k if k.startswith("FTKX_") else "FTKX_MASK_" + k      # (full names for knobs outside the FTKX_MASK_ family)
-            old[k] = os.environ.get(k)
-            os.environ[k] = val
+            if k.startswith("FTKX_"):                                   # (full names for knobs outside the mask-plan family, e.g. FTKX_U_ROWS)
+                old[k] = os.environ.get(k)
+                os.environ[k] = val
+            else:
+                plan.append("%s=%s" % (k.lower(), val))                 # FTKX_MASK_PLAN: "swizzle=..,yg=..,zchunk=..,lmin=..,lcap=..,order=..,lean=.."
+        old["FTKX_MASK_PLAN"] = os.environ.get("FTKX_MASK_PLAN")
+        os.environ["FTKX_MASK_PLAN"] = ",".join(plan)
         ctx.invalidate_masks()
         ctx.set_profiling(True)      # resets the accumulated kernel times
         ctx.slices_prepare(range(nt), 0)
