@@ -10,12 +10,14 @@
 //      --------------------------------------------------------------------------------------------------- barrier
 //   2  every workgroup for itself: the sticky running minimum and nbits per step (update_vector_field_scaling_factor,
 //      critical_point_tracker.hh:850-864; series_device.hpp: nbits_of)
-//   3  a contiguous range of (step, corner) per workgroup: vertices quantised once per corner, the strict-sign cull per simplex, the robust
-//      integer test (cp_device.hpp), degenerate simplices dealt over all lanes; the order keys of the simplices that passed stay in LDS
+//   3  the (step, corner) range in BLOCKS of one staging batch, a run of consecutive blocks per workgroup: vertices quantised once per corner, the cell-level and the per-simplex strict-sign cull, the
+//      robust integer test (cp_device.hpp), degenerate simplices dealt over all lanes; the order keys of the simplices that passed stay
+//      in LDS, a count per block goes to device memory
 //      --------------------------------------------------------------------------------------------------- barrier
-//   4  offsets from the workgroups' counts; own keys ranked in LDS (ranges are contiguous in the order key: ranks within a workgroup +
-//      the offset = the place in tag order); records built in that order (the FP64 half: sweep_device.hpp, make_record_*) and written
-//      straight into the pinned host buffer; the workgroup that finishes last publishes the results block and the flag the host waits for.
+//   4  every workgroup scans the blocks' counts for the offsets of its own blocks; a block's keys ranked among themselves in LDS (a block is
+//      a contiguous range of the order key: rank + offset = the place in tag order); records built in that order (the FP64 half:
+//      sweep_device.hpp, make_record_*) and written into the pinned host buffer in contiguous runs; the workgroup that finishes last
+//      publishes the results block and the flag the host waits for.
 //
 // No masks are built (nothing is left for a later pass to reuse -- at these sizes there is nothing to save), no survivor lists, no sort.
 // Anything this kernel cannot decide -- a factor that hangs on the last bit of log2, more hits than a workgroup parks -- is flagged and the
@@ -46,7 +48,7 @@ __device__ inline bool grid_barrier(unsigned *ctr, unsigned nwg, unsigned *abort
         ok = 0;
         break;
       }
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
     }
     s_ok = ok;
   }
@@ -55,6 +57,19 @@ __device__ inline bool grid_barrier(unsigned *ctr, unsigned nwg, unsigned *abort
 }
 
 }  // namespace
+
+#ifdef FTKX_ONE_STAMPS
+__device__ unsigned long long g_one_stamps[16];      // [k]: the latest passage of phase boundary k over all workgroups (diagnostic builds: -DFTKX_ONE_STAMPS)
+#define ONE_STAMP(k) do { if (threadIdx.x == 0) atomicMax(&g_one_stamps[k], (unsigned long long)wall_clock64()); } while (0)
+extern "C" void ftkx_debug_one_stamps(unsigned long long *out, int reset)
+{
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_one_stamps), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16]; for (auto &x : z) x = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_one_stamps), z, sizeof(z)); }
+}
+#else
+#define ONE_STAMP(k) do { } while (0)
+#endif
 
 template <int ND>
 __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, const OneArgs a)
@@ -67,16 +82,20 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
   __shared__ i64 s_vf[SUB * G][NVC][ND];
   __shared__ unsigned char s_flag[SUB * G][NVC];
   __shared__ unsigned s_tab[NTYPES];
-  __shared__ unsigned short s_deg[G * NTYPES];
-  __shared__ unsigned s_nkeys, s_ndeg, s_status, s_tested, s_cells, s_last;
+  __shared__ unsigned short s_deg[G * NTYPES];                  // (gi << 6) | type: gi < SUB * G <= 128
+  __shared__ unsigned s_nkeys, s_ndeg, s_status, s_tested, s_cells, s_last, s_nsurv;
+  __shared__ unsigned short s_surv[SUB * G];
   __shared__ double s_rmn[kThreads / 64], s_rmx[kThreads / 64];
+  __shared__ unsigned s_wsum[kThreads / 64], s_lanepre[kThreads], s_bstart[kOneOwnBlocks], s_bcnt[kOneOwnBlocks], s_boff[kOneOwnBlocks], s_pos[KCAP];
+  __shared__ unsigned s_bc[kOneMaxBlocks];                        // every block's count (phase 4)
+  __shared__ u64 s_rec[kThreads / 64][64 * 9];                   // a wavefront's records, staged for contiguous stores
   __shared__ u64 s_base, s_total;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const unsigned nwg = gridDim.x, w = blockIdx.x;
   const fan_table<N> &fan = dev_fan<ND>();
   unsigned *bar = reinterpret_cast<unsigned *>(a.scratch + ONE_BAR);      // [0], [1]: the two barriers, [2]: arrivals at the exit, [3]: somebody gave up
   u64 *parts = a.scratch + ONE_PARTS;                          // [nslices * kOneParts][2]
-  u64 *counts = a.scratch + ONE_COUNTS;                        // [nwg]
+  unsigned *bcount = reinterpret_cast<unsigned *>(a.scratch + ONE_BCOUNT);      // [nblocks]
   if (tid == 0) { s_nkeys = 0; s_ndeg = 0; s_status = 0; s_tested = 0; s_cells = 0; s_base = 0; s_total = 0; }
   if (tid < NTYPES) {
     unsigned t = 0;
@@ -84,19 +103,23 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
     s_tab[tid] = t;
   }
 
-  // ---- 1: reductions, chunk = (slice, part) --------------------------------------------------------------------------------------------
+#ifdef FTKX_ONE_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == 0) g_one_stamps[0] = wall_clock64();
+#endif
+  // ---- 1: reductions, chunk = (slice, part): as many chunks as there are workgroups, at least ---------------------------------------------
+  const int parts_per_slice = (int)min((unsigned)kOneParts, max(1u, (nwg + (unsigned)a.nslices - 1u) / (unsigned)a.nslices));
   {
-    const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1;
-    const size_t nv = (size_t)DW * DH * DD, per = (nv + kOneParts - 1) / kOneParts;
-    const int nchunks = a.nslices * kOneParts;
+    const unsigned DW = (unsigned)m.ext_sz[0], DH = (unsigned)m.ext_sz[1], DD = (ND == 3) ? (unsigned)m.ext_sz[2] : 1u;
+    const unsigned nv = DW * DH * DD, per = (nv + (unsigned)parts_per_slice - 1u) / (unsigned)parts_per_slice;      // (small series: far below 2^32 vertices)
+    const int nchunks = a.nslices * parts_per_slice;
     for (int c = (int)w; c < nchunks; c += (int)nwg) {
-      const OneSlice sl = a.slice[c / kOneParts];
-      const size_t lo = (size_t)(c % kOneParts) * per, hi = lo + per < nv ? lo + per : nv;
+      const OneSlice sl = a.slice[c / parts_per_slice];
+      const unsigned lo = (unsigned)(c % parts_per_slice) * per, hi = lo + per < nv ? lo + per : nv;
       double mn = DBL_MAX_D, mx = 0.0;
-      for (size_t idx = lo + tid; idx < hi; idx += kThreads) {
-        const int i = (int)(idx % DW), j = (int)((idx / DW) % DH), k = (int)(idx / ((size_t)DW * DH));
+      for (unsigned idx = lo + (unsigned)tid; idx < hi; idx += kThreads) {
+        const unsigned row = idx / DW, i = idx - row * DW, k = row / DH, j = row - k * DH;
         double v[ND];
-        vector_at<ND>(m, sl.S, sl.V, i, j, k, v);
+        vector_at<ND>(m, sl.S, sl.V, (int)i, (int)j, (int)k, v);
         for (int q = 0; q < ND; q ++) {                          // (mask_kernel's fused reduction, sweep_kernels.hip: the WHOLE array, like ndarray::resolution())
           const double x = fabs(v[q]);
           mn = fmin(mn, (x == 0.0 || !(x < a.cap)) ? DBL_MAX_D : x);
@@ -113,18 +136,25 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
       }
     }
   }
+  ONE_STAMP(1);
   bool alive = grid_barrier(bar + 0, nwg, bar + 3);
+  ONE_STAMP(2);
 
   // ---- 2: factors (every workgroup for itself) -----------------------------------------------------------------------------------------
-  if (alive && tid < a.nslices) {
-    double mn = DBL_MAX_D, mx = 0.0;
-    for (int p = 0; p < kOneParts; p ++) {
-      const u64 x = __hip_atomic_load(&parts[2 * (tid * kOneParts + p)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const u64 y = __hip_atomic_load(&parts[2 * (tid * kOneParts + p) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      mn = fmin(mn, __longlong_as_double((long long)x)); mx = fmax(mx, __longlong_as_double((long long)y));
+  if (alive) {
+    // every part of every slice by its own lane (the loads of a lane that walked a slice's parts went out one L2 round trip after the other)
+    if (tid < a.nslices) { s_res[tid] = DBL_MAX_D; s_mx[tid] = 0.0; }
+    __syncthreads();
+    const int nparts = a.nslices * parts_per_slice;
+    for (int c = tid; c < nparts; c += kThreads) {
+      const u64 x = __hip_atomic_load(&parts[2 * c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 y = __hip_atomic_load(&parts[2 * c + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (bit patterns of non-negative doubles order like the values: LDS atomics on the patterns)
+      atomicMin(reinterpret_cast<unsigned long long *>(&s_res[c / parts_per_slice]), (unsigned long long)x);
+      atomicMax(reinterpret_cast<unsigned long long *>(&s_mx[c / parts_per_slice]), (unsigned long long)y);
     }
-    s_res[tid] = mn; s_mx[tid] = mx;
-    if (isinf(mx)) atomicOr(&s_status, (unsigned)SERIES_INF);
+    __syncthreads();
+    if (tid < a.nslices && isinf(s_mx[tid])) atomicOr(&s_status, (unsigned)SERIES_INF);
   }
   __syncthreads();
   if (alive && tid == 0) {
@@ -147,15 +177,23 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
   }
   __syncthreads();
   const unsigned flagged = s_status;                             // (the same in every workgroup: computed from the same numbers)
+  ONE_STAMP(3);
 
-  // ---- 3: the cells of this workgroup: [lo, hi) of (step * cells + corner) -------------------------------------------------------------
+  // ---- 3: the cells: blocks b = w, w + nwg, ... of SUB x G consecutive (step * cells + corner) -----------------------------------------
   const u64 cells = m.core_cells, total_cs = cells * (u64)a.nsteps;
-  const u64 per_wg = (total_cs + nwg - 1) / nwg;
-  const u64 c_lo = (u64)w * per_wg < total_cs ? (u64)w * per_wg : total_cs, c_hi = c_lo + per_wg < total_cs ? c_lo + per_wg : total_cs;
+  constexpr unsigned BS = SUB * G;
+  const unsigned nblocks = (unsigned)((total_cs + BS - 1) / BS);
   unsigned tested = 0;
   bool overflow = false;
+  unsigned nown = 0;
   if (alive && !flagged) {
-    for (u64 base = c_lo; base < c_hi; base += SUB * G) {
+    // (a workgroup's blocks are CONSECUTIVE: dealt round-robin -- hits cluster, and a contiguous share leaves some workgroups with most of them --
+    // the workgroups finished closer together, 14 instead of 20 us of waiting at the barrier on woven 128^2 x 10, but each of them took longer
+    // over blocks that share no rows: 38 instead of 25 us)
+    const unsigned bpw = (nblocks + nwg - 1) / nwg;
+    for (unsigned blk = w * bpw; blk < nblocks && blk < (w + 1) * bpw; blk ++, nown ++) {
+      const u64 base = (u64)blk * BS, c_hi = base + BS < total_cs ? base + BS : total_cs;
+      const unsigned k_before = s_nkeys;                         // (workgroup-uniform: read behind the barrier that closed the block before)
       __syncthreads();                                           // (the staged vertices of the round before are no longer read)
       bool narrow;
       {
@@ -183,8 +221,11 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
         }
         narrow = __syncthreads_and(mine_narrow) != 0;
       }
-      // (statistics: the cells the mask cull of the kernel chain would have let through -- no strict sign bit common to all the vertices a
-      // scope reads; vertices outside the domain and non-finite ones are neutral, as their mask bytes are)
+      // the cell-level cull (what the mask cull of the kernel chain does): a corner none of whose scopes lacks a strict sign bit common to all the
+      // vertices it reads has no simplex to test -- vertices outside the domain and non-finite ones are neutral, as their mask bytes are.  The
+      // survivors of the SUB x G corners staged go on a list; the (corner, type) pairs below walk that list only
+      if (tid == 0) s_nsurv = 0;
+      __syncthreads();
       for (unsigned gi = tid; gi < (unsigned)(SUB * G); gi += kThreads) {
         const u64 cs = base + gi;
         if (cs >= c_hi) continue;
@@ -195,31 +236,38 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
           const unsigned b = (fl & (kInvalid | kNonFinite)) ? 0x3fu : (unsigned)(fl & 0x3f);
           if ((v >> ND) & 1) a1 &= b; else a0 &= b;
         }
-        if (((scope & FTKX_SCOPE_ORDINAL) && a0 == 0) || ((scope & FTKX_SCOPE_INTERVAL) && (a0 & a1) == 0)) atomicAdd(&s_cells, 1u);
+        const unsigned want = (((scope & FTKX_SCOPE_ORDINAL) && a0 == 0) ? 1u : 0u) | (((scope & FTKX_SCOPE_INTERVAL) && (a0 & a1) == 0) ? 2u : 0u);
+        if (want) s_surv[atomicAdd(&s_nsurv, 1u)] = (unsigned short)(gi | (want << 8));
       }
-      for (unsigned sub = 0; sub < (unsigned)SUB && base + sub * G < c_hi; sub ++) {
-        if (sub) __syncthreads();
-        const u64 sbase = base + sub * G;
+      __syncthreads();
+      const unsigned nsurv = s_nsurv;
+      if (tid == 0) s_cells += nsurv;
+      for (unsigned sb = 0; sb < nsurv; sb += G) {               // G surviving corners x NTYPES simplices over the lanes
+        if (sb) __syncthreads();
         for (int wb = 0; wb < G * NTYPES; wb += kThreads) {
           const int wi = wb + tid;
           if (wi >= G * NTYPES) continue;
-          const int gi = wi / NTYPES, type = wi % NTYPES;
-          const u64 cs = sbase + (u64)gi;
-          if (cs >= c_hi) continue;
+          const unsigned si = sb + (unsigned)(wi / NTYPES);
+          const int type = wi % NTYPES;
+          if (si >= nsurv) continue;
+          const unsigned ent = s_surv[si], gi = ent & 0xffu, want = ent >> 8;
+          if (!(fan.ordinal[type] ? (want & 1u) : (want & 2u))) continue;
+          const unsigned tab = s_tab[type];
+          unsigned char flags[N];
+          for (int i = 0; i < N; i ++) flags[i] = s_flag[gi][(tab >> (8 * i)) & 0xffu];
+          unsigned m_and = 0x3f, m_or = 0;
+          for (int i = 0; i < N; i ++) { m_and &= flags[i]; m_or |= flags[i]; }
+          if ((m_or & (kInvalid | kNonFinite)) || (m_and & 0x3f)) continue;      // (simplex_inside's own first test: before anything is fetched for it)
+          const u64 cs = base + gi;
           const u64 step = cs / cells, lin = cs - step * cells;
           const Fields &f = s_fields[step];
-          const bool wanted = fan.ordinal[type] ? (f.scope_mask & FTKX_SCOPE_ORDINAL) : (f.scope_mask & FTKX_SCOPE_INTERVAL);
-          if (!wanted) continue;
           int corner[N];
           core_corner<ND>(m, lin, corner);
           corner[ND] = f.t;
-          const unsigned tab = s_tab[type];
-          unsigned char flags[N];
           u64 X[N][ND];
           for (int i = 0; i < N; i ++) {
             const unsigned vm = (tab >> (8 * i)) & 0xffu;
-            flags[i] = s_flag[sub * G + gi][vm];
-            for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[sub * G + gi][vm][c];
+            for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[gi][vm][c];
           }
           int ids[N]; double mu[N]; bool presolved, degenerate = false;
           if (simplex_inside<ND>(m, f, 1, corner, tab, flags, X, tested, ids, mu, &presolved, narrow, &degenerate)) {
@@ -232,8 +280,9 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
         const unsigned ndeg = s_ndeg;
         for (unsigned it = tid; it < ndeg; it += kThreads) {       // degenerate values: the literal cascade, dealt over all lanes
           const unsigned item = s_deg[it];
-          const int gi = (int)(item >> 6), type = (int)(item & 63u);
-          const u64 cs = sbase + (u64)gi;
+          const unsigned gi = item >> 6;
+          const int type = (int)(item & 63u);
+          const u64 cs = base + gi;
           const u64 step = cs / cells, lin = cs - step * cells;
           const Fields &f = s_fields[step];
           int corner[N];
@@ -244,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
           int ids[N];
           for (int i = 0; i < N; i ++) {
             const unsigned vm = (tab >> (8 * i)) & 0xffu;
-            for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[sub * G + gi][vm][c];
+            for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[gi][vm][c];
             ids[i] = vertex_id<ND>(m, corner, vm);
           }
           if (sos_origin_in_simplex_resolved<ND>(X, ids)) {
@@ -255,88 +304,126 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
         __syncthreads();
         if (tid == 0) s_ndeg = 0;
       }
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned k_now = s_nkeys < KCAP ? s_nkeys : KCAP, kb = k_before < KCAP ? k_before : KCAP;
+        if (nown < kOneOwnBlocks) { s_bstart[nown] = kb; s_bcnt[nown] = k_now - kb; }
+        __hip_atomic_store(&bcount[blk], k_now - kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     __syncthreads();
-    overflow = s_nkeys > KCAP;
+    overflow = s_nkeys > KCAP || nown > kOneOwnBlocks;
     unsigned t_sum = tested;
     for (int o = 32; o > 0; o >>= 1) t_sum += __shfl_down(t_sum, o);
     if (lane == 0 && t_sum) atomicAdd(&s_tested, t_sum);
     __syncthreads();
   }
   if (tid == 0) {
-    __hip_atomic_store(&counts[w], (u64)(overflow ? KCAP : s_nkeys) | (overflow ? (1ull << 63) : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (overflow) __hip_atomic_store(a.scratch + ONE_OVER, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (s_tested) atomicAdd((unsigned long long *)(a.scratch + ONE_TESTED), (unsigned long long)s_tested);
     if (s_cells) atomicAdd((unsigned long long *)(a.scratch + ONE_CELLS), (unsigned long long)s_cells);
   }
+  ONE_STAMP(4);
   alive = alive && grid_barrier(bar + 1, nwg, bar + 3);
+  ONE_STAMP(5);
   if (!alive && tid == 0) s_status |= (unsigned)SERIES_OVERFLOW;      // (given up: the host sweeps the steps the usual way)
   __syncthreads();
 
   // ---- 4: offsets, ranks, records ------------------------------------------------------------------------------------------------------
-  if (alive && tid == 0) {
-    u64 run = 0, mine = 0;
-    bool any_over = false;
-    for (unsigned q = 0; q < nwg; q ++) {
-      const u64 cq = __hip_atomic_load(&counts[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (q == w) mine = run;
-      run += cq & ~(1ull << 63);
-      any_over = any_over || (cq >> 63);
+  if (alive) {
+    // offsets: every workgroup scans ALL the blocks' counts (a contiguous share per lane, the lanes' sums scanned across the workgroup) and keeps
+    // the exclusive prefix of its own blocks
+    const unsigned per = (nblocks + kThreads - 1) / kThreads, lo = (unsigned)tid * per, hi = lo + per < nblocks ? lo + per : nblocks;
+    unsigned sum = 0;
+    for (unsigned b = lo; b < hi; b ++) { const unsigned cb = __hip_atomic_load(&bcount[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_bc[b] = cb; sum += cb; }
+    unsigned incl = sum;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    unsigned before = 0;
+    for (int q = 0; q < wv; q ++) before += s_wsum[q];
+    s_lanepre[tid] = before + incl - sum;                        // the blocks before this lane's share
+    if (tid == kThreads - 1) {
+      s_total = (u64)(before + incl);
+      if ((u64)(before + incl) > a.capacity || __hip_atomic_load(a.scratch + ONE_OVER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&s_status, (unsigned)SERIES_OVERFLOW);
     }
-    s_base = mine; s_total = run;
-    if (any_over || run > a.capacity) s_status |= (unsigned)SERIES_OVERFLOW;
+    __syncthreads();
+    for (unsigned i = tid; i < nown && i < kOneOwnBlocks; i += kThreads) {
+      const unsigned b = w * ((nblocks + nwg - 1) / nwg) + i, ln = b / per;
+      unsigned off = s_lanepre[ln];
+      for (unsigned q = ln * per; q < b; q ++) off += s_bc[q];
+      s_boff[i] = off;
+    }
   }
   __syncthreads();
   const unsigned status = s_status;
   const unsigned nk = (status || overflow) ? 0u : s_nkeys;
   if (!status) {
-    for (unsigned i = tid; i < nk; i += kThreads) {               // rank = the number of smaller keys (keys are unique)
+    // a block's keys among themselves: rank = the number of smaller keys of the block (keys are unique), place = the block's offset + rank
+    for (unsigned i = tid; i < nk; i += kThreads) {
+      unsigned bi = 0;
+      while (bi + 1 < nown && s_bstart[bi + 1] <= i) bi ++;
+      const unsigned b0 = s_bstart[bi], bn = s_bcnt[bi];
       const u64 key = s_keys[i];
       unsigned r = 0;
-      for (unsigned q = 0; q < nk; q ++) r += s_keys[q] < key ? 1u : 0u;
-      s_sorted[r] = key;
+      for (unsigned q = b0; q < b0 + bn; q ++) r += s_keys[q] < key ? 1u : 0u;
+      s_sorted[b0 + r] = key;
+      s_pos[b0 + r] = s_boff[bi] + r;
     }
     __syncthreads();
-    for (unsigned p = tid; p < nk; p += kThreads) {
-      const u64 key = s_sorted[p];
-      const int type = (int)(key & 63u);
-      const u64 q = key >> 6, step = q / cells, lin = q - step * cells;
-      const Fields &f = s_fields[step];
-      int corner[N];
-      core_corner<ND>(m, lin, corner);
-      corner[ND] = f.t;
-      u64 X[N][ND];
-      int ids[N];
-      if (ND == 2 && m.compute_degrees)
-      for (int v = 0; v < N; v ++) {
-        const unsigned vm = fan.vert[type][v];
-        int vx[3] = {0, 0, 0};
-        for (int d = 0; d < ND; d ++) vx[d] = corner[d] + (int)((vm >> d) & 1u);
-        const int sl = (int)((vm >> ND) & 1u);
-        i64 qq[ND];
-        classify_vertex<ND>(m, f.S[sl], f.V[sl], f.factor, vx, qq);
-        for (int c = 0; c < ND; c ++) X[v][c] = (u64)qq[c];
-        ids[v] = vertex_id<ND>(m, corner, vm);
-      }
-      bool fragile = false;
-      double Jfrag[9];
-      ftkx_cp_t rec;
-      if (record_is_fast<ND>(m, f, corner)) make_record_impl<ND, true>(m, f, corner, type, X, ids, false, nullptr, &rec, &fragile, Jfrag);
-      else make_record_general<ND>(m, f, corner, type, X, ids, false, nullptr, &rec, &fragile, Jfrag);
-      const u64 at = s_base + p;
-      const u64 *src = reinterpret_cast<const u64 *>(&rec);
-      u64 *dst = reinterpret_cast<u64 *>(a.out + at);
+    const unsigned nk_pad = (nk + 63u) / 64u * 64u;
+    for (unsigned p = tid; p < nk_pad; p += kThreads) {           // (wave-uniform trip count: a wavefront's 64 positions are one contiguous run of the output)
+      if (p < nk) {
+        const u64 key = s_sorted[p];
+        const int type = (int)(key & 63u);
+        const u64 q = key >> 6, step = q / cells, lin = q - step * cells;
+        const Fields &f = s_fields[step];
+        int corner[N];
+        core_corner<ND>(m, lin, corner);
+        corner[ND] = f.t;
+        u64 X[N][ND];
+        int ids[N];
+        if (ND == 2 && m.compute_degrees)
+        for (int v = 0; v < N; v ++) {
+          const unsigned vm = fan.vert[type][v];
+          int vx[3] = {0, 0, 0};
+          for (int d = 0; d < ND; d ++) vx[d] = corner[d] + (int)((vm >> d) & 1u);
+          const int sl = (int)((vm >> ND) & 1u);
+          i64 qq[ND];
+          classify_vertex<ND>(m, f.S[sl], f.V[sl], f.factor, vx, qq);
+          for (int c = 0; c < ND; c ++) X[v][c] = (u64)qq[c];
+          ids[v] = vertex_id<ND>(m, corner, vm);
+        }
+        bool fragile = false;
+        double Jfrag[9];
+        ftkx_cp_t rec;
+        if (record_is_fast<ND>(m, f, corner)) make_record_impl<ND, true>(m, f, corner, type, X, ids, false, nullptr, &rec, &fragile, Jfrag);
+        else make_record_general<ND>(m, f, corner, type, X, ids, false, nullptr, &rec, &fragile, Jfrag);
+        const u64 *src = reinterpret_cast<const u64 *>(&rec);
 #pragma unroll
-      for (int k = 0; k < 9; k ++) __hip_atomic_store(dst + k, src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (ND == 3 && fragile) {
-        const u64 e = atomicAdd((unsigned long long *)(a.scratch + ONE_NFRAG), 1ull);
-        if (e < a.fragile_capacity) {
-          u64 *fd = a.fragile + e * 10;
-          fd[0] = at;
-          for (int k = 0; k < 9; k ++) fd[1 + k] = (u64)__double_as_longlong(Jfrag[k]);
+        for (int k = 0; k < 9; k ++) s_rec[wv][lane * 9 + k] = src[k];
+        if (ND == 3 && fragile) {
+          const u64 e = atomicAdd((unsigned long long *)(a.scratch + ONE_NFRAG), 1ull);
+          if (e < a.fragile_capacity) {
+            u64 *fd = a.fragile + e * 10;
+            fd[0] = (u64)s_pos[p];
+            for (int k = 0; k < 9; k ++) fd[1 + k] = (u64)__double_as_longlong(Jfrag[k]);
+          }
         }
       }
+      __builtin_amdgcn_wave_barrier();
+      const unsigned p0 = p - (unsigned)lane;
+      const unsigned nvalid = nk - p0 >= 64u ? 64u : (p0 < nk ? nk - p0 : 0u);
+      // (consecutive positions of a block are consecutive records of the output: consecutive lanes write consecutive words wherever the
+      // wavefront's 64 records do not cross into another block -- 512-byte pieces over PCIe, like series_record_kernel)
+      for (unsigned w8 = (unsigned)lane; w8 < nvalid * 9u; w8 += 64u) {
+        const unsigned ri = w8 / 9u, kk = w8 - ri * 9u;
+        __hip_atomic_store(reinterpret_cast<u64 *>(a.out + s_pos[p0 + ri]) + kk, s_rec[wv][w8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
+  ONE_STAMP(6);
   // ---- the workgroup that finishes last hands the pass over to the host ----
   __threadfence_system();
   __syncthreads();
@@ -369,9 +456,10 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
   }
   for (u64 wd = tid; wd < nf * 10; wd += kThreads) a.h_results[a.nwords + wd] = a.fragile[wd];
   if (tid < 4) bar[tid] = 0u;                                    // as found, for the next launch
-  if (tid == 4) { a.scratch[ONE_NFRAG] = 0ull; a.scratch[ONE_TESTED] = 0ull; a.scratch[ONE_CELLS] = 0ull; }
+  if (tid == 4) { a.scratch[ONE_NFRAG] = 0ull; a.scratch[ONE_TESTED] = 0ull; a.scratch[ONE_CELLS] = 0ull; a.scratch[ONE_OVER] = 0ull; }
   __threadfence_system();
   __syncthreads();
+  ONE_STAMP(7);
   if (tid == 0) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

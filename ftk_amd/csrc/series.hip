@@ -230,8 +230,15 @@ bool series_one_eligible(ftkx_ctx *c, const ftkx_series_pending &P, int n, size_
   const bool one_on = ftkx::env_hook("FTKX_SERIES_HOOKS", "one", 1) != 0;
   if (!one_on || dist || c->sr_one_off > 0) { if (c->sr_one_off > 0 && !dist) c->sr_one_off --; return false; }
   if (n > ftkx::kOneMaxSteps || k > (size_t)ftkx::kOneMaxSlices) return false;
-  // small: a few hundred corners per workgroup at most, and slices whose reduction is a few chunks' worth of reading
-  if (cells * (u64)n > (1ull << 21) || (u64)n_vertices(c) * (u64)k > (1ull << 22)) return false;
+  // small: at most kOneMaxBlocks staging batches of (step, corner) -- 128 corners a batch in 2D, 64 in 3D --, and slices whose reduction is a few
+  // chunks' worth of reading
+  const u64 bs = c->nd == 2 ? 128 : 64;
+  if ((cells * (u64)n + bs - 1) / bs > (u64)ftkx::kOneMaxBlocks || (u64)n_vertices(c) * (u64)k > (1ull << 22)) return false;
+  // ... and where it wins.  Measured (tools: in-kernel stamps, NOTES.md round 5): a device-wide barrier costs ~10 us on this part, two of them plus
+  // launch and hand-over ~35 us before any work; moving_extremum_3d 32^3 x 8 (sparse): 138 against 192 us for the kernel chain; woven 128^2 x 10
+  // (7 357 records, BASELINE config 1): 92-105 against 91 -- hit-dense series of that size stay with the chain, whose kernels overlap nothing
+  // either but whose ten launches cost no more than this kernel's barriers and its one wavefront per SIMD.  The last pass's record count decides.
+  if (cells * (u64)n > (1ull << 17) && c->stats.hits > 2048) return false;
   (void)P;
   return true;
 }
@@ -287,8 +294,8 @@ int series_plan_one(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const in
   }
   if (before && before->open && before->split) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->sr_buf[before->buf].ev_tail, 0));   // (its tail shares the fragile list)
   if (B.copy_out) { HIP_TRY(c, hipStreamWaitEvent(c->stream, B.ev_copied, 0)); B.copy_out = false; }
-  const u64 work = P.cells * (u64)n;
-  const int nwg = (int)std::max<u64>(8, std::min<u64>(256, (work + 255) / 256));
+  const u64 bs = c->nd == 2 ? 128 : 64, nblocks = (P.cells * (u64)n + bs - 1) / bs;
+  const int nwg = (int)std::max<u64>(8, std::min<u64>(256, (nblocks + 3) / 4));      // (four or more blocks per workgroup, kOneOwnBlocks at most)
   ev_begin(c, K_EXACT);
   ftkx::launch_series_one(m, a, nwg, c->stream);
   ev_end(c);

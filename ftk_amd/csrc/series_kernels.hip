@@ -263,11 +263,11 @@ extern "C" void ftkx_debug_small_stamps(unsigned long long *out, int reset)
 #endif
 
 template <int ND>
-__global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, const Mesh mc, const Fields *__restrict__ steps, int two_level,
-                                                                const u64 *__restrict__ refine, const u64 *__restrict__ list,
-                                                                ftkx_cp_t *__restrict__ out /* pinned */, u64 *__restrict__ results, size_t nwords,
-                                                                u64 *__restrict__ h_results /* pinned, coherent */, unsigned *flag, unsigned seq, unsigned *__restrict__ done,
-                                                                int report_decline /* nothing is queued behind this kernel: if it declines, it says so itself */)
+__device__ __forceinline__ void series_small_body(const Mesh &m, const Mesh &mc, const Fields *__restrict__ steps, int two_level,
+                                                  const u64 *__restrict__ refine, const u64 *__restrict__ list,
+                                                  ftkx_cp_t *__restrict__ out /* pinned */, u64 *__restrict__ results, size_t nwords,
+                                                  u64 *__restrict__ h_results /* pinned, coherent */, unsigned *flag, unsigned seq, unsigned *__restrict__ done,
+                                                  int report_decline /* nothing is queued behind this kernel: if it declines, it says so itself */)
 {
   constexpr int N = ND + 1, NVC = 1 << N, G = kThreads / NVC, NTYPES = fan_table<N>::NTYPES;
   constexpr unsigned LIST_CAP = kSmallPer * 128, PASS_CAP = 2048;   // a coarse cell is 8 x u_rows corners, u_rows <= 16 (mask_summary_rows)
@@ -687,6 +687,12 @@ __global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, co
     __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+
+template <int ND>
+__global__ __launch_bounds__(kThreads) void series_small_kernel(const Mesh m, const Mesh mc, const Fields *__restrict__ steps, int two_level, const u64 *__restrict__ refine,
+                                                                const u64 *__restrict__ list, ftkx_cp_t *__restrict__ out, u64 *__restrict__ results, size_t nwords,
+                                                                u64 *__restrict__ h_results, unsigned *flag, unsigned seq, unsigned *__restrict__ done, int report_decline)
+{ series_small_body<ND>(m, mc, steps, two_level, refine, list, out, results, nwords, h_results, flag, seq, done, report_decline); }
 
 // ---- finish: counters, factors and reductions to the host, then the flag --------------------------------------------------------------
 // One workgroup.  Runs behind the record kernel (a kernel boundary: its stores have been released); copies the device results block

@@ -185,7 +185,7 @@ enum { SR_STATUS = 0, SR_RUNNING = 1, SR_NHITS = 2, SR_NFRAGILE = 3, SR_SPARE = 
 enum { DB_WORDS = 0 /* mask words compacted into the outgoing message */, DB_BAD = 1 /* the incoming mask message did not fit / did not match */,
        DB_DONE = 2 /* workgroups of the export kernel that have finished */, DB_BAD2 = 3 /* the incoming message named a word outside the mask array */, DB_PSEUDO = 8, DB_N = 16 };
 // the one-launch pass for small series (one_kernel.hip): everything the kernel needs comes by value, in its arguments
-constexpr int kOneMaxSlices = 48, kOneMaxSteps = 47, kOneParts = 8;
+constexpr int kOneMaxSlices = 48, kOneMaxSteps = 47, kOneParts = 32;      // (parts: at most; a slice's reduction is cut into min(32, ceil(workgroups / slices)) chunks)
 constexpr unsigned kOneKeys = 1024;             // order keys a workgroup parks in LDS
 struct OneSlice { const double *S, *V, *J; int t, pad; };
 struct OneStep { int t, scope, slice0, slice1, last, pad; };
@@ -199,8 +199,10 @@ struct OneArgs {
   u64 *results, *h_results; size_t nwords; unsigned *flag; unsigned seq;
   ftkx_cp_t *out; u64 capacity; u64 *fragile; u64 fragile_capacity;
 };
-enum { ONE_BAR = 0 /* three 32-bit arrival counters */, ONE_TESTED = 2, ONE_NFRAG = 3, ONE_CELLS = 4, ONE_COUNTS = 8 /* one word per workgroup */, ONE_PARTS = 8 + 256,
-       ONE_WORDS = 8 + 256 + 2 * kOneMaxSlices * kOneParts };
+constexpr unsigned kOneMaxBlocks = 8192;        // blocks of (step, corner) a pass is cut into (a block = one staging batch of the kernel), dealt to the workgroups round-robin
+constexpr unsigned kOneOwnBlocks = 64;          // ... of which a workgroup takes at most this many
+enum { ONE_BAR = 0 /* four 32-bit words: two barriers, arrivals at the exit, "somebody gave up" */, ONE_TESTED = 2, ONE_NFRAG = 3, ONE_CELLS = 4, ONE_OVER = 5,
+       ONE_BCOUNT = 8 /* one 32-bit count per block */, ONE_PARTS = 8 + kOneMaxBlocks / 2, ONE_WORDS = 8 + kOneMaxBlocks / 2 + 2 * kOneMaxSlices * kOneParts };
 constexpr int kDistContrib = 4;            // words a rank contributes to the all_gather: slab min resolution, slab max |v|, the same of its FIRST slice
 
 }  // namespace ftkx
