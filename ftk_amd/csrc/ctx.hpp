@@ -53,7 +53,6 @@ void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u6
 void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st,
                          const void *desc_src = nullptr, void *desc_dst = nullptr, size_t desc_bytes = 0, unsigned *fetched = nullptr, unsigned fetched_val = 0);
 void launch_series_one(const Mesh &m, const OneArgs &a, int nwg, hipStream_t st);
-void launch_series_tail_begin(u64 *counters, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st);
 void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,
                            double safe_m, u64 *results, u64 *counters, hipStream_t st);
 void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff, u64 *sorted, u64 *results, hipStream_t st);
@@ -146,11 +145,7 @@ struct ftkx_series_pending {
   const u64 *running_from = nullptr;   // a results block on the device whose SR_RUNNING word this pass continues from (the pass before it, or a slab pass's stub)
   bool pipelined = false;
   bool refined = false;             // the refine kernel has been queued already (a slab pass lists the halo's cells from its output)
-  // split pass (series.hip, "the tail next to the next mask kernel"): begin + masks on the context's stream, the tail -- counters, cull + factors,
-  // fused tail -- on the tail stream behind an event; the pass queued behind it starts its mask kernel when THIS pass's cull is through
-  bool split = false;
   bool one = false;                 // the one-launch pass for small series (one_kernel.hip)
-  std::vector<std::pair<unsigned char *, unsigned char *>> retired;   // (M, U) arrays this pass still reads, replaced in their slices by the pass queued behind it
   // slab pass (ftkx_series_dist_*): one rank's part of a series cut into timestep slabs, queued in stages with the caller's collectives between them
   bool dist = false;
   int dist_stage = 0;               // 1 begun (masks, contribution, outgoing masks), 2 culled (request written), 3 served (reply written), 4 finished = open
@@ -169,7 +164,6 @@ struct ftkx_series_buffers {
   ftkx_cp_t *d_out = nullptr; size_t d_out_cap = 0;   // device: the records of a pass whose way over PCIe is left to the copy kernel on its own stream
   unsigned *copy_done = nullptr;                       // that kernel's workgroup counter
   hipEvent_t ev_copied = nullptr, ev_export = nullptr;
-  hipEvent_t ev_masks = nullptr, ev_cull = nullptr, ev_tail = nullptr;   // split pass: masks done (stream), cull done / tail done (tail stream)
   u64 *red = nullptr; size_t red_cap = 0;             // the reduction slots of this pass's mask jobs (128 words per slice): its own, the next pass's begin kernel must not wipe them
   bool copy_out = false;                               // a copy has been queued since the buffers were last used: the next record kernel waits for it
   void *h_desc = nullptr, *d_desc = nullptr; size_t desc_cap = 0;
@@ -250,7 +244,7 @@ struct ftkx_ctx {
   // cull is queued, cleared whenever the host-driven batch takes them (series.hip: a pass whose fused tail declined may queue the rest of
   // its chain only while they are still its own)
   unsigned long long sr_pass_uid = 0, sr_lists_owner = 0;
-  hipStream_t sr_copy_stream = nullptr, sr_fetch_stream = nullptr, sr_tail_stream = nullptr;
+  hipStream_t sr_copy_stream = nullptr, sr_fetch_stream = nullptr;
   int sr_one_off = 0;                  // passes for which the one-launch form is not tried (it declined a moment ago)
   u64 *sr_one_scratch = nullptr;       // the one-launch pass's barrier counters, partial reductions and per-workgroup counts (ONE_WORDS)
   unsigned *sr_fetch_flag = nullptr;   // device: [0] the number of the last pass whose descriptors have been fetched (series_begin_kernel), [1] its arrival counter

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void series_begin_kernel(u64 *counters, u64 *r
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   // (the pass's descriptors, pinned host -> device: the first workgroups, so that the read over PCIe is under way at once)
   for (size_t w = i; w < desc_words; w += (size_t)gridDim.x * 256) desc_dst[w] = desc_src[w];
-  if (counters && i < (size_t)CNT_N) counters[i] = 0ull;      // (nullptr: a split pass zeroes them on its tail stream -- series.hip)
+  if (i < (size_t)CNT_N) counters[i] = 0ull;
   if (i < nslots) { red[2 * i] = 0x7fefffffffffffffull; red[2 * i + 1] = 0ull; }   // {min = DBL_MAX, max = 0} as bit patterns
   if (i < nbins) hist[i] = 0u;
   if (i < nresults) results[i] = 0ull;
@@ -36,17 +36,6 @@ __global__ __launch_bounds__(256) void series_begin_kernel(u64 *counters, u64 *r
       __hip_atomic_store(&fetched[0], fetched_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-}
-
-// a split pass (series.hip): what the pass's TAIL owns -- the counters and the histogram -- zeroed on the tail stream, behind the tail of the pass before it
-// -- and the pass's results block: the pass before this one may still read the block's last contents (it is the block of the pass before
-// THAT, whose running minimum and reductions it continues from) until its own tail is through, which on the tail stream it is
-__global__ __launch_bounds__(256) void series_tail_begin_kernel(u64 *counters, unsigned *hist, size_t nbins, u64 *results, size_t nresults)
-{
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < (size_t)CNT_N) counters[i] = 0ull;
-  if (i < nbins) hist[i] = 0u;
-  if (i < nresults) results[i] = 0ull;
 }
 
 // ---- the sticky factor: series_device.hpp ---------------------------------------------------------------------------------------------
@@ -793,13 +782,6 @@ void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist,
   if (desc_src && n < 1024) n = 1024;
   hipLaunchKernelGGL(series_begin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, counters, red, nslots, hist, nbins, results, nresults,
                      (const u64 *)desc_src, (u64 *)desc_dst, desc_src ? desc_bytes / 8 : (size_t)0, fetched, fetched_val);
-}
-
-void launch_series_tail_begin(u64 *counters, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st)
-{
-  size_t n = nbins > (size_t)CNT_N ? nbins : (size_t)CNT_N;
-  n = n > nresults ? n : nresults;
-  hipLaunchKernelGGL(series_tail_begin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, counters, hist, nbins, results, nresults);
 }
 
 void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,
