@@ -303,7 +303,7 @@ def streaming_tracker(nd, case, dims, nt_run, torch, dev, ftk_amd, synthetic, ho
     hipMemcpyAsync."""
     T = ftk_amd.CriticalPointTracker3DRegular if nd == 3 else ftk_amd.CriticalPointTracker2DRegular
 
-    def make(deferred=False):
+    def make(deferred=False, depth=1):
         tr = T()
         tr.set_scalar_field_source(ftk_amd.SOURCE_GIVEN); tr.set_vector_field_source(ftk_amd.SOURCE_DERIVED)
         tr.set_jacobian_field_source(ftk_amd.SOURCE_DERIVED); tr.set_jacobian_symmetric(True)
@@ -311,7 +311,7 @@ def streaming_tracker(nd, case, dims, nt_run, torch, dev, ftk_amd, synthetic, ho
         tr.set_tag_mode(ftk_amd.TAG_EXACT64)
         tr.initialize()
         if deferred:
-            tr.set_deferred_collection(True)
+            tr.set_deferred_collection(True, depth)
         return tr
 
     def drive(tr, snaps):
@@ -350,6 +350,20 @@ def streaming_tracker(nd, case, dims, nt_run, torch, dev, ftk_amd, synthetic, ho
     out["device_resident_deferred"] = {"timesteps": nt_run, "ms_per_step": best / nt_run * 1e3, "records": int(nrec2),
                                        "note": "set_deferred_collection(True): step t+1's sweep is queued (continuing on the device from step t's running minimum) before "
                                                "step t's records are collected; same records, visible one step later; sync() inside the timed series; best of 3"}
+    best = None
+    for rep in range(3):
+        tr = make(deferred=True, depth=4)
+        t0 = time.perf_counter()
+        drive(tr, dev_snaps)
+        tr.sync()
+        dt = time.perf_counter() - t0
+        nrec3 = len(tr.get_critical_points()[0])
+        tr.close()
+        best = dt if best is None or dt < best else best
+    out["device_resident_deferred_4"] = {"timesteps": nt_run, "ms_per_step": best / nt_run * 1e3, "records": int(nrec3),
+                                         "note": "set_deferred_collection(True, 4): the same per-step calls; the sweeps of four consecutive steps are queued as ONE pass (one mask "
+                                                 "launch, one tail) when the fourth is advanced, two passes in flight; same records, visible up to 2 x 4 steps later; sync() inside "
+                                                 "the timed series; best of 3"}
     # host-fed: numpy arrays in pageable memory, like an ndarray<double> of the reference
     h = min(host_steps, nt_run)
     host_snaps = [dev_snaps[t].cpu().numpy() for t in range(h)]
@@ -454,8 +468,8 @@ def launch_ranks(args, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default=os.environ.get("FTKX_BENCH_CONFIG", "c4"), choices=sorted(CONFIGS))
     ap.add_argument("--exact-only", action="store_true", help="disable the sign cull (every simplex takes the integer test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -981,7 +995,7 @@ def job(args, env):
             slices.clear(); halo_buf = None
             torch.cuda.empty_cache()
             try:
-                out["streaming_tracker"] = streaming_tracker(nd, case, dims, min(nt, 12), torch, dev, ftk_amd, synthetic)
+                out["streaming_tracker"] = streaming_tracker(nd, case, dims, min(nt, 32), torch, dev, ftk_amd, synthetic)
             except Exception as e:   # noqa: BLE001
                 out["streaming_tracker"] = {"error": repr(e)}
         if not multi and not light and not args.no_streaming_tracker and not args.exact_only:

@@ -613,11 +613,12 @@ class _TrackerRegular:
     def set_tag_mode(self, m): self._flags["tag_mode"] = int(m)
     def set_stream(self, ptr): self._ck(self._L.ftkx_tracker_set_stream(self._h, C.c_void_p(ptr)))
     def set_current_timestep(self, t): self._ck(self._L.ftkx_tracker_set_current_timestep(self._h, int(t)))
-    def set_deferred_collection(self, b):
-        """the sweep of step t + 1 is queued before the records of step t are collected (ftkx_tracker.hh); pushed device tensors are kept alive
-        one step longer"""
+    def set_deferred_collection(self, b, depth=1):
+        """the sweep of step t + 1 is queued before the records of step t are collected (ftkx_tracker.hh); depth > 1: the sweeps of `depth`
+        consecutive steps are queued as one pass.  Pushed device tensors are kept alive until their batch has been collected"""
         self._deferred = bool(b)
-        self._ck(self._L.ftkx_tracker_set_deferred_collection(self._h, int(bool(b))))
+        self._deferred_depth = max(1, int(depth)) if b else 1
+        self._ck(self._L.ftkx_tracker_set_deferred_collection(self._h, self._deferred_depth if b else 0))
 
     # several ranks behind the tracker (include/ftkx_tracker.hh: slab mode): this rank's tracker takes the snapshots of its timestep slab
     # (tslab.slab_range), sweeps it as one device-driven pass, finalize() gathers the points on rank 0.  Pushed device tensors are kept alive.
@@ -667,7 +668,7 @@ class _TrackerRegular:
         self._ck(self._L.ftkx_tracker_advance_timestep(self._h))
         if hasattr(self, "_slab_keep"):             # slab mode: the snapshots stay resident until the slab's pass has run
             self._slab_keep += self._keep
-        self._keep = self._keep[-(3 if getattr(self, "_deferred", False) else 2):]
+        self._keep = self._keep[-((2 * getattr(self, "_deferred_depth", 1) + 2) if getattr(self, "_deferred", False) else 2):]
 
     def update_timestep(self): self._ck(self._L.ftkx_tracker_update_timestep(self._h))
     def sync(self): self._ck(self._L.ftkx_tracker_sync(self._h))

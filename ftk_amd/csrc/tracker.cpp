@@ -244,6 +244,7 @@ void critical_point_tracker_regular::wait_devices() const
     multi->wait_all();
     multi->rethrow();
   }
+  if (!batch_ts.empty()) submit_batch();                       // deferred collection in batches: the steps recorded since the last full batch
   while (!open_steps.empty()) collect_open_step();             // deferred collection: what is still out
 }
 
@@ -265,12 +266,36 @@ void critical_point_tracker_regular::collect_open_step() const
     ftkx_last_error(ctx, why, sizeof(why));
     open_steps.clear();
     (void)ftkx_sweep_series_abort(ctx);
+    batch_ts.clear(); batch_scopes.clear();
+    for (int d : batch_drops) (void)ftkx_drop_slice(ctx, d);
+    batch_drops.clear();
     throw ftkx_error(rc, why);
   }
   self->vector_field_resolution = res;
   self->vector_field_scaling_factor = f;
-  self->take_records(recs, n, t);
+  if (t >= 0) self->take_records(recs, n, t);
+  else for (size_t i = 0; i < n;) {                             // a batch: runs of one timestep (the records are ordered by tag, not by step)
+    size_t j = i + 1;
+    while (j < n && ftkx_cp_timestep(&recs[j]) == ftkx_cp_timestep(&recs[i])) j ++;
+    self->take_records(recs + i, j - i, ftkx_cp_timestep(&recs[i]));
+    i = j;
+  }
   check(ftkx_get_stats(ctx, &self->last_stats));
+}
+
+// deferred collection in batches: the recorded steps as one pass (continuing, on the device, from the pass queued before it if that one is
+// still out); the snapshots popped since the batch began are dropped behind it -- their buffers are reused in stream order
+void critical_point_tracker_regular::submit_batch() const
+{
+  critical_point_tracker_regular *self = const_cast<critical_point_tracker_regular *>(this);
+  const bool chained = !open_steps.empty();
+  std::vector<int> ts, scopes, drops;
+  ts.swap(batch_ts); scopes.swap(batch_scopes); drops.swap(batch_drops);
+  int rc = ftkx_sweep_series_submit(ctx, ts.data(), scopes.data(), (int)ts.size(), chained ? nullptr : &self->vector_field_resolution);
+  if (rc == FTKX_OK) open_steps.push_back(-1);
+  for (int t : drops) { const int rc2 = ftkx_drop_slice(ctx, t); if (rc == FTKX_OK) rc = rc2; }
+  check(rc);
+  if (open_steps.size() >= 2) collect_open_step();
 }
 
 void critical_point_tracker_regular::sync() const
@@ -472,7 +497,8 @@ bool critical_point_tracker_regular::pop_field_data_snapshot()
       multi->post(d, [=] { const int rc = ftkx_drop_slice(c, t); if (rc) { char buf[512]; ftkx_last_error(c, buf, sizeof(buf)); throw ftkx_error(rc, buf); } });
     }
     multi->resident.erase(t);
-  } else check(ftkx_drop_slice(ctx, t));
+  } else if (!batch_ts.empty() && t >= batch_ts.front()) batch_drops.push_back(t);      // (a recorded step still reads it: dropped behind its batch)
+  else check(ftkx_drop_slice(ctx, t));
   field_data_snapshots.erase(field_data_snapshots.begin());
   return true;
 }
@@ -530,12 +556,18 @@ void critical_point_tracker_regular::update_timestep()
     if (deferred_collection && !enable_streaming_trajectories && field_data_snapshots.size() <= 2 && field_data_snapshots.front() == current_timestep) {
       // queue this step (continuing, on the device, from the running minimum of the step queued before it if that one is still out),
       // then collect the step before it
+      if (deferred_depth > 1) {                 // batches: recorded; queued with the batch's last step (submit_batch)
+        batch_ts.push_back(current_timestep); batch_scopes.push_back(scope);
+        if ((int)batch_ts.size() >= deferred_depth) submit_batch();
+        return;
+      }
       const bool chained = !open_steps.empty();
       check(ftkx_sweep_series_submit(ctx, &current_timestep, &scope, 1, chained ? nullptr : &vector_field_resolution));
       open_steps.push_back(current_timestep);
       if (open_steps.size() >= 2) collect_open_step();
       return;
     }
+    if (!batch_ts.empty()) submit_batch();
     while (!open_steps.empty()) collect_open_step();
     if (field_data_snapshots.size() <= 2 && field_data_snapshots.front() == current_timestep) {
       // The device-driven pass (ftkx_sweep_series): the newly arrived snapshot's masks and reduction, the sticky factor (formed on the
@@ -931,7 +963,7 @@ int ftkx_tracker_set_flags(ftkx_tracker *h, int robust, int use_tf, unsigned tf,
   });
 }
 int ftkx_tracker_set_stream(ftkx_tracker *h, void *s) { return guarded(h, [&] { h->t->set_stream(s); }); }
-int ftkx_tracker_set_deferred_collection(ftkx_tracker *h, int on) { return guarded(h, [&] { h->t->set_deferred_collection(on != 0); }); }
+int ftkx_tracker_set_deferred_collection(ftkx_tracker *h, int on) { return guarded(h, [&] { h->t->set_deferred_collection(on != 0, on); }); }
 int ftkx_tracker_set_communicator(ftkx_tracker *h, void *comm, int rank, int nranks, int nt) { return guarded(h, [&] { h->t->set_communicator(comm, rank, nranks, nt); }); }
 int ftkx_tracker_set_slab_transport(ftkx_tracker *h, const ftkx_slab_transport *tr, int rank, int nranks, int nt)
 { return guarded(h, [&] { if (!tr) throw ftkx::ftkx_error(FTKX_E_INVALID, "null transport"); h->t->set_slab_transport(*tr, rank, nranks, nt); }); }

@@ -140,7 +140,11 @@ public:
   // host takes step t's records.  Same records, factors and statistics; they become visible one step later, and every accessor,
   // sync() and finalize() collect what is still out first.  A snapshot pushed as a DEVICE pointer is borrowed, not copied: with this on
   // it must stay valid until the step AFTER the one that pops it has been advanced (or sync() has been called).
-  void set_deferred_collection(bool b) { sync(); deferred_collection = b; }
+  // depth > 1: the sweeps of `depth` consecutive steps are queued as ONE device-driven pass (ftkx_sweep_series_submit with n = depth: one
+  // mask launch over the batch's new snapshots, one tail) when the last of them is advanced -- the latency chain behind the mask kernel
+  // is paid once per batch; a popped snapshot stays resident (and a borrowed device pointer must stay valid) until its batch has been
+  // collected: 2 * depth + 1 steps at most.  Same records, factors and statistics; sync(), finalize() and every accessor submit a partial batch.
+  void set_deferred_collection(bool b, int depth = 1) { sync(); deferred_collection = b; deferred_depth = depth > 1 ? depth : 1; }
   // Several RANKS behind the tracker -- one process per GPU, or one tracker per device and thread in one process.  The reference keeps an
   // MPI communicator on the filter and distributes inside the tracker (regular_tracker.hh:127-149), gathering the discrete points on the
   // root in front of pass 2 (critical_point_tracker.hh:689).  Here the series of `nt` timesteps is cut in TIME (include/ftkx_slab.h): this
@@ -218,6 +222,9 @@ protected:
   bool deferred_collection = false;
   mutable std::vector<int> open_steps;                      // deferred collection: the timesteps of the sweeps that are queued and not yet collected (at most two)
   void collect_open_step() const;
+  int deferred_depth = 1;
+  mutable std::vector<int> batch_ts, batch_scopes, batch_drops;    // deferred collection in batches: the steps recorded and not yet queued; the snapshots popped meanwhile
+  void submit_batch() const;
   ftkx_online_tracer *online = nullptr;
   void grow();                                                 // 2d:288-322: trace_critical_points_online on the points found since the last call
   bool use_type_filter = false;
@@ -300,7 +307,7 @@ int  ftkx_tracker_set_sources(ftkx_tracker *, int scalar, int vector, int jacobi
 int  ftkx_tracker_set_flags(ftkx_tracker *, int robust, int use_type_filter, unsigned type_filter, int compute_degrees, int exact_only, int tag_mode);
 int  ftkx_tracker_set_stream(ftkx_tracker *, void *hip_stream);
 int  ftkx_tracker_set_current_timestep(ftkx_tracker *, int t);
-int  ftkx_tracker_set_deferred_collection(ftkx_tracker *, int on);   /* not in the reference: see critical_point_tracker_regular::set_deferred_collection */
+int  ftkx_tracker_set_deferred_collection(ftkx_tracker *, int on);   /* not in the reference: see critical_point_tracker_regular::set_deferred_collection; on > 1: batches of `on` steps */
 /* several ranks behind the tracker (critical_point_tracker_regular::set_communicator / set_slab_transport / set_slab_hub): this rank's
  * tracker takes the snapshots of its timestep slab, sweeps it as one device-driven pass, and ftkx_tracker_finalize gathers the points on rank 0 */
 int  ftkx_tracker_set_communicator(ftkx_tracker *, void *nccl_comm, int rank, int nranks, int nt);

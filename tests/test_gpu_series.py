@@ -426,6 +426,53 @@ def test_tracker_with_deferred_collection(gpu, name, each_step):
     assert_records_equal(recs, g["records"], coord_tol=0.0, what=f"{name} deferred")
 
 
+@pytest.mark.parametrize("depth", [2, 3, 5])
+@pytest.mark.parametrize("name", ["woven_128x128x10", "woven_31x37x32", "double_gyre_64x32x50", "merger_2d_32x32x100", "moving_extremum_3d_21x21x21x32",
+                                  "adversarial_3d_scalar_9x9x9x4", "adversarial_3d_vector_8x8x8x3"])
+def test_tracker_with_deferred_batches(gpu, name, depth):
+    """set_deferred_collection(True, depth): the sweeps of `depth` consecutive update_timestep() calls go out as ONE device-driven pass (the
+    snapshots popped meanwhile stay resident until it has been queued), two such passes in flight; a series whose length is not a multiple
+    of the depth ends in a partial batch.  Same records (each with the timestep of ITS step) and the same final factor as the fixture."""
+    from gpu_common import run_tracker
+    g = load_golden(name)
+    if not _plain(g):
+        pytest.skip("physical coordinates are set on the tracker")
+    out = run_tracker(g["steps"], g["nd"], g["nv"], robust=g["robust"], type_filter=g["type_filter"], compute_degrees=g["degrees"],
+                      device=True, deferred=True, depth=depth, factor_each_step=False)
+    recs, factors = out[0], out[1]
+    assert int(factors[-1]) == int(g["factors"][-1])
+    assert_records_equal(recs, g["records"], coord_tol=0.0, what=f"{name} deferred in batches of {depth}")
+
+
+def test_tracker_with_deferred_batches_looked_at_midway(gpu):
+    """a getter between the steps of a batch submits the partial batch and collects what is out: the factor sequence read every OTHER step is the fixture's"""
+    from gpu_common import run_tracker
+    import ftk_amd, torch
+    g = load_golden("double_gyre_64x32x50")
+    tr = ftk_amd.CriticalPointTracker2DRegular()
+    D = [g["steps"][0].shape[1], g["steps"][0].shape[0]]
+    tr.set_scalar_field_source(ftk_amd.SOURCE_NONE); tr.set_vector_field_source(ftk_amd.SOURCE_GIVEN)
+    tr.set_jacobian_field_source(ftk_amd.SOURCE_DERIVED); tr.set_jacobian_symmetric(False)
+    tr.set_domain([1, 1], [d - 2 for d in D]); tr.set_array_domain([0, 0], D)
+    tr.initialize()
+    tr.set_deferred_collection(True, 4)
+    seen = {}
+    for k, a in enumerate(g["steps"]):
+        tr.push_vector_field_snapshot(torch.from_numpy(np.ascontiguousarray(a)).cuda())
+        if k:
+            tr.advance_timestep()
+            if k % 2 == 0:
+                seen[k - 1] = tr.get_vector_field_scaling_factor()
+    tr.update_timestep()
+    seen[len(g["steps"]) - 1] = tr.get_vector_field_scaling_factor()
+    recs, o, ts = tr.get_critical_points()
+    tr.close()
+    for k, f in seen.items():
+        assert int(f) == int(g["factors"][k]), (k, f, g["factors"][k])
+    assert len(recs) == len(g["records"]) and np.array_equal(np.sort(recs["tag"]), np.sort(g["records"]["tag"]))
+    assert np.array_equal(ts[np.argsort(recs["tag"], kind="stable")], g["records"]["timestep"][np.argsort(g["records"]["tag"], kind="stable")])
+
+
 def test_pipelined_records_through_the_copy_engine(gpu):
     """more than 4096 records per pass: from the second pipelined pass on the record kernel leaves them in device memory and the copy
     engine brings them over while the next pass runs; records and factors as ftkx_sweep_series returns them"""
