@@ -1291,6 +1291,166 @@ __global__ __launch_bounds__((ND == 2 || (PD == 1 && RY <= 4)) ? 768 : 512) void
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 2D scalar input, round 5: the arithmetic of mask_march4_kernel<2, false, 1, 8> by a wavefront that MARCHES DOWN y.
+// In 2D that kernel's wavefront takes 8 rows x 128 columns -- 8 KB of input -- and leaves: ten row loads issued at once and all of them
+// waited for before the first row is classified, one set-up and one pair of reduction atomics per 8 KB.  Here a wavefront takes `groups`
+// consecutive groups of 8 rows of its 128 columns: the set-up once, the loads of group g + 1 on their way while group g is classified (two
+// register sets that rotate by name).  Faster on WIDE slices only (launch_masks_impl has the numbers): most of the scalar instructions of
+// either kernel are the per-row uniform tests inside the step, not the set-up.
+// Same mask words, summaries and reductions as the kernel above, bit for bit (tests/test_gpu_properties.py::test_mask_kernel_generations_agree
+// runs them against each other: FTKX_MASK_PLAN rows=0 takes the kernel above).
+// ---------------------------------------------------------------------------------------------------------------
+template <int RY>
+__global__ __launch_bounds__(256) void mask_rows2_kernel(const Mesh m, const MaskJob *__restrict__ jobs, int groups, int swizzle)
+{
+  static_assert(RY == 8, "two 8 x 4 blocks per group; the edge register holds 2 RY <= 16 values");
+  const int DW = m.ext_sz[0], DH = m.ext_sz[1], P = m.mask_pitch;
+  unsigned bx, by, bz;
+  remap_block(swizzle, bx, by, bz);
+  const MaskJob job = jobs[bz];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wpb = blockDim.x >> 6;
+  const int i0 = (int)bx * 128 + 2 * lane;                     // this lane's columns i0, i0 + 1
+  const int jbase = ((int)by * wpb + wv) * RY * groups;        // this wavefront's rows: jbase .. jend - 1
+  if (jbase >= DH) return;
+  const int jend = jbase + RY * groups < DH ? jbase + RY * groups : DH;
+  const unsigned sy = (unsigned)DW * 8u;
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void *)job.S, 0, (int)(sy * (unsigned)DH), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)job.M, 0, (int)((unsigned)P * (unsigned)DH), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)job.U, 0, (int)((unsigned)m.u_pitch * (unsigned)DH), 0x00020000);
+  const bool have_u = job.U != nullptr;
+  const bool block4 = have_u && m.u_rows == 4;                 // (wave-uniform) one summary byte per 8 x 4 block
+  const double thr = job.threshold;
+  const int ic = i0 < DW ? i0 : DW - 2;                        // clamped (even) column pair: lanes beyond the row load valid memory
+  const unsigned cb = (unsigned)ic * 8u;
+  // edge register: lane r < RY fetches the left neighbour of row r's first column, lane 64 - RY + r the right neighbour of its last
+  const int t0c = (int)bx * 128;
+  const int xr = lane < RY ? lane : (lane >= 64 - RY ? lane - (64 - RY) : -1);
+  const unsigned xcol8 = (unsigned)(lane < RY ? (t0c > 0 ? t0c - 1 : 0) : (t0c + 128 < DW ? t0c + 128 : DW - 1)) * 8u;
+  unsigned xkeep = 0, xneutral = 0;                            // per column: byte c of the pair
+  for (int c = 0; c < 2; c ++) {
+    const int i = i0 + c;
+    const bool x_dom = i < DW && i + m.ext_st[0] >= m.dom_lb[0] && i + m.ext_st[0] <= m.dom_ub[0];
+    xkeep |= 0x3fu << (8 * c);
+    if (!x_dom) xneutral |= 0x3fu << (8 * c);
+  }
+  const bool in_row = i0 < DW;
+  const unsigned mcol = (unsigned)i0, ucol = (unsigned)(i0 >> 3);
+  const bool u_lane = (lane & 3) == 0 && in_row;
+  double red_mn = DBL_MAX;
+  double acc0 = 0.0, acc1 = 0.0, accy0 = 0.0, accy1 = 0.0;     // max |dx|, max |dy| per column, unscaled (mask_march4_kernel: LEAN)
+  const unsigned cmask = in_row ? (xkeep & 0x0303u) : 0u;
+  const double tbig = job.big;
+  const bool per_vertex_rule = job.big < HUGE_VAL;
+  const double fx2 = (double)(DW - 1), fy2 = (double)(DH - 1);
+  const double tpx = job.tx > 0.0 ? job.tx : exact_threshold(thr, fx2), tpy = job.ty > 0.0 ? job.ty : exact_threshold(thr, fy2);
+
+  struct Rows { unsigned roff[RY + 2]; unsigned row_dom, row_ok, xoff, cbv; int j0; };
+  // a group's wave-uniform row offsets and flags; a group past the wavefront's rows loads nothing (offsets beyond num_records: answered with 0
+  // without touching memory -- no branch around a load) and stores nothing
+  auto setup = [&](Rows &R, int j0) {
+    R.j0 = j0;
+    const bool live = j0 < jend;
+    R.row_dom = 0; R.row_ok = 0;
+    for (int r = 0; r < RY + 2; r ++) {
+      const int j = j0 + r - 1;
+      R.roff[r] = sy * (unsigned)clampi(j, 0, DH - 1);
+      if (r >= 1 && r <= RY) {
+        if (j < jend) R.row_ok |= 1u << (r - 1);
+        if (j + m.ext_st[1] >= m.dom_lb[1] && j + m.ext_st[1] <= m.dom_ub[1]) R.row_dom |= 1u << (r - 1);
+      }
+    }
+    R.cbv = live ? cb : 0xfffffff0u;
+    R.xoff = (live && xr >= 0) ? sy * (unsigned)clampi(j0 + xr, 0, DH - 1) + xcol8 : 0xfffffff0u;
+  };
+  auto load = [&](v2d (&B)[RY + 2], double &X, const Rows &R) {
+    for (int r = 0; r < RY + 2; r ++) B[r] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rS, R.cbv, R.roff[r], 0));
+    X = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rS, R.xoff, 0, 0));
+  };
+  auto step = [&](const v2d (&CU)[RY + 2], const double XC, const Rows &R) {
+    const unsigned mplane = (unsigned)P * (unsigned)R.j0, uplane = (unsigned)m.u_pitch * (unsigned)R.j0;
+    unsigned bw[RY];
+    static_for<RY>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      const v2d c = CU[r + 1];
+      const double xe = edge_for_row<r, RY>(XC);               // lane 0: left neighbour of row r, lane 63: right neighbour
+      const double xm = dpp_lower_or(c.y, xe);                 // left neighbour of column i0
+      double xp = dpp_upper_or(c.x, xe);                       // right neighbour of column i0 + 1
+      if (i0 + 1 == DW - 1) xp = c.y;                          // 2D clamp: the right neighbour of the last column is itself
+      const double dx0 = c.y - xm, dx1 = xp - c.x;
+      const double dy0 = CU[r + 2].x - CU[r].x, dy1 = CU[r + 2].y - CU[r].y;
+      const bool rok = (R.row_ok >> r) & 1, u_dom = (R.row_dom >> r) & 1;
+      unsigned a0 = 0, a1 = 0;
+      shift_in_signs2(a0, a1, dx0, dx1, dy0, dy1, -tpx, tpx, -tpy, tpy);
+      unsigned bits = a0 | (a1 << 8);
+      if (rok) {                                               // wave-uniform
+        acc0 = max_with_abs(acc0, dx0); acc1 = max_with_abs(acc1, dx1);
+        accy0 = max_with_abs(accy0, dy0); accy1 = max_with_abs(accy1, dy1);
+        const unsigned u = bits | (bits >> 3);
+        if (__builtin_amdgcn_ballot_w64((~u & cmask) != 0u)) {
+          auto take = [&](double g) { const double a = fabs(g); red_mn = fmin(red_mn, a == 0.0 ? DBL_MAX : a); };
+          if (cmask & 0x00ffu) { take(dx0 * fx2); take(dy0 * fy2); }
+          if (cmask & 0xff00u) { take(dx1 * fx2); take(dy1 * fy2); }
+        }
+      }
+      if (per_vertex_rule) {                                   // wave-uniform, rare: the scaled magnitudes after all
+        asm volatile("" ::: "memory");
+        const double m0 = max_abs2(dx0 * fx2, dy0 * fy2), m1 = max_abs2(dx1 * fx2, dy1 * fy2);
+        bits = (m0 >= tbig ? 0u : (bits & 0x00ffu)) | (m1 >= tbig ? 0u : (bits & 0xff00u));
+      }
+      const unsigned neut = u_dom ? xneutral : 0x3f3fu;        // outside the domain / row padding: never blocks a cull
+      bits = (bits & xkeep) | neut;
+      if (block4) { bw[r] = rok ? bits : 0x3f3fu; return; }
+      bool word_uniform = false;
+      if (have_u) {                                            // one summary byte per word of 8 (FTKX_U_ROWS=1)
+        int q = (int)((bits & (bits >> 8)) & 0x3fu);
+        q &= __builtin_amdgcn_update_dpp(q, q, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+        q &= __builtin_amdgcn_update_dpp(q, q, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
+        if (rok && u_lane) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)q, rU, ucol, uplane + (unsigned)m.u_pitch * (unsigned)r, 0);
+        word_uniform = q != 0;
+      }
+      if (rok && in_row && !word_uniform) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rM, mcol, mplane + (unsigned)P * (unsigned)r, 0);
+    });
+    if (block4) {
+      static_for<RY / 4>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        const unsigned all = (bw[4 * b] & bw[4 * b + 1]) & (bw[4 * b + 2] & bw[4 * b + 3]);
+        int q = (int)((all & (all >> 8)) & 0x3fu);
+        q &= __builtin_amdgcn_update_dpp(q, q, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+        q &= __builtin_amdgcn_update_dpp(q, q, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
+        const bool first_ok = (R.row_ok >> (4 * b)) & 1;
+        if (first_ok && u_lane) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)q, rU, ucol, (unsigned)m.u_pitch * (unsigned)(R.j0 / 4 + b), 0);
+        if (q == 0 && in_row) {
+#pragma unroll
+          for (int r = 4 * b; r < 4 * b + 4; r ++)
+            if ((R.row_ok >> r) & 1) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bw[r], rM, mcol, mplane + (unsigned)P * (unsigned)r, 0);
+        }
+      });
+    }
+  };
+
+  Rows Ra, Rb;
+  v2d A[RY + 2], B[RY + 2];
+  double XA, XB;
+  setup(Ra, jbase);
+  load(A, XA, Ra);
+  for (int g = 0; g < groups; g += 2) {
+    setup(Rb, jbase + (g + 1) * RY);
+    load(B, XB, Rb);
+    step(A, XA, Ra);
+    setup(Ra, jbase + (g + 2) * RY);
+    load(A, XA, Ra);
+    if (g + 1 < groups) step(B, XB, Rb);
+  }
+  if (job.red) {
+    const double mxx = fmax((cmask & 0x00ffu) ? acc0 : 0.0, (cmask & 0xff00u) ? acc1 : 0.0) * fx2;   // fl(max |d| f) = max fl(|d| f)
+    const double mxy = fmax((cmask & 0x00ffu) ? accy0 : 0.0, (cmask & 0xff00u) ? accy1 : 0.0) * fy2;
+    red_commit(job.red, red_mn < job.threshold ? red_mn : DBL_MAX, max_plain(mxx, mxy), blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u + (unsigned)wv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The same walk WITHOUT a dedicated producer: every wavefront of the workgroup is a consumer and issues the LDS-DMA loads of its
 // own rows (plus one of the three odd jobs: the two halo rows and the edge values).  Why: a workgroup's wavefronts land on the
 // CU's four SIMDs round-robin from a random start (tools/probe/simd_map.hip), so with 1 + 3 wavefronts per workgroup and three
@@ -2617,6 +2777,28 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
     // 2D, and the exact stand-alone reduction (ftkx_slice_resolution) of either dimension: mask_march4_kernel -- every wavefront loads
     // its rows into registers (4 wavefronts of 8 rows in 2D, of 4 rows marching along z in 3D)
     const int RY = (m.nd == 3) ? 4 : 8, wpb = 4;
+    if (m.nd == 2 && !reduce) {
+      // mask_rows2_kernel: a wavefront marches down `groups` groups of 8 rows (FTKX_MASK_PLAN rows=n, test hook; rows=0: the kernel below).
+      // Measured (tools/ab_mask.py, interleaved on one box, 4 groups against the kernel below): 4096^2 x 16 0.428 -> 0.384 ms, 2048^2 x 64
+      // 0.412 -> 0.397 (8 groups: 0.390), but 1024^2 x 64 0.096 -> 0.109 and 1024^2 x 256 0.379 -> 0.399: with rows of 8 KB the short
+      // wavefronts of the kernel below, whose neighbours in x run together, read whole rows; taken for rows of 32 KB and more
+      int groups = (DW >= 4096 && m.ext_sz[1] >= 512) ? 4 : 0;
+      if (env_hook_set("FTKX_MASK_PLAN", "rows")) groups = (int)env_hook("FTKX_MASK_PLAN", "rows", groups);
+      if (groups > 64) groups = 64;
+      if (groups >= 1) {
+        dim3 gridr((unsigned)((DW + 127) / 128), (unsigned)((m.ext_sz[1] + wpb * RY * groups - 1) / (wpb * RY * groups)), (unsigned)njobs);
+        int sw = swizzle;
+        if (sw & 8) {
+          int yg = 4;
+          if (env_hook_set("FTKX_MASK_PLAN", "yg")) { const long v = env_hook("FTKX_MASK_PLAN", "yg", 4); yg = v > 0 ? (v > 255 ? 255 : (int)v) : 1; }
+          while (yg > 1 && gridr.y % (unsigned)yg) yg --;
+          sw = (sw & 0xff) | (yg << 8);
+        }
+        g_last_mask_kernel = "ftkx::mask_rows2_kernel<8>";
+        hipLaunchKernelGGL(mask_rows2_kernel<8>, gridr, dim3((unsigned)(64 * wpb)), 0, stream, m, d_jobs, groups, sw);
+        return;
+      }
+    }
     const int nzc = m.nd == 3 ? (DD + zchunk - 1) / zchunk : 1;
     const dim3 grid4((unsigned)((DW + 127) / 128), (unsigned)((m.ext_sz[1] + wpb * RY - 1) / (wpb * RY)), (unsigned)(nzc * njobs));
     if (swizzle & 8) {     // (the group height must divide the grid's y extent)

@@ -187,6 +187,9 @@ def test_mask_kernel_generations_agree(gpu, case, dims, nt, rough):
                 {"FTKX_MASK_LMIN": "1", "FTKX_MASK_LCAP": "3"}, {"FTKX_MASK_LCAP": "100000"}, {"FTKX_MASK_LMIN": "1", "FTKX_MASK_LCAP": "1"}, {"FTKX_MASK_ZCHUNK": "1"},
                 {"FTKX_MASK_ZCHUNK": "32"}, {"FTKX_MASK_LMIN": "6", "FTKX_MASK_LCAP": "24"}, {"FTKX_MASK_ORDER": "0"}, {"FTKX_MASK_ORDER": "1"}, {"FTKX_MASK_ORDER": "0", "FTKX_MASK_ZCHUNK": "5"}]
     variants += [{"FTKX_U_ROWS": "4"}, {"FTKX_U_ROWS": "4", "FTKX_MASK_ZCHUNK": "7"}, {"FTKX_U_ROWS": "4", "FTKX_MASK_LCAP": "3", "FTKX_MASK_LMIN": "1"}]
+    # 2D: mask_rows2_kernel (a wavefront marches down `rows` groups of 8 rows; 0: mask_march4_kernel, one group per wavefront)
+    variants += [{"FTKX_MASK_ROWS": "0"}, {"FTKX_MASK_ROWS": "1"}, {"FTKX_MASK_ROWS": "3"}, {"FTKX_MASK_ROWS": "5", "FTKX_U_ROWS": "1"},
+                 {"FTKX_MASK_ROWS": "2", "FTKX_TWO_LEVEL": "0"}, {"FTKX_MASK_ROWS": "7", "FTKX_MASK_SWIZZLE": "0"}, {"FTKX_MASK_ROWS": "0", "FTKX_U_ROWS": "1"}]
     base = None
     by_geometry = {}
     def hooks(env):
