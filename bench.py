@@ -172,7 +172,26 @@ def cpu_baseline(nd, case, want_seconds=20.0):
         port = None
     if not out and port:
         out, port = port, None
+    # (a container's CPU share can be far below the core count `cores` threads were started on: said beside it)
+    share = host_cpu_share()
+    for o in (out, port):
+        if o:
+            o["host_cpu_share"] = share
     return out, port
+
+
+def host_cpu_share():
+    """CPUs this process may use: the cgroup's quota (cpu.max) if there is one, else its affinity mask"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return round(float(q) / float(per), 2)
+    except Exception:   # noqa: BLE001
+        pass
+    try:
+        return float(len(os.sched_getaffinity(0)))
+    except Exception:   # noqa: BLE001
+        return float(os.cpu_count() or 1)
 
 
 def side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=5, warmup=2):
