@@ -1004,7 +1004,7 @@ def job(args, env):
                                     "end_to_end_frac": out["roofline_end_to_end"]["frac"], "hits": n_hits, "check": check, "headline": True, **spread(per_pass_ms)}
                     continue
                 try:
-                    others[name] = side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=3 if name == "c4" else 16, warmup=3)
+                    others[name] = side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=3 if name == "c4" else 48, warmup=6)
                 except Exception as e:   # noqa: BLE001
                     others[name] = {"error": repr(e)}
             out["configs"] = others
