@@ -25,7 +25,7 @@ void launch_tile_stats_fold(u64 *slots, u64 *counters, hipStream_t stream);
 void tile_dims(int nd, int tile[3]);
 void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream);
 void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream, const FactorJob *job = nullptr);
-void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64 *d_list, u64 cap, hipStream_t stream);
+void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64 *d_list, u64 cap, hipStream_t stream, int few_wgs = 0);
 void launch_records(const Mesh &m, const Fields *d_fields, hipStream_t stream);
 void launch_compact_words(const Mesh &m, const unsigned char *U, const unsigned char *M, unsigned *idx, u64 *words, u64 capacity, u64 *counter, hipStream_t st);
 void launch_scatter_words(const unsigned *idx, const u64 *words, size_t n, unsigned char *M, size_t mask_words, u64 *bad, hipStream_t st);
@@ -49,16 +49,17 @@ void launch_resolution(const double *p, size_t n, u64 *out2, hipStream_t st);
 void launch_calib_read(const void *p, size_t bytes, double *scratch, hipStream_t stream);
 const char *last_mask_kernel();
 void launch_cull_coarse(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, hipStream_t stream, const FactorJob *job = nullptr);
-void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream);
+void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream, int few_wgs = 0);
 void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st,
                          const void *desc_src = nullptr, void *desc_dst = nullptr, size_t desc_bytes = 0, unsigned *fetched = nullptr, unsigned fetched_val = 0);
 void launch_series_one(const Mesh &m, const OneArgs &a, int nwg, hipStream_t st);
+void launch_series_tail_begin(u64 *counters, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st);
 void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,
                            double safe_m, u64 *results, u64 *counters, hipStream_t st);
-void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff, u64 *sorted, u64 *results, hipStream_t st);
-void launch_bucket_scan(unsigned *hist, unsigned *boff, unsigned nbins, u64 *counters, hipStream_t st);
-void launch_bucket_scatter(const Mesh &m, unsigned *boff, u64 *bucketed, hipStream_t st);
-void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, hipStream_t st);
+void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff, u64 *sorted, u64 *results, hipStream_t st, int few_wgs = 0);
+void launch_bucket_scan(unsigned *hist, unsigned *boff, unsigned nbins, u64 *counters, hipStream_t st, bool small_wg = false);
+void launch_bucket_scatter(const Mesh &m, unsigned *boff, u64 *bucketed, hipStream_t st, int few_wgs = 0);
+void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, hipStream_t st, bool lean = false);
 Mesh coarse_view(const Mesh &m);
 void launch_series_small(const Mesh &m, const Mesh &mc, const Fields *d_steps, bool two_level, const u64 *d_refine, const u64 *d_list, ftkx_cp_t *out,
                          u64 *results, size_t nwords, u64 *h_results, unsigned *flag, unsigned seq, unsigned *done, bool report_decline, hipStream_t st);
@@ -145,7 +146,11 @@ struct ftkx_series_pending {
   const u64 *running_from = nullptr;   // a results block on the device whose SR_RUNNING word this pass continues from (the pass before it, or a slab pass's stub)
   bool pipelined = false;
   bool refined = false;             // the refine kernel has been queued already (a slab pass lists the halo's cells from its output)
+  // split pass (series.hip, "the tail next to the next mask kernel"): begin + masks on the context's stream, the tail -- counters, cull + factors,
+  // the kernel chain -- on the tail stream behind an event, next to the mask kernel of the pass queued behind it
+  bool split = false;
   bool one = false;                 // the one-launch pass for small series (one_kernel.hip)
+  std::vector<std::pair<unsigned char *, unsigned char *>> retired;   // (M, U) arrays this pass still reads, replaced in their slices by the pass queued behind it
   // slab pass (ftkx_series_dist_*): one rank's part of a series cut into timestep slabs, queued in stages with the caller's collectives between them
   bool dist = false;
   int dist_stage = 0;               // 1 begun (masks, contribution, outgoing masks), 2 culled (request written), 3 served (reply written), 4 finished = open
@@ -164,6 +169,7 @@ struct ftkx_series_buffers {
   ftkx_cp_t *d_out = nullptr; size_t d_out_cap = 0;   // device: the records of a pass whose way over PCIe is left to the copy kernel on its own stream
   unsigned *copy_done = nullptr;                       // that kernel's workgroup counter
   hipEvent_t ev_copied = nullptr, ev_export = nullptr;
+  hipEvent_t ev_masks = nullptr, ev_tail = nullptr;   // split pass: masks done (stream), tail done (tail stream)
   u64 *red = nullptr; size_t red_cap = 0;             // the reduction slots of this pass's mask jobs (128 words per slice): its own, the next pass's begin kernel must not wipe them
   bool copy_out = false;                               // a copy has been queued since the buffers were last used: the next record kernel waits for it
   void *h_desc = nullptr, *d_desc = nullptr; size_t desc_cap = 0;
@@ -244,7 +250,7 @@ struct ftkx_ctx {
   // cull is queued, cleared whenever the host-driven batch takes them (series.hip: a pass whose fused tail declined may queue the rest of
   // its chain only while they are still its own)
   unsigned long long sr_pass_uid = 0, sr_lists_owner = 0;
-  hipStream_t sr_copy_stream = nullptr, sr_fetch_stream = nullptr;
+  hipStream_t sr_copy_stream = nullptr, sr_fetch_stream = nullptr, sr_tail_stream = nullptr;
   int sr_one_off = 0;                  // passes for which the one-launch form is not tried (it declined a moment ago)
   u64 *sr_one_scratch = nullptr;       // the one-launch pass's barrier counters, partial reductions and per-workgroup counts (ONE_WORDS)
   unsigned *sr_fetch_flag = nullptr;   // device: [0] the number of the last pass whose descriptors have been fetched (series_begin_kernel), [1] its arrival counter
@@ -261,6 +267,7 @@ struct ftkx_ctx {
   int sr_skip_small = 0;             // passes for which the fused tail kernel is not launched (the data was hit-dense a moment ago)
   int sr_late_streak = 0;            // consecutive passes the fused tail declined late
   bool sr_short_chain = false;       // the last pass was finished by the fused tail kernel: the next one is queued without the kernels behind it
+  bool sr_sparse = false;            // the last pass had few survivors and records (the fused tail's range): a pass whose mask kernel is long enough is split
   int sr_last_buf = 0;               // the buffers of the pass completed last (ftkx_series_dist_status reads its results block)
   size_t sr_last_gathered_off = 0; int sr_last_nranks = 0;   // where its gathered contributions sit in that block (0 ranks: not a slab pass)
   int sr_last_path = 0;              // which way the last ftkx_sweep_series went: 1 device-driven, 2 early single-workgroup tail, 0 the host-driven batch

@@ -384,10 +384,12 @@ void ftkx_destroy(ftkx_ctx *c)
     for (void *p : {(void *)B.results, (void *)B.d_out, B.d_desc, (void *)B.copy_done, (void *)B.dist_block}) if (p) (void)hipFree(p);
     if (B.ev_copied) (void)hipEventDestroy(B.ev_copied);
     if (B.ev_export) (void)hipEventDestroy(B.ev_export);
+    for (hipEvent_t e : {B.ev_masks, B.ev_tail}) if (e) (void)hipEventDestroy(e);
     if (B.red) (void)hipFree(B.red);
     for (void *p : {(void *)B.h_results, (void *)B.out, B.h_desc}) if (p) (void)hipHostFree(p);
   }
   if (c->sr_copy_stream) (void)hipStreamDestroy(c->sr_copy_stream);
+  if (c->sr_tail_stream) (void)hipStreamDestroy(c->sr_tail_stream);
   if (c->sr_one_scratch) (void)hipFree(c->sr_one_scratch);
   if (c->sr_fetch_flag) (void)hipFree(c->sr_fetch_flag);
   if (c->sr_ev_fetched) (void)hipEventDestroy(c->sr_ev_fetched);

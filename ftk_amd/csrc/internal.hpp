@@ -11,7 +11,7 @@ void set_global_error(const char *msg);
 #include "../../include/ftkx.h"
 namespace ftkx {
 // The library's test hooks come in two families, one environment variable each, "name=value,name=value" (DESIGN.md section 8):
-// FTKX_SERIES_HOOKS (small, short, fold, one, rank_max: which forms of the device-driven pass are taken) and FTKX_MASK_PLAN (swizzle,
+// FTKX_SERIES_HOOKS (small, short, fold, split, one, rank_max: which forms of the device-driven pass are taken) and FTKX_MASK_PLAN (swizzle,
 // yg, zchunk, lmin, lcap, order, rows, lean: launch geometry of the mask kernels).  Read at every use: tests switch them inside one process.
 inline long env_hook(const char *var, const char *name, long dflt)
 {

@@ -30,6 +30,9 @@ int series_by_host(ftkx_ctx *c, const int *ts, const int *scopes, int n, const s
 {
   c->sr_last_path = 0;
   c->sr_lists_owner = 0;                                      // (the batch takes the counters and the survivor lists over)
+  // (... from whatever still runs on the tail stream: the tail of a split pass queued behind the one the batch sweeps for shares them in
+  // STREAM order only with its own stream -- it must be through before the batch's kernels start on the context's stream)
+  if (c->sr_tail_stream) HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream));
   struct Through { ftkx_ctx *c; bool was; ~Through() { c->sr_internal = was; } } through{c, c->sr_internal};
   c->sr_internal = true;
   const unsigned long long hint = std::max<unsigned long long>(factor_of(*running), 256ull);
@@ -162,21 +165,54 @@ int ensure_series_buffers(ftkx_ctx *c, ftkx_series_buffers &B, size_t nwords, si
 
 void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, const unsigned *wait_flag, unsigned wait_val);
 
+// ---- the tail next to the next mask kernel (round 5) -------------------------------------------------------------------------------------
+// A sparse pass ends in a latency chain -- cull + factors, refine, exact test, ordering, records: ~70 us for a handful of workgroups -- and the
+// mask kernel of the pass queued behind it used to wait for all of it.  A SPLIT pass queues only its begin and mask kernels on the context's
+// stream; its tail goes to a stream of its own behind an event and runs NEXT TO the mask kernel of the pass queued behind.  What makes that
+// work is the shape of the tail: every kernel of it must fit next to two of the mask kernel's three wavefronts per SIMD (168 registers) --
+// a kernel that needs more gets no wavefront slot before the mask kernel drains (tools/probe/anyorder.hip; the fused tail, 388 registers in
+// 3D, was tried first: it had to be let in FRONT of the mask kernel by a gate, which cost more than the overlap gained -- NOTES.md).  So the
+// tail of a split pass is the kernel chain with the record kernel held to 168 registers (series_record_lean_kernel: its few records do not
+// care about the scratch) and the bucket scan as one workgroup of four wavefronts.  Under the mask kernel's memory traffic every dependent
+// load of the chain takes several times as long (256^3 x 16: the chain 340 us instead of 70) -- hidden as long as the mask kernel is longer:
+// taken by pipelined, single-rank passes whose last pass was sparse and whose mask kernel reads at least kSplitMinBytes.
+// What the two sides share is kept apart: the reduction slots are the pass's own (ftkx_series_buffers::red), the counters and the histogram
+// are zeroed on the tail stream, and a slice whose masks the next pass rebuilds while this pass's tail still reads them gets fresh arrays
+// (`retired`: back to the pool when this pass is completed).
+constexpr unsigned long long kSplitMinBytes = 2000000000ull;
+hipStream_t tail_stream(ftkx_ctx *c, const ftkx_series_pending &P) { return P.split ? c->sr_tail_stream : c->stream; }
+
+void release_retired(ftkx_ctx *c, ftkx_series_pending &P)
+{
+  for (auto &mu : P.retired) { if (mu.first) c->pool_M.push_back(mu.first); if (mu.second) c->pool_U.push_back(mu.second); }
+  P.retired.clear();
+}
+
+bool short_chain_now(const ftkx_ctx *c, bool to_device, bool *small_now)
+{
+  const bool small_on = ftkx::env_hook("FTKX_SERIES_HOOKS", "small", 1) != 0, short_on = ftkx::env_hook("FTKX_SERIES_HOOKS", "short", 1) != 0;
+  const bool sn = small_on && c->sr_skip_small == 0 && !to_device;
+  if (small_now) *small_now = sn;
+  return sn && short_on && c->sr_short_chain;
+}
+
 // the kernels behind the fused tail: refine, exact test, ordering, records, finish
 void series_queue_rest(ftkx_ctx *c, const ftkx_series_pending &P, const Mesh &m, unsigned seq)
 {
   ftkx_series_buffers &B = c->sr_buf[P.buf];
   Fields *d_steps = (Fields *)((char *)B.d_desc + P.off_steps);
   unsigned *flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
-  hipStream_t st = c->stream;
-  if (P.two_level && !P.refined) ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, st);   // (a slab pass refines before it asks for patches)
-  ftkx::launch_exact(m, d_steps, 0, c->d_list, c->list_capacity, st);
-  ftkx::launch_bucket_scan(c->sr_hist, c->sr_boff, (unsigned)P.nbins, c->d_counters, st);
-  ftkx::launch_bucket_scatter(m, c->sr_boff, c->sr_bucketed, st);
-  ftkx::launch_bucket_rank(m, c->sr_bucketed, c->sr_boff, c->sr_sorted, B.results, st);
+  hipStream_t st = tail_stream(c, P);
+  // (a split pass: sparse data next to a mask kernel -- every workgroup of these kernels waits for a wavefront slot: few of them)
+  const bool few = P.split;
+  if (P.two_level && !P.refined) ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, st, few ? 64 : 0);   // (a slab pass refines before it asks for patches)
+  ftkx::launch_exact(m, d_steps, 0, c->d_list, c->list_capacity, st, few ? 64 : 0);
+  ftkx::launch_bucket_scan(c->sr_hist, c->sr_boff, (unsigned)P.nbins, c->d_counters, st, P.split);
+  ftkx::launch_bucket_scatter(m, c->sr_boff, c->sr_bucketed, st, few ? 16 : 0);
+  ftkx::launch_bucket_rank(m, c->sr_bucketed, c->sr_boff, c->sr_sorted, B.results, st, few ? 16 : 0);
   if (B.copy_out) { (void)hipStreamWaitEvent(st, B.ev_copied, 0); B.copy_out = false; }   // (the copy of the pass that used these buffers last: long through)
-  ftkx::launch_series_records(m, d_steps, c->sr_sorted, P.to_device ? B.d_out : B.out, st);
-  ev_end(c);
+  ftkx::launch_series_records(m, d_steps, c->sr_sorted, P.to_device ? B.d_out : B.out, st, P.split);
+  if (!P.split) ev_end(c);
   ftkx::launch_series_finish(m, B.results, P.nwords, c->list_capacity, c->refine_capacity, B.h_results, flag, seq, st);
 }
 
@@ -219,7 +255,7 @@ int series_plan_one(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const in
 {
   const size_t k = P.k;
   int rc;
-  P.one = true; P.to_device = false; P.short_chain = false; P.small_now = false;
+  P.one = true; P.split = false; P.to_device = false; P.short_chain = false; P.small_now = false;
   P.red_index.assign(k, -1); P.gen.assign(k, 0);               // (no masks are built: nothing to mark when the pass is collected)
   P.ntodo = 0;
   if ((rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16)))) return rc;
@@ -263,6 +299,7 @@ int series_plan_one(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const in
     HIP_TRY(c, hipStreamWaitEvent(c->sr_copy_stream, c->sr_ev_fetched, 0));
     series_queue_copy(c, *before, nullptr, 0);
   }
+  if (before && before->open && before->split) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->sr_buf[before->buf].ev_tail, 0));   // (its tail shares the fragile list)
   if (B.copy_out) { HIP_TRY(c, hipStreamWaitEvent(c->stream, B.ev_copied, 0)); B.copy_out = false; }
   const u64 bs = c->nd == 2 ? 128 : 64, nblocks = (P.cells * (u64)n + bs - 1) / bs;
   const int nwg = (int)std::max<u64>(8, std::min<u64>(256, (nblocks + 3) / 4));      // (four or more blocks per workgroup, kOneOwnBlocks at most)
@@ -289,6 +326,7 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
                 ftkx_series_pending *before = nullptr /* the pass queued before this one, if it is still open */, const DistPlan *dist = nullptr)
 {
   const int nd = c->nd;
+  release_retired(c, P);                                     // (a slot that was abandoned with arrays still parked in it)
   P = ftkx_series_pending();
   if (dist) { P.dist = true; P.t_halo = dist->t_halo; P.dist_rank = dist->rank; P.dist_nranks = dist->nranks; P.dist_upper = dist->upper; P.gathered = dist->gathered; }
   P.ts.assign(ts, ts + n); P.scopes.assign(scopes, scopes + n); P.n = n;
@@ -352,13 +390,34 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   if ((rc = ensure_hit_buffer(c, std::max<u64>(c->capacity, 1u << 16)))) return rc;
   if ((rc = ensure_fragile(c, std::max<u64>(c->fragile_capacity, 1u << 12)))) return rc;
   if ((rc = ensure_list(c, std::max<u64>(c->list_capacity, 1u << 20))) || (rc = ensure_refine(c, std::max<u64>(c->refine_capacity, 1u << 20)))) return rc;
-  P.to_device = pipelined && c->stats.hits > 4096;
+  // split?  (decided here: the begin kernel of a split pass leaves the counters to the tail stream)
+  P.to_device = false;
+  {
+    P.to_device = pipelined && c->stats.hits > 4096;
+    // split?  hook: 0 never, 2 whatever the size (tests).  (Profiling level 2 times the mask kernel only, with events on the context's
+    // stream: they do not stand between the tail and anything.)
+    const long split_mode = ftkx::env_hook("FTKX_SERIES_HOOKS", "split", 1);
+    const unsigned long long mask_bytes = (unsigned long long)ntodo * (unsigned long long)n_vertices(c) * 8ull * (c->scalar_mode == 1 ? 1ull : (unsigned long long)nd);
+    P.split = split_mode != 0 && pipelined && !dist && (c->profiling == 0 || c->profiling == 2) && c->sr_sparse && !P.to_device && ntodo > 0 &&
+              (mask_bytes >= kSplitMinBytes || split_mode == 2);
+  }
+  const bool before_split = before && before->open && before->split;
+  // a slice whose masks this pass rebuilds while the tail of the pass before it -- on its own stream -- still reads them: fresh arrays here,
+  // the old ones parked with that pass until it is completed
+  if (before_split)
+    for (size_t j = 0; j < k; j ++) {
+      if (red_index[j] < 0 || !(sl[j]->M || sl[j]->U)) continue;
+      if (!std::binary_search(before->slice_ts.begin(), before->slice_ts.end(), slice_ts[j])) continue;
+      before->retired.push_back({sl[j]->M, sl[j]->U});
+      sl[j]->M = nullptr; sl[j]->U = nullptr;
+    }
   for (size_t j = 0; j < k; j ++) if (red_index[j] >= 0 && (rc = ensure_mask_arrays(c, *sl[j], two_level))) return rc;
   // order key -> bucket: at most 2^16 buckets over the keys this pass can produce
   const u64 max_key = (u64)n * cells * 64ull;
   int key_bits = 1;
   while (key_bits < 63 && (1ull << key_bits) < max_key) key_bits ++;
-  const int shift = std::max(0, key_bits - bins_log2());
+  // (a split pass: few records, and its scan -- one workgroup of four wavefronts next to a mask kernel -- pays several us per round of loads: 2^10)
+  const int shift = std::max(0, key_bits - (P.split ? 10 : bins_log2()));
   const size_t nbins = (size_t)((max_key - 1) >> shift) + 1;
   P.nbins = nbins;
   if (c->sr_bins_cap < nbins + 1) {
@@ -387,6 +446,15 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
     if (B.red) { HIP_TRY(c, hipFree(B.red)); B.red = nullptr; B.red_cap = 0; }
     HIP_TRY(c, hipMalloc((void **)&B.red, std::max<size_t>(ntodo, 1) * 128 * sizeof(u64)));
     B.red_cap = std::max<size_t>(ntodo, 1);
+  }
+  if (P.split || before_split) {
+    if (!c->sr_tail_stream) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      HIP_TRY(c, hipStreamCreateWithPriority(&c->sr_tail_stream, hipStreamNonBlocking, hi));    // (the tail is a latency chain: it goes first wherever a slot frees up)
+    }
+    for (ftkx_series_buffers &X : c->sr_buf)
+      for (hipEvent_t *e : {&X.ev_masks, &X.ev_tail}) if (!*e) HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
   if (P.to_device && !c->sr_copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->sr_copy_stream, hipStreamNonBlocking));
   fill_mesh(c, m);                                           // (the buffers may have moved)
@@ -453,7 +521,14 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   const bool copy_by_flag = copy_behind && !copy_by_event;
   if (copy_by_flag && !c->sr_fetch_flag) { HIP_TRY(c, hipMalloc((void **)&c->sr_fetch_flag, 2 * sizeof(unsigned))); HIP_TRY(c, hipMemsetAsync(c->sr_fetch_flag, 0, 2 * sizeof(unsigned), c->stream)); HIP_TRY(c, hipStreamSynchronize(c->stream)); }   // (once per context; waited for: the copy stream reads it)
   const unsigned fetch_val = copy_by_flag ? ++ c->sr_fetch_seq : 0u;
-  ftkx::launch_series_begin(c->d_counters, B.red, ntodo * 64, c->sr_hist, nbins + 1, B.results, nwords, c->stream, B.h_desc, B.d_desc, total, copy_by_flag ? c->sr_fetch_flag : nullptr, fetch_val);
+  // (the pass before this one has its tail on the tail stream: a pass that is not split itself shares the counters with it in STREAM order,
+  // so the context's stream waits for that tail; a split pass only needs that pass's cull -- its mask kernel must not start before the fused
+  // tail behind that cull can be placed -- and zeroes the counters on the tail stream, behind it)
+  if (before_split && !P.split) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->sr_buf[before->buf].ev_tail, 0));
+  // (a split pass: what its TAIL owns -- counters, histogram, the results block, which the tail of the pass before may still be reading as the
+  // block it continues from -- is zeroed on the tail stream)
+  ftkx::launch_series_begin(P.split ? nullptr : c->d_counters, B.red, ntodo * 64, P.split ? nullptr : c->sr_hist, P.split ? 0 : nbins + 1, P.split ? nullptr : B.results, P.split ? 0 : nwords,
+                            c->stream, B.h_desc, B.d_desc, total, copy_by_flag ? c->sr_fetch_flag : nullptr, fetch_val);
   c->sr_lists_owner = 0;                                      // (the begin kernel zeroes the counters and the histogram: they are nobody's until this pass's cull is queued)
   if (copy_by_flag) series_queue_copy(c, *before, c->sr_fetch_flag, fetch_val);
   if (copy_by_event) {
@@ -482,6 +557,12 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
     }
     if (ntodo > done) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs + done, (int)(ntodo - done), c->stream); ev_end(c); }
   } else if (ntodo) { ev_begin(c, K_MASK); ftkx::launch_masks(m, d_jobs, (int)ntodo, c->stream); ev_end(c); }
+  if (P.split) {
+    // the tail's side: behind the masks (an event), the counters and the histogram zeroed there
+    HIP_TRY(c, hipEventRecord(B.ev_masks, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->sr_tail_stream, B.ev_masks, 0));
+    ftkx::launch_series_tail_begin(c->d_counters, c->sr_hist, nbins + 1, B.results, nwords, c->sr_tail_stream);
+  }
   P.running_from = prev ? c->sr_buf[prev->buf].results : nullptr;
   P.pipelined = pipelined;
   HIP_TRY(c, hipGetLastError());
@@ -505,8 +586,8 @@ int series_queue_cull(ftkx_ctx *c, ftkx_series_pending &P)
   Fields *d_steps = (Fields *)((char *)B.d_desc + P.off_steps);
   const ftkx::SeriesSlice *d_slices = (const ftkx::SeriesSlice *)((char *)B.d_desc + P.off_slices);
   const ftkx::SeriesStep *d_sinfo = (const ftkx::SeriesStep *)((char *)B.d_desc + P.off_sinfo);
-  hipStream_t st = c->stream;
-  ev_begin(c, K_CULL);
+  hipStream_t st = tail_stream(c, P);
+  if (!P.split) ev_begin(c, K_CULL);
   P.uid = ++ c->sr_pass_uid;
   c->sr_lists_owner = P.uid;                                  // (from here on the counters and lists hold this pass's cull)
   {
@@ -524,7 +605,7 @@ int series_queue_cull(ftkx_ctx *c, ftkx_series_pending &P)
     else ftkx::launch_cull(m, d_steps, n, c->d_list, c->list_capacity, st, &fj);
     if (!fj.enabled) ftkx::launch_series_factors(d_steps, n, d_slices, (int)k, d_sinfo, B.red, fj.running_in, running_from, safe_m, B.results, c->d_counters, st);
   }
-  ev_end(c);
+  if (!P.split) ev_end(c);
   HIP_TRY(c, hipGetLastError());
   return FTKX_OK;
 }
@@ -539,20 +620,22 @@ int series_queue_tail(ftkx_ctx *c, ftkx_series_pending &P)
   const unsigned seq = P.seq;
   const bool two_level = P.two_level;
   const size_t nwords = P.nwords;
-  hipStream_t st = c->stream;
-  ev_begin(c, K_EXACT);
+  hipStream_t st = tail_stream(c, P);
+  if (!P.split) ev_begin(c, K_EXACT);
   // sparse data: one kernel does the rest of the pass (and the kernels below leave at once).  (A pass that has just found far more
   // survivors than the fused kernel takes does not launch it for a while: finding nothing to do costs its 256 workgroups of 256-VGPR
   // wavefronts ~15 us.)  The fused tail finished the last pass too: this one is queued WITHOUT the seven kernels behind it -- each of them
   // costs a few us just to find out that it has nothing to do.  Should the fused tail decline this time, it says so itself and the rest is
   // queued then (or, with another pass queued behind already, the host-driven batch sweeps the steps).
-  const bool small_now = ftkx::env_hook("FTKX_SERIES_HOOKS", "small", 1) != 0 && c->sr_skip_small == 0 && !P.to_device;
-  P.short_chain = small_now && ftkx::env_hook("FTKX_SERIES_HOOKS", "short", 1) != 0 && c->sr_short_chain;
+  bool small_now = false;
+  P.short_chain = short_chain_now(c, P.to_device, &small_now);
+  if (P.split) { small_now = false; P.short_chain = false; }      // (the fused tail does not fit next to a mask kernel: the chain)
   if (c->sr_skip_small > 0) c->sr_skip_small --;
   P.small_now = small_now;
   if (small_now) ftkx::launch_series_small(m, two_level ? ftkx::coarse_view(m) : m, d_steps, two_level, c->d_refine, c->d_list, B.out, B.results, nwords,
                                           B.h_results, flag, seq, reinterpret_cast<unsigned *>(c->d_counters + ftkx::CNT_SMALL_DONE), P.short_chain, st);
   if (!P.short_chain) series_queue_rest(c, P, m, seq);
+  if (P.split) HIP_TRY(c, hipEventRecord(B.ev_tail, st));
   P.copy_pending = P.to_device;
   HIP_TRY(c, hipGetLastError());
   return FTKX_OK;
@@ -586,13 +669,12 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
   ftkx_series_buffers &B = c->sr_buf[P.buf];
   unsigned *flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
   Mesh m; fill_mesh(c, m);
-  {
-    const u64 max_key = (u64)n * P.cells * 64ull;
-    int key_bits = 1;
-    while (key_bits < 63 && (1ull << key_bits) < max_key) key_bits ++;
-    m.hist = c->sr_hist; m.hist_shift = std::max(0, key_bits - bins_log2()); m.core_cells = P.cells;
-  }
-  if (const char *why = ftkx::wait_flag(flag, P.seq, c->stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+  m.hist = c->sr_hist; m.hist_shift = P.shift; m.core_cells = P.cells;
+  if (const char *why = ftkx::wait_flag(flag, P.seq, tail_stream(c, P))) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+  release_retired(c, P);                                     // (the tail that read them is through)
+  // (with no pass left open the tail stream is at its end: waited for, so that whatever the caller does next on the context's stream --
+  // a host-driven batch, a pass that is not split -- finds the counters and lists idle)
+  if (P.split && c->sr_open == 0) HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream));
 
   // ---- what came back ----------------------------------------------------------------------------------------------------------------
   // (whoever stored the flag -- the fused tail, finishing or declining, or the finish kernel -- copied the whole results block first: the
@@ -634,7 +716,7 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     }
     if (status & ftkx::SERIES_HALO_FULL) {
       c->sr_short_chain = false;
-      if (P.short_chain) ev_end(c);
+      if (P.short_chain && !P.split) ev_end(c);
       ev_harvest(c, false);
       *running_resolution = running;
       return fail(c, FTKX_E_NOSLICE, "slab pass: the halo slice %d is needed as a whole (request -1: too many surviving cells, a mask message that did not fit, or masks the host rebuilds): nothing was swept", P.t_halo);
@@ -647,7 +729,7 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
       // completed back to back).  The host-driven batch sweeps the steps; it happens when sparse data turns dense.  A slab pass: from the
       // running minimum the lower ranks' contributions give, over a halo slice that has its patches -- both settled above)
       c->sr_short_chain = false;
-      ev_end(c);
+      if (!P.split) ev_end(c);
       int rc = series_by_host(c, P.ts.data(), P.scopes.data(), n, P.slice_ts, &running, factors, out, n_out);
       if (rc == FTKX_OK) *running_resolution = running;
       return rc;
@@ -655,16 +737,17 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     if (status & ftkx::SERIES_TAIL_PENDING) {
       const unsigned seq2 = ++ B.seq;
       series_queue_rest(c, P, m, seq2);
+      if (P.split) HIP_TRY(c, hipEventRecord(B.ev_tail, c->sr_tail_stream));
       HIP_TRY(c, hipGetLastError());
-      if (const char *why = ftkx::wait_flag(flag, seq2, c->stream)) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
+      if (const char *why = ftkx::wait_flag(flag, seq2, tail_stream(c, P))) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
       status = R[ftkx::SR_STATUS];                           // (the finish kernel's copy of the block: the same reductions, the final counters)
       c->sr_last_status = status;
-    } else ev_end(c);
+    } else if (!P.split) ev_end(c);
   }
   ev_harvest(c, false);
   const unsigned long long redo = ftkx::SERIES_AMBIGUOUS | ftkx::SERIES_MASKS_INVALID | ftkx::SERIES_INF | ftkx::SERIES_OVERFLOW;
   if (status & redo) {
-    c->sr_short_chain = false;
+    c->sr_short_chain = false; c->sr_sparse = false;
     if (P.one) c->sr_one_off = 16;                           // (more hits than a workgroup parks, or the device was not this kernel's alone: the usual way for a while)
     int rc;
     if (status & ftkx::SERIES_OVERFLOW) {                    // grow what was too small (the host-driven batch would find out the same way, one replay later)
@@ -680,8 +763,12 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     if (rc == FTKX_OK) *running_resolution = running;
     return rc;
   }
-  c->sr_last_path = (status & ftkx::SERIES_ONE) ? 4 : (status & ftkx::SERIES_EARLY) ? 2 : 1;
-  if (!P.one) c->sr_short_chain = (status & ftkx::SERIES_EARLY) != 0;
+  c->sr_last_path = (status & ftkx::SERIES_ONE) ? 4 : P.split ? 5 : (status & ftkx::SERIES_EARLY) ? 2 : 1;
+  if (!P.one && !P.split) c->sr_short_chain = (status & ftkx::SERIES_EARLY) != 0;      // (a split pass says nothing about the fused tail)
+  if (!P.one) {
+    const u64 *cn = R + ftkx::SR_COUNTERS;
+    c->sr_sparse = (status & ftkx::SERIES_EARLY) != 0 || (R[ftkx::SR_NHITS] <= 1024 && (P.two_level ? cn[ftkx::CNT_REFINE_PEAK] : cn[ftkx::CNT_LIST_PEAK]) <= 4 * 2048ull);
+  }
   const u64 *cnt = R + ftkx::SR_COUNTERS;
   if (!(status & ftkx::SERIES_EARLY) && (P.two_level ? cnt[ftkx::CNT_REFINE_PEAK] : cnt[ftkx::CNT_LIST_PEAK]) > 4 * 2048ull) c->sr_skip_small = 16;
   // (few coarse cells, many records in them: the fused tail declined late, tens of microseconds lost.  Twice in a row: the series is like that)
@@ -977,6 +1064,7 @@ int ftkx_sweep_series_abort(ftkx_ctx *c)
   // whatever the open passes queued runs to its end (their kernels write buffers that stay allocated); nothing of it is read
   hipError_t e = hipStreamSynchronize(c->stream);
   if (c->sr_copy_stream && e == hipSuccess) e = hipStreamSynchronize(c->sr_copy_stream);
+  if (c->sr_tail_stream && e == hipSuccess) e = hipStreamSynchronize(c->sr_tail_stream);
   for (ftkx_series_pending &P : c->sr_pend) {
     if (P.dist && P.dist_stage > 0 && P.dist_stage < 4) { P.open = true; }      // (a slab pass that was never finished: its masks are nobody's either)
     if (!P.open) continue;
@@ -985,11 +1073,12 @@ int ftkx_sweep_series_abort(ftkx_ctx *c)
       auto it = c->slices.find(P.slice_ts[j]);
       if (P.red_index[j] >= 0 && it != c->slices.end() && it->second.mask_gen == P.gen[j]) { it->second.mask_factor = 0; it->second.have_fused = false; }
     }
+    release_retired(c, P);
     P.open = false; P.copy_pending = false; P.dist_stage = 0;
   }
   for (ftkx_series_buffers &B : c->sr_buf) B.copy_out = false;
   c->sr_open = 0; c->sr_head = 0;
-  c->sr_short_chain = false; c->sr_lists_owner = 0; c->sr_last_running = 0;
+  c->sr_short_chain = false; c->sr_sparse = false; c->sr_lists_owner = 0; c->sr_last_running = 0;
   c->ahead.clear(); c->announced.clear();
   if (e != hipSuccess) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series_abort: %s", hipGetErrorString(e));
   return FTKX_OK;

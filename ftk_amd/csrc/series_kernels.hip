@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void series_begin_kernel(u64 *counters, u64 *r
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   // (the pass's descriptors, pinned host -> device: the first workgroups, so that the read over PCIe is under way at once)
   for (size_t w = i; w < desc_words; w += (size_t)gridDim.x * 256) desc_dst[w] = desc_src[w];
-  if (i < (size_t)CNT_N) counters[i] = 0ull;
+  if (counters && i < (size_t)CNT_N) counters[i] = 0ull;      // (nullptr: a split pass zeroes them on its tail stream -- series.hip)
   if (i < nslots) { red[2 * i] = 0x7fefffffffffffffull; red[2 * i + 1] = 0ull; }   // {min = DBL_MAX, max = 0} as bit patterns
   if (i < nbins) hist[i] = 0u;
   if (i < nresults) results[i] = 0ull;
@@ -36,6 +36,17 @@ __global__ __launch_bounds__(256) void series_begin_kernel(u64 *counters, u64 *r
       __hip_atomic_store(&fetched[0], fetched_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// a split pass (series.hip): what the pass's TAIL owns -- the counters and the histogram -- zeroed on the tail stream, behind the tail of the pass before it
+// -- and the pass's results block: the pass before this one may still read the block's last contents (it is the block of the pass before
+// THAT, whose running minimum and reductions it continues from) until its own tail is through, which on the tail stream it is
+__global__ __launch_bounds__(256) void series_tail_begin_kernel(u64 *counters, unsigned *hist, size_t nbins, u64 *results, size_t nresults)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < (size_t)CNT_N) counters[i] = 0ull;
+  if (i < nbins) hist[i] = 0u;
+  if (i < nresults) results[i] = 0ull;
 }
 
 // ---- the sticky factor: series_device.hpp ---------------------------------------------------------------------------------------------
@@ -64,13 +75,14 @@ __device__ inline unsigned wave_inclusive_sum(unsigned v)
 // and walks it in rows of 64 consecutive bins (every load and store is one contiguous 256-byte run): a first pass for the wavefront's
 // total, a second one -- the counts come from the L2 now -- for the offsets.  The counts are zeroed for their second life as scatter
 // cursors; the fullest bucket is published (CNT_BUCKET_MAX).  nbins <= kSeriesMaxBins.
-__global__ __launch_bounds__(1024) void bucket_scan_kernel(unsigned *__restrict__ hist, unsigned *__restrict__ boff, unsigned nbins, u64 *__restrict__ counters)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void bucket_scan_kernel(unsigned *__restrict__ hist, unsigned *__restrict__ boff, unsigned nbins, u64 *__restrict__ counters)
 {
-  __shared__ unsigned s_wave[16];
+  __shared__ unsigned s_wave[NW];
   __shared__ unsigned s_max;
   if (counters[CNT_SERIES_DONE]) return;
   const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const unsigned seg = (nbins + 15u) / 16u, rows = (seg + 63u) / 64u;      // rows of 64 bins per wavefront
+  const unsigned seg = (nbins + (unsigned)NW - 1u) / (unsigned)NW, rows = (seg + 63u) / 64u;      // rows of 64 bins per wavefront
   const unsigned base = wv * rows * 64u;
   if (tid == 0) s_max = 0;
   __syncthreads();
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(unsigned *__restrict_
       carry += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
     }
   }
-  if (tid == 1023) boff[nbins] = carry;                  // (the last wavefront's carry is the total)
+  if (tid == (unsigned)(NW * 64 - 1)) boff[nbins] = carry;   // (the last wavefront's carry is the total)
   if (tid == 0) counters[CNT_BUCKET_MAX] = s_max;
 }
 
@@ -160,8 +172,7 @@ __global__ __launch_bounds__(256) void bucket_rank_kernel(const u64 *__restrict_
 // ---- records, in order, streamed to the host -------------------------------------------------------------------------------------------
 
 template <int ND>
-__global__ __launch_bounds__(kThreads) void series_record_kernel(const Mesh m, const Fields *__restrict__ fields, const u64 *__restrict__ sorted,
-                                                                 ftkx_cp_t *__restrict__ out /* pinned host memory */)
+__device__ __forceinline__ void series_record_body(const Mesh &m, const Fields *__restrict__ fields, const u64 *__restrict__ sorted, ftkx_cp_t *__restrict__ out /* pinned host memory */)
 {
   constexpr int N = ND + 1;
   __shared__ u64 s_rec[kThreads / 64][64 * 9];
@@ -222,6 +233,15 @@ __global__ __launch_bounds__(kThreads) void series_record_kernel(const Mesh m, c
     __builtin_amdgcn_wave_barrier();
   }
 }
+
+template <int ND>
+__global__ __launch_bounds__(kThreads) void series_record_kernel(const Mesh m, const Fields *__restrict__ fields, const u64 *__restrict__ sorted, ftkx_cp_t *__restrict__ out)
+{ series_record_body<ND>(m, fields, sorted, out); }
+// the same held to a third of a SIMD's registers (3D: 168 + 1.1 KB of scratch per lane instead of 369): a wavefront of it fits next to two of
+// the mask kernel's -- the tail of a split pass, whose few records do not care
+template <int ND>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void series_record_lean_kernel(const Mesh m, const Fields *__restrict__ fields, const u64 *__restrict__ sorted, ftkx_cp_t *__restrict__ out)
+{ series_record_body<ND>(m, fields, sorted, out); }
 
 // ---- the whole tail in one kernel (sparse data) -----------------------------------------------------------------------------------------
 // Where almost everything is culled -- one moving extremum in 512^3 x 32: a few hundred coarse cells survive -- refine, exact test,
@@ -784,26 +804,41 @@ void launch_series_begin(u64 *counters, u64 *red, size_t nslots, unsigned *hist,
                      (const u64 *)desc_src, (u64 *)desc_dst, desc_src ? desc_bytes / 8 : (size_t)0, fetched, fetched_val);
 }
 
+void launch_series_tail_begin(u64 *counters, unsigned *hist, size_t nbins, u64 *results, size_t nresults, hipStream_t st)
+{
+  size_t n = nbins > (size_t)CNT_N ? nbins : (size_t)CNT_N;
+  n = n > nresults ? n : nresults;
+  hipLaunchKernelGGL(series_tail_begin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, counters, hist, nbins, results, nresults);
+}
+
 void launch_series_factors(Fields *steps, int nsteps, const SeriesSlice *slices, int nslices, const SeriesStep *sinfo, const u64 *red, double running_in, const u64 *running_from,
                            double safe_m, u64 *results, u64 *counters, hipStream_t st)
 { hipLaunchKernelGGL(series_factors_kernel, dim3(1), dim3(1024), 0, st, steps, nsteps, slices, nslices, sinfo, red, running_in, running_from, safe_m, results, counters); }
 
-void launch_bucket_scan(unsigned *hist, unsigned *boff, unsigned nbins, u64 *counters, hipStream_t st)
-{ hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, hist, boff, nbins, counters); }
+void launch_bucket_scan(unsigned *hist, unsigned *boff, unsigned nbins, u64 *counters, hipStream_t st, bool small_wg)
+{
+  if (small_wg) hipLaunchKernelGGL(bucket_scan_kernel<4>, dim3(1), dim3(256), 0, st, hist, boff, nbins, counters);
+  else hipLaunchKernelGGL(bucket_scan_kernel<16>, dim3(1), dim3(1024), 0, st, hist, boff, nbins, counters);
+}
 
-void launch_bucket_scatter(const Mesh &m, unsigned *boff, u64 *bucketed, hipStream_t st)
-{ hipLaunchKernelGGL(bucket_scatter_kernel, dim3(256), dim3(256), 0, st, m.pass, m.capacity, boff, m.hist, m.hist_shift, m.core_cells, bucketed, m.counters); }
+void launch_bucket_scatter(const Mesh &m, unsigned *boff, u64 *bucketed, hipStream_t st, int few_wgs)
+{ hipLaunchKernelGGL(bucket_scatter_kernel, dim3(few_wgs > 0 ? (unsigned)few_wgs : 256u), dim3(256), 0, st, m.pass, m.capacity, boff, m.hist, m.hist_shift, m.core_cells, bucketed, m.counters); }
 
-void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff, u64 *sorted, u64 *results, hipStream_t st)
+void launch_bucket_rank(const Mesh &m, const u64 *bucketed, const unsigned *boff, u64 *sorted, u64 *results, hipStream_t st, int few_wgs)
 {
   unsigned rank_max = 4096;
   rank_max = (unsigned)env_hook("FTKX_SERIES_HOOKS", "rank_max", 4096);
-  hipLaunchKernelGGL(bucket_rank_kernel, dim3(256), dim3(256), 0, st, bucketed, m.capacity, boff, m.hist_shift, rank_max, sorted, m.counters, results);
+  hipLaunchKernelGGL(bucket_rank_kernel, dim3(few_wgs > 0 ? (unsigned)few_wgs : 256u), dim3(256), 0, st, bucketed, m.capacity, boff, m.hist_shift, rank_max, sorted, m.counters, results);
 }
 
-void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, hipStream_t st)
+void launch_series_records(const Mesh &m, const Fields *d_fields, const u64 *sorted, ftkx_cp_t *out, hipStream_t st, bool lean)
 {
-  const dim3 grid(256u * 2u);
+  const dim3 grid(lean ? 64u : 256u * 2u);
+  if (lean) {
+    if (m.nd == 2) hipLaunchKernelGGL(series_record_lean_kernel<2>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out);
+    else hipLaunchKernelGGL(series_record_lean_kernel<3>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out);
+    return;
+  }
   if (m.nd == 2) hipLaunchKernelGGL(series_record_kernel<2>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out);
   else hipLaunchKernelGGL(series_record_kernel<3>, grid, dim3(kThreads), 0, st, m, d_fields, sorted, out);
 }

@@ -2931,10 +2931,10 @@ void launch_cull_coarse(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d
   launch_cull_level<true>(coarse_view(m), d_steps, nsteps, d_refine, refine_cap, stream, job);
 }
 
-void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream)
+void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream, int few_wgs)
 {
   const Mesh mc = coarse_view(m);
-  const dim3 grid(256 * 4);
+  const dim3 grid(few_wgs > 0 ? (unsigned)few_wgs : 256u * 4u);      // (few: the tail of a split pass, next to a mask kernel -- sparse data, every workgroup waits for a slot)
   if (m.nd == 2) hipLaunchKernelGGL(refine_kernel<2>, grid, dim3(kThreads), 0, stream, m, mc, d_steps, d_refine, refine_cap, d_list, cap);
   else hipLaunchKernelGGL(refine_kernel<3>, grid, dim3(kThreads), 0, stream, m, mc, d_steps, d_refine, refine_cap, d_list, cap);
 }
@@ -2943,7 +2943,7 @@ void launch_cull_two_level(const Mesh &m, const Fields *d_steps, int nsteps, u64
 {
   if (nsteps <= 0) return;
   launch_cull_coarse(m, d_steps, nsteps, d_refine, refine_cap, stream, nullptr);
-  launch_refine(m, d_steps, d_refine, refine_cap, d_list, cap, stream);
+  launch_refine(m, d_steps, d_refine, refine_cap, d_list, cap, stream, 0);
 }
 
 void launch_records(const Mesh &m, const Fields *d_fields, hipStream_t stream)
@@ -2954,12 +2954,12 @@ void launch_records(const Mesh &m, const Fields *d_fields, hipStream_t stream)
   else hipLaunchKernelGGL(record_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_fields);
 }
 
-void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64 *d_list, u64 cap, hipStream_t stream)
+void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64 *d_list, u64 cap, hipStream_t stream, int few_wgs)
 {
   // persistent-style: workgroups stride over the list, every wave exits when it is drained (no scratch; 21-23 KB of LDS).  Four per
   // CU: woven 1024^2 x 64 (181 853 cells) 0.084 ms with the record kernel, double_gyre 2048 x 1024 x 128 0.078 (0.097 with two)
   int per_cu = 4;
-  const dim3 grid(256u * (unsigned)per_cu);
+  const dim3 grid(few_wgs > 0 ? (unsigned)few_wgs : 256u * (unsigned)per_cu);
   if (m.nd == 2) hipLaunchKernelGGL(exact_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, step_base, d_list, cap);
   else hipLaunchKernelGGL(exact_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_steps, step_base, d_list, cap);
 }

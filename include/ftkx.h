@@ -258,8 +258,10 @@ int ftkx_series_dist_finish(ftkx_ctx *ctx, const void *reply_in);
  * slice, 0: nothing), and the gathered contributions (4 * nranks doubles, nullable) */
 int ftkx_series_dist_status(const ftkx_ctx *ctx, long long *asked, long long *served, double *gathered, int nranks);
 
-/* which way the last ftkx_sweep_series went: 1 = device-driven, 2 = device-driven and finished by the fused tail kernel (sparse
- * data), 0 = host-driven batch; *status (nullable) = the SERIES_* bits the kernels raised (csrc/sweep_params.hpp) */
+/* which way the last ftkx_sweep_series went: 1 = device-driven (the kernel chain), 2 = device-driven and finished by the fused tail
+ * kernel (sparse data), 4 = the whole pass in one launch (small series), 5 = split: the kernel chain on a stream of its own next to the
+ * mask kernel of the pass queued behind (pipelined passes over sparse data whose mask kernel is long enough to hide it), 0 = host-driven
+ * batch; *status (nullable) = the SERIES_* bits the kernels raised (csrc/sweep_params.hpp) */
 int ftkx_series_last_path(const ftkx_ctx *ctx, unsigned long long *status);
 
 /* counters of the last collect: simplices visited (work items), cells/simplices surviving the cull, device-side hits */

@@ -102,7 +102,8 @@ def _timed_path(gpu, case, dims, nt, nv, want_path, keep_host=False, k=5):
         R.pipelined(3)                                   # bench.py's warm-up: both buffer sets, the copy stream, the record count known
         runs = R.pipelined(k)
         for i, (recs, f, path) in enumerate(runs):
-            assert path == want_path, (i, path, "a pass of the timed loop left the device-driven form")
+            # (pipelined passes over sparse data whose mask kernel is long enough: the split pass, path 5 -- its tail next to the next mask kernel)
+            assert path == want_path or (want_path == (2, SERIES_EARLY) and path == (5, 0)), (i, path, "a pass of the timed loop left the device-driven form")
             assert f == runs[0][1], (i, "factors differ between passes")
             assert _bytes_equal(recs, runs[0][0]), (i, len(recs), len(runs[0][0]), "pass %d differs from the first pipelined pass" % i)
         recs, f, path, st = R.alone()
@@ -114,7 +115,7 @@ def _timed_path(gpu, case, dims, nt, nv, want_path, keep_host=False, k=5):
         assert b_st["work_items"] == st["work_items"]
         # and back: the context that has just run the batch takes the device-driven form again
         again = R.pipelined(2)
-        assert all(p == want_path and _bytes_equal(r, recs) for r, _, p in again), [p for _, _, p in again]
+        assert all((p == want_path or (want_path == (2, SERIES_EARLY) and p == (5, 0))) and _bytes_equal(r, recs) for r, _, p in again), [p for _, _, p in again]
         return recs, f, R.host, st
     finally:
         R.close()
@@ -186,7 +187,7 @@ def test_c5_series_double_gyre_2048x1024x128(gpu, oracle):
 
 
 def test_c3_series_moving_extremum_256cubed_x16(gpu):
-    """BASELINE configs[2] through the timed path: sparse 3D, the fused tail (path 2)"""
+    """BASELINE configs[2] through the timed path: sparse 3D, the fused tail (path 2) on its own, the split pass (path 5) with two in flight"""
     dims, nt = (256, 256, 256), 16
     recs, f, _, st = _timed_path(gpu, "moving_extremum_3d", dims, nt, 1, (2, SERIES_EARLY))
     _analytic_3d(gpu, recs, st, f, dims, nt)

@@ -345,12 +345,18 @@ def test_abort_discards_the_open_passes_and_leaves_the_context_usable(gpu):
 
 @pytest.mark.parametrize("name", ["woven_128x128x10", "woven_31x37x32", "double_gyre_64x32x50", "merger_2d_32x32x100", "moving_extremum_3d_21x21x21x32",
                                   "adversarial_3d_scalar_9x9x9x4", "random_2d_scalar_29x24x6_saddles", "adversarial_3d_scalar_9x9x9x3_norobust"])
-def test_pipelined_passes_equal_the_plain_ones(gpu, name):
+@pytest.mark.parametrize("split", [False, True], ids=["in_order", "split"])
+def test_pipelined_passes_equal_the_plain_ones(gpu, name, split, monkeypatch):
     """ftkx_sweep_series_submit / _complete, two passes open at a time: (a) the whole series swept again and again, masks dropped in
     between (what bench.py times), (b) the series in consecutive pieces, each continuing on the device from the running minimum of the one
     before it, while the host has not even seen that one yet (a streaming caller).  Records, factors and running minima are those of
     ftkx_sweep_series on the same steps; the copy engine carries the records of the later passes (more than 4096 of them, where the
-    fixture has that many)."""
+    fixture has that many).
+    split: FTKX_SERIES_HOOKS split=2 -- the SPLIT pass whatever the size of the mask launch (by default: 2 GB and more): where the pass before
+    was sparse, the tail of a pass (the kernel chain, its record kernel held to a third of a SIMD's registers) runs on a stream of its own
+    next to the begin and mask kernels of the pass queued behind; counters zeroed there, mask arrays that the next pass rebuilds replaced."""
+    if split:
+        monkeypatch.setenv("FTKX_SERIES_HOOKS", "one=0,split=2")
     g = load_golden(name)
     nd, nv, nt = g["nd"], g["nv"], g["DT"]
     scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
@@ -370,6 +376,8 @@ def test_pipelined_passes_equal_the_plain_ones(gpu, name):
         assert _same(got, want) and np.array_equal(f, wf) and run == wrun, (name, it, len(got), len(want))
     got, f, run = ctx.sweep_series_complete()
     assert _same(got, want) and np.array_equal(f, wf) and run == wrun
+    if split and name == "moving_extremum_3d_21x21x21x32":
+        assert ctx.series_last_path()[0] == 5, (name, ctx.series_last_path())      # (sparse fixtures: the passes after the first were split)
     with pytest.raises(Exception):
         ctx.sweep_series_complete()
     # (b) pieces of the series; the reference: the same pieces through ftkx_sweep_series, the running minimum carried by the caller
