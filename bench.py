@@ -1014,7 +1014,7 @@ def job(args, env):
             slices.clear(); halo_buf = None
             torch.cuda.empty_cache()
             try:
-                out["streaming_tracker"] = streaming_tracker(nd, case, dims, min(nt, 32), torch, dev, ftk_amd, synthetic)
+                out["streaming_tracker"] = streaming_tracker(nd, case, dims, min(2 * nt, 64), torch, dev, ftk_amd, synthetic)
             except Exception as e:   # noqa: BLE001
                 out["streaming_tracker"] = {"error": repr(e)}
         if not multi and not light and not args.no_streaming_tracker and not args.exact_only:
