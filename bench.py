@@ -258,7 +258,7 @@ def side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=5, warmup=2):
     symbol = "ftkx::%s<%d>" % (domk, nd)
     if domk == "mask_kernel":
         symbol = (ctx._L.ftkx_last_mask_kernel() or b"").decode() or symbol
-    want_paths = [(2, 32), (5, 0)] if case == "moving_extremum_3d" else ([(1, 0), (2, 32), (4, 544)] if name == "c1" else [(1, 0)])      # (c1: the one-launch pass for small series; small hit-dense series may also take (1, 64): see job())
+    want_paths = [(2, 32), (5, 0)] if case == "moving_extremum_3d" else ([(1, 0), (2, 32), (4, 544)] if name == "c1" else [(1, 0), (5, 0)])      # (c1: the one-launch pass for small series; small hit-dense series may also take (1, 64): see job())
     out = {"workload": f"{case} {'x'.join(str(d) for d in dims)}x{nt}", "steps": steps, "ms_per_step": elapsed / steps * 1e3, "value": nsimp * steps / elapsed,
            "simplices_per_step": nsimp, "kernel": symbol, "kernel_avg_launch_ms": dom_ms / max(1, dom_n),
            "frac": alg / (dom_ms / max(1, dom_n) * 1e-3) / 1e9 / HBM_PEAK_GBS if dom_n else None,
@@ -899,7 +899,7 @@ def job(args, env):
         if (not multi or slab is not None) and not args.host_driven:
             # ((1, 64): the fused tail declined late -- few coarse cells with more records than it orders -- and the chain took the pass: device-driven
             # all the same; only the small test configurations see it)
-            want_paths = [(2, 32), (5, 0)] if case == "moving_extremum_3d" else ([(1, 0), (2, 32), (4, 544)] if args.config == "c1" else ([(1, 0), (1, 64), (4, 544)] if args.config.startswith("small") else [(1, 0)]))
+            want_paths = [(2, 32), (5, 0)] if case == "moving_extremum_3d" else ([(1, 0), (2, 32), (4, 544)] if args.config == "c1" else ([(1, 0), (1, 64), (4, 544)] if args.config.startswith("small") else [(1, 0), (5, 0)]))
             if multi:
                 want_paths = want_paths + [(4, 544)]      # (a rank's slab may be small enough for the one-launch pass where it sweeps on its own: the whole-slice recovery)
             check = check_records(args.config if args.timesteps == 0 else "", case, dims, nt, merged, timed_paths, want_paths)

@@ -149,6 +149,7 @@ struct ftkx_series_pending {
   // split pass (series.hip, "the tail next to the next mask kernel"): begin + masks on the context's stream, the tail -- counters, cull + factors,
   // the kernel chain -- on the tail stream behind an event, next to the mask kernel of the pass queued behind it
   bool split = false;
+  bool split_sparse = false;        // ... of a sparse pass: few workgroups per chain kernel, 2^10 buckets
   bool one = false;                 // the one-launch pass for small series (one_kernel.hip)
   std::vector<std::pair<unsigned char *, unsigned char *>> retired;   // (M, U) arrays this pass still reads, replaced in their slices by the pass queued behind it
   // slab pass (ftkx_series_dist_*): one rank's part of a series cut into timestep slabs, queued in stages with the caller's collectives between them

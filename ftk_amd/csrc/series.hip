@@ -175,7 +175,7 @@ void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, const unsigned *wait
 // tail of a split pass is the kernel chain with the record kernel held to 168 registers (series_record_lean_kernel: its few records do not
 // care about the scratch) and the bucket scan as one workgroup of four wavefronts.  Under the mask kernel's memory traffic every dependent
 // load of the chain takes several times as long (256^3 x 16: the chain 340 us instead of 70) -- hidden as long as the mask kernel is longer:
-// taken by pipelined, single-rank passes whose last pass was sparse and whose mask kernel reads at least kSplitMinBytes.
+// taken by pipelined, single-rank passes whose mask kernel reads at least kSplitMinBytes -- after a sparse pass, and in 2D after any.
 // What the two sides share is kept apart: the reduction slots are the pass's own (ftkx_series_buffers::red), the counters and the histogram
 // are zeroed on the tail stream, and a slice whose masks the next pass rebuilds while this pass's tail still reads them gets fresh arrays
 // (`retired`: back to the pool when this pass is completed).
@@ -204,7 +204,7 @@ void series_queue_rest(ftkx_ctx *c, const ftkx_series_pending &P, const Mesh &m,
   unsigned *flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
   hipStream_t st = tail_stream(c, P);
   // (a split pass: sparse data next to a mask kernel -- every workgroup of these kernels waits for a wavefront slot: few of them)
-  const bool few = P.split;
+  const bool few = P.split_sparse;
   if (P.two_level && !P.refined) ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, st, few ? 64 : 0);   // (a slab pass refines before it asks for patches)
   ftkx::launch_exact(m, d_steps, 0, c->d_list, c->list_capacity, st, few ? 64 : 0);
   ftkx::launch_bucket_scan(c->sr_hist, c->sr_boff, (unsigned)P.nbins, c->d_counters, st, P.split);
@@ -398,8 +398,12 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
     // stream: they do not stand between the tail and anything.)
     const long split_mode = ftkx::env_hook("FTKX_SERIES_HOOKS", "split", 1);
     const unsigned long long mask_bytes = (unsigned long long)ntodo * (unsigned long long)n_vertices(c) * 8ull * (c->scalar_mode == 1 ? 1ull : (unsigned long long)nd);
-    P.split = split_mode != 0 && pipelined && !dist && (c->profiling == 0 || c->profiling == 2) && c->sr_sparse && !P.to_device && ntodo > 0 &&
+    // hit-dense passes as well -- their chain at full grids, the records by way of the copy kernel -- in 2D, where the lean record kernel has
+    // no scratch: double_gyre 2048 x 1024 x 128 0.836 -> 0.781 ms (its mask kernel 692 -> 752 us next to the chain's 550)
+    const bool dense_too = nd == 2 || split_mode == 2;
+    P.split = split_mode != 0 && pipelined && !dist && (c->profiling == 0 || c->profiling == 2) && ((c->sr_sparse && !P.to_device) || dense_too) && ntodo > 0 &&
               (mask_bytes >= kSplitMinBytes || split_mode == 2);
+    P.split_sparse = P.split && c->sr_sparse && !P.to_device;
   }
   const bool before_split = before && before->open && before->split;
   // a slice whose masks this pass rebuilds while the tail of the pass before it -- on its own stream -- still reads them: fresh arrays here,
@@ -417,7 +421,7 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   int key_bits = 1;
   while (key_bits < 63 && (1ull << key_bits) < max_key) key_bits ++;
   // (a split pass: few records, and its scan -- one workgroup of four wavefronts next to a mask kernel -- pays several us per round of loads: 2^10)
-  const int shift = std::max(0, key_bits - (P.split ? 10 : bins_log2()));
+  const int shift = std::max(0, key_bits - (P.split_sparse ? 10 : bins_log2()));
   const size_t nbins = (size_t)((max_key - 1) >> shift) + 1;
   P.nbins = nbins;
   if (c->sr_bins_cap < nbins + 1) {
@@ -517,8 +521,9 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   // (single-rank passes: the copy waits on a word of device memory.  Slab passes: their begin kernel may sit behind the pass before it with
   // its messages from other ranks for as long as a peer lags -- sixteen workgroups would spin for that long, and give up in the end; the
   // copy is ordered behind the begin kernel by an event instead, 5 us on a path that waits for the network anyway)
-  const bool copy_by_event = copy_behind && (dist != nullptr || before->dist);
-  const bool copy_by_flag = copy_behind && !copy_by_event;
+  const bool copy_by_tail = copy_behind && before->split;      // (its finish kernel is on the tail stream: the copy goes behind that stream's event)
+  const bool copy_by_event = copy_behind && !copy_by_tail && (dist != nullptr || before->dist);
+  const bool copy_by_flag = copy_behind && !copy_by_event && !copy_by_tail;
   if (copy_by_flag && !c->sr_fetch_flag) { HIP_TRY(c, hipMalloc((void **)&c->sr_fetch_flag, 2 * sizeof(unsigned))); HIP_TRY(c, hipMemsetAsync(c->sr_fetch_flag, 0, 2 * sizeof(unsigned), c->stream)); HIP_TRY(c, hipStreamSynchronize(c->stream)); }   // (once per context; waited for: the copy stream reads it)
   const unsigned fetch_val = copy_by_flag ? ++ c->sr_fetch_seq : 0u;
   // (the pass before this one has its tail on the tail stream: a pass that is not split itself shares the counters with it in STREAM order,
@@ -531,6 +536,10 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
                             c->stream, B.h_desc, B.d_desc, total, copy_by_flag ? c->sr_fetch_flag : nullptr, fetch_val);
   c->sr_lists_owner = 0;                                      // (the begin kernel zeroes the counters and the histogram: they are nobody's until this pass's cull is queued)
   if (copy_by_flag) series_queue_copy(c, *before, c->sr_fetch_flag, fetch_val);
+  if (copy_by_tail) {
+    HIP_TRY(c, hipStreamWaitEvent(c->sr_copy_stream, c->sr_buf[before->buf].ev_tail, 0));
+    series_queue_copy(c, *before, nullptr, 0);
+  }
   if (copy_by_event) {
     if (!c->sr_ev_fetched) HIP_TRY(c, hipEventCreateWithFlags(&c->sr_ev_fetched, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->sr_ev_fetched, c->stream));

@@ -103,7 +103,7 @@ def _timed_path(gpu, case, dims, nt, nv, want_path, keep_host=False, k=5):
         runs = R.pipelined(k)
         for i, (recs, f, path) in enumerate(runs):
             # (pipelined passes over sparse data whose mask kernel is long enough: the split pass, path 5 -- its tail next to the next mask kernel)
-            assert path == want_path or (want_path == (2, SERIES_EARLY) and path == (5, 0)), (i, path, "a pass of the timed loop left the device-driven form")
+            assert path == want_path or path == (5, 0), (i, path, "a pass of the timed loop left the device-driven form")
             assert f == runs[0][1], (i, "factors differ between passes")
             assert _bytes_equal(recs, runs[0][0]), (i, len(recs), len(runs[0][0]), "pass %d differs from the first pipelined pass" % i)
         recs, f, path, st = R.alone()
@@ -115,7 +115,7 @@ def _timed_path(gpu, case, dims, nt, nv, want_path, keep_host=False, k=5):
         assert b_st["work_items"] == st["work_items"]
         # and back: the context that has just run the batch takes the device-driven form again
         again = R.pipelined(2)
-        assert all((p == want_path or (want_path == (2, SERIES_EARLY) and p == (5, 0))) and _bytes_equal(r, recs) for r, _, p in again), [p for _, _, p in again]
+        assert all((p == want_path or p == (5, 0)) and _bytes_equal(r, recs) for r, _, p in again), [p for _, _, p in again]
         return recs, f, R.host, st
     finally:
         R.close()
