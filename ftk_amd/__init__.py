@@ -275,7 +275,8 @@ class Context:
         self._ck(self._L.ftkx_sweep_series_abort(self._h))
 
     def series_last_path(self):
-        """(path, status bits) of the last sweep_series: 1 device-driven, 2 finished by the single-workgroup tail, 0 host-driven batch"""
+        """(path, status bits) of the last sweep_series: 1 device-driven (kernel chain), 2 finished by the fused tail, 4 one launch, 5 split (the
+        chain next to the next pass's mask kernel), 0 host-driven batch"""
         st = C.c_ulonglong()
         return int(self._L.ftkx_series_last_path(self._h, C.byref(st))), int(st.value)
 
