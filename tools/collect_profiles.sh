@@ -10,8 +10,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 be
 # --skip 7 = a timed pass with another one in flight; --skip 4 = a pass on its own)
 python3 tools/pass_timeline.py $OUT/trace --first series_begin_kernel,series_one_kernel --skip 7 > $OUT/timeline.txt 2>&1
 python3 tools/pass_timeline.py $OUT/trace --first series_begin_kernel,series_one_kernel --skip 4 > $OUT/timeline_single.txt 2>&1
-# the same passes with NO events between the kernels (what `sustained`, the side configurations and the streaming tracker run; round 5 had the tail of a
-# sparse pass on its own stream here, since removed) (3 warm-up + 8 timed + 3 latency passes: --skip 6 = a timed pass)
+# the same passes with NO events between the kernels (what `sustained`, the side configurations and the streaming tracker run): the split pass's
+# tail next to the next pass's mask kernel (3 warm-up + 8 timed + 3 latency passes: --skip 6 = a timed pass)
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_plain -- python3 bench.py --config $CFG --steps 8 --warmup 2 --no-kernel-events $LIGHT > $OUT/bench_under_trace_plain.log 2>&1
 python3 tools/pass_timeline.py $OUT/trace_plain --first series_begin_kernel,series_one_kernel --skip 6 > $OUT/timeline_overlap.txt 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --config $CFG --steps 2 --warmup 1 $LIGHT > $OUT/bench_under_pmc_fetch.log 2>&1

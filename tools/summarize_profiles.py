@@ -32,7 +32,7 @@ if os.path.exists(os.path.join(src, "timeline.txt")):
     shutil.copy(os.path.join(src, "timeline.txt"), os.path.join(dst, f"{tag}_{cfg}_pass_timeline.txt"))
 if os.path.exists(os.path.join(src, "timeline_single.txt")):
     shutil.copy(os.path.join(src, "timeline_single.txt"), os.path.join(dst, f"{tag}_{cfg}_pass_timeline_single.txt"))
-if os.path.exists(os.path.join(src, "timeline_overlap.txt")):      # the passes without events between the kernels (what `sustained` and the side configurations run)
+if os.path.exists(os.path.join(src, "timeline_overlap.txt")):      # the passes without events between the kernels (what `sustained` and the side configurations run): the split pass's tail next to the next mask kernel
     shutil.copy(os.path.join(src, "timeline_overlap.txt"), os.path.join(dst, f"{tag}_{cfg}_pass_timeline_plain.txt"))
 import subprocess
 try:
