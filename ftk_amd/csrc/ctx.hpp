@@ -152,6 +152,8 @@ struct ftkx_series_pending {
   bool split_sparse = false;        // ... of a sparse pass: few workgroups per chain kernel, 2^10 buckets
   bool one = false;                 // the one-launch pass for small series (one_kernel.hip)
   std::vector<std::pair<unsigned char *, unsigned char *>> retired;   // (M, U) arrays this pass still reads, replaced in their slices by the pass queued behind it
+  std::vector<ftkxh::Slice> parked;        // slices dropped (or replaced) while this split pass was the newest one open: its tail -- on a stream of its own -- may still read
+                                    // their arrays, which go back to the pools when it has been completed (free_slice)
   // slab pass (ftkx_series_dist_*): one rank's part of a series cut into timestep slabs, queued in stages with the caller's collectives between them
   bool dist = false;
   int dist_stage = 0;               // 1 begun (masks, contribution, outgoing masks), 2 culled (request written), 3 served (reply written), 4 finished = open

@@ -70,10 +70,17 @@ size_t mask_bytes(const ftkx_ctx *c) { return (size_t)mask_pitch(c) * (size_t)c-
 
 void free_slice(Slice &s, ftkx_ctx *pool_owner)
 {
+  // The newest open pass is a SPLIT pass: its tail runs on a stream of its own and may still read this slice's arrays, while whatever takes
+  // them out of the pools next -- a push, the mask kernel of the next pass -- runs on the context's stream, in no order with that tail.
+  // The slice is parked with that pass and comes back here when it has been completed (series.hip, release_retired).
+  if (pool_owner && pool_owner->sr_open > 0) {
+    ftkx_series_pending &N = pool_owner->sr_pend[(pool_owner->sr_head + pool_owner->sr_open - 1) & 1];
+    if (N.open && N.split) { N.parked.push_back(s); s = Slice(); return; }
+  }
   // owned copies go back to the context's pool: a streaming caller pushes and pops one slice per step, and hipMalloc + hipFree of a
   // slice-sized array cost more than sweeping a 256^3 slice
   auto give_back = [&](double *p, size_t count) {
-    if (pool_owner && pool_owner->pool_F.size() < 6) pool_owner->pool_F.push_back({p, count});
+    if (pool_owner && pool_owner->pool_F.size() < 12) pool_owner->pool_F.push_back({p, count});      // (12: a batch of steps parked with a split pass comes back at once)
     else (void)hipFree(p);
   };
   size_t nv = 0;
@@ -83,8 +90,8 @@ void free_slice(Slice &s, ftkx_ctx *pool_owner)
   if (s.ownJ && s.J) give_back(s.J, nv * nd_ * nd_);
   if (s.ownS && s.S) give_back(s.S, nv);
   s.ownV = s.ownJ = s.ownS = false;
-  if (s.M) { if (pool_owner && pool_owner->pool_M.size() < 4) pool_owner->pool_M.push_back(s.M); else (void)hipFree(s.M); }
-  if (s.U) { if (pool_owner && pool_owner->pool_U.size() < 4) pool_owner->pool_U.push_back(s.U); else (void)hipFree(s.U); }
+  if (s.M) { if (pool_owner && pool_owner->pool_M.size() < 12) pool_owner->pool_M.push_back(s.M); else (void)hipFree(s.M); }
+  if (s.U) { if (pool_owner && pool_owner->pool_U.size() < 12) pool_owner->pool_U.push_back(s.U); else (void)hipFree(s.U); }
   s = Slice();
 }
 
@@ -367,6 +374,7 @@ void ftkx_destroy(ftkx_ctx *c)
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto &kv : c->slices) free_slice(kv.second);
+  for (ftkx_series_pending &P : c->sr_pend) { for (Slice &sl : P.parked) free_slice(sl); P.parked.clear(); }
   release_pools(c);
   for (auto &e : c->events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);

@@ -186,6 +186,20 @@ void release_retired(ftkx_ctx *c, ftkx_series_pending &P)
 {
   for (auto &mu : P.retired) { if (mu.first) c->pool_M.push_back(mu.first); if (mu.second) c->pool_U.push_back(mu.second); }
   P.retired.clear();
+  // (slices dropped while this pass was the newest one open: called with P.open already false, so that free_slice does not park them again
+  // with THIS pass; a pass queued behind it was planned after the drop and does not know them)
+  std::vector<Slice> parked;
+  parked.swap(P.parked);
+  const bool was_open = P.open;
+  P.open = false;
+  for (Slice &sl : parked) {
+    // (free_slice parks with the newest open split pass: not this one, and a newer one never read these -- straight to the pools)
+    const int open_was = c->sr_open;
+    c->sr_open = 0;
+    free_slice(sl, c);
+    c->sr_open = open_was;
+  }
+  P.open = was_open;
 }
 
 bool short_chain_now(const ftkx_ctx *c, bool to_device, bool *small_now)

@@ -434,14 +434,17 @@ def test_tracker_with_deferred_collection(gpu, name, each_step):
     assert_records_equal(recs, g["records"], coord_tol=0.0, what=f"{name} deferred")
 
 
-@pytest.mark.parametrize("depth", [2, 3, 5])
+@pytest.mark.parametrize("depth", [2, 3, 5, -3])
 @pytest.mark.parametrize("name", ["woven_128x128x10", "woven_31x37x32", "double_gyre_64x32x50", "merger_2d_32x32x100", "moving_extremum_3d_21x21x21x32",
                                   "adversarial_3d_scalar_9x9x9x4", "adversarial_3d_vector_8x8x8x3"])
-def test_tracker_with_deferred_batches(gpu, name, depth):
+def test_tracker_with_deferred_batches(gpu, name, depth, monkeypatch):
     """set_deferred_collection(True, depth): the sweeps of `depth` consecutive update_timestep() calls go out as ONE device-driven pass (the
     snapshots popped meanwhile stay resident until it has been queued), two such passes in flight; a series whose length is not a multiple
     of the depth ends in a partial batch.  Same records (each with the timestep of ITS step) and the same final factor as the fixture."""
     from gpu_common import run_tracker
+    if depth < 0:      # batches of 3 as SPLIT passes (FTKX_SERIES_HOOKS split=2: whatever their size): the snapshots the tracker pops while a batch's tail
+        depth = -depth                       # still runs on its own stream are parked with that pass, not recycled under it (free_slice)
+        monkeypatch.setenv("FTKX_SERIES_HOOKS", "one=0,split=2")
     g = load_golden(name)
     if not _plain(g):
         pytest.skip("physical coordinates are set on the tracker")
