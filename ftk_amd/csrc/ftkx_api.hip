@@ -373,6 +373,7 @@ void ftkx_destroy(ftkx_ctx *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (hipStream_t st : {c->sr_tail_stream, c->sr_copy_stream}) if (st) (void)hipStreamSynchronize(st);      // (passes left open: their tails and copies read what is freed below)
   for (auto &kv : c->slices) free_slice(kv.second);
   for (ftkx_series_pending &P : c->sr_pend) { for (Slice &sl : P.parked) free_slice(sl); P.parked.clear(); }
   release_pools(c);
