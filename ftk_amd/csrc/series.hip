@@ -415,8 +415,10 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
     // hit-dense passes as well -- their chain at full grids, the records by way of the copy kernel -- in 2D, where the lean record kernel has
     // no scratch: double_gyre 2048 x 1024 x 128 0.836 -> 0.781 ms (its mask kernel 692 -> 752 us next to the chain's 550)
     const bool dense_too = nd == 2 || split_mode == 2;
-    P.split = split_mode != 0 && pipelined && !dist && (c->profiling == 0 || c->profiling == 2) && ((c->sr_sparse && !P.to_device) || dense_too) && ntodo > 0 &&
-              (mask_bytes >= kSplitMinBytes || split_mode == 2);
+    const bool sparse_now = c->sr_sparse && !P.to_device;
+    // (a hit-dense chain is ~550 us next to a mask kernel -- double_gyre's 56 766 records --: only mask launches of 4 GB and more hide it)
+    P.split = split_mode != 0 && pipelined && !dist && (c->profiling == 0 || c->profiling == 2) && (sparse_now || dense_too) && ntodo > 0 &&
+              (mask_bytes >= (sparse_now ? kSplitMinBytes : 2 * kSplitMinBytes) || split_mode == 2);
     P.split_sparse = P.split && c->sr_sparse && !P.to_device;
   }
   const bool before_split = before && before->open && before->split;
