@@ -669,7 +669,7 @@ class _TrackerRegular:
         self._ck(self._L.ftkx_tracker_advance_timestep(self._h))
         if hasattr(self, "_slab_keep"):             # slab mode: the snapshots stay resident until the slab's pass has run
             self._slab_keep += self._keep
-        self._keep = self._keep[-((2 * getattr(self, "_deferred_depth", 1) + 2) if getattr(self, "_deferred", False) else 2):]
+        self._keep = self._keep[-((3 * getattr(self, "_deferred_depth", 1) + 2) if getattr(self, "_deferred", False) else 2):]
 
     def update_timestep(self): self._ck(self._L.ftkx_tracker_update_timestep(self._h))
     def sync(self): self._ck(self._L.ftkx_tracker_sync(self._h))

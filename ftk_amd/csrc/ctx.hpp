@@ -149,6 +149,8 @@ struct ftkx_series_pending {
   // split pass (series.hip, "the tail next to the next mask kernel"): begin + masks on the context's stream, the tail -- counters, cull + factors,
   // the kernel chain -- on the tail stream behind an event, next to the mask kernel of the pass queued behind it
   bool split = false;
+  int before_buf = -1;              // the place of the split pass that was open when this one was planned (its factor job is waited for by this pass's tail), or -1
+  int tail_set = 0;                 // 0: the context's own counters and lists, 1: sr_set1
   bool split_sparse = false;        // ... of a sparse pass: few workgroups per chain kernel, 2^10 buckets
   bool one = false;                 // the one-launch pass for small series (one_kernel.hip)
   std::vector<std::pair<unsigned char *, unsigned char *>> retired;   // (M, U) arrays this pass still reads, replaced in their slices by the pass queued behind it
@@ -172,7 +174,7 @@ struct ftkx_series_buffers {
   ftkx_cp_t *d_out = nullptr; size_t d_out_cap = 0;   // device: the records of a pass whose way over PCIe is left to the copy kernel on its own stream
   unsigned *copy_done = nullptr;                       // that kernel's workgroup counter
   hipEvent_t ev_copied = nullptr, ev_export = nullptr;
-  hipEvent_t ev_masks = nullptr, ev_tail = nullptr;   // split pass: masks done (stream), tail done (tail stream)
+  hipEvent_t ev_masks = nullptr, ev_factors = nullptr, ev_tail = nullptr;   // split pass: masks done (stream), cull + factor job / tail done (tail stream)
   u64 *red = nullptr; size_t red_cap = 0;             // the reduction slots of this pass's mask jobs (128 words per slice): its own, the next pass's begin kernel must not wipe them
   bool copy_out = false;                               // a copy has been queued since the buffers were last used: the next record kernel waits for it
   void *h_desc = nullptr, *d_desc = nullptr; size_t desc_cap = 0;
@@ -245,15 +247,28 @@ struct ftkx_ctx {
   void *d_packed = nullptr; size_t packed_cap = 0;                                   // staging of a packed mask message for host-side callers
   // series pass (series.hip): per pass in flight the results block (device + coherent pinned copy: it also holds the fragile list, the flag
   // lives behind it), the record buffers and the descriptors; shared, in stream order: the ordering buffers
-  ftkx_series_buffers sr_buf[2];
-  ftkx_series_pending sr_pend[2];
+  static constexpr int kPlaces = 3;   // passes in flight at most: two keep the stream fed; the third lets the host run one pass ahead of a split pass's
+                                      // tail, which ends behind the mask kernel of the pass after it
+  ftkx_series_buffers sr_buf[kPlaces];
+  ftkx_series_pending sr_pend[kPlaces];
+  int sr_place(int k) const { return (sr_head + k) % kPlaces; }      // the k-th oldest open pass's place
   int sr_open = 0, sr_head = 0;       // passes open, and which of sr_pend is the oldest
   bool sr_internal = false;           // the host-driven batch is sweeping for a series pass: its calls are let through while passes are open
   // which pass the context's counters and survivor lists (d_counters, d_list, d_refine, d_pass) belong to right now: stamped when a pass's
   // cull is queued, cleared whenever the host-driven batch takes them (series.hip: a pass whose fused tail declined may queue the rest of
   // its chain only while they are still its own)
   unsigned long long sr_pass_uid = 0, sr_lists_owner = 0;
-  hipStream_t sr_copy_stream = nullptr, sr_fetch_stream = nullptr, sr_tail_stream = nullptr;
+  hipStream_t sr_copy_stream = nullptr, sr_fetch_stream = nullptr, sr_tail_stream = nullptr, sr_tail_stream2 = nullptr;
+  // what the tail of a split pass works on besides the context's own counters, lists, pass descriptors, fragile list and ordering arrays: a second
+  // set (same capacities) for every other split pass, on the second tail stream, so that the tails of two passes can run at the same time -- a
+  // mask launch shorter than one tail next to it (a single 512^3 slice) then still hides half a tail behind every mask kernel
+  struct tail_set {
+    u64 *counters = nullptr, *list = nullptr, *refine = nullptr, *pass = nullptr, *fragile = nullptr, *bucketed = nullptr, *sorted = nullptr;
+    unsigned *hist = nullptr, *boff = nullptr;
+    u64 capacity = 0, list_capacity = 0, refine_capacity = 0, fragile_capacity = 0;
+    size_t bins_cap = 0;
+  } sr_set1;
+  unsigned sr_split_seq = 0;          // split passes queued so far: their parity picks the set
   int sr_one_off = 0;                  // passes for which the one-launch form is not tried (it declined a moment ago)
   u64 *sr_one_scratch = nullptr;       // the one-launch pass's barrier counters, partial reductions and per-workgroup counts (ONE_WORDS)
   unsigned *sr_fetch_flag = nullptr;   // device: [0] the number of the last pass whose descriptors have been fetched (series_begin_kernel), [1] its arrival counter

@@ -74,7 +74,7 @@ void free_slice(Slice &s, ftkx_ctx *pool_owner)
   // them out of the pools next -- a push, the mask kernel of the next pass -- runs on the context's stream, in no order with that tail.
   // The slice is parked with that pass and comes back here when it has been completed (series.hip, release_retired).
   if (pool_owner && pool_owner->sr_open > 0) {
-    ftkx_series_pending &N = pool_owner->sr_pend[(pool_owner->sr_head + pool_owner->sr_open - 1) & 1];
+    ftkx_series_pending &N = pool_owner->sr_pend[pool_owner->sr_place(pool_owner->sr_open - 1)];
     if (N.open && N.split) { N.parked.push_back(s); s = Slice(); return; }
   }
   // owned copies go back to the context's pool: a streaming caller pushes and pops one slice per step, and hipMalloc + hipFree of a
@@ -373,7 +373,7 @@ void ftkx_destroy(ftkx_ctx *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (hipStream_t st : {c->sr_tail_stream, c->sr_copy_stream}) if (st) (void)hipStreamSynchronize(st);      // (passes left open: their tails and copies read what is freed below)
+  for (hipStream_t st : {c->sr_tail_stream, c->sr_tail_stream2, c->sr_copy_stream}) if (st) (void)hipStreamSynchronize(st);      // (passes left open: their tails and copies read what is freed below)
   for (auto &kv : c->slices) free_slice(kv.second);
   for (ftkx_series_pending &P : c->sr_pend) { for (Slice &sl : P.parked) free_slice(sl); P.parked.clear(); }
   release_pools(c);
@@ -393,12 +393,15 @@ void ftkx_destroy(ftkx_ctx *c)
     for (void *p : {(void *)B.results, (void *)B.d_out, B.d_desc, (void *)B.copy_done, (void *)B.dist_block}) if (p) (void)hipFree(p);
     if (B.ev_copied) (void)hipEventDestroy(B.ev_copied);
     if (B.ev_export) (void)hipEventDestroy(B.ev_export);
-    for (hipEvent_t e : {B.ev_masks, B.ev_tail}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {B.ev_masks, B.ev_factors, B.ev_tail}) if (e) (void)hipEventDestroy(e);
     if (B.red) (void)hipFree(B.red);
     for (void *p : {(void *)B.h_results, (void *)B.out, B.h_desc}) if (p) (void)hipHostFree(p);
   }
   if (c->sr_copy_stream) (void)hipStreamDestroy(c->sr_copy_stream);
   if (c->sr_tail_stream) (void)hipStreamDestroy(c->sr_tail_stream);
+  if (c->sr_tail_stream2) (void)hipStreamDestroy(c->sr_tail_stream2);
+  for (void *q : {(void *)c->sr_set1.counters, (void *)c->sr_set1.list, (void *)c->sr_set1.refine, (void *)c->sr_set1.pass, (void *)c->sr_set1.fragile,
+                  (void *)c->sr_set1.bucketed, (void *)c->sr_set1.sorted, (void *)c->sr_set1.hist, (void *)c->sr_set1.boff}) if (q) (void)hipFree(q);
   if (c->sr_one_scratch) (void)hipFree(c->sr_one_scratch);
   if (c->sr_fetch_flag) (void)hipFree(c->sr_fetch_flag);
   if (c->sr_ev_fetched) (void)hipEventDestroy(c->sr_ev_fetched);

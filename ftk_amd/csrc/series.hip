@@ -32,7 +32,7 @@ int series_by_host(ftkx_ctx *c, const int *ts, const int *scopes, int n, const s
   c->sr_lists_owner = 0;                                      // (the batch takes the counters and the survivor lists over)
   // (... from whatever still runs on the tail stream: the tail of a split pass queued behind the one the batch sweeps for shares them in
   // STREAM order only with its own stream -- it must be through before the batch's kernels start on the context's stream)
-  if (c->sr_tail_stream) HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream));
+  if (c->sr_tail_stream) { HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream)); HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream2)); }
   struct Through { ftkx_ctx *c; bool was; ~Through() { c->sr_internal = was; } } through{c, c->sr_internal};
   c->sr_internal = true;
   const unsigned long long hint = std::max<unsigned long long>(factor_of(*running), 256ull);
@@ -179,8 +179,42 @@ void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, const unsigned *wait
 // What the two sides share is kept apart: the reduction slots are the pass's own (ftkx_series_buffers::red), the counters and the histogram
 // are zeroed on the tail stream, and a slice whose masks the next pass rebuilds while this pass's tail still reads them gets fresh arrays
 // (`retired`: back to the pool when this pass is completed).
-constexpr unsigned long long kSplitMinBytes = 2000000000ull;
-hipStream_t tail_stream(ftkx_ctx *c, const ftkx_series_pending &P) { return P.split ? c->sr_tail_stream : c->stream; }
+constexpr unsigned long long kSplitMinBytes = 1000000000ull;
+hipStream_t tail_stream(ftkx_ctx *c, const ftkx_series_pending &P) { return P.split ? (P.tail_set ? c->sr_tail_stream2 : c->sr_tail_stream) : c->stream; }
+
+// the counters, lists and ordering arrays a pass's tail works on: the context's own, or the second set
+struct TailView { u64 *counters, *list, *refine, *pass, *fragile, *bucketed, *sorted; unsigned *hist, *boff; };
+TailView tail_view(ftkx_ctx *c, const ftkx_series_pending &P)
+{
+  if (P.tail_set == 0) return TailView{c->d_counters, c->d_list, c->d_refine, c->d_pass, c->d_fragile, c->sr_bucketed, c->sr_sorted, c->sr_hist, c->sr_boff};
+  const ftkx_ctx::tail_set &S = c->sr_set1;
+  return TailView{S.counters, S.list, S.refine, S.pass, S.fragile, S.bucketed, S.sorted, S.hist, S.boff};
+}
+// the second set at the context's capacities (they change only where everything has been waited for; its stream is drained before anything
+// of it is freed)
+int ensure_set1(ftkx_ctx *c)
+{
+  ftkx_ctx::tail_set &S = c->sr_set1;
+  if (S.counters && S.capacity == c->capacity && S.list_capacity == c->list_capacity && S.refine_capacity == c->refine_capacity &&
+      S.fragile_capacity == c->fragile_capacity && S.bins_cap == c->sr_bins_cap) return FTKX_OK;
+  if (c->sr_tail_stream2) HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream2));
+  for (void **q : {(void **)&S.counters, (void **)&S.list, (void **)&S.refine, (void **)&S.pass, (void **)&S.fragile, (void **)&S.bucketed, (void **)&S.sorted, (void **)&S.hist, (void **)&S.boff})
+    if (*q) { HIP_TRY(c, hipFree(*q)); *q = nullptr; }
+  S = ftkx_ctx::tail_set();
+  HIP_TRY(c, hipMalloc((void **)&S.counters, (ftkx::CNT_N + 128 + 8) * sizeof(u64)));
+  HIP_TRY(c, hipMemsetAsync(S.counters, 0, (ftkx::CNT_N + 128 + 8) * sizeof(u64), c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMalloc((void **)&S.list, (size_t)c->list_capacity * sizeof(u64)));
+  HIP_TRY(c, hipMalloc((void **)&S.refine, (size_t)c->refine_capacity * sizeof(u64)));
+  HIP_TRY(c, hipMalloc((void **)&S.pass, (size_t)c->capacity * sizeof(u64)));
+  HIP_TRY(c, hipMalloc((void **)&S.fragile, (size_t)c->fragile_capacity * 10 * sizeof(u64)));
+  HIP_TRY(c, hipMalloc((void **)&S.bucketed, (size_t)c->capacity * sizeof(u64)));
+  HIP_TRY(c, hipMalloc((void **)&S.sorted, (size_t)c->capacity * sizeof(u64)));
+  HIP_TRY(c, hipMalloc((void **)&S.hist, c->sr_bins_cap * sizeof(unsigned)));
+  HIP_TRY(c, hipMalloc((void **)&S.boff, c->sr_bins_cap * sizeof(unsigned)));
+  S.capacity = c->capacity; S.list_capacity = c->list_capacity; S.refine_capacity = c->refine_capacity; S.fragile_capacity = c->fragile_capacity; S.bins_cap = c->sr_bins_cap;
+  return FTKX_OK;
+}
 
 void release_retired(ftkx_ctx *c, ftkx_series_pending &P)
 {
@@ -219,13 +253,14 @@ void series_queue_rest(ftkx_ctx *c, const ftkx_series_pending &P, const Mesh &m,
   hipStream_t st = tail_stream(c, P);
   // (a split pass: sparse data next to a mask kernel -- every workgroup of these kernels waits for a wavefront slot: few of them)
   const bool few = P.split_sparse;
-  if (P.two_level && !P.refined) ftkx::launch_refine(m, d_steps, c->d_refine, c->refine_capacity, c->d_list, c->list_capacity, st, few ? 64 : 0);   // (a slab pass refines before it asks for patches)
-  ftkx::launch_exact(m, d_steps, 0, c->d_list, c->list_capacity, st, few ? 64 : 0);
-  ftkx::launch_bucket_scan(c->sr_hist, c->sr_boff, (unsigned)P.nbins, c->d_counters, st, P.split);
-  ftkx::launch_bucket_scatter(m, c->sr_boff, c->sr_bucketed, st, few ? 16 : 0);
-  ftkx::launch_bucket_rank(m, c->sr_bucketed, c->sr_boff, c->sr_sorted, B.results, st, few ? 16 : 0);
+  const TailView T = tail_view(c, P);
+  if (P.two_level && !P.refined) ftkx::launch_refine(m, d_steps, T.refine, c->refine_capacity, T.list, c->list_capacity, st, few ? 64 : 0);   // (a slab pass refines before it asks for patches)
+  ftkx::launch_exact(m, d_steps, 0, T.list, c->list_capacity, st, few ? 64 : 0);
+  ftkx::launch_bucket_scan(T.hist, T.boff, (unsigned)P.nbins, T.counters, st, P.split);
+  ftkx::launch_bucket_scatter(m, T.boff, T.bucketed, st, few ? 16 : 0);
+  ftkx::launch_bucket_rank(m, T.bucketed, T.boff, T.sorted, B.results, st, few ? 16 : 0);
   if (B.copy_out) { (void)hipStreamWaitEvent(st, B.ev_copied, 0); B.copy_out = false; }   // (the copy of the pass that used these buffers last: long through)
-  ftkx::launch_series_records(m, d_steps, c->sr_sorted, P.to_device ? B.d_out : B.out, st, P.split);
+  ftkx::launch_series_records(m, d_steps, T.sorted, P.to_device ? B.d_out : B.out, st, P.split);
   if (!P.split) ev_end(c);
   ftkx::launch_series_finish(m, B.results, P.nwords, c->list_capacity, c->refine_capacity, B.h_results, flag, seq, st);
 }
@@ -418,7 +453,7 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
     const bool sparse_now = c->sr_sparse && !P.to_device;
     // (a hit-dense chain is ~550 us next to a mask kernel -- double_gyre's 56 766 records --: only mask launches of 4 GB and more hide it)
     P.split = split_mode != 0 && pipelined && !dist && (c->profiling == 0 || c->profiling == 2) && (sparse_now || dense_too) && ntodo > 0 &&
-              (mask_bytes >= (sparse_now ? kSplitMinBytes : 2 * kSplitMinBytes) || split_mode == 2);
+              (mask_bytes >= (sparse_now ? kSplitMinBytes : 4 * kSplitMinBytes) || split_mode == 2);
     P.split_sparse = P.split && c->sr_sparse && !P.to_device;
   }
   const bool before_split = before && before->open && before->split;
@@ -472,13 +507,18 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
       HIP_TRY(c, hipStreamCreateWithPriority(&c->sr_tail_stream, hipStreamNonBlocking, hi));    // (the tail is a latency chain: it goes first wherever a slot frees up)
+      HIP_TRY(c, hipStreamCreateWithPriority(&c->sr_tail_stream2, hipStreamNonBlocking, hi));
     }
     for (ftkx_series_buffers &X : c->sr_buf)
-      for (hipEvent_t *e : {&X.ev_masks, &X.ev_tail}) if (!*e) HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+      for (hipEvent_t *e : {&X.ev_masks, &X.ev_factors, &X.ev_tail}) if (!*e) HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
+  // (every other split pass works on the second set of counters and lists, on the second tail stream: two tails at a time)
+  P.tail_set = P.split ? (int)(c->sr_split_seq ++ & 1u) : 0;
+  P.before_buf = before_split ? before->buf : -1;
+  if (P.tail_set == 1 && (rc = ensure_set1(c))) return rc;
   if (P.to_device && !c->sr_copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->sr_copy_stream, hipStreamNonBlocking));
   fill_mesh(c, m);                                           // (the buffers may have moved)
-  m.hist = c->sr_hist; m.hist_shift = shift; m.core_cells = cells;
+  m.hist = tail_view(c, P).hist; m.hist_shift = shift; m.core_cells = cells;
   {
     MaskJob *jobs = (MaskJob *)((char *)B.h_desc + off_jobs);
     Fields *steps = (Fields *)((char *)B.h_desc + off_steps);
@@ -585,8 +625,9 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   if (P.split) {
     // the tail's side: behind the masks (an event), the counters and the histogram zeroed there
     HIP_TRY(c, hipEventRecord(B.ev_masks, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->sr_tail_stream, B.ev_masks, 0));
-    ftkx::launch_series_tail_begin(c->d_counters, c->sr_hist, nbins + 1, B.results, nwords, c->sr_tail_stream);
+    const TailView T = tail_view(c, P);
+    HIP_TRY(c, hipStreamWaitEvent(tail_stream(c, P), B.ev_masks, 0));
+    ftkx::launch_series_tail_begin(T.counters, T.hist, nbins + 1, B.results, nwords, tail_stream(c, P));
   }
   P.running_from = prev ? c->sr_buf[prev->buf].results : nullptr;
   P.pipelined = pipelined;
@@ -598,7 +639,9 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
 void series_mesh(ftkx_ctx *c, const ftkx_series_pending &P, Mesh &m)
 {
   fill_mesh(c, m);
-  m.hist = c->sr_hist; m.hist_shift = P.shift; m.core_cells = P.cells;
+  const TailView T = tail_view(c, P);
+  m.counters = T.counters; m.pass = T.pass; m.fragile = T.fragile;
+  m.hist = T.hist; m.hist_shift = P.shift; m.core_cells = P.cells;
 }
 
 // stage 2: the cull, with the factor job riding in it
@@ -612,7 +655,11 @@ int series_queue_cull(ftkx_ctx *c, ftkx_series_pending &P)
   const ftkx::SeriesSlice *d_slices = (const ftkx::SeriesSlice *)((char *)B.d_desc + P.off_slices);
   const ftkx::SeriesStep *d_sinfo = (const ftkx::SeriesStep *)((char *)B.d_desc + P.off_sinfo);
   hipStream_t st = tail_stream(c, P);
+  const TailView T = tail_view(c, P);
   if (!P.split) ev_begin(c, K_CULL);
+  // (two tails at a time: this pass's factor job continues from the running minimum the factor job of the pass before it leaves -- on the
+  // other tail stream)
+  if (P.split && P.before_buf >= 0 && tail_stream(c, c->sr_pend[P.before_buf]) != st) HIP_TRY(c, hipStreamWaitEvent(st, c->sr_buf[P.before_buf].ev_factors, 0));
   P.uid = ++ c->sr_pass_uid;
   c->sr_lists_owner = P.uid;                                  // (from here on the counters and lists hold this pass's cull)
   {
@@ -622,15 +669,16 @@ int series_queue_cull(ftkx_ctx *c, ftkx_series_pending &P)
     const u64 *running_from = P.running_from;
     ftkx::FactorJob fj;
     memset(&fj, 0, sizeof(fj));
-    fj.steps = d_steps; fj.slices = d_slices; fj.sinfo = d_sinfo; fj.red = B.red; fj.running_from = running_from; fj.results = B.results; fj.counters = c->d_counters;
+    fj.steps = d_steps; fj.slices = d_slices; fj.sinfo = d_sinfo; fj.red = B.red; fj.running_from = running_from; fj.results = B.results; fj.counters = T.counters;
     fj.running_in = running_from ? DBL_MAX : P.running_in; fj.safe_m = safe_m; fj.nsteps = n; fj.nslices = (int)k;
     const bool fold_on = ftkx::env_hook("FTKX_SERIES_HOOKS", "fold", 1) != 0;
     fj.enabled = (fold_on && k <= (size_t)ftkx::kFoldMaxSlices) ? 1 : 0;
-    if (P.two_level) ftkx::launch_cull_coarse(m, d_steps, n, c->d_refine, c->refine_capacity, st, &fj);
-    else ftkx::launch_cull(m, d_steps, n, c->d_list, c->list_capacity, st, &fj);
-    if (!fj.enabled) ftkx::launch_series_factors(d_steps, n, d_slices, (int)k, d_sinfo, B.red, fj.running_in, running_from, safe_m, B.results, c->d_counters, st);
+    if (P.two_level) ftkx::launch_cull_coarse(m, d_steps, n, T.refine, c->refine_capacity, st, &fj);
+    else ftkx::launch_cull(m, d_steps, n, T.list, c->list_capacity, st, &fj);
+    if (!fj.enabled) ftkx::launch_series_factors(d_steps, n, d_slices, (int)k, d_sinfo, B.red, fj.running_in, running_from, safe_m, B.results, T.counters, st);
   }
-  if (!P.split) ev_end(c);
+  if (P.split) HIP_TRY(c, hipEventRecord(B.ev_factors, st));
+  else ev_end(c);
   HIP_TRY(c, hipGetLastError());
   return FTKX_OK;
 }
@@ -694,12 +742,13 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
   ftkx_series_buffers &B = c->sr_buf[P.buf];
   unsigned *flag = reinterpret_cast<unsigned *>(B.h_results + B.h_results_cap);
   Mesh m; fill_mesh(c, m);
-  m.hist = c->sr_hist; m.hist_shift = P.shift; m.core_cells = P.cells;
+  { const TailView T = tail_view(c, P); m.counters = T.counters; m.pass = T.pass; m.fragile = T.fragile; m.hist = T.hist; }
+  m.hist_shift = P.shift; m.core_cells = P.cells;
   if (const char *why = ftkx::wait_flag(flag, P.seq, tail_stream(c, P))) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
   release_retired(c, P);                                     // (the tail that read them is through)
   // (with no pass left open the tail stream is at its end: waited for, so that whatever the caller does next on the context's stream --
   // a host-driven batch, a pass that is not split -- finds the counters and lists idle)
-  if (P.split && c->sr_open == 0) HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream));
+  if (P.split && c->sr_open == 0) { HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream)); HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream2)); }
 
   // ---- what came back ----------------------------------------------------------------------------------------------------------------
   // (whoever stored the flag -- the fused tail, finishing or declining, or the finish kernel -- copied the whole results block first: the
@@ -762,7 +811,7 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     if (status & ftkx::SERIES_TAIL_PENDING) {
       const unsigned seq2 = ++ B.seq;
       series_queue_rest(c, P, m, seq2);
-      if (P.split) HIP_TRY(c, hipEventRecord(B.ev_tail, c->sr_tail_stream));
+      if (P.split) HIP_TRY(c, hipEventRecord(B.ev_tail, tail_stream(c, P)));
       HIP_TRY(c, hipGetLastError());
       if (const char *why = ftkx::wait_flag(flag, seq2, tail_stream(c, P))) return fail(c, FTKX_E_DEVICE, "ftkx_sweep_series: %s", why);
       status = R[ftkx::SR_STATUS];                           // (the finish kernel's copy of the block: the same reductions, the final counters)
@@ -778,7 +827,10 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     if (status & ftkx::SERIES_OVERFLOW) {                    // grow what was too small (the host-driven batch would find out the same way, one replay later)
       const u64 *cnt = R + ftkx::SR_COUNTERS;
       const u64 hits = cnt[ftkx::CNT_PASS], listed = cnt[ftkx::CNT_LIST_PEAK], refined = cnt[ftkx::CNT_REFINE_PEAK], fragile = cnt[ftkx::CNT_FRAGILE];
-      if (c->sr_open > 0) HIP_TRY(c, hipStreamSynchronize(c->stream));   // (a pass queued behind this one still uses the buffers)
+      if (c->sr_open > 0) {                                  // (a pass queued behind this one still uses the buffers)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->sr_tail_stream) { HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream)); HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream2)); }
+      }
       if (hits > c->capacity && (rc = ensure_hit_buffer(c, hits + hits / 8 + 1024))) return rc;
       if (listed > c->list_capacity && (rc = ensure_list(c, listed + listed / 8 + 1024))) return rc;
       if (refined > c->refine_capacity && (rc = ensure_refine(c, refined + refined / 8 + 1024))) return rc;
@@ -866,7 +918,7 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
 // not count in sr_open yet -- no other pass may be queued, swept or completed until it has been finished (or aborted)
 static bool slab_half_queued(const ftkx_ctx *c)
 {
-  const ftkx_series_pending &Q = c->sr_pend[(c->sr_head + c->sr_open) & 1];
+  const ftkx_series_pending &Q = c->sr_pend[c->sr_place(c->sr_open)];
   return Q.dist && Q.dist_stage > 0 && Q.dist_stage < 4;
 }
 
@@ -877,15 +929,15 @@ int ftkx_sweep_series_submit(ftkx_ctx *c, const int *ts, const int *scopes, int 
   if (!c || n <= 0 || !ts || !scopes) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: null argument or no steps");
   if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "sweep: call ftkx_set_mesh first");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: sweeps pending, collect first");
-  if (c->sr_open >= 2) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: two passes are open, complete one first");
+  if (c->sr_open >= ftkx_ctx::kPlaces) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: three passes are open, complete one first");
   if (slab_half_queued(c)) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: a slab pass is half queued (ftkx_series_dist_finish or ftkx_sweep_series_abort first)");
   if (!running_resolution && c->sr_open == 0) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: no pass open to continue from, give the running resolution");
   if (running_resolution && !(*running_resolution > 0)) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_submit: the running resolution must be positive (DBL_MAX: none yet)");
   c->ahead.clear(); c->announced.clear();
   HIP_TRY(c, hipSetDevice(c->device));
-  ftkx_series_pending *before = c->sr_open > 0 ? &c->sr_pend[(c->sr_head + c->sr_open - 1) & 1] : nullptr;
+  ftkx_series_pending *before = c->sr_open > 0 ? &c->sr_pend[c->sr_place(c->sr_open - 1)] : nullptr;
   const ftkx_series_pending *prev = (!running_resolution) ? before : nullptr;
-  ftkx_series_pending &P = c->sr_pend[(c->sr_head + c->sr_open) & 1];
+  ftkx_series_pending &P = c->sr_pend[c->sr_place(c->sr_open)];
   // (a chain starts here: what the host knows of its running minimum is what the caller says -- not what an earlier series left behind, whose
   // smaller value would make the hint of the passes chained behind this one larger than their factor)
   if (running_resolution) c->sr_last_running = *running_resolution;
@@ -905,7 +957,7 @@ int ftkx_sweep_series_complete(ftkx_ctx *c, double *running_resolution, unsigned
   if (slab_half_queued(c)) return fail(c, FTKX_E_INVALID, "ftkx_sweep_series_complete: a slab pass is half queued (ftkx_series_dist_finish or ftkx_sweep_series_abort first)");
   HIP_TRY(c, hipSetDevice(c->device));
   ftkx_series_pending &P = c->sr_pend[c->sr_head];
-  c->sr_head ^= 1; c->sr_open --;
+  c->sr_head = (c->sr_head + 1) % ftkx_ctx::kPlaces; c->sr_open --;
   *running_resolution = P.chained ? c->sr_last_running : P.running_in;   // (a chained pass continues from what the pass before it returned)
   int rc = series_complete(c, P, running_resolution, factors, out, n_out);
   if (rc == FTKX_OK) c->sr_last_running = *running_resolution;
@@ -927,7 +979,7 @@ size_t dist_cells_cap(const ftkx_ctx *c)
 }
 ftkx_series_pending *dist_pending(ftkx_ctx *c, int stage, const char *who)
 {
-  ftkx_series_pending &P = c->sr_pend[(c->sr_head + c->sr_open) & 1];
+  ftkx_series_pending &P = c->sr_pend[c->sr_place(c->sr_open)];
   if (!P.dist || P.dist_stage != stage) { fail(c, FTKX_E_INVALID, "%s: no slab pass at that stage (ftkx_series_dist_begin, _cull, _serve, _finish in this order)", who); return nullptr; }
   return &P;
 }
@@ -942,14 +994,14 @@ int ftkx_series_dist_begin(ftkx_ctx *c, const int *ts, const int *scopes, int n,
   if (!c || n <= 0 || !ts || !scopes || !running_resolution || !contrib || !gathered) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: null argument or no steps");
   if (!c->mesh_set) return fail(c, FTKX_E_INVALID, "sweep: call ftkx_set_mesh first");
   if (!c->pending.empty()) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: sweeps pending, collect first");
-  if (c->sr_open >= 2) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: two passes are open, complete one first");
+  if (c->sr_open >= 2) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: two passes are open, complete one first");      // (slab passes: two, as their callers keep)
   if (rank < 0 || rank >= nranks) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: rank %d of %d", rank, nranks);
   if (!(*running_resolution > 0)) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: the running resolution must be positive (DBL_MAX: none yet)");
   if (halo && (upper <= rank || upper >= nranks || !(scopes[n - 1] & FTKX_SCOPE_INTERVAL))) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: the upper neighbour must be a later rank, and the last step an interval sweep");
   if (c->scalar_mode < 0) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: push this rank's slices first");
   c->ahead.clear(); c->announced.clear();
   HIP_TRY(c, hipSetDevice(c->device));
-  ftkx_series_pending &Q = c->sr_pend[(c->sr_head + c->sr_open) & 1];
+  ftkx_series_pending &Q = c->sr_pend[c->sr_place(c->sr_open)];
   if (slab_half_queued(c)) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: a slab pass is half queued (finish or abort it)");
   int rc;
   {
@@ -958,7 +1010,7 @@ int ftkx_series_dist_begin(ftkx_ctx *c, const int *ts, const int *scopes, int n,
   }
   const int t_halo = halo ? ts[n - 1] + 1 : -1;
   if (halo && (rc = ensure_sparse_slice(c, t_halo, c->scalar_mode))) return rc;
-  ftkx_series_pending *before = c->sr_open > 0 ? &c->sr_pend[(c->sr_head + c->sr_open - 1) & 1] : nullptr;
+  ftkx_series_pending *before = c->sr_open > 0 ? &c->sr_pend[c->sr_place(c->sr_open - 1)] : nullptr;
   DistPlan dp{t_halo, rank, nranks, upper, (const u64 *)gathered, (u64 *)contrib, masks_out, (hipStream_t)side_stream};
   if ((rc = series_plan(c, Q, ts, scopes, n, *running_resolution, nullptr, true, before, &dp))) { Q.open = false; Q.dist = false; return rc; }
   if (Q.by_host) {      // (options the device-driven form does not cover: a slab pass has no host-driven form of its own -- the caller's protocol does)
@@ -1090,6 +1142,7 @@ int ftkx_sweep_series_abort(ftkx_ctx *c)
   hipError_t e = hipStreamSynchronize(c->stream);
   if (c->sr_copy_stream && e == hipSuccess) e = hipStreamSynchronize(c->sr_copy_stream);
   if (c->sr_tail_stream && e == hipSuccess) e = hipStreamSynchronize(c->sr_tail_stream);
+  if (c->sr_tail_stream2 && e == hipSuccess) e = hipStreamSynchronize(c->sr_tail_stream2);
   for (ftkx_series_pending &P : c->sr_pend) {
     if (P.dist && P.dist_stage > 0 && P.dist_stage < 4) { P.open = true; }      // (a slab pass that was never finished: its masks are nobody's either)
     if (!P.open) continue;

@@ -295,7 +295,7 @@ void critical_point_tracker_regular::submit_batch() const
   if (rc == FTKX_OK) open_steps.push_back(-1);
   for (int t : drops) { const int rc2 = ftkx_drop_slice(ctx, t); if (rc == FTKX_OK) rc = rc2; }
   check(rc);
-  if (open_steps.size() >= 2) collect_open_step();
+  if (open_steps.size() >= 3) collect_open_step();      // (three in flight: the host runs one pass ahead of a split pass's tail)
 }
 
 void critical_point_tracker_regular::sync() const
@@ -564,7 +564,7 @@ void critical_point_tracker_regular::update_timestep()
       const bool chained = !open_steps.empty();
       check(ftkx_sweep_series_submit(ctx, &current_timestep, &scope, 1, chained ? nullptr : &vector_field_resolution));
       open_steps.push_back(current_timestep);
-      if (open_steps.size() >= 2) collect_open_step();
+      if (open_steps.size() >= 3) collect_open_step();      // (three in flight: the host runs one pass ahead of a split pass's tail)
       return;
     }
     if (!batch_ts.empty()) submit_batch();

@@ -205,8 +205,10 @@ int ftkx_sweep_cancel(ftkx_ctx *ctx);    /* forgets the enqueued, not yet collec
 int ftkx_sweep_series(ftkx_ctx *ctx, const int *timesteps, const int *scopes, int n, double *running_resolution,
                       unsigned long long *factors, const ftkx_cp_t **out, size_t *n_out);
 /* The same pass in two halves, for callers that keep the device busy across passes (a streaming tracker, bench.py): _submit queues a
- * pass and returns; _complete waits for the OLDEST open pass and returns what ftkx_sweep_series returns.  At most two passes are open at
- * a time: submit(N), submit(N + 1), complete(N), submit(N + 2), complete(N + 1), ...  While pass N + 1's mask kernel runs, the host
+ * pass and returns; _complete waits for the OLDEST open pass and returns what ftkx_sweep_series returns.  At most three passes are open at
+ * a time; two keep the device busy -- submit(N), submit(N + 1), complete(N), submit(N + 2), complete(N + 1), ... --, the third lets the
+ * host run one pass ahead of a split pass's tail (ftkx_series_last_path = 5), which ends behind the mask kernel of the pass after it
+ * (slab passes, ftkx_series_dist_*: two).  While pass N + 1's mask kernel runs, the host
  * collects pass N, and the records of a pass with many of them cross PCIe on a copy engine instead of holding the stream.
  * running_resolution of _submit: the running minimum before this pass, or NULL = continue from the pass queued before it, still open
  * (the minimum is handed on ON THE DEVICE; _complete then reports the chained value).  Between _submit and _complete only slices may be

@@ -220,7 +220,7 @@ protected:
   bool is_jacobian_field_symmetric = false;
   bool enable_robust_detection = true, enable_computing_degrees = false, enable_streaming_trajectories = false;
   bool deferred_collection = false;
-  mutable std::vector<int> open_steps;                      // deferred collection: the timesteps of the sweeps that are queued and not yet collected (at most two)
+  mutable std::vector<int> open_steps;                      // deferred collection: the timesteps of the sweeps that are queued and not yet collected (at most three)
   void collect_open_step() const;
   int deferred_depth = 1;
   mutable std::vector<int> batch_ts, batch_scopes, batch_drops;    // deferred collection in batches: the steps recorded and not yet queued; the snapshots popped meanwhile

@@ -484,6 +484,53 @@ def test_tracker_with_deferred_batches_looked_at_midway(gpu):
     assert np.array_equal(ts[np.argsort(recs["tag"], kind="stable")], g["records"]["timestep"][np.argsort(g["records"]["tag"], kind="stable")])
 
 
+@pytest.mark.parametrize("hooks", ["one=0", "one=0,split=2"], ids=["in_order", "split"])
+@pytest.mark.parametrize("name", ["moving_extremum_3d_21x21x21x32", "woven_128x128x10", "double_gyre_64x32x50"])
+def test_three_passes_in_flight(gpu, name, hooks, monkeypatch):
+    """three passes open at a time (the third lets the host run one pass ahead of a split pass's tail; split passes alternate between two sets
+    of counters and lists, on two tail streams): the whole series again and again, masks dropped in between, and a chain of pieces that
+    each continue on the device from the one before -- records, factors and running minima of ftkx_sweep_series; a fourth submit is refused"""
+    monkeypatch.setenv("FTKX_SERIES_HOOKS", hooks)
+    g = load_golden(name)
+    nd, nv, nt = g["nd"], g["nv"], g["DT"]
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    ctx = _ctx(gpu, g["dims"], nd, nv, tag_mode=gpu.TAG_EXACT64, robust=int(g["robust"]), compute_degrees=int(g["degrees"]))
+    _push_all(ctx, g["steps"], nv)
+    want, wf, wrun = ctx.sweep_series(range(nt), scopes)
+    for _ in range(2):
+        ctx.invalidate_masks(); ctx.sweep_series_submit(range(nt), scopes)
+    for it in range(6):
+        ctx.invalidate_masks(); ctx.sweep_series_submit(range(nt), scopes)
+        if it == 0:
+            with pytest.raises(Exception):
+                ctx.sweep_series_submit(range(nt), scopes)
+        got, f, run = ctx.sweep_series_complete()
+        assert _same(got, want) and np.array_equal(f, wf) and run == wrun, (name, it, len(got), len(want))
+    for _ in range(2):
+        got, f, run = ctx.sweep_series_complete()
+        assert _same(got, want) and np.array_equal(f, wf) and run == wrun
+    # pieces of two steps, chained on the device, three open
+    pieces = [list(range(a, min(a + 2, nt))) for a in range(0, nt, 2)]
+    ctx.invalidate_masks()
+    ref, run = [], None
+    for p in pieces:
+        sc = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in p]
+        r, f, run = ctx.sweep_series(p, sc, running_resolution=run)
+        ref.append((r, [int(v) for v in f]))
+    ctx.invalidate_masks()
+    done = []
+    for i, p in enumerate(pieces):
+        sc = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in p]
+        ctx.sweep_series_submit(p, sc, chain=i > 0)
+        if i >= 2:
+            done.append(ctx.sweep_series_complete())
+    while len(done) < len(pieces):
+        done.append(ctx.sweep_series_complete())
+    for i, (r, f, run) in enumerate(done):
+        assert _same(r, ref[i][0]) and [int(v) for v in f] == ref[i][1], (name, i, len(r), len(ref[i][0]))
+    ctx.close()
+
+
 def test_pipelined_records_through_the_copy_engine(gpu):
     """more than 4096 records per pass: from the second pipelined pass on the record kernel leaves them in device memory and the copy
     engine brings them over while the next pass runs; records and factors as ftkx_sweep_series returns them"""
