@@ -74,6 +74,11 @@ def spread(samples_ms):
             "ms_per_step_samples": [round(float(v), 4) for v in np.asarray(samples_ms, dtype=np.float64)[:64]]}     # (in the order the passes completed)
 
 
+# passes in flight in the timed loops: two keep the stream fed; the third lets the host run one pass ahead of a split pass's tail, which ends
+# behind the mask kernel of the pass after it
+IN_FLIGHT = int(os.environ.get("FTKX_BENCH_IN_FLIGHT", "3"))
+
+
 def check_records(name, case, dims, nt, recs, paths, want_paths):
     """the result of the timed passes against what the configuration must give; -> the `check` object (ok: everything held)"""
     from ftk_amd import synthetic
@@ -219,21 +224,22 @@ def side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=5, warmup=2):
     stamps = []
 
     def passes(k, count):
-        # two passes in flight, like the headline run (main(): passes)
-        ctx.invalidate_masks()
-        ctx.sweep_series_submit(ts, scopes)
-        for i in range(1, k + 1):
-            if i < k:
+        # up to IN_FLIGHT passes in flight, like the headline run (main(): passes)
+        submitted = done = 0
+        while done < k:
+            while submitted < k and submitted - done < IN_FLIGHT:
                 ctx.invalidate_masks()
                 ctx.sweep_series_submit(ts, scopes)
+                submitted += 1
             recs, f, _r = ctx.sweep_series_complete(copy=False)
+            done += 1
             if count:
                 stamps.append(time.perf_counter())
                 p = ctx.series_last_path()
                 path_list.append(p)
                 paths[str(p)] = paths.get(str(p), 0) + 1
         return recs, f
-    recs, f = passes(max(warmup, 6), False)      # (see main(): everything a pass allocates exists before the clock starts)
+    recs, f = passes(max(warmup, 8), False)      # (see main(): everything a pass allocates exists before the clock starts)
     # no HIP events inside the timed region of a side configuration: a pair costs the stream ~10 us, which a 0.2 ms pass notices; the
     # dominant kernel is timed in extra passes behind it
     ctx.set_profiling(0)
@@ -381,7 +387,7 @@ def streaming_tracker(nd, case, dims, nt_run, torch, dev, ftk_amd, synthetic, ho
         best = dt if best is None or dt < best else best
     out["device_resident_deferred_4"] = {"timesteps": nt_run, "ms_per_step": best / nt_run * 1e3, "records": int(nrec3),
                                          "note": "set_deferred_collection(True, 4): the same per-step calls; the sweeps of four consecutive steps are queued as ONE pass (one mask "
-                                                 "launch, one tail) when the fourth is advanced, two passes in flight; same records, visible up to 2 x 4 steps later; sync() inside "
+                                                 "launch, one tail) when the fourth is advanced, up to three passes in flight; same records, visible up to 3 x 4 steps later; sync() inside "
                                                  "the timed series; best of 3"}
     # host-fed: numpy arrays in pageable memory, like an ndarray<double> of the reference
     h = min(host_steps, nt_run)
@@ -505,7 +511,7 @@ def main():
     ap.add_argument("--timesteps", type=int, default=0, help="override the length of the series")
     ap.add_argument("--no-cull-ahead", action="store_true", help="experiment: do not announce the sweeps to slices_prepare (the cull then waits for the factors)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the kernels (what do they cost a pass?); the line then carries no roofline")
-    ap.add_argument("--no-pipeline", action="store_true", help="N = 1: one pass after the other (ftkx_sweep_series) instead of two passes in flight (ftkx_sweep_series_submit / _complete)")
+    ap.add_argument("--no-pipeline", action="store_true", help="N = 1: one pass after the other (ftkx_sweep_series) instead of passes in flight (ftkx_sweep_series_submit / _complete)")
     ap.add_argument("--host-driven", action="store_true", help="N = 1: the host-driven batch (slices_prepare, factors on the host, enqueue, collect) instead of the device-driven ftkx_sweep_series")
     ap.add_argument("--no-streaming-tracker", action="store_true", help="N = 1: skip the per-timestep tracker measurement (device-resident and host-fed) that follows the timed region")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the few passes of the other BASELINE configurations that follow the timed region")
@@ -728,7 +734,7 @@ def job(args, env):
     pipelined = (not multi or slab is not None) and (not args.host_driven) and (not args.no_pipeline) and (not args.exact_only)
 
     def passes(k):
-        """k passes.  One GPU, device-driven: two passes in flight (ftkx_sweep_series_submit / _complete) -- the host prepares and queues
+        """k passes.  One GPU, device-driven: up to IN_FLIGHT passes in flight (ftkx_sweep_series_submit / _complete) -- the host prepares and queues
         pass i + 1 while the device works on pass i, and the records of pass i cross PCIe on a copy engine while the mask kernel of pass
         i + 1 runs; every pass still does ALL the work and hands its records to the host.  Otherwise: one pass after the other."""
         if not pipelined or k < 2:
@@ -741,11 +747,14 @@ def job(args, env):
         def submit():
             ctx.invalidate_masks()
             slab.submit() if slab is not None else ctx.sweep_series_submit(ann_ts, ann_scopes)
-        submit()
-        for i in range(1, k + 1):
-            if i < k:
+        in_flight = IN_FLIGHT if slab is None else 2          # (slab passes: two)
+        submitted = done = 0
+        while done < k:
+            while submitted < k and submitted - done < in_flight:
                 submit()
+                submitted += 1
             recs, f, _ = slab.complete(copy=False) if slab is not None else ctx.sweep_series_complete(copy=False)
+            done += 1
             pass_stamps.append(time.perf_counter())
             p = slab.last_path if slab is not None else ctx.series_last_path()
             if own:
@@ -756,11 +765,11 @@ def job(args, env):
         return recs, ctx.stats()
 
     if args.warmup or pipelined:
-        # (two in flight, a third pass so that one has been queued KNOWING how many records the data gives, and three more so that the
+        # (passes in flight, one queued KNOWING how many records the data gives, and enough of them that the
         # split pass -- taken from the third pass on -- has its stream, its events and the second set of mask arrays it swaps in for the slices
         # the pass before still reads (512^3 x 32: 4.3 GB of hipMalloc, 48 ms once): both sets of buffers, the device-side record buffers, the
         # copy and tail streams exist before the clock starts -- also when --warmup 0 is asked for)
-        recs, st = passes(max(args.warmup, 6) if pipelined else args.warmup)
+        recs, st = passes(max(args.warmup, 8) if pipelined else args.warmup)
     # HIP events on the stream the kernels run on: around the dominant (mask) kernel only inside the timed region -- a pair of events costs
     # the stream ~10 us of idle time, which a 0.4 ms pass notices --, around every kernel family in a few extra passes afterwards
     ctx.set_profiling(0 if args.no_kernel_events else (1 if args.exact_only else 2))     # (--exact-only: the dominant kernel is the tile kernel)
@@ -960,7 +969,7 @@ def job(args, env):
                        "simplices_per_step": total_simplices, "exact_only": bool(args.exact_only),
                        "nbits": int(np.log2(max(int(v) for v in getattr(one_pass, "factors", factors)))), "cull": bool(st["cull_enabled"]),
                        "pass": ((("device-driven slab pass (ftkx_series_dist_* with the collectives queued between its stages)" + (", two passes in flight" if pipelined else "")) if slab is not None else
-                                 "device-driven, two passes in flight (ftkx_sweep_series_submit / _complete)" if pipelined else "device-driven (ftkx_sweep_series)") +
+                                 "device-driven, up to %d passes in flight (ftkx_sweep_series_submit / _complete)" % IN_FLIGHT if pipelined else "device-driven (ftkx_sweep_series)") +
                                 ": paths taken {(path, status): passes} = %s" % {str(k): v for k, v in series_paths.items()}) if series_paths
                                else "host-driven batch (slices_prepare, host factors, enqueue, collect)",
                        "input_resident": "the field the tracker API is given (S, or V for vector input) in HBM; gradient/Jacobian evaluated in flight"},
