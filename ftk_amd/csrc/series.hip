@@ -441,15 +441,18 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   if ((rc = ensure_list(c, std::max<u64>(c->list_capacity, 1u << 20))) || (rc = ensure_refine(c, std::max<u64>(c->refine_capacity, 1u << 20)))) return rc;
   // split?  (decided here: the begin kernel of a split pass leaves the counters to the tail stream)
   P.to_device = false;
+  const unsigned long long mask_bytes_of_pass = (unsigned long long)ntodo * (unsigned long long)n_vertices(c) * 8ull * (c->scalar_mode == 1 ? 1ull : (unsigned long long)nd);
   {
     P.to_device = pipelined && c->stats.hits > 4096;
     // split?  hook: 0 never, 2 whatever the size (tests).  (Profiling level 2 times the mask kernel only, with events on the context's
     // stream: they do not stand between the tail and anything.)
     const long split_mode = ftkx::env_hook("FTKX_SERIES_HOOKS", "split", 1);
-    const unsigned long long mask_bytes = (unsigned long long)ntodo * (unsigned long long)n_vertices(c) * 8ull * (c->scalar_mode == 1 ? 1ull : (unsigned long long)nd);
-    // hit-dense passes as well -- their chain at full grids, the records by way of the copy kernel -- in 2D, where the lean record kernel has
-    // no scratch: double_gyre 2048 x 1024 x 128 0.836 -> 0.781 ms (its mask kernel 692 -> 752 us next to the chain's 550)
-    const bool dense_too = nd == 2 || split_mode == 2;
+    const unsigned long long mask_bytes = mask_bytes_of_pass;
+    // hit-dense passes as well (hook 3; 2 for the tests) -- their chain at full grids, the records by way of the copy kernel: double_gyre
+    // 2048 x 1024 x 128 0.836 -> 0.78 ms (its mask kernel 692 -> 752 us next to the chain's 550) in a fresh process, but 0.93-0.97 where the
+    // tail stream's priority does not take -- it needs it, its big grids queue behind the mask kernel's pending workgroups otherwise, and
+    // after another hit-dense context in the same process it does not get it (cause not found: NOTES.md).  Not by default.
+    const bool dense_too = split_mode == 3 || split_mode == 2;
     const bool sparse_now = c->sr_sparse && !P.to_device;
     // (a hit-dense chain is ~550 us next to a mask kernel -- double_gyre's 56 766 records --: only mask launches of 4 GB and more hide it)
     P.split = split_mode != 0 && pipelined && !dist && (c->profiling == 0 || c->profiling == 2) && (sparse_now || dense_too) && ntodo > 0 &&
@@ -512,8 +515,12 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
     for (ftkx_series_buffers &X : c->sr_buf)
       for (hipEvent_t *e : {&X.ev_masks, &X.ev_factors, &X.ev_tail}) if (!*e) HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
-  // (every other split pass works on the second set of counters and lists, on the second tail stream: two tails at a time)
-  P.tail_set = P.split ? (int)(c->sr_split_seq ++ & 1u) : 0;
+  // (every other split pass of a SHORT mask launch works on the second set of counters and lists, on the second tail stream: two tails at a
+  // time, each hidden behind two mask kernels.  Where one mask kernel hides a whole tail -- 2 GB and more -- the tails stay one behind the
+  // other: two of them at once slow each other and the mask kernel down until the tails are what a pass takes: 256^3 x 16 0.41 -> 0.49 ms,
+  // double_gyre 0.77 -> 0.97, in some runs and not in others)
+  const bool two_tails = P.split_sparse && mask_bytes_of_pass < 2 * kSplitMinBytes;
+  P.tail_set = two_tails ? (int)(c->sr_split_seq ++ & 1u) : 0;
   P.before_buf = before_split ? before->buf : -1;
   if (P.tail_set == 1 && (rc = ensure_set1(c))) return rc;
   if (P.to_device && !c->sr_copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->sr_copy_stream, hipStreamNonBlocking));
