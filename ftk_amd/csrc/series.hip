@@ -32,7 +32,7 @@ int series_by_host(ftkx_ctx *c, const int *ts, const int *scopes, int n, const s
   c->sr_lists_owner = 0;                                      // (the batch takes the counters and the survivor lists over)
   // (... from whatever still runs on the tail stream: the tail of a split pass queued behind the one the batch sweeps for shares them in
   // STREAM order only with its own stream -- it must be through before the batch's kernels start on the context's stream)
-  if (c->sr_tail_stream) { HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream)); HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream2)); }
+  if (c->sr_tail_stream) { HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream)); if (c->sr_tail_stream2) HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream2)); }
   struct Through { ftkx_ctx *c; bool was; ~Through() { c->sr_internal = was; } } through{c, c->sr_internal};
   c->sr_internal = true;
   const unsigned long long hint = std::max<unsigned long long>(factor_of(*running), 256ull);
@@ -510,7 +510,6 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
       HIP_TRY(c, hipStreamCreateWithPriority(&c->sr_tail_stream, hipStreamNonBlocking, hi));    // (the tail is a latency chain: it goes first wherever a slot frees up)
-      HIP_TRY(c, hipStreamCreateWithPriority(&c->sr_tail_stream2, hipStreamNonBlocking, hi));
     }
     for (ftkx_series_buffers &X : c->sr_buf)
       for (hipEvent_t *e : {&X.ev_masks, &X.ev_factors, &X.ev_tail}) if (!*e) HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -521,6 +520,11 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   // double_gyre 0.77 -> 0.97, in some runs and not in others)
   const bool two_tails = P.split_sparse && mask_bytes_of_pass < 2 * kSplitMinBytes;
   P.tail_set = two_tails ? (int)(c->sr_split_seq ++ & 1u) : 0;
+  if (two_tails && !c->sr_tail_stream2) {                    // (only where it is used: streams beyond the runtime's hardware queues share them, and a tail
+    int lo = 0, hi = 0;                                      // that shares its mask kernel's queue runs behind it)
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIP_TRY(c, hipStreamCreateWithPriority(&c->sr_tail_stream2, hipStreamNonBlocking, hi));
+  }
   P.before_buf = before_split ? before->buf : -1;
   if (P.tail_set == 1 && (rc = ensure_set1(c))) return rc;
   if (P.to_device && !c->sr_copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->sr_copy_stream, hipStreamNonBlocking));
@@ -755,7 +759,7 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
   release_retired(c, P);                                     // (the tail that read them is through)
   // (with no pass left open the tail stream is at its end: waited for, so that whatever the caller does next on the context's stream --
   // a host-driven batch, a pass that is not split -- finds the counters and lists idle)
-  if (P.split && c->sr_open == 0) { HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream)); HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream2)); }
+  if (P.split && c->sr_open == 0) { HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream)); if (c->sr_tail_stream2) HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream2)); }
 
   // ---- what came back ----------------------------------------------------------------------------------------------------------------
   // (whoever stored the flag -- the fused tail, finishing or declining, or the finish kernel -- copied the whole results block first: the
@@ -836,7 +840,7 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
       const u64 hits = cnt[ftkx::CNT_PASS], listed = cnt[ftkx::CNT_LIST_PEAK], refined = cnt[ftkx::CNT_REFINE_PEAK], fragile = cnt[ftkx::CNT_FRAGILE];
       if (c->sr_open > 0) {                                  // (a pass queued behind this one still uses the buffers)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->sr_tail_stream) { HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream)); HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream2)); }
+        if (c->sr_tail_stream) { HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream)); if (c->sr_tail_stream2) HIP_TRY(c, hipStreamSynchronize(c->sr_tail_stream2)); }
       }
       if (hits > c->capacity && (rc = ensure_hit_buffer(c, hits + hits / 8 + 1024))) return rc;
       if (listed > c->list_capacity && (rc = ensure_list(c, listed + listed / 8 + 1024))) return rc;
