@@ -239,7 +239,7 @@ def side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=5, warmup=2):
                 path_list.append(p)
                 paths[str(p)] = paths.get(str(p), 0) + 1
         return recs, f
-    recs, f = passes(max(warmup, 8), False)      # (see main(): everything a pass allocates exists before the clock starts)
+    recs, f = passes(max(warmup, 26), False)      # (see main(): everything a pass allocates exists before the clock starts)
     # no HIP events inside the timed region of a side configuration: a pair costs the stream ~10 us, which a 0.2 ms pass notices; the
     # dominant kernel is timed in extra passes behind it
     ctx.set_profiling(0)
@@ -765,11 +765,12 @@ def job(args, env):
         return recs, ctx.stats()
 
     if args.warmup or pipelined:
-        # (passes in flight, one queued KNOWING how many records the data gives, and enough of them that the
+        # (passes in flight, one queued KNOWING how many records the data gives, the library's self-check of the split pass -- a few passes in
+        # order, a few split, then its decision: ~22 passes -- and enough of them that the
         # split pass -- taken from the third pass on -- has its stream, its events and the second set of mask arrays it swaps in for the slices
         # the pass before still reads (512^3 x 32: 4.3 GB of hipMalloc, 48 ms once): both sets of buffers, the device-side record buffers, the
         # copy and tail streams exist before the clock starts -- also when --warmup 0 is asked for)
-        recs, st = passes(max(args.warmup, 8) if pipelined else args.warmup)
+        recs, st = passes(max(args.warmup, 26) if pipelined else args.warmup)
     # HIP events on the stream the kernels run on: around the dominant (mask) kernel only inside the timed region -- a pair of events costs
     # the stream ~10 us of idle time, which a 0.4 ms pass notices --, around every kernel family in a few extra passes afterwards
     ctx.set_profiling(0 if args.no_kernel_events else (1 if args.exact_only else 2))     # (--exact-only: the dominant kernel is the tile kernel)

@@ -150,6 +150,7 @@ struct ftkx_series_pending {
   // the kernel chain -- on the tail stream behind an event, next to the mask kernel of the pass queued behind it
   bool split = false;
   int before_buf = -1;              // the place of the split pass that was open when this one was planned (its factor job is waited for by this pass's tail), or -1
+  int cal_kind = 0;                 // a pass of the split calibration: 1 measured in order, 2 measured split
   int tail_set = 0;                 // 0: the context's own counters and lists, 1: sr_set1
   bool split_sparse = false;        // ... of a sparse pass: few workgroups per chain kernel, 2^10 buckets
   bool one = false;                 // the one-launch pass for small series (one_kernel.hip)
@@ -268,6 +269,20 @@ struct ftkx_ctx {
     u64 capacity = 0, list_capacity = 0, refine_capacity = 0, fragile_capacity = 0;
     size_t bins_cap = 0;
   } sr_set1;
+  // Does the split pass pay HERE?  How the hardware arbitrates between the context's queue and the tail's is not something the library sees
+  // (NOTES.md: the same binary runs 256^3 x 16 at 0.41 or at 0.51 ms per pass, against 0.44 in order, with the runtime's number of hardware
+  // queues).  So the first passes that qualify are measured: a few in order, a few split -- the host's time between two completions while the
+  // pipeline is full -- and the split pass is taken for the passes of that shape only if it was faster.
+  struct split_cal {
+    unsigned long long signature = 0;   // (steps, slices to mask, cells): what the samples are about
+    int phase = 0;                      // 0: in-order samples, 1: split samples, 2: decided
+    int skip = 0;                       // samples to discard (a change of form: buffers, streams, mask arrays of its first passes)
+    std::vector<double> t_order, t_split;
+    bool good = true;
+    unsigned countdown = 0;             // decided "not here": passes until it is measured again
+  } sr_cal;
+  double sr_last_complete_s = 0;        // host clock of the last completion (0: the pipeline ran empty since)
+  int sr_last_complete_kind = 0;        // 1 in order / 2 split, of a calibration pass; 0 otherwise
   unsigned sr_split_seq = 0;          // split passes queued so far: their parity picks the set
   int sr_one_off = 0;                  // passes for which the one-launch form is not tried (it declined a moment ago)
   u64 *sr_one_scratch = nullptr;       // the one-launch pass's barrier counters, partial reductions and per-workgroup counts (ONE_WORDS)

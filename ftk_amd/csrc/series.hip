@@ -10,6 +10,8 @@
 // flagged by the kernels (a factor that hangs on the last bit of the host's log2, slices whose masks need the per-vertex overflow rule,
 // buffers that were too small) -- is swept by the host-driven batch (ftkx_slices_prepare / ftkx_sweep_enqueue / ftkx_sweep_collect)
 // inside the same call, with the same result.
+#include <algorithm>
+#include <chrono>
 #include "ctx.hpp"
 #include "cp_device.hpp"   // classify3 on the HOST (fragile 3D records)
 
@@ -457,6 +459,19 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
     // (a hit-dense chain is ~550 us next to a mask kernel -- double_gyre's 56 766 records --: only mask launches of 4 GB and more hide it)
     P.split = split_mode != 0 && pipelined && !dist && (c->profiling == 0 || c->profiling == 2) && (sparse_now || dense_too) && ntodo > 0 &&
               (mask_bytes >= (sparse_now ? kSplitMinBytes : 4 * kSplitMinBytes) || split_mode == 2);
+    // the self-check (ctx.hpp, split_cal); a hook that forces or forbids the split pass (0, 2, 3) goes around it
+    P.cal_kind = 0;
+    if (P.split && split_mode == 1) {
+      ftkx_ctx::split_cal &K = c->sr_cal;
+      const unsigned long long sig = ((unsigned long long)n << 48) ^ ((unsigned long long)ntodo << 32) ^ (unsigned long long)cells;
+      if (K.signature != sig) { K = ftkx_ctx::split_cal(); K.signature = sig; K.skip = 2; }
+      if (K.phase == 0) { P.split = false; P.cal_kind = 1; }
+      else if (K.phase == 1) P.cal_kind = 2;
+      else if (!K.good) {
+        P.split = false;
+        if (K.countdown > 0 && -- K.countdown == 0) { const unsigned long long keep = K.signature; K = ftkx_ctx::split_cal(); K.signature = keep; K.skip = 2; }
+      }
+    }
     P.split_sparse = P.split && c->sr_sparse && !P.to_device;
   }
   const bool before_split = before && before->open && before->split;
@@ -745,6 +760,10 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
   const size_t k = P.k;
   P.open = false;
   double running = *running_resolution;                       // (what the pass started from: the host-driven batch, if it comes to that, starts there too)
+  // (the split pass's self-check samples the time between two completions by the plain way out of this function: any other way out breaks the chain)
+  const double last_complete_s = c->sr_last_complete_s;
+  const int last_complete_kind = c->sr_last_complete_kind;
+  c->sr_last_complete_s = 0; c->sr_last_complete_kind = 0;
   if (P.by_host) {
     int rc = series_by_host(c, P.ts.data(), P.scopes.data(), n, P.slice_ts, &running, factors, out, n_out);
     if (rc == FTKX_OK) *running_resolution = running;
@@ -852,6 +871,27 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     return rc;
   }
   c->sr_last_path = (status & ftkx::SERIES_ONE) ? 4 : P.split ? 5 : (status & ftkx::SERIES_EARLY) ? 2 : 1;
+  {
+    // the split pass's self-check: the time since the last completion is a sample of this pass's form if the pipeline was full all the while
+    // (another pass is open now and one was when the last one completed) and the last completion was of the same form
+    const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    ftkx_ctx::split_cal &K = c->sr_cal;
+    if (P.cal_kind && K.phase < 2) {
+      if (last_complete_s > 0 && last_complete_kind == P.cal_kind && c->sr_open > 0) {
+        if (K.skip > 0) K.skip --;
+        else (P.cal_kind == 1 ? K.t_order : K.t_split).push_back(now - last_complete_s);
+      }
+      auto median = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+      if (K.phase == 0 && K.t_order.size() >= 5) { K.phase = 1; K.skip = 4; }      // (the first split passes allocate: their stream, the mask arrays they swap in)
+      else if (K.phase == 1 && K.t_split.size() >= 5) {
+        K.phase = 2;
+        K.good = median(K.t_split) <= 0.995 * median(K.t_order);
+        K.countdown = K.good ? 0u : 4096u;
+      }
+    }
+    c->sr_last_complete_kind = P.cal_kind;
+    c->sr_last_complete_s = c->sr_open > 0 ? now : 0.0;
+  }
   if (!P.one && !P.split) c->sr_short_chain = (status & ftkx::SERIES_EARLY) != 0;      // (a split pass says nothing about the fused tail)
   if (!P.one) {
     const u64 *cn = R + ftkx::SR_COUNTERS;
