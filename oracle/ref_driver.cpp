@@ -51,12 +51,33 @@ struct probe : public Base {
   probe(diy::mpi::communicator comm) : Base(comm), ftk::tracker(comm) {}
   std::vector<uint64_t> factors;  // factor in force at each update_timestep()
   std::vector<int> factor_steps;
-  double sweep_seconds = 0;
+  double sweep_seconds = 0, push_seconds = 0;
+  std::vector<double> push_ms, sweep_ms;   // per call
+  // (push_*_field_snapshot: virtual in critical_point_tracker.hh:130-131.  Timed because that is where a snapshot costs the host: the
+  // ndarray copies and gradient / jacobian of the CPU path, the upload of the patched FTK_XL_HIP path)
+  void push_scalar_field_snapshot(const ftk::ndarray<double> &a) override {
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    Base::push_scalar_field_snapshot(a);
+    push_ms.push_back(1e3 * std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count());
+    push_seconds += 1e-3 * push_ms.back();
+  }
+  void push_vector_field_snapshot(const ftk::ndarray<double> &a) override {
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    Base::push_vector_field_snapshot(a);
+    push_ms.push_back(1e3 * std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count());
+    push_seconds += 1e-3 * push_ms.back();
+  }
+#ifdef FTKX_SHIM
+  bool resident() const { return this->hip_is_resident(); }     // (the patch's: snapshots in HBM, critical_point_tracker_regular.hh)
+#else
+  bool resident() const { return false; }
+#endif
   void update_timestep() override {
     const auto t0 = std::chrono::high_resolution_clock::now();
     Base::update_timestep();
     const auto t1 = std::chrono::high_resolution_clock::now();
     sweep_seconds += std::chrono::duration<double>(t1 - t0).count();
+    sweep_ms.push_back(1e3 * std::chrono::duration<double>(t1 - t0).count());
     factors.push_back(this->vector_field_scaling_factor);
     factor_steps.push_back(this->current_timestep);
   }
@@ -186,6 +207,9 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
   }
 #ifdef FTKX_SHIM
   tracker.use_accelerator("hip");      // filter.hh (patched): FTK_XL_HIP -- update_timestep() takes the accelerator branch into libftkx.so
+  // FTK_SHIM_ONESHOT: the patched tracker without resident snapshots -- every update_timestep() hands host V, J, S to extract_cp*dt_hip
+  // (the literal reference boundary); default: snapshots resident in HBM (critical_point_tracker_regular::hip_push_snapshot)
+  if (getenv("FTK_SHIM_ONESHOT")) tracker.set_hip_resident(false);
 #endif
   tracker.initialize();
   // FTK_REF_T0: the series starts at a later timestep (tracker::set_current_timestep, filters/tracker.hh:40) -- with a large value
@@ -194,17 +218,31 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
   const int T0 = getenv("FTK_REF_T0") ? atoi(getenv("FTK_REF_T0")) : 0;
   if (T0) tracker.set_current_timestep(T0);
 
+  // the loop of the reference's callers (json_interface.hh:690-725): push, advance, and a last update for the final ordinal sweep.
+  // loop_seconds = everything the tracker does per step (push + update_timestep + pop), without the making of the input array
+  double loop_seconds = 0;
+  bool resident = false;
   for (int k = 0; k < in.DT; k ++) {
     const auto a = make_array(in, k);
+    const auto t0 = std::chrono::high_resolution_clock::now();
     if (in.nv == 1) tracker.push_scalar_field_snapshot(a);
     else tracker.push_vector_field_snapshot(a);
     if (k != 0) tracker.advance_timestep();
     if (k == in.DT - 1) tracker.update_timestep();
+    resident = resident || tracker.resident();
+    loop_seconds += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
   }
 
   const auto cps = tracker.get_critical_points();
-  fprintf(stdout, "{\"sweep_seconds\": %.6f, \"records\": %zu, \"nthreads\": %d}\n",
-      tracker.sweep_seconds, cps.size(), tracker.get_number_of_threads());
+  fprintf(stdout, "{\"sweep_seconds\": %.6f, \"push_seconds\": %.6f, \"loop_seconds\": %.6f, \"steps\": %d, \"records\": %zu, \"nthreads\": %d, \"hip_resident\": %s}\n",
+      tracker.sweep_seconds, tracker.push_seconds, loop_seconds, in.DT, cps.size(), tracker.get_number_of_threads(), resident ? "true" : "false");
+  if (getenv("FTK_REF_PER_CALL")) {      // one line more: the milliseconds of every push and every update_timestep()
+    fprintf(stdout, "{\"push_ms\": [");
+    for (size_t i = 0; i < tracker.push_ms.size(); i ++) fprintf(stdout, "%s%.4f", i ? ", " : "", tracker.push_ms[i]);
+    fprintf(stdout, "], \"update_ms\": [");
+    for (size_t i = 0; i < tracker.sweep_ms.size(); i ++) fprintf(stdout, "%s%.4f", i ? ", " : "", tracker.sweep_ms[i]);
+    fprintf(stdout, "]}\n");
+  }
   if (!out) return;
 
   FILE *fp = fopen(out, "wb");

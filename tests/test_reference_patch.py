@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 PATCH = os.path.join(ROOT, "patches", "ftk-xl-hip.patch")
 PATCHED = ["include/ftk/object.hh", "include/ftk/config.hh.in", "include/ftk/filters/filter.hh",
-           "include/ftk/filters/critical_point_tracker_2d_regular.hh", "include/ftk/filters/critical_point_tracker_3d_regular.hh"]
+           "include/ftk/filters/critical_point_tracker_2d_regular.hh", "include/ftk/filters/critical_point_tracker_3d_regular.hh",
+           "include/ftk/filters/critical_point_tracker_regular.hh"]
 
 needs_reference = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "include", "ftk", "object.hh")), reason="needs the reference tree (build container)")
 
@@ -41,6 +42,21 @@ def test_patch_applies_to_the_reference(tmp_path):
     # the two caller defects the HIP branch must not inherit: domain size - 1, snapshot 0 twice as Sl
     assert "domain.size(0) - (xl == FTK_XL_HIP ? 0 : 1)" in t2 and "vector_field_scaling_factor, is_jacobian_field_symmetric, use_type_filter, type_filter" in t2
     assert "field_data_snapshots[xl == FTK_XL_HIP ? 1 : 0].scalar" in t3 and "enable_robust_detection" in t3
+    # the resident form (round 6): the tracker owns the device context; push / update_timestep / pop reach the resident C ABI through it
+    tr = (tmp_path / "include/ftk/filters/critical_point_tracker_regular.hh").read_text()
+    assert "ftkx::resident_sweep hip;" in tr and "bool pop_field_data_snapshot();" in tr and "hip.pop_front()" in tr
+    assert "hip.push_scalar(t, scalar->data())" in tr and "hip.sweep(current_timestep, field_data_snapshots.size() >= 2, vector_field_resolution" in tr
+    for t in (t2, t3):
+        assert t.count("if (hip_push_snapshot(&s, NULL, NULL))") == 1 and t.count("if (hip_push_snapshot(NULL, &v, NULL))") == 1
+        assert "if (resident) hip_sweep_current_timestep();" in t
+        assert "resident ? hip_take_results(ELEMENT_SCOPE_ORDINAL) :" in t and "resident ? hip_take_results(ELEMENT_SCOPE_INTERVAL) :" in t
+        assert "if (!hip_is_resident())" in t
+        # the host derivation stays where it was, behind the early return: gradient / jacobian are NOT evaluated for a resident snapshot
+        push = t[t.index("::push_scalar_field_snapshot(const ndarray<double>& s)"):]
+        assert push.index("hip_push_snapshot(&s") < push.index("gradient")
+    shim = open(os.path.join(ROOT, "include", "ftkx_shim.hh")).read()
+    for sym in ("ftkx_push_scalar_slice", "ftkx_push_slice", "ftkx_sweep_series", "ftkx_drop_slice", "ftkx_set_mesh"):
+        assert sym in shim, sym
     # reversible: the patch and nothing else
     r = subprocess.run(["git", "apply", "-R", "-p1", PATCH], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -64,6 +80,13 @@ def test_patch_applies_to_the_reference(tmp_path):
     ("include/ftk/filters/critical_point_tracker_3d_regular.hh", 203, 304, ["FTK_XL_CUDA", "ftk::lattice domain4", "extract_cp3dt_cuda(", "from_work_index"]),
     ("include/ftk/filters/critical_point_tracker_3d_regular.hh", 284, 285, ["field_data_snapshots[0].scalar.data()"]),
     ("include/ftk/object.hh", 33, 38, ["FTK_XL_NONE", "FTK_XL_CUDA"]),
+    # what the resident form replaces (patch header)
+    ("include/ftk/filters/critical_point_tracker_2d_regular.hh", 238, 261, ["push_scalar_field_snapshot", "gradient2D(s)", "jacobian2D<double, true>", "push_vector_field_snapshot"]),
+    ("include/ftk/filters/critical_point_tracker_3d_regular.hh", 125, 148, ["push_scalar_field_snapshot", "gradient3D(s)", "jacobian3D(snapshot.vector)"]),
+    ("include/ftk/filters/critical_point_tracker.hh", 231, 237, ["pop_field_data_snapshot", "pop_front"]),
+    ("include/ftk/filters/critical_point_tracker.hh", 841, 848, ["advance_timestep", "update_timestep();", "pop_field_data_snapshot();"]),
+    ("include/ftk/filters/critical_point_tracker.hh", 850, 864, ["update_vector_field_scaling_factor", "s.vector.resolution()", "1 << nbits"]),
+    ("include/ftk/filters/critical_point_tracker.hh", 155, 159, ["field_data_snapshot_t", "std::deque<field_data_snapshot_t> field_data_snapshots"]),
 ])
 def test_cited_line_ranges_hold_what_the_docs_say(path, first, last, anchors):
     lines = open(os.path.join(REF, path)).read().split("\n")
@@ -82,6 +105,8 @@ def test_shim_driver_is_the_patched_reference():
     undefined = subprocess.run(["nm", "-C", "--undefined-only", drv], capture_output=True, text=True).stdout
     assert "extract_cp2dt_hip(" in defined and "extract_cp3dt_hip(" in defined            # the patch's new source file is linked in
     assert "ftkx_extract_cp2dt" in undefined and "ftkx_extract_cp3dt" in undefined        # ... and binds the C ABI of libftkx.so
+    for sym in ("ftkx_push_scalar_slice", "ftkx_push_slice", "ftkx_sweep_series", "ftkx_drop_slice"):       # the resident calls too
+        assert sym in undefined, sym
     assert "hip_tracker" not in defined                                                   # no subclass, no update_timestep() override
     src = open(os.path.join(ROOT, "oracle", "ref_driver.cpp")).read()
     assert 'use_accelerator("hip")' in src and "hip_tracker_2d" not in src

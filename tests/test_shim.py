@@ -8,11 +8,12 @@ import subprocess
 import numpy as np
 import pytest
 
-from common import load_golden
+from common import golden_names, load_golden, wrap_golden_names
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/include"
 REFCFG = os.path.join(ROOT, "oracle", "_ref", "include")
+SHIM_DRIVER = os.path.join(ROOT, "oracle", "_ref", "ftk_shim_driver")
 
 
 def _lib_dir():
@@ -75,7 +76,80 @@ def test_shim_returns_oracle_records(name, tmp_path, oracle):
             assert np.array_equal(got[fld][o], ref[fld][p], equal_nan=True), fld
 
 
-SHIM_DRIVER = os.path.join(ROOT, "oracle", "_ref", "ftk_shim_driver")
+def _driver_env(name, g, mode):
+    """the options a fixture was made with (tests/golden/make_golden*.py), as oracle/ref_driver.cpp reads them"""
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith(("FTK_REF_", "FTK_SHIM_")):
+            del env[k]
+    if not g["robust"]:
+        env["FTK_REF_NO_ROBUST"] = "1"
+    if g["type_filter"]:
+        env["FTK_REF_TYPE_FILTER"] = str(g["type_filter"])
+    if g["degrees"]:
+        env["FTK_REF_DEGREES"] = "1"
+    if g["bounds"]:
+        env["FTK_REF_BOUNDS"] = ",".join(repr(float(v)) for v in g["bounds"])
+    for m in ("rect", "explicit2", "explicit3"):
+        if name.endswith("_" + m):
+            env["FTK_REF_COORDS"] = m
+    if g["t0"]:
+        env["FTK_REF_T0"] = str(g["t0"])
+    if mode == "oneshot":
+        env["FTK_SHIM_ONESHOT"] = "1"
+    return env
+
+
+def _run_shim_driver(name, mode, tmp_path):
+    import json
+    from refdump import read_dump, write_input
+    g = load_golden(name)
+    inp, out = tmp_path / "in.bin", tmp_path / "o.bin"
+    write_input(str(inp), g["steps"], g["nd"], g["nv"])
+    r = subprocess.run([SHIM_DRIVER, "file", str(inp), str(out)], capture_output=True, text=True, timeout=600, env=_driver_env(name, g, mode))
+    assert r.returncode == 0, r.stderr[-2000:]
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["hip_resident"] == (mode == "resident")
+    return g, read_dump(str(out)), info
+
+
+def _assert_dump_equals_fixture(d, g):
+    assert np.array_equal(d["factors"], g["factors"])
+    got, ref = d["records"], g["records"]
+    assert len(got) == len(ref)
+    o, p = np.argsort(got["tag"], kind="stable"), np.argsort(ref["tag"], kind="stable")
+    for f in ("tag", "type", "ordinal", "timestep"):
+        assert np.array_equal(got[f][o], ref[f][p]), f
+    for f in ("x", "t", "scalar"):
+        assert np.array_equal(got[f][o], ref[f][p], equal_nan=True), f            # bit-identical (north_star asks for 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", golden_names() + wrap_golden_names())
+def test_patched_reference_tracker_is_resident_and_matches_every_fixture(name, tmp_path):
+    """patches/ftk-xl-hip.patch, executed on every record fixture: oracle/_ref/ftk_shim_driver is the REAL
+    ftk::critical_point_tracker_{2d,3d}_regular built from the patched headers, told use_accelerator("hip") and nothing else.  Its
+    push_*_field_snapshot hand each ndarray to libftkx.so once (no host gradient / jacobian), update_timestep() sweeps the resident
+    slices with the factor formed on the device, pop_field_data_snapshot drops the slice; the reference's own from_work_index /
+    to_integer loops, std::map and finalize() consume the records.  Result: the CPU fixture of the same reference -- per-step factors,
+    records (bit for bit), traced curves -- over every option the fixtures cover (robust off, type filter, degrees, the four
+    coordinate modes, int32-wrapped tags, near-singular Hessians incl. 72x64x56x8)."""
+    if not os.path.exists(SHIM_DRIVER):
+        pytest.skip("oracle/_ref/ftk_shim_driver not built (needs the build container: make -C oracle ref)")
+    g, d, _ = _run_shim_driver(name, "resident", tmp_path)
+    _assert_dump_equals_fixture(d, g)
+    if g["curves"] is not None:
+        assert sorted((tuple(t.tolist()), l) for l, t in d["curves"]) == sorted((tuple(t.tolist()), l) for l, t in g["curves"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["woven_31x37x32", "random_3d_scalar_13x12x11x4", "random_2d_vector_23x20x5", "random_2d_scalar_29x24x6_saddles"])
+def test_patched_reference_tracker_one_shot_mode(name, tmp_path):
+    """set_hip_resident(false): the same patched tracker through the literal reference boundary (extract_cp{2,3}dt_hip with host V, J, S)"""
+    if not os.path.exists(SHIM_DRIVER):
+        pytest.skip("oracle/_ref/ftk_shim_driver not built (needs the build container: make -C oracle ref)")
+    g, d, _ = _run_shim_driver(name, "oneshot", tmp_path)
+    _assert_dump_equals_fixture(d, g)
 
 
 @pytest.mark.gpu
