@@ -321,6 +321,57 @@ def boundary_call(torch, dev, ftk_amd, synthetic):
     return out
 
 
+def patched_reference_tracker(synthetic, expect_records=None):
+    """What a user of hguo/ftk gets from patches/ftk-xl-hip.patch: oracle/_ref/ftk_shim_driver is the REAL
+    ftk::critical_point_tracker_3d_regular compiled from the patched headers, told use_accelerator("hip"), driven the way the reference's
+    callers drive it (push_scalar_field_snapshot + advance_timestep per timestep, pageable ndarray<double>s made afresh for every step).
+    resident (the patch's default): each snapshot crosses PCIe once, 8 bytes per vertex, and stays in HBM for the two steps that read it;
+    one_shot (set_hip_resident(false)): host gradient / jacobian per push and V, J, S of both snapshots across PCIe on every call.
+    A separate process, after the timed region; never `value`."""
+    drv = os.path.join(ROOT, "oracle", "_ref", "ftk_shim_driver")
+    if not os.path.exists(drv):
+        return {"error": "oracle/_ref/ftk_shim_driver not built (needs the reference tree: build container only)"}
+    dims = (256, 256, 256)
+    x0, dv = synthetic.moving_extremum_params(dims)
+    nvert = dims[0] * dims[1] * dims[2]
+    out = {"workload": "moving_extremum_3d 256x256x256, host-fed scalar snapshots (8 B/vertex), the reference's own push / advance_timestep loop",
+           "binary": "oracle/_ref/ftk_shim_driver (the reference's trackers + patches/ftk-xl-hip.patch, no override)"}
+
+    def run(nt, oneshot):
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("FTK_REF_", "FTK_SHIM_"))}
+        env["FTK_REF_PER_CALL"] = "1"
+        if oneshot:
+            env["FTK_SHIM_ONESHOT"] = "1"
+        cmd = [drv, "synthetic", "moving_extremum_3d", str(dims[0]), str(dims[1]), str(dims[2]), str(nt), "/dev/null"] + [repr(float(v)) for v in list(x0) + list(dv)]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True, env=env)
+        lines = r.stdout.decode().strip().splitlines()
+        return json.loads(lines[-2]), json.loads(lines[-1])
+
+    def med(v):
+        v = sorted(v)
+        return v[len(v) // 2] if v else None
+
+    try:
+        info, per = run(16, False)
+        push, upd = per["push_ms"][1:], per["update_ms"][1:-1]          # (the first calls create the context and allocate; the last update is ordinal only)
+        steady = med(push) + med(upd)
+        out["resident"] = {"timesteps": 16, "ms_per_step": steady, "push_ms": med(push), "update_timestep_ms": med(upd),
+                           "ms_per_step_mean_incl_first_call": info["loop_seconds"] / info["steps"] * 1e3,
+                           "first_push_ms": per["push_ms"][0], "first_update_ms": per["update_ms"][0],
+                           "host_GB/s": 8.0 * nvert / (med(push) * 1e-3) / 1e9, "records": info["records"], "hip_resident": info["hip_resident"],
+                           "ok": bool(info["hip_resident"] and info["records"] >= 1 and (expect_records is None or info["records"] == expect_records)),
+                           "note": "median over steps 1..15 of push (upload of the pageable ndarray) + update_timestep (one device-driven pass, records through the reference's from_work_index / to_integer loops)"}
+        info1, per1 = run(3, True)
+        push1, upd1 = per1["push_ms"][1:], per1["update_ms"][1:-1]
+        out["one_shot"] = {"timesteps": 3, "ms_per_step": med(push1) + med(upd1), "push_ms": med(push1), "update_timestep_ms": med(upd1),
+                           "records": info1["records"], "hip_resident": info1["hip_resident"],
+                           "note": "push = the reference's host gradient3D + jacobian3D; update_timestep = extract_cp3dt_hip twice (V, J, S over PCIe, 104 B/vertex and slice)"}
+        out["speedup"] = out["one_shot"]["ms_per_step"] / steady
+    except Exception as e:   # noqa: BLE001
+        out["error"] = repr(e)
+    return out
+
+
 def streaming_tracker(nd, case, dims, nt_run, torch, dev, ftk_amd, synthetic, host_steps=4):
     """The drop-in's everyday use (critical_point_tracker_regular: push_*_snapshot / advance_timestep per timestep, the records of every
     step on the host before the next push): per-step wall time with device-resident input, and the same fed from HOST arrays -- what the
@@ -429,6 +480,7 @@ def launch_ranks(args, argv):
     include/ftk/filters/critical_point_tracker.hh:689)."""
     import socket
     n = args.gpus
+    attempt = getattr(args, "_launch_attempt", 0)
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -473,6 +525,11 @@ def launch_ranks(args, argv):
     def tail(r, what, nbytes=6000):
         with open(os.path.join(tmp, f"rank{r}.{what}"), "rb") as f:
             return f.read()[-nbytes:].decode(errors="replace")
+    if failed and not timed_out and attempt == 0 and any("address already in use" in tail(r, "err").lower() or "eaddrinuse" in tail(r, "err").lower() for r, _, _, _ in procs):
+        # the port was free when it was picked and taken when rank 0's store bound it (another launch on this box): once more, with a fresh one
+        print("bench.py --gpus %d: rendezvous port %d was taken meanwhile; launching the ranks once more" % (n, port), file=sys.stderr)
+        args._launch_attempt = 1
+        return launch_ranks(args, argv)
     if failed or timed_out:
         codes = {r: p.returncode for r, p, _, _ in procs}
         bad = failed if failed else [r for r, _, _, _ in procs]
@@ -1034,6 +1091,8 @@ def job(args, env):
                 out["boundary_call"] = boundary_call(torch, dev, ftk_amd, synthetic)
             except Exception as e:   # noqa: BLE001
                 out["boundary_call"] = {"error": repr(e)}
+            c3 = (out.get("configs") or {}).get("c3") or {}
+            out["patched_reference_tracker"] = patched_reference_tracker(synthetic, expect_records=c3.get("hits"))
         if not multi and not light and not args.no_cpu_baseline:
             base, port = cpu_baseline(nd, case)
             out["cpu_baseline"] = base

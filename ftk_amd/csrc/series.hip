@@ -39,7 +39,18 @@ int series_by_host(ftkx_ctx *c, const int *ts, const int *scopes, int n, const s
   c->sr_internal = true;
   const unsigned long long hint = std::max<unsigned long long>(factor_of(*running), 256ull);
   std::vector<double> below(slice_ts.size());
-  int rc = ftkx_sweep_announce(c, ts, scopes, n);
+  // work-index tags count inside one scope (simplicial_regular_mesh.hh:480-493): the batch takes a step of both scopes as two requests
+  // (their tags may coincide; ftkx_cp_ordinal tells the records apart -- what the patched tracker's resident step asks for)
+  std::vector<int> ets(ts, ts + n), esc(scopes, scopes + n), origin((size_t)n);
+  for (int i = 0; i < n; i ++) origin[(size_t)i] = i;
+  if (c->opt.tag_mode == FTKX_TAG_WORK_INDEX)
+    for (size_t i = 0; i < esc.size(); i ++)
+      if (esc[i] == FTKX_SCOPE_BOTH) {
+        esc[i] = FTKX_SCOPE_ORDINAL;
+        ets.insert(ets.begin() + (long)i + 1, ets[i]); esc.insert(esc.begin() + (long)i + 1, FTKX_SCOPE_INTERVAL); origin.insert(origin.begin() + (long)i + 1, origin[i]);
+        i ++;
+      }
+  int rc = ftkx_sweep_announce(c, ets.data(), esc.data(), (int)ets.size());
   if (rc) return rc;
   if ((rc = ftkx_slices_prepare(c, slice_ts.data(), (int)slice_ts.size(), hint, below.data(), nullptr))) return rc;
   std::vector<unsigned long long> f((size_t)n);
@@ -50,7 +61,9 @@ int series_by_host(ftkx_ctx *c, const int *ts, const int *scopes, int n, const s
     f[(size_t)i] = factor_of(run);
   }
   for (; j < slice_ts.size(); j ++) run = std::min(run, below[j]);
-  if ((rc = ftkx_sweep_enqueue_many(c, ts, scopes, f.data(), n))) return rc;
+  std::vector<unsigned long long> ef(ets.size());
+  for (size_t i = 0; i < ets.size(); i ++) ef[i] = f[(size_t)origin[i]];
+  if ((rc = ftkx_sweep_enqueue_many(c, ets.data(), esc.data(), ef.data(), (int)ets.size()))) return rc;
   if ((rc = ftkx_sweep_collect(c, out, n_out))) return rc;
   *running = run;
   if (factors) for (int i = 0; i < n; i ++) factors[i] = f[(size_t)i];
@@ -98,7 +111,9 @@ bool series_applicable(ftkx_ctx *c, const int *ts, const int *scopes, int n, con
   bool ok = !c->opt.exact_only && (nd == 2 || c->opt.robust) && c->dense_collects == 0 && !c->opt.use_type_filter && cells > 0 && n <= ftkx::kSeriesMaxSlices && k <= (size_t)ftkx::kSeriesMaxSlices;
   if (const char *e = getenv("FTKX_SERIES")) ok = ok && atoi(e) != 0;
   // the order of (step, corner, type) must be the order of the tags
-  if (ok && c->opt.tag_mode == FTKX_TAG_WORK_INDEX) ok = n == 1 && scopes[0] != FTKX_SCOPE_BOTH;
+  // (work-index tags: one step.  With both scopes the records come in element order -- step, corner, type -- which is not the order of
+  // their tags any more: each counts inside its own scope)
+  if (ok && c->opt.tag_mode == FTKX_TAG_WORK_INDEX) ok = n == 1;
   if (ok && c->opt.tag_mode == FTKX_TAG_REFERENCE) {         // int32 products: equal to the 64-bit formula only while nothing wraps
     long double bound = nd == 2 ? 12.0L : 60.0L;
     for (int d = 0; d < nd; d ++) bound *= (long double)c->dom_sz[d];
@@ -282,6 +297,17 @@ void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, const unsigned *wait
   P.copy_pending = false;
 }
 
+// A pass that is NOT split works on the context's counters, lists and ordering arrays in the order of the context's stream -- and so does
+// whatever recycles a dropped slice's arrays behind it.  Every split pass still open has its tail on a stream of its own (two of them may
+// be out at once: tail sets 0 and 1): the context's stream waits for ALL of them, not only for the pass queued last -- with two tails
+// open, the newest one's event says nothing about the older one's.
+int wait_for_open_tails(ftkx_ctx *c, const ftkx_series_pending *self)
+{
+  for (ftkx_series_pending &X : c->sr_pend)
+    if (&X != self && X.open && X.split && c->sr_buf[X.buf].ev_tail) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->sr_buf[X.buf].ev_tail, 0));
+  return FTKX_OK;
+}
+
 // ---- the one-launch pass for small series (one_kernel.hip) --------------------------------------------------------------------------------
 bool series_one_eligible(ftkx_ctx *c, const ftkx_series_pending &P, int n, size_t k, u64 cells, bool dist)
 {
@@ -350,7 +376,7 @@ int series_plan_one(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const in
     HIP_TRY(c, hipStreamWaitEvent(c->sr_copy_stream, c->sr_ev_fetched, 0));
     series_queue_copy(c, *before, nullptr, 0);
   }
-  if (before && before->open && before->split) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->sr_buf[before->buf].ev_tail, 0));   // (its tail shares the fragile list)
+  if ((rc = wait_for_open_tails(c, &P))) return rc;         // (their tails share the fragile list and the counters)
   if (B.copy_out) { HIP_TRY(c, hipStreamWaitEvent(c->stream, B.ev_copied, 0)); B.copy_out = false; }
   const u64 bs = c->nd == 2 ? 128 : 64, nblocks = (P.cells * (u64)n + bs - 1) / bs;
   const int nwg = (int)std::max<u64>(8, std::min<u64>(256, (nblocks + 3) / 4));      // (four or more blocks per workgroup, kOneOwnBlocks at most)
@@ -611,7 +637,7 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   // (the pass before this one has its tail on the tail stream: a pass that is not split itself shares the counters with it in STREAM order,
   // so the context's stream waits for that tail; a split pass only needs that pass's cull -- its mask kernel must not start before the fused
   // tail behind that cull can be placed -- and zeroes the counters on the tail stream, behind it)
-  if (before_split && !P.split) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->sr_buf[before->buf].ev_tail, 0));
+  if (!P.split && (rc = wait_for_open_tails(c, &P))) return rc;
   // (a split pass: what its TAIL owns -- counters, histogram, the results block, which the tail of the pass before may still be reading as the
   // block it continues from -- is zeroed on the tail stream)
   ftkx::launch_series_begin(P.split ? nullptr : c->d_counters, B.red, ntodo * 64, P.split ? nullptr : c->sr_hist, P.split ? 0 : nbins + 1, P.split ? nullptr : B.results, P.split ? 0 : nwords,

@@ -58,7 +58,9 @@ enum {
 enum { FTKX_SCOPE_ORDINAL = 1, FTKX_SCOPE_INTERVAL = 2, FTKX_SCOPE_BOTH = 3 };
 
 enum {
-  FTKX_TAG_WORK_INDEX = 0,  /* index inside `core` for the given scope: what extract_cp*dt_cuda returns (src/filters/critical_point_tracer_2d_regular.cu:162-164) */
+  FTKX_TAG_WORK_INDEX = 0,  /* index inside `core` for the given scope: what extract_cp*dt_cuda returns (src/filters/critical_point_tracer_2d_regular.cu:162-164).
+                               FTKX_SCOPE_BOTH: ftkx_sweep_series only; every record counts inside its OWN scope (ftkx_cp_ordinal says which),
+                               so tags of the two scopes may coincide and the records come in element order, not in tag order */
   FTKX_TAG_REFERENCE  = 1,  /* e.to_integer(m) bit-for-bit, including its int32 products (simplicial_regular_mesh.hh:496-502) */
   FTKX_TAG_EXACT64    = 2   /* same formula in 64-bit arithmetic: equal to REFERENCE whenever that does not overflow */
 };

@@ -147,11 +147,11 @@ class resident_sweep {
   }
   void clear() { while (pop_front()) {} }
 
-  // One update_timestep(): the ordinal sweep of slice t and, if `interval`, the sweep of [t, t + 1], both under
+  // One update_timestep(): the ordinal sweep of slice t and, if `interval`, the sweep of [t, t + 1], as ONE pass under
   //   factor = scaling_factor(min(running_resolution, resolution(V_t), resolution(V_t+1)))
-  // -- update_vector_field_scaling_factor runs over every snapshot in the deque before either sweep (2d:267-269, 3d:156-158), so the
-  // interval pass goes first here: it folds both slices into the running minimum, and the ordinal pass continues from it.
-  // running_resolution: the tracker's sticky vector_field_resolution, in and out; tags are work indices inside the step's core.
+  // -- update_vector_field_scaling_factor runs over every snapshot in the deque before either sweep (2d:267-269, 3d:156-158).
+  // running_resolution: the tracker's sticky vector_field_resolution, in and out.  Tags are work indices inside the step's core, each
+  // inside its own scope (from_work_index, simplicial_regular_mesh.hh:480-493); the records' aux word says which scope.
   template <class PointLite>
   void sweep(int t, bool interval, double &running_resolution, unsigned long long &factor, std::vector<PointLite> &ordinal_out, std::vector<PointLite> &interval_out)
   {
@@ -162,16 +162,16 @@ class resident_sweep {
     const ftkx_cp_t *recs = nullptr;
     size_t n = 0;
     unsigned long long f = 0;
-    if (interval) {
-      const int scope = FTKX_SCOPE_INTERVAL;
-      check(ftkx_sweep_series(ctx_, &t, &scope, 1, &running_resolution, &f, &recs, &n));
-      interval_out.resize(n);
-      if (n) std::memcpy(static_cast<void *>(interval_out.data()), recs, n * sizeof(ftkx_cp_t));
-    }
-    const int scope = FTKX_SCOPE_ORDINAL;
+    const int scope = interval ? FTKX_SCOPE_BOTH : FTKX_SCOPE_ORDINAL;
     check(ftkx_sweep_series(ctx_, &t, &scope, 1, &running_resolution, &f, &recs, &n));
-    ordinal_out.resize(n);
-    if (n) std::memcpy(static_cast<void *>(ordinal_out.data()), recs, n * sizeof(ftkx_cp_t));
+    size_t n_ordinal = 0;
+    for (size_t i = 0; i < n; i ++) n_ordinal += (size_t)ftkx_cp_ordinal(recs + i);
+    ordinal_out.reserve(n_ordinal); interval_out.reserve(n - n_ordinal);
+    for (size_t i = 0; i < n; i ++) {
+      PointLite p;
+      std::memcpy(static_cast<void *>(&p), recs + i, sizeof(ftkx_cp_t));
+      (ftkx_cp_ordinal(recs + i) ? ordinal_out : interval_out).push_back(p);
+    }
     factor = f;
   }
 

@@ -138,12 +138,16 @@ public:
   // Deferred collection (single-device trackers without streaming trajectories): update_timestep() QUEUES the step's sweep and
   // collects the step before it -- the device works on step t + 1 (continuing on the device from step t's running minimum) while the
   // host takes step t's records.  Same records, factors and statistics; they become visible one step later, and every accessor,
-  // sync() and finalize() collect what is still out first.  A snapshot pushed as a DEVICE pointer is borrowed, not copied: with this on
-  // it must stay valid until the step AFTER the one that pops it has been advanced (or sync() has been called).
+  // sync() and finalize() collect what is still out first.  A snapshot pushed as a DEVICE pointer is borrowed, not copied.  Up to THREE
+  // steps are in flight (a step is collected when the second step after it is advanced): with this on a borrowed pointer must stay valid
+  // until TWO further steps after the one that pops it have been advanced -- snapshot t is popped by advance_timestep() number t and is
+  // free when advance_timestep() number t + 2 has returned -- or until sync() has been called.
   // depth > 1: the sweeps of `depth` consecutive steps are queued as ONE device-driven pass (ftkx_sweep_series_submit with n = depth: one
   // mask launch over the batch's new snapshots, one tail) when the last of them is advanced -- the latency chain behind the mask kernel
   // is paid once per batch; a popped snapshot stays resident (and a borrowed device pointer must stay valid) until its batch has been
-  // collected: 2 * depth + 1 steps at most.  Same records, factors and statistics; sync(), finalize() and every accessor submit a partial batch.
+  // collected, which is when the second batch after it is submitted: 3 * depth + 2 steps after its push at most (ftk_amd.Tracker keeps
+  // borrowed tensors alive for exactly that long).  Same records, factors and statistics; sync(), finalize() and every accessor submit a
+  // partial batch and collect everything, after which nothing is borrowed any more.
   void set_deferred_collection(bool b, int depth = 1) { sync(); deferred_collection = b; deferred_depth = depth > 1 ? depth : 1; }
   // Several RANKS behind the tracker -- one process per GPU, or one tracker per device and thread in one process.  The reference keeps an
   // MPI communicator on the filter and distributes inside the tracker (regular_tracker.hh:127-149), gathering the discrete points on the

@@ -45,9 +45,10 @@ def _as_fixture(recs):
     return out
 
 
-def _push_all(ctx, steps, nv):
+def _push_all(ctx, steps, nv, only=None):
     for t, a in enumerate(steps):
-        (ctx.push_scalar_slice if nv == 1 else ctx.push_slice)(t, a)
+        if only is None or t in only:
+            (ctx.push_scalar_slice if nv == 1 else ctx.push_slice)(t, a)
 
 
 def _same(a, b):
@@ -528,6 +529,46 @@ def test_three_passes_in_flight(gpu, name, hooks, monkeypatch):
         done.append(ctx.sweep_series_complete())
     for i, (r, f, run) in enumerate(done):
         assert _same(r, ref[i][0]) and [int(v) for v in f] == ref[i][1], (name, i, len(r), len(ref[i][0]))
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["moving_extremum_3d_21x21x21x32", "woven_128x128x10"])
+def test_unsplit_pass_behind_two_open_tails(gpu, name, monkeypatch):
+    """Two split passes open, their tails on the two tail streams (tail sets 0 and 1), then a pass that is NOT split -- it zeroes and reuses
+    the context's own counters, lists and ordering arrays, and what is dropped while it is the newest pass goes straight back to the pools:
+    the context's stream has to wait for BOTH tails, not only for the pass queued last (round-5 advisor finding, series.hip
+    wait_for_open_tails).  Cycles of split, split, unsplit (chain, one-launch and host-driven batch in turn), a slice dropped and pushed
+    again behind the unsplit pass; every pass returns the records of ftkx_sweep_series."""
+    g = load_golden(name)
+    nd, nv, nt = g["nd"], g["nv"], g["DT"]
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    ctx = _ctx(gpu, g["dims"], nd, nv, tag_mode=gpu.TAG_EXACT64, robust=int(g["robust"]), compute_degrees=int(g["degrees"]))
+    _push_all(ctx, g["steps"], nv)
+    monkeypatch.setenv("FTKX_SERIES_HOOKS", "one=0")
+    want, wf, wrun = ctx.sweep_series(range(nt), scopes)
+    third = ["one=0,split=0", "one=1,split=0", "one=0,split=0"]
+    for it in range(6):
+        for k in range(3):
+            monkeypatch.setenv("FTKX_SERIES_HOOKS", "one=0,split=2" if k < 2 else third[it % 3])
+            if k == 2 and it % 3 == 2:
+                monkeypatch.setenv("FTKX_SERIES", "0")                 # the host-driven batch as the unsplit pass
+            ctx.invalidate_masks(); ctx.sweep_series_submit(range(nt), scopes)
+            monkeypatch.delenv("FTKX_SERIES", raising=False)
+        # the newest pass is not split: a dropped slice is not parked with it -- its arrays go to the pools and come straight back, here
+        # under another timestep and full of other values, while the three passes that read the slice are still out
+        # (not behind the host-driven batch: that one reads its slices when it is completed)
+        last = nt - 1
+        swap = it % 3 != 2
+        if swap:
+            ctx.drop_slice(last)
+            junk = np.full_like(g["steps"][last], 1234.5)
+            (ctx.push_scalar_slice if nv == 1 else ctx.push_slice)(nt + 5, junk)
+        for k in range(3):
+            got, f, run = ctx.sweep_series_complete()
+            assert _same(got, want) and np.array_equal(f, wf) and run == wrun, (name, it, k, len(got), len(want))
+        if swap:
+            ctx.drop_slice(nt + 5)
+            _push_all(ctx, g["steps"], nv, only=[last])
     ctx.close()
 
 
