@@ -280,6 +280,98 @@ def side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=5, warmup=2):
     return out
 
 
+INT_PROFILES = {"c3_exact_only": "profiles/r06_c3x_valu_summary.json", "c3o": "profiles/r06_c3o_valu_summary.json"}
+
+
+def integer_config(name, torch, dev, ftk_amd, synthetic, tslab):
+    """The INTEGER regime: where the sign cull is illegal (`exact_only`: c3_exact_only = C3 with every simplex through the
+    integer test) or useless (c3o: nbits 21 with |V| large enough that determinants may wrap -- most cells survive, the library replays the
+    batch through the tile kernel with its in-tile cull), every simplex takes tile_kernel: 64-bit integer / FP64 VALU work on vertices
+    staged in LDS, no HBM bound to speak of.  Reference arithmetic: critical_point_tracker_3d_regular.hh:453-464, numeric/sign_det.hh:92-200,
+    360-414, numeric/det.hh:16-55.  Roofline of that kernel, `bound: int_valu`, in simplices/s:
+      achieved = simplices the kernel tested / its device time (HIP events around tile_kernel alone, live);
+      peak     = the same simplices / the time of the predicate arithmetic ALONE -- the fan phase on tiles already staged in LDS, without
+                 staging, lists and records: the kernel is run with its fan phase 6 and 2 times per tile (ftkx_debug_tile_repeat), a
+                 quarter of the difference is one repetition;
+      counters: VALU busy and VALU instructions per wavefront as collected by tools/pmc_int.sh into profiles/ (committed figures, stamped)."""
+    base = "c3" if name == "c3_exact_only" else name
+    nd, nv, case, dims, nt = CONFIGS[base]
+    exact_only = name == "c3_exact_only"
+    stream = torch.cuda.current_stream()
+    ctx = ftk_amd.Context(nd, dev.index or 0)
+    ctx.set_stream(stream.cuda_stream)
+    dom = ([2] * nd, [d - 3 for d in dims])
+    ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
+    opts = dict(jacobian_symmetric=1, derive_jacobian=1, tag_mode=ftk_amd.TAG_EXACT64)
+    ctx.set_options(exact_only=1 if exact_only else 0, **opts)
+    keep = []
+    for t in range(nt):
+        a = synthetic.generate(case, dims, t, nt, torch, dev)
+        keep.append(a)
+        torch.cuda.synchronize()
+        ctx.push_scalar_slice(t, a)
+    ts = np.arange(nt, dtype=np.int32)
+    scopes = np.array([ftk_amd.SCOPE_BOTH if t + 1 < nt else ftk_amd.SCOPE_ORDINAL for t in range(nt)], dtype=np.int32)
+
+    def one_pass(profile):
+        ctx.invalidate_masks()
+        ctx.set_profiling(1 if profile else 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        recs, f, _r = ctx.sweep_series(ts, scopes, copy=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kt = ctx.kernel_times() if profile else None
+        ctx.set_profiling(0)
+        return recs, f, dt, kt
+    steps = 3 if exact_only else 2
+    one_pass(False); one_pass(False)                     # (the first passes allocate; c3o: the first one finds the cull useless and the rest go to the tile kernel up front)
+    wall, tile_ms, launches = [], [], 0
+    for _ in range(steps):
+        recs, f, dt, kt = one_pass(True)
+        wall.append(dt); tile_ms.append(kt["tile_kernel"][0]); launches = kt["tile_kernel"][1]
+    st = ctx.stats()
+    nrec = int(len(recs))
+    tags = np.array(recs["tag"]) if nrec else np.zeros(0, dtype=np.uint64)
+    # the predicate arithmetic alone
+    rep_ms = {}
+    for r in (6, 2):
+        ctx.debug_tile_repeat(r)
+        _recs, _f, _dt, kt = one_pass(True)
+        rep_ms[r] = kt["tile_kernel"][0]
+    ctx.debug_tile_repeat(1)
+    fan_ms = (rep_ms[6] - rep_ms[2]) / 4.0
+    # the check: the other way through the library gives the same records (c3_exact_only: the culled, device-driven pass; c3o: exact_only)
+    ctx.set_options(exact_only=0 if exact_only else 1, **opts)
+    recs2, f2, _dt, _kt = one_pass(False)
+    path2 = ctx.series_last_path()
+    same = bool(len(recs2) == nrec and np.array_equal(np.array(recs2["tag"]), tags) and np.array_equal(np.asarray(f2), np.asarray(f)))
+    nsimp = tslab.count_simplices(nd, dims, nt, True)
+    tested = int(st["simplices_tested"])
+    t_ms = float(np.mean(tile_ms))
+    prof = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, INT_PROFILES[name])))
+        k = next(v for kk, v in pj["kernels"].items() if "tile_kernel" in kk)
+        prof = {"valu_busy": k.get("valu_busy"), "valu_instructions_per_wave": k.get("valu_instructions_per_wave"), "source": INT_PROFILES[name], "kernel_sources_at": pj.get("kernel_sources_at")}
+    except Exception:   # noqa: BLE001
+        pass
+    out = {"workload": f"{case} {'x'.join(str(d) for d in dims)}x{nt}" + (", exact_only (no sign cull: every simplex takes the integer test)" if exact_only else " (nbits 21, determinants may wrap: the cull is useless, every cell goes to the tile kernel)"),
+           "steps": steps, "ms_per_step": float(np.mean(wall)) * 1e3, "value": nsimp / float(np.mean(wall)), "simplices_per_step": nsimp,
+           "simplices_tested_exactly": tested, "hits": nrec, "nbits": int(np.log2(max(int(v) for v in f))),
+           "kernel": "ftkx::tile_kernel<3, %d, false>" % (2 if exact_only else 1), "kernel_launches_per_pass": int(launches), "kernel_ms_per_pass": t_ms,
+           "roofline": {"bound": "int_valu", "unit": "simplices/s", "achieved": tested / (t_ms * 1e-3), "peak": tested / (fan_ms * 1e-3) if fan_ms > 0 else None,
+                        "frac": fan_ms / t_ms if fan_ms > 0 else None, "fan_phase_ms_per_pass": fan_ms, "traffic": None, "counters": prof,
+                        "note": "achieved: simplices tested / device time of tile_kernel (HIP events, live); peak: the same simplices / the time of the kernel's fan phase alone "
+                                "(predicate arithmetic on tiles staged in LDS: passes with the phase repeated 6 and 2 times, differenced); the rest of the kernel is staging "
+                                "(block of S, gradients, quantisation), the list of degenerate simplices and the hand-over of hits"},
+           "check": {"hits": nrec, "same_records_and_factors_the_other_way": same, "other_way": ("culled pass" if exact_only else "exact_only"), "other_way_path": list(path2), "ok": same and nrec > 0}}
+    ctx.close()
+    del keep
+    torch.cuda.empty_cache()
+    return out
+
+
 def boundary_call(torch, dev, ftk_amd, synthetic):
     """The literal drop-in boundary -- ftkx_extract_cp3dt with the reference's argument list (critical_point_tracker_3d_regular.hh:42-56, call
     sites 248-260 / 274-286): HOST V / J / S of the current and the next timestep, one call per scope, records back in a malloc'ed array --
@@ -1074,6 +1166,11 @@ def job(args, env):
                     continue
                 try:
                     others[name] = side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=3 if name == "c4" else 48, warmup=6)
+                except Exception as e:   # noqa: BLE001
+                    others[name] = {"error": repr(e)}
+            for name in ("c3_exact_only", "c3o"):
+                try:
+                    others[name] = integer_config(name, torch, dev, ftk_amd, synthetic, tslab)
                 except Exception as e:   # noqa: BLE001
                     others[name] = {"error": repr(e)}
             out["configs"] = others

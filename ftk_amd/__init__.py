@@ -327,6 +327,10 @@ class Context:
         """0 / False off, 1 / True every kernel family, 2 the mask kernel only"""
         self._ck(self._L.ftkx_set_profiling(self._h, int(on)))
 
+    def debug_tile_repeat(self, repeat):
+        """profiling aid: the tile kernel's fan phase `repeat` times per tile and step from the next sweep on (1 = off)"""
+        self._ck(self._L.ftkx_debug_tile_repeat(self._h, int(repeat)))
+
     def kernel_times(self):
         """{kernel: (summed device ms, launches)} measured with HIP events on the context's stream"""
         ms = (C.c_double * 4)(); n = (C.c_ulonglong * 4)()

@@ -224,7 +224,7 @@ int run_batch(ftkx_ctx *c, const double *sparse_field, bool cull_done)
       subs.back().steps.push_back(f);
     } else {
       TileParams p;
-      p.m = m; p.f = f; p.cull = r.mode == MODE_TILE_CULL ? 1 : 0; p.step = 0;
+      p.m = m; p.f = f; p.cull = r.mode == MODE_TILE_CULL ? 1 : 0; p.step = 0; p.repeat = c->tile_repeat;
       { const char *e = getenv("FTKX_TILE_FAN"); p.fan = e ? atoi(e) : 2; }
       {
         // largest |quantised component| the request can meet, where the slices' maxima are known (the kernel checks every tile anyway)
@@ -304,7 +304,8 @@ int run_batch(ftkx_ctx *c, const double *sparse_field, bool cull_done)
     ftkx::launch_tile_stats_fold(c->d_tile_stats, m.counters, c->stream);
   }
   // the FP64 half, once for the whole batch: records of every simplex that passed (timed with the kernel family that fed it)
-  if (nfields) { ev_begin(c, tiles.empty() ? K_EXACT : K_TILE); ftkx::launch_records(m, d_fields, c->stream); ev_end(c); }
+  // (K_EXACT also behind tile requests: K_TILE is the integer test of every simplex and nothing else -- bench.py's int-VALU figure)
+  if (nfields) { ev_begin(c, K_EXACT); ftkx::launch_records(m, d_fields, c->stream); ev_end(c); }
   HIP_TRY(c, hipGetLastError());
   return FTKX_OK;
 }

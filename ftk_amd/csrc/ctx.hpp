@@ -241,6 +241,7 @@ struct ftkx_ctx {
   size_t h_red_cap = 0;             //   (slots it can hold; the flag lives behind them)
   unsigned red_seq = 0;
   int dense_collects = 0;           // > 0: the last fast collect found most cells surviving; fast requests run MODE_TILE_CULL for a while
+  int tile_repeat = 1;              // ftkx_debug_tile_repeat: the tile kernel's fan phase that many times per tile (the int-VALU yardstick of bench.py)
   // compact halo: the compacted mask words of the last ftkx_export_masks_size, the surviving cells of the last ftkx_sweep_cull
   unsigned *d_word_idx = nullptr; u64 *d_words = nullptr; size_t words_cap = 0, n_words = 0; int words_t = -1;
   u64 *d_cells = nullptr; size_t cells_cap = 0, n_cells = 0;

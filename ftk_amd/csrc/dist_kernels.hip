@@ -3,7 +3,7 @@
 // What links the ranks of a t-slab partition is small: the sticky running minimum of update_vector_field_scaling_factor
 // (include/ftk/filters/critical_point_tracker.hh:850-864) runs over the slices in time order, so rank r needs the minimum over the slabs
 // before it and the reduction of the one slice it shares with rank r + 1; and its last interval sweep reads that slice -- as sign masks
-// plus the input values around the cells that survive the cull (the compact halo, sweep_kernels.hip).  Every one of these numbers is
+// plus the input values around the cells that survive the cull (the compact halo, halo_kernels.hip).  Every one of these numbers is
 // produced and consumed by a kernel here, so that the collectives between them (an all_gather of four doubles per rank, three
 // neighbour messages) are queued on the stream by the caller and the host waits once per pass, as with one rank.
 #include "sweep_device.hpp"
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void dist_contrib_kernel(const SeriesSlice *__
 // word in M, its 8 bytes; any order).  A wavefront reserves its run of the list with ONE atomic.  The workgroup that finishes last
 // writes the header (the count lives on the device; the receiver reads it there).  block[DB_WORDS], block[DB_DONE] must be 0 on entry
 // (the import kernel of the pass that used this block before leaves them so).
-constexpr u64 kPackedMagicD = 0x66746b786d61736bull;      // "ftkxmask" (sweep_kernels.hip: kPackedMagic)
+constexpr u64 kPackedMagicD = 0x66746b786d61736bull;      // "ftkxmask" (halo_kernels.hip: kPackedMagic)
 __global__ __launch_bounds__(256) void dist_export_kernel(const Mesh m, const u64 *__restrict__ U, const unsigned char *__restrict__ M, u64 u_bytes, u64 *__restrict__ hdr,
                                                           unsigned *__restrict__ idx, u64 *__restrict__ words, u64 capacity, unsigned factor_log2, u64 *__restrict__ block)
 {

@@ -681,6 +681,15 @@ int ftkx_invalidate_masks(ftkx_ctx *c)
   return FTKX_OK;
 }
 
+
+// profiling aid (bench.py's int-VALU yardstick): from the next sweep on, the tile kernel runs its fan phase -- the predicate arithmetic on
+// the tile staged in LDS -- `repeat` times per tile and step; records and statistics are those of one.  1 = off.
+int ftkx_debug_tile_repeat(ftkx_ctx *c, int repeat)
+{
+  if (!c || repeat < 1) return fail(c, FTKX_E_INVALID, "ftkx_debug_tile_repeat: repeat >= 1");
+  c->tile_repeat = repeat;
+  return FTKX_OK;
+}
 int ftkx_debug_stream_read(ftkx_ctx *c, const void *device_ptr, size_t bytes)
 {
   if (!c || !device_ptr) return fail(c, FTKX_E_INVALID, "null argument");

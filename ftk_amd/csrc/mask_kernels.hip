@@ -1,555 +1,12 @@
-// HIP kernels of the critical-point space-time simplex sweep for gfx950 (MI355X, CDNA4).
-//
-// Replaces, behind the reference's accelerator boundary, what the reference does per timestep in
-//   critical_point_tracker_{2d,3d}_regular::update_timestep() -> element_for_{ordinal,interval} -> check_simplex
-//   (include/ftk/filters/critical_point_tracker_2d_regular.hh:263-433, 584-685; ..._3d_regular.hh:150-308, 425-514)
-// and what its CUDA back-end does with one thread per simplex and a global atomic per hit
-//   (src/filters/critical_point_tracer_{2d,3d}_regular.cu).
-//
-// Two paths, chosen by the host per request (ftkx_api.hip):
-//
-// FAST PATH (robust test, no int64 overflow possible -> the strict-sign cull is exact):
-//   mask_kernel    streams a slice once (S, 8 B/vertex, gradient evaluated in flight -- or V for vector input) and writes one
-//                  byte per vertex: which components are strictly positive / strictly negative after quantisation;
-//   cull_kernel    streams the mask bytes of slices t and t+1 (2 B/vertex): 8 corners per lane as one 64-bit word, the AND
-//                  over the 2^(d+1) hypercube vertices done with shifts (SWAR); a corner whose AND is non-zero has a component
-//                  of uniform strict sign, none of its 12/60 simplices can contain the origin; survivors are appended to a
-//                  work list with one atomic per wavefront (prefix sum across lanes);
-//   exact_kernel   persistent workgroups pull chunks of surviving corners, stage each corner's 2^(d+1) quantised vertices in
-//                  LDS once, and spread the (corner x simplex type) pairs over all lanes: per-simplex cull, exact integer
-//                  predicate (cp_device.hpp), FP64 solve + classification for hits, ballot-compacted append.
-// TILE PATH (exact_only, non-robust 3D, or determinants that may wrap): one workgroup per tile of corners stages the tile's
-//   vertex block in LDS and tests every simplex (optionally with the same cull); used as-is when the cull is illegal.
-//
-// No MFMA: 64-bit integer VALU work on 8-24 bytes per vertex, HBM-bound once the cull applies.
+// The MASK kernels of the fast path (gfx950): one pass over a slice -- S, 8 bytes per vertex, the gradient evaluated in flight, or V for
+// vector input -- writes a sign-mask byte per vertex, the block summaries and the reduction update_vector_field_scaling_factor needs
+// (critical_point_tracker.hh:850-864, ndarray.hh:770-778).  HBM-bound; which kernel takes which mesh: launch_masks_impl at the end.
+// (Split from sweep_kernels.hip in round 6.)
 #include "internal.hpp"
 #include "sweep_device.hpp"
 #include "series_device.hpp"
 
 namespace ftkx {
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// TILE PATH
-// ---------------------------------------------------------------------------------------------------------------
-template <class F, int... I> __device__ __forceinline__ void fan_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F> __device__ __forceinline__ void fan_for(F &&f) { fan_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
-#ifdef FTKX_TILE_STAMPS
-__device__ unsigned long long g_tile_stamps[512 * 8];
-#define TILE_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); phase_[k] = now_ - stamp_; stamp_ = now_; } while (0)
-#else
-#define TILE_STAMP(k) do { } while (0)
-#endif
-#ifndef FTKX_FAN_WAVES
-#define FTKX_FAN_WAVES 2
-#endif
-struct fan_result { unsigned hits[2], unsure[2], tested; };     // bit T of the 64: simplex type T
-
-// sum_k p_k * b_k in Z / 2^64 for 64-bit p_k and sign-extended 32-bit b_k: per term ONE 32 x 32 -> 64 multiply-add on the low words,
-// one 32-bit multiply for the high word, and the sign of b_k as a mask instead of a third multiply
-// (p * b = lo * bu + 2^32 * (hi * bu - [b < 0] * lo), bu = b as unsigned)
-__device__ __forceinline__ u64 dot3_64_s32(u64 p0, u64 p1, u64 p2, int b0, int b1, int b2)
-{
-  const unsigned l0 = (unsigned)p0, l1 = (unsigned)p1, l2 = (unsigned)p2, h0 = (unsigned)(p0 >> 32), h1 = (unsigned)(p1 >> 32), h2 = (unsigned)(p2 >> 32);
-  const u64 r = (u64)l0 * (unsigned)b0 + (u64)l1 * (unsigned)b1 + (u64)l2 * (unsigned)b2;
-  const unsigned h = (unsigned)(r >> 32) + h0 * (unsigned)b0 + h1 * (unsigned)b1 + h2 * (unsigned)b2
-                   - (l0 & (unsigned)(b0 >> 31)) - (l1 & (unsigned)(b1 >> 31)) - (l2 & (unsigned)(b2 >> 31));
-  return (u64)(unsigned)r | ((u64)h << 32);
-}
-
-// The whole 3D+t fan of ONE corner on one lane.  The generic loop of tile_kernel spreads (corner, type) pairs over the lanes and computes
-// every simplex from scratch: twelve LDS reads, a decode of the pair, four 3 x 3 minors.  Here a lane computes the 50 minors that
-// contain its corner ONCE (det(X_0, X_a, X_b), shared by 3.6 simplices each: fan_tables.hpp) and then walks the 60 simplex types with
-// compile-time vertex indices (`at(v, c)`: component c of hypercube vertex v, an LDS read at a constant offset from the lane's
-// corner): per simplex one minor of its own, three look-ups, the sign test.  Invalid / non-finite vertices and the strict-sign cull are
-// sixteen-bit masks tested against the simplex's vertex set.  Two arithmetics for the same values:
-//   * integer (comp_t = int): |component| < 2^31 (tile_kernel checks).  2 x 2 minors from 32 x 32 -> 64 multiplies, determinants by
-//     dot3_64_s32, everything in Z / 2^64 exactly as origin_in_simplex3 -- wrapped determinants included;
-//   * fp64 (comp_t = double): |component| < 2^19.  Nothing wraps there (|3 x 3 determinant| < 6 * 2^57, |D| < 42 * 2^57 < 2^63), so the
-//     reference's wrapped signs are the integers' true signs, and a double-precision evaluation decides them whenever the value is
-//     clear of its rounding error: minors are exact (< 2^39), a determinant is off by less than 2^9, D by less than 2^11; `clear` =
-//     4096 then, and 0.5 where |component| < 2^16, since then every intermediate is an integer below 2^53 and the evaluation is
-//     exact.  v_fma_f64 is a full-rate instruction on gfx950, a 32 x 32 -> 64 integer multiply a quarter-rate one.
-// A simplex with a value that is zero / INT64_MIN (fp64: not clear of zero) comes back in `unsure`: tile_kernel gives it the integer
-// test with the literal cascade.
-template <class comp_t, class At>
-__device__ __forceinline__ fan_result fan_of_corner3(At &&at, unsigned inv, const unsigned (&pos)[3], const unsigned (&neg)[3],
-                                                     bool do_ord, bool do_int, int cull, double clear)
-{
-  constexpr bool FP = std::is_same<comp_t, double>::value;
-  using minor_t = std::conditional_t<FP, double, u64>;
-  auto minor = [](comp_t a, comp_t b, comp_t c, comp_t d) __attribute__((always_inline)) -> minor_t {      // a * b - c * d
-    if constexpr (FP) return fma(a, b, -(c * d));             // (exact either way: both products are integers below 2^38)
-    else return (u64)((i64)a * (i64)b) - (u64)((i64)c * (i64)d);
-  };
-  // X_k . (X_i x X_j)
-  auto det = [&](auto I, auto J, auto K) __attribute__((always_inline)) -> minor_t {
-    constexpr int i = decltype(I)::value, j = decltype(J)::value, k = decltype(K)::value;
-    const comp_t i0 = at(I, 0), i1 = at(I, 1), i2 = at(I, 2), j0 = at(J, 0), j1 = at(J, 1), j2 = at(J, 2);
-    const minor_t c0 = minor(i1, j2, i2, j1), c1 = minor(i2, j0, i0, j2), c2 = minor(i0, j1, i1, j0);
-    if constexpr (FP) return fma(c2, at(K, 2), fma(c1, at(K, 1), c0 * at(K, 0)));
-    else return dot3_64_s32(c0, c1, c2, at(K, 0), at(K, 1), at(K, 2));
-    (void)i; (void)j; (void)k;
-  };
-  minor_t D[50];                                               // det(X_0, X_a, X_b) = X_b . (X_0 x X_a)
-  fan_for<50>([&](auto IC) __attribute__((always_inline)) {
-    constexpr int i = decltype(IC)::value;
-    // (the same cross product for every b: the compiler keeps one copy per a)
-    D[i] = det(std::integral_constant<int, 0>{}, std::integral_constant<int, k_fan_pairs.a[i]>{}, std::integral_constant<int, k_fan_pairs.b[i]>{});
-  });
-  unsigned h0 = 0, h1 = 0, g0 = 0, g1 = 0, tested = 0;
-  // "clear of zero", on ONE word per value.  Integer: x == 0 || x == INT64_MIN  <=>  (lo | hi << 1) == 0.  fp64: the high word of |x|
-  // above the high word of `clear` (4096.0 or 0.5, both with a zero low word) -- as good as the comparison of the doubles for 0.5 (the
-  // values are integers there) and only slightly stricter for 4096.
-  auto word = [](minor_t x) __attribute__((always_inline)) -> unsigned {
-    if constexpr (FP) return (unsigned)__double2hiint(x) & 0x7fffffffu;
-    else return (unsigned)x | ((unsigned)(x >> 32) << 1);
-  };
-  auto top = [](minor_t x) __attribute__((always_inline)) -> unsigned {        // the word with the sign bit
-    if constexpr (FP) return (unsigned)__double2hiint(x); else return (unsigned)(x >> 32);
-  };
-  const unsigned clear_word = FP ? (unsigned)__double2hiint(clear) : 0u;
-  fan_for<60>([&](auto IC) __attribute__((always_inline)) {
-    constexpr int T = decltype(IC)::value;
-    constexpr int m1 = k_fan4.vert[T][1], m2 = k_fan4.vert[T][2], m3 = k_fan4.vert[T][3];
-    constexpr unsigned tm = 1u | (1u << m1) | (1u << m2) | (1u << m3);
-    constexpr bool ordinal = k_fan4.ordinal[T] != 0;
-    constexpr unsigned bit = 1u << (T & 31);
-    bool active = (ordinal ? do_ord : do_int) && !(inv & tm);
-    if (cull) {
-      const bool same = (pos[0] & tm) == tm || (neg[0] & tm) == tm || (pos[1] & tm) == tm || (neg[1] & tm) == tm || (pos[2] & tm) == tm || (neg[2] & tm) == tm;
-      active = active && !same;
-    }
-    if (active) {
-      tested ++;
-      // C0 = -n0, C1 = n1, C2 = -n2, C3 = n3, D = their sum; n0 = det(X_m1, X_m2, X_m3) = X_m1 . (X_m2 x X_m3) is the simplex's own
-      // minor, the other three are shared ones.  First those three: if they are clear of zero and C1, C2, C3 do not have one sign, the
-      // origin is outside whatever C0 and D are (the cascade too wants all signs equal, and gives a non-degenerate value its own
-      // sign) -- on smooth data neighbouring corners agree on that, and whole wavefronts skip the fourth determinant.
-      const minor_t n1 = D[k_fan_pairs.index[m2][m3]], n2 = D[k_fan_pairs.index[m1][m3]], n3 = D[k_fan_pairs.index[m1][m2]];
-      const unsigned w1 = top(n1), w2 = top(n2), w3 = top(n3);
-      const bool sure3 = min(min(word(n1), word(n2)), word(n3)) > clear_word;
-      const bool agree3 = (int)(~(w1 ^ w2) | (w1 ^ w3)) >= 0;         // sign bits: C1 = C2 (n1 != n2) and C1 = C3
-      unsigned is_hit = 0, is_unsure = sure3 ? 0u : bit;
-      if (sure3 && agree3) {
-        const minor_t n0 = det(std::integral_constant<int, m2>{}, std::integral_constant<int, m3>{}, std::integral_constant<int, m1>{});
-        const minor_t d = (n1 - n0) + (n3 - n2);
-        // (a value that passed and its negative have opposite sign bits: C0 = D <=> n0 != D in the sign bit)
-        const bool sure = min(word(n0), word(d)) > clear_word;
-        const unsigned w0 = top(n0), wd = top(d);
-        is_hit = (sure && (int)(~(w0 ^ wd) | (w1 ^ wd)) >= 0) ? bit : 0u;
-        is_unsure = sure ? 0u : bit;
-      }
-      if (T < 32) { h0 |= is_hit; g0 |= is_unsure; } else { h1 |= is_hit; g1 |= is_unsure; }
-    }
-  });
-  fan_result r;
-  r.hits[0] = h0; r.hits[1] = h1; r.unsure[0] = g0; r.unsure[1] = g1; r.tested = tested;
-  return r;
-}
-
-// The 2D+t fan of one corner on one lane: 12 triangles over the 8 vertices of the corner's space-time cube.  A triangle is a chain
-// 0 < m1 < m2; of its three "vertex replaced by the origin" determinants two contain the corner -- det(X_0, X_a), seven of them for the
-// whole fan -- and one, det(X_m1, X_m2), is its own: C0 = det(X_m1, X_m2), C1 = -det(X_0, X_m2), C2 = det(X_0, X_m1), D = their sum
-// (origin_in_simplex2).  Integer: components below 2^31, minors from 32 x 32 -> 64 multiplies, D in Z / 2^64 as the reference has it.  fp64:
-// components below 2^25 -- products below 2^50, every value an integer below 2^53: the evaluation is EXACT, and only a true zero is "unsure".
-template <class comp_t, class At>
-__device__ __forceinline__ fan_result fan_of_corner2(At &&at, unsigned inv, const unsigned (&pos)[3], const unsigned (&neg)[3],
-                                                     bool do_ord, bool do_int, int cull, double clear)
-{
-  constexpr bool FP = std::is_same<comp_t, double>::value;
-  using minor_t = std::conditional_t<FP, double, u64>;
-  auto minor = [&](auto I, auto J) __attribute__((always_inline)) -> minor_t {          // det(X_i, X_j)
-    const comp_t a = at(I, 0), b = at(J, 1), c = at(I, 1), d = at(J, 0);
-    if constexpr (FP) return fma(a, b, -(c * d));
-    else return (u64)((i64)a * (i64)b) - (u64)((i64)c * (i64)d);
-  };
-  minor_t M[8];                                                // det(X_0, X_a)
-  M[0] = minor_t(0);
-  fan_for<7>([&](auto IC) __attribute__((always_inline)) {
-    constexpr int a = decltype(IC)::value + 1;
-    M[a] = minor(std::integral_constant<int, 0>{}, std::integral_constant<int, a>{});
-  });
-  auto word = [](minor_t x) __attribute__((always_inline)) -> unsigned {
-    if constexpr (FP) return (unsigned)__double2hiint(x) & 0x7fffffffu;
-    else return (unsigned)x | ((unsigned)(x >> 32) << 1);
-  };
-  auto top = [](minor_t x) __attribute__((always_inline)) -> unsigned {
-    if constexpr (FP) return (unsigned)__double2hiint(x); else return (unsigned)(x >> 32);
-  };
-  const unsigned clear_word = FP ? (unsigned)__double2hiint(clear) : 0u;
-  unsigned h0 = 0, g0 = 0, tested = 0;
-  fan_for<12>([&](auto IC) __attribute__((always_inline)) {
-    constexpr int T = decltype(IC)::value;
-    constexpr int m1 = k_fan3.vert[T][1], m2 = k_fan3.vert[T][2];
-    constexpr unsigned tm = 1u | (1u << m1) | (1u << m2);
-    constexpr bool ordinal = k_fan3.ordinal[T] != 0;
-    constexpr unsigned bit = 1u << T;
-    bool active = (ordinal ? do_ord : do_int) && !(inv & tm);
-    if (cull) {
-      const bool same = (pos[0] & tm) == tm || (neg[0] & tm) == tm || (pos[1] & tm) == tm || (neg[1] & tm) == tm;
-      active = active && !same;
-    }
-    if (active) {
-      tested ++;
-      // C1 = -M[m2] and C2 = M[m1] first: clear of zero and of different signs -> outside, whatever C0 and D are
-      const minor_t n1 = M[m2], n2 = M[m1];
-      const unsigned w1 = top(n1), w2 = top(n2);
-      const bool sure2 = min(word(n1), word(n2)) > clear_word;
-      const bool agree2 = (int)(w1 ^ w2) < 0;                    // sign(-n1) == sign(n2)
-      unsigned is_hit = 0, is_unsure = sure2 ? 0u : bit;
-      if (sure2 && agree2) {
-        const minor_t n0 = minor(std::integral_constant<int, m1>{}, std::integral_constant<int, m2>{});
-        const minor_t d = (n0 - n1) + n2;
-        const bool sure = min(word(n0), word(d)) > clear_word;
-        const unsigned w0 = top(n0), wd = top(d);
-        is_hit = (sure && (int)((w0 ^ wd) | (w2 ^ wd)) >= 0) ? bit : 0u;
-        is_unsure = sure ? 0u : bit;
-      }
-      h0 |= is_hit; g0 |= is_unsure;
-    }
-  });
-  fan_result r;
-  r.hits[0] = h0; r.hits[1] = 0; r.unsure[0] = g0; r.unsure[1] = 0; r.tested = tested;
-  return r;
-}
-
-// FORM 0: (corner, type) pairs over the lanes for every tile.  FORM 1 (3D, robust test): tiles whose components fit in 32 bits take the
-// integer fan, the others the pairs.  FORM 2: tiles with |component| < 2^19 take the fp64 fan, else as FORM 1.  The host picks the form
-// from what it knows of the slices' magnitudes (launch_tile); every form is correct on every tile -- the forms differ in registers.
-template <int ND, int FORM>
-__global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile_kernel(const TileParams p)
-{
-  using cfg = tile_cfg<ND>;
-  constexpr int N = ND + 1;
-  constexpr int HX = cfg::TX + 1, HY = cfg::TY + 1, HZ = (ND == 3) ? cfg::TZ + 1 : 1;
-  constexpr int NH = HX * HY * HZ;
-  constexpr int NORD = fan_table<N>::NORD, NINT = fan_table<N>::NINT;
-  static_assert(cfg::TX * cfg::TY * cfg::TZ == kThreads, "one corner per lane");
-
-  // 3D, scalar input: the gradients of a tile's 17 x 5 x 5 x 2 vertices read a 19 x 7 x 7 x 2 block of S -- loaded once into LDS with every
-  // load of a lane in flight together (one round trip), instead of six dependent global loads per vertex and 2.7 reads per value
-  constexpr bool S_BLOCK = ND == 3;
-  constexpr int SX = cfg::TX + 3, SY = cfg::TY + 3, SZ = cfg::TZ + 3, NS = S_BLOCK ? SX * SY * SZ : 1;
-  constexpr int kItems = 512;
-  __shared__ i64 s_vf[2][ND][NH];                      // quantised components, one array per (slice, component)
-  __shared__ double s_vd[FORM >= 2 ? 2 * ND * NH : 1]; // FORM 2: the same as doubles (exact below 2^53; read where the tile is below 2^19)
-  __shared__ double s_s[2][NS];
-  __shared__ unsigned char s_mask[2][NH];
-  __shared__ unsigned s_tab[fan_table<N>::NTYPES];     // the vertex masks of a type packed in one word
-  __shared__ unsigned short s_list[2][kThreads];       // surviving corners: [0] ordinal sweep, [1] interval sweep
-  __shared__ unsigned s_cnt[2];
-  __shared__ unsigned s_wflags[kThreads / 64];
-  __shared__ unsigned short s_items[FORM >= 1 ? kItems : 1];   // fan forms: (lane, type) of the simplices the fan was not sure of
-  __shared__ unsigned s_nitems, s_stat[2];
-
-  const int tid = threadIdx.x;
-  const fan_table<N> &fan = dev_fan<ND>();
-  const Mesh &m = p.m;
-  const Fields &f = p.f;
-#ifdef FTKX_TILE_STAMPS
-  unsigned long long stamp_ = __builtin_readcyclecounter(), phase_[6] = {0, 0, 0, 0, 0, 0};
-#endif
-
-  // workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2): give each XCD a
-  // contiguous run of tiles so that neighbouring tiles' shared halo vertices hit the same L2.
-  const unsigned nblocks = gridDim.x;
-  unsigned b = blockIdx.x;
-  {
-    const unsigned per = nblocks / 8, rem = nblocks % 8, xcd = b % 8, k = b / 8;
-    b = xcd * per + (xcd < rem ? xcd : rem) + k;
-  }
-  const int tile[3] = {(int)(b % p.ntiles[0]), (int)((b / p.ntiles[0]) % p.ntiles[1]), (int)(b / (p.ntiles[0] * p.ntiles[1]))};
-  const int origin[3] = {m.core_st[0] + tile[0] * cfg::TX, m.core_st[1] + tile[1] * cfg::TY, (ND == 3) ? m.core_st[2] + tile[2] * cfg::TZ : 0};
-  const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0;
-
-  if (tid < fan_table<N>::NTYPES) {
-    unsigned w = 0;
-    for (int i = 0; i < N; i ++) w |= (unsigned)fan.vert[tid][i] << (8 * i);
-    s_tab[tid] = w;
-  }
-  if (tid < 2) { s_cnt[tid] = 0; s_stat[tid] = 0; }
-  if (tid == 2) s_nitems = 0;
-
-  // ---- stage ----
-  const bool from_block = S_BLOCK && m.scalar_mode;
-  if constexpr (S_BLOCK) {
-    if (from_block) {
-      constexpr int ROUNDS = (2 * NS + kThreads - 1) / kThreads;
-      double got[ROUNDS];
-#pragma unroll
-      for (int r = 0; r < ROUNDS; r ++) {
-        const int idx = tid + r * kThreads, sl = idx / NS, at = idx - sl * NS;
-        const int i = origin[0] - 1 + at % SX - m.ext_st[0], j = origin[1] - 1 + (at / SX) % SY - m.ext_st[1], k = origin[2] - 1 + at / (SX * SY) - m.ext_st[2];
-        const bool in = idx < 2 * NS && (sl == 0 || need_next) && i >= 0 && i < m.ext_sz[0] && j >= 0 && j < m.ext_sz[1] && k >= 0 && k < m.ext_sz[2];
-        got[r] = in ? f.S[sl][arr_index<3>(m, i, j, k)] : 0.0;
-      }
-#pragma unroll
-      for (int r = 0; r < ROUNDS; r ++) {
-        const int idx = tid + r * kThreads;
-        if (idx < 2 * NS) s_s[idx / NS][idx % NS] = got[r];
-      }
-      __syncthreads();
-    }
-  }
-  TILE_STAMP(0);
-  bool mine_narrow = true, mine_mid = true, mine_small = true;
-  for (int h = tid; h < 2 * NH; h += kThreads) {
-    const int sl = h / NH, hv = h - sl * NH;
-    if (sl == 1 && !need_next) break;
-    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-    const int vx[3] = {origin[0] + hx, origin[1] + hy, origin[2] + hz};
-    i64 q[ND];
-    unsigned char mk;
-    if (from_block) {
-      // gradient3D of ndarray/grad.hh out of the block: the same operations as gradient_at on the same values
-      for (int j = 0; j < ND; j ++) q[j] = 0;
-      mk = kInvalid;
-      if (vertex_usable<ND>(m, vx)) {
-        const int i = vx[0] - m.ext_st[0], j = vx[1] - m.ext_st[1], k = vx[2] - m.ext_st[2];
-        double g[3] = {0.0, 0.0, 0.0};
-        if (i >= 1 && i < m.ext_sz[0] - 1 && j >= 1 && j < m.ext_sz[1] - 1 && k >= 1 && k < m.ext_sz[2] - 1) {
-          const double *c = &s_s[sl][(hx + 1) + SX * ((hy + 1) + SY * (hz + 1))];
-          g[0] = 0.5 * (c[1] - c[-1]);
-          g[1] = 0.5 * (c[SX] - c[-SX]);
-          g[2] = 0.5 * (c[SX * SY] - c[-SX * SY]);
-        }
-        mk = classify_value<ND>(g, f.factor, q);
-      }
-    } else mk = classify_vertex<ND>(m, f.S[sl], f.V[sl], f.factor, vx, q);
-    s_mask[sl][hv] = mk;
-    for (int j = 0; j < ND; j ++) {
-      s_vf[sl][j][hv] = q[j];
-      if constexpr (FORM >= 2) s_vd[(sl * ND + j) * NH + hv] = (double)q[j];
-      mine_narrow = mine_narrow && fits_s32(q[j]);
-      const u64 aq = (u64)(q[j] < 0 ? -q[j] : q[j]);
-      mine_mid = mine_mid && aq < (1ull << (ND == 3 ? 19 : 25)); mine_small = mine_small && aq < (1ull << (ND == 3 ? 16 : 25));
-    }
-  }
-  TILE_STAMP(1);
-  // all quantised components of the tile fit in 32 bits: the integer test takes its cheaper multiplies -- same values, see cp_device.hpp;
-  // below 2^19, 2^16: the 3D fan decides signs in double precision, fan_of_corner3.  (One word per wavefront and ONE barrier, which is
-  // also the one between staging and everything that reads the staged tile.)
-  {
-    const unsigned bits = (__all(mine_narrow) ? 1u : 0u) | (__all(mine_mid) ? 2u : 0u) | (__all(mine_small) ? 4u : 0u);
-    if ((tid & 63) == 0) s_wflags[tid >> 6] = bits;
-  }
-  __syncthreads();
-  unsigned tile_bits = 7u;
-  for (int w = 0; w < kThreads / 64; w ++) tile_bits &= s_wflags[w];
-  const bool narrow = (tile_bits & 1u) != 0;
-  TILE_STAMP(2);
-  const bool fan_int = FORM >= 1 && narrow && (ND == 2 || m.robust) && p.fan >= 1;
-  const bool fan_fp = FORM >= 2 && fan_int && p.fan >= 2 && (tile_bits & 2u);
-  const bool small = fan_fp && (tile_bits & 4u);
-
-  // ---- cull: one corner per lane ----
-  const int cx = tid % cfg::TX, cy = (tid / cfg::TX) % cfg::TY, cz = tid / (cfg::TX * cfg::TY);
-  bool in_core = true;
-  {
-    const int csp[3] = {origin[0] + cx, origin[1] + cy, origin[2] + cz};
-    for (int d = 0; d < ND; d ++) in_core = in_core && csp[d] < m.core_st[d] + m.core_sz[d];
-  }
-  const int hbase = cx + HX * (cy + HY * cz);
-  bool keep_o = false, keep_i = false;
-  {
-    unsigned and0 = 0x3f, and1 = 0x3f;
-    for (int c = 0; c < (1 << ND); c ++) {
-      const int off = (c & 1) + HX * (((c >> 1) & 1) + HY * ((c >> 2) & 1));
-      // vertices no simplex may use (outside the domain, non-finite) are neutral for the sign argument
-      const unsigned m0 = s_mask[0][hbase + off];
-      and0 &= (m0 & (kInvalid | kNonFinite)) ? 0x3fu : m0;
-      if (need_next) { const unsigned m1 = s_mask[1][hbase + off]; and1 &= (m1 & (kInvalid | kNonFinite)) ? 0x3fu : m1; }
-    }
-    keep_o = in_core && (f.scope_mask & FTKX_SCOPE_ORDINAL) && !(p.cull && (and0 & 0x3f));
-    keep_i = in_core && need_next && !(p.cull && (and0 & and1 & 0x3f));
-  }
-  const unsigned long long ballot_o = __ballot(keep_o), ballot_i = __ballot(keep_i);
-  unsigned tested = 0;
-  if constexpr (FORM >= 1) {
-    // ---- test, one corner per lane (fan_of_corner3 / fan_of_corner2) ----
-    if (fan_int && p.fan != 9) {
-      u64 hits = 0, unsure = 0;
-      constexpr int NV = 1 << N;                                  // vertices of the corner's space-time hypercube
-      int corner[N];
-      corner[0] = origin[0] + cx; corner[1] = origin[1] + cy;
-      if (ND == 3) corner[2] = origin[2] + cz;
-      corner[ND] = f.t;
-      // (vertex v of the corner's hypercube: bit d = one step along axis d, bit ND = the next slice)
-      auto offset = [](int v) constexpr { return (v & 1) + HX * (((v >> 1) & 1) + (ND == 3 ? HY * ((v >> 2) & 1) : 0)); };
-      if (ballot_o | ballot_i) {                                 // (a wavefront nothing of which survived its cull: nothing to do)
-        unsigned inv = 0, pos[3] = {0, 0, 0}, neg[3] = {0, 0, 0};
-#pragma unroll
-        for (int v = 0; v < NV; v ++) {
-          unsigned mk = kInvalid;
-          if ((v >> ND) == 0 || need_next) mk = s_mask[v >> ND][hbase + offset(v)];
-          if (mk & (kInvalid | kNonFinite)) inv |= 1u << v;
-#pragma unroll
-          for (int c = 0; c < ND; c ++) { if (mk & (1u << c)) pos[c] |= 1u << v; if (mk & (8u << c)) neg[c] |= 1u << v; }
-        }
-        // (component c of vertex v; slice 1 of an ordinal-only request is not staged: whatever is read there only enters simplices that
-        // `inv` switches off)
-        fan_result fr;
-        if (FORM >= 2 && fan_fp) {
-          const double *base = s_vd + hbase;
-          auto at = [&](auto V, int c) __attribute__((always_inline)) { constexpr int v = decltype(V)::value; return base[((v >> ND) * ND + c) * NH + offset(v)]; };
-          if constexpr (ND == 3) fr = fan_of_corner3<double>(at, inv, pos, neg, keep_o, keep_i, p.cull, small ? 0.5 : 4096.0);
-          else fr = fan_of_corner2<double>(at, inv, pos, neg, keep_o, keep_i, p.cull, 0.5);
-        } else {
-          const i64 *base = &s_vf[0][0][0] + hbase;
-          auto at = [&](auto V, int c) __attribute__((always_inline)) { constexpr int v = decltype(V)::value; return (int)base[((v >> ND) * ND + c) * NH + offset(v)]; };
-          if constexpr (ND == 3) fr = fan_of_corner3<int>(at, inv, pos, neg, keep_o, keep_i, p.cull, 0.0);
-          else fr = fan_of_corner2<int>(at, inv, pos, neg, keep_o, keep_i, p.cull, 0.0);
-        }
-        tested += fr.tested;
-        hits = (u64)fr.hits[0] | ((u64)fr.hits[1] << 32); unsure = (u64)fr.unsure[0] | ((u64)fr.unsure[1] << 32);
-      }
-      TILE_STAMP(3);
-      // A value that is zero / INT64_MIN (fp64: not clear of zero): the integer test and the literal cascade on the vertices as staged.
-      // One simplex in thousands, but a long computation: the (lane, type) pairs of the whole tile go on a list and are dealt to the lanes
-      // again (a lane that walked its own would hold its wavefront for each of them).
-      auto corner_of = [&](int lane_tid, int (&lc)[N]) -> int {
-        const int lx = lane_tid % cfg::TX, ly = (lane_tid / cfg::TX) % cfg::TY, lz = lane_tid / (cfg::TX * cfg::TY);
-        lc[0] = origin[0] + lx; lc[1] = origin[1] + ly;
-        if (ND == 3) lc[2] = origin[2] + lz;
-        lc[ND] = f.t;
-        return lx + HX * (ly + HY * lz);
-      };
-      auto resolve = [&](int lane_tid, int type) -> bool {
-        int lc[N];
-        const int hb = corner_of(lane_tid, lc);
-        const unsigned tab = s_tab[type];
-        u64 X[N][ND]; int ids[N];
-        for (int i = 0; i < N; i ++) {
-          const unsigned vm = (tab >> (8 * i)) & 0xffu;
-          const int hidx = hb + (vm & 1) + HX * (((vm >> 1) & 1) + (ND == 3 ? HY * ((vm >> 2) & 1) : 0));
-          for (int j = 0; j < ND; j ++) X[i][j] = (u64)s_vf[(vm >> ND) & 1][j][hidx];
-          ids[i] = vertex_id<ND>(m, lc, vm);
-        }
-        int r;
-        if constexpr (ND == 2) r = origin_in_simplex2_try(X, true); else r = origin_in_simplex3_try(X, true);
-        return r < 0 ? sos_origin_in_simplex_resolved<ND>(X, ids) : r != 0;
-      };
-      for (;;) {                                                 // (one round unless the tile has more than kItems of them)
-        while (__any(unsure != 0)) {                             // append (wave-uniform trip count)
-          const bool have = unsure != 0;
-          const int type = have ? __ffsll((long long)unsure) - 1 : 0;
-          const unsigned long long hb = __ballot(have);
-          const int leader = __ffsll((long long)hb) - 1;
-          unsigned base = 0;
-          if ((tid & 63) == leader) base = atomicAdd(&s_nitems, (unsigned)__popcll(hb));
-          base = __shfl(base, leader);
-          const unsigned slot = base + (unsigned)__popcll(hb & ((1ull << (tid & 63)) - 1ull));
-          if (have && slot < (unsigned)kItems) { s_items[slot] = (unsigned short)((tid << 6) | type); unsure &= unsure - 1; }
-          if (base + (unsigned)__popcll(hb) > (unsigned)kItems) break;   // (the list is full -- the count says so to everybody: what is left waits for the next round)
-        }
-        __syncthreads();
-        const unsigned appended = s_nitems, nitems = appended < (unsigned)kItems ? appended : (unsigned)kItems;
-        for (unsigned base = 0; base < nitems; base += kThreads) {
-          const unsigned it = base + tid;
-          bool hit = false;
-          u64 desc = 0;
-          if (it < nitems) {
-            const unsigned item = s_items[it];
-            const int lane_tid = (int)(item >> 6), type = (int)(item & 63u);
-            hit = resolve(lane_tid, type);
-            int lc[N];
-            (void)corner_of(lane_tid, lc);
-            desc = core_linear<ND>(m, lc) | ((u64)type << kPassTypeShift) | ((u64)p.step << kPassStepShift);
-          }
-          emit_pass(m, hit, desc);
-        }
-        if (appended <= (unsigned)kItems) break;                 // (block-uniform: everybody read the same count)
-        __syncthreads();
-        if (tid == 0) s_nitems = 0;
-        __syncthreads();
-      }
-      const u64 lin = in_core ? core_linear<ND>(m, corner) : 0ull;
-      while (__any(hits != 0)) {
-        const bool hit = hits != 0;
-        const int type = hit ? __ffsll((long long)hits) - 1 : 0;
-        hits &= hits - 1;
-        emit_pass(m, hit, lin | ((u64)type << kPassTypeShift) | ((u64)p.step << kPassStepShift));
-      }
-    }
-  }
-  // the surviving corners as lists, for the (corner, type) pairs below
-  const bool pairs = !(fan_int || p.fan == 9);                 // (block-uniform)
-  if (pairs) {
-    const int lane = tid & 63;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    unsigned base_o = 0, base_i = 0;
-    if (lane == 0) {
-      if (ballot_o) base_o = atomicAdd(&s_cnt[0], (unsigned)__popcll(ballot_o));
-      if (ballot_i) base_i = atomicAdd(&s_cnt[1], (unsigned)__popcll(ballot_i));
-    }
-    base_o = __shfl(base_o, 0);
-    base_i = __shfl(base_i, 0);
-    if (keep_o) s_list[0][base_o + __popcll(ballot_o & below)] = (unsigned short)tid;
-    if (keep_i) s_list[1][base_i + __popcll(ballot_i & below)] = (unsigned short)tid;
-    __syncthreads();
-  }
-  const unsigned n_o = pairs ? s_cnt[0] : 0u, n_i = pairs ? s_cnt[1] : 0u;
-  // ---- test: (corner, type) pairs over all lanes ----
-  const unsigned items_o = n_o * NORD, total = items_o + n_i * NINT;
-  for (unsigned base = 0; base < total; base += kThreads) {   // wave-uniform trip count: the ballot in emit_hits stays convergent
-    const unsigned w = base + tid;
-    bool hit = false;
-    u64 desc = 0;
-    if (w < total) {
-      const bool ordinal = w < items_o;
-      const unsigned wl = ordinal ? w : w - items_o;
-      const unsigned ci = ordinal ? wl / NORD : wl / NINT;
-      const unsigned it = ordinal ? wl % NORD : wl % NINT;
-      const int type = ordinal ? fan.ord_types[it] : fan.int_types[it];
-      const int ct = s_list[ordinal ? 0 : 1][ci];
-      const int ccx = ct % cfg::TX, ccy = (ct / cfg::TX) % cfg::TY, ccz = ct / (cfg::TX * cfg::TY);
-      const int hb = ccx + HX * (ccy + HY * ccz);
-      const unsigned tab = s_tab[type];
-      unsigned char flags[N];
-      u64 X[N][ND];
-      for (int i = 0; i < N; i ++) {
-        const unsigned vm = (tab >> (8 * i)) & 0xffu;
-        const int hidx = hb + (vm & 1) + HX * (((vm >> 1) & 1) + ((ND == 3) ? HY * ((vm >> 2) & 1) : 0));
-        const int hsl = (vm >> ND) & 1;
-        flags[i] = s_mask[hsl][hidx];
-        for (int j = 0; j < ND; j ++) X[i][j] = (u64)s_vf[hsl][j][hidx];
-      }
-      int corner[N];
-      corner[0] = origin[0] + ccx; corner[1] = origin[1] + ccy;
-      if (ND == 3) corner[2] = origin[2] + ccz;
-      corner[ND] = f.t;
-      int ids[N]; double mu[N]; bool presolved;
-      hit = simplex_inside<ND>(m, f, p.cull, corner, tab, flags, X, tested, ids, mu, &presolved, narrow);
-      desc = core_linear<ND>(m, corner) | ((u64)type << kPassTypeShift) | ((u64)p.step << kPassStepShift);
-    }
-    emit_pass(m, hit, desc);
-  }
-  TILE_STAMP(4);
-  {
-    // statistics: one atomic per counter and workgroup (same-address atomics serialise chip-wide)
-    unsigned t_sum = tested;
-    for (int o = 32; o > 0; o >>= 1) t_sum += __shfl_down(t_sum, o);
-    if ((tid & 63) == 0) {
-      if (t_sum) atomicAdd(&s_stat[0], t_sum);
-      const unsigned kept = (unsigned)__popcll(need_next ? ballot_i : ballot_o);
-      if (kept) atomicAdd(&s_stat[1], kept);
-    }
-    __syncthreads();
-    u64 *slot = p.stats + 2u * (blockIdx.x & 255u);
-    if (tid == 0 && s_stat[0]) atomicAdd(&slot[0], (u64)s_stat[0]);
-    if (tid == 64 && s_stat[1]) atomicAdd(&slot[1], (u64)s_stat[1]);
-  }
-  TILE_STAMP(5);
-#ifdef FTKX_TILE_STAMPS
-  if ((tid & 63) == 0) {
-    unsigned long long *g = g_tile_stamps + (blockIdx.x % 512u) * 8;
-    for (int k = 0; k < 6; k ++) atomicAdd(&g[k], phase_[k]);
-    atomicAdd(&g[7], 1ull);
-  }
-#endif
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // FAST PATH 1/3: vertex sign masks.  One lane per mask byte (row pitch padded to whole 8-byte words, see Mesh::mask_pitch).
@@ -1894,691 +1351,6 @@ __global__ __launch_bounds__(64 * CY) void mask_march6_kernel(const Mesh m, cons
   march6_body<NS, CY, RY, TWOB>(m, jobs, swizzle, njobs, plan);
 }
 // ---------------------------------------------------------------------------------------------------------------
-// FAST PATH 2/3: corner cull on the mask bytes, 8 corners per lane (SWAR), survivors -> work list
-// ---------------------------------------------------------------------------------------------------------------
-// list entry: bits 0..39 corner index inside core (x fastest), bits 40..41 scope flags (1 ordinal, 2 interval), bits 44.. step
-__device__ inline u64 load_row_pair_and(const unsigned char *__restrict__ M, size_t row_off, int g)
-{
-  const u64 *w = reinterpret_cast<const u64 *>(M + row_off) + g;
-  const u64 w0 = w[0], w1 = w[1];                  // the pitch has 8 spare bytes: w[1] always exists
-  return w0 & ((w0 >> 8) | (w1 << 56));            // byte b = mask(x = 8g + b) & mask(x + 1)
-}
-
-// Marching form of the cull: a lane keeps, for its 8 corners and a short run of z planes, the AND over each slice's 2^d
-// spatial cube vertices in registers and walks through the consecutive timesteps of the batch, so that every mask byte is
-// read from HBM once per batch instead of once per (step, role).  The x+1 word of a lane is its upper neighbour's word (DPP).
-__device__ inline u64 dpp_u64_from_upper_lane(u64 v)
-{
-  int lo = (int)v, hi = (int)(v >> 32);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
-  return ((u64)(unsigned)hi << 32) | (u64)(unsigned)lo;
-}
-
-// COARSE = true runs the very same cull one level up: the "mask array" is the per-word summary U (one byte = 8 vertices), a
-// "corner" is an aligned group of 8 corners, and what survives is appended to the refine list instead of the final list.
-template <int ND, int ZC, bool COARSE>
-__global__ __launch_bounds__(kThreads) void cull_march_kernel(const Mesh m, const Fields *__restrict__ steps, int nsteps, int step_chunk,
-                                                              int gx_log2, u64 *__restrict__ list, u64 list_capacity, const FactorJob fj)
-{
-  if (fj.enabled && blockIdx.z == gridDim.z - 1) {             // the extra layer of the grid: one of its workgroups forms the factors
-    if (blockIdx.x == 0 && blockIdx.y == 0)
-      series_factors_body<kThreads, kFoldMaxSlices>(fj.steps, fj.nsteps, fj.slices, fj.nslices, fj.sinfo, fj.red, fj.running_in, fj.running_from, fj.safe_m, fj.results, fj.counters);
-    return;
-  }
-  constexpr int kListCounter = COARSE ? CNT_REFINE_LIST : CNT_SURVIVOR_LIST;
-  __shared__ unsigned s_wave_total[4];
-  __shared__ u64 s_block_base;
-  // 2D: the survivors of a workgroup's steps are parked in LDS and appended with ONE atomic at the end (or when the buffer could
-  // overflow): on hit-dense data every workgroup has survivors in every step, and the list counter is a single address -- 4 096
-  // returning atomics on it were half of this kernel's 40 us on 64 steps of 1024^2
-  constexpr unsigned STAGE_CAP = (ND == 2) ? 2048u : 1u;             // (a step's worst case: 256 lanes x 8 corners)
-  __shared__ u64 s_stage[STAGE_CAP];
-  __shared__ unsigned s_staged, s_run;
-  if (ND == 2) { if (threadIdx.x == 0) s_staged = 0; __syncthreads(); }
-  auto flush_stage = [&]() {                                   // called by the whole workgroup, after a barrier that made s_staged final
-    const unsigned n = s_staged;
-    if (threadIdx.x == 0) s_block_base = n ? atomicAdd(&m.counters[kListCounter], (u64)n) : 0ull;
-    __syncthreads();
-    const u64 base = s_block_base;
-    for (unsigned h = threadIdx.x; h < n; h += kThreads) if (base + h < list_capacity) list[base + h] = s_stage[h];
-    __syncthreads();
-    if (threadIdx.x == 0) s_staged = 0;
-    __syncthreads();
-  };
-  constexpr u64 kAll = 0x3f3f3f3f3f3f3f3full, k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
-  const int DW = m.ext_sz[0], DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // a wavefront covers GX 8-corner groups along x times 64/GX rows (GX = 64 for rows of 512+ vertices)
-  const int GX = 1 << gx_log2, rows_per_wave = 64 >> gx_log2;
-  const int gl = lane & (GX - 1);
-  const int g = blockIdx.x * GX + gl;
-  const int j = (blockIdx.y * 4 + wv) * rows_per_wave + (lane >> gx_log2);
-  const int nzc = (ND == 3) ? (DD + ZC - 1) / ZC : 1;
-  const int z0 = (ND == 3) ? (int)(blockIdx.z % nzc) * ZC : 0;
-  const int s0 = (int)(blockIdx.z / nzc) * step_chunk;
-  const int s1 = s0 + step_chunk < nsteps ? s0 + step_chunk : nsteps;
-  const int ngroups = (DW + 7) / 8;
-  const bool g_ok = g < ngroups;
-  const int gc = g_ok ? g : ngroups - 1;                       // clamped: every lane issues valid loads
-  const int jc = j < DH ? j : DH - 1;
-  const int cy = j + m.ext_st[1];
-  const bool row_ok = j < DH && cy >= m.core_st[1] && cy < m.core_st[1] + m.core_sz[1];
-  u64 in_core = 0;
-  if (g_ok && row_ok)
-    for (int b = 0; b < 8; b ++) {
-      const int cx = g * 8 + b + m.ext_st[0];
-      if (cx >= m.core_st[0] && cx < m.core_st[0] + m.core_sz[0]) in_core |= 0x80ull << (8 * b);
-    }
-  unsigned zmask = 0;                                          // planes of the chunk whose corners are in core
-  for (int zi = 0; zi < ZC; zi ++) {
-    const int k = z0 + zi, cz = k + m.ext_st[2];
-    if (k < DD && (ND == 2 || (cz >= m.core_st[2] && cz < m.core_st[2] + m.core_sz[2]))) zmask |= 1u << zi;
-  }
-  if (zmask == 0) return;                                      // wave-uniform
-  const bool have_row1 = jc + 1 < DH;
-  const bool seg_end = gl == GX - 1;                           // the x+1 word is not in the next lane
-
-  // raw words of one slice for this lane: planes z0 .. z0+ZC (ND == 3) x rows (y, y+1) x (own word, x+1 word).
-  // The lane at the end of an x segment reads its x+1 word from memory (the pitch has 8 spare bytes: always addressable);
-  // the other lanes take it from the next lane by DPP, their second load just re-reads their own word from L1.
-  constexpr int NP = (ND == 3) ? ZC + 1 : 1;
-  struct Raw { u64 a0[NP], b0[NP], an[NP], bn[NP]; };
-  const int gn = seg_end ? gc + 1 : gc;
-  auto load_raw = [&](const unsigned char *__restrict__ M, Raw &r) {
-    for (int p = 0; p < NP; p ++) {
-      const int k = z0 + p < DD ? z0 + p : DD - 1;             // clamped: a plane beyond the array is replaced by neutral below
-      const size_t off0 = (size_t)P * ((size_t)jc + (size_t)DH * (size_t)k);
-      const u64 *row0 = reinterpret_cast<const u64 *>(M + off0);
-      const u64 *row1 = reinterpret_cast<const u64 *>(M + off0 + (have_row1 ? (size_t)P : 0));
-      r.a0[p] = row0[gc]; r.b0[p] = row1[gc]; r.an[p] = row0[gn]; r.bn[p] = row1[gn];
-    }
-  };
-  // AND over the 2^d spatial cube vertices, per plane pair
-  auto combine = [&](const Raw &r, u64 cube[ZC]) {
-    u64 pl[NP];
-    for (int p = 0; p < NP; p ++) {
-      // DPP reads need every source lane active: shift first, under the full exec mask, select afterwards
-      const u64 da = dpp_u64_from_upper_lane(r.a0[p]), db = dpp_u64_from_upper_lane(r.b0[p]);
-      const u64 a1 = seg_end ? r.an[p] : da, b1 = seg_end ? r.bn[p] : db;
-      const u64 v = (r.a0[p] & ((r.a0[p] >> 8) | (a1 << 56))) & (r.b0[p] & ((r.b0[p] >> 8) | (b1 << 56)));
-      pl[p] = (z0 + p < DD) ? v : kAll;
-    }
-    for (int zi = 0; zi < ZC; zi ++) cube[zi] = (ND == 3) ? (pl[zi] & pl[zi + 1]) : pl[0];
-  };
-
-  const u64 row_lin = (u64)(cy - m.core_st[1]) * (u64)m.core_sz[0];
-  const u64 plane_sz = (u64)m.core_sz[0] * (u64)m.core_sz[1];
-  u64 cur[ZC], nxt[ZC];
-  const unsigned char *have_cur = nullptr, *pending_ptr = nullptr;
-  Raw pending;                                                 // software prefetch: the slice the NEXT step will need first
-  auto fetch = [&](const unsigned char *ptr, u64 cube[ZC]) {
-    if (ptr == pending_ptr) combine(pending, cube);
-    else { Raw r; load_raw(ptr, r); combine(r, cube); }
-  };
-#pragma unroll 1
-  for (int s = s0; s < s1; s ++) {
-    const Fields f = steps[s];
-    const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0;
-    const unsigned char *fm0 = COARSE ? f.U[0] : f.M[0], *fm1 = COARSE ? f.U[1] : f.M[1];
-    if (have_cur != fm0) fetch(fm0, cur);                      // otherwise slice t is last step's slice t+1: already in registers
-    if (need_next) fetch(fm1, nxt);
-    have_cur = need_next ? fm1 : fm0;
-    pending_ptr = nullptr;
-    if (s + 1 < s1) {                                          // issue the next step's loads now; they land while this step is scanned
-      const Fields g = steps[s + 1];
-      const unsigned char *gm0 = COARSE ? g.U[0] : g.M[0], *gm1 = COARSE ? g.U[1] : g.M[1];
-      const unsigned char *want = (gm0 != have_cur) ? gm0 : ((g.scope_mask & FTKX_SCOPE_INTERVAL) ? gm1 : nullptr);
-      if (want) { load_raw(want, pending); pending_ptr = want; }
-    }
-    for (int zi = 0; zi < ZC; zi ++) {
-      u64 surv_o = 0, surv_i = 0;
-      if ((zmask >> zi) & 1) {
-        // bytes are <= 0x3f: adding 0x7f sets bit 7 exactly in the non-zero bytes, without carries between bytes
-        if (f.scope_mask & FTKX_SCOPE_ORDINAL) surv_o = ~(cur[zi] + k7f) & k80 & in_core;
-        if (need_next) surv_i = ~((cur[zi] & nxt[zi]) + k7f) & k80 & in_core;
-      }
-      const u64 any = surv_o | surv_i;
-      u64 pos;
-      unsigned cnt;
-      if constexpr (ND == 2) {
-        // hit-dense 2D data: most wavefronts have survivors.  Wave totals through LDS give every lane its place in the workgroup's
-        // staging buffer; the list counter is touched once per workgroup (flush_stage).
-        if (__syncthreads_or(any != 0) == 0) continue;         // (block-uniform: no wavefront left the kernel, see the early exits above)
-        cnt = (unsigned)__popcll(any);
-        unsigned incl = cnt;
-        for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-        if (lane == 63) s_wave_total[wv] = incl;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          unsigned run = 0;
-          for (int q = 0; q < 4; q ++) { const unsigned t = s_wave_total[q]; s_wave_total[q] = run; run += t; }
-          s_run = run;
-        }
-        __syncthreads();
-        if (s_staged + s_run > STAGE_CAP) flush_stage();       // (block-uniform)
-        unsigned at = s_staged + s_wave_total[wv] + (incl - cnt);
-        if (cnt) {
-          const u64 lin0 = row_lin;
-          for (int b = 0; b < 8; b ++) {
-            const unsigned fl = (unsigned)((surv_o >> (8 * b + 7)) & 1) | ((unsigned)((surv_i >> (8 * b + 7)) & 1) << 1);
-            if (!fl) continue;
-            s_stage[at ++] = (lin0 + (u64)(g * 8 + b + m.ext_st[0] - m.core_st[0])) | ((u64)fl << 40) | ((u64)s << 44);
-          }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_staged += s_run;
-        continue;                                              // (the staged entries go out at the end of the kernel)
-      } else {
-        if (__ballot(any != 0) == 0) continue;                 // the common case: nothing survives in this wavefront
-        cnt = (unsigned)__popcll(any);
-        unsigned incl = cnt;
-        for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-        const unsigned total = __shfl(incl, 63);
-        u64 base = 0;
-        if (lane == 63) base = atomicAdd(&m.counters[kListCounter], (u64)total);
-        base = __shfl(base, 63);
-        pos = base + (incl - cnt);
-      }
-      if (cnt) {
-        const u64 lin0 = row_lin + (ND == 3 ? (u64)(z0 + zi + m.ext_st[2] - m.core_st[2]) * plane_sz : 0ull);
-        for (int b = 0; b < 8; b ++) {
-          const unsigned fl = (unsigned)((surv_o >> (8 * b + 7)) & 1) | ((unsigned)((surv_i >> (8 * b + 7)) & 1) << 1);
-          if (!fl) continue;
-          const u64 lin = lin0 + (u64)(g * 8 + b + m.ext_st[0] - m.core_st[0]);
-          if (pos < list_capacity) list[pos] = lin | ((u64)fl << 40) | ((u64)s << 44);
-          pos ++;
-        }
-      }
-    }
-    if (need_next) for (int zi = 0; zi < ZC; zi ++) cur[zi] = nxt[zi];
-  }
-  if constexpr (ND == 2) { __syncthreads(); if (s_staged) flush_stage(); }   // (block-uniform)
-}
-
-// Second level of the two-level cull: one lane per refine-list entry (an aligned word of 8 corners whose summaries could not
-// rule it out) repeats the test on the vertex mask bytes and appends the corners that still survive to the work list.
-// `mc` is the coarse view the first level ran on (its core / ext describe words), `m` the real mesh.
-template <int ND>
-__global__ __launch_bounds__(kThreads) void refine_kernel(const Mesh m, const Mesh mc, const Fields *__restrict__ steps,
-                                                          const u64 *__restrict__ refine, u64 refine_capacity,
-                                                          u64 *__restrict__ list, u64 list_capacity)
-{
-  const int DH = m.ext_sz[1], DD = (ND == 3) ? m.ext_sz[2] : 1, P = m.mask_pitch;
-  const int lane = threadIdx.x & 63;
-  __shared__ unsigned s_wave_total[kThreads / 64];
-  __shared__ u64 s_block_base;
-  if (m.counters[CNT_SERIES_DONE]) return;              // (series pass: finished early; block-uniform)
-  u64 count = m.counters[CNT_REFINE_LIST];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { atomicMax(&m.counters[CNT_REFINE_PEAK], count); atomicAdd(&m.counters[CNT_WORDS_REFINED], count); }
-  if (count > refine_capacity) count = refine_capacity;
-  const u64 k7f = 0x7f7f7f7f7f7f7f7full, k80 = 0x8080808080808080ull;
-  // an entry of the refine list is a coarse cell: 8 corners along x times u_rows rows -- one lane per row of it
-  const u64 UR = (u64)m.u_rows, urows = (u64)((DH + m.u_rows - 1) / m.u_rows);
-  const u64 work = count * UR;
-  for (u64 base = (u64)blockIdx.x * kThreads; base < work; base += (u64)gridDim.x * kThreads) {   // block-uniform trip count
-    const u64 idx = base + threadIdx.x;
-    u64 surv_o = 0, surv_i = 0, row_lin = 0;
-    int g = 0, step = 0;
-    bool mine = idx < work;
-    int j = 0, k = 0, cy = 0, cz = 0;
-    unsigned want = 0;
-    if (mine) {
-      const u64 e = refine[idx / UR];
-      step = (int)(e >> 44);
-      want = (unsigned)((e >> 40) & 3);
-      u64 lin = e & 0xffffffffffull;
-      g = mc.core_st[0] + (int)(lin % (u64)mc.core_sz[0]); lin /= (u64)mc.core_sz[0];
-      const int cyc = mc.core_st[1] + (int)(lin % (u64)mc.core_sz[1]); lin /= (u64)mc.core_sz[1];   // coarse row, relative to the array
-      cz = (ND == 3) ? mc.core_st[2] + (int)lin : 0;
-      j = cyc * m.u_rows + (int)(idx % UR); k = cz - m.ext_st[2];
-      cy = j + m.ext_st[1];
-      mine = cy >= m.core_st[1] && cy < m.core_st[1] + m.core_sz[1];      // (a block at the edge of the core: not all of its rows are corners)
-    }
-    if (mine) {
-      const Fields f = steps[step];
-      const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0 && (want & 2);
-      u64 a0 = ~0ull, a1 = ~0ull;
-      // words whose summary is non-zero were not written to M (mask_march2_kernel): their summary, replicated, stands in
-      auto row_pair_and = [&](const unsigned char *__restrict__ Mp, const unsigned char *__restrict__ Up, int jj, int kk) -> u64 {
-        const size_t row = (size_t)jj + (size_t)DH * (size_t)kk;
-        const unsigned char *u = Up + (size_t)m.u_pitch * ((size_t)(jj / m.u_rows) + (size_t)urows * (size_t)kk) + g;
-        const u64 *w = reinterpret_cast<const u64 *>(Mp + (size_t)P * row) + g;
-        const unsigned u0 = u[0], u1 = u[1];                       // the summary pitch has spare bytes too
-        const u64 w0 = u0 ? (u64)u0 * 0x0101010101010101ull : w[0];
-        const u64 w1 = u1 ? (u64)u1 * 0x0101010101010101ull : w[1];
-        return w0 & ((w0 >> 8) | (w1 << 56));
-      };
-      for (int dz = 0; dz < (ND == 3 ? 2 : 1); dz ++)
-        for (int dy = 0; dy < 2; dy ++) {
-          if (j + dy >= DH || k + dz >= DD) continue;                   // row outside the array: invalid vertices, neutral
-          a0 &= row_pair_and(f.M[0], f.U[0], j + dy, k + dz);
-          if (need_next) a1 &= row_pair_and(f.M[1], f.U[1], j + dy, k + dz);
-        }
-      u64 in_core = 0;
-      for (int b = 0; b < 8; b ++) {
-        const int cx = g * 8 + b + m.ext_st[0];
-        if (cx >= m.core_st[0] && cx < m.core_st[0] + m.core_sz[0]) in_core |= 0x80ull << (8 * b);
-      }
-      if ((f.scope_mask & FTKX_SCOPE_ORDINAL) && (want & 1)) surv_o = ~(a0 + k7f) & k80 & in_core;
-      if (need_next) surv_i = ~((a0 & a1) + k7f) & k80 & in_core;
-      row_lin = (u64)(cy - m.core_st[1]) * (u64)m.core_sz[0] + (ND == 3 ? (u64)(cz - m.core_st[2]) * (u64)m.core_sz[0] * (u64)m.core_sz[1] : 0ull);
-    }
-    const u64 any = surv_o | surv_i;
-    // one list atomic per workgroup and iteration (wave totals through LDS): on hit-dense data nearly every wavefront has survivors
-    if (__syncthreads_or(any != 0) == 0) continue;             // block-uniform trip count, see the loop header
-    const unsigned cnt = (unsigned)__popcll(any);
-    unsigned incl = cnt;
-    for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-    if (lane == 63) s_wave_total[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned run = 0;
-      for (int q = 0; q < kThreads / 64; q ++) { const unsigned t = s_wave_total[q]; s_wave_total[q] = run; run += t; }
-      s_block_base = run ? atomicAdd(&m.counters[CNT_SURVIVOR_LIST], (u64)run) : 0ull;
-    }
-    __syncthreads();
-    u64 pos = s_block_base + s_wave_total[threadIdx.x >> 6] + (incl - cnt);
-    for (int b = 0; b < 8 && cnt; b ++) {
-      const unsigned fl = (unsigned)((surv_o >> (8 * b + 7)) & 1) | ((unsigned)((surv_i >> (8 * b + 7)) & 1) << 1);
-      if (!fl) continue;
-      const u64 lin = row_lin + (u64)(g * 8 + b + m.ext_st[0] - m.core_st[0]);
-      if (pos < list_capacity) list[pos] = lin | ((u64)fl << 40) | ((u64)step << 44);
-      pos ++;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// FAST PATH 3/3: exact test of the surviving corners
-// ---------------------------------------------------------------------------------------------------------------
-template <int ND>
-__global__ __launch_bounds__(kThreads) void exact_kernel(const Mesh m, const Fields *__restrict__ steps, int step_base, const u64 *__restrict__ list, u64 list_capacity)
-{
-  constexpr int N = ND + 1;
-  constexpr int NVC = 1 << N;                 // vertices of a corner's space-time hypercube
-  constexpr int G = kThreads / NVC;           // corners per chunk: one lane per hypercube vertex while staging
-  constexpr int NTYPES = fan_table<N>::NTYPES;
-  constexpr int SUB = 4;                      // rounds of G corners staged together
-  __shared__ i64 s_vf[SUB * G][NVC][ND];
-  __shared__ unsigned char s_flag[SUB * G][NVC];
-  __shared__ u64 s_entry[SUB * G];
-  __shared__ unsigned s_tab[NTYPES];
-  // descriptors of the (corner, type) pairs that passed the predicate, parked in LDS across chunks: the counter behind m.pass is ONE
-  // address for the whole device (a same-address atomic costs ~5 ns of serialised L2 time: one per chunk was a quarter of this
-  // kernel on hit-dense 2D data), so a workgroup takes a range of it only when its buffer could overflow, and once at the end
-  constexpr unsigned OUT_CAP = 2048;
-  static_assert(G * NTYPES <= OUT_CAP / 2, "a chunk's worst case must fit twice");
-  __shared__ u64 s_out[OUT_CAP];
-  __shared__ unsigned s_nout, s_tested;
-  __shared__ u64 s_base;
-
-  const int tid = threadIdx.x;
-  const fan_table<N> &fan = dev_fan<ND>();
-  if (m.counters[CNT_SERIES_DONE]) return;              // (series pass: the single-workgroup tail has finished this pass already)
-  u64 count = m.counters[CNT_SURVIVOR_LIST];
-  if (blockIdx.x == 0 && tid == 0) {   // the host checks the peak against the capacity; the statistic: cells that survived the cull
-    atomicMax(&m.counters[CNT_LIST_PEAK], count);
-    atomicAdd(&m.counters[CNT_CELLS_SURVIVED], count);
-  }
-  if (count > list_capacity) count = list_capacity;     // overflow: the host grows the list and replays the batch
-  if ((u64)blockIdx.x * (SUB * G) >= count) return;     // nothing for this workgroup: leave before touching LDS or scratch
-  if (tid < NTYPES) {
-    unsigned w = 0;
-    for (int i = 0; i < N; i ++) w |= (unsigned)fan.vert[tid][i] << (8 * i);
-    s_tab[tid] = w;
-  }
-  if (tid == 0) { s_nout = 0; s_tested = 0; }
-  unsigned tested = 0;
-
-  auto flush = [&]() {                                  // called by the whole workgroup, after a barrier that made s_nout final
-    const unsigned n = s_nout;
-    if (tid == 0) s_base = atomicAdd(&m.counters[CNT_PASS], (u64)n);
-    __syncthreads();
-    const u64 base = s_base;
-    for (unsigned h = tid; h < n; h += kThreads)
-      if (base + h < m.capacity) {
-        m.pass[base + h] = s_out[h];
-        // series pass: how many simplices passed per bucket of the order key (the records are put in order without a sort, series.hip)
-        if (m.hist) atomicAdd(&m.hist[order_key(s_out[h], m.core_cells) >> m.hist_shift], 1u);
-      }
-    __syncthreads();
-    if (tid == 0) s_nout = 0;
-  };
-
-  // Staging is a chain of dependent memory round trips (list entry, the step's descriptor, the field values) with barriers in between:
-  // SUB x G corners are fetched per chain instead of G (woven 1024^2 x 64: 5.5 chains per workgroup -> 1.4).  The test itself goes G
-  // corners at a time, so that s_out can be emptied in between.
-  bool narrow = false;
-  for (u64 chunk = blockIdx.x; chunk * (SUB * G) < count; chunk += gridDim.x) {
-    __syncthreads();                                    // previous chunk's LDS readers are done
-    if (tid < SUB * G) s_entry[tid] = (chunk * (SUB * G) + tid < count) ? list[chunk * (SUB * G) + tid] : ~0ull;
-    __syncthreads();
-    {
-      const int vtx = tid % NVC, sl = (vtx >> ND) & 1;
-      u64 ent[SUB];
-      const double *pS[SUB], *pV[SUB];
-      double factor[SUB];
-      bool live[SUB];
-#pragma unroll
-      for (int r = 0; r < SUB; r ++) {                  // descriptors
-        ent[r] = s_entry[r * G + tid / NVC];
-        live[r] = false; pS[r] = nullptr; pV[r] = nullptr; factor[r] = 0.0;
-        if (ent[r] != ~0ull) {
-          const Fields &f = steps[ent[r] >> 44];
-          live[r] = sl == 0 || (f.scope_mask & FTKX_SCOPE_INTERVAL);
-          pS[r] = f.S[sl]; pV[r] = f.V[sl]; factor[r] = f.factor;
-        }
-      }
-      double raw[SUB][6];
-      int vxs[SUB][3];
-      bool usable[SUB], inner[SUB];
-#pragma unroll
-      for (int r = 0; r < SUB; r ++) {                  // field values: every load of the round in flight before the first is used
-        for (int k = 0; k < 6; k ++) raw[r][k] = 0.0;
-        for (int d = 0; d < 3; d ++) vxs[r][d] = 0;
-        core_corner<ND>(m, ent[r] & 0xffffffffffull, vxs[r]);
-        for (int d = 0; d < ND; d ++) vxs[r][d] += (vtx >> d) & 1;
-        usable[r] = live[r] && vertex_usable<ND>(m, vxs[r]);
-        inner[r] = false;
-        if (usable[r]) {
-          const int i = vxs[r][0] - m.ext_st[0], j = vxs[r][1] - m.ext_st[1], k = ND == 3 ? vxs[r][2] - m.ext_st[2] : 0;
-          const int DW = m.ext_sz[0], DH = m.ext_sz[1];
-          if (!m.scalar_mode) {
-            const size_t at = arr_index<ND>(m, i, j, k) * ND;
-            for (int c = 0; c < ND; c ++) raw[r][c] = pV[r][at + c];
-          } else if constexpr (ND == 2) {               // gradient2D (grad.hh:17-28): clamped indices
-            const int ip = clampi(i + 1, 0, DW - 1), im = clampi(i - 1, 0, DW - 1), jp = clampi(j + 1, 0, DH - 1), jm = clampi(j - 1, 0, DH - 1);
-            const int ic = clampi(i, 0, DW - 1), jc = clampi(j, 0, DH - 1);
-            raw[r][0] = pS[r][(size_t)ip + (size_t)DW * jc]; raw[r][1] = pS[r][(size_t)im + (size_t)DW * jc];
-            raw[r][2] = pS[r][(size_t)ic + (size_t)DW * jp]; raw[r][3] = pS[r][(size_t)ic + (size_t)DW * jm];
-          } else {                                      // gradient3D (grad.hh:138-146): interior vertices only
-            const int DD = m.ext_sz[2];
-            inner[r] = i >= 1 && i < DW - 1 && j >= 1 && j < DH - 1 && k >= 1 && k < DD - 1;
-            if (inner[r]) {
-              const size_t sy = (size_t)DW, sz = (size_t)DW * DH, c = (size_t)i + sy * j + sz * k;
-              raw[r][0] = pS[r][c + 1]; raw[r][1] = pS[r][c - 1]; raw[r][2] = pS[r][c + sy]; raw[r][3] = pS[r][c - sy]; raw[r][4] = pS[r][c + sz]; raw[r][5] = pS[r][c - sz];
-            }
-          }
-        }
-      }
-      bool mine_narrow = true;
-#pragma unroll
-      for (int r = 0; r < SUB; r ++) {                  // the same operations as vector_at / gradient_at on the same values, then classify_vertex's
-        const int gi = r * G + tid / NVC;
-        i64 q[ND];
-        for (int c = 0; c < ND; c ++) q[c] = 0;
-        unsigned char fl = kInvalid;
-        if (usable[r]) {
-          double v[ND];
-          if (!m.scalar_mode) { for (int c = 0; c < ND; c ++) v[c] = raw[r][c]; }
-          else if constexpr (ND == 2) { v[0] = (raw[r][0] - raw[r][1]) * (double)(m.ext_sz[0] - 1); v[1] = (raw[r][2] - raw[r][3]) * (double)(m.ext_sz[1] - 1); }
-          else {
-            if (inner[r]) { v[0] = 0.5 * (raw[r][0] - raw[r][1]); v[1] = 0.5 * (raw[r][2] - raw[r][3]); v[2] = 0.5 * (raw[r][4] - raw[r][5]); }
-            else { v[0] = 0.0; v[1] = 0.0; v[2] = 0.0; }
-          }
-          fl = classify_value<ND>(v, factor[r], q);
-        }
-        s_flag[gi][vtx] = fl;
-        for (int c = 0; c < ND; c ++) { s_vf[gi][vtx][c] = q[c]; mine_narrow = mine_narrow && fits_s32(q[c]); }
-      }
-      narrow = __syncthreads_and(mine_narrow) != 0;       // (the barrier between staging and testing, with the chunk's "fits in 32 bits" on it)
-    }
-    // (corner, type) pairs over all lanes; the few that pass go to record_kernel, whose expensive FP64 record construction then
-    // runs on densely packed lanes instead of one or two lanes per wavefront
-    for (int sub = 0; sub < SUB && (chunk * SUB + (u64)sub) * G < count; sub ++) {
-      if (sub) __syncthreads();
-      if (s_nout > OUT_CAP - G * NTYPES) flush();       // (workgroup-uniform: s_nout was final at the barrier above)
-      for (int base = 0; base < G * NTYPES; base += kThreads) {
-        const int w = base + tid;
-        if (w < G * NTYPES) {
-          const int gi = sub * G + w / NTYPES, type = w % NTYPES;
-          const u64 e = s_entry[gi];
-          const unsigned scope_flags = (e == ~0ull) ? 0u : (unsigned)((e >> 40) & 3);
-          const bool wanted = fan.ordinal[type] ? (scope_flags & 1) : (scope_flags & 2);
-          if (wanted) {
-            const Fields &f = steps[e >> 44];
-            int corner[N];
-            core_corner<ND>(m, e & 0xffffffffffull, corner);
-            corner[ND] = f.t;
-            const unsigned tab = s_tab[type];
-            unsigned char flags[N];
-            u64 X[N][ND];
-            for (int i = 0; i < N; i ++) {
-              const unsigned vm = (tab >> (8 * i)) & 0xffu;   // the axis bitmask IS the hypercube vertex index
-              flags[i] = s_flag[gi][vm];
-              for (int c = 0; c < ND; c ++) X[i][c] = (u64)s_vf[gi][vm][c];
-            }
-            int ids[N]; double mu[N]; bool presolved;
-            if (simplex_inside<ND>(m, f, 1, corner, tab, flags, X, tested, ids, mu, &presolved, narrow))
-              s_out[atomicAdd(&s_nout, 1u)] = (e & kPassLinMask) | ((u64)type << kPassTypeShift) | ((u64)(step_base + (int)(e >> 44)) << kPassStepShift);
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (s_nout) flush();
-  {
-    unsigned t_sum = tested;
-    for (int o = 32; o > 0; o >>= 1) t_sum += __shfl_down(t_sum, o);
-    if ((tid & 63) == 0 && t_sum) atomicAdd(&s_tested, t_sum);
-    __syncthreads();
-    if (tid == 0 && s_tested) atomicAdd(&m.counters[CNT_SIMPLICES_TESTED], (u64)s_tested);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The FP64 half of the sweep: one lane per simplex that passed the integer test (CNT_PASS descriptors written by exact_kernel /
-// tile_kernel).  Re-quantises the simplex's d+1 vertices (a handful of loads), then inverse interpolation, lerps, Jacobian and
-// classification exactly as check_simplex does after its test (2d:624-684, 3d:468-512), and the ballot-compacted append.
-// Keeping this out of the integer kernels takes their scratch from 800-944 bytes per lane to none.
-// ---------------------------------------------------------------------------------------------------------------
-template <int ND>
-__global__ __launch_bounds__(kThreads) void record_kernel(const Mesh m, const Fields *__restrict__ fields)
-{
-  constexpr int N = ND + 1;
-  const fan_table<N> &fan = dev_fan<ND>();
-  u64 count = m.counters[CNT_PASS];
-  if (count > m.capacity) count = m.capacity;               // overflow: the host grows the buffers and replays the batch
-  const u64 padded = (count + 63) / 64 * 64;                // wave-uniform trip count: emit_hits ballots
-  for (u64 i = (u64)blockIdx.x * kThreads + threadIdx.x; i < padded; i += (u64)gridDim.x * kThreads) {
-    bool hit = false, fragile = false;
-    double Jfrag[9];
-    ftkx_cp_t rec;
-    if (i < count) {
-      const u64 d = m.pass[i];
-      const Fields &f = fields[d >> kPassStepShift];
-      const int type = (int)((d >> kPassTypeShift) & 63u);
-      u64 lin = d & kPassLinMask;
-      int corner[N];
-      core_corner<ND>(m, lin, corner);
-      corner[ND] = f.t;
-      u64 X[N][ND];
-      int ids[N];
-      // (the quantised vectors and SoS ids feed only the 2D degree computation: nobody else pays for re-deriving them)
-      if (ND == 2 && m.compute_degrees)
-      for (int v = 0; v < N; v ++) {
-        const unsigned vm = fan.vert[type][v];
-        int vx[3] = {0, 0, 0};
-        for (int a = 0; a < ND; a ++) vx[a] = corner[a] + (int)((vm >> a) & 1u);
-        const int sl = (int)((vm >> ND) & 1u);
-        i64 q[ND];
-        classify_vertex<ND>(m, f.S[sl], f.V[sl], f.factor, vx, q);
-        for (int c = 0; c < ND; c ++) X[v][c] = (u64)q[c];
-        ids[v] = vertex_id<ND>(m, corner, vm);
-      }
-      // (per lane: records next to the array border, given J, vector input, degrees take the general path)
-      hit = record_is_fast<ND>(m, f, corner) ? make_record_impl<ND, true>(m, f, corner, type, X, ids, false, nullptr, &rec, &fragile, Jfrag)
-                                             : make_record_general<ND>(m, f, corner, type, X, ids, false, nullptr, &rec, &fragile, Jfrag);
-    }
-    const u64 slot = emit_hits(m, hit, rec);
-    if (ND == 3 && hit && fragile && slot != ~0ull) {          // (rare) handed to the host for classification with ITS libm
-      const u64 e = atomicAdd(&m.counters[CNT_FRAGILE], 1ull);
-      if (e < m.fragile_capacity) {
-        u64 *dst = m.fragile + e * 10;
-        dst[0] = slot;
-        for (int q = 0; q < 9; q ++) dst[1 + q] = (u64)__double_as_longlong(Jfrag[q]);
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Compact t-slab halo.  The rank that owns a boundary slice hands its neighbour the slice's sign masks -- the summary
-// array U as it is and the mask words the summaries do not describe, compacted here -- instead of the slice; the neighbour culls
-// with them, asks for the input values around the few cells that survive (sparse_cells_kernel -> gather_patches_kernel on the
-// owner -> scatter_patches_kernel into an otherwise empty array on the neighbour) and runs the exact test on those.
-// ---------------------------------------------------------------------------------------------------------------
-// words of M whose summary byte is 0 (the only ones the mask kernels write): (index of the 8-byte word in M, its 8 bytes)
-__global__ __launch_bounds__(kThreads) void compact_words_kernel(const Mesh m, const unsigned char *__restrict__ U, const unsigned char *__restrict__ M,
-                                                                 unsigned *__restrict__ idx, u64 *__restrict__ words, u64 capacity, u64 *counter)
-{
-  const int UP = m.u_pitch, P = m.mask_pitch, DH = m.ext_sz[1], DD = m.nd == 3 ? m.ext_sz[2] : 1;
-  const int ngroups = (m.ext_sz[0] + 7) / 8;
-  const size_t total = (size_t)ngroups * DH * DD, padded = (total + 63) / 64 * 64;
-  const size_t urows = (size_t)((DH + m.u_rows - 1) / m.u_rows);
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < padded; i += (size_t)gridDim.x * kThreads) {
-    bool take = false;
-    size_t row = 0; int g = 0;
-    if (i < total) {
-      row = i / ngroups; g = (int)(i - row * ngroups);
-      const size_t k = row / (size_t)DH, j = row - k * (size_t)DH;       // the summary of the word's block: row j / u_rows of plane k
-      take = U[(j / (size_t)m.u_rows + urows * k) * (size_t)UP + g] == 0;
-    }
-    const unsigned long long b = __ballot(take);
-    if (!b) continue;
-    const int lane = threadIdx.x & 63, leader = __ffsll((long long)b) - 1;
-    u64 base = 0;
-    if (lane == leader) base = atomicAdd(counter, (u64)__popcll(b));
-    base = __shfl(base, leader);
-    if (take) {
-      const u64 slot = base + (u64)__popcll(b & ((1ull << lane) - 1ull));
-      const size_t w = (row * (size_t)P) / 8 + (size_t)g;                 // P is a multiple of 8: whole words
-      if (slot < capacity) { idx[slot] = (unsigned)w; words[slot] = reinterpret_cast<const u64 *>(M)[w]; }
-    }
-  }
-}
-
-// (word indices come from another rank: anything outside the mask array is dropped and flagged, never written)
-__global__ __launch_bounds__(kThreads) void scatter_words_kernel(const unsigned *__restrict__ idx, const u64 *__restrict__ words, size_t n, unsigned char *__restrict__ M,
-                                                                 size_t mask_words, u64 *bad)
-{
-  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n) return;
-  const size_t w = idx[i];
-  if (w < mask_words) reinterpret_cast<u64 *>(M)[w] = words[i];
-  else if (bad) atomicOr((unsigned long long *)bad, 1ull);
-}
-
-// Packed form of a slice's masks -- ONE message for the compact halo: u64 header {words, summary bytes, word capacity | rows per summary
-// byte << 48 | log2(factor the masks were built under) << 56, magic}, the summary array, the word indices (capacity entries), the words
-// (capacity entries).  The header is written on the device (the count of compacted words lives there) and read on the device: neither
-// side waits for the other's numbers on the host.  The summary array travels through these kernels too (a copy queued through the
-// runtime behind a running kernel holds the host until that kernel has finished: DESIGN.md 4, cull-ahead).
-constexpr u64 kPackedMagic = 0x66746b786d61736bull;       // "ftkxmask"
-__global__ __launch_bounds__(kThreads) void pack_masks_kernel(u64 *__restrict__ hdr, const u64 *__restrict__ counter, const u64 *__restrict__ U, u64 u_bytes, u64 capacity,
-                                                              unsigned u_rows, unsigned factor_log2)
-{
-  u64 *dst = hdr + 4;
-  const u64 nw = (u_bytes + 7) / 8;                        // (U is allocated in whole words: u_pitch is a multiple of 8)
-  for (u64 i = (u64)blockIdx.x * kThreads + threadIdx.x; i < nw; i += (u64)gridDim.x * kThreads) dst[i] = U[i];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = *counter; hdr[1] = u_bytes; hdr[2] = capacity | ((u64)u_rows << 48) | ((u64)factor_log2 << 56); hdr[3] = kPackedMagic; }
-}
-
-// import: header checked (geometry, rows per summary byte, and the factor the sender built the masks under must not exceed max_factor_log2:
-// masks only serve factors at least as large as their own), summary array and words into the slice's arrays
-__global__ __launch_bounds__(kThreads) void scatter_packed_kernel(const u64 *__restrict__ hdr, const unsigned *__restrict__ idx, const u64 *__restrict__ words,
-                                                                  u64 u_bytes, u64 capacity, unsigned u_rows, unsigned max_factor_log2, u64 *__restrict__ U,
-                                                                  unsigned char *__restrict__ M, size_t mask_words, u64 *bad)
-{
-  const u64 n = hdr[0], geo = hdr[2];
-  if (hdr[1] != u_bytes || (geo & ((1ull << 48) - 1ull)) != capacity || ((geo >> 48) & 0xffull) != (u64)u_rows || (geo >> 56) > (u64)max_factor_log2 ||
-      hdr[3] != kPackedMagic || n > capacity) {            // another geometry or mask setting, a larger factor, or more words than the message holds
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr((unsigned long long *)bad, 1ull);
-    return;
-  }
-  const u64 *src = hdr + 4;
-  const u64 nw = (u_bytes + 7) / 8;
-  for (u64 i = (u64)blockIdx.x * kThreads + threadIdx.x; i < nw; i += (u64)gridDim.x * kThreads) U[i] = src[i];
-  for (u64 i = (u64)blockIdx.x * kThreads + threadIdx.x; i < n; i += (u64)gridDim.x * kThreads) {
-    const size_t w = idx[i];
-    if (w < mask_words) reinterpret_cast<u64 *>(M)[w] = words[i];
-    else atomicOr((unsigned long long *)bad, 1ull);
-  }
-}
-
-// survivors of the cull whose interval sweep reads the slice `sparse` (by its S or V pointer): their corner index inside core
-__global__ __launch_bounds__(kThreads) void sparse_cells_kernel(const Mesh m, const Fields *__restrict__ steps, const u64 *__restrict__ list, u64 list_capacity,
-                                                                const double *sparse, u64 *__restrict__ cells, u64 cells_capacity)
-{
-  u64 count = m.counters[CNT_SURVIVOR_LIST];
-  if (count > list_capacity) count = list_capacity;
-  const u64 padded = (count + 63) / 64 * 64;
-  for (u64 i = (u64)blockIdx.x * kThreads + threadIdx.x; i < padded; i += (u64)gridDim.x * kThreads) {
-    bool take = false;
-    u64 lin = 0;
-    if (i < count) {
-      const u64 e = list[i];
-      const Fields &f = steps[e >> 44];
-      lin = e & 0xffffffffffull;
-      take = ((e >> 40) & 2) && (f.S[1] == sparse || f.V[1] == sparse);
-    }
-    const unsigned long long b = __ballot(take);
-    if (!b) continue;
-    const int lane = threadIdx.x & 63, leader = __ffsll((long long)b) - 1;
-    u64 base = 0;
-    if (lane == leader) base = atomicAdd(&m.counters[CNT_SPARSE], (u64)__popcll(b));
-    base = __shfl(base, leader);
-    if (take) { const u64 slot = base + (u64)__popcll(b & ((1ull << lane) - 1ull)); if (slot < cells_capacity) cells[slot] = lin; }
-  }
-}
-
-// the input values a cell's exact test and record can touch: array coordinates corner - 2 .. corner + 3 on every axis (vertices
-// 0/1, +-1 for the gradient, +-1 more for the Jacobian of the gradient), clamped to the array; ncomp values per vertex
-template <bool SCATTER>
-__global__ __launch_bounds__(kThreads) void patches_kernel(const Mesh m, const u64 *__restrict__ cells, size_t n, int ncomp, double *field, double *patches)
-{
-  const int nd = m.nd, pe = nd == 3 ? 216 : 36;
-  const size_t total = n * (size_t)pe;
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (size_t)gridDim.x * kThreads) {
-    const size_t cell = i / pe;
-    int p = (int)(i - cell * pe);
-    u64 lin = cells[cell];
-    size_t at = 0, stride = 1;
-    for (int a = 0; a < nd; a ++) {
-      const int corner = m.core_st[a] + (int)(lin % (u64)m.core_sz[a]) - m.ext_st[a]; lin /= (u64)m.core_sz[a];
-      const int x = clampi(corner - 2 + p % 6, 0, m.ext_sz[a] - 1); p /= 6;
-      at += (size_t)x * stride; stride *= (size_t)m.ext_sz[a];
-    }
-    for (int c = 0; c < ncomp; c ++) {
-      if (SCATTER) field[at * ncomp + c] = patches[i * ncomp + c];
-      else patches[i * ncomp + c] = field[at * ncomp + c];
-    }
-  }
-}
-
-void launch_compact_words(const Mesh &m, const unsigned char *U, const unsigned char *M, unsigned *idx, u64 *words, u64 capacity, u64 *counter, hipStream_t st)
-{ hipLaunchKernelGGL(compact_words_kernel, dim3(256 * 8), dim3(kThreads), 0, st, m, U, M, idx, words, capacity, counter); }
-void launch_scatter_words(const unsigned *idx, const u64 *words, size_t n, unsigned char *M, size_t mask_words, u64 *bad, hipStream_t st)
-{ if (n) hipLaunchKernelGGL(scatter_words_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, idx, words, n, M, mask_words, bad); }
-void launch_pack_masks(u64 *hdr, const u64 *counter, const unsigned char *U, u64 u_bytes, u64 capacity, int u_rows, int factor_log2, hipStream_t st)
-{ hipLaunchKernelGGL(pack_masks_kernel, dim3(128), dim3(kThreads), 0, st, hdr, counter, reinterpret_cast<const u64 *>(U), u_bytes, capacity, (unsigned)u_rows, (unsigned)factor_log2); }
-void launch_scatter_packed(const u64 *hdr, const unsigned *idx, const u64 *words, u64 u_bytes, u64 capacity, int u_rows, int max_factor_log2, unsigned char *U, unsigned char *M,
-                           size_t mask_words, u64 *bad, hipStream_t st)
-{ hipLaunchKernelGGL(scatter_packed_kernel, dim3(128), dim3(kThreads), 0, st, hdr, idx, words, u_bytes, capacity, (unsigned)u_rows, (unsigned)max_factor_log2, reinterpret_cast<u64 *>(U), M, mask_words, bad); }
-void launch_sparse_cells(const Mesh &m, const Fields *d_steps, const u64 *d_list, u64 cap, const double *sparse, u64 *cells, u64 cells_cap, hipStream_t st)
-{ hipLaunchKernelGGL(sparse_cells_kernel, dim3(256 * 2), dim3(kThreads), 0, st, m, d_steps, d_list, cap, sparse, cells, cells_cap); }
-void launch_patches(const Mesh &m, bool scatter, const u64 *cells, size_t n, int ncomp, double *field, double *patches, hipStream_t st)
-{
-  if (!n) return;
-  size_t b = (n * (m.nd == 3 ? 216 : 36) + kThreads - 1) / kThreads;
-  if (b > 4096) b = 4096;
-  if (scatter) hipLaunchKernelGGL(patches_kernel<true>, dim3((unsigned)b), dim3(kThreads), 0, st, m, cells, n, ncomp, field, patches);
-  else hipLaunchKernelGGL(patches_kernel<false>, dim3((unsigned)b), dim3(kThreads), 0, st, m, cells, n, ncomp, field, patches);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // ndarray::resolution() of V = gradient(S) without materialising V (include/ftk/ndarray.hh:770-778 over grad.hh's output):
 // min over non-zero finite |v| and max finite |v| as raw IEEE bit patterns (they order like unsigned integers for v >= 0)
 // ---------------------------------------------------------------------------------------------------------------
@@ -2644,52 +1416,6 @@ __global__ __launch_bounds__(kThreads) void calib_read_kernel(const double2 *__r
 void launch_calib_read(const void *p, size_t bytes, double *scratch, hipStream_t stream)
 {
   hipLaunchKernelGGL(calib_read_kernel, dim3(256 * 16), dim3(kThreads), 0, stream, (const double2 *)p, bytes / 16, scratch);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// launchers
-// ---------------------------------------------------------------------------------------------------------------
-// the tile kernels' statistics, 256 slots -> the two counters (and the slots cleared for the next batch)
-__global__ __launch_bounds__(256) void tile_stats_fold_kernel(u64 *__restrict__ slots, u64 *__restrict__ counters)
-{
-  u64 a = slots[2 * threadIdx.x], b = slots[2 * threadIdx.x + 1];
-  slots[2 * threadIdx.x] = 0; slots[2 * threadIdx.x + 1] = 0;
-  for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
-  if ((threadIdx.x & 63) == 0) {
-    if (a) atomicAdd(&counters[CNT_SIMPLICES_TESTED], a);
-    if (b) atomicAdd(&counters[CNT_CELLS_SURVIVED], b);
-  }
-}
-void launch_tile_stats_fold(u64 *slots, u64 *counters, hipStream_t stream) { hipLaunchKernelGGL(tile_stats_fold_kernel, dim3(1), dim3(256), 0, stream, slots, counters); }
-
-#ifdef FTKX_TILE_STAMPS
-extern "C" void ftkx_debug_tile_stamps(unsigned long long *out, int reset)
-{
-  static unsigned long long h[512 * 8];
-  (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile_stamps), sizeof(h));
-  for (int k = 0; k < 8; k ++) { out[k] = 0; for (int b = 0; b < 512; b ++) out[k] += h[b * 8 + k]; }
-  if (reset) { for (auto &x : h) x = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stamps), h, sizeof(h)); }
-}
-#endif
-void launch_tile(const TileParams &p, hipStream_t stream)
-{
-  const unsigned nblocks = (unsigned)p.ntiles[0] * p.ntiles[1] * p.ntiles[2];
-  if (nblocks == 0) return;
-  if (p.m.nd == 2) {
-    if (p.form >= 2) hipLaunchKernelGGL((tile_kernel<2, 2>), dim3(nblocks), dim3(kThreads), 0, stream, p);
-    else if (p.form == 1) hipLaunchKernelGGL((tile_kernel<2, 1>), dim3(nblocks), dim3(kThreads), 0, stream, p);
-    else hipLaunchKernelGGL((tile_kernel<2, 0>), dim3(nblocks), dim3(kThreads), 0, stream, p);
-  }
-  else if (p.form >= 2) hipLaunchKernelGGL((tile_kernel<3, 2>), dim3(nblocks), dim3(kThreads), 0, stream, p);
-  else if (p.form == 1) hipLaunchKernelGGL((tile_kernel<3, 1>), dim3(nblocks), dim3(kThreads), 0, stream, p);
-  else hipLaunchKernelGGL((tile_kernel<3, 0>), dim3(nblocks), dim3(kThreads), 0, stream, p);
-}
-
-void tile_dims(int nd, int tile[3])
-{
-  if (nd == 2) { tile[0] = tile_cfg<2>::TX; tile[1] = tile_cfg<2>::TY; tile[2] = 1; }
-  else { tile[0] = tile_cfg<3>::TX; tile[1] = tile_cfg<3>::TY; tile[2] = tile_cfg<3>::TZ; }
 }
 
 // does this mesh take the fast vector-input kernel?
@@ -2875,93 +1601,8 @@ bool masks_have_summary(const Mesh &m)
 // are the reduction slots of MaskJob::red filled by launch_masks (the fused one-pass form)?  All mask kernels do.
 bool masks_fuse_reduction(const Mesh &) { return true; }
 
-template <bool COARSE>
-static void launch_cull_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream, const FactorJob *job = nullptr)
-{
-  FactorJob fj = FactorJob();
-  if (job) fj = *job;
-  int ZC = m.nd == 3 ? 4 : 1;
-  const int groups = (m.ext_sz[0] + 7) / 8;
-  int gx_log2 = 3;
-  while (gx_log2 < 6 && (1 << gx_log2) < groups) gx_log2 ++;
-  const int GX = 1 << gx_log2, rows_per_block = 4 * (64 >> gx_log2);
-  const int nzc = m.nd == 3 ? (m.ext_sz[2] + ZC - 1) / ZC : 1;
-  // steps per lane: consecutive steps reuse the shared slice from registers; more chunks = more parallelism
-  // (3D: 4 -- a chunk re-reads one slice, a quarter more bytes of arrays that are 1/256 of the input, and gives four times the
-  // wavefronts: the coarse cull of 256^3 x 16 0.052 -> 0.026 ms, of 512^3 x 32 0.089 -> 0.081 ms)
-  int step_chunk = 4;   // (2D: the survivors of a workgroup's four steps leave with one atomic on the list counter)
-  const int nsc = (nsteps + step_chunk - 1) / step_chunk;
-  const dim3 grid((unsigned)((groups + GX - 1) / GX), (unsigned)((m.ext_sz[1] + rows_per_block - 1) / rows_per_block), (unsigned)(nzc * nsc) + (fj.enabled ? 1u : 0u));
-#define FTKX_CULL_LAUNCH(ND_, ZC_) hipLaunchKernelGGL((cull_march_kernel<ND_, ZC_, COARSE>), grid, dim3(kThreads), 0, stream, m, d_steps, nsteps, step_chunk, gx_log2, d_list, cap, fj)
-  if (m.nd == 2) FTKX_CULL_LAUNCH(2, 1);
-  else if (ZC == 2) FTKX_CULL_LAUNCH(3, 2);
-  else if (ZC == 8) FTKX_CULL_LAUNCH(3, 8);
-  else FTKX_CULL_LAUNCH(3, 4);
-#undef FTKX_CULL_LAUNCH
-}
-
 void launch_masks(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream) { launch_masks_impl(m, d_jobs, njobs, false, stream); }
 // pre-pass: only valid when march2_supported(m)
 void launch_reduce_march(const Mesh &m, const MaskJob *d_jobs, int njobs, hipStream_t stream) { launch_masks_impl(m, d_jobs, njobs, true, stream); }
-
-void launch_cull(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_list, u64 cap, hipStream_t stream, const FactorJob *job)
-{
-  if (nsteps <= 0) return;
-  launch_cull_level<false>(m, d_steps, nsteps, d_list, cap, stream, job);
-}
-
-// two-level form: summaries first (1/8 of the bytes), vertex masks only for the words the summaries could not rule out
-Mesh coarse_view(const Mesh &m)
-{
-  Mesh mc = m;                                   // the coarse view: one "vertex" per aligned word of 8 (x) and u_rows rows (y)
-  const int w0 = (m.core_st[0] - m.ext_st[0]) / 8, w1 = (m.core_st[0] + m.core_sz[0] - 1 - m.ext_st[0]) / 8;
-  mc.ext_st[0] = 0; mc.ext_sz[0] = (m.ext_sz[0] + 7) / 8;
-  mc.core_st[0] = w0; mc.core_sz[0] = w1 - w0 + 1;
-  const int r0 = (m.core_st[1] - m.ext_st[1]) / m.u_rows, r1 = (m.core_st[1] + m.core_sz[1] - 1 - m.ext_st[1]) / m.u_rows;
-  mc.ext_st[1] = 0; mc.ext_sz[1] = (m.ext_sz[1] + m.u_rows - 1) / m.u_rows;
-  mc.core_st[1] = r0; mc.core_sz[1] = r1 - r0 + 1;
-  mc.mask_pitch = m.u_pitch;
-  return mc;
-}
-
-// the two levels as separate launches (the series pass puts its factor kernel between them)
-void launch_cull_coarse(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, hipStream_t stream, const FactorJob *job)
-{
-  if (nsteps <= 0) return;
-  launch_cull_level<true>(coarse_view(m), d_steps, nsteps, d_refine, refine_cap, stream, job);
-}
-
-void launch_refine(const Mesh &m, const Fields *d_steps, const u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream, int few_wgs)
-{
-  const Mesh mc = coarse_view(m);
-  const dim3 grid(few_wgs > 0 ? (unsigned)few_wgs : 256u * 4u);      // (few: the tail of a split pass, next to a mask kernel -- sparse data, every workgroup waits for a slot)
-  if (m.nd == 2) hipLaunchKernelGGL(refine_kernel<2>, grid, dim3(kThreads), 0, stream, m, mc, d_steps, d_refine, refine_cap, d_list, cap);
-  else hipLaunchKernelGGL(refine_kernel<3>, grid, dim3(kThreads), 0, stream, m, mc, d_steps, d_refine, refine_cap, d_list, cap);
-}
-
-void launch_cull_two_level(const Mesh &m, const Fields *d_steps, int nsteps, u64 *d_refine, u64 refine_cap, u64 *d_list, u64 cap, hipStream_t stream)
-{
-  if (nsteps <= 0) return;
-  launch_cull_coarse(m, d_steps, nsteps, d_refine, refine_cap, stream, nullptr);
-  launch_refine(m, d_steps, d_refine, refine_cap, d_list, cap, stream, 0);
-}
-
-void launch_records(const Mesh &m, const Fields *d_fields, hipStream_t stream)
-{
-  // grid-stride over a device-side count: a few workgroups per CU are plenty (hits are rare; hit-dense 2D data: 1e4-1e5 per batch)
-  const dim3 grid(256u * 2u);
-  if (m.nd == 2) hipLaunchKernelGGL(record_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_fields);
-  else hipLaunchKernelGGL(record_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_fields);
-}
-
-void launch_exact(const Mesh &m, const Fields *d_steps, int step_base, const u64 *d_list, u64 cap, hipStream_t stream, int few_wgs)
-{
-  // persistent-style: workgroups stride over the list, every wave exits when it is drained (no scratch; 21-23 KB of LDS).  Four per
-  // CU: woven 1024^2 x 64 (181 853 cells) 0.084 ms with the record kernel, double_gyre 2048 x 1024 x 128 0.078 (0.097 with two)
-  int per_cu = 4;
-  const dim3 grid(few_wgs > 0 ? (unsigned)few_wgs : 256u * (unsigned)per_cu);
-  if (m.nd == 2) hipLaunchKernelGGL(exact_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_steps, step_base, d_list, cap);
-  else hipLaunchKernelGGL(exact_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_steps, step_base, d_list, cap);
-}
 
 }  // namespace ftkx

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kThreads) void series_one_kernel(const Mesh m, cons
         const unsigned row = idx / DW, i = idx - row * DW, k = row / DH, j = row - k * DH;
         double v[ND];
         vector_at<ND>(m, sl.S, sl.V, (int)i, (int)j, (int)k, v);
-        for (int q = 0; q < ND; q ++) {                          // (mask_kernel's fused reduction, sweep_kernels.hip: the WHOLE array, like ndarray::resolution())
+        for (int q = 0; q < ND; q ++) {                          // (mask_kernel's fused reduction, mask_kernels.hip: the WHOLE array, like ndarray::resolution())
           const double x = fabs(v[q]);
           mn = fmin(mn, (x == 0.0 || !(x < a.cap)) ? DBL_MAX_D : x);
           mx = fmax(mx, x);

@@ -1,5 +1,5 @@
 // The sticky quantisation factor on the device: shared by series_factors_kernel (series_kernels.hip) and the workgroup of the cull
-// kernel that does the same job while the others cull (sweep_kernels.hip, FactorJob).
+// kernel that does the same job while the others cull (cull_exact_kernels.hip, FactorJob).
 #pragma once
 #include "sweep_device.hpp"
 

@@ -1,6 +1,18 @@
-// Device functions shared by the kernels of the sweep (sweep_kernels.hip) and of the device-driven series pass (series_kernels.hip):
-// field access with the reference's derived-field arithmetic (ndarray/grad.hh), vertex classification, element tags, the per-simplex
-// test and the FP64 record construction (check_simplex, critical_point_tracker_2d_regular.hh:584-685, ..._3d_regular.hh:425-514).
+// Device functions shared by the kernels of the sweep and of the device-driven series pass (series_kernels.hip): field access with the
+// reference's derived-field arithmetic (ndarray/grad.hh), vertex classification, element tags, the per-simplex test and the FP64 record
+// construction (check_simplex, critical_point_tracker_2d_regular.hh:584-685, ..._3d_regular.hh:425-514).
+//
+// The kernels replace, behind the reference's accelerator boundary, what update_timestep() -> element_for_{ordinal,interval} ->
+// check_simplex does per timestep (critical_point_tracker_2d_regular.hh:263-433, ..._3d_regular.hh:150-308), and what its CUDA back-end
+// does with one thread per simplex and a global atomic per hit (src/filters/critical_point_tracer_{2d,3d}_regular.cu).  Where they live:
+//   mask_kernels.hip        FAST PATH 1/3 -- a slice is streamed once (S, 8 B/vertex, gradient in flight; V for vector input): one sign
+//                           byte per vertex, block summaries, the reduction the scaling factor needs.  HBM-bound, the dominant kernel.
+//   cull_exact_kernels.hip  FAST PATH 2/3, 3/3 -- SWAR AND over the 2^(d+1) hypercube on the summaries / mask words; the surviving corners'
+//                           simplices through the exact integer predicate (cp_device.hpp); the FP64 half of a record.
+//   tile_kernels.hip        TILE PATH -- exact_only, non-robust 3D, odd factors, the overflow regime: every simplex of a tile of corners
+//                           staged in LDS.  Integer / FP64 VALU-bound.
+//   halo_kernels.hip, dist_kernels.hip   the compact t-slab halo (several ranks);  series_kernels.hip, one_kernel.hip   the device-driven pass.
+// No MFMA anywhere: nothing here is a contraction.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>

@@ -82,6 +82,7 @@ struct TileParams {
   Mesh m;
   Fields f;
   int cull;                  // 1: strict-sign cull legal and enabled
+  int repeat;                // > 1: the fan phase alone that many times on the staged tile (ftkx_debug_tile_repeat); records are not affected
   int ntiles[3];
   int step;                  // index of `f` in the batch's device array of Fields (what record_kernel looks it up by)
   int fan;                   // the tests' knob (FTKX_TILE_FAN): 0 = (corner, type) pairs over the lanes everywhere, 1 = no fp64 fan, 2 = as the tiles allow

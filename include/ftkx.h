@@ -283,7 +283,8 @@ int ftkx_get_stats(const ftkx_ctx *ctx, ftkx_stats *st);
 int ftkx_invalidate_masks(ftkx_ctx *ctx);
 
 /* optional kernel timing with HIP events on the context's stream (for bench.py's roofline figure).  Index: 0 mask_kernel,
- * 1 cull_kernel, 2 exact_kernel, 3 tile_kernel; ms[] = summed device time, launches[] = launches timed since set_profiling(1). */
+ * 1 cull_kernel, 2 exact_kernel (+ everything behind it: the FP64 half of the records, their ordering), 3 tile_kernel (the integer test of
+ * every simplex: exact_only, the overflow regime); ms[] = summed device time, launches[] = launches timed since set_profiling(1). */
 int ftkx_set_profiling(ftkx_ctx *ctx, int on);      /* 0 off, 1 every kernel family, 2 the mask kernel only (an event pair costs the stream a few us) */
 int ftkx_get_kernel_times(const ftkx_ctx *ctx, double ms[4], unsigned long long launches[4]);
 
@@ -392,6 +393,11 @@ int ftkx_jacobian3D(ftkx_ctx *ctx, const double *V, int DW, int DH, int DD, doub
 /* profiling aid: streams `bytes` of device memory with the mask kernel's load shape (16 B per lane) and nothing else, so that
  * rocprofv3's FETCH_SIZE can be calibrated on a known byte count (tools/calibrate_fetch.py) */
 int ftkx_debug_stream_read(ftkx_ctx *ctx, const void *device_ptr, size_t bytes);
+
+/* profiling aid (bench.py's int-VALU yardstick): from the next sweep on the tile kernel -- exact_only, the overflow regime -- repeats its fan
+ * phase, the predicate arithmetic on a tile staged in LDS, `repeat` times per tile and step; records are those of one.  The time the extra
+ * repetitions add is the time of the arithmetic alone.  1 = off. */
+int ftkx_debug_tile_repeat(ftkx_ctx *ctx, int repeat);
 
 /* profiling aid: the mask-kernel instantiation of the most recent sweep in this process, spelled as rocprofv3 lists it */
 const char *ftkx_last_mask_kernel(void);

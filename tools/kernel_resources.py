@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "ftk_amd", "csrc", "sweep_kernels.hip")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "ftk_amd", "csrc", "tile_kernels.hip")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-c", src,
        "-o", "/tmp/ftkx_res.o", "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
