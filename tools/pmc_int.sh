@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_int_$LABEL; rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/int_regime.py $NAME > $OUT/trace.log 2>&1
 cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) gpurun_out/r06_${LABEL}_kernel_stats.csv
-tail -1 $OUT/trace.log > gpurun_out/r06_${LABEL}_bench.json
+grep "^{\"workload\"" $OUT/trace.log | tail -1 > gpurun_out/r06_${LABEL}_bench.json
 for c in "SQ_INSTS_VALU SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE" VALUBusy; do
   d=$OUT/$(echo $c | tr ' ' '_')
   rocprofv3 --pmc $c --output-format csv -d $d -- python3 tools/int_regime.py $NAME > $d.log 2>&1
