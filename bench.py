@@ -271,7 +271,8 @@ def side_config(name, torch, dev, ftk_amd, synthetic, tslab, steps=5, warmup=2):
            "frac_of_streaming_ceiling": alg / (dom_ms / max(1, dom_n) * 1e-3) / 1e9 / STREAM_CEILING_GBS if dom_n else None,
            "end_to_end_frac": alg / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg,
            "hits": int(len(recs)), "simplices_tested_exactly": int(st["simplices_tested"]), "nbits": int(np.log2(max(int(v) for v in f))),
-           "series_paths": paths, "check": check_records(name, case, dims, nt, recs, path_list, want_paths),
+           "series_paths": paths, "split_pass": ctx.series_split_decision(), "warmup_effective": max(warmup, 26),
+           "check": check_records(name, case, dims, nt, recs, path_list, want_paths),
            "kernel_timing": "HIP events around the mask kernel in 4 passes BEHIND the timed region (none inside it)"}
     out.update(spread(per_pass))
     ctx.close()
@@ -1111,7 +1112,11 @@ def job(args, env):
                 traffic = None
         out = {
             "metric": "space-time simplices/sec", "value": total_simplices * args.steps / elapsed, "unit": "simplices/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # what ran before the clock: a pipelined pass allocates over its first passes and the split pass measures itself (ten passes and the
+            # ones it discards) -- all of that is warm-up, whatever --warmup said
+            "warmup_effective": (max(args.warmup, 26) if pipelined else args.warmup),
+            "ms_per_step": elapsed / args.steps * 1e3,
             **spread(per_pass_ms),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": f"{case} {'x'.join(str(d) for d in dims)}x{nt} ({args.config}), "
@@ -1122,6 +1127,7 @@ def job(args, env):
                                  "device-driven, up to %d passes in flight (ftkx_sweep_series_submit / _complete)" % IN_FLIGHT if pipelined else "device-driven (ftkx_sweep_series)") +
                                 ": paths taken {(path, status): passes} = %s" % {str(k): v for k, v in series_paths.items()}) if series_paths
                                else "host-driven batch (slices_prepare, host factors, enqueue, collect)",
+                       "split_pass": (ctx.series_split_decision() if slab is None and series_paths else None),
                        "input_resident": "the field the tracker API is given (S, or V for vector input) in HBM; gradient/Jacobian evaluated in flight"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,

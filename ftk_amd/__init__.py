@@ -280,6 +280,14 @@ class Context:
         st = C.c_ulonglong()
         return int(self._L.ftkx_series_last_path(self._h, C.byref(st))), int(st.value)
 
+    def series_split_decision(self):
+        """how this context decides on the split pass: {"state": "auto: measuring" | "auto: split" | "auto: in order" | "forced on" | "forced off",
+        "median_in_order_ms", "median_split_ms"} (ftkx_series_split_decision)"""
+        st, a, b = C.c_int(), C.c_double(), C.c_double()
+        self._ck(self._L.ftkx_series_split_decision(self._h, C.byref(st), C.byref(a), C.byref(b)))
+        names = ["auto: measuring", "auto: split", "auto: in order", "forced on", "forced off"]
+        return {"state": names[st.value], "median_in_order_ms": a.value, "median_split_ms": b.value}
+
     def sweep_cancel(self):
         self._ck(self._L.ftkx_sweep_cancel(self._h))
 

@@ -280,8 +280,10 @@ struct ftkx_ctx {
     int skip = 0;                       // samples to discard (a change of form: buffers, streams, mask arrays of its first passes)
     std::vector<double> t_order, t_split;
     bool good = true;
+    double median_order = 0, median_split = 0;   // seconds per pass, what the decision was taken on
     unsigned countdown = 0;             // decided "not here": passes until it is measured again
   } sr_cal;
+  int sr_split_forced = 0;              // the last plan's FTKX_SERIES_HOOKS split setting: 0 auto, 1 forced on (2, 3, 4), 2 forced off (0)
   double sr_last_complete_s = 0;        // host clock of the last completion (0: the pipeline ran empty since)
   int sr_last_complete_kind = 0;        // 1 in order / 2 split, of a calibration pass; 0 otherwise
   unsigned sr_split_seq = 0;          // split passes queued so far: their parity picks the set
@@ -361,6 +363,8 @@ bool masks_valid(const ftkx_ctx *c, const Slice &s, u64 factor, bool two_level, 
 double job_big(const ftkx_ctx *c, const Slice &s, u64 factor, bool *rule_on);
 int ensure_mask_arrays(ftkx_ctx *c, Slice &s, bool two_level);
 int upload_from_host(ftkx_ctx *c, void *dst, const void *src, size_t bytes);
+int aux_stream_get(ftkx_ctx *c, bool high_priority, hipStream_t *out);       // the library's own streams, kept for the process (ftkx_api.hip)
+void aux_stream_put(ftkx_ctx *c, bool high_priority, hipStream_t st);
 // halo.hip
 bool packed_layout(const ftkx_ctx *c, const Mesh &m, size_t *ub, size_t *cap, size_t *off_idx, size_t *off_words, size_t *total);
 int ensure_sparse_slice(ftkx_ctx *c, int t, int scalar_input);

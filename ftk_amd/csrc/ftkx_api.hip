@@ -3,6 +3,8 @@
 // (src/filters/critical_point_tracer_2d_regular.cu:168-272, ..._3d_regular.cu:144-250), which re-allocates, re-uploads and
 // frees everything on every call and synchronises the whole device; here slices stay resident, launches go to a stream,
 // and the hit buffer is persistent (grown and the batch replayed if a launch overflows it).
+#include <map>
+#include <mutex>
 #include "ctx.hpp"
 #include "cp_device.hpp"
 #include <sched.h>
@@ -275,6 +277,40 @@ int upload_from_host(ftkx_ctx *c, void *dst, const void *src, size_t bytes)
   return FTKX_OK;
 }
 
+// ---- the library's auxiliary streams ----------------------------------------------------------------------------------------------
+// A pass's tail (series.hip) and the copy of its records run on streams of the library's own.  They are kept for the PROCESS, per device and
+// priority, and handed from a context that is destroyed to the next one that asks: what a stream is mapped to -- the hardware queue, its
+// priority -- is decided by the runtime when the stream is made, and a process that makes and destroys contexts (bench.py's configurations,
+// a test session) otherwise gets a different mapping for every context (round 5: the split pass of hit-dense data ran at 0.78 ms in a
+// fresh process and at 0.93-0.97 behind other contexts).  FTKX_STREAM_POOL=0: streams made and destroyed with the context, as before.
+namespace {
+std::mutex g_aux_mutex;
+std::map<std::pair<int, int>, std::vector<hipStream_t>> g_aux_free;      // (device, high priority?) -> idle streams
+bool aux_pool_on() { const char *e = getenv("FTKX_STREAM_POOL"); return !e || atoi(e) != 0; }
+}
+int aux_stream_get(ftkx_ctx *c, bool high, hipStream_t *out)
+{
+  if (aux_pool_on()) {
+    std::lock_guard<std::mutex> g(g_aux_mutex);
+    auto &v = g_aux_free[{c->device, high ? 1 : 0}];
+    if (!v.empty()) { *out = v.back(); v.pop_back(); return FTKX_OK; }
+  }
+  if (high) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIP_TRY(c, hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi));
+  } else HIP_TRY(c, hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+  return FTKX_OK;
+}
+void aux_stream_put(ftkx_ctx *c, bool high, hipStream_t st)
+{
+  if (!st) return;
+  (void)hipStreamSynchronize(st);
+  if (!aux_pool_on()) { (void)hipStreamDestroy(st); return; }
+  std::lock_guard<std::mutex> g(g_aux_mutex);
+  g_aux_free[{c->device, high ? 1 : 0}].push_back(st);
+}
+
 int ensure_mask_arrays(ftkx_ctx *c, Slice &s, bool two_level)
 {
   s.mask_gen = ++ c->mask_epoch;    // (every builder of masks comes through here: a series pass collected later leaves this slice's marks alone)
@@ -397,9 +433,9 @@ void ftkx_destroy(ftkx_ctx *c)
     if (B.red) (void)hipFree(B.red);
     for (void *p : {(void *)B.h_results, (void *)B.out, B.h_desc}) if (p) (void)hipHostFree(p);
   }
-  if (c->sr_copy_stream) (void)hipStreamDestroy(c->sr_copy_stream);
-  if (c->sr_tail_stream) (void)hipStreamDestroy(c->sr_tail_stream);
-  if (c->sr_tail_stream2) (void)hipStreamDestroy(c->sr_tail_stream2);
+  aux_stream_put(c, false, c->sr_copy_stream);
+  aux_stream_put(c, true, c->sr_tail_stream);
+  aux_stream_put(c, true, c->sr_tail_stream2);
   for (void *q : {(void *)c->sr_set1.counters, (void *)c->sr_set1.list, (void *)c->sr_set1.refine, (void *)c->sr_set1.pass, (void *)c->sr_set1.fragile,
                   (void *)c->sr_set1.bucketed, (void *)c->sr_set1.sorted, (void *)c->sr_set1.hist, (void *)c->sr_set1.boff}) if (q) (void)hipFree(q);
   if (c->sr_one_scratch) (void)hipFree(c->sr_one_scratch);

@@ -472,21 +472,26 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   const unsigned long long mask_bytes_of_pass = (unsigned long long)ntodo * (unsigned long long)n_vertices(c) * 8ull * (c->scalar_mode == 1 ? 1ull : (unsigned long long)nd);
   {
     P.to_device = pipelined && c->stats.hits > 4096;
-    // split?  hook: 0 never, 2 whatever the size (tests).  (Profiling level 2 times the mask kernel only, with events on the context's
-    // stream: they do not stand between the tail and anything.)
+    // split?  FTKX_SERIES_HOOKS split = 0 never | 1 auto (default): where the size rule below says so AND the self-check found it no slower
+    // | 4 on: the size rule alone, no self-check -- the deterministic setting | 2 whatever the size, no self-check (tests) | 3 = 4.
+    // ftkx_series_split_decision says which way a context went and on what numbers.  (Profiling level 2 times the mask kernel only, with
+    // events on the context's stream: they do not stand between the tail and anything.)
     const long split_mode = ftkx::env_hook("FTKX_SERIES_HOOKS", "split", 1);
     const unsigned long long mask_bytes = mask_bytes_of_pass;
-    // hit-dense passes as well (hook 3; 2 for the tests) -- their chain at full grids, the records by way of the copy kernel: double_gyre
-    // 2048 x 1024 x 128 0.836 -> 0.78 ms (its mask kernel 692 -> 752 us next to the chain's 550) in a fresh process, but 0.93-0.97 where the
-    // tail stream's priority does not take -- it needs it, its big grids queue behind the mask kernel's pending workgroups otherwise, and
-    // after another hit-dense context in the same process it does not get it (cause not found: NOTES.md).  Not by default.
-    const bool dense_too = split_mode == 3 || split_mode == 2;
+    // hit-dense passes as well, where the mask launch reads 4 GB and more -- their chain at full grids, the records by way of the copy kernel:
+    // double_gyre 2048 x 1024 x 128 0.83 -> 0.77 ms (its mask kernel 692 -> 752 us next to the chain's 550).  Round 5 saw 0.93-0.97 behind other
+    // hit-dense contexts of the same process and kept them in order; round 6 (every open tail waited for by an unsplit pass, the library's
+    // streams kept for the process) measures 0.764-0.774 alone, behind three other configurations and inside the driver's full line
+    // (tools/dense_split.py) -- and auto's self-check keeps a context in order where it is not so.  Smaller hit-dense passes lose: woven
+    // 1024^2 x 64, tail = mask kernel = 100 us, 0.205 -> 0.279 split.
+    const bool dense_too = true;
     const bool sparse_now = c->sr_sparse && !P.to_device;
     // (a hit-dense chain is ~550 us next to a mask kernel -- double_gyre's 56 766 records --: only mask launches of 4 GB and more hide it)
     P.split = split_mode != 0 && pipelined && !dist && (c->profiling == 0 || c->profiling == 2) && (sparse_now || dense_too) && ntodo > 0 &&
               (mask_bytes >= (sparse_now ? kSplitMinBytes : 4 * kSplitMinBytes) || split_mode == 2);
-    // the self-check (ctx.hpp, split_cal); a hook that forces or forbids the split pass (0, 2, 3) goes around it
+    // the self-check (ctx.hpp, split_cal); a hook that forces or forbids the split pass (0, 2, 3, 4) goes around it
     P.cal_kind = 0;
+    c->sr_split_forced = split_mode == 0 ? 2 : split_mode != 1 ? 1 : 0;
     if (P.split && split_mode == 1) {
       ftkx_ctx::split_cal &K = c->sr_cal;
       const unsigned long long sig = ((unsigned long long)n << 48) ^ ((unsigned long long)ntodo << 32) ^ (unsigned long long)cells;
@@ -547,11 +552,7 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
     B.red_cap = std::max<size_t>(ntodo, 1);
   }
   if (P.split || before_split) {
-    if (!c->sr_tail_stream) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      HIP_TRY(c, hipStreamCreateWithPriority(&c->sr_tail_stream, hipStreamNonBlocking, hi));    // (the tail is a latency chain: it goes first wherever a slot frees up)
-    }
+    if (!c->sr_tail_stream && (rc = aux_stream_get(c, true, &c->sr_tail_stream))) return rc;    // (high priority: the tail is a latency chain, it goes first wherever a slot frees up)
     for (ftkx_series_buffers &X : c->sr_buf)
       for (hipEvent_t *e : {&X.ev_masks, &X.ev_factors, &X.ev_tail}) if (!*e) HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
@@ -561,14 +562,11 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
   // double_gyre 0.77 -> 0.97, in some runs and not in others)
   const bool two_tails = P.split_sparse && mask_bytes_of_pass < 2 * kSplitMinBytes;
   P.tail_set = two_tails ? (int)(c->sr_split_seq ++ & 1u) : 0;
-  if (two_tails && !c->sr_tail_stream2) {                    // (only where it is used: streams beyond the runtime's hardware queues share them, and a tail
-    int lo = 0, hi = 0;                                      // that shares its mask kernel's queue runs behind it)
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    HIP_TRY(c, hipStreamCreateWithPriority(&c->sr_tail_stream2, hipStreamNonBlocking, hi));
-  }
+  // (only where it is used: streams beyond the runtime's hardware queues share them, and a tail that shares its mask kernel's queue runs behind it)
+  if (two_tails && !c->sr_tail_stream2 && (rc = aux_stream_get(c, true, &c->sr_tail_stream2))) return rc;
   P.before_buf = before_split ? before->buf : -1;
   if (P.tail_set == 1 && (rc = ensure_set1(c))) return rc;
-  if (P.to_device && !c->sr_copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->sr_copy_stream, hipStreamNonBlocking));
+  if (P.to_device && !c->sr_copy_stream && (rc = aux_stream_get(c, false, &c->sr_copy_stream))) return rc;
   fill_mesh(c, m);                                           // (the buffers may have moved)
   m.hist = tail_view(c, P).hist; m.hist_shift = shift; m.core_cells = cells;
   {
@@ -911,7 +909,8 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
       if (K.phase == 0 && K.t_order.size() >= 5) { K.phase = 1; K.skip = 4; }      // (the first split passes allocate: their stream, the mask arrays they swap in)
       else if (K.phase == 1 && K.t_split.size() >= 5) {
         K.phase = 2;
-        K.good = median(K.t_split) <= 1.02 * median(K.t_order);      // (kept unless clearly slower: the bad state is +13 %, a good one between -1 and -10 %)
+        K.median_order = median(K.t_order); K.median_split = median(K.t_split);
+        K.good = K.median_split <= 1.02 * K.median_order;      // (kept unless clearly slower: the bad state is +13 %, a good one between -1 and -10 %)
         K.countdown = K.good ? 0u : 4096u;
       }
     }
@@ -1260,6 +1259,20 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
   ftkx_series_pending &P = c->sr_pend[0];
   if ((rc = series_submit(c, P, ts, scopes, n, *running_resolution, nullptr, false))) { P.open = false; return rc; }
   return series_complete(c, P, running_resolution, factors, out, n_out);
+}
+
+// The split pass (path 5) of this context: how it is decided and on what.  *state: 0 auto, still measuring (or no pass of a qualifying shape
+// yet); 1 auto, decided for the split pass; 2 auto, decided against it (in order; measured again after 4 096 passes); 3 forced on; 4 forced off
+// (FTKX_SERIES_HOOKS split=...).  The medians (ms per pass, in order and split, the host's time between completions with the pipeline full)
+// are those of the last decision, 0 where none was taken.
+int ftkx_series_split_decision(const ftkx_ctx *c, int *state, double *median_in_order_ms, double *median_split_ms)
+{
+  if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
+  const ftkx_ctx::split_cal &K = c->sr_cal;
+  if (state) *state = c->sr_split_forced == 1 ? 3 : c->sr_split_forced == 2 ? 4 : K.phase < 2 ? 0 : K.good ? 1 : 2;
+  if (median_in_order_ms) *median_in_order_ms = K.median_order * 1e3;
+  if (median_split_ms) *median_split_ms = K.median_split * 1e3;
+  return FTKX_OK;
 }
 
 int ftkx_series_last_path(const ftkx_ctx *c, unsigned long long *status)

@@ -268,6 +268,14 @@ int ftkx_series_dist_status(const ftkx_ctx *ctx, long long *asked, long long *se
  * batch; *status (nullable) = the SERIES_* bits the kernels raised (csrc/sweep_params.hpp) */
 int ftkx_series_last_path(const ftkx_ctx *ctx, unsigned long long *status);
 
+/* The split pass (path 5) is taken where a pass's mask launch is long enough to hide its tail (sparse data: 1 GB and more; hit-dense data:
+ * 4 GB and more) AND -- in the default setting, "auto" -- the context's own measurement found it no slower: the first qualifying passes of
+ * a shape run five in order, five split, the host's time between completions is sampled, and the split pass is kept unless it was more
+ * than 2 % slower (how two queues share the device is the hardware's business; GPU_MAX_HW_QUEUES alone can turn it).  Deterministic
+ * settings: FTKX_SERIES_HOOKS="split=4" (the size rule alone) / "split=0" (never).  This call says which way the context went:
+ * *state 0 auto, still measuring; 1 auto, split; 2 auto, in order; 3 forced on; 4 forced off; medians in ms per pass (0: none taken). */
+int ftkx_series_split_decision(const ftkx_ctx *ctx, int *state, double *median_in_order_ms, double *median_split_ms);
+
 /* counters of the last collect: simplices visited (work items), cells/simplices surviving the cull, device-side hits */
 typedef struct ftkx_stats {
   unsigned long long work_items, cells, cells_survived, simplices_tested, hits;

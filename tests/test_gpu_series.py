@@ -572,6 +572,42 @@ def test_unsplit_pass_behind_two_open_tails(gpu, name, monkeypatch):
     ctx.close()
 
 
+def test_split_forced_on_and_off_give_identical_bytes_at_256_cubed(gpu, monkeypatch):
+    """The split pass pinned both ways (FTKX_SERIES_HOOKS split=0 / split=2) on a C3-sized volume, 256^3 x 4, pipelined: the same bytes, the
+    same factors, path 5 only where it was asked for -- and ftkx_series_split_decision says which setting a context ran under (auto: what the
+    self-check measured; forced: that it was forced)."""
+    import torch
+    from ftk_amd import synthetic
+    dev = torch.device("cuda", 0)
+    dims, nt = (256, 256, 256), 4
+    scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+    slices = [synthetic.generate("moving_extremum_3d", dims, t, 16, torch, dev) for t in range(nt)]
+    torch.cuda.synchronize()
+    got = {}
+    for mode, hooks in (("off", "one=0,split=0"), ("on", "one=0,split=2"), ("auto", "one=0")):
+        monkeypatch.setenv("FTKX_SERIES_HOOKS", hooks)
+        ctx = _ctx(gpu, dims, 3, 1, tag_mode=gpu.TAG_EXACT64)
+        for t in range(nt):
+            ctx.push_scalar_slice(t, slices[t])
+        outs, paths = [], set()
+        for _ in range(2):
+            ctx.invalidate_masks(); ctx.sweep_series_submit(range(nt), scopes)
+        for it in range(6):
+            ctx.invalidate_masks(); ctx.sweep_series_submit(range(nt), scopes)
+            r, f, run = ctx.sweep_series_complete()
+            outs.append((np.ascontiguousarray(r).tobytes(), [int(v) for v in f], run)); paths.add(ctx.series_last_path()[0])
+        for _ in range(2):
+            r, f, run = ctx.sweep_series_complete()
+            outs.append((np.ascontiguousarray(r).tobytes(), [int(v) for v in f], run)); paths.add(ctx.series_last_path()[0])
+        d = ctx.series_split_decision()
+        ctx.close()
+        assert all(o == outs[0] for o in outs), mode
+        got[mode] = (outs[0], paths, d)
+    assert got["off"][0] == got["on"][0] == got["auto"][0] and len(got["off"][0][0]) > 0
+    assert 5 not in got["off"][1] and 5 in got["on"][1]
+    assert got["off"][2]["state"] == "forced off" and got["on"][2]["state"] == "forced on" and got["auto"][2]["state"].startswith("auto")
+
+
 def test_pipelined_records_through_the_copy_engine(gpu):
     """more than 4096 records per pass: from the second pipelined pass on the record kernel leaves them in device memory and the copy
     engine brings them over while the next pass runs; records and factors as ftkx_sweep_series returns them"""
