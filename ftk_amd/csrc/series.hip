@@ -148,14 +148,14 @@ int ensure_series_buffers(ftkx_ctx *c, ftkx_series_buffers &B, size_t nwords, si
   }
   if (B.out_cap < (size_t)c->capacity) {
     if (B.out) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipHostFree(B.out)); B.out = nullptr; B.out_cap = 0; }
-    // Non-coherent = ordinary cached host memory for the CPU (as ensure_host_buffer has it): the host reads the records after it has seen
-    // the flag, which a LATER kernel on the same stream (series_finish / the copy kernel's last workgroup) stores with system scope
-    // behind a __threadfence_system().  What this relies on -- gfx950 behaviour, not the HIP programming model, which promises
-    // visibility of coarse-grained host memory only at synchronisation points -- is that the record kernel's stores have left the
-    // device when that later kernel starts (they are system-scope stores, and a kernel boundary on one queue writes the L2 back) and
-    // that PCIe writes snoop the CPU's caches (x86).  FTKX_SERIES_OUT_COHERENT=1 allocates the buffer coherent (fine-grained) instead:
-    // the model's guarantee, at the price of uncached CPU reads of the records.
-    static const bool coherent_out = getenv("FTKX_SERIES_OUT_COHERENT") && atoi(getenv("FTKX_SERIES_OUT_COHERENT")) != 0;
+    // The host reads the records after it has seen the flag, which a LATER kernel on the same stream (series_finish / the copy kernel's
+    // last workgroup) stores with system scope behind a __threadfence_system() -- there is no synchronisation point of the runtime in
+    // between.  The HIP programming model promises visibility of such stores for COHERENT (fine-grained) host memory; that is what the
+    // buffer is (round 6: it costs nothing measurable -- woven 1024^2 x 64 0.2033 against 0.2075 ms per pass, double_gyre 0.760 / 0.763,
+    // 512^3 x 32 5.479 / 5.486, the host's copy of 62 181 records 0.83 / 0.81 ms either way: profiles/r06_coherent_cost.txt).
+    // FTKX_SERIES_OUT_COHERENT=0: coarse-grained as in rounds 3-5, which relies on gfx950 behaviour -- the record kernel's system-scope
+    // stores have left the device when the later kernel starts, and PCIe writes snoop the CPU's caches.
+    const bool coherent_out = !(getenv("FTKX_SERIES_OUT_COHERENT") && atoi(getenv("FTKX_SERIES_OUT_COHERENT")) == 0);
     HIP_TRY(c, hipHostMalloc((void **)&B.out, (size_t)c->capacity * sizeof(ftkx_cp_t), coherent_out ? hipHostMallocCoherent : hipHostMallocNonCoherent));
     B.out_cap = (size_t)c->capacity;
   }

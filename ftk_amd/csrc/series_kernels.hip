@@ -743,8 +743,9 @@ __global__ __launch_bounds__(256) void series_copy_out_kernel(const ftkx_cp_t *_
   // With a pass queued behind the one whose records these are: not before that pass's begin kernel has stored its number (wait_val) --
   // the records' pass is then through (same stream, in order: no event needed, and none is recorded) and the next pass's descriptors have
   // been fetched over PCIe (a read queued behind this kernel's writes took 65 us instead of 4).  This kernel may well start while the
-  // records' pass is still running: sixteen workgroups whose first lanes sleep and poll.  (The bound -- seconds -- only keeps a begin kernel
-  // that never ran from hanging the device.)  Slab passes do not take this form: their begin kernel can sit behind a peer's messages, and
+  // records' pass is still running: sixteen workgroups whose first lanes sleep and poll -- for as long as the rest of the records' pass and
+  // the next pass's begin kernel take, and for at most 2^16 polls (some 0.1 s: what keeps a begin kernel that never ran from hanging the
+  // device; round 5: 2^23, eight seconds).  Slab passes do not take this form: their begin kernel can sit behind a peer's messages, and
   // the copy is ordered behind it by an event instead (series.hip, series_plan).
   // A workgroup that gives up still arrives at the counter below (marked), so that the counter is left at zero and the flag is NOT stored:
   // the host, which has waited for the records' pass itself by then, sees the copy stream drain without the flag and queues the copy again
@@ -754,8 +755,8 @@ __global__ __launch_bounds__(256) void series_copy_out_kernel(const ftkx_cp_t *_
   if (wait_flag) {
     if (threadIdx.x == 0) {
       unsigned it = 0;
-      while (it < (1u << 23) && (int)(__hip_atomic_load(wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - wait_val) < 0) { __builtin_amdgcn_s_sleep(32); it ++; }
-      s_gave_up = it == (1u << 23);
+      while (it < (1u << 16) && (int)(__hip_atomic_load(wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - wait_val) < 0) { __builtin_amdgcn_s_sleep(32); it ++; }
+      s_gave_up = it == (1u << 16);
     }
   }
   __syncthreads();

@@ -346,8 +346,8 @@ def test_abort_discards_the_open_passes_and_leaves_the_context_usable(gpu):
 
 @pytest.mark.parametrize("name", ["woven_128x128x10", "woven_31x37x32", "double_gyre_64x32x50", "merger_2d_32x32x100", "moving_extremum_3d_21x21x21x32",
                                   "adversarial_3d_scalar_9x9x9x4", "random_2d_scalar_29x24x6_saddles", "adversarial_3d_scalar_9x9x9x3_norobust"])
-@pytest.mark.parametrize("split", [False, True], ids=["in_order", "split"])
-def test_pipelined_passes_equal_the_plain_ones(gpu, name, split, monkeypatch):
+@pytest.mark.parametrize("split,coarse_out", [(False, False), (True, False), (True, True)], ids=["in_order", "split", "split_coarse_grained_records"])
+def test_pipelined_passes_equal_the_plain_ones(gpu, name, split, coarse_out, monkeypatch):
     """ftkx_sweep_series_submit / _complete, two passes open at a time: (a) the whole series swept again and again, masks dropped in
     between (what bench.py times), (b) the series in consecutive pieces, each continuing on the device from the running minimum of the one
     before it, while the host has not even seen that one yet (a streaming caller).  Records, factors and running minima are those of
@@ -358,6 +358,10 @@ def test_pipelined_passes_equal_the_plain_ones(gpu, name, split, monkeypatch):
     next to the begin and mask kernels of the pass queued behind; counters zeroed there, mask arrays that the next pass rebuilds replaced."""
     if split:
         monkeypatch.setenv("FTKX_SERIES_HOOKS", "one=0,split=2")
+    # the record buffer: coherent host memory by default (the HIP memory model's guarantee for records read behind a flag); the switch back
+    # to coarse-grained memory (rounds 3-5, gfx950 behaviour) stays covered
+    if coarse_out:
+        monkeypatch.setenv("FTKX_SERIES_OUT_COHERENT", "0")
     g = load_golden(name)
     nd, nv, nt = g["nd"], g["nv"], g["DT"]
     scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
@@ -485,13 +489,15 @@ def test_tracker_with_deferred_batches_looked_at_midway(gpu):
     assert np.array_equal(ts[np.argsort(recs["tag"], kind="stable")], g["records"]["timestep"][np.argsort(g["records"]["tag"], kind="stable")])
 
 
-@pytest.mark.parametrize("hooks", ["one=0", "one=0,split=2"], ids=["in_order", "split"])
+@pytest.mark.parametrize("hooks,coarse_out", [("one=0", False), ("one=0,split=2", False), ("one=0,split=2", True)], ids=["in_order", "split", "split_coarse_grained_records"])
 @pytest.mark.parametrize("name", ["moving_extremum_3d_21x21x21x32", "woven_128x128x10", "double_gyre_64x32x50"])
-def test_three_passes_in_flight(gpu, name, hooks, monkeypatch):
+def test_three_passes_in_flight(gpu, name, hooks, coarse_out, monkeypatch):
     """three passes open at a time (the third lets the host run one pass ahead of a split pass's tail; split passes alternate between two sets
     of counters and lists, on two tail streams): the whole series again and again, masks dropped in between, and a chain of pieces that
     each continue on the device from the one before -- records, factors and running minima of ftkx_sweep_series; a fourth submit is refused"""
     monkeypatch.setenv("FTKX_SERIES_HOOKS", hooks)
+    if coarse_out:
+        monkeypatch.setenv("FTKX_SERIES_OUT_COHERENT", "0")      # (the record buffer in coarse-grained host memory: the switch of rounds 3-5's default)
     g = load_golden(name)
     nd, nv, nt = g["nd"], g["nv"], g["DT"]
     scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
