@@ -193,7 +193,11 @@ int run_batch(ftkx_ctx *c, const double *sparse_field, bool cull_done)
   struct Sub { std::vector<MaskJob> jobs; std::vector<Fields> steps; };
   std::vector<Sub> subs(1);
   const bool two_level = ftkx::masks_have_summary(m);
+  // the tile requests: one launch per run of consecutive requests with the same cull setting -- a workgroup walks the run's steps in time
+  // order with its tile staged in LDS (tile_kernels.hip) -- under the smallest form any of them asks for (every form is correct everywhere)
   std::vector<TileParams> tiles;
+  std::vector<Fields> tile_fields;
+  const bool tile_walk = !(getenv("FTKX_TILE_WALK") && atoi(getenv("FTKX_TILE_WALK")) == 0);      // (test hook: 0 = a launch per step)
   for (const Request &r : c->pending) {
     Slice &s0 = c->slices[r.t];
     Slice *s1 = (r.scope & FTKX_SCOPE_INTERVAL) ? &c->slices[r.t + 1] : nullptr;
@@ -224,7 +228,8 @@ int run_batch(ftkx_ctx *c, const double *sparse_field, bool cull_done)
       subs.back().steps.push_back(f);
     } else {
       TileParams p;
-      p.m = m; p.f = f; p.cull = r.mode == MODE_TILE_CULL ? 1 : 0; p.step = 0; p.repeat = c->tile_repeat;
+      p.m = m; p.steps = nullptr; p.nsteps = 1; p.repeat = c->tile_repeat; p.cull = r.mode == MODE_TILE_CULL ? 1 : 0; p.step = (int)tile_fields.size();
+      tile_fields.push_back(f);
       { const char *e = getenv("FTKX_TILE_FAN"); p.fan = e ? atoi(e) : 2; }
       {
         // largest |quantised component| the request can meet, where the slices' maxima are known (the kernel checks every tile anyway)
@@ -237,7 +242,10 @@ int run_batch(ftkx_ctx *c, const double *sparse_field, bool cull_done)
       int tile[3];
       ftkx::tile_dims(nd, tile);
       for (int d = 0; d < 3; d ++) p.ntiles[d] = d < nd ? (int)((c->core_sz[d] + tile[d] - 1) / tile[d]) : 1;
-      tiles.push_back(p);
+      if (tile_walk && !tiles.empty() && tiles.back().cull == p.cull && tiles.back().fan == p.fan && tiles.back().step + tiles.back().nsteps == p.step) {
+        tiles.back().nsteps ++;
+        tiles.back().form = std::min(tiles.back().form, p.form);
+      } else tiles.push_back(p);
     }
   }
   // one upload for all descriptors: the mask jobs of each sub-batch, then ONE array of Fields for the whole batch -- the steps of
@@ -250,7 +258,7 @@ int run_batch(ftkx_ctx *c, const double *sparse_field, bool cull_done)
   size_t nfields = 0;
   for (const Sub &sb : subs) { step_base.push_back(nfields); nfields += sb.steps.size(); }
   const size_t tile_base = nfields;
-  nfields += tiles.size();
+  nfields += tile_fields.size();
   total += (nfields * sizeof(Fields) + 255) / 256 * 256;
   if ((nfields >> (64 - ftkx::kPassStepShift)) != 0) return fail(c, FTKX_E_INVALID, "sweep: too many requests in one batch (%zu)", nfields);
   if (total) {
@@ -261,10 +269,11 @@ int run_batch(ftkx_ctx *c, const double *sparse_field, bool cull_done)
       if (!subs[i].jobs.empty()) memcpy((char *)c->h_desc + job_off[i], subs[i].jobs.data(), subs[i].jobs.size() * sizeof(MaskJob));
       if (!subs[i].steps.empty()) memcpy(hf + step_base[i], subs[i].steps.data(), subs[i].steps.size() * sizeof(Fields));
     }
-    for (size_t i = 0; i < tiles.size(); i ++) { hf[tile_base + i] = tiles[i].f; tiles[i].step = (int)(tile_base + i); }
+    for (size_t i = 0; i < tile_fields.size(); i ++) hf[tile_base + i] = tile_fields[i];
     HIP_TRY(c, hipMemcpyAsync(c->d_desc, c->h_desc, total, hipMemcpyHostToDevice, c->stream));
   }
   const Fields *d_fields = (const Fields *)((char *)c->d_desc + fields_off);
+  for (TileParams &p : tiles) { p.step += (int)tile_base; p.steps = d_fields + p.step; }
   if (cull_only && (subs.size() > 1 || !tiles.empty()))
     return fail(c, FTKX_E_UNSUPPORTED, "ftkx_sweep_cull: the batch needs masks under two factors or the tile path (send the slice itself)");
   for (size_t i = 0; i < subs.size(); i ++) {

@@ -80,11 +80,12 @@ struct Fields {
 // tile kernel (exact_only / non-robust / overflow regime, and small jobs)
 struct TileParams {
   Mesh m;
-  Fields f;
+  const Fields *steps;       // the requests of this launch in the batch's device array of Fields, in time order: a workgroup keeps its tile
+  int nsteps;                // for all of them, and a slice two consecutive steps share is staged once (tile_kernels.hip)
   int cull;                  // 1: strict-sign cull legal and enabled
   int repeat;                // > 1: the fan phase alone that many times on the staged tile (ftkx_debug_tile_repeat); records are not affected
   int ntiles[3];
-  int step;                  // index of `f` in the batch's device array of Fields (what record_kernel looks it up by)
+  int step;                  // index of steps[0] in the batch's device array of Fields (what record_kernel looks a simplex's request up by)
   int fan;                   // the tests' knob (FTKX_TILE_FAN): 0 = (corner, type) pairs over the lanes everywhere, 1 = no fp64 fan, 2 = as the tiles allow
   int form;                  // which tile_kernel<ND, FORM> to launch: from the slices' largest magnitude x factor where the context knows it
   u64 *stats;                // 256 x {simplices tested, cells survived}: a workgroup adds to slot blockIdx % 256, tile_stats_fold_kernel sums

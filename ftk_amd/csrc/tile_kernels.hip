@@ -242,11 +242,16 @@ __device__ __forceinline__ unsigned char stage_value(const double *v, double fac
 // FORM 0: (corner, type) pairs over the lanes for every tile.  FORM 1 (3D, robust test): tiles whose components fit in 32 bits take the
 // integer fan, the others the pairs.  FORM 2: tiles with |component| < 2^19 take the fp64 fan, else as FORM 1.  The host picks the form
 // from what it knows of the slices' magnitudes (launch_tile); every form is correct on every tile -- the forms differ in registers.
-// PROBE (TileParams::repeat > 1: ftkx_debug_tile_repeat, bench.py's int-VALU yardstick): an instantiation of its own that runs the fan phase
-// alone `repeat` times on the staged tile -- the rate of the predicate arithmetic without staging, lists and records.  (Its own
-// instantiation: the fan lives within a few registers of the 256 two wavefronts per SIMD leave it, and a loop around it in the production
-// kernel, or a step loop around the whole tile -- tried in round 6: one staged slice per step instead of two -- costs it spills that
-// double its time.)
+//
+// Round 6: a workgroup keeps its tile for ALL the steps of the launch (TileParams::steps, nsteps -- the requests of one batch in time
+// order).  Slice t + 1 of step t is slice t of step t + 1: where the next step reads the same array under the same factor, its staged
+// vertices -- quantised components, doubles, mask bytes, magnitude flags -- move from slot 1 to slot 0 inside LDS (a dozen 8-byte copies
+// per lane; swapping the slots' roles instead made every LDS address of the fan a run-time one and cost it its registers);
+// a step stages ONE slice instead of two (round 5: both, every step: 14.5 k of a wavefront's 34.6 k cycles), and the statistics leave once
+// per workgroup instead of once per step.  The block of S a slice's gradients are taken from is loaded by rows -- 13 rows of 19 values per
+// round over 247 lanes, row and column fixed per lane -- instead of by a linear index that every round took apart again.
+// PROBE (TileParams::repeat > 1: ftkx_debug_tile_repeat, bench.py's int-VALU yardstick): the fan phase alone is run that many times on the
+// staged tile -- the rate of the predicate arithmetic without staging, lists and records.
 template <int ND, int FORM, bool PROBE = false>
 __global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile_kernel(const TileParams p)
 {
@@ -257,28 +262,29 @@ __global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile
   constexpr int NORD = fan_table<N>::NORD, NINT = fan_table<N>::NINT;
   static_assert(cfg::TX * cfg::TY * cfg::TZ == kThreads, "one corner per lane");
 
-  // 3D, scalar input: the gradients of a tile's 17 x 5 x 5 x 2 vertices read a 19 x 7 x 7 x 2 block of S -- loaded once into LDS with every
+  // 3D, scalar input: the gradients of a slice's 17 x 5 x 5 vertices read a 19 x 7 x 7 block of S -- loaded once into LDS with every
   // load of a lane in flight together (one round trip), instead of six dependent global loads per vertex and 2.7 reads per value
   constexpr bool S_BLOCK = ND == 3;
   constexpr int SX = cfg::TX + 3, SY = cfg::TY + 3, SZ = cfg::TZ + 3, NS = S_BLOCK ? SX * SY * SZ : 1;
   constexpr int kItems = 512;
-  __shared__ i64 s_vf[2][ND][NH];                      // quantised components, one array per (slice, component)
+  __shared__ i64 s_vf[2][ND][NH];                      // quantised components, one array per (slot, component)
   __shared__ double s_vd[FORM >= 2 ? 2 * ND * NH : 1]; // FORM 2: the same as doubles (exact below 2^53; read where the tile is below 2^19)
-  __shared__ double s_s[2][NS];
+  __shared__ double s_s[NS];                           // the block of S of the slice being staged
   __shared__ unsigned char s_mask[2][NH];
   __shared__ unsigned s_tab[fan_table<N>::NTYPES];     // the vertex masks of a type packed in one word
   __shared__ unsigned short s_list[2][kThreads];       // surviving corners: [0] ordinal sweep, [1] interval sweep
   __shared__ unsigned s_cnt[2];
-  __shared__ unsigned s_wflags[kThreads / 64];
+  __shared__ unsigned s_wflags[2][kThreads / 64];      // per slot and wavefront: the magnitude flags of the vertices it staged
   __shared__ unsigned short s_items[FORM >= 1 ? kItems : 1];   // fan forms: (lane, type) of the simplices the fan was not sure of
   __shared__ unsigned s_nitems, s_stat[2];
 
   const int tid = threadIdx.x;
   const fan_table<N> &fan = dev_fan<ND>();
   const Mesh &m = p.m;
-  const Fields &f = p.f;
 #ifdef FTKX_TILE_STAMPS
   unsigned long long stamp_ = __builtin_readcyclecounter(), phase_[6] = {0, 0, 0, 0, 0, 0};
+#undef TILE_STAMP
+#define TILE_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); phase_[k] += now_ - stamp_; stamp_ = now_; } while (0)
 #endif
 
   // workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2): give each XCD a
@@ -291,86 +297,16 @@ __global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile
   }
   const int tile[3] = {(int)(b % p.ntiles[0]), (int)((b / p.ntiles[0]) % p.ntiles[1]), (int)(b / (p.ntiles[0] * p.ntiles[1]))};
   const int origin[3] = {m.core_st[0] + tile[0] * cfg::TX, m.core_st[1] + tile[1] * cfg::TY, (ND == 3) ? m.core_st[2] + tile[2] * cfg::TZ : 0};
-  const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0;
 
   if (tid < fan_table<N>::NTYPES) {
     unsigned w = 0;
     for (int i = 0; i < N; i ++) w |= (unsigned)fan.vert[tid][i] << (8 * i);
     s_tab[tid] = w;
   }
-  if (tid < 2) { s_cnt[tid] = 0; s_stat[tid] = 0; }
-  if (tid == 2) s_nitems = 0;
+  if (tid < 2) s_stat[tid] = 0;
 
-  // ---- stage ----
   const bool from_block = S_BLOCK && m.scalar_mode;
-  if constexpr (S_BLOCK) {
-    if (from_block) {
-      constexpr int ROUNDS = (2 * NS + kThreads - 1) / kThreads;
-      double got[ROUNDS];
-#pragma unroll
-      for (int r = 0; r < ROUNDS; r ++) {
-        const int idx = tid + r * kThreads, sl = idx / NS, at = idx - sl * NS;
-        const int i = origin[0] - 1 + at % SX - m.ext_st[0], j = origin[1] - 1 + (at / SX) % SY - m.ext_st[1], k = origin[2] - 1 + at / (SX * SY) - m.ext_st[2];
-        const bool in = idx < 2 * NS && (sl == 0 || need_next) && i >= 0 && i < m.ext_sz[0] && j >= 0 && j < m.ext_sz[1] && k >= 0 && k < m.ext_sz[2];
-        got[r] = in ? f.S[sl][arr_index<3>(m, i, j, k)] : 0.0;
-      }
-#pragma unroll
-      for (int r = 0; r < ROUNDS; r ++) {
-        const int idx = tid + r * kThreads;
-        if (idx < 2 * NS) s_s[idx / NS][idx % NS] = got[r];
-      }
-      __syncthreads();
-    }
-  }
-  TILE_STAMP(0);
-  bool mine_narrow = true, mine_mid = true, mine_small = true;
-  for (int h = tid; h < 2 * NH; h += kThreads) {
-    const int sl = h / NH, hv = h - sl * NH;
-    if (sl == 1 && !need_next) break;
-    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-    const int vx[3] = {origin[0] + hx, origin[1] + hy, origin[2] + hz};
-    i64 q[ND];
-    double tq[ND];
-    unsigned char mk = kInvalid;
-    for (int j = 0; j < ND; j ++) { q[j] = 0; tq[j] = 0.0; }
-    if (vertex_usable<ND>(m, vx)) {
-      double g[3] = {0.0, 0.0, 0.0};
-      if (from_block) {
-        // gradient3D of ndarray/grad.hh out of the block: the same operations as gradient_at on the same values
-        const int i = vx[0] - m.ext_st[0], j = vx[1] - m.ext_st[1], k = vx[2] - m.ext_st[2];
-        if (i >= 1 && i < m.ext_sz[0] - 1 && j >= 1 && j < m.ext_sz[1] - 1 && k >= 1 && k < m.ext_sz[2] - 1) {
-          const double *c = &s_s[sl][(hx + 1) + SX * ((hy + 1) + SY * (hz + 1))];
-          g[0] = 0.5 * (c[1] - c[-1]);
-          g[1] = 0.5 * (c[SX] - c[-SX]);
-          g[2] = 0.5 * (c[SX * SY] - c[-SX * SY]);
-        }
-      } else vector_at<ND>(m, f.S[sl], f.V[sl], vx[0] - m.ext_st[0], vx[1] - m.ext_st[1], ND == 3 ? vx[2] - m.ext_st[2] : 0, g);
-      mk = stage_value<ND>(g, f.factor, q, tq, mine_narrow, mine_mid, mine_small);
-    }
-    s_mask[sl][hv] = mk;
-    for (int j = 0; j < ND; j ++) {
-      s_vf[sl][j][hv] = q[j];
-      if constexpr (FORM >= 2) s_vd[(sl * ND + j) * NH + hv] = tq[j];
-    }
-  }
-  TILE_STAMP(1);
-  // all quantised components of the tile fit in 32 bits: the integer test takes its cheaper multiplies -- same values, see cp_device.hpp;
-  // below 2^19, 2^16: the 3D fan decides signs in double precision, fan_of_corner3.  (One word per wavefront and ONE barrier, which is
-  // also the one between staging and everything that reads the staged tile.)
-  {
-    const unsigned bits = (__all(mine_narrow) ? 1u : 0u) | (__all(mine_mid) ? 2u : 0u) | (__all(mine_small) ? 4u : 0u);
-    if ((tid & 63) == 0) s_wflags[tid >> 6] = bits;
-  }
-  __syncthreads();
-  unsigned tile_bits = 7u;
-  for (int w = 0; w < kThreads / 64; w ++) tile_bits &= s_wflags[w];
-  const bool narrow = (tile_bits & 1u) != 0;
-  TILE_STAMP(2);
-  const bool fan_int = FORM >= 1 && narrow && (ND == 2 || m.robust) && p.fan >= 1;
-  const bool fan_fp = FORM >= 2 && fan_int && p.fan >= 2 && (tile_bits & 2u);
-  const bool small = fan_fp && (tile_bits & 4u);
-
-  // ---- cull: one corner per lane ----
+  // this lane's corner
   const int cx = tid % cfg::TX, cy = (tid / cfg::TX) % cfg::TY, cz = tid / (cfg::TX * cfg::TY);
   bool in_core = true;
   {
@@ -378,195 +314,303 @@ __global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile
     for (int d = 0; d < ND; d ++) in_core = in_core && csp[d] < m.core_st[d] + m.core_sz[d];
   }
   const int hbase = cx + HX * (cy + HY * cz);
-  bool keep_o = false, keep_i = false;
-  {
-    unsigned and0 = 0x3f, and1 = 0x3f;
-    for (int c = 0; c < (1 << ND); c ++) {
-      const int off = (c & 1) + HX * (((c >> 1) & 1) + HY * ((c >> 2) & 1));
-      // vertices no simplex may use (outside the domain, non-finite) are neutral for the sign argument
-      const unsigned m0 = s_mask[0][hbase + off];
-      and0 &= (m0 & (kInvalid | kNonFinite)) ? 0x3fu : m0;
-      if (need_next) { const unsigned m1 = s_mask[1][hbase + off]; and1 &= (m1 & (kInvalid | kNonFinite)) ? 0x3fu : m1; }
-    }
-    keep_o = in_core && (f.scope_mask & FTKX_SCOPE_ORDINAL) && !(p.cull && (and0 & 0x3f));
-    keep_i = in_core && need_next && !(p.cull && (and0 & and1 & 0x3f));
-  }
-  const unsigned long long ballot_o = __ballot(keep_o), ballot_i = __ballot(keep_i);
-  unsigned tested = 0;
-  if constexpr (FORM >= 1) {
-    // ---- test, one corner per lane (fan_of_corner3 / fan_of_corner2) ----
-    if (fan_int && p.fan != 9) {
-      u64 hits = 0, unsure = 0;
-      constexpr int NV = 1 << N;                                  // vertices of the corner's space-time hypercube
-      int corner[N];
-      corner[0] = origin[0] + cx; corner[1] = origin[1] + cy;
-      if (ND == 3) corner[2] = origin[2] + cz;
-      corner[ND] = f.t;
-      // (vertex v of the corner's hypercube: bit d = one step along axis d, bit ND = the next slice)
-      auto offset = [](int v) constexpr { return (v & 1) + HX * (((v >> 1) & 1) + (ND == 3 ? HY * ((v >> 2) & 1) : 0)); };
-      if (ballot_o | ballot_i) {                                 // (a wavefront nothing of which survived its cull: nothing to do)
-        unsigned inv = 0, pos[3] = {0, 0, 0}, neg[3] = {0, 0, 0};
+
+  // ---- one slice into one slot: mask bytes, quantised components (+ doubles), the magnitude flags of what this wavefront staged ----
+  // (tl = the lane's index seen through an empty asm in every step: what the staging derives from it -- rows, vertices, LDS addresses, bounds
+  // checks -- is loop-invariant, and hoisted out of the step loop it would sit in registers across the fan, which has none to spare)
+  auto stage_slice = [&](const Fields &f, int sl, int slot, const int tl) {
+    if constexpr (S_BLOCK) {
+      if (from_block) {
+        // the block by rows: lane -> (row0, col) once, 13 rows a round; row = y + SY * z of the block
+        constexpr int RPR = kThreads / SX, ROUNDS = (SY * SZ + RPR - 1) / RPR;
+        const int row0 = tl / SX, col = tl - row0 * SX;
+        const int i = origin[0] - 1 + col - m.ext_st[0];
+        const bool lane_on = row0 < RPR && i >= 0 && i < m.ext_sz[0];
+        const double *S = f.S[sl];
+        double got[ROUNDS];
 #pragma unroll
-        for (int v = 0; v < NV; v ++) {
-          unsigned mk = kInvalid;
-          if ((v >> ND) == 0 || need_next) mk = s_mask[v >> ND][hbase + offset(v)];
-          if (mk & (kInvalid | kNonFinite)) inv |= 1u << v;
-#pragma unroll
-          for (int c = 0; c < ND; c ++) { if (mk & (1u << c)) pos[c] |= 1u << v; if (mk & (8u << c)) neg[c] |= 1u << v; }
+        for (int r = 0; r < ROUNDS; r ++) {
+          const int row = row0 + r * RPR, y = row % SY, z = row / SY;
+          const int j = origin[1] - 1 + y - m.ext_st[1], k = origin[2] - 1 + z - m.ext_st[2];
+          const bool in = lane_on && row < SY * SZ && j >= 0 && j < m.ext_sz[1] && k >= 0 && k < m.ext_sz[2];
+          got[r] = in ? S[arr_index<3>(m, i, j, k)] : 0.0;
         }
-        // (component c of vertex v; slice 1 of an ordinal-only request is not staged: whatever is read there only enters simplices that
-        // `inv` switches off)
-        auto run_fan = [&](const int hb_) __attribute__((always_inline)) -> fan_result {
-          if (FORM >= 2 && fan_fp) {
-            const double *base = s_vd + hb_;
-            auto at = [&](auto V, int c) __attribute__((always_inline)) { constexpr int v = decltype(V)::value; return base[((v >> ND) * ND + c) * NH + offset(v)]; };
-            if constexpr (ND == 3) return fan_of_corner3<double>(at, inv, pos, neg, keep_o, keep_i, p.cull, small ? 0.5 : 4096.0);
-            else return fan_of_corner2<double>(at, inv, pos, neg, keep_o, keep_i, p.cull, 0.5);
-          } else {
-            const i64 *base = &s_vf[0][0][0] + hb_;
-            auto at = [&](auto V, int c) __attribute__((always_inline)) { constexpr int v = decltype(V)::value; return (int)base[((v >> ND) * ND + c) * NH + offset(v)]; };
-            if constexpr (ND == 3) return fan_of_corner3<int>(at, inv, pos, neg, keep_o, keep_i, p.cull, 0.0);
-            else return fan_of_corner2<int>(at, inv, pos, neg, keep_o, keep_i, p.cull, 0.0);
-          }
-        };
-        fan_result fr;
-        if constexpr (PROBE) {
-          // the lane's LDS offset through an empty asm in every repetition: nothing of the fan, its loads included, is loop-invariant then
-          for (int rep_ = 0; rep_ < p.repeat; rep_ ++) { int hb_ = hbase; asm volatile("" : "+v"(hb_)); fr = run_fan(hb_); }
-        } else fr = run_fan(hbase);
-        tested += fr.tested;
-        hits = (u64)fr.hits[0] | ((u64)fr.hits[1] << 32); unsure = (u64)fr.unsure[0] | ((u64)fr.unsure[1] << 32);
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r ++) {
+          const int row = row0 + r * RPR;
+          if (row0 < RPR && row < SY * SZ) s_s[col + SX * row] = got[r];
+        }
+        __syncthreads();
       }
-      TILE_STAMP(3);
-      // A value that is zero / INT64_MIN (fp64: not clear of zero): the integer test and the literal cascade on the vertices as staged.
-      // One simplex in thousands, but a long computation: the (lane, type) pairs of the whole tile go on a list and are dealt to the lanes
-      // again (a lane that walked its own would hold its wavefront for each of them).
-      auto corner_of = [&](int lane_tid, int (&lc)[N]) -> int {
-        const int lx = lane_tid % cfg::TX, ly = (lane_tid / cfg::TX) % cfg::TY, lz = lane_tid / (cfg::TX * cfg::TY);
-        lc[0] = origin[0] + lx; lc[1] = origin[1] + ly;
-        if (ND == 3) lc[2] = origin[2] + lz;
-        lc[ND] = f.t;
-        return lx + HX * (ly + HY * lz);
-      };
-      auto resolve = [&](int lane_tid, int type) -> bool {
-        int lc[N];
-        const int hb = corner_of(lane_tid, lc);
+    }
+    TILE_STAMP(0);
+    bool mine_narrow = true, mine_mid = true, mine_small = true;
+    for (int hv = tl; hv < NH; hv += kThreads) {
+      const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+      const int vx[3] = {origin[0] + hx, origin[1] + hy, origin[2] + hz};
+      i64 q[ND];
+      double tq[ND];
+      unsigned char mk = kInvalid;
+      for (int j = 0; j < ND; j ++) { q[j] = 0; tq[j] = 0.0; }
+      if (vertex_usable<ND>(m, vx)) {
+        double g[3] = {0.0, 0.0, 0.0};
+        if (from_block) {
+          // gradient3D of ndarray/grad.hh out of the block: the same operations as gradient_at on the same values
+          const int i = vx[0] - m.ext_st[0], j = vx[1] - m.ext_st[1], k = vx[2] - m.ext_st[2];
+          if (i >= 1 && i < m.ext_sz[0] - 1 && j >= 1 && j < m.ext_sz[1] - 1 && k >= 1 && k < m.ext_sz[2] - 1) {
+            const double *c = &s_s[(hx + 1) + SX * ((hy + 1) + SY * (hz + 1))];
+            g[0] = 0.5 * (c[1] - c[-1]);
+            g[1] = 0.5 * (c[SX] - c[-SX]);
+            g[2] = 0.5 * (c[SX * SY] - c[-SX * SY]);
+          }
+        } else vector_at<ND>(m, f.S[sl], f.V[sl], vx[0] - m.ext_st[0], vx[1] - m.ext_st[1], ND == 3 ? vx[2] - m.ext_st[2] : 0, g);
+        mk = stage_value<ND>(g, f.factor, q, tq, mine_narrow, mine_mid, mine_small);
+      }
+      s_mask[slot][hv] = mk;
+      for (int j = 0; j < ND; j ++) {
+        s_vf[slot][j][hv] = q[j];
+        if constexpr (FORM >= 2) s_vd[(slot * ND + j) * NH + hv] = tq[j];
+      }
+    }
+    // all quantised components fit in 32 bits: the integer test takes its cheaper multiplies -- same values, see cp_device.hpp; below
+    // 2^19, 2^16: the 3D fan decides signs in double precision, fan_of_corner3.  One word per slot and wavefront.
+    const unsigned bits = (__all(mine_narrow) ? 1u : 0u) | (__all(mine_mid) ? 2u : 0u) | (__all(mine_small) ? 4u : 0u);
+    if ((tl & 63) == 0) s_wflags[slot][tl >> 6] = bits;
+    TILE_STAMP(1);
+  };
+
+  bool have_next = false;                              // slot 1 holds `prev_*` staged under prev_factor
+  const double *prev_S = nullptr, *prev_V = nullptr;
+  double prev_factor = 0.0;
+  unsigned tested = 0, kept_sum = 0;
+
+  for (int si = 0; si < p.nsteps; si ++) {
+    const Fields &f = p.steps[si];                     // (in global memory, read with scalar loads: a copy would live in scratch -- the lambdas below take its address)
+    const int step = p.step + si;
+    const bool need_next = (f.scope_mask & FTKX_SCOPE_INTERVAL) != 0;
+    // (block-uniform) the slice the last step staged as its slice 1 is this step's slice 0, under the same factor: the slots swap
+    const bool reuse0 = have_next && f.S[0] == prev_S && f.V[0] == prev_V && f.factor == prev_factor;
+    __syncthreads();                                   // (the step before is through with the lists, the counters and the slots; si = 0: s_tab, s_stat)
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    if (tl < 2) s_cnt[tl] = 0;
+    if (tl == 2) s_nitems = 0;
+    if (reuse0) {
+      // slot 1 -> slot 0.  (Every lane moves the entries it stages itself -- the same hv below -- so its later stores to slot 1 are behind its
+      // loads here in program order; the other lanes read either slot only behind the barrier after the staging.)
+      for (int hv = tl; hv < NH; hv += kThreads) {
+        s_mask[0][hv] = s_mask[1][hv];
+        for (int j = 0; j < ND; j ++) {
+          s_vf[0][j][hv] = s_vf[1][j][hv];
+          if constexpr (FORM >= 2) s_vd[j * NH + hv] = s_vd[(ND + j) * NH + hv];
+        }
+      }
+      if ((tl & 63) == 0) s_wflags[0][tl >> 6] = s_wflags[1][tl >> 6];
+    } else stage_slice(f, 0, 0, tl);
+    if (need_next) {
+      if (!reuse0 && from_block) __syncthreads();      // (slice 0's vertices have been taken from s_s)
+      stage_slice(f, 1, 1, tl);
+    }
+    have_next = need_next; prev_S = f.S[1]; prev_V = f.V[1]; prev_factor = f.factor;
+    __syncthreads();
+    unsigned tile_bits = 7u;
+    for (int w = 0; w < kThreads / 64; w ++) { tile_bits &= s_wflags[0][w]; if (need_next) tile_bits &= s_wflags[1][w]; }
+    const bool narrow = (tile_bits & 1u) != 0;
+    TILE_STAMP(2);
+    const bool fan_int = FORM >= 1 && narrow && (ND == 2 || m.robust) && p.fan >= 1;
+    const bool fan_fp = FORM >= 2 && fan_int && p.fan >= 2 && (tile_bits & 2u);
+    const bool small = fan_fp && (tile_bits & 4u);
+    const unsigned char *mask0 = s_mask[0], *mask1 = s_mask[1];
+
+    // ---- cull: one corner per lane ----
+    bool keep_o = false, keep_i = false;
+    {
+      unsigned and0 = 0x3f, and1 = 0x3f;
+      for (int c = 0; c < (1 << ND); c ++) {
+        const int off = (c & 1) + HX * (((c >> 1) & 1) + HY * ((c >> 2) & 1));
+        // vertices no simplex may use (outside the domain, non-finite) are neutral for the sign argument
+        const unsigned m0 = mask0[hbase + off];
+        and0 &= (m0 & (kInvalid | kNonFinite)) ? 0x3fu : m0;
+        if (need_next) { const unsigned m1 = mask1[hbase + off]; and1 &= (m1 & (kInvalid | kNonFinite)) ? 0x3fu : m1; }
+      }
+      keep_o = in_core && (f.scope_mask & FTKX_SCOPE_ORDINAL) && !(p.cull && (and0 & 0x3f));
+      keep_i = in_core && need_next && !(p.cull && (and0 & and1 & 0x3f));
+    }
+    const unsigned long long ballot_o = __ballot(keep_o), ballot_i = __ballot(keep_i);
+    if ((tid & 63) == 0) kept_sum += (unsigned)__popcll(need_next ? ballot_i : ballot_o);
+    if constexpr (FORM >= 1) {
+      // ---- test, one corner per lane (fan_of_corner3 / fan_of_corner2) ----
+      if (fan_int && p.fan != 9) {
+        u64 hits = 0, unsure = 0;
+        constexpr int NV = 1 << N;                                  // vertices of the corner's space-time hypercube
+        int corner[N];
+        corner[0] = origin[0] + cx; corner[1] = origin[1] + cy;
+        if (ND == 3) corner[2] = origin[2] + cz;
+        corner[ND] = f.t;
+        // (vertex v of the corner's hypercube: bit d = one step along axis d, bit ND = the next slice)
+        auto offset = [](int v) constexpr { return (v & 1) + HX * (((v >> 1) & 1) + (ND == 3 ? HY * ((v >> 2) & 1) : 0)); };
+        if (ballot_o | ballot_i) {                                 // (a wavefront nothing of which survived its cull: nothing to do)
+          unsigned inv = 0, pos[3] = {0, 0, 0}, neg[3] = {0, 0, 0};
+#pragma unroll
+          for (int v = 0; v < NV; v ++) {
+            unsigned mk = kInvalid;
+            if ((v >> ND) == 0 || need_next) mk = ((v >> ND) ? mask1 : mask0)[hbase + offset(v)];
+            if (mk & (kInvalid | kNonFinite)) inv |= 1u << v;
+#pragma unroll
+            for (int c = 0; c < ND; c ++) { if (mk & (1u << c)) pos[c] |= 1u << v; if (mk & (8u << c)) neg[c] |= 1u << v; }
+          }
+          // (component c of vertex v; slice 1 of an ordinal-only request is not staged: whatever is read there only enters simplices that
+          // `inv` switches off)
+          auto run_fan = [&](const int hb_) __attribute__((always_inline)) -> fan_result {
+            if (FORM >= 2 && fan_fp) {
+              const double *base = s_vd + hb_;
+              auto at = [&](auto V, int c) __attribute__((always_inline)) { constexpr int v = decltype(V)::value; return base[((v >> ND) * ND + c) * NH + offset(v)]; };
+              if constexpr (ND == 3) return fan_of_corner3<double>(at, inv, pos, neg, keep_o, keep_i, p.cull, small ? 0.5 : 4096.0);
+              else return fan_of_corner2<double>(at, inv, pos, neg, keep_o, keep_i, p.cull, 0.5);
+            } else {
+              const i64 *base = &s_vf[0][0][0] + hb_;
+              auto at = [&](auto V, int c) __attribute__((always_inline)) { constexpr int v = decltype(V)::value; return (int)base[((v >> ND) * ND + c) * NH + offset(v)]; };
+              if constexpr (ND == 3) return fan_of_corner3<int>(at, inv, pos, neg, keep_o, keep_i, p.cull, 0.0);
+              else return fan_of_corner2<int>(at, inv, pos, neg, keep_o, keep_i, p.cull, 0.0);
+            }
+          };
+          fan_result fr;
+          if constexpr (PROBE) {
+            for (int rep_ = 0; rep_ < p.repeat; rep_ ++) { int hb_ = hbase; asm volatile("" : "+v"(hb_)); fr = run_fan(hb_); }
+          } else fr = run_fan(hbase);
+          tested += fr.tested;
+          hits = (u64)fr.hits[0] | ((u64)fr.hits[1] << 32); unsure = (u64)fr.unsure[0] | ((u64)fr.unsure[1] << 32);
+        }
+        TILE_STAMP(3);
+        // A value that is zero / INT64_MIN (fp64: not clear of zero): the integer test and the literal cascade on the vertices as staged.
+        // One simplex in thousands, but a long computation: the (lane, type) pairs of the whole tile go on a list and are dealt to the lanes
+        // again (a lane that walked its own would hold its wavefront for each of them).
+        auto corner_of = [&](int lane_tid, int (&lc)[N]) -> int {
+          const int lx = lane_tid % cfg::TX, ly = (lane_tid / cfg::TX) % cfg::TY, lz = lane_tid / (cfg::TX * cfg::TY);
+          lc[0] = origin[0] + lx; lc[1] = origin[1] + ly;
+          if (ND == 3) lc[2] = origin[2] + lz;
+          lc[ND] = f.t;
+          return lx + HX * (ly + HY * lz);
+        };
+        auto resolve = [&](int lane_tid, int type) -> bool {
+          int lc[N];
+          const int hb = corner_of(lane_tid, lc);
+          const unsigned tab = s_tab[type];
+          u64 X[N][ND]; int ids[N];
+          for (int i = 0; i < N; i ++) {
+            const unsigned vm = (tab >> (8 * i)) & 0xffu;
+            const int hidx = hb + (vm & 1) + HX * (((vm >> 1) & 1) + (ND == 3 ? HY * ((vm >> 2) & 1) : 0));
+            for (int j = 0; j < ND; j ++) X[i][j] = (u64)s_vf[(vm >> ND) & 1][j][hidx];
+            ids[i] = vertex_id<ND>(m, lc, vm);
+          }
+          int r;
+          if constexpr (ND == 2) r = origin_in_simplex2_try(X, true); else r = origin_in_simplex3_try(X, true);
+          return r < 0 ? sos_origin_in_simplex_resolved<ND>(X, ids) : r != 0;
+        };
+        for (;;) {                                                 // (one round unless the tile has more than kItems of them)
+          while (__any(unsure != 0)) {                             // append (wave-uniform trip count)
+            const bool have = unsure != 0;
+            const int type = have ? __ffsll((long long)unsure) - 1 : 0;
+            const unsigned long long hb = __ballot(have);
+            const int leader = __ffsll((long long)hb) - 1;
+            unsigned base = 0;
+            if ((tid & 63) == leader) base = atomicAdd(&s_nitems, (unsigned)__popcll(hb));
+            base = __shfl(base, leader);
+            const unsigned slot = base + (unsigned)__popcll(hb & ((1ull << (tid & 63)) - 1ull));
+            if (have && slot < (unsigned)kItems) { s_items[slot] = (unsigned short)((tid << 6) | type); unsure &= unsure - 1; }
+            if (base + (unsigned)__popcll(hb) > (unsigned)kItems) break;   // (the list is full -- the count says so to everybody: what is left waits for the next round)
+          }
+          __syncthreads();
+          const unsigned appended = s_nitems, nitems = appended < (unsigned)kItems ? appended : (unsigned)kItems;
+          for (unsigned base = 0; base < nitems; base += kThreads) {
+            const unsigned it = base + tid;
+            bool hit = false;
+            u64 desc = 0;
+            if (it < nitems) {
+              const unsigned item = s_items[it];
+              const int lane_tid = (int)(item >> 6), type = (int)(item & 63u);
+              hit = resolve(lane_tid, type);
+              int lc[N];
+              (void)corner_of(lane_tid, lc);
+              desc = core_linear<ND>(m, lc) | ((u64)type << kPassTypeShift) | ((u64)step << kPassStepShift);
+            }
+            emit_pass(m, hit, desc);
+          }
+          if (appended <= (unsigned)kItems) break;                 // (block-uniform: everybody read the same count)
+          __syncthreads();
+          if (tid == 0) s_nitems = 0;
+          __syncthreads();
+        }
+        const u64 lin = in_core ? core_linear<ND>(m, corner) : 0ull;
+        while (__any(hits != 0)) {
+          const bool hit = hits != 0;
+          const int type = hit ? __ffsll((long long)hits) - 1 : 0;
+          hits &= hits - 1;
+          emit_pass(m, hit, lin | ((u64)type << kPassTypeShift) | ((u64)step << kPassStepShift));
+        }
+      }
+    }
+    // the surviving corners as lists, for the (corner, type) pairs below
+    const bool pairs = !(fan_int || p.fan == 9);                 // (block-uniform)
+    if (pairs) {
+      const int lane = tid & 63;
+      const unsigned long long below = (1ull << lane) - 1ull;
+      unsigned base_o = 0, base_i = 0;
+      if (lane == 0) {
+        if (ballot_o) base_o = atomicAdd(&s_cnt[0], (unsigned)__popcll(ballot_o));
+        if (ballot_i) base_i = atomicAdd(&s_cnt[1], (unsigned)__popcll(ballot_i));
+      }
+      base_o = __shfl(base_o, 0);
+      base_i = __shfl(base_i, 0);
+      if (keep_o) s_list[0][base_o + __popcll(ballot_o & below)] = (unsigned short)tid;
+      if (keep_i) s_list[1][base_i + __popcll(ballot_i & below)] = (unsigned short)tid;
+      __syncthreads();
+    }
+    const unsigned n_o = pairs ? s_cnt[0] : 0u, n_i = pairs ? s_cnt[1] : 0u;
+    // ---- test: (corner, type) pairs over all lanes ----
+    const unsigned items_o = n_o * NORD, total = items_o + n_i * NINT;
+    for (unsigned base = 0; base < total; base += kThreads) {   // wave-uniform trip count: the ballot in emit_hits stays convergent
+      const unsigned w = base + tid;
+      bool hit = false;
+      u64 desc = 0;
+      if (w < total) {
+        const bool ordinal = w < items_o;
+        const unsigned wl = ordinal ? w : w - items_o;
+        const unsigned ci = ordinal ? wl / NORD : wl / NINT;
+        const unsigned it = ordinal ? wl % NORD : wl % NINT;
+        const int type = ordinal ? fan.ord_types[it] : fan.int_types[it];
+        const int ct = s_list[ordinal ? 0 : 1][ci];
+        const int ccx = ct % cfg::TX, ccy = (ct / cfg::TX) % cfg::TY, ccz = ct / (cfg::TX * cfg::TY);
+        const int hb = ccx + HX * (ccy + HY * ccz);
         const unsigned tab = s_tab[type];
-        u64 X[N][ND]; int ids[N];
+        unsigned char flags[N];
+        u64 X[N][ND];
         for (int i = 0; i < N; i ++) {
           const unsigned vm = (tab >> (8 * i)) & 0xffu;
-          const int hidx = hb + (vm & 1) + HX * (((vm >> 1) & 1) + (ND == 3 ? HY * ((vm >> 2) & 1) : 0));
-          for (int j = 0; j < ND; j ++) X[i][j] = (u64)s_vf[(vm >> ND) & 1][j][hidx];
-          ids[i] = vertex_id<ND>(m, lc, vm);
+          const int hidx = hb + (vm & 1) + HX * (((vm >> 1) & 1) + ((ND == 3) ? HY * ((vm >> 2) & 1) : 0));
+          const int hsl = (vm >> ND) & 1;
+          flags[i] = s_mask[hsl][hidx];
+          for (int j = 0; j < ND; j ++) X[i][j] = (u64)s_vf[hsl][j][hidx];
         }
-        int r;
-        if constexpr (ND == 2) r = origin_in_simplex2_try(X, true); else r = origin_in_simplex3_try(X, true);
-        return r < 0 ? sos_origin_in_simplex_resolved<ND>(X, ids) : r != 0;
-      };
-      for (;;) {                                                 // (one round unless the tile has more than kItems of them)
-        while (__any(unsure != 0)) {                             // append (wave-uniform trip count)
-          const bool have = unsure != 0;
-          const int type = have ? __ffsll((long long)unsure) - 1 : 0;
-          const unsigned long long hb = __ballot(have);
-          const int leader = __ffsll((long long)hb) - 1;
-          unsigned base = 0;
-          if ((tid & 63) == leader) base = atomicAdd(&s_nitems, (unsigned)__popcll(hb));
-          base = __shfl(base, leader);
-          const unsigned slot = base + (unsigned)__popcll(hb & ((1ull << (tid & 63)) - 1ull));
-          if (have && slot < (unsigned)kItems) { s_items[slot] = (unsigned short)((tid << 6) | type); unsure &= unsure - 1; }
-          if (base + (unsigned)__popcll(hb) > (unsigned)kItems) break;   // (the list is full -- the count says so to everybody: what is left waits for the next round)
-        }
-        __syncthreads();
-        const unsigned appended = s_nitems, nitems = appended < (unsigned)kItems ? appended : (unsigned)kItems;
-        for (unsigned base = 0; base < nitems; base += kThreads) {
-          const unsigned it = base + tid;
-          bool hit = false;
-          u64 desc = 0;
-          if (it < nitems) {
-            const unsigned item = s_items[it];
-            const int lane_tid = (int)(item >> 6), type = (int)(item & 63u);
-            hit = resolve(lane_tid, type);
-            int lc[N];
-            (void)corner_of(lane_tid, lc);
-            desc = core_linear<ND>(m, lc) | ((u64)type << kPassTypeShift) | ((u64)p.step << kPassStepShift);
-          }
-          emit_pass(m, hit, desc);
-        }
-        if (appended <= (unsigned)kItems) break;                 // (block-uniform: everybody read the same count)
-        __syncthreads();
-        if (tid == 0) s_nitems = 0;
-        __syncthreads();
+        int corner[N];
+        corner[0] = origin[0] + ccx; corner[1] = origin[1] + ccy;
+        if (ND == 3) corner[2] = origin[2] + ccz;
+        corner[ND] = f.t;
+        int ids[N]; double mu[N]; bool presolved;
+        hit = simplex_inside<ND>(m, f, p.cull, corner, tab, flags, X, tested, ids, mu, &presolved, narrow);
+        desc = core_linear<ND>(m, corner) | ((u64)type << kPassTypeShift) | ((u64)step << kPassStepShift);
       }
-      const u64 lin = in_core ? core_linear<ND>(m, corner) : 0ull;
-      while (__any(hits != 0)) {
-        const bool hit = hits != 0;
-        const int type = hit ? __ffsll((long long)hits) - 1 : 0;
-        hits &= hits - 1;
-        emit_pass(m, hit, lin | ((u64)type << kPassTypeShift) | ((u64)p.step << kPassStepShift));
-      }
+      emit_pass(m, hit, desc);
     }
+    TILE_STAMP(4);
   }
-  // the surviving corners as lists, for the (corner, type) pairs below
-  const bool pairs = !(fan_int || p.fan == 9);                 // (block-uniform)
-  if (pairs) {
-    const int lane = tid & 63;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    unsigned base_o = 0, base_i = 0;
-    if (lane == 0) {
-      if (ballot_o) base_o = atomicAdd(&s_cnt[0], (unsigned)__popcll(ballot_o));
-      if (ballot_i) base_i = atomicAdd(&s_cnt[1], (unsigned)__popcll(ballot_i));
-    }
-    base_o = __shfl(base_o, 0);
-    base_i = __shfl(base_i, 0);
-    if (keep_o) s_list[0][base_o + __popcll(ballot_o & below)] = (unsigned short)tid;
-    if (keep_i) s_list[1][base_i + __popcll(ballot_i & below)] = (unsigned short)tid;
-    __syncthreads();
-  }
-  const unsigned n_o = pairs ? s_cnt[0] : 0u, n_i = pairs ? s_cnt[1] : 0u;
-  // ---- test: (corner, type) pairs over all lanes ----
-  const unsigned items_o = n_o * NORD, total = items_o + n_i * NINT;
-  for (unsigned base = 0; base < total; base += kThreads) {   // wave-uniform trip count: the ballot in emit_hits stays convergent
-    const unsigned w = base + tid;
-    bool hit = false;
-    u64 desc = 0;
-    if (w < total) {
-      const bool ordinal = w < items_o;
-      const unsigned wl = ordinal ? w : w - items_o;
-      const unsigned ci = ordinal ? wl / NORD : wl / NINT;
-      const unsigned it = ordinal ? wl % NORD : wl % NINT;
-      const int type = ordinal ? fan.ord_types[it] : fan.int_types[it];
-      const int ct = s_list[ordinal ? 0 : 1][ci];
-      const int ccx = ct % cfg::TX, ccy = (ct / cfg::TX) % cfg::TY, ccz = ct / (cfg::TX * cfg::TY);
-      const int hb = ccx + HX * (ccy + HY * ccz);
-      const unsigned tab = s_tab[type];
-      unsigned char flags[N];
-      u64 X[N][ND];
-      for (int i = 0; i < N; i ++) {
-        const unsigned vm = (tab >> (8 * i)) & 0xffu;
-        const int hidx = hb + (vm & 1) + HX * (((vm >> 1) & 1) + ((ND == 3) ? HY * ((vm >> 2) & 1) : 0));
-        const int hsl = (vm >> ND) & 1;
-        flags[i] = s_mask[hsl][hidx];
-        for (int j = 0; j < ND; j ++) X[i][j] = (u64)s_vf[hsl][j][hidx];
-      }
-      int corner[N];
-      corner[0] = origin[0] + ccx; corner[1] = origin[1] + ccy;
-      if (ND == 3) corner[2] = origin[2] + ccz;
-      corner[ND] = f.t;
-      int ids[N]; double mu[N]; bool presolved;
-      hit = simplex_inside<ND>(m, f, p.cull, corner, tab, flags, X, tested, ids, mu, &presolved, narrow);
-      desc = core_linear<ND>(m, corner) | ((u64)type << kPassTypeShift) | ((u64)p.step << kPassStepShift);
-    }
-    emit_pass(m, hit, desc);
-  }
-  TILE_STAMP(4);
   {
-    // statistics: one atomic per counter and workgroup (same-address atomics serialise chip-wide)
+    // statistics, once per workgroup: one atomic per counter (same-address atomics serialise chip-wide)
     unsigned t_sum = tested;
     for (int o = 32; o > 0; o >>= 1) t_sum += __shfl_down(t_sum, o);
     if ((tid & 63) == 0) {
       if (t_sum) atomicAdd(&s_stat[0], t_sum);
-      const unsigned kept = (unsigned)__popcll(need_next ? ballot_i : ballot_o);
-      if (kept) atomicAdd(&s_stat[1], kept);
+      if (kept_sum) atomicAdd(&s_stat[1], kept_sum);
     }
     __syncthreads();
     u64 *slot = p.stats + 2u * (blockIdx.x & 255u);
@@ -578,7 +622,7 @@ __global__ __launch_bounds__(kThreads, FORM == 0 ? 1 : FTKX_FAN_WAVES) void tile
   if ((tid & 63) == 0) {
     unsigned long long *g = g_tile_stamps + (blockIdx.x % 512u) * 8;
     for (int k = 0; k < 6; k ++) atomicAdd(&g[k], phase_[k]);
-    atomicAdd(&g[7], 1ull);
+    atomicAdd(&g[7], (unsigned long long)p.nsteps);
   }
 #endif
 }
