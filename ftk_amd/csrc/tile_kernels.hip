@@ -250,6 +250,10 @@ __device__ __forceinline__ unsigned char stage_value(const double *v, double fac
 // a step stages ONE slice instead of two (round 5: both, every step: 14.5 k of a wavefront's 34.6 k cycles), and the statistics leave once
 // per workgroup instead of once per step.  The block of S a slice's gradients are taken from is loaded by rows -- 13 rows of 19 values per
 // round over 247 lanes, row and column fixed per lane -- instead of by a linear index that every round took apart again.
+// Tried on top of this in round 6 and not kept: the NEXT step's block of S on its way while the fan runs.  As LDS-DMA (buffer_load ... lds
+// behind the staging barrier, no registers): the compiler puts a vmcnt(0) in front of the next LDS read it generates, which is the fan's
+// first -- 25.7 -> 30.6 ms on 256^3 x 16.  As plain loads issued behind the fan and committed at the top of the next step: 27.3 ms.  What
+// a step waits for is not that round trip.
 // PROBE (TileParams::repeat > 1: ftkx_debug_tile_repeat, bench.py's int-VALU yardstick): the fan phase alone is run that many times on the
 // staged tile -- the rate of the predicate arithmetic without staging, lists and records.
 template <int ND, int FORM, bool PROBE = false>

@@ -446,6 +446,40 @@ def test_tile_kernel_forms_agree(gpu, monkeypatch, scale):
     _same(culled[0], got["0"][0])
 
 
+@pytest.mark.parametrize("nd", [2, 3])
+def test_tile_kernel_walking_the_steps_equals_a_launch_per_step(gpu, monkeypatch, nd):
+    """Round 6: one tile-kernel launch covers the consecutive tile requests of a batch; a workgroup keeps its tile for all of them and the
+    slice two consecutive steps share is staged once (moved from LDS slot 1 to slot 0).  FTKX_TILE_WALK=0 is the old way, a launch per
+    step with both slices staged.  Series whose factor changes half way (the shared slice is then staged again under the new factor), with
+    planted zeros and a NaN, all three forms: equal records, factors and counts -- and equal to the culled pass."""
+    rng = np.random.default_rng(31 + nd)
+    dims, nt = ((40, 33, 21), 6) if nd == 3 else ((70, 41), 7)
+    steps = []
+    for t in range(nt):
+        K = 16.0 if t < 3 else 4096.0        # values on a grid: the gradient's smallest non-zero magnitude is 1 / 2K -- nbits 8, then 13
+        f = np.round(rng.standard_normal(tuple(reversed(dims))) * K) / K
+        if nd == 3:
+            f[10, 11, 12] = np.nan
+        else:
+            f[15, 17] = np.nan
+        steps.append(f)
+    got = {}
+    for walk in ("1", "0"):
+        for fan in ("0", "1", "2"):
+            monkeypatch.setenv("FTKX_TILE_WALK", walk); monkeypatch.setenv("FTKX_TILE_FAN", fan)
+            got[walk, fan] = _run(gpu, None, dims, nt, steps=steps, exact_only=True)
+    monkeypatch.delenv("FTKX_TILE_WALK"); monkeypatch.delenv("FTKX_TILE_FAN")
+    ref = got["0", "0"]
+    assert len(ref[0]) > 50
+    if nd == 3:
+        assert len(set(int(v) for v in ref[2])) > 1, "the factor is meant to change inside the series (the shared slice is staged again)"
+    for key, g in got.items():
+        _same(ref[0], g[0])
+        assert ref[2] == g[2] and ref[1]["simplices_tested"] == g[1]["simplices_tested"], key
+    culled = _run(gpu, None, dims, nt, steps=steps)
+    _same(culled[0], ref[0])
+
+
 def test_cull_ahead_changes_nothing_but_the_schedule(gpu):
     """ftkx_sweep_announce: the cull queued behind the mask kernel, before the factors exist.  Same records and statistics as the
     plain order -- when the announcement is what gets swept, when it is not (other scopes, other steps, a subset: the list is
