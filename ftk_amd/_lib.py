@@ -95,7 +95,7 @@ EXPORTS = [
     "ftkx_tracker_get_critical_points", "ftkx_tracker_get_scaling", "ftkx_tracker_get_stats",
     "ftkx_tracker_finalize", "ftkx_tracker_num_curves", "ftkx_tracker_get_curves",
     # include/ftkx_slab.h
-    "ftkx_slab_range", "ftkx_slab_owner", "ftkx_slab_create", "ftkx_slab_create_custom", "ftkx_slab_create_rccl", "ftkx_slab_destroy", "ftkx_slab_submit", "ftkx_slab_complete",
+    "ftkx_slab_range", "ftkx_slab_owner", "ftkx_slab_create", "ftkx_slab_create_custom", "ftkx_slab_create_rccl", "ftkx_slab_destroy", "ftkx_slab_set_periodic", "ftkx_slab_submit", "ftkx_slab_complete",
     "ftkx_slab_gather_records", "ftkx_slab_get_info", "ftkx_slab_last_error", "ftkx_rccl_unique_id", "ftkx_rccl_comm_create", "ftkx_rccl_comm_destroy", "ftkx_rccl_version",
     "ftkx_slab_transport_rccl", "ftkx_upload", "ftkx_download", "ftkx_slab_hub_create", "ftkx_slab_hub_destroy", "ftkx_slab_create_local", "ftkx_slab_hub_abort",
 ]
@@ -240,6 +240,7 @@ def load():
     L.ftkx_slab_create_custom.argtypes = [C.POINTER(SlabBackend), C.c_int, C.c_int, C.c_int, C.POINTER(SlabTransport), C.POINTER(vp)]
     L.ftkx_slab_create_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(vp)]
     L.ftkx_slab_destroy.argtypes = [vp]; L.ftkx_slab_destroy.restype = None
+    L.ftkx_slab_set_periodic.argtypes = [vp, C.c_int]
     L.ftkx_slab_submit.argtypes = [vp, C.POINTER(C.c_double)]
     L.ftkx_slab_complete.argtypes = [vp, C.POINTER(C.c_double), vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ftkx_slab_gather_records.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]

@@ -1048,7 +1048,7 @@ size_t dist_cells_cap(const ftkx_ctx *c)
   // cells a request carries: the reply has a FIXED size (the owner never sees the count on the host) -- at most 1 MiB of patches
   // (~15 us of one xGMI link) and at most a sixteenth of the slice it stands for
   const size_t pd = ftkx_patch_doubles(c) * sizeof(double);
-  static const long forced = getenv("FTKX_DIST_CELLS") ? atol(getenv("FTKX_DIST_CELLS")) : 0;      // (tests: a small request forces the whole-slice way)
+  const long forced = getenv("FTKX_DIST_CELLS") ? atol(getenv("FTKX_DIST_CELLS")) : 0;      // (tests: a small request forces the whole-slice way, a large one keeps small meshes compact; read by every context afresh)
   if (forced > 0) return (size_t)forced;
   const size_t slice_bytes = n_vertices(c) * (size_t)(c->scalar_mode == 1 ? 1 : c->nd) * sizeof(double);
   return pd ? std::max<size_t>(16, std::min<size_t>(4096, std::min<size_t>((size_t)1 << 20, slice_bytes / 16) / pd)) : 0;
@@ -1073,7 +1073,8 @@ int ftkx_series_dist_begin(ftkx_ctx *c, const int *ts, const int *scopes, int n,
   if (c->sr_open >= 2) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: two passes are open, complete one first");      // (slab passes: two, as their callers keep)
   if (rank < 0 || rank >= nranks) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: rank %d of %d", rank, nranks);
   if (!(*running_resolution > 0)) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: the running resolution must be positive (DBL_MAX: none yet)");
-  if (halo && (upper <= rank || upper >= nranks || !(scopes[n - 1] & FTKX_SCOPE_INTERVAL))) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: the upper neighbour must be a later rank, and the last step an interval sweep");
+  // (upper <= rank: a series that is periodic in time -- the slice behind the last slab is the first slab's first, include/ftkx_slab.h)
+  if (halo && (upper >= nranks || !(scopes[n - 1] & FTKX_SCOPE_INTERVAL))) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: the upper neighbour must be a rank of the series, and the last step an interval sweep");
   if (c->scalar_mode < 0) return fail(c, FTKX_E_INVALID, "ftkx_series_dist_begin: push this rank's slices first");
   c->ahead.clear(); c->announced.clear();
   HIP_TRY(c, hipSetDevice(c->device));

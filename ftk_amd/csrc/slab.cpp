@@ -67,6 +67,7 @@ struct ftkx_slab {
   // a mesh without summarised masks (rows that are not a multiple of 8 vertices: the generic mask kernel) has no compact halo: such a slab
   // is swept the plain way -- exact reductions all_gathered, the neighbour's first slice as a whole, ftkx_sweep_series -- inside submit
   bool plain = false;
+  bool periodic = false;                  // the series is periodic in time: slice nt is slice 0 again (ftkx_slab_set_periodic)
   std::deque<Outcome> plain_out;
   std::string err;
 };
@@ -274,6 +275,19 @@ int submit_plain(ftkx_slab *s, Set &b, double run)
   return FTKX_OK;
 }
 
+// this rank's steps and neighbours.  Periodic: slice nt is slice 0 again -- the last timestep's sweep is an interval sweep too, its halo is
+// the first slice of the rank that owns timestep 0, which may be this rank itself (one rank: its own lower and upper neighbour)
+void layout(ftkx_slab *s)
+{
+  const int nt = s->nt, nranks = s->nranks;
+  s->ts.clear(); s->scopes.clear();
+  for (int t = s->t0; t < s->t1; t ++) { s->ts.push_back(t); s->scopes.push_back((t + 1 < nt || s->periodic) ? FTKX_SCOPE_BOTH : FTKX_SCOPE_ORDINAL); }
+  const bool own = s->t1 > s->t0;
+  s->t_halo = (own && (s->t1 < nt || s->periodic)) ? s->t1 : -1;
+  s->lower = (own && s->t0 > 0) ? ftkx_slab_owner(s->t0 - 1, nt, nranks) : (own && s->periodic) ? ftkx_slab_owner(nt - 1, nt, nranks) : -1;   // the rank whose last interval sweep reads OUR first slice
+  s->upper = s->t_halo < 0 ? -1 : s->t1 < nt ? ftkx_slab_owner(s->t1, nt, nranks) : ftkx_slab_owner(0, nt, nranks);
+}
+
 }  // namespace
 
 extern "C" {
@@ -300,12 +314,17 @@ int ftkx_slab_create_custom(const ftkx_slab_backend *backend, int nt, int rank, 
   s->be = *backend; s->tr = *tr;
   s->nt = nt; s->rank = rank; s->nranks = nranks;
   ftkx_slab_range(nt, nranks, rank, &s->t0, &s->t1);
-  for (int t = s->t0; t < s->t1; t ++) { s->ts.push_back(t); s->scopes.push_back(t + 1 < nt ? FTKX_SCOPE_BOTH : FTKX_SCOPE_ORDINAL); }
-  const bool own = s->t1 > s->t0;
-  s->t_halo = (own && s->t1 < nt) ? s->t1 : -1;
-  s->lower = (own && s->t0 > 0) ? ftkx_slab_owner(s->t0 - 1, nt, nranks) : -1;      // the rank whose last interval sweep reads OUR first slice
-  s->upper = s->t_halo >= 0 ? ftkx_slab_owner(s->t1, nt, nranks) : -1;
+  layout(s);
   *out = s;
+  return FTKX_OK;
+}
+
+int ftkx_slab_set_periodic(ftkx_slab *s, int on)
+{
+  if (!s) return FTKX_E_INVALID;
+  if (s->sized || !s->open.empty()) return sfail(s, FTKX_E_INVALID, "ftkx_slab_set_periodic: before the first pass");
+  s->periodic = on != 0;
+  layout(s);
   return FTKX_OK;
 }
 

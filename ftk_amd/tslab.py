@@ -309,8 +309,8 @@ class SlabSeries:
         return self
 
     @classmethod
-    def rccl(cls, ctx, nt, rank, world, comm, side_comm=None):
-        """over a caller's ncclComm_t (ftkx_slab_create_rccl)"""
+    def rccl(cls, ctx, nt, rank, world, comm, side_comm=None, periodic=False):
+        """over a caller's ncclComm_t (ftkx_slab_create_rccl).  periodic: slice nt is slice 0 again (ftkx_slab_set_periodic)"""
         import ctypes as C
         from . import _lib
         self = object.__new__(cls)
@@ -320,6 +320,8 @@ class SlabSeries:
         self.own = list(range(*slab_range(nt, world, rank)))
         self._h = C.c_void_p()
         _lib.check(self._L.ftkx_slab_create_rccl(ctx._h, nt, rank, world, comm, side_comm, C.byref(self._h)))
+        if periodic:
+            _lib.check(self._L.ftkx_slab_set_periodic(self._h, 1))
         self._base = (0, 0, 0)
         self.last_path, self.last_asked = (0, 0), 0
         return self

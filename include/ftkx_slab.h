@@ -87,9 +87,17 @@ int ftkx_slab_create(ftkx_ctx *ctx, int nt, int rank, int nranks, const ftkx_sla
 int ftkx_slab_create_custom(const ftkx_slab_backend *backend, int nt, int rank, int nranks, const ftkx_slab_transport *tr, ftkx_slab **out);
 /* RCCL: `comm` is the caller's ncclComm_t over the ranks (rank / nranks must be its); messages are ncclAllGather and grouped ncclSend /
  * ncclRecv on the context's stream (the masks: on the slab's side stream).  side_comm (nullable): a second communicator for the side
- * stream's traffic -- with one communicator RCCL runs the masks' message and the all_gather one after the other, in the order issued. */
+ * stream's traffic -- with one communicator RCCL runs the masks' message and the all_gather one after the other, in the order issued.
+ * Two communicators on one device run CONCURRENTLY: that needs an RCCL that makes progress on both (its kernels co-resident; every rank
+ * issues on both in the same order, which the protocol does) -- a rank without neighbours takes no part in the side exchange. */
 int ftkx_slab_create_rccl(ftkx_ctx *ctx, int nt, int rank, int nranks, void *comm, void *side_comm, ftkx_slab **out);
 void ftkx_slab_destroy(ftkx_slab *s);
+/* A series that is PERIODIC in time: slice nt is slice 0 again.  The last timestep's sweep is then an interval sweep as well, [nt - 1, nt], and
+ * the rank that owns it has the owner of timestep 0 for its upper neighbour -- with one rank, itself: it sends the masks of its first slice,
+ * its request and its patches to itself, over the same transport calls (RCCL: grouped ncclSend / ncclRecv with its own rank as the peer).
+ * The records of that last sweep carry t in [nt - 1, nt].  Call before the first pass.  (Also how a ONE-GPU box executes every message of
+ * the slab protocol over RCCL, the whole-slice recovery included: tests/test_gpu_slab_host.py.) */
+int ftkx_slab_set_periodic(ftkx_slab *s, int on);
 
 /* queues one pass over this rank's slab.  running_resolution: the running minimum before the SERIES (NULL: none yet = DBL_MAX); the
  * minimum before this slab comes from the lower ranks' contributions, on the device. */

@@ -184,6 +184,69 @@ def test_rccl_with_one_rank_equals_the_plain_pass(gpu):
             torch.cuda.set_stream(torch.cuda.default_stream())
 
 
+@pytest.mark.parametrize("recover", [False, True], ids=["compact_halo", "whole_slice_recovery"])
+def test_rccl_point_to_point_on_one_gpu_by_a_series_that_is_periodic_in_time(gpu, recover, monkeypatch):
+    """Every message of the slab protocol over RCCL on ONE GPU: a series that is periodic in time (ftkx_slab_set_periodic: slice nt is slice 0
+    again) makes a single rank its own lower and upper neighbour -- the masks of its first slice go out over the SIDE communicator on the side
+    stream (ncclSend / ncclRecv with its own rank as the peer) next to the ncclAllGather on the main one, the request and the patches follow
+    on the context's stream, and with FTKX_DIST_CELLS=1 the request cannot hold the surviving cells: both sides learn it from the same number
+    and the slice itself is sent (the whole-slice recovery), again over RCCL.  Result: the records, factors and running minimum of the plain
+    pass over nt + 1 slices whose last one is the first again.  (What a box with one GPU can execute of round 5's open item: slab_rccl.cpp's
+    neighbour branches, side_comm included, had never run.)"""
+    import torch
+    from ftk_amd import tslab, _lib
+    L = _lib.load()
+    # (the request's capacity: 1 cell forces the recovery; 4096 keeps these small meshes -- whose own capacity is 16 cells -- on the compact way)
+    monkeypatch.setenv("FTKX_DIST_CELLS", "1" if recover else "4096")
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    for nd, nv, dims, nt, kind in ((3, 1, (40, 33, 17), 5, "smooth"), (2, 1, (136, 60), 6, "rough"), (2, 2, (64, 40), 4, "smooth")):
+        sp = tuple(reversed(dims))
+        # (periodic AND smooth in time: a field and a small periodic part -- the wrap-around interval is an interval like any other)
+        two = _field(rng, (2,) + sp, kind) if nv == 1 else _vector_series(rng, 2, sp, kind)
+        steps = [np.ascontiguousarray(two[0] + 0.03 * np.cos(2 * np.pi * t / nt) * two[1]) for t in range(nt)]
+        st = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(st)
+        try:
+            # the plain pass: nt + 1 slices, the last one the first again, every step an interval sweep
+            one = _make_ctx(gpu, nd, nv, dims, st)
+            for t in range(nt + 1):
+                (one.push_scalar_slice if nv == 1 else one.push_slice)(t, steps[t % nt])
+            want, wf, wrun = one.sweep_series(range(nt), [gpu.SCOPE_BOTH] * nt, copy=True)
+            one.close()
+            wf = [int(v) for v in wf]
+            assert len(want) > 0
+            ctx = _make_ctx(gpu, nd, nv, dims, st)
+            for t in range(nt):
+                (ctx.push_scalar_slice if nv == 1 else ctx.push_slice)(t, steps[t])
+            comms = []
+            for _ in range(2):
+                raw = (C.c_ubyte * 128)()
+                _lib.check(L.ftkx_rccl_unique_id(raw))
+                comm = C.c_void_p()
+                _lib.check(L.ftkx_rccl_comm_create(raw, 0, 1, 0, C.byref(comm)))
+                comms.append(comm)
+            slab = tslab.SlabSeries.rccl(ctx, nt, 0, 1, comms[0], side_comm=comms[1], periodic=True)
+            slab.submit(); slab.submit()
+            a = slab.complete(copy=True)
+            slab.submit()
+            b = slab.complete(copy=True)
+            c = slab.complete(copy=True)
+            for recs, f, run in (a, b, c):
+                assert [int(v) for v in f] == wf and run == wrun, (nd, nv, dims, kind, [int(v) for v in f], wf)
+                assert recs.tobytes() == np.ascontiguousarray(want).tobytes(), (nd, nv, dims, kind, len(recs), len(want))
+            if recover:
+                assert slab.fallbacks >= 1, "FTKX_DIST_CELLS=1 was meant to force the whole-slice recovery"
+            else:
+                assert slab.fallbacks == 0 and slab.bytes_sent > 0
+            slab.close()
+            for comm in comms:
+                L.ftkx_rccl_comm_destroy(comm)
+            ctx.close()
+        finally:
+            torch.cuda.set_stream(torch.cuda.default_stream())
+
+
 def _make_tracker(gpu, nd, nv, D):
     T = gpu.CriticalPointTracker2DRegular if nd == 2 else gpu.CriticalPointTracker3DRegular
     tr = T()

@@ -43,6 +43,41 @@ def test_simplex_count_matches_baseline_table():
     assert tslab.count_simplices(2, (2048, 1024), 128, scalar_input=False) == 2091012 * (2 * 128 + 10 * 127)
 
 
+def test_neighbours_of_a_series_that_is_periodic_in_time():
+    """ftkx_slab_set_periodic (include/ftkx_slab.h): slice nt is slice 0 again -- the rank that owns the last timestep has the owner of
+    timestep 0 for its upper neighbour, which has it for its lower one; with one rank both are the rank itself; ranks in between keep
+    their neighbours; empty slabs have none.  Checked on the C++ host's own bookkeeping (no pass is queued: no GPU)."""
+    import ctypes as C
+    from ftk_amd import _lib
+    L = _lib.load()
+    keep = [_lib.BEGIN_FN(lambda *a: -1), _lib.CULL_FN(lambda *a: -1), _lib.CULL_FN(lambda *a: -1), _lib.FINISH_FN(lambda *a: -1), _lib.COMPLETE_FN(lambda *a: -1),
+            _lib.STATUS_FN(lambda *a: -1), _lib.RECOVER_FN(lambda *a: -1), _lib.FIRST_FN(lambda *a: None), _lib.ALLOC_FN(lambda *a: None), _lib.RELEASE_FN(lambda *a: None),
+            _lib.COPY_FN(lambda *a: -1), _lib.COPY_FN(lambda *a: -1), _lib.ABORT_FN(lambda u: None)]
+    be = _lib.SlabBackend(None, *keep, 64, 4, 4, 64, None, 0)
+    tr = _lib.SlabTransport(None, _lib.AG_FN(lambda *a: -1), _lib.XCHG_FN(lambda *a: -1), 0, _lib.DESTROY_FN(0))
+    for nt, world in ((5, 1), (6, 2), (7, 3), (3, 5), (32, 8)):
+        for periodic in (False, True):
+            info = {}
+            for r in range(world):
+                h = C.c_void_p()
+                _lib.check(L.ftkx_slab_create_custom(C.byref(be), nt, r, world, C.byref(tr), C.byref(h)))
+                if periodic:
+                    _lib.check(L.ftkx_slab_set_periodic(h, 1))
+                i = _lib.SlabInfo()
+                L.ftkx_slab_get_info(h, C.byref(i))
+                info[r] = (i.t0, i.t1, i.lower, i.upper)
+                L.ftkx_slab_destroy(h)
+            owners = [r for r in range(world) if info[r][1] > info[r][0]]
+            for k, r in enumerate(owners):
+                t0, t1, lower, upper = info[r]
+                want_lower = owners[k - 1] if k > 0 else (owners[-1] if periodic else -1)
+                want_upper = owners[k + 1] if k + 1 < len(owners) else (owners[0] if periodic else -1)
+                assert (lower, upper) == (want_lower, want_upper), (nt, world, periodic, r, info[r])
+            for r in range(world):
+                if r not in owners:
+                    assert info[r][2:] == (-1, -1), (nt, world, periodic, r, info[r])
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
