@@ -17,9 +17,11 @@
 #include <vector>
 
 #include "sweep_params.hpp"
+#include "split_policy.hpp"
 #include "internal.hpp"
 
 namespace ftkx {
+void mask_kernel_launches(unsigned long long *out, const char **names);
 void launch_tile(const TileParams &p, hipStream_t stream);
 void launch_tile_stats_fold(u64 *slots, u64 *counters, hipStream_t stream);
 void tile_dims(int nd, int tile[3]);
@@ -270,19 +272,7 @@ struct ftkx_ctx {
     u64 capacity = 0, list_capacity = 0, refine_capacity = 0, fragile_capacity = 0;
     size_t bins_cap = 0;
   } sr_set1;
-  // Does the split pass pay HERE?  How the hardware arbitrates between the context's queue and the tail's is not something the library sees
-  // (NOTES.md: the same binary runs 256^3 x 16 at 0.41 or at 0.51 ms per pass, against 0.44 in order, with the runtime's number of hardware
-  // queues).  So the first passes that qualify are measured: a few in order, a few split -- the host's time between two completions while the
-  // pipeline is full -- and the split pass is taken for the passes of that shape only if it was faster.
-  struct split_cal {
-    unsigned long long signature = 0;   // (steps, slices to mask, cells): what the samples are about
-    int phase = 0;                      // 0: in-order samples, 1: split samples, 2: decided
-    int skip = 0;                       // samples to discard (a change of form: buffers, streams, mask arrays of its first passes)
-    std::vector<double> t_order, t_split;
-    bool good = true;
-    double median_order = 0, median_split = 0;   // seconds per pass, what the decision was taken on
-    unsigned countdown = 0;             // decided "not here": passes until it is measured again
-  } sr_cal;
+  ftkxh::split_cal sr_cal;              // the split pass's self-check (split_policy.hpp)
   int sr_split_forced = 0;              // the last plan's FTKX_SERIES_HOOKS split setting: 0 auto, 1 forced on (2, 3, 4), 2 forced off (0)
   double sr_last_complete_s = 0;        // host clock of the last completion (0: the pipeline ran empty since)
   int sr_last_complete_kind = 0;        // 1 in order / 2 split, of a calibration pass; 0 otherwise

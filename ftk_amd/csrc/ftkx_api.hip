@@ -339,6 +339,13 @@ int ensure_mask_arrays(ftkx_ctx *c, Slice &s, bool two_level)
 extern "C" {
 
 const char *ftkx_last_mask_kernel(void) { return ftkx::last_mask_kernel(); }
+int ftkx_debug_mask_kernel_launches(unsigned long long *launches, const char **names, int n)
+{
+  unsigned long long l[ftkx::kMaskKernels]; const char *nm[ftkx::kMaskKernels];
+  ftkx::mask_kernel_launches(l, nm);
+  for (int i = 0; i < n && i < ftkx::kMaskKernels; i ++) { if (launches) launches[i] = l[i]; if (names) names[i] = nm[i]; }
+  return ftkx::kMaskKernels;
+}
 
 const char *ftkx_version(void) { return "ftkx 0.1 (gfx950)"; }
 

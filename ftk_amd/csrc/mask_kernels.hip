@@ -1382,6 +1382,14 @@ __global__ __launch_bounds__(kThreads) void resolution_scalar_kernel(const Mesh 
 // kernel family so that its roofline line can be matched with the profiler's summary
 static const char *g_last_mask_kernel = "";
 const char *last_mask_kernel() { return g_last_mask_kernel; }
+// Which mask kernel took how many launches in this process: launch_masks_impl picks one of six by the mesh (3D scalar: march6; 2D scalar: march4,
+// rows2 for rows of 32 KB and more; vector input: vec2 with block summaries, vec without; everything else: the generic kernel), and the GPU
+// suite is meant to reach every one of them (tests/conftest.py writes the table; profiles/r06_mask_kernel_coverage.json).
+static unsigned long long g_mask_launches[kMaskKernels] = {0, 0, 0, 0, 0, 0, 0};
+static const char *const g_mask_names[kMaskKernels] = {"mask_march6_kernel (3D scalar)", "mask_march4_kernel (2D scalar)", "mask_rows2_kernel (2D scalar, long rows)",
+                                                       "mask_march4_kernel<reduce> (stand-alone reduction)", "mask_vec2_kernel (vector input, block summaries)",
+                                                       "mask_vec_kernel (vector input)", "mask_kernel (generic)"};
+void mask_kernel_launches(unsigned long long *out, const char **names) { for (int i = 0; i < kMaskKernels; i ++) { if (out) out[i] = g_mask_launches[i]; if (names) names[i] = g_mask_names[i]; } }
 
 void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool reduce, hipStream_t stream);
 bool masks_have_summary(const Mesh &m);
@@ -1488,7 +1496,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
         for (size_t i = 0; i < lens.size(); i ++) { plan.z0[i] = (unsigned)z; plan.len[i] = (unsigned)lens[i]; z += lens[i]; }
       }
       constexpr int NS6 = 2, CY6 = 4, RY6 = 4, rows = CY6 * RY6;
-      g_last_mask_kernel = "ftkx::mask_march6_kernel<2, 4, 4, false>";
+      g_last_mask_kernel = "ftkx::mask_march6_kernel<2, 4, 4, false>"; g_mask_launches[0] ++;
       dim3 grid6((unsigned)((DW + 127) / 128), (unsigned)((m.ext_sz[1] + rows - 1) / rows), plan.npieces * (unsigned)njobs);
       int sw = swizzle;
       // grouped placement needs a y extent that is a multiple of the group height: pad it (workgroups past the last row leave at once)
@@ -1520,7 +1528,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
           while (yg > 1 && gridr.y % (unsigned)yg) yg --;
           sw = (sw & 0xff) | (yg << 8);
         }
-        g_last_mask_kernel = "ftkx::mask_rows2_kernel<8>";
+        g_last_mask_kernel = "ftkx::mask_rows2_kernel<8>"; g_mask_launches[2] ++;
         hipLaunchKernelGGL(mask_rows2_kernel<8>, gridr, dim3((unsigned)(64 * wpb)), 0, stream, m, d_jobs, groups, sw);
         return;
       }
@@ -1534,7 +1542,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       swizzle = (swizzle & 0xff) | (yg << 8);
     }
     const dim3 blk((unsigned)(64 * wpb));
-#define FTKX_M4(ND_, R_, PD_, RY_) do { if (!reduce) g_last_mask_kernel = "ftkx::mask_march4_kernel<" #ND_ ", " #R_ ", " #PD_ ", " #RY_ ">"; \
+#define FTKX_M4(ND_, R_, PD_, RY_) do { if (!reduce) g_last_mask_kernel = "ftkx::mask_march4_kernel<" #ND_ ", " #R_ ", " #PD_ ", " #RY_ ">"; g_mask_launches[reduce ? 3 : 1] ++; \
       hipLaunchKernelGGL((mask_march4_kernel<ND_, R_, PD_, RY_>), grid4, blk, 0, stream, m, d_jobs, zchunk, swizzle); } while (0)
     if (reduce) { if (m.nd == 2) FTKX_M4(2, true, 1, 8); else FTKX_M4(3, true, 1, 4); }
     else FTKX_M4(2, false, 1, 8);
@@ -1556,12 +1564,12 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
       size_t bx2 = (units + 7) / 8;             // two units (32 KB) per wavefront where the slice has them (four: +1.3 %, one: +0.3 % on double_gyre 2048 x 1024 x 128)
       if (bx2 > 2048) bx2 = 2048;
       const dim3 grid((unsigned)bx2, (unsigned)njobs);
-      g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_vec2_kernel<2>" : "ftkx::mask_vec2_kernel<3>";
+      g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_vec2_kernel<2>" : "ftkx::mask_vec2_kernel<3>"; g_mask_launches[4] ++;
       if (m.nd == 2) hipLaunchKernelGGL(mask_vec2_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs);
       else hipLaunchKernelGGL(mask_vec2_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs);
       return;
     }
-    g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_vec_kernel<2>" : "ftkx::mask_vec_kernel<3>";
+    g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_vec_kernel<2>" : "ftkx::mask_vec_kernel<3>"; g_mask_launches[5] ++;
     if (m.nd == 2) hipLaunchKernelGGL(mask_vec_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs);
     else hipLaunchKernelGGL(mask_vec_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs);
     return;
@@ -1571,7 +1579,7 @@ void launch_masks_impl(const Mesh &m, const MaskJob *d_jobs, int njobs, bool red
   size_t bx = (n + kThreads - 1) / kThreads;
   if (bx > 4096) bx = 4096;                 // grid-stride the rest
   const dim3 grid((unsigned)bx, (unsigned)njobs);
-  g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_kernel<2>" : "ftkx::mask_kernel<3>";
+  g_last_mask_kernel = m.nd == 2 ? "ftkx::mask_kernel<2>" : "ftkx::mask_kernel<3>"; g_mask_launches[6] ++;
   if (m.nd == 2) hipLaunchKernelGGL(mask_kernel<2>, grid, dim3(kThreads), 0, stream, m, d_jobs);
   else hipLaunchKernelGGL(mask_kernel<3>, grid, dim3(kThreads), 0, stream, m, d_jobs);
 }

@@ -196,7 +196,7 @@ void series_queue_copy(ftkx_ctx *c, ftkx_series_pending &P, const unsigned *wait
 // What the two sides share is kept apart: the reduction slots are the pass's own (ftkx_series_buffers::red), the counters and the histogram
 // are zeroed on the tail stream, and a slice whose masks the next pass rebuilds while this pass's tail still reads them gets fresh arrays
 // (`retired`: back to the pool when this pass is completed).
-constexpr unsigned long long kSplitMinBytes = 1000000000ull;
+using ftkxh::kSplitMinBytes;
 hipStream_t tail_stream(ftkx_ctx *c, const ftkx_series_pending &P) { return P.split ? (P.tail_set ? c->sr_tail_stream2 : c->sr_tail_stream) : c->stream; }
 
 // the counters, lists and ordering arrays a pass's tail works on: the context's own, or the second set
@@ -484,25 +484,15 @@ int series_plan(ftkx_ctx *c, ftkx_series_pending &P, const int *ts, const int *s
     // streams kept for the process) measures 0.764-0.774 alone, behind three other configurations and inside the driver's full line
     // (tools/dense_split.py) -- and auto's self-check keeps a context in order where it is not so.  Smaller hit-dense passes lose: woven
     // 1024^2 x 64, tail = mask kernel = 100 us, 0.205 -> 0.279 split.
-    const bool dense_too = true;
     const bool sparse_now = c->sr_sparse && !P.to_device;
-    // (a hit-dense chain is ~550 us next to a mask kernel -- double_gyre's 56 766 records --: only mask launches of 4 GB and more hide it)
-    P.split = split_mode != 0 && pipelined && !dist && (c->profiling == 0 || c->profiling == 2) && (sparse_now || dense_too) && ntodo > 0 &&
-              (mask_bytes >= (sparse_now ? kSplitMinBytes : 4 * kSplitMinBytes) || split_mode == 2);
-    // the self-check (ctx.hpp, split_cal); a hook that forces or forbids the split pass (0, 2, 3, 4) goes around it
-    P.cal_kind = 0;
-    c->sr_split_forced = split_mode == 0 ? 2 : split_mode != 1 ? 1 : 0;
-    if (P.split && split_mode == 1) {
-      ftkx_ctx::split_cal &K = c->sr_cal;
-      const unsigned long long sig = ((unsigned long long)n << 48) ^ ((unsigned long long)ntodo << 32) ^ (unsigned long long)cells;
-      if (K.signature != sig) { K = ftkx_ctx::split_cal(); K.signature = sig; K.skip = 2; }
-      if (K.phase == 0) { P.split = false; P.cal_kind = 1; }
-      else if (K.phase == 1) P.cal_kind = 2;
-      else if (!K.good) {
-        P.split = false;
-        if (K.countdown > 0 && -- K.countdown == 0) { const unsigned long long keep = K.signature; K = ftkx_ctx::split_cal(); K.signature = keep; K.skip = 2; }
-      }
-    }
+    // (a hit-dense chain is ~550 us next to a mask kernel -- double_gyre's 56 766 records --: only mask launches of 4 GB and more hide it.)
+    // The decision, and in "auto" the self-check behind it: split_policy.hpp
+    ftkxh::split_inputs in;
+    in.mode = split_mode; in.pipelined = pipelined; in.dist = dist != nullptr; in.profiling_ok = c->profiling == 0 || c->profiling == 2;
+    in.sparse_now = sparse_now; in.ntodo = ntodo; in.mask_bytes = mask_bytes;
+    in.signature = ((unsigned long long)n << 48) ^ ((unsigned long long)ntodo << 32) ^ (unsigned long long)cells;
+    const ftkxh::split_verdict v = ftkxh::split_decide(c->sr_cal, in);
+    P.split = v.split; P.cal_kind = v.cal_kind; c->sr_split_forced = v.forced;
     P.split_sparse = P.split && c->sr_sparse && !P.to_device;
   }
   const bool before_split = before && before->open && before->split;
@@ -899,21 +889,7 @@ int series_complete(ftkx_ctx *c, ftkx_series_pending &P, double *running_resolut
     // the split pass's self-check: the time since the last completion is a sample of this pass's form if the pipeline was full all the while
     // (another pass is open now and one was when the last one completed) and the last completion was of the same form
     const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    ftkx_ctx::split_cal &K = c->sr_cal;
-    if (P.cal_kind && K.phase < 2) {
-      if (last_complete_s > 0 && last_complete_kind == P.cal_kind && c->sr_open > 0) {
-        if (K.skip > 0) K.skip --;
-        else (P.cal_kind == 1 ? K.t_order : K.t_split).push_back(now - last_complete_s);
-      }
-      auto median = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
-      if (K.phase == 0 && K.t_order.size() >= 5) { K.phase = 1; K.skip = 4; }      // (the first split passes allocate: their stream, the mask arrays they swap in)
-      else if (K.phase == 1 && K.t_split.size() >= 5) {
-        K.phase = 2;
-        K.median_order = median(K.t_order); K.median_split = median(K.t_split);
-        K.good = K.median_split <= 1.02 * K.median_order;      // (kept unless clearly slower: the bad state is +13 %, a good one between -1 and -10 %)
-        K.countdown = K.good ? 0u : 4096u;
-      }
-    }
+    ftkxh::split_sample(c->sr_cal, P.cal_kind, now, last_complete_s, last_complete_kind, c->sr_open > 0);
     c->sr_last_complete_kind = P.cal_kind;
     c->sr_last_complete_s = c->sr_open > 0 ? now : 0.0;
   }
@@ -1269,8 +1245,8 @@ int ftkx_sweep_series(ftkx_ctx *c, const int *ts, const int *scopes, int n, doub
 int ftkx_series_split_decision(const ftkx_ctx *c, int *state, double *median_in_order_ms, double *median_split_ms)
 {
   if (!c) return fail(nullptr, FTKX_E_INVALID, "null context");
-  const ftkx_ctx::split_cal &K = c->sr_cal;
-  if (state) *state = c->sr_split_forced == 1 ? 3 : c->sr_split_forced == 2 ? 4 : K.phase < 2 ? 0 : K.good ? 1 : 2;
+  const ftkxh::split_cal &K = c->sr_cal;
+  if (state) *state = ftkxh::split_state(K, c->sr_split_forced);
   if (median_in_order_ms) *median_in_order_ms = K.median_order * 1e3;
   if (median_split_ms) *median_split_ms = K.median_split * 1e3;
   return FTKX_OK;

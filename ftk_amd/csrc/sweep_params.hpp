@@ -77,6 +77,8 @@ struct Fields {
   int scope_mask;            // FTKX_SCOPE_*
 };
 
+constexpr int kMaskKernels = 7;      // mask-kernel families launch_masks picks from (mask_kernels.hip: mask_kernel_launches)
+
 // tile kernel (exact_only / non-robust / overflow regime, and small jobs)
 struct TileParams {
   Mesh m;

@@ -410,6 +410,10 @@ int ftkx_debug_tile_repeat(ftkx_ctx *ctx, int repeat);
 /* profiling aid: the mask-kernel instantiation of the most recent sweep in this process, spelled as rocprofv3 lists it */
 const char *ftkx_last_mask_kernel(void);
 
+/* profiling aid: launches per mask-kernel instantiation family in this process (seven of them; returns that number): which shapes the
+ * suite / a workload reached -- every kernel behind launch_masks is reachable by some mesh, none is there for history's sake */
+int ftkx_debug_mask_kernel_launches(unsigned long long *launches, const char **names, int n);
+
 /* library / device identification */
 const char *ftkx_version(void);
 int ftkx_device_count(void);

@@ -28,3 +28,25 @@ def pytest_collection_finish(session):
             Z.start_background()
         except Exception:   # noqa: BLE001
             pass
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """after a GPU session: which mask kernel took how many launches in this process (ftkx_debug_mask_kernel_launches) -> gpurun_out/"""
+    try:
+        if "ftk_amd" not in sys.modules:
+            return
+        import ctypes as C
+        import json
+        from ftk_amd import _lib
+        L = _lib.load()
+        n = 7
+        cnt = (C.c_ulonglong * n)(); names = (C.c_char_p * n)()
+        L.ftkx_debug_mask_kernel_launches(cnt, names, n)
+        if not any(cnt):
+            return
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "r06_mask_kernel_coverage.json"), "w") as f:
+            json.dump({"note": "launches per mask kernel in the pytest process (subprocess tests not counted)", "tests_run": session.testscollected,
+                       "launches": {names[i].decode(): int(cnt[i]) for i in range(n)}}, f, indent=1)
+    except Exception:   # noqa: BLE001
+        pass

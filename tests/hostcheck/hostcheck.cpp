@@ -3,6 +3,7 @@
 // inputs without a GPU.  Nothing in the product loads this library; the same headers run on the device in the HIP kernels.
 #include "../../ftk_amd/csrc/cp_device.hpp"
 #include "../../ftk_amd/csrc/fan_tables.hpp"
+#include "../../ftk_amd/csrc/split_policy.hpp"
 
 using namespace ftkx;
 
@@ -62,5 +63,23 @@ int hc_fan(int n, int *verts /* [ntypes][n][n] */, int *ordinal, int *ord_types,
   for (int i = 0; i < 6; i ++) ord_types[i] = k_fan4.ord_types[i];
   for (int i = 0; i < 54; i ++) int_types[i] = k_fan4.int_types[i];
   return 60;
+}
+
+// ---- the split pass's policy (ftk_amd/csrc/split_policy.hpp), driven without a device: tests/test_split_policy.py ----
+void *hc_split_new() { return new ftkxh::split_cal(); }
+void hc_split_delete(void *k) { delete (ftkxh::split_cal *)k; }
+// -> split | cal_kind << 1 | forced << 3
+int hc_split_decide(void *k, long mode, int pipelined, int dist, int profiling_ok, int sparse_now, unsigned long long ntodo, unsigned long long mask_bytes, unsigned long long signature)
+{
+  ftkxh::split_inputs in{mode, pipelined != 0, dist != 0, profiling_ok != 0, sparse_now != 0, ntodo, mask_bytes, signature};
+  const ftkxh::split_verdict v = ftkxh::split_decide(*(ftkxh::split_cal *)k, in);
+  return (v.split ? 1 : 0) | (v.cal_kind << 1) | (v.forced << 3);
+}
+void hc_split_sample(void *k, int cal_kind, double now, double last_s, int last_kind, int chained) { ftkxh::split_sample(*(ftkxh::split_cal *)k, cal_kind, now, last_s, last_kind, chained != 0); }
+int hc_split_state(void *k, int forced, double *median_order, double *median_split, int *phase, unsigned *countdown)
+{
+  const ftkxh::split_cal &K = *(const ftkxh::split_cal *)k;
+  *median_order = K.median_order; *median_split = K.median_split; *phase = K.phase; *countdown = K.countdown;
+  return ftkxh::split_state(K, forced);
 }
 }
