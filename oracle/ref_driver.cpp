@@ -158,10 +158,11 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
   probe<Tracker> tracker(comm);
   const size_t DW = in.D[0], DH = in.D[1], DD = in.D[2];
   // json_interface.hh:634-656
+  const bool push_all = getenv("FTK_REF_PUSH_ALL") != NULL && in.nv == 1;
   if (in.nv == 1) {
     tracker.set_scalar_field_source(ftk::SOURCE_GIVEN);
-    tracker.set_vector_field_source(ftk::SOURCE_DERIVED);
-    tracker.set_jacobian_field_source(ftk::SOURCE_DERIVED);
+    tracker.set_vector_field_source(push_all ? ftk::SOURCE_GIVEN : ftk::SOURCE_DERIVED);
+    tracker.set_jacobian_field_source(push_all ? ftk::SOURCE_GIVEN : ftk::SOURCE_DERIVED);
     tracker.set_jacobian_symmetric(true);
     if (in.nd == 2) tracker.set_domain(ftk::lattice({2, 2}, {DW - 3, DH - 3}));
     else tracker.set_domain(ftk::lattice({2, 2, 2}, {DW - 3, DH - 3, DD - 3}));
@@ -225,6 +226,14 @@ static void run(const input_t &in, int nthreads, const char *out, bool robust, u
   for (int k = 0; k < in.DT; k ++) {
     const auto a = make_array(in, k);
     const auto t0 = std::chrono::high_resolution_clock::now();
+    if (push_all) {
+      // FTK_REF_PUSH_ALL: scalar, vector and Jacobian all GIVEN (critical_point_tracker::push_field_data_snapshot, critical_point_tracker.hh:202-213),
+      // derived here with the reference's own functions -- the arrays the tracker would have derived itself
+      ftk::ndarray<double> V, J;
+      if (in.nd == 2) { V = ftk::gradient2D(a); J = ftk::jacobian2D<double, true>(V); }
+      else { V = ftk::gradient3D(a); J = ftk::jacobian3D(V); }
+      tracker.push_field_data_snapshot(a, V, J);
+    } else
     if (in.nv == 1) tracker.push_scalar_field_snapshot(a);
     else tracker.push_vector_field_snapshot(a);
     if (k != 0) tracker.advance_timestep();

@@ -45,6 +45,7 @@ def test_patch_applies_to_the_reference(tmp_path):
     # the resident form (round 6): the tracker owns the device context; push / update_timestep / pop reach the resident C ABI through it
     tr = (tmp_path / "include/ftk/filters/critical_point_tracker_regular.hh").read_text()
     assert "ftkx::resident_sweep hip;" in tr and "bool pop_field_data_snapshot();" in tr and "hip.pop_front()" in tr
+    assert "if (hip_push_snapshot(&scalar, &vector, &jacobian))" in tr          # (all three given: critical_point_tracker.hh:202-213)
     assert "hip.push_scalar(t, scalar->data())" in tr and "hip.sweep(current_timestep, field_data_snapshots.size() >= 2, vector_field_resolution" in tr
     for t in (t2, t3):
         assert t.count("if (hip_push_snapshot(&s, NULL, NULL))") == 1 and t.count("if (hip_push_snapshot(NULL, &v, NULL))") == 1

@@ -97,6 +97,8 @@ def _driver_env(name, g, mode):
         env["FTK_REF_T0"] = str(g["t0"])
     if mode == "oneshot":
         env["FTK_SHIM_ONESHOT"] = "1"
+    if mode == "resident_all_given":
+        env["FTK_REF_PUSH_ALL"] = "1"
     return env
 
 
@@ -109,7 +111,7 @@ def _run_shim_driver(name, mode, tmp_path):
     r = subprocess.run([SHIM_DRIVER, "file", str(inp), str(out)], capture_output=True, text=True, timeout=600, env=_driver_env(name, g, mode))
     assert r.returncode == 0, r.stderr[-2000:]
     info = json.loads(r.stdout.strip().splitlines()[-1])
-    assert info["hip_resident"] == (mode == "resident")
+    assert info["hip_resident"] == (mode != "oneshot")
     return g, read_dump(str(out)), info
 
 
@@ -140,6 +142,18 @@ def test_patched_reference_tracker_is_resident_and_matches_every_fixture(name, t
     _assert_dump_equals_fixture(d, g)
     if g["curves"] is not None:
         assert sorted((tuple(t.tolist()), l) for l, t in d["curves"]) == sorted((tuple(t.tolist()), l) for l, t in g["curves"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["woven_31x37x32", "random_3d_scalar_13x12x11x4", "moving_extremum_3d_12x10x9x5_aligned"])
+def test_patched_reference_tracker_with_scalar_vector_and_jacobian_given(name, tmp_path):
+    """critical_point_tracker::push_field_data_snapshot(scalar, vector, jacobian) (critical_point_tracker.hh:202-213), the third way a snapshot
+    reaches the tracker: all three arrays GIVEN -- here derived by the driver with the reference's own gradient / jacobian functions -- go to
+    HBM once through the patch's override (ftkx_push_slice with V, J and S); the records are those of the fixture."""
+    if not os.path.exists(SHIM_DRIVER):
+        pytest.skip("oracle/_ref/ftk_shim_driver not built (needs the build container: make -C oracle ref)")
+    g, d, _ = _run_shim_driver(name, "resident_all_given", tmp_path)
+    _assert_dump_equals_fixture(d, g)
 
 
 @pytest.mark.gpu
