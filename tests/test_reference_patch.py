@@ -88,6 +88,8 @@ def test_patch_applies_to_the_reference(tmp_path):
     ("include/ftk/filters/critical_point_tracker.hh", 841, 848, ["advance_timestep", "update_timestep();", "pop_field_data_snapshot();"]),
     ("include/ftk/filters/critical_point_tracker.hh", 850, 864, ["update_vector_field_scaling_factor", "s.vector.resolution()", "1 << nbits"]),
     ("include/ftk/filters/critical_point_tracker.hh", 155, 159, ["field_data_snapshot_t", "std::deque<field_data_snapshot_t> field_data_snapshots"]),
+    ("include/ftk/filters/critical_point_tracker.hh", 202, 213, ["push_field_data_snapshot", "snapshot.jacobian = jacobian"]),
+    ("include/ftk/filters/regular_tracker.hh", 38, 40, ["set_coords_bounds", "set_coords_rectilinear", "set_coords_explicit"]),
 ])
 def test_cited_line_ranges_hold_what_the_docs_say(path, first, last, anchors):
     lines = open(os.path.join(REF, path)).read().split("\n")
