@@ -90,23 +90,44 @@ static_assert(k_fan4.vert[16][1] == 0b0100 && k_fan4.vert[16][2] == 0b0110 && k_
 // The 3 x 3 minors the 60 simplices of a 3D+t corner share.  A simplex is a chain 0 < m1 < m2 < m3 of vertex masks; three of its four
 // "vertex replaced by the origin" determinants contain the corner -- det(X_0, X_a, X_b) for a pair a < b of its masks -- and there are
 // only 50 such pairs in the whole fan (each used by 3.6 simplices on average); the fourth, det(X_m1, X_m2, X_m3), is the simplex's own.
-struct fan_pairs {
-  signed char index[16][16];        // (a, b), a a proper non-empty subset of b -> 0 .. 49; -1 otherwise
-  unsigned char a[50], b[50];
+// The fan grouped by the MIDDLE vertex of the chain 0 < m1 < m2 < m3 (tile_kernels.hip, fan_of_corner3_grouped): with c(m) = X_0 x X_m,
+//   n1 = det(X_0, X_m2, X_m3) =  X_m3 . c(m2),   n3 = det(X_0, X_m1, X_m2) = -X_m1 . c(m2),   n2 = det(X_0, X_m1, X_m3) = -X_m1 . c(m3)
+// -- a group (one m2: 10 of them, |m2| = 2 or 3) needs c(m2), at most three n1, at most six n3 and the c(m3) of its at most three m3,
+// eighteen doubles live instead of the fifty shared determinants of the flat form.
+struct fan_groups {
+  unsigned char m2[10];
+  unsigned char nsub[10], sub[10][6];   // proper non-empty subsets of m2
+  unsigned char nsup[10], sup[10][3];   // proper supersets of m2
+  signed char type_of[16][16][16];      // (m1, m2, m3) -> type id, -1: not a chain
 };
-constexpr fan_pairs make_fan_pairs()
+constexpr fan_groups make_fan_groups()
 {
-  fan_pairs p{};
-  for (int i = 0; i < 16; i ++) for (int j = 0; j < 16; j ++) p.index[i][j] = -1;
+  fan_groups g{};
+  for (int a = 0; a < 16; a ++) for (int b = 0; b < 16; b ++) for (int c = 0; c < 16; c ++) g.type_of[a][b][c] = -1;
+  for (int t = 0; t < 60; t ++) g.type_of[k_fan4.vert[t][1]][k_fan4.vert[t][2]][k_fan4.vert[t][3]] = (signed char)t;
   int n = 0;
-  for (unsigned a = 1; a < 16; a ++)
-    for (unsigned b = 1; b < 16; b ++)
-      if (a != b && (a & b) == a) { p.index[a][b] = (signed char)n; p.a[n] = (unsigned char)a; p.b[n] = (unsigned char)b; n ++; }
-  return p;
+  for (unsigned m = 1; m < 15; m ++) {
+    int bits = 0;
+    for (int a = 0; a < 4; a ++) bits += (m >> a) & 1u;
+    if (bits != 2 && bits != 3) continue;
+    g.m2[n] = (unsigned char)m;
+    for (unsigned x = 1; x < 16; x ++) {
+      if (x != m && (x & m) == x) g.sub[n][g.nsub[n] ++] = (unsigned char)x;
+      if (x != m && (x & m) == m) g.sup[n][g.nsup[n] ++] = (unsigned char)x;
+    }
+    n ++;
+  }
+  return g;
 }
-inline constexpr fan_pairs k_fan_pairs = make_fan_pairs();
-static_assert(k_fan_pairs.index[7][15] == 49 - 7 || k_fan_pairs.index[7][15] >= 0, "pairs enumerated");
-static_assert(k_fan_pairs.b[49] == 15 && k_fan_pairs.a[49] == 14, "50 nested pairs of non-empty masks over four axes");
+inline constexpr fan_groups k_fan_groups = make_fan_groups();
+constexpr int fan_groups_types()
+{
+  int n = 0;
+  for (int i = 0; i < 10; i ++) for (int a = 0; a < k_fan_groups.nsub[i]; a ++) for (int b = 0; b < k_fan_groups.nsup[i]; b ++)
+    if (k_fan_groups.type_of[k_fan_groups.sub[i][a]][k_fan_groups.m2[i]][k_fan_groups.sup[i][b]] >= 0) n ++;
+  return n;
+}
+static_assert(fan_groups_types() == 60, "the ten groups cover the sixty types exactly once");
 
 template <int N> struct fan_of;
 template <> struct fan_of<3> { static constexpr const fan_table<3> &get() { return k_fan3; } };

@@ -23,8 +23,9 @@ __device__ unsigned long long g_tile_stamps[512 * 8];
 #define TILE_STAMP(k) do { } while (0)
 #endif
 #ifndef FTKX_FAN_WAVES
-#define FTKX_FAN_WAVES 2
+#define FTKX_FAN_WAVES 3
 #endif
+
 struct fan_result { unsigned hits[2], unsure[2], tested; };     // bit T of the 64: simplex type T
 
 // sum_k p_k * b_k in Z / 2^64 for 64-bit p_k and sign-extended 32-bit b_k: per term ONE 32 x 32 -> 64 multiply-add on the low words,
@@ -40,11 +41,12 @@ __device__ __forceinline__ u64 dot3_64_s32(u64 p0, u64 p1, u64 p2, int b0, int b
 }
 
 // The whole 3D+t fan of ONE corner on one lane.  The generic loop of tile_kernel spreads (corner, type) pairs over the lanes and computes
-// every simplex from scratch: twelve LDS reads, a decode of the pair, four 3 x 3 minors.  Here a lane computes the 50 minors that
-// contain its corner ONCE (det(X_0, X_a, X_b), shared by 3.6 simplices each: fan_tables.hpp) and then walks the 60 simplex types with
-// compile-time vertex indices (`at(v, c)`: component c of hypercube vertex v, an LDS read at a constant offset from the lane's
-// corner): per simplex one minor of its own, three look-ups, the sign test.  Invalid / non-finite vertices and the strict-sign cull are
-// sixteen-bit masks tested against the simplex's vertex set.  Two arithmetics for the same values:
+// every simplex from scratch: twelve LDS reads, a decode of the pair, four 3 x 3 minors.  Here a lane walks the 60 simplex types with
+// compile-time vertex indices (`at(v, c)`: component c of hypercube vertex v, an LDS read at a constant offset from the lane's corner).
+// A simplex is a chain 0 < m1 < m2 < m3 of vertex masks; three of its four "vertex replaced by the origin" determinants contain the corner,
+//   n1 = det(X_0, X_m2, X_m3),  n2 = det(X_0, X_m1, X_m3),  n3 = det(X_0, X_m1, X_m2),
+// and are shared between simplices; the fourth, det(X_m1, X_m2, X_m3), is its own.  Invalid / non-finite vertices and the strict-sign cull
+// are sixteen-bit masks tested against the simplex's vertex set.  Two arithmetics for the same values:
 //   * integer (comp_t = int): |component| < 2^31 (tile_kernel checks).  2 x 2 minors from 32 x 32 -> 64 multiplies, determinants by
 //     dot3_64_s32, everything in Z / 2^64 exactly as origin_in_simplex3 -- wrapped determinants included;
 //   * fp64 (comp_t = double): |component| < 2^19.  Nothing wraps there (|3 x 3 determinant| < 6 * 2^57, |D| < 42 * 2^57 < 2^63), so the
@@ -54,76 +56,101 @@ __device__ __forceinline__ u64 dot3_64_s32(u64 p0, u64 p1, u64 p2, int b0, int b
 //     exact.  v_fma_f64 is a full-rate instruction on gfx950, a 32 x 32 -> 64 integer multiply a quarter-rate one.
 // A simplex with a value that is zero / INT64_MIN (fp64: not clear of zero) comes back in `unsure`: tile_kernel gives it the integer
 // test with the literal cascade.
+//
+// Round 6: the shared determinants by GROUPS of the chain's middle vertex (fan_tables.hpp, fan_groups).  Rounds 3-5 computed all fifty
+// det(X_0, X_a, X_b) up front -- a hundred registers that held the kernel at two wavefronts per SIMD.  With c(m) = X_0 x X_m,
+//   n1 =  X_m3 . c(m2),   n3 = -X_m1 . c(m2),   n2 = -X_m1 . c(m3):
+// per group one cross product c(m2), the n3 of its (at most six) m1, and per m3 (at most three) its n1 and c(m3) -- eighteen doubles live
+// at a time, at the price of more arithmetic (23 cross and 118 dot products instead of 15 and 50: +12 % of the fan's instructions) -- and a
+// scheduling barrier behind every group, without which the compiler interleaves the groups for latency and is back at 256 registers (or,
+// held to 168, at 316 bytes of spills: 28.5 ms).  168 registers, no scratch, three wavefronts per SIMD: 256^3 x 16 exact-only 25.7 ->
+// 22.1 ms (a barrier behind every m3 instead: 22.9).  Same values up to rounding in the fp64 form (the error bounds above hold for any
+// order of the three products of a determinant), identical ones in the integer form (Z / 2^64).
 template <class comp_t, class At>
 __device__ __forceinline__ fan_result fan_of_corner3(At &&at, unsigned inv, const unsigned (&pos)[3], const unsigned (&neg)[3],
-                                                     bool do_ord, bool do_int, int cull, double clear)
+                                                             bool do_ord, bool do_int, int cull, double clear)
 {
   constexpr bool FP = std::is_same<comp_t, double>::value;
   using minor_t = std::conditional_t<FP, double, u64>;
   auto minor = [](comp_t a, comp_t b, comp_t c, comp_t d) __attribute__((always_inline)) -> minor_t {      // a * b - c * d
-    if constexpr (FP) return fma(a, b, -(c * d));             // (exact either way: both products are integers below 2^38)
+    if constexpr (FP) return fma(a, b, -(c * d));
     else return (u64)((i64)a * (i64)b) - (u64)((i64)c * (i64)d);
   };
-  // X_k . (X_i x X_j)
-  auto det = [&](auto I, auto J, auto K) __attribute__((always_inline)) -> minor_t {
-    constexpr int i = decltype(I)::value, j = decltype(J)::value, k = decltype(K)::value;
-    const comp_t i0 = at(I, 0), i1 = at(I, 1), i2 = at(I, 2), j0 = at(J, 0), j1 = at(J, 1), j2 = at(J, 2);
-    const minor_t c0 = minor(i1, j2, i2, j1), c1 = minor(i2, j0, i0, j2), c2 = minor(i0, j1, i1, j0);
-    if constexpr (FP) return fma(c2, at(K, 2), fma(c1, at(K, 1), c0 * at(K, 0)));
-    else return dot3_64_s32(c0, c1, c2, at(K, 0), at(K, 1), at(K, 2));
-    (void)i; (void)j; (void)k;
+  struct vec3 { minor_t c0, c1, c2; };
+  const comp_t o0 = at(std::integral_constant<int, 0>{}, 0), o1 = at(std::integral_constant<int, 0>{}, 1), o2 = at(std::integral_constant<int, 0>{}, 2);
+  auto cross0 = [&](auto J) __attribute__((always_inline)) -> vec3 {          // X_0 x X_J
+    const comp_t j0 = at(J, 0), j1 = at(J, 1), j2 = at(J, 2);
+    return vec3{minor(o1, j2, o2, j1), minor(o2, j0, o0, j2), minor(o0, j1, o1, j0)};
   };
-  minor_t D[50];                                               // det(X_0, X_a, X_b) = X_b . (X_0 x X_a)
-  fan_for<50>([&](auto IC) __attribute__((always_inline)) {
-    constexpr int i = decltype(IC)::value;
-    // (the same cross product for every b: the compiler keeps one copy per a)
-    D[i] = det(std::integral_constant<int, 0>{}, std::integral_constant<int, k_fan_pairs.a[i]>{}, std::integral_constant<int, k_fan_pairs.b[i]>{});
-  });
-  unsigned h0 = 0, h1 = 0, g0 = 0, g1 = 0, tested = 0;
-  // "clear of zero", on ONE word per value.  Integer: x == 0 || x == INT64_MIN  <=>  (lo | hi << 1) == 0.  fp64: the high word of |x|
-  // above the high word of `clear` (4096.0 or 0.5, both with a zero low word) -- as good as the comparison of the doubles for 0.5 (the
-  // values are integers there) and only slightly stricter for 4096.
+  auto dot = [&](const vec3 &c, auto K) __attribute__((always_inline)) -> minor_t {      // X_K . c
+    if constexpr (FP) return fma(c.c2, at(K, 2), fma(c.c1, at(K, 1), c.c0 * at(K, 0)));
+    else return dot3_64_s32(c.c0, c.c1, c.c2, at(K, 0), at(K, 1), at(K, 2));
+  };
+  auto neg_of = [](minor_t x) __attribute__((always_inline)) -> minor_t { if constexpr (FP) return -x; else return (u64)0 - x; };
   auto word = [](minor_t x) __attribute__((always_inline)) -> unsigned {
     if constexpr (FP) return (unsigned)__double2hiint(x) & 0x7fffffffu;
     else return (unsigned)x | ((unsigned)(x >> 32) << 1);
   };
-  auto top = [](minor_t x) __attribute__((always_inline)) -> unsigned {        // the word with the sign bit
+  auto top = [](minor_t x) __attribute__((always_inline)) -> unsigned {
     if constexpr (FP) return (unsigned)__double2hiint(x); else return (unsigned)(x >> 32);
   };
   const unsigned clear_word = FP ? (unsigned)__double2hiint(clear) : 0u;
-  fan_for<60>([&](auto IC) __attribute__((always_inline)) {
-    constexpr int T = decltype(IC)::value;
-    constexpr int m1 = k_fan4.vert[T][1], m2 = k_fan4.vert[T][2], m3 = k_fan4.vert[T][3];
-    constexpr unsigned tm = 1u | (1u << m1) | (1u << m2) | (1u << m3);
-    constexpr bool ordinal = k_fan4.ordinal[T] != 0;
-    constexpr unsigned bit = 1u << (T & 31);
-    bool active = (ordinal ? do_ord : do_int) && !(inv & tm);
-    if (cull) {
-      const bool same = (pos[0] & tm) == tm || (neg[0] & tm) == tm || (pos[1] & tm) == tm || (neg[1] & tm) == tm || (pos[2] & tm) == tm || (neg[2] & tm) == tm;
-      active = active && !same;
-    }
-    if (active) {
-      tested ++;
-      // C0 = -n0, C1 = n1, C2 = -n2, C3 = n3, D = their sum; n0 = det(X_m1, X_m2, X_m3) = X_m1 . (X_m2 x X_m3) is the simplex's own
-      // minor, the other three are shared ones.  First those three: if they are clear of zero and C1, C2, C3 do not have one sign, the
-      // origin is outside whatever C0 and D are (the cascade too wants all signs equal, and gives a non-degenerate value its own
-      // sign) -- on smooth data neighbouring corners agree on that, and whole wavefronts skip the fourth determinant.
-      const minor_t n1 = D[k_fan_pairs.index[m2][m3]], n2 = D[k_fan_pairs.index[m1][m3]], n3 = D[k_fan_pairs.index[m1][m2]];
-      const unsigned w1 = top(n1), w2 = top(n2), w3 = top(n3);
-      const bool sure3 = min(min(word(n1), word(n2)), word(n3)) > clear_word;
-      const bool agree3 = (int)(~(w1 ^ w2) | (w1 ^ w3)) >= 0;         // sign bits: C1 = C2 (n1 != n2) and C1 = C3
-      unsigned is_hit = 0, is_unsure = sure3 ? 0u : bit;
-      if (sure3 && agree3) {
-        const minor_t n0 = det(std::integral_constant<int, m2>{}, std::integral_constant<int, m3>{}, std::integral_constant<int, m1>{});
-        const minor_t d = (n1 - n0) + (n3 - n2);
-        // (a value that passed and its negative have opposite sign bits: C0 = D <=> n0 != D in the sign bit)
-        const bool sure = min(word(n0), word(d)) > clear_word;
-        const unsigned w0 = top(n0), wd = top(d);
-        is_hit = (sure && (int)(~(w0 ^ wd) | (w1 ^ wd)) >= 0) ? bit : 0u;
-        is_unsure = sure ? 0u : bit;
-      }
-      if (T < 32) { h0 |= is_hit; g0 |= is_unsure; } else { h1 |= is_hit; g1 |= is_unsure; }
-    }
+  unsigned h0 = 0, h1 = 0, g0 = 0, g1 = 0, tested = 0;
+  const vec3 c15 = cross0(std::integral_constant<int, 15>{});                  // (every group's last m3)
+  fan_for<10>([&](auto GC) __attribute__((always_inline)) {
+    constexpr int G = decltype(GC)::value;
+    constexpr int M2 = k_fan_groups.m2[G], NSUB = k_fan_groups.nsub[G], NSUP = k_fan_groups.nsup[G];
+    const vec3 c2 = cross0(std::integral_constant<int, M2>{});
+    minor_t n3s[NSUB];
+    fan_for<NSUB>([&](auto AC) __attribute__((always_inline)) {
+      constexpr int a = decltype(AC)::value;
+      n3s[a] = neg_of(dot(c2, std::integral_constant<int, k_fan_groups.sub[G][a]>{}));
+    });
+    fan_for<NSUP>([&](auto BC) __attribute__((always_inline)) {
+      constexpr int b = decltype(BC)::value;
+      constexpr int M3 = k_fan_groups.sup[G][b];
+      const minor_t n1 = dot(c2, std::integral_constant<int, M3>{});
+      vec3 c3 = c15;
+      if constexpr (M3 != 15) c3 = cross0(std::integral_constant<int, M3>{});
+      fan_for<NSUB>([&](auto AC) __attribute__((always_inline)) {
+        constexpr int a = decltype(AC)::value;
+        constexpr int M1 = k_fan_groups.sub[G][a];
+        constexpr int T = k_fan_groups.type_of[M1][M2][M3];
+        static_assert(T >= 0 && T < 60, "a chain of the fan");
+        constexpr unsigned tm = 1u | (1u << M1) | (1u << M2) | (1u << M3);
+        constexpr bool ordinal = k_fan4.ordinal[T] != 0;
+        constexpr unsigned bit = 1u << (T & 31);
+        bool active = (ordinal ? do_ord : do_int) && !(inv & tm);
+        if (cull) {
+          const bool same = (pos[0] & tm) == tm || (neg[0] & tm) == tm || (pos[1] & tm) == tm || (neg[1] & tm) == tm || (pos[2] & tm) == tm || (neg[2] & tm) == tm;
+          active = active && !same;
+        }
+        if (active) {
+          tested ++;
+          // (as in fan_of_corner3: C1 = n1, C2 = -n2, C3 = n3 first; the simplex's own determinant n0 only where they agree)
+          const minor_t n3 = n3s[a];
+          const minor_t n2 = neg_of(dot(c3, std::integral_constant<int, M1>{}));
+          const unsigned w1 = top(n1), w2 = top(n2), w3 = top(n3);
+          const bool sure3 = min(min(word(n1), word(n2)), word(n3)) > clear_word;
+          const bool agree3 = (int)(~(w1 ^ w2) | (w1 ^ w3)) >= 0;
+          unsigned is_hit = 0, is_unsure = sure3 ? 0u : bit;
+          if (sure3 && agree3) {
+            // n0 = det(X_m1, X_m2, X_m3) = X_m1 . (X_m2 x X_m3)
+            const comp_t i0 = at(std::integral_constant<int, M2>{}, 0), i1 = at(std::integral_constant<int, M2>{}, 1), i2 = at(std::integral_constant<int, M2>{}, 2);
+            const comp_t j0 = at(std::integral_constant<int, M3>{}, 0), j1 = at(std::integral_constant<int, M3>{}, 1), j2 = at(std::integral_constant<int, M3>{}, 2);
+            const vec3 cx{minor(i1, j2, i2, j1), minor(i2, j0, i0, j2), minor(i0, j1, i1, j0)};
+            const minor_t n0 = dot(cx, std::integral_constant<int, M1>{});
+            const minor_t d = (n1 - n0) + (n3 - n2);
+            const bool sure = min(word(n0), word(d)) > clear_word;
+            const unsigned w0 = top(n0), wd = top(d);
+            is_hit = (sure && (int)(~(w0 ^ wd) | (w1 ^ wd)) >= 0) ? bit : 0u;
+            is_unsure = sure ? 0u : bit;
+          }
+          if (T < 32) { h0 |= is_hit; g0 |= is_unsure; } else { h1 |= is_hit; g1 |= is_unsure; }
+        }
+      });
+    });
+    __builtin_amdgcn_sched_barrier(0);        // (a group's values die with it: no instruction of the next group is moved up into this one)
   });
   fan_result r;
   r.hits[0] = h0; r.hits[1] = h1; r.unsure[0] = g0; r.unsure[1] = g1; r.tested = tested;

@@ -1,6 +1,6 @@
-"""The tile kernel's fan forms live within a few registers of the 256 that two wavefronts per SIMD leave them (tile_kernels.hip): a change that
-tips the allocation over doubles the fan's time without failing any parity test (round 6: 34 -> 48 ms on 256^3 x 16 from a loop around the
-fan; 25.7 -> 30.6 from spills).  This compiles the file the way the build does and holds the production instantiations to their budget:
+"""The tile kernel's 3D fan forms sit exactly at the 168 registers that three wavefronts per SIMD leave them (tile_kernels.hip: the fan's shared
+determinants by groups, a scheduling barrier behind every group): a change that tips the allocation over costs spills or the third wavefront
+without failing any parity test (round 6: 34 -> 48 ms on 256^3 x 16 from a loop around the fan; 22 -> 28 ms from 316 bytes of spills).  This compiles the file the way the build does and holds the production instantiations to their budget:
 scratch (spills + private arrays) within what the measured build has, occupancy as designed."""
 import os
 import re
@@ -30,7 +30,7 @@ def test_tile_kernel_register_and_scratch_budget(tmp_path):
         elif cur:
             rows[cur][k] = v
     budget = {  # kernel: (max scratch bytes per lane, min occupancy in waves per SIMD)
-        "ftkx::tile_kernel<3, 2, false>": (64, 2), "ftkx::tile_kernel<3, 1, false>": (64, 2), "ftkx::tile_kernel<3, 0, false>": (64, 3),
+        "ftkx::tile_kernel<3, 2, false>": (0, 3), "ftkx::tile_kernel<3, 1, false>": (0, 3), "ftkx::tile_kernel<3, 0, false>": (0, 3),
         "ftkx::tile_kernel<2, 2, false>": (0, 4), "ftkx::tile_kernel<2, 1, false>": (0, 4), "ftkx::tile_kernel<2, 0, false>": (0, 6),
     }
     for k, (scratch, occ) in budget.items():
