@@ -99,6 +99,8 @@ def _driver_env(name, g, mode):
         env["FTK_SHIM_ONESHOT"] = "1"
     if mode == "resident_all_given":
         env["FTK_REF_PUSH_ALL"] = "1"
+    if mode == "resident_streaming":
+        env["FTK_REF_STREAMING"] = "1"
     return env
 
 
@@ -154,6 +156,25 @@ def test_patched_reference_tracker_with_scalar_vector_and_jacobian_given(name, t
         pytest.skip("oracle/_ref/ftk_shim_driver not built (needs the build container: make -C oracle ref)")
     g, d, _ = _run_shim_driver(name, "resident_all_given", tmp_path)
     _assert_dump_equals_fixture(d, g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["woven_31x37x32", "double_gyre_64x32x50", "moving_extremum_3d_21x21x21x32"])
+def test_patched_reference_tracker_with_streaming_trajectories(name, tmp_path):
+    """enable_streaming_trajectories (critical_point_tracker.hh:38; update_timestep 2d:326-330, 3d:197-201): the reference's own grow() --
+    trace_critical_points_online, critical_point_tracker.hh:523-639 -- consumes the resident sweep's records after every interval sweep
+    inside the patched update_timestep().  The trajectories and the discrete points left over are those the reference grew on the CPU
+    (tests/golden/streaming_*.npz)."""
+    if not os.path.exists(SHIM_DRIVER):
+        pytest.skip("oracle/_ref/ftk_shim_driver not built (needs the build container: make -C oracle ref)")
+    from common import load_streaming_golden
+    sg = load_streaming_golden(name)
+    g, d, _ = _run_shim_driver(name, "resident_streaming", tmp_path)
+    assert np.array_equal(d["factors"], g["factors"])
+    assert np.array_equal(np.sort(d["records"]["tag"]), sg["leftover_tags"])
+    assert len(d["curves"]) == len(sg["curves"])
+    assert sorted((tuple(t.tolist()), l) for l, t in d["curves"]) == sorted((tuple(t.tolist()), l) for l, t in sg["curves"])
+    assert len(d["pp"]) == sg["pp_count"]
 
 
 @pytest.mark.gpu
