@@ -48,13 +48,23 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
             cmd = [hipcc()] + cflags + ["-c", src, "-o", obj]
-            if verbose:
+            # the tile kernels' register / scratch / occupancy figures go to a file next to the object: tests/test_kernel_budget.py holds
+            # them to their budget without compiling the file a second time
+            keep = os.path.basename(src) == "tile_kernels.hip"
+            if verbose or keep:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            if verbose:
                 print(" ".join(cmd))
-            procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
+            err = open(obj + ".resources.txt", "w") if keep and not verbose else None
+            procs.append((cmd, subprocess.Popen(cmd, stderr=err), err))
+    for cmd, p, err in procs:
+        rc = p.wait()
+        if err:
+            err.close()
+        if rc != 0:
+            if err:
+                sys.stderr.write(open(err.name).read()[-4000:])
+            raise subprocess.CalledProcessError(rc, cmd)
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lrccl"])     # (slab_rccl.cpp: the slab pass's messages over RCCL)
     return OUT
 
