@@ -269,3 +269,45 @@ def test_random_medium_sizes_equal_the_oracle(gpu, oracle, seed):
         what = f"seed {seed}: nd {nd} nv {nv} dims {dims} {kind} [{mode}]"
         assert [int(f) for f in rf] == [int(f) for f in gf], what
         assert_records_equal(got, ref, coord_tol=0.0, what=what)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_exact_only_batches_equal_the_oracle(gpu, oracle, seed, monkeypatch):
+    """exact_only over a whole series in ONE batch: the tile kernel keeps its tile for all the steps of the launch (round 6) -- random
+    dimensions with partial tiles, scalar and vector input, every kind of trouble (values that wrap determinants, plateaus, NaN / Inf,
+    gradients below 2^-8), robust and not, every form of the kernel (FTKX_TILE_FAN) -- against the oracle, bit for bit."""
+    from common import assert_records_equal
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(52000 + seed)
+    for case in range(3):
+        nd = int(rng.choice([2, 3])); nv = int(rng.choice([1, nd])); nt = int(rng.integers(2, 8))
+        if nd == 2:
+            dims = (int(rng.choice([16, 24, 40, 64, 130, 136, 257])) + int(rng.integers(0, 2)), int(rng.integers(9, 70)))
+        else:
+            dims = (int(rng.choice([8, 16, 24, 40, 130])) + int(rng.integers(0, 2)), int(rng.integers(7, 36)), int(rng.integers(7, 20)))
+        sp = tuple(reversed(dims)); kind = str(rng.choice(KINDS))
+        steps = _field(rng, (nt,) + sp, kind) if nv == 1 else _vector_series(rng, nt, sp, kind)
+        robust = bool(rng.random() < 0.85) or nd == 2
+        fan = str(rng.choice(["0", "1", "2", "2"]))
+        monkeypatch.setenv("FTKX_TILE_FAN", fan)
+        what = f"seed {seed} case {case}: nd {nd} nv {nv} dims {dims} nt {nt} {kind} robust {robust} fan {fan}"
+        ref, rf, _ = oracle.track(steps, nd, nv, robust=robust, tag_mode=oracle.TAG_EXACT64, nthreads=8)
+        scalar = nv == 1
+        lo = 2 if scalar else 1
+        dom = ([lo] * nd, [d - (3 if scalar else 2) for d in dims])
+        ctx = gpu.Context(nd)
+        ctx.set_mesh(dom, dom, ([0] * nd, list(dims)))
+        ctx.set_options(jacobian_symmetric=scalar, derive_jacobian=1, tag_mode=gpu.TAG_EXACT64, exact_only=1, robust=int(robust))
+        keep = []
+        for t in range(nt):
+            a = torch.from_numpy(np.ascontiguousarray(steps[t])).to(dev); keep.append(a)
+            (ctx.push_scalar_slice if scalar else ctx.push_slice)(t, a)
+        scopes = [gpu.SCOPE_BOTH if t + 1 < nt else gpu.SCOPE_ORDINAL for t in range(nt)]
+        recs, f, _r = ctx.sweep_series(range(nt), scopes)
+        ctx.close()
+        assert [int(v) for v in f] == [int(v) for v in rf], (what, list(f), list(rf))
+        got = np.zeros(len(recs), dtype=[("tag", "<u8"), ("type", "<u4"), ("x", "<f8", (3,)), ("t", "<f8"), ("scalar", "<f8", (3,))])
+        for k in ("tag", "type", "x", "t", "scalar"):
+            got[k] = recs[k]
+        assert_records_equal(got, ref, coord_tol=0.0, what=what)
