@@ -3,6 +3,7 @@
 // several host threads on streams of their own, hipHostRegister around the copy, and a pinned source for reference.
 //   hipcc --offload-arch=gfx950 -O2 -o h2d_probe h2d_probe.hip -lpthread && ./h2d_probe [MiB]
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,24 @@ int main(int argc, char **argv)
   v.clear();
   for (int r = 0; r < reps; r ++) { char *h = fresh(bytes); auto t0 = clk::now(); CK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st[0])); CK(hipStreamSynchronize(st[0])); v.push_back(ms(t0, clk::now())); free(h); }
   report("fresh pageable, one hipMemcpyAsync", v);
+  v.clear();
+  for (int r = 0; r < reps; r ++) { char *h = fresh(bytes); auto t0 = clk::now(); CK(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); v.push_back(ms(t0, clk::now())); free(h); }
+  report("fresh pageable, one synchronous hipMemcpy", v);
+  v.clear();
+  for (int r = 0; r < reps; r ++) { char *h = fresh(bytes); auto t0 = clk::now(); CK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, 0)); CK(hipStreamSynchronize(0)); v.push_back(ms(t0, clk::now())); free(h); }
+  report("fresh pageable, hipMemcpyAsync on the null stream", v);
+  v.clear();
+  for (int r = 0; r < reps; r ++) {      // the same, but the array's pages touched by the copy's own thread right before (a caller that has just written it)
+    char *h = (char *)malloc(bytes); for (size_t i = 0; i < bytes; i += 4096) h[i] = 1;
+    auto t0 = clk::now(); CK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st[0])); CK(hipStreamSynchronize(st[0])); v.push_back(ms(t0, clk::now())); free(h);
+  }
+  report("fresh pageable (one write per page), hipMemcpyAsync", v);
+  v.clear();
+  for (int r = 0; r < reps; r ++) {      // 2 MiB-aligned and advised huge: what the kernel has to pin is 64 pages instead of 32 768
+    char *h = (char *)aligned_alloc(2u << 20, bytes); madvise(h, bytes, MADV_HUGEPAGE); memset(h, 1, bytes);
+    auto t0 = clk::now(); CK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st[0])); CK(hipStreamSynchronize(st[0])); v.push_back(ms(t0, clk::now())); free(h);
+  }
+  report("fresh pageable, 2 MiB-aligned + MADV_HUGEPAGE", v);
   for (int chunks : {2, 4, 8, 16}) {
     v.clear();
     for (int r = 0; r < reps; r ++) {
