@@ -440,13 +440,11 @@ def patched_reference_tracker(synthetic, expect_records=None):
     out = {"workload": "moving_extremum_3d 256x256x256, host-fed scalar snapshots (8 B/vertex), the reference's own push / advance_timestep loop",
            "binary": "oracle/_ref/ftk_shim_driver (the reference's trackers + patches/ftk-xl-hip.patch, no override)"}
 
-    def run(nt, oneshot, hugepages=False):
+    def run(nt, oneshot):
         env = {k: v for k, v in os.environ.items() if not k.startswith(("FTK_REF_", "FTK_SHIM_"))}
         env["FTK_REF_PER_CALL"] = "1"
         if oneshot:
             env["FTK_SHIM_ONESHOT"] = "1"
-        if hugepages:
-            env["GLIBC_TUNABLES"] = "glibc.malloc.hugetlb=1"
         cmd = [drv, "synthetic", "moving_extremum_3d", str(dims[0]), str(dims[1]), str(dims[2]), str(nt), "/dev/null"] + [repr(float(v)) for v in list(x0) + list(dv)]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True, env=env)
         lines = r.stdout.decode().strip().splitlines()
@@ -466,17 +464,6 @@ def patched_reference_tracker(synthetic, expect_records=None):
                            "host_GB/s": 8.0 * nvert / (med(push) * 1e-3) / 1e9, "records": info["records"], "hip_resident": info["hip_resident"],
                            "ok": bool(info["hip_resident"] and info["records"] >= 1 and (expect_records is None or info["records"] == expect_records)),
                            "note": "median over steps 1..15 of push (upload of the pageable ndarray) + update_timestep (one device-driven pass, records through the reference's from_work_index / to_integer loops)"}
-        # The same binary with ONE environment variable for the application: glibc then backs large allocations -- the ndarray<double>s the caller
-        # makes per timestep -- with transparent huge pages (this pool runs THP in `madvise` mode), and what the runtime has to pin for the
-        # copy is 64 pages instead of 32 768: the push runs at the pinned rate whatever the box (tools/probe/h2d_probe.hip).
-        try:
-            info2, per2 = run(16, False, hugepages=True)
-            push2, upd2 = per2["push_ms"][1:], per2["update_ms"][1:-1]
-            out["resident_hugepage_arrays"] = {"environment": "GLIBC_TUNABLES=glibc.malloc.hugetlb=1", "timesteps": 16, "ms_per_step": med(push2) + med(upd2), "push_ms": med(push2),
-                                               "update_timestep_ms": med(upd2), "host_GB/s": 8.0 * nvert / (med(push2) * 1e-3) / 1e9, "records": info2["records"],
-                                               "ok": bool(info2["hip_resident"] and info2["records"] == info["records"])}
-        except Exception as e:   # noqa: BLE001
-            out["resident_hugepage_arrays"] = {"error": repr(e)}
         info1, per1 = run(3, True)
         push1, upd1 = per1["push_ms"][1:], per1["update_ms"][1:-1]
         out["one_shot"] = {"timesteps": 3, "ms_per_step": med(push1) + med(upd1), "push_ms": med(push1), "update_timestep_ms": med(upd1),
