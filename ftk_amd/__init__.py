@@ -339,6 +339,12 @@ class Context:
         """profiling aid: the tile kernel's fan phase `repeat` times per tile and step from the next sweep on (1 = off)"""
         self._ck(self._L.ftkx_debug_tile_repeat(self._h, int(repeat)))
 
+    def upload_counts(self):
+        """(staged, direct): host arrays of this context that went up through the library's pinned staging / the runtime's own copy"""
+        a = C.c_ulonglong(0); b = C.c_ulonglong(0)
+        self._ck(self._L.ftkx_debug_upload_counts(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def kernel_times(self):
         """{kernel: (summed device ms, launches)} measured with HIP events on the context's stream"""
         ms = (C.c_double * 4)(); n = (C.c_ulonglong * 4)()

@@ -86,7 +86,7 @@ EXPORTS = [
     "ftkx_create", "ftkx_destroy", "ftkx_last_error", "ftkx_set_stream", "ftkx_set_options", "ftkx_default_options", "ftkx_set_mesh",
     "ftkx_push_slice", "ftkx_push_scalar_slice", "ftkx_drop_slice", "ftkx_slice_resolution", "ftkx_slices_resolution", "ftkx_slices_prepare", "ftkx_sweep_announce", "ftkx_set_slice_resolution", "ftkx_export_masks_size", "ftkx_export_masks", "ftkx_push_masked_slice", "ftkx_packed_masks_bytes", "ftkx_export_masks_packed", "ftkx_push_masked_slice_packed", "ftkx_sweep_cull", "ftkx_get_sparse_cells", "ftkx_patch_doubles", "ftkx_gather_patches", "ftkx_scatter_patches", "ftkx_scaling_factor",
     "ftkx_sweep", "ftkx_sweep_series", "ftkx_sweep_series_submit", "ftkx_sweep_series_complete", "ftkx_sweep_series_abort", "ftkx_series_dist_cells", "ftkx_series_dist_begin", "ftkx_series_dist_cull", "ftkx_series_dist_serve", "ftkx_series_dist_finish", "ftkx_series_dist_status", "ftkx_series_last_path", "ftkx_series_split_decision", "ftkx_sweep_enqueue", "ftkx_sweep_enqueue_many", "ftkx_sweep_collect", "ftkx_sweep_cancel", "ftkx_get_stats", "ftkx_invalidate_masks", "ftkx_debug_stream_read", "ftkx_debug_tile_repeat", "ftkx_set_profiling", "ftkx_get_kernel_times", "ftkx_extract_cp2dt", "ftkx_extract_cp3dt", "ftkx_free",
-    "ftkx_trace_curves", "ftkx_trace_curves_ctx", "ftkx_trace_curves_tags_ctx", "ftkx_free_curves", "ftkx_post_process_curves", "ftkx_free_trajectories", "ftkx_format_from_path", "ftkx_write_critical_points", "ftkx_read_critical_points", "ftkx_write_traced_critical_points", "ftkx_read_traced_critical_points", "ftkx_gradient2D", "ftkx_jacobian2D", "ftkx_gradient3D", "ftkx_jacobian3D", "ftkx_version", "ftkx_device_count", "ftkx_pointer_device", "ftkx_context_device", "ftkx_last_mask_kernel", "ftkx_debug_mask_kernel_launches",
+    "ftkx_trace_curves", "ftkx_trace_curves_ctx", "ftkx_trace_curves_tags_ctx", "ftkx_free_curves", "ftkx_post_process_curves", "ftkx_free_trajectories", "ftkx_format_from_path", "ftkx_write_critical_points", "ftkx_read_critical_points", "ftkx_write_traced_critical_points", "ftkx_read_traced_critical_points", "ftkx_gradient2D", "ftkx_jacobian2D", "ftkx_gradient3D", "ftkx_jacobian3D", "ftkx_version", "ftkx_device_count", "ftkx_pointer_device", "ftkx_context_device", "ftkx_last_mask_kernel", "ftkx_debug_mask_kernel_launches", "ftkx_debug_upload_counts", "ftkx_debug_mask_relaunch",
     "ftkx_tracker_post_process", "ftkx_tracker_get_curve_points", "ftkx_tracker_write", "ftkx_tracker_read_critical_points",
     "ftkx_tracker_create", "ftkx_tracker_create_multi", "ftkx_tracker_sync", "ftkx_tracker_destroy", "ftkx_tracker_last_error", "ftkx_tracker_set_domain", "ftkx_tracker_set_array_domain",
     "ftkx_tracker_set_sources", "ftkx_tracker_set_flags", "ftkx_tracker_set_stream", "ftkx_tracker_set_current_timestep", "ftkx_tracker_set_enable_streaming_trajectories", "ftkx_tracker_set_deferred_collection", "ftkx_tracker_set_communicator", "ftkx_tracker_set_slab_transport", "ftkx_tracker_set_slab_hub", "ftkx_online_tracer_create", "ftkx_online_tracer_destroy", "ftkx_online_tracer_grow", "ftkx_online_tracer_curves", "ftkx_tracker_set_coords_bounds", "ftkx_tracker_set_coords_rectilinear", "ftkx_tracker_set_coords_explicit", "ftkx_set_coords_rectilinear", "ftkx_set_coords_explicit", "ftkx_tracker_initialize",
@@ -140,6 +140,8 @@ def load():
     L.ftkx_invalidate_masks.argtypes = [vp]
     L.ftkx_debug_stream_read.argtypes = [vp, vp, C.c_size_t]
     L.ftkx_debug_tile_repeat.argtypes = [vp, C.c_int]
+    L.ftkx_debug_upload_counts.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    L.ftkx_debug_mask_relaunch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.ftkx_series_split_decision.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ftkx_get_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]
     L.ftkx_extract_cp2dt.argtypes = [C.c_int, C.c_int] + [ll3] * 6 + [dbl] * 6 + [C.c_int, dbl, C.c_ulonglong, C.POINTER(Options), C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", f) for f in ("tile_kernels.hip", "mask_kernels.hip", "cull_exact_kernels.hip", "halo_kernels.hip", "derive_kernels.hip", "ftkx_api.hip", "prepare.hip", "collect.hip", "halo.hip", "series.hip", "series_kernels.hip", "one_kernel.hip", "dist_kernels.hip", "trace_device.hip", "tracker.cpp", "trace.cpp", "io.cpp", "slab.cpp", "slab_rccl.cpp")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("tile_kernels.hip", "mask_kernels.hip", "cull_exact_kernels.hip", "halo_kernels.hip", "derive_kernels.hip", "ftkx_api.hip", "prepare.hip", "collect.hip", "halo.hip", "series.hip", "series_kernels.hip", "one_kernel.hip", "dist_kernels.hip", "trace_device.hip", "tracker.cpp", "trace.cpp", "io.cpp", "slab.cpp", "slab_rccl.cpp", "upload.cpp")]
 OUT = os.path.join(HERE, "libftkx.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]

@@ -243,6 +243,7 @@ struct ftkx_ctx {
   size_t h_red_cap = 0;             //   (slots it can hold; the flag lives behind them)
   unsigned red_seq = 0;
   int dense_collects = 0;           // > 0: the last fast collect found most cells surviving; fast requests run MODE_TILE_CULL for a while
+  unsigned long long uploads_staged = 0, uploads_direct = 0;   // ftkx_debug_upload_counts (upload.cpp)
   int tile_repeat = 1;              // ftkx_debug_tile_repeat: the tile kernel's fan phase that many times per tile (the int-VALU yardstick of bench.py)
   // compact halo: the compacted mask words of the last ftkx_export_masks_size, the surviving cells of the last ftkx_sweep_cull
   unsigned *d_word_idx = nullptr; u64 *d_words = nullptr; size_t words_cap = 0, n_words = 0; int words_t = -1;
@@ -352,7 +353,7 @@ bool pow2_factor(u64 factor);
 bool masks_valid(const ftkx_ctx *c, const Slice &s, u64 factor, bool two_level, int u_rows);
 double job_big(const ftkx_ctx *c, const Slice &s, u64 factor, bool *rule_on);
 int ensure_mask_arrays(ftkx_ctx *c, Slice &s, bool two_level);
-int upload_from_host(ftkx_ctx *c, void *dst, const void *src, size_t bytes);
+int upload_from_host(ftkx_ctx *c, void *dst, const void *src, size_t bytes);       // upload.cpp
 int aux_stream_get(ftkx_ctx *c, bool high_priority, hipStream_t *out);       // the library's own streams, kept for the process (ftkx_api.hip)
 void aux_stream_put(ftkx_ctx *c, bool high_priority, hipStream_t st);
 // halo.hip

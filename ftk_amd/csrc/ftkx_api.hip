@@ -264,18 +264,7 @@ double job_big(const ftkx_ctx *c, const Slice &s, u64 factor, bool *rule_on)
   return off ? HUGE_VAL : big_threshold(c->nd, factor);
 }
 
-// ---- host memory -> HBM -------------------------------------------------------------------------------------------------------------
-// The reference boundary hands HOST arrays over on every call (critical_point_tracker_2d_regular.hh:369-384; its CUDA back-end
-// cudaMemcpy's them from pageable memory, src/filters/critical_point_tracer_2d_regular.cu:194-232).  A 512^3 slice is 1 GiB: the
-// upload, not the sweep, is what such a call costs.  The runtime's own pageable copy runs at 96 % of a pinned hipMemcpyAsync on this
-// platform (54.6 of 56.8 GB/s measured, bench.py `streaming_tracker.host_fed`); a hand-made ring of pinned staging buffers filled by
-// eight host threads reached 33 GB/s and was dropped again.
-int upload_from_host(ftkx_ctx *c, void *dst, const void *src, size_t bytes)
-{
-  HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));            // (the caller may reuse its array on return)
-  return FTKX_OK;
-}
+// (host memory -> HBM: upload.cpp)
 
 // ---- the library's auxiliary streams ----------------------------------------------------------------------------------------------
 // A pass's tail (series.hip) and the copy of its records run on streams of the library's own.  They are kept for the PROCESS, per device and

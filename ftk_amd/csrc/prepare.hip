@@ -248,6 +248,47 @@ int ftkx_slices_prepare(ftkx_ctx *c, const int *ts, int n, unsigned long long fa
   return FTKX_OK;
 }
 
+// PROBE (tools/mask_overlap.py): slice t's mask job launched `reps` times back to back -- on the context's stream alone (nstreams 1) or
+// alternately on it and on a second stream of the same priority (2), with a small dependent kernel in front of each launch when
+// with_begin (the series pass's begin kernel) -- and the device time per launch.  The slice's masks must exist (ftkx_slices_prepare).
+int ftkx_debug_mask_relaunch(ftkx_ctx *c, int t, int reps, int nstreams, int with_begin, double *ms_per_launch)
+{
+  if (!c || !ms_per_launch || reps < 1 || nstreams < 1 || nstreams > 2) return fail(c, FTKX_E_INVALID, "ftkx_debug_mask_relaunch: bad argument");
+  auto it = c->slices.find(t);
+  if (it == c->slices.end()) return fail(c, FTKX_E_NOSLICE, "ftkx_debug_mask_relaunch: timestep %d not resident", t);
+  Slice &s = it->second;
+  Mesh m; fill_mesh(c, m);
+  const bool two_level = ftkx::masks_have_summary(m);
+  if (!s.M || (two_level && !s.U) || !c->d_red || s.sparse) return fail(c, FTKX_E_INVALID, "ftkx_debug_mask_relaunch: ftkx_slices_prepare first");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure_desc(c, 2 * 4096))) return rc;
+  MaskJob *job = (MaskJob *)c->h_desc;
+  *job = with_lean_thresholds(MaskJob{s.S, s.V, s.M, two_level ? s.U : nullptr, c->d_red, 1.0 / 256.0, HUGE_VAL}, m);
+  HIP_TRY(c, hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(MaskJob), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  hipStream_t st[2] = {c->stream, nullptr};
+  if (nstreams == 2 && (rc = aux_stream_get(c, false, &st[1]))) return rc;
+  hipEvent_t e0, e1, eb;
+  HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1)); HIP_TRY(c, hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(e0, st[0]));
+  if (nstreams == 2) HIP_TRY(c, hipStreamWaitEvent(st[1], e0, 0));
+  for (int r = 0; r < reps; r ++) {
+    hipStream_t q = st[r % nstreams];
+    if (with_begin) launch_fetch_desc(c->h_desc, (char *)c->d_desc + 4096, 4096, q);
+    ftkx::launch_masks(m, (const MaskJob *)c->d_desc, 1, q);
+  }
+  if (nstreams == 2) { HIP_TRY(c, hipEventRecord(eb, st[1])); HIP_TRY(c, hipStreamWaitEvent(st[0], eb, 0)); }
+  HIP_TRY(c, hipEventRecord(e1, st[0]));
+  HIP_TRY(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(eb);
+  if (st[1]) aux_stream_put(c, false, st[1]);
+  *ms_per_launch = (double)ms / reps;
+  return FTKX_OK;
+}
+
 // The sweeps that will follow the next ftkx_slices_prepare, in the order they will be enqueued: that call then queues their cull
 // right behind the mask kernel (it needs the masks, not the factor), so that it runs while the host still waits for the reduction
 // and forms the factors.  A hint, never an obligation: ftkx_sweep_collect uses the list only if the pending sweeps are exactly these.

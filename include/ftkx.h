@@ -414,6 +414,15 @@ const char *ftkx_last_mask_kernel(void);
  * suite / a workload reached -- every kernel behind launch_masks is reachable by some mesh, none is there for history's sake */
 int ftkx_debug_mask_kernel_launches(unsigned long long *launches, const char **names, int n);
 
+/* profiling aid: how the host arrays this context was handed (on_device = 0) reached HBM -- staged by the library's copy threads through
+ * pinned pieces (pageable sources of 32 MiB and more; FTKX_UPLOAD_THREADS, default 4, 0 = never) or by the runtime's own copy */
+int ftkx_debug_upload_counts(const ftkx_ctx *ctx, unsigned long long *staged, unsigned long long *direct);
+
+/* profiling aid (tools/mask_overlap.py): slice t's mask job -- its masks must exist, ftkx_slices_prepare -- launched `reps` times back to
+ * back on the context's stream (nstreams 1) or alternately on it and a second stream (2), with a small dependent kernel in front of each
+ * launch when with_begin; device time per launch.  What a streaming tracker's one-slice launch pays for its ramp. */
+int ftkx_debug_mask_relaunch(ftkx_ctx *ctx, int t, int reps, int nstreams, int with_begin, double *ms_per_launch);
+
 /* library / device identification */
 const char *ftkx_version(void);
 int ftkx_device_count(void);
