@@ -19,6 +19,8 @@
 //    process's first ten then take 9-10 ms: a hipMemcpyAsync blocks for 6.5-8 ms where the runtime brings up another DMA queue the first time
 //    it finds the ones it has busy (more of them with six streams; a warm-up of concurrent copies moved some of them into the first call,
 //    not all).  Two streams: none in 60 uploads.  One stream: 3.3 ms, the gaps between its copies show.
+//  * 1 GiB (a 512^3 snapshot): 8 MiB pieces 19.5-20.0 ms = 0.95-0.97 of a pinned source, fresh array or not; 4 MiB pieces 22.1, 16 MiB 20.9;
+//    the runtime's copy 19.2 for an array it knows, 21.1 (calls of 25-28) for a fresh one.
 // The staged path is taken for pageable sources of kStagedMinBytes and more; pinned or registered sources and small arrays go through the
 // runtime's copy.  FTKX_UPLOAD_THREADS: the number of copy threads (default 4, the caller's thread is one of them); 0 or 1: the runtime's
 // copy always.
@@ -32,17 +34,19 @@ using namespace ftkxh;
 
 namespace {
 
-constexpr size_t kPiece = 4u << 20;            // one DMA
+constexpr size_t kPieceSmall = 4u << 20;       // one DMA ...
+constexpr size_t kPieceBig = 8u << 20;         // ... of arrays of kBigBytes and more: 1 GiB in 19.5 ms (55 GB/s, 0.97 of a pinned source) against 22.1 with
+constexpr size_t kBigBytes = 256u << 20;       // 4 MiB pieces (~10 us are lost per DMA); 128 MiB in 2.85 ms with 4 MiB pieces against 2.98 with 8 (the first piece's memcpy)
 constexpr int kRing = 4;                       // pinned pieces per thread
 constexpr int kMaxLanes = 8;
 constexpr int kDmaStreams = 2;                 // lane l queues its DMAs on stream l % kDmaStreams
 constexpr size_t kStagedMinBytes = 32u << 20;
 
-struct Lane { char *pin = nullptr; hipEvent_t ev[kRing] = {}; };
+struct Lane { char *pin = nullptr; size_t pin_bytes = 0; hipEvent_t ev[kRing] = {}; };
 struct Engine { Lane lane[kMaxLanes]; int lanes = 0; hipStream_t dma[kDmaStreams] = {}; hipEvent_t gate = nullptr; };
 
 std::mutex g_mutex;                            // one staged upload at a time per process: the pinned rings are the process's
-std::map<int, Engine> g_engine;                // per device; kept for the process (64 MiB of pinned memory at four lanes)
+std::map<int, Engine> g_engine;                // per device; kept for the process (64 MiB of pinned memory at four lanes, 128 once a big array has come)
 
 int upload_threads()
 {
@@ -61,21 +65,25 @@ bool source_is_pageable(const void *src)
   return a.type == hipMemoryTypeUnregistered;
 }
 
-int ensure_lanes(ftkx_ctx *c, Engine &E, int want)
+int ensure_lanes(ftkx_ctx *c, Engine &E, int want, size_t piece)
 {
   if (!E.gate) HIP_TRY(c, hipEventCreateWithFlags(&E.gate, hipEventDisableTiming));
   for (hipStream_t &s : E.dma) if (!s) HIP_TRY(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-  while (E.lanes < want) {
-    Lane &L = E.lane[E.lanes];
-    if (!L.pin) HIP_TRY(c, hipHostMalloc((void **)&L.pin, kPiece * kRing, hipHostMallocDefault));
+  if (E.lanes < want) E.lanes = want;
+  for (int l = 0; l < want; l ++) {
+    Lane &L = E.lane[l];
+    if (L.pin_bytes < piece * kRing) {           // (no upload is in flight: every one of them has waited for its DMAs)
+      if (L.pin) { HIP_TRY(c, hipHostFree(L.pin)); L.pin = nullptr; L.pin_bytes = 0; }
+      HIP_TRY(c, hipHostMalloc((void **)&L.pin, piece * kRing, hipHostMallocDefault));
+      L.pin_bytes = piece * kRing;
+    }
     for (hipEvent_t &e : L.ev) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    E.lanes ++;
   }
   return FTKX_OK;
 }
 
 struct Job {
-  int device; char *dst; const char *src; size_t bytes, npieces;
+  int device; char *dst; const char *src; size_t bytes, piece, npieces;
   std::atomic<size_t> next{0};
   std::atomic<int> err{0};                     // the first hipError_t any lane met; the others stop at their next piece
   int line = 0;
@@ -94,9 +102,9 @@ void lane_work(Job &J, Lane &L, hipStream_t st)
     if (i >= J.npieces) break;
     const int slot = (int)(mine % kRing);
     if (mine >= (size_t)kRing) LANE_TRY(hipEventSynchronize(L.ev[slot]));      // (the DMA that last read this pinned piece)
-    const size_t off = i * kPiece, len = std::min(kPiece, J.bytes - off);
-    memcpy(L.pin + (size_t)slot * kPiece, J.src + off, len);
-    LANE_TRY(hipMemcpyAsync(J.dst + off, L.pin + (size_t)slot * kPiece, len, hipMemcpyHostToDevice, st));
+    const size_t off = i * J.piece, len = std::min(J.piece, J.bytes - off);
+    memcpy(L.pin + (size_t)slot * J.piece, J.src + off, len);
+    LANE_TRY(hipMemcpyAsync(J.dst + off, L.pin + (size_t)slot * J.piece, len, hipMemcpyHostToDevice, st));
     LANE_TRY(hipEventRecord(L.ev[slot], st));
     mine ++;
   }
@@ -109,14 +117,15 @@ int staged_upload(ftkx_ctx *c, void *dst, const void *src, size_t bytes, int thr
   std::unique_lock<std::mutex> lock(g_mutex, std::try_to_lock);
   if (!lock.owns_lock()) return 1;             // (another context of the process is uploading: the rings are taken)
   Engine &E = g_engine[c->device];
-  int rc = ensure_lanes(c, E, threads);
+  const size_t piece = bytes >= kBigBytes ? kPieceBig : kPieceSmall;
+  int rc = ensure_lanes(c, E, threads, piece);
   if (rc) return rc;
   // behind whatever the context's stream still does with the destination (an array recycled from a dropped slice: free_slice has made the
   // stream wait for the passes that read it)
   HIP_TRY(c, hipEventRecord(E.gate, c->stream));
   for (hipStream_t s : E.dma) HIP_TRY(c, hipStreamWaitEvent(s, E.gate, 0));
   Job J;
-  J.device = c->device; J.dst = (char *)dst; J.src = (const char *)src; J.bytes = bytes; J.npieces = (bytes + kPiece - 1) / kPiece;
+  J.device = c->device; J.dst = (char *)dst; J.src = (const char *)src; J.bytes = bytes; J.piece = piece; J.npieces = (bytes + piece - 1) / piece;
   std::vector<std::thread> th;
   th.reserve((size_t)threads);
   for (int l = 1; l < threads; l ++) {

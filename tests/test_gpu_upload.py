@@ -45,7 +45,8 @@ def _sweep(gpu, dims, slices, *, scalar, poison):
     return recs, f, run, counts
 
 
-@pytest.mark.parametrize("case,dims,scalar", [("woven", (2500, 2100), True), ("double_gyre", (2200, 1000), False)], ids=["scalar_2d", "vector_2d"])
+@pytest.mark.parametrize("case,dims,scalar", [("woven", (2500, 2100), True), ("double_gyre", (2200, 1000), False), ("woven", (6000, 5600), True)],
+                         ids=["scalar_2d", "vector_2d", "scalar_2d_256MiB"])
 def test_staged_upload_equals_the_runtimes_copy_equals_device_fed(gpu, monkeypatch, case, dims, scalar):
     import torch
     from ftk_amd import synthetic
@@ -54,7 +55,7 @@ def test_staged_upload_equals_the_runtimes_copy_equals_device_fed(gpu, monkeypat
     dev_slices = [synthetic.generate(case, dims, t, nt, torch, dev) for t in range(nt)]
     torch.cuda.synchronize()
     host = [np.ascontiguousarray(a.cpu().numpy()) for a in dev_slices]
-    assert host[0].nbytes >= 32 << 20 and host[0].nbytes % (4 << 20) != 0       # (staged, and the last piece ragged)
+    assert host[0].nbytes >= 32 << 20 and host[0].nbytes % (8 << 20) != 0 and host[0].nbytes % (4 << 20) != 0   # (staged, and the last piece ragged; 256 MiB and more: 8 MiB pieces)
     want, fw, rw, cw = _sweep(gpu, dims, dev_slices, scalar=scalar, poison=False)
     assert cw == (0, 0) and len(want) > 500
     monkeypatch.setenv("FTKX_UPLOAD_THREADS", "0")
