@@ -463,7 +463,7 @@ def patched_reference_tracker(synthetic, expect_records=None):
                            "first_push_ms": per["push_ms"][0], "first_update_ms": per["update_ms"][0],
                            "host_GB/s": 8.0 * nvert / (med(push) * 1e-3) / 1e9, "records": info["records"], "hip_resident": info["hip_resident"],
                            "ok": bool(info["hip_resident"] and info["records"] >= 1 and (expect_records is None or info["records"] == expect_records)),
-                           "note": "median over steps 1..15 of push (upload of the pageable ndarray) + update_timestep (one device-driven pass, records through the reference's from_work_index / to_integer loops)"}
+                           "note": "median over steps 1..15 of push (the fresh pageable ndarray staged through pinned pieces by the library's copy threads, ftk_amd/csrc/upload.cpp) + update_timestep (one device-driven pass, records through the reference's from_work_index / to_integer loops)"}
         info1, per1 = run(3, True)
         push1, upd1 = per1["push_ms"][1:], per1["update_ms"][1:-1]
         out["one_shot"] = {"timesteps": 3, "ms_per_step": med(push1) + med(upd1), "push_ms": med(push1), "update_timestep_ms": med(upd1),
@@ -570,7 +570,7 @@ def streaming_tracker(nd, case, dims, nt_run, torch, dev, ftk_amd, synthetic, ho
         best = dt if best is None or dt < best else best
     out["host_fed"] = {"timesteps": h, "bytes_per_step": bytes_each, "ms_per_step": best / h * 1e3, "GB/s": bytes_each * h / best / 1e9,
                        "pinned_hipMemcpyAsync_GB/s": pinned_rate, "frac_of_pinned": bytes_each * h / best / 1e9 / pinned_rate,
-                       "note": "pageable host arrays (numpy), uploaded by the push; the sweep of every step included"}
+                       "note": "pageable host arrays (numpy, 1 GiB each at 512^3), staged by the push through pinned pieces (upload.cpp); the sweep of every step included"}
     return out
 
 
