@@ -14,7 +14,7 @@ import pytest
 
 from common import assert_records_equal
 from refdump import read_dump, write_input
-from test_gpu_fuzz import _field, _vector_series, KINDS
+from test_gpu_fuzz import _field, _vector_series, KINDS, FUZZ_OFFSET
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,7 +46,7 @@ def _reference(steps, nd, nv, env):
 @pytest.mark.parametrize("seed", range(25))
 def test_random_series_equal_the_real_reference(gpu, seed):
     from gpu_common import run_tracker
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + FUZZ_OFFSET + seed)
     for case in range(4):
         nd = int(rng.choice([2, 3]))
         nv = int(rng.choice([1, nd]))
