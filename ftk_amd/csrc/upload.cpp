@@ -26,6 +26,8 @@
 // copy always.
 #include "ctx.hpp"
 
+#include <sched.h>
+
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -48,10 +50,17 @@ struct Engine { Lane lane[kMaxLanes]; int lanes = 0; hipStream_t dma[kDmaStreams
 std::mutex g_mutex;                            // one staged upload at a time per process: the pinned rings are the process's
 std::map<int, Engine> g_engine;                // per device; kept for the process (64 MiB of pinned memory at four lanes, 128 once a big array has come)
 
+// (default: four, or as many CPUs as the process may run on if those are fewer -- copy threads that share a CPU are slower than the runtime's copy)
 int upload_threads()
 {
   const char *e = getenv("FTKX_UPLOAD_THREADS");
-  const int t = e ? atoi(e) : 4;
+  int t = 4;
+  if (e) t = atoi(e);
+  else {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) t = std::min(t, CPU_COUNT(&set));
+  }
   return t < 0 ? 0 : (t > kMaxLanes ? kMaxLanes : t);
 }
 
