@@ -141,7 +141,7 @@ int staged_upload(ftkx_ctx *c, void *dst, const void *src, size_t bytes, int thr
   J.device = c->device; J.dst = (char *)dst; J.src = (const char *)src; J.bytes = bytes; J.piece = piece; J.npieces = (bytes + piece - 1) / piece;
   // Starting a thread costs 40 us in a process that has the runtime loaded: the caller starts ONE and goes to work, that one starts the others
   // before its own lane (the first DMA is on its way 0.1 ms earlier).  th[0] is joined first: what it wrote into th[1..] is visible then.
-  std::vector<std::thread> th((size_t)std::max(0, threads - 1));
+  std::thread th[kMaxLanes];                   // (th[l - 1]: lane l)
   auto start = [&](int l) {                    // lane l on a thread of its own; false: no thread to be had (the lanes that run take all the pieces)
     try { th[(size_t)l - 1] = std::thread(lane_work, std::ref(J), std::ref(E.lane[l]), E.dma[l % kDmaStreams]); return true; }
     catch (...) { return false; }
@@ -156,7 +156,7 @@ int staged_upload(ftkx_ctx *c, void *dst, const void *src, size_t bytes, int thr
     } catch (...) {}
   }
   lane_work(J, E.lane[0], E.dma[0]);
-  for (std::thread &t : th) if (t.joinable()) t.join();
+  for (std::thread &t : th) if (t.joinable()) t.join();         // (in order: th[0] first)
   if (const int e = J.err.load()) {
     for (hipStream_t s : E.dma) (void)hipStreamSynchronize(s);          // (nothing of this upload is in flight when the error is reported)
     return fail(c, e == (int)hipErrorOutOfMemory ? FTKX_E_NOMEM : FTKX_E_DEVICE, "upload: %s (%s:%d)", hipGetErrorString((hipError_t)e), __FILE__, J.line);
