@@ -95,3 +95,43 @@ def test_small_and_pinned_sources_take_the_runtimes_copy(gpu, monkeypatch):
     recs, _, _ = ctx.sweep_series([0, 1], [gpu.SCOPE_BOTH, gpu.SCOPE_ORDINAL])
     ctx.close()
     assert len(recs) > 100
+
+
+def test_two_contexts_pushing_at_once_share_the_staging_without_mixing_anything(gpu, monkeypatch):
+    """the pinned rings are the process's: of two contexts that push at the same moment one is staged, the other takes the runtime's copy
+    (upload.cpp: try_lock) -- both must end up with their own data"""
+    import threading
+    import torch
+    from ftk_amd import synthetic
+    monkeypatch.delenv("FTKX_UPLOAD_THREADS", raising=False)
+    dev = torch.device("cuda", 0)
+    dims, nt = (2500, 2100), 4
+    series = {}
+    for name, case in (("a", "woven"), ("b", "moving_extremum_2d")):
+        d = [synthetic.generate(case, dims, t, nt, torch, dev) for t in range(nt)]
+        torch.cuda.synchronize()
+        series[name] = (d, [np.ascontiguousarray(x.cpu().numpy()) for x in d])
+    want = {k: _sweep(gpu, dims, v[0], scalar=True, poison=False) for k, v in series.items()}
+    got, errors = {}, []
+    go = threading.Barrier(2)
+
+    def work(name):
+        try:
+            go.wait()
+            got[name] = _sweep(gpu, dims, series[name][1], scalar=True, poison=True)
+        except Exception as e:      # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    for rep in range(3):
+        got.clear()
+        th = [threading.Thread(target=work, args=(n,)) for n in series]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        for n in series:
+            recs, f, run, counts = got[n]
+            assert recs.tobytes() == want[n][0].tobytes() and np.array_equal(f, want[n][1]) and run == want[n][2], n
+            assert sum(counts) == 2 * nt
+    # (over three rounds of eight pushes each both ways were taken, with overwhelming likelihood; not asserted: a race is not a guarantee)
