@@ -105,7 +105,9 @@ int ftkx_set_coords_explicit(ftkx_ctx *ctx, const double *coords, int ncomp, siz
 
 /* ---- slices resident in HBM (== field_data_snapshots, critical_point_tracker.hh:155-159) --------------------- */
 /* V required; J, S nullable.  on_device = 0: host pointers, copied to the device; 1: device pointers (of this context's device),
- * adopted without a copy and owned by the caller until ftkx_drop_slice(); 2: device pointers of any device, copied (peer copy). */
+ * adopted without a copy and owned by the caller until ftkx_drop_slice(); 2: device pointers of any device, copied (peer copy).
+ * Host arrays are in HBM when the call returns (the caller may reuse or free them); pageable ones of 32 MiB and more are staged by a few
+ * threads the call starts and joins (FTKX_UPLOAD_THREADS, default 4; 0: the runtime's own copy), pinned ones go by DMA as they are. */
 int ftkx_push_slice(ftkx_ctx *ctx, int t, const double *V, const double *J, const double *S, int on_device);
 /* scalar input (vector_field_source == SOURCE_DERIVED, 2d:238-250, 3d:125-137): uploads S and derives V = gradient2D/3D(S)
  * on the device bit-for-bit like ndarray/grad.hh.  With options.derive_jacobian the Jacobian at hit vertices is the one
