@@ -74,20 +74,24 @@ bool source_is_pageable(const void *src)
   return a.type == hipMemoryTypeUnregistered;
 }
 
-int ensure_lanes(ftkx_ctx *c, Engine &E, int want, size_t piece)
+// (what the staging needs and cannot get -- pinned memory is a limited resource of the process -- is not an error of the push: +1, and the
+// array goes up by the runtime's copy)
+int ensure_lanes(Engine &E, int want, size_t piece)
 {
-  if (!E.gate) HIP_TRY(c, hipEventCreateWithFlags(&E.gate, hipEventDisableTiming));
-  for (hipStream_t &s : E.dma) if (!s) HIP_TRY(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+#define LANES_TRY(call) do { if ((call) != hipSuccess) { (void)hipGetLastError(); return 1; } } while (0)
+  if (!E.gate) LANES_TRY(hipEventCreateWithFlags(&E.gate, hipEventDisableTiming));
+  for (hipStream_t &s : E.dma) if (!s) LANES_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   if (E.lanes < want) E.lanes = want;
   for (int l = 0; l < want; l ++) {
     Lane &L = E.lane[l];
     if (L.pin_bytes < piece * kRing) {           // (no upload is in flight: every one of them has waited for its DMAs)
-      if (L.pin) { HIP_TRY(c, hipHostFree(L.pin)); L.pin = nullptr; L.pin_bytes = 0; }
-      HIP_TRY(c, hipHostMalloc((void **)&L.pin, piece * kRing, hipHostMallocDefault));
+      if (L.pin) { char *old = L.pin; L.pin = nullptr; L.pin_bytes = 0; LANES_TRY(hipHostFree(old)); }
+      if (hipHostMalloc((void **)&L.pin, piece * kRing, hipHostMallocDefault) != hipSuccess) { L.pin = nullptr; (void)hipGetLastError(); return 1; }
       L.pin_bytes = piece * kRing;
     }
-    for (hipEvent_t &e : L.ev) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t &e : L.ev) if (!e) LANES_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
+#undef LANES_TRY
   return FTKX_OK;
 }
 
@@ -127,8 +131,7 @@ int staged_upload(ftkx_ctx *c, void *dst, const void *src, size_t bytes, int thr
   if (!lock.owns_lock()) return 1;             // (another context of the process is uploading: the rings are taken)
   Engine &E = g_engine[c->device];
   const size_t piece = bytes >= kBigBytes ? kPieceBig : kPieceSmall;
-  int rc = ensure_lanes(c, E, threads, piece);
-  if (rc) return rc;
+  if (ensure_lanes(E, threads, piece)) return 1;
   // behind whatever the context's stream still does with the destination (an array recycled from a dropped slice: free_slice has made the
   // stream wait for the passes that read it)
   // (nothing to be ordered behind when that stream is idle -- the tracker's push after a collected step --: 35 us)
